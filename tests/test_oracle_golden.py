@@ -1,0 +1,108 @@
+"""Pin the oracle (oracle/sasrec_oracle.py) against golden vectors produced by RUNNING the reference
+(tools/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sasrec_oracle as O
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    params = {k[len("param."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}
+    batch = {k[len("batch."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("batch.")}
+    return g, params, batch
+
+
+def meta(g):
+    return int(g["meta.head_num"]), int(g["meta.layer_num"]), float(g["meta.layer_norm_eps"])
+
+
+@pytest.mark.parametrize("name", ["sasrec_d64", "sasrec_d128"])
+def test_forward_activations_and_loss(golden_dir, name):
+    g, p, b = load(golden_dir, name)
+    H, nl, eps = meta(g)
+    q, acts = O.sasrec_encode(p, b["in_item_id"], b["seqlen"], H, nl, eps, "origin", return_all=True)
+    # bit-exact embedding stage (pure gather + one IEEE add)
+    assert np.array_equal(acts["x0"].numpy(), g["act.x0"])
+    # the reference's per-layer outputs are only meaningful on rows < seqlen (pad rows are garbage but finite)
+    L = b["in_item_id"].shape[1]
+    valid = (torch.arange(L).view(1, L) < b["seqlen"].view(-1, 1)).numpy()
+    for i in range(nl):
+        np.testing.assert_allclose(acts[f"layer{i}"].numpy()[valid], g[f"act.layer{i}"][valid], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(q.numpy(), g["out.query"], rtol=2e-5, atol=2e-6)
+    loss, pos, ng = O.score_bce(q, p["item_embedding.weight"], b["item_id"], b["neg_item"], True)
+    tv = (b["item_id"] != 0).numpy()           # fixture holds basemodel.py:206 before the -inf fill of :208
+    np.testing.assert_allclose(pos.numpy()[tv], g["out.pos_score"][tv], rtol=2e-5, atol=2e-6)
+    assert np.isneginf(pos.numpy()[~tv]).all()
+    np.testing.assert_allclose(ng.numpy(), g["out.neg_score"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(float(loss), float(g["out.loss"]), rtol=1e-6)
+    loss_nr, _, _ = O.score_bce(q, p["item_embedding.weight"], b["item_id"], b["neg_item"], False)
+    np.testing.assert_allclose(loss_nr.numpy(), g["out.loss_noreduce"], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["sasrec_d64", "sasrec_d128"])
+def test_gradients(golden_dir, name):
+    g, p, b = load(golden_dir, name)
+    H, nl, eps = meta(g)
+    loss, q, grads = O.grads_of(p, b, H, nl, eps)
+    for k, gv in grads.items():
+        ref = g["grad." + k]
+        scale = max(1e-8, float(np.abs(ref).max()))
+        err = float(np.abs(gv.numpy() - ref).max()) / scale
+        assert err < 2e-4, (k, err)
+
+
+@pytest.mark.parametrize("name", ["sasrec_d64", "sasrec_d128"])
+def test_adam_two_steps(golden_dir, name):
+    g, p, b = load(golden_dir, name)
+    H, nl, eps = meta(g)
+    params = {k: v.clone() for k, v in p.items() if k != "query_encoder.item_encoder.weight"}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(x) for k, x in params.items()}
+    for t, tag in ((1, "adam1."), (2, "adam2.")):
+        full = dict(params)
+        _, _, grads = O.grads_of(full, b, H, nl, eps)
+        params = O.adam_step(params, grads, m, v, t, lr=float(g["meta.lr"]), wd=float(g["meta.weight_decay"]))
+        for k in params:
+            # Adam's first steps are ~lr*g/(|g|+eps): elements with |g| ~ eps=1e-8 are ill-conditioned
+            # (fp32 rounding noise in g moves them by a visible fraction of lr) -> strict check only
+            # where the reference gradient is well away from eps, loose bound elsewhere.
+            well = np.abs(g["grad." + k]) > 1e-5
+            np.testing.assert_allclose(params[k].numpy()[well], g[tag + k][well], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(params[k].numpy(), g[tag + k], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["sasrec_d64", "sasrec_d128"])
+def test_eval_topk_and_metrics(golden_dir, name):
+    g, p, _ = load(golden_dir, name)
+    H, nl, eps = meta(g)
+    idx = torch.from_numpy(g["eval.in_item_id"])
+    sl = torch.from_numpy(g["eval.seqlen"])
+    q = O.sasrec_encode(p, idx, sl, H, nl, eps, "last")
+    np.testing.assert_allclose(q.numpy(), g["eval.query_last"], rtol=5e-5, atol=5e-6)
+    hist = torch.from_numpy(g["eval.user_hist"])
+    k = g["eval.topk_items"].shape[1]
+    score, items = O.full_score_topk(q, p["item_embedding.weight"], hist, k)
+    np.testing.assert_allclose(score.numpy(), g["eval.topk_score"], rtol=5e-5, atol=5e-6)
+    assert (items.numpy() == g["eval.topk_items"]).mean() > 0.99     # ties/near-ties may swap
+    hit = torch.from_numpy(g["eval.item_id"]).view(-1, 1) == torch.from_numpy(g["eval.topk_items"])
+    for kk in (20, 10):
+        np.testing.assert_allclose(O.ndcg_at(hit, kk).numpy(), g[f"eval.ndcg@{kk}"], rtol=1e-6)
+        np.testing.assert_allclose(O.recall_at(hit, kk).numpy(), g[f"eval.recall@{kk}"], rtol=1e-6)
+
+
+def test_neg_sampler_contract(golden_dir):
+    z = np.load(os.path.join(golden_dir, "neg_sampler_stats.npz"))
+    assert tuple(z["shape2d"]) == (4000, 50, 1) and tuple(z["shape1d"]) == (9, 1)
+    assert z["counts"][0] == 0                      # PAD never sampled (basemodel.py:55)
+    neg = O.neg_sample_reference_like(4000, 50, 37, torch.Generator().manual_seed(3))
+    cnt = torch.bincount(neg.flatten(), minlength=37).numpy()
+    assert cnt[0] == 0 and neg.shape == (4000, 50, 1) and neg.dtype == torch.int64
+    exp = 4000 * 50 / 36
+    for c in (cnt[1:], z["counts"][1:]):            # both uniform on 1..N-1 (chi-square, 35 dof)
+        chi2 = float(((c - exp) ** 2 / exp).sum())
+        assert chi2 < 80, chi2

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING the reference (USTC-StarTeam/DR4SR).
+
+This script only works in the build container where /root/reference exists.  It
+imports the reference unmodified (with no-op stubs for the three absent third
+party modules wandb / faiss / torchmetrics), builds a tiny synthetic dataset in
+the reference's on-disk row format, runs fixed batches through the reference's
+own `training_step` / `backward` / `optimizer.step` / `topk`, and dumps inputs and
+outputs as small .npz fixtures under tests/golden/.
+
+Only DATA is committed (tests/golden/*.npz); no reference source travels.
+
+Reference entry points exercised (file:line under /root/reference):
+  utils/utils.py:90-109    load_config            (3-way YAML merge)
+  utils/utils.py:38-55     prepare_datasets / prepare_model
+  model/basemodel.py:44-48 _init_model            (normal_initialization, Adam, BCE)
+  model/basemodel.py:204   training_step          (encoder fwd + tied scorer + BCE)
+  model/basemodel.py:354   topk                   (full-item scorer + history mask + top-k)
+  model/sasrec.py:39-75    SASRecQueryEncoder.forward
+  model/loss_func.py:9-38  BinaryCrossEntropyLoss.forward
+
+Usage:  python tools/make_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+L = 50
+
+
+# --------------------------------------------------------------------------- stubs
+def _install_stubs():
+    class _Ctx:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    wandb = types.ModuleType("wandb")
+    wandb.init = lambda *a, **k: _Ctx()
+    wandb.log = lambda *a, **k: None
+    wandb.finish = lambda *a, **k: None
+    wandb.sweep = lambda *a, **k: None
+    wandb.agent = lambda *a, **k: None
+    wandb.Image = lambda *a, **k: None
+    wandb.config = {}
+    sys.modules["wandb"] = wandb
+
+    faiss = types.ModuleType("faiss")
+    faiss.Kmeans = type("Kmeans", (), {})
+    sys.modules["faiss"] = faiss
+
+    tm = types.ModuleType("torchmetrics")
+    tmf = types.ModuleType("torchmetrics.functional")
+    for n in ("recall", "precision", "f1_score", "auroc", "accuracy",
+              "mean_squared_error", "mean_absolute_error"):
+        setattr(tmf, n, lambda *a, **k: None)
+    tm.functional = tmf
+    sys.modules["torchmetrics"] = tm
+    sys.modules["torchmetrics.functional"] = tmf
+
+
+# --------------------------------------------------------------------------- data
+def _pad(seq, n=L):
+    return list(seq) + [0] * (n - len(seq))
+
+
+def build_dataset(root, n_items, seqlens, rng, dataset="amazon-toys", domain="toy"):
+    """Write inter.csv/train_ori.pth/val.pth/test.pth in the reference row format.
+
+    Row format (dataset/preprocess_amazon.ipynb cell 20; data/dataset.py:79-91):
+      train: [user_id, hist[50], target[50], seqlen, label[50], domain_id[50]]
+      val/test: [user_id, hist[50], target, seqlen, 1, domain_id[50], hist]
+    """
+    import torch
+    d = os.path.join(root, "dataset", dataset, domain)
+    os.makedirs(d, exist_ok=True)
+    train, val, test = [], [], []
+    for u, sl in enumerate(seqlens, start=1):
+        full = rng.integers(1, n_items, size=sl + 3).tolist()      # sl inputs + 1 shift + val + test
+        hist = full[:sl]
+        tgt = full[1:sl + 1]
+        train.append([u, _pad(hist), _pad(tgt), sl, [1] * sl + [0] * (L - sl), [0] * L])
+        vh = full[:sl + 1][-L:]
+        val.append([u, _pad(vh), full[sl + 1], len(vh), 1, [0] * L, _pad(vh)])
+        th = full[:sl + 2][-L:]
+        test.append([u, _pad(th), full[sl + 2], len(th), 1, [0] * L, _pad(th)])
+    torch.save(train, os.path.join(d, "train_ori.pth"))
+    torch.save(val, os.path.join(d, "val.pth"))
+    torch.save(test, os.path.join(d, "test.pth"))
+    # inter.csv must cover every user and every item id 1..n_items-1 (data/dataset.py:56-65)
+    with open(os.path.join(d, "inter.csv"), "w") as f:
+        f.write("user_id,item_id,rating,timestamp,domain\n")
+        nu = len(seqlens)
+        for i in range(1, n_items):
+            f.write(f"{(i - 1) % nu + 1},{i},1.0,{i},0\n")
+        for u in range(1, nu + 1):
+            f.write(f"{u},{(u % (n_items - 1)) + 1},1.0,{u},0\n")
+    return train, val, test
+
+
+# --------------------------------------------------------------------------- runner
+def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overrides=None):
+    import torch
+    rng = np.random.default_rng(seed)
+    work = tempfile.mkdtemp(prefix="dr4sr_golden_")
+    cwd = os.getcwd()
+    try:
+        os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
+        build_dataset(work, n_items, seqlens, rng)
+        os.chdir(work)
+        from utils import load_config, setup_environment, prepare_datasets, prepare_model
+        config = load_config({"model": model_name, "dataset": "amazon-toys"})
+        config["train"]["device"] = "cpu"
+        config["data"]["train_file"] = "_ori"
+        config["model"]["dropout_rate"] = 0.0
+        config["model"]["embed_dim"] = embed_dim
+        for sec, kv in (overrides or {}).items():
+            config[sec].update(kv)
+        setup_environment(config["train"])
+        torch.manual_seed(seed)
+        ds = prepare_datasets(config)
+        model = prepare_model(config, ds)
+        model._init_model(ds[0])
+        # The reference zero-inits biases; perturb every parameter slightly so that
+        # bias / LayerNorm-affine paths are actually pinned by the fixture.
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if "item_embedding" in n or "item_encoder" in n:
+                    continue
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        out = {}
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for k, v in sd0.items():
+            out["param." + k] = v.numpy()
+
+        # ---- training batch = all rows, in dataset order (no shuffle) ----------------
+        loader = ds[0].get_loader(batch_size=len(seqlens), shuffle=False)
+        batch = next(iter(loader))
+        model.train()
+        torch.manual_seed(seed + 2)
+        batch["neg_item"] = model._neg_sampling(batch)
+        for k, v in batch.items():
+            out["batch." + k] = v.numpy()
+
+        cap = {}
+        enc = model.query_encoder
+        hooks = []
+        if model_name == "SASRec":
+            hooks.append(enc.transformer_layer.register_forward_pre_hook(
+                lambda m, a, kw: cap.__setitem__("x0", kw["src"].detach().clone()), with_kwargs=True))
+            for i, lyr in enumerate(enc.transformer_layer.layers):
+                hooks.append(lyr.register_forward_hook(
+                    lambda m, a, o, i=i: cap.__setitem__(f"layer{i}", o.detach().clone())))
+
+        model.optimizer.zero_grad()
+        loss, query = model.training_step(batch, reduce=True, return_query=True)
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        for k, v in cap.items():
+            out["act." + k] = v.numpy()
+        out["out.query"] = query.detach().numpy()
+        out["out.loss"] = loss.detach().numpy()
+        seen = set()
+        for n, p in model.named_parameters():      # named_parameters de-duplicates the tied table
+            out["grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            seen.add(n)
+        with torch.no_grad():
+            loss_nr = model.training_step(batch, reduce=False)
+        out["out.loss_noreduce"] = loss_nr.detach().numpy()
+
+        # scores, restated from the two lines at basemodel.py:206-207 on the reference's query
+        with torch.no_grad():
+            W = model.item_embedding.weight
+            out["out.pos_score"] = (query * W[batch["item_id"]]).sum(-1).numpy()
+            out["out.neg_score"] = (query.unsqueeze(-2) * W[batch["neg_item"]]).sum(-1).numpy()
+
+        # ---- one optimizer step --------------------------------------------------------
+        model.optimizer.step()
+        for n, p in model.named_parameters():
+            out["adam1." + n] = p.detach().numpy().copy()
+        # second step on the same batch (pins the moment/bias-correction recursion)
+        if model_name == "SASRec":
+            model.optimizer.zero_grad()
+            loss2 = model.training_step(batch)
+            loss2.backward()
+            model.optimizer.step()
+            out["out.loss_step2"] = loss2.detach().numpy()
+            for n, p in model.named_parameters():
+                out["adam2." + n] = p.detach().numpy().copy()
+
+        # ---- eval: full-item scorer + top-k on the validation rows, with the INITIAL weights
+        model.load_state_dict(sd0)
+        model.eval()
+        ds[1].set_eval_domain("toy")
+        model.set_eval_domain("toy")
+        vb = next(iter(ds[1].get_loader(batch_size=len(seqlens))))
+        with torch.no_grad():
+            k = 20
+            score, items = model.topk(vb, k, vb["user_hist"])
+            q_last = model.forward(vb)
+        for kk, v in vb.items():
+            out["eval." + kk] = v.numpy()
+        out["eval.topk_score"] = score.numpy()
+        out["eval.topk_items"] = items.numpy()
+        out["eval.query_last"] = q_last.numpy()
+        import evaluation
+        label = vb["item_id"].view(-1, 1) == items
+        out["eval.ndcg@20"] = evaluation.ndcg(label, vb["label"].view(-1, 1), 20, mean=False).numpy()
+        out["eval.recall@20"] = evaluation.recall(label, vb["label"].view(-1, 1), 20, mean=False).numpy()
+        out["eval.ndcg@10"] = evaluation.ndcg(label, vb["label"].view(-1, 1), 10, mean=False).numpy()
+        out["eval.recall@10"] = evaluation.recall(label, vb["label"].view(-1, 1), 10, mean=False).numpy()
+
+        out["meta.num_items"] = np.int64(model.num_items)
+        out["meta.embed_dim"] = np.int64(embed_dim)
+        mc = config["model"]
+        out["meta.head_num"] = np.int64(mc.get("head_num", 0))
+        out["meta.hidden_size"] = np.int64(mc.get("hidden_size", 0))
+        out["meta.layer_num"] = np.int64(mc.get("layer_num", 0))
+        out["meta.layer_norm_eps"] = np.float64(mc.get("layer_norm_eps", 1e-12))
+        out["meta.lr"] = np.float64(config["train"]["learning_rate"])
+        out["meta.weight_decay"] = np.float64(config["train"]["weight_decay"])
+        out["meta.torch_version"] = np.array(torch.__version__)
+        os.chdir(cwd)
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), loss={float(loss.detach()):.6f}")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def neg_sampler_stats(out_dir):
+    """Pin the *distribution* of basemodel.py:50-61 (uniform on 1..N-1, never PAD)."""
+    import torch
+    from model.basemodel import BaseModel
+
+    class _M:                       # minimal duck for the unbound method
+        fiid = "item_id"
+        device = "cpu"
+        num_items = 37
+        max_seq_len = L
+    torch.manual_seed(7)
+    b = {"in_item_id": torch.zeros(4000, L, dtype=torch.long), "item_id": torch.zeros(4000, L, dtype=torch.long)}
+    neg = BaseModel._neg_sampling(_M, b)
+    cnt = torch.bincount(neg.flatten(), minlength=37).numpy()
+    b1 = {"in_item_id": torch.zeros(9, L, dtype=torch.long), "item_id": torch.zeros(9, dtype=torch.long)}
+    neg1 = BaseModel._neg_sampling(_M, b1)
+    np.savez_compressed(os.path.join(out_dir, "neg_sampler_stats.npz"),
+                        counts=cnt, shape2d=np.array(neg.shape), shape1d=np.array(neg1.shape),
+                        dtype=np.array(str(neg.dtype)))
+    print("neg sampler: shape", tuple(neg.shape), tuple(neg1.shape), "count[0] =", cnt[0],
+          "min/max over 1..N-1:", cnt[1:].min(), cnt[1:].max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    if not os.path.isdir(REF):
+        sys.exit("reference not present; golden vectors can only be regenerated in the build container")
+    _install_stubs()
+    sys.path.insert(0, REF)
+    seqlens = [1, 2, 3, 5, 8, 13, 21, 34, 47, 49, 50, 4, 2, 50]
+    run_case(out_dir, "sasrec_d64", "SASRec", n_items=211, seqlens=seqlens, embed_dim=64, seed=11)
+    run_case(out_dir, "sasrec_d128", "SASRec", n_items=97, seqlens=seqlens[:9], embed_dim=128, seed=12)
+    # GRU4Rec: hidden 128 instead of configs/gru4rec.yaml's 256 only to keep the fixture small
+    run_case(out_dir, "gru4rec_d64", "GRU4Rec", n_items=131, seqlens=seqlens[:10], embed_dim=64, seed=13,
+             overrides={"model": {"hidden_size": 128}})
+    neg_sampler_stats(out_dir)
+
+
+if __name__ == "__main__":
+    main()
