@@ -1,0 +1,112 @@
+"""ctypes binding of libdr4sr_hip.so (the C ABI declared in include/dr4sr_hip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing any compute path
+of dr4sr_amd raises.  PyTorch is only used for device memory and streams (tensor.data_ptr(),
+torch.cuda.current_stream().cuda_stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdr4sr_hip.so")
+
+ABI_VERSION = 1
+GRAD_TAIL = 4
+STATE_WORDS = 16
+STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
+POOL_NONE, POOL_ORIGIN, POOL_LAST = 0, 1, 2
+SITE_EMB, SITE_ATTN, SITE_PROJ, SITE_ACT, SITE_FFN = 0, 1, 2, 3, 4
+
+_f32p = C.c_void_p
+_i64p = C.c_void_p
+
+
+class SasrecPlan(C.Structure):
+    """mirror of `dr4sr_sasrec_plan` (include/dr4sr_hip.h)"""
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("B", C.c_int32), ("L", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("F", C.c_int32),
+        ("n_layer", C.c_int32), ("n_items", C.c_int32),
+        ("ln_eps", C.c_float), ("p_drop", C.c_float),
+        ("seed", C.c_uint64),
+        ("params", _f32p), ("grads", _f32p), ("adam_m", _f32p), ("adam_v", _f32p),
+        ("n_params", C.c_int64),
+        ("in_item_id", _i64p), ("item_id", _i64p), ("seqlen", _i64p), ("rows", _i64p), ("neg_item", _i64p),
+        ("sample_neg", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("state", C.c_void_p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("weight_decay", C.c_float),
+    ]
+
+
+_PLANP = C.POINTER(SasrecPlan)
+
+# name -> (restype, argtypes); every symbol include/dr4sr_hip.h declares
+SYMBOLS = {
+    "dr4sr_abi_version": (C.c_int, []),
+    "dr4sr_sasrec_param_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_sasrec_workspace_bytes": (C.c_int64, [_PLANP]),
+    "dr4sr_sasrec_fwd_bwd": (C.c_int, [_PLANP, C.c_void_p]),
+    "dr4sr_adam_step": (C.c_int, [_PLANP, C.c_void_p]),
+    "dr4sr_sasrec_train_step": (C.c_int, [_PLANP, C.c_void_p]),
+    "dr4sr_sasrec_encode": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
+    "dr4sr_sasrec_encode_bwd": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
+    "dr4sr_embed_gather_posadd": (C.c_int, [_f32p, _f32p, _i64p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_score_bce_fwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_score_bce_bwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_neg_sample": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "dr4sr_dropout_mask": (C.c_int, [_f32p, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+_lib = None
+
+
+class Dr4srError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library once and type every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Dr4srError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C dr4sr_amd/csrc`).  dr4sr_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.dr4sr_abi_version()
+    if v != ABI_VERSION:
+        raise Dr4srError(f"libdr4sr_hip.so ABI {v} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "DR4SR_E_ARG (null pointer / bad size)", -2: "DR4SR_E_SHAPE (unsupported D/H/F/L)",
+        -3: "DR4SR_E_WS (workspace too small)"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise Dr4srError(f"{what} failed: {_ERR.get(rc, 'hipError_t ' + str(rc))}")
+
+
+def ptr(t):
+    """device pointer of a contiguous torch tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "dr4sr_amd kernels need contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,187 @@
+// common.h — device helpers shared by the gfx950 kernels (wave64, MFMA f32 32x32x2, Philox).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dr4sr_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DR4SR_WAVE 64
+
+// ---------------------------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG: the mask of element e at (seed, step, site) is a pure function, so backward
+// kernels regenerate forward masks instead of storing them.  4 consecutive elements share one call.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+struct RngKey {
+    uint32_t seed_lo, seed_hi, step;
+    float p;           // drop probability
+    float scale;       // 1/(1-p)
+    uint32_t thresh;   // keep iff r >= thresh
+};
+
+__device__ __forceinline__ RngKey make_rng(uint64_t seed, uint32_t step, float p) {
+    RngKey k;
+    k.seed_lo = (uint32_t)seed;
+    k.seed_hi = (uint32_t)(seed >> 32);
+    k.step = step;
+    k.p = p;
+    k.scale = 1.0f / (1.0f - p);
+    double t = (double)p * 4294967296.0;
+    k.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    return k;
+}
+
+// random words for elements [4*call, 4*call+3] of stream (site)
+__device__ __forceinline__ uint4 rng_call(const RngKey& k, uint32_t site, uint64_t call) {
+    return philox4x32_10(make_uint4((uint32_t)call, (uint32_t)(call >> 32), site, k.step),
+                         make_uint2(k.seed_lo, k.seed_hi));
+}
+
+// multiplicative keep factors (0 or 1/(1-p)) for 4 consecutive elements starting at e (e % 4 == 0)
+__device__ __forceinline__ float4 drop4(const RngKey& k, uint32_t site, uint64_t e) {
+    const uint4 r = rng_call(k, site, e >> 2);
+    return make_float4(r.x >= k.thresh ? k.scale : 0.f, r.y >= k.thresh ? k.scale : 0.f,
+                       r.z >= k.thresh ? k.scale : 0.f, r.w >= k.thresh ? k.scale : 0.f);
+}
+
+// keep factor of a single element (recomputes the shared call; use only off the hot path)
+__device__ __forceinline__ float drop1(const RngKey& k, uint32_t site, uint64_t e) {
+    const uint4 r = rng_call(k, site, e >> 2);
+    const uint32_t c = (uint32_t)(e & 3);
+    const uint32_t w = c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w;
+    return w >= k.thresh ? k.scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+// softplus(x) = log(1 + e^x), stable
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------- MFMA tile GEMM
+// C[64 x N] = A[64 x K] * W^T, A in LDS (row stride lda floats, 16-B aligned rows), W global [N][K].
+// 256 threads = 4 waves; wave w owns row-half rh = w&1 and column tiles ct = (w>>1) + 2*i, i<NTW,
+// N = 64*NTW.  v_mfma_f32_32x32x2_f32: lane (r = l&31, g = l>>5) feeds A[r][k], B[k][r] for one k
+// per instruction; the k ORDER is permuted (g takes k in [g*K/2, (g+1)*K/2)) so every lane streams
+// contiguous floats (ds_read_b128 / global_load_dwordx4) — the sum over k is order-free.
+template <int K, int NTW>
+__device__ __forceinline__ void mma_64xN(const float* __restrict__ As, int lda,
+                                         const float* __restrict__ W, f32x16 (&acc)[NTW]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, g = lane >> 5, rh = w & 1, cg = w >> 1;
+    const float* arow = As + (rh * 32 + r) * lda + g * (K / 2);
+    const float* wrow[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) wrow[i] = W + (size_t)((cg + 2 * i) * 32 + r) * K + g * (K / 2);
+#pragma unroll
+    for (int c = 0; c < K / 2; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + c);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(wrow[i] + c);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[i], 0, 0, 0);
+        }
+    }
+}
+
+// accumulators (+ bias[n]) -> LDS C tile [64][ldc].  C/D map of 32x32: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int NTW>
+__device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NTW], float* __restrict__ Cs, int ldc,
+                                           const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, g = lane >> 5, rh = w & 1, cg = w >> 1;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int col = (cg + 2 * i) * 32 + r;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = rh * 32 + (q & 3) + 8 * (q >> 2) + 4 * g;
+            Cs[row * ldc + col] = acc[i][q] + bv;
+        }
+    }
+}
+
+template <int NTW>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NTW]) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+}
+
+// cooperative load of a [64 x K] tile (rows t0..t0+63 of a [T x ldg] global matrix, zero beyond T)
+// into LDS with row stride lda.  256 threads, float4 per thread per pass.
+template <int K>
+__device__ __forceinline__ void load_tile(float* __restrict__ As, int lda, const float* __restrict__ G,
+                                          int ldg, int t0, int T) {
+    constexpr int C4 = K / 4;                 // float4 per row
+    for (int i = threadIdx.x; i < 64 * C4; i += 256) {
+        const int row = i / C4, c = (i % C4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 + row < T) v = ld4(G + (size_t)(t0 + row) * ldg + c);
+        st4(As + row * lda + c, v);
+    }
+}
+
+// LayerNorm statistics of one row held as NV float4 per lane across a 16-lane group (D = 64*NV)
+template <int NV>
+__device__ __forceinline__ void ln_stats16(const float4 (&v)[NV], float& mean, float& rstd, float eps) {
+    constexpr float invD = 1.0f / (64 * NV);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    mean = group16_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    rstd = 1.0f / sqrtf(group16_sum(q) * invD + eps);
+}
+
+// dynamic LDS above 64 KiB has to be opted into per kernel (gfx950 has 160 KiB per CU)
+template <typename K>
+static inline void big_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+static inline int hip_ret(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+#define DR4SR_LAUNCH_CHECK() hip_ret(hipGetLastError())

@@ -1,0 +1,265 @@
+// embed.hip — K1 item-embedding gather + position add (dense, bit-exact) and its packed/ragged
+// training variants (forward with dropout, backward scatter-add), plus the prefix-scan "prep" kernel.
+//
+// Reference: model/sasrec.py:43-46,:62-66 (item_encoder(idx) + position_emb(arange(L)), dropout);
+// autograd of nn.Embedding(padding_idx=0) (model/basemodel.py:42) for the backward.
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// K1 dense: out[b,l,:] = E[idx[b,l],:] + P[l,:] for ALL B*L positions (pads included: E[0] + P[l]).
+// HBM-bound stream: 8 B idx read + 4D B row read (L2/MALL resident table) + 4D B write per token.
+// One 16-lane group per token and float4 per lane (D=64) => each wave instruction reads/writes
+// 4 x 256 B contiguous segments; grid-stride over tokens.
+template <int D>
+__global__ __launch_bounds__(256) void k_embed_dense(const float* __restrict__ E, const float* __restrict__ P,
+                                                         const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                         int64_t ntok, int L, int n_items) {
+    constexpr int LPT = D / 4;
+    constexpr int TPB = 256 / LPT;
+    const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
+    for (int64_t t = (int64_t)blockIdx.x * TPB + sub; t < ntok; t += (int64_t)gridDim.x * TPB) {
+        int64_t id = idx[t];
+        id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+        const int l = (int)(t % L);
+        const float4 e = ld4(E + id * D + c);
+        const float4 p = ld4(P + (size_t)l * D + c);
+        st4(out + t * D + c, make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w));
+    }
+}
+
+extern "C" int dr4sr_embed_gather_posadd(const float* E, const float* P, const int64_t* idx, float* out,
+                                         int64_t B, int32_t L, int32_t D, int32_t n_items, void* stream) {
+    if (!E || !P || !idx || !out || B < 0 || L <= 0 || n_items <= 0) return DR4SR_E_ARG;
+    if (D != 64 && D != 128) return DR4SR_E_SHAPE;
+    const int64_t ntok = B * L;
+    if (ntok == 0) return 0;
+    const int tpb = 256 / (D / 4);
+    int64_t blocks = (ntok + tpb - 1) / tpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 64) hipLaunchKernelGGL(k_embed_dense<64>, dim3((unsigned)blocks), dim3(256), 0, s, E, P, idx, out, ntok, L, n_items);
+    else hipLaunchKernelGGL(k_embed_dense<128>, dim3((unsigned)blocks), dim3(256), 0, s, E, P, idx, out, ntok, L, n_items);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: cu[b] = exclusive prefix sum of clamp(seqlen[row(b)], 0, L); state[T] = total.  One block.
+// Also bumps the RNG step so that every fwd_bwd draws fresh dropout masks / negatives.
+__global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqlen, const int64_t* __restrict__ rows,
+                                               int* __restrict__ cu, int* __restrict__ state, int B, int L,
+                                               int bump_rng) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int b0 = tid * per, b1 = min(B, b0 + per);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) {
+        int64_t n = seqlen[rows ? rows[b] : b];
+        s += (int)(n < 0 ? 0 : (n > L ? L : n));
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {               // Hillis-Steele inclusive scan
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;                            // exclusive prefix of this thread's chunk
+    for (int b = b0; b < b1; ++b) {
+        cu[b] = run;
+        int64_t n = seqlen[rows ? rows[b] : b];
+        run += (int)(n < 0 ? 0 : (n > L ? L : n));
+    }
+    if (tid == 1023) {
+        cu[B] = part[1023];
+        state[DR4SR_STATE_T] = part[1023];
+        if (bump_rng) state[DR4SR_STATE_RNGSTEP] += 1;
+    }
+}
+
+int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, hipStream_t s) {
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, s, p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed forward: for sequence slot b and pos < n_b:  x[cu[b]+pos,:] = drop(E[idx,:] + P[pos,:]).
+// One wave per sequence (toys-shaped batches average 5.5 valid positions), LPT lanes per row.
+template <int D>
+__global__ __launch_bounds__(256) void k_embed_fwd(const float* __restrict__ E, const float* __restrict__ P,
+                                                   const int64_t* __restrict__ idx, const int64_t* __restrict__ rows,
+                                                   const int* __restrict__ cu, float* __restrict__ X, int B, int L,
+                                                   int n_items, const int* __restrict__ state, uint64_t seed, float p,
+                                                   int training) {
+    constexpr int LPT = D / 4, RPW = 64 / LPT;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63, sub = lane / LPT, c = (lane % LPT) * 4;
+    const int t0 = cu[b], n = cu[b + 1] - t0;
+    const int64_t row = rows ? rows[b] : b;
+    const bool dodrop = training && p > 0.f;
+    RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], p);
+    for (int pos = sub; pos < n; pos += RPW) {
+        int64_t id = idx[row * L + pos];
+        id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+        const float4 e = ld4(E + id * D + c);
+        const float4 pe = ld4(P + (size_t)pos * D + c);
+        float4 o = make_float4(e.x + pe.x, e.y + pe.y, e.z + pe.z, e.w + pe.w);
+        if (dodrop) {
+            const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
+            o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+        }
+        st4(X + (size_t)(t0 + pos) * D + c, o);
+    }
+}
+
+int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    const float* E = p->params + ws.off[0];
+    const float* P = p->params + ws.off[1];
+    dim3 grid((p->B + 3) / 4), blk(256);
+    if (p->D == 64)
+        hipLaunchKernelGGL(k_embed_fwd<64>, grid, blk, 0, s, E, P, p->in_item_id, p->rows, ws.cu, ws.X[0], p->B, p->L,
+                           p->n_items, p->state, p->seed, p->p_drop, training);
+    else
+        hipLaunchKernelGGL(k_embed_fwd<128>, grid, blk, 0, s, E, P, p->in_item_id, p->rows, ws.cu, ws.X[0], p->B, p->L,
+                           p->n_items, p->state, p->seed, p->p_drop, training);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed backward: g = dX[t,:] * mask;  dE[idx,:] += g (skipped for idx == 0: padding_idx),
+// dP[pos,:] += g.  Each block walks sequences b = blockIdx.x, +gridDim.x, ... and keeps its share of
+// dP in registers (thread = (pos mod PG, 4 dims)), so dP costs gridDim.x*L*D atomics, not T*D.
+template <int D>
+__global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dX, const int64_t* __restrict__ idx,
+                                                   const int64_t* __restrict__ rows, const int* __restrict__ cu,
+                                                   float* __restrict__ dE, float* __restrict__ dP, int B, int L,
+                                                   int n_items, const int* __restrict__ state, uint64_t seed, float p,
+                                                   int training) {
+    constexpr int LPT = D / 4, PG = 256 / LPT;          // PG position groups (16 for D=64, 8 for D=128)
+    constexpr int MAXP = (64 + PG - 1) / PG;            // L <= 64
+    const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
+    float4 accP[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) accP[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool dodrop = training && p > 0.f;
+    RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], p);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int t0 = cu[b], n = cu[b + 1] - t0;
+        const int64_t row = rows ? rows[b] : b;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int pos = sub + i * PG;
+            if (pos < n) {
+                float4 g = ld4(dX + (size_t)(t0 + pos) * D + c);
+                if (dodrop) {
+                    const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
+                    g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+                }
+                accP[i].x += g.x; accP[i].y += g.y; accP[i].z += g.z; accP[i].w += g.w;
+                const int64_t id = idx[row * L + pos];
+                if (id > 0 && id < n_items) {
+                    float* d = dE + id * D + c;
+                    unsafeAtomicAdd(d, g.x); unsafeAtomicAdd(d + 1, g.y);
+                    unsafeAtomicAdd(d + 2, g.z); unsafeAtomicAdd(d + 3, g.w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int pos = sub + i * PG;
+        if (pos < L) {
+            float* d = dP + (size_t)pos * D + c;
+            unsafeAtomicAdd(d, accP[i].x); unsafeAtomicAdd(d + 1, accP[i].y);
+            unsafeAtomicAdd(d + 2, accP[i].z); unsafeAtomicAdd(d + 3, accP[i].w);
+        }
+    }
+}
+
+int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    float* dE = p->grads + ws.off[0];
+    float* dP = p->grads + ws.off[1];
+    int g = p->B < 64 ? p->B : 64;
+    dim3 grid(g), blk(256);
+    if (p->D == 64)
+        hipLaunchKernelGGL(k_embed_bwd<64>, grid, blk, 0, s, ws.dX[0], p->in_item_id, p->rows, ws.cu, dE, dP, p->B, p->L,
+                           p->n_items, p->state, p->seed, p->p_drop, training);
+    else
+        hipLaunchKernelGGL(k_embed_bwd<128>, grid, blk, 0, s, ws.dX[0], p->in_item_id, p->rows, ws.cu, dE, dP, p->B, p->L,
+                           p->n_items, p->state, p->seed, p->p_drop, training);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack / unpack between the dense API layout and the packed workspace layout
+// unpack: out[b,l,:] = l < n_b ? X[cu[b]+l,:] : 0   (ORIGIN/NONE)   or  out[b,:] = X[cu[b]+n_b-1,:]  (LAST)
+template <int D>
+__global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ X, const int* __restrict__ cu,
+                                                float* __restrict__ out, int B, int L, int last) {
+    constexpr int LPT = D / 4, RPB = 256 / LPT;
+    const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
+    const int b = blockIdx.x;
+    const int t0 = cu[b], n = cu[b + 1] - t0;
+    if (last) {
+        if (sub == 0) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n > 0) v = ld4(X + (size_t)(t0 + n - 1) * D + c);
+            st4(out + (size_t)b * D + c, v);
+        }
+        return;
+    }
+    for (int l = sub; l < L; l += RPB) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < n) v = ld4(X + (size_t)(t0 + l) * D + c);
+        st4(out + ((size_t)b * L + l) * D + c, v);
+    }
+}
+// pack (backward of unpack): dX[cu[b]+l,:] = d_out[b,l,:]  /  LAST: only row n_b-1 gets d_out[b,:], others 0
+template <int D>
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ dout, const int* __restrict__ cu,
+                                              float* __restrict__ dX, int B, int L, int last) {
+    constexpr int LPT = D / 4, RPB = 256 / LPT;
+    const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
+    const int b = blockIdx.x;
+    const int t0 = cu[b], n = cu[b + 1] - t0;
+    for (int l = sub; l < n; l += RPB) {
+        float4 v;
+        if (last) v = (l == n - 1) ? ld4(dout + (size_t)b * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else v = ld4(dout + ((size_t)b * L + l) * D + c);
+        st4(dX + (size_t)(t0 + l) * D + c, v);
+    }
+}
+
+int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int last, hipStream_t s) {
+    dim3 grid(p->B), blk(256);
+    if (p->D == 64) hipLaunchKernelGGL(k_unpack<64>, grid, blk, 0, s, X, ws.cu, out, p->B, p->L, last);
+    else hipLaunchKernelGGL(k_unpack<128>, grid, blk, 0, s, X, ws.cu, out, p->B, p->L, last);
+    return DR4SR_LAUNCH_CHECK();
+}
+int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int last, hipStream_t s) {
+    dim3 grid(p->B), blk(256);
+    if (p->D == 64) hipLaunchKernelGGL(k_pack<64>, grid, blk, 0, s, dout, ws.cu, dX, p->B, p->L, last);
+    else hipLaunchKernelGGL(k_pack<128>, grid, blk, 0, s, dout, ws.cu, dX, p->B, p->L, last);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// test hook: keep-mask materialisation
+__global__ void k_dropout_mask(float* __restrict__ out, int64_t n4, float p, uint64_t seed, uint32_t step, uint32_t site) {
+    RngKey rk = make_rng(seed, step, p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 m = drop4(rk, site, (uint64_t)i * 4);
+        st4(out + i * 4, make_float4(m.x != 0.f, m.y != 0.f, m.z != 0.f, m.w != 0.f));
+    }
+}
+extern "C" int dr4sr_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint32_t step, uint32_t site, void* stream) {
+    if (!out || n < 0 || (n & 3) || p < 0.f || p >= 1.f) return DR4SR_E_ARG;
+    if (n == 0) return 0;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n / 4, p, seed, step, site);
+    return DR4SR_LAUNCH_CHECK();
+}

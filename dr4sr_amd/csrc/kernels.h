@@ -1,0 +1,63 @@
+// kernels.h — host-side workspace carve-up and launcher prototypes (internal to libdr4sr_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dr4sr_hip.h"
+
+#define DR4SR_MAX_LAYERS 8
+
+// per-layer saved activations / gradients, all packed [Tmax, *] fp32 (Tmax = B*L)
+struct LayerWs {
+    float* qkv;    // [T,3D]  in_proj output (q|k|v)
+    float* ctx;    // [T,D]   attention output (heads merged), before out_proj
+    float* u1;     // [T,D]   x + drop(out_proj(ctx))                     (LayerNorm1 input)
+    float* y;      // [T,D]   LayerNorm1 output
+    float* st1;    // [T,2]   (mean, rstd) of u1
+    float* a;      // [T,F]   linear1 pre-activation
+    float* u2;     // [T,D]   y + drop(linear2(drop(gelu(a))))            (LayerNorm2 input)
+    float* st2;    // [T,2]
+    // gradients kept for the weight-gradient pass
+    float* du2;    // [T,D]
+    float* da;     // [T,F]
+    float* du1;    // [T,D]
+    float* dqkv;   // [T,3D]
+};
+
+struct Workspace {
+    int64_t off[2 + 12 * DR4SR_MAX_LAYERS];   // flat parameter offsets (dr4sr_sasrec_param_layout)
+    int64_t n_params;
+    int Tmax;
+    int* cu;                                   // [B+1] packed row offset of each sequence slot
+    float* X[DR4SR_MAX_LAYERS + 1];            // X[0] = embedding stage output, X[i+1] = output of layer i
+    float* dX[DR4SR_MAX_LAYERS + 1];           // gradients w.r.t. X[i]
+    float* dctx;                               // [T,D] scratch
+    float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
+    int64_t wT_stride;                         // floats per layer in wT
+    LayerWs layer[DR4SR_MAX_LAYERS];
+    int64_t bytes;
+};
+
+// index of tensor j of layer i in Workspace::off
+enum { P_IN_W = 0, P_IN_B, P_OUT_W, P_OUT_B, P_W1, P_B1, P_W2, P_B2, P_LN1_W, P_LN1_B, P_LN2_W, P_LN2_B };
+static inline int64_t poff(const Workspace& ws, int layer, int j) { return ws.off[2 + 12 * layer + j]; }
+
+int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws);   // fills ws from p->workspace (or sizes only if NULL)
+
+int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, hipStream_t s);
+int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
+int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
+int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int last, hipStream_t s);
+int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int last, hipStream_t s);
+
+int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
+int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s);
+int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
+int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
+int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s);
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
+
+int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
+int launch_attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
+
+int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
+int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s);

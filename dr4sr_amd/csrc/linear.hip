@@ -1,0 +1,619 @@
+// linear.hip — token-tile (64 packed tokens per workgroup) fused GEMM kernels of the SASRec layer,
+// fp32 on v_mfma_f32_32x32x2_f32, activations staged through LDS:
+//   k_qkv_fwd   : qkv = x W_in^T + b_in
+//   k_post_fwd  : ctx -> out_proj -> dropout -> +x -> LayerNorm1 -> linear1 -> GELU -> dropout
+//                 -> linear2 -> dropout -> +y -> LayerNorm2            (one launch, y/h stay in LDS)
+//   k_post_bwd  : the exact reverse chain (LN2 bwd, linear2/GELU/linear1 data grads, LN1 bwd,
+//                 out_proj data grad), LayerNorm affine grads by atomics
+//   k_qkv_bwd   : dx = dqkv W_in + du1
+//   k_wgrad     : all weight/bias gradients of all layers, split over token tiles, atomics at the end
+//
+// Reference arithmetic: torch.nn.TransformerEncoderLayer as configured at model/sasrec.py:21-30
+// (post-norm, gelu(erf), batch_first), called at model/sasrec.py:65-68.
+#include "common.h"
+#include "kernels.h"
+
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+// ------------------------------------------------------------------------------------------------
+// transposed weight copies for the data-gradient GEMMs (dX = dY W  ==  dY (W^T)^T in "x W^T" form)
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ params, float* __restrict__ wT,
+                                                   int64_t o_in, int64_t o_out, int64_t o_w1, int64_t o_w2,
+                                                   int64_t layer_stride, int64_t wT_stride, int D, int F) {
+    const int m = blockIdx.y, layer = blockIdx.z;
+    const float* src;
+    float* dst = wT + layer * wT_stride;
+    int R, C;                                             // src is [R][C], dst is [C][R]
+    if (m == 0) { src = params + o_in + layer * layer_stride; R = 3 * D; C = D; }
+    else if (m == 1) { src = params + o_out + layer * layer_stride; R = D; C = D; dst += 3 * D * D; }
+    else if (m == 2) { src = params + o_w1 + layer * layer_stride; R = F; C = D; dst += 4 * D * D; }
+    else { src = params + o_w2 + layer * layer_stride; R = D; C = F; dst += 4 * D * D + D * F; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < R * C; i += gridDim.x * 256) {
+        const int r = i / C, c = i % C;
+        dst[c * R + r] = src[i];
+    }
+}
+
+int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
+    const int64_t layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
+    hipLaunchKernelGGL(k_transpose, dim3(16, 4, p->n_layer), dim3(256), 0, s, p->params, ws.wT, poff(ws, 0, P_IN_W),
+                       poff(ws, 0, P_OUT_W), poff(ws, 0, P_W1), poff(ws, 0, P_W2), layer_stride, ws.wT_stride, p->D, p->F);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                 const float* __restrict__ bias, float* __restrict__ QKV,
+                                                 const int* __restrict__ state) {
+    constexpr int N = 3 * D, LDA = D + 4, LDC = N + 4;
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    if (t0 >= T) return;
+    float* As = smem;
+    float* Cs = smem + 64 * LDA;
+    load_tile<D>(As, LDA, X, D, t0, T);
+    __syncthreads();
+    f32x16 acc[N / 64];
+    acc_zero(acc);
+    mma_64xN<D, N / 64>(As, LDA, W, acc);
+    acc_to_lds(acc, Cs, LDC, bias);
+    __syncthreads();
+    constexpr int C4 = N / 4;
+    for (int i = threadIdx.x; i < 64 * C4; i += 256) {
+        const int row = i / C4, c = (i % C4) * 4;
+        if (t0 + row < T) st4(QKV + (size_t)(t0 + row) * N + c, ld4(Cs + row * LDC + c));
+    }
+}
+
+int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s) {
+    const int D = p->D;
+    const size_t lds = sizeof(float) * 64 * ((D + 4) + (3 * D + 4));
+    dim3 grid((ws.Tmax + 63) / 64), blk(256);
+    const float* W = p->params + poff(ws, layer, P_IN_W);
+    const float* b = p->params + poff(ws, layer, P_IN_B);
+    if (D == 64) { big_lds(k_qkv_fwd<64>, lds); hipLaunchKernelGGL(k_qkv_fwd<64>, grid, blk, lds, s, ws.X[layer], W, b, ws.layer[layer].qkv, p->state); }
+    else { big_lds(k_qkv_fwd<128>, lds); hipLaunchKernelGGL(k_qkv_fwd<128>, grid, blk, lds, s, ws.X[layer], W, b, ws.layer[layer].qkv, p->state); }
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+struct PostArgs {
+    // forward inputs / saved activations
+    const float* ctx; const float* x;
+    const float* out_w; const float* out_b; const float* ln1_w; const float* ln1_b;
+    const float* w1; const float* b1; const float* w2; const float* b2; const float* ln2_w; const float* ln2_b;
+    float* u1; float* y; float* st1; float* a; float* u2; float* st2; float* z;
+    // backward
+    const float* dz; const float* w2T; const float* w1T; const float* out_wT;
+    float* du2; float* da; float* du1; float* dctx;
+    float* g_ln1_w; float* g_ln1_b; float* g_ln2_w; float* g_ln2_b;
+    const int* state; uint64_t seed; float p; float eps; int layer; int training;
+};
+
+template <int D, int F>
+__global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
+    constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    if (t0 >= T) return;
+    float* R0 = smem;                 // [64][LD]  ctx tile, later linear2 output
+    float* R1 = R0 + 64 * LD;         // [64][LD]  y tile
+    float* R2 = R1 + 64 * LD;         // [64][LF]  out_proj output (ld LD), then linear1 output / h
+    const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const uint32_t sP = DR4SR_SITE_PROJ + 4 * A.layer, sA = DR4SR_SITE_ACT + 4 * A.layer, sF = DR4SR_SITE_FFN + 4 * A.layer;
+
+    load_tile<D>(R0, LD, A.ctx, D, t0, T);
+    __syncthreads();
+    {
+        f32x16 acc[NV];
+        acc_zero(acc);
+        mma_64xN<D, NV>(R0, LD, A.out_w, acc);
+        acc_to_lds(acc, R2, LD, A.out_b);
+    }
+    __syncthreads();
+    // ---- dropout1 + residual + LayerNorm1
+    float4 gam[NV], bet[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { gam[j] = ld4(A.ln1_w + 4 * l16 + 64 * j); bet[j] = ld4(A.ln1_b + 4 * l16 + 64 * j); }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        if (t < T) {
+            float4 v[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                float4 o = ld4(R2 + row * LD + c);
+                if (dodrop) { const float4 m = drop4(rk, sP, (uint64_t)t * D + c); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+                const float4 xr = ld4(A.x + (size_t)t * D + c);
+                v[j] = make_float4(xr.x + o.x, xr.y + o.y, xr.z + o.z, xr.w + o.w);
+                st4(A.u1 + (size_t)t * D + c, v[j]);
+            }
+            float mean, rstd;
+            ln_stats16<NV>(v, mean, rstd, A.eps);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                const float4 yv = make_float4((v[j].x - mean) * rstd * gam[j].x + bet[j].x, (v[j].y - mean) * rstd * gam[j].y + bet[j].y,
+                                              (v[j].z - mean) * rstd * gam[j].z + bet[j].z, (v[j].w - mean) * rstd * gam[j].w + bet[j].w);
+                st4(A.y + (size_t)t * D + c, yv);
+                st4(R1 + row * LD + c, yv);
+            }
+            if (l16 == 0) { A.st1[2 * (size_t)t] = mean; A.st1[2 * (size_t)t + 1] = rstd; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) st4(R1 + row * LD + 4 * l16 + 64 * j, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    __syncthreads();
+    // ---- linear1 + GELU + dropout
+    {
+        f32x16 acc[NVF];
+        acc_zero(acc);
+        mma_64xN<D, NVF>(R1, LD, A.w1, acc);
+        acc_to_lds(acc, R2, LF, A.b1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+#pragma unroll
+        for (int j = 0; j < NVF; ++j) {
+            const int c = 4 * l16 + 64 * j;
+            const float4 av = ld4(R2 + row * LF + c);
+            float4 h = make_float4(gelu_erf(av.x), gelu_erf(av.y), gelu_erf(av.z), gelu_erf(av.w));
+            if (t < T) {
+                st4(A.a + (size_t)t * F + c, av);
+                if (dodrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); h.x *= m.x; h.y *= m.y; h.z *= m.z; h.w *= m.w; }
+            }
+            st4(R2 + row * LF + c, h);
+        }
+    }
+    __syncthreads();
+    // ---- linear2 + dropout2 + residual + LayerNorm2
+    {
+        f32x16 acc[NV];
+        acc_zero(acc);
+        mma_64xN<F, NV>(R2, LF, A.w2, acc);
+        acc_to_lds(acc, R0, LD, A.b2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { gam[j] = ld4(A.ln2_w + 4 * l16 + 64 * j); bet[j] = ld4(A.ln2_b + 4 * l16 + 64 * j); }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        if (t < T) {
+            float4 v[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                float4 o = ld4(R0 + row * LD + c);
+                if (dodrop) { const float4 m = drop4(rk, sF, (uint64_t)t * D + c); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+                const float4 yr = ld4(R1 + row * LD + c);
+                v[j] = make_float4(yr.x + o.x, yr.y + o.y, yr.z + o.z, yr.w + o.w);
+                st4(A.u2 + (size_t)t * D + c, v[j]);
+            }
+            float mean, rstd;
+            ln_stats16<NV>(v, mean, rstd, A.eps);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                st4(A.z + (size_t)t * D + c,
+                    make_float4((v[j].x - mean) * rstd * gam[j].x + bet[j].x, (v[j].y - mean) * rstd * gam[j].y + bet[j].y,
+                                (v[j].z - mean) * rstd * gam[j].z + bet[j].z, (v[j].w - mean) * rstd * gam[j].w + bet[j].w));
+            }
+            if (l16 == 0) { A.st2[2 * (size_t)t] = mean; A.st2[2 * (size_t)t + 1] = rstd; }
+        }
+    }
+}
+
+// LayerNorm backward of one row spread over a 16-lane group.  dzv: upstream grad, uv: LN input.
+// Returns du in dzv; accumulates affine partials.
+template <int NV>
+__device__ __forceinline__ void ln_bwd_row(float4 (&dzv)[NV], const float4 (&uv)[NV], float mean, float rstd,
+                                           const float4 (&gam)[NV], float4 (&dgam)[NV], float4 (&dbet)[NV]) {
+    constexpr float invD = 1.0f / (64 * NV);
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        xh[j] = make_float4((uv[j].x - mean) * rstd, (uv[j].y - mean) * rstd, (uv[j].z - mean) * rstd, (uv[j].w - mean) * rstd);
+        g[j] = make_float4(dzv[j].x * gam[j].x, dzv[j].y * gam[j].y, dzv[j].z * gam[j].z, dzv[j].w * gam[j].w);
+        s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+        dgam[j].x += dzv[j].x * xh[j].x; dgam[j].y += dzv[j].y * xh[j].y; dgam[j].z += dzv[j].z * xh[j].z; dgam[j].w += dzv[j].w * xh[j].w;
+        dbet[j].x += dzv[j].x; dbet[j].y += dzv[j].y; dbet[j].z += dzv[j].z; dbet[j].w += dzv[j].w;
+    }
+    s1 = group16_sum(s1) * invD;
+    s2 = group16_sum(s2) * invD;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        dzv[j].x = rstd * (g[j].x - s1 - xh[j].x * s2);
+        dzv[j].y = rstd * (g[j].y - s1 - xh[j].y * s2);
+        dzv[j].z = rstd * (g[j].z - s1 - xh[j].z * s2);
+        dzv[j].w = rstd * (g[j].w - s1 - xh[j].w * s2);
+    }
+}
+
+// fold the 4 row-groups of a wave (lanes l16 + 16k) and add the wave's partial to global
+__device__ __forceinline__ void flush1(float v, float* dst) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if ((threadIdx.x & 63) < 16) unsafeAtomicAdd(dst, v);
+}
+template <int NV>
+__device__ __forceinline__ void flush_affine(const float4 (&dgam)[NV], const float4 (&dbet)[NV], float* g_w, float* g_b) {
+    const int l16 = threadIdx.x & 15;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * l16 + 64 * j;
+        flush1(dgam[j].x, g_w + c); flush1(dgam[j].y, g_w + c + 1); flush1(dgam[j].z, g_w + c + 2); flush1(dgam[j].w, g_w + c + 3);
+        flush1(dbet[j].x, g_b + c); flush1(dbet[j].y, g_b + c + 1); flush1(dbet[j].z, g_b + c + 2); flush1(dbet[j].w, g_b + c + 3);
+    }
+}
+
+template <int D, int F>
+__global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
+    constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    if (t0 >= T) return;
+    float* R0 = smem;
+    float* R1 = R0 + 64 * LD;
+    float* R2 = R1 + 64 * LD;
+    const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const uint32_t sP = DR4SR_SITE_PROJ + 4 * A.layer, sA = DR4SR_SITE_ACT + 4 * A.layer, sF = DR4SR_SITE_FFN + 4 * A.layer;
+    float4 gam[NV], dgam[NV], dbet[NV];
+
+    // ---- LayerNorm2 backward: du2 -> global + R1 (residual branch); df = du2*mask -> R0
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gam[j] = ld4(A.ln2_w + 4 * l16 + 64 * j);
+        dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dbet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        if (t < T) {
+            float4 dzv[NV], uv[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                dzv[j] = ld4(A.dz + (size_t)t * D + c);
+                uv[j] = ld4(A.u2 + (size_t)t * D + c);
+            }
+            const float mean = A.st2[2 * (size_t)t], rstd = A.st2[2 * (size_t)t + 1];
+            ln_bwd_row<NV>(dzv, uv, mean, rstd, gam, dgam, dbet);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                st4(A.du2 + (size_t)t * D + c, dzv[j]);
+                st4(R1 + row * LD + c, dzv[j]);
+                float4 df = dzv[j];
+                if (dodrop) { const float4 m = drop4(rk, sF, (uint64_t)t * D + c); df.x *= m.x; df.y *= m.y; df.z *= m.z; df.w *= m.w; }
+                st4(R0 + row * LD + c, df);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                st4(R0 + row * LD + 4 * l16 + 64 * j, make_float4(0.f, 0.f, 0.f, 0.f));
+                st4(R1 + row * LD + 4 * l16 + 64 * j, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+    }
+    flush_affine<NV>(dgam, dbet, A.g_ln2_w, A.g_ln2_b);
+    __syncthreads();
+    // ---- dh = df W2   (x W^T form with W2^T [F][D])
+    {
+        f32x16 acc[NVF];
+        acc_zero(acc);
+        mma_64xN<D, NVF>(R0, LD, A.w2T, acc);
+        acc_to_lds(acc, R2, LF, nullptr);
+    }
+    __syncthreads();
+    // ---- da = dh * mask_act * gelu'(a)
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+#pragma unroll
+        for (int j = 0; j < NVF; ++j) {
+            const int c = 4 * l16 + 64 * j;
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) {
+                d = ld4(R2 + row * LF + c);
+                const float4 av = ld4(A.a + (size_t)t * F + c);
+                if (dodrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+                d.x *= gelu_erf_grad(av.x); d.y *= gelu_erf_grad(av.y); d.z *= gelu_erf_grad(av.z); d.w *= gelu_erf_grad(av.w);
+                st4(A.da + (size_t)t * F + c, d);
+            }
+            st4(R2 + row * LF + c, d);
+        }
+    }
+    __syncthreads();
+    // ---- dy = da W1 + du2 ;  LayerNorm1 backward -> du1 ;  do = du1*mask -> R1
+    {
+        f32x16 acc[NV];
+        acc_zero(acc);
+        mma_64xN<F, NV>(R2, LF, A.w1T, acc);
+        acc_to_lds(acc, R0, LD, nullptr);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gam[j] = ld4(A.ln1_w + 4 * l16 + 64 * j);
+        dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dbet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        if (t < T) {
+            float4 dyv[NV], uv[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                const float4 p0 = ld4(R0 + row * LD + c), p1 = ld4(R1 + row * LD + c);
+                dyv[j] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+                uv[j] = ld4(A.u1 + (size_t)t * D + c);
+            }
+            const float mean = A.st1[2 * (size_t)t], rstd = A.st1[2 * (size_t)t + 1];
+            ln_bwd_row<NV>(dyv, uv, mean, rstd, gam, dgam, dbet);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                st4(A.du1 + (size_t)t * D + c, dyv[j]);
+                float4 dd = dyv[j];
+                if (dodrop) { const float4 m = drop4(rk, sP, (uint64_t)t * D + c); dd.x *= m.x; dd.y *= m.y; dd.z *= m.z; dd.w *= m.w; }
+                st4(R1 + row * LD + c, dd);
+            }
+        }   // rows >= T of R1 are already zero
+    }
+    flush_affine<NV>(dgam, dbet, A.g_ln1_w, A.g_ln1_b);
+    __syncthreads();
+    // ---- dctx = do W_out
+    {
+        f32x16 acc[NV];
+        acc_zero(acc);
+        mma_64xN<D, NV>(R1, LD, A.out_wT, acc);
+        acc_to_lds(acc, R0, LD, nullptr);
+    }
+    __syncthreads();
+    constexpr int C4 = D / 4;
+    for (int i = threadIdx.x; i < 64 * C4; i += 256) {
+        const int row = i / C4, c = (i % C4) * 4;
+        if (t0 + row < T) st4(A.dctx + (size_t)(t0 + row) * D + c, ld4(R0 + row * LD + c));
+    }
+}
+
+static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
+    PostArgs A;
+    const LayerWs& lw = ws.layer[layer];
+    const float* P = p->params;
+    A.ctx = lw.ctx; A.x = ws.X[layer];
+    A.out_w = P + poff(ws, layer, P_OUT_W); A.out_b = P + poff(ws, layer, P_OUT_B);
+    A.ln1_w = P + poff(ws, layer, P_LN1_W); A.ln1_b = P + poff(ws, layer, P_LN1_B);
+    A.w1 = P + poff(ws, layer, P_W1); A.b1 = P + poff(ws, layer, P_B1);
+    A.w2 = P + poff(ws, layer, P_W2); A.b2 = P + poff(ws, layer, P_B2);
+    A.ln2_w = P + poff(ws, layer, P_LN2_W); A.ln2_b = P + poff(ws, layer, P_LN2_B);
+    A.u1 = lw.u1; A.y = lw.y; A.st1 = lw.st1; A.a = lw.a; A.u2 = lw.u2; A.st2 = lw.st2; A.z = ws.X[layer + 1];
+    A.dz = ws.dX[layer + 1];
+    const float* wT = ws.wT + layer * ws.wT_stride;
+    const int D = p->D, F = p->F;
+    A.out_wT = wT + 3 * D * D; A.w1T = wT + 4 * D * D; A.w2T = wT + 4 * D * D + D * F;
+    A.du2 = lw.du2; A.da = lw.da; A.du1 = lw.du1; A.dctx = ws.dctx;
+    float* G = p->grads;
+    A.g_ln1_w = G + poff(ws, layer, P_LN1_W); A.g_ln1_b = G + poff(ws, layer, P_LN1_B);
+    A.g_ln2_w = G + poff(ws, layer, P_LN2_W); A.g_ln2_b = G + poff(ws, layer, P_LN2_B);
+    A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
+    return A;
+}
+
+static size_t post_lds(int D, int F) { return sizeof(float) * 64 * (2 * (D + 4) + (F + 4)); }
+
+int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
+    const PostArgs A = make_post_args(p, ws, layer, training);
+    dim3 grid((ws.Tmax + 63) / 64), blk(256);
+    const size_t lds = post_lds(p->D, p->F);
+    if (p->D == 64 && p->F == 128) { big_lds(k_post_fwd<64, 128>, lds); hipLaunchKernelGGL((k_post_fwd<64, 128>), grid, blk, lds, s, A); }
+    else if (p->D == 128 && p->F == 128) { big_lds(k_post_fwd<128, 128>, lds); hipLaunchKernelGGL((k_post_fwd<128, 128>), grid, blk, lds, s, A); }
+    else if (p->D == 64 && p->F == 256) { big_lds(k_post_fwd<64, 256>, lds); hipLaunchKernelGGL((k_post_fwd<64, 256>), grid, blk, lds, s, A); }
+    else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}
+int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
+    const PostArgs A = make_post_args(p, ws, layer, training);
+    dim3 grid((ws.Tmax + 63) / 64), blk(256);
+    const size_t lds = post_lds(p->D, p->F);
+    if (p->D == 64 && p->F == 128) { big_lds(k_post_bwd<64, 128>, lds); hipLaunchKernelGGL((k_post_bwd<64, 128>), grid, blk, lds, s, A); }
+    else if (p->D == 128 && p->F == 128) { big_lds(k_post_bwd<128, 128>, lds); hipLaunchKernelGGL((k_post_bwd<128, 128>), grid, blk, lds, s, A); }
+    else if (p->D == 64 && p->F == 256) { big_lds(k_post_bwd<64, 256>, lds); hipLaunchKernelGGL((k_post_bwd<64, 256>), grid, blk, lds, s, A); }
+    else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// dx = dqkv W_in + du1   (x W^T form with W_in^T [D][3D])
+template <int D>
+__global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQKV, const float* __restrict__ WT,
+                                                 const float* __restrict__ dU1, float* __restrict__ dXo,
+                                                 const int* __restrict__ state) {
+    constexpr int K = 3 * D, LDA = K + 4, LDC = D + 4, NV = D / 64;
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    if (t0 >= T) return;
+    float* As = smem;
+    float* Cs = smem + 64 * LDA;
+    load_tile<K>(As, LDA, dQKV, K, t0, T);
+    __syncthreads();
+    f32x16 acc[NV];
+    acc_zero(acc);
+    mma_64xN<K, NV>(As, LDA, WT, acc);
+    acc_to_lds(acc, Cs, LDC, nullptr);
+    __syncthreads();
+    constexpr int C4 = D / 4;
+    for (int i = threadIdx.x; i < 64 * C4; i += 256) {
+        const int row = i / C4, c = (i % C4) * 4;
+        if (t0 + row < T) {
+            const float4 v = ld4(Cs + row * LDC + c), r = ld4(dU1 + (size_t)(t0 + row) * D + c);
+            st4(dXo + (size_t)(t0 + row) * D + c, make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w));
+        }
+    }
+}
+
+int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s) {
+    const int D = p->D;
+    const size_t lds = sizeof(float) * 64 * ((3 * D + 4) + (D + 4));
+    dim3 grid((ws.Tmax + 63) / 64), blk(256);
+    const float* WT = ws.wT + layer * ws.wT_stride;
+    const LayerWs& lw = ws.layer[layer];
+    if (D == 64) { big_lds(k_qkv_bwd<64>, lds); hipLaunchKernelGGL(k_qkv_bwd<64>, grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); }
+    else { big_lds(k_qkv_bwd<128>, lds); hipLaunchKernelGGL(k_qkv_bwd<128>, grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); }
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients: dW[n][k] = sum_t G[t][n] X[t][k], db[n] = sum_t G[t][n].
+// MFMA 32x32x2 with the TOKEN axis as the contraction: lane (r, g) feeds A[n0+r][t=2s+g] = Gs[t][n0+r]
+// and B[t][k0+r] = Xs[t][k0+r] (conflict-free ds_read_b32).  Each workgroup owns the full [NG x KX]
+// output (tiles spread over its 4 waves) for a strided subset of token tiles and adds it to the
+// flat gradient with 128-B-coalesced fp32 atomics at the end.
+struct WgradJob {
+    const float* G; int ldg; int gcol;        // G rows start at column gcol
+    const float* X; int ldx;
+    float* dW; float* db;
+    uint32_t gsite; int gmode;                // 1: G *= dropout keep factor at element t*ldg + col
+    uint32_t xsite; int xmode;                // 1: X = gelu(X) * keep factor
+};
+struct WgradArgs {
+    WgradJob job[6 * DR4SR_MAX_LAYERS];
+    const int* state; uint64_t seed; float p; int training;
+};
+
+template <int NG, int KX>
+__device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A) {
+    constexpr int NT = NG / 32, KT = KX / 32, TPW = (NT * KT) / 4;
+    static_assert((NT * KT) % 4 == 0, "tile count must split over 4 waves");
+    const int T = A.state[DR4SR_STATE_T];
+    const int ntiles = (T + 63) / 64;
+    float* Gs = smem;                 // [64][NG]
+    float* Xs = smem + 64 * NG;       // [64][KX]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, g = lane >> 5;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    f32x16 acc[TPW];
+    acc_zero(acc);
+    float bsum[(NG + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (NG + 255) / 256; ++i) bsum[i] = 0.f;
+
+    for (int tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+        const int t0 = tt * 64;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * (NG / 4); i += 256) {
+            const int row = i / (NG / 4), c = (i % (NG / 4)) * 4, t = t0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) {
+                v = ld4(J.G + (size_t)t * J.ldg + J.gcol + c);
+                if (J.gmode && dodrop) { const float4 m = drop4(rk, J.gsite, (uint64_t)t * J.ldg + J.gcol + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+            }
+            st4(Gs + row * NG + c, v);
+        }
+        for (int i = threadIdx.x; i < 64 * (KX / 4); i += 256) {
+            const int row = i / (KX / 4), c = (i % (KX / 4)) * 4, t = t0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) {
+                v = ld4(J.X + (size_t)t * J.ldx + c);
+                if (J.xmode) {
+                    v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+                    if (dodrop) { const float4 m = drop4(rk, J.xsite, (uint64_t)t * J.ldx + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+                }
+            }
+            st4(Xs + row * KX + c, v);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < 32; ++s) {
+            const int t = 2 * s + g;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int q = w + 4 * i, nt = q / KT, kt = q % KT;
+                const float a = Gs[t * NG + nt * 32 + r];
+                const float b = Xs[t * KX + kt * 32 + r];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (NG + 255) / 256; ++i) {
+            const int n = threadIdx.x + 256 * i;
+            if (n < NG) {
+                float sacc = 0.f;
+                for (int t = 0; t < 64; ++t) sacc += Gs[t * NG + n];
+                bsum[i] += sacc;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int q = w + 4 * i, nt = q / KT, kt = q % KT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+            unsafeAtomicAdd(J.dW + (size_t)row * KX + kt * 32 + r, acc[i][e]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (NG + 255) / 256; ++i) {
+        const int n = threadIdx.x + 256 * i;
+        if (n < NG) unsafeAtomicAdd(J.db + n, bsum[i]);
+    }
+}
+
+// blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2), blockIdx.z = layer
+template <int D, int F>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A) {
+    const int j = blockIdx.y;
+    const WgradJob& J = A.job[blockIdx.z * 6 + j];
+    if (j < 4) wgrad_body<D, D>(J, A);
+    else if (j == 4) wgrad_body<F, D>(J, A);
+    else wgrad_body<D, F>(J, A);
+}
+
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    WgradArgs A;
+    const int D = p->D, F = p->F;
+    float* G = p->grads;
+    for (int l = 0; l < p->n_layer; ++l) {
+        const LayerWs& lw = ws.layer[l];
+        for (int part = 0; part < 3; ++part) {          // in_proj rows [part*D, (part+1)*D)
+            WgradJob& J = A.job[l * 6 + part];
+            J.G = lw.dqkv; J.ldg = 3 * D; J.gcol = part * D; J.gsite = 0; J.gmode = 0;
+            J.X = ws.X[l]; J.ldx = D; J.xsite = 0; J.xmode = 0;
+            J.dW = G + poff(ws, l, P_IN_W) + (int64_t)part * D * D; J.db = G + poff(ws, l, P_IN_B) + part * D;
+        }
+        { WgradJob& J = A.job[l * 6 + 3];                 // out_proj: G = du1 * mask_proj, X = ctx
+          J.G = lw.du1; J.ldg = D; J.gcol = 0; J.gsite = DR4SR_SITE_PROJ + 4 * l; J.gmode = 1;
+          J.X = lw.ctx; J.ldx = D; J.xsite = 0; J.xmode = 0;
+          J.dW = G + poff(ws, l, P_OUT_W); J.db = G + poff(ws, l, P_OUT_B); }
+        { WgradJob& J = A.job[l * 6 + 4];                 // linear1: G = da, X = y
+          J.G = lw.da; J.ldg = F; J.gcol = 0; J.gsite = 0; J.gmode = 0;
+          J.X = lw.y; J.ldx = D; J.xsite = 0; J.xmode = 0;
+          J.dW = G + poff(ws, l, P_W1); J.db = G + poff(ws, l, P_B1); }
+        { WgradJob& J = A.job[l * 6 + 5];                 // linear2: G = du2 * mask_ffn, X = drop(gelu(a))
+          J.G = lw.du2; J.ldg = D; J.gcol = 0; J.gsite = DR4SR_SITE_FFN + 4 * l; J.gmode = 1;
+          J.X = lw.a; J.ldx = F; J.xsite = DR4SR_SITE_ACT + 4 * l; J.xmode = 1;
+          J.dW = G + poff(ws, l, P_W2); J.db = G + poff(ws, l, P_B2); }
+    }
+    A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.training = training;
+    const int ntiles = (ws.Tmax + 63) / 64;
+    int gw = ntiles < 24 ? ntiles : 24;
+    dim3 grid(gw, 6, p->n_layer), blk(256);
+    const size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
+    if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A); }
+    else if (D == 128 && F == 128) { big_lds(k_wgrad<128, 128>, lds); hipLaunchKernelGGL((k_wgrad<128, 128>), grid, blk, lds, s, A); }
+    else if (D == 64 && F == 256) { big_lds(k_wgrad<64, 256>, lds); hipLaunchKernelGGL((k_wgrad<64, 256>), grid, blk, lds, s, A); }
+    else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}

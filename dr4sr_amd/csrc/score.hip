@@ -1,0 +1,220 @@
+// score.hip — K0 negative sampler + K4 tied-embedding scorer with BCE, forward and backward.
+//
+// Reference: BaseModel._neg_sampling (model/basemodel.py:50-61): uniform over ids 1..N-1 with
+// replacement, history NOT excluded, never PAD;  BaseModel.training_step (model/basemodel.py:204-214):
+// pos = <q, E[target]>, neg = <q, E[neg]>, pos[target==0] = -inf;  BinaryCrossEntropyLoss
+// (model/loss_func.py:9-38): -logsigmoid(pos) + softplus(neg), masked where target == 0, / n_valid.
+//
+// One wave per (sequence, position): 64 lanes cover the D dims (D/64 floats per lane), the two dot
+// products are wave shuffles.  Gradients into the item table are row-sparse fp32 atomics on a dense
+// [N,D] buffer (the table is 3 MB: L2-resident), pads skipped.
+#include "common.h"
+#include "kernels.h"
+
+#define DR4SR_SITE_NEG 0x4e454721u     // RNG stream of the negative sampler
+
+__device__ __forceinline__ int64_t sample_neg_id(const RngKey& rk, uint64_t e, int n_items) {
+    const uint4 r = rng_call(rk, DR4SR_SITE_NEG, e >> 2);
+    const uint32_t c = (uint32_t)(e & 3);
+    const uint32_t w = c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w;
+    return 1 + (int64_t)__umulhi(w, (uint32_t)(n_items - 1));       // uniform on [1, n_items-1]
+}
+
+__global__ void k_neg_sample(int64_t* __restrict__ out, int64_t n, int n_items, uint64_t seed, uint32_t step) {
+    const RngKey rk = make_rng(seed, step, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = sample_neg_id(rk, (uint64_t)i, n_items);
+}
+
+extern "C" int dr4sr_neg_sample(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, uint32_t step, void* stream) {
+    if (!out || n < 0 || n_items < 2) return DR4SR_E_ARG;
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, n_items, seed, step);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed training scorer: forward + backward fused (upstream weight 1, un-normalised).
+template <int D>
+__global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ Z, const float* __restrict__ E,
+                                                      float* __restrict__ dE, float* __restrict__ dZ,
+                                                      const int64_t* __restrict__ target, const int64_t* __restrict__ rows,
+                                                      const int* __restrict__ cu, int64_t* __restrict__ neg_item,
+                                                      int sample_neg, float* __restrict__ tail, const int* __restrict__ state,
+                                                      uint64_t seed, int n_items, int B, int L) {
+    constexpr int NV = D / 64;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t0 = cu[b], n = cu[b + 1] - t0;
+    const int64_t row = rows ? rows[b] : b;
+    const RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], 0.f);
+    float lsum = 0.f, cnt = 0.f;
+    for (int l = w; l < L; l += 4) {
+        const int64_t tgt = target[row * L + l];
+        int64_t ng;
+        if (sample_neg) {
+            ng = sample_neg_id(rk, (uint64_t)b * L + l, n_items);
+            if (lane == 0) neg_item[(size_t)b * L + l] = ng;
+        } else {
+            ng = neg_item[(size_t)b * L + l];
+        }
+        const bool in = l < n;
+        if (tgt <= 0 || tgt >= n_items) {                 // pad target: masked out of loss and grads
+            if (in)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) dZ[(size_t)(t0 + l) * D + lane + 64 * j] = 0.f;
+            continue;
+        }
+        ng = ng < 0 ? 0 : (ng >= n_items ? n_items - 1 : ng);
+        float q[NV], ep[NV], en[NV];
+        float sp = 0.f, sn = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            q[j] = in ? Z[(size_t)(t0 + l) * D + lane + 64 * j] : 0.f;
+            ep[j] = E[tgt * D + lane + 64 * j];
+            en[j] = E[ng * D + lane + 64 * j];
+            sp += q[j] * ep[j];
+            sn += q[j] * en[j];
+        }
+        sp = wave_sum(sp);
+        sn = wave_sum(sn);
+        lsum += softplus_f(-sp) + softplus_f(sn);
+        cnt += 1.f;
+        if (in) {
+            const float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                dZ[(size_t)(t0 + l) * D + lane + 64 * j] = dpos * ep[j] + dneg * en[j];
+                unsafeAtomicAdd(dE + tgt * D + lane + 64 * j, dpos * q[j]);
+                unsafeAtomicAdd(dE + ng * D + lane + 64 * j, dneg * q[j]);
+            }
+        }
+    }
+    if (lane == 0 && cnt > 0.f) {
+        unsafeAtomicAdd(tail + 0, cnt);
+        unsafeAtomicAdd(tail + 1, lsum);
+    }
+}
+
+int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
+    const float* E = p->params + ws.off[0];
+    float* dE = p->grads + ws.off[0];
+    float* tail = p->grads + ws.n_params;
+    dim3 grid(p->B), blk(256);
+    const float* Z = ws.X[p->n_layer];
+    float* dZ = ws.dX[p->n_layer];
+    if (p->D == 64)
+        hipLaunchKernelGGL(k_score_packed<64>, grid, blk, 0, s, Z, E, dE, dZ, p->item_id, p->rows, ws.cu, p->neg_item,
+                           p->sample_neg, tail, p->state, p->seed, p->n_items, p->B, p->L);
+    else
+        hipLaunchKernelGGL(k_score_packed<128>, grid, blk, 0, s, Z, E, dE, dZ, p->item_id, p->rows, ws.cu, p->neg_item,
+                           p->sample_neg, tail, p->state, p->seed, p->n_items, p->B, p->L);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense API scorer (query [B,L,D]); one wave per position.
+template <int D>
+__global__ __launch_bounds__(256) void k_score_dense_fwd(const float* __restrict__ Q, const float* __restrict__ E,
+                                                         const int64_t* __restrict__ target, const int64_t* __restrict__ neg,
+                                                         float* __restrict__ pos_score, float* __restrict__ neg_score,
+                                                         float* __restrict__ loss_pos, float* __restrict__ stats, int64_t npos) {
+    constexpr int NV = D / 64;
+    const int lane = threadIdx.x & 63;
+    float lsum = 0.f, cnt = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < npos; i += (int64_t)gridDim.x * 4) {
+        const int64_t tgt = target[i], ng = neg[i];
+        float sp = 0.f, sn = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float q = Q[i * D + lane + 64 * j];
+            sp += q * E[tgt * D + lane + 64 * j];
+            sn += q * E[ng * D + lane + 64 * j];
+        }
+        sp = wave_sum(sp);
+        sn = wave_sum(sn);
+        const bool pad = tgt == 0;
+        const float lp = pad ? 0.f : softplus_f(-sp) + softplus_f(sn);
+        if (lane == 0) {
+            if (pos_score) pos_score[i] = pad ? -INFINITY : sp;
+            if (neg_score) neg_score[i] = sn;
+            if (loss_pos) loss_pos[i] = lp;
+        }
+        if (!pad) { lsum += lp; cnt += 1.f; }
+    }
+    if (stats && lane == 0 && cnt > 0.f) {
+        unsafeAtomicAdd(stats + 0, cnt);
+        unsafeAtomicAdd(stats + 1, lsum);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_score_dense_bwd(const float* __restrict__ Q, const float* __restrict__ E,
+                                                         const int64_t* __restrict__ target, const int64_t* __restrict__ neg,
+                                                         const float* __restrict__ wgt, const float* __restrict__ scale,
+                                                         float* __restrict__ dQ, float* __restrict__ dE, int64_t npos) {
+    constexpr int NV = D / 64;
+    const int lane = threadIdx.x & 63;
+    const float sc = scale ? *scale : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < npos; i += (int64_t)gridDim.x * 4) {
+        const int64_t tgt = target[i], ng = neg[i];
+        if (tgt == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) dQ[i * D + lane + 64 * j] = 0.f;
+            continue;
+        }
+        float q[NV], ep[NV], en[NV];
+        float sp = 0.f, sn = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            q[j] = Q[i * D + lane + 64 * j];
+            ep[j] = E[tgt * D + lane + 64 * j];
+            en[j] = E[ng * D + lane + 64 * j];
+            sp += q[j] * ep[j];
+            sn += q[j] * en[j];
+        }
+        sp = wave_sum(sp);
+        sn = wave_sum(sn);
+        const float up = sc * (wgt ? wgt[i] : 1.f);
+        const float dpos = -sigmoid_f(-sp) * up, dneg = sigmoid_f(sn) * up;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            dQ[i * D + lane + 64 * j] = dpos * ep[j] + dneg * en[j];
+            if (dE) {
+                unsafeAtomicAdd(dE + tgt * D + lane + 64 * j, dpos * q[j]);
+                unsafeAtomicAdd(dE + ng * D + lane + 64 * j, dneg * q[j]);
+            }
+        }
+    }
+}
+
+extern "C" int dr4sr_score_bce_fwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                                   float* pos_score, float* neg_score, float* loss_pos, float* stats, int64_t B,
+                                   int32_t L, int32_t D, void* stream) {
+    if (!query || !E || !target || !neg || B < 0 || L <= 0) return DR4SR_E_ARG;
+    if (D != 64 && D != 128) return DR4SR_E_SHAPE;
+    const int64_t npos = B * L;
+    if (npos == 0) return 0;
+    int64_t blocks = (npos + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 64) hipLaunchKernelGGL(k_score_dense_fwd<64>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
+    else hipLaunchKernelGGL(k_score_dense_fwd<128>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_score_bce_bwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                                   const float* w, const float* scale, float* d_query, float* dE, int64_t B, int32_t L,
+                                   int32_t D, void* stream) {
+    if (!query || !E || !target || !neg || !d_query || B < 0 || L <= 0) return DR4SR_E_ARG;
+    if (D != 64 && D != 128) return DR4SR_E_SHAPE;
+    const int64_t npos = B * L;
+    if (npos == 0) return 0;
+    int64_t blocks = (npos + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 64) hipLaunchKernelGGL(k_score_dense_bwd<64>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
+    else hipLaunchKernelGGL(k_score_dense_bwd<128>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
+    return DR4SR_LAUNCH_CHECK();
+}

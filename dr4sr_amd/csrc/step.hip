@@ -1,0 +1,197 @@
+// step.hip — host-side orchestration behind the C ABI: parameter layout, workspace carve-up, the
+// fused dense Adam kernel, and the launch sequences of fwd_bwd / encode / encode_bwd.
+// Every function only enqueues kernels (and one memset) on the caller's stream: graph-capturable.
+//
+// Reference control flow being replaced: model/basemodel.py:193-199 (one iteration of training_epoch).
+#include "common.h"
+#include "kernels.h"
+
+extern "C" int dr4sr_abi_version(void) { return DR4SR_ABI_VERSION; }
+
+extern "C" int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
+                                             int64_t* off) {
+    int64_t o = 0;
+    auto put = [&](int i, int64_t n) { if (off) off[i] = o; o += n; };
+    put(0, (int64_t)n_items * D);
+    put(1, (int64_t)L * D);
+    for (int l = 0; l < n_layer; ++l) {
+        const int b = 2 + 12 * l;
+        put(b + P_IN_W, 3LL * D * D); put(b + P_IN_B, 3LL * D);
+        put(b + P_OUT_W, (int64_t)D * D); put(b + P_OUT_B, D);
+        put(b + P_W1, (int64_t)F * D); put(b + P_B1, F);
+        put(b + P_W2, (int64_t)D * F); put(b + P_B2, D);
+        put(b + P_LN1_W, D); put(b + P_LN1_B, D); put(b + P_LN2_W, D); put(b + P_LN2_B, D);
+    }
+    return o;
+}
+
+static int check_plan(const dr4sr_sasrec_plan* p) {
+    if (!p || p->abi_version != DR4SR_ABI_VERSION) return DR4SR_E_ARG;
+    if (p->B <= 0 || p->L <= 0 || p->n_items < 2 || p->n_layer <= 0 || p->n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    if (p->L > 64) return DR4SR_E_SHAPE;
+    if (!((p->D == 64 && (p->F == 128 || p->F == 256)) || (p->D == 128 && p->F == 128))) return DR4SR_E_SHAPE;
+    if (p->H <= 0 || p->H > 4 || p->D % p->H || (p->D / p->H != 32 && p->D / p->H != 64)) return DR4SR_E_SHAPE;
+    if (!(p->p_drop >= 0.f && p->p_drop < 1.f)) return DR4SR_E_ARG;
+    if (!p->params || !p->state || !p->in_item_id || !p->seqlen) return DR4SR_E_ARG;
+    return 0;
+}
+
+int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
+    const int64_t D = p->D, F = p->F, Tmax = (int64_t)p->B * p->L;
+    ws->n_params = dr4sr_sasrec_param_layout(p->n_items, p->L, p->D, p->F, p->n_layer, ws->off);
+    ws->Tmax = (int)Tmax;
+    char* base = (char*)p->workspace;
+    int64_t o = 0;
+    auto take = [&](int64_t nfloat) -> float* {
+        float* r = base ? (float*)(base + o) : nullptr;
+        o += ((nfloat * 4 + 255) / 256) * 256;
+        return r;
+    };
+    ws->cu = (int*)take(p->B + 1);
+    for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
+    ws->dctx = take(Tmax * D);
+    ws->wT_stride = 4 * D * D + 2 * D * F;
+    ws->wT = take(ws->wT_stride * p->n_layer);
+    for (int l = 0; l < p->n_layer; ++l) {
+        LayerWs& w = ws->layer[l];
+        w.qkv = take(Tmax * 3 * D); w.ctx = take(Tmax * D);
+        w.u1 = take(Tmax * D); w.y = take(Tmax * D); w.st1 = take(Tmax * 2);
+        w.a = take(Tmax * F); w.u2 = take(Tmax * D); w.st2 = take(Tmax * 2);
+        w.du2 = take(Tmax * D); w.da = take(Tmax * F); w.du1 = take(Tmax * D); w.dqkv = take(Tmax * 3 * D);
+    }
+    ws->bytes = o;
+    return 0;
+}
+
+extern "C" int64_t dr4sr_sasrec_workspace_bytes(const dr4sr_sasrec_plan* plan) {
+    if (!plan) return DR4SR_E_ARG;
+    dr4sr_sasrec_plan q = *plan;
+    q.workspace = nullptr;
+    if (q.B <= 0 || q.L <= 0 || q.n_layer <= 0 || q.n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    Workspace ws;
+    carve_workspace(&q, &ws);
+    return ws.bytes;
+}
+
+static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
+    int rc = check_plan(p);
+    if (rc) return rc;
+    if (!p->workspace) return DR4SR_E_ARG;
+    carve_workspace(p, ws);
+    if (ws->bytes > p->workspace_bytes) return DR4SR_E_WS;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense Adam over the flat buffers (torch.optim.Adam, single-tensor formula):
+//   g = grad/n_valid + wd*p ; m += (g-m)(1-b1) ; v = b2 v + (1-b2) g^2
+//   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// t = state[STEP]+1; the last block to finish bumps state[STEP] (ticket in state[8]).
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M,
+                                              float* __restrict__ V, int64_t n, int* __restrict__ state, float lr, float b1,
+                                              float b2, float eps, float wd) {
+    const int t = state[DR4SR_STATE_STEP] + 1;
+    const float nvalid = G[n];
+    const float gs = nvalid > 0.f ? 1.0f / nvalid : 0.f;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 p = ld4(P + 4 * i), m = ld4(M + 4 * i), v = ld4(V + 4 * i);
+        const float4 g0 = ld4(G + 4 * i);
+        auto upd = [&](float& pe, float& me, float& ve, float ge) {
+            const float g = ge * gs + wd * pe;
+            me = me + (g - me) * (1.0f - b1);
+            ve = ve * b2 + (1.0f - b2) * g * g;
+            const float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
+            pe = pe - step_size * (me / denom);
+        };
+        upd(p.x, m.x, v.x, g0.x); upd(p.y, m.y, v.y, g0.y); upd(p.z, m.z, v.z, g0.z); upd(p.w, m.w, v.w, g0.w);
+        st4(P + 4 * i, p); st4(M + 4 * i, m); st4(V + 4 * i, v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(&state[8], 1);
+        if (ticket == (int)gridDim.x - 1) { state[8] = 0; state[DR4SR_STATE_STEP] = t; }
+    }
+}
+
+int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s) {
+    if (!p->grads || !p->adam_m || !p->adam_v || p->n_params <= 0 || (p->n_params & 3)) return DR4SR_E_ARG;
+    int64_t blocks = (p->n_params / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, p->params, p->grads, p->adam_m, p->adam_v, p->n_params,
+                       p->state, p->lr, p->beta1, p->beta2, p->adam_eps, p->weight_decay);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_adam_step(const dr4sr_sasrec_plan* plan, void* stream) {
+    if (!plan || plan->abi_version != DR4SR_ABI_VERSION || !plan->params || !plan->state) return DR4SR_E_ARG;
+    return launch_adam(plan, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    RC(launch_embed_fwd(p, ws, training, s));
+    for (int l = 0; l < p->n_layer; ++l) {
+        RC(launch_qkv_fwd(p, ws, l, s));
+        RC(launch_attn_fwd(p, ws, l, training, s));
+        RC(launch_post_fwd(p, ws, l, training, s));
+    }
+    return 0;
+}
+
+static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    RC(launch_transpose_weights(p, ws, s));
+    for (int l = p->n_layer - 1; l >= 0; --l) {
+        RC(launch_post_bwd(p, ws, l, training, s));
+        RC(launch_attn_bwd(p, ws, l, training, s));
+        RC(launch_qkv_bwd(p, ws, l, s));
+    }
+    RC(launch_embed_bwd(p, ws, training, s));
+    RC(launch_wgrad(p, ws, training, s));
+    return 0;
+}
+
+extern "C" int dr4sr_sasrec_fwd_bwd(const dr4sr_sasrec_plan* plan, void* stream) {
+    Workspace ws;
+    RC(get_ws(plan, &ws));
+    if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(hip_ret(hipMemsetAsync(plan->grads, 0, sizeof(float) * (ws.n_params + DR4SR_GRAD_TAIL), s)));
+    RC(launch_prep(plan, ws, 1, s));
+    RC(forward_layers(plan, ws, 1, s));
+    RC(launch_score_packed(plan, ws, s));
+    RC(backward_layers(plan, ws, 1, s));
+    return 0;
+}
+
+extern "C" int dr4sr_sasrec_train_step(const dr4sr_sasrec_plan* plan, void* stream) {
+    RC(dr4sr_sasrec_fwd_bwd(plan, stream));
+    return dr4sr_adam_step(plan, stream);
+}
+
+extern "C" int dr4sr_sasrec_encode(const dr4sr_sasrec_plan* plan, int32_t training, int32_t pooling, float* out,
+                                   void* stream) {
+    Workspace ws;
+    RC(get_ws(plan, &ws));
+    if (!out || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(launch_prep(plan, ws, training ? 1 : 0, s));
+    RC(forward_layers(plan, ws, training, s));
+    return launch_unpack(plan, ws, ws.X[plan->n_layer], out, pooling == DR4SR_POOL_LAST, s);
+}
+
+extern "C" int dr4sr_sasrec_encode_bwd(const dr4sr_sasrec_plan* plan, int32_t training, int32_t pooling,
+                                       const float* d_out, void* stream) {
+    Workspace ws;
+    RC(get_ws(plan, &ws));
+    if (!d_out || !plan->grads || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(launch_pack(plan, ws, d_out, ws.dX[plan->n_layer], pooling == DR4SR_POOL_LAST, s));
+    return backward_layers(plan, ws, training, s);
+}

@@ -1,0 +1,166 @@
+"""SasrecEngine — owns the flat fp32 buffers (params / grads / Adam moments), the workspace and the
+device state words, and drives the C ABI (include/dr4sr_hip.h).  PyTorch supplies device memory and
+the stream only; all arithmetic runs in libdr4sr_hip.so.
+
+Replaces, on the device: one iteration of BaseModel.training_epoch
+(/root/reference model/basemodel.py:193-199) for model = SASRec (model/sasrec.py:39-75).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+_LAYER_TENSORS = [  # order of include/dr4sr_hip.h "Flat parameter layout"
+    ("self_attn.in_proj_weight", lambda D, F: (3 * D, D)),
+    ("self_attn.in_proj_bias", lambda D, F: (3 * D,)),
+    ("self_attn.out_proj.weight", lambda D, F: (D, D)),
+    ("self_attn.out_proj.bias", lambda D, F: (D,)),
+    ("linear1.weight", lambda D, F: (F, D)),
+    ("linear1.bias", lambda D, F: (F,)),
+    ("linear2.weight", lambda D, F: (D, F)),
+    ("linear2.bias", lambda D, F: (D,)),
+    ("norm1.weight", lambda D, F: (D,)),
+    ("norm1.bias", lambda D, F: (D,)),
+    ("norm2.weight", lambda D, F: (D,)),
+    ("norm2.bias", lambda D, F: (D,)),
+]
+
+
+def param_names(n_layer: int):
+    names = ["item_embedding.weight", "query_encoder.position_emb.weight"]
+    for i in range(n_layer):
+        names += [f"query_encoder.transformer_layer.layers.{i}.{n}" for n, _ in _LAYER_TENSORS]
+    return names
+
+
+def param_shapes(n_items, L, D, F, n_layer):
+    shapes = [(n_items, D), (L, D)]
+    for _ in range(n_layer):
+        shapes += [fn(D, F) for _, fn in _LAYER_TENSORS]
+    return shapes
+
+
+class SasrecEngine:
+    def __init__(self, n_items: int, L: int, D: int, H: int, F: int, n_layer: int, ln_eps: float = 1e-12,
+                 p_drop: float = 0.0, max_batch: int = 256, device="cuda", seed: int = 2023, lr: float = 1e-3,
+                 betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.Dr4srError("SasrecEngine needs a GPU device; dr4sr_amd has no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_items, self.L, self.D, self.H, self.F, self.n_layer = n_items, L, D, H, F, n_layer
+        self.ln_eps, self.p_drop, self.seed = float(ln_eps), float(p_drop), int(seed)
+        self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        self.max_batch = max_batch
+        noff = 2 + 12 * n_layer
+        off = (C.c_int64 * noff)()
+        self.n_params = int(self.lib.dr4sr_sasrec_param_layout(n_items, L, D, F, n_layer, off))
+        self.offsets = list(off)
+        dev = self.device
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_params + _lib.GRAD_TAIL, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int32, device=dev)
+        self.names = param_names(n_layer)
+        self.shapes = param_shapes(n_items, L, D, F, n_layer)
+        self.views: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self.grad_views: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for name, shp, o in zip(self.names, self.shapes, self.offsets):
+            n = 1
+            for s in shp:
+                n *= s
+            self.views[name] = self.params[o:o + n].view(shp)
+            self.grad_views[name] = self.grads[o:o + n].view(shp)
+        probe = self._plan(max_batch, None, None, None, None, None, False, with_ws=False)
+        self.ws_bytes = int(self.lib.dr4sr_sasrec_workspace_bytes(C.byref(probe)))
+        if self.ws_bytes <= 0:
+            raise _lib.Dr4srError(f"workspace_bytes failed ({self.ws_bytes})")
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.neg_scratch = torch.zeros(max_batch * L, dtype=torch.int64, device=dev)
+        self._keep = []          # tensors referenced by the last plan
+
+    # ------------------------------------------------------------------------------------------
+    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True):
+        p = _lib.SasrecPlan()
+        p.abi_version = _lib.ABI_VERSION
+        p.B, p.L, p.D, p.H, p.F, p.n_layer, p.n_items = B, self.L, self.D, self.H, self.F, self.n_layer, self.n_items
+        p.ln_eps, p.p_drop, p.seed = self.ln_eps, self.p_drop, self.seed
+        p.params, p.grads = self.params.data_ptr(), self.grads.data_ptr()
+        p.adam_m, p.adam_v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        p.n_params = self.n_params
+        for name, t in (("in_item_id", in_item_id), ("item_id", item_id), ("seqlen", seqlen), ("rows", rows),
+                        ("neg_item", neg_item)):
+            if t is not None:
+                assert t.dtype == torch.int64 and t.is_contiguous() and t.device == self.device, name
+                setattr(p, name, t.data_ptr())
+        p.sample_neg = 1 if sample_neg else 0
+        if with_ws:
+            p.workspace, p.workspace_bytes = self.workspace.data_ptr(), self.ws_bytes
+        p.state = self.state.data_ptr()
+        p.lr, (p.beta1, p.beta2), p.adam_eps, p.weight_decay = self.lr, self.betas, self.adam_eps, self.weight_decay
+        self._keep = [in_item_id, item_id, seqlen, rows, neg_item]
+        return p
+
+    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None):
+        """rows=None: the tensors ARE the batch ([B,L]/[B]); else they are dataset tensors indexed by rows[B]."""
+        B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
+        if B > self.max_batch:
+            raise _lib.Dr4srError(f"batch {B} > max_batch {self.max_batch}")
+        if sample_neg is None:
+            sample_neg = neg_item is None
+        if neg_item is None:
+            neg_item = self.neg_scratch
+        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg)
+
+    # ------------------------------------------------------------------------------------------
+    def fwd_bwd(self, plan):
+        _lib.check(self.lib.dr4sr_sasrec_fwd_bwd(C.byref(plan), _lib.cur_stream()), "dr4sr_sasrec_fwd_bwd")
+
+    def adam_step(self, plan):
+        _lib.check(self.lib.dr4sr_adam_step(C.byref(plan), _lib.cur_stream()), "dr4sr_adam_step")
+
+    def train_step(self, plan):
+        _lib.check(self.lib.dr4sr_sasrec_train_step(C.byref(plan), _lib.cur_stream()), "dr4sr_sasrec_train_step")
+
+    def encode(self, plan, training: bool, pooling: int, out: Optional[torch.Tensor] = None):
+        B = plan.B
+        shape = (B, self.D) if pooling == _lib.POOL_LAST else (B, self.L, self.D)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dr4sr_sasrec_encode(C.byref(plan), int(training), pooling, _lib.ptr(out), _lib.cur_stream()),
+                   "dr4sr_sasrec_encode")
+        return out
+
+    def encode_bwd(self, plan, training: bool, pooling: int, d_out: torch.Tensor):
+        _lib.check(self.lib.dr4sr_sasrec_encode_bwd(C.byref(plan), int(training), pooling, _lib.ptr(d_out.contiguous()),
+                                                    _lib.cur_stream()), "dr4sr_sasrec_encode_bwd")
+
+    # ------------------------------------------------------------------------------------------
+    def loss_and_count(self):
+        """(mean loss, n_valid) of the last fwd_bwd — reads the gradient tail (one host sync)."""
+        tail = self.grads[self.n_params:self.n_params + 2].tolist()
+        n = tail[0]
+        return (tail[1] / n if n > 0 else float("nan")), int(n)
+
+    def normalized_grads(self) -> Dict[str, torch.Tensor]:
+        n = self.grads[self.n_params]
+        return {k: v / n for k, v in self.grad_views.items()}
+
+    def load_named(self, sd: Dict[str, torch.Tensor]):
+        for k, v in self.views.items():
+            v.copy_(sd[k].to(self.device, torch.float32))
+
+    def dropout_mask(self, n: int, site: int, step: int, p: Optional[float] = None) -> torch.Tensor:
+        n4 = (n + 3) // 4 * 4
+        out = torch.empty(n4, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dr4sr_dropout_mask(_lib.ptr(out), n4, self.p_drop if p is None else p, self.seed, step, site,
+                                               _lib.cur_stream()), "dr4sr_dropout_mask")
+        return out[:n]

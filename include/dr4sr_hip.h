@@ -1,0 +1,166 @@
+/* dr4sr_hip.h — C ABI of the MI355X (gfx950) hot path for DR4SR's target-model training loop.
+ *
+ * The reference (USTC-StarTeam/DR4SR) has no FFI of its own: the path is pure PyTorch.  The
+ * boundary a maintainer would bind is therefore "what the reference asks torch to do" on
+ *   model/basemodel.py:177-214  (training_epoch / training_step: neg-sampling, encoder forward,
+ *                                tied-embedding scorer, BCE, backward, Adam)
+ *   model/sasrec.py:39-75       (SASRecQueryEncoder.forward)
+ *   model/loss_func.py:9-38     (BinaryCrossEntropyLoss)
+ *   model/basemodel.py:354-365  (topk: full-item scorer)
+ * Every entry point below names the reference lines it replaces.  INTEGRATION.md shows the
+ * ctypes stub that binds them from the reference's Python.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless said otherwise
+ *   - fp32 activations/parameters, int64 ids (as the reference stores them), row-major, contiguous
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no host sync,
+ *     no allocation) so calls may be captured into a hipGraph
+ *   - return value: 0 = ok, negative = argument error (DR4SR_E_*), positive = hipError_t
+ *   - nothing is retained across calls except what the caller passes in (plan + workspace)
+ */
+#ifndef DR4SR_HIP_H
+#define DR4SR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR4SR_ABI_VERSION 1
+
+#define DR4SR_E_ARG      (-1)   /* null pointer / bad size                                   */
+#define DR4SR_E_SHAPE    (-2)   /* unsupported D / H / F / L combination     */
+#define DR4SR_E_WS       (-3)   /* workspace too small                                       */
+
+/* dropout sites (RNG stream ids); per-layer sites are  kind + 4*layer */
+#define DR4SR_SITE_EMB   0      /* sasrec.py:66   dropout(seq_embs + position_embs)          */
+#define DR4SR_SITE_ATTN  1      /* torch MHA      dropout on attention probabilities         */
+#define DR4SR_SITE_PROJ  2      /* torch TEL      dropout1 after out_proj                    */
+#define DR4SR_SITE_ACT   3      /* torch TEL      dropout after the activation               */
+#define DR4SR_SITE_FFN   4      /* torch TEL      dropout2 after linear2                     */
+
+#define DR4SR_POOL_NONE   0
+#define DR4SR_POOL_ORIGIN 1     /* module/layers.py:41-50  zero rows >= seqlen  -> [B,L,D]   */
+#define DR4SR_POOL_LAST   2     /* module/layers.py:69-73  row seqlen-1         -> [B,D]     */
+
+/* slots of the int32 `state` buffer (device), DR4SR_STATE_WORDS words, owned by the caller */
+#define DR4SR_STATE_STEP     0  /* optimizer step counter t (incremented by dr4sr_adam_step) */
+#define DR4SR_STATE_T        1  /* number of packed (valid) tokens of the current batch      */
+#define DR4SR_STATE_NVALID   2  /* number of loss positions (target != 0)                    */
+#define DR4SR_STATE_RNGSTEP  3  /* RNG step (incremented by every fwd_bwd)                   */
+#define DR4SR_STATE_WORDS    16
+
+/* Flat parameter layout (fp32), identical for params / grads / adam_m / adam_v:
+ *   E[N,D] | P[L,D] | per layer: in_w[3D,D] in_b[3D] out_w[D,D] out_b[D] w1[F,D] b1[F] w2[D,F] b2[D]
+ *                                 ln1_w[D] ln1_b[D] ln2_w[D] ln2_b[D]
+ * (names: item_embedding.weight, query_encoder.position_emb.weight,
+ *  query_encoder.transformer_layer.layers.{i}.{self_attn.in_proj_weight, ...} — SURVEY.md §8a)
+ * The grads buffer has DR4SR_GRAD_TAIL extra floats after n_params:
+ *   grads[n_params+0] = number of loss positions (as float), grads[n_params+1] = loss SUM.
+ * Gradients are accumulated UN-normalised (d loss_sum); dr4sr_adam_step divides by
+ * grads[n_params+0], so that under data parallelism ONE sum-all-reduce of the whole buffer yields
+ * the reference's global-batch normalisation (loss_func.py:18-19, :29-30). */
+#define DR4SR_GRAD_TAIL 4
+
+typedef struct dr4sr_sasrec_plan {
+    int32_t abi_version;            /* must be DR4SR_ABI_VERSION                                */
+    /* ---- model dims (configs/basemodel.yaml, configs/sasrec.yaml) ---- */
+    int32_t B, L, D, H, F, n_layer, n_items;
+    float   ln_eps;                 /* layer_norm_eps                                            */
+    float   p_drop;                 /* dropout_rate (0 => no RNG work at all)                    */
+    uint64_t seed;                  /* Philox key                                                */
+    /* ---- parameters ---- */
+    float*  params;                 /* [n_params]                                                */
+    float*  grads;                  /* [n_params + DR4SR_GRAD_TAIL]                              */
+    float*  adam_m;                 /* [n_params]                                                */
+    float*  adam_v;                 /* [n_params]                                                */
+    int64_t n_params;
+    /* ---- batch: rows `rows[0..B)` of device-resident dataset tensors (data/dataset.py:79-91).
+     *      rows == NULL means rows 0..B-1, i.e. the three pointers ARE the batch tensors. ---- */
+    const int64_t* in_item_id;      /* [U,L]  batch['in_item_id']                                */
+    const int64_t* item_id;         /* [U,L]  batch['item_id'] (targets), may be NULL for encode */
+    const int64_t* seqlen;          /* [U]    batch['seqlen']                                    */
+    const int64_t* rows;            /* [B] or NULL                                               */
+    int64_t* neg_item;              /* [B,L]  batch['neg_item'] (K = 1)                          */
+    int32_t  sample_neg;            /* 1: draw negatives in-kernel (basemodel.py:50-61) and WRITE
+                                          them to neg_item; 0: READ neg_item                     */
+    /* ---- scratch ---- */
+    void*    workspace;             /* >= dr4sr_sasrec_workspace_bytes(plan) bytes               */
+    int64_t  workspace_bytes;
+    int32_t* state;                 /* [DR4SR_STATE_WORDS] device words, zero-initialised once   */
+    /* ---- optimizer (basemodel.py:79-98: torch.optim.Adam) ---- */
+    float lr, beta1, beta2, adam_eps, weight_decay;
+} dr4sr_sasrec_plan;
+
+/* -------------------------------------------------------------------------------------------- */
+int  dr4sr_abi_version(void);
+/* Fills offsets[0]=E, [1]=P, [2+12*i+j] = j-th tensor of layer i (order above); returns n_params. */
+int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
+                                  int64_t* offsets /* [2+12*n_layer] or NULL */);
+int64_t dr4sr_sasrec_workspace_bytes(const dr4sr_sasrec_plan* plan);
+
+/* One reference training step minus the optimizer:  basemodel.py:193-198
+ *   (_neg_sampling) -> training_step (sasrec.py:39-75 encoder, basemodel.py:204-214 scorer,
+ *   loss_func.py:9-38 BCE) -> loss.backward().
+ * Leaves un-normalised gradients + {n_valid, loss_sum} in plan->grads (zeroed first). */
+int dr4sr_sasrec_fwd_bwd(const dr4sr_sasrec_plan* plan, void* stream);
+
+/* optimizer.step() (basemodel.py:199) on the flat buffers: dense torch.optim.Adam semantics,
+ * g = grads[i] / grads[n_params] (+ weight_decay * p).  Increments state[STEP]. */
+int dr4sr_adam_step(const dr4sr_sasrec_plan* plan, void* stream);
+
+/* fwd_bwd + adam in one call (single-GPU fast path). */
+int dr4sr_sasrec_train_step(const dr4sr_sasrec_plan* plan, void* stream);
+
+/* SASRecQueryEncoder.forward + SeqPoolingLayer (sasrec.py:39-75, layers.py:41-50/:69-73).
+ * training != 0 applies dropout (RNG step = state[RNGSTEP]) and keeps activations in the
+ * workspace for dr4sr_sasrec_encode_bwd.  out: [B,L,D] (NONE/ORIGIN; NONE leaves rows >= seqlen
+ * ZERO as well — they are never computed) or [B,D] (LAST). */
+int dr4sr_sasrec_encode(const dr4sr_sasrec_plan* plan, int32_t training, int32_t pooling,
+                        float* out, void* stream);
+/* autograd of the above (same `training` / `pooling` as the forward call it differentiates, no
+ * other encode call in between): d_out has the shape of `out`; parameter gradients are ACCUMULATED
+ * into plan->grads (exactly d_out-weighted, no normalisation). */
+int dr4sr_sasrec_encode_bwd(const dr4sr_sasrec_plan* plan, int32_t training, int32_t pooling,
+                            const float* d_out, void* stream);
+
+/* K1: item_encoder(idx) + position_emb(arange(L))  (sasrec.py:43-46, :64) for ALL B*L positions,
+ * bit-exact with torch (gather + one IEEE add).  out [B,L,D]. */
+int dr4sr_embed_gather_posadd(const float* E, const float* P, const int64_t* idx, float* out,
+                              int64_t B, int32_t L, int32_t D, int32_t n_items, void* stream);
+
+/* K4: tied-embedding scorer + BCE on a DENSE query (basemodel.py:204-214, loss_func.py:9-38).
+ * query [B,L,D]; target, neg [B,L] int64.  Outputs (any may be NULL): pos/neg score [B,L] (pos is
+ * -inf where target==0), loss_pos [B,L] = per-position (-logsigmoid(pos)+softplus(neg)) or 0 at
+ * pads (UN-normalised), stats[0] = n_valid, stats[1] = loss sum (floats, accumulated: zero them). */
+int dr4sr_score_bce_fwd(const float* query, const float* E, const int64_t* target,
+                        const int64_t* neg, float* pos_score, float* neg_score, float* loss_pos,
+                        float* stats, int64_t B, int32_t L, int32_t D, void* stream);
+/* backward of the above with per-position upstream weight w[B,L] (NULL => 1) times *scale
+ * (device float, NULL => 1):  d_query [B,L,D] written, dE [N,D] accumulated (atomics). */
+int dr4sr_score_bce_bwd(const float* query, const float* E, const int64_t* target,
+                        const int64_t* neg, const float* w, const float* scale, float* d_query,
+                        float* dE, int64_t B, int32_t L, int32_t D, void* stream);
+
+/* K0: _neg_sampling (basemodel.py:50-61): uniform on 1..n_items-1 with replacement, never PAD.
+ * out [n] int64.  Stream (seed, step) is the one dr4sr_sasrec_fwd_bwd uses for sample_neg=1. */
+int dr4sr_neg_sample(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, uint32_t step,
+                     void* stream);
+
+/* Materialise the keep-mask (1.0 / 0.0) the kernels use for (seed, step, site) over n elements
+ * (n multiple of 4).  Test hook: lets the oracle run with the library's exact dropout masks. */
+int dr4sr_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint32_t step, uint32_t site,
+                       void* stream);
+
+/* BaseModel.topk (basemodel.py:354-365) for the single-domain case: scores = q @ E[:n_items]^T,
+ * column 0 (PAD) and every id in hist[b,:] set to -inf, top-k (k <= 128) by score, ties -> lower id.
+ * q [B,D], hist [B,Lh] int64, out_score [B,k] fp32, out_item [B,k] int64. */
+int dr4sr_full_score_topk(const float* q, const float* E, const int64_t* hist, float* out_score,
+                          int64_t* out_item, int64_t B, int32_t D, int32_t n_items, int32_t Lh,
+                          int32_t k, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DR4SR_HIP_H */
