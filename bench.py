@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py — training sequences/sec of the SASRec hot path (BASELINE.json metric) on N MI355X.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the reference's training iteration (model/basemodel.py:193-199) over one batch of
+B = 256 rows per GPU (configs/basemodel.yaml:2) of synthetic Amazon-toys-shaped data (N = 11 925 items,
+L = 50, d = 64, toys seqlen histogram): device-side batch selection, in-kernel negative sampling, SASRec
+forward with dropout 0.5, tied scorer + BCE, full backward, [sum-all-reduce of the flat gradient over RCCL
+when N > 1], dense Adam.  Inputs (dataset tensors + permutation) are resident in HBM before timing starts.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import ctypes as C  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def init_params_like_reference(eng, seed):
+    """utils/utils.py:70-81 normal_initialization (N(0,0.02) embeddings/linears, zero biases, LN (1,0), PAD row 0);
+    in_proj_weight keeps torch's xavier_uniform (it is a bare Parameter) and is identical in all layers."""
+    g = torch.Generator().manual_seed(seed)
+    D = eng.D
+    bound = (6.0 / (3 * D + D)) ** 0.5
+    in_proj = (torch.rand(3 * D, D, generator=g) * 2 - 1) * bound
+    sd = {}
+    for name, shp in zip(eng.names, eng.shapes):
+        if name.endswith("in_proj_weight"):
+            sd[name] = in_proj.clone()
+        elif name.endswith(("norm1.weight", "norm2.weight")):
+            sd[name] = torch.ones(shp)
+        elif name.endswith("bias"):
+            sd[name] = torch.zeros(shp)
+        else:
+            sd[name] = 0.02 * torch.randn(shp, generator=g)
+    sd["item_embedding.weight"][0] = 0
+    eng.load_named(sd)
+
+
+def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen):
+    """ALGORITHMIC flops of one launch on the packed batch: 2*M*N*K per GEMM over the T valid tokens."""
+    if kind in ("post_fwd", "post_bwd"):
+        return 2.0 * T * (D * D + 2 * D * F)
+    if kind in ("qkv_fwd", "qkv_bwd"):
+        return 2.0 * T * 3 * D * D
+    if kind == "wgrad":
+        return 2.0 * T * (4 * D * D + 2 * D * F) * n_layer
+    if kind in ("attn_fwd", "attn_bwd"):
+        pairs = float((seqlen * (seqlen + 1) // 2).sum())
+        return (2.0 if kind == "attn_fwd" else 5.0) * 2.0 * pairs * D      # QK^T + PV (fwd); +dP, dQ, dK, dV (bwd)
+    return 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=256, help="rows per GPU per step (configs/basemodel.yaml batch_size)")
+    ap.add_argument("--dense", action="store_true", help="all seqlen = 50 (worst case) instead of the toys histogram")
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dr4sr_amd import _lib
+    from dr4sr_amd.data.synthetic import TOYS_N_ITEMS, make_rows
+    from dr4sr_amd.engine import SasrecEngine
+    lib = _lib.load()
+
+    B, L, D, H, F, NL, N = args.batch, 50, 64, 2, 128, 2, TOYS_N_ITEMS
+    rows_np = make_rows(seed=2024, dense=args.dense)
+    U = rows_np["seqlen"].shape[0]
+    data = {k: torch.from_numpy(rows_np[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
+    eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023, lr=1e-3)
+    init_params_like_reference(eng, 2023)
+    perm = torch.from_numpy(np.random.default_rng(7).permutation(U)).to(dev)      # same permutation on every rank
+    rows_buf = torch.zeros(B, dtype=torch.int64, device=dev)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    negbuf = torch.zeros(B, L, dtype=torch.int64, device=dev)
+    plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+    stream = torch.cuda.Stream(device=dev)
+
+    def select():
+        _lib.check(lib.dr4sr_select_rows(_lib.ptr(perm), U, _lib.ptr(rows_buf), B, B * world, rank * B, _lib.ptr(counter),
+                                         _lib.cur_stream()), "select_rows")
+
+    def step_eager():
+        select()
+        if world == 1:
+            eng.train_step(plan)
+        else:
+            eng.fwd_bwd(plan)
+            dist.all_reduce(eng.grads)                 # sum over ranks: grads + {n_valid, loss_sum} tail
+            eng.adam_step(plan)
+
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            step_eager()
+        stream.synchronize()
+        use_graph = not args.no_graph
+        if use_graph and world == 1:
+            g_all = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_all, stream=stream):
+                select()
+                eng.train_step(plan)
+            run = g_all.replay
+        elif use_graph:
+            g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_a, stream=stream):
+                select()
+                eng.fwd_bwd(plan)
+            with torch.cuda.graph(g_b, stream=stream):
+                eng.adam_step(plan)
+
+            def run():
+                g_a.replay()
+                dist.all_reduce(eng.grads)
+                g_b.replay()
+        else:
+            run = step_eager
+
+        for _ in range(args.warmup):
+            run()
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        gpu_ms = e0.elapsed_time(e1)
+        if world > 1:
+            tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax)
+        loss, nvalid = eng.loss_and_count()
+        T_last = int(eng.state[_lib.STATE_T])
+
+        out = {
+            "metric": "training sequences/sec, SASRec d=64 L=50", "value": world * B * args.steps / wall,
+            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[1]): N=11925, L=50, d=64, "
+                                   "2 layers, 2 heads, FFN 128, dropout %.2f, B=%d rows/GPU/step, %s seqlen" %
+                                   (args.dropout, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
+                       "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(use_graph)},
+            "gpu_ms_per_step_events": gpu_ms / args.steps, "final_loss": loss, "valid_tokens_last_step": T_last,
+        }
+
+        if rank == 0:
+            # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
+            seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
+            kinds = ["embed_fwd", "qkv_fwd", "attn_fwd", "post_fwd", "score", "transpose", "post_bwd", "attn_bwd",
+                     "qkv_bwd", "embed_bwd", "wgrad", "zero_grads", "prep", "adam"]
+            per_step_launches = {"qkv_fwd": NL, "attn_fwd": NL, "post_fwd": NL, "post_bwd": NL, "attn_bwd": NL, "qkv_bwd": NL}
+            ktime = {}
+            reps = 50
+            for kind in kinds:
+                kid = _lib.KERNEL_IDS[kind]
+                for _ in range(5):
+                    _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+                b.record()
+                b.synchronize()
+                ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
+            step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
+            dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last) > 0), key=lambda k: step_us[k])
+            fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last)
+            ach = fl / (ktime[dom] * 1e-6) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "us_per_launch": ktime[dom],
+                               "flops_per_launch": fl}
+            out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
+
+            # ---- K1 gather microbench (HBM roofline of the embedding gather): large launch
+            ntok = args.gather_tokens
+            Bg = ntok // L
+            idx = torch.from_numpy(rows_np["in_item_id"]).to(dev)
+            reps_rows = (Bg + U - 1) // U
+            idx_big = idx.repeat(reps_rows, 1)[:Bg].contiguous()
+            idx_big = torch.where(idx_big == 0, torch.randint(1, N, idx_big.shape, device=dev), idx_big)
+            outbuf = torch.empty(Bg, L, D, device=dev)
+            E, P = eng.views["item_embedding.weight"], eng.views["query_encoder.position_emb.weight"]
+            for _ in range(3):
+                lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx_big), _lib.ptr(outbuf), Bg, L, D, N, _lib.cur_stream())
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx_big), _lib.ptr(outbuf), Bg, L, D, N, _lib.cur_stream())
+            b.record()
+            b.synchronize()
+            us = a.elapsed_time(b) * 1e3 / 10
+            gbytes = Bg * L * (8 + 8 * D) / 1e9
+            out["roofline_gather"] = {"kernel": "k_embed_dense<64>", "bound": "hbm", "achieved": gbytes / (us * 1e-6),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbytes / (us * 1e-6) / HBM_PEAK_GBS,
+                                      "traffic": None, "tokens": Bg * L, "us_per_launch": us,
+                                      "algorithmic_bytes_per_token": 8 + 8 * D}
+            del outbuf, idx_big
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.ref_trainer import time_training
+            r = time_training(rows_np, N, batch_size=256, warmup=3, max_steps=40, max_seconds=20.0, anomaly=True, p=args.dropout)
+            out["cpu_baseline"] = {"value": r["seq_per_s"], "unit": "sequences/s", "cores": r["threads"], "kind": "port",
+                                   "sample": "%d steps of B=256 (%.1f s) of oracle/ref_trainer.py: the reference's torch op "
+                                             "sequence (nn.TransformerEncoder, multinomial sampler, per-sample DataLoader, "
+                                             "Adam, anomaly detection ON as utils/utils.py:11) on the same synthetic rows; "
+                                             "host has %d logical CPUs" % (r["steps"], r["seconds"], os.cpu_count() or 0)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,9 @@ STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
 POOL_NONE, POOL_ORIGIN, POOL_LAST = 0, 1, 2
 SITE_EMB, SITE_ATTN, SITE_PROJ, SITE_ACT, SITE_FFN = 0, 1, 2, 3, 4
 
+KERNEL_IDS = {"prep": 0, "embed_fwd": 1, "qkv_fwd": 2, "attn_fwd": 3, "post_fwd": 4, "score": 5, "transpose": 6,
+              "post_bwd": 7, "attn_bwd": 8, "qkv_bwd": 9, "embed_bwd": 10, "wgrad": 11, "adam": 12, "zero_grads": 13}
+
 _f32p = C.c_void_p
 _i64p = C.c_void_p
 
@@ -47,6 +50,7 @@ _PLANP = C.POINTER(SasrecPlan)
 # name -> (restype, argtypes); every symbol include/dr4sr_hip.h declares
 SYMBOLS = {
     "dr4sr_abi_version": (C.c_int, []),
+    "dr4sr_sasrec_plan_sizeof": (C.c_int, []),
     "dr4sr_sasrec_param_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_workspace_bytes": (C.c_int64, [_PLANP]),
     "dr4sr_sasrec_fwd_bwd": (C.c_int, [_PLANP, C.c_void_p]),
@@ -54,11 +58,13 @@ SYMBOLS = {
     "dr4sr_sasrec_train_step": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_sasrec_encode": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_sasrec_encode_bwd": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
+    "dr4sr_select_rows": (C.c_int, [_i64p, C.c_int64, _i64p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "dr4sr_embed_gather_posadd": (C.c_int, [_f32p, _f32p, _i64p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_score_bce_fwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_score_bce_bwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_neg_sample": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p]),
     "dr4sr_dropout_mask": (C.c_int, [_f32p, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }
 
@@ -86,6 +92,8 @@ def load():
     v = lib.dr4sr_abi_version()
     if v != ABI_VERSION:
         raise Dr4srError(f"libdr4sr_hip.so ABI {v} != binding ABI {ABI_VERSION}")
+    if lib.dr4sr_sasrec_plan_sizeof() != C.sizeof(SasrecPlan):
+        raise Dr4srError("ctypes mirror of dr4sr_sasrec_plan does not match the compiled struct")
     _lib = lib
     return lib
 

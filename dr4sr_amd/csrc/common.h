@@ -177,10 +177,10 @@ __device__ __forceinline__ void ln_stats16(const float4 (&v)[NV], float& mean, f
 }
 
 // dynamic LDS above 64 KiB has to be opted into per kernel (gfx950 has 160 KiB per CU)
+void big_lds_impl(const void* kernel, size_t bytes);      // step.hip: remembers what was granted per kernel
 template <typename K>
 static inline void big_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (bytes > 48 * 1024) big_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 static inline int hip_ret(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

@@ -263,3 +263,21 @@ extern "C" int dr4sr_dropout_mask(float* out, int64_t n, float p, uint64_t seed,
     hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n / 4, p, seed, step, site);
     return DR4SR_LAUNCH_CHECK();
 }
+
+// ------------------------------------------------------------------------------------------------
+// a1 device-side batch selection: rows_out[i] = perm[(counter*stride + offset + i) mod n_perm]; counter++.
+// Replaces DataLoader(shuffle=True) + 256 x 7 __getitem__ + default_collate (data/dataset.py:105-108,
+// :149-164): the batch is never materialised, kernels index the resident dataset tensors via rows[].
+__global__ void k_select_rows(const int64_t* __restrict__ perm, int64_t n_perm, int64_t* __restrict__ rows_out, int B,
+                              int64_t stride, int64_t offset, int* __restrict__ counter) {
+    const int64_t c = *counter;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) rows_out[i] = perm[(c * stride + offset + i) % n_perm];
+    __syncthreads();
+    if (threadIdx.x == 0) *counter = (int)(c + 1);
+}
+extern "C" int dr4sr_select_rows(const int64_t* perm, int64_t n_perm, int64_t* rows_out, int32_t B, int64_t stride,
+                                 int64_t offset, int32_t* counter, void* stream) {
+    if (!perm || !rows_out || !counter || n_perm <= 0 || B <= 0) return DR4SR_E_ARG;
+    hipLaunchKernelGGL(k_select_rows, dim3(1), dim3(256), 0, (hipStream_t)stream, perm, n_perm, rows_out, B, stride, offset, counter);
+    return DR4SR_LAUNCH_CHECK();
+}

@@ -33,6 +33,9 @@ struct Workspace {
     float* dctx;                               // [T,D] scratch
     float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
     int64_t wT_stride;                         // floats per layer in wT
+    float* score_part;                         // [B][2]  per-sequence (count, loss sum) of the scorer
+    float* ln_part;                            // [n_layer][ntiles][4][D]  per-token-tile LayerNorm affine grad partials
+                                               //   rows: d ln2_w, d ln2_b, d ln1_w, d ln1_b
     LayerWs layer[DR4SR_MAX_LAYERS];
     int64_t bytes;
 };
@@ -54,7 +57,7 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s);
-int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s);
 
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);

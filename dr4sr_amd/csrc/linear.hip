@@ -12,6 +12,7 @@
 // (post-norm, gelu(erf), batch_first), called at model/sasrec.py:65-68.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -86,7 +87,7 @@ struct PostArgs {
     // backward
     const float* dz; const float* w2T; const float* w1T; const float* out_wT;
     float* du2; float* da; float* du1; float* dctx;
-    float* g_ln1_w; float* g_ln1_b; float* g_ln2_w; float* g_ln2_b;
+    float* ln_part;                            // this layer's [ntiles][4][D] LayerNorm affine partials
     const int* state; uint64_t seed; float p; float eps; int layer; int training;
 };
 
@@ -237,21 +238,25 @@ __device__ __forceinline__ void ln_bwd_row(float4 (&dzv)[NV], const float4 (&uv)
     }
 }
 
-// fold the 4 row-groups of a wave (lanes l16 + 16k) and add the wave's partial to global
-__device__ __forceinline__ void flush1(float v, float* dst) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if ((threadIdx.x & 63) < 16) unsafeAtomicAdd(dst, v);
-}
+// fold the 16 row-groups of the workgroup (4 per wave x 4 waves) into ONE partial row per token tile:
+// dst[0..D) = sum dgam, dst[D..2D) = sum dbet.  `scr` is a [4 waves][2*D] LDS scratch.  Deterministic, no atomics;
+// the tile partials are summed by k_wgrad's reduce job.
 template <int NV>
-__device__ __forceinline__ void flush_affine(const float4 (&dgam)[NV], const float4 (&dbet)[NV], float* g_w, float* g_b) {
-    const int l16 = threadIdx.x & 15;
+__device__ __forceinline__ void flush_affine(const float4 (&dgam)[NV], const float4 (&dbet)[NV], float* scr, float* dst) {
+    constexpr int D = 64 * NV;
+    const int l16 = threadIdx.x & 15, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = 4 * l16 + 64 * j;
-        flush1(dgam[j].x, g_w + c); flush1(dgam[j].y, g_w + c + 1); flush1(dgam[j].z, g_w + c + 2); flush1(dgam[j].w, g_w + c + 3);
-        flush1(dbet[j].x, g_b + c); flush1(dbet[j].y, g_b + c + 1); flush1(dbet[j].z, g_b + c + 2); flush1(dbet[j].w, g_b + c + 3);
+        const float4 a = make_float4(fold(dgam[j].x), fold(dgam[j].y), fold(dgam[j].z), fold(dgam[j].w));
+        const float4 b = make_float4(fold(dbet[j].x), fold(dbet[j].y), fold(dbet[j].z), fold(dbet[j].w));
+        if (lane < 16) { st4(scr + w * 2 * D + c, a); st4(scr + w * 2 * D + D + c, b); }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256)
+        dst[i] = (scr[i] + scr[2 * D + i]) + (scr[4 * D + i] + scr[6 * D + i]);
+    __syncthreads();
 }
 
 template <int D, int F>
@@ -305,8 +310,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
             }
         }
     }
-    flush_affine<NV>(dgam, dbet, A.g_ln2_w, A.g_ln2_b);
-    __syncthreads();
+    flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D);
     // ---- dh = df W2   (x W^T form with W2^T [F][D])
     {
         f32x16 acc[NVF];
@@ -372,8 +376,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
             }
         }   // rows >= T of R1 are already zero
     }
-    flush_affine<NV>(dgam, dbet, A.g_ln1_w, A.g_ln1_b);
-    __syncthreads();
+    flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D + 2 * D);
     // ---- dctx = do W_out
     {
         f32x16 acc[NV];
@@ -405,9 +408,7 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     const int D = p->D, F = p->F;
     A.out_wT = wT + 3 * D * D; A.w1T = wT + 4 * D * D; A.w2T = wT + 4 * D * D + D * F;
     A.du2 = lw.du2; A.da = lw.da; A.du1 = lw.du1; A.dctx = ws.dctx;
-    float* G = p->grads;
-    A.g_ln1_w = G + poff(ws, layer, P_LN1_W); A.g_ln1_b = G + poff(ws, layer, P_LN1_B);
-    A.g_ln2_w = G + poff(ws, layer, P_LN2_W); A.g_ln2_b = G + poff(ws, layer, P_LN2_B);
+    A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 63) / 64) * 4 * p->D;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
     return A;
 }
@@ -490,6 +491,9 @@ struct WgradJob {
 struct WgradArgs {
     WgradJob job[6 * DR4SR_MAX_LAYERS];
     const int* state; uint64_t seed; float p; int training;
+    // reduce jobs (blockIdx.y == 6): LayerNorm affine partials of every layer, scorer partials
+    const float* ln_part; int64_t ln_layer_stride; float* grads; int64_t o_ln1_w; int64_t layer_stride;   // ln1_w,ln1_b,ln2_w,ln2_b contiguous
+    const float* score_part; float* tail; int B; int D;
 };
 
 template <int NG, int KX>
@@ -571,17 +575,45 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
     }
 }
 
-// blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2), blockIdx.z = layer
+// sum per-token-tile LayerNorm partials [ntiles][4][D] (rows: ln2_w, ln2_b, ln1_w, ln1_b) into the flat gradient
+// (layout ln1_w | ln1_b | ln2_w | ln2_b), tiles strided over gridDim.x blocks; block (0, layer 0) also folds the
+// scorer's per-sequence (count, loss) partials into the gradient tail.
+__device__ __forceinline__ void reduce_jobs(const WgradArgs& A) {
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + 63) / 64, D = A.D, layer = blockIdx.z;
+    const float* part = A.ln_part + (size_t)layer * A.ln_layer_stride;
+    float* g = A.grads + A.o_ln1_w + (size_t)layer * A.layer_stride;
+    for (int c = threadIdx.x; c < 4 * D; c += 256) {
+        float s = 0.f;
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) s += part[(size_t)t * 4 * D + c];
+        const int dstc = c < 2 * D ? c + 2 * D : c - 2 * D;          // partial rows are (ln2, ln1); gradient is (ln1, ln2)
+        if (gridDim.x == 1) g[dstc] += s; else unsafeAtomicAdd(g + dstc, s);
+    }
+    if (blockIdx.x == 0 && layer == 0 && A.score_part) {
+        __shared__ float red[512];
+        float c = 0.f, l = 0.f;
+        for (int b = threadIdx.x; b < A.B; b += 256) { c += A.score_part[2 * b]; l += A.score_part[2 * b + 1]; }
+        red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { A.tail[0] += red[0]; A.tail[1] += red[256]; }
+    }
+}
+
+// blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2, 6: reductions), blockIdx.z = layer
 template <int D, int F>
 __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A) {
     const int j = blockIdx.y;
+    if (j == 6) { reduce_jobs(A); return; }
     const WgradJob& J = A.job[blockIdx.z * 6 + j];
     if (j < 4) wgrad_body<D, D>(J, A);
     else if (j == 4) wgrad_body<F, D>(J, A);
     else wgrad_body<D, F>(J, A);
 }
 
-int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s) {
     WgradArgs A;
     const int D = p->D, F = p->F;
     float* G = p->grads;
@@ -608,8 +640,12 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     }
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.training = training;
     const int ntiles = (ws.Tmax + 63) / 64;
-    int gw = ntiles < 24 ? ntiles : 24;
-    dim3 grid(gw, 6, p->n_layer), blk(256);
+    A.ln_part = ws.ln_part; A.ln_layer_stride = (int64_t)ntiles * 4 * D; A.grads = G;
+    A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
+    A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
+    static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 24;   // tuning knob
+    int gw = ntiles < gw_max ? ntiles : gw_max;
+    dim3 grid(gw, 7, p->n_layer), blk(256);
     const size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
     if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A); }
     else if (D == 128 && F == 128) { big_lds(k_wgrad<128, 128>, lds); hipLaunchKernelGGL((k_wgrad<128, 128>), grid, blk, lds, s, A); }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
                                                       float* __restrict__ dE, float* __restrict__ dZ,
                                                       const int64_t* __restrict__ target, const int64_t* __restrict__ rows,
                                                       const int* __restrict__ cu, int64_t* __restrict__ neg_item,
-                                                      int sample_neg, float* __restrict__ tail, const int* __restrict__ state,
+                                                      int sample_neg, float* __restrict__ part, const int* __restrict__ state,
                                                       uint64_t seed, int n_items, int B, int L) {
     constexpr int NV = D / 64;
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -91,16 +91,19 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
             }
         }
     }
-    if (lane == 0 && cnt > 0.f) {
-        unsafeAtomicAdd(tail + 0, cnt);
-        unsafeAtomicAdd(tail + 1, lsum);
+    __shared__ float red[8];
+    if (lane == 0) { red[2 * w] = cnt; red[2 * w + 1] = lsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                      // deterministic per-sequence partial; summed by k_wgrad's reduce job
+        part[2 * b] = (red[0] + red[2]) + (red[4] + red[6]);
+        part[2 * b + 1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
 }
 
 int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
     const float* E = p->params + ws.off[0];
     float* dE = p->grads + ws.off[0];
-    float* tail = p->grads + ws.n_params;
+    float* tail = ws.score_part;
     dim3 grid(p->B), blk(256);
     const float* Z = ws.X[p->n_layer];
     float* dZ = ws.dX[p->n_layer];

@@ -6,7 +6,21 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <mutex>
+#include <unordered_map>
+void big_lds_impl(const void* kernel, size_t bytes) {
+    static std::unordered_map<const void*, size_t> granted;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& g = granted[kernel];
+    if (bytes > g) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        g = bytes;
+    }
+}
+
 extern "C" int dr4sr_abi_version(void) { return DR4SR_ABI_VERSION; }
+extern "C" int dr4sr_sasrec_plan_sizeof(void) { return (int)sizeof(dr4sr_sasrec_plan); }
 
 extern "C" int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
                                              int64_t* off) {
@@ -52,6 +66,8 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->dctx = take(Tmax * D);
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
+    ws->score_part = take(2LL * p->B);
+    ws->ln_part = take((int64_t)p->n_layer * ((Tmax + 63) / 64) * 4 * D);
     for (int l = 0; l < p->n_layer; ++l) {
         LayerWs& w = ws->layer[l];
         w.qkv = take(Tmax * 3 * D); w.ctx = take(Tmax * D);
@@ -90,12 +106,17 @@ static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M,
                                               float* __restrict__ V, int64_t n, int* __restrict__ state, float lr, float b1,
                                               float b2, float eps, float wd) {
+    __shared__ float sh[2];
     const int t = state[DR4SR_STATE_STEP] + 1;
+    if (threadIdx.x == 0) {               // double-precision bias corrections, once per block
+        const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+        sh[0] = (float)((double)lr / bc1);
+        sh[1] = (float)(1.0 / sqrt(bc2));
+    }
+    __syncthreads();
+    const float step_size = sh[0], inv_sqrt_bc2 = sh[1];
     const float nvalid = G[n];
     const float gs = nvalid > 0.f ? 1.0f / nvalid : 0.f;
-    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 p = ld4(P + 4 * i), m = ld4(M + 4 * i), v = ld4(V + 4 * i);
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float
 int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s) {
     if (!p->grads || !p->adam_m || !p->adam_v || p->n_params <= 0 || (p->n_params & 3)) return DR4SR_E_ARG;
     int64_t blocks = (p->n_params / 4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, p->params, p->grads, p->adam_m, p->adam_v, p->n_params,
                        p->state, p->lr, p->beta1, p->beta2, p->adam_eps, p->weight_decay);
     return DR4SR_LAUNCH_CHECK();
@@ -130,6 +151,20 @@ int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s) {
 extern "C" int dr4sr_adam_step(const dr4sr_sasrec_plan* plan, void* stream) {
     if (!plan || plan->abi_version != DR4SR_ABI_VERSION || !plan->params || !plan->state) return DR4SR_E_ARG;
     return launch_adam(plan, (hipStream_t)stream);
+}
+
+// zero the flat gradient (+tail) with our own kernel: a hipMemsetAsync node captured into a hipGraph was observed
+// (ROCm 7.2) to fill the last 16 bytes with a stale pattern on later replays, which poisons n_valid.
+__global__ __launch_bounds__(256) void k_zero(float* __restrict__ p, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        st4(p + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+static int launch_zero_grads(const dr4sr_sasrec_plan* p, int64_t n_params, hipStream_t s) {
+    const int64_t n4 = (n_params + DR4SR_GRAD_TAIL) / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_zero, dim3((unsigned)blocks), dim3(256), 0, s, p->grads, n4);
+    return DR4SR_LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,7 +180,7 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
     return 0;
 }
 
-static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s) {
     RC(launch_transpose_weights(p, ws, s));
     for (int l = p->n_layer - 1; l >= 0; --l) {
         RC(launch_post_bwd(p, ws, l, training, s));
@@ -153,7 +188,7 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
         RC(launch_qkv_bwd(p, ws, l, s));
     }
     RC(launch_embed_bwd(p, ws, training, s));
-    RC(launch_wgrad(p, ws, training, s));
+    RC(launch_wgrad(p, ws, training, with_score, s));
     return 0;
 }
 
@@ -162,11 +197,11 @@ extern "C" int dr4sr_sasrec_fwd_bwd(const dr4sr_sasrec_plan* plan, void* stream)
     RC(get_ws(plan, &ws));
     if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    RC(hip_ret(hipMemsetAsync(plan->grads, 0, sizeof(float) * (ws.n_params + DR4SR_GRAD_TAIL), s)));
+    RC(launch_zero_grads(plan, ws.n_params, s));
     RC(launch_prep(plan, ws, 1, s));
     RC(forward_layers(plan, ws, 1, s));
     RC(launch_score_packed(plan, ws, s));
-    RC(backward_layers(plan, ws, 1, s));
+    RC(backward_layers(plan, ws, 1, 1, s));
     return 0;
 }
 
@@ -193,5 +228,32 @@ extern "C" int dr4sr_sasrec_encode_bwd(const dr4sr_sasrec_plan* plan, int32_t tr
     if (!d_out || !plan->grads || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     RC(launch_pack(plan, ws, d_out, ws.dX[plan->n_layer], pooling == DR4SR_POOL_LAST, s));
-    return backward_layers(plan, ws, training, s);
+    return backward_layers(plan, ws, training, 0, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Measurement hook (bench.py / profiles): enqueue ONE kernel of the step so that its launch duration can
+// be bracketed with HIP events on the caller's stream.  Uses whatever the last fwd_bwd left in the workspace.
+extern "C" int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, int32_t layer, void* stream) {
+    Workspace ws;
+    RC(get_ws(plan, &ws));
+    if (layer < 0 || layer >= plan->n_layer) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (kernel) {
+        case DR4SR_K_PREP: return launch_prep(plan, ws, 0, s);
+        case DR4SR_K_EMBED_FWD: return launch_embed_fwd(plan, ws, 1, s);
+        case DR4SR_K_QKV_FWD: return launch_qkv_fwd(plan, ws, layer, s);
+        case DR4SR_K_ATTN_FWD: return launch_attn_fwd(plan, ws, layer, 1, s);
+        case DR4SR_K_POST_FWD: return launch_post_fwd(plan, ws, layer, 1, s);
+        case DR4SR_K_SCORE: return launch_score_packed(plan, ws, s);
+        case DR4SR_K_TRANSPOSE: return launch_transpose_weights(plan, ws, s);
+        case DR4SR_K_POST_BWD: return launch_post_bwd(plan, ws, layer, 1, s);
+        case DR4SR_K_ATTN_BWD: return launch_attn_bwd(plan, ws, layer, 1, s);
+        case DR4SR_K_QKV_BWD: return launch_qkv_bwd(plan, ws, layer, s);
+        case DR4SR_K_EMBED_BWD: return launch_embed_bwd(plan, ws, 1, s);
+        case DR4SR_K_WGRAD: return launch_wgrad(plan, ws, 1, 1, s);
+        case DR4SR_K_ADAM: return launch_adam(plan, s);
+        case DR4SR_K_ZERO_GRADS: return launch_zero_grads(plan, ws.n_params, s);
+        default: return DR4SR_E_ARG;
+    }
 }

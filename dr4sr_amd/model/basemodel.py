@@ -1,0 +1,365 @@
+"""RecStudio-style trainer with the interface of the reference's model/basemodel.py (BaseModel :19-407), driving the
+HIP engine instead of torch ops.  Same public surface: fit / evaluate / forward / training_step / _neg_sampling /
+topk / _init_model / set_eval_domain / load_checkpoint, attrs item_embedding, optimizer, device, fiid, fuid, config,
+logged_metrics, ckpt_path.
+
+Two execution paths, numerically the same kernels:
+  * API path  — forward() / training_step() return tensors wired into torch.autograd (custom Functions around the
+                C ABI); loss.backward() fills p.grad (views of the flat gradient); optimizer.step() is the fused Adam.
+  * fast path — training_epoch() replays one captured HIP graph per batch (batch selection, negative sampling,
+                forward, scorer+BCE, backward, [RCCL all-reduce], Adam) with no host work in between.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+import time
+from collections import defaultdict
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, evaluation
+from ..data.dataset import BaseDataset, SeparateDataset, SyntheticDataset
+from ..utils import callbacks
+from .loss_func import BinaryCrossEntropyLoss, BPRLoss
+
+
+def normal_initialization(module, initial_range=0.02):
+    """utils/utils.py:70-81 of the reference: N(0, 0.02) for Embedding/Linear, PAD row zero, LayerNorm (1, 0)."""
+    if isinstance(module, nn.Embedding):
+        module.weight.data.normal_(mean=0.0, std=initial_range)
+        if module.padding_idx is not None:
+            module.weight.data[module.padding_idx].zero_()
+    elif isinstance(module, nn.Linear):
+        module.weight.data.normal_(mean=0.0, std=initial_range)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+
+
+class FusedAdam:
+    """optimizer facade over dr4sr_adam_step (torch.optim.Adam semantics, dense, flat buffers)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.param_groups = [{"lr": model.engine.lr, "weight_decay": model.engine.weight_decay}]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.engine.grads.zero_()
+
+    def step(self):
+        eng = self.model.engine
+        eng.grads[eng.n_params] = 1.0                 # API path: the loss is already normalised
+        eng.adam_step(self.model._api_plan())
+
+    def state_dict(self):
+        eng = self.model.engine
+        return {"step": int(eng.state[_lib.STATE_STEP]), "exp_avg": eng.adam_m.clone(), "exp_avg_sq": eng.adam_v.clone()}
+
+
+class _ScoreBCE(torch.autograd.Function):
+    """basemodel.py:204-214 + loss_func.py:9-38 on the dense query through dr4sr_score_bce_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, model, query, table, target, neg, reduce):
+        lib, eng = model.engine.lib, model.engine
+        B = target.shape[0]
+        L = target.shape[1] if target.dim() == 2 else 1
+        q = query.contiguous()
+        tgt, ng = target.contiguous().view(-1), neg.contiguous().view(-1)
+        lp = torch.empty(B * L, dtype=torch.float32, device=q.device)
+        stats = torch.zeros(2, dtype=torch.float32, device=q.device)
+        _lib.check(lib.dr4sr_score_bce_fwd(_lib.ptr(q), _lib.ptr(table), _lib.ptr(tgt), _lib.ptr(ng), None, None,
+                                           _lib.ptr(lp), _lib.ptr(stats), B, L, eng.D, _lib.cur_stream()), "score_bce_fwd")
+        ctx.model, ctx.reduce, ctx.shape = model, reduce, (B, L)
+        ctx.save_for_backward(q, table, tgt, ng, stats)
+        if reduce:
+            return stats[1] / stats[0]
+        return (lp / stats[0]).view(target.shape)
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, table, tgt, ng, stats = ctx.saved_tensors
+        model = ctx.model
+        lib, eng = model.engine.lib, model.engine
+        B, L = ctx.shape
+        dq = torch.empty_like(q)
+        if ctx.reduce:
+            w, scale = None, (gout.reshape(1) / stats[0]).contiguous()
+        else:
+            w, scale = gout.contiguous().view(-1).float(), (1.0 / stats[0]).reshape(1).contiguous()
+        dE = eng.grad_views["item_embedding.weight"]
+        _lib.check(lib.dr4sr_score_bce_bwd(_lib.ptr(q), _lib.ptr(table), _lib.ptr(tgt), _lib.ptr(ng), _lib.ptr(w),
+                                           _lib.ptr(scale), _lib.ptr(dq), _lib.ptr(dE), B, L, eng.D, _lib.cur_stream()),
+                   "score_bce_bwd")
+        return None, dq, None, None, None, None
+
+
+class BaseModel(nn.Module):
+    def __init__(self, config: Dict, dataset_list: List[BaseDataset]) -> None:
+        super().__init__()
+        self.config = config
+        self.ckpt_path = None
+        self.logger = logging.getLogger("CDR")
+        self.dataset_list = dataset_list
+        self.device = config["train"]["device"]
+        self.fuid, self.fiid = "user_id", "item_id"
+        self.domain_name_list = dataset_list[0].domain_name_list
+        self.domain_user_mapping = dataset_list[0].domain_user_mapping
+        self.domain_item_mapping = dataset_list[0].domain_item_mapping
+        self.training_time = 0
+        self.inference_time = 0
+        self.embed_dim = config["model"]["embed_dim"]
+        self.max_seq_len = config["data"]["max_seq_len"]
+        self.num_users = dataset_list[0].num_users
+        self.num_items = dataset_list[0].num_items
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.engine = None                       # set by the subclass (owns item_embedding's storage)
+        self._graphs = {}
+
+    # ------------------------------------------------------------------------------------------ setup
+    @staticmethod
+    def _get_dataset_class(config):
+        kind = config["data"]["dataset_class"]
+        if kind == "general":
+            return SeparateDataset
+        if kind == "synthetic":
+            return SyntheticDataset
+        raise NotImplementedError(f"dataset_class '{kind}': only 'general' (SeparateDataset) is on the hot path")
+
+    def _init_model(self, train_data):
+        self.apply(normal_initialization)
+        self._sync_replicas()
+        self.optimizer = self._get_optimizers()
+        self.loss_fn = self._get_loss_func()
+
+    def _sync_replicas(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(self.engine.params, src=0)
+
+    def _get_optimizers(self):
+        name = self.config["train"]["optimizer"].lower()
+        if name != "adam":
+            raise NotImplementedError(f"optimizer '{name}': the HIP path implements the shipped configs' Adam only")
+        eng = self.engine
+        eng.lr = float(self.config["train"]["learning_rate"])
+        eng.weight_decay = float(self.config["train"]["weight_decay"])
+        return FusedAdam(self)
+
+    def _get_loss_func(self):
+        name = self.config["model"]["loss_fn"]
+        if name == "bce":
+            return BinaryCrossEntropyLoss()
+        if name == "bpr":
+            return BPRLoss()
+
+    # ------------------------------------------------------------------------------------------ sampling / steps
+    def _neg_sampling(self, batch):
+        """uniform over 1..N-1 with replacement, never PAD; [B,L,1] for 2-D targets else [B,1] (basemodel.py:50-61)"""
+        tgt = batch[self.fiid]
+        n = tgt.numel()
+        out = torch.empty(n, dtype=torch.int64, device=tgt.device)
+        eng = self.engine
+        self._neg_calls = getattr(self, "_neg_calls", 0) + 1
+        _lib.check(eng.lib.dr4sr_neg_sample(_lib.ptr(out), n, self.num_items, eng.seed ^ 0x5DEECE66D, self._neg_calls,
+                                            _lib.cur_stream()), "neg_sample")
+        return out.view(*tgt.shape, 1)
+
+    def forward(self, batch, need_pooling=True):
+        raise NotImplementedError
+
+    def _api_plan(self):
+        raise NotImplementedError
+
+    def training_step(self, batch, reduce=True, return_query=False):
+        if not isinstance(self.loss_fn, BinaryCrossEntropyLoss):
+            raise TypeError("BPRLoss.forward() got an unexpected keyword argument 'reduce'")   # as the reference would
+        query = self.forward(batch)
+        loss = _ScoreBCE.apply(self, query, self.item_embedding.weight, batch[self.fiid], batch["neg_item"], reduce)
+        return (loss, query) if return_query else loss
+
+    # ------------------------------------------------------------------------------------------ fit
+    def fit(self):
+        self.callback = callbacks.EarlyStopping(self, "ndcg@20", self.config["data"]["dataset"],
+                                                patience=self.config["train"]["early_stop_patience"])
+        self.logger.info("save_dir:" + self.callback.save_dir)
+        self._init_model(self.dataset_list[0])
+        self.logger.info(self)
+        self.fit_loop()
+
+    def fit_loop(self):
+        nepoch = 0
+        try:
+            self.train_start()
+            for _ in range(self.config["train"]["epochs"]):
+                self.logged_metrics = {"epoch": nepoch}
+                tik = time.time()
+                self.train()
+                training_output_list = self.training_epoch(nepoch)
+                torch.cuda.synchronize()
+                self.training_time += time.time() - tik
+
+                tik = time.time()
+                self.eval()
+                for domain in self.domain_name_list:
+                    val_dataset = self.dataset_list[1]
+                    val_dataset.set_eval_domain(domain)
+                    self.set_eval_domain(domain)
+                    outs = self.validation_epoch(nepoch, val_dataset.get_loader())
+                    self.validation_epoch_end(outs, domain)
+                summed = defaultdict(float)
+                for k, v in self.logged_metrics.items():
+                    for dn in self.domain_name_list:
+                        if dn in k:
+                            summed[k.removeprefix(dn + "_")] += v
+                            break
+                self.logged_metrics.update(summed)
+                self.inference_time += time.time() - tik
+
+                self.training_epoch_end(training_output_list)
+                if self.callback(self, nepoch, self.logged_metrics):
+                    break
+                nepoch += 1
+            self.training_end()
+            self.callback.save_checkpoint(nepoch)
+            self.ckpt_path = self.callback.get_checkpoint_path()
+        except KeyboardInterrupt:
+            self.callback.save_checkpoint(nepoch)
+            self.ckpt_path = self.callback.get_checkpoint_path()
+
+    def current_epoch_trainloaders(self, nepoch):
+        return self.dataset_list[0].get_loader()
+
+    def train_start(self):
+        pass
+
+    def training_end(self):
+        pass
+
+    def _fast_path_ok(self) -> bool:
+        return (type(self).training_step is not None and getattr(self, "_fused_epoch", None) is not None
+                and isinstance(getattr(self, "loss_fn", None), BinaryCrossEntropyLoss)
+                and not os.environ.get("DR4SR_NO_FAST_PATH"))
+
+    def training_epoch(self, nepoch):
+        loader = self.current_epoch_trainloaders(nepoch)
+        if self._fast_path_ok():
+            return [self._fused_epoch(loader)]
+        outputs = []
+        for batch in loader:                                        # API path (reference loop, basemodel.py:192-200)
+            batch["neg_item"] = self._neg_sampling(batch)
+            self.optimizer.zero_grad()
+            loss = self.training_step(batch=batch)
+            loss.backward()
+            self.optimizer.step()
+            outputs.append({"loss_0": loss.detach()})
+        return [outputs]
+
+    def training_epoch_end(self, output_list):
+        output_list = output_list if isinstance(output_list, list) else [output_list]
+        for outputs in output_list:
+            if isinstance(outputs, list):
+                metric = {"train_" + k: torch.hstack([e[k] for e in outputs]).mean() for k in outputs[0]}
+            elif isinstance(outputs, torch.Tensor):
+                metric = {"train_loss": outputs.item()}
+            else:
+                metric = {"train_" + k: v for k, v in outputs.items()}
+            self.logged_metrics.update(metric)
+        self.logger.info(self.logged_metrics)
+        self.logger.info(f"training_time: {self.training_time}")
+        self.logger.info(f"inference_time: {self.inference_time}")
+
+    # ------------------------------------------------------------------------------------------ eval
+    @torch.no_grad()
+    def validation_epoch(self, nepoch, dataloader):
+        return [self.validation_step(batch) for batch in dataloader]
+
+    @torch.no_grad()
+    def test_epoch(self, dataloader):
+        return [self.test_step(batch) for batch in dataloader]
+
+    def _epoch_end(self, outputs, metric_names):
+        metric_list, bs = zip(*outputs)
+        bs = torch.tensor(bs, dtype=torch.float32)
+        out = {}
+        for k in metric_list[0]:
+            vals = torch.stack([m[k].float().cpu() for m in metric_list])
+            out[k] = float((vals * bs).sum() / bs.sum())           # batch-size-weighted mean (basemodel.py:316-324)
+        return out
+
+    def validation_epoch_end(self, outputs, domain):
+        names = evaluation.get_eval_metrics(self.config["eval"]["val_metrics"], self.config["eval"]["cutoff"], validation=True)
+        out = {domain + "_" + k: v for k, v in self._epoch_end(outputs, names).items()}
+        self.logged_metrics.update(out)
+        return out
+
+    def test_epoch_end(self, outputs, domain):
+        names = evaluation.get_eval_metrics(self.config["eval"]["test_metrics"], self.config["eval"]["cutoff"], validation=False)
+        out = {domain + "_" + k: v for k, v in self._epoch_end(outputs, names).items()}
+        self.logged_metrics.update(out)
+        return out
+
+    def validation_step(self, batch):
+        return self._test_step(batch, self.config["eval"]["val_metrics"], [self.config["eval"]["cutoff"][0]])
+
+    def test_step(self, batch):
+        return self._test_step(batch, self.config["eval"]["test_metrics"], self.config["eval"]["cutoff"])
+
+    def _test_step(self, batch, metric, cutoffs):
+        rank_m = evaluation.get_rank_metrics(metric)
+        assert len(rank_m) > 0
+        bs = batch["user_id"].size(0)
+        _, topk_items = self.topk(batch, self.config["eval"]["topk"], batch["user_hist"])
+        label = batch[self.fiid].view(-1, 1) == topk_items
+        pos_rating = batch["label"].view(-1, 1)
+        return {f"{name}@{c}": fn(label, pos_rating, c) for c in cutoffs for name, fn in rank_m}, bs
+
+    def topk(self, batch, k, user_h=None):
+        """full-item scores with PAD + history masked, top-k — basemodel.py:354-365 via dr4sr_full_score_topk"""
+        items = self.domain_item_mapping[self.eval_domain]
+        if len(items) != self.num_items - 1:
+            raise NotImplementedError("multi-domain item masks are outside the HIP hot path (single-domain configs only)")
+        query = self.forward(batch).contiguous()
+        B = query.shape[0]
+        hist = user_h.contiguous() if user_h is not None else None
+        score = torch.empty(B, k, dtype=torch.float32, device=query.device)
+        ids = torch.empty(B, k, dtype=torch.int64, device=query.device)
+        eng = self.engine
+        _lib.check(eng.lib.dr4sr_full_score_topk(_lib.ptr(query), _lib.ptr(self.item_embedding.weight), _lib.ptr(hist),
+                                                 _lib.ptr(score), _lib.ptr(ids), B, eng.D, self.num_items,
+                                                 hist.shape[1] if hist is not None else 0, k, _lib.cur_stream()), "topk")
+        return score, ids
+
+    def set_eval_domain(self, domain):
+        self.eval_domain = domain
+
+    def evaluate(self) -> Dict:
+        test_data = self.dataset_list[-1]
+        output = defaultdict(float)
+        self.load_checkpoint(os.path.join(self.config["eval"]["save_path"], self.ckpt_path))
+        self.eval()
+        for domain in self.domain_name_list:
+            test_data.set_eval_domain(domain)
+            self.set_eval_domain(domain)
+            output.update(self.test_epoch_end(self.test_epoch(test_data.get_loader()), domain))
+        summed = defaultdict(float)
+        for k, v in output.items():
+            for dn in self.domain_name_list:
+                if dn in k:
+                    summed[k.removeprefix(dn + "_")] += v
+        output.update(summed)
+        self.logger.info(dict(output))
+        self.logger.info({"training_time": self.training_time, "inference_time": self.inference_time})
+        return dict(output)
+
+    def load_checkpoint(self, path: str) -> None:
+        ckpt = torch.load(path, weights_only=False, map_location=self.device)
+        self.config = ckpt["config"]
+        self.load_state_dict(ckpt["parameters"])

@@ -95,6 +95,7 @@ typedef struct dr4sr_sasrec_plan {
 
 /* -------------------------------------------------------------------------------------------- */
 int  dr4sr_abi_version(void);
+int  dr4sr_sasrec_plan_sizeof(void);   /* sizeof(dr4sr_sasrec_plan) as compiled: lets a binding verify its struct mirror */
 /* Fills offsets[0]=E, [1]=P, [2+12*i+j] = j-th tensor of layer i (order above); returns n_params. */
 int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
                                   int64_t* offsets /* [2+12*n_layer] or NULL */);
@@ -124,6 +125,13 @@ int dr4sr_sasrec_encode(const dr4sr_sasrec_plan* plan, int32_t training, int32_t
  * into plan->grads (exactly d_out-weighted, no normalisation). */
 int dr4sr_sasrec_encode_bwd(const dr4sr_sasrec_plan* plan, int32_t training, int32_t pooling,
                             const float* d_out, void* stream);
+
+/* a1: device-side batch selection replacing DataLoader(shuffle=True) + per-sample __getitem__ +
+ * default_collate (data/dataset.py:105-108, :149-164).  rows_out[i] = perm[(c*stride + offset + i)
+ * mod n_perm] for i < B where c = *counter (device int32), then *counter = c + 1.  With
+ * stride = global batch and offset = rank*B every rank walks its own slice of one permutation. */
+int dr4sr_select_rows(const int64_t* perm, int64_t n_perm, int64_t* rows_out, int32_t B,
+                      int64_t stride, int64_t offset, int32_t* counter, void* stream);
 
 /* K1: item_encoder(idx) + position_emb(arange(L))  (sasrec.py:43-46, :64) for ALL B*L positions,
  * bit-exact with torch (gather + one IEEE add).  out [B,L,D]. */
@@ -159,6 +167,24 @@ int dr4sr_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint32_t s
 int dr4sr_full_score_topk(const float* q, const float* E, const int64_t* hist, float* out_score,
                           int64_t* out_item, int64_t B, int32_t D, int32_t n_items, int32_t Lh,
                           int32_t k, void* stream);
+
+/* Measurement hook: enqueue ONE kernel of the training step (on the state the last fwd_bwd left in
+ * the workspace) so bench.py can bracket it with HIP events.  Not part of the reference surface. */
+#define DR4SR_K_PREP       0
+#define DR4SR_K_EMBED_FWD  1
+#define DR4SR_K_QKV_FWD    2
+#define DR4SR_K_ATTN_FWD   3
+#define DR4SR_K_POST_FWD   4
+#define DR4SR_K_SCORE      5
+#define DR4SR_K_TRANSPOSE  6
+#define DR4SR_K_POST_BWD   7
+#define DR4SR_K_ATTN_BWD   8
+#define DR4SR_K_QKV_BWD    9
+#define DR4SR_K_EMBED_BWD  10
+#define DR4SR_K_WGRAD      11
+#define DR4SR_K_ADAM       12
+#define DR4SR_K_ZERO_GRADS 13
+int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, int32_t layer, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,139 @@
+"""GPU tests of the drop-in surface: dr4sr_amd.model.sasrec.SASRec behind the reference's BaseModel protocol."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sasrec_oracle as O  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_config(dropout=0.0, n_rows=600, n_items=300, batch=64, epochs=2):
+    return {
+        "data": {"dataset": "synthetic-toys", "domain_name_list": ["toy"], "max_seq_len": 50, "dataset_class": "synthetic",
+                 "train_file": "", "n_items": n_items, "n_rows": n_rows, "n_eval_rows": 128, "seed": 5},
+        "model": {"model": "SASRec", "embed_dim": 64, "loss_fn": "bce", "hidden_size": 128, "layer_num": 2, "head_num": 2,
+                  "dropout_rate": dropout, "activation": "gelu", "layer_norm_eps": 1e-12},
+        "train": {"batch_size": batch, "early_stop_mode": "max", "early_stop_patience": 20, "epochs": epochs, "device": "cuda",
+                  "optimizer": "adam", "learning_rate": 0.001, "weight_decay": 0, "num_neg": 1, "seed": 2023, "hip_graph": True},
+        "eval": {"batch_size": 128, "cutoff": [20, 10], "val_metrics": ["ndcg", "recall"], "test_metrics": ["ndcg", "recall"],
+                 "topk": 100, "save_path": "./saved/"},
+    }
+
+
+def build(config):
+    from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
+    seed_everything(config["train"]["seed"])
+    ds = prepare_datasets(config)
+    model = prepare_model(config, ds)
+    return ds, model
+
+
+def test_state_dict_names_and_golden_checkpoint_loads(golden_dir):
+    z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
+    cfg = make_config(n_items=int(z["meta.num_items"]))
+    ds, model = build(cfg)
+    ref = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    assert set(model.state_dict()) == set(ref)
+    model.load_state_dict(ref, strict=True)
+    assert model.item_embedding.weight.data_ptr() == model.query_encoder.item_encoder.weight.data_ptr()   # tied table
+    # the API forward reproduces the reference's query and eval rows
+    batch = {k[6:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("batch.")}
+    model.train()
+    q = model.forward(batch)
+    assert float((q.cpu() - torch.from_numpy(z["out.query"])).abs().max()) < 2e-4 * float(np.abs(z["out.query"]).max())
+    model.eval()
+    ev = {k[5:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("eval.") and k[5:] in
+          ("in_item_id", "seqlen", "item_id", "user_hist", "user_id", "label")}
+    model.set_eval_domain("toy")
+    with torch.no_grad():
+        score, items = model.topk(ev, 20, ev["user_hist"])
+    assert (items.cpu().numpy() == z["eval.topk_items"]).mean() > 0.99
+    np.testing.assert_allclose(score.cpu().numpy(), z["eval.topk_score"], rtol=2e-4, atol=2e-5)
+
+
+def test_api_training_step_backward_and_optimizer_match_reference(golden_dir):
+    """loss = model.training_step(batch); loss.backward(); optimizer.step()  ==  the reference's numbers"""
+    z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
+    cfg = make_config(n_items=int(z["meta.num_items"]))
+    ds, model = build(cfg)
+    model._init_model(ds[0])
+    model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")})
+    batch = {k[6:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("batch.")}
+    model.train()
+    model.optimizer.zero_grad()
+    loss, query = model.training_step(batch, reduce=True, return_query=True)
+    loss.backward()
+    assert abs(float(loss) - float(z["out.loss"])) < 2e-6
+    for n, p in model.named_parameters():
+        ref = z["grad." + n]
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) < 2e-4 * max(1e-8, float(np.abs(ref).max())), n
+    with torch.no_grad():
+        lnr = model.training_step(batch, reduce=False)
+    np.testing.assert_allclose(lnr.cpu().numpy(), z["out.loss_noreduce"], rtol=2e-4, atol=1e-7)
+    model.optimizer.step()
+    for n, p in model.named_parameters():
+        well = np.abs(z["grad." + n]) > 1e-5
+        d = p.detach().cpu().numpy() - z["adam1." + n]
+        assert np.abs(d[well]).max(initial=0) < 5e-6 and np.abs(d).max() < 2e-4, n
+    neg = model._neg_sampling(batch)
+    assert neg.shape == batch["neg_item"].shape and int(neg.min()) >= 1 and int(neg.max()) < model.num_items
+
+
+def test_fast_path_epoch_equals_api_path_step(golden_dir):
+    """one fused-graph step == one API-path step on the same rows and the same negatives (dropout 0)"""
+    cfg = make_config(dropout=0.0, n_rows=64, batch=64)
+    ds, ma = build(cfg)
+    ma._init_model(ds[0])
+    _, mb = build(copy.deepcopy(cfg))
+    mb._init_model(ds[0])
+    mb.load_state_dict(ma.state_dict())
+    loader = ds[0].get_loader(shuffle=False)
+    ma.train()
+    out = ma._fused_epoch(loader)                      # 1 batch of 64 rows, negatives drawn in-kernel
+    neg = ma._neg_buf.view(64, 50, 1).clone()
+    batch = next(iter(loader))
+    batch["neg_item"] = neg
+    mb.train()
+    mb.optimizer.zero_grad()
+    loss = mb.training_step(batch)
+    loss.backward()
+    mb.optimizer.step()
+    assert abs(float(out[0]["loss_0"][0]) - float(loss)) < 2e-6
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        d = (pa - pb).abs()           # Adam's first step is lr*g/(|g|+eps): elements with |g| ~ eps amplify fp32 atomic-order noise
+        assert float(d.max()) < 2e-4 and float(d.mean()) < 2e-7, n
+
+
+def test_fit_and_evaluate_end_to_end(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    from dr4sr_amd import quickstart
+    cfg = make_config(dropout=0.2, n_rows=1500, n_items=200, batch=128, epochs=4)
+    out = quickstart.run(cfg)
+    assert {"ndcg@20", "recall@20", "ndcg@10", "recall@10", "toy_ndcg@20"} <= set(out)
+    assert all(np.isfinite(v) for v in out.values())
+    logs = [os.path.join(dp, f) for dp, _, fs in os.walk("log") for f in fs]
+    ckpts = [os.path.join(dp, f) for dp, _, fs in os.walk("saved") for f in fs]
+    assert len(logs) == 1 and len(ckpts) == 1 and ckpts[0].startswith("saved/SASRec/synthetic-toys/")
+    ck = torch.load(ckpts[0], weights_only=False)
+    assert set(ck) == {"config", "model", "epoch", "parameters", "metric"} and "ndcg@20" in ck["metric"]
+    text = open(logs[0]).read()
+    losses = [float(x) for x in __import__("re").findall(r"'train_loss_0': tensor\(([0-9.]+)", text)]
+    assert len(losses) == 4 and losses[-1] < losses[0]            # it learns
+
+
+def test_last_partial_batch_and_graph_cache(tmp_path):
+    cfg = make_config(dropout=0.5, n_rows=150, batch=64, epochs=1)
+    ds, model = build(cfg)
+    model._init_model(ds[0])
+    model.train()
+    for _ in range(2):
+        out = model._fused_epoch(ds[0].get_loader())
+        assert out[0]["loss_0"].shape == (3,) and torch.isfinite(out[0]["loss_0"]).all()    # 64 + 64 + 22
+    assert len(model._graphs) == 2                                 # one graph per distinct batch length, reused
+    assert int(model.engine.state[0]) == 6

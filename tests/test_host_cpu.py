@@ -1,0 +1,221 @@
+"""CPU tests of the host-side logic (no GPU): config merge, dataset row format, batch loader, metrics, early
+stopping, C-ABI symbol export, parameter layout, and the data-parallel math over gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "dr4sr_hip.h")).read()
+    declared = set(re.findall(r"\b(dr4sr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.dr4sr_abi_version() == _lib.ABI_VERSION
+    # the ctypes mirror of the plan struct must match the C layout the library was compiled with
+    assert C.sizeof(_lib.SasrecPlan) == lib.dr4sr_sasrec_plan_sizeof()
+
+
+def test_param_layout_matches_reference_state_dict(golden_dir):
+    from dr4sr_amd import _lib
+    from dr4sr_amd.engine import param_names, param_shapes
+    lib = _lib.load()
+    z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
+    N = int(z["meta.num_items"])
+    names, shapes = param_names(2), param_shapes(N, 50, 64, 128, 2)
+    off = (C.c_int64 * 26)()
+    n = lib.dr4sr_sasrec_param_layout(N, 50, 64, 128, 2, off)
+    assert n == sum(int(np.prod(s)) for s in shapes)
+    o = 0
+    for i, (nm, sh) in enumerate(zip(names, shapes)):
+        assert off[i] == o and tuple(z["param." + nm].shape) == tuple(sh), nm
+        o += int(np.prod(sh))
+    ref_keys = {k[6:] for k in z.files if k.startswith("param.")}
+    assert ref_keys == set(names) | {"query_encoder.item_encoder.weight"}
+    assert lib.dr4sr_sasrec_param_layout(11925, 50, 64, 128, 2, None) == 833344
+
+
+def test_plan_validation_errors():
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    p = _lib.SasrecPlan()
+    assert lib.dr4sr_sasrec_fwd_bwd(C.byref(p), None) == -1            # abi_version 0
+    p.abi_version = _lib.ABI_VERSION
+    p.B, p.L, p.D, p.H, p.F, p.n_layer, p.n_items = 4, 50, 96, 2, 128, 2, 100
+    p.params = p.state = p.in_item_id = p.seqlen = 1                 # never dereferenced: shape check comes first
+    assert lib.dr4sr_sasrec_fwd_bwd(C.byref(p), None) == -2            # unsupported D
+    p.D, p.L = 64, 80
+    assert lib.dr4sr_sasrec_fwd_bwd(C.byref(p), None) == -2            # L > 64
+    p.L = 50
+    assert lib.dr4sr_sasrec_workspace_bytes(C.byref(p)) > 0
+    assert lib.dr4sr_sasrec_fwd_bwd(C.byref(p), None) == -1            # no workspace
+    assert lib.dr4sr_neg_sample(None, 4, 10, 0, 0, None) == -1
+    assert lib.dr4sr_dropout_mask(None, 8, 0.5, 0, 0, 0, None) == -1
+
+
+def test_load_config_three_way_merge(tmp_path, monkeypatch):
+    from dr4sr_amd.utils import load_config
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    cfg = load_config({"model": "SASRec", "dataset": "amazon-toys"})
+    assert set(cfg) == {"model", "data", "train", "eval"}
+    assert cfg["data"]["dataset"] == "amazon-toys" and cfg["data"]["domain_name_list"] == ["toy"]
+    assert cfg["data"]["max_seq_len"] == 50 and cfg["data"]["dataset_class"] == "general" and cfg["data"]["train_file"] == "_regen"
+    assert cfg["train"]["batch_size"] == 256 and cfg["train"]["learning_rate"] == 0.001 and cfg["train"]["seed"] == 2023
+    m = cfg["model"]
+    assert (m["embed_dim"], m["hidden_size"], m["layer_num"], m["head_num"], m["dropout_rate"]) == (64, 128, 2, 2, 0.5)
+    assert m["activation"] == "gelu" and m["layer_norm_eps"] == 1e-12 and m["loss_fn"] == "bce" and m["model"] == "SASRec"
+    assert cfg["eval"]["batch_size"] == 2048 and cfg["eval"]["cutoff"] == [20, 10] and cfg["eval"]["topk"] == 100
+    monkeypatch.setenv("DR4SR_EMBED_DIM", "128")
+    assert load_config({"model": "SASRec", "dataset": "yelp"})["model"]["embed_dim"] == 128
+
+
+def _write_dataset(root, n_items=40, seqlens=(1, 3, 50, 7, 2)):
+    d = os.path.join(root, "dataset", "tiny", "toy")
+    os.makedirs(d)
+    rng = np.random.default_rng(0)
+    pad = lambda s: list(s) + [0] * (50 - len(s))
+    train, val = [], []
+    for u, sl in enumerate(seqlens, 1):
+        full = rng.integers(1, n_items, sl + 2).tolist()
+        train.append([u, pad(full[:sl]), pad(full[1:sl + 1]), sl, [1] * sl + [0] * (50 - sl), [0] * 50])
+        val.append([u, pad(full[:sl]), full[sl], sl, 1, [0] * 50, pad(full[:sl])])
+    torch.save(train, os.path.join(d, "train_ori.pth"))
+    torch.save(val, os.path.join(d, "val.pth"))
+    torch.save(val, os.path.join(d, "test.pth"))
+    with open(os.path.join(d, "inter.csv"), "w") as f:
+        f.write("user_id,item_id,rating,timestamp,domain\n")
+        for i in range(1, n_items):
+            f.write(f"{(i - 1) % len(seqlens) + 1},{i},1.0,{i},0\n")
+    return train, val
+
+
+def test_separate_dataset_reads_reference_row_format(tmp_path, monkeypatch):
+    from dr4sr_amd.data.dataset import SeparateDataset
+    train, val = _write_dataset(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    cfg = {"data": {"dataset": "tiny", "domain_name_list": ["toy"], "max_seq_len": 50, "train_file": "_ori"},
+           "train": {"device": "cpu", "batch_size": 2}, "eval": {"batch_size": 4}}
+    tr = SeparateDataset(cfg, "train")
+    tr.build()
+    assert tr.num_items == 40 and tr.num_users == 6 and len(tr) == 5
+    f = tr.fields()
+    assert f["in_item_id"].shape == (5, 50) and f["in_item_id"].dtype == torch.int64
+    assert f["seqlen"].tolist() == [1, 3, 50, 7, 2]
+    assert f["item_id"][1, :3].tolist() == train[1][2][:3] and f["label"][2].sum() == 50
+    loader = tr.get_loader()
+    assert len(loader) == 3                                   # no drop_last: 2 + 2 + 1
+    seen = []
+    for b in loader:
+        assert set(b) == {"user_id", "in_item_id", "item_id", "seqlen", "label", "domain_id", "index"}
+        assert torch.equal(b["in_item_id"], f["in_item_id"][b["index"]])
+        seen += b["index"].tolist()
+    assert sorted(seen) == [0, 1, 2, 3, 4]                    # one epoch = one permutation
+    va = SeparateDataset(cfg, "val")
+    va.build()
+    vb = next(iter(va.get_loader()))
+    assert vb["item_id"].shape == (4,) and torch.equal(vb["user_hist"], vb["in_item_id"])
+    assert tr[1]["seqlen"] == 3 and tr[1]["index"] == 1      # per-sample access still works
+
+
+def test_metrics_match_golden(golden_dir):
+    from dr4sr_amd import evaluation
+    z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
+    hit = torch.from_numpy(z["eval.item_id"]).view(-1, 1) == torch.from_numpy(z["eval.topk_items"])
+    tgt = torch.from_numpy(z["eval.label"]).view(-1, 1)
+    for k in (20, 10):
+        np.testing.assert_allclose(evaluation.ndcg(hit, tgt, k, mean=False).numpy(), z[f"eval.ndcg@{k}"], rtol=1e-6)
+        np.testing.assert_allclose(evaluation.recall(hit, tgt, k, mean=False).numpy(), z[f"eval.recall@{k}"], rtol=1e-6)
+    assert evaluation.get_eval_metrics(["ndcg", "recall"], [20, 10], validation=True) == ["ndcg@20", "recall@20"]
+    assert evaluation.get_eval_metrics(["ndcg", "recall"], [20, 10]) == ["ndcg@20", "recall@20", "ndcg@10", "recall@10"]
+
+
+def test_early_stopping_and_checkpoint_format(tmp_path, monkeypatch):
+    from dr4sr_amd.utils.callbacks import EarlyStopping
+    monkeypatch.chdir(tmp_path)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+            self.config = {"x": 1}
+    m = M()
+    es = EarlyStopping(m, "ndcg@20", "ds", patience=2)
+    assert es(m, 0, {"ndcg@20": 0.1}) is False
+    m.w.data.fill_(1.0)
+    assert es(m, 1, {"ndcg@20": 0.05}) is False and es(m, 2, {"ndcg@20": 0.02}) is True
+    ck = torch.load(os.path.join("saved", es.get_checkpoint_path()), weights_only=False)
+    assert set(ck) == {"config", "model", "epoch", "parameters", "metric"} and ck["model"] == "M" and ck["epoch"] == 0
+    assert float(ck["parameters"]["w"].sum()) == 0.0           # the BEST state was kept, not the latest
+
+
+def test_shard_bounds_cover_every_batch_once():
+    from dr4sr_amd.parallel import shard_bounds
+    n, B = 19412, 256
+    for W in (1, 2, 4, 8, 3):
+        nb = (n + B - 1) // B
+        for i in (0, 1, nb - 1):
+            spans = [shard_bounds(i, B, n, W, r) for r in range(W)]
+            assert spans[0][0] == i * B and spans[-1][1] == min(n, (i + 1) * B)
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0] and a[0] <= a[1]
+    assert shard_bounds(0, 256, 3, 8, 5) == (3, 3)             # more ranks than rows: empty slice
+
+
+def _dp_worker(rank, world, port, golden_dir, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from oracle import sasrec_oracle as O
+    from dr4sr_amd.parallel import allreduce_flat, shard_bounds
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
+    params = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    batch = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("batch.")}
+    B = batch["seqlen"].shape[0]
+    lo, hi = shard_bounds(0, B, B, world, rank)
+    sl = {k: v[lo:hi] for k, v in batch.items()}
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items() if k != "query_encoder.item_encoder.weight"}
+    # un-normalised local gradient: d(sum loss) = d(mean loss * n_local)
+    loss, _, _, _ = O.training_step(leaf, sl, 2, 2, 1e-12)
+    n_local = (sl["item_id"] != 0).sum()
+    (loss * n_local).backward()
+    flat = torch.cat([leaf[k].grad.flatten() for k in sorted(leaf)] + [torch.tensor([float(n_local), float(loss * n_local), 0, 0])])
+    allreduce_flat(flat)
+    if rank == 0:
+        q.put(flat.numpy())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_math_gloo_world2(golden_dir):
+    """sum-all-reduce of un-normalised shard gradients + {n_valid, loss_sum} tail == the reference's global-batch gradient"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
+    n, loss_sum = flat[-4], flat[-3]
+    assert n == (z["batch.item_id"] != 0).sum()
+    np.testing.assert_allclose(loss_sum / n, float(z["out.loss"]), rtol=1e-5)
+    keys = sorted(k[5:] for k in z.files if k.startswith("grad."))
+    o = 0
+    for k in keys:
+        ref = z["grad." + k]
+        got = flat[o:o + ref.size].reshape(ref.shape) / n
+        o += ref.size
+        assert np.abs(got - ref).max() <= 2e-4 * max(1e-8, np.abs(ref).max()), k

@@ -106,3 +106,21 @@ def test_neg_sampler_contract(golden_dir):
     for c in (cnt[1:], z["counts"][1:]):            # both uniform on 1..N-1 (chi-square, 35 dof)
         chi2 = float(((c - exp) ** 2 / exp).sum())
         assert chi2 < 80, chi2
+
+
+@pytest.mark.parametrize("name", ["sasrec_d64", "sasrec_d128"])
+def test_ref_like_trainer_matches_golden(golden_dir, name):
+    """the cpu_baseline trainer (same torch modules as the reference) reproduces the reference's loss and grads"""
+    from oracle.ref_trainer import RefLikeSASRec
+    g, p, b = load(golden_dir, name)
+    H, nl, eps = meta(g)
+    m = RefLikeSASRec(int(g["meta.num_items"]), D=int(g["meta.embed_dim"]), H=H, Fh=int(g["meta.hidden_size"]), p=0.0,
+                      eps=eps, n_layer=nl)
+    m.load_state_dict(p, strict=True)
+    m.train()
+    loss = m.training_step(b)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["out.loss"]), rtol=1e-6)
+    for n, prm in m.named_parameters():
+        ref = g["grad." + n]
+        assert float(np.abs(prm.grad.numpy() - ref).max()) <= 2e-5 * max(1e-8, float(np.abs(ref).max())) + 1e-9, n
