@@ -1,0 +1,341 @@
+// attn_mfma.hip — causal 2-head self-attention over ragged sequences on v_mfma_f32_16x16x4_f32 (exact fp32).
+//
+// One workgroup (4 waves) per sequence; wave w owns head h = w&1 and query row-tiles {0,3} (w>>1 == 0) or {1,2}
+// (causal work balance: 1+4 vs 2+3 key tiles).  Everything is computed in the TRANSPOSED orientation
+//     S^T[j][i] = sum_k K[j][k] Q[i][k]          (A = K rows, B = Q rows)
+// so the C-layout registers of a tile (lane: i = l&15, j = 4*(l>>4)+r) are, as they stand, the B operand of the next
+// product  out^T[d][i] = sum_j V[j][d] P[i][j]  (k-permuted: lane group g supplies j = 4g+s at step s) — no LDS
+// round trip, no shuffles between softmax and PV.  Row statistics reduce over r in-lane and over the 4 lane groups
+// with two shuffles.  The backward pass recomputes P in both orientations: phase A (query-tile owners) produces dQ and
+// the row statistics, phase B (key-tile owners) produces dK and dV, so no cross-wave accumulation is needed.
+//
+// Reference arithmetic: torch.nn.MultiheadAttention inside nn.TransformerEncoderLayer, attn_mask = triu(ones,1)
+// (model/sasrec.py:58), key_padding_mask = (idx == 0) (model/sasrec.py:48), scale 1/sqrt(head_dim), dropout on the
+// probabilities.  Dropout element index ((b*H+h)*64 + i)*64 + j, 4 consecutive j per Philox call (= one lane's r=0..3).
+#include "common.h"
+#include "kernels.h"
+
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+struct AttnArgs2 {
+    const float* qkv; float* ctx;
+    const float* dctx; float* dqkv;
+    const int64_t* idx; const int64_t* rows; const int* cu;
+    const int* state; uint64_t seed; float p; int layer; int training; int L;
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float xgroup_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
+__device__ __forceinline__ float xgroup_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float lane16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// rows of one operand: lane (r16 = l&15, g = l>>4) reads DH/4 contiguous floats of row (row0 + r16) at column h*DH + g*DH/4
+template <int DH>
+__device__ __forceinline__ void load_frag(float (&f)[DH / 4], const float* __restrict__ base, int ld, int row0, int col0) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    const float* p = base + (row0 + r16) * ld + col0 + g * (DH / 4);
+#pragma unroll
+    for (int c = 0; c < DH / 4; c += 4) {
+        const float4 v = ld4(p + c);
+        f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
+    }
+}
+
+// C[16x16] += A_rows . B_rows^T over DH features (both given as row fragments)
+template <int DH>
+__device__ __forceinline__ f32x4 mma_rows(const float (&a)[DH / 4], const float (&b)[DH / 4]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < DH / 4; ++s) acc = mfma16(a[s], b[s], acc);
+    return acc;
+}
+
+template <int D>
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, int ld, const float* __restrict__ src, int src_ld, int n) {
+    for (int i = threadIdx.x; i < 64 * (D / 4); i += 256) {
+        const int r = i / (D / 4), c = (i % (D / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) v = ld4(src + (size_t)r * src_ld + c);
+        st4(dst + r * ld + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
+    constexpr int D = 2 * DH, LD = D + 4, H = 2;
+    const int b = blockIdx.x;
+    const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
+    if (n <= 0) return;
+    float* Qs = smem;                    // [64][LD]
+    float* Ks = Qs + 64 * LD;
+    float* Vs = Ks + 64 * LD;
+    int* kpad = reinterpret_cast<int*>(Vs + 64 * LD);      // [64]
+    const int64_t row = A.rows ? A.rows[b] : b;
+    const float* src = A.qkv + (size_t)t0 * 3 * D;
+    stage_rows<D>(Qs, LD, src, 3 * D, n);
+    stage_rows<D>(Ks, LD, src + D, 3 * D, n);
+    stage_rows<D>(Vs, LD, src + 2 * D, 3 * D, n);
+    if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const int ntile = (n + 15) >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int it = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);
+        if (it >= ntile) continue;
+        const int i = it * 16 + i16;                       // this lane's query row
+        float qf[DH / 4];
+        load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
+        f32x4 s[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt <= it) {
+                float kf[DH / 4];
+                load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
+                s[jt] = mma_rows<DH>(kf, qf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + 4 * g + r;
+                    const float v = (j <= i && j < n && !kpad[j]) ? s[jt][r] * scale : -INFINITY;
+                    s[jt][r] = v;
+                    m = fmaxf(m, v);
+                }
+            }
+        }
+        m = xgroup_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt <= it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
+        sum = xgroup_sum(sum);
+        const float inv = 1.0f / sum;
+        const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt <= it) {
+                float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
+                s[jt][0] *= inv * mk.x; s[jt][1] *= inv * mk.y; s[jt][2] *= inv * mk.z; s[jt][3] *= inv * mk.w;
+            }
+        // out^T[d][i] = sum_j V[j][d] P~[i][j]
+#pragma unroll
+        for (int db = 0; db < DH / 16; ++db) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                if (jt <= it)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        o = mfma16(Vs[(jt * 16 + 4 * g + sidx) * LD + h * DH + db * 16 + i16], s[jt][sidx], o);
+            if (i < n) st4(A.ctx + (size_t)(t0 + i) * D + h * DH + db * 16 + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
+    constexpr int D = 2 * DH, LD = D + 4, H = 2;
+    const int b = blockIdx.x;
+    const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
+    if (n <= 0) return;
+    float* Qs = smem;
+    float* Ks = Qs + 64 * LD;
+    float* Vs = Ks + 64 * LD;
+    float* Cs = Vs + 64 * LD;                               // dctx rows
+    float* stat = Cs + 64 * LD;                             // [H][64][3]  row max, 1/sum, sum_j P dP
+    int* kpad = reinterpret_cast<int*>(stat + H * 64 * 3);
+    const int64_t row = A.rows ? A.rows[b] : b;
+    const float* src = A.qkv + (size_t)t0 * 3 * D;
+    stage_rows<D>(Qs, LD, src, 3 * D, n);
+    stage_rows<D>(Ks, LD, src + D, 3 * D, n);
+    stage_rows<D>(Vs, LD, src + 2 * D, 3 * D, n);
+    stage_rows<D>(Cs, LD, A.dctx + (size_t)t0 * D, D, n);
+    if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const int ntile = (n + 15) >> 4;
+
+    // ---- phase A: query tiles (transposed orientation: lane i = l&15, j = 4g+r) -> row stats + dQ
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int it = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);
+        if (it >= ntile) continue;
+        const int i = it * 16 + i16;
+        float qf[DH / 4], cf[DH / 4];
+        load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
+        load_frag<DH>(cf, Cs, LD, it * 16, h * DH);
+        f32x4 s[4], dp[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt <= it) {
+                float kf[DH / 4];
+                load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
+                s[jt] = mma_rows<DH>(kf, qf);
+                load_frag<DH>(kf, Vs, LD, jt * 16, h * DH);
+                dp[jt] = mma_rows<DH>(kf, cf);             // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + 4 * g + r;
+                    const float v = (j <= i && j < n && !kpad[j]) ? s[jt][r] * scale : -INFINITY;
+                    s[jt][r] = v;
+                    m = fmaxf(m, v);
+                }
+            }
+        m = xgroup_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt <= it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
+        sum = xgroup_sum(sum);
+        const float inv = 1.0f / sum;
+        const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
+        float rowdot = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt <= it) {
+                float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
+                const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[jt][r] *= inv;                       // P
+                    dp[jt][r] *= mkv[r];                   // dP = dP~ * mask
+                    rowdot += s[jt][r] * dp[jt][r];
+                }
+            }
+        rowdot = xgroup_sum(rowdot);
+        if (g == 0 && i < n) {
+            float* st = stat + (h * 64 + i) * 3;
+            st[0] = m; st[1] = inv; st[2] = rowdot;
+        }
+        // dS^T[j][i] = P (dP - rowdot) * scale ;  dQ^T[f][i] = sum_j K[j][f] dS^T[j][i]
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt <= it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * (dp[jt][r] - rowdot) * scale;
+#pragma unroll
+        for (int fb = 0; fb < DH / 16; ++fb) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                if (jt <= it)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        o = mfma16(Ks[(jt * 16 + 4 * g + sidx) * LD + h * DH + fb * 16 + i16], s[jt][sidx], o);
+            if (i < n) st4(A.dqkv + (size_t)(t0 + i) * 3 * D + h * DH + fb * 16 + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+    __syncthreads();
+    // ---- phase B: key tiles (natural orientation: lane j = l&15, i = 4g+r) -> dK, dV
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int jt = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);     // key tile 0 has 4 query tiles, 3 has 1
+        if (jt >= ntile) continue;
+        const int j = jt * 16 + i16;                       // this lane's key row
+        float kf[DH / 4], vf[DH / 4];
+        load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
+        load_frag<DH>(vf, Vs, LD, jt * 16, h * DH);
+        const bool jok = j < n && !kpad[j];
+        f32x4 dk[DH / 16], dv[DH / 16];
+#pragma unroll
+        for (int fb = 0; fb < DH / 16; ++fb) { dk[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (it >= jt && it < ntile) {
+                float qf[DH / 4];
+                load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
+                f32x4 s = mma_rows<DH>(qf, kf);            // S[i][j]: rows i = 4g+r (C layout), col j = l&15
+                load_frag<DH>(qf, Cs, LD, it * 16, h * DH);
+                f32x4 dp = mma_rows<DH>(qf, vf);           // dP~[i][j] = sum_d dctx[i][d] V[j][d]
+                f32x4 pt, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + 4 * g + r;
+                    float p = 0.f, mkv = 1.f, rd = 0.f;
+                    if (i < n) {
+                        const float* st = stat + (h * 64 + i) * 3;
+                        if (jok && j <= i) p = expf(s[r] * scale - st[0]) * st[1];
+                        rd = st[2];
+                        if (dodrop) mkv = drop1(rk, site, ((uint64_t)(b * H + h) * 64 + i) * 64 + j);
+                    }
+                    pt[r] = p * mkv;                       // P~[i][j]
+                    ds[r] = p * (dp[r] * mkv - rd) * scale;
+                }
+                // dK^T[f][j] = sum_i Q[i][f] dS[i][j] ;  dV^T[d][j] = sum_i dctx[i][d] P~[i][j]
+#pragma unroll
+                for (int fb = 0; fb < DH / 16; ++fb)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        const int irow = (it * 16 + 4 * g + sidx) * LD + h * DH + fb * 16 + i16;
+                        dk[fb] = mfma16(Qs[irow], ds[sidx], dk[fb]);
+                        dv[fb] = mfma16(Cs[irow], pt[sidx], dv[fb]);
+                    }
+            }
+        }
+        if (j < n) {
+#pragma unroll
+            for (int fb = 0; fb < DH / 16; ++fb) {
+                float* base = A.dqkv + (size_t)(t0 + j) * 3 * D + h * DH + fb * 16 + 4 * g;
+                st4(base + D, make_float4(dk[fb][0], dk[fb][1], dk[fb][2], dk[fb][3]));
+                st4(base + 2 * D, make_float4(dv[fb][0], dv[fb][1], dv[fb][2], dv[fb][3]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
+    AttnArgs2 A;
+    const LayerWs& lw = ws.layer[layer];
+    A.qkv = lw.qkv; A.ctx = lw.ctx; A.dctx = ws.dctx; A.dqkv = lw.dqkv;
+    A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
+    A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.layer = layer; A.training = training; A.L = p->L;
+    return A;
+}
+
+int launch_attn2_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
+    const AttnArgs2 A = make_args2(p, ws, layer, training);
+    const int dh = p->D / 2;
+    const size_t lds = sizeof(float) * (3 * 64 * (p->D + 4) + 64);
+    dim3 grid(p->B), blk(256);
+    if (dh == 32) { big_lds(k_attn2_fwd<32>, lds); hipLaunchKernelGGL(k_attn2_fwd<32>, grid, blk, lds, s, A); }
+    else if (dh == 64) { big_lds(k_attn2_fwd<64>, lds); hipLaunchKernelGGL(k_attn2_fwd<64>, grid, blk, lds, s, A); }
+    else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}
+
+int launch_attn2_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
+    const AttnArgs2 A = make_args2(p, ws, layer, training);
+    const int dh = p->D / 2;
+    const size_t lds = sizeof(float) * (4 * 64 * (p->D + 4) + 2 * 64 * 3 + 64);
+    dim3 grid(p->B), blk(256);
+    if (dh == 32) { big_lds(k_attn2_bwd<32>, lds); hipLaunchKernelGGL(k_attn2_bwd<32>, grid, blk, lds, s, A); }
+    else if (dh == 64) { big_lds(k_attn2_bwd<64>, lds); hipLaunchKernelGGL(k_attn2_bwd<64>, grid, blk, lds, s, A); }
+    else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}

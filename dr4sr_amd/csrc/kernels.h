@@ -62,5 +62,8 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 
+int launch_attn2_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);   // MFMA, H == 2
+int launch_attn2_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
+
 int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
 int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s);

@@ -6,6 +6,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 void big_lds_impl(const void* kernel, size_t bytes) {
@@ -170,11 +171,23 @@ static int launch_zero_grads(const dr4sr_sasrec_plan* p, int64_t n_params, hipSt
 // ------------------------------------------------------------------------------------------------
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
+// MFMA attention needs exactly 2 heads (one wave pair per head); other head counts use the VALU kernels.
+static bool use_mfma_attn(const dr4sr_sasrec_plan* p) {
+    static const bool off = getenv("DR4SR_ATTN_VALU") != nullptr;
+    return p->H == 2 && !off;
+}
+static int attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int training, hipStream_t s) {
+    return use_mfma_attn(p) ? launch_attn2_fwd(p, ws, l, training, s) : launch_attn_fwd(p, ws, l, training, s);
+}
+static int attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int training, hipStream_t s) {
+    return use_mfma_attn(p) ? launch_attn2_bwd(p, ws, l, training, s) : launch_attn_bwd(p, ws, l, training, s);
+}
+
 static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
     RC(launch_embed_fwd(p, ws, training, s));
     for (int l = 0; l < p->n_layer; ++l) {
         RC(launch_qkv_fwd(p, ws, l, s));
-        RC(launch_attn_fwd(p, ws, l, training, s));
+        RC(attn_fwd(p, ws, l, training, s));
         RC(launch_post_fwd(p, ws, l, training, s));
     }
     return 0;
@@ -184,7 +197,7 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
     RC(launch_transpose_weights(p, ws, s));
     for (int l = p->n_layer - 1; l >= 0; --l) {
         RC(launch_post_bwd(p, ws, l, training, s));
-        RC(launch_attn_bwd(p, ws, l, training, s));
+        RC(attn_bwd(p, ws, l, training, s));
         RC(launch_qkv_bwd(p, ws, l, s));
     }
     RC(launch_embed_bwd(p, ws, training, s));
@@ -243,12 +256,12 @@ extern "C" int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t
         case DR4SR_K_PREP: return launch_prep(plan, ws, 0, s);
         case DR4SR_K_EMBED_FWD: return launch_embed_fwd(plan, ws, 1, s);
         case DR4SR_K_QKV_FWD: return launch_qkv_fwd(plan, ws, layer, s);
-        case DR4SR_K_ATTN_FWD: return launch_attn_fwd(plan, ws, layer, 1, s);
+        case DR4SR_K_ATTN_FWD: return attn_fwd(plan, ws, layer, 1, s);
         case DR4SR_K_POST_FWD: return launch_post_fwd(plan, ws, layer, 1, s);
         case DR4SR_K_SCORE: return launch_score_packed(plan, ws, s);
         case DR4SR_K_TRANSPOSE: return launch_transpose_weights(plan, ws, s);
         case DR4SR_K_POST_BWD: return launch_post_bwd(plan, ws, layer, 1, s);
-        case DR4SR_K_ATTN_BWD: return launch_attn_bwd(plan, ws, layer, 1, s);
+        case DR4SR_K_ATTN_BWD: return attn_bwd(plan, ws, layer, 1, s);
         case DR4SR_K_QKV_BWD: return launch_qkv_bwd(plan, ws, layer, s);
         case DR4SR_K_EMBED_BWD: return launch_embed_bwd(plan, ws, 1, s);
         case DR4SR_K_WGRAD: return launch_wgrad(plan, ws, 1, 1, s);
