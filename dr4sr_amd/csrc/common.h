@@ -118,6 +118,30 @@ __device__ __forceinline__ void mma_64xN(const float* __restrict__ As, int lda,
     }
 }
 
+// Data-gradient form:  C[64 x N] = A[64 x KR] * W  with W global [KR][ldw] row-major (the forward weight [out][in] used
+// as-is: KR = out features = reduction, N = in features).  B operand lane (r, g) at step kk reads W[g*KR/2 + kk][ct*32 + r]:
+// a 128-B-coalesced dword per half-wave; A as in mma_64xN.  Removes the per-step transposed weight copies.
+template <int KR, int NTW>
+__device__ __forceinline__ void mma_64xN_wT(const float* __restrict__ As, int lda, const float* __restrict__ W, int ldw,
+                                            f32x16 (&acc)[NTW]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, g = lane >> 5, rh = w & 1, cg = w >> 1;
+    const float* arow = As + (rh * 32 + r) * lda + g * (KR / 2);
+    const float* wcol = W + (size_t)(g * (KR / 2)) * ldw + cg * 32 + r;
+#pragma unroll
+    for (int c = 0; c < KR / 2; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + c);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const float* wp = wcol + (size_t)c * ldw + 64 * i;
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wp[0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wp[ldw], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wp[2 * ldw], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wp[3 * ldw], acc[i], 0, 0, 0);
+        }
+    }
+}
+
 // accumulators (+ bias[n]) -> LDS C tile [64][ldc].  C/D map of 32x32: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 template <int NTW>

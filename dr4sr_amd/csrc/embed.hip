@@ -46,9 +46,16 @@ extern "C" int dr4sr_embed_gather_posadd(const float* E, const float* P, const i
 // ------------------------------------------------------------------------------------------------
 // prep: cu[b] = exclusive prefix sum of clamp(seqlen[row(b)], 0, L); state[T] = total.  One block.
 // Also bumps the RNG step so that every fwd_bwd draws fresh dropout masks / negatives.
+// Blocks 1.. of the same launch zero the flat gradient (+tail) when `zero` is given (saves a launch per step; a
+// hipMemsetAsync graph node is NOT used: on ROCm 7.2 its replay was observed to fill the last 16 bytes with a stale pattern).
 __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqlen, const int64_t* __restrict__ rows,
                                                int* __restrict__ cu, int* __restrict__ state, int B, int L,
-                                               int bump_rng) {
+                                               int bump_rng, float* __restrict__ zero, int64_t zero_n4) {
+    if (blockIdx.x > 0) {
+        for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n4; i += (int64_t)(gridDim.x - 1) * 1024)
+            st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     const int per = (B + 1023) / 1024;
@@ -79,8 +86,12 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
     }
 }
 
-int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, hipStream_t s) {
-    hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, s, p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng);
+int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
+    const int64_t n4 = zero_grads ? (ws.n_params + DR4SR_GRAD_TAIL) / 4 : 0;
+    int zb = (int)((n4 + 1023) / 1024);
+    if (zb > 255) zb = 255;
+    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng,
+                       zero_grads ? p->grads : nullptr, n4);
     return DR4SR_LAUNCH_CHECK();
 }
 

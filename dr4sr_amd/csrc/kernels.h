@@ -14,12 +14,14 @@ struct LayerWs {
     float* y;      // [T,D]   LayerNorm1 output
     float* st1;    // [T,2]   (mean, rstd) of u1
     float* a;      // [T,F]   linear1 pre-activation
+    float* h;      // [T,F]   drop(gelu(a))  (kept so the weight-gradient pass is a plain GEMM)
     float* u2;     // [T,D]   y + drop(linear2(drop(gelu(a))))            (LayerNorm2 input)
     float* st2;    // [T,2]
     // gradients kept for the weight-gradient pass
-    float* du2;    // [T,D]
+    float* df;     // [T,D]   d(linear2 output) = du2 * dropout2 mask
     float* da;     // [T,F]
-    float* du1;    // [T,D]
+    float* du1;    // [T,D]   d(LayerNorm1 input) (residual branch of qkv_bwd)
+    float* dout;   // [T,D]   d(out_proj output) = du1 * dropout1 mask
     float* dqkv;   // [T,3D]
 };
 
@@ -46,7 +48,7 @@ static inline int64_t poff(const Workspace& ws, int layer, int j) { return ws.of
 
 int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws);   // fills ws from p->workspace (or sizes only if NULL)
 
-int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, hipStream_t s);
+int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s);
 int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int last, hipStream_t s);

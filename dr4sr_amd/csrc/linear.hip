@@ -83,10 +83,10 @@ struct PostArgs {
     const float* ctx; const float* x;
     const float* out_w; const float* out_b; const float* ln1_w; const float* ln1_b;
     const float* w1; const float* b1; const float* w2; const float* b2; const float* ln2_w; const float* ln2_b;
-    float* u1; float* y; float* st1; float* a; float* u2; float* st2; float* z;
+    float* u1; float* y; float* st1; float* a; float* h; float* u2; float* st2; float* z;
     // backward
     const float* dz; const float* w2T; const float* w1T; const float* out_wT;
-    float* du2; float* da; float* du1; float* dctx;
+    float* df; float* da; float* du1; float* dout; float* dctx;
     float* ln_part;                            // this layer's [ntiles][4][D] LayerNorm affine partials
     const int* state; uint64_t seed; float p; float eps; int layer; int training;
 };
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
             if (t < T) {
                 st4(A.a + (size_t)t * F + c, av);
                 if (dodrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); h.x *= m.x; h.y *= m.y; h.z *= m.z; h.w *= m.w; }
+                st4(A.h + (size_t)t * F + c, h);
             }
             st4(R2 + row * LF + c, h);
         }
@@ -296,10 +297,10 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int c = 4 * l16 + 64 * j;
-                st4(A.du2 + (size_t)t * D + c, dzv[j]);
                 st4(R1 + row * LD + c, dzv[j]);
                 float4 df = dzv[j];
                 if (dodrop) { const float4 m = drop4(rk, sF, (uint64_t)t * D + c); df.x *= m.x; df.y *= m.y; df.z *= m.z; df.w *= m.w; }
+                st4(A.df + (size_t)t * D + c, df);
                 st4(R0 + row * LD + c, df);
             }
         } else {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     {
         f32x16 acc[NVF];
         acc_zero(acc);
-        mma_64xN<D, NVF>(R0, LD, A.w2T, acc);
+        mma_64xN_wT<D, NVF>(R0, LD, A.w2, F, acc);
         acc_to_lds(acc, R2, LF, nullptr);
     }
     __syncthreads();
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     {
         f32x16 acc[NV];
         acc_zero(acc);
-        mma_64xN<F, NV>(R2, LF, A.w1T, acc);
+        mma_64xN_wT<F, NV>(R2, LF, A.w1, D, acc);
         acc_to_lds(acc, R0, LD, nullptr);
     }
     __syncthreads();
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
                 st4(A.du1 + (size_t)t * D + c, dyv[j]);
                 float4 dd = dyv[j];
                 if (dodrop) { const float4 m = drop4(rk, sP, (uint64_t)t * D + c); dd.x *= m.x; dd.y *= m.y; dd.z *= m.z; dd.w *= m.w; }
+                st4(A.dout + (size_t)t * D + c, dd);
                 st4(R1 + row * LD + c, dd);
             }
         }   // rows >= T of R1 are already zero
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     {
         f32x16 acc[NV];
         acc_zero(acc);
-        mma_64xN<D, NV>(R1, LD, A.out_wT, acc);
+        mma_64xN_wT<D, NV>(R1, LD, A.out_w, D, acc);
         acc_to_lds(acc, R0, LD, nullptr);
     }
     __syncthreads();
@@ -402,12 +404,12 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     A.w1 = P + poff(ws, layer, P_W1); A.b1 = P + poff(ws, layer, P_B1);
     A.w2 = P + poff(ws, layer, P_W2); A.b2 = P + poff(ws, layer, P_B2);
     A.ln2_w = P + poff(ws, layer, P_LN2_W); A.ln2_b = P + poff(ws, layer, P_LN2_B);
-    A.u1 = lw.u1; A.y = lw.y; A.st1 = lw.st1; A.a = lw.a; A.u2 = lw.u2; A.st2 = lw.st2; A.z = ws.X[layer + 1];
+    A.u1 = lw.u1; A.y = lw.y; A.st1 = lw.st1; A.a = lw.a; A.h = lw.h; A.u2 = lw.u2; A.st2 = lw.st2; A.z = ws.X[layer + 1];
     A.dz = ws.dX[layer + 1];
     const float* wT = ws.wT + layer * ws.wT_stride;
     const int D = p->D, F = p->F;
     A.out_wT = wT + 3 * D * D; A.w1T = wT + 4 * D * D; A.w2T = wT + 4 * D * D + D * F;
-    A.du2 = lw.du2; A.da = lw.da; A.du1 = lw.du1; A.dctx = ws.dctx;
+    A.df = lw.df; A.da = lw.da; A.du1 = lw.du1; A.dout = lw.dout; A.dctx = ws.dctx;
     A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 63) / 64) * 4 * p->D;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
     return A;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQKV,
     __syncthreads();
     f32x16 acc[NV];
     acc_zero(acc);
-    mma_64xN<K, NV>(As, LDA, WT, acc);
+    mma_64xN_wT<K, NV>(As, LDA, WT, D, acc);
     acc_to_lds(acc, Cs, LDC, nullptr);
     __syncthreads();
     constexpr int C4 = D / 4;
@@ -468,7 +470,7 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
     const int D = p->D;
     const size_t lds = sizeof(float) * 64 * ((3 * D + 4) + (D + 4));
     dim3 grid((ws.Tmax + 63) / 64), blk(256);
-    const float* WT = ws.wT + layer * ws.wT_stride;
+    const float* WT = p->params + poff(ws, layer, P_IN_W);      // forward weight used as-is (column-mode B operand)
     const LayerWs& lw = ws.layer[layer];
     if (D == 64) { big_lds(k_qkv_bwd<64>, lds); hipLaunchKernelGGL(k_qkv_bwd<64>, grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); }
     else { big_lds(k_qkv_bwd<128>, lds); hipLaunchKernelGGL(k_qkv_bwd<128>, grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); }
@@ -513,31 +515,50 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
 #pragma unroll
     for (int i = 0; i < (NG + 255) / 256; ++i) bsum[i] = 0.f;
 
-    for (int tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    // software pipeline (async-STAGE split): the global loads of the NEXT token tile are issued into registers
+    // before the MFMA phase of the current one and committed (dropout / GELU applied) to LDS after it.
+    constexpr int GQ = NG / 16, XQ = KX / 16;      // float4 per thread per tile
+    float4 gq[GQ], xq[XQ];
+    auto issue = [&](int tt) {
         const int t0 = tt * 64;
-        __syncthreads();
-        for (int i = threadIdx.x; i < 64 * (NG / 4); i += 256) {
-            const int row = i / (NG / 4), c = (i % (NG / 4)) * 4, t = t0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < T) {
-                v = ld4(J.G + (size_t)t * J.ldg + J.gcol + c);
-                if (J.gmode && dodrop) { const float4 m = drop4(rk, J.gsite, (uint64_t)t * J.ldg + J.gcol + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
-            }
+#pragma unroll
+        for (int u = 0; u < GQ; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / (NG / 4), c = (i % (NG / 4)) * 4, t = t0 + row;
+            gq[u] = t < T ? ld4(J.G + (size_t)t * J.ldg + J.gcol + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < XQ; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / (KX / 4), c = (i % (KX / 4)) * 4, t = t0 + row;
+            xq[u] = t < T ? ld4(J.X + (size_t)t * J.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int tt) {
+        const int t0 = tt * 64;
+#pragma unroll
+        for (int u = 0; u < GQ; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / (NG / 4), c = (i % (NG / 4)) * 4, t = t0 + row;
+            float4 v = gq[u];
+            if (J.gmode && dodrop && t < T) { const float4 m = drop4(rk, J.gsite, (uint64_t)t * J.ldg + J.gcol + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
             st4(Gs + row * NG + c, v);
         }
-        for (int i = threadIdx.x; i < 64 * (KX / 4); i += 256) {
-            const int row = i / (KX / 4), c = (i % (KX / 4)) * 4, t = t0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < T) {
-                v = ld4(J.X + (size_t)t * J.ldx + c);
-                if (J.xmode) {
-                    v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-                    if (dodrop) { const float4 m = drop4(rk, J.xsite, (uint64_t)t * J.ldx + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
-                }
+#pragma unroll
+        for (int u = 0; u < XQ; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / (KX / 4), c = (i % (KX / 4)) * 4, t = t0 + row;
+            float4 v = xq[u];
+            if (J.xmode && t < T) {
+                v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+                if (dodrop) { const float4 m = drop4(rk, J.xsite, (uint64_t)t * J.ldx + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
             }
             st4(Xs + row * KX + c, v);
         }
+    };
+    int tt = blockIdx.x;
+    if (tt < ntiles) issue(tt);
+    for (; tt < ntiles; tt += gridDim.x) {
+        __syncthreads();                                   // previous MFMA phase has finished reading LDS
+        commit(tt);
         __syncthreads();
+        if (tt + (int)gridDim.x < ntiles) issue(tt + gridDim.x);
 #pragma unroll 4
         for (int s = 0; s < 32; ++s) {
             const int t = 2 * s + g;
@@ -553,9 +574,12 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
         for (int i = 0; i < (NG + 255) / 256; ++i) {
             const int n = threadIdx.x + 256 * i;
             if (n < NG) {
-                float sacc = 0.f;
-                for (int t = 0; t < 64; ++t) sacc += Gs[t * NG + n];
-                bsum[i] += sacc;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+                for (int t = 0; t < 64; t += 4) {
+                    s0 += Gs[t * NG + n]; s1 += Gs[(t + 1) * NG + n]; s2 += Gs[(t + 2) * NG + n]; s3 += Gs[(t + 3) * NG + n];
+                }
+                bsum[i] += (s0 + s1) + (s2 + s3);
             }
         }
     }
@@ -625,17 +649,17 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
             J.X = ws.X[l]; J.ldx = D; J.xsite = 0; J.xmode = 0;
             J.dW = G + poff(ws, l, P_IN_W) + (int64_t)part * D * D; J.db = G + poff(ws, l, P_IN_B) + part * D;
         }
-        { WgradJob& J = A.job[l * 6 + 3];                 // out_proj: G = du1 * mask_proj, X = ctx
-          J.G = lw.du1; J.ldg = D; J.gcol = 0; J.gsite = DR4SR_SITE_PROJ + 4 * l; J.gmode = 1;
+        { WgradJob& J = A.job[l * 6 + 3];                 // out_proj: G = dout (= du1 * mask_proj), X = ctx
+          J.G = lw.dout; J.ldg = D; J.gcol = 0; J.gsite = 0; J.gmode = 0;
           J.X = lw.ctx; J.ldx = D; J.xsite = 0; J.xmode = 0;
           J.dW = G + poff(ws, l, P_OUT_W); J.db = G + poff(ws, l, P_OUT_B); }
         { WgradJob& J = A.job[l * 6 + 4];                 // linear1: G = da, X = y
           J.G = lw.da; J.ldg = F; J.gcol = 0; J.gsite = 0; J.gmode = 0;
           J.X = lw.y; J.ldx = D; J.xsite = 0; J.xmode = 0;
           J.dW = G + poff(ws, l, P_W1); J.db = G + poff(ws, l, P_B1); }
-        { WgradJob& J = A.job[l * 6 + 5];                 // linear2: G = du2 * mask_ffn, X = drop(gelu(a))
-          J.G = lw.du2; J.ldg = D; J.gcol = 0; J.gsite = DR4SR_SITE_FFN + 4 * l; J.gmode = 1;
-          J.X = lw.a; J.ldx = F; J.xsite = DR4SR_SITE_ACT + 4 * l; J.xmode = 1;
+        { WgradJob& J = A.job[l * 6 + 5];                 // linear2: G = df (= du2 * mask_ffn), X = h = drop(gelu(a))
+          J.G = lw.df; J.ldg = D; J.gcol = 0; J.gsite = 0; J.gmode = 0;
+          J.X = lw.h; J.ldx = F; J.xsite = 0; J.xmode = 0;
           J.dW = G + poff(ws, l, P_W2); J.db = G + poff(ws, l, P_B2); }
     }
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.training = training;
@@ -643,7 +667,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     A.ln_part = ws.ln_part; A.ln_layer_stride = (int64_t)ntiles * 4 * D; A.grads = G;
     A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
-    static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 24;   // tuning knob
+    static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 48;   // tuning knob
     int gw = ntiles < gw_max ? ntiles : gw_max;
     dim3 grid(gw, 7, p->n_layer), blk(256);
     const size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);

@@ -73,8 +73,8 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         LayerWs& w = ws->layer[l];
         w.qkv = take(Tmax * 3 * D); w.ctx = take(Tmax * D);
         w.u1 = take(Tmax * D); w.y = take(Tmax * D); w.st1 = take(Tmax * 2);
-        w.a = take(Tmax * F); w.u2 = take(Tmax * D); w.st2 = take(Tmax * 2);
-        w.du2 = take(Tmax * D); w.da = take(Tmax * F); w.du1 = take(Tmax * D); w.dqkv = take(Tmax * 3 * D);
+        w.a = take(Tmax * F); w.h = take(Tmax * F); w.u2 = take(Tmax * D); w.st2 = take(Tmax * 2);
+        w.df = take(Tmax * D); w.da = take(Tmax * F); w.du1 = take(Tmax * D); w.dout = take(Tmax * D); w.dqkv = take(Tmax * 3 * D);
     }
     ws->bytes = o;
     return 0;
@@ -194,7 +194,6 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
 }
 
 static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s) {
-    RC(launch_transpose_weights(p, ws, s));
     for (int l = p->n_layer - 1; l >= 0; --l) {
         RC(launch_post_bwd(p, ws, l, training, s));
         RC(attn_bwd(p, ws, l, training, s));
@@ -210,8 +209,7 @@ extern "C" int dr4sr_sasrec_fwd_bwd(const dr4sr_sasrec_plan* plan, void* stream)
     RC(get_ws(plan, &ws));
     if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    RC(launch_zero_grads(plan, ws.n_params, s));
-    RC(launch_prep(plan, ws, 1, s));
+    RC(launch_prep(plan, ws, 1, 1, s));
     RC(forward_layers(plan, ws, 1, s));
     RC(launch_score_packed(plan, ws, s));
     RC(backward_layers(plan, ws, 1, 1, s));
@@ -229,7 +227,7 @@ extern "C" int dr4sr_sasrec_encode(const dr4sr_sasrec_plan* plan, int32_t traini
     RC(get_ws(plan, &ws));
     if (!out || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    RC(launch_prep(plan, ws, training ? 1 : 0, s));
+    RC(launch_prep(plan, ws, training ? 1 : 0, 0, s));
     RC(forward_layers(plan, ws, training, s));
     return launch_unpack(plan, ws, ws.X[plan->n_layer], out, pooling == DR4SR_POOL_LAST, s);
 }
@@ -253,7 +251,7 @@ extern "C" int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t
     if (layer < 0 || layer >= plan->n_layer) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     switch (kernel) {
-        case DR4SR_K_PREP: return launch_prep(plan, ws, 0, s);
+        case DR4SR_K_PREP: return launch_prep(plan, ws, 0, 0, s);
         case DR4SR_K_EMBED_FWD: return launch_embed_fwd(plan, ws, 1, s);
         case DR4SR_K_QKV_FWD: return launch_qkv_fwd(plan, ws, layer, s);
         case DR4SR_K_ATTN_FWD: return attn_fwd(plan, ws, layer, 1, s);
