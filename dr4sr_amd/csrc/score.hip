@@ -37,6 +37,9 @@ extern "C" int dr4sr_neg_sample(int64_t* out, int64_t n, int32_t n_items, uint64
 
 // ------------------------------------------------------------------------------------------------
 // Packed training scorer: forward + backward fused (upstream weight 1, un-normalised).
+// One workgroup per sequence.  Wave 0 first handles all L positions at once (lane = position): loads the targets,
+// draws/loads the negatives, and publishes them to LDS; then the 8 half-waves walk only the positions with a non-PAD
+// target (ballot + bit scan), one position per half-wave (32 lanes x D/32 dims, shuffle reduction within the half).
 template <int D>
 __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ Z, const float* __restrict__ E,
                                                       float* __restrict__ dE, float* __restrict__ dZ,
@@ -44,59 +47,79 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
                                                       const int* __restrict__ cu, int64_t* __restrict__ neg_item,
                                                       int sample_neg, float* __restrict__ part, const int* __restrict__ state,
                                                       uint64_t seed, int n_items, int B, int L) {
-    constexpr int NV = D / 64;
+    constexpr int NV = D / 32;                            // floats per lane (half-wave covers D)
+    __shared__ int s_tgt[64], s_neg[64], s_list[64];
+    __shared__ unsigned long long s_valid;
+    __shared__ float red[16];
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t0 = cu[b], n = cu[b + 1] - t0;
     const int64_t row = rows ? rows[b] : b;
-    const RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], 0.f);
+    if (w == 0) {
+        int64_t tgt = 0, ng = 1;
+        if (lane < L) {
+            tgt = target[row * L + lane];
+            if (sample_neg) {
+                const RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], 0.f);
+                ng = sample_neg_id(rk, (uint64_t)b * L + lane, n_items);
+                neg_item[(size_t)b * L + lane] = ng;
+            } else {
+                ng = neg_item[(size_t)b * L + lane];
+            }
+            ng = ng < 0 ? 0 : (ng >= n_items ? n_items - 1 : ng);
+        }
+        const bool ok = lane < L && tgt > 0 && tgt < n_items;
+        s_tgt[lane] = ok ? (int)tgt : 0;
+        s_neg[lane] = (int)ng;
+        const unsigned long long m = __ballot(ok);
+        if (ok) s_list[__popcll(m & ((1ull << lane) - 1ull))] = lane;     // compacted list of loss positions
+        if (lane == 0) s_valid = m;
+    }
+    __syncthreads();
+    // rows < n whose target is PAD receive a zero upstream gradient (they are masked out of the loss)
+    const unsigned long long valid = s_valid;
+    for (int i = threadIdx.x; i < n * (D / 4); i += 256) {
+        const int l = i / (D / 4), c = (i % (D / 4)) * 4;
+        if (!((valid >> l) & 1ull)) st4(dZ + (size_t)(t0 + l) * D + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    const int hw = threadIdx.x >> 5, l32 = threadIdx.x & 31;          // 8 half-waves
     float lsum = 0.f, cnt = 0.f;
-    for (int l = w; l < L; l += 4) {
-        const int64_t tgt = target[row * L + l];
-        int64_t ng;
-        if (sample_neg) {
-            ng = sample_neg_id(rk, (uint64_t)b * L + l, n_items);
-            if (lane == 0) neg_item[(size_t)b * L + l] = ng;
-        } else {
-            ng = neg_item[(size_t)b * L + l];
-        }
+    const int nvalid = __popcll(valid);
+    for (int k = hw; k < nvalid; k += 8) {                 // half-waves stay in lock-step on consecutive list entries
+        const int l = s_list[k];
+        const int tgt = s_tgt[l], ng = s_neg[l];
         const bool in = l < n;
-        if (tgt <= 0 || tgt >= n_items) {                 // pad target: masked out of loss and grads
-            if (in)
-#pragma unroll
-                for (int j = 0; j < NV; ++j) dZ[(size_t)(t0 + l) * D + lane + 64 * j] = 0.f;
-            continue;
-        }
-        ng = ng < 0 ? 0 : (ng >= n_items ? n_items - 1 : ng);
         float q[NV], ep[NV], en[NV];
         float sp = 0.f, sn = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            q[j] = in ? Z[(size_t)(t0 + l) * D + lane + 64 * j] : 0.f;
-            ep[j] = E[tgt * D + lane + 64 * j];
-            en[j] = E[ng * D + lane + 64 * j];
+            q[j] = in ? Z[(size_t)(t0 + l) * D + l32 + 32 * j] : 0.f;
+            ep[j] = E[(size_t)tgt * D + l32 + 32 * j];
+            en[j] = E[(size_t)ng * D + l32 + 32 * j];
             sp += q[j] * ep[j];
             sn += q[j] * en[j];
         }
-        sp = wave_sum(sp);
-        sn = wave_sum(sn);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); sn += __shfl_xor(sn, o, 64); }
         lsum += softplus_f(-sp) + softplus_f(sn);
         cnt += 1.f;
         if (in) {
             const float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                dZ[(size_t)(t0 + l) * D + lane + 64 * j] = dpos * ep[j] + dneg * en[j];
-                unsafeAtomicAdd(dE + tgt * D + lane + 64 * j, dpos * q[j]);
-                unsafeAtomicAdd(dE + ng * D + lane + 64 * j, dneg * q[j]);
+                dZ[(size_t)(t0 + l) * D + l32 + 32 * j] = dpos * ep[j] + dneg * en[j];
+                unsafeAtomicAdd(dE + (size_t)tgt * D + l32 + 32 * j, dpos * q[j]);
+                unsafeAtomicAdd(dE + (size_t)ng * D + l32 + 32 * j, dneg * q[j]);
             }
         }
     }
-    __shared__ float red[8];
-    if (lane == 0) { red[2 * w] = cnt; red[2 * w + 1] = lsum; }
+    if (l32 == 0) { red[2 * hw] = cnt; red[2 * hw + 1] = lsum; }
     __syncthreads();
     if (threadIdx.x == 0) {                      // deterministic per-sequence partial; summed by k_wgrad's reduce job
-        part[2 * b] = (red[0] + red[2]) + (red[4] + red[6]);
-        part[2 * b + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+        float c = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c += red[2 * i]; s2 += red[2 * i + 1]; }
+        part[2 * b] = c;
+        part[2 * b + 1] = s2;
     }
 }
 

@@ -133,8 +133,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float
         st4(P + 4 * i, p); st4(M + 4 * i, m); st4(V + 4 * i, v);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
+    if (threadIdx.x == 0) {                    // no fence needed: the kernel boundary publishes the parameter writes
         const int ticket = atomicAdd(&state[8], 1);
         if (ticket == (int)gridDim.x - 1) { state[8] = 0; state[DR4SR_STATE_STEP] = t; }
     }
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float
 int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s) {
     if (!p->grads || !p->adam_m || !p->adam_v || p->n_params <= 0 || (p->n_params & 3)) return DR4SR_E_ARG;
     int64_t blocks = (p->n_params / 4 + 255) / 256;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, p->params, p->grads, p->adam_m, p->adam_v, p->n_params,
                        p->state, p->lr, p->beta1, p->beta2, p->adam_eps, p->weight_decay);
     return DR4SR_LAUNCH_CHECK();
