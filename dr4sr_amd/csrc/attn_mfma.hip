@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
     stage_rows<D>(Ks, LD, src + D, 3 * D, n);
     stage_rows<D>(Vs, LD, src + 2 * D, 3 * D, n);
     if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
-    __syncthreads();
+    lds_barrier();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
     const int i16 = lane & 15, g = lane >> 4;
     const bool dodrop = A.training && A.p > 0.f;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
     stage_rows<D>(Vs, LD, src + 2 * D, 3 * D, n);
     stage_rows<D>(Cs, LD, A.dctx + (size_t)t0 * D, D, n);
     if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
-    __syncthreads();
+    lds_barrier();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
     const int i16 = lane & 15, g = lane >> 4;
     const bool dodrop = A.training && A.p > 0.f;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
             if (i < n) st4(A.dqkv + (size_t)(t0 + i) * 3 * D + h * DH + fb * 16 + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase B: key tiles (natural orientation: lane j = l&15, i = 4g+r) -> dK, dV
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {

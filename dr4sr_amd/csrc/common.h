@@ -64,6 +64,13 @@ __device__ __forceinline__ float drop1(const RngKey& k, uint32_t site, uint64_t 
     return w >= k.thresh ? k.scale : 0.f;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global stores count on CDNA4), which
+// makes every phase of the tile kernels wait ~1-2 us for its activation stores to be acknowledged; nothing in these kernels
+// communicates between waves through global memory, so LDS ordering (lgkmcnt) + s_barrier is sufficient.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -79,9 +86,21 @@ __device__ __forceinline__ float group16_sum(float v) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-rounding class) on v_rcp/v_exp: ~15 VALU instead of
+// libm erff's ~60 — the GELU row passes are VALU-latency-bound with one wave per SIMD.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#define STAMP(i) do { if (A.stamps && blockIdx.x == 0 && threadIdx.x == 0) A.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -53,12 +54,12 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ X, co
     float* As = smem;
     float* Cs = smem + 64 * LDA;
     load_tile<D>(As, LDA, X, D, t0, T);
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[N / 64];
     acc_zero(acc);
     mma_64xN<D, N / 64>(As, LDA, W, acc);
     acc_to_lds(acc, Cs, LDC, bias);
-    __syncthreads();
+    lds_barrier();
     constexpr int C4 = N / 4;
     for (int i = threadIdx.x; i < 64 * C4; i += 256) {
         const int row = i / C4, c = (i % C4) * 4;
@@ -89,7 +90,59 @@ struct PostArgs {
     float* df; float* da; float* du1; float* dout; float* dctx;
     float* ln_part;                            // this layer's [ntiles][4][D] LayerNorm affine partials
     const int* state; uint64_t seed; float p; float eps; int layer; int training;
+    unsigned long long* stamps;                // debug: per-phase s_memtime of block 0 (NULL normally)
 };
+
+// dropout + residual + LayerNorm over the 64 rows of a C tile held in LDS, 16 lanes per row, all four row passes of
+// a thread issued together (loads first, then four independent reduction chains, then stores) so that the single wave
+// per SIMD overlaps global-load / shuffle / Philox latencies across rows instead of serialising them.
+//   v = res + drop(C)  -> U (global);  LN(v) -> OUT (global) [+ LDS copy];  (mean, rstd) -> ST
+template <int D, bool RES_IN_LDS, bool COPY_LDS>
+__device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc, const float* __restrict__ res, int ldres,
+                                           const float* __restrict__ lnw, const float* __restrict__ lnb, float eps,
+                                           float* __restrict__ U, float* __restrict__ OUT, float* __restrict__ ST,
+                                           float* __restrict__ Ls, int ldl, int t0, int T, bool dodrop, const RngKey& rk,
+                                           uint32_t site) {
+    constexpr int NV = D / 64;
+    const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    float4 gam[NV], bet[NV], v[4][NV];
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { gam[j] = ld4(lnw + 4 * l16 + 64 * j); bet[j] = ld4(lnb + 4 * l16 + 64 * j); }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        const bool ok = t < T;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * l16 + 64 * j;
+            float4 o = ld4(Cs + row * ldc + c);
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (RES_IN_LDS) r = ld4(res + row * ldres + c);
+            else if (ok) r = ld4(res + (size_t)t * ldres + c);
+            if (dodrop) { const float4 m = drop4(rk, site, (uint64_t)t * D + c); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+            v[ps][j] = make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w);
+            if (ok) st4(U + (size_t)t * D + c, v[ps][j]);
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) ln_stats16<NV>(v[ps], mean[ps], rstd[ps], eps);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        const bool ok = t < T;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * l16 + 64 * j;
+            const float m = mean[ps], rs = rstd[ps];
+            const float4 yv = make_float4((v[ps][j].x - m) * rs * gam[j].x + bet[j].x, (v[ps][j].y - m) * rs * gam[j].y + bet[j].y,
+                                          (v[ps][j].z - m) * rs * gam[j].z + bet[j].z, (v[ps][j].w - m) * rs * gam[j].w + bet[j].w);
+            if (ok) st4(OUT + (size_t)t * D + c, yv);
+            if (COPY_LDS) st4(Ls + row * ldl + c, ok ? yv : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        if (ok && l16 == 0) { ST[2 * (size_t)t] = mean[ps]; ST[2 * (size_t)t + 1] = rstd[ps]; }
+    }
+}
 
 template <int D, int F>
 __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
@@ -104,50 +157,19 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     const uint32_t sP = DR4SR_SITE_PROJ + 4 * A.layer, sA = DR4SR_SITE_ACT + 4 * A.layer, sF = DR4SR_SITE_FFN + 4 * A.layer;
 
+    STAMP(0);
     load_tile<D>(R0, LD, A.ctx, D, t0, T);
-    __syncthreads();
+    lds_barrier(); STAMP(1);
     {
         f32x16 acc[NV];
         acc_zero(acc);
         mma_64xN<D, NV>(R0, LD, A.out_w, acc);
         acc_to_lds(acc, R2, LD, A.out_b);
     }
-    __syncthreads();
+    lds_barrier(); STAMP(2);
     // ---- dropout1 + residual + LayerNorm1
-    float4 gam[NV], bet[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { gam[j] = ld4(A.ln1_w + 4 * l16 + 64 * j); bet[j] = ld4(A.ln1_b + 4 * l16 + 64 * j); }
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 16 + rsub, t = t0 + row;
-        if (t < T) {
-            float4 v[NV];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                float4 o = ld4(R2 + row * LD + c);
-                if (dodrop) { const float4 m = drop4(rk, sP, (uint64_t)t * D + c); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
-                const float4 xr = ld4(A.x + (size_t)t * D + c);
-                v[j] = make_float4(xr.x + o.x, xr.y + o.y, xr.z + o.z, xr.w + o.w);
-                st4(A.u1 + (size_t)t * D + c, v[j]);
-            }
-            float mean, rstd;
-            ln_stats16<NV>(v, mean, rstd, A.eps);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                const float4 yv = make_float4((v[j].x - mean) * rstd * gam[j].x + bet[j].x, (v[j].y - mean) * rstd * gam[j].y + bet[j].y,
-                                              (v[j].z - mean) * rstd * gam[j].z + bet[j].z, (v[j].w - mean) * rstd * gam[j].w + bet[j].w);
-                st4(A.y + (size_t)t * D + c, yv);
-                st4(R1 + row * LD + c, yv);
-            }
-            if (l16 == 0) { A.st1[2 * (size_t)t] = mean; A.st1[2 * (size_t)t + 1] = rstd; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) st4(R1 + row * LD + 4 * l16 + 64 * j, make_float4(0.f, 0.f, 0.f, 0.f));
-        }
-    }
-    __syncthreads();
+    ln_rowpass<D, false, true>(R2, LD, A.x, D, A.ln1_w, A.ln1_b, A.eps, A.u1, A.y, A.st1, R1, LD, t0, T, dodrop, rk, sP);
+    lds_barrier(); STAMP(3);
     // ---- linear1 + GELU + dropout
     {
         f32x16 acc[NVF];
@@ -155,24 +177,29 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
         mma_64xN<D, NVF>(R1, LD, A.w1, acc);
         acc_to_lds(acc, R2, LF, A.b1);
     }
-    __syncthreads();
+    lds_barrier(); STAMP(4);
+    {
+        float4 av[4][NVF];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 16 + rsub, t = t0 + row;
+        for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-        for (int j = 0; j < NVF; ++j) {
-            const int c = 4 * l16 + 64 * j;
-            const float4 av = ld4(R2 + row * LF + c);
-            float4 h = make_float4(gelu_erf(av.x), gelu_erf(av.y), gelu_erf(av.z), gelu_erf(av.w));
-            if (t < T) {
-                st4(A.a + (size_t)t * F + c, av);
+            for (int j = 0; j < NVF; ++j) av[ps][j] = ld4(R2 + (ps * 16 + rsub) * LF + 4 * l16 + 64 * j);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 16 + rsub, t = t0 + row;
+            const bool ok = t < T;
+#pragma unroll
+            for (int j = 0; j < NVF; ++j) {
+                const int c = 4 * l16 + 64 * j;
+                const float4 a4 = av[ps][j];
+                float4 h = make_float4(gelu_erf(a4.x), gelu_erf(a4.y), gelu_erf(a4.z), gelu_erf(a4.w));
                 if (dodrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); h.x *= m.x; h.y *= m.y; h.z *= m.z; h.w *= m.w; }
-                st4(A.h + (size_t)t * F + c, h);
+                if (ok) { st4(A.a + (size_t)t * F + c, a4); st4(A.h + (size_t)t * F + c, h); }
+                st4(R2 + row * LF + c, h);
             }
-            st4(R2 + row * LF + c, h);
         }
     }
-    __syncthreads();
+    lds_barrier(); STAMP(5);
     // ---- linear2 + dropout2 + residual + LayerNorm2
     {
         f32x16 acc[NV];
@@ -180,35 +207,9 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
         mma_64xN<F, NV>(R2, LF, A.w2, acc);
         acc_to_lds(acc, R0, LD, A.b2);
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { gam[j] = ld4(A.ln2_w + 4 * l16 + 64 * j); bet[j] = ld4(A.ln2_b + 4 * l16 + 64 * j); }
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 16 + rsub, t = t0 + row;
-        if (t < T) {
-            float4 v[NV];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                float4 o = ld4(R0 + row * LD + c);
-                if (dodrop) { const float4 m = drop4(rk, sF, (uint64_t)t * D + c); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
-                const float4 yr = ld4(R1 + row * LD + c);
-                v[j] = make_float4(yr.x + o.x, yr.y + o.y, yr.z + o.z, yr.w + o.w);
-                st4(A.u2 + (size_t)t * D + c, v[j]);
-            }
-            float mean, rstd;
-            ln_stats16<NV>(v, mean, rstd, A.eps);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                st4(A.z + (size_t)t * D + c,
-                    make_float4((v[j].x - mean) * rstd * gam[j].x + bet[j].x, (v[j].y - mean) * rstd * gam[j].y + bet[j].y,
-                                (v[j].z - mean) * rstd * gam[j].z + bet[j].z, (v[j].w - mean) * rstd * gam[j].w + bet[j].w));
-            }
-            if (l16 == 0) { A.st2[2 * (size_t)t] = mean; A.st2[2 * (size_t)t + 1] = rstd; }
-        }
-    }
+    lds_barrier(); STAMP(6);
+    ln_rowpass<D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
+    STAMP(15);
 }
 
 // LayerNorm backward of one row spread over a 16-lane group.  dzv: upstream grad, uv: LN input.
@@ -254,10 +255,68 @@ __device__ __forceinline__ void flush_affine(const float4 (&dgam)[NV], const flo
         const float4 b = make_float4(fold(dbet[j].x), fold(dbet[j].y), fold(dbet[j].z), fold(dbet[j].w));
         if (lane < 16) { st4(scr + w * 2 * D + c, a); st4(scr + w * 2 * D + D + c, b); }
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = threadIdx.x; i < 2 * D; i += 256)
         dst[i] = (scr[i] + scr[2 * D + i]) + (scr[4 * D + i] + scr[6 * D + i]);
-    __syncthreads();
+    lds_barrier();
+}
+
+// LayerNorm backward over the 64 rows of a tile with the four row passes of a thread issued together (see ln_rowpass).
+//   g = SRC_GLOBAL ? Gg[t] : La[row] + Lb[row];   du = LN'(g; u, mean, rstd, gamma)
+//   du -> DUg (global, optional) and DUl (LDS, optional);   du * dropout(site) -> DMg (global) and DMl (LDS)
+template <int D, bool SRC_GLOBAL>
+__device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, const float* __restrict__ La,
+                                               const float* __restrict__ Lb, int ldl, const float* __restrict__ Ug,
+                                               const float* __restrict__ ST, const float* __restrict__ lnw,
+                                               float* __restrict__ DUg, float* __restrict__ DUl, float* __restrict__ DMg,
+                                               float* __restrict__ DMl, float4 (&dgam)[D / 64], float4 (&dbet)[D / 64],
+                                               int t0, int T, bool dodrop, const RngKey& rk, uint32_t site) {
+    constexpr int NV = D / 64;
+    const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    float4 gam[NV], g[4][NV], u[4][NV];
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gam[j] = ld4(lnw + 4 * l16 + 64 * j);
+        dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dbet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        const bool ok = t < T;
+        mean[ps] = ok ? ST[2 * (size_t)t] : 0.f;
+        rstd[ps] = ok ? ST[2 * (size_t)t + 1] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * l16 + 64 * j;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            u[ps][j] = ok ? ld4(Ug + (size_t)t * D + c) : z4;
+            if (SRC_GLOBAL) g[ps][j] = ok ? ld4(Gg + (size_t)t * D + c) : z4;
+            else {
+                const float4 p0 = ld4(La + row * ldl + c), p1 = ld4(Lb + row * ldl + c);
+                g[ps][j] = ok ? make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w) : z4;
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) ln_bwd_row<NV>(g[ps], u[ps], mean[ps], rstd[ps], gam, dgam, dbet);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 16 + rsub, t = t0 + row;
+        const bool ok = t < T;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * l16 + 64 * j;
+            const float4 du = g[ps][j];
+            if (DUg && ok) st4(DUg + (size_t)t * D + c, du);
+            if (DUl) st4(DUl + row * ldl + c, du);
+            float4 dm = du;
+            if (dodrop) { const float4 m = drop4(rk, site, (uint64_t)t * D + c); dm.x *= m.x; dm.y *= m.y; dm.z *= m.z; dm.w *= m.w; }
+            if (ok) st4(DMg + (size_t)t * D + c, dm);
+            st4(DMl + row * ldl + c, dm);
+        }
+    }
 }
 
 template <int D, int F>
@@ -272,45 +331,10 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     const uint32_t sP = DR4SR_SITE_PROJ + 4 * A.layer, sA = DR4SR_SITE_ACT + 4 * A.layer, sF = DR4SR_SITE_FFN + 4 * A.layer;
-    float4 gam[NV], dgam[NV], dbet[NV];
+    float4 dgam[NV], dbet[NV];
 
-    // ---- LayerNorm2 backward: du2 -> global + R1 (residual branch); df = du2*mask -> R0
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        gam[j] = ld4(A.ln2_w + 4 * l16 + 64 * j);
-        dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        dbet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 16 + rsub, t = t0 + row;
-        if (t < T) {
-            float4 dzv[NV], uv[NV];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                dzv[j] = ld4(A.dz + (size_t)t * D + c);
-                uv[j] = ld4(A.u2 + (size_t)t * D + c);
-            }
-            const float mean = A.st2[2 * (size_t)t], rstd = A.st2[2 * (size_t)t + 1];
-            ln_bwd_row<NV>(dzv, uv, mean, rstd, gam, dgam, dbet);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                st4(R1 + row * LD + c, dzv[j]);
-                float4 df = dzv[j];
-                if (dodrop) { const float4 m = drop4(rk, sF, (uint64_t)t * D + c); df.x *= m.x; df.y *= m.y; df.z *= m.z; df.w *= m.w; }
-                st4(A.df + (size_t)t * D + c, df);
-                st4(R0 + row * LD + c, df);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                st4(R0 + row * LD + 4 * l16 + 64 * j, make_float4(0.f, 0.f, 0.f, 0.f));
-                st4(R1 + row * LD + 4 * l16 + 64 * j, make_float4(0.f, 0.f, 0.f, 0.f));
-            }
-        }
-    }
+    // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
+    ln_bwd_rowpass<D, true>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D);
     // ---- dh = df W2   (x W^T form with W2^T [F][D])
     {
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         mma_64xN_wT<D, NVF>(R0, LD, A.w2, F, acc);
         acc_to_lds(acc, R2, LF, nullptr);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- da = dh * mask_act * gelu'(a)
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
             st4(R2 + row * LF + c, d);
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- dy = da W1 + du2 ;  LayerNorm1 backward -> du1 ;  do = du1*mask -> R1
     {
         f32x16 acc[NV];
@@ -346,38 +370,8 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         mma_64xN_wT<F, NV>(R2, LF, A.w1, D, acc);
         acc_to_lds(acc, R0, LD, nullptr);
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        gam[j] = ld4(A.ln1_w + 4 * l16 + 64 * j);
-        dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        dbet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 16 + rsub, t = t0 + row;
-        if (t < T) {
-            float4 dyv[NV], uv[NV];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                const float4 p0 = ld4(R0 + row * LD + c), p1 = ld4(R1 + row * LD + c);
-                dyv[j] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
-                uv[j] = ld4(A.u1 + (size_t)t * D + c);
-            }
-            const float mean = A.st1[2 * (size_t)t], rstd = A.st1[2 * (size_t)t + 1];
-            ln_bwd_row<NV>(dyv, uv, mean, rstd, gam, dgam, dbet);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = 4 * l16 + 64 * j;
-                st4(A.du1 + (size_t)t * D + c, dyv[j]);
-                float4 dd = dyv[j];
-                if (dodrop) { const float4 m = drop4(rk, sP, (uint64_t)t * D + c); dd.x *= m.x; dd.y *= m.y; dd.z *= m.z; dd.w *= m.w; }
-                st4(A.dout + (size_t)t * D + c, dd);
-                st4(R1 + row * LD + c, dd);
-            }
-        }   // rows >= T of R1 are already zero
-    }
+    lds_barrier();
+    ln_bwd_rowpass<D, false>(nullptr, R0, R1, LD, A.u1, A.st1, A.ln1_w, A.du1, nullptr, A.dout, R1, dgam, dbet, t0, T, dodrop, rk, sP);
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D + 2 * D);
     // ---- dctx = do W_out
     {
@@ -386,7 +380,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         mma_64xN_wT<D, NV>(R1, LD, A.out_w, D, acc);
         acc_to_lds(acc, R0, LD, nullptr);
     }
-    __syncthreads();
+    lds_barrier();
     constexpr int C4 = D / 4;
     for (int i = threadIdx.x; i < 64 * C4; i += 256) {
         const int row = i / C4, c = (i % C4) * 4;
@@ -412,6 +406,7 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     A.df = lw.df; A.da = lw.da; A.du1 = lw.du1; A.dout = lw.dout; A.dctx = ws.dctx;
     A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 63) / 64) * 4 * p->D;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
+    A.stamps = getenv("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
     return A;
 }
 
@@ -450,12 +445,12 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQKV,
     float* As = smem;
     float* Cs = smem + 64 * LDA;
     load_tile<K>(As, LDA, dQKV, K, t0, T);
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[NV];
     acc_zero(acc);
     mma_64xN_wT<K, NV>(As, LDA, WT, D, acc);
     acc_to_lds(acc, Cs, LDC, nullptr);
-    __syncthreads();
+    lds_barrier();
     constexpr int C4 = D / 4;
     for (int i = threadIdx.x; i < 64 * C4; i += 256) {
         const int row = i / C4, c = (i % C4) * 4;
@@ -555,9 +550,9 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
     int tt = blockIdx.x;
     if (tt < ntiles) issue(tt);
     for (; tt < ntiles; tt += gridDim.x) {
-        __syncthreads();                                   // previous MFMA phase has finished reading LDS
+        lds_barrier();                                   // previous MFMA phase has finished reading LDS
         commit(tt);
-        __syncthreads();
+        lds_barrier();
         if (tt + (int)gridDim.x < ntiles) issue(tt + gridDim.x);
 #pragma unroll 4
         for (int s = 0; s < 32; ++s) {
@@ -617,10 +612,10 @@ __device__ __forceinline__ void reduce_jobs(const WgradArgs& A) {
         float c = 0.f, l = 0.f;
         for (int b = threadIdx.x; b < A.B; b += 256) { c += A.score_part[2 * b]; l += A.score_part[2 * b + 1]; }
         red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
-        __syncthreads();
+        lds_barrier();
         for (int o = 128; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
-            __syncthreads();
+            lds_barrier();
         }
         if (threadIdx.x == 0) { A.tail[0] += red[0]; A.tail[1] += red[256]; }
     }
@@ -668,7 +663,8 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
     static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 48;   // tuning knob
-    int gw = ntiles < gw_max ? ntiles : gw_max;
+    int gw_t = ntiles / 16 > gw_max ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : gw_max;   // >= 16 token tiles per workgroup at scale
+    int gw = ntiles < gw_t ? ntiles : gw_t;
     dim3 grid(gw, 7, p->n_layer), blk(256);
     const size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
     if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A); }
