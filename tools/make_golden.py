@@ -106,6 +106,37 @@ def build_dataset(root, n_items, seqlens, rng, dataset="amazon-toys", domain="to
     return train, val, test
 
 
+def build_dataset_fmlp(root, n_items, seqlens, rng, dataset="amazon-toys", domain="toy"):
+    """Per-prefix, LEFT-padded rows with a scalar target (dataset/dataset_transform.ipynb cell 3; README.md:78):
+    what FMLP needs because FMLP.forward returns x[:, -1] in train and eval (model/fmlp.py:38-39)."""
+    import torch
+    d = os.path.join(root, "dataset", dataset, domain)
+    os.makedirs(d, exist_ok=True)
+    lpad = lambda s: [0] * (L - len(s)) + list(s)
+    train, val, test = [], [], []
+    for u, sl in enumerate(seqlens, start=1):
+        full = rng.integers(1, n_items, size=sl + 3).tolist()
+        for k in range(1, sl + 1):                                  # one row per prefix
+            if sl > 10 and k < sl - 2:                              # fixture size: long users keep their last 3 prefixes
+                continue
+            train.append([u, lpad(full[:k][-L:]), full[k], min(k, L), 1, [0] * L])
+        vh = full[:sl + 1][-L:]
+        val.append([u, lpad(vh), full[sl + 1], len(vh), 1, [0] * L, lpad(vh)])
+        th = full[:sl + 2][-L:]
+        test.append([u, lpad(th), full[sl + 2], len(th), 1, [0] * L, lpad(th)])
+    torch.save(train, os.path.join(d, "train_ori.pth"))
+    torch.save(val, os.path.join(d, "val.pth"))
+    torch.save(test, os.path.join(d, "test.pth"))
+    with open(os.path.join(d, "inter.csv"), "w") as f:
+        f.write("user_id,item_id,rating,timestamp,domain\n")
+        nu = len(seqlens)
+        for i in range(1, n_items):
+            f.write(f"{(i - 1) % nu + 1},{i},1.0,{i},0\n")
+        for u in range(1, nu + 1):
+            f.write(f"{u},{(u % (n_items - 1)) + 1},1.0,{u},0\n")
+    return train, val, test
+
+
 # --------------------------------------------------------------------------- runner
 def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overrides=None):
     import torch
@@ -114,7 +145,7 @@ def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overr
     cwd = os.getcwd()
     try:
         os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
-        build_dataset(work, n_items, seqlens, rng)
+        (build_dataset_fmlp if model_name == "FMLP" else build_dataset)(work, n_items, seqlens, rng)
         os.chdir(work)
         from utils import load_config, setup_environment, prepare_datasets, prepare_model
         config = load_config({"model": model_name, "dataset": "amazon-toys"})
@@ -129,6 +160,10 @@ def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overr
         ds = prepare_datasets(config)
         model = prepare_model(config, ds)
         model._init_model(ds[0])
+        if model_name == "FMLP":          # FMLP hard-codes nn.Dropout(0.5) (model/fmlp.py:13, module/layers.py:744,767)
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
         # The reference zero-inits biases; perturb every parameter slightly so that
         # bias / LayerNorm-affine paths are actually pinned by the fixture.
         g = torch.Generator().manual_seed(seed + 1)
@@ -143,7 +178,7 @@ def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overr
             out["param." + k] = v.numpy()
 
         # ---- training batch = all rows, in dataset order (no shuffle) ----------------
-        loader = ds[0].get_loader(batch_size=len(seqlens), shuffle=False)
+        loader = ds[0].get_loader(batch_size=len(ds[0]), shuffle=False)
         batch = next(iter(loader))
         model.train()
         torch.manual_seed(seed + 2)
@@ -152,8 +187,16 @@ def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overr
             out["batch." + k] = v.numpy()
 
         cap = {}
-        enc = model.query_encoder
+        enc = getattr(model, "query_encoder", None)
         hooks = []
+        if model_name == "FMLP":
+            hooks.append(model.item_encoder.register_forward_pre_hook(
+                lambda m, a, kw: cap.__setitem__("x0", a[0].detach().clone()), with_kwargs=True))
+            for i, lyr in enumerate(model.item_encoder.layer):
+                hooks.append(lyr.filterlayer.register_forward_hook(
+                    lambda m, a, o, i=i: cap.__setitem__(f"filter{i}", o.detach().clone())))
+                hooks.append(lyr.register_forward_hook(
+                    lambda m, a, o, i=i: cap.__setitem__(f"layer{i}", o.detach().clone())))
         if model_name == "SASRec":
             hooks.append(enc.transformer_layer.register_forward_pre_hook(
                 lambda m, a, kw: cap.__setitem__("x0", kw["src"].detach().clone()), with_kwargs=True))
@@ -189,7 +232,7 @@ def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overr
         for n, p in model.named_parameters():
             out["adam1." + n] = p.detach().numpy().copy()
         # second step on the same batch (pins the moment/bias-correction recursion)
-        if model_name == "SASRec":
+        if model_name in ("SASRec", "FMLP"):
             model.optimizer.zero_grad()
             loss2 = model.training_step(batch)
             loss2.backward()
@@ -273,11 +316,16 @@ def main():
     _install_stubs()
     sys.path.insert(0, REF)
     seqlens = [1, 2, 3, 5, 8, 13, 21, 34, 47, 49, 50, 4, 2, 50]
+    only = os.environ.get("GOLDEN_ONLY")
+    if only == "fmlp":
+        run_case(out_dir, "fmlp_d64", "FMLP", n_items=113, seqlens=[1, 3, 6, 50, 2], embed_dim=64, seed=14)
+        return
     run_case(out_dir, "sasrec_d64", "SASRec", n_items=211, seqlens=seqlens, embed_dim=64, seed=11)
     run_case(out_dir, "sasrec_d128", "SASRec", n_items=97, seqlens=seqlens[:9], embed_dim=128, seed=12)
     # GRU4Rec: hidden 128 instead of configs/gru4rec.yaml's 256 only to keep the fixture small
     run_case(out_dir, "gru4rec_d64", "GRU4Rec", n_items=131, seqlens=seqlens[:10], embed_dim=64, seed=13,
              overrides={"model": {"hidden_size": 128}})
+    run_case(out_dir, "fmlp_d64", "FMLP", n_items=113, seqlens=[1, 3, 6, 50, 2], embed_dim=64, seed=14)
     neg_sampler_stats(out_dir)
 
 
