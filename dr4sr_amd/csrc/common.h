@@ -219,6 +219,34 @@ __device__ __forceinline__ void ln_stats16(const float4 (&v)[NV], float& mean, f
     rstd = 1.0f / sqrtf(group16_sum(q) * invD + eps);
 }
 
+// LayerNorm backward of one row spread over a 16-lane group.  dzv: upstream grad, uv: LN input.
+// Returns du in dzv; accumulates affine partials.
+template <int NV>
+__device__ __forceinline__ void ln_bwd_row(float4 (&dzv)[NV], const float4 (&uv)[NV], float mean, float rstd,
+                                           const float4 (&gam)[NV], float4 (&dgam)[NV], float4 (&dbet)[NV]) {
+    constexpr float invD = 1.0f / (64 * NV);
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        xh[j] = make_float4((uv[j].x - mean) * rstd, (uv[j].y - mean) * rstd, (uv[j].z - mean) * rstd, (uv[j].w - mean) * rstd);
+        g[j] = make_float4(dzv[j].x * gam[j].x, dzv[j].y * gam[j].y, dzv[j].z * gam[j].z, dzv[j].w * gam[j].w);
+        s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+        dgam[j].x += dzv[j].x * xh[j].x; dgam[j].y += dzv[j].y * xh[j].y; dgam[j].z += dzv[j].z * xh[j].z; dgam[j].w += dzv[j].w * xh[j].w;
+        dbet[j].x += dzv[j].x; dbet[j].y += dzv[j].y; dbet[j].z += dzv[j].z; dbet[j].w += dzv[j].w;
+    }
+    s1 = group16_sum(s1) * invD;
+    s2 = group16_sum(s2) * invD;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        dzv[j].x = rstd * (g[j].x - s1 - xh[j].x * s2);
+        dzv[j].y = rstd * (g[j].y - s1 - xh[j].y * s2);
+        dzv[j].z = rstd * (g[j].z - s1 - xh[j].z * s2);
+        dzv[j].w = rstd * (g[j].w - s1 - xh[j].w * s2);
+    }
+}
+
 // dynamic LDS above 64 KiB has to be opted into per kernel (gfx950 has 160 KiB per CU)
 void big_lds_impl(const void* kernel, size_t bytes);      // step.hip: remembers what was granted per kernel
 template <typename K>

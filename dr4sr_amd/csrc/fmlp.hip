@@ -1,0 +1,573 @@
+// fmlp.hip — FMLP target model (reference model/fmlp.py:18-39, module/layers.py:740-807) on gfx950.
+//
+// The spectral FilterLayer  irfft(rfft(x, dim=seq, 'ortho') * W, 'ortho')  is, per feature d, a circular convolution
+// along the sequence with the real kernel
+//     m[r,d] = (1/L) sum_k c_k (Wre[k,d] cos(2 pi k r / L) - Wim[k,d] sin(2 pi k r / L)),   c_0 = c_{L/2} = 1, else 2
+// (irfft ignores the imaginary part of the DC and Nyquist bins).  k_fmlp_coef builds m from the complex weight once per
+// step; k_fmlp_filter_fwd/bwd apply it (and its transpose) with the whole [L x 64] sequence tile resident in LDS, fused
+// with dropout + residual + LayerNorm; the weight gradient is accumulated as dm and folded back to d(complex weight) by
+// k_fmlp_coef_bwd.  The Intermediate block re-uses the MFMA tile kernels of linear.hip (FFN_ONLY instantiation, F = 256).
+// All B*L positions are computed: FMLP rows are left-padded prefixes and the filter mixes every position.
+#include "common.h"
+#include "kernels.h"
+
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+#define FM_D 64
+#define FM_F 256
+#define FS_EMB 0u
+#define FS_FILT(l) (1u + 2u * (l))
+#define FS_FFN(l) (2u + 2u * (l))
+
+struct FmlpLayerWs {
+    float* uf; float* stf; float* xf;        // filter: LN input, (mean,rstd), LN output (= Intermediate input)
+    float* a; float* h; float* u2; float* st2;
+    float* df; float* da; float* dxf;        // grads: d(dense_2 out)*mask, d(pre-activation), d(xf)
+};
+struct FmlpWs {
+    int64_t off[4 + 9 * DR4SR_MAX_LAYERS];
+    int64_t n_params;
+    int Tn;
+    float* e0; float* st0;
+    float* X[DR4SR_MAX_LAYERS + 1]; float* dX[DR4SR_MAX_LAYERS + 1];
+    float* m; float* dm;                      // [n_layer][L][D]
+    float* score_part; float* ln_part;        // [B][2]; [n_layer][ntiles][4][D]
+    FmlpLayerWs layer[DR4SR_MAX_LAYERS];
+    int64_t bytes;
+};
+enum { FP_CW = 0, FP_FLN_W, FP_FLN_B, FP_W1, FP_B1, FP_W2, FP_B2, FP_ILN_W, FP_ILN_B };
+static inline int64_t foff(const FmlpWs& ws, int l, int j) { return ws.off[4 + 9 * l + j]; }
+
+extern "C" int dr4sr_fmlp_plan_sizeof(void) { return (int)sizeof(dr4sr_fmlp_plan); }
+
+extern "C" int64_t dr4sr_fmlp_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer, int64_t* off) {
+    int64_t o = 0;
+    auto put = [&](int i, int64_t n) { if (off) off[i] = o; o += n; };
+    put(0, (int64_t)n_items * D); put(1, (int64_t)L * D); put(2, D); put(3, D);
+    for (int l = 0; l < n_layer; ++l) {
+        const int b = 4 + 9 * l;
+        put(b + FP_CW, (int64_t)(L / 2 + 1) * D * 2); put(b + FP_FLN_W, D); put(b + FP_FLN_B, D);
+        put(b + FP_W1, (int64_t)F * D); put(b + FP_B1, F); put(b + FP_W2, (int64_t)D * F); put(b + FP_B2, D);
+        put(b + FP_ILN_W, D); put(b + FP_ILN_B, D);
+    }
+    return o;
+}
+
+static int fmlp_check(const dr4sr_fmlp_plan* p) {
+    if (!p || p->abi_version != DR4SR_ABI_VERSION) return DR4SR_E_ARG;
+    if (p->B <= 0 || p->n_items < 2 || p->n_layer <= 0 || p->n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    if (p->D != FM_D || p->F != FM_F || p->L <= 0 || p->L > 50 || (p->L & 1)) return DR4SR_E_SHAPE;
+    if (!(p->p_drop >= 0.f && p->p_drop < 1.f) || !p->params || !p->state || !p->in_item_id) return DR4SR_E_ARG;
+    return 0;
+}
+
+static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
+    const int64_t D = p->D, F = p->F, Tn = (int64_t)p->B * p->L;
+    ws->n_params = dr4sr_fmlp_param_layout(p->n_items, p->L, p->D, p->F, p->n_layer, ws->off);
+    ws->Tn = (int)Tn;
+    char* base = (char*)p->workspace;
+    int64_t o = 0;
+    auto take = [&](int64_t nfloat) -> float* {
+        float* r = base ? (float*)(base + o) : nullptr;
+        o += ((nfloat * 4 + 255) / 256) * 256;
+        return r;
+    };
+    ws->e0 = take(Tn * D); ws->st0 = take(Tn * 2);
+    for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tn * D); ws->dX[i] = take(Tn * D); }
+    ws->m = take((int64_t)p->n_layer * p->L * D); ws->dm = take((int64_t)p->n_layer * p->L * D);
+    ws->score_part = take(2LL * p->B);
+    ws->ln_part = take((int64_t)p->n_layer * ((Tn + 63) / 64) * 4 * D);
+    for (int l = 0; l < p->n_layer; ++l) {
+        FmlpLayerWs& w = ws->layer[l];
+        w.uf = take(Tn * D); w.stf = take(Tn * 2); w.xf = take(Tn * D);
+        w.a = take(Tn * F); w.h = take(Tn * F); w.u2 = take(Tn * D); w.st2 = take(Tn * 2);
+        w.df = take(Tn * D); w.da = take(Tn * F); w.dxf = take(Tn * D);
+    }
+    ws->bytes = o;
+}
+
+extern "C" int64_t dr4sr_fmlp_workspace_bytes(const dr4sr_fmlp_plan* plan) {
+    if (!plan || plan->B <= 0 || plan->L <= 0 || plan->n_layer <= 0 || plan->n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    dr4sr_fmlp_plan q = *plan;
+    q.workspace = nullptr;
+    FmlpWs ws;
+    fmlp_carve(&q, &ws);
+    return ws.bytes;
+}
+
+static int fmlp_ws(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
+    int rc = fmlp_check(p);
+    if (rc) return rc;
+    if (!p->workspace) return DR4SR_E_ARG;
+    fmlp_carve(p, ws);
+    return ws->bytes > p->workspace_bytes ? DR4SR_E_WS : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ prep + coefficients
+// block 0: state[T] = B*L, RNG bump; blocks 1..: zero the flat gradient (+tail)
+__global__ __launch_bounds__(1024) void k_fmlp_prep(int* __restrict__ state, int Tn, int bump, float* __restrict__ zero, int64_t n4) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { state[DR4SR_STATE_T] = Tn; if (bump) state[DR4SR_STATE_RNGSTEP] += 1; }
+        return;
+    }
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < n4; i += (int64_t)(gridDim.x - 1) * 1024)
+        st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+// m[l][r][d] from complex_weight[k][d][2]; also zeroes dm.  grid = n_layer, 256 threads.
+__global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ params, int64_t o_cw0, int64_t layer_stride,
+                                                   float* __restrict__ m, float* __restrict__ dm, int L) {
+    __shared__ float ct[64], sn[64];
+    const int layer = blockIdx.x, K = L / 2 + 1;
+    if ((int)threadIdx.x < L) sincospif(2.0f * threadIdx.x / (float)L, &sn[threadIdx.x], &ct[threadIdx.x]);
+    __syncthreads();
+    const float* cw = params + o_cw0 + layer * layer_stride;
+    for (int i = threadIdx.x; i < L * FM_D; i += 256) {
+        const int r = i / FM_D, d = i % FM_D;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int j = (k * r) % L;
+            const float c = (k == 0 || 2 * k == L) ? 1.f : 2.f;
+            acc += c * (cw[(k * FM_D + d) * 2] * ct[j] - cw[(k * FM_D + d) * 2 + 1] * sn[j]);
+        }
+        m[(size_t)layer * L * FM_D + i] = acc / (float)L;
+        dm[(size_t)layer * L * FM_D + i] = 0.f;
+    }
+}
+// d(complex_weight) += fold(dm)
+__global__ __launch_bounds__(256) void k_fmlp_coef_bwd(float* __restrict__ grads, int64_t o_cw0, int64_t layer_stride,
+                                                       const float* __restrict__ dm, int L) {
+    __shared__ float ct[64], sn[64];
+    const int layer = blockIdx.x, K = L / 2 + 1;
+    if ((int)threadIdx.x < L) sincospif(2.0f * threadIdx.x / (float)L, &sn[threadIdx.x], &ct[threadIdx.x]);
+    __syncthreads();
+    float* g = grads + o_cw0 + layer * layer_stride;
+    const float* dml = dm + (size_t)layer * L * FM_D;
+    for (int i = threadIdx.x; i < K * FM_D; i += 256) {
+        const int k = i / FM_D, d = i % FM_D;
+        float gr = 0.f, gi = 0.f;
+        for (int r = 0; r < L; ++r) {
+            const int j = (k * r) % L;
+            const float v = dml[r * FM_D + d];
+            gr += ct[j] * v;
+            gi -= sn[j] * v;
+        }
+        const float c = ((k == 0 || 2 * k == L) ? 1.f : 2.f) / (float)L;
+        g[(k * FM_D + d) * 2] += c * gr;
+        g[(k * FM_D + d) * 2 + 1] += c * gi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding + LayerNorm
+struct FEmbArgs {
+    const float* E; const float* P; const float* lnw; const float* lnb;
+    const int64_t* idx; const int64_t* rows;
+    float* e0; float* st0; float* x0;
+    const float* dx0; float* dE; float* dP; float* dlnw; float* dlnb;
+    int B, L, n_items; float eps; const int* state; uint64_t seed; float p; int training;
+};
+
+__global__ __launch_bounds__(256) void k_fmlp_embed_fwd(const FEmbArgs A) {
+    const int l16 = threadIdx.x & 15, c = 4 * l16;
+    const int64_t Tn = (int64_t)A.B * A.L;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const float4 gam = ld4(A.lnw + c), bet = ld4(A.lnb + c);
+    for (int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); t < Tn; t += (int64_t)gridDim.x * 16) {
+        const int b = (int)(t / A.L), l = (int)(t % A.L);
+        const int64_t row = A.rows ? A.rows[b] : b;
+        int64_t id = A.idx[row * A.L + l];
+        id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
+        const float4 e = ld4(A.E + id * FM_D + c), pe = ld4(A.P + (size_t)l * FM_D + c);
+        float4 v[1] = {make_float4(e.x + pe.x, e.y + pe.y, e.z + pe.z, e.w + pe.w)};
+        st4(A.e0 + t * FM_D + c, v[0]);
+        float mean, rstd;
+        ln_stats16<1>(v, mean, rstd, A.eps);
+        float4 y = make_float4((v[0].x - mean) * rstd * gam.x + bet.x, (v[0].y - mean) * rstd * gam.y + bet.y,
+                               (v[0].z - mean) * rstd * gam.z + bet.z, (v[0].w - mean) * rstd * gam.w + bet.w);
+        if (dodrop) { const float4 mk = drop4(rk, FS_EMB, (uint64_t)t * FM_D + c); y.x *= mk.x; y.y *= mk.y; y.z *= mk.z; y.w *= mk.w; }
+        st4(A.x0 + t * FM_D + c, y);
+        if (l16 == 0) { A.st0[2 * t] = mean; A.st0[2 * t + 1] = rstd; }
+    }
+}
+
+// backward: g = dx0*mask -> LN' -> de;  dE[idx] += de (idx != 0), dP[pos] += de, LN affine grads.
+// Block-strided over sequences; dP and the affine grads are accumulated in registers and added once per block.
+__global__ __launch_bounds__(256) void k_fmlp_embed_bwd(const FEmbArgs A) {
+    __shared__ float scr[4 * 2 * FM_D];
+    const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4, c = 4 * l16;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const float4 gamv = ld4(A.lnw + c);
+    float4 gam[1] = {gamv}, dgam[1] = {make_float4(0.f, 0.f, 0.f, 0.f)}, dbet[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4 accP[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accP[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+        const int64_t row = A.rows ? A.rows[b] : b;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int l = ps * 16 + rsub;
+            if (l < A.L) {                               // uniform per 16-lane group
+                const int64_t t = (int64_t)b * A.L + l;
+                float4 g[1] = {ld4(A.dx0 + t * FM_D + c)};
+                if (dodrop) { const float4 mk = drop4(rk, FS_EMB, (uint64_t)t * FM_D + c); g[0].x *= mk.x; g[0].y *= mk.y; g[0].z *= mk.z; g[0].w *= mk.w; }
+                const float4 u[1] = {ld4(A.e0 + t * FM_D + c)};
+                ln_bwd_row<1>(g, u, A.st0[2 * t], A.st0[2 * t + 1], gam, dgam, dbet);
+                accP[ps].x += g[0].x; accP[ps].y += g[0].y; accP[ps].z += g[0].z; accP[ps].w += g[0].w;
+                const int64_t id = A.idx[row * A.L + l];
+                if (id > 0 && id < A.n_items) {
+                    float* d = A.dE + id * FM_D + c;
+                    unsafeAtomicAdd(d, g[0].x); unsafeAtomicAdd(d + 1, g[0].y); unsafeAtomicAdd(d + 2, g[0].z); unsafeAtomicAdd(d + 3, g[0].w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int l = ps * 16 + rsub;
+        if (l < A.L) {
+            float* d = A.dP + (size_t)l * FM_D + c;
+            unsafeAtomicAdd(d, accP[ps].x); unsafeAtomicAdd(d + 1, accP[ps].y); unsafeAtomicAdd(d + 2, accP[ps].z); unsafeAtomicAdd(d + 3, accP[ps].w);
+        }
+    }
+    // fold the 16 row groups -> one [2*D] row in LDS, then one atomic per column per block
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+        const float4 a = make_float4(fold(dgam[0].x), fold(dgam[0].y), fold(dgam[0].z), fold(dgam[0].w));
+        const float4 bb = make_float4(fold(dbet[0].x), fold(dbet[0].y), fold(dbet[0].z), fold(dbet[0].w));
+        if (lane < 16) { st4(scr + w * 2 * FM_D + c, a); st4(scr + w * 2 * FM_D + FM_D + c, bb); }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * FM_D; i += 256) {
+            const float v = (scr[i] + scr[2 * FM_D + i]) + (scr[4 * FM_D + i] + scr[6 * FM_D + i]);
+            unsafeAtomicAdd((i < FM_D ? A.dlnw : A.dlnb - FM_D) + i, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ filter layer
+struct FFiltArgs {
+    const float* m; float* dm;                 // this layer's [L][D]
+    const float* x; const float* lnw; const float* lnb;
+    float* uf; float* stf; float* xf;          // forward outputs
+    const float* dxf; float* dx; float* dlnw; float* dlnb;   // backward
+    int B, L; float eps; const int* state; uint64_t seed; float p; int training; uint32_t site;
+};
+
+// one workgroup per sequence; thread (d = lane, g = wave) owns rows l = g, g+4, ...
+__global__ __launch_bounds__(256) void k_fmlp_filter_fwd(const FFiltArgs A) {
+    const int L = A.L, b = blockIdx.x, d = threadIdx.x & 63, g = threadIdx.x >> 6;
+    float* ML = smem;                          // [L][64]
+    float* X2 = ML + L * FM_D;                 // [2L][64]   x twice: x[(l-r) mod L] = X2[l - r + L]
+    const float* xb = A.x + (size_t)b * L * FM_D;
+    for (int i = threadIdx.x; i < L * FM_D / 4; i += 256) {
+        st4(ML + 4 * i, ld4(A.m + 4 * i));
+        const float4 v = ld4(xb + 4 * i);
+        st4(X2 + 4 * i, v);
+        st4(X2 + L * FM_D + 4 * i, v);
+    }
+    __syncthreads();
+    float acc[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+    for (int r = 0; r < L; ++r) {
+        const float mr = ML[r * FM_D + d];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const int l = g + 4 * i;
+            if (l < L) acc[i] += mr * X2[(l - r + L) * FM_D + d];
+        }
+    }
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const float gam = A.lnw[d], bet = A.lnb[d];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int l = g + 4 * i;
+        if (l < L) {                               // wave-uniform
+            const size_t t = (size_t)b * L + l;
+            float y = acc[i];
+            if (dodrop) y *= drop1(rk, A.site, (uint64_t)t * FM_D + d);
+            const float u = y + X2[l * FM_D + d];
+            const float mean = wave_sum(u) * (1.0f / FM_D);
+            const float dv = u - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum(dv * dv) * (1.0f / FM_D) + A.eps);
+            A.uf[t * FM_D + d] = u;
+            A.xf[t * FM_D + d] = dv * rstd * gam + bet;
+            if (d == 0) { A.stf[2 * t] = mean; A.stf[2 * t + 1] = rstd; }
+        }
+    }
+}
+
+// backward; block-strided over sequences so that dm and the LN affine grads cost one atomic per block
+__global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
+    const int L = A.L, d = threadIdx.x & 63, g = threadIdx.x >> 6;
+    float* ML = smem;                          // [L][64]
+    float* X2 = ML + L * FM_D;                 // [2L][64]
+    float* DY2 = X2 + 2 * L * FM_D;            // [2L][64]  dy twice: dy[(l'+r) mod L] = DY2[l' + r]
+    float* red = DY2 + 2 * L * FM_D;           // [4][2][64]
+    for (int i = threadIdx.x; i < L * FM_D / 4; i += 256) st4(ML + 4 * i, ld4(A.m + 4 * i));
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const float gam = A.lnw[d];
+    float dgam = 0.f, dbet = 0.f;
+    float dmacc[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) dmacc[i] = 0.f;
+    for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+        __syncthreads();                           // previous iteration finished with X2 / DY2
+        const float* xb = A.x + (size_t)b * L * FM_D;
+        for (int i = threadIdx.x; i < L * FM_D / 4; i += 256) {
+            const float4 v = ld4(xb + 4 * i);
+            st4(X2 + 4 * i, v);
+            st4(X2 + L * FM_D + 4 * i, v);
+        }
+        float du[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const int l = g + 4 * i;
+            du[i] = 0.f;
+            if (l < L) {
+                const size_t t = (size_t)b * L + l;
+                const float dz = A.dxf[t * FM_D + d];
+                const float mean = A.stf[2 * t], rstd = A.stf[2 * t + 1];
+                const float xh = (A.uf[t * FM_D + d] - mean) * rstd;
+                const float gg = dz * gam;
+                const float s1 = wave_sum(gg) * (1.0f / FM_D), s2 = wave_sum(gg * xh) * (1.0f / FM_D);
+                dgam += dz * xh;
+                dbet += dz;
+                du[i] = rstd * (gg - s1 - xh * s2);
+                float dy = du[i];
+                if (dodrop) dy *= drop1(rk, A.site, (uint64_t)t * FM_D + d);
+                DY2[l * FM_D + d] = dy;
+                DY2[(l + L) * FM_D + d] = dy;
+            }
+        }
+        __syncthreads();
+        // dx[l'] = du[l'] + sum_r m[r] dy[(l'+r) mod L]
+        float acc[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) acc[i] = du[i];
+        for (int r = 0; r < L; ++r) {
+            const float mr = ML[r * FM_D + d];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                const int l = g + 4 * i;
+                if (l < L) acc[i] += mr * DY2[(l + r) * FM_D + d];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const int l = g + 4 * i;
+            if (l < L) A.dx[((size_t)b * L + l) * FM_D + d] = acc[i];
+        }
+        // dm[r] += sum_l dy[l] x[(l-r) mod L]   (this thread owns r = g + 4i)
+        for (int l = 0; l < L; ++l) {
+            const float dyl = DY2[l * FM_D + d];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                const int r = g + 4 * i;
+                if (r < L) dmacc[i] += dyl * X2[(l - r + L) * FM_D + d];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int r = g + 4 * i;
+        if (r < L) unsafeAtomicAdd(A.dm + r * FM_D + d, dmacc[i]);
+    }
+    __syncthreads();
+    red[(g * 2) * FM_D + d] = dgam;
+    red[(g * 2 + 1) * FM_D + d] = dbet;
+    __syncthreads();
+    if (threadIdx.x < 2 * FM_D) {
+        const int which = threadIdx.x >> 6, dd = threadIdx.x & 63;
+        const float v = (red[(0 + which) * FM_D + dd] + red[(2 + which) * FM_D + dd]) + (red[(4 + which) * FM_D + dd] + red[(6 + which) * FM_D + dd]);
+        unsafeAtomicAdd((which == 0 ? A.dlnw : A.dlnb) + dd, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scorer (1-D targets)
+// one wave per row b: q = z[b, L-1, :];  loss / gradient as model/basemodel.py:204-214 + loss_func.py:9-38 with pos [B], neg [B,1]
+#define DR4SR_SITE_NEG_F 0x4e454722u
+__global__ __launch_bounds__(256) void k_fmlp_score(const float* __restrict__ Z, const float* __restrict__ E, float* __restrict__ dE,
+                                                    float* __restrict__ dZ, const int64_t* __restrict__ target,
+                                                    const int64_t* __restrict__ rows, int64_t* __restrict__ neg_item, int sample_neg,
+                                                    float* __restrict__ part, const int* __restrict__ state, uint64_t seed,
+                                                    int n_items, int B, int L) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int64_t row = rows ? rows[b] : b;
+    const int64_t tgt = target[row];
+    int64_t ng;
+    if (sample_neg) {
+        const RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], 0.f);
+        const uint4 r = rng_call(rk, DR4SR_SITE_NEG_F, (uint64_t)b >> 2);
+        const uint32_t cc = b & 3, wv = cc == 0 ? r.x : cc == 1 ? r.y : cc == 2 ? r.z : r.w;
+        ng = 1 + (int64_t)__umulhi(wv, (uint32_t)(n_items - 1));
+        if (lane == 0) neg_item[b] = ng;
+    } else {
+        ng = neg_item[b];
+    }
+    ng = ng < 0 ? 0 : (ng >= n_items ? n_items - 1 : ng);
+    float* dzb = dZ + (size_t)b * L * FM_D;
+    for (int i = lane; i < (L - 1) * FM_D / 4; i += 64) st4(dzb + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    const size_t tl = ((size_t)b * L + L - 1) * FM_D;
+    float cnt = 0.f, ls = 0.f;
+    if (tgt > 0 && tgt < n_items) {
+        const float q = Z[tl + lane], ep = E[tgt * FM_D + lane], en = E[ng * FM_D + lane];
+        const float sp = wave_sum(q * ep), sn = wave_sum(q * en);
+        ls = softplus_f(-sp) + softplus_f(sn);
+        cnt = 1.f;
+        const float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn);
+        dZ[tl + lane] = dpos * ep + dneg * en;
+        unsafeAtomicAdd(dE + tgt * FM_D + lane, dpos * q);
+        unsafeAtomicAdd(dE + ng * FM_D + lane, dneg * q);
+    } else {
+        dZ[tl + lane] = 0.f;
+    }
+    if (lane == 0) { part[2 * b] = cnt; part[2 * b + 1] = ls; }
+}
+
+// out[b,:] = X[b, L-1, :]  /  dX[b, l, :] = (l == L-1) ? d_out[b,:] : 0
+__global__ void k_fmlp_last(const float* __restrict__ X, float* __restrict__ out, int B, int L) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * FM_D; i += gridDim.x * blockDim.x)
+        out[i] = X[((size_t)(i / FM_D) * L + L - 1) * FM_D + (i % FM_D)];
+}
+__global__ void k_fmlp_last_bwd(const float* __restrict__ dout, float* __restrict__ dX, int B, int L) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)B * L * FM_D; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / FM_D;
+        const int l = (int)(t % L);
+        dX[i] = l == L - 1 ? dout[(t / L) * FM_D + (i % FM_D)] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ orchestration
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int zero_grads, hipStream_t s) {
+    const int L = p->L, nl = p->n_layer;
+    const int64_t n4 = zero_grads ? (ws.n_params + DR4SR_GRAD_TAIL) / 4 : 0;
+    int zb = (int)((n4 + 1023) / 1024); if (zb > 255) zb = 255;
+    hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb), dim3(1024), 0, s, p->state, ws.Tn, training ? 1 : 0, zero_grads ? p->grads : nullptr, n4);
+    const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
+    hipLaunchKernelGGL(k_fmlp_coef, dim3(nl), dim3(256), 0, s, p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L);
+    FEmbArgs E{};
+    E.E = p->params + ws.off[0]; E.P = p->params + ws.off[1]; E.lnw = p->params + ws.off[2]; E.lnb = p->params + ws.off[3];
+    E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0; E.x0 = ws.X[0];
+    E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
+    int eb = (ws.Tn + 15) / 16; if (eb > 2048) eb = 2048;
+    hipLaunchKernelGGL(k_fmlp_embed_fwd, dim3(eb), dim3(256), 0, s, E);
+    for (int l = 0; l < nl; ++l) {
+        const FmlpLayerWs& w = ws.layer[l];
+        FFiltArgs Fa{};
+        Fa.m = ws.m + (size_t)l * L * FM_D; Fa.x = ws.X[l];
+        Fa.lnw = p->params + foff(ws, l, FP_FLN_W); Fa.lnb = p->params + foff(ws, l, FP_FLN_B);
+        Fa.uf = w.uf; Fa.stf = w.stf; Fa.xf = w.xf; Fa.B = p->B; Fa.L = L; Fa.eps = p->ln_eps; Fa.state = p->state; Fa.seed = p->seed;
+        Fa.p = p->p_drop; Fa.training = training; Fa.site = FS_FILT(l);
+        const size_t lds = sizeof(float) * 3 * L * FM_D;
+        hipLaunchKernelGGL(k_fmlp_filter_fwd, dim3(p->B), dim3(256), lds, s, Fa);
+        PostArgs A{};
+        A.x = w.xf; A.w1 = p->params + foff(ws, l, FP_W1); A.b1 = p->params + foff(ws, l, FP_B1);
+        A.w2 = p->params + foff(ws, l, FP_W2); A.b2 = p->params + foff(ws, l, FP_B2);
+        A.ln2_w = p->params + foff(ws, l, FP_ILN_W); A.ln2_b = p->params + foff(ws, l, FP_ILN_B);
+        A.a = w.a; A.h = w.h; A.u2 = w.u2; A.st2 = w.st2; A.z = ws.X[l + 1];
+        A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
+        A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr;
+        RC(launch_ffn_fwd(A, ws.Tn, s));
+    }
+    return DR4SR_LAUNCH_CHECK();
+}
+
+static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int with_score, hipStream_t s) {
+    const int L = p->L, nl = p->n_layer;
+    const int ntiles = (ws.Tn + 63) / 64;
+    for (int l = nl - 1; l >= 0; --l) {
+        const FmlpLayerWs& w = ws.layer[l];
+        PostArgs A{};
+        A.dz = ws.dX[l + 1]; A.u2 = w.u2; A.st2 = w.st2; A.ln2_w = p->params + foff(ws, l, FP_ILN_W);
+        A.a = w.a; A.w1 = p->params + foff(ws, l, FP_W1); A.w2 = p->params + foff(ws, l, FP_W2);
+        A.df = w.df; A.da = w.da; A.du1 = w.dxf;
+        A.ln_part = ws.ln_part + (size_t)l * ntiles * 4 * FM_D;
+        A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
+        A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr;
+        RC(launch_ffn_bwd(A, ws.Tn, s));
+        FFiltArgs Fa{};
+        Fa.m = ws.m + (size_t)l * L * FM_D; Fa.dm = ws.dm + (size_t)l * L * FM_D; Fa.x = ws.X[l];
+        Fa.lnw = p->params + foff(ws, l, FP_FLN_W); Fa.uf = w.uf; Fa.stf = w.stf;
+        Fa.dxf = w.dxf; Fa.dx = ws.dX[l]; Fa.dlnw = p->grads + foff(ws, l, FP_FLN_W); Fa.dlnb = p->grads + foff(ws, l, FP_FLN_B);
+        Fa.B = p->B; Fa.L = L; Fa.eps = p->ln_eps; Fa.state = p->state; Fa.seed = p->seed; Fa.p = p->p_drop; Fa.training = training;
+        Fa.site = FS_FILT(l);
+        const size_t lds = sizeof(float) * (5 * L * FM_D + 8 * FM_D);
+        big_lds(k_fmlp_filter_bwd, lds);
+        const int gb = p->B < 128 ? p->B : 128;
+        hipLaunchKernelGGL(k_fmlp_filter_bwd, dim3(gb), dim3(256), lds, s, Fa);
+    }
+    FEmbArgs E{};
+    E.lnw = p->params + ws.off[2]; E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0;
+    E.dx0 = ws.dX[0]; E.dE = p->grads + ws.off[0]; E.dP = p->grads + ws.off[1]; E.dlnw = p->grads + ws.off[2]; E.dlnb = p->grads + ws.off[3];
+    E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
+    hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < 64 ? p->B : 64), dim3(256), 0, s, E);
+    const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
+    hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
+    WgradArgs W{};
+    for (int l = 0; l < nl; ++l) {
+        const FmlpLayerWs& w = ws.layer[l];
+        WgradJob& J1 = W.job[l * 6 + 4];
+        J1.G = w.da; J1.ldg = FM_F; J1.gcol = 0; J1.X = w.xf; J1.ldx = FM_D;
+        J1.dW = p->grads + foff(ws, l, FP_W1); J1.db = p->grads + foff(ws, l, FP_B1);
+        WgradJob& J2 = W.job[l * 6 + 5];
+        J2.G = w.df; J2.ldg = FM_D; J2.gcol = 0; J2.X = w.h; J2.ldx = FM_F;
+        J2.dW = p->grads + foff(ws, l, FP_W2); J2.db = p->grads + foff(ws, l, FP_B2);
+    }
+    W.state = p->state; W.seed = p->seed; W.p = p->p_drop; W.training = training;
+    W.ln_part = ws.ln_part; W.ln_layer_stride = (int64_t)ntiles * 4 * FM_D; W.grads = p->grads;
+    W.o_ln1_w = foff(ws, 0, FP_ILN_W); W.layer_stride = lstride;
+    W.score_part = with_score ? ws.score_part : nullptr; W.tail = p->grads + ws.n_params; W.B = p->B; W.D = FM_D;
+    RC(launch_fmlp_wgrad(W, ws.Tn, nl, s));
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_fmlp_fwd_bwd(const dr4sr_fmlp_plan* plan, void* stream) {
+    FmlpWs ws;
+    RC(fmlp_ws(plan, &ws));
+    if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(fmlp_forward(plan, ws, 1, 1, s));
+    hipLaunchKernelGGL(k_fmlp_score, dim3((plan->B + 3) / 4), dim3(256), 0, s, ws.X[plan->n_layer], plan->params + ws.off[0],
+                       plan->grads + ws.off[0], ws.dX[plan->n_layer], plan->item_id, plan->rows, plan->neg_item, plan->sample_neg,
+                       ws.score_part, plan->state, plan->seed, plan->n_items, plan->B, plan->L);
+    return fmlp_backward(plan, ws, 1, 1, s);
+}
+
+extern "C" int dr4sr_adam_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    return launch_adam_flat(params, grads, adam_m, adam_v, n, state, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+}
+
+extern "C" int dr4sr_fmlp_train_step(const dr4sr_fmlp_plan* plan, void* stream) {
+    RC(dr4sr_fmlp_fwd_bwd(plan, stream));
+    return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
+                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream);
+}
+
+extern "C" int dr4sr_fmlp_encode(const dr4sr_fmlp_plan* plan, int32_t training, float* out, void* stream) {
+    FmlpWs ws;
+    RC(fmlp_ws(plan, &ws));
+    if (!out) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(fmlp_forward(plan, ws, training, 0, s));
+    hipLaunchKernelGGL(k_fmlp_last, dim3((plan->B * FM_D + 255) / 256), dim3(256), 0, s, ws.X[plan->n_layer], out, plan->B, plan->L);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_fmlp_encode_bwd(const dr4sr_fmlp_plan* plan, int32_t training, const float* d_out, void* stream) {
+    FmlpWs ws;
+    RC(fmlp_ws(plan, &ws));
+    if (!d_out || !plan->grads) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int gb = (int)(((int64_t)ws.Tn * FM_D + 255) / 256); if (gb > 2048) gb = 2048;
+    hipLaunchKernelGGL(k_fmlp_last_bwd, dim3(gb), dim3(256), 0, s, d_out, ws.dX[plan->n_layer], plan->B, plan->L);
+    return fmlp_backward(plan, ws, training, 0, s);
+}

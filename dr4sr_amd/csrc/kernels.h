@@ -46,6 +46,42 @@ struct Workspace {
 enum { P_IN_W = 0, P_IN_B, P_OUT_W, P_OUT_B, P_W1, P_B1, P_W2, P_B2, P_LN1_W, P_LN1_B, P_LN2_W, P_LN2_B };
 static inline int64_t poff(const Workspace& ws, int layer, int j) { return ws.off[2 + 12 * layer + j]; }
 
+// argument blocks shared by the tile kernels of linear.hip (SASRec layer) and their FMLP re-use
+struct PostArgs {
+    // forward inputs / saved activations
+    const float* ctx; const float* x;
+    const float* out_w; const float* out_b; const float* ln1_w; const float* ln1_b;
+    const float* w1; const float* b1; const float* w2; const float* b2; const float* ln2_w; const float* ln2_b;
+    float* u1; float* y; float* st1; float* a; float* h; float* u2; float* st2; float* z;
+    // backward
+    const float* dz; const float* w2T; const float* w1T; const float* out_wT;
+    float* df; float* da; float* du1; float* dout; float* dctx;
+    float* ln_part;                            // this layer's [ntiles][4][D] LayerNorm affine partials
+    const int* state; uint64_t seed; float p; float eps; int layer; int training;
+    uint32_t sP, sA, sF;                       // dropout sites: after out_proj / after activation (0xffffffff = none) / after linear2
+    unsigned long long* stamps;                // debug: per-phase s_memtime of block 0 (NULL normally)
+};
+
+struct WgradJob {
+    const float* G; int ldg; int gcol;        // G rows start at column gcol
+    const float* X; int ldx;
+    float* dW; float* db;
+    uint32_t gsite; int gmode;                // 1: G *= dropout keep factor at element t*ldg + col
+    uint32_t xsite; int xmode;                // 1: X = gelu(X) * keep factor
+};
+struct WgradArgs {
+    WgradJob job[6 * DR4SR_MAX_LAYERS];
+    const int* state; uint64_t seed; float p; int training;
+    // reduce jobs (blockIdx.y == 6): LayerNorm affine partials of every layer, scorer partials
+    const float* ln_part; int64_t ln_layer_stride; float* grads; int64_t o_ln1_w; int64_t layer_stride;   // ln1_w,ln1_b,ln2_w,ln2_b contiguous
+    const float* score_part; float* tail; int B; int D;
+};
+
+int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);
+int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s);
+int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s);
+int launch_adam_flat(float* P, const float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2, float eps, float wd, hipStream_t s);
+
 int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws);   // fills ws from p->workspace (or sizes only if NULL)
 
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s);

@@ -79,19 +79,6 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 }
 
 // ------------------------------------------------------------------------------------------------
-struct PostArgs {
-    // forward inputs / saved activations
-    const float* ctx; const float* x;
-    const float* out_w; const float* out_b; const float* ln1_w; const float* ln1_b;
-    const float* w1; const float* b1; const float* w2; const float* b2; const float* ln2_w; const float* ln2_b;
-    float* u1; float* y; float* st1; float* a; float* h; float* u2; float* st2; float* z;
-    // backward
-    const float* dz; const float* w2T; const float* w1T; const float* out_wT;
-    float* df; float* da; float* du1; float* dout; float* dctx;
-    float* ln_part;                            // this layer's [ntiles][4][D] LayerNorm affine partials
-    const int* state; uint64_t seed; float p; float eps; int layer; int training;
-    unsigned long long* stamps;                // debug: per-phase s_memtime of block 0 (NULL normally)
-};
 
 // dropout + residual + LayerNorm over the 64 rows of a C tile held in LDS, 16 lanes per row, all four row passes of
 // a thread issued together (loads first, then four independent reduction chains, then stores) so that the single wave
@@ -144,7 +131,7 @@ __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc
     }
 }
 
-template <int D, int F>
+template <int D, int F, bool FFN_ONLY>
 __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
     constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64;
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
@@ -155,20 +142,25 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
-    const uint32_t sP = DR4SR_SITE_PROJ + 4 * A.layer, sA = DR4SR_SITE_ACT + 4 * A.layer, sF = DR4SR_SITE_FFN + 4 * A.layer;
+    const uint32_t sP = A.sP, sA = A.sA, sF = A.sF;
+    const bool actdrop = dodrop && sA != 0xffffffffu;
 
     STAMP(0);
-    load_tile<D>(R0, LD, A.ctx, D, t0, T);
-    lds_barrier(); STAMP(1);
-    {
-        f32x16 acc[NV];
-        acc_zero(acc);
-        mma_64xN<D, NV>(R0, LD, A.out_w, acc);
-        acc_to_lds(acc, R2, LD, A.out_b);
+    if (FFN_ONLY) {                            // FMLP Intermediate block: the input tile IS y
+        load_tile<D>(R1, LD, A.x, D, t0, T);
+    } else {
+        load_tile<D>(R0, LD, A.ctx, D, t0, T);
+        lds_barrier(); STAMP(1);
+        {
+            f32x16 acc[NV];
+            acc_zero(acc);
+            mma_64xN<D, NV>(R0, LD, A.out_w, acc);
+            acc_to_lds(acc, R2, LD, A.out_b);
+        }
+        lds_barrier(); STAMP(2);
+        // ---- dropout1 + residual + LayerNorm1
+        ln_rowpass<D, false, true>(R2, LD, A.x, D, A.ln1_w, A.ln1_b, A.eps, A.u1, A.y, A.st1, R1, LD, t0, T, dodrop, rk, sP);
     }
-    lds_barrier(); STAMP(2);
-    // ---- dropout1 + residual + LayerNorm1
-    ln_rowpass<D, false, true>(R2, LD, A.x, D, A.ln1_w, A.ln1_b, A.eps, A.u1, A.y, A.st1, R1, LD, t0, T, dodrop, rk, sP);
     lds_barrier(); STAMP(3);
     // ---- linear1 + GELU + dropout
     {
@@ -193,7 +185,7 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
                 const int c = 4 * l16 + 64 * j;
                 const float4 a4 = av[ps][j];
                 float4 h = make_float4(gelu_erf(a4.x), gelu_erf(a4.y), gelu_erf(a4.z), gelu_erf(a4.w));
-                if (dodrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); h.x *= m.x; h.y *= m.y; h.z *= m.z; h.w *= m.w; }
+                if (actdrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); h.x *= m.x; h.y *= m.y; h.z *= m.z; h.w *= m.w; }
                 if (ok) { st4(A.a + (size_t)t * F + c, a4); st4(A.h + (size_t)t * F + c, h); }
                 st4(R2 + row * LF + c, h);
             }
@@ -210,34 +202,6 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
     lds_barrier(); STAMP(6);
     ln_rowpass<D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
     STAMP(15);
-}
-
-// LayerNorm backward of one row spread over a 16-lane group.  dzv: upstream grad, uv: LN input.
-// Returns du in dzv; accumulates affine partials.
-template <int NV>
-__device__ __forceinline__ void ln_bwd_row(float4 (&dzv)[NV], const float4 (&uv)[NV], float mean, float rstd,
-                                           const float4 (&gam)[NV], float4 (&dgam)[NV], float4 (&dbet)[NV]) {
-    constexpr float invD = 1.0f / (64 * NV);
-    float4 xh[NV], g[NV];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        xh[j] = make_float4((uv[j].x - mean) * rstd, (uv[j].y - mean) * rstd, (uv[j].z - mean) * rstd, (uv[j].w - mean) * rstd);
-        g[j] = make_float4(dzv[j].x * gam[j].x, dzv[j].y * gam[j].y, dzv[j].z * gam[j].z, dzv[j].w * gam[j].w);
-        s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
-        s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
-        dgam[j].x += dzv[j].x * xh[j].x; dgam[j].y += dzv[j].y * xh[j].y; dgam[j].z += dzv[j].z * xh[j].z; dgam[j].w += dzv[j].w * xh[j].w;
-        dbet[j].x += dzv[j].x; dbet[j].y += dzv[j].y; dbet[j].z += dzv[j].z; dbet[j].w += dzv[j].w;
-    }
-    s1 = group16_sum(s1) * invD;
-    s2 = group16_sum(s2) * invD;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        dzv[j].x = rstd * (g[j].x - s1 - xh[j].x * s2);
-        dzv[j].y = rstd * (g[j].y - s1 - xh[j].y * s2);
-        dzv[j].z = rstd * (g[j].z - s1 - xh[j].z * s2);
-        dzv[j].w = rstd * (g[j].w - s1 - xh[j].w * s2);
-    }
 }
 
 // fold the 16 row-groups of the workgroup (4 per wave x 4 waves) into ONE partial row per token tile:
@@ -319,7 +283,7 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
     }
 }
 
-template <int D, int F>
+template <int D, int F, bool FFN_ONLY>
 __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64;
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
@@ -330,7 +294,8 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
-    const uint32_t sP = DR4SR_SITE_PROJ + 4 * A.layer, sA = DR4SR_SITE_ACT + 4 * A.layer, sF = DR4SR_SITE_FFN + 4 * A.layer;
+    const uint32_t sP = A.sP, sA = A.sA, sF = A.sF;
+    const bool actdrop = dodrop && sA != 0xffffffffu;
     float4 dgam[NV], dbet[NV];
 
     // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
@@ -355,7 +320,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
             if (t < T) {
                 d = ld4(R2 + row * LF + c);
                 const float4 av = ld4(A.a + (size_t)t * F + c);
-                if (dodrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+                if (actdrop) { const float4 m = drop4(rk, sA, (uint64_t)t * F + c); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
                 d.x *= gelu_erf_grad(av.x); d.y *= gelu_erf_grad(av.y); d.z *= gelu_erf_grad(av.z); d.w *= gelu_erf_grad(av.w);
                 st4(A.da + (size_t)t * F + c, d);
             }
@@ -371,6 +336,17 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         acc_to_lds(acc, R0, LD, nullptr);
     }
     lds_barrier();
+    if (FFN_ONLY) {                            // FMLP: d(input) = da W1 + du2, nothing upstream inside this kernel
+        constexpr int C4f = D / 4;
+        for (int i = threadIdx.x; i < 64 * C4f; i += 256) {
+            const int row = i / C4f, c = (i % C4f) * 4;
+            if (t0 + row < T) {
+                const float4 p0 = ld4(R0 + row * LD + c), p1 = ld4(R1 + row * LD + c);
+                st4(A.du1 + (size_t)(t0 + row) * D + c, make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w));
+            }
+        }
+        return;
+    }
     ln_bwd_rowpass<D, false>(nullptr, R0, R1, LD, A.u1, A.st1, A.ln1_w, A.du1, nullptr, A.dout, R1, dgam, dbet, t0, T, dodrop, rk, sP);
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D + 2 * D);
     // ---- dctx = do W_out
@@ -406,6 +382,7 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     A.df = lw.df; A.da = lw.da; A.du1 = lw.du1; A.dout = lw.dout; A.dctx = ws.dctx;
     A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 63) / 64) * 4 * p->D;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
+    A.sP = DR4SR_SITE_PROJ + 4 * layer; A.sA = DR4SR_SITE_ACT + 4 * layer; A.sF = DR4SR_SITE_FFN + 4 * layer;
     A.stamps = getenv("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
     return A;
 }
@@ -416,9 +393,9 @@ int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, 
     const PostArgs A = make_post_args(p, ws, layer, training);
     dim3 grid((ws.Tmax + 63) / 64), blk(256);
     const size_t lds = post_lds(p->D, p->F);
-    if (p->D == 64 && p->F == 128) { big_lds(k_post_fwd<64, 128>, lds); hipLaunchKernelGGL((k_post_fwd<64, 128>), grid, blk, lds, s, A); }
-    else if (p->D == 128 && p->F == 128) { big_lds(k_post_fwd<128, 128>, lds); hipLaunchKernelGGL((k_post_fwd<128, 128>), grid, blk, lds, s, A); }
-    else if (p->D == 64 && p->F == 256) { big_lds(k_post_fwd<64, 256>, lds); hipLaunchKernelGGL((k_post_fwd<64, 256>), grid, blk, lds, s, A); }
+    if (p->D == 64 && p->F == 128) { big_lds(k_post_fwd<64, 128, false>, lds); hipLaunchKernelGGL((k_post_fwd<64, 128, false>), grid, blk, lds, s, A); }
+    else if (p->D == 128 && p->F == 128) { big_lds(k_post_fwd<128, 128, false>, lds); hipLaunchKernelGGL((k_post_fwd<128, 128, false>), grid, blk, lds, s, A); }
+    else if (p->D == 64 && p->F == 256) { big_lds(k_post_fwd<64, 256, false>, lds); hipLaunchKernelGGL((k_post_fwd<64, 256, false>), grid, blk, lds, s, A); }
     else return DR4SR_E_SHAPE;
     return DR4SR_LAUNCH_CHECK();
 }
@@ -426,10 +403,26 @@ int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, 
     const PostArgs A = make_post_args(p, ws, layer, training);
     dim3 grid((ws.Tmax + 63) / 64), blk(256);
     const size_t lds = post_lds(p->D, p->F);
-    if (p->D == 64 && p->F == 128) { big_lds(k_post_bwd<64, 128>, lds); hipLaunchKernelGGL((k_post_bwd<64, 128>), grid, blk, lds, s, A); }
-    else if (p->D == 128 && p->F == 128) { big_lds(k_post_bwd<128, 128>, lds); hipLaunchKernelGGL((k_post_bwd<128, 128>), grid, blk, lds, s, A); }
-    else if (p->D == 64 && p->F == 256) { big_lds(k_post_bwd<64, 256>, lds); hipLaunchKernelGGL((k_post_bwd<64, 256>), grid, blk, lds, s, A); }
+    if (p->D == 64 && p->F == 128) { big_lds(k_post_bwd<64, 128, false>, lds); hipLaunchKernelGGL((k_post_bwd<64, 128, false>), grid, blk, lds, s, A); }
+    else if (p->D == 128 && p->F == 128) { big_lds(k_post_bwd<128, 128, false>, lds); hipLaunchKernelGGL((k_post_bwd<128, 128, false>), grid, blk, lds, s, A); }
+    else if (p->D == 64 && p->F == 256) { big_lds(k_post_bwd<64, 256, false>, lds); hipLaunchKernelGGL((k_post_bwd<64, 256, false>), grid, blk, lds, s, A); }
     else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// FMLP Intermediate block (module/layers.py:761-779): linear1 -> GELU -> linear2 -> dropout -> +x -> LayerNorm, D=64, F=256
+int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s) {
+    dim3 grid((Tmax + 63) / 64), blk(256);
+    const size_t lds = post_lds(64, 256);
+    big_lds(k_post_fwd<64, 256, true>, lds);
+    hipLaunchKernelGGL((k_post_fwd<64, 256, true>), grid, blk, lds, s, A);
+    return DR4SR_LAUNCH_CHECK();
+}
+int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s) {
+    dim3 grid((Tmax + 63) / 64), blk(256);
+    const size_t lds = post_lds(64, 256);
+    big_lds(k_post_bwd<64, 256, true>, lds);
+    hipLaunchKernelGGL((k_post_bwd<64, 256, true>), grid, blk, lds, s, A);
     return DR4SR_LAUNCH_CHECK();
 }
 
@@ -478,20 +471,6 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // and B[t][k0+r] = Xs[t][k0+r] (conflict-free ds_read_b32).  Each workgroup owns the full [NG x KX]
 // output (tiles spread over its 4 waves) for a strided subset of token tiles and adds it to the
 // flat gradient with 128-B-coalesced fp32 atomics at the end.
-struct WgradJob {
-    const float* G; int ldg; int gcol;        // G rows start at column gcol
-    const float* X; int ldx;
-    float* dW; float* db;
-    uint32_t gsite; int gmode;                // 1: G *= dropout keep factor at element t*ldg + col
-    uint32_t xsite; int xmode;                // 1: X = gelu(X) * keep factor
-};
-struct WgradArgs {
-    WgradJob job[6 * DR4SR_MAX_LAYERS];
-    const int* state; uint64_t seed; float p; int training;
-    // reduce jobs (blockIdx.y == 6): LayerNorm affine partials of every layer, scorer partials
-    const float* ln_part; int64_t ln_layer_stride; float* grads; int64_t o_ln1_w; int64_t layer_stride;   // ln1_w,ln1_b,ln2_w,ln2_b contiguous
-    const float* score_part; float* tail; int B; int D;
-};
 
 template <int NG, int KX>
 __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A) {
@@ -630,6 +609,46 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A) {
     if (j < 4) wgrad_body<D, D>(J, A);
     else if (j == 4) wgrad_body<F, D>(J, A);
     else wgrad_body<D, F>(J, A);
+}
+
+// ---- FMLP: weight gradients of the Intermediate blocks (dense_1, dense_2) + LayerNorm / scorer partial reductions
+__device__ __forceinline__ void reduce_jobs_fmlp(const WgradArgs& A) {
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + 63) / 64, D = A.D, layer = blockIdx.z;
+    const float* part = A.ln_part + (size_t)layer * A.ln_layer_stride;          // [ntiles][4][D], rows 0,1 = (d ln_w, d ln_b)
+    float* g = A.grads + A.o_ln1_w + (size_t)layer * A.layer_stride;           // intermediate.LayerNorm.weight | .bias
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        float s = 0.f;
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) s += part[(size_t)t * 4 * D + c];
+        unsafeAtomicAdd(g + c, s);
+    }
+    if (blockIdx.x == 0 && layer == 0 && A.score_part) {
+        __shared__ float red[512];
+        float c = 0.f, l = 0.f;
+        for (int b = threadIdx.x; b < A.B; b += 256) { c += A.score_part[2 * b]; l += A.score_part[2 * b + 1]; }
+        red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
+        lds_barrier();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
+            lds_barrier();
+        }
+        if (threadIdx.x == 0) { A.tail[0] += red[0]; A.tail[1] += red[256]; }
+    }
+}
+__global__ __launch_bounds__(256) void k_fmlp_wgrad(const WgradArgs A) {
+    const int j = blockIdx.y;
+    if (j == 2) { reduce_jobs_fmlp(A); return; }
+    const WgradJob& J = A.job[blockIdx.z * 6 + 4 + j];
+    if (j == 0) wgrad_body<256, 64>(J, A);
+    else wgrad_body<64, 256>(J, A);
+}
+int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) {
+    const int ntiles = (Tmax + 63) / 64;
+    int gw_t = ntiles / 16 > 48 ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : 48;
+    int gw = ntiles < gw_t ? ntiles : gw_t;
+    const size_t lds = sizeof(float) * 64 * (64 + 256);
+    big_lds(k_fmlp_wgrad, lds);
+    hipLaunchKernelGGL(k_fmlp_wgrad, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
+    return DR4SR_LAUNCH_CHECK();
 }
 
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s) {

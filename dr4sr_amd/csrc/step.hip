@@ -139,13 +139,17 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float
     }
 }
 
-int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s) {
-    if (!p->grads || !p->adam_m || !p->adam_v || p->n_params <= 0 || (p->n_params & 3)) return DR4SR_E_ARG;
-    int64_t blocks = (p->n_params / 4 + 255) / 256;
+int launch_adam_flat(float* P, const float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2,
+                     float eps, float wd, hipStream_t s) {
+    if (!P || !G || !M || !V || !state || n <= 0 || (n & 3)) return DR4SR_E_ARG;
+    int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, p->params, p->grads, p->adam_m, p->adam_v, p->n_params,
-                       p->state, p->lr, p->beta1, p->beta2, p->adam_eps, p->weight_decay);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd);
     return DR4SR_LAUNCH_CHECK();
+}
+int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s) {
+    return launch_adam_flat(p->params, p->grads, p->adam_m, p->adam_v, p->n_params, p->state, p->lr, p->beta1, p->beta2,
+                            p->adam_eps, p->weight_decay, s);
 }
 
 extern "C" int dr4sr_adam_step(const dr4sr_sasrec_plan* plan, void* stream) {

@@ -168,6 +168,48 @@ int dr4sr_full_score_topk(const float* q, const float* E, const int64_t* hist, f
                           int64_t* out_item, int64_t B, int32_t D, int32_t n_items, int32_t Lh,
                           int32_t k, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FMLP (model/fmlp.py:18-39, module/layers.py:740-807): embedding + position -> LayerNorm -> dropout ->
+ * n_layer x { spectral FilterLayer (rfft * complex weight -> irfft, 'ortho') -> dropout -> +x -> LayerNorm ;
+ * Intermediate (64 -> 256 GELU -> 64, dropout, +x, LayerNorm) } -> x[:, -1].  Rows are LEFT-padded prefixes with a SCALAR
+ * target (dataset/dataset_transform.ipynb), all B*L positions are computed (the filter mixes every position).
+ * The reference hard-codes L = 50, D = 64, hidden 256, dropout 0.5 (fmlp.py:11-13, layers.py:743-744,:762); the kernels
+ * require D = 64, F = 256, L <= 50... any L <= 50 even.
+ * Flat parameter layout: E[N,D] | P[L,D] | ln_w[D] ln_b[D] | per layer: complex_weight[L/2+1, D, 2] | filt_ln_w filt_ln_b |
+ *   dense_1.w[F,D] dense_1.b[F] dense_2.w[D,F] dense_2.b[D] | inter_ln_w inter_ln_b      (+ DR4SR_GRAD_TAIL on grads) */
+typedef struct dr4sr_fmlp_plan {
+    int32_t abi_version;
+    int32_t B, L, D, F, n_layer, n_items;
+    float   ln_eps, p_drop;
+    uint64_t seed;
+    float*  params; float* grads; float* adam_m; float* adam_v;
+    int64_t n_params;
+    const int64_t* in_item_id;      /* [U,L] left-padded prefixes                                  */
+    const int64_t* item_id;         /* [U]   scalar targets (may be NULL for encode)               */
+    const int64_t* rows;            /* [B] or NULL                                                  */
+    int64_t* neg_item;              /* [B]   one negative per row                                   */
+    int32_t  sample_neg;
+    void*    workspace; int64_t workspace_bytes;
+    int32_t* state;                 /* [DR4SR_STATE_WORDS]                                          */
+    float lr, beta1, beta2, adam_eps, weight_decay;
+} dr4sr_fmlp_plan;
+
+int     dr4sr_fmlp_plan_sizeof(void);
+/* offsets[0]=E [1]=P [2]=ln_w [3]=ln_b, [4+9*i+j] = j-th tensor of layer i in the order above; returns n_params */
+int64_t dr4sr_fmlp_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer, int64_t* offsets);
+int64_t dr4sr_fmlp_workspace_bytes(const dr4sr_fmlp_plan* plan);
+/* basemodel.py:193-198 for model = FMLP: negatives, forward, scorer + BCE (1-D targets), backward; un-normalised grads */
+int dr4sr_fmlp_fwd_bwd(const dr4sr_fmlp_plan* plan, void* stream);
+/* fwd_bwd + dense Adam */
+int dr4sr_fmlp_train_step(const dr4sr_fmlp_plan* plan, void* stream);
+/* FMLP.forward -> out [B,D] (= encoder output at the last position); training != 0 applies dropout */
+int dr4sr_fmlp_encode(const dr4sr_fmlp_plan* plan, int32_t training, float* out, void* stream);
+/* autograd of dr4sr_fmlp_encode: d_out [B,D]; parameter gradients ACCUMULATE into plan->grads */
+int dr4sr_fmlp_encode_bwd(const dr4sr_fmlp_plan* plan, int32_t training, const float* d_out, void* stream);
+/* torch.optim.Adam on arbitrary flat buffers (grads[n] = normaliser, as dr4sr_adam_step); state[STEP] is bumped */
+int dr4sr_adam_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* Measurement hook: enqueue ONE kernel of the training step (on the state the last fwd_bwd left in
  * the workspace) so bench.py can bracket it with HIP events.  Not part of the reference surface. */
 #define DR4SR_K_PREP       0

@@ -1,0 +1,118 @@
+"""GPU parity of the FMLP path (dr4sr_fmlp_* through the C ABI) vs golden vectors from the reference and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fmlp_oracle as FO  # noqa: E402
+
+REL = 3e-4
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+def load(golden_dir):
+    z = np.load(os.path.join(golden_dir, "fmlp_d64.npz"))
+    g = {k: z[k] for k in z.files}
+    params = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}
+    batch = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("batch.")}
+    return g, params, batch
+
+
+def engine(g, params, B, p=0.0, **kw):
+    from dr4sr_amd.fmlp_engine import FmlpEngine
+    eng = FmlpEngine(int(g["meta.num_items"]), 50, 64, 256, int(g["meta.layer_num"]), 1e-12, p, B, "cuda", **kw)
+    eng.load_named(params)
+    return eng
+
+
+def test_fmlp_encode_fwd_bwd_adam_vs_golden(golden_dir):
+    g, params, b = load(golden_dir)
+    B = b["in_item_id"].shape[0]
+    eng = engine(g, params, B, lr=float(g["meta.lr"]))
+    dev = eng.device
+    idx, tgt = b["in_item_id"].to(dev), b["item_id"].to(dev)
+    neg = b["neg_item"].view(-1).contiguous().to(dev)
+    plan = eng.make_plan(idx, tgt, neg_item=neg, sample_neg=False)
+    q = eng.encode(plan, False)
+    assert relerr(q, g["out.query"]) < REL
+    # eval rows (initial weights): query at the last position
+    ev = eng.encode(eng.make_plan(torch.from_numpy(g["eval.in_item_id"]).to(dev), None), False)
+    assert relerr(ev, g["eval.query_last"]) < REL
+    eng.fwd_bwd(plan)
+    loss, n = eng.loss_and_count()
+    assert n == B and abs(loss - float(g["out.loss"])) < 1e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, g["grad." + k]) < REL, k
+    eng.adam_step()
+    for k, v in eng.views.items():
+        well = np.abs(g["grad." + k]) > 1e-5
+        d = v.cpu().numpy() - g["adam1." + k]
+        assert np.abs(d[well]).max(initial=0) < 1e-5 and np.abs(d).max() < 1.1e-3, k
+    eng.fwd_bwd(plan)
+    assert abs(eng.loss_and_count()[0] - float(g["out.loss_step2"])) < 3e-5
+
+
+def test_fmlp_dropout_masks_match_oracle(golden_dir):
+    g, params, b = load(golden_dir)
+    B, L = b["in_item_id"].shape
+    p = 0.5
+    eng = engine(g, params, B, p=p, seed=77)
+    dev = eng.device
+    neg = b["neg_item"].view(-1).contiguous().to(dev)
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), neg_item=neg, sample_neg=False)
+    eng.fwd_bwd(plan)
+    step = int(eng.state[3])
+    masks = {FO.SITE_EMB: eng.dropout_mask(B * L * 64, 0, step).view(B, L, 64).cpu()}
+    for l in range(2):
+        masks[FO.site(FO.SITE_FILT, l)] = eng.dropout_mask(B * L * 64, 1 + 2 * l, step).view(B, L, 64).cpu()
+        masks[FO.site(FO.SITE_FFN, l)] = eng.dropout_mask(B * L * 64, 2 + 2 * l, step).view(B, L, 64).cpu()
+    loss_o, _, grads_o = FO.grads_of(params, b, 2, masks=masks, pdrop=p)
+    loss, n = eng.loss_and_count()
+    assert abs(loss - float(loss_o)) < 3e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, grads_o[k]) < REL, k
+
+
+def test_fmlp_full_size_and_training_decreases_loss():
+    from dr4sr_amd.data.synthetic import TOYS_N_ITEMS
+    from dr4sr_amd.fmlp_engine import FmlpEngine, fmlp_param_names, fmlp_param_shapes
+    B, L, N = 256, 50, TOYS_N_ITEMS
+    gen = torch.Generator().manual_seed(0)
+    idx = torch.zeros(B, L, dtype=torch.long)
+    for i in range(B):
+        n = int(torch.randint(1, L + 1, (1,), generator=gen))
+        idx[i, L - n:] = torch.randint(1, N, (n,), generator=gen)          # left-padded prefixes
+    tgt = torch.randint(1, N, (B,), generator=gen)
+    tgt[3] = 0                                                             # one masked row
+    neg = torch.randint(1, N, (B, 1), generator=gen)
+    params = {}
+    for nme, shp in zip(fmlp_param_names(2), fmlp_param_shapes(N, L, 64, 256, 2)):
+        params[nme] = (1.0 if nme.endswith("LayerNorm.weight") else 0.0) + 0.05 * torch.randn(shp, generator=gen)
+    params["item_embedding.weight"][0] = 0
+    eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.0, B, "cuda")
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(idx.to(dev), tgt.to(dev), neg_item=neg.view(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    batch = {"in_item_id": idx, "item_id": tgt, "neg_item": neg}
+    loss_o, _, grads_o = FO.grads_of(params, batch, 2)
+    loss, n = eng.loss_and_count()
+    assert n == B - 1 and abs(loss - float(loss_o)) < 3e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, grads_o[k]) < REL, k
+    first = loss
+    for _ in range(30):
+        eng.train_step(plan)
+    assert eng.loss_and_count()[0] < first - 0.05 and int(eng.state[0]) == 30
+    # in-kernel negatives stay in range
+    plan2 = eng.make_plan(idx.to(dev), tgt.to(dev))
+    eng.fwd_bwd(plan2)
+    assert int(eng.neg_scratch[:B].min()) >= 1 and int(eng.neg_scratch[:B].max()) < N
