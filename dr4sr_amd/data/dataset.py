@@ -192,9 +192,21 @@ class SyntheticDataset(BaseDataset):
         seed = int(d.get("seed", 2024))
         L = self.max_seq_len
         dev = self.device
-        if self.phase == "train":
+        prefix = bool(d.get("prefix_rows", False))          # FMLP format: left-padded prefix, scalar target
+        if self.phase == "train" and not prefix:
             r = make_rows(self._n_rows, self._num_items, L, seed, bool(d.get("dense", False)))
             self._data = tuple(torch.from_numpy(r[k]).to(dev) for k in FIELDS_TRAIN)
+            return
+        if self.phase == "train":
+            r = make_rows(self._n_rows, self._num_items, L, seed, bool(d.get("dense", False)))
+            sl = torch.from_numpy(r["seqlen"])
+            hist = torch.from_numpy(r["in_item_id"])
+            shift = (L - sl).view(-1, 1)                                            # roll the valid prefix to the right edge
+            cols = (torch.arange(L).view(1, -1) - shift) % L
+            lp = torch.where(torch.arange(L).view(1, -1) >= shift, hist.gather(1, cols), torch.zeros_like(hist))
+            target = torch.from_numpy(r["item_id"]).gather(1, (sl - 1).clamp(min=0).view(-1, 1)).squeeze(1)
+            self._data = (torch.from_numpy(r["user_id"]).to(dev), lp.to(dev), target.to(dev), sl.to(dev),
+                          torch.ones_like(sl).to(dev), torch.zeros_like(hist).to(dev))
             return
         n_eval = int(d.get("n_eval_rows", min(self._n_rows, 4096)))
         r = make_rows(n_eval, self._num_items, L, seed + (1 if self.phase == "val" else 2), False)
@@ -202,6 +214,10 @@ class SyntheticDataset(BaseDataset):
         sl = torch.from_numpy(r["seqlen"]).to(dev)
         tgt_all = torch.from_numpy(r["item_id"]).to(dev)
         target = tgt_all.gather(1, (sl - 1).clamp(min=0).view(-1, 1)).squeeze(1)      # next item after the history
+        if prefix:
+            shift = (L - sl).view(-1, 1)
+            ar = torch.arange(L, device=dev).view(1, -1)
+            hist = torch.where(ar >= shift, hist.gather(1, (ar - shift) % L), torch.zeros_like(hist))
         cols = (torch.from_numpy(r["user_id"]).to(dev), hist, target, sl, torch.ones_like(sl),
                 torch.zeros_like(hist), hist)
         self._data = {dn: cols for dn in self.domain_name_list}

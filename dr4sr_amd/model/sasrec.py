@@ -161,79 +161,6 @@ class SASRec(BaseModel):
     def _api_plan(self):
         return self.engine.make_plan(self._dummy.view(1, 1).expand(1, self.max_seq_len).contiguous(), None, self._dummy)
 
-    # ------------------------------------------------------------------------------------------ fast path
-    def _step_graph(self, fields, bl):
-        """captured HIP graph(s) for a local batch of `bl` rows addressed through self._rows_buf[:bl]"""
-        key = (fields["in_item_id"].data_ptr(), bl)
-        if key in self._graphs:
-            return self._graphs[key]
-        eng = self.engine
-        plan = eng.make_plan(fields["in_item_id"], fields["item_id"], fields["seqlen"], rows=self._rows_buf[:bl],
-                             neg_item=self._neg_buf, sample_neg=True)
-        use_graph = bool(self.config["train"].get("hip_graph", True))
-
-        def warm_up(fn):
-            """run the step once OUTSIDE capture (code-object load, LDS attributes) and undo its side effects"""
-            snap = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.state)]
-            fn()
-            torch.cuda.synchronize()
-            for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.state), snap):
-                dst.copy_(src)
-
-        if self.world_size == 1:
-            def eager():
-                eng.train_step(plan)
-            if use_graph:
-                warm_up(eager)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    eng.train_step(plan)
-                run = g.replay
-            else:
-                run = eager
-        else:
-            import torch.distributed as dist
-
-            def eager():
-                eng.fwd_bwd(plan)
-                allreduce_flat(eng.grads)                 # RCCL sum: gradients + {n_valid, loss_sum} tail
-                eng.adam_step(plan)
-            if use_graph:
-                warm_up(eager)
-                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
-                    eng.fwd_bwd(plan)
-                with torch.cuda.graph(gb):
-                    eng.adam_step(plan)
-
-                def run():
-                    ga.replay()
-                    allreduce_flat(eng.grads)
-                    gb.replay()
-            else:
-                run = eager
-        self._graphs[key] = (run, plan)
-        return self._graphs[key]
-
-    def _fused_epoch(self, loader):
-        eng, W, r = self.engine, self.world_size, self.rank
-        B, n, nb = loader.batch_size, loader.n, len(loader)
-        perm = loader.permutation()
-        if W > 1:
-            import torch.distributed as dist
-            dist.broadcast(perm, src=0)
-        losses = torch.empty(nb, dtype=torch.float32, device=self.device)
-        tail = eng.grads[eng.n_params:eng.n_params + 2]
-        for i in range(nb):
-            lo, hi = shard_bounds(i, B, n, W, r)
-            bl = hi - lo
-            if bl > 0:
-                self._rows_buf[:bl].copy_(perm[lo:hi])
-                run, _ = self._step_graph(loader.fields, bl)
-                run()
-            else:                                          # tail batch smaller than the rank count: contribute zeros
-                eng.grads.zero_()
-                allreduce_flat(eng.grads)
-                eng.adam_step(self._api_plan())
-            losses[i] = tail[1] / tail[0]
-        return [{"loss_0": losses}]
+    def _train_plan(self, fields, rows):
+        return self.engine.make_plan(fields["in_item_id"], fields["item_id"], fields["seqlen"], rows=rows,
+                                     neg_item=self._neg_buf, sample_neg=True)

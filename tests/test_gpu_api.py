@@ -137,3 +137,39 @@ def test_last_partial_batch_and_graph_cache(tmp_path):
         assert out[0]["loss_0"].shape == (3,) and torch.isfinite(out[0]["loss_0"]).all()    # 64 + 64 + 22
     assert len(model._graphs) == 2                                 # one graph per distinct batch length, reused
     assert int(model.engine.state[0]) == 6
+
+
+def test_fmlp_model_api_and_fast_path(golden_dir, tmp_path, monkeypatch):
+    """dr4sr_amd.model.fmlp.FMLP: reference state-dict names, API-path loss/backward == reference, fit() end to end"""
+    z = np.load(os.path.join(golden_dir, "fmlp_d64.npz"))
+    cfg = make_config(n_items=int(z["meta.num_items"]))
+    cfg["model"].update({"model": "FMLP", "layer_num": 2})
+    cfg["data"]["prefix_rows"] = True
+    ds, model = build(cfg)
+    model._init_model(ds[0])
+    ref = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    assert set(model.state_dict()) == set(ref)
+    model.load_state_dict(ref, strict=True)
+    model.engine.p_drop = 0.0                                   # fixture was generated with the hard-coded dropout disabled
+    batch = {k[6:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("batch.")}
+    model.train()
+    model.optimizer.zero_grad()
+    loss = model.training_step(batch)
+    loss.backward()
+    assert abs(float(loss) - float(z["out.loss"])) < 3e-6
+    for n, p in model.named_parameters():
+        r = z["grad." + n]
+        assert float(np.abs(p.grad.cpu().numpy() - r).max()) < 3e-4 * max(1e-8, float(np.abs(r).max())), n
+    model.optimizer.step()
+    for n, p in model.named_parameters():
+        well = np.abs(z["grad." + n]) > 1e-5
+        d = p.detach().cpu().numpy() - z["adam1." + n]
+        assert np.abs(d[well]).max(initial=0) < 1e-5, n
+    # end-to-end fit on synthetic prefix rows with the fused-graph fast path
+    monkeypatch.chdir(tmp_path)
+    from dr4sr_amd import quickstart
+    cfg2 = make_config(n_rows=1200, n_items=150, batch=128, epochs=3)
+    cfg2["model"].update({"model": "FMLP", "layer_num": 2})
+    cfg2["data"]["prefix_rows"] = True
+    out = quickstart.run(cfg2)
+    assert {"ndcg@20", "recall@20"} <= set(out) and all(np.isfinite(v) for v in out.values())
