@@ -63,8 +63,27 @@ class FmlpPlan(C.Structure):
     ]
 
 
+class GruPlan(C.Structure):
+    """mirror of `dr4sr_gru4rec_plan` (include/dr4sr_hip.h)"""
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("B", C.c_int32), ("L", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("n_layer", C.c_int32), ("n_items", C.c_int32),
+        ("p_drop", C.c_float),
+        ("seed", C.c_uint64),
+        ("params", _f32p), ("grads", _f32p), ("adam_m", _f32p), ("adam_v", _f32p),
+        ("n_params", C.c_int64),
+        ("in_item_id", _i64p), ("item_id", _i64p), ("seqlen", _i64p), ("rows", _i64p), ("neg_item", _i64p),
+        ("sample_neg", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("state", C.c_void_p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("weight_decay", C.c_float),
+    ]
+
+
 _PLANP = C.POINTER(SasrecPlan)
 _FPLANP = C.POINTER(FmlpPlan)
+_GPLANP = C.POINTER(GruPlan)
 
 # name -> (restype, argtypes); every symbol include/dr4sr_hip.h declares
 SYMBOLS = {
@@ -90,6 +109,13 @@ SYMBOLS = {
     "dr4sr_fmlp_train_step": (C.c_int, [_FPLANP, C.c_void_p]),
     "dr4sr_fmlp_encode": (C.c_int, [_FPLANP, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_fmlp_encode_bwd": (C.c_int, [_FPLANP, C.c_int32, _f32p, C.c_void_p]),
+    "dr4sr_gru4rec_plan_sizeof": (C.c_int, []),
+    "dr4sr_gru4rec_param_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_gru4rec_workspace_bytes": (C.c_int64, [_GPLANP]),
+    "dr4sr_gru4rec_fwd_bwd": (C.c_int, [_GPLANP, C.c_void_p]),
+    "dr4sr_gru4rec_train_step": (C.c_int, [_GPLANP, C.c_void_p]),
+    "dr4sr_gru4rec_encode": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
+    "dr4sr_gru4rec_encode_bwd": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_adam_flat": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -123,6 +149,8 @@ def load():
         raise Dr4srError("ctypes mirror of dr4sr_sasrec_plan does not match the compiled struct")
     if lib.dr4sr_fmlp_plan_sizeof() != C.sizeof(FmlpPlan):
         raise Dr4srError("ctypes mirror of dr4sr_fmlp_plan does not match the compiled struct")
+    if lib.dr4sr_gru4rec_plan_sizeof() != C.sizeof(GruPlan):
+        raise Dr4srError("ctypes mirror of dr4sr_gru4rec_plan does not match the compiled struct")
     _lib = lib
     return lib
 

@@ -137,6 +137,27 @@ __device__ __forceinline__ void mma_64xN(const float* __restrict__ As, int lda,
     }
 }
 
+// same as mma_64xN with an explicit weight row stride (K-chunked GEMMs: W points at the chunk's first column)
+template <int K, int NTW>
+__device__ __forceinline__ void mma_64xN_ld(const float* __restrict__ As, int lda, const float* __restrict__ W, int ldw,
+                                            f32x16 (&acc)[NTW]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, g = lane >> 5, rh = w & 1, cg = w >> 1;
+    const float* arow = As + (rh * 32 + r) * lda + g * (K / 2);
+#pragma unroll
+    for (int c = 0; c < K / 2; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + c);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(W + (size_t)((cg + 2 * i) * 32 + r) * ldw + g * (K / 2) + c);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[i], 0, 0, 0);
+        }
+    }
+}
+
 // Data-gradient form:  C[64 x N] = A[64 x KR] * W  with W global [KR][ldw] row-major (the forward weight [out][in] used
 // as-is: KR = out features = reduction, N = in features).  B operand lane (r, g) at step kk reads W[g*KR/2 + kk][ct*32 + r]:
 // a 128-B-coalesced dword per half-wave; A as in mma_64xN.  Removes the per-step transposed weight copies.

@@ -86,13 +86,17 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
     }
 }
 
-int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
-    const int64_t n4 = zero_grads ? (ws.n_params + DR4SR_GRAD_TAIL) / 4 : 0;
+int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
+                    int64_t zero_floats, hipStream_t s) {
+    const int64_t n4 = zero ? zero_floats / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024);
     if (zb > 255) zb = 255;
-    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng,
-                       zero_grads ? p->grads : nullptr, n4);
+    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, seqlen, rows, cu, state, B, L, bump_rng, zero, n4);
     return DR4SR_LAUNCH_CHECK();
+}
+int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
+    return launch_prep_raw(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, zero_grads ? p->grads : nullptr,
+                           ws.n_params + DR4SR_GRAD_TAIL, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -116,8 +120,11 @@ __global__ __launch_bounds__(256) void k_embed_fwd(const float* __restrict__ E, 
         int64_t id = idx[row * L + pos];
         id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
         const float4 e = ld4(E + id * D + c);
-        const float4 pe = ld4(P + (size_t)pos * D + c);
-        float4 o = make_float4(e.x + pe.x, e.y + pe.y, e.z + pe.z, e.w + pe.w);
+        float4 o = e;
+        if (P) {                                        // GRU4Rec has no position table
+            const float4 pe = ld4(P + (size_t)pos * D + c);
+            o = make_float4(e.x + pe.x, e.y + pe.y, e.z + pe.z, e.w + pe.w);
+        }
         if (dodrop) {
             const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
             o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
@@ -126,17 +133,16 @@ __global__ __launch_bounds__(256) void k_embed_fwd(const float* __restrict__ E, 
     }
 }
 
-int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
-    const float* E = p->params + ws.off[0];
-    const float* P = p->params + ws.off[1];
-    dim3 grid((p->B + 3) / 4), blk(256);
-    if (p->D == 64)
-        hipLaunchKernelGGL(k_embed_fwd<64>, grid, blk, 0, s, E, P, p->in_item_id, p->rows, ws.cu, ws.X[0], p->B, p->L,
-                           p->n_items, p->state, p->seed, p->p_drop, training);
-    else
-        hipLaunchKernelGGL(k_embed_fwd<128>, grid, blk, 0, s, E, P, p->in_item_id, p->rows, ws.cu, ws.X[0], p->B, p->L,
-                           p->n_items, p->state, p->seed, p->p_drop, training);
+int launch_embed_fwd_raw(const float* E, const float* P, const int64_t* idx, const int64_t* rows, const int* cu, float* X, int B,
+                         int L, int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s) {
+    dim3 grid((B + 3) / 4), blk(256);
+    if (D == 64) hipLaunchKernelGGL(k_embed_fwd<64>, grid, blk, 0, s, E, P, idx, rows, cu, X, B, L, n_items, state, seed, p, training);
+    else hipLaunchKernelGGL(k_embed_fwd<128>, grid, blk, 0, s, E, P, idx, rows, cu, X, B, L, n_items, state, seed, p, training);
     return DR4SR_LAUNCH_CHECK();
+}
+int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    return launch_embed_fwd_raw(p->params + ws.off[0], p->params + ws.off[1], p->in_item_id, p->rows, ws.cu, ws.X[0], p->B, p->L,
+                                p->D, p->n_items, p->state, p->seed, p->p_drop, training, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dX,
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         const int pos = sub + i * PG;
-        if (pos < L) {
+        if (dP && pos < L) {
             float* d = dP + (size_t)pos * D + c;
             unsafeAtomicAdd(d, accP[i].x); unsafeAtomicAdd(d + 1, accP[i].y);
             unsafeAtomicAdd(d + 2, accP[i].z); unsafeAtomicAdd(d + 3, accP[i].w);
@@ -190,18 +196,16 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dX,
     }
 }
 
-int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
-    float* dE = p->grads + ws.off[0];
-    float* dP = p->grads + ws.off[1];
-    int g = p->B < 64 ? p->B : 64;
-    dim3 grid(g), blk(256);
-    if (p->D == 64)
-        hipLaunchKernelGGL(k_embed_bwd<64>, grid, blk, 0, s, ws.dX[0], p->in_item_id, p->rows, ws.cu, dE, dP, p->B, p->L,
-                           p->n_items, p->state, p->seed, p->p_drop, training);
-    else
-        hipLaunchKernelGGL(k_embed_bwd<128>, grid, blk, 0, s, ws.dX[0], p->in_item_id, p->rows, ws.cu, dE, dP, p->B, p->L,
-                           p->n_items, p->state, p->seed, p->p_drop, training);
+int launch_embed_bwd_raw(const float* dX, const int64_t* idx, const int64_t* rows, const int* cu, float* dE, float* dP, int B, int L,
+                         int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s) {
+    dim3 grid(B < 64 ? B : 64), blk(256);
+    if (D == 64) hipLaunchKernelGGL(k_embed_bwd<64>, grid, blk, 0, s, dX, idx, rows, cu, dE, dP, B, L, n_items, state, seed, p, training);
+    else hipLaunchKernelGGL(k_embed_bwd<128>, grid, blk, 0, s, dX, idx, rows, cu, dE, dP, B, L, n_items, state, seed, p, training);
     return DR4SR_LAUNCH_CHECK();
+}
+int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    return launch_embed_bwd_raw(ws.dX[0], p->in_item_id, p->rows, ws.cu, p->grads + ws.off[0], p->grads + ws.off[1], p->B, p->L, p->D,
+                                p->n_items, p->state, p->seed, p->p_drop, training, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,17 +248,23 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ dout, co
     }
 }
 
-int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int last, hipStream_t s) {
-    dim3 grid(p->B), blk(256);
-    if (p->D == 64) hipLaunchKernelGGL(k_unpack<64>, grid, blk, 0, s, X, ws.cu, out, p->B, p->L, last);
-    else hipLaunchKernelGGL(k_unpack<128>, grid, blk, 0, s, X, ws.cu, out, p->B, p->L, last);
+int launch_unpack_raw(const float* X, const int* cu, float* out, int B, int L, int D, int last, hipStream_t s) {
+    dim3 grid(B), blk(256);
+    if (D == 64) hipLaunchKernelGGL(k_unpack<64>, grid, blk, 0, s, X, cu, out, B, L, last);
+    else hipLaunchKernelGGL(k_unpack<128>, grid, blk, 0, s, X, cu, out, B, L, last);
     return DR4SR_LAUNCH_CHECK();
 }
-int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int last, hipStream_t s) {
-    dim3 grid(p->B), blk(256);
-    if (p->D == 64) hipLaunchKernelGGL(k_pack<64>, grid, blk, 0, s, dout, ws.cu, dX, p->B, p->L, last);
-    else hipLaunchKernelGGL(k_pack<128>, grid, blk, 0, s, dout, ws.cu, dX, p->B, p->L, last);
+int launch_pack_raw(const float* dout, const int* cu, float* dX, int B, int L, int D, int last, hipStream_t s) {
+    dim3 grid(B), blk(256);
+    if (D == 64) hipLaunchKernelGGL(k_pack<64>, grid, blk, 0, s, dout, cu, dX, B, L, last);
+    else hipLaunchKernelGGL(k_pack<128>, grid, blk, 0, s, dout, cu, dX, B, L, last);
     return DR4SR_LAUNCH_CHECK();
+}
+int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int last, hipStream_t s) {
+    return launch_unpack_raw(X, ws.cu, out, p->B, p->L, p->D, last, s);
+}
+int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int last, hipStream_t s) {
+    return launch_pack_raw(dout, ws.cu, dX, p->B, p->L, p->D, last, s);
 }
 
 // ------------------------------------------------------------------------------------------------

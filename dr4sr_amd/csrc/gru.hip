@@ -1,0 +1,504 @@
+// gru.hip — GRU4Rec target model (reference model/gru4rec.py:12-34, module/layers.py:117-136 = torch.nn.GRU(bias=False,
+// batch_first, n_layer) + Linear(H -> D)) on gfx950, over ragged (packed) sequences.
+//
+//   x = dropout(E[idx])                                  packed gather (embed.hip, no position table)
+//   per layer:  gi = in W_ih^T                           token-parallel MFMA GEMM (k_gemm, K-chunked through LDS)
+//               recurrence over t                        k_gru_fwd: 16 sequences per workgroup, h in LDS, gh = h W_hh^T on
+//                                                        v_mfma_f32_16x16x4_f32 with W_hh streamed from L2 every step
+//   y = h_top W_out^T + b                                k_gemm
+// torch GRU cell (gates r|z|n, no biases):  r = s(gi_r+gh_r)  z = s(gi_z+gh_z)  n = tanh(gi_n + r*gh_n)  h' = (1-z) n + z h.
+// Rows >= seqlen never influence loss or gradients ('origin' pooling + causality of the recurrence), so only the valid
+// prefix of every sequence is computed.  Backward = BPTT in k_gru_bwd (same tiling, dh W_hh on MFMA with W_hh read
+// column-wise), weight gradients as token-parallel split GEMMs with fp32 atomics (k_wgrad64).
+//
+// W_hh (3H x H fp32 = 786 KB at H=256) fits neither one CU's LDS (160 KB) nor its registers (512 KB); streaming it from L2
+// each step bounds a workgroup at ~10 us per step on the fp32 MFMA pipe.
+#include "common.h"
+#include "kernels.h"
+
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#define GRU_MAX_LAYERS 4
+
+struct GruLayerWs {
+    float* gi; float* r; float* z; float* n; float* ghn; float* hprev; float* hout;
+    float* dgi; float* dgh;
+};
+struct GruWs {
+    int64_t off_E, off_wih[GRU_MAX_LAYERS], off_whh[GRU_MAX_LAYERS], off_ow, off_ob, n_params;
+    int Tmax;
+    int* cu;
+    float* X0; float* dX0; float* Y; float* dY; float* dH;     // dH: grad w.r.t. a layer's output rows [T,H]
+    float* score_part;
+    GruLayerWs layer[GRU_MAX_LAYERS];
+    int64_t bytes;
+};
+
+extern "C" int dr4sr_gru4rec_plan_sizeof(void) { return (int)sizeof(dr4sr_gru4rec_plan); }
+
+// offsets: [0]=E, [1+2l]=weight_ih_l, [2+2l]=weight_hh_l, [1+2n]=out_w, [2+2n]=out_b
+extern "C" int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_t H, int32_t n_layer, int64_t* off) {
+    int64_t o = 0;
+    auto put = [&](int i, int64_t n) { if (off) off[i] = o; o += n; };
+    put(0, (int64_t)n_items * D);
+    for (int l = 0; l < n_layer; ++l) {
+        put(1 + 2 * l, 3LL * H * (l == 0 ? D : H));
+        put(2 + 2 * l, 3LL * H * H);
+    }
+    put(1 + 2 * n_layer, (int64_t)D * H);
+    put(2 + 2 * n_layer, D);
+    return o;
+}
+
+static int gru_check(const dr4sr_gru4rec_plan* p) {
+    if (!p || p->abi_version != DR4SR_ABI_VERSION) return DR4SR_E_ARG;
+    if (p->B <= 0 || p->L <= 0 || p->n_items < 2 || p->n_layer <= 0 || p->n_layer > GRU_MAX_LAYERS) return DR4SR_E_ARG;
+    if (p->D != 64 || (p->H != 128 && p->H != 256) || p->L > 64) return DR4SR_E_SHAPE;
+    if (!(p->p_drop >= 0.f && p->p_drop < 1.f) || !p->params || !p->state || !p->in_item_id || !p->seqlen) return DR4SR_E_ARG;
+    return 0;
+}
+
+static void gru_carve(const dr4sr_gru4rec_plan* p, GruWs* ws) {
+    const int64_t D = p->D, H = p->H, Tmax = (int64_t)p->B * p->L;
+    int64_t off[3 + 2 * GRU_MAX_LAYERS];
+    ws->n_params = dr4sr_gru4rec_param_layout(p->n_items, p->D, p->H, p->n_layer, off);
+    ws->off_E = off[0];
+    for (int l = 0; l < p->n_layer; ++l) { ws->off_wih[l] = off[1 + 2 * l]; ws->off_whh[l] = off[2 + 2 * l]; }
+    ws->off_ow = off[1 + 2 * p->n_layer]; ws->off_ob = off[2 + 2 * p->n_layer];
+    ws->Tmax = (int)Tmax;
+    char* base = (char*)p->workspace;
+    int64_t o = 0;
+    auto take = [&](int64_t nfloat) -> float* {
+        float* r = base ? (float*)(base + o) : nullptr;
+        o += ((nfloat * 4 + 255) / 256) * 256;
+        return r;
+    };
+    ws->cu = (int*)take(p->B + 1);
+    ws->X0 = take(Tmax * D); ws->dX0 = take(Tmax * D); ws->Y = take(Tmax * D); ws->dY = take(Tmax * D); ws->dH = take(Tmax * H);
+    ws->score_part = take(2LL * p->B);
+    for (int l = 0; l < p->n_layer; ++l) {
+        GruLayerWs& w = ws->layer[l];
+        w.gi = take(Tmax * 3 * H); w.r = take(Tmax * H); w.z = take(Tmax * H); w.n = take(Tmax * H); w.ghn = take(Tmax * H);
+        w.hprev = take(Tmax * H); w.hout = take(Tmax * H); w.dgi = take(Tmax * 3 * H); w.dgh = take(Tmax * 3 * H);
+    }
+    ws->bytes = o;
+}
+
+extern "C" int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan) {
+    if (!plan || plan->B <= 0 || plan->L <= 0 || plan->n_layer <= 0 || plan->n_layer > GRU_MAX_LAYERS) return DR4SR_E_ARG;
+    dr4sr_gru4rec_plan q = *plan;
+    q.workspace = nullptr;
+    GruWs ws;
+    gru_carve(&q, &ws);
+    return ws.bytes;
+}
+
+static int gru_ws(const dr4sr_gru4rec_plan* p, GruWs* ws) {
+    int rc = gru_check(p);
+    if (rc) return rc;
+    if (!p->workspace) return DR4SR_E_ARG;
+    gru_carve(p, ws);
+    return ws->bytes > p->workspace_bytes ? DR4SR_E_WS : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ generic packed-row GEMM
+// C[T x N] = A[T x K] * op(W) (+ bias), 64 rows x 64*NTW columns per workgroup, K in chunks of 64 through LDS.
+//   COLMODE = false: op(W) = W^T, W is [N][ldw]   (forward linear: x W^T)
+//   COLMODE = true : op(W) = W,   W is [K][ldw]   (data gradient: dy W)
+template <int NTW, bool COLMODE>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                              const float* __restrict__ bias, float* __restrict__ C, int ldc, int K,
+                                              const int* __restrict__ state) {
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    if (t0 >= T) return;
+    const int n0 = blockIdx.y * 64 * NTW;
+    float* As = smem;                                   // [64][68]
+    f32x16 acc[NTW];
+    acc_zero(acc);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        if (k0) lds_barrier();
+        load_tile<64>(As, 68, A + k0, lda, t0, T);
+        lds_barrier();
+        if (COLMODE) mma_64xN_wT<64, NTW>(As, 68, W + (size_t)k0 * ldw + n0, ldw, acc);
+        else mma_64xN_ld<64, NTW>(As, 68, W + (size_t)n0 * ldw + k0, ldw, acc);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, g = lane >> 5, rh = w & 1, cg = w >> 1;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int col = n0 + (cg + 2 * i) * 32 + r;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int t = t0 + rh * 32 + (q & 3) + 8 * (q >> 2) + 4 * g;
+            if (t < T) C[(size_t)t * ldc + col] = acc[i][q] + bv;
+        }
+    }
+}
+
+static int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K, int N,
+                       bool colmode, int Tmax, const int* state, hipStream_t s) {
+    const size_t lds = sizeof(float) * 64 * 68;
+    dim3 blk(256);
+    if (N % 128 == 0) {
+        dim3 grid((Tmax + 63) / 64, N / 128);
+        if (colmode) hipLaunchKernelGGL((k_gemm<2, true>), grid, blk, lds, s, A, lda, W, ldw, bias, C, ldc, K, state);
+        else hipLaunchKernelGGL((k_gemm<2, false>), grid, blk, lds, s, A, lda, W, ldw, bias, C, ldc, K, state);
+    } else {
+        dim3 grid((Tmax + 63) / 64, N / 64);
+        if (colmode) hipLaunchKernelGGL((k_gemm<1, true>), grid, blk, lds, s, A, lda, W, ldw, bias, C, ldc, K, state);
+        else hipLaunchKernelGGL((k_gemm<1, false>), grid, blk, lds, s, A, lda, W, ldw, bias, C, ldc, K, state);
+    }
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------ generic weight gradient
+// dW[n0..n0+64)[k0..k0+64) += sum_t G[t][gcol+..] X[t][xcol+..]   (one 64x64 output tile per job, token tiles strided over
+// gridDim.x workgroups, fp32 atomics at the end);  db[n0..] += column sums of G when db != NULL.
+struct Wg64Job { const float* G; int ldg; int gcol; const float* X; int ldx; int xcol; float* dW; int ldw; float* db; };
+struct Wg64Mat { const float* G; const float* X; float* dW; float* db; int ldg, NG, ldx, KX, start; };   // dW is [NG][KX]
+struct Wg64Args { Wg64Mat mat[2 * GRU_MAX_LAYERS + 1]; int nmat; const int* state; };
+
+__global__ __launch_bounds__(256) void k_wgrad64(const Wg64Args A) {
+    int mi = 0;
+    for (int m = 1; m < A.nmat; ++m) if ((int)blockIdx.y >= A.mat[m].start) mi = m;
+    const Wg64Mat M = A.mat[mi];
+    Wg64Job J;
+    {
+        const int local = blockIdx.y - M.start, nkb = M.KX / 64, n0 = (local / nkb) * 64, k0 = (local % nkb) * 64;
+        J.G = M.G; J.ldg = M.ldg; J.gcol = n0; J.X = M.X; J.ldx = M.ldx; J.xcol = k0;
+        J.dW = M.dW + (size_t)n0 * M.KX + k0; J.ldw = M.KX; J.db = (M.db && k0 == 0) ? M.db + n0 : nullptr;
+    }
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + 63) / 64;
+    float* Gs = smem;                                   // [64][64]
+    float* Xs = smem + 64 * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, g = lane >> 5;
+    const int nt = w >> 1, kt = w & 1;                  // wave -> 32x32 tile of the 64x64 block
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float bsum = 0.f;
+    float4 gq[4], xq[4];
+    auto issue = [&](int tt) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i >> 4, c = (i & 15) * 4, t = tt * 64 + row;
+            gq[u] = t < T ? ld4(J.G + (size_t)t * J.ldg + J.gcol + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[u] = t < T ? ld4(J.X + (size_t)t * J.ldx + J.xcol + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int tt = blockIdx.x;
+    if (tt < ntiles) issue(tt);
+    for (; tt < ntiles; tt += gridDim.x) {
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i >> 4, c = (i & 15) * 4;
+            st4(Gs + row * 64 + c, gq[u]);
+            st4(Xs + row * 64 + c, xq[u]);
+        }
+        lds_barrier();
+        if (tt + (int)gridDim.x < ntiles) issue(tt + gridDim.x);
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const int t = 2 * s + g;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[t * 64 + nt * 32 + r], Xs[t * 64 + kt * 32 + r], acc, 0, 0, 0);
+        }
+        if (J.db && threadIdx.x < 64) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+            for (int t = 0; t < 64; t += 2) { s0 += Gs[t * 64 + threadIdx.x]; s1 += Gs[(t + 1) * 64 + threadIdx.x]; }
+            bsum += s0 + s1;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = nt * 32 + (q & 3) + 8 * (q >> 2) + 4 * g;
+        unsafeAtomicAdd(J.dW + (size_t)row * J.ldw + kt * 32 + r, acc[q]);
+    }
+    if (J.db && threadIdx.x < 64) unsafeAtomicAdd(J.db + threadIdx.x, bsum);
+}
+
+// ------------------------------------------------------------------------------------------------ recurrence
+struct GruRecArgs {
+    const float* gi; const float* whh; const int* cu;
+    float* r; float* z; float* n; float* ghn; float* hprev; float* hout;          // saved per token [T,H]
+    const float* dhout; float* dgi; float* dgh;                                   // backward
+    int B;
+};
+
+__device__ __forceinline__ f32x4 mfma16g(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { const float e = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - e) / (1.0f + e), x); }
+
+// 16 sequences per workgroup, 8 waves; wave w owns hidden units [w*H/8, (w+1)*H/8) of all three gates, so the gate math of a
+// unit is register-local (C-layout fragments of the r, z and n tiles coincide: lane = (sequence 4g+q, unit l&15)).
+template <int H>
+__global__ __launch_bounds__(512) void k_gru_fwd(const GruRecArgs A) {
+    constexpr int UT = H / 128;                           // 16-unit tiles per wave
+    constexpr int LDH = H + 4, KQ = H / 4;                // lane group g contracts k in [g*KQ, (g+1)*KQ)
+    float* hb = smem;                                     // [2][16][LDH]
+    int* meta = reinterpret_cast<int*>(hb + 2 * 16 * LDH);   // [16] t0, [16] n
+    const int b0 = blockIdx.x * 16;
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    for (int i = threadIdx.x; i < 2 * 16 * LDH; i += 512) hb[i] = 0.f;
+    lds_barrier();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    int tq[4], nq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { tq[q] = meta[4 * g + q]; nq[q] = meta[16 + 4 * g + q]; }
+    f32x4 hreg[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) hreg[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nmax; ++t) {
+        const float* hc = hb + (t & 1) * 16 * LDH + l16 * LDH + g * KQ;       // A operand rows: sequence l16
+        float* hn = hb + ((t + 1) & 1) * 16 * LDH;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int unit = w * (H / 8) + u * 16 + l16;                     // B operand row / C column of this lane
+            f32x4 acc[3];
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* wr = A.whh + (size_t)unit * H + g * KQ;
+#pragma unroll 4
+            for (int c = 0; c < KQ; c += 4) {
+                const float4 a = ld4(hc + c);
+#pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3) {
+                    const float4 bv = ld4(wr + (size_t)q3 * H * H + c);
+                    acc[q3] = mfma16g(a.x, bv.x, acc[q3]);
+                    acc[q3] = mfma16g(a.y, bv.y, acc[q3]);
+                    acc[q3] = mfma16g(a.z, bv.z, acc[q3]);
+                    acc[q3] = mfma16g(a.w, bv.w, acc[q3]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool act = t < nq[q];
+                const size_t tok = (size_t)(tq[q] + t);
+                float hnew = hreg[u][q];
+                if (act) {
+                    const float* gip = A.gi + tok * 3 * H + unit;
+                    const float rr = sigm(gip[0] + acc[0][q]);
+                    const float zz = sigm(gip[H] + acc[1][q]);
+                    const float nn = tanh_f(gip[2 * H] + rr * acc[2][q]);
+                    const float hold = hreg[u][q];
+                    hnew = (1.0f - zz) * nn + zz * hold;
+                    const size_t o = tok * H + unit;
+                    A.r[o] = rr; A.z[o] = zz; A.n[o] = nn; A.ghn[o] = acc[2][q]; A.hprev[o] = hold; A.hout[o] = hnew;
+                }
+                hreg[u][q] = hnew;
+                hn[(4 * g + q) * LDH + unit] = hnew;
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// BPTT.  Per step (t descending): dh = dhout[t] + carry;  gate derivatives for the wave's own units (registers);
+// dgh rows -> LDS;  carry' = dh*z + dgh W_hh  (MFMA, W_hh read column-wise: B[k=j][n=unit] = W_hh[j][unit]).
+template <int H>
+__global__ __launch_bounds__(512) void k_gru_bwd(const GruRecArgs A) {
+    constexpr int UT = H / 128, G3 = 3 * H, LDG = G3 + 4, KQ = G3 / 4;
+    float* db = smem;                                     // [16][LDG]  dgh rows of the current step
+    int* meta = reinterpret_cast<int*>(db + 16 * LDG);
+    const int b0 = blockIdx.x * 16;
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    lds_barrier();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    int tq[4], nq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { tq[q] = meta[4 * g + q]; nq[q] = meta[16 + 4 * g + q]; }
+    f32x4 carry[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) carry[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = nmax - 1; t >= 0; --t) {
+        f32x4 dhz[UT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int unit = w * (H / 8) + u * 16 + l16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool act = t < nq[q];
+                float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, keep = 0.f;
+                if (act) {
+                    const size_t tok = (size_t)(tq[q] + t), o = tok * H + unit;
+                    const float dh = A.dhout[o] + carry[u][q];
+                    const float rr = A.r[o], zz = A.z[o], nn = A.n[o], gh = A.ghn[o], hp = A.hprev[o];
+                    dn = dh * (1.0f - zz) * (1.0f - nn * nn);
+                    dz = dh * (hp - nn) * zz * (1.0f - zz);
+                    dr = dn * gh * rr * (1.0f - rr);
+                    dnr = dn * rr;
+                    keep = dh * zz;
+                    float* gp = A.dgi + tok * G3 + unit;
+                    gp[0] = dr; gp[H] = dz; gp[2 * H] = dn;
+                    float* hp2 = A.dgh + tok * G3 + unit;
+                    hp2[0] = dr; hp2[H] = dz; hp2[2 * H] = dnr;
+                }
+                dhz[u][q] = keep;
+                float* row = db + (4 * g + q) * LDG + unit;
+                row[0] = dr; row[H] = dz; row[2 * H] = dnr;
+            }
+        }
+        lds_barrier();
+        const float* ar = db + l16 * LDG + g * KQ;                      // A operand: dgh row of sequence l16
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int unit = w * (H / 8) + u * 16 + l16;                // output column (hidden unit) of this lane
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* wc = A.whh + (size_t)(g * KQ) * H + unit;
+#pragma unroll 4
+            for (int c = 0; c < KQ; c += 4) {
+                const float4 a = ld4(ar + c);
+                acc = mfma16g(a.x, wc[(size_t)c * H], acc);
+                acc = mfma16g(a.y, wc[(size_t)(c + 1) * H], acc);
+                acc = mfma16g(a.z, wc[(size_t)(c + 2) * H], acc);
+                acc = mfma16g(a.w, wc[(size_t)(c + 3) * H], acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) carry[u][q] = dhz[u][q] + acc[q];
+        }
+        lds_barrier();
+    }
+}
+
+static int launch_gru_rec(const GruRecArgs& A, int H, bool bwd, hipStream_t s) {
+    dim3 grid((A.B + 15) / 16), blk(512);
+    if (!bwd) {
+        const size_t lds = sizeof(float) * 2 * 16 * (H + 4) + 32 * sizeof(int);
+        if (H == 256) hipLaunchKernelGGL(k_gru_fwd<256>, grid, blk, lds, s, A);
+        else hipLaunchKernelGGL(k_gru_fwd<128>, grid, blk, lds, s, A);
+    } else {
+        const size_t lds = sizeof(float) * 16 * (3 * H + 4) + 32 * sizeof(int);
+        if (H == 256) { big_lds(k_gru_bwd<256>, lds); hipLaunchKernelGGL(k_gru_bwd<256>, grid, blk, lds, s, A); }
+        else hipLaunchKernelGGL(k_gru_bwd<128>, grid, blk, lds, s, A);
+    }
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// tail[0..1] += sum of the scorer's per-sequence (count, loss) partials
+__global__ __launch_bounds__(256) void k_sum_score_part(const float* __restrict__ part, float* __restrict__ tail, int B) {
+    __shared__ float red[512];
+    float c = 0.f, l = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) { c += part[2 * b]; l += part[2 * b + 1]; }
+    red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { tail[0] += red[0]; tail[1] += red[256]; }
+}
+
+// ------------------------------------------------------------------------------------------------ orchestration
+static int gru_forward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int zero_grads, hipStream_t s) {
+    const int D = p->D, H = p->H;
+    RC(launch_prep_raw(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, training ? 1 : 0, zero_grads ? p->grads : nullptr,
+                       ws.n_params + DR4SR_GRAD_TAIL, s));
+    RC(launch_embed_fwd_raw(p->params + ws.off_E, nullptr, p->in_item_id, p->rows, ws.cu, ws.X0, p->B, p->L, D, p->n_items, p->state,
+                            p->seed, p->p_drop, training, s));
+    const float* in = ws.X0;
+    int K = D;
+    for (int l = 0; l < p->n_layer; ++l) {
+        const GruLayerWs& w = ws.layer[l];
+        RC(launch_gemm(in, K, p->params + ws.off_wih[l], K, nullptr, w.gi, 3 * H, K, 3 * H, false, ws.Tmax, p->state, s));
+        GruRecArgs A{};
+        A.gi = w.gi; A.whh = p->params + ws.off_whh[l]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn;
+        A.hprev = w.hprev; A.hout = w.hout; A.B = p->B;
+        RC(launch_gru_rec(A, H, false, s));
+        in = w.hout;
+        K = H;
+    }
+    return launch_gemm(in, H, p->params + ws.off_ow, H, p->params + ws.off_ob, ws.Y, D, H, D, false, ws.Tmax, p->state, s);
+}
+
+static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int with_score, hipStream_t s) {
+    const int D = p->D, H = p->H, nl = p->n_layer;
+    // dH_top = dY W_out
+    RC(launch_gemm(ws.dY, D, p->params + ws.off_ow, H, nullptr, ws.dH, H, D, H, true, ws.Tmax, p->state, s));
+    for (int l = nl - 1; l >= 0; --l) {
+        const GruLayerWs& w = ws.layer[l];
+        GruRecArgs A{};
+        A.whh = p->params + ws.off_whh[l]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn; A.hprev = w.hprev;
+        A.dhout = ws.dH; A.dgi = w.dgi; A.dgh = w.dgh; A.B = p->B;
+        RC(launch_gru_rec(A, H, true, s));
+        // d(input of this layer) = dgi W_ih
+        if (l > 0) RC(launch_gemm(w.dgi, 3 * H, p->params + ws.off_wih[l], H, nullptr, ws.dH, H, 3 * H, H, true, ws.Tmax, p->state, s));
+        else RC(launch_gemm(w.dgi, 3 * H, p->params + ws.off_wih[0], D, nullptr, ws.dX0, D, 3 * H, D, true, ws.Tmax, p->state, s));
+    }
+    RC(launch_embed_bwd_raw(ws.dX0, p->in_item_id, p->rows, ws.cu, p->grads + ws.off_E, nullptr, p->B, p->L, D, p->n_items, p->state,
+                            p->seed, p->p_drop, training, s));
+    // weight gradients: one 64x64 output tile per job (jobs decoded in-kernel from per-matrix descriptors)
+    Wg64Args WA{};
+    int nj = 0;
+    auto add = [&](const float* G, int ldg, int NG, const float* X, int ldx, int KX, float* dW, float* dbias) {
+        Wg64Mat& M = WA.mat[WA.nmat++];
+        M.G = G; M.X = X; M.dW = dW; M.db = dbias; M.ldg = ldg; M.NG = NG; M.ldx = ldx; M.KX = KX; M.start = nj;
+        nj += (NG / 64) * (KX / 64);
+    };
+    float* Gd = p->grads;
+    for (int l = 0; l < nl; ++l) {
+        const GruLayerWs& w = ws.layer[l];
+        add(w.dgi, 3 * H, 3 * H, l == 0 ? ws.X0 : ws.layer[l - 1].hout, l == 0 ? D : H, l == 0 ? D : H, Gd + ws.off_wih[l], nullptr);
+        add(w.dgh, 3 * H, 3 * H, w.hprev, H, H, Gd + ws.off_whh[l], nullptr);
+    }
+    add(ws.dY, D, D, ws.layer[nl - 1].hout, H, H, Gd + ws.off_ow, Gd + ws.off_ob);
+    WA.state = p->state;
+    const int ntiles = (ws.Tmax + 63) / 64;
+    int gw = ntiles / 16 > 8 ? (ntiles / 16 > 32 ? 32 : ntiles / 16) : 8;
+    if (gw > ntiles) gw = ntiles;
+    hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
+    if (with_score) hipLaunchKernelGGL(k_sum_score_part, dim3(1), dim3(256), 0, s, ws.score_part, p->grads + ws.n_params, p->B);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream) {
+    GruWs ws;
+    RC(gru_ws(plan, &ws));
+    if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(gru_forward(plan, ws, 1, 1, s));
+    RC(launch_score_packed_raw(ws.Y, plan->params + ws.off_E, plan->grads + ws.off_E, ws.dY, plan->item_id, plan->rows, ws.cu,
+                               plan->neg_item, plan->sample_neg, ws.score_part, plan->state, plan->seed, plan->n_items, plan->B,
+                               plan->L, plan->D, s));
+    return gru_backward(plan, ws, 1, 1, s);
+}
+
+extern "C" int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream) {
+    RC(dr4sr_gru4rec_fwd_bwd(plan, stream));
+    return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
+                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream);
+}
+
+extern "C" int dr4sr_gru4rec_encode(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, float* out, void* stream) {
+    GruWs ws;
+    RC(gru_ws(plan, &ws));
+    if (!out || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(gru_forward(plan, ws, training, 0, s));
+    return launch_unpack_raw(ws.Y, ws.cu, out, plan->B, plan->L, plan->D, pooling == DR4SR_POOL_LAST, s);
+}
+
+extern "C" int dr4sr_gru4rec_encode_bwd(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, const float* d_out,
+                                        void* stream) {
+    GruWs ws;
+    RC(gru_ws(plan, &ws));
+    if (!d_out || !plan->grads || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RC(launch_pack_raw(d_out, ws.cu, ws.dY, plan->B, plan->L, plan->D, pooling == DR4SR_POOL_LAST, s));
+    return gru_backward(plan, ws, training, 0, s);
+}

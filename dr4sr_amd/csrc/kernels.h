@@ -100,6 +100,19 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 
+// raw (plan-independent) launchers shared with the GRU4Rec path
+int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
+                    int64_t zero_floats, hipStream_t s);
+int launch_embed_fwd_raw(const float* E, const float* P, const int64_t* idx, const int64_t* rows, const int* cu, float* X, int B,
+                         int L, int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s);
+int launch_embed_bwd_raw(const float* dX, const int64_t* idx, const int64_t* rows, const int* cu, float* dE, float* dP, int B, int L,
+                         int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s);
+int launch_unpack_raw(const float* X, const int* cu, float* out, int B, int L, int D, int last, hipStream_t s);
+int launch_pack_raw(const float* dout, const int* cu, float* dX, int B, int L, int D, int last, hipStream_t s);
+int launch_score_packed_raw(const float* Z, const float* E, float* dE, float* dZ, const int64_t* target, const int64_t* rows,
+                            const int* cu, int64_t* neg_item, int sample_neg, float* part, const int* state, uint64_t seed,
+                            int n_items, int B, int L, int D, hipStream_t s);
+
 int launch_attn2_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);   // MFMA, H == 2
 int launch_attn2_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 

@@ -123,20 +123,18 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
     }
 }
 
-int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
-    const float* E = p->params + ws.off[0];
-    float* dE = p->grads + ws.off[0];
-    float* tail = ws.score_part;
-    dim3 grid(p->B), blk(256);
-    const float* Z = ws.X[p->n_layer];
-    float* dZ = ws.dX[p->n_layer];
-    if (p->D == 64)
-        hipLaunchKernelGGL(k_score_packed<64>, grid, blk, 0, s, Z, E, dE, dZ, p->item_id, p->rows, ws.cu, p->neg_item,
-                           p->sample_neg, tail, p->state, p->seed, p->n_items, p->B, p->L);
-    else
-        hipLaunchKernelGGL(k_score_packed<128>, grid, blk, 0, s, Z, E, dE, dZ, p->item_id, p->rows, ws.cu, p->neg_item,
-                           p->sample_neg, tail, p->state, p->seed, p->n_items, p->B, p->L);
+int launch_score_packed_raw(const float* Z, const float* E, float* dE, float* dZ, const int64_t* target, const int64_t* rows,
+                            const int* cu, int64_t* neg_item, int sample_neg, float* part, const int* state, uint64_t seed,
+                            int n_items, int B, int L, int D, hipStream_t s) {
+    dim3 grid(B), blk(256);
+    if (D == 64) hipLaunchKernelGGL(k_score_packed<64>, grid, blk, 0, s, Z, E, dE, dZ, target, rows, cu, neg_item, sample_neg, part, state, seed, n_items, B, L);
+    else hipLaunchKernelGGL(k_score_packed<128>, grid, blk, 0, s, Z, E, dE, dZ, target, rows, cu, neg_item, sample_neg, part, state, seed, n_items, B, L);
     return DR4SR_LAUNCH_CHECK();
+}
+int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
+    return launch_score_packed_raw(ws.X[p->n_layer], p->params + ws.off[0], p->grads + ws.off[0], ws.dX[p->n_layer], p->item_id,
+                                   p->rows, ws.cu, p->neg_item, p->sample_neg, ws.score_part, p->state, p->seed, p->n_items, p->B,
+                                   p->L, p->D, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -210,6 +210,41 @@ int dr4sr_fmlp_encode_bwd(const dr4sr_fmlp_plan* plan, int32_t training, const f
 int dr4sr_adam_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * GRU4Rec (model/gru4rec.py:12-34; module/layers.py:117-136 = torch.nn.GRU(bias=False, batch_first, n_layer) + Linear(H->D)):
+ * x = dropout(E[idx]) -> GRU -> Linear -> 'origin'/'last' pooling -> scorer + BCE as SASRec.  D = 64, H in {128, 256},
+ * n_layer <= 4, L <= 64.  Only rows < seqlen are computed (post-padded rows; the recurrence is causal).
+ * Flat parameter layout: E[N,D] | per layer: weight_ih_l[3H,in] weight_hh_l[3H,H] | out_w[D,H] out_b[D]
+ *   (names: item_embedding.weight == query_encoder.0.1.weight, query_encoder.0.3.gru.weight_{ih,hh}_l{l},
+ *    query_encoder.1.{weight,bias}; gates ordered r|z|n as torch).  Optimizer: dr4sr_adam_flat (weight_decay 1e-4 in
+ *   configs/gru4rec.yaml is torch.optim.Adam's L2 form). */
+typedef struct dr4sr_gru4rec_plan {
+    int32_t abi_version;
+    int32_t B, L, D, H, n_layer, n_items;
+    float   p_drop;                 /* dropout on the item embeddings (configs/gru4rec.yaml: 0.2) */
+    uint64_t seed;
+    float*  params; float* grads; float* adam_m; float* adam_v;
+    int64_t n_params;
+    const int64_t* in_item_id;      /* [U,L] */
+    const int64_t* item_id;         /* [U,L] targets (may be NULL for encode) */
+    const int64_t* seqlen;          /* [U]   */
+    const int64_t* rows;            /* [B] or NULL */
+    int64_t* neg_item;              /* [B,L] */
+    int32_t  sample_neg;
+    void*    workspace; int64_t workspace_bytes;
+    int32_t* state;
+    float lr, beta1, beta2, adam_eps, weight_decay;
+} dr4sr_gru4rec_plan;
+
+int     dr4sr_gru4rec_plan_sizeof(void);
+/* offsets[0]=E, [1+2l]=weight_ih_l, [2+2l]=weight_hh_l, [1+2n]=out_w, [2+2n]=out_b; returns n_params */
+int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_t H, int32_t n_layer, int64_t* offsets);
+int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan);
+int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream);       /* basemodel.py:193-198, un-normalised grads */
+int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream);    /* + dense Adam */
+int dr4sr_gru4rec_encode(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, float* out, void* stream);
+int dr4sr_gru4rec_encode_bwd(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, const float* d_out, void* stream);
+
 /* Measurement hook: enqueue ONE kernel of the training step (on the state the last fwd_bwd left in
  * the workspace) so bench.py can bracket it with HIP events.  Not part of the reference surface. */
 #define DR4SR_K_PREP       0

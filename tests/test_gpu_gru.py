@@ -1,0 +1,86 @@
+"""GPU parity of the GRU4Rec path (dr4sr_gru4rec_* through the C ABI) vs golden vectors from the reference and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gru4rec_oracle as GO  # noqa: E402
+
+REL = 3e-4
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+def test_gru4rec_vs_golden(golden_dir):
+    from dr4sr_amd import _lib
+    from dr4sr_amd.gru_engine import GruEngine
+    z = np.load(os.path.join(golden_dir, "gru4rec_d64.npz"))
+    g = {k: z[k] for k in z.files}
+    params = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}
+    b = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("batch.")}
+    B = b["in_item_id"].shape[0]
+    eng = GruEngine(int(g["meta.num_items"]), 50, 64, int(g["meta.hidden_size"]), int(g["meta.layer_num"]), 0.0, B, "cuda",
+                    lr=float(g["meta.lr"]), weight_decay=float(g["meta.weight_decay"]))
+    eng.load_named(params)
+    dev = eng.device
+    idx, tgt, sl = b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev)
+    neg = b["neg_item"].squeeze(-1).contiguous().to(dev)
+    plan = eng.make_plan(idx, tgt, sl, neg_item=neg, sample_neg=False)
+    q = eng.encode(plan, False, _lib.POOL_ORIGIN)
+    assert relerr(q, g["out.query"]) < REL
+    ql = eng.encode(eng.make_plan(torch.from_numpy(g["eval.in_item_id"]).to(dev), None, torch.from_numpy(g["eval.seqlen"]).to(dev)),
+                    False, _lib.POOL_LAST)
+    assert relerr(ql, g["eval.query_last"]) < REL
+    eng.fwd_bwd(plan)
+    loss, n = eng.loss_and_count()
+    assert n == int((b["item_id"] != 0).sum()) and abs(loss - float(g["out.loss"])) < 1e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, g["grad." + k]) < REL, k
+    eng.adam_step()
+    for k, v in eng.views.items():
+        well = np.abs(g["grad." + k]) > 1e-4
+        d = v.cpu().numpy() - g["adam1." + k]
+        assert np.abs(d[well]).max(initial=0) < 1e-5 and np.abs(d).max() < 1.1e-3, k
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_gru4rec_full_size_vs_oracle(dense):
+    """BASELINE config 3 shapes: H = 256, 2 layers, d = 64, beauty-sized table, B = 64 rows (oracle BPTT on CPU stays fast)"""
+    from dr4sr_amd.data.synthetic import make_rows
+    from dr4sr_amd.gru_engine import GruEngine, gru_param_names, gru_param_shapes
+    N, B, H = 12102, 64, 256
+    rows = make_rows(n_rows=B, n_items=N, seed=3, dense=dense)
+    b = {k: torch.from_numpy(rows[k]) for k in ("in_item_id", "item_id", "seqlen")}
+    gen = torch.Generator().manual_seed(1)
+    b["neg_item"] = torch.randint(1, N, (B, 50, 1), generator=gen)
+    params = {}
+    for nme, shp in zip(gru_param_names(2), gru_param_shapes(N, 64, H, 2)):
+        params[nme] = 0.08 * torch.randn(shp, generator=gen)
+    params["item_embedding.weight"][0] = 0
+    p = 0.2
+    eng = GruEngine(N, 50, 64, H, 2, p, B, "cuda", seed=5)
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                         neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    step = int(eng.state[3])
+    mask = eng.dropout_mask(B * 50 * 64, 0, step).view(B, 50, 64).cpu()
+    op = dict(params)
+    op["query_encoder.0.1.weight"] = params["item_embedding.weight"]
+    loss_o, _, grads_o = GO.grads_of(op, b, 2, mask=mask, pdrop=p)
+    loss, n = eng.loss_and_count()
+    assert n == int((b["item_id"] != 0).sum()) and abs(loss - float(loss_o)) < 3e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, grads_o[k]) < REL, k
+    first = loss
+    for _ in range(20):
+        eng.train_step(plan)
+    assert eng.loss_and_count()[0] < first and int(eng.state[0]) == 20
