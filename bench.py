@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
+    ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp"],
+                    help="sasrec = BASELINE headline (configs[1]); gru4rec = configs[2] (beauty-sized table, dropout 0.2, wd 1e-4); "
+                         "fmlp = per-prefix left-padded rows, all B*L positions computed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,16 +101,41 @@ def main():
     lib = _lib.load()
 
     B, L, D, H, F, NL, N = args.batch, 50, 64, 2, 128, 2, TOYS_N_ITEMS
-    rows_np = make_rows(seed=2024, dense=args.dense)
+    if args.model == "gru4rec":
+        N = 12102                                       # amazon-beauty item count (2.Pretrain_regenerator.py:37-42)
+    rows_np = make_rows(n_items=N, seed=2024, dense=args.dense)
     U = rows_np["seqlen"].shape[0]
     data = {k: torch.from_numpy(rows_np[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
-    eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023, lr=1e-3)
-    init_params_like_reference(eng, 2023)
     perm = torch.from_numpy(np.random.default_rng(7).permutation(U)).to(dev)      # same permutation on every rank
     rows_buf = torch.zeros(B, dtype=torch.int64, device=dev)
     counter = torch.zeros(1, dtype=torch.int32, device=dev)
     negbuf = torch.zeros(B, L, dtype=torch.int64, device=dev)
-    plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+    if args.model == "sasrec":
+        eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023, lr=1e-3)
+        init_params_like_reference(eng, 2023)
+        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+    elif args.model == "gru4rec":
+        from dr4sr_amd.gru_engine import GruEngine
+        eng = GruEngine(N, L, D, 256, 2, 0.2, B, dev, seed=2023, lr=1e-3, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(2023)
+        for k, v in eng.views.items():
+            v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / 16.0 if "gru" in k else 0.02 * torch.randn(v.shape, generator=g))
+        eng.views["item_embedding.weight"][0] = 0
+        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+    else:
+        from dr4sr_amd.fmlp_engine import FmlpEngine
+        sl, hist = data["seqlen"], data["in_item_id"]                                # roll every row to a left-padded prefix
+        ar = torch.arange(L, device=dev).view(1, -1)
+        shift = (L - sl).view(-1, 1)
+        data["in_item_id"] = torch.where(ar >= shift, hist.gather(1, (ar - shift) % L), torch.zeros_like(hist)).contiguous()
+        data["item_id"] = data["item_id"].gather(1, (sl - 1).clamp(min=0).view(-1, 1)).squeeze(1).contiguous()
+        eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.5, B, dev, seed=2023, lr=1e-3)
+        g = torch.Generator().manual_seed(2023)
+        for k, v in eng.views.items():
+            v.copy_(torch.ones(v.shape) if k.endswith("LayerNorm.weight") else (torch.zeros(v.shape) if k.endswith("bias") else 0.02 * torch.randn(v.shape, generator=g)))
+        eng.views["item_embedding.weight"][0] = 0
+        negbuf = torch.zeros(B, dtype=torch.int64, device=dev)
+        plan = eng.make_plan(data["in_item_id"], data["item_id"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
     stream = torch.cuda.Stream(device=dev)
 
     def select():
@@ -172,21 +200,27 @@ def main():
             wall = float(tmax)
         loss, nvalid = eng.loss_and_count()
         T_last = int(eng.state[_lib.STATE_T])
+        model_desc = {"sasrec": "SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[1]): N=11925, L=50, d=64, 2 layers, 2 heads, "
+                                "FFN 128, dropout %.2f" % args.dropout,
+                      "gru4rec": "GRU4Rec on amazon-beauty-sized synthetic rows (BASELINE configs[2]): N=12102, L=50, d=64, GRU 2x256 no bias, "
+                                 "dropout 0.2, Adam wd 1e-4",
+                      "fmlp": "FMLP on toys-shaped synthetic per-prefix left-padded rows: N=11925, L=50, d=64, 2 x (filter + FFN 256), "
+                              "dropout 0.5, all B*L positions computed"}[args.model]
 
         out = {
-            "metric": "training sequences/sec, SASRec d=64 L=50", "value": world * B * args.steps / wall,
+            "metric": "training sequences/sec, %s d=64 L=50" % {"sasrec": "SASRec", "gru4rec": "GRU4Rec", "fmlp": "FMLP"}[args.model],
+            "value": world * B * args.steps / wall,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[1]): N=11925, L=50, d=64, "
-                                   "2 layers, 2 heads, FFN 128, dropout %.2f, B=%d rows/GPU/step, %s seqlen" %
-                                   (args.dropout, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
+            "config": {"workload": "%s, B=%d rows/GPU/step, %s seqlen" %
+                                   (model_desc, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
                        "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
                        "hip_graph": bool(use_graph)},
             "gpu_ms_per_step_events": gpu_ms / args.steps, "final_loss": loss, "valid_tokens_last_step": T_last,
         }
 
-        if rank == 0:
+        if rank == 0 and args.model == "sasrec":
             # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
             seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
             kinds = ["embed_fwd", "qkv_fwd", "attn_fwd", "post_fwd", "score", "transpose", "post_bwd", "attn_bwd",
@@ -240,7 +274,7 @@ def main():
             del outbuf, idx_big
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "sasrec":
             from oracle.ref_trainer import time_training
             r = time_training(rows_np, N, batch_size=256, warmup=3, max_steps=40, max_seconds=20.0, anomaly=True, p=args.dropout)
             out["cpu_baseline"] = {"value": r["seq_per_s"], "unit": "sequences/s", "cores": r["threads"], "kind": "port",
