@@ -267,9 +267,14 @@ def main():
             b.synchronize()
             us = a.elapsed_time(b) * 1e3 / 10
             gbytes = Bg * L * (8 + 8 * D) / 1e9
+            traffic = None                      # HBM bytes per launch from the PMC passes kept under profiles/ (separate runs)
+            pj = os.path.join(ROOT, "profiles", "round1_gather_pmc.json")
+            if os.path.exists(pj):
+                pm = json.load(open(pj))
+                traffic = Bg * L * (pm["fetch_bytes_per_token_corrected"] + pm["write_bytes_per_token"])
             out["roofline_gather"] = {"kernel": "k_embed_dense<64>", "bound": "hbm", "achieved": gbytes / (us * 1e-6),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbytes / (us * 1e-6) / HBM_PEAK_GBS,
-                                      "traffic": None, "tokens": Bg * L, "us_per_launch": us,
+                                      "traffic": traffic, "tokens": Bg * L, "us_per_launch": us,
                                       "algorithmic_bytes_per_token": 8 + 8 * D}
             del outbuf, idx_big
 
