@@ -201,6 +201,24 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NTW], float* __re
     }
 }
 
+// accumulators (+ bias) -> global C rows directly (C layout: 32 consecutive columns per half-wave = 128-B segments)
+template <int NTW>
+__device__ __forceinline__ void acc_to_global(const f32x16 (&acc)[NTW], float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                              int t0, int T) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, g = lane >> 5, rh = w & 1, cg = w >> 1;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int col = (cg + 2 * i) * 32 + r;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int t = t0 + rh * 32 + (q & 3) + 8 * (q >> 2) + 4 * g;
+            if (t < T) C[(size_t)t * ldc + col] = acc[i][q] + bv;
+        }
+    }
+}
+
 template <int NTW>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NTW]) {
 #pragma unroll

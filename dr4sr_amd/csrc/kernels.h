@@ -60,6 +60,9 @@ struct PostArgs {
     const int* state; uint64_t seed; float p; float eps; int layer; int training;
     uint32_t sP, sA, sF;                       // dropout sites: after out_proj / after activation (0xffffffff = none) / after linear2
     unsigned long long* stamps;                // debug: per-phase s_memtime of block 0 (NULL normally)
+    // layer-boundary fusions (NULL = not fused)
+    const float* nx_in_w; const float* nx_in_b; float* nx_qkv;     // fwd: also emit qkv of layer+1 = z W_in^T + b
+    const float* up_dqkv; const float* up_in_w; const float* up_du1;   // bwd: dz = up_dqkv W_in(layer+1) + up_du1 instead of reading A.dz
 };
 
 struct WgradJob {

@@ -85,10 +85,10 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // per SIMD overlaps global-load / shuffle / Philox latencies across rows instead of serialising them.
 //   v = res + drop(C)  -> U (global);  LN(v) -> OUT (global) [+ LDS copy];  (mean, rstd) -> ST
 template <int D, bool RES_IN_LDS, bool COPY_LDS>
-__device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc, const float* __restrict__ res, int ldres,
+__device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc, const float* res, int ldres,
                                            const float* __restrict__ lnw, const float* __restrict__ lnb, float eps,
                                            float* __restrict__ U, float* __restrict__ OUT, float* __restrict__ ST,
-                                           float* __restrict__ Ls, int ldl, int t0, int T, bool dodrop, const RngKey& rk,
+                                           float* Ls, int ldl, int t0, int T, bool dodrop, const RngKey& rk,
                                            uint32_t site) {
     constexpr int NV = D / 64;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
@@ -200,7 +200,16 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
         acc_to_lds(acc, R0, LD, A.b2);
     }
     lds_barrier(); STAMP(6);
-    ln_rowpass<D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
+    if (!FFN_ONLY && A.nx_qkv) {               // layer-boundary fusion: keep z in LDS and emit the next layer's in_proj
+        ln_rowpass<D, true, true>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, R1, LD, t0, T, dodrop, rk, sF);
+        lds_barrier();
+        f32x16 acc[3 * NV];
+        acc_zero(acc);
+        mma_64xN<D, 3 * NV>(R1, LD, A.nx_in_w, acc);
+        acc_to_global<3 * NV>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
+    } else {
+        ln_rowpass<D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
+    }
     STAMP(15);
 }
 
@@ -226,14 +235,14 @@ __device__ __forceinline__ void flush_affine(const float4 (&dgam)[NV], const flo
 }
 
 // LayerNorm backward over the 64 rows of a tile with the four row passes of a thread issued together (see ln_rowpass).
-//   g = SRC_GLOBAL ? Gg[t] : La[row] + Lb[row];   du = LN'(g; u, mean, rstd, gamma)
+//   g = Gg[t] (SRC 0) | La[row] + Lb[row] (SRC 1) | La[row] + Gg[t] (SRC 2);   du = LN'(g; u, mean, rstd, gamma)
 //   du -> DUg (global, optional) and DUl (LDS, optional);   du * dropout(site) -> DMg (global) and DMl (LDS)
-template <int D, bool SRC_GLOBAL>
-__device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, const float* __restrict__ La,
-                                               const float* __restrict__ Lb, int ldl, const float* __restrict__ Ug,
+template <int D, int SRC>
+__device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, const float* La,
+                                               const float* Lb, int ldl, const float* __restrict__ Ug,
                                                const float* __restrict__ ST, const float* __restrict__ lnw,
-                                               float* __restrict__ DUg, float* __restrict__ DUl, float* __restrict__ DMg,
-                                               float* __restrict__ DMl, float4 (&dgam)[D / 64], float4 (&dbet)[D / 64],
+                                               float* __restrict__ DUg, float* DUl, float* __restrict__ DMg,
+                                               float* DMl, float4 (&dgam)[D / 64], float4 (&dbet)[D / 64],
                                                int t0, int T, bool dodrop, const RngKey& rk, uint32_t site) {
     constexpr int NV = D / 64;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
@@ -256,9 +265,12 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
             const int c = 4 * l16 + 64 * j;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             u[ps][j] = ok ? ld4(Ug + (size_t)t * D + c) : z4;
-            if (SRC_GLOBAL) g[ps][j] = ok ? ld4(Gg + (size_t)t * D + c) : z4;
+            if (SRC == 0) g[ps][j] = ok ? ld4(Gg + (size_t)t * D + c) : z4;
             else {
-                const float4 p0 = ld4(La + row * ldl + c), p1 = ld4(Lb + row * ldl + c);
+                const float4 p0 = ld4(La + row * ldl + c);
+                float4 p1 = z4;
+                if (SRC == 1) p1 = ld4(Lb + row * ldl + c);
+                else if (ok) p1 = ld4(Gg + (size_t)t * D + c);
                 g[ps][j] = ok ? make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w) : z4;
             }
         }
@@ -288,9 +300,9 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64;
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
     if (t0 >= T) return;
-    float* R0 = smem;
-    float* R1 = R0 + 64 * LD;
-    float* R2 = R1 + 64 * LD;
+    float* R1 = smem;                          // R1 first: R0 and R2 are contiguous and together hold a [64][3D+4] dqkv tile
+    float* R0 = R1 + 64 * LD;
+    float* R2 = R0 + 64 * LD;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
@@ -299,7 +311,21 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     float4 dgam[NV], dbet[NV];
 
     // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
-    ln_bwd_rowpass<D, true>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
+    if (!FFN_ONLY && A.up_dqkv) {
+        // layer-boundary fusion: dz = dqkv(layer+1) W_in(layer+1) + du1(layer+1), computed here instead of a separate launch
+        constexpr int LQ = 3 * D + 4;
+        float* Aq = R0;                            // [64][LQ] spans R0 + R2 (see post_lds)
+        load_tile<3 * D>(Aq, LQ, A.up_dqkv, 3 * D, t0, T);
+        lds_barrier();
+        f32x16 acc[NV];
+        acc_zero(acc);
+        mma_64xN_wT<3 * D, NV>(Aq, LQ, A.up_in_w, D, acc);
+        acc_to_lds(acc, R1, LD, nullptr);
+        lds_barrier();
+        ln_bwd_rowpass<D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
+    } else {
+        ln_bwd_rowpass<D, 0>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
+    }
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D);
     // ---- dh = df W2   (x W^T form with W2^T [F][D])
     {
@@ -347,7 +373,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         }
         return;
     }
-    ln_bwd_rowpass<D, false>(nullptr, R0, R1, LD, A.u1, A.st1, A.ln1_w, A.du1, nullptr, A.dout, R1, dgam, dbet, t0, T, dodrop, rk, sP);
+    ln_bwd_rowpass<D, 1>(nullptr, R0, R1, LD, A.u1, A.st1, A.ln1_w, A.du1, nullptr, A.dout, R1, dgam, dbet, t0, T, dodrop, rk, sP);
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D + 2 * D);
     // ---- dctx = do W_out
     {
@@ -383,11 +409,19 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 63) / 64) * 4 * p->D;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
     A.sP = DR4SR_SITE_PROJ + 4 * layer; A.sA = DR4SR_SITE_ACT + 4 * layer; A.sF = DR4SR_SITE_FFN + 4 * layer;
+    A.nx_in_w = A.nx_in_b = nullptr; A.nx_qkv = nullptr; A.up_dqkv = A.up_in_w = A.up_du1 = nullptr;
+    if (layer + 1 < p->n_layer && !getenv("DR4SR_NO_FUSE")) {
+        A.nx_in_w = P + poff(ws, layer + 1, P_IN_W); A.nx_in_b = P + poff(ws, layer + 1, P_IN_B); A.nx_qkv = ws.layer[layer + 1].qkv;
+        A.up_dqkv = ws.layer[layer + 1].dqkv; A.up_in_w = P + poff(ws, layer + 1, P_IN_W); A.up_du1 = ws.layer[layer + 1].du1;
+    }
     A.stamps = getenv("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
     return A;
 }
 
-static size_t post_lds(int D, int F) { return sizeof(float) * 64 * (2 * (D + 4) + (F + 4)); }
+static size_t post_lds(int D, int F) {
+    const int rest = (D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4;     // R0+R2 must hold a [64][3D+4] tile
+    return sizeof(float) * 64 * ((D + 4) + rest);
+}
 
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const PostArgs A = make_post_args(p, ws, layer, training);
