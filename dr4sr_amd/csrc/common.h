@@ -227,6 +227,123 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NTW]) {
         for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------- tile-size abstraction
+// TileAcc<BM, N>: accumulators of a [BM x N] output tile owned by a 256-thread workgroup.
+//   BM = 64     : v_mfma_f32_32x32x2_f32, wave = (row half, column group), f32x16 per 32x32 tile       (throughput tiles)
+//   BM = 16 / 32: v_mfma_f32_16x16x4_f32, wave w owns column tiles w + 4i of every 16-row tile         (latency / occupancy tiles:
+//                 4x / 2x less serial MFMA work per workgroup, 4x / 2x less LDS => more workgroups per CU)
+__device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int BM, int N> struct TileAcc { f32x4 a[BM / 16][N / 64]; };
+template <int N> struct TileAcc<64, N> { f32x16 a[N / 64]; };
+
+template <int BM, int N> __device__ __forceinline__ void tile_zero(TileAcc<BM, N>& t) {
+    if constexpr (BM == 64) acc_zero(t.a);
+    else {
+#pragma unroll
+        for (int r = 0; r < BM / 16; ++r)
+#pragma unroll
+            for (int i = 0; i < N / 64; ++i) t.a[r][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+// C += A[BM x K] * W^T, W global [N][ldw]
+template <int BM, int K, int N>
+__device__ __forceinline__ void tile_mma_xwT(const float* __restrict__ As, int lda, const float* __restrict__ W, int ldw, TileAcc<BM, N>& t) {
+    if constexpr (BM == 64) mma_64xN_ld<K, N / 64>(As, lda, W, ldw, t.a);
+    else {
+        constexpr int KQ = K / 4, RT = BM / 16, CW = N / 64;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int c = 0; c < KQ; c += 4) {
+            float4 a[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = ld4(As + (r * 16 + r16) * lda + g * KQ + c);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+                const float4 b = ld4(W + (size_t)((w + 4 * i) * 16 + r16) * ldw + g * KQ + c);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    t.a[r][i] = mfma16x4(a[r].x, b.x, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].y, b.y, t.a[r][i]);
+                    t.a[r][i] = mfma16x4(a[r].z, b.z, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].w, b.w, t.a[r][i]);
+                }
+            }
+        }
+    }
+}
+// C += A[BM x KR] * W, W global [KR][ldw] (data-gradient form: forward weight read column-wise)
+template <int BM, int KR, int N>
+__device__ __forceinline__ void tile_mma_xw(const float* __restrict__ As, int lda, const float* __restrict__ W, int ldw, TileAcc<BM, N>& t) {
+    if constexpr (BM == 64) mma_64xN_wT<KR, N / 64>(As, lda, W, ldw, t.a);
+    else {
+        constexpr int KQ = KR / 4, RT = BM / 16, CW = N / 64;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int c = 0; c < KQ; c += 4) {
+            float4 a[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = ld4(As + (r * 16 + r16) * lda + g * KQ + c);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+                const float* wp = W + (size_t)(g * KQ + c) * ldw + (w + 4 * i) * 16 + r16;
+                const float b0 = wp[0], b1 = wp[ldw], b2 = wp[2 * ldw], b3 = wp[3 * ldw];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    t.a[r][i] = mfma16x4(a[r].x, b0, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].y, b1, t.a[r][i]);
+                    t.a[r][i] = mfma16x4(a[r].z, b2, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].w, b3, t.a[r][i]);
+                }
+            }
+        }
+    }
+}
+template <int BM, int N>
+__device__ __forceinline__ void tile_to_lds(const TileAcc<BM, N>& t, float* __restrict__ Cs, int ldc, const float* __restrict__ bias) {
+    if constexpr (BM == 64) acc_to_lds(t.a, Cs, ldc, bias);
+    else {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < N / 64; ++i) {
+            const int col = (w + 4 * i) * 16 + r16;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < BM / 16; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Cs[(r * 16 + 4 * g + q) * ldc + col] = t.a[r][i][q] + bv;
+        }
+    }
+}
+template <int BM, int N>
+__device__ __forceinline__ void tile_to_global(const TileAcc<BM, N>& t, float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                               int t0, int T) {
+    if constexpr (BM == 64) acc_to_global(t.a, C, ldc, bias, t0, T);
+    else {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < N / 64; ++i) {
+            const int col = (w + 4 * i) * 16 + r16;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < BM / 16; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tt = t0 + r * 16 + 4 * g + q;
+                    if (tt < T) C[(size_t)tt * ldc + col] = t.a[r][i][q] + bv;
+                }
+        }
+    }
+}
+
+// cooperative load of a [BM x K] tile (rows t0.. of a [T x ldg] global matrix, zero beyond T) into LDS, row stride lda
+template <int BM, int K>
+__device__ __forceinline__ void load_tile_bm(float* __restrict__ As, int lda, const float* __restrict__ G, int ldg, int t0, int T) {
+    constexpr int C4 = K / 4;
+    for (int i = threadIdx.x; i < BM * C4; i += 256) {
+        const int row = i / C4, c = (i % C4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 + row < T) v = ld4(G + (size_t)(t0 + row) * ldg + c);
+        st4(As + row * lda + c, v);
+    }
+}
+
 // cooperative load of a [64 x K] tile (rows t0..t0+63 of a [T x ldg] global matrix, zero beyond T)
 // into LDS with row stride lda.  256 threads, float4 per thread per pass.
 template <int K>

@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dX,
 
 int launch_embed_bwd_raw(const float* dX, const int64_t* idx, const int64_t* rows, const int* cu, float* dE, float* dP, int B, int L,
                          int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s) {
-    dim3 grid(B < 64 ? B : 64), blk(256);
+    int g = B / 4;                                   // ~4 sequences per block: dP costs g*L*D atomics, g-way per address
+    g = g < 1 ? 1 : (g > 128 ? 128 : g);
+    dim3 grid(g), blk(256);
     if (D == 64) hipLaunchKernelGGL(k_embed_bwd<64>, grid, blk, 0, s, dX, idx, rows, cu, dE, dP, B, L, n_items, state, seed, p, training);
     else hipLaunchKernelGGL(k_embed_bwd<128>, grid, blk, 0, s, dX, idx, rows, cu, dE, dP, B, L, n_items, state, seed, p, training);
     return DR4SR_LAUNCH_CHECK();

@@ -78,6 +78,7 @@ struct WgradArgs {
     // reduce jobs (blockIdx.y == 6): LayerNorm affine partials of every layer, scorer partials
     const float* ln_part; int64_t ln_layer_stride; float* grads; int64_t o_ln1_w; int64_t layer_stride;   // ln1_w,ln1_b,ln2_w,ln2_b contiguous
     const float* score_part; float* tail; int B; int D;
+    int ln_tile_rows;                          // token rows per LayerNorm-partial row (tile size of the post kernels)
 };
 
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);

@@ -44,37 +44,41 @@ int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hi
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int D>
+template <int BM, int D>
 __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                  const float* __restrict__ bias, float* __restrict__ QKV,
                                                  const int* __restrict__ state) {
-    constexpr int N = 3 * D, LDA = D + 4, LDC = N + 4;
-    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    constexpr int N = 3 * D, LDA = D + 4;
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
     float* As = smem;
-    float* Cs = smem + 64 * LDA;
-    load_tile<D>(As, LDA, X, D, t0, T);
+    load_tile_bm<BM, D>(As, LDA, X, D, t0, T);
     lds_barrier();
-    f32x16 acc[N / 64];
-    acc_zero(acc);
-    mma_64xN<D, N / 64>(As, LDA, W, acc);
-    acc_to_lds(acc, Cs, LDC, bias);
-    lds_barrier();
-    constexpr int C4 = N / 4;
-    for (int i = threadIdx.x; i < 64 * C4; i += 256) {
-        const int row = i / C4, c = (i % C4) * 4;
-        if (t0 + row < T) st4(QKV + (size_t)(t0 + row) * N + c, ld4(Cs + row * LDC + c));
-    }
+    TileAcc<BM, N> acc;
+    tile_zero(acc);
+    tile_mma_xwT<BM, D, N>(As, LDA, W, D, acc);
+    tile_to_global<BM, N>(acc, QKV, N, bias, t0, T);
 }
 
+// tile rows per workgroup for the token-tile kernels: 16 while the whole batch is small (latency regime: 4x shorter MFMA
+// chains, every CU gets work), 32 at scale (occupancy regime: 4 workgroups per CU interleave their latency chains).
+int tile_rows(const Workspace& ws) {
+    static const int forced = getenv("DR4SR_BM") ? atoi(getenv("DR4SR_BM")) : 0;
+    if (forced == 16 || forced == 32 || forced == 64) return forced;
+    return ws.Tmax <= 16384 ? 16 : 32;
+}
+#define BM_DISPATCH(bm, CALL) do { if ((bm) == 16) { CALL(16); } else if ((bm) == 32) { CALL(32); } else { CALL(64); } } while (0)
+
 int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s) {
-    const int D = p->D;
-    const size_t lds = sizeof(float) * 64 * ((D + 4) + (3 * D + 4));
-    dim3 grid((ws.Tmax + 63) / 64), blk(256);
+    const int D = p->D, bm = tile_rows(ws);
+    const size_t lds = sizeof(float) * bm * (D + 4);
+    dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
     const float* W = p->params + poff(ws, layer, P_IN_W);
     const float* b = p->params + poff(ws, layer, P_IN_B);
-    if (D == 64) { big_lds(k_qkv_fwd<64>, lds); hipLaunchKernelGGL(k_qkv_fwd<64>, grid, blk, lds, s, ws.X[layer], W, b, ws.layer[layer].qkv, p->state); }
-    else { big_lds(k_qkv_fwd<128>, lds); hipLaunchKernelGGL(k_qkv_fwd<128>, grid, blk, lds, s, ws.X[layer], W, b, ws.layer[layer].qkv, p->state); }
+#define QF(B_) do { if (D == 64) hipLaunchKernelGGL((k_qkv_fwd<B_, 64>), grid, blk, lds, s, ws.X[layer], W, b, ws.layer[layer].qkv, p->state); \
+                    else hipLaunchKernelGGL((k_qkv_fwd<B_, 128>), grid, blk, lds, s, ws.X[layer], W, b, ws.layer[layer].qkv, p->state); } while (0)
+    BM_DISPATCH(bm, QF);
+#undef QF
     return DR4SR_LAUNCH_CHECK();
 }
 
@@ -84,20 +88,20 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // a thread issued together (loads first, then four independent reduction chains, then stores) so that the single wave
 // per SIMD overlaps global-load / shuffle / Philox latencies across rows instead of serialising them.
 //   v = res + drop(C)  -> U (global);  LN(v) -> OUT (global) [+ LDS copy];  (mean, rstd) -> ST
-template <int D, bool RES_IN_LDS, bool COPY_LDS>
+template <int BM, int D, bool RES_IN_LDS, bool COPY_LDS>
 __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc, const float* res, int ldres,
                                            const float* __restrict__ lnw, const float* __restrict__ lnb, float eps,
                                            float* __restrict__ U, float* __restrict__ OUT, float* __restrict__ ST,
                                            float* Ls, int ldl, int t0, int T, bool dodrop, const RngKey& rk,
                                            uint32_t site) {
-    constexpr int NV = D / 64;
+    constexpr int NV = D / 64, PASSES = BM / 16;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
-    float4 gam[NV], bet[NV], v[4][NV];
-    float mean[4], rstd[4];
+    float4 gam[NV], bet[NV], v[PASSES][NV];
+    float mean[PASSES], rstd[PASSES];
 #pragma unroll
     for (int j = 0; j < NV; ++j) { gam[j] = ld4(lnw + 4 * l16 + 64 * j); bet[j] = ld4(lnb + 4 * l16 + 64 * j); }
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
         const int row = ps * 16 + rsub, t = t0 + row;
         const bool ok = t < T;
 #pragma unroll
@@ -113,9 +117,9 @@ __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc
         }
     }
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) ln_stats16<NV>(v[ps], mean[ps], rstd[ps], eps);
+    for (int ps = 0; ps < PASSES; ++ps) ln_stats16<NV>(v[ps], mean[ps], rstd[ps], eps);
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
         const int row = ps * 16 + rsub, t = t0 + row;
         const bool ok = t < T;
 #pragma unroll
@@ -131,14 +135,14 @@ __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc
     }
 }
 
-template <int D, int F, bool FFN_ONLY>
+template <int BM, int D, int F, bool FFN_ONLY>
 __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
-    constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64;
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    constexpr int LD = D + 4, LF = F + 4, NVF = F / 64, PASSES = BM / 16;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
     float* R0 = smem;                 // [64][LD]  ctx tile, later linear2 output
-    float* R1 = R0 + 64 * LD;         // [64][LD]  y tile
-    float* R2 = R1 + 64 * LD;         // [64][LF]  out_proj output (ld LD), then linear1 output / h
+    float* R1 = R0 + BM * LD;         // [64][LD]  y tile
+    float* R2 = R1 + BM * LD;         // [64][LF]  out_proj output (ld LD), then linear1 output / h
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
@@ -147,37 +151,37 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
 
     STAMP(0);
     if (FFN_ONLY) {                            // FMLP Intermediate block: the input tile IS y
-        load_tile<D>(R1, LD, A.x, D, t0, T);
+        load_tile_bm<BM, D>(R1, LD, A.x, D, t0, T);
     } else {
-        load_tile<D>(R0, LD, A.ctx, D, t0, T);
+        load_tile_bm<BM, D>(R0, LD, A.ctx, D, t0, T);
         lds_barrier(); STAMP(1);
         {
-            f32x16 acc[NV];
-            acc_zero(acc);
-            mma_64xN<D, NV>(R0, LD, A.out_w, acc);
-            acc_to_lds(acc, R2, LD, A.out_b);
+            TileAcc<BM, D> acc;
+            tile_zero(acc);
+            tile_mma_xwT<BM, D, D>(R0, LD, A.out_w, D, acc);
+            tile_to_lds<BM, D>(acc, R2, LD, A.out_b);
         }
         lds_barrier(); STAMP(2);
         // ---- dropout1 + residual + LayerNorm1
-        ln_rowpass<D, false, true>(R2, LD, A.x, D, A.ln1_w, A.ln1_b, A.eps, A.u1, A.y, A.st1, R1, LD, t0, T, dodrop, rk, sP);
+        ln_rowpass<BM, D, false, true>(R2, LD, A.x, D, A.ln1_w, A.ln1_b, A.eps, A.u1, A.y, A.st1, R1, LD, t0, T, dodrop, rk, sP);
     }
     lds_barrier(); STAMP(3);
     // ---- linear1 + GELU + dropout
     {
-        f32x16 acc[NVF];
-        acc_zero(acc);
-        mma_64xN<D, NVF>(R1, LD, A.w1, acc);
-        acc_to_lds(acc, R2, LF, A.b1);
+        TileAcc<BM, F> acc;
+        tile_zero(acc);
+        tile_mma_xwT<BM, D, F>(R1, LD, A.w1, D, acc);
+        tile_to_lds<BM, F>(acc, R2, LF, A.b1);
     }
     lds_barrier(); STAMP(4);
     {
-        float4 av[4][NVF];
+        float4 av[PASSES][NVF];
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
+        for (int ps = 0; ps < PASSES; ++ps)
 #pragma unroll
             for (int j = 0; j < NVF; ++j) av[ps][j] = ld4(R2 + (ps * 16 + rsub) * LF + 4 * l16 + 64 * j);
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
+        for (int ps = 0; ps < PASSES; ++ps) {
             const int row = ps * 16 + rsub, t = t0 + row;
             const bool ok = t < T;
 #pragma unroll
@@ -194,21 +198,21 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
     lds_barrier(); STAMP(5);
     // ---- linear2 + dropout2 + residual + LayerNorm2
     {
-        f32x16 acc[NV];
-        acc_zero(acc);
-        mma_64xN<F, NV>(R2, LF, A.w2, acc);
-        acc_to_lds(acc, R0, LD, A.b2);
+        TileAcc<BM, D> acc;
+        tile_zero(acc);
+        tile_mma_xwT<BM, F, D>(R2, LF, A.w2, F, acc);
+        tile_to_lds<BM, D>(acc, R0, LD, A.b2);
     }
     lds_barrier(); STAMP(6);
     if (!FFN_ONLY && A.nx_qkv) {               // layer-boundary fusion: keep z in LDS and emit the next layer's in_proj
-        ln_rowpass<D, true, true>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, R1, LD, t0, T, dodrop, rk, sF);
+        ln_rowpass<BM, D, true, true>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, R1, LD, t0, T, dodrop, rk, sF);
         lds_barrier();
-        f32x16 acc[3 * NV];
-        acc_zero(acc);
-        mma_64xN<D, 3 * NV>(R1, LD, A.nx_in_w, acc);
-        acc_to_global<3 * NV>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
+        TileAcc<BM, 3 * D> acc;
+        tile_zero(acc);
+        tile_mma_xwT<BM, D, 3 * D>(R1, LD, A.nx_in_w, D, acc);
+        tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
     } else {
-        ln_rowpass<D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
+        ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
     }
     STAMP(15);
 }
@@ -237,17 +241,17 @@ __device__ __forceinline__ void flush_affine(const float4 (&dgam)[NV], const flo
 // LayerNorm backward over the 64 rows of a tile with the four row passes of a thread issued together (see ln_rowpass).
 //   g = Gg[t] (SRC 0) | La[row] + Lb[row] (SRC 1) | La[row] + Gg[t] (SRC 2);   du = LN'(g; u, mean, rstd, gamma)
 //   du -> DUg (global, optional) and DUl (LDS, optional);   du * dropout(site) -> DMg (global) and DMl (LDS)
-template <int D, int SRC>
+template <int BM, int D, int SRC>
 __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, const float* La,
                                                const float* Lb, int ldl, const float* __restrict__ Ug,
                                                const float* __restrict__ ST, const float* __restrict__ lnw,
                                                float* __restrict__ DUg, float* DUl, float* __restrict__ DMg,
                                                float* DMl, float4 (&dgam)[D / 64], float4 (&dbet)[D / 64],
                                                int t0, int T, bool dodrop, const RngKey& rk, uint32_t site) {
-    constexpr int NV = D / 64;
+    constexpr int NV = D / 64, PASSES = BM / 16;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
-    float4 gam[NV], g[4][NV], u[4][NV];
-    float mean[4], rstd[4];
+    float4 gam[NV], g[PASSES][NV], u[PASSES][NV];
+    float mean[PASSES], rstd[PASSES];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         gam[j] = ld4(lnw + 4 * l16 + 64 * j);
@@ -255,7 +259,7 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
         dbet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
         const int row = ps * 16 + rsub, t = t0 + row;
         const bool ok = t < T;
         mean[ps] = ok ? ST[2 * (size_t)t] : 0.f;
@@ -276,9 +280,9 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
         }
     }
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) ln_bwd_row<NV>(g[ps], u[ps], mean[ps], rstd[ps], gam, dgam, dbet);
+    for (int ps = 0; ps < PASSES; ++ps) ln_bwd_row<NV>(g[ps], u[ps], mean[ps], rstd[ps], gam, dgam, dbet);
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
         const int row = ps * 16 + rsub, t = t0 + row;
         const bool ok = t < T;
 #pragma unroll
@@ -295,14 +299,14 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
     }
 }
 
-template <int D, int F, bool FFN_ONLY>
+template <int BM, int D, int F, bool FFN_ONLY>
 __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
-    constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64;
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64, PASSES = BM / 16;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
     float* R1 = smem;                          // R1 first: R0 and R2 are contiguous and together hold a [64][3D+4] dqkv tile
-    float* R0 = R1 + 64 * LD;
-    float* R2 = R0 + 64 * LD;
+    float* R0 = R1 + BM * LD;
+    float* R2 = R0 + BM * LD;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
@@ -315,29 +319,29 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         // layer-boundary fusion: dz = dqkv(layer+1) W_in(layer+1) + du1(layer+1), computed here instead of a separate launch
         constexpr int LQ = 3 * D + 4;
         float* Aq = R0;                            // [64][LQ] spans R0 + R2 (see post_lds)
-        load_tile<3 * D>(Aq, LQ, A.up_dqkv, 3 * D, t0, T);
+        load_tile_bm<BM, 3 * D>(Aq, LQ, A.up_dqkv, 3 * D, t0, T);
         lds_barrier();
-        f32x16 acc[NV];
-        acc_zero(acc);
-        mma_64xN_wT<3 * D, NV>(Aq, LQ, A.up_in_w, D, acc);
-        acc_to_lds(acc, R1, LD, nullptr);
+        TileAcc<BM, D> acc;
+        tile_zero(acc);
+        tile_mma_xw<BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, acc);
+        tile_to_lds<BM, D>(acc, R1, LD, nullptr);
         lds_barrier();
-        ln_bwd_rowpass<D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
+        ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
     } else {
-        ln_bwd_rowpass<D, 0>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
+        ln_bwd_rowpass<BM, D, 0>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
     }
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D);
     // ---- dh = df W2   (x W^T form with W2^T [F][D])
     {
-        f32x16 acc[NVF];
-        acc_zero(acc);
-        mma_64xN_wT<D, NVF>(R0, LD, A.w2, F, acc);
-        acc_to_lds(acc, R2, LF, nullptr);
+        TileAcc<BM, F> acc;
+        tile_zero(acc);
+        tile_mma_xw<BM, D, F>(R0, LD, A.w2, F, acc);
+        tile_to_lds<BM, F>(acc, R2, LF, nullptr);
     }
     lds_barrier();
     // ---- da = dh * mask_act * gelu'(a)
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
         const int row = ps * 16 + rsub, t = t0 + row;
 #pragma unroll
         for (int j = 0; j < NVF; ++j) {
@@ -356,15 +360,15 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     lds_barrier();
     // ---- dy = da W1 + du2 ;  LayerNorm1 backward -> du1 ;  do = du1*mask -> R1
     {
-        f32x16 acc[NV];
-        acc_zero(acc);
-        mma_64xN_wT<F, NV>(R2, LF, A.w1, D, acc);
-        acc_to_lds(acc, R0, LD, nullptr);
+        TileAcc<BM, D> acc;
+        tile_zero(acc);
+        tile_mma_xw<BM, F, D>(R2, LF, A.w1, D, acc);
+        tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
     if (FFN_ONLY) {                            // FMLP: d(input) = da W1 + du2, nothing upstream inside this kernel
         constexpr int C4f = D / 4;
-        for (int i = threadIdx.x; i < 64 * C4f; i += 256) {
+        for (int i = threadIdx.x; i < BM * C4f; i += 256) {
             const int row = i / C4f, c = (i % C4f) * 4;
             if (t0 + row < T) {
                 const float4 p0 = ld4(R0 + row * LD + c), p1 = ld4(R1 + row * LD + c);
@@ -373,18 +377,18 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         }
         return;
     }
-    ln_bwd_rowpass<D, 1>(nullptr, R0, R1, LD, A.u1, A.st1, A.ln1_w, A.du1, nullptr, A.dout, R1, dgam, dbet, t0, T, dodrop, rk, sP);
+    ln_bwd_rowpass<BM, D, 1>(nullptr, R0, R1, LD, A.u1, A.st1, A.ln1_w, A.du1, nullptr, A.dout, R1, dgam, dbet, t0, T, dodrop, rk, sP);
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D + 2 * D);
     // ---- dctx = do W_out
     {
-        f32x16 acc[NV];
-        acc_zero(acc);
-        mma_64xN_wT<D, NV>(R1, LD, A.out_w, D, acc);
-        acc_to_lds(acc, R0, LD, nullptr);
+        TileAcc<BM, D> acc;
+        tile_zero(acc);
+        tile_mma_xw<BM, D, D>(R1, LD, A.out_w, D, acc);
+        tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
     constexpr int C4 = D / 4;
-    for (int i = threadIdx.x; i < 64 * C4; i += 256) {
+    for (int i = threadIdx.x; i < BM * C4; i += 256) {
         const int row = i / C4, c = (i % C4) * 4;
         if (t0 + row < T) st4(A.dctx + (size_t)(t0 + row) * D + c, ld4(R0 + row * LD + c));
     }
@@ -406,7 +410,7 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     const int D = p->D, F = p->F;
     A.out_wT = wT + 3 * D * D; A.w1T = wT + 4 * D * D; A.w2T = wT + 4 * D * D + D * F;
     A.df = lw.df; A.da = lw.da; A.du1 = lw.du1; A.dout = lw.dout; A.dctx = ws.dctx;
-    A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 63) / 64) * 4 * p->D;
+    A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 15) / 16) * 4 * p->D;      // stride sized for the smallest tile
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
     A.sP = DR4SR_SITE_PROJ + 4 * layer; A.sA = DR4SR_SITE_ACT + 4 * layer; A.sF = DR4SR_SITE_FFN + 4 * layer;
     A.nx_in_w = A.nx_in_b = nullptr; A.nx_qkv = nullptr; A.up_dqkv = A.up_in_w = A.up_du1 = nullptr;
@@ -418,68 +422,71 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     return A;
 }
 
-static size_t post_lds(int D, int F) {
-    const int rest = (D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4;     // R0+R2 must hold a [64][3D+4] tile
-    return sizeof(float) * 64 * ((D + 4) + rest);
+static size_t post_lds(int D, int F, int bm = 64) {
+    const int rest = (D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4;     // R0+R2 must hold a [BM][3D+4] tile
+    return sizeof(float) * bm * ((D + 4) + rest);
 }
 
+template <int BM>
+static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, bool bwd, hipStream_t s) {
+    dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
+    const size_t lds = post_lds(p->D, p->F, BM);
+#define PL(D_, F_) do { if (bwd) { big_lds(k_post_bwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_bwd<BM, D_, F_, false>), grid, blk, lds, s, A); } \
+                        else { big_lds(k_post_fwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_fwd<BM, D_, F_, false>), grid, blk, lds, s, A); } } while (0)
+    if (p->D == 64 && p->F == 128) PL(64, 128);
+    else if (p->D == 128 && p->F == 128) PL(128, 128);
+    else if (p->D == 64 && p->F == 256) PL(64, 256);
+    else return DR4SR_E_SHAPE;
+#undef PL
+    return DR4SR_LAUNCH_CHECK();
+}
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const PostArgs A = make_post_args(p, ws, layer, training);
-    dim3 grid((ws.Tmax + 63) / 64), blk(256);
-    const size_t lds = post_lds(p->D, p->F);
-    if (p->D == 64 && p->F == 128) { big_lds(k_post_fwd<64, 128, false>, lds); hipLaunchKernelGGL((k_post_fwd<64, 128, false>), grid, blk, lds, s, A); }
-    else if (p->D == 128 && p->F == 128) { big_lds(k_post_fwd<128, 128, false>, lds); hipLaunchKernelGGL((k_post_fwd<128, 128, false>), grid, blk, lds, s, A); }
-    else if (p->D == 64 && p->F == 256) { big_lds(k_post_fwd<64, 256, false>, lds); hipLaunchKernelGGL((k_post_fwd<64, 256, false>), grid, blk, lds, s, A); }
-    else return DR4SR_E_SHAPE;
-    return DR4SR_LAUNCH_CHECK();
+    const int bm = tile_rows(ws);
+    return bm == 16 ? post_launch_bm<16>(p, ws, A, false, s) : bm == 32 ? post_launch_bm<32>(p, ws, A, false, s) : post_launch_bm<64>(p, ws, A, false, s);
 }
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const PostArgs A = make_post_args(p, ws, layer, training);
-    dim3 grid((ws.Tmax + 63) / 64), blk(256);
-    const size_t lds = post_lds(p->D, p->F);
-    if (p->D == 64 && p->F == 128) { big_lds(k_post_bwd<64, 128, false>, lds); hipLaunchKernelGGL((k_post_bwd<64, 128, false>), grid, blk, lds, s, A); }
-    else if (p->D == 128 && p->F == 128) { big_lds(k_post_bwd<128, 128, false>, lds); hipLaunchKernelGGL((k_post_bwd<128, 128, false>), grid, blk, lds, s, A); }
-    else if (p->D == 64 && p->F == 256) { big_lds(k_post_bwd<64, 256, false>, lds); hipLaunchKernelGGL((k_post_bwd<64, 256, false>), grid, blk, lds, s, A); }
-    else return DR4SR_E_SHAPE;
-    return DR4SR_LAUNCH_CHECK();
+    const int bm = tile_rows(ws);
+    return bm == 16 ? post_launch_bm<16>(p, ws, A, true, s) : bm == 32 ? post_launch_bm<32>(p, ws, A, true, s) : post_launch_bm<64>(p, ws, A, true, s);
 }
 
 // FMLP Intermediate block (module/layers.py:761-779): linear1 -> GELU -> linear2 -> dropout -> +x -> LayerNorm, D=64, F=256
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s) {
     dim3 grid((Tmax + 63) / 64), blk(256);
     const size_t lds = post_lds(64, 256);
-    big_lds(k_post_fwd<64, 256, true>, lds);
-    hipLaunchKernelGGL((k_post_fwd<64, 256, true>), grid, blk, lds, s, A);
+    big_lds(k_post_fwd<64, 64, 256, true>, lds);
+    hipLaunchKernelGGL((k_post_fwd<64, 64, 256, true>), grid, blk, lds, s, A);
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s) {
     dim3 grid((Tmax + 63) / 64), blk(256);
     const size_t lds = post_lds(64, 256);
-    big_lds(k_post_bwd<64, 256, true>, lds);
-    hipLaunchKernelGGL((k_post_bwd<64, 256, true>), grid, blk, lds, s, A);
+    big_lds(k_post_bwd<64, 64, 256, true>, lds);
+    hipLaunchKernelGGL((k_post_bwd<64, 64, 256, true>), grid, blk, lds, s, A);
     return DR4SR_LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------
 // dx = dqkv W_in + du1   (x W^T form with W_in^T [D][3D])
-template <int D>
+template <int BM, int D>
 __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQKV, const float* __restrict__ WT,
                                                  const float* __restrict__ dU1, float* __restrict__ dXo,
                                                  const int* __restrict__ state) {
-    constexpr int K = 3 * D, LDA = K + 4, LDC = D + 4, NV = D / 64;
-    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    constexpr int K = 3 * D, LDA = K + 4, LDC = D + 4;
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
     float* As = smem;
-    float* Cs = smem + 64 * LDA;
-    load_tile<K>(As, LDA, dQKV, K, t0, T);
+    float* Cs = smem + BM * LDA;
+    load_tile_bm<BM, K>(As, LDA, dQKV, K, t0, T);
     lds_barrier();
-    f32x16 acc[NV];
-    acc_zero(acc);
-    mma_64xN_wT<K, NV>(As, LDA, WT, D, acc);
-    acc_to_lds(acc, Cs, LDC, nullptr);
+    TileAcc<BM, D> acc;
+    tile_zero(acc);
+    tile_mma_xw<BM, K, D>(As, LDA, WT, D, acc);
+    tile_to_lds<BM, D>(acc, Cs, LDC, nullptr);
     lds_barrier();
     constexpr int C4 = D / 4;
-    for (int i = threadIdx.x; i < 64 * C4; i += 256) {
+    for (int i = threadIdx.x; i < BM * C4; i += 256) {
         const int row = i / C4, c = (i % C4) * 4;
         if (t0 + row < T) {
             const float4 v = ld4(Cs + row * LDC + c), r = ld4(dU1 + (size_t)(t0 + row) * D + c);
@@ -489,13 +496,15 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQKV,
 }
 
 int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s) {
-    const int D = p->D;
-    const size_t lds = sizeof(float) * 64 * ((3 * D + 4) + (D + 4));
-    dim3 grid((ws.Tmax + 63) / 64), blk(256);
+    const int D = p->D, bm = tile_rows(ws);
+    const size_t lds = sizeof(float) * bm * ((3 * D + 4) + (D + 4));
+    dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
     const float* WT = p->params + poff(ws, layer, P_IN_W);      // forward weight used as-is (column-mode B operand)
     const LayerWs& lw = ws.layer[layer];
-    if (D == 64) { big_lds(k_qkv_bwd<64>, lds); hipLaunchKernelGGL(k_qkv_bwd<64>, grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); }
-    else { big_lds(k_qkv_bwd<128>, lds); hipLaunchKernelGGL(k_qkv_bwd<128>, grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); }
+#define QB(B_) do { if (D == 64) { big_lds(k_qkv_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_bwd<B_, 64>), grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); } \
+                    else { big_lds(k_qkv_bwd<B_, 128>, lds); hipLaunchKernelGGL((k_qkv_bwd<B_, 128>), grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); } } while (0)
+    BM_DISPATCH(bm, QB);
+#undef QB
     return DR4SR_LAUNCH_CHECK();
 }
 
@@ -611,7 +620,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
 // (layout ln1_w | ln1_b | ln2_w | ln2_b), tiles strided over gridDim.x blocks; block (0, layer 0) also folds the
 // scorer's per-sequence (count, loss) partials into the gradient tail.
 __device__ __forceinline__ void reduce_jobs(const WgradArgs& A) {
-    const int T = A.state[DR4SR_STATE_T], ntiles = (T + 63) / 64, D = A.D, layer = blockIdx.z;
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + A.ln_tile_rows - 1) / A.ln_tile_rows, D = A.D, layer = blockIdx.z;
     const float* part = A.ln_part + (size_t)layer * A.ln_layer_stride;
     float* g = A.grads + A.o_ln1_w + (size_t)layer * A.layer_stride;
     for (int c = threadIdx.x; c < 4 * D; c += 256) {
@@ -712,7 +721,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     }
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.training = training;
     const int ntiles = (ws.Tmax + 63) / 64;
-    A.ln_part = ws.ln_part; A.ln_layer_stride = (int64_t)ntiles * 4 * D; A.grads = G;
+    A.ln_part = ws.ln_part; A.ln_layer_stride = (int64_t)((ws.Tmax + 15) / 16) * 4 * D; A.grads = G; A.ln_tile_rows = tile_rows(ws);
     A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
     static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 48;   // tuning knob

@@ -68,7 +68,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
     ws->score_part = take(2LL * p->B);
-    ws->ln_part = take((int64_t)p->n_layer * ((Tmax + 63) / 64) * 4 * D);
+    ws->ln_part = take((int64_t)p->n_layer * ((Tmax + 15) / 16) * 4 * D);
     for (int l = 0; l < p->n_layer; ++l) {
         LayerWs& w = ws->layer[l];
         w.qkv = take(Tmax * 3 * D); w.ctx = take(Tmax * D);
