@@ -100,42 +100,49 @@ int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Packed forward: for sequence slot b and pos < n_b:  x[cu[b]+pos,:] = drop(E[idx,:] + P[pos,:]).
-// One wave per sequence (toys-shaped batches average 5.5 valid positions), LPT lanes per row.
+// sequence slot of packed token t: the b with cu[b] <= t < cu[b+1] (binary search; cu is L1/L2 resident)
+__device__ __forceinline__ int find_seq(const int* __restrict__ cu, int B, int t) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Packed forward, token-parallel: token t belongs to sequence slot b = find_seq(t) at pos = t - cu[b]:
+//   x[t,:] = drop(E[idx[row(b),pos],:] + P[pos,:])      (P == NULL: no position table, GRU4Rec)
+// One 16/32-lane group per token; the grid covers the worst case B*L tokens, groups beyond T exit.
 template <int D>
 __global__ __launch_bounds__(256) void k_embed_fwd(const float* __restrict__ E, const float* __restrict__ P,
                                                    const int64_t* __restrict__ idx, const int64_t* __restrict__ rows,
                                                    const int* __restrict__ cu, float* __restrict__ X, int B, int L,
                                                    int n_items, const int* __restrict__ state, uint64_t seed, float p,
                                                    int training) {
-    constexpr int LPT = D / 4, RPW = 64 / LPT;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int lane = threadIdx.x & 63, sub = lane / LPT, c = (lane % LPT) * 4;
-    const int t0 = cu[b], n = cu[b + 1] - t0;
+    constexpr int LPT = D / 4, TPB = 256 / LPT;
+    const int T = state[DR4SR_STATE_T];
+    const int t = blockIdx.x * TPB + threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
+    if (t >= T) return;
+    const int b = find_seq(cu, B, t), pos = t - cu[b];
     const int64_t row = rows ? rows[b] : b;
-    const bool dodrop = training && p > 0.f;
-    RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], p);
-    for (int pos = sub; pos < n; pos += RPW) {
-        int64_t id = idx[row * L + pos];
-        id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
-        const float4 e = ld4(E + id * D + c);
-        float4 o = e;
-        if (P) {                                        // GRU4Rec has no position table
-            const float4 pe = ld4(P + (size_t)pos * D + c);
-            o = make_float4(e.x + pe.x, e.y + pe.y, e.z + pe.z, e.w + pe.w);
-        }
-        if (dodrop) {
-            const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
-            o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
-        }
-        st4(X + (size_t)(t0 + pos) * D + c, o);
+    int64_t id = idx[row * L + pos];
+    id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+    float4 o = ld4(E + id * D + c);
+    if (P) {
+        const float4 pe = ld4(P + (size_t)pos * D + c);
+        o = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
     }
+    if (training && p > 0.f) {
+        const RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], p);
+        const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
+        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+    }
+    st4(X + (size_t)t * D + c, o);
 }
 
 int launch_embed_fwd_raw(const float* E, const float* P, const int64_t* idx, const int64_t* rows, const int* cu, float* X, int B,
                          int L, int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s) {
-    dim3 grid((B + 3) / 4), blk(256);
+    dim3 grid(((int64_t)B * L + (256 / (D / 4)) - 1) / (256 / (D / 4))), blk(256);
     if (D == 64) hipLaunchKernelGGL(k_embed_fwd<64>, grid, blk, 0, s, E, P, idx, rows, cu, X, B, L, n_items, state, seed, p, training);
     else hipLaunchKernelGGL(k_embed_fwd<128>, grid, blk, 0, s, E, P, idx, rows, cu, X, B, L, n_items, state, seed, p, training);
     return DR4SR_LAUNCH_CHECK();
@@ -146,61 +153,53 @@ int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int traini
 }
 
 // ------------------------------------------------------------------------------------------------
-// Packed backward: g = dX[t,:] * mask;  dE[idx,:] += g (skipped for idx == 0: padding_idx),
-// dP[pos,:] += g.  Each block walks sequences b = blockIdx.x, +gridDim.x, ... and keeps its share of
-// dP in registers (thread = (pos mod PG, 4 dims)), so dP costs gridDim.x*L*D atomics, not T*D.
+// Packed backward, token-parallel: g = dX[t,:] * mask;  dE[idx,:] += g (skipped for idx == 0: padding_idx), dP[pos,:] += g.
+// Each block handles 64 consecutive tokens; dP is first accumulated in LDS (ds atomics) and flushed once per block.
 template <int D>
 __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dX, const int64_t* __restrict__ idx,
                                                    const int64_t* __restrict__ rows, const int* __restrict__ cu,
                                                    float* __restrict__ dE, float* __restrict__ dP, int B, int L,
                                                    int n_items, const int* __restrict__ state, uint64_t seed, float p,
                                                    int training) {
-    constexpr int LPT = D / 4, PG = 256 / LPT;          // PG position groups (16 for D=64, 8 for D=128)
-    constexpr int MAXP = (64 + PG - 1) / PG;            // L <= 64
-    const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
-    float4 accP[MAXP];
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) accP[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int LPT = D / 4, TPB = 256 / LPT;
+    __shared__ float accP[64 * D];                      // [L <= 64][D]
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 64;
+    if (t0 >= T) return;
+    if (dP) for (int i = threadIdx.x; i < L * D; i += 256) accP[i] = 0.f;
+    __syncthreads();
+    const int c = (threadIdx.x % LPT) * 4;
     const bool dodrop = training && p > 0.f;
-    RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], p);
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const int t0 = cu[b], n = cu[b + 1] - t0;
+    const RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], p);
+    for (int t = t0 + threadIdx.x / LPT; t < min(T, t0 + 64); t += TPB) {
+        const int b = find_seq(cu, B, t), pos = t - cu[b];
         const int64_t row = rows ? rows[b] : b;
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int pos = sub + i * PG;
-            if (pos < n) {
-                float4 g = ld4(dX + (size_t)(t0 + pos) * D + c);
-                if (dodrop) {
-                    const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
-                    g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
-                }
-                accP[i].x += g.x; accP[i].y += g.y; accP[i].z += g.z; accP[i].w += g.w;
-                const int64_t id = idx[row * L + pos];
-                if (id > 0 && id < n_items) {
-                    float* d = dE + id * D + c;
-                    unsafeAtomicAdd(d, g.x); unsafeAtomicAdd(d + 1, g.y);
-                    unsafeAtomicAdd(d + 2, g.z); unsafeAtomicAdd(d + 3, g.w);
-                }
-            }
+        float4 g = ld4(dX + (size_t)t * D + c);
+        if (dodrop) {
+            const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
+            g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+        }
+        if (dP) {
+            float* a = accP + pos * D + c;
+            atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); atomicAdd(a + 3, g.w);
+        }
+        const int64_t id = idx[row * L + pos];
+        if (id > 0 && id < n_items) {
+            float* d = dE + id * D + c;
+            unsafeAtomicAdd(d, g.x); unsafeAtomicAdd(d + 1, g.y); unsafeAtomicAdd(d + 2, g.z); unsafeAtomicAdd(d + 3, g.w);
         }
     }
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int pos = sub + i * PG;
-        if (dP && pos < L) {
-            float* d = dP + (size_t)pos * D + c;
-            unsafeAtomicAdd(d, accP[i].x); unsafeAtomicAdd(d + 1, accP[i].y);
-            unsafeAtomicAdd(d + 2, accP[i].z); unsafeAtomicAdd(d + 3, accP[i].w);
+    if (dP) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < L * D; i += 256) {
+            const float v = accP[i];
+            if (v != 0.f) unsafeAtomicAdd(dP + i, v);
         }
     }
 }
 
 int launch_embed_bwd_raw(const float* dX, const int64_t* idx, const int64_t* rows, const int* cu, float* dE, float* dP, int B, int L,
                          int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s) {
-    int g = B / 4;                                   // ~4 sequences per block: dP costs g*L*D atomics, g-way per address
-    g = g < 1 ? 1 : (g > 128 ? 128 : g);
-    dim3 grid(g), blk(256);
+    dim3 grid(((int64_t)B * L + 63) / 64), blk(256);
     if (D == 64) hipLaunchKernelGGL(k_embed_bwd<64>, grid, blk, 0, s, dX, idx, rows, cu, dE, dP, B, L, n_items, state, seed, p, training);
     else hipLaunchKernelGGL(k_embed_bwd<128>, grid, blk, 0, s, dX, idx, rows, cu, dE, dP, B, L, n_items, state, seed, p, training);
     return DR4SR_LAUNCH_CHECK();
