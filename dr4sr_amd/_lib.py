@@ -118,6 +118,19 @@ SYMBOLS = {
     "dr4sr_gru4rec_encode_bwd": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_adam_flat": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_meta_param_count": (C.c_int64, [C.c_int32]),
+    "dr4sr_meta_select_workspace_floats": (C.c_int64, [C.c_int64]),
+    "dr4sr_meta_select_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_void_p, _f32p, C.c_void_p]),
+    "dr4sr_meta_select_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,
+                                        C.c_int32, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
+    "dr4sr_fd_step_size": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_float, _f32p, C.c_void_p]),
+    "dr4sr_fd_shift": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
+    "dr4sr_fd_neumann": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
+    "dr4sr_fd_diff": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
+    "dr4sr_scale_by": (C.c_int, [_f32p, _f32p, _f32p, C.c_int64, C.c_void_p]),
+    "dr4sr_meta_sgd_step": (C.c_int, [_f32p, _f32p, _f32p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                      _f32p, C.c_void_p]),
     "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }
 

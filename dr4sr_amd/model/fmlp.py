@@ -92,6 +92,18 @@ class FMLP(BaseModel):
     def training_step(self, batch, reduce=True, return_query=False, align=False):
         return super().training_step(batch, reduce, return_query)
 
+    def _encode_raw(self, batch, training=True):
+        eng = self.engine
+        return eng.encode(eng.make_plan(batch["in_" + self.fiid], None), training)
+
+    def _encode_bwd_raw(self, batch, d_query, training=True):
+        eng = self.engine
+        eng.encode_bwd(eng.make_plan(batch["in_" + self.fiid], None), training, d_query)
+
+    def _batch_plan(self, batch):
+        return self.engine.make_plan(batch["in_" + self.fiid], batch[self.fiid],
+                                     neg_item=batch["neg_item"].contiguous().view(-1), sample_neg=False)
+
     def _api_plan(self):
         return None
 

@@ -1,0 +1,354 @@
+"""MetaModel (DR4SR+) with the class surface of the reference's model/metamodel.py (MetaModel :19-197) and the
+implicit-differentiation optimiser of utils/utils.py:134-252 (Hypergrad, MetaOptimizer), over the HIP sub-models.
+
+  inner step (metamodel.py:174-194)   loss = sum_p weight_p * loss_p,  weight = gumbel_softmax(meta_module(query))[..., 0],
+                                      1 on pattern rows (user_id == 0), 0 on PAD targets.  The gradient reaches the
+                                      sub-model through loss_p AND through weight_p(query) as in the reference.
+  outer step (metamodel.py:123-166)   every `interval` steps after `warmup_epoch`: hyper-gradient of the plain loss on a
+                                      second batch w.r.t. the meta module via a truncated Neumann series (3 Hessian-vector
+                                      products) and one mixed second derivative; clip to 10; SGD(momentum 0.9, wd).
+
+Second order WITHOUT double-backward kernels: the library's hand-written first-order backward G(W) = dL_train/dW is
+differentiated by central differences along the needed directions only (dr4sr_fd_* in include/dr4sr_hip.h):
+      H v            = [G(W + e v) - G(W - e v)] / 2e            (x hpo_lr = 1e-3 inside the Neumann recursion)
+      d/dphi (G . p) = [dL_train/dphi(W + e p) - dL_train/dphi(W - e p)] / 2e
+with identical dropout masks, negatives and Gumbel noise in every evaluation and the meta module's ReLU pattern frozen at
+W (autograd's ReLU'' = 0).  tests/test_meta_oracle.py shows this form within 2e-4 of the reference's double-backward result
+(golden vectors from RUNNING the reference), tests/test_gpu_meta.py checks the HIP path against the same vectors.
+
+All arithmetic runs in libdr4sr_hip.so; torch provides buffers, copies and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..parallel import allreduce_flat, shard_bounds
+from ..utils.config import get_model_class, load_config
+from .basemodel import BaseModel, normal_initialization
+from .sasrec import _Linear
+
+
+class _PhiStore:
+    """flat fp32 storage of the meta module (layout of dr4sr_meta_param_count) + its gradient, exposing named views"""
+
+    def __init__(self, lib, D: int, device):
+        n = int(lib.dr4sr_meta_param_count(D))
+        if n <= 0:
+            raise _lib.Dr4srError(f"MetaModel: embed_dim {D} unsupported by the meta-module kernels (D = 64)")
+        self.n = n
+        self.params = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=device)
+        self.views, self.grad_views = OrderedDict(), OrderedDict()
+        off = 0
+        for name, shp in (("0.weight", (D, D)), ("0.bias", (D,)), ("2.weight", (2, D)), ("2.bias", (2,))):
+            k = 1
+            for s in shp:
+                k *= s
+            self.views[name] = self.params[off:off + k].view(shp)
+            self.grad_views[name] = self.grads[off:off + k].view(shp)
+            off += k
+
+
+class _Select(torch.autograd.Function):
+    """MetaModel.selection + the weight masks of training_step through dr4sr_meta_select_fwd/_bwd (API path)"""
+
+    @staticmethod
+    def forward(ctx, meta, query, anchor, user_id, target):
+        q = query.contiguous()
+        w = meta._select_fwd(q, user_id, target, meta._gumbel, None, None)
+        ctx.meta = meta
+        ctx.save_for_backward(q, user_id, target)
+        return w.view(target.shape)
+
+    @staticmethod
+    def backward(ctx, gw):
+        q, user_id, target = ctx.saved_tensors
+        dq = torch.zeros_like(q)
+        ctx.meta._select_bwd(q, user_id, target, ctx.meta._gumbel, None, gw.contiguous().view(-1).float(), dq)
+        return None, dq, None, None, None
+
+
+class MetaOptimizer:
+    """utils/utils.py:207-255 facade: clip_grad_norm_(10) + the reference's default meta optimizer (SGD momentum 0.9)"""
+
+    def __init__(self, model, lr, hpo_lr, weight_decay, truncate_iter=3, max_grad_norm=10.0):
+        self.model, self.lr, self.hpo_lr, self.weight_decay = model, lr, hpo_lr, weight_decay
+        self.truncate_iter, self.max_grad_norm, self.momentum = truncate_iter, max_grad_norm, 0.9
+        dev = model._phi.params.device
+        self.momentum_buf = torch.zeros_like(model._phi.params)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def zero_grad(self):
+        self.model._phi.grads.zero_()
+
+    def step_with(self, hyper_grad: torch.Tensor):
+        phi = self.model._phi
+        _lib.check(self.model.lib.dr4sr_meta_sgd_step(_lib.ptr(phi.params), _lib.ptr(hyper_grad), _lib.ptr(self.momentum_buf), phi.n,
+                                                      self.lr, self.momentum, self.weight_decay,
+                                                      self.max_grad_norm if self.max_grad_norm is not None else 0.0,
+                                                      _lib.ptr(self.step_count), _lib.ptr(self.last_grad_norm), _lib.cur_stream()),
+                   "dr4sr_meta_sgd_step")
+
+
+class MetaModel(BaseModel):
+    def __init__(self, config: Dict, dataset_list) -> None:
+        super().__init__(config, dataset_list)
+        self.interval = config["train"]["interval"]
+        self.step_counter = 0
+        self.item_embedding = None                    # MetaModel is just a trainer without item embedding (metamodel.py:24)
+        self.tau = nn.Parameter(torch.ones(1, device=self.device) * 10)
+        self.counter = 0
+        self._gumbel = None                           # explicit Gumbel noise [n,2] (tests); None = Philox in-kernel
+        self._bufs: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------ setup
+    def _init_model(self, train_data):
+        self.sub_model: BaseModel = self._register_sub_model()
+        self.sub_model._init_model(train_data)
+        self.item_embedding = self.sub_model.item_embedding
+        self.engine = self.sub_model.engine           # topk / evaluate run on the sub-model's engine
+        self.lib = self.engine.lib
+        self.device = self.sub_model.device
+        self._phi = _PhiStore(self.lib, self.embed_dim, self.device)
+        self.meta_module: nn.Module = self._register_meta_modules()
+        self.meta_module.apply(normal_initialization)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(self._phi.params, src=0)
+        self.meta_optimizer = self._get_meta_optimizers()
+        self.metaloader_iter = iter(self.current_epoch_metaloaders(nepoch=0))
+        n = self.engine.n_params
+        self._sel_ws = torch.empty(int(self.lib.dr4sr_meta_select_workspace_floats(
+            int(self.config["train"]["batch_size"]) * self.max_seq_len)), dtype=torch.float32, device=self.device)
+        self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._e = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._tail_p = torch.zeros(_lib.GRAD_TAIL, dtype=torch.float32, device=self.device)
+
+    def _register_sub_model(self) -> BaseModel:
+        sub_cfg = load_config({"dataset": self.config["data"]["dataset"], "model": self.config["model"]["sub_model"]})
+        sub_cfg["train"]["device"] = self.config["train"]["device"]     # the reference hard-codes 0 (metamodel.py:47)
+        for k in ("batch_size", "seed"):
+            sub_cfg["train"][k] = self.config["train"][k]
+        for sec, kv in (self.config["model"].get("sub_overrides") or {}).items():     # extension: e.g. {'model': {'dropout_rate': 0}}
+            sub_cfg[sec].update(kv)
+        self.logger.info(sub_cfg)
+        return get_model_class(sub_cfg["model"]["model"])(sub_cfg, self.dataset_list)
+
+    def _register_meta_modules(self) -> nn.Module:
+        D = self.embed_dim
+        return nn.Sequential(_Linear(self._phi, "0.", D, D), nn.ReLU(), _Linear(self._phi, "2.", 2, D))
+
+    def _get_meta_optimizers(self):
+        tc = self.config["train"]
+        if tc["meta_optimizer"].lower() != "sgd":
+            raise NotImplementedError("meta_optimizer: the HIP path implements configs/metamodel.yaml's SGD(momentum 0.9) only")
+        return MetaOptimizer(self, float(tc["meta_learning_rate"]), float(tc["hpo_learning_rate"]), float(tc["meta_weight_decay"]))
+
+    def forward(self, batch):
+        return self.sub_model.forward(batch)
+
+    def current_epoch_metaloaders(self, nepoch):
+        return self.dataset_list[0].get_loader()
+
+    def _tau_eff(self) -> float:
+        return max(float(self.tau.detach()), float(self.config["model"]["tau_min"]))
+
+    def _buf(self, name, n, dtype=torch.float32):
+        t = self._bufs.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(n, dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t[:n]
+
+    # ------------------------------------------------------------------------------------------ selection kernels
+    @staticmethod
+    def _bl(target):
+        return int(target.shape[0]), (int(target.shape[1]) if target.dim() == 2 else 1)
+
+    def _select_fwd(self, q, user_id, target, gumbel, gate_in, gate_out):
+        B, L = self._bl(target)
+        w = torch.empty(B * L, dtype=torch.float32, device=q.device)
+        _lib.check(self.lib.dr4sr_meta_select_fwd(_lib.ptr(q), _lib.ptr(self._phi.params), _lib.ptr(gumbel), self.engine.seed,
+                                                  self.counter, self._tau_eff(), _lib.ptr(user_id), _lib.ptr(target.contiguous()),
+                                                  B, L, self.embed_dim, _lib.ptr(gate_in), _lib.ptr(gate_out), _lib.ptr(w),
+                                                  _lib.cur_stream()), "dr4sr_meta_select_fwd")
+        return w
+
+    def _select_bwd(self, q, user_id, target, gumbel, gate_in, d_weight, d_query):
+        B, L = self._bl(target)
+        need = int(self.lib.dr4sr_meta_select_workspace_floats(B * L))
+        if self._sel_ws.numel() < need:
+            self._sel_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dr4sr_meta_select_bwd(_lib.ptr(q), _lib.ptr(self._phi.params), _lib.ptr(gumbel), self.engine.seed,
+                                                  self.counter, self._tau_eff(), _lib.ptr(user_id), _lib.ptr(target.contiguous()),
+                                                  B, L, self.embed_dim, _lib.ptr(gate_in), _lib.ptr(d_weight), None,
+                                                  _lib.ptr(d_query), _lib.ptr(self._phi.grads), _lib.ptr(self._sel_ws),
+                                                  _lib.cur_stream()), "dr4sr_meta_select_bwd")
+
+    def selection(self, query):
+        """metamodel.py:169-172 (no masks): weight in (0,1) per position"""
+        shp = query.shape[:-1]
+        ones = torch.ones(shp, dtype=torch.int64, device=query.device)
+        return _Select.apply(self, query, self._phi.params, None, ones).view(shp)
+
+    # ------------------------------------------------------------------------------------------ API path (autograd)
+    def training_step(self, batch, reduce=True, return_query=True, align=False):
+        loss_value, query = self.sub_model.training_step(batch, reduce=False, return_query=True, align=False)
+        weight = _Select.apply(self, query, self._phi.params, batch["user_id"].contiguous(), batch[self.fiid].contiguous())
+        self.counter += 1
+        return (loss_value * weight).sum()
+
+    # ------------------------------------------------------------------------------------------ fused weighted step
+    def _weighted_fwd_bwd(self, batch, gate_in=None, gate_out=None):
+        """un-normalised gradients of sum_p weight_p loss_p: d/dW into sub.engine.grads (tail = {n_valid, weighted loss sum}),
+        d/dphi into self._phi.grads.  Every rank-local quantity is a plain SUM, so DP is one all-reduce of both buffers."""
+        sub, eng, lib = self.sub_model, self.engine, self.lib
+        tgt, neg, uid = batch[self.fiid].contiguous(), batch["neg_item"].contiguous(), batch["user_id"].contiguous()
+        B, L = self._bl(tgt)
+        eng.grads.zero_()
+        self._phi.grads.zero_()
+        self._stats.zero_()
+        q = sub._encode_raw(batch, True)
+        lp = self._buf("lp", B * L)
+        E = self.item_embedding.weight
+        _lib.check(lib.dr4sr_score_bce_fwd(_lib.ptr(q), _lib.ptr(E), _lib.ptr(tgt), _lib.ptr(neg), None, None, _lib.ptr(lp),
+                                           _lib.ptr(self._stats), B, L, eng.D, _lib.cur_stream()), "score_bce_fwd")
+        w = self._select_fwd(q, uid, tgt, self._gumbel, gate_in, gate_out)
+        dq = self._buf("dq", q.numel()).view(q.shape)
+        dE = eng.grad_views["item_embedding.weight"]
+        _lib.check(lib.dr4sr_score_bce_bwd(_lib.ptr(q), _lib.ptr(E), _lib.ptr(tgt), _lib.ptr(neg), _lib.ptr(w), None, _lib.ptr(dq),
+                                           _lib.ptr(dE), B, L, eng.D, _lib.cur_stream()), "score_bce_bwd")
+        self._select_bwd(q, uid, tgt, self._gumbel, gate_in, lp, dq)
+        sub._encode_bwd_raw(batch, dq, True)
+        tail = eng.grads[eng.n_params:eng.n_params + 2]
+        tail[0:1].copy_(self._stats[0:1])
+        tail[1:2].copy_(torch.dot(w, lp).view(1))      # reported loss only
+        return w, lp
+
+    def _reduce_grads(self):
+        if self.world_size > 1:
+            allreduce_flat(self.engine.grads)
+            allreduce_flat(self._phi.grads)
+
+    def _local_batch(self, loader, perm, i):
+        lo, hi = shard_bounds(i, loader.batch_size, loader.n, self.world_size, self.rank)
+        rows = perm[lo:hi]
+        batch = {k: v.index_select(0, rows) for k, v in loader.fields.items()}
+        batch["index"] = rows
+        return batch
+
+    def _perm(self, loader):
+        perm = loader.permutation()
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(perm, src=0)
+        return perm
+
+    def training_epoch(self, nepoch):
+        loader = self.current_epoch_trainloaders(nepoch)
+        sub, eng = self.sub_model, self.engine
+        if not nepoch > self.config["train"]["warmup_epoch"]:
+            out = sub.training_epoch(nepoch)              # metamodel.py:111-112: plain sub-model steps, no outer loop
+            self.step_counter += len(loader)
+            return out
+        perm = self._perm(loader)
+        nb = len(loader)
+        losses = torch.empty(nb, dtype=torch.float32, device=self.device)
+        for i in range(nb):
+            batch = self._local_batch(loader, perm, i)
+            if batch["user_id"].shape[0] > 0:
+                batch["neg_item"] = self._neg_sampling(batch)
+                self._weighted_fwd_bwd(batch)
+            else:
+                eng.grads.zero_()
+                self._phi.grads.zero_()
+            self.counter += 1
+            self._reduce_grads()
+            losses[i] = eng.grads[eng.n_params + 1]       # metamodel.py:186-194: the weighted SUM (already / n_valid)
+            losses[i] /= eng.grads[eng.n_params]
+            eng.adam_step(sub._api_plan())
+            self.step_counter += 1
+            if self.step_counter % self.config["train"]["interval"] == 0:
+                self._outter_loop(nepoch)
+        return [[{"loss_0": losses}]]
+
+    def _neg_sampling(self, batch):
+        return self.sub_model._neg_sampling(batch)
+
+    # ------------------------------------------------------------------------------------------ outer loop
+    def _outter_loop(self, nepoch):
+        """metamodel.py:123-166: one meta ('validation') batch + one train batch, fresh shuffles, then MetaOptimizer.step"""
+        ml = self.current_epoch_metaloaders(nepoch)
+        bv = self._local_batch(ml, self._perm(ml), 0)
+        bv["neg_item"] = self._neg_sampling(bv)
+        tl = self.current_epoch_trainloaders(nepoch)
+        bt = self._local_batch(tl, self._perm(tl), 0)
+        bt["neg_item"] = self._neg_sampling(bt)
+        self.hypergrad_step(bv, bt)
+
+    def hypergrad(self, bv, bt) -> torch.Tensor:
+        """Hypergrad.grad (utils/utils.py:145-178) -> flat d/dphi [n_phi]; see the module docstring for the formulation."""
+        sub, eng, lib, st = self.sub_model, self.engine, self.lib, _lib.cur_stream
+        n, nphi = eng.n_params, self._phi.n
+        mo = self.meta_optimizer
+        rel = float(self.config["train"].get("hypergrad_rel_step", 5e-4))
+        theta0 = self._buf("theta0", n)
+        theta0.copy_(eng.params)
+        v, pacc, gp = self._buf("v", n), self._buf("pacc", n), self._buf("gp", n + _lib.GRAD_TAIL)
+        # dL_val/dW: plain training_step on the meta batch (fresh dropout masks)                      utils.py:154-159
+        eng.fwd_bwd(sub._batch_plan(bv))
+        if self.world_size > 1:
+            allreduce_flat(eng.grads)
+        _lib.check(lib.dr4sr_scale_by(_lib.ptr(v), _lib.ptr(eng.grads), _lib.ptr(eng.grads[n:n + 1]), n, st()), "scale_by")
+        pacc.copy_(v)
+        # the train-batch graph: ONE set of dropout masks / Gumbel noise shared by every evaluation     utils.py:161-166
+        rng0 = eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].clone()
+        self.counter += 1
+        gate = self._buf("gate", bt[self.fiid].numel(), torch.int64)
+        q0 = sub._encode_raw(bt, True)
+        self._select_fwd(q0, bt["user_id"].contiguous(), bt[self.fiid].contiguous(), self._gumbel, None, gate)
+
+        def probe(direction, sign):
+            _lib.check(lib.dr4sr_fd_shift(_lib.ptr(eng.params), _lib.ptr(theta0), _lib.ptr(direction), _lib.ptr(self._e), sign, n,
+                                          st()), "fd_shift")
+            eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0)
+            self._weighted_fwd_bwd(bt, gate_in=gate)
+            self._reduce_grads()
+
+        for _ in range(mo.truncate_iter):                                                             # utils.py:180-205
+            _lib.check(lib.dr4sr_fd_step_size(_lib.ptr(theta0), _lib.ptr(v), n, rel, _lib.ptr(self._e), st()), "fd_step_size")
+            probe(v, 1.0)
+            gp.copy_(eng.grads)
+            probe(v, -1.0)
+            _lib.check(lib.dr4sr_fd_neumann(_lib.ptr(v), _lib.ptr(pacc), _lib.ptr(gp), _lib.ptr(eng.grads), _lib.ptr(gp[n:n + 1]),
+                                            _lib.ptr(eng.grads[n:n + 1]), _lib.ptr(self._e), mo.hpo_lr, n, st()), "fd_neumann")
+        # mixed second derivative d/dphi (dL_train/dW . p)                                               utils.py:170-178
+        _lib.check(lib.dr4sr_fd_step_size(_lib.ptr(theta0), _lib.ptr(pacc), n, rel, _lib.ptr(self._e), st()), "fd_step_size")
+        fp = self._buf("fp", nphi)
+        probe(pacc, 1.0)
+        fp.copy_(self._phi.grads)
+        self._tail_p.copy_(eng.grads[n:n + _lib.GRAD_TAIL])
+        probe(pacc, -1.0)
+        hyper = self._buf("hyper", nphi)
+        _lib.check(lib.dr4sr_fd_diff(_lib.ptr(hyper), _lib.ptr(fp), _lib.ptr(self._phi.grads), _lib.ptr(self._tail_p[0:1]),
+                                     _lib.ptr(eng.grads[n:n + 1]), _lib.ptr(self._e), -1.0, nphi, st()), "fd_diff")
+        eng.params.copy_(theta0)
+        eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0 + 1)
+        return hyper
+
+    def hypergrad_step(self, bv, bt):
+        """MetaOptimizer.step (utils/utils.py:221-252): hyper-gradient -> p.grad, clip_grad_norm_(10), meta SGD step"""
+        hyper = self.hypergrad(bv, bt)
+        self._phi.grads.copy_(hyper)
+        self.meta_optimizer.step_with(hyper)
+        return hyper
+
+    def evaluate(self) -> Dict:
+        return super().evaluate()

@@ -158,6 +158,20 @@ class SASRec(BaseModel):
             raise NotImplementedError("alignment/uniformity objective (sasrec.py:110-119) is not used by any shipped config")
         return super().training_step(batch, reduce, return_query)
 
+    # raw (non-autograd) hooks used by MetaModel's fused weighted step / hyper-gradient
+    def _encode_raw(self, batch, training=True):
+        eng = self.engine
+        return eng.encode(eng.make_plan(batch["in_" + self.fiid], None, batch["seqlen"]), training, _lib.POOL_ORIGIN)
+
+    def _encode_bwd_raw(self, batch, d_query, training=True):
+        eng = self.engine
+        eng.encode_bwd(eng.make_plan(batch["in_" + self.fiid], None, batch["seqlen"]), training, _lib.POOL_ORIGIN, d_query)
+
+    def _batch_plan(self, batch):
+        """plan of the fused fwd_bwd on a materialised batch with the batch's own negatives"""
+        return self.engine.make_plan(batch["in_" + self.fiid], batch[self.fiid], batch["seqlen"],
+                                     neg_item=batch["neg_item"].contiguous().view(-1), sample_neg=False)
+
     def _api_plan(self):
         return self.engine.make_plan(self._dummy.view(1, 1).expand(1, self.max_seq_len).contiguous(), None, self._dummy)
 

@@ -245,6 +245,55 @@ int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream);    /
 int dr4sr_gru4rec_encode(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, float* out, void* stream);
 int dr4sr_gru4rec_encode_bwd(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, const float* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DR4SR+ MetaModel (model/metamodel.py:19-197, utils/utils.py:134-252).
+ *
+ * The meta module is nn.Sequential(Linear(D,D), ReLU, Linear(D,2)) (metamodel.py:52-57); phi is its flat parameter vector
+ * W1[D,D] | b1[D] | W2[2,D] | b2[2] (dr4sr_meta_param_count floats; D = 64).
+ *
+ * dr4sr_meta_select_fwd — MetaModel.selection + the two masks of training_step (metamodel.py:169-185):
+ *   weight[p] = softmax((meta_module(query[p]) + gumbel[p]) / tau)[0];  1 where user_id[p / L] == 0;  0 where target[p] == 0.
+ *   n = B*L positions (L = 1 for scalar-target models).  gumbel [n,2] explicit noise, or NULL: drawn in-kernel from Philox
+ *   (seed, step) as -log(-log(u)) like F.gumbel_softmax.  tau = clip(tau, tau_min) is passed by the caller.
+ *   gate_in  [n] (NULL = off): a FROZEN ReLU pattern (bit j = unit j active) used instead of (pre > 0);
+ *   gate_out [n] (NULL = off): the pattern this call used.
+ * dr4sr_meta_select_bwd — backward of the above for upstream d_weight[n] (times *scale if scale != NULL):
+ *   d_query [n,D] is ACCUMULATED (+=; NULL = skip), d_phi ACCUMULATED, deterministically (per-block partials in `workspace`,
+ *   dr4sr_meta_select_workspace_floats(n) floats, summed in a fixed order). */
+int64_t dr4sr_meta_param_count(int32_t D);
+int64_t dr4sr_meta_select_workspace_floats(int64_t n);
+int dr4sr_meta_select_fwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step, float tau,
+                          const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
+                          const uint64_t* gate_in, uint64_t* gate_out, float* weight, void* stream);
+int dr4sr_meta_select_bwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step, float tau,
+                          const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
+                          const uint64_t* gate_in, const float* d_weight, const float* scale, float* d_query, float* d_phi,
+                          float* workspace, void* stream);
+
+/* Hypergrad.grad (utils/utils.py:145-205) from FIRST-ORDER gradients: with G(W) = dL_train/dW (this library's backward),
+ *     H v            = [G(W + e v) - G(W - e v)] / 2e                      (Neumann terms; scaled by hpo_lr, :196-203)
+ *     d/dphi (G . p) = [dL_train/dphi(W + e p) - dL_train/dphi(W - e p)] / 2e   (:170-175)
+ * evaluated with identical dropout masks / negatives / Gumbel noise and the meta module's ReLU pattern frozen at W (autograd's
+ * second derivative of ReLU is 0).  All scalars stay on the device.
+ *   step_size: *out_e = rel_step * sqrt(sum_{dir!=0} theta^2 / sum dir^2)
+ *   shift    : out = x + sign * (*e) * dir
+ *   neumann  : v -= lr * (gp / *np - gm / *nm) / (2 * *e) ;  pacc += v          (gp, gm un-normalised, np/nm their n_valid)
+ *   diff     : out = coef * (fp / *np - fm / *nm) / (2 * *e)
+ *   scale_by : out = x / *den */
+int dr4sr_fd_step_size(const float* theta, const float* dir, int64_t n, float rel_step, float* out_e, void* stream);
+int dr4sr_fd_shift(float* out, const float* x, const float* dir, const float* e, float sign, int64_t n, void* stream);
+int dr4sr_fd_neumann(float* v, float* pacc, const float* gp, const float* gm, const float* np, const float* nm, const float* e,
+                     float lr, int64_t n, void* stream);
+int dr4sr_fd_diff(float* out, const float* fp, const float* fm, const float* np, const float* nm, const float* e, float coef,
+                  int64_t n, void* stream);
+int dr4sr_scale_by(float* out, const float* x, const float* den, int64_t n, void* stream);
+
+/* MetaOptimizer.step tail (utils/utils.py:240-247) for the reference's default meta optimizer (metamodel.py:68-69):
+ * clip_grad_norm_(max_norm; <= 0 disables) then torch.optim.SGD(lr, momentum, weight_decay) on phi[n].
+ * step_count (device int32) selects the first-step momentum initialisation and is incremented; out_norm (NULL ok) = |grad|. */
+int dr4sr_meta_sgd_step(float* phi, const float* grad, float* momentum_buf, int32_t n, float lr, float momentum,
+                        float weight_decay, float max_norm, int32_t* step_count, float* out_norm, void* stream);
+
 /* Measurement hook: enqueue ONE kernel of the training step (on the state the last fwd_bwd left in
  * the workspace) so bench.py can bracket it with HIP events.  Not part of the reference surface. */
 #define DR4SR_K_PREP       0

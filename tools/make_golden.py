@@ -283,6 +283,164 @@ def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overr
         shutil.rmtree(work, ignore_errors=True)
 
 
+def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed):
+    """MetaModel (DR4SR+): weighted inner step + one outer hyper-gradient step, by RUNNING the reference
+    (model/metamodel.py:123-194, utils/utils.py:134-252).  Dropout 0; the Gumbel noise of F.gumbel_softmax is pinned
+    by re-seeding torch right before each weighted training_step and is stored (the script asserts that the stored
+    noise reproduces the reference's weights)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(seed)
+    work = tempfile.mkdtemp(prefix="dr4sr_golden_")
+    cwd = os.getcwd()
+    try:
+        os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
+        (build_dataset_fmlp if sub_model == "FMLP" else build_dataset)(work, n_items, seqlens, rng)
+        os.chdir(work)
+        import utils as rutils
+        import model.metamodel as mm
+        orig_load = rutils.load_config
+
+        def patched_load(cfg):                       # metamodel.py:41-50 hard-codes device 0 for the sub-model
+            c = orig_load(cfg)
+            c["train"]["device"] = "cpu"
+            c["data"]["train_file"] = "_ori"
+            c["model"]["dropout_rate"] = 0.0
+            if sub_model == "GRU4Rec":
+                c["model"]["hidden_size"] = 128
+            return c
+        mm.load_config = patched_load
+
+        def register_sub_model(self):                 # metamodel.py:41-50 with the device line dropped
+            sc = patched_load({"dataset": self.config["data"]["dataset"], "model": self.config["model"]["sub_model"]})
+            return rutils.get_model_class(sc["model"])(sc, self.dataset_list)
+        mm.MetaModel._register_sub_model = register_sub_model
+        config = patched_load({"model": "MetaModel", "dataset": "amazon-toys"})
+        config["model"]["sub_model"] = sub_model
+        rutils.setup_environment(config["train"])
+        torch.manual_seed(seed)
+        ds = rutils.prepare_datasets(config)
+        model = rutils.prepare_model(config, ds)
+        model._init_model(ds[0])
+        sub = model.sub_model
+        if sub_model == "FMLP":
+            for m in sub.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for n, p in list(sub.named_parameters()) + list(model.meta_module.named_parameters()):
+                if "item_embedding" in n or "item_encoder.weight" in n:
+                    continue
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        out = {}
+        for k, v in sub.state_dict().items():
+            out["param." + k] = v.detach().numpy().copy()
+        for k, v in model.meta_module.state_dict().items():
+            out["meta_param." + k] = v.detach().numpy().copy()
+        out["meta.tau"] = model.tau.detach().numpy().copy()
+
+        rows = next(iter(ds[0].get_loader(batch_size=len(ds[0]), shuffle=False)))
+        nrow = rows["user_id"].shape[0]
+        half = nrow // 2
+        model.train()
+
+        def take(sl):
+            b = {k: v[sl].clone() for k, v in rows.items()}
+            return b
+        bt, bv = take(slice(0, half)), take(slice(half, nrow))     # train batch / meta ("validation") batch
+        bt["user_id"][1] = 0                                        # a pattern row: weight forced to 1 (metamodel.py:180-183)
+        torch.manual_seed(seed + 2)
+        bt["neg_item"] = model._neg_sampling(bt)
+        bv["neg_item"] = model._neg_sampling(bv)
+        for k, v in bt.items():
+            out["train." + k] = v.numpy()
+        for k, v in bv.items():
+            out["val." + k] = v.numpy()
+
+        def gumbel_of(shape, s):
+            torch.manual_seed(s)
+            return -torch.empty(shape).exponential_().log()
+
+        # ---- inner (weighted) step: metamodel.py:174-194 -----------------------------------------
+        sub.optimizer.zero_grad()
+        torch.manual_seed(seed + 3)
+        loss = model.training_step(batch=bt, align=False)
+        loss.backward()
+        with torch.no_grad():
+            lv, query = sub.training_step(bt, reduce=False, return_query=True, align=False)
+            gshape = tuple(query.shape[:-1]) + (2,)
+            gn = gumbel_of(gshape, seed + 3)
+            logits = model.meta_module(query)
+            tau = torch.clip(model.tau, min=config["model"]["tau_min"])
+            w = ((logits + gn) / tau).softmax(-1)[..., 0]
+            torch.manual_seed(seed + 3)
+            w_ref = model.selection(query)
+            assert torch.equal(w, w_ref), "stored Gumbel noise does not reproduce the reference's weights"
+            wm = w.masked_fill((bt["user_id"] == 0).unsqueeze(-1) if w.dim() == 2 else (bt["user_id"] == 0), 1.0)
+            wm = wm.masked_fill(bt["item_id"] == 0, 0.0)
+            assert torch.allclose((lv * wm).sum(), loss.detach(), rtol=1e-6, atol=1e-7)
+        out["inner.gumbel"] = gn.numpy()
+        out["inner.query"] = query.numpy()
+        out["inner.loss_pos"] = lv.numpy()
+        out["inner.weight"] = wm.numpy()
+        out["inner.loss"] = loss.detach().numpy()
+        for n, p in sub.named_parameters():
+            out["inner.grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+        for n, p in model.meta_module.named_parameters():           # loss.backward() also reaches phi (never stepped by it)
+            out["inner.meta_grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            p.grad = None
+
+        # ---- outer step: metamodel.py:148-166, utils/utils.py:145-252 -------------------------------
+        params = list(sub.parameters())
+        aux = list(model.meta_module.parameters())
+        # torch >= 2.x routes MultiheadAttention to a fused CPU flash kernel that has no double-backward; the math backend
+        # (what torch 1.13, the reference's pinned version, always used) does.
+        from torch.nn.attention import sdpa_kernel, SDPBackend
+        ctx = sdpa_kernel(SDPBackend.MATH)
+        ctx.__enter__()
+
+        def losses():
+            meta_loss = sub.training_step(batch=bv, align=False)
+            torch.manual_seed(seed + 3)
+            meta_train_loss = model.training_step(batch=bt, align=False)
+            return meta_loss, meta_train_loss
+        ml, mtl = losses()
+        out["outer.val_loss"] = ml.detach().numpy()
+        gval = torch.autograd.grad(ml, params, retain_graph=True, allow_unused=True)
+        for (n, _), gg in zip(sub.named_parameters(), gval):
+            out["outer.grad_val." + n] = gg.numpy().copy()
+        hg = model.meta_optimizer.hypergrad.grad(loss_val=ml, loss_train=mtl, aux_params=aux, params=params)
+        for (n, _), gg in zip(model.meta_module.named_parameters(), hg):
+            out["outer.hypergrad." + n] = gg.detach().numpy().copy()
+        ml, mtl = losses()
+        for _ in range(2):                                          # two outer steps on the same pair: pins SGD momentum + wd + clip
+            model.meta_optimizer.step(val_loss=ml, train_loss=mtl, aux_params=aux, parameters=params, return_grads=False)
+            ml, mtl = losses()
+            for n, p in model.meta_module.named_parameters():
+                out[f"outer.step{_ + 1}." + n] = p.detach().numpy().copy()
+        ctx.__exit__(None, None, None)
+        tc = config["train"]
+        for k in ("meta_learning_rate", "hpo_learning_rate", "meta_weight_decay"):
+            out["meta." + k] = np.float64(tc[k])
+        out["meta.meta_optimizer"] = np.array(tc["meta_optimizer"])
+        out["meta.tau_min"] = np.float64(config["model"]["tau_min"])
+        out["meta.sub_model"] = np.array(sub_model)
+        out["meta.num_items"] = np.int64(model.num_items)
+        smc = sub.config["model"]
+        for k in ("head_num", "hidden_size", "layer_num"):
+            out["meta." + k] = np.int64(smc.get(k, 0))
+        out["meta.layer_norm_eps"] = np.float64(smc.get("layer_norm_eps", 1e-12))
+        os.chdir(cwd)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **out)
+        hn = float(torch.sqrt(sum((h ** 2).sum() for h in hg)))
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), weighted loss={float(loss.detach()):.6f}, |hypergrad|={hn:.3e}")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def neg_sampler_stats(out_dir):
     """Pin the *distribution* of basemodel.py:50-61 (uniform on 1..N-1, never PAD)."""
     import torch
@@ -317,6 +475,9 @@ def main():
     sys.path.insert(0, REF)
     seqlens = [1, 2, 3, 5, 8, 13, 21, 34, 47, 49, 50, 4, 2, 50]
     only = os.environ.get("GOLDEN_ONLY")
+    if only == "meta":
+        run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
+        return
     if only == "fmlp":
         run_case(out_dir, "fmlp_d64", "FMLP", n_items=113, seqlens=[1, 3, 6, 50, 2], embed_dim=64, seed=14)
         return
@@ -326,6 +487,7 @@ def main():
     run_case(out_dir, "gru4rec_d64", "GRU4Rec", n_items=131, seqlens=seqlens[:10], embed_dim=64, seed=13,
              overrides={"model": {"hidden_size": 128}})
     run_case(out_dir, "fmlp_d64", "FMLP", n_items=113, seqlens=[1, 3, 6, 50, 2], embed_dim=64, seed=14)
+    run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
     neg_sampler_stats(out_dir)
 
 
