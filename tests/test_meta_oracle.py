@@ -68,7 +68,7 @@ def test_hypergradient_exact_and_meta_sgd(golden_dir):
             np.testing.assert_allclose(M[k].numpy(), g[f"outer.step{s}.{k}"], rtol=1e-5, atol=2e-7)
 
 
-@pytest.mark.parametrize("rel_step", [3e-3, 1e-2])
+@pytest.mark.parametrize("rel_step", [3e-4, 1e-3])
 def test_first_order_formulation_matches_exact(golden_dir, rel_step):
     """the finite-difference form used on the GPU reproduces the reference's double-backward hyper-gradient"""
     g, p, meta, bt, bv, cfg = load_meta(golden_dir)
@@ -80,4 +80,4 @@ def test_first_order_formulation_matches_exact(golden_dir, rel_step):
     ref = np.concatenate([g["outer.hypergrad." + k].ravel() for k in MO.META_NAMES])
     err = rel(flat({k: v.numpy() for k, v in hg.items()}), ref)
     print("rel_step", rel_step, "hypergrad rel err", err)
-    assert err < 1e-3, err
+    assert err < 3e-4, err
