@@ -66,6 +66,82 @@ def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen):
     return 0.0
 
 
+def bench_metamodel(args):
+    """BASELINE configs[4]: MetaModel (DR4SR+) with sub_model = SASRec on toys-shaped synthetic rows, after warm-up:
+    every step = weighted fwd/bwd + Adam, every --interval steps one outer hyper-gradient step (9 extra fwd/bwd)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    os.environ.setdefault("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    import logging
+    logging.getLogger("CDR").setLevel(logging.WARNING)
+    from dr4sr_amd.utils import load_config, prepare_datasets, prepare_model, seed_everything
+    cfg = load_config({"model": "MetaModel", "dataset": "synthetic-toys"})
+    cfg["model"]["sub_model"] = "SASRec"
+    cfg["model"]["sub_overrides"] = {"model": {"dropout_rate": args.dropout}}
+    cfg["train"].update({"device": str(dev), "batch_size": args.batch * world, "interval": args.interval, "warmup_epoch": -1})
+    if args.dense:
+        cfg["data"]["dense"] = True
+    seed_everything(cfg["train"]["seed"])
+    ds = prepare_datasets(cfg)
+    model = prepare_model(cfg, ds)
+    model._init_model(ds[0])
+    model.train()
+    loader = ds[0].get_loader()
+    perm = model._perm(loader)
+    nb = len(loader)
+
+    def step(i):
+        return model._train_batch(model._local_batch(loader, perm, i % (nb - 1)), 0)      # skip the ragged last batch
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    # one outer step alone
+    bv = model._local_batch(loader, perm, 0)
+    bv["neg_item"] = model._neg_sampling(bv)
+    bt = model._local_batch(loader, perm, 1)
+    bt["neg_item"] = model._neg_sampling(bt)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        model.hypergrad_step(bv, bt)
+    torch.cuda.synchronize()
+    outer_ms = (time.perf_counter() - t1) / 5 * 1e3
+    if world > 1:
+        tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax)
+    if rank == 0:
+        B = args.batch
+        print(json.dumps({
+            "metric": "training sequences/sec, MetaModel(SASRec) d=64 L=50", "value": world * B * args.steps / wall,
+            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MetaModel (DR4SR+) around SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[4]): weighted "
+                                   "inner step every step + hyper-gradient outer step every %d steps, B=%d rows/GPU/step, dropout %.2f"
+                                   % (args.interval, B, args.dropout),
+                       "global_batch": B * world, "seq_len": 50, "parallelism": "dp%d" % world, "hip_graph": False},
+            "outer_step_ms": outer_ms, "final_loss": float(loss)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,10 +153,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
-    ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp"],
+    ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp", "metamodel"],
                     help="sasrec = BASELINE headline (configs[1]); gru4rec = configs[2] (beauty-sized table, dropout 0.2, wd 1e-4); "
-                         "fmlp = per-prefix left-padded rows, all B*L positions computed")
+                         "fmlp = per-prefix left-padded rows, all B*L positions computed; metamodel = configs[4] (DR4SR+ around "
+                         "SASRec: weighted inner steps + one hyper-gradient outer step every --interval steps)")
+    ap.add_argument("--interval", type=int, default=30, help="metamodel: outer-loop period (configs/metamodel.yaml interval)")
     args = ap.parse_args()
+    if args.model == "metamodel":
+        return bench_metamodel(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

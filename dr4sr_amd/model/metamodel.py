@@ -262,22 +262,26 @@ class MetaModel(BaseModel):
         nb = len(loader)
         losses = torch.empty(nb, dtype=torch.float32, device=self.device)
         for i in range(nb):
-            batch = self._local_batch(loader, perm, i)
-            if batch["user_id"].shape[0] > 0:
-                batch["neg_item"] = self._neg_sampling(batch)
-                self._weighted_fwd_bwd(batch)
-            else:
-                eng.grads.zero_()
-                self._phi.grads.zero_()
-            self.counter += 1
-            self._reduce_grads()
-            losses[i] = eng.grads[eng.n_params + 1]       # metamodel.py:186-194: the weighted SUM (already / n_valid)
-            losses[i] /= eng.grads[eng.n_params]
-            eng.adam_step(sub._api_plan())
-            self.step_counter += 1
-            if self.step_counter % self.config["train"]["interval"] == 0:
-                self._outter_loop(nepoch)
+            losses[i] = self._train_batch(self._local_batch(loader, perm, i), nepoch)
         return [[{"loss_0": losses}]]
+
+    def _train_batch(self, batch, nepoch):
+        """one post-warm-up iteration of metamodel.py:101-120: weighted step, sub-model Adam, outer loop on the interval"""
+        sub, eng = self.sub_model, self.engine
+        if batch["user_id"].shape[0] > 0:
+            batch["neg_item"] = self._neg_sampling(batch)
+            self._weighted_fwd_bwd(batch)
+        else:                                             # a rank whose slice of the tail batch is empty contributes zeros
+            eng.grads.zero_()
+            self._phi.grads.zero_()
+        self.counter += 1
+        self._reduce_grads()
+        loss = eng.grads[eng.n_params + 1] / eng.grads[eng.n_params]     # metamodel.py:186-194: sum_p w_p loss_p (loss_p is / n_valid)
+        eng.adam_step(sub._api_plan())
+        self.step_counter += 1
+        if self.step_counter % self.config["train"]["interval"] == 0:
+            self._outter_loop(nepoch)
+        return loss
 
     def _neg_sampling(self, batch):
         return self.sub_model._neg_sampling(batch)
