@@ -18,6 +18,7 @@ import logging
 import os
 from typing import Dict, List
 
+import numpy as np
 import torch
 
 FIELDS_TRAIN = ("user_id", "in_item_id", "item_id", "seqlen", "label", "domain_id")
@@ -104,10 +105,13 @@ class BaseDataset:
         return {d: self._inter_data[self._inter_data["domain"] == i]["item_id"].unique().tolist()
                 for i, d in enumerate(self.domain_name_list)}
 
-    def unpack(self, rows: List[list]):
-        """list-of-rows -> tuple of device tensors in the reference's order (data/dataset.py:79-91)."""
+    def unpack(self, rows):
+        """rows -> tuple of int64 device tensors in the reference's order (data/dataset.py:79-91).  `rows` is the reference's
+        list of python rows or the column dict of data/packed.py (int32 arrays, possibly memory-mapped)."""
+        from .packed import COLS, rows_to_arrays
         dev = self.device
-        cols = [torch.tensor([r[i] for r in rows], device=dev) for i in range(6)]
+        arrays = rows if isinstance(rows, dict) else rows_to_arrays(rows, self.max_seq_len)
+        cols = [torch.from_numpy(np.asarray(arrays[k]).astype(np.int64)).to(dev) for k in COLS]
         if self.phase != "train":
             cols.append(cols[1])                                    # user_hist = the input sequence
         return tuple(cols)
@@ -155,14 +159,16 @@ class SeparateDataset(BaseDataset):
 
     def _load_datasets(self):
         super()._load_datasets()
+        from .packed import load_split
         self._raw = []
+        cache = bool(self.config["data"].get("packed_cache", True))
         for d in self.domain_name_list:
             fname = ("train" + self.config["data"]["train_file"] if self.phase == "train" else self.phase) + ".pth"
-            self._raw.append(torch.load(os.path.join(self._domain_dir(d), fname), weights_only=False))
+            self._raw.append(load_split(os.path.join(self._domain_dir(d), fname), self.max_seq_len, cache))
 
     def _build(self):
         if self.phase == "train":
-            rows = [r for dom in self._raw for r in dom]
+            rows = {k: np.concatenate([dom[k] for dom in self._raw]) for k in self._raw[0]}
             self._data = self.unpack(rows)
         else:
             self._data = {d: self.unpack(rows) for d, rows in zip(self.domain_name_list, self._raw)}

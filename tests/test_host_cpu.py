@@ -127,6 +127,54 @@ def test_separate_dataset_reads_reference_row_format(tmp_path, monkeypatch):
     assert tr[1]["seqlen"] == 3 and tr[1]["index"] == 1      # per-sample access still works
 
 
+def test_packed_row_cache_roundtrip_and_staleness(tmp_path, monkeypatch):
+    """data/packed.py: the packed image reproduces the .pth rows bit for bit, is reused while fresh, rebuilt when the source changes"""
+    import time as _time
+    from dr4sr_amd.data import packed
+    from dr4sr_amd.data.dataset import SeparateDataset
+    train, val = _write_dataset(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    cfg = {"data": {"dataset": "tiny", "domain_name_list": ["toy"], "max_seq_len": 50, "train_file": "_ori"},
+           "train": {"device": "cpu", "batch_size": 2}, "eval": {"batch_size": 4}}
+    d = os.path.join("dataset", "tiny", "toy")
+    ref = {}
+    for phase in ("train", "val"):                                 # first build: from the pickles (writes the images)
+        ds = SeparateDataset(cfg, phase)
+        ds.build()
+        ref[phase] = {k: v.clone() for k, v in ds.fields().items()}
+    pk = os.path.join(d, "train_ori.pth.dr4srpk")
+    assert os.path.exists(pk) and os.path.exists(os.path.join(d, "val.pth.dr4srpk"))
+    got = packed.read_packed(pk, os.path.join(d, "train_ori.pth"))
+    assert got is not None and got["item_id"].shape == (5, 50) and got["seqlen"].dtype == np.int32
+    calls = []
+    real_load = torch.load
+    monkeypatch.setattr(torch, "load", lambda *a, **k: calls.append(a) or real_load(*a, **k))
+    for phase in ("train", "val"):                                 # second build: from the images only
+        ds = SeparateDataset(cfg, phase)
+        ds.build()
+        for k, v in ds.fields().items():
+            assert v.dtype == torch.int64 and torch.equal(v, ref[phase][k]), (phase, k)
+    assert calls == []
+    # stale source -> image ignored and rebuilt
+    train[0][3] = 1
+    train[0][1][0] = 39
+    _time.sleep(0.01)
+    torch.save(train, os.path.join(d, "train_ori.pth"))
+    assert packed.read_packed(pk, os.path.join(d, "train_ori.pth")) is None
+    ds = SeparateDataset(cfg, "train")
+    ds.build()
+    assert len(calls) == 1 and int(ds.fields()["in_item_id"][0, 0]) == 39
+    assert packed.read_packed(pk, os.path.join(d, "train_ori.pth")) is not None
+    # corrupt / truncated image -> ignored
+    with open(pk, "r+b") as f:
+        f.truncate(100)
+    assert packed.read_packed(pk, os.path.join(d, "train_ori.pth")) is None
+    cfg["data"]["packed_cache"] = False                            # opt-out never touches the image
+    os.remove(pk)
+    SeparateDataset(cfg, "train").build()
+    assert not os.path.exists(pk)
+
+
 def test_metrics_match_golden(golden_dir):
     from dr4sr_amd import evaluation
     z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
