@@ -72,12 +72,17 @@ def bench_metamodel(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
+    # DR4SR_BENCH_SHARE_GPU=1 + DR4SR_BENCH_BACKEND=gloo: debug knobs that run the N-rank code path on ONE GPU (functional check only)
+    dev = torch.device("cuda", 0 if os.environ.get("DR4SR_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DR4SR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     os.environ.setdefault("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
     import logging
     logging.getLogger("CDR").setLevel(logging.WARNING)
@@ -168,12 +173,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    dev = torch.device("cuda", local_rank)
+    # DR4SR_BENCH_SHARE_GPU=1 + DR4SR_BENCH_BACKEND=gloo: debug knobs that run the N-rank code path on ONE GPU (functional check only)
+    dev = torch.device("cuda", 0 if os.environ.get("DR4SR_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DR4SR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from dr4sr_amd import _lib
     from dr4sr_amd.data.synthetic import TOYS_N_ITEMS, make_rows
