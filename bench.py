@@ -203,7 +203,9 @@ def main():
     if args.model == "sasrec":
         eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023, lr=1e-3)
         init_params_like_reference(eng, 2023)
-        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+        # a1 fused: rows_buf is filled by the step's first kernel from (perm, counter); no separate selection launch
+        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True,
+                             perm_sel=(perm, B * world, rank * B, counter))
     elif args.model == "gru4rec":
         from dr4sr_amd.gru_engine import GruEngine
         eng = GruEngine(N, L, D, 256, 2, 0.2, B, dev, seed=2023, lr=1e-3, weight_decay=1e-4)
@@ -229,6 +231,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
 
     def select():
+        if args.model == "sasrec":
+            return
         _lib.check(lib.dr4sr_select_rows(_lib.ptr(perm), U, _lib.ptr(rows_buf), B, B * world, rank * B, _lib.ptr(counter),
                                          _lib.cur_stream()), "select_rows")
 

@@ -71,6 +71,16 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// sequence slot of packed token t: the b with cu[b] <= t < cu[b+1] (binary search; cu is L1/L2 resident)
+__device__ __forceinline__ int find_seq(const int* __restrict__ cu, int B, int t) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // ---------------------------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

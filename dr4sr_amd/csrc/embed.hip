@@ -48,9 +48,11 @@ extern "C" int dr4sr_embed_gather_posadd(const float* E, const float* P, const i
 // Also bumps the RNG step so that every fwd_bwd draws fresh dropout masks / negatives.
 // Blocks 1.. of the same launch zero the flat gradient (+tail) when `zero` is given (saves a launch per step; a
 // hipMemsetAsync graph node is NOT used: on ROCm 7.2 its replay was observed to fill the last 16 bytes with a stale pattern).
-__global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqlen, const int64_t* __restrict__ rows,
+struct PermSel { const int64_t* perm; int64_t n, stride, offset; int* counter; };
+
+__global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqlen, const int64_t* rows,
                                                int* __restrict__ cu, int* __restrict__ state, int B, int L,
-                                               int bump_rng, float* __restrict__ zero, int64_t zero_n4) {
+                                               int bump_rng, float* __restrict__ zero, int64_t zero_n4, PermSel sel) {
     if (blockIdx.x > 0) {
         for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n4; i += (int64_t)(gridDim.x - 1) * 1024)
             st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -58,6 +60,13 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
     }
     __shared__ int part[1024];
     const int tid = threadIdx.x;
+    if (sel.perm) {                                     // a1: this step's batch = a slice of the epoch permutation
+        const int64_t c = *sel.counter;
+        int64_t* rw = const_cast<int64_t*>(rows);
+        for (int i = tid; i < B; i += 1024) rw[i] = sel.perm[(c * sel.stride + sel.offset + i) % sel.n];
+        __syncthreads();
+        if (tid == 0) *sel.counter = (int)(c + 1);
+    }
     const int per = (B + 1023) / 1024;
     const int b0 = tid * per, b1 = min(B, b0 + per);
     int s = 0;
@@ -86,29 +95,29 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
     }
 }
 
-int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
-                    int64_t zero_floats, hipStream_t s) {
+static int launch_prep_sel(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
+                           int64_t zero_floats, const PermSel& sel, hipStream_t s) {
     const int64_t n4 = zero ? zero_floats / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024);
     if (zb > 255) zb = 255;
-    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, seqlen, rows, cu, state, B, L, bump_rng, zero, n4);
+    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, seqlen, rows, cu, state, B, L, bump_rng, zero, n4, sel);
     return DR4SR_LAUNCH_CHECK();
 }
+int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
+                    int64_t zero_floats, hipStream_t s) {
+    return launch_prep_sel(seqlen, rows, cu, state, B, L, bump_rng, zero, zero_floats, PermSel{nullptr, 0, 0, 0, nullptr}, s);
+}
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
-    return launch_prep_raw(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, zero_grads ? p->grads : nullptr,
-                           ws.n_params + DR4SR_GRAD_TAIL, s);
+    PermSel sel{nullptr, 0, 0, 0, nullptr};
+    if (p->perm && bump_rng) {                          // selection only in the calls that start a new step
+        if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
+        sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
+    }
+    return launch_prep_sel(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, zero_grads ? p->grads : nullptr,
+                           ws.n_params + DR4SR_GRAD_TAIL, sel, s);
 }
 
 // ------------------------------------------------------------------------------------------------
-// sequence slot of packed token t: the b with cu[b] <= t < cu[b+1] (binary search; cu is L1/L2 resident)
-__device__ __forceinline__ int find_seq(const int* __restrict__ cu, int B, int t) {
-    int lo = 0, hi = B;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (cu[mid] <= t) lo = mid; else hi = mid;
-    }
-    return lo;
-}
 
 // Packed forward, token-parallel: token t belongs to sequence slot b = find_seq(t) at pos = t - cu[b]:
 //   x[t,:] = drop(E[idx[row(b),pos],:] + P[pos,:])      (P == NULL: no position table, GRU4Rec)

@@ -82,6 +82,68 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
     return DR4SR_LAUNCH_CHECK();
 }
 
+
+// Layer-0 fusion: the token tile is gathered straight from the item/position tables (a3: sasrec.py:42-48,:61-66 —
+// x = drop(E[idx] + P[pos]), 16 lanes per token, sequence slot by binary search in cu[]) into LDS, written once to X[0]
+// (residual + weight-gradient input) and multiplied by W_in in the same launch.
+struct EmbQkvArgs {
+    const float* E; const float* P; const int64_t* idx; const int64_t* rows; const int* cu; float* X;
+    const float* W; const float* bias; float* QKV; const int* state;
+    int B, L, n_items, training; uint64_t seed; float p;
+};
+template <int BM, int D>
+__global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
+    constexpr int N = 3 * D, LDA = D + 4, LPT = D / 4, TPB = 256 / LPT;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    if (t0 >= T) return;
+    float* As = smem;
+    const int c = (threadIdx.x % LPT) * 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+#pragma unroll
+    for (int r0 = 0; r0 < BM; r0 += TPB) {
+        const int r = r0 + threadIdx.x / LPT, t = t0 + r;
+        if (r < BM) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) {
+                const int b = find_seq(A.cu, A.B, t), pos = t - A.cu[b];
+                const int64_t row = A.rows ? A.rows[b] : b;
+                int64_t id = A.idx[row * A.L + pos];
+                id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
+                o = ld4(A.E + id * D + c);
+                const float4 pe = ld4(A.P + (size_t)pos * D + c);
+                o = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
+                if (dodrop) {
+                    const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * A.L + pos) * D + c);
+                    o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+                }
+                st4(A.X + (size_t)t * D + c, o);
+            }
+            st4(As + r * LDA + c, o);
+        }
+    }
+    lds_barrier();
+    TileAcc<BM, N> acc;
+    tile_zero(acc);
+    tile_mma_xwT<BM, D, N>(As, LDA, A.W, D, acc);
+    tile_to_global<BM, N>(acc, A.QKV, N, A.bias, t0, T);
+}
+
+int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    const int D = p->D, bm = tile_rows(ws);
+    const size_t lds = sizeof(float) * bm * (D + 4);
+    dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
+    EmbQkvArgs A;
+    A.E = p->params + ws.off[0]; A.P = p->params + ws.off[1]; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu; A.X = ws.X[0];
+    A.W = p->params + poff(ws, 0, P_IN_W); A.bias = p->params + poff(ws, 0, P_IN_B); A.QKV = ws.layer[0].qkv; A.state = p->state;
+    A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
+#define EQ(B_) do { if (D == 64) hipLaunchKernelGGL((k_embqkv_fwd<B_, 64>), grid, blk, lds, s, A); \
+                    else hipLaunchKernelGGL((k_embqkv_fwd<B_, 128>), grid, blk, lds, s, A); } while (0)
+    BM_DISPATCH(bm, EQ);
+#undef EQ
+    return DR4SR_LAUNCH_CHECK();
+}
+
 // ------------------------------------------------------------------------------------------------
 
 // dropout + residual + LayerNorm over the 64 rows of a C tile held in LDS, 16 lanes per row, all four row passes of
@@ -505,6 +567,77 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
                     else { big_lds(k_qkv_bwd<B_, 128>, lds); hipLaunchKernelGGL((k_qkv_bwd<B_, 128>), grid, blk, lds, s, lw.dqkv, WT, lw.du1, ws.dX[layer], p->state); } } while (0)
     BM_DISPATCH(bm, QB);
 #undef QB
+    return DR4SR_LAUNCH_CHECK();
+}
+
+
+// Layer-0 fusion of the backward tail: dx0 = dqkv W_in + du1 stays in LDS and is scattered straight into the tables
+// (a3 backward: g = dx0 * mask_emb; dE[idx] += g except padding_idx 0; dP[pos] += g), 16 lanes per token; dP is first
+// accumulated in LDS and flushed with one atomic per touched element per workgroup.
+struct QkvEmbBwdArgs {
+    const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu;
+    float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
+};
+template <int BM, int D>
+__global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
+    constexpr int K = 3 * D, LDA = K + 4, LDC = D + 4, LPT = D / 4, TPB = 256 / LPT;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    if (t0 >= T) return;
+    float* As = smem;
+    float* Cs = As + BM * LDA;
+    float* accP = Cs + BM * LDC;                        // [L][D]
+    for (int i = threadIdx.x; i < A.L * D; i += 256) accP[i] = 0.f;
+    load_tile_bm<BM, K>(As, LDA, A.dQKV, K, t0, T);
+    lds_barrier();
+    TileAcc<BM, D> acc;
+    tile_zero(acc);
+    tile_mma_xw<BM, K, D>(As, LDA, A.W, D, acc);
+    tile_to_lds<BM, D>(acc, Cs, LDC, nullptr);
+    lds_barrier();
+    const int c = (threadIdx.x % LPT) * 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+#pragma unroll
+    for (int r0 = 0; r0 < BM; r0 += TPB) {
+        const int r = r0 + threadIdx.x / LPT, t = t0 + r;
+        if (r < BM && t < T) {
+            const int b = find_seq(A.cu, A.B, t), pos = t - A.cu[b];
+            const int64_t row = A.rows ? A.rows[b] : b;
+            const float4 v = ld4(Cs + r * LDC + c), u = ld4(A.dU1 + (size_t)t * D + c);
+            float4 g = make_float4(v.x + u.x, v.y + u.y, v.z + u.z, v.w + u.w);
+            if (dodrop) {
+                const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * A.L + pos) * D + c);
+                g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+            }
+            float* a = accP + pos * D + c;
+            atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); atomicAdd(a + 3, g.w);
+            const int64_t id = A.idx[row * A.L + pos];
+            if (id > 0 && id < A.n_items) {
+                float* d = A.dE + id * D + c;
+                unsafeAtomicAdd(d, g.x); unsafeAtomicAdd(d + 1, g.y); unsafeAtomicAdd(d + 2, g.z); unsafeAtomicAdd(d + 3, g.w);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.L * D; i += 256) {
+        const float v = accP[i];
+        if (v != 0.f) unsafeAtomicAdd(A.dP + i, v);
+    }
+}
+
+int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    const int D = p->D, bm = tile_rows(ws);
+    const size_t lds = sizeof(float) * (bm * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D);
+    dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
+    const LayerWs& lw = ws.layer[0];
+    QkvEmbBwdArgs A;
+    A.dQKV = lw.dqkv; A.W = p->params + poff(ws, 0, P_IN_W); A.dU1 = lw.du1; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
+    A.dE = p->grads + ws.off[0]; A.dP = p->grads + ws.off[1]; A.state = p->state; A.B = p->B; A.L = p->L; A.n_items = p->n_items;
+    A.training = training; A.seed = p->seed; A.p = p->p_drop;
+#define QE(B_) do { if (D == 64) { big_lds(k_qkv_embed_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 64>), grid, blk, lds, s, A); } \
+                    else { big_lds(k_qkv_embed_bwd<B_, 128>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 128>), grid, blk, lds, s, A); } } while (0)
+    BM_DISPATCH(bm, QE);
+#undef QE
     return DR4SR_LAUNCH_CHECK();
 }
 

@@ -187,10 +187,11 @@ static int attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int 
 }
 
 static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
-    RC(launch_embed_fwd(p, ws, training, s));
-    static const bool fuse = getenv("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1)
+    static const bool fuse = getenv("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1),
+    if (fuse) RC(launch_embqkv_fwd(p, ws, training, s));             // qkv of layer 0 by the embedding gather
+    else RC(launch_embed_fwd(p, ws, training, s));
     for (int l = 0; l < p->n_layer; ++l) {
-        if (l == 0 || !fuse) RC(launch_qkv_fwd(p, ws, l, s));
+        if (!fuse) RC(launch_qkv_fwd(p, ws, l, s));
         RC(attn_fwd(p, ws, l, training, s));
         RC(launch_post_fwd(p, ws, l, training, s));
     }
@@ -201,9 +202,10 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
     for (int l = p->n_layer - 1; l >= 0; --l) {
         RC(launch_post_bwd(p, ws, l, training, s));
         RC(attn_bwd(p, ws, l, training, s));
-        if (l == 0 || getenv("DR4SR_NO_FUSE")) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1)
+        if (getenv("DR4SR_NO_FUSE")) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
     }
-    RC(launch_embed_bwd(p, ws, training, s));
+    if (getenv("DR4SR_NO_FUSE")) RC(launch_embed_bwd(p, ws, training, s));
+    else RC(launch_qkv_embed_bwd(p, ws, training, s));
     RC(launch_wgrad(p, ws, training, with_score, s));
     return 0;
 }

@@ -88,7 +88,7 @@ class SasrecEngine:
         self._keep = []          # tensors referenced by the last plan
 
     # ------------------------------------------------------------------------------------------
-    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True):
+    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True, perm_sel=None):
         p = _lib.SasrecPlan()
         p.abi_version = _lib.ABI_VERSION
         p.B, p.L, p.D, p.H, p.F, p.n_layer, p.n_items = B, self.L, self.D, self.H, self.F, self.n_layer, self.n_items
@@ -106,11 +106,17 @@ class SasrecEngine:
             p.workspace, p.workspace_bytes = self.workspace.data_ptr(), self.ws_bytes
         p.state = self.state.data_ptr()
         p.lr, (p.beta1, p.beta2), p.adam_eps, p.weight_decay = self.lr, self.betas, self.adam_eps, self.weight_decay
-        self._keep = [in_item_id, item_id, seqlen, rows, neg_item]
+        if perm_sel is not None:           # (perm[n], stride, offset, counter[1] int32): rows[] is FILLED by the step's first kernel
+            perm, stride, offset, counter = perm_sel
+            assert rows is not None and perm.dtype == torch.int64 and counter.dtype == torch.int32
+            p.perm, p.n_perm, p.perm_stride, p.perm_offset = perm.data_ptr(), int(perm.shape[0]), int(stride), int(offset)
+            p.perm_counter = counter.data_ptr()
+        self._keep = [in_item_id, item_id, seqlen, rows, neg_item, perm_sel]
         return p
 
-    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None):
-        """rows=None: the tensors ARE the batch ([B,L]/[B]); else they are dataset tensors indexed by rows[B]."""
+    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None):
+        """rows=None: the tensors ARE the batch ([B,L]/[B]); else they are dataset tensors indexed by rows[B].
+        perm_sel: fused device-side batch selection (include/dr4sr_hip.h: dr4sr_sasrec_plan.perm)."""
         B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
         if B > self.max_batch:
             raise _lib.Dr4srError(f"batch {B} > max_batch {self.max_batch}")
@@ -118,7 +124,7 @@ class SasrecEngine:
             sample_neg = neg_item is None
         if neg_item is None:
             neg_item = self.neg_scratch
-        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg)
+        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, perm_sel=perm_sel)
 
     # ------------------------------------------------------------------------------------------
     def fwd_bwd(self, plan):

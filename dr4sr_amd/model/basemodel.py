@@ -252,21 +252,26 @@ class BaseModel(nn.Module):
                 and not os.environ.get("DR4SR_NO_FAST_PATH"))
 
     # ------------------------------------------------------------------------------------------ fast path (fused HIP graph per batch)
-    def _step_graph(self, fields, bl):
-        """captured HIP graph(s) for a local batch of `bl` rows addressed through self._rows_buf[:bl]"""
-        key = (fields["in_item_id"].data_ptr(), bl)
+    _supports_perm_sel = False
+
+    def _step_graph(self, fields, bl, perm_sel=None):
+        """captured HIP graph(s) for a local batch of `bl` rows addressed through self._rows_buf[:bl]; with perm_sel =
+        (perm, global batch, rank offset, counter) the rows are selected on the device by the step's first kernel"""
+        key = (fields["in_item_id"].data_ptr(), bl, None if perm_sel is None else (perm_sel[0].data_ptr(), perm_sel[1], perm_sel[2]))
         if key in self._graphs:
             return self._graphs[key]
         eng = self.engine
-        plan = self._train_plan(fields, self._rows_buf[:bl])
+        plan = self._train_plan(fields, self._rows_buf[:bl]) if perm_sel is None else \
+            self._train_plan(fields, self._rows_buf[:bl], perm_sel=perm_sel)
         use_graph = bool(self.config["train"].get("hip_graph", True))
+        undo = [eng.params, eng.adam_m, eng.adam_v, eng.state] + ([perm_sel[3]] if perm_sel is not None else [])
 
         def warm_up(fn):
             """run the step once OUTSIDE capture (code-object load, LDS attributes) and undo its side effects"""
-            snap = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.state)]
+            snap = [t.clone() for t in undo]
             fn()
             torch.cuda.synchronize()
-            for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.state), snap):
+            for dst, src in zip(undo, snap):
                 dst.copy_(src)
 
         if self.world_size == 1:
@@ -313,10 +318,22 @@ class BaseModel(nn.Module):
             dist.broadcast(perm, src=0)
         losses = torch.empty(nb, dtype=torch.float32, device=self.device)
         tail = eng.grads[eng.n_params:eng.n_params + 2]
+        fused_sel = self._supports_perm_sel
+        if fused_sel:                                       # a1 on the device: one permutation upload per EPOCH, no per-step copy
+            if getattr(self, "_perm_buf", None) is None or self._perm_buf.shape[0] != n:
+                self._perm_buf = torch.empty(n, dtype=torch.int64, device=self.device)
+                self._perm_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._perm_buf.copy_(perm)
+            self._perm_counter.zero_()
         for i in range(nb):
             lo, hi = shard_bounds(i, B, n, W, r)
             bl = hi - lo
-            if bl > 0:
+            if bl > 0 and fused_sel:
+                if i == nb - 1 and W > 1:
+                    self._perm_counter.fill_(i)             # a rank whose earlier tail slice was empty re-aligns its batch index
+                run, _ = self._step_graph(loader.fields, bl, (self._perm_buf, B, lo - i * B, self._perm_counter))
+                run()
+            elif bl > 0:
                 self._rows_buf[:bl].copy_(perm[lo:hi])
                 run, _ = self._step_graph(loader.fields, bl)
                 run()

@@ -175,6 +175,8 @@ class SASRec(BaseModel):
     def _api_plan(self):
         return self.engine.make_plan(self._dummy.view(1, 1).expand(1, self.max_seq_len).contiguous(), None, self._dummy)
 
-    def _train_plan(self, fields, rows):
+    _supports_perm_sel = True          # batch selection fused into the step's first kernel (no per-step rows copy)
+
+    def _train_plan(self, fields, rows, perm_sel=None):
         return self.engine.make_plan(fields["in_item_id"], fields["item_id"], fields["seqlen"], rows=rows,
-                                     neg_item=self._neg_buf, sample_neg=True)
+                                     neg_item=self._neg_buf, sample_neg=True, perm_sel=perm_sel)

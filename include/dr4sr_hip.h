@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DR4SR_ABI_VERSION 1
+#define DR4SR_ABI_VERSION 2
 
 #define DR4SR_E_ARG      (-1)   /* null pointer / bad size                                   */
 #define DR4SR_E_SHAPE    (-2)   /* unsupported D / H / F / L combination     */
@@ -91,6 +91,14 @@ typedef struct dr4sr_sasrec_plan {
     int32_t* state;                 /* [DR4SR_STATE_WORDS] device words, zero-initialised once   */
     /* ---- optimizer (basemodel.py:79-98: torch.optim.Adam) ---- */
     float lr, beta1, beta2, adam_eps, weight_decay;
+    /* ---- a1 fused batch selection (optional; replaces a separate dr4sr_select_rows launch): when perm != NULL the first
+     *      kernel of dr4sr_sasrec_fwd_bwd/_train_step/_encode(training) FILLS rows[i] = perm[(c*perm_stride + perm_offset + i)
+     *      mod n_perm], i < B, with c = *perm_counter, then sets *perm_counter = c + 1.  `rows` must then be writable. ---- */
+    const int64_t* perm;            /* [n_perm] one epoch's permutation of dataset rows, or NULL  */
+    int64_t  n_perm;
+    int64_t  perm_stride;           /* global batch size                                          */
+    int64_t  perm_offset;           /* this rank's offset inside the global batch                 */
+    int32_t* perm_counter;          /* device int32: batch index within the epoch                 */
 } dr4sr_sasrec_plan;
 
 /* -------------------------------------------------------------------------------------------- */
