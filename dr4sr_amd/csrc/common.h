@@ -64,6 +64,16 @@ __device__ __forceinline__ float drop1(const RngKey& k, uint32_t site, uint64_t 
     return w >= k.thresh ? k.scale : 0.f;
 }
 
+// a2 negative sampler (basemodel.py:50-61): element e of the (seed, step) stream
+#define DR4SR_SITE_NEG 0x4e454721u     // RNG stream of the negative sampler
+
+__device__ __forceinline__ int64_t sample_neg_id(const RngKey& rk, uint64_t e, int n_items) {
+    const uint4 r = rng_call(rk, DR4SR_SITE_NEG, e >> 2);
+    const uint32_t c = (uint32_t)(e & 3);
+    const uint32_t w = c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w;
+    return 1 + (int64_t)__umulhi(w, (uint32_t)(n_items - 1));       // uniform on [1, n_items-1]
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global stores count on CDNA4), which
 // makes every phase of the tile kernels wait ~1-2 us for its activation stores to be acknowledged; nothing in these kernels
 // communicates between waves through global memory, so LDS ordering (lgkmcnt) + s_barrier is sufficient.

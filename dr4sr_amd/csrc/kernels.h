@@ -78,6 +78,7 @@ struct WgradArgs {
     // reduce jobs (blockIdx.y == 6): LayerNorm affine partials of every layer, scorer partials
     const float* ln_part; int64_t ln_layer_stride; float* grads; int64_t o_ln1_w; int64_t layer_stride;   // ln1_w,ln1_b,ln2_w,ln2_b contiguous
     const float* score_part; float* tail; int B; int D;
+    int score_tiles;                           // 1: score_part holds one (count, loss) pair per token tile instead of per sequence
     int ln_tile_rows;                          // token rows per LayerNorm-partial row (tile size of the post kernels)
 };
 
@@ -97,6 +98,7 @@ int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* do
 int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
 int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
+int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s);
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);

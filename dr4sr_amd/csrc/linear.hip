@@ -198,10 +198,8 @@ __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc
 }
 
 template <int BM, int D, int F, bool FFN_ONLY>
-__global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
+__device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, const int T) {
     constexpr int LD = D + 4, LF = F + 4, NVF = F / 64, PASSES = BM / 16;
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
-    if (t0 >= T) return;
     float* R0 = smem;                 // [64][LD]  ctx tile, later linear2 output
     float* R1 = R0 + BM * LD;         // [64][LD]  y tile
     float* R2 = R1 + BM * LD;         // [64][LF]  out_proj output (ld LD), then linear1 output / h
@@ -277,6 +275,13 @@ __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
         ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
     }
     STAMP(15);
+}
+
+template <int BM, int D, int F, bool FFN_ONLY>
+__global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    if (t0 >= T) return;
+    post_fwd_body<BM, D, F, FFN_ONLY>(A, t0, T);
 }
 
 // fold the 16 row-groups of the workgroup (4 per wave x 4 waves) into ONE partial row per token tile:
@@ -362,10 +367,8 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
 }
 
 template <int BM, int D, int F, bool FFN_ONLY>
-__global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
+__device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, const int T, const int tile) {
     constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64, PASSES = BM / 16;
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
-    if (t0 >= T) return;
     float* R1 = smem;                          // R1 first: R0 and R2 are contiguous and together hold a [64][3D+4] dqkv tile
     float* R0 = R1 + BM * LD;
     float* R2 = R0 + BM * LD;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     } else {
         ln_bwd_rowpass<BM, D, 0>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
     }
-    flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D);
+    flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)tile * 4 * D);
     // ---- dh = df W2   (x W^T form with W2^T [F][D])
     {
         TileAcc<BM, F> acc;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         return;
     }
     ln_bwd_rowpass<BM, D, 1>(nullptr, R0, R1, LD, A.u1, A.st1, A.ln1_w, A.du1, nullptr, A.dout, R1, dgam, dbet, t0, T, dodrop, rk, sP);
-    flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)blockIdx.x * 4 * D + 2 * D);
+    flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)tile * 4 * D + 2 * D);
     // ---- dctx = do W_out
     {
         TileAcc<BM, D> acc;
@@ -454,6 +457,97 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
         const int row = i / C4, c = (i % C4) * 4;
         if (t0 + row < T) st4(A.dctx + (size_t)(t0 + row) * D + c, ld4(R0 + row * LD + c));
     }
+}
+
+template <int BM, int D, int F, bool FFN_ONLY>
+__global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    if (t0 >= T) return;
+    post_bwd_body<BM, D, F, FFN_ONLY>(A, t0, T, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Last-layer fusion: the scorer is per TOKEN (basemodel.py:204-214), so the last post_fwd, the scorer + BCE (fwd and bwd)
+// and the last post_bwd of a token tile need nothing from any other workgroup — one launch instead of three.
+// Scorer per token (LPT lanes per token, like the embedding kernels): negative drawn in-kernel or read, pos/neg dot
+// products by lane-group shuffles, un-normalised dz + table-gradient atomics; the tile's (count, loss) partial goes to
+// part[2*tile] (summed by k_wgrad's reduce job).  Valid targets at positions >= seqlen (query row is zero there) are
+// counted by the sequence's last token, as the per-sequence scorer does.
+struct ScoreTileArgs {
+    const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; int64_t* neg_item; float* part;
+    int sample_neg, n_items, B, L;
+};
+template <int LPT>
+__device__ __forceinline__ float lane_group_sum(float v) {
+#pragma unroll
+    for (int o = LPT / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int BM, int D>
+__device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile) {
+    constexpr int LPT = D / 4, TPB = 256 / LPT;
+    const int c = (threadIdx.x % LPT) * 4, sub = threadIdx.x % LPT;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
+    float lsum = 0.f, cnt = 0.f;
+    float* dZ = const_cast<float*>(A.dz);
+#pragma unroll
+    for (int r0 = 0; r0 < BM; r0 += TPB) {
+        const int r = r0 + threadIdx.x / LPT, t = t0 + r;
+        if (r < BM && t < T) {
+            const int b = find_seq(S.cu, S.B, t), pos = t - S.cu[b], n = S.cu[b + 1] - S.cu[b];
+            const int64_t row = S.rows ? S.rows[b] : b;
+            int64_t tgt = S.target[row * S.L + pos], ng;
+            if (S.sample_neg) {
+                ng = sample_neg_id(rk, (uint64_t)b * S.L + pos, S.n_items);
+                if (sub == 0) S.neg_item[(size_t)b * S.L + pos] = ng;
+            } else {
+                ng = S.neg_item[(size_t)b * S.L + pos];
+            }
+            ng = ng < 0 ? 0 : (ng >= S.n_items ? S.n_items - 1 : ng);
+            float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tgt > 0 && tgt < S.n_items) {
+                const float4 q = ld4(A.z + (size_t)t * D + c), ep = ld4(S.E + tgt * D + c), en = ld4(S.E + ng * D + c);
+                const float sp = lane_group_sum<LPT>(q.x * ep.x + q.y * ep.y + q.z * ep.z + q.w * ep.w);
+                const float sn = lane_group_sum<LPT>(q.x * en.x + q.y * en.y + q.z * en.z + q.w * en.w);
+                if (sub == 0) { lsum += softplus_f(-sp) + softplus_f(sn); cnt += 1.f; }
+                const float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn);
+                dz = make_float4(dpos * ep.x + dneg * en.x, dpos * ep.y + dneg * en.y, dpos * ep.z + dneg * en.z, dpos * ep.w + dneg * en.w);
+                float* gp = S.dE + tgt * D + c;
+                float* gn = S.dE + ng * D + c;
+                unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
+                unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
+            }
+            st4(dZ + (size_t)t * D + c, dz);
+            if (pos == n - 1) {                               // tail positions of this sequence (zero query): loss terms only
+                for (int l = n + sub; l < S.L; l += LPT) {
+                    const int64_t tl = S.target[row * S.L + l];
+                    if (S.sample_neg) S.neg_item[(size_t)b * S.L + l] = sample_neg_id(rk, (uint64_t)b * S.L + l, S.n_items);
+                    if (tl > 0 && tl < S.n_items) { lsum += 2.0f * 0.69314718055994530942f; cnt += 1.f; }
+                }
+            }
+        }
+    }
+    // workgroup reduction of (cnt, lsum) -> one partial per tile
+    float* red = smem;
+    cnt = wave_sum(cnt); lsum = wave_sum(lsum);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = cnt; red[2 * (threadIdx.x >> 6) + 1] = lsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S.part[2 * tile] = (red[0] + red[2]) + (red[4] + red[6]);
+        S.part[2 * tile + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
+template <int BM, int D, int F>
+__global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) {
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    if (t0 >= T) return;
+    post_fwd_body<BM, D, F, false>(A, t0, T);
+    __syncthreads();                                   // z rows of this tile are visible to the whole workgroup
+    score_tile<BM, D>(A, S, t0, T, blockIdx.x);
+    __syncthreads();                                   // dz rows written, LDS scratch free again
+    post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x);
 }
 
 static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
@@ -501,6 +595,28 @@ static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const
     else return DR4SR_E_SHAPE;
 #undef PL
     return DR4SR_LAUNCH_CHECK();
+}
+template <int BM>
+static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, const ScoreTileArgs& S, hipStream_t s) {
+    dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
+    const size_t lds = post_lds(p->D, p->F, BM);
+#define PM(D_, F_) do { big_lds(k_post_mid<BM, D_, F_>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_>), grid, blk, lds, s, A, S); } while (0)
+    if (p->D == 64 && p->F == 128) PM(64, 128);
+    else if (p->D == 128 && p->F == 128) PM(128, 128);
+    else if (p->D == 64 && p->F == 256) PM(64, 256);
+    else return DR4SR_E_SHAPE;
+#undef PM
+    return DR4SR_LAUNCH_CHECK();
+}
+// post_fwd + scorer/BCE fwd+bwd + post_bwd of the LAST layer in one launch (training step only)
+int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    const int layer = p->n_layer - 1;
+    const PostArgs A = make_post_args(p, ws, layer, training);
+    ScoreTileArgs S;
+    S.E = p->params + ws.off[0]; S.dE = p->grads + ws.off[0]; S.target = p->item_id; S.rows = p->rows; S.cu = ws.cu;
+    S.neg_item = p->neg_item; S.part = ws.score_part; S.sample_neg = p->sample_neg; S.n_items = p->n_items; S.B = p->B; S.L = p->L;
+    const int bm = tile_rows(ws);
+    return bm == 16 ? post_mid_bm<16>(p, ws, A, S, s) : bm == 32 ? post_mid_bm<32>(p, ws, A, S, s) : post_mid_bm<64>(p, ws, A, S, s);
 }
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const PostArgs A = make_post_args(p, ws, layer, training);
@@ -765,7 +881,8 @@ __device__ __forceinline__ void reduce_jobs(const WgradArgs& A) {
     if (blockIdx.x == 0 && layer == 0 && A.score_part) {
         __shared__ float red[512];
         float c = 0.f, l = 0.f;
-        for (int b = threadIdx.x; b < A.B; b += 256) { c += A.score_part[2 * b]; l += A.score_part[2 * b + 1]; }
+        const int nsc = A.score_tiles ? ntiles : A.B;             // per-tile partials (fused last layer) or per-sequence
+        for (int b = threadIdx.x; b < nsc; b += 256) { c += A.score_part[2 * b]; l += A.score_part[2 * b + 1]; }
         red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
         lds_barrier();
         for (int o = 128; o > 0; o >>= 1) {
@@ -857,6 +974,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     A.ln_part = ws.ln_part; A.ln_layer_stride = (int64_t)((ws.Tmax + 15) / 16) * 4 * D; A.grads = G; A.ln_tile_rows = tile_rows(ws);
     A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
+    A.score_tiles = with_score == 2;
     static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 48;   // tuning knob
     int gw_t = ntiles / 16 > gw_max ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : gw_max;   // >= 16 token tiles per workgroup at scale
     int gw = ntiles < gw_t ? ntiles : gw_t;

@@ -11,14 +11,6 @@
 #include "common.h"
 #include "kernels.h"
 
-#define DR4SR_SITE_NEG 0x4e454721u     // RNG stream of the negative sampler
-
-__device__ __forceinline__ int64_t sample_neg_id(const RngKey& rk, uint64_t e, int n_items) {
-    const uint4 r = rng_call(rk, DR4SR_SITE_NEG, e >> 2);
-    const uint32_t c = (uint32_t)(e & 3);
-    const uint32_t w = c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w;
-    return 1 + (int64_t)__umulhi(w, (uint32_t)(n_items - 1));       // uniform on [1, n_items-1]
-}
 
 __global__ void k_neg_sample(int64_t* __restrict__ out, int64_t n, int n_items, uint64_t seed, uint32_t step) {
     const RngKey rk = make_rng(seed, step, 0.f);

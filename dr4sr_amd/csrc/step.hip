@@ -67,7 +67,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->dctx = take(Tmax * D);
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
-    ws->score_part = take(2LL * p->B);
+    ws->score_part = take(2LL * (p->B > (Tmax + 15) / 16 ? p->B : (Tmax + 15) / 16));   // per sequence, or per token tile (fused last layer)
     ws->ln_part = take((int64_t)p->n_layer * ((Tmax + 15) / 16) * 4 * D);
     for (int l = 0; l < p->n_layer; ++l) {
         LayerWs& w = ws->layer[l];
@@ -186,21 +186,23 @@ static int attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int 
     return use_mfma_attn(p) ? launch_attn2_bwd(p, ws, l, training, s) : launch_attn_bwd(p, ws, l, training, s);
 }
 
-static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+// mid_fused: the last layer's post_fwd / scorer / post_bwd run as ONE launch (launch_post_mid) between the two halves
+static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s, bool mid_fused = false) {
     static const bool fuse = getenv("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1),
     if (fuse) RC(launch_embqkv_fwd(p, ws, training, s));             // qkv of layer 0 by the embedding gather
     else RC(launch_embed_fwd(p, ws, training, s));
     for (int l = 0; l < p->n_layer; ++l) {
         if (!fuse) RC(launch_qkv_fwd(p, ws, l, s));
         RC(attn_fwd(p, ws, l, training, s));
-        RC(launch_post_fwd(p, ws, l, training, s));
+        if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_fwd(p, ws, l, training, s));
     }
     return 0;
 }
 
-static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s) {
+static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s,
+                           bool mid_fused = false) {
     for (int l = p->n_layer - 1; l >= 0; --l) {
-        RC(launch_post_bwd(p, ws, l, training, s));
+        if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_bwd(p, ws, l, training, s));
         RC(attn_bwd(p, ws, l, training, s));
         if (getenv("DR4SR_NO_FUSE")) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
     }
@@ -216,6 +218,12 @@ extern "C" int dr4sr_sasrec_fwd_bwd(const dr4sr_sasrec_plan* plan, void* stream)
     if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     RC(launch_prep(plan, ws, 1, 1, s));
+    if (!getenv("DR4SR_NO_FUSE")) {
+        RC(forward_layers(plan, ws, 1, s, true));
+        RC(launch_post_mid(plan, ws, 1, s));
+        RC(backward_layers(plan, ws, 1, 2, s, true));
+        return 0;
+    }
     RC(forward_layers(plan, ws, 1, s));
     RC(launch_score_packed(plan, ws, s));
     RC(backward_layers(plan, ws, 1, 1, s));
