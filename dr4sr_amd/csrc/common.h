@@ -91,6 +91,14 @@ __device__ __forceinline__ int find_seq(const int* __restrict__ cu, int B, int t
     return lo;
 }
 
+// same, starting from a hint b0 <= answer (k_prep's tile_seq[t >> 4]): a short forward walk over L1-resident entries instead
+// of log2(B) dependent loads
+__device__ __forceinline__ int find_seq_from(const int* __restrict__ cu, int B, int t, int b0) {
+    int b = b0;
+    while (b + 1 < B && cu[b + 1] <= t) ++b;
+    return b;
+}
+
 // ---------------------------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -311,6 +319,54 @@ __device__ __forceinline__ void tile_mma_xw(const float* __restrict__ As, int ld
                     t.a[r][i] = mfma16x4(a[r].x, b0, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].y, b1, t.a[r][i]);
                     t.a[r][i] = mfma16x4(a[r].z, b2, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].w, b3, t.a[r][i]);
                 }
+            }
+        }
+    }
+}
+
+// Register-resident B-operand fragments of the BM = 16 / 32 tile GEMMs.  Loading them is decoupled from the MFMA loop so that
+// a latency-bound kernel can issue ALL its weight loads up front (they depend on nothing) and overlap their L2 round trips
+// with the phases before the GEMM that consumes them.
+template <int K, int N> struct WFragT { float4 b[K / 16][N / 64]; };     // for C += A W^T, W [N][ldw]  (tile_mma_xwT addressing)
+template <int K, int N> struct WFragC { float4 b[K / 16][N / 64]; };     // for C += A W,   W [K][ldw]  (tile_mma_xw addressing)
+template <int K, int N>
+__device__ __forceinline__ void wfrag_load(WFragT<K, N>& f, const float* __restrict__ W, int ldw) {
+    constexpr int KQ = K / 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ci = 0; ci < K / 16; ++ci)
+#pragma unroll
+        for (int i = 0; i < N / 64; ++i) f.b[ci][i] = ld4(W + (size_t)((w + 4 * i) * 16 + r16) * ldw + g * KQ + 4 * ci);
+}
+template <int K, int N>
+__device__ __forceinline__ void wfrag_load(WFragC<K, N>& f, const float* __restrict__ W, int ldw) {
+    constexpr int KQ = K / 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ci = 0; ci < K / 16; ++ci)
+#pragma unroll
+        for (int i = 0; i < N / 64; ++i) {
+            const float* wp = W + (size_t)(g * KQ + 4 * ci) * ldw + (w + 4 * i) * 16 + r16;
+            f.b[ci][i] = make_float4(wp[0], wp[ldw], wp[2 * ldw], wp[3 * ldw]);
+        }
+}
+template <int BM, int K, int N, typename FRAG>
+__device__ __forceinline__ void tile_mma_frag(const float* __restrict__ As, int lda, const FRAG& f, TileAcc<BM, N>& t) {
+    static_assert(BM == 16 || BM == 32, "fragment GEMM is the 16x16x4 path");
+    constexpr int KQ = K / 4, RT = BM / 16, CW = N / 64;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ci = 0; ci < K / 16; ++ci) {
+        float4 a[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[r] = ld4(As + (r * 16 + r16) * lda + g * KQ + 4 * ci);
+#pragma unroll
+        for (int i = 0; i < CW; ++i) {
+            const float4 b = f.b[ci][i];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                t.a[r][i] = mfma16x4(a[r].x, b.x, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].y, b.y, t.a[r][i]);
+                t.a[r][i] = mfma16x4(a[r].z, b.z, t.a[r][i]); t.a[r][i] = mfma16x4(a[r].w, b.w, t.a[r][i]);
             }
         }
     }

@@ -87,7 +87,7 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // x = drop(E[idx] + P[pos]), 16 lanes per token, sequence slot by binary search in cu[]) into LDS, written once to X[0]
 // (residual + weight-gradient input) and multiplied by W_in in the same launch.
 struct EmbQkvArgs {
-    const float* E; const float* P; const int64_t* idx; const int64_t* rows; const int* cu; float* X;
+    const float* E; const float* P; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq; float* X;
     const float* W; const float* bias; float* QKV; const int* state;
     int B, L, n_items, training; uint64_t seed; float p;
 };
@@ -100,13 +100,14 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     const int c = (threadIdx.x % LPT) * 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const int bh = A.tile_seq[t0 >> 4];
 #pragma unroll
     for (int r0 = 0; r0 < BM; r0 += TPB) {
         const int r = r0 + threadIdx.x / LPT, t = t0 + r;
         if (r < BM) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < T) {
-                const int b = find_seq(A.cu, A.B, t), pos = t - A.cu[b];
+                const int b = find_seq_from(A.cu, A.B, t, bh), pos = t - A.cu[b];
                 const int64_t row = A.rows ? A.rows[b] : b;
                 int64_t id = A.idx[row * A.L + pos];
                 id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
@@ -134,7 +135,7 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     const size_t lds = sizeof(float) * bm * (D + 4);
     dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
     EmbQkvArgs A;
-    A.E = p->params + ws.off[0]; A.P = p->params + ws.off[1]; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu; A.X = ws.X[0];
+    A.E = p->params + ws.off[0]; A.P = p->params + ws.off[1]; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu; A.tile_seq = ws.tile_seq; A.X = ws.X[0];
     A.W = p->params + poff(ws, 0, P_IN_W); A.bias = p->params + poff(ws, 0, P_IN_B); A.QKV = ws.layer[0].qkv; A.state = p->state;
     A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
 #define EQ(B_) do { if (D == 64) hipLaunchKernelGGL((k_embqkv_fwd<B_, 64>), grid, blk, lds, s, A); \
@@ -209,16 +210,30 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
     const uint32_t sP = A.sP, sA = A.sA, sF = A.sF;
     const bool actdrop = dodrop && sA != 0xffffffffu;
 
+    // latency regime (BM = 16): every weight fragment is requested before the first barrier, so the four L2 round trips of
+    // the four GEMMs overlap with the phases in front of them instead of each starting after its barrier
+    constexpr bool PF = BM == 16 && !FFN_ONLY;
+    WFragT<PF ? D : 16, PF ? D : 64> f_out;
+    WFragT<PF ? D : 16, PF ? F : 64> f_w1;
+    WFragT<PF ? F : 16, PF ? D : 64> f_w2;
+    WFragT<PF ? D : 16, PF ? 3 * D : 64> f_nx;
     STAMP(0);
     if (FFN_ONLY) {                            // FMLP Intermediate block: the input tile IS y
         load_tile_bm<BM, D>(R1, LD, A.x, D, t0, T);
     } else {
         load_tile_bm<BM, D>(R0, LD, A.ctx, D, t0, T);
+        if constexpr (PF) {
+            wfrag_load(f_out, A.out_w, D);
+            wfrag_load(f_w1, A.w1, D);
+            wfrag_load(f_w2, A.w2, F);
+            if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+        }
         lds_barrier(); STAMP(1);
         {
             TileAcc<BM, D> acc;
             tile_zero(acc);
-            tile_mma_xwT<BM, D, D>(R0, LD, A.out_w, D, acc);
+            if constexpr (PF) tile_mma_frag<BM, D, D>(R0, LD, f_out, acc);
+            else tile_mma_xwT<BM, D, D>(R0, LD, A.out_w, D, acc);
             tile_to_lds<BM, D>(acc, R2, LD, A.out_b);
         }
         lds_barrier(); STAMP(2);
@@ -230,7 +245,8 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
     {
         TileAcc<BM, F> acc;
         tile_zero(acc);
-        tile_mma_xwT<BM, D, F>(R1, LD, A.w1, D, acc);
+        if constexpr (PF) tile_mma_frag<BM, D, F>(R1, LD, f_w1, acc);
+        else tile_mma_xwT<BM, D, F>(R1, LD, A.w1, D, acc);
         tile_to_lds<BM, F>(acc, R2, LF, A.b1);
     }
     lds_barrier(); STAMP(4);
@@ -260,7 +276,8 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
     {
         TileAcc<BM, D> acc;
         tile_zero(acc);
-        tile_mma_xwT<BM, F, D>(R2, LF, A.w2, F, acc);
+        if constexpr (PF) tile_mma_frag<BM, F, D>(R2, LF, f_w2, acc);
+        else tile_mma_xwT<BM, F, D>(R2, LF, A.w2, F, acc);
         tile_to_lds<BM, D>(acc, R0, LD, A.b2);
     }
     lds_barrier(); STAMP(6);
@@ -269,7 +286,8 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         lds_barrier();
         TileAcc<BM, 3 * D> acc;
         tile_zero(acc);
-        tile_mma_xwT<BM, D, 3 * D>(R1, LD, A.nx_in_w, D, acc);
+        if constexpr (PF) tile_mma_frag<BM, D, 3 * D>(R1, LD, f_nx, acc);
+        else tile_mma_xwT<BM, D, 3 * D>(R1, LD, A.nx_in_w, D, acc);
         tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
     } else {
         ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
 // part[2*tile] (summed by k_wgrad's reduce job).  Valid targets at positions >= seqlen (query row is zero there) are
 // counted by the sequence's last token, as the per-sequence scorer does.
 struct ScoreTileArgs {
-    const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; int64_t* neg_item; float* part;
+    const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq; int64_t* neg_item; float* part;
     int sample_neg, n_items, B, L;
 };
 template <int LPT>
@@ -490,11 +508,12 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
     float lsum = 0.f, cnt = 0.f;
     float* dZ = const_cast<float*>(A.dz);
+    const int bh = S.tile_seq[t0 >> 4];
 #pragma unroll
     for (int r0 = 0; r0 < BM; r0 += TPB) {
         const int r = r0 + threadIdx.x / LPT, t = t0 + r;
         if (r < BM && t < T) {
-            const int b = find_seq(S.cu, S.B, t), pos = t - S.cu[b], n = S.cu[b + 1] - S.cu[b];
+            const int b = find_seq_from(S.cu, S.B, t, bh), pos = t - S.cu[b], n = S.cu[b + 1] - S.cu[b];
             const int64_t row = S.rows ? S.rows[b] : b;
             int64_t tgt = S.target[row * S.L + pos], ng;
             if (S.sample_neg) {
@@ -613,7 +632,7 @@ int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int trainin
     const int layer = p->n_layer - 1;
     const PostArgs A = make_post_args(p, ws, layer, training);
     ScoreTileArgs S;
-    S.E = p->params + ws.off[0]; S.dE = p->grads + ws.off[0]; S.target = p->item_id; S.rows = p->rows; S.cu = ws.cu;
+    S.E = p->params + ws.off[0]; S.dE = p->grads + ws.off[0]; S.target = p->item_id; S.rows = p->rows; S.cu = ws.cu; S.tile_seq = ws.tile_seq;
     S.neg_item = p->neg_item; S.part = ws.score_part; S.sample_neg = p->sample_neg; S.n_items = p->n_items; S.B = p->B; S.L = p->L;
     const int bm = tile_rows(ws);
     return bm == 16 ? post_mid_bm<16>(p, ws, A, S, s) : bm == 32 ? post_mid_bm<32>(p, ws, A, S, s) : post_mid_bm<64>(p, ws, A, S, s);
@@ -691,7 +710,7 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // (a3 backward: g = dx0 * mask_emb; dE[idx] += g except padding_idx 0; dP[pos] += g), 16 lanes per token; dP is first
 // accumulated in LDS and flushed with one atomic per touched element per workgroup.
 struct QkvEmbBwdArgs {
-    const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu;
+    const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
     float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
 };
 template <int BM, int D>
@@ -713,11 +732,12 @@ __global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
     const int c = (threadIdx.x % LPT) * 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const int bh = A.tile_seq[t0 >> 4];
 #pragma unroll
     for (int r0 = 0; r0 < BM; r0 += TPB) {
         const int r = r0 + threadIdx.x / LPT, t = t0 + r;
         if (r < BM && t < T) {
-            const int b = find_seq(A.cu, A.B, t), pos = t - A.cu[b];
+            const int b = find_seq_from(A.cu, A.B, t, bh), pos = t - A.cu[b];
             const int64_t row = A.rows ? A.rows[b] : b;
             const float4 v = ld4(Cs + r * LDC + c), u = ld4(A.dU1 + (size_t)t * D + c);
             float4 g = make_float4(v.x + u.x, v.y + u.y, v.z + u.z, v.w + u.w);
@@ -747,7 +767,7 @@ int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int tr
     dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
     const LayerWs& lw = ws.layer[0];
     QkvEmbBwdArgs A;
-    A.dQKV = lw.dqkv; A.W = p->params + poff(ws, 0, P_IN_W); A.dU1 = lw.du1; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
+    A.dQKV = lw.dqkv; A.W = p->params + poff(ws, 0, P_IN_W); A.dU1 = lw.du1; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu; A.tile_seq = ws.tile_seq;
     A.dE = p->grads + ws.off[0]; A.dP = p->grads + ws.off[1]; A.state = p->state; A.B = p->B; A.L = p->L; A.n_items = p->n_items;
     A.training = training; A.seed = p->seed; A.p = p->p_drop;
 #define QE(B_) do { if (D == 64) { big_lds(k_qkv_embed_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 64>), grid, blk, lds, s, A); } \

@@ -1,0 +1,36 @@
+"""Timeline of ONE steady-state training step from a rocprofv3 --kernel-trace database: per kernel start offset, duration
+and the idle gap before it (averaged over the last `n` steps).  A step = the launches from one k_prep to the next.
+usage: python tools/ktimeline.py <results.db> [n_steps]"""
+import sqlite3
+import sys
+
+c = sqlite3.connect(sys.argv[1])
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+rows = c.execute("select name, start, end from kernels order by start").fetchall()
+starts = [i for i, r in enumerate(rows) if r[0].startswith("k_prep")]
+steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)][-n_steps:]
+lens = {}
+for a, b in steps:
+    lens[b - a] = lens.get(b - a, 0) + 1
+L = max(lens, key=lens.get)
+steps = [(a, b) for a, b in steps if b - a == L]
+acc = [[0.0, 0.0, 0.0] for _ in range(L)]
+total = 0.0
+for a, b in steps:
+    t0 = rows[a][1]
+    for k in range(L):
+        name, st, en = rows[a + k]
+        prev_end = rows[a + k - 1][2] if k else st
+        acc[k][0] += st - t0
+        acc[k][1] += en - st
+        acc[k][2] += st - prev_end
+    total += rows[b][1] - t0
+n = len(steps)
+print(f"# {n} steps of {L} launches; step period {total / n / 1e3:.2f} us")
+print(f"{'#':>2s} {'kernel':52s} {'start_us':>9s} {'dur_us':>8s} {'gap_us':>7s}")
+busy = 0.0
+for k in range(L):
+    name = rows[steps[0][0] + k][0]
+    print(f"{k:2d} {name[:52]:52s} {acc[k][0] / n / 1e3:9.2f} {acc[k][1] / n / 1e3:8.2f} {acc[k][2] / n / 1e3:7.2f}")
+    busy += acc[k][1] / n
+print(f"# sum of kernel durations {busy / 1e3:.2f} us, idle inside the step {(total / n - busy) / 1e3:.2f} us")

@@ -1,0 +1,35 @@
+import os, sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from dr4sr_amd import _lib
+from dr4sr_amd.engine import SasrecEngine
+from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
+import bench
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+B, L, D, H, F, NL, N = 256, 50, 64, 2, 128, 2, TOYS_N_ITEMS
+rows = make_rows(n_items=N, seed=2024, dense=bool(int(os.environ.get("DENSE", "0"))))
+data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
+eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, 0.5, B, dev, seed=2023)
+bench.init_params_like_reference(eng, 2023)
+rb = torch.arange(B, device=dev)
+neg = torch.zeros(B, L, dtype=torch.int64, device=dev)
+plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rb, neg_item=neg, sample_neg=True)
+for _ in range(3):
+    eng.train_step(plan)
+torch.cuda.synchronize()
+Tmax = B * L
+r = lambda nfl: (nfl * 4 + 255) // 256 * 256
+off = r(B + 1) + r((Tmax + 15) // 16 + 1) + 2 * (NL + 1) * r(Tmax * D)
+os.environ["DR4SR_STAMPS"] = "1"
+for kind, layer in (("post_fwd", 0), ("post_fwd", 1)):
+    kid = _lib.KERNEL_IDS[kind]
+    for _ in range(3):
+        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), kind)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), kind)
+    b.record(); b.synchronize()
+    st = eng.workspace[off:off + 16 * 8].view(torch.int64).cpu().numpy()
+    d = np.diff(st[[0, 1, 2, 3, 4, 5, 6, 15]])
+    print(kind, layer, "us/launch %.2f" % (a.elapsed_time(b) * 1e3 / 20), "phase ticks", d.tolist(), "total", int(st[15] - st[0]))
