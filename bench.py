@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
     ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp", "metamodel"],
                     help="sasrec = BASELINE headline (configs[1]); gru4rec = configs[2] (beauty-sized table, dropout 0.2, wd 1e-4); "
@@ -190,188 +191,201 @@ def main():
     from dr4sr_amd.engine import SasrecEngine
     lib = _lib.load()
 
-    B, L, D, H, F, NL, N = args.batch, 50, 64, 2, 128, 2, TOYS_N_ITEMS
-    if args.model == "gru4rec":
-        N = 12102                                       # amazon-beauty item count (2.Pretrain_regenerator.py:37-42)
-    rows_np = make_rows(n_items=N, seed=2024, dense=args.dense)
-    U = rows_np["seqlen"].shape[0]
-    data = {k: torch.from_numpy(rows_np[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
-    perm = torch.from_numpy(np.random.default_rng(7).permutation(U)).to(dev)      # same permutation on every rank
-    rows_buf = torch.zeros(B, dtype=torch.int64, device=dev)
-    counter = torch.zeros(1, dtype=torch.int32, device=dev)
-    negbuf = torch.zeros(B, L, dtype=torch.int64, device=dev)
-    if args.model == "sasrec":
-        eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023, lr=1e-3)
-        init_params_like_reference(eng, 2023)
-        # a1 fused: rows_buf is filled by the step's first kernel from (perm, counter); no separate selection launch
-        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True,
-                             perm_sel=(perm, B * world, rank * B, counter))
-    elif args.model == "gru4rec":
-        from dr4sr_amd.gru_engine import GruEngine
-        eng = GruEngine(N, L, D, 256, 2, 0.2, B, dev, seed=2023, lr=1e-3, weight_decay=1e-4)
-        g = torch.Generator().manual_seed(2023)
-        for k, v in eng.views.items():
-            v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / 16.0 if "gru" in k else 0.02 * torch.randn(v.shape, generator=g))
-        eng.views["item_embedding.weight"][0] = 0
-        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
-    else:
-        from dr4sr_amd.fmlp_engine import FmlpEngine
-        sl, hist = data["seqlen"], data["in_item_id"]                                # roll every row to a left-padded prefix
-        ar = torch.arange(L, device=dev).view(1, -1)
-        shift = (L - sl).view(-1, 1)
-        data["in_item_id"] = torch.where(ar >= shift, hist.gather(1, (ar - shift) % L), torch.zeros_like(hist)).contiguous()
-        data["item_id"] = data["item_id"].gather(1, (sl - 1).clamp(min=0).view(-1, 1)).squeeze(1).contiguous()
-        eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.5, B, dev, seed=2023, lr=1e-3)
-        g = torch.Generator().manual_seed(2023)
-        for k, v in eng.views.items():
-            v.copy_(torch.ones(v.shape) if k.endswith("LayerNorm.weight") else (torch.zeros(v.shape) if k.endswith("bias") else 0.02 * torch.randn(v.shape, generator=g)))
-        eng.views["item_embedding.weight"][0] = 0
-        negbuf = torch.zeros(B, dtype=torch.int64, device=dev)
-        plan = eng.make_plan(data["in_item_id"], data["item_id"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
-    stream = torch.cuda.Stream(device=dev)
-
-    def select():
+    def measure(B_arg, steps, warmup, extras):
+        """one timed run of the training step at B_arg rows per GPU; extras = per-kernel launch times + the K1 gather microbench"""
+        B, L, D, H, F, NL, N = B_arg, 50, 64, 2, 128, 2, TOYS_N_ITEMS
+        if args.model == "gru4rec":
+            N = 12102                                       # amazon-beauty item count (2.Pretrain_regenerator.py:37-42)
+        rows_np = make_rows(n_items=N, seed=2024, dense=args.dense)
+        U = rows_np["seqlen"].shape[0]
+        data = {k: torch.from_numpy(rows_np[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
+        perm = torch.from_numpy(np.random.default_rng(7).permutation(U)).to(dev)      # same permutation on every rank
+        rows_buf = torch.zeros(B, dtype=torch.int64, device=dev)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        negbuf = torch.zeros(B, L, dtype=torch.int64, device=dev)
         if args.model == "sasrec":
-            return
-        _lib.check(lib.dr4sr_select_rows(_lib.ptr(perm), U, _lib.ptr(rows_buf), B, B * world, rank * B, _lib.ptr(counter),
-                                         _lib.cur_stream()), "select_rows")
-
-    def step_eager():
-        select()
-        if world == 1:
-            eng.train_step(plan)
+            eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023, lr=1e-3)
+            init_params_like_reference(eng, 2023)
+            # a1 fused: rows_buf is filled by the step's first kernel from (perm, counter); no separate selection launch
+            plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True,
+                                 perm_sel=(perm, B * world, rank * B, counter))
+        elif args.model == "gru4rec":
+            from dr4sr_amd.gru_engine import GruEngine
+            eng = GruEngine(N, L, D, 256, 2, 0.2, B, dev, seed=2023, lr=1e-3, weight_decay=1e-4)
+            g = torch.Generator().manual_seed(2023)
+            for k, v in eng.views.items():
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / 16.0 if "gru" in k else 0.02 * torch.randn(v.shape, generator=g))
+            eng.views["item_embedding.weight"][0] = 0
+            plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
         else:
-            eng.fwd_bwd(plan)
-            dist.all_reduce(eng.grads)                 # sum over ranks: grads + {n_valid, loss_sum} tail
-            eng.adam_step(plan)
+            from dr4sr_amd.fmlp_engine import FmlpEngine
+            sl, hist = data["seqlen"], data["in_item_id"]                                # roll every row to a left-padded prefix
+            ar = torch.arange(L, device=dev).view(1, -1)
+            shift = (L - sl).view(-1, 1)
+            data["in_item_id"] = torch.where(ar >= shift, hist.gather(1, (ar - shift) % L), torch.zeros_like(hist)).contiguous()
+            data["item_id"] = data["item_id"].gather(1, (sl - 1).clamp(min=0).view(-1, 1)).squeeze(1).contiguous()
+            eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.5, B, dev, seed=2023, lr=1e-3)
+            g = torch.Generator().manual_seed(2023)
+            for k, v in eng.views.items():
+                v.copy_(torch.ones(v.shape) if k.endswith("LayerNorm.weight") else (torch.zeros(v.shape) if k.endswith("bias") else 0.02 * torch.randn(v.shape, generator=g)))
+            eng.views["item_embedding.weight"][0] = 0
+            negbuf = torch.zeros(B, dtype=torch.int64, device=dev)
+            plan = eng.make_plan(data["in_item_id"], data["item_id"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+        stream = torch.cuda.Stream(device=dev)
 
-    with torch.cuda.stream(stream):
-        for _ in range(3):
-            step_eager()
-        stream.synchronize()
-        use_graph = not args.no_graph
-        if use_graph and world == 1:
-            g_all = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_all, stream=stream):
-                select()
+        def select():
+            if args.model == "sasrec":
+                return
+            _lib.check(lib.dr4sr_select_rows(_lib.ptr(perm), U, _lib.ptr(rows_buf), B, B * world, rank * B, _lib.ptr(counter),
+                                             _lib.cur_stream()), "select_rows")
+
+        def step_eager():
+            select()
+            if world == 1:
                 eng.train_step(plan)
-            run = g_all.replay
-        elif use_graph:
-            g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_a, stream=stream):
-                select()
+            else:
                 eng.fwd_bwd(plan)
-            with torch.cuda.graph(g_b, stream=stream):
+                dist.all_reduce(eng.grads)                 # sum over ranks: grads + {n_valid, loss_sum} tail
                 eng.adam_step(plan)
 
-            def run():
-                g_a.replay()
-                dist.all_reduce(eng.grads)
-                g_b.replay()
-        else:
-            run = step_eager
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                step_eager()
+            stream.synchronize()
+            use_graph = not args.no_graph
+            if use_graph and world == 1:
+                g_all = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_all, stream=stream):
+                    select()
+                    eng.train_step(plan)
+                run = g_all.replay
+            elif use_graph:
+                g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_a, stream=stream):
+                    select()
+                    eng.fwd_bwd(plan)
+                with torch.cuda.graph(g_b, stream=stream):
+                    eng.adam_step(plan)
 
-        for _ in range(args.warmup):
-            run()
-        stream.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(args.steps):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        wall = time.perf_counter() - t0
-        gpu_ms = e0.elapsed_time(e1)
-        if world > 1:
-            tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            wall = float(tmax)
-        loss, nvalid = eng.loss_and_count()
-        T_last = int(eng.state[_lib.STATE_T])
-        model_desc = {"sasrec": "SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[1]): N=11925, L=50, d=64, 2 layers, 2 heads, "
-                                "FFN 128, dropout %.2f" % args.dropout,
-                      "gru4rec": "GRU4Rec on amazon-beauty-sized synthetic rows (BASELINE configs[2]): N=12102, L=50, d=64, GRU 2x256 no bias, "
-                                 "dropout 0.2, Adam wd 1e-4",
-                      "fmlp": "FMLP on toys-shaped synthetic per-prefix left-padded rows: N=11925, L=50, d=64, 2 x (filter + FFN 256), "
-                              "dropout 0.5, all B*L positions computed"}[args.model]
+                def run():
+                    g_a.replay()
+                    dist.all_reduce(eng.grads)
+                    g_b.replay()
+            else:
+                run = step_eager
 
-        out = {
-            "metric": "training sequences/sec, %s d=64 L=50" % {"sasrec": "SASRec", "gru4rec": "GRU4Rec", "fmlp": "FMLP"}[args.model],
-            "value": world * B * args.steps / wall,
-            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, B=%d rows/GPU/step, %s seqlen" %
-                                   (model_desc, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
-                       "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
-                       "hip_graph": bool(use_graph)},
-            "gpu_ms_per_step_events": gpu_ms / args.steps, "final_loss": loss, "valid_tokens_last_step": T_last,
-        }
+            for _ in range(warmup):
+                run()
+            stream.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            wall = time.perf_counter() - t0
+            gpu_ms = e0.elapsed_time(e1)
+            if world > 1:
+                tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                wall = float(tmax)
+            loss, nvalid = eng.loss_and_count()
+            T_last = int(eng.state[_lib.STATE_T])
+            model_desc = {"sasrec": "SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[1]): N=11925, L=50, d=64, 2 layers, 2 heads, "
+                                    "FFN 128, dropout %.2f" % args.dropout,
+                          "gru4rec": "GRU4Rec on amazon-beauty-sized synthetic rows (BASELINE configs[2]): N=12102, L=50, d=64, GRU 2x256 no bias, "
+                                     "dropout 0.2, Adam wd 1e-4",
+                          "fmlp": "FMLP on toys-shaped synthetic per-prefix left-padded rows: N=11925, L=50, d=64, 2 x (filter + FFN 256), "
+                                  "dropout 0.5, all B*L positions computed"}[args.model]
 
-        if rank == 0 and args.model == "sasrec":
-            # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
-            seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
-            kinds = ["embed_fwd", "qkv_fwd", "attn_fwd", "post_fwd", "score", "transpose", "post_bwd", "attn_bwd",
-                     "qkv_bwd", "embed_bwd", "wgrad", "zero_grads", "prep", "adam"]
-            per_step_launches = {"qkv_fwd": NL, "attn_fwd": NL, "post_fwd": NL, "post_bwd": NL, "attn_bwd": NL, "qkv_bwd": NL}
-            ktime = {}
-            reps = 50
-            for kind in kinds:
-                kid = _lib.KERNEL_IDS[kind]
-                for _ in range(5):
-                    _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+            out = {
+                "metric": "training sequences/sec, %s d=64 L=50" % {"sasrec": "SASRec", "gru4rec": "GRU4Rec", "fmlp": "FMLP"}[args.model],
+                "value": world * B * steps / wall,
+                "unit": "sequences/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": 1e3 * wall / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s, B=%d rows/GPU/step, %s seqlen" %
+                                       (model_desc, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
+                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
+                           "hip_graph": bool(use_graph)},
+                "gpu_ms_per_step_events": gpu_ms / steps, "final_loss": loss, "valid_tokens_last_step": T_last,
+            }
+
+            if rank == 0 and args.model == "sasrec" and extras:
+                # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
+                seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
+                kinds = ["embed_fwd", "qkv_fwd", "attn_fwd", "post_fwd", "score", "transpose", "post_bwd", "attn_bwd",
+                         "qkv_bwd", "embed_bwd", "wgrad", "zero_grads", "prep", "adam"]
+                per_step_launches = {"qkv_fwd": NL, "attn_fwd": NL, "post_fwd": NL, "post_bwd": NL, "attn_bwd": NL, "qkv_bwd": NL}
+                ktime = {}
+                reps = 50
+                for kind in kinds:
+                    kid = _lib.KERNEL_IDS[kind]
+                    for _ in range(5):
+                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(reps):
+                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+                    b.record()
+                    b.synchronize()
+                    ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
+                step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
+                dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last) > 0), key=lambda k: step_us[k])
+                fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last)
+                ach = fl / (ktime[dom] * 1e-6) / 1e12
+                out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "us_per_launch": ktime[dom],
+                                   "flops_per_launch": fl}
+                out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
+
+                if extras != "full":
+                    return out, rows_np, N
+                # ---- K1 gather microbench (HBM roofline of the embedding gather, SURVEY §8d): large launch
+                ntok = args.gather_tokens
+                Bg = ntok // L
+                idx = torch.from_numpy(rows_np["in_item_id"]).to(dev)
+                reps_rows = (Bg + U - 1) // U
+                idx_big = idx.repeat(reps_rows, 1)[:Bg].contiguous()
+                idx_big = torch.where(idx_big == 0, torch.randint(1, N, idx_big.shape, device=dev), idx_big)
+                outbuf = torch.empty(Bg, L, D, device=dev)
+                E, P = eng.views["item_embedding.weight"], eng.views["query_encoder.position_emb.weight"]
+                for _ in range(3):
+                    lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx_big), _lib.ptr(outbuf), Bg, L, D, N, _lib.cur_stream())
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                for _ in range(reps):
-                    _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+                for _ in range(10):
+                    lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx_big), _lib.ptr(outbuf), Bg, L, D, N, _lib.cur_stream())
                 b.record()
                 b.synchronize()
-                ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
-            step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
-            dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last) > 0), key=lambda k: step_us[k])
-            fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last)
-            ach = fl / (ktime[dom] * 1e-6) / 1e12
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "us_per_launch": ktime[dom],
-                               "flops_per_launch": fl}
-            out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
+                us = a.elapsed_time(b) * 1e3 / 10
+                gbytes = Bg * L * (8 + 8 * D) / 1e9
+                traffic = None                      # HBM bytes per launch from the PMC passes kept under profiles/ (separate runs)
+                pj = os.path.join(ROOT, "profiles", "round1_gather_pmc.json")
+                if os.path.exists(pj):
+                    pm = json.load(open(pj))
+                    traffic = Bg * L * (pm["fetch_bytes_per_token_corrected"] + pm["write_bytes_per_token"])
+                out["roofline_gather"] = {"kernel": "k_embed_dense<64>", "bound": "hbm", "achieved": gbytes / (us * 1e-6),
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbytes / (us * 1e-6) / HBM_PEAK_GBS,
+                                          "traffic": traffic, "tokens": Bg * L, "us_per_launch": us,
+                                          "algorithmic_bytes_per_token": 8 + 8 * D}
+                del outbuf, idx_big
 
-            # ---- K1 gather microbench (HBM roofline of the embedding gather): large launch
-            ntok = args.gather_tokens
-            Bg = ntok // L
-            idx = torch.from_numpy(rows_np["in_item_id"]).to(dev)
-            reps_rows = (Bg + U - 1) // U
-            idx_big = idx.repeat(reps_rows, 1)[:Bg].contiguous()
-            idx_big = torch.where(idx_big == 0, torch.randint(1, N, idx_big.shape, device=dev), idx_big)
-            outbuf = torch.empty(Bg, L, D, device=dev)
-            E, P = eng.views["item_embedding.weight"], eng.views["query_encoder.position_emb.weight"]
-            for _ in range(3):
-                lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx_big), _lib.ptr(outbuf), Bg, L, D, N, _lib.cur_stream())
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(10):
-                lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx_big), _lib.ptr(outbuf), Bg, L, D, N, _lib.cur_stream())
-            b.record()
-            b.synchronize()
-            us = a.elapsed_time(b) * 1e3 / 10
-            gbytes = Bg * L * (8 + 8 * D) / 1e9
-            traffic = None                      # HBM bytes per launch from the PMC passes kept under profiles/ (separate runs)
-            pj = os.path.join(ROOT, "profiles", "round1_gather_pmc.json")
-            if os.path.exists(pj):
-                pm = json.load(open(pj))
-                traffic = Bg * L * (pm["fetch_bytes_per_token_corrected"] + pm["write_bytes_per_token"])
-            out["roofline_gather"] = {"kernel": "k_embed_dense<64>", "bound": "hbm", "achieved": gbytes / (us * 1e-6),
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbytes / (us * 1e-6) / HBM_PEAK_GBS,
-                                      "traffic": traffic, "tokens": Bg * L, "us_per_launch": us,
-                                      "algorithmic_bytes_per_token": 8 + 8 * D}
-            del outbuf, idx_big
+        return out, rows_np, N
 
+    out, rows_np, N = measure(args.batch, args.steps, args.warmup, "full")
+    if args.model == "sasrec" and args.batch < 8192 and not args.no_throughput_mode:
+        # BASELINE.md §3 asks for B=256 (reference batch size) AND B=8192 (throughput / scaling mode); same data, same step
+        tm, _, _ = measure(8192, max(20, min(100, args.steps)), 10, "kernels")
+        if rank == 0:
+            out["throughput_mode"] = {k: tm[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline",
+                                                          "kernel_us_per_step", "valid_tokens_last_step") if k in tm}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.model == "sasrec":
             from oracle.ref_trainer import time_training

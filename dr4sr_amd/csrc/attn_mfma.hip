@@ -22,6 +22,9 @@ struct AttnArgs2 {
     const float* dctx; float* dqkv;
     const int64_t* idx; const int64_t* rows; const int* cu;
     const int* state; uint64_t seed; float p; int layer; int training; int L;
+    // large batches: sequences are split by length class (k_prep's seq_class lists) into a short kernel (n <= 16: 16 LDS rows,
+    // 2 waves, ~9 workgroups per CU) and a long kernel, each a persistent loop over its list.  list == NULL: block b = sequence b.
+    const int* list; const int* list_count;
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -56,9 +59,9 @@ __device__ __forceinline__ f32x4 mma_rows(const float (&a)[DH / 4], const float 
     return acc;
 }
 
-template <int D>
+template <int D, int ROWS, int NT>
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, int ld, const float* __restrict__ src, int src_ld, int n) {
-    for (int i = threadIdx.x; i < 64 * (D / 4); i += 256) {
+    for (int i = threadIdx.x; i < ROWS * (D / 4); i += NT) {
         const int r = i / (D / 4), c = (i % (D / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < n) v = ld4(src + (size_t)r * src_ld + c);
@@ -67,21 +70,20 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, int ld, cons
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int DH>
-__global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
-    constexpr int D = 2 * DH, LD = D + 4, H = 2;
-    const int b = blockIdx.x;
+template <int DH, int ROWS, int NT>
+__device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
+    constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16;
     const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
     if (n <= 0) return;
-    float* Qs = smem;                    // [64][LD]
-    float* Ks = Qs + 64 * LD;
-    float* Vs = Ks + 64 * LD;
-    int* kpad = reinterpret_cast<int*>(Vs + 64 * LD);      // [64]
+    float* Qs = smem;                    // [ROWS][LD]
+    float* Ks = Qs + ROWS * LD;
+    float* Vs = Ks + ROWS * LD;
+    int* kpad = reinterpret_cast<int*>(Vs + ROWS * LD);      // [64]
     const int64_t row = A.rows ? A.rows[b] : b;
     const float* src = A.qkv + (size_t)t0 * 3 * D;
-    stage_rows<D>(Qs, LD, src, 3 * D, n);
-    stage_rows<D>(Ks, LD, src + D, 3 * D, n);
-    stage_rows<D>(Vs, LD, src + 2 * D, 3 * D, n);
+    stage_rows<D, ROWS, NT>(Qs, LD, src, 3 * D, n);
+    stage_rows<D, ROWS, NT>(Ks, LD, src + D, 3 * D, n);
+    stage_rows<D, ROWS, NT>(Vs, LD, src + 2 * D, 3 * D, n);
     if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
     lds_barrier();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
@@ -92,16 +94,16 @@ __global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
     const float scale = 1.0f / sqrtf((float)DH);
     const int ntile = (n + 15) >> 4;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (MT == 1 ? 1 : 2); ++pass) {
         const int it = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);
         if (it >= ntile) continue;
         const int i = it * 16 + i16;                       // this lane's query row
         float qf[DH / 4];
         load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
-        f32x4 s[4];
+        f32x4 s[MT];
         float m = -INFINITY;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
+        for (int jt = 0; jt < MT; ++jt) {
             if (jt <= it) {
                 float kf[DH / 4];
                 load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
         m = xgroup_max(m);
         float sum = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < MT; ++jt)
             if (jt <= it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
         const float inv = 1.0f / sum;
         const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < MT; ++jt)
             if (jt <= it) {
                 float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
         for (int db = 0; db < DH / 16; ++db) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < MT; ++jt)
                 if (jt <= it)
 #pragma unroll
                     for (int sidx = 0; sidx < 4; ++sidx)
@@ -147,25 +149,35 @@ __global__ __launch_bounds__(256) void k_attn2_fwd(const AttnArgs2 A) {
     }
 }
 
+
+template <int DH, int ROWS, int NT>
+__global__ __launch_bounds__(NT) void k_attn2_fwd(const AttnArgs2 A) {
+    if (!A.list) { attn_fwd_seq<DH, ROWS, NT>(A, blockIdx.x); return; }
+    const int cnt = *A.list_count;
+    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+        attn_fwd_seq<DH, ROWS, NT>(A, A.list[k]);
+        __syncthreads();                                   // LDS is reused by the next sequence
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
-template <int DH>
-__global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
-    constexpr int D = 2 * DH, LD = D + 4, H = 2;
-    const int b = blockIdx.x;
+template <int DH, int ROWS, int NT>
+__device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
+    constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16;
     const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
     if (n <= 0) return;
     float* Qs = smem;
-    float* Ks = Qs + 64 * LD;
-    float* Vs = Ks + 64 * LD;
-    float* Cs = Vs + 64 * LD;                               // dctx rows
-    float* stat = Cs + 64 * LD;                             // [H][64][3]  row max, 1/sum, sum_j P dP
-    int* kpad = reinterpret_cast<int*>(stat + H * 64 * 3);
+    float* Ks = Qs + ROWS * LD;
+    float* Vs = Ks + ROWS * LD;
+    float* Cs = Vs + ROWS * LD;                             // dctx rows
+    float* stat = Cs + ROWS * LD;                           // [H][ROWS][3]  row max, 1/sum, sum_j P dP
+    int* kpad = reinterpret_cast<int*>(stat + H * ROWS * 3);
     const int64_t row = A.rows ? A.rows[b] : b;
     const float* src = A.qkv + (size_t)t0 * 3 * D;
-    stage_rows<D>(Qs, LD, src, 3 * D, n);
-    stage_rows<D>(Ks, LD, src + D, 3 * D, n);
-    stage_rows<D>(Vs, LD, src + 2 * D, 3 * D, n);
-    stage_rows<D>(Cs, LD, A.dctx + (size_t)t0 * D, D, n);
+    stage_rows<D, ROWS, NT>(Qs, LD, src, 3 * D, n);
+    stage_rows<D, ROWS, NT>(Ks, LD, src + D, 3 * D, n);
+    stage_rows<D, ROWS, NT>(Vs, LD, src + 2 * D, 3 * D, n);
+    stage_rows<D, ROWS, NT>(Cs, LD, A.dctx + (size_t)t0 * D, D, n);
     if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
     lds_barrier();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
@@ -178,17 +190,17 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
 
     // ---- phase A: query tiles (transposed orientation: lane i = l&15, j = 4g+r) -> row stats + dQ
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (MT == 1 ? 1 : 2); ++pass) {
         const int it = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);
         if (it >= ntile) continue;
         const int i = it * 16 + i16;
         float qf[DH / 4], cf[DH / 4];
         load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
         load_frag<DH>(cf, Cs, LD, it * 16, h * DH);
-        f32x4 s[4], dp[4];
+        f32x4 s[MT], dp[MT];
         float m = -INFINITY;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < MT; ++jt)
             if (jt <= it) {
                 float kf[DH / 4];
                 load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
         m = xgroup_max(m);
         float sum = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < MT; ++jt)
             if (jt <= it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
         const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
         float rowdot = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < MT; ++jt)
             if (jt <= it) {
                 float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
@@ -229,12 +241,12 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
             }
         rowdot = xgroup_sum(rowdot);
         if (g == 0 && i < n) {
-            float* st = stat + (h * 64 + i) * 3;
+            float* st = stat + (h * ROWS + i) * 3;
             st[0] = m; st[1] = inv; st[2] = rowdot;
         }
         // dS^T[j][i] = P (dP - rowdot) * scale ;  dQ^T[f][i] = sum_j K[j][f] dS^T[j][i]
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < MT; ++jt)
             if (jt <= it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * (dp[jt][r] - rowdot) * scale;
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
         for (int fb = 0; fb < DH / 16; ++fb) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < MT; ++jt)
                 if (jt <= it)
 #pragma unroll
                     for (int sidx = 0; sidx < 4; ++sidx)
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
     lds_barrier();
     // ---- phase B: key tiles (natural orientation: lane j = l&15, i = 4g+r) -> dK, dV
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (MT == 1 ? 1 : 2); ++pass) {
         const int jt = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);     // key tile 0 has 4 query tiles, 3 has 1
         if (jt >= ntile) continue;
         const int j = jt * 16 + i16;                       // this lane's key row
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
 #pragma unroll
         for (int fb = 0; fb < DH / 16; ++fb) { dk[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < MT; ++it) {
             if (it >= jt && it < ntile) {
                 float qf[DH / 4];
                 load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
                     const int i = it * 16 + 4 * g + r;
                     float p = 0.f, mkv = 1.f, rd = 0.f;
                     if (i < n) {
-                        const float* st = stat + (h * 64 + i) * 3;
+                        const float* st = stat + (h * ROWS + i) * 3;
                         if (jok && j <= i) p = expf(s[r] * scale - st[0]) * st[1];
                         rd = st[2];
                         if (dodrop) mkv = drop1(rk, site, ((uint64_t)(b * H + h) * 64 + i) * 64 + j);
@@ -308,6 +320,17 @@ __global__ __launch_bounds__(256) void k_attn2_bwd(const AttnArgs2 A) {
     }
 }
 
+
+template <int DH, int ROWS, int NT>
+__global__ __launch_bounds__(NT) void k_attn2_bwd(const AttnArgs2 A) {
+    if (!A.list) { attn_bwd_seq<DH, ROWS, NT>(A, blockIdx.x); return; }
+    const int cnt = *A.list_count;
+    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+        attn_bwd_seq<DH, ROWS, NT>(A, A.list[k]);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
     AttnArgs2 A;
@@ -315,27 +338,51 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
     A.qkv = lw.qkv; A.ctx = lw.ctx; A.dctx = ws.dctx; A.dqkv = lw.dqkv;
     A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.layer = layer; A.training = training; A.L = p->L;
+    A.list = nullptr; A.list_count = nullptr;
     return A;
+}
+
+// Large batches (same threshold as tile_rows): two persistent launches over k_prep's length-class lists instead of one
+// workgroup per sequence with worst-case LDS.  seq_class = [n_short, n_long, short_list[B], long_list[B]].
+static bool split_by_length(const Workspace& ws) { return ws.Tmax > 16384 && !getenv("DR4SR_ATTN_NOSPLIT"); }
+
+template <int DH>
+static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArgs2 A, bool bwd, hipStream_t s) {
+    const int D = p->D, B = p->B;
+    auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? 4 : 3) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
+    if (!split_by_length(ws)) {
+        const size_t lds = lds_of(64);
+        if (bwd) { big_lds(k_attn2_bwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A); }
+        else { big_lds(k_attn2_fwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A); }
+        return DR4SR_LAUNCH_CHECK();
+    }
+    const int gs = B < 256 * 8 ? B : 256 * 8, gl = B < 256 * 2 ? B : 256 * 2;
+    AttnArgs2 S = A, Lg = A;
+    S.list = ws.seq_class + 2; S.list_count = ws.seq_class;
+    Lg.list = ws.seq_class + 2 + B; Lg.list_count = ws.seq_class + 1;
+    const size_t lds_s = lds_of(16), lds_l = lds_of(64);
+    if (bwd) {
+        hipLaunchKernelGGL((k_attn2_bwd<DH, 16, 128>), dim3(gs), dim3(128), lds_s, s, S);
+        big_lds(k_attn2_bwd<DH, 64, 256>, lds_l);
+        hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(gl), dim3(256), lds_l, s, Lg);
+    } else {
+        hipLaunchKernelGGL((k_attn2_fwd<DH, 16, 128>), dim3(gs), dim3(128), lds_s, s, S);
+        big_lds(k_attn2_fwd<DH, 64, 256>, lds_l);
+        hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256>), dim3(gl), dim3(256), lds_l, s, Lg);
+    }
+    return DR4SR_LAUNCH_CHECK();
 }
 
 int launch_attn2_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const AttnArgs2 A = make_args2(p, ws, layer, training);
-    const int dh = p->D / 2;
-    const size_t lds = sizeof(float) * (3 * 64 * (p->D + 4) + 64);
-    dim3 grid(p->B), blk(256);
-    if (dh == 32) { big_lds(k_attn2_fwd<32>, lds); hipLaunchKernelGGL(k_attn2_fwd<32>, grid, blk, lds, s, A); }
-    else if (dh == 64) { big_lds(k_attn2_fwd<64>, lds); hipLaunchKernelGGL(k_attn2_fwd<64>, grid, blk, lds, s, A); }
-    else return DR4SR_E_SHAPE;
-    return DR4SR_LAUNCH_CHECK();
+    if (p->D == 64) return attn2_launch<32>(p, ws, A, false, s);
+    if (p->D == 128) return attn2_launch<64>(p, ws, A, false, s);
+    return DR4SR_E_SHAPE;
 }
 
 int launch_attn2_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const AttnArgs2 A = make_args2(p, ws, layer, training);
-    const int dh = p->D / 2;
-    const size_t lds = sizeof(float) * (4 * 64 * (p->D + 4) + 2 * 64 * 3 + 64);
-    dim3 grid(p->B), blk(256);
-    if (dh == 32) { big_lds(k_attn2_bwd<32>, lds); hipLaunchKernelGGL(k_attn2_bwd<32>, grid, blk, lds, s, A); }
-    else if (dh == 64) { big_lds(k_attn2_bwd<64>, lds); hipLaunchKernelGGL(k_attn2_bwd<64>, grid, blk, lds, s, A); }
-    else return DR4SR_E_SHAPE;
-    return DR4SR_LAUNCH_CHECK();
+    if (p->D == 64) return attn2_launch<32>(p, ws, A, true, s);
+    if (p->D == 128) return attn2_launch<64>(p, ws, A, true, s);
+    return DR4SR_E_SHAPE;
 }

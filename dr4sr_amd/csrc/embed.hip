@@ -53,14 +53,16 @@ struct PermSel { const int64_t* perm; int64_t n, stride, offset; int* counter; }
 __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqlen, const int64_t* rows,
                                                int* __restrict__ cu, int* __restrict__ state, int B, int L,
                                                int bump_rng, float* __restrict__ zero, int64_t zero_n4, PermSel sel,
-                                               int* __restrict__ tile_seq) {
+                                               int* __restrict__ tile_seq, int* __restrict__ seq_class) {
     if (blockIdx.x > 0) {
         for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n4; i += (int64_t)(gridDim.x - 1) * 1024)
             st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         return;
     }
     __shared__ int part[1024];
+    __shared__ int ncls[2];
     const int tid = threadIdx.x;
+    if (tid < 2) ncls[tid] = 0;
     if (sel.perm) {                                     // a1: this step's batch = a slice of the epoch permutation
         const int64_t c = *sel.counter;
         int64_t* rw = const_cast<int64_t*>(rows);
@@ -87,7 +89,12 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
     for (int b = b0; b < b1; ++b) {
         cu[b] = run;
         int64_t n = seqlen[rows ? rows[b] : b];
-        run += (int)(n < 0 ? 0 : (n > L ? L : n));
+        const int nn = (int)(n < 0 ? 0 : (n > L ? L : n));
+        run += nn;
+        if (seq_class && nn > 0) {                      // length classes for the split attention launches (order is irrelevant)
+            const int cls = nn > 16;
+            seq_class[2 + cls * B + atomicAdd(&ncls[cls], 1)] = b;
+        }
     }
     if (tid == 1023) {
         cu[B] = part[1023];
@@ -96,22 +103,23 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
     }
     if (tile_seq) {                                     // sequence slot of the first token of every 16-token tile
         const int Ttot = part[1023];
-        __syncthreads();                                // cu[] written above is read back by other threads of this block
+        __syncthreads();
+        if (seq_class && tid < 2) seq_class[tid] = ncls[tid];                                // cu[] written above is read back by other threads of this block
         for (int tile = tid; tile * 16 < Ttot; tile += 1024) tile_seq[tile] = find_seq(cu, B, tile * 16);
     }
 }
 
 static int launch_prep_sel(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
-                           int64_t zero_floats, const PermSel& sel, int* tile_seq, hipStream_t s) {
+                           int64_t zero_floats, const PermSel& sel, int* tile_seq, int* seq_class, hipStream_t s) {
     const int64_t n4 = zero ? zero_floats / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024);
     if (zb > 255) zb = 255;
-    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, seqlen, rows, cu, state, B, L, bump_rng, zero, n4, sel, tile_seq);
+    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, seqlen, rows, cu, state, B, L, bump_rng, zero, n4, sel, tile_seq, seq_class);
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
                     int64_t zero_floats, hipStream_t s) {
-    return launch_prep_sel(seqlen, rows, cu, state, B, L, bump_rng, zero, zero_floats, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, s);
+    return launch_prep_sel(seqlen, rows, cu, state, B, L, bump_rng, zero, zero_floats, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, s);
 }
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
     PermSel sel{nullptr, 0, 0, 0, nullptr};
@@ -120,7 +128,7 @@ int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, i
         sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
     }
     return launch_prep_sel(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, zero_grads ? p->grads : nullptr,
-                           ws.n_params + DR4SR_GRAD_TAIL, sel, ws.tile_seq, s);
+                           ws.n_params + DR4SR_GRAD_TAIL, sel, ws.tile_seq, ws.seq_class, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ struct Workspace {
     int64_t n_params;
     int Tmax;
     int* cu;                                   // [B+1] packed row offset of each sequence slot
+    int* seq_class;                            // [2 + 2B] n_short, n_long, short_list[B] (n <= 16), long_list[B]  (k_prep)
     int* tile_seq;                             // [ceil(Tmax/16)] sequence slot of token 16*i (k_prep), search hint of the token-tile kernels
     float* X[DR4SR_MAX_LAYERS + 1];            // X[0] = embedding stage output, X[i+1] = output of layer i
     float* dX[DR4SR_MAX_LAYERS + 1];           // gradients w.r.t. X[i]

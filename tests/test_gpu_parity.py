@@ -246,6 +246,51 @@ def test_full_size_batch_vs_oracle(dev, dense):
         assert relerr(v, g1[k].cpu()) < 1e-5, k
 
 
+def test_large_batch_length_split_attention(dev, monkeypatch):
+    """B = 1024 (T_max > 16384): BM = 32 token tiles and the attention split into a short-sequence (n <= 16) and a long-sequence
+    persistent launch over k_prep's length-class lists.  Checked against the oracle and against the unsplit launch."""
+    from dr4sr_amd.engine import SasrecEngine
+    B = 1024
+    b, N = _toys_batch(B, False, seed=9)
+    b["seqlen"][5] = 16
+    b["seqlen"][6] = 17                                            # both sides of the class boundary
+    for r in (5, 6):
+        n = int(b["seqlen"][r])
+        b["in_item_id"][r] = 0
+        b["item_id"][r] = 0
+        b["in_item_id"][r, :n] = torch.arange(1, n + 1)
+        b["item_id"][r, :n] = torch.arange(2, n + 2)
+    params = _random_params(N, 64, 128, 2, seed=2)
+    eng = SasrecEngine(N, 50, 64, 2, 128, 2, 1e-12, 0.0, B, "cuda")
+    eng.load_named(params)
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                         neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    loss, n = eng.loss_and_count()
+    g_split = {k: v.clone() for k, v in eng.normalized_grads().items()}
+    loss_o, _, grads_o = O.grads_of(params, b, 2, 2, 1e-12)
+    assert n == int((b["item_id"] != 0).sum()) and abs(loss - float(loss_o)) < 2e-5
+    for k, gv in g_split.items():
+        assert relerr(gv, grads_o[k]) < REL, k
+    monkeypatch.setenv("DR4SR_ATTN_NOSPLIT", "1")
+    eng.fwd_bwd(plan)
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, g_split[k].cpu()) < 1e-5, k
+    monkeypatch.delenv("DR4SR_ATTN_NOSPLIT")
+    # with dropout: split and unsplit launches draw identical masks (element-indexed Philox), so they agree to atomics noise
+    eng2 = SasrecEngine(N, 50, 64, 2, 128, 2, 1e-12, 0.5, B, "cuda", seed=7)
+    eng2.load_named(params)
+    plan2 = eng2.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                           neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+    eng2.fwd_bwd(plan2)
+    ga = {k: v.clone() for k, v in eng2.normalized_grads().items()}
+    eng2.state[3] -= 1                                            # replay the same RNG step
+    monkeypatch.setenv("DR4SR_ATTN_NOSPLIT", "1")
+    eng2.fwd_bwd(plan2)
+    for k, gv in eng2.normalized_grads().items():
+        assert relerr(gv, ga[k].cpu()) < 1e-5, k
+
+
 def test_ragged_edge_cases(dev):
     """seqlen 1, seqlen L, last-batch odd size, a row whose targets are all PAD."""
     from dr4sr_amd.engine import SasrecEngine
