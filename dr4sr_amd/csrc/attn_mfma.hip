@@ -22,6 +22,8 @@ struct AttnArgs2 {
     const float* dctx; float* dqkv;
     const int64_t* idx; const int64_t* rows; const int* cu;
     const int* state; uint64_t seed; float p; int layer; int training; int L;
+    float* stat;                 // [T][H][2]  softmax row max, 1/row sum: written by the forward, read by the backward
+    const float* rd;             // [T][H]     sum_j P dP = <dctx, ctx> per head, from the epilogue of k_post_bwd
     // large batches: sequences are split by length class (k_prep's seq_class lists) into a short kernel (n <= 16: 16 LDS rows,
     // 2 waves, ~9 workgroups per CU) and a long kernel, each a persistent loop over its list.  list == NULL: block b = sequence b.
     const int* list; const int* list_count;
@@ -126,6 +128,7 @@ __device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
                 for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
         sum = xgroup_sum(sum);
         const float inv = 1.0f / sum;
+        if (g == 0 && i < n) { float* st = A.stat + ((size_t)(t0 + i) * H + h) * 2; st[0] = m; st[1] = inv; }
         const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
 #pragma unroll
         for (int jt = 0; jt < MT; ++jt)
@@ -161,9 +164,13 @@ __global__ __launch_bounds__(NT) void k_attn2_fwd(const AttnArgs2 A) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// No softmax pass: P = exp(s - m) / sum from the statistics the forward saved, and the row term sum_j P dP = <dctx, ctx>
+// (per head; also true under dropout) comes from k_post_bwd.  dQ (phase A, query-tile owners) and dK/dV (phase B, key-tile
+// owners) are therefore independent and run CONCURRENTLY on two halves of the workgroup: waves [0, NT/128) do phase A,
+// waves [NT/128, NT/64) phase B — half the serial chain of a long sequence, twice the waves per workgroup to hide latency.
 template <int DH, int ROWS, int NT>
 __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
-    constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16;
+    constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16, NW = NT / 64;
     const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
     if (n <= 0) return;
     float* Qs = smem;
@@ -179,8 +186,19 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
     stage_rows<D, ROWS, NT>(Vs, LD, src + 2 * D, 3 * D, n);
     stage_rows<D, ROWS, NT>(Cs, LD, A.dctx + (size_t)t0 * D, D, n);
     if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
+    for (int i = threadIdx.x; i < H * ROWS; i += NT) {      // (h, row) -> m, 1/sum, rowdot
+        const int hh = i / ROWS, r = i % ROWS;
+        float m = 0.f, inv = 0.f, rdot = 0.f;
+        if (r < n) {
+            const float* st = A.stat + ((size_t)(t0 + r) * H + hh) * 2;
+            m = st[0]; inv = st[1]; rdot = A.rd[(size_t)(t0 + r) * H + hh];
+        }
+        stat[i * 3] = m; stat[i * 3 + 1] = inv; stat[i * 3 + 2] = rdot;
+    }
     lds_barrier();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1;
+    const int half = NW == 8 ? (w >> 1) & 1 : 0;            // NW = 8: two waves per (phase, head); NW = 4 (short variant): one
+    const bool phaseB = w >= NW / 2;
     const int i16 = lane & 15, g = lane >> 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
@@ -188,81 +206,53 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
     const float scale = 1.0f / sqrtf((float)DH);
     const int ntile = (n + 15) >> 4;
 
-    // ---- phase A: query tiles (transposed orientation: lane i = l&15, j = 4g+r) -> row stats + dQ
+    if (!phaseB) {
+        // ---- phase A: query tiles (transposed orientation: lane i = l&15, j = 4g+r) -> dQ
 #pragma unroll
-    for (int pass = 0; pass < (MT == 1 ? 1 : 2); ++pass) {
-        const int it = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);
-        if (it >= ntile) continue;
-        const int i = it * 16 + i16;
-        float qf[DH / 4], cf[DH / 4];
-        load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
-        load_frag<DH>(cf, Cs, LD, it * 16, h * DH);
-        f32x4 s[MT], dp[MT];
-        float m = -INFINITY;
-#pragma unroll
-        for (int jt = 0; jt < MT; ++jt)
-            if (jt <= it) {
-                float kf[DH / 4];
-                load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
-                s[jt] = mma_rows<DH>(kf, qf);
-                load_frag<DH>(kf, Vs, LD, jt * 16, h * DH);
-                dp[jt] = mma_rows<DH>(kf, cf);             // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = jt * 16 + 4 * g + r;
-                    const float v = (j <= i && j < n && !kpad[j]) ? s[jt][r] * scale : -INFINITY;
-                    s[jt][r] = v;
-                    m = fmaxf(m, v);
-                }
-            }
-        m = xgroup_max(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < MT; ++jt)
-            if (jt <= it)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
-        sum = xgroup_sum(sum);
-        const float inv = 1.0f / sum;
-        const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
-        float rowdot = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < MT; ++jt)
-            if (jt <= it) {
-                float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
-                const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[jt][r] *= inv;                       // P
-                    dp[jt][r] *= mkv[r];                   // dP = dP~ * mask
-                    rowdot += s[jt][r] * dp[jt][r];
-                }
-            }
-        rowdot = xgroup_sum(rowdot);
-        if (g == 0 && i < n) {
-            float* st = stat + (h * ROWS + i) * 3;
-            st[0] = m; st[1] = inv; st[2] = rowdot;
-        }
-        // dS^T[j][i] = P (dP - rowdot) * scale ;  dQ^T[f][i] = sum_j K[j][f] dS^T[j][i]
-#pragma unroll
-        for (int jt = 0; jt < MT; ++jt)
-            if (jt <= it)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * (dp[jt][r] - rowdot) * scale;
-#pragma unroll
-        for (int fb = 0; fb < DH / 16; ++fb) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int pass = 0; pass < (MT == 1 ? 1 : 2); ++pass) {
+            const int it = pass == 0 ? (half == 0 ? 0 : 1) : (half == 0 ? 3 : 2);
+            if (it >= ntile) continue;
+            const int i = it * 16 + i16;
+            float qf[DH / 4], cf[DH / 4];
+            load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
+            load_frag<DH>(cf, Cs, LD, it * 16, h * DH);
+            const float* sti = stat + (h * ROWS + i) * 3;
+            const float mi = sti[0], inv = sti[1], rdot = sti[2];
+            const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
+            f32x4 ds[MT];
 #pragma unroll
             for (int jt = 0; jt < MT; ++jt)
-                if (jt <= it)
+                if (jt <= it) {
+                    float kf[DH / 4];
+                    load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
+                    const f32x4 s = mma_rows<DH>(kf, qf);
+                    load_frag<DH>(kf, Vs, LD, jt * 16, h * DH);
+                    const f32x4 dp = mma_rows<DH>(kf, cf);         // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
+                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
+                    const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-                    for (int sidx = 0; sidx < 4; ++sidx)
-                        o = mfma16(Ks[(jt * 16 + 4 * g + sidx) * LD + h * DH + fb * 16 + i16], s[jt][sidx], o);
-            if (i < n) st4(A.dqkv + (size_t)(t0 + i) * 3 * D + h * DH + fb * 16 + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = jt * 16 + 4 * g + r;
+                        const float p = (j <= i && j < n && !kpad[j]) ? expf(s[r] * scale - mi) * inv : 0.f;
+                        ds[jt][r] = p * (dp[r] * mkv[r] - rdot) * scale;   // dS^T[j][i]
+                    }
+                }
+            // dQ^T[f][i] = sum_j K[j][f] dS^T[j][i]
+#pragma unroll
+            for (int fb = 0; fb < DH / 16; ++fb) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jt = 0; jt < MT; ++jt)
+                    if (jt <= it)
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx)
+                            o = mfma16(Ks[(jt * 16 + 4 * g + sidx) * LD + h * DH + fb * 16 + i16], ds[jt][sidx], o);
+                if (i < n) st4(A.dqkv + (size_t)(t0 + i) * 3 * D + h * DH + fb * 16 + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
+            }
         }
+        return;
     }
-    lds_barrier();
     // ---- phase B: key tiles (natural orientation: lane j = l&15, i = 4g+r) -> dK, dV
 #pragma unroll
     for (int pass = 0; pass < (MT == 1 ? 1 : 2); ++pass) {
@@ -320,7 +310,6 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
     }
 }
 
-
 template <int DH, int ROWS, int NT>
 __global__ __launch_bounds__(NT) void k_attn2_bwd(const AttnArgs2 A) {
     if (!A.list) { attn_bwd_seq<DH, ROWS, NT>(A, blockIdx.x); return; }
@@ -338,7 +327,7 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
     A.qkv = lw.qkv; A.ctx = lw.ctx; A.dctx = ws.dctx; A.dqkv = lw.dqkv;
     A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.layer = layer; A.training = training; A.L = p->L;
-    A.list = nullptr; A.list_count = nullptr;
+    A.list = nullptr; A.list_count = nullptr; A.stat = lw.attn_st; A.rd = ws.attn_rd;
     return A;
 }
 
@@ -352,7 +341,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? 4 : 3) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
     if (!split_by_length(ws)) {
         const size_t lds = lds_of(64);
-        if (bwd) { big_lds(k_attn2_bwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A); }
+        if (bwd) { big_lds(k_attn2_bwd<DH, 64, 512>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512>), dim3(B), dim3(512), lds, s, A); }
         else { big_lds(k_attn2_fwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A); }
         return DR4SR_LAUNCH_CHECK();
     }
@@ -362,9 +351,9 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     Lg.list = ws.seq_class + 2 + B; Lg.list_count = ws.seq_class + 1;
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
     if (bwd) {
-        hipLaunchKernelGGL((k_attn2_bwd<DH, 16, 128>), dim3(gs), dim3(128), lds_s, s, S);
-        big_lds(k_attn2_bwd<DH, 64, 256>, lds_l);
-        hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(gl), dim3(256), lds_l, s, Lg);
+        hipLaunchKernelGGL((k_attn2_bwd<DH, 16, 256>), dim3(gs), dim3(256), lds_s, s, S);
+        big_lds(k_attn2_bwd<DH, 64, 512>, lds_l);
+        hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512>), dim3(gl), dim3(512), lds_l, s, Lg);
     } else {
         hipLaunchKernelGGL((k_attn2_fwd<DH, 16, 128>), dim3(gs), dim3(128), lds_s, s, S);
         big_lds(k_attn2_fwd<DH, 64, 256>, lds_l);

@@ -474,7 +474,7 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
         A.ln2_w = p->params + foff(ws, l, FP_ILN_W); A.ln2_b = p->params + foff(ws, l, FP_ILN_B);
         A.a = w.a; A.h = w.h; A.u2 = w.u2; A.st2 = w.st2; A.z = ws.X[l + 1];
         A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
-        A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr;
+        A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr; A.rd = nullptr; A.n_head = 1;
         RC(launch_ffn_fwd(A, ws.Tn, s));
     }
     return DR4SR_LAUNCH_CHECK();
@@ -491,7 +491,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         A.df = w.df; A.da = w.da; A.du1 = w.dxf;
         A.ln_part = ws.ln_part + (size_t)l * ntiles * 4 * FM_D;
         A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
-        A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr;
+        A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr; A.rd = nullptr; A.n_head = 1;
         RC(launch_ffn_bwd(A, ws.Tn, s));
         FFiltArgs Fa{};
         Fa.m = ws.m + (size_t)l * L * FM_D; Fa.dm = ws.dm + (size_t)l * L * FM_D; Fa.x = ws.X[l];

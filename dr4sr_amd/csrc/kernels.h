@@ -10,6 +10,7 @@
 struct LayerWs {
     float* qkv;    // [T,3D]  in_proj output (q|k|v)
     float* ctx;    // [T,D]   attention output (heads merged), before out_proj
+    float* attn_st; // [T,H,2] softmax row max and 1/row sum per (token, head), saved by the MFMA attention forward
     float* u1;     // [T,D]   x + drop(out_proj(ctx))                     (LayerNorm1 input)
     float* y;      // [T,D]   LayerNorm1 output
     float* st1;    // [T,2]   (mean, rstd) of u1
@@ -31,6 +32,7 @@ struct Workspace {
     int Tmax;
     int* cu;                                   // [B+1] packed row offset of each sequence slot
     int* seq_class;                            // [2 + 2B] n_short, n_long, short_list[B] (n <= 16), long_list[B]  (k_prep)
+    float* attn_rd;                            // [Tmax][H] <dctx, ctx> per (token, head): softmax-backward row term, from k_post_bwd
     int* tile_seq;                             // [ceil(Tmax/16)] sequence slot of token 16*i (k_prep), search hint of the token-tile kernels
     float* X[DR4SR_MAX_LAYERS + 1];            // X[0] = embedding stage output, X[i+1] = output of layer i
     float* dX[DR4SR_MAX_LAYERS + 1];           // gradients w.r.t. X[i]
@@ -58,6 +60,7 @@ struct PostArgs {
     // backward
     const float* dz; const float* w2T; const float* w1T; const float* out_wT;
     float* df; float* da; float* du1; float* dout; float* dctx;
+    float* rd; int n_head;                     // optional: rd[t][h] = <dctx[t], ctx[t]> over head h's columns (MFMA attention backward)
     float* ln_part;                            // this layer's [ntiles][4][D] LayerNorm affine partials
     const int* state; uint64_t seed; float p; float eps; int layer; int training;
     uint32_t sP, sA, sF;                       // dropout sites: after out_proj / after activation (0xffffffff = none) / after linear2

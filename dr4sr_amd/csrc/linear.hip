@@ -473,7 +473,17 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     constexpr int C4 = D / 4;
     for (int i = threadIdx.x; i < BM * C4; i += 256) {
         const int row = i / C4, c = (i % C4) * 4;
-        if (t0 + row < T) st4(A.dctx + (size_t)(t0 + row) * D + c, ld4(R0 + row * LD + c));
+        const bool ok = t0 + row < T;
+        const float4 v = ld4(R0 + row * LD + c);
+        if (ok) st4(A.dctx + (size_t)(t0 + row) * D + c, v);
+        if (A.rd) {                                    // softmax-backward row term of the attention: sum_j P dP = <dctx, ctx> per head
+            const int lph = C4 / A.n_head;             // lanes per head (contiguous, power of two)
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) o = ld4(A.ctx + (size_t)(t0 + row) * D + c);
+            float d = (v.x * o.x + v.y * o.y) + (v.z * o.z + v.w * o.w);
+            for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+            if (ok && (i % C4) % lph == 0) A.rd[(size_t)(t0 + row) * A.n_head + (i % C4) / lph] = d;
+        }
     }
 }
 
@@ -585,6 +595,7 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     const int D = p->D, F = p->F;
     A.out_wT = wT + 3 * D * D; A.w1T = wT + 4 * D * D; A.w2T = wT + 4 * D * D + D * F;
     A.df = lw.df; A.da = lw.da; A.du1 = lw.du1; A.dout = lw.dout; A.dctx = ws.dctx;
+    A.rd = p->H == 2 ? ws.attn_rd : nullptr; A.n_head = p->H;
     A.ln_part = ws.ln_part + (size_t)layer * ((ws.Tmax + 15) / 16) * 4 * p->D;      // stride sized for the smallest tile
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
     A.sP = DR4SR_SITE_PROJ + 4 * layer; A.sA = DR4SR_SITE_ACT + 4 * layer; A.sF = DR4SR_SITE_FFN + 4 * layer;

@@ -65,6 +65,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->cu = (int*)take(p->B + 1);
     ws->tile_seq = (int*)take((Tmax + 15) / 16 + 1);
     ws->seq_class = (int*)take(2 + 2LL * p->B);
+    ws->attn_rd = take(Tmax * p->H);
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
     ws->dctx = take(Tmax * D);
     ws->wT_stride = 4 * D * D + 2 * D * F;
@@ -73,7 +74,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->ln_part = take((int64_t)p->n_layer * ((Tmax + 15) / 16) * 4 * D);
     for (int l = 0; l < p->n_layer; ++l) {
         LayerWs& w = ws->layer[l];
-        w.qkv = take(Tmax * 3 * D); w.ctx = take(Tmax * D);
+        w.qkv = take(Tmax * 3 * D); w.ctx = take(Tmax * D); w.attn_st = take(Tmax * p->H * 2);
         w.u1 = take(Tmax * D); w.y = take(Tmax * D); w.st1 = take(Tmax * 2);
         w.a = take(Tmax * F); w.h = take(Tmax * F); w.u2 = take(Tmax * D); w.st2 = take(Tmax * 2);
         w.df = take(Tmax * D); w.da = take(Tmax * F); w.du1 = take(Tmax * D); w.dout = take(Tmax * D); w.dqkv = take(Tmax * 3 * D);
