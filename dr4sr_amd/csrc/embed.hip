@@ -59,10 +59,9 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
             st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         return;
     }
-    __shared__ int part[1024];
-    __shared__ int ncls[2];
+    // one packed scan: bits 0-31 tokens, 32-47 short sequences (1..16 tokens), 48-63 long sequences
+    __shared__ unsigned long long part[1024];
     const int tid = threadIdx.x;
-    if (tid < 2) ncls[tid] = 0;
     if (sel.perm) {                                     // a1: this step's batch = a slice of the epoch permutation
         const int64_t c = *sel.counter;
         int64_t* rw = const_cast<int64_t*>(rows);
@@ -72,40 +71,59 @@ __global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqle
     }
     const int per = (B + 1023) / 1024;
     const int b0 = tid * per, b1 = min(B, b0 + per);
-    int s = 0;
+    unsigned long long s = 0;
+    constexpr int KEEP = 8;                             // lengths of the first 8 sequences of the chunk stay in registers (B <= 8192):
+    int keep[KEEP];                                     // independent loads issued together instead of 3 x per dependent chains
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        int nn = 0;
+        if (b0 + k < b1) {
+            const int64_t n = seqlen[rows ? rows[b0 + k] : b0 + k];
+            nn = (int)(n < 0 ? 0 : (n > L ? L : n));
+        }
+        keep[k] = nn;
+    }
+    auto len_of = [&](int b) -> int {
+        const int k = b - b0;
+        if (k < KEEP) {
+            int v = 0;
+#pragma unroll
+            for (int q = 0; q < KEEP; ++q) v = k == q ? keep[q] : v;
+            return v;
+        }
+        const int64_t n = seqlen[rows ? rows[b] : b];
+        return (int)(n < 0 ? 0 : (n > L ? L : n));
+    };
     for (int b = b0; b < b1; ++b) {
-        int64_t n = seqlen[rows ? rows[b] : b];
-        s += (int)(n < 0 ? 0 : (n > L ? L : n));
+        const int nn = len_of(b);
+        s += (unsigned long long)nn + (nn > 0 && nn <= 16 ? (1ull << 32) : 0ull) + (nn > 16 ? (1ull << 48) : 0ull);
     }
     part[tid] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {               // Hillis-Steele inclusive scan
-        int v = tid >= o ? part[tid - o] : 0;
+        const unsigned long long v = tid >= o ? part[tid - o] : 0ull;
         __syncthreads();
         part[tid] += v;
         __syncthreads();
     }
-    int run = part[tid] - s;                            // exclusive prefix of this thread's chunk
+    const unsigned long long ex = part[tid] - s;        // exclusive prefix of this thread's chunk
+    int run = (int)(ex & 0xffffffffull), ns = (int)((ex >> 32) & 0xffff), nl = (int)(ex >> 48);
     for (int b = b0; b < b1; ++b) {
         cu[b] = run;
-        int64_t n = seqlen[rows ? rows[b] : b];
-        const int nn = (int)(n < 0 ? 0 : (n > L ? L : n));
-        run += nn;
-        if (seq_class && nn > 0) {                      // length classes for the split attention launches (order is irrelevant)
-            const int cls = nn > 16;
-            seq_class[2 + cls * B + atomicAdd(&ncls[cls], 1)] = b;
+        const int nn = len_of(b);
+        if (tile_seq)                                   // sequence slot of the first token of every 16-token tile it starts
+            for (int k = (run + 15) >> 4; (k << 4) < run + nn; ++k) tile_seq[k] = b;
+        if (seq_class && nn > 0) {                      // length classes for the split attention launches
+            if (nn <= 16) seq_class[2 + ns++] = b; else seq_class[2 + B + nl++] = b;
         }
+        run += nn;
     }
     if (tid == 1023) {
-        cu[B] = part[1023];
-        state[DR4SR_STATE_T] = part[1023];
+        const unsigned long long tot = part[1023];
+        cu[B] = (int)(tot & 0xffffffffull);
+        state[DR4SR_STATE_T] = (int)(tot & 0xffffffffull);
         if (bump_rng) state[DR4SR_STATE_RNGSTEP] += 1;
-    }
-    if (tile_seq) {                                     // sequence slot of the first token of every 16-token tile
-        const int Ttot = part[1023];
-        __syncthreads();
-        if (seq_class && tid < 2) seq_class[tid] = ncls[tid];                                // cu[] written above is read back by other threads of this block
-        for (int tile = tid; tile * 16 < Ttot; tile += 1024) tile_seq[tile] = find_seq(cu, B, tile * 16);
+        if (seq_class) { seq_class[0] = (int)((tot >> 32) & 0xffff); seq_class[1] = (int)(tot >> 48); }
     }
 }
 

@@ -146,7 +146,8 @@ int launch_adam_flat(float* P, const float* G, float* M, float* V, int64_t n, in
                      float eps, float wd, hipStream_t s) {
     if (!P || !G || !M || !V || !state || n <= 0 || (n & 3)) return DR4SR_E_ARG;
     int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 256) blocks = 256;
+    static const int cap = getenv("DR4SR_ADAM_BLOCKS") ? atoi(getenv("DR4SR_ADAM_BLOCKS")) : 256;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd);
     return DR4SR_LAUNCH_CHECK();
 }

@@ -8,12 +8,13 @@ c = sqlite3.connect(sys.argv[1])
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 starts = [i for i, r in enumerate(rows) if r[0].startswith("k_prep")]
-steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)][-n_steps:]
+steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
 lens = {}
 for a, b in steps:
-    lens[b - a] = lens.get(b - a, 0) + 1
-L = max(lens, key=lens.get)
-steps = [(a, b) for a, b in steps if b - a == L]
+    if b - a > 1:
+        lens[b - a] = lens.get(b - a, 0) + 1
+L = max(lens, key=lens.get)                      # the graph-replayed training step (most frequent multi-launch period)
+steps = [(a, b) for a, b in steps if b - a == L][-n_steps:]
 acc = [[0.0, 0.0, 0.0] for _ in range(L)]
 total = 0.0
 for a, b in steps:
