@@ -163,6 +163,8 @@ def main():
                     help="sasrec = BASELINE headline (configs[1]); gru4rec = configs[2] (beauty-sized table, dropout 0.2, wd 1e-4); "
                          "fmlp = per-prefix left-padded rows, all B*L positions computed; metamodel = configs[4] (DR4SR+ around "
                          "SASRec: weighted inner steps + one hyper-gradient outer step every --interval steps)")
+    ap.add_argument("--embed-dim", type=int, default=64, choices=[64, 128],
+                    help="sasrec: 128 = BASELINE configs[3] shape (yelp: N=20034 items, d=128, FFN 128)")
     ap.add_argument("--interval", type=int, default=30, help="metamodel: outer-loop period (configs/metamodel.yaml interval)")
     args = ap.parse_args()
     if args.model == "metamodel":
@@ -196,6 +198,8 @@ def main():
         B, L, D, H, F, NL, N = B_arg, 50, 64, 2, 128, 2, TOYS_N_ITEMS
         if args.model == "gru4rec":
             N = 12102                                       # amazon-beauty item count (2.Pretrain_regenerator.py:37-42)
+        if args.model == "sasrec" and args.embed_dim == 128:
+            D, N = 128, 20034                               # yelp item count (2.Pretrain_regenerator.py:37-42), configs[3]
         rows_np = make_rows(n_items=N, seed=2024, dense=args.dense)
         U = rows_np["seqlen"].shape[0]
         data = {k: torch.from_numpy(rows_np[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
@@ -297,15 +301,17 @@ def main():
                 wall = float(tmax)
             loss, nvalid = eng.loss_and_count()
             T_last = int(eng.state[_lib.STATE_T])
-            model_desc = {"sasrec": "SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[1]): N=11925, L=50, d=64, 2 layers, 2 heads, "
-                                    "FFN 128, dropout %.2f" % args.dropout,
+            model_desc = {"sasrec": ("SASRec on yelp-sized synthetic rows (BASELINE configs[3] shape): N=20034, L=50, d=128, 2 layers, 2 heads, "
+                                     if D == 128 else
+                                     "SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[1]): N=11925, L=50, d=64, 2 layers, 2 heads, ")
+                                    + "FFN 128, dropout %.2f" % args.dropout,
                           "gru4rec": "GRU4Rec on amazon-beauty-sized synthetic rows (BASELINE configs[2]): N=12102, L=50, d=64, GRU 2x256 no bias, "
                                      "dropout 0.2, Adam wd 1e-4",
                           "fmlp": "FMLP on toys-shaped synthetic per-prefix left-padded rows: N=11925, L=50, d=64, 2 x (filter + FFN 256), "
                                   "dropout 0.5, all B*L positions computed"}[args.model]
 
             out = {
-                "metric": "training sequences/sec, %s d=64 L=50" % {"sasrec": "SASRec", "gru4rec": "GRU4Rec", "fmlp": "FMLP"}[args.model],
+                "metric": "training sequences/sec, %s d=%d L=50" % ({"sasrec": "SASRec", "gru4rec": "GRU4Rec", "fmlp": "FMLP"}[args.model], D),
                 "value": world * B * steps / wall,
                 "unit": "sequences/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                 "ms_per_step": 1e3 * wall / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -371,7 +377,7 @@ def main():
                 if os.path.exists(pj):
                     pm = json.load(open(pj))
                     traffic = Bg * L * (pm["fetch_bytes_per_token_corrected"] + pm["write_bytes_per_token"])
-                out["roofline_gather"] = {"kernel": "k_embed_dense<64>", "bound": "hbm", "achieved": gbytes / (us * 1e-6),
+                out["roofline_gather"] = {"kernel": "k_embed_dense<%d>" % D, "bound": "hbm", "achieved": gbytes / (us * 1e-6),
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbytes / (us * 1e-6) / HBM_PEAK_GBS,
                                           "traffic": traffic, "tokens": Bg * L, "us_per_launch": us,
                                           "algorithmic_bytes_per_token": 8 + 8 * D}
