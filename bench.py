@@ -259,16 +259,16 @@ def main():
             use_graph = not args.no_graph
             if use_graph and world == 1:
                 g_all = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_all, stream=stream):
+                with torch.cuda.graph(g_all, stream=stream, capture_error_mode="thread_local"):
                     select()
                     eng.train_step(plan)
                 run = g_all.replay
             elif use_graph:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_a, stream=stream):
+                with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):
                     select()
                     eng.fwd_bwd(plan)
-                with torch.cuda.graph(g_b, stream=stream):
+                with torch.cuda.graph(g_b, stream=stream, capture_error_mode="thread_local"):
                     eng.adam_step(plan)
 
                 def run():

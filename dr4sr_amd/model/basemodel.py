@@ -280,7 +280,7 @@ class BaseModel(nn.Module):
             if use_graph:
                 warm_up(eager)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):       # other threads (RCCL watchdog) may touch the device
                     eng.train_step(plan)
                 run = g.replay
             else:
@@ -295,9 +295,9 @@ class BaseModel(nn.Module):
             if use_graph:
                 warm_up(eager)
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     eng.fwd_bwd(plan)
-                with torch.cuda.graph(gb):
+                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     eng.adam_step(plan)
 
                 def run():
