@@ -260,6 +260,17 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const GruRecArgs A) {
     for (int t = 0; t < nmax; ++t) {
         const float* hc = hb + (t & 1) * 16 * LDH + l16 * LDH + g * KQ;       // A operand rows: sequence l16
         float* hn = hb + ((t + 1) & 1) * 16 * LDH;
+        // the input-projection terms of this step do not depend on the recurrence: request them before the MFMA loops so that
+        // their L2 round trip hides behind ~10 us of matrix work instead of sitting between the loop and the gate math
+        float gir[UT][4], giz[UT][4], gin[UT][4];
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool act = t < nq[q];
+                const float* gip = A.gi + (size_t)(tq[q] + (act ? t : 0)) * 3 * H + w * (H / 8) + u * 16 + l16;
+                gir[u][q] = act ? gip[0] : 0.f; giz[u][q] = act ? gip[H] : 0.f; gin[u][q] = act ? gip[2 * H] : 0.f;
+            }
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
             const int unit = w * (H / 8) + u * 16 + l16;                     // B operand row / C column of this lane
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const GruRecArgs A) {
 #pragma unroll
             for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* wr = A.whh + (size_t)unit * H + g * KQ;
-#pragma unroll 4
+#pragma unroll 8
             for (int c = 0; c < KQ; c += 4) {
                 const float4 a = ld4(hc + c);
 #pragma unroll
@@ -285,10 +296,9 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const GruRecArgs A) {
                 const size_t tok = (size_t)(tq[q] + t);
                 float hnew = hreg[u][q];
                 if (act) {
-                    const float* gip = A.gi + tok * 3 * H + unit;
-                    const float rr = sigm(gip[0] + acc[0][q]);
-                    const float zz = sigm(gip[H] + acc[1][q]);
-                    const float nn = tanh_f(gip[2 * H] + rr * acc[2][q]);
+                    const float rr = sigm(gir[u][q] + acc[0][q]);
+                    const float zz = sigm(giz[u][q] + acc[1][q]);
+                    const float nn = tanh_f(gin[u][q] + rr * acc[2][q]);
                     const float hold = hreg[u][q];
                     hnew = (1.0f - zz) * nn + zz * hold;
                     const size_t o = tok * H + unit;
@@ -326,6 +336,21 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruRecArgs A) {
     f32x4 carry[UT];
 #pragma unroll
     for (int u = 0; u < UT; ++u) carry[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // saved activations of a step are independent of the carry: they are loaded one step AHEAD (registers), so their L2
+    // round trip overlaps the previous step's MFMA loop instead of heading every step's serial chain
+    float sv[UT][4][6];
+    auto load_saved = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool act = t >= 0 && t < nq[q];
+                const size_t o = (size_t)(tq[q] + (act ? t : 0)) * H + w * (H / 8) + u * 16 + l16;
+                sv[u][q][0] = act ? A.dhout[o] : 0.f; sv[u][q][1] = act ? A.r[o] : 0.f; sv[u][q][2] = act ? A.z[o] : 0.f;
+                sv[u][q][3] = act ? A.n[o] : 0.f; sv[u][q][4] = act ? A.ghn[o] : 0.f; sv[u][q][5] = act ? A.hprev[o] : 0.f;
+            }
+    };
+    load_saved(nmax - 1);
     for (int t = nmax - 1; t >= 0; --t) {
         f32x4 dhz[UT];
 #pragma unroll
@@ -336,9 +361,9 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruRecArgs A) {
                 const bool act = t < nq[q];
                 float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, keep = 0.f;
                 if (act) {
-                    const size_t tok = (size_t)(tq[q] + t), o = tok * H + unit;
-                    const float dh = A.dhout[o] + carry[u][q];
-                    const float rr = A.r[o], zz = A.z[o], nn = A.n[o], gh = A.ghn[o], hp = A.hprev[o];
+                    const size_t tok = (size_t)(tq[q] + t);
+                    const float dh = sv[u][q][0] + carry[u][q];
+                    const float rr = sv[u][q][1], zz = sv[u][q][2], nn = sv[u][q][3], gh = sv[u][q][4], hp = sv[u][q][5];
                     dn = dh * (1.0f - zz) * (1.0f - nn * nn);
                     dz = dh * (hp - nn) * zz * (1.0f - zz);
                     dr = dn * gh * rr * (1.0f - rr);
@@ -355,13 +380,14 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruRecArgs A) {
             }
         }
         lds_barrier();
+        load_saved(t - 1);
         const float* ar = db + l16 * LDG + g * KQ;                      // A operand: dgh row of sequence l16
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
             const int unit = w * (H / 8) + u * 16 + l16;                // output column (hidden unit) of this lane
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* wc = A.whh + (size_t)(g * KQ) * H + unit;
-#pragma unroll 4
+#pragma unroll 8
             for (int c = 0; c < KQ; c += 4) {
                 const float4 a = ld4(ar + c);
                 acc = mfma16g(a.x, wc[(size_t)c * H], acc);
