@@ -346,8 +346,19 @@ def main():
                 dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last) > 0), key=lambda k: step_us[k])
                 fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last)
                 ach = fl / (ktime[dom] * 1e-6) / 1e12
+                # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (tools/traffic_pmc.sh: FETCH_SIZE x2
+                # gfx950 correction + WRITE_SIZE, separate rocprofv3 runs); only for the workloads that were profiled
+                traffic = None
+                tag = {(256, False): "B256_toys", (8192, False): "B8192_toys", (8192, True): "B8192_dense"}.get((B, bool(args.dense)))
+                pj = os.path.join(ROOT, "profiles", "round1_pmc_traffic_%s.json" % tag) if tag and D == 64 else None
+                if pj and os.path.exists(pj):
+                    pm = json.load(open(pj))
+                    prefix = {"attn_fwd": "k_attn2_fwd", "attn_bwd": "k_attn2_bwd", "post_fwd": "k_post_fwd", "post_bwd": "k_post_bwd",
+                              "qkv_fwd": "k_qkv_fwd", "qkv_bwd": "k_qkv_bwd", "wgrad": "k_wgrad"}[dom]
+                    hits = [v["hbm_bytes_per_launch"] for k, v in pm.items() if k.startswith(prefix)]
+                    traffic = float(sum(hits)) if hits else None
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "us_per_launch": ktime[dom],
+                                   "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "us_per_launch": ktime[dom],
                                    "flops_per_launch": fl}
                 out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
 
