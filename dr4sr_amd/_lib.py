@@ -16,7 +16,7 @@ ABI_VERSION = 2
 GRAD_TAIL = 4
 STATE_WORDS = 16
 STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
-POOL_NONE, POOL_ORIGIN, POOL_LAST = 0, 1, 2
+POOL_NONE, POOL_ORIGIN, POOL_LAST, POOL_MEAN = 0, 1, 2, 3
 SITE_EMB, SITE_ATTN, SITE_PROJ, SITE_ACT, SITE_FFN = 0, 1, 2, 3, 4
 
 KERNEL_IDS = {"prep": 0, "embed_fwd": 1, "qkv_fwd": 2, "attn_fwd": 3, "post_fwd": 4, "score": 5, "transpose": 6,
@@ -133,6 +133,10 @@ SYMBOLS = {
     "dr4sr_scale_by": (C.c_int, [_f32p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_meta_sgd_step": (C.c_int, [_f32p, _f32p, _f32p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                       _f32p, C.c_void_p]),
+    "dr4sr_cl_augment": (C.c_int, [_i64p, _i64p, _i64p, _i64p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                   C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "dr4sr_infonce_fwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, C.c_void_p]),
+    "dr4sr_infonce_bwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }
 

@@ -1,0 +1,192 @@
+// cl.hip — CL4SRec pieces (reference model/cl4srec.py, module/data_augmentation.py:20-95, :305-350, :577-619).
+//
+//   k_cl_augment   : Item_Crop / Item_Mask / Item_Reorder / Item_Random on the device (the reference loops over the batch in
+//                    Python with torch/numpy/random generators; the DISTRIBUTION is reproduced with Philox, not the streams).
+//   k_infonce_*    : InfoNCELoss(sim_method='inner_product', neg_type='batch_both'): logits = [x_i x_j^T | x_i x_i^T (diag -inf)] / T,
+//                    cross-entropy against the diagonal of the first block; rows with valid[b] == 0 are removed from rows AND
+//                    columns (the reference drops sequences of length 1 before the loss, data_augmentation.py:613-615).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+#define DR4SR_SITE_AUG 0x41554721u
+
+__device__ __forceinline__ uint32_t aug_rand(const RngKey& rk, uint64_t stream, uint32_t k) {
+    const uint4 r = rng_call(rk, DR4SR_SITE_AUG, (stream << 8) + (k >> 2));
+    const uint32_t c = k & 3;
+    return c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w;
+}
+__device__ __forceinline__ int rand_below(uint32_t r, int n) { return (int)__umulhi(r, (uint32_t)n); }     // uniform on [0, n)
+
+// one thread per sequence; mode 0 crop (tau), 1 mask (gamma), 2 reorder (beta), 3 = one of the three drawn per CALL (Item_Random)
+__global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __restrict__ seqlen, int64_t* __restrict__ out,
+                             int64_t* __restrict__ out_len, int B, int L, int mode, double tau, double gamma, double beta,
+                             int64_t mask_id, uint64_t seed, uint32_t step) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const RngKey rk = make_rng(seed, step, 0.f);
+    if (mode == 3) mode = rand_below(aug_rand(rk, 0xffffffu, 0), 3);          // data_augmentation.py:95: one method for the whole batch
+    int n = (int)seqlen[b];
+    n = n < 0 ? 0 : (n > L ? L : n);
+    const int64_t* src = seq + (size_t)b * L;
+    int64_t* dst = out + (size_t)b * L;
+    const uint64_t st = (uint64_t)b + 1;
+    if (mode == 0) {                                   // Item_Crop :20-41: contiguous sub-sequence of length max(1, int(tau n))
+        const int sub = n > 0 ? max(1, (int)(tau * (double)n)) : 0;       // int(tau * n) in double, as Python does
+        const int start = n > 0 ? rand_below(aug_rand(rk, st, 0), n - sub + 1) : 0;
+        for (int l = 0; l < L; ++l) dst[l] = l < sub ? src[start + l] : 0;
+        out_len[b] = sub;
+    } else if (mode == 1) {                            // Item_Mask :44-62: int(gamma n) distinct positions -> mask_id
+        const int sub = (int)(gamma * (double)n);
+        int pos[64];
+        for (int l = 0; l < n; ++l) pos[l] = l;
+        for (int k = 0; k < sub; ++k) {                // partial Fisher-Yates = np.random.choice(n, sub, replace=False)
+            const int j = k + rand_below(aug_rand(rk, st, k), n - k);
+            const int t = pos[k]; pos[k] = pos[j]; pos[j] = t;
+        }
+        for (int l = 0; l < L; ++l) dst[l] = src[l];
+        for (int k = 0; k < sub; ++k) dst[pos[k]] = mask_id;
+        out_len[b] = n;
+    } else {                                           // Item_Reorder :65-85: shuffle a contiguous segment of length int(beta n)
+        const int sub = (int)(beta * (double)n);
+        const int start = rand_below(aug_rand(rk, st, 0), n - sub + 1);
+        int idx[64];
+        for (int k = 0; k < sub; ++k) idx[k] = k;
+        for (int k = sub - 1; k > 0; --k) {            // Fisher-Yates = random.shuffle
+            const int j = rand_below(aug_rand(rk, st, 1 + k), k + 1);
+            const int t = idx[k]; idx[k] = idx[j]; idx[j] = t;
+        }
+        for (int l = 0; l < L; ++l) dst[l] = src[l];
+        for (int k = 0; k < sub; ++k) dst[start + k] = src[start + idx[k]];
+        out_len[b] = n;
+    }
+}
+
+// ---- InfoNCE.  One wave per row i: lane j-strided over the 2B logits, dot products over D from global (B*D floats: L2 resident).
+template <int D>
+__device__ __forceinline__ float dot_rows(const float* __restrict__ a, const float* __restrict__ b) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const float4 x = ld4(a + c), y = ld4(b + c);
+        s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    return s;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// lse[i] = logsumexp_j logits[i][j], loss_row[i] = lse[i] - logits[i][i] (0 for invalid rows); stats += {n_valid rows, sum loss_row}
+template <int D>
+__global__ __launch_bounds__(256) void k_infonce_fwd(const float* __restrict__ xi, const float* __restrict__ xj,
+                                                     const uint8_t* __restrict__ valid, int B, float inv_t, float* __restrict__ lse,
+                                                     float* __restrict__ loss_row, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    if (valid && !valid[i]) { if (lane == 0) { lse[i] = 0.f; loss_row[i] = 0.f; } return; }
+    const float* qi = xi + (size_t)i * D;
+    float m = -INFINITY, s = 0.f, pos = 0.f;
+    for (int j = lane; j < 2 * B; j += 64) {
+        const int jj = j < B ? j : j - B;
+        if (valid && !valid[jj]) continue;
+        if (j >= B && jj == i) continue;                            // sim_ii diagonal = -inf
+        const float v = dot_rows<D>(qi, (j < B ? xj : xi) + (size_t)jj * D) * inv_t;
+        if (j == i) pos = v;
+        const float mn = fmaxf(m, v);
+        s = s * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+    }
+    const float mg = wave_max(m);
+    s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - mg));
+    pos = wave_sum(pos);
+    if (lane == 0) {
+        const float l = mg + logf(s);
+        lse[i] = l;
+        loss_row[i] = l - pos;
+        unsafeAtomicAdd(stats, 1.0f);
+        unsafeAtomicAdd(stats + 1, l - pos);
+    }
+}
+
+// d loss_sum / d x  scaled by *scale (device scalar or NULL):  with P = softmax(logits) (rows = valid i)
+//   dxi[i] += sum_j P1_ij xj[j] + sum_{j!=i} P2_ij xi[j] - xj[i]        (row pass, this kernel, role 0)
+//   dxj[j] += sum_i P1_ij xi[i] - xi[j] ;  dxi[j] += sum_{i!=j} P2_ij xi[i]   (column pass, role 1)
+// One wave per (row | column), lanes over D (D/64 floats per lane), the other index looped: O(B^2 D), fine for B <= 1024.
+template <int D>
+__global__ __launch_bounds__(256) void k_infonce_bwd(const float* __restrict__ xi, const float* __restrict__ xj,
+                                                     const uint8_t* __restrict__ valid, int B, float inv_t,
+                                                     const float* __restrict__ lse, const float* __restrict__ scale,
+                                                     float* __restrict__ dxi, float* __restrict__ dxj) {
+    constexpr int NV = D / 64;
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= 2 * B) return;
+    const int role = item >= B, a = role ? item - B : item;
+    if (valid && !valid[a]) return;
+    const float sc = (scale ? *scale : 1.0f) * inv_t;
+    float acc_i[NV], acc_j[NV], xa_i[NV], xa_j[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { acc_i[v] = 0.f; acc_j[v] = 0.f; xa_i[v] = xi[(size_t)a * D + lane + 64 * v]; xa_j[v] = xj[(size_t)a * D + lane + 64 * v]; }
+    for (int o = 0; o < B; ++o) {
+        if (valid && !valid[o]) continue;
+        float xo_i[NV], xo_j[NV];
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            xo_i[v] = xi[(size_t)o * D + lane + 64 * v]; xo_j[v] = xj[(size_t)o * D + lane + 64 * v];
+            if (!role) { d1 += xa_i[v] * xo_j[v]; d2 += xa_i[v] * xo_i[v]; }      // logits of row a: sim_ij[a][o], sim_ii[a][o]
+            else { d1 += xo_i[v] * xa_j[v]; d2 += xo_i[v] * xa_i[v]; }            // logits of row o at column a
+        }
+        d1 = wave_sum(d1); d2 = wave_sum(d2);
+        const float l = role ? lse[o] : lse[a];
+        const float p1 = __expf(d1 * inv_t - l), p2 = o == a ? 0.f : __expf(d2 * inv_t - l);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!role) acc_i[v] += p1 * xo_j[v] + p2 * xo_i[v];
+            else { acc_j[v] += p1 * xo_i[v]; acc_i[v] += p2 * xo_i[v]; }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const size_t e = (size_t)a * D + lane + 64 * v;
+        if (!role) unsafeAtomicAdd(dxi + e, sc * (acc_i[v] - xa_j[v]));
+        else { unsafeAtomicAdd(dxj + e, sc * (acc_j[v] - xa_i[v])); unsafeAtomicAdd(dxi + e, sc * acc_i[v]); }
+    }
+}
+
+}  // namespace
+
+extern "C" int dr4sr_cl_augment(const int64_t* seq, const int64_t* seqlen, int64_t* out, int64_t* out_len, int32_t B, int32_t L,
+                                int32_t mode, double tau, double gamma, double beta, int64_t mask_id, uint64_t seed, uint32_t step,
+                                void* stream) {
+    if (!seq || !seqlen || !out || !out_len || B < 0 || L <= 0 || L > 64 || mode < 0 || mode > 3) return DR4SR_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_cl_augment, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, seq, seqlen, out, out_len, B, L, mode, tau,
+                       gamma, beta, mask_id, seed, step);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
+                                 float* lse, float* loss_row, float* stats, void* stream) {
+    if (!xi || !xj || !lse || !loss_row || !stats || B <= 0 || !(temperature > 0.f)) return DR4SR_E_ARG;
+    dim3 grid((B + 3) / 4), blk(256);
+    if (D == 64) hipLaunchKernelGGL(k_infonce_fwd<64>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, loss_row, stats);
+    else if (D == 128) hipLaunchKernelGGL(k_infonce_fwd<128>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, loss_row, stats);
+    else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
+                                 const float* lse, const float* scale, float* dxi, float* dxj, void* stream) {
+    if (!xi || !xj || !lse || !dxi || !dxj || B <= 0 || !(temperature > 0.f)) return DR4SR_E_ARG;
+    dim3 grid((2 * B + 3) / 4), blk(256);
+    if (D == 64) hipLaunchKernelGGL(k_infonce_bwd<64>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, scale, dxi, dxj);
+    else if (D == 128) hipLaunchKernelGGL(k_infonce_bwd<128>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, scale, dxi, dxj);
+    else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}

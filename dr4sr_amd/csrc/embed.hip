@@ -252,19 +252,40 @@ int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int traini
 
 // ------------------------------------------------------------------------------------------------
 // pack / unpack between the dense API layout and the packed workspace layout
-// unpack: out[b,l,:] = l < n_b ? X[cu[b]+l,:] : 0   (ORIGIN/NONE)   or  out[b,:] = X[cu[b]+n_b-1,:]  (LAST)
+// unpack: out[b,l,:] = l < n_b ? X[cu[b]+l,:] : 0   (mode 0: ORIGIN/NONE)  |  out[b,:] = X[cu[b]+n_b-1,:]  (mode 1: LAST)
+//       | out[b,:] = sum_{l<n_b} X[cu[b]+l,:] / n_b  (mode 2: MEAN — module/functional.py:50-55 with keepdim=False)
 template <int D>
 __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ X, const int* __restrict__ cu,
-                                                float* __restrict__ out, int B, int L, int last) {
+                                                float* __restrict__ out, int B, int L, int mode) {
     constexpr int LPT = D / 4, RPB = 256 / LPT;
+    __shared__ float red[256 * 4];
     const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
     const int b = blockIdx.x;
     const int t0 = cu[b], n = cu[b + 1] - t0;
-    if (last) {
+    if (mode == 1) {
         if (sub == 0) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n > 0) v = ld4(X + (size_t)(t0 + n - 1) * D + c);
             st4(out + (size_t)b * D + c, v);
+        }
+        return;
+    }
+    if (mode == 2) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = sub; l < n; l += RPB) {
+            const float4 v = ld4(X + (size_t)(t0 + l) * D + c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        st4(red + threadIdx.x * 4, a);
+        __syncthreads();
+        if (sub == 0) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < RPB; ++k) {
+                const float4 v = ld4(red + (k * LPT + threadIdx.x) * 4);
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            const float inv = 1.0f / (float)n;           // n = 0 -> inf/nan like the reference's division by seq_len
+            st4(out + (size_t)b * D + c, make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv));
         }
         return;
     }
@@ -274,39 +295,43 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ X, con
         st4(out + ((size_t)b * L + l) * D + c, v);
     }
 }
-// pack (backward of unpack): dX[cu[b]+l,:] = d_out[b,l,:]  /  LAST: only row n_b-1 gets d_out[b,:], others 0
+// pack (backward of unpack): dX[cu[b]+l,:] = d_out[b,l,:]  |  LAST: only row n_b-1 gets d_out[b,:]  |  MEAN: every row d_out[b,:]/n_b
 template <int D>
 __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ dout, const int* __restrict__ cu,
-                                              float* __restrict__ dX, int B, int L, int last) {
+                                              float* __restrict__ dX, int B, int L, int mode) {
     constexpr int LPT = D / 4, RPB = 256 / LPT;
     const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
     const int b = blockIdx.x;
     const int t0 = cu[b], n = cu[b + 1] - t0;
     for (int l = sub; l < n; l += RPB) {
         float4 v;
-        if (last) v = (l == n - 1) ? ld4(dout + (size_t)b * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        else v = ld4(dout + ((size_t)b * L + l) * D + c);
+        if (mode == 1) v = (l == n - 1) ? ld4(dout + (size_t)b * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (mode == 2) {
+            const float4 g = ld4(dout + (size_t)b * D + c);
+            const float inv = 1.0f / (float)n;
+            v = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+        } else v = ld4(dout + ((size_t)b * L + l) * D + c);
         st4(dX + (size_t)(t0 + l) * D + c, v);
     }
 }
 
-int launch_unpack_raw(const float* X, const int* cu, float* out, int B, int L, int D, int last, hipStream_t s) {
+int launch_unpack_raw(const float* X, const int* cu, float* out, int B, int L, int D, int mode, hipStream_t s) {
     dim3 grid(B), blk(256);
-    if (D == 64) hipLaunchKernelGGL(k_unpack<64>, grid, blk, 0, s, X, cu, out, B, L, last);
-    else hipLaunchKernelGGL(k_unpack<128>, grid, blk, 0, s, X, cu, out, B, L, last);
+    if (D == 64) hipLaunchKernelGGL(k_unpack<64>, grid, blk, 0, s, X, cu, out, B, L, mode);
+    else hipLaunchKernelGGL(k_unpack<128>, grid, blk, 0, s, X, cu, out, B, L, mode);
     return DR4SR_LAUNCH_CHECK();
 }
-int launch_pack_raw(const float* dout, const int* cu, float* dX, int B, int L, int D, int last, hipStream_t s) {
+int launch_pack_raw(const float* dout, const int* cu, float* dX, int B, int L, int D, int mode, hipStream_t s) {
     dim3 grid(B), blk(256);
-    if (D == 64) hipLaunchKernelGGL(k_pack<64>, grid, blk, 0, s, dout, cu, dX, B, L, last);
-    else hipLaunchKernelGGL(k_pack<128>, grid, blk, 0, s, dout, cu, dX, B, L, last);
+    if (D == 64) hipLaunchKernelGGL(k_pack<64>, grid, blk, 0, s, dout, cu, dX, B, L, mode);
+    else hipLaunchKernelGGL(k_pack<128>, grid, blk, 0, s, dout, cu, dX, B, L, mode);
     return DR4SR_LAUNCH_CHECK();
 }
-int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int last, hipStream_t s) {
-    return launch_unpack_raw(X, ws.cu, out, p->B, p->L, p->D, last, s);
+int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int mode, hipStream_t s) {
+    return launch_unpack_raw(X, ws.cu, out, p->B, p->L, p->D, mode, s);
 }
-int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int last, hipStream_t s) {
-    return launch_pack_raw(dout, ws.cu, dX, p->B, p->L, p->D, last, s);
+int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int mode, hipStream_t s) {
+    return launch_pack_raw(dout, ws.cu, dX, p->B, p->L, p->D, mode, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -97,8 +97,8 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws);   // fills ws fr
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s);
 int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
-int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int last, hipStream_t s);
-int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int last, hipStream_t s);
+int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int mode, hipStream_t s);
+int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int mode, hipStream_t s);
 
 int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
 int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);

@@ -243,20 +243,20 @@ extern "C" int dr4sr_sasrec_encode(const dr4sr_sasrec_plan* plan, int32_t traini
                                    void* stream) {
     Workspace ws;
     RC(get_ws(plan, &ws));
-    if (!out || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
+    if (!out || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_MEAN) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     RC(launch_prep(plan, ws, training ? 1 : 0, 0, s));
     RC(forward_layers(plan, ws, training, s));
-    return launch_unpack(plan, ws, ws.X[plan->n_layer], out, pooling == DR4SR_POOL_LAST, s);
+    return launch_unpack(plan, ws, ws.X[plan->n_layer], out, pooling == DR4SR_POOL_LAST ? 1 : pooling == DR4SR_POOL_MEAN ? 2 : 0, s);
 }
 
 extern "C" int dr4sr_sasrec_encode_bwd(const dr4sr_sasrec_plan* plan, int32_t training, int32_t pooling,
                                        const float* d_out, void* stream) {
     Workspace ws;
     RC(get_ws(plan, &ws));
-    if (!d_out || !plan->grads || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_LAST) return DR4SR_E_ARG;
+    if (!d_out || !plan->grads || pooling < DR4SR_POOL_NONE || pooling > DR4SR_POOL_MEAN) return DR4SR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    RC(launch_pack(plan, ws, d_out, ws.dX[plan->n_layer], pooling == DR4SR_POOL_LAST, s));
+    RC(launch_pack(plan, ws, d_out, ws.dX[plan->n_layer], pooling == DR4SR_POOL_LAST ? 1 : pooling == DR4SR_POOL_MEAN ? 2 : 0, s));
     return backward_layers(plan, ws, training, 0, s);
 }
 

@@ -48,7 +48,7 @@ def param_shapes(n_items, L, D, F, n_layer):
 class SasrecEngine:
     def __init__(self, n_items: int, L: int, D: int, H: int, F: int, n_layer: int, ln_eps: float = 1e-12,
                  p_drop: float = 0.0, max_batch: int = 256, device="cuda", seed: int = 2023, lr: float = 1e-3,
-                 betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0):
+                 betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0, n_slots: int = 1):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -83,12 +83,16 @@ class SasrecEngine:
         self.ws_bytes = int(self.lib.dr4sr_sasrec_workspace_bytes(C.byref(probe)))
         if self.ws_bytes <= 0:
             raise _lib.Dr4srError(f"workspace_bytes failed ({self.ws_bytes})")
-        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        # slot = (workspace, state words): several forward passes can be alive before their backward passes (CL4SRec encodes
+        # three views per step); slot 0 is the default and the one the optimizer's step counter lives in
+        self.workspaces = [torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+        self.states = [self.state] + [torch.zeros(_lib.STATE_WORDS, dtype=torch.int32, device=dev) for _ in range(n_slots - 1)]
+        self.workspace = self.workspaces[0]
         self.neg_scratch = torch.zeros(max_batch * L, dtype=torch.int64, device=dev)
         self._keep = []          # tensors referenced by the last plan
 
     # ------------------------------------------------------------------------------------------
-    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True, perm_sel=None):
+    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True, perm_sel=None, slot=0):
         p = _lib.SasrecPlan()
         p.abi_version = _lib.ABI_VERSION
         p.B, p.L, p.D, p.H, p.F, p.n_layer, p.n_items = B, self.L, self.D, self.H, self.F, self.n_layer, self.n_items
@@ -103,8 +107,11 @@ class SasrecEngine:
                 setattr(p, name, t.data_ptr())
         p.sample_neg = 1 if sample_neg else 0
         if with_ws:
-            p.workspace, p.workspace_bytes = self.workspace.data_ptr(), self.ws_bytes
-        p.state = self.state.data_ptr()
+            p.workspace, p.workspace_bytes = self.workspaces[slot].data_ptr(), self.ws_bytes
+            p.state = self.states[slot].data_ptr()
+            p.seed = (self.seed + 0x9E3779B97F4A7C15 * slot) & 0xFFFFFFFFFFFFFFFF     # independent dropout streams per slot
+        else:
+            p.state = self.state.data_ptr()
         p.lr, (p.beta1, p.beta2), p.adam_eps, p.weight_decay = self.lr, self.betas, self.adam_eps, self.weight_decay
         if perm_sel is not None:           # (perm[n], stride, offset, counter[1] int32): rows[] is FILLED by the step's first kernel
             perm, stride, offset, counter = perm_sel
@@ -114,7 +121,7 @@ class SasrecEngine:
         self._keep = [in_item_id, item_id, seqlen, rows, neg_item, perm_sel]
         return p
 
-    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None):
+    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None, slot=0):
         """rows=None: the tensors ARE the batch ([B,L]/[B]); else they are dataset tensors indexed by rows[B].
         perm_sel: fused device-side batch selection (include/dr4sr_hip.h: dr4sr_sasrec_plan.perm)."""
         B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
@@ -124,7 +131,7 @@ class SasrecEngine:
             sample_neg = neg_item is None
         if neg_item is None:
             neg_item = self.neg_scratch
-        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, perm_sel=perm_sel)
+        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, perm_sel=perm_sel, slot=slot)
 
     # ------------------------------------------------------------------------------------------
     def fwd_bwd(self, plan):
@@ -138,7 +145,7 @@ class SasrecEngine:
 
     def encode(self, plan, training: bool, pooling: int, out: Optional[torch.Tensor] = None):
         B = plan.B
-        shape = (B, self.D) if pooling == _lib.POOL_LAST else (B, self.L, self.D)
+        shape = (B, self.D) if pooling in (_lib.POOL_LAST, _lib.POOL_MEAN) else (B, self.L, self.D)
         if out is None:
             out = torch.empty(shape, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.dr4sr_sasrec_encode(C.byref(plan), int(training), pooling, _lib.ptr(out), _lib.cur_stream()),

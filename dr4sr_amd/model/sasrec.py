@@ -81,20 +81,20 @@ class _Encode(torch.autograd.Function):
     """SASRecQueryEncoder.forward + SeqPoolingLayer through dr4sr_sasrec_encode / _encode_bwd"""
 
     @staticmethod
-    def forward(ctx, model, anchor, idx, seqlen, training, pooling):
+    def forward(ctx, model, anchor, idx, seqlen, training, pooling, slot=0):
         eng = model.engine
         idx, seqlen = idx.contiguous(), seqlen.contiguous()
-        plan = eng.make_plan(idx, None, seqlen)
+        plan = eng.make_plan(idx, None, seqlen, slot=slot)
         out = eng.encode(plan, training, pooling)
-        ctx.model, ctx.args = model, (idx, seqlen, training, pooling)
+        ctx.model, ctx.args = model, (idx, seqlen, training, pooling, slot)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        idx, seqlen, training, pooling = ctx.args
+        idx, seqlen, training, pooling, slot = ctx.args
         eng = ctx.model.engine
-        eng.encode_bwd(eng.make_plan(idx, None, seqlen), training, pooling, gout.contiguous())
-        return None, None, None, None, None, None
+        eng.encode_bwd(eng.make_plan(idx, None, seqlen, slot=slot), training, pooling, gout.contiguous())
+        return None, None, None, None, None, None, None
 
 
 class SASRecQueryEncoder(nn.Module):
@@ -118,18 +118,22 @@ class SASRecQueryEncoder(nn.Module):
             lyr.self_attn.in_proj_weight.data.copy_(w)
             lyr.self_attn.in_proj_bias.data.zero_()
 
-    _POOL = {"origin": _lib.POOL_ORIGIN, "last": _lib.POOL_LAST}
+    _POOL = {"origin": _lib.POOL_ORIGIN, "last": _lib.POOL_LAST, "mean": _lib.POOL_MEAN}
 
-    def forward(self, batch, need_pooling=True):
+    def forward(self, batch, need_pooling=True, slot=0, pooling=None):
+        """slot: engine workspace of this pass (passes whose backward has not run yet must not share one); pooling: override
+        ('mean' = module/functional.py:50-55 fused into the encoder call, used by the CL4SRec views)"""
         if batch.get("seq_emb", None) is not None or "input_weight" in batch:
             raise NotImplementedError("seq_emb / input_weight inputs are unused by the shipped configs and not on the HIP path")
-        if not need_pooling:
+        if pooling is not None:
+            pooling = self._POOL[pooling]
+        elif not need_pooling:
             pooling = _lib.POOL_NONE
         else:
             pooling = self._POOL[self.training_pooling_type if self.training else self.eval_pooling_type]
         model = self._owner[0]
         return _Encode.apply(model, model.item_embedding.weight, batch["in_" + self.fiid], batch["seqlen"],
-                             bool(self.training), pooling)
+                             bool(self.training), pooling, slot)
 
 
 class SASRec(BaseModel):
@@ -137,18 +141,24 @@ class SASRec(BaseModel):
         super().__init__(config, dataset_list)
         mc, tc = config["model"], config["train"]
         max_b = max(int(tc["batch_size"]), int(config["eval"]["batch_size"]))
-        self.engine = SasrecEngine(self.num_items, self.max_seq_len, self.embed_dim, mc["head_num"], mc["hidden_size"],
+        self.engine = SasrecEngine(self._table_rows(), self.max_seq_len, self.embed_dim, mc["head_num"], mc["hidden_size"],
                                    mc["layer_num"], mc["layer_norm_eps"], mc["dropout_rate"], max_b, self.device,
                                    seed=int(tc["seed"]) + 7919 * self.rank, lr=float(tc["learning_rate"]),
-                                   weight_decay=float(tc["weight_decay"]))
+                                   weight_decay=float(tc["weight_decay"]), n_slots=self._n_slots())
         self.device = self.engine.device
-        self.item_embedding = _Embedding(self.engine, "item_embedding.weight", self.num_items, self.embed_dim, padding_idx=0)
+        self.item_embedding = _Embedding(self.engine, "item_embedding.weight", self._table_rows(), self.embed_dim, padding_idx=0)
         self.query_encoder = SASRecQueryEncoder(self.fiid, self.embed_dim, self.max_seq_len, mc["head_num"], mc["hidden_size"],
                                                 mc["dropout_rate"], mc["activation"], mc["layer_norm_eps"], mc["layer_num"],
                                                 self.item_embedding, self.engine, self)
         self._rows_buf = torch.zeros(int(tc["batch_size"]), dtype=torch.int64, device=self.device)
         self._neg_buf = torch.zeros(int(tc["batch_size"]) * self.max_seq_len, dtype=torch.int64, device=self.device)
         self._dummy = torch.ones(1, dtype=torch.int64, device=self.device)
+
+    def _table_rows(self) -> int:          # rows of the item table (CL4SRec adds the mask item)
+        return self.num_items
+
+    def _n_slots(self) -> int:             # forward passes alive per step
+        return 1
 
     def forward(self, batch, need_pooling=True):
         return self.query_encoder(batch, need_pooling)

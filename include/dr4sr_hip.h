@@ -43,6 +43,7 @@ extern "C" {
 #define DR4SR_POOL_NONE   0
 #define DR4SR_POOL_ORIGIN 1     /* module/layers.py:41-50  zero rows >= seqlen  -> [B,L,D]   */
 #define DR4SR_POOL_LAST   2     /* module/layers.py:69-73  row seqlen-1         -> [B,D]     */
+#define DR4SR_POOL_MEAN   3     /* module/functional.py:50-55  mean of rows < seqlen -> [B,D] (CL4SRec views)   */
 
 /* slots of the int32 `state` buffer (device), DR4SR_STATE_WORDS words, owned by the caller */
 #define DR4SR_STATE_STEP     0  /* optimizer step counter t (incremented by dr4sr_adam_step) */
@@ -125,7 +126,7 @@ int dr4sr_sasrec_train_step(const dr4sr_sasrec_plan* plan, void* stream);
 /* SASRecQueryEncoder.forward + SeqPoolingLayer (sasrec.py:39-75, layers.py:41-50/:69-73).
  * training != 0 applies dropout (RNG step = state[RNGSTEP]) and keeps activations in the
  * workspace for dr4sr_sasrec_encode_bwd.  out: [B,L,D] (NONE/ORIGIN; NONE leaves rows >= seqlen
- * ZERO as well — they are never computed) or [B,D] (LAST). */
+ * ZERO as well — they are never computed) or [B,D] (LAST, MEAN). */
 int dr4sr_sasrec_encode(const dr4sr_sasrec_plan* plan, int32_t training, int32_t pooling,
                         float* out, void* stream);
 /* autograd of the above (same `training` / `pooling` as the forward call it differentiates, no
@@ -301,6 +302,26 @@ int dr4sr_scale_by(float* out, const float* x, const float* den, int64_t n, void
  * step_count (device int32) selects the first-step momentum initialisation and is incremented; out_norm (NULL ok) = |grad|. */
 int dr4sr_meta_sgd_step(float* phi, const float* grad, float* momentum_buf, int32_t n, float lr, float momentum,
                         float weight_decay, float max_norm, int32_t* step_count, float* out_norm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CL4SRec (model/cl4srec.py, module/data_augmentation.py:20-95,:305-350,:577-619): two augmented views of every sequence are
+ * encoded by the SAME SASRec encoder (dr4sr_sasrec_encode with DR4SR_POOL_MEAN, one workspace per view), InfoNCE between the views.
+ *
+ * dr4sr_cl_augment — Item_Crop (mode 0: contiguous max(1, int(tau n)) items, left-aligned, out_len = that), Item_Mask (mode 1:
+ *   int(gamma n) distinct positions -> mask_id), Item_Reorder (mode 2: a contiguous int(beta n) segment shuffled), Item_Random
+ *   (mode 3: one of the three, drawn once per call).  seq/out [B,L] int64 (L <= 64), seqlen/out_len [B].  Philox (seed, step):
+ *   same distributions as the reference's torch/numpy/random draws, not the same streams.
+ * dr4sr_infonce_fwd — InfoNCELoss('inner_product', 'batch_both'): logits[i] = [x_i.x_j^T | x_i.x_i^T, diagonal -inf] / temperature,
+ *   cross-entropy with label i.  valid[B] (uint8, NULL = all): rows with 0 are removed from rows and columns (the reference drops
+ *   sequences of length 1, data_augmentation.py:613-615).  Outputs lse[B], loss_row[B] (0 at invalid rows), stats[0] += #valid rows,
+ *   stats[1] += sum loss_row  (reduce=True loss = stats[1] / stats[0]; reduce=False = loss_row / #valid).
+ * dr4sr_infonce_bwd — d(sum loss_row) * (*scale) accumulated into dxi, dxj [B,D]. */
+int dr4sr_cl_augment(const int64_t* seq, const int64_t* seqlen, int64_t* out, int64_t* out_len, int32_t B, int32_t L, int32_t mode,
+                     double tau, double gamma, double beta, int64_t mask_id, uint64_t seed, uint32_t step, void* stream);
+int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature, float* lse,
+                      float* loss_row, float* stats, void* stream);
+int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
+                      const float* lse, const float* scale, float* dxi, float* dxj, void* stream);
 
 /* Measurement hook: enqueue ONE kernel of the training step (on the state the last fwd_bwd left in
  * the workspace) so bench.py can bracket it with HIP events.  Not part of the reference surface. */

@@ -1,0 +1,167 @@
+"""GPU parity of the CL4SRec path: augmentation kernel (legality + distribution), mean pooling, InfoNCE fwd/bwd, and the whole
+training step of dr4sr_amd.model.cl4srec.CL4SRec vs golden vectors made by RUNNING the reference (views recorded)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cl4srec_oracle as CO  # noqa: E402
+from tests.test_cl_oracle import load_cl  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def make_config(n_items, n_rows=300, batch=64, epochs=2, dropout=0.0, augment="item_random"):
+    return {
+        "data": {"dataset": "synthetic-toys", "domain_name_list": ["toy"], "max_seq_len": 50, "dataset_class": "synthetic",
+                 "train_file": "", "n_items": n_items, "n_rows": n_rows, "n_eval_rows": 128, "seed": 5},
+        "model": {"model": "CL4SRec", "embed_dim": 64, "loss_fn": "bce", "hidden_size": 128, "layer_num": 2, "head_num": 2,
+                  "dropout_rate": dropout, "activation": "gelu", "layer_norm_eps": 1e-12, "augment_type": augment,
+                  "temperature": 1.0, "cl_weight": 0.1, "tau": 0.2, "gamma": 0.7, "beta": 0.2},
+        "train": {"batch_size": batch, "early_stop_mode": "max", "early_stop_patience": 20, "epochs": epochs, "device": "cuda",
+                  "optimizer": "adam", "learning_rate": 0.001, "weight_decay": 0, "num_neg": 1, "seed": 2023, "hip_graph": True},
+        "eval": {"batch_size": 128, "cutoff": [20, 10], "val_metrics": ["ndcg", "recall"], "test_metrics": ["ndcg", "recall"],
+                 "topk": 100, "save_path": "./saved/"},
+    }
+
+
+def test_augment_kernel_legal_and_well_distributed():
+    from dr4sr_amd.module.data_augmentation import Item_Crop, Item_Mask, Item_Random, Item_Reorder
+    torch.manual_seed(0)
+    B, L, N = 4096, 50, 1000
+    sl = torch.randint(1, 51, (B,))
+    seq = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        seq[b, :sl[b]] = torch.arange(1, int(sl[b]) + 1) + 100 * (b % 7)        # distinct items inside a sequence
+    seqd, sld = seq.cuda(), sl.cuda()
+    tau, gamma, beta = 0.2, 0.7, 0.2
+    # crop
+    out, ol = Item_Crop(tau)(seqd, sld)
+    out, ol = out.cpu(), ol.cpu()
+    starts = []
+    for b in range(B):
+        n, k = int(sl[b]), int(ol[b])
+        assert k == CO.crop_len(n, tau) and (out[b, k:] == 0).all()
+        s0 = int(out[b, 0] - seq[b, 0])
+        assert 0 <= s0 <= n - k and torch.equal(out[b, :k], seq[b, s0:s0 + k])
+        if n == 50:
+            starts.append(s0)
+    assert len(set(starts)) > 30                                                 # uniform over 41 start positions
+    # mask
+    out, ol = Item_Mask(N, gamma)(seqd, sld)
+    out, ol = out.cpu(), ol.cpu()
+    assert torch.equal(ol, sl)
+    hit = torch.zeros(50)
+    for b in range(B):
+        n = int(sl[b])
+        m = out[b, :n] == N
+        assert int(m.sum()) == CO.mask_count(n, gamma) and torch.equal(out[b, :n][~m], seq[b, :n][~m]) and (out[b, n:] == 0).all()
+        if n == 50:
+            hit += m.float()
+    assert hit.min() > 0.4 * hit.max()                                           # every position gets masked about equally often
+    # reorder
+    out, ol = Item_Reorder(beta)(seqd, sld)
+    out, ol = out.cpu(), ol.cpu()
+    moved = 0
+    for b in range(B):
+        n, k = int(sl[b]), CO.reorder_len(int(sl[b]), beta)
+        assert sorted(out[b, :n].tolist()) == sorted(seq[b, :n].tolist()) and (out[b, n:] == 0).all()
+        diff = (out[b, :n] != seq[b, :n]).nonzero().flatten()
+        if len(diff):
+            assert int(diff.max() - diff.min()) < k                              # all moves inside one window of length k
+            moved += 1
+    assert moved > B // 2
+    # random: the method is drawn once per CALL (data_augmentation.py:95) and all three occur
+    aug = Item_Random(N, tau, gamma, beta)
+    kinds = set()
+    for _ in range(24):
+        o, l2 = aug(seqd[:64], sld[:64])
+        o, l2 = o.cpu(), l2.cpu()
+        big = sl[:64] >= 10
+        if (l2[big] != sl[:64][big]).all():
+            kinds.add("crop")
+        elif (o == N).any():
+            kinds.add("mask")
+        else:
+            kinds.add("reorder")
+    assert kinds == {"crop", "mask", "reorder"}
+
+
+def test_infonce_kernels_match_oracle():
+    from dr4sr_amd.module.data_augmentation import InfoNCELoss
+    torch.manual_seed(1)
+    for B, D, T in ((37, 64, 1.0), (130, 128, 0.5)):
+        xi, xj = torch.randn(B, D) * 0.5, torch.randn(B, D) * 0.5
+        valid = torch.rand(B) > 0.15
+        a, b = xi.clone().requires_grad_(True), xj.clone().requires_grad_(True)
+        ref = CO.infonce(a[valid], b[valid], T)
+        ref.backward()
+        ad, bd = xi.cuda().requires_grad_(True), xj.cuda().requires_grad_(True)
+        loss = InfoNCELoss(T)(ad, bd, valid=valid.cuda())
+        loss.backward()
+        assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+        assert rel(ad.grad.cpu().numpy(), a.grad.numpy()) < 2e-4 and rel(bd.grad.cpu().numpy(), b.grad.numpy()) < 2e-4
+        rows = InfoNCELoss(T)(xi.cuda(), xj.cuda(), reduce=False, valid=valid.cuda())
+        np.testing.assert_allclose(rows.cpu().numpy(), CO.infonce(xi[valid], xj[valid], T, reduce=False).numpy(), rtol=2e-4, atol=1e-7)
+
+
+def test_cl4srec_training_step_matches_reference(golden_dir, monkeypatch):
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    g, p, batch, views, cfg = load_cl(golden_dir)
+    from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
+    config = make_config(int(g["meta.num_items"]))
+    seed_everything(config["train"]["seed"])
+    ds = prepare_datasets(config)
+    model = prepare_model(config, ds)
+    model._init_model(ds[0])
+    ref_sd = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}
+    assert set(model.state_dict()) == set(ref_sd)
+    model.load_state_dict(ref_sd, strict=True)
+    dev = model.device
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    # mean pooling of the views == the reference's need_pooling=False + seq_pooling_function('mean')
+    model.train()
+    (vi, li), (vj, lj) = views
+    with torch.no_grad():
+        oi = model.query_encoder({"in_item_id": vi.to(dev), "seqlen": li.to(dev)}, need_pooling=False, slot=1, pooling="mean")
+    assert rel(oi.cpu().numpy(), g["out.view_i_mean"]) < 2e-4
+
+    class Replay(torch.nn.Module):                                   # feed the views the reference drew
+        def __init__(self):
+            super().__init__()
+            self.k = 0
+
+        def forward(self, sequences, seq_lens):
+            v = views[self.k % 2]
+            self.k += 1
+            return v[0].to(dev), v[1].to(dev)
+    model.augmentation_model.augmentation = Replay()
+    model.optimizer.zero_grad()
+    loss = model.training_step(bd)
+    loss.backward()
+    assert abs(float(loss) - float(g["out.loss"])) < 3e-5
+    for n, prm in model.named_parameters():
+        ref = g["grad." + n]
+        assert rel(prm.grad.cpu().numpy(), ref) < 3e-4, n
+    model.optimizer.step()
+    for n, prm in model.named_parameters():
+        ref, gr = g["adam1." + n], g["grad." + n]
+        d = np.abs(prm.detach().cpu().numpy() - ref)
+        well = np.abs(gr) > 1e-5                                     # Adam is ill-conditioned where |g| ~ eps
+        assert d[well].max(initial=0) < 2e-5 and d.max() < 2.1e-3, n
+
+
+def test_cl4srec_fit_end_to_end(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    from dr4sr_amd import quickstart
+    out = quickstart.run(make_config(150, n_rows=300, batch=64, epochs=2, dropout=0.5))
+    assert {"ndcg@20", "recall@20"} <= set(out) and all(np.isfinite(v) for v in out.values())

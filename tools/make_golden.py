@@ -441,6 +441,97 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def run_cl_case(out_dir, name, n_items, seqlens, seed, augment_type="item_random"):
+    """CL4SRec (model/cl4srec.py:49-73): BCE + cl_weight * InfoNCE between two augmented views.  Dropout 0.  The augmentations are
+    random (torch / numpy / random streams): the views the reference drew are RECORDED and stored, so the deterministic part
+    (encoder on the views, mean pooling, length-1 filter, InfoNCE, total gradient) is pinned exactly; the augmentation
+    distributions are tested separately."""
+    import random
+    import torch
+    rng = np.random.default_rng(seed)
+    work = tempfile.mkdtemp(prefix="dr4sr_golden_")
+    cwd = os.getcwd()
+    try:
+        os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
+        build_dataset(work, n_items, seqlens, rng)
+        os.chdir(work)
+        from utils import load_config, setup_environment, prepare_datasets, prepare_model
+        config = load_config({"model": "CL4SRec", "dataset": "amazon-toys"})
+        config["train"]["device"] = "cpu"
+        config["data"]["train_file"] = "_ori"
+        config["model"]["dropout_rate"] = 0.0
+        config["model"]["augment_type"] = augment_type
+        setup_environment(config["train"])
+        torch.manual_seed(seed)
+        ds = prepare_datasets(config)
+        model = prepare_model(config, ds)
+        model._init_model(ds[0])
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if "item_embedding" in n or "item_encoder" in n:
+                    continue
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        out = {}
+        for k, v in model.state_dict().items():
+            out["param." + k] = v.detach().numpy().copy()
+        batch = next(iter(ds[0].get_loader(batch_size=len(ds[0]), shuffle=False)))
+        model.train()
+        torch.manual_seed(seed + 2)
+        random.seed(seed + 2)
+        np.random.seed(seed + 2)
+        batch["neg_item"] = model._neg_sampling(batch)
+        for k, v in batch.items():
+            out["batch." + k] = v.numpy()
+        views = []
+        real_aug = model.augmentation_model.augmentation
+
+        class Recorder(torch.nn.Module):
+            def forward(self, sequences, seq_lens):
+                s, l = real_aug(sequences, seq_lens)
+                full = torch.zeros_like(sequences)
+                full[:, :s.shape[1]] = s                      # Item_Crop pads to the longest crop only
+                views.append((full.clone(), l.clone()))
+                return s, l
+        model.augmentation_model.augmentation = Recorder()
+        model.optimizer.zero_grad()
+        loss = model.training_step(batch)
+        loss.backward()
+        (vi, li), (vj, lj) = views
+        out["view.i"], out["view.i_len"], out["view.j"], out["view.j_len"] = vi.numpy(), li.numpy(), vj.numpy(), lj.numpy()
+        out["out.loss"] = loss.detach().numpy()
+        for n, p in model.named_parameters():
+            out["grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+        with torch.no_grad():                                     # the contrastive term alone, on the recorded views
+            from module import functional as recfn
+            enc = model.query_encoder
+            oi = recfn.seq_pooling_function(enc({"in_item_id": vi, "seqlen": li}, need_pooling=False), li, pooling_type="mean")
+            oj = recfn.seq_pooling_function(enc({"in_item_id": vj, "seqlen": lj}, need_pooling=False), lj, pooling_type="mean")
+            keep = batch["seqlen"] != 1
+            out["out.view_i_mean"], out["out.view_j_mean"] = oi.numpy(), oj.numpy()
+            out["out.cl_loss"] = model.augmentation_model.InfoNCE_loss_fn(oi[keep], oj[keep]).numpy()
+            out["out.cl_loss_rows"] = model.augmentation_model.InfoNCE_loss_fn(oi[keep], oj[keep], reduce=False).numpy()
+            out["out.bce_loss"] = (loss.detach() - config["model"]["cl_weight"] * torch.from_numpy(out["out.cl_loss"])).numpy()
+        model.optimizer.step()
+        for n, p in model.named_parameters():
+            out["adam1." + n] = p.detach().numpy().copy()
+        mc = config["model"]
+        out["meta.num_items"] = np.int64(model.num_items)
+        for k in ("head_num", "hidden_size", "layer_num"):
+            out["meta." + k] = np.int64(mc[k])
+        for k in ("layer_norm_eps", "temperature", "cl_weight", "tau", "gamma", "beta"):
+            out["meta." + k] = np.float64(mc[k])
+        out["meta.augment_type"] = np.array(augment_type)
+        out["meta.lr"] = np.float64(config["train"]["learning_rate"])
+        os.chdir(cwd)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), loss={float(loss.detach()):.6f}, cl_loss={float(out['out.cl_loss']):.6f}")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def neg_sampler_stats(out_dir):
     """Pin the *distribution* of basemodel.py:50-61 (uniform on 1..N-1, never PAD)."""
     import torch
@@ -475,6 +566,9 @@ def main():
     sys.path.insert(0, REF)
     seqlens = [1, 2, 3, 5, 8, 13, 21, 34, 47, 49, 50, 4, 2, 50]
     only = os.environ.get("GOLDEN_ONLY")
+    if only == "cl":
+        run_cl_case(out_dir, "cl4srec_d64", n_items=173, seqlens=seqlens, seed=16)
+        return
     if only == "meta":
         run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
         return
@@ -488,6 +582,7 @@ def main():
              overrides={"model": {"hidden_size": 128}})
     run_case(out_dir, "fmlp_d64", "FMLP", n_items=113, seqlens=[1, 3, 6, 50, 2], embed_dim=64, seed=14)
     run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
+    run_cl_case(out_dir, "cl4srec_d64", n_items=173, seqlens=seqlens, seed=16)
     neg_sampler_stats(out_dir)
 
 
