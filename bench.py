@@ -147,6 +147,55 @@ def bench_metamodel(args):
         dist.destroy_process_group()
 
 
+def bench_cl4srec(args):
+    """CL4SRec on toys-shaped synthetic rows: BCE step + two augmented views + InfoNCE, API path (single GPU)."""
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    import logging
+    logging.getLogger("CDR").setLevel(logging.WARNING)
+    from dr4sr_amd.utils import load_config, prepare_datasets, prepare_model, seed_everything
+    cfg = load_config({"model": "CL4SRec", "dataset": "synthetic-toys"})
+    cfg["model"]["dropout_rate"] = args.dropout
+    cfg["train"].update({"device": str(dev), "batch_size": args.batch})
+    seed_everything(cfg["train"]["seed"])
+    ds = prepare_datasets(cfg)
+    model = prepare_model(cfg, ds)
+    model._init_model(ds[0])
+    model.train()
+    batches = []
+    for b in ds[0].get_loader():
+        if b["user_id"].shape[0] == args.batch:
+            batches.append(b)
+        if len(batches) == 16:
+            break
+
+    def step(i):
+        batch = dict(batches[i % len(batches)])
+        batch["neg_item"] = model._neg_sampling(batch)
+        model.optimizer.zero_grad()
+        loss = model.training_step(batch)
+        loss.backward()
+        model.optimizer.step()
+        return loss
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "training sequences/sec, CL4SRec d=64 L=50", "value": args.batch * args.steps / wall, "unit": "sequences/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CL4SRec (item_random augmentation, cl_weight 0.1) on amazon-toys-shaped synthetic rows, B=%d, dropout %.2f: "
+                               "three encoder passes + InfoNCE per step, eager API path" % (args.batch, args.dropout),
+                   "global_batch": args.batch, "seq_len": 50, "parallelism": "dp1", "hip_graph": False},
+        "final_loss": float(loss.detach())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +208,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
-    ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp", "metamodel"],
+    ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp", "metamodel", "cl4srec"],
                     help="sasrec = BASELINE headline (configs[1]); gru4rec = configs[2] (beauty-sized table, dropout 0.2, wd 1e-4); "
                          "fmlp = per-prefix left-padded rows, all B*L positions computed; metamodel = configs[4] (DR4SR+ around "
                          "SASRec: weighted inner steps + one hyper-gradient outer step every --interval steps)")
@@ -169,6 +218,8 @@ def main():
     args = ap.parse_args()
     if args.model == "metamodel":
         return bench_metamodel(args)
+    if args.model == "cl4srec":
+        return bench_cl4srec(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -22,4 +22,6 @@ timeout 300 python bench.py --batch 8192 --dense --no-cpu-baseline --steps 60 2>
 timeout 300 python bench.py --model gru4rec --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_gru4rec.json
 timeout 300 python bench.py --model fmlp --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fmlp.json
 timeout 300 python bench.py --model metamodel 2>/dev/null | tail -1 > $O/bench_metamodel.json
+timeout 300 python bench.py --model cl4srec 2>/dev/null | tail -1 > $O/bench_cl4srec.json
+timeout 300 python bench.py --embed-dim 128 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_sasrec_d128.json
 ls -la $O | tail -20
