@@ -103,6 +103,7 @@ SYMBOLS = {
     "dr4sr_score_bce_fwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_score_bce_bwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_neg_sample": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "dr4sr_neg_sample_dev": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "dr4sr_dropout_mask": (C.c_int, [_f32p, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
     "dr4sr_fmlp_plan_sizeof": (C.c_int, []),
     "dr4sr_fmlp_param_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -122,9 +123,9 @@ SYMBOLS = {
     "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_meta_param_count": (C.c_int64, [C.c_int32]),
     "dr4sr_meta_select_workspace_floats": (C.c_int64, [C.c_int64]),
-    "dr4sr_meta_select_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,
+    "dr4sr_meta_select_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,
                                         C.c_int32, C.c_void_p, C.c_void_p, _f32p, C.c_void_p]),
-    "dr4sr_meta_select_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,
+    "dr4sr_meta_select_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,
                                         C.c_int32, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_fd_step_size": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_float, _f32p, C.c_void_p]),
     "dr4sr_fd_shift": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),

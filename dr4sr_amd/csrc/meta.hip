@@ -34,11 +34,13 @@ struct SelArgs {
     float inv_tau;
     uint64_t seed;
     uint32_t step;
+    const int* step_dev;       // when non-null the Gumbel step is read from the device (graph replays draw fresh noise)
 };
 
 __device__ __forceinline__ float2 gumbel_pair(const SelArgs& A, int64_t p) {
     if (A.gumbel) return make_float2(A.gumbel[2 * p], A.gumbel[2 * p + 1]);
-    const uint4 r = philox4x32_10(make_uint4((uint32_t)p, (uint32_t)(p >> 32), 0x6D657461u, A.step),
+    const uint32_t step = A.step_dev ? (uint32_t)*A.step_dev : A.step;
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)p, (uint32_t)(p >> 32), 0x6D657461u, step),
                                   make_uint2((uint32_t)A.seed, (uint32_t)(A.seed >> 32)));
     // u in (0,1): (r + 0.5) / 2^32 ; torch: gumbel = -log(Exp(1)) = -log(-log(u))
     const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -284,7 +286,7 @@ extern "C" int64_t dr4sr_meta_param_count(int32_t D) { return D == MD ? N_PHI : 
 extern "C" int64_t dr4sr_meta_select_workspace_floats(int64_t n) { return (int64_t)sel_grid(n) * N_PHI; }
 
 extern "C" int dr4sr_meta_select_fwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step,
-                                     float tau, const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
+                                     const int32_t* step_dev, float tau, const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
                                      const uint64_t* gate_in, uint64_t* gate_out, float* weight, void* stream) {
     if (!query || !phi || !target || !weight || B < 0 || L <= 0 || !(tau > 0.f)) return DR4SR_E_ARG;
     if (D != MD) return DR4SR_E_SHAPE;
@@ -292,13 +294,13 @@ extern "C" int dr4sr_meta_select_fwd(const float* query, const float* phi, const
     if (n == 0) return 0;
     SelArgs A{};
     A.q = query; A.phi = phi; A.gumbel = gumbel; A.user_id = user_id; A.target = target; A.gate_in = gate_in; A.gate_out = gate_out;
-    A.weight = weight; A.n = n; A.L = L; A.inv_tau = 1.0f / tau; A.seed = seed; A.step = step;
+    A.weight = weight; A.n = n; A.L = L; A.inv_tau = 1.0f / tau; A.seed = seed; A.step = step; A.step_dev = step_dev;
     hipLaunchKernelGGL(k_meta_select_fwd, dim3(sel_grid(n)), dim3(SEL_WAVES * 64), 0, (hipStream_t)stream, A);
     return (int)hipGetLastError();
 }
 
 extern "C" int dr4sr_meta_select_bwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step,
-                                     float tau, const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
+                                     const int32_t* step_dev, float tau, const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
                                      const uint64_t* gate_in, const float* d_weight, const float* scale, float* d_query,
                                      float* d_phi, float* workspace, void* stream) {
     if (!query || !phi || !target || !d_weight || !d_phi || !workspace || B < 0 || L <= 0 || !(tau > 0.f)) return DR4SR_E_ARG;
@@ -308,7 +310,7 @@ extern "C" int dr4sr_meta_select_bwd(const float* query, const float* phi, const
     SelArgs A{};
     A.q = query; A.phi = phi; A.gumbel = gumbel; A.user_id = user_id; A.target = target; A.gate_in = gate_in;
     A.d_weight = d_weight; A.scale = scale; A.d_query = d_query; A.part = workspace; A.n = n; A.L = L; A.inv_tau = 1.0f / tau;
-    A.seed = seed; A.step = step;
+    A.seed = seed; A.step = step; A.step_dev = step_dev;
     const int g = sel_grid(n);
     hipLaunchKernelGGL(k_meta_select_bwd, dim3(g), dim3(SEL_WAVES * 64), 0, (hipStream_t)stream, A);
     hipLaunchKernelGGL(k_meta_reduce, dim3((N_PHI + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, g, d_phi);

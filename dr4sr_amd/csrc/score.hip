@@ -12,8 +12,8 @@
 #include "kernels.h"
 
 
-__global__ void k_neg_sample(int64_t* __restrict__ out, int64_t n, int n_items, uint64_t seed, uint32_t step) {
-    const RngKey rk = make_rng(seed, step, 0.f);
+__global__ void k_neg_sample(int64_t* __restrict__ out, int64_t n, int n_items, uint64_t seed, uint32_t step, const int* step_dev) {
+    const RngKey rk = make_rng(seed, step_dev ? (uint32_t)*step_dev : step, 0.f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = sample_neg_id(rk, (uint64_t)i, n_items);
 }
@@ -23,7 +23,15 @@ extern "C" int dr4sr_neg_sample(int64_t* out, int64_t n, int32_t n_items, uint64
     if (n == 0) return 0;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, n_items, seed, step);
+    hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, n_items, seed, step, nullptr);
+    return DR4SR_LAUNCH_CHECK();
+}
+extern "C" int dr4sr_neg_sample_dev(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, const int32_t* step_dev, void* stream) {
+    if (!out || !step_dev || n < 0 || n_items < 2) return DR4SR_E_ARG;
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, n_items, seed, 0u, step_dev);
     return DR4SR_LAUNCH_CHECK();
 }
 

@@ -106,6 +106,7 @@ class MetaModel(BaseModel):
         self.tau = nn.Parameter(torch.ones(1, device=self.device) * 10)
         self.counter = 0
         self._gumbel = None                           # explicit Gumbel noise [n,2] (tests); None = Philox in-kernel
+        self._tau_host = None
         self._bufs: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------ setup
@@ -158,7 +159,15 @@ class MetaModel(BaseModel):
         return self.dataset_list[0].get_loader()
 
     def _tau_eff(self) -> float:
-        return max(float(self.tau.detach()), float(self.config["model"]["tau_min"]))
+        """clip(tau, min=tau_min) (metamodel.py:171).  tau is a Parameter that no optimizer ever steps (it is not in aux_params,
+        metamodel.py:142), so its host copy is cached — no device->host read inside the step (or inside a graph capture)."""
+        if self._tau_host is None:
+            self._tau_host = max(float(self.tau.detach()), float(self.config["model"]["tau_min"]))
+        return self._tau_host
+
+    def load_state_dict(self, *args, **kwargs):
+        self._tau_host = None
+        return super().load_state_dict(*args, **kwargs)
 
     def _buf(self, name, n, dtype=torch.float32):
         t = self._bufs.get(name)
@@ -176,7 +185,7 @@ class MetaModel(BaseModel):
         B, L = self._bl(target)
         w = torch.empty(B * L, dtype=torch.float32, device=q.device)
         _lib.check(self.lib.dr4sr_meta_select_fwd(_lib.ptr(q), _lib.ptr(self._phi.params), _lib.ptr(gumbel), self.engine.seed,
-                                                  self.counter, self._tau_eff(), _lib.ptr(user_id), _lib.ptr(target.contiguous()),
+                                                  0, _lib.ptr(self._noise_step()), self._tau_eff(), _lib.ptr(user_id), _lib.ptr(target.contiguous()),
                                                   B, L, self.embed_dim, _lib.ptr(gate_in), _lib.ptr(gate_out), _lib.ptr(w),
                                                   _lib.cur_stream()), "dr4sr_meta_select_fwd")
         return w
@@ -187,10 +196,15 @@ class MetaModel(BaseModel):
         if self._sel_ws.numel() < need:
             self._sel_ws = torch.empty(need, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.dr4sr_meta_select_bwd(_lib.ptr(q), _lib.ptr(self._phi.params), _lib.ptr(gumbel), self.engine.seed,
-                                                  self.counter, self._tau_eff(), _lib.ptr(user_id), _lib.ptr(target.contiguous()),
+                                                  0, _lib.ptr(self._noise_step()), self._tau_eff(), _lib.ptr(user_id), _lib.ptr(target.contiguous()),
                                                   B, L, self.embed_dim, _lib.ptr(gate_in), _lib.ptr(d_weight), None,
                                                   _lib.ptr(d_query), _lib.ptr(self._phi.grads), _lib.ptr(self._sel_ws),
                                                   _lib.cur_stream()), "dr4sr_meta_select_bwd")
+
+    def _noise_step(self):
+        """device word keying the Gumbel noise: the sub-model engine's RNG step (bumped by every training forward), so that a
+        captured graph draws fresh noise per replay and the hyper-gradient probes (which restore that word) share one draw"""
+        return self.engine.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1]
 
     def selection(self, query):
         """metamodel.py:169-172 (no masks): weight in (0,1) per position"""
@@ -268,20 +282,78 @@ class MetaModel(BaseModel):
     def _train_batch(self, batch, nepoch):
         """one post-warm-up iteration of metamodel.py:101-120: weighted step, sub-model Adam, outer loop on the interval"""
         sub, eng = self.sub_model, self.engine
-        if batch["user_id"].shape[0] > 0:
-            batch["neg_item"] = self._neg_sampling(batch)
-            self._weighted_fwd_bwd(batch)
-        else:                                             # a rank whose slice of the tail batch is empty contributes zeros
-            eng.grads.zero_()
-            self._phi.grads.zero_()
+        bl = int(batch["user_id"].shape[0])
+        if bl > 0 and bool(self.config["train"].get("hip_graph", True)):
+            st, run = self._weighted_graph(batch)
+            for k in self._STATIC_KEYS:                    # the only per-step host work: four small copies + one graph replay
+                st[k].copy_(batch[k])
+            run()
+        else:
+            if bl > 0:
+                batch["neg_item"] = self._neg_sampling(batch)
+                self._weighted_fwd_bwd(batch)
+            else:                                          # a rank whose slice of the tail batch is empty contributes zeros
+                eng.grads.zero_()
+                self._phi.grads.zero_()
+            self._reduce_grads()
+            eng.adam_step(sub._api_plan())
         self.counter += 1
-        self._reduce_grads()
         loss = eng.grads[eng.n_params + 1] / eng.grads[eng.n_params]     # metamodel.py:186-194: sum_p w_p loss_p (loss_p is / n_valid)
-        eng.adam_step(sub._api_plan())
         self.step_counter += 1
         if self.step_counter % self.config["train"]["interval"] == 0:
             self._outter_loop(nepoch)
         return loss
+
+    _STATIC_KEYS = ("user_id", "in_item_id", "item_id", "seqlen")
+
+    def _weighted_graph(self, batch):
+        """captured HIP graph(s) of the weighted step on static copies of the batch tensors: negative sampling keyed by the engine's
+        device RNG step, weighted fwd/bwd, [all-reduce between two graphs], sub-model Adam"""
+        bl = int(batch["user_id"].shape[0])
+        key = (bl, tuple(batch["item_id"].shape[1:]))
+        if key in self._graphs:
+            return self._graphs[key]
+        sub, eng, lib = self.sub_model, self.engine, self.lib
+        st = {k: torch.empty_like(batch[k]) for k in self._STATIC_KEYS}
+        tgt = st["item_id"]
+        st["neg_item"] = torch.empty(*tgt.shape, 1, dtype=torch.int64, device=self.device)
+        for k in self._STATIC_KEYS:
+            st[k].copy_(batch[k])
+
+        def fwd_bwd():
+            _lib.check(lib.dr4sr_neg_sample_dev(_lib.ptr(st["neg_item"]), tgt.numel(), self.num_items, eng.seed ^ 0x5DEECE66D,
+                                                _lib.ptr(self._noise_step()), _lib.cur_stream()), "neg_sample_dev")
+            self._weighted_fwd_bwd(st)
+
+        def adam():
+            eng.adam_step(sub._api_plan())
+        undo = [eng.params, eng.adam_m, eng.adam_v, eng.state]
+        snap = [t.clone() for t in undo]
+        fwd_bwd()                                          # warm-up outside capture (allocates the persistent scratch buffers)
+        self._reduce_grads()
+        adam()
+        torch.cuda.synchronize()
+        for dst, src in zip(undo, snap):
+            dst.copy_(src)
+        if self.world_size == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fwd_bwd()
+                adam()
+            run = g.replay
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                fwd_bwd()
+            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                adam()
+
+            def run():
+                ga.replay()
+                self._reduce_grads()
+                gb.replay()
+        self._graphs[key] = (st, run)
+        return self._graphs[key]
 
     def _neg_sampling(self, batch):
         return self.sub_model._neg_sampling(batch)

@@ -164,6 +164,8 @@ int dr4sr_score_bce_bwd(const float* query, const float* E, const int64_t* targe
  * out [n] int64.  Stream (seed, step) is the one dr4sr_sasrec_fwd_bwd uses for sample_neg=1. */
 int dr4sr_neg_sample(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, uint32_t step,
                      void* stream);
+/* the same with the step read from a device word at run time (graph replays) */
+int dr4sr_neg_sample_dev(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, const int32_t* step_dev, void* stream);
 
 /* Materialise the keep-mask (1.0 / 0.0) the kernels use for (seed, step, site) over n elements
  * (n multiple of 4).  Test hook: lets the oracle run with the library's exact dropout masks. */
@@ -263,7 +265,8 @@ int dr4sr_gru4rec_encode_bwd(const dr4sr_gru4rec_plan* plan, int32_t training, i
  * dr4sr_meta_select_fwd — MetaModel.selection + the two masks of training_step (metamodel.py:169-185):
  *   weight[p] = softmax((meta_module(query[p]) + gumbel[p]) / tau)[0];  1 where user_id[p / L] == 0;  0 where target[p] == 0.
  *   n = B*L positions (L = 1 for scalar-target models).  gumbel [n,2] explicit noise, or NULL: drawn in-kernel from Philox
- *   (seed, step) as -log(-log(u)) like F.gumbel_softmax.  tau = clip(tau, tau_min) is passed by the caller.
+ *   (seed, step) as -log(-log(u)) like F.gumbel_softmax; step_dev != NULL: the step is *step_dev (a device word such as the plan's
+ *   state[RNGSTEP], so that a captured graph draws fresh noise on every replay).  tau = clip(tau, tau_min) is passed by the caller.
  *   gate_in  [n] (NULL = off): a FROZEN ReLU pattern (bit j = unit j active) used instead of (pre > 0);
  *   gate_out [n] (NULL = off): the pattern this call used.
  * dr4sr_meta_select_bwd — backward of the above for upstream d_weight[n] (times *scale if scale != NULL):
@@ -271,10 +274,12 @@ int dr4sr_gru4rec_encode_bwd(const dr4sr_gru4rec_plan* plan, int32_t training, i
  *   dr4sr_meta_select_workspace_floats(n) floats, summed in a fixed order). */
 int64_t dr4sr_meta_param_count(int32_t D);
 int64_t dr4sr_meta_select_workspace_floats(int64_t n);
-int dr4sr_meta_select_fwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step, float tau,
+int dr4sr_meta_select_fwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step,
+                          const int32_t* step_dev, float tau,
                           const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
                           const uint64_t* gate_in, uint64_t* gate_out, float* weight, void* stream);
-int dr4sr_meta_select_bwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step, float tau,
+int dr4sr_meta_select_bwd(const float* query, const float* phi, const float* gumbel, uint64_t seed, uint32_t step,
+                          const int32_t* step_dev, float tau,
                           const int64_t* user_id, const int64_t* target, int64_t B, int32_t L, int32_t D,
                           const uint64_t* gate_in, const float* d_weight, const float* scale, float* d_query, float* d_phi,
                           float* workspace, void* stream);

@@ -87,14 +87,14 @@ def test_select_kernels_match_oracle():
     w = torch.empty(B * L, device="cuda")
     gate = torch.zeros(B * L, dtype=torch.int64, device="cuda")
     st = _lib.cur_stream()
-    _lib.check(lib.dr4sr_meta_select_fwd(_lib.ptr(qd), _lib.ptr(phi), _lib.ptr(gd), 1, 0, tau, _lib.ptr(ud), _lib.ptr(td), B, L, D,
+    _lib.check(lib.dr4sr_meta_select_fwd(_lib.ptr(qd), _lib.ptr(phi), _lib.ptr(gd), 1, 0, None, tau, _lib.ptr(ud), _lib.ptr(td), B, L, D,
                                          None, _lib.ptr(gate), _lib.ptr(w), st), "fwd")
     np.testing.assert_allclose(w.cpu().numpy().reshape(B, L), w_ref.detach().numpy(), rtol=2e-5, atol=1e-6)
     dq = torch.zeros(B, L, D, device="cuda")
     dphi = torch.zeros(nphi, device="cuda")
     ws = torch.empty(int(lib.dr4sr_meta_select_workspace_floats(B * L)), device="cuda")
     for _ in range(2):                                   # accumulating semantics: two calls = twice the gradient
-        _lib.check(lib.dr4sr_meta_select_bwd(_lib.ptr(qd), _lib.ptr(phi), _lib.ptr(gd), 1, 0, tau, _lib.ptr(ud), _lib.ptr(td), B, L, D,
+        _lib.check(lib.dr4sr_meta_select_bwd(_lib.ptr(qd), _lib.ptr(phi), _lib.ptr(gd), 1, 0, None, tau, _lib.ptr(ud), _lib.ptr(td), B, L, D,
                                              None, _lib.ptr(upd), None, _lib.ptr(dq), _lib.ptr(dphi), _lib.ptr(ws), st), "bwd")
     assert rel(dq.cpu().numpy() / 2, qo.grad.numpy()) < 1e-5
     ref_phi = torch.cat([mo[k].grad.reshape(-1) for k in NAMES]).numpy()
@@ -106,15 +106,20 @@ def test_select_kernels_match_oracle():
     assert torch.equal(bits[valid].bool(), pre[valid])
     q2 = q + 0.05 * torch.randn_like(q)
     w2 = torch.empty(B * L, device="cuda")
-    _lib.check(lib.dr4sr_meta_select_fwd(_lib.ptr(q2.cuda()), _lib.ptr(phi), _lib.ptr(gd), 1, 0, tau, _lib.ptr(ud), _lib.ptr(td), B, L,
+    _lib.check(lib.dr4sr_meta_select_fwd(_lib.ptr(q2.cuda()), _lib.ptr(phi), _lib.ptr(gd), 1, 0, None, tau, _lib.ptr(ud), _lib.ptr(td), B, L,
                                          D, _lib.ptr(gate), None, _lib.ptr(w2), st), "fwd frozen")
     w2_ref = MO.mask_weight(MO.selection(q2, meta, gum, tau, 1.0, relu_gate=pre.float()), uid, tgt)
     np.testing.assert_allclose(w2.cpu().numpy().reshape(B, L), w2_ref.numpy(), rtol=2e-5, atol=1e-6)
     # in-kernel Gumbel noise: weights in (0,1), reproducible per (seed, step), different across steps
     wa, wb, wc = (torch.empty(B * L, device="cuda") for _ in range(3))
     for out, step in ((wa, 7), (wb, 7), (wc, 8)):
-        _lib.check(lib.dr4sr_meta_select_fwd(_lib.ptr(qd), _lib.ptr(phi), None, 11, step, tau, None, _lib.ptr(td), B, L, D, None, None,
+        _lib.check(lib.dr4sr_meta_select_fwd(_lib.ptr(qd), _lib.ptr(phi), None, 11, step, None, tau, None, _lib.ptr(td), B, L, D, None, None,
                                              _lib.ptr(out), st), "fwd philox")
+    wd = torch.empty(B * L, device="cuda")                     # the step read from a device word (graph replays)
+    sdev = torch.tensor([8], dtype=torch.int32, device="cuda")
+    _lib.check(lib.dr4sr_meta_select_fwd(_lib.ptr(qd), _lib.ptr(phi), None, 11, 0, _lib.ptr(sdev), tau, None, _lib.ptr(td), B, L, D, None,
+                                         None, _lib.ptr(wd), st), "fwd philox dev step")
+    assert torch.equal(wd, wc)
     v = valid.reshape(-1).cuda()
     assert torch.equal(wa, wb) and not torch.equal(wa, wc)
     assert float(wa[v].min()) > 0 and float(wa[v].max()) < 1 and float(wa[~v].abs().max()) == 0
