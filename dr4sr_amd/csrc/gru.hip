@@ -21,6 +21,12 @@ extern __shared__ __attribute__((aligned(16))) float smem[];
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 #define GRU_MAX_LAYERS 4
 
+// gru_coop.hip: multi-CU cooperative recurrence for small batches
+int64_t gru_coop_words(int B, int H);
+int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float* r, float* z, float* n, float* ghn, float* hprev,
+                        float* hout, const float* dhout, float* dgi, float* dgh, unsigned long long* xch, int* ctl, int B, int H, bool bwd,
+                        hipStream_t s);
+
 struct GruLayerWs {
     float* gi; float* r; float* z; float* n; float* ghn; float* hprev; float* hout;
     float* dgi; float* dgh;
@@ -31,6 +37,7 @@ struct GruWs {
     int* cu;
     float* X0; float* dX0; float* Y; float* dY; float* dH;     // dH: grad w.r.t. a layer's output rows [T,H]
     float* score_part;
+    unsigned long long* xch; int* ctl;                        // cooperative recurrence (gru_coop.hip): granule area, control words
     GruLayerWs layer[GRU_MAX_LAYERS];
     int64_t bytes;
 };
@@ -74,6 +81,9 @@ static void gru_carve(const dr4sr_gru4rec_plan* p, GruWs* ws) {
         o += ((nfloat * 4 + 255) / 256) * 256;
         return r;
     };
+    // control words and granules FIRST: their offsets must not move with B (they hold state that survives across calls)
+    ws->ctl = (int*)take(4);
+    { const int64_t words = gru_coop_words(p->B, p->H); ws->xch = words ? (unsigned long long*)take(2 * words) : nullptr; }
     ws->cu = (int*)take(p->B + 1);
     ws->X0 = take(Tmax * D); ws->dX0 = take(Tmax * D); ws->Y = take(Tmax * D); ws->dY = take(Tmax * D); ws->dH = take(Tmax * H);
     ws->score_part = take(2LL * p->B);
@@ -402,7 +412,12 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruRecArgs A) {
     }
 }
 
-static int launch_gru_rec(const GruRecArgs& A, int H, bool bwd, hipStream_t s) {
+static int launch_gru_rec(const GruRecArgs& A, int H, bool bwd, hipStream_t s, unsigned long long* xch = nullptr, int* ctl = nullptr) {
+    {   // small batches: 8 CUs per group of 16 sequences, W_hh slices resident in LDS, per-step exchange inside the launch
+        const int rc = launch_gru_rec_coop(A.gi, A.whh, A.cu, A.r, A.z, A.n, A.ghn, A.hprev, A.hout, A.dhout, A.dgi, A.dgh, xch, ctl, A.B, H,
+                                           bwd, s);
+        if (rc != -100) return rc;
+    }
     dim3 grid((A.B + 15) / 16), blk(512);
     if (!bwd) {
         const size_t lds = sizeof(float) * 2 * 16 * (H + 4) + 32 * sizeof(int);
@@ -445,7 +460,7 @@ static int gru_forward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int trainin
         GruRecArgs A{};
         A.gi = w.gi; A.whh = p->params + ws.off_whh[l]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn;
         A.hprev = w.hprev; A.hout = w.hout; A.B = p->B;
-        RC(launch_gru_rec(A, H, false, s));
+        RC(launch_gru_rec(A, H, false, s, ws.xch, ws.ctl));
         in = w.hout;
         K = H;
     }
@@ -461,7 +476,7 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
         GruRecArgs A{};
         A.whh = p->params + ws.off_whh[l]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn; A.hprev = w.hprev;
         A.dhout = ws.dH; A.dgi = w.dgi; A.dgh = w.dgh; A.B = p->B;
-        RC(launch_gru_rec(A, H, true, s));
+        RC(launch_gru_rec(A, H, true, s, ws.xch, ws.ctl));
         // d(input of this layer) = dgi W_ih
         if (l > 0) RC(launch_gemm(w.dgi, 3 * H, p->params + ws.off_wih[l], H, nullptr, ws.dH, H, 3 * H, H, true, ws.Tmax, p->state, s));
         else RC(launch_gemm(w.dgi, 3 * H, p->params + ws.off_wih[0], D, nullptr, ws.dX0, D, 3 * H, D, true, ws.Tmax, p->state, s));

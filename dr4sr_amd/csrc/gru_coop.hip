@@ -1,0 +1,279 @@
+// gru_coop.hip — multi-CU cooperative GRU recurrence for SMALL batches (B <= 384): latency instead of throughput.
+//
+// The single-workgroup recurrence of gru.hip (16 sequences per workgroup, W_hh streamed from L2) is bound by one CU's fp32
+// MFMA pipe: 6.3 MFLOP per time step = ~11 us, and a B = 256 batch occupies 16 of the 256 CUs.  Here a group of 16 sequences
+// is spread over NS = 8 workgroups (8 CUs): slice s owns hidden units [s*H/8, (s+1)*H/8) of all three gates, keeps its
+// 3*H/8 rows of W_hh RESIDENT in LDS for the whole launch (98 KB at H = 256) and needs 1/8 of the MFMA work per step; the
+// price is one all-gather of h_t (forward) / one reduce-scatter of the dh partials (backward) per time step between the 8
+// workgroups of a group, INSIDE the launch.
+//
+// Exchange protocol (cdna_hip_programming.md §6 Guideline 16, form R2 "the data is the flag"): every exchanged float travels
+// as ONE aligned 8-byte granule {tag, value} written with a relaxed agent-scope store (sc1, write-through) and polled with
+// relaxed agent-scope loads until the tag matches this step's epoch — no fences, no separate flags, correct for any
+// placement of the workgroups over XCDs.  Two granule buffers alternate by step parity (a slice can only produce step t+2
+// after every slice has consumed step t).  Epochs are unique across launches: epoch = 64 * launch_counter + step + 1 with the
+// launch counter kept in a device word that the last workgroup to finish increments, so nothing has to be re-zeroed per call
+// (the exchange area must be zero once, when the workspace is created).  All 8*ceil(B/16) workgroups must be co-resident
+// (one per CU, ~140 KB LDS): the launcher only takes this path when they fit with margin; spins are bounded and a timeout
+// raises a device error word instead of hanging.
+#include "common.h"
+#include "kernels.h"
+
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+namespace {
+
+constexpr int NS = 8;                           // slices (workgroups) per group of 16 sequences
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+typedef unsigned long long u64;
+
+struct CoopArgs {
+    const float* gi; const float* whh; const int* cu;
+    float* r; float* z; float* n; float* ghn; float* hprev; float* hout;          // saved per token [T,H]
+    const float* dhout; float* dgi; float* dgh;                                   // backward
+    u64* xch;                    // granules: fwd [grp][2][16][H] | bwd [grp][2][NS][16][H]
+    int* ctl;                    // [0] launch counter, [1] finish ticket, [2] error word
+    int B;
+};
+
+__device__ __forceinline__ f32x4 mfma16c(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { const float e = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - e) / (1.0f + e), x); }
+
+__device__ __forceinline__ void put_granule(u64* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// poll until the tag matches (bounded; a timeout anywhere releases everybody through the error word)
+__device__ __forceinline__ float get_granule(const u64* g, unsigned tag, int* err) {
+    unsigned spins = 0;
+    for (;;) {
+        const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
+        if ((++spins & 1023u) == 0) {
+            if (spins >= SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0.f;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+__device__ __forceinline__ void finish_launch(int* ctl) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(&ctl[1], 1);
+        if (t == (int)gridDim.x - 1) { ctl[1] = 0; ctl[0] += 1; }          // visible to the next launch (kernel boundary)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int H>
+__global__ __launch_bounds__(H * 2) void k_gru_fwd_coop(const CoopArgs A) {
+    constexpr int US = H / NS, UTL = US / 16, NW = UTL * 4, NT = NW * 64, LDW = H + 4, LDH = H + 4;
+    static_assert(NT == H * 2, "thread count");
+    float* Ws = smem;                                     // [3*US][LDW]  this slice's rows of W_hh (gate-major)
+    float* hA = Ws + 3 * US * LDW;                        // [16][LDH]    h_{t-1} of the group's 16 sequences
+    float* part = hA + 16 * LDH;                          // [4 kq][3][16][US]
+    int* meta = reinterpret_cast<int*>(part + 4 * 3 * 16 * US);       // [16] t0, [16] n
+    const int grp = blockIdx.x / NS, sl = blockIdx.x % NS, b0 = grp * 16;
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    for (int i = threadIdx.x; i < 3 * US * (H / 4); i += NT) {
+        const int lr = i / (H / 4), c = (i % (H / 4)) * 4, gate = lr / US, u = lr % US;
+        st4(Ws + lr * LDW + c, ld4(A.whh + (size_t)(gate * H + sl * US + u) * H + c));
+    }
+    for (int i = threadIdx.x; i < 16 * LDH; i += NT) hA[i] = 0.f;
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const unsigned base = (unsigned)A.ctl[0] * 64u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const int ct = w >> 2, kq = w & 3;                    // wave = (unit tile, K quarter)
+    // element owned by this thread in the gate math: (sequence es, unit eu of the slice)
+    const bool own = (int)threadIdx.x < 16 * US;
+    const int es = own ? threadIdx.x / US : 0, eu = own ? threadIdx.x % US : 0;
+    const int tq = meta[es], nq = own ? meta[16 + es] : 0, gu = sl * US + eu;     // global unit
+    float hown = 0.f;
+    u64* xg = A.xch + (size_t)grp * 2 * 16 * H;
+    for (int t = 0; t < nmax; ++t) {
+        const bool act = t < nq;
+        float gir = 0.f, giz = 0.f, gin = 0.f;
+        if (act) { const float* gip = A.gi + (size_t)(tq + t) * 3 * H + gu; gir = gip[0]; giz = gip[H]; gin = gip[2 * H]; }
+        // gh partial over this wave's K quarter for its 16 units, all three gates
+        f32x4 acc[3];
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* ar = hA + l16 * LDH + kq * (H / 4) + g * (H / 16);
+        const float* br = Ws + (ct * 16 + l16) * LDW + kq * (H / 4) + g * (H / 16);
+#pragma unroll
+        for (int c = 0; c < H / 16; c += 4) {
+            const float4 a = ld4(ar + c);
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) {
+                const float4 b = ld4(br + q3 * US * LDW + c);
+                acc[q3] = mfma16c(a.x, b.x, acc[q3]); acc[q3] = mfma16c(a.y, b.y, acc[q3]);
+                acc[q3] = mfma16c(a.z, b.z, acc[q3]); acc[q3] = mfma16c(a.w, b.w, acc[q3]);
+            }
+        }
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[((kq * 3 + q3) * 16 + 4 * g + r) * US + ct * 16 + l16] = acc[q3][r];
+        __syncthreads();
+        if (own) {
+            float gh[3];
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) {
+                const float* pp = part + (q3 * 16 + es) * US + eu;
+                gh[q3] = (pp[0] + pp[3 * 16 * US]) + (pp[2 * 3 * 16 * US] + pp[3 * 3 * 16 * US]);
+            }
+            if (act) {
+                const float rr = sigm(gir + gh[0]), zz = sigm(giz + gh[1]), nn = tanh_f(gin + rr * gh[2]);
+                const float hnew = (1.0f - zz) * nn + zz * hown;
+                const size_t o = (size_t)(tq + t) * H + gu;
+                A.r[o] = rr; A.z[o] = zz; A.n[o] = nn; A.ghn[o] = gh[2]; A.hprev[o] = hown; A.hout[o] = hnew;
+                hown = hnew;
+            }
+            if (t + 1 < nmax) put_granule(xg + ((size_t)(t & 1) * 16 + es) * H + gu, base + t + 1, hown);
+        }
+        if (t + 1 < nmax) {                                // all-gather h_t of the 8 slices into the A operand tile
+            const u64* src = xg + (size_t)(t & 1) * 16 * H;
+            for (int i = threadIdx.x; i < 16 * H; i += NT) hA[(i / H) * LDH + (i % H)] = get_granule(src + i, base + t + 1, A.ctl + 2);
+        }
+        __syncthreads();
+    }
+    finish_launch(A.ctl);
+}
+
+// ------------------------------------------------------------------------------------------------ backward (BPTT)
+// Per step (t descending): dh = dhout[t] + carry for the slice's own units; gate derivatives -> the slice's dgh tile [16][3*US]
+// (LDS) and dgi/dgh rows (global); partial[16][H] = dgh_tile . W_hh[slice rows][:] on MFMA (W rows read column-wise);
+// reduce-scatter over the 8 slices: carry'[own units] = dh*z + sum_slices partial[:, own units].
+template <int H>
+__global__ __launch_bounds__(H * 2) void k_gru_bwd_coop(const CoopArgs A) {
+    constexpr int US = H / NS, UTL = US / 16, NW = UTL * 4, NT = NW * 64, LDW = H + 4, KL = 3 * US, LDG = KL + 4;
+    constexpr int CTW = (H / 16) / NW;                    // output column tiles per wave
+    float* Ws = smem;                                     // [3*US][LDW]
+    float* dgl = Ws + 3 * US * LDW;                       // [16][LDG]  dgh tile of this slice (A operand)
+    int* meta = reinterpret_cast<int*>(dgl + 16 * LDG);
+    const int grp = blockIdx.x / NS, sl = blockIdx.x % NS, b0 = grp * 16;
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    for (int i = threadIdx.x; i < 3 * US * (H / 4); i += NT) {
+        const int lr = i / (H / 4), c = (i % (H / 4)) * 4, gate = lr / US, u = lr % US;
+        st4(Ws + lr * LDW + c, ld4(A.whh + (size_t)(gate * H + sl * US + u) * H + c));
+    }
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const unsigned base = (unsigned)A.ctl[0] * 64u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const bool own = (int)threadIdx.x < 16 * US;
+    const int es = own ? threadIdx.x / US : 0, eu = own ? threadIdx.x % US : 0;
+    const int tq = meta[es], nq = own ? meta[16 + es] : 0, gu = sl * US + eu;
+    float carry = 0.f;
+    u64* xg = A.xch + (size_t)grp * 2 * NS * 16 * H;
+    float sv[6];
+    auto load_saved = [&](int t) {
+        const bool a = own && t >= 0 && t < nq;
+        const size_t o = (size_t)(tq + (a ? t : 0)) * H + gu;
+        sv[0] = a ? A.dhout[o] : 0.f; sv[1] = a ? A.r[o] : 0.f; sv[2] = a ? A.z[o] : 0.f;
+        sv[3] = a ? A.n[o] : 0.f; sv[4] = a ? A.ghn[o] : 0.f; sv[5] = a ? A.hprev[o] : 0.f;
+    };
+    load_saved(nmax - 1);
+    for (int t = nmax - 1; t >= 0; --t) {
+        const unsigned tag = base + (unsigned)(nmax - 1 - t) + 1u;
+        const int par = (nmax - 1 - t) & 1;
+        float keep = 0.f;
+        if (own) {
+            float dr = 0.f, dz = 0.f, dnr = 0.f;
+            if (t < nq) {
+                const float dh = sv[0] + carry, rr = sv[1], zz = sv[2], nn = sv[3], gh = sv[4], hp = sv[5];
+                const float dn = dh * (1.0f - zz) * (1.0f - nn * nn);
+                dz = dh * (hp - nn) * zz * (1.0f - zz);
+                dr = dn * gh * rr * (1.0f - rr);
+                dnr = dn * rr;
+                keep = dh * zz;
+                float* gp = A.dgi + (size_t)(tq + t) * 3 * H + gu;
+                gp[0] = dr; gp[H] = dz; gp[2 * H] = dn;
+                float* hp2 = A.dgh + (size_t)(tq + t) * 3 * H + gu;
+                hp2[0] = dr; hp2[H] = dz; hp2[2 * H] = dnr;
+            }
+            float* row = dgl + es * LDG + eu;
+            row[0] = dr; row[US] = dz; row[2 * US] = dnr;
+        }
+        __syncthreads();
+        load_saved(t - 1);
+        if (t > 0) {
+            // partial[16][H] = dgl[16][KL] . Ws[KL][H]   (B[k = local row][n = column] read column-wise)
+            const float* ar = dgl + l16 * LDG + g * (KL / 4);
+#pragma unroll
+            for (int ci = 0; ci < CTW; ++ci) {
+                const int col = (w * CTW + ci) * 16 + l16;
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* wc = Ws + (size_t)(g * (KL / 4)) * LDW + col;
+#pragma unroll
+                for (int c = 0; c < KL / 4; c += 4) {
+                    const float4 a = ld4(ar + c);
+                    acc = mfma16c(a.x, wc[(c + 0) * LDW], acc); acc = mfma16c(a.y, wc[(c + 1) * LDW], acc);
+                    acc = mfma16c(a.z, wc[(c + 2) * LDW], acc); acc = mfma16c(a.w, wc[(c + 3) * LDW], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    put_granule(xg + (((size_t)par * NS + sl) * 16 + 4 * g + r) * H + col, tag, acc[r]);
+            }
+            if (own) {                                     // reduce-scatter: the 8 partials of this thread's (sequence, unit)
+                float s = keep;
+#pragma unroll
+                for (int src = 0; src < NS; ++src)
+                    s += get_granule(xg + (((size_t)par * NS + src) * 16 + es) * H + gu, tag, A.ctl + 2);
+                carry = s;
+            }
+        }
+        __syncthreads();
+    }
+    finish_launch(A.ctl);
+}
+
+template <int H> size_t coop_lds(bool bwd) {
+    constexpr int US = H / NS;
+    return sizeof(float) * (3 * US * (H + 4) + (bwd ? 16 * (3 * US + 4) : 16 * (H + 4) + 4 * 3 * 16 * US)) + 32 * sizeof(int);
+}
+
+}  // namespace
+
+// granule words needed by the cooperative path for a batch of B sequences (0 = the batch does not qualify)
+int64_t gru_coop_words(int B, int H) {
+    const int groups = (B + 15) / 16;
+    if (groups * NS > 192 || getenv("DR4SR_GRU_NOCOOP")) return 0;
+    return (int64_t)groups * 2 * NS * 16 * H;
+}
+
+// returns -100 when the batch does not qualify (caller falls back to the single-workgroup recurrence)
+int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float* r, float* z, float* n, float* ghn, float* hprev,
+                        float* hout, const float* dhout, float* dgi, float* dgh, unsigned long long* xch, int* ctl, int B, int H, bool bwd,
+                        hipStream_t s) {
+    if (!xch || !ctl || gru_coop_words(B, H) == 0) return -100;
+    CoopArgs A;
+    A.gi = gi; A.whh = whh; A.cu = cu; A.r = r; A.z = z; A.n = n; A.ghn = ghn; A.hprev = hprev; A.hout = hout;
+    A.dhout = dhout; A.dgi = dgi; A.dgh = dgh; A.xch = xch; A.ctl = ctl; A.B = B;
+    dim3 grid(((B + 15) / 16) * NS), blk(H * 2);
+    if (H == 256) {
+        const size_t lds = coop_lds<256>(bwd);
+        if (!bwd) { big_lds(k_gru_fwd_coop<256>, lds); hipLaunchKernelGGL(k_gru_fwd_coop<256>, grid, blk, lds, s, A); }
+        else { big_lds(k_gru_bwd_coop<256>, lds); hipLaunchKernelGGL(k_gru_bwd_coop<256>, grid, blk, lds, s, A); }
+    } else if (H == 128) {
+        const size_t lds = coop_lds<128>(bwd);
+        if (!bwd) { big_lds(k_gru_fwd_coop<128>, lds); hipLaunchKernelGGL(k_gru_fwd_coop<128>, grid, blk, lds, s, A); }
+        else { big_lds(k_gru_bwd_coop<128>, lds); hipLaunchKernelGGL(k_gru_bwd_coop<128>, grid, blk, lds, s, A); }
+    } else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}

@@ -60,7 +60,8 @@ class GruEngine:
         self.ws_bytes = int(self.lib.dr4sr_gru4rec_workspace_bytes(C.byref(probe)))
         if self.ws_bytes <= 0:
             raise _lib.Dr4srError(f"gru4rec workspace_bytes failed ({self.ws_bytes})")
-        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)     # zero ONCE: the cooperative recurrence's
+        #                                                                               granule tags / launch counter live in it
         self.neg_scratch = torch.zeros(max_batch * L, dtype=torch.int64, device=dev)
 
     def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True):

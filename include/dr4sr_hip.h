@@ -250,6 +250,9 @@ typedef struct dr4sr_gru4rec_plan {
 int     dr4sr_gru4rec_plan_sizeof(void);
 /* offsets[0]=E, [1+2l]=weight_ih_l, [2+2l]=weight_hh_l, [1+2n]=out_w, [2+2n]=out_b; returns n_params */
 int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_t H, int32_t n_layer, int64_t* offsets);
+/* The workspace must be ZERO-initialised once by the caller (hipMemset at allocation): for small batches (8*ceil(B/16) <= 192
+ * workgroups) the recurrences run cooperatively over 8 CUs per 16 sequences and keep their exchange granules and a launch counter
+ * there (csrc/gru_coop.hip); `DR4SR_GRU_NOCOOP=1` forces the single-workgroup recurrence. */
 int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan);
 int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream);       /* basemodel.py:193-198, un-normalised grads */
 int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream);    /* + dense Adam */
