@@ -146,10 +146,37 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     }
 }
 
+
+// Latency variant of the data-gradient GEMM for small batches: C[T x N] = A[T x K] * W (W [K][ldw] read column-wise), 16-row
+// tiles (v_mfma_f32_16x16x4) with the whole K of the A tile in LDS, 64 output columns per workgroup: T/16 x N/64 workgroups
+// instead of T/64 x N/128 — the K = 3H = 768 gradients dgi W_ih otherwise run on ~40 workgroups for ~100 us each.
+template <int K>
+__global__ __launch_bounds__(256) void k_gemm16_col(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                    float* __restrict__ C, int ldc, const int* __restrict__ state) {
+    constexpr int LDA = K + 4;
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 16;
+    if (t0 >= T) return;
+    const int n0 = blockIdx.y * 64;
+    float* As = smem;                                   // [16][LDA]
+    load_tile_bm<16, K>(As, LDA, A, lda, t0, T);
+    lds_barrier();
+    TileAcc<16, 64> acc;
+    tile_zero(acc);
+    tile_mma_xw<16, K, 64>(As, LDA, W + n0, ldw, acc);
+    tile_to_global<16, 64>(acc, C + n0, ldc, nullptr, t0, T);
+}
+
 static int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K, int N,
                        bool colmode, int Tmax, const int* state, hipStream_t s) {
     const size_t lds = sizeof(float) * 64 * 68;
     dim3 blk(256);
+    if (colmode && !bias && Tmax <= 16384 && (K == 768 || K == 384) && N % 64 == 0) {      // small batch, K = 3H: latency tiles
+        const size_t l16 = sizeof(float) * 16 * (K + 4);
+        dim3 grid((Tmax + 15) / 16, N / 64);
+        if (K == 768) { big_lds(k_gemm16_col<768>, l16); hipLaunchKernelGGL(k_gemm16_col<768>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
+        else { big_lds(k_gemm16_col<384>, l16); hipLaunchKernelGGL(k_gemm16_col<384>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
+        return DR4SR_LAUNCH_CHECK();
+    }
     if (N % 128 == 0) {
         dim3 grid((Tmax + 63) / 64, N / 128);
         if (colmode) hipLaunchKernelGGL((k_gemm<2, true>), grid, blk, lds, s, A, lda, W, ldw, bias, C, ldc, K, state);
