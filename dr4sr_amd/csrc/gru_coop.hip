@@ -58,6 +58,28 @@ __device__ __forceinline__ float get_granule(const u64* g, unsigned tag, int* er
     }
 }
 
+// all N granules of a lane are requested together and re-read every pass until every tag matches (the guide's sweep): one L2
+// round trip per pass instead of one per granule
+template <int N>
+__device__ __forceinline__ void sweep_granules(const u64* g, int stride, unsigned tag, float (&v)[N], int* err) {
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const u64 x = __hip_atomic_load(g + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = __uint_as_float((unsigned)x);
+            ok &= (unsigned)(x >> 32) == tag;
+        }
+        if (ok) return;
+        if ((++spins & 255u) == 0) {
+            if (spins >= SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
 __device__ __forceinline__ void finish_launch(int* ctl) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -142,7 +164,10 @@ __global__ __launch_bounds__(H * 2) void k_gru_fwd_coop(const CoopArgs A) {
         }
         if (t + 1 < nmax) {                                // all-gather h_t of the 8 slices into the A operand tile
             const u64* src = xg + (size_t)(t & 1) * 16 * H;
-            for (int i = threadIdx.x; i < 16 * H; i += NT) hA[(i / H) * LDH + (i % H)] = get_granule(src + i, base + t + 1, A.ctl + 2);
+            float hv[(16 * H) / NT];                       // 8 granules per thread, stride NT
+            sweep_granules<(16 * H) / NT>(src + threadIdx.x, NT, base + t + 1, hv, A.ctl + 2);
+#pragma unroll
+            for (int k = 0; k < (16 * H) / NT; ++k) { const int i = threadIdx.x + k * NT; hA[(i / H) * LDH + (i % H)] = hv[k]; }
         }
         __syncthreads();
     }
@@ -231,10 +256,11 @@ __global__ __launch_bounds__(H * 2) void k_gru_bwd_coop(const CoopArgs A) {
                     put_granule(xg + (((size_t)par * NS + sl) * 16 + 4 * g + r) * H + col, tag, acc[r]);
             }
             if (own) {                                     // reduce-scatter: the 8 partials of this thread's (sequence, unit)
+                float pv[NS];
+                sweep_granules<NS>(xg + ((size_t)par * NS * 16 + es) * H + gu, 16 * H, tag, pv, A.ctl + 2);
                 float s = keep;
 #pragma unroll
-                for (int src = 0; src < NS; ++src)
-                    s += get_granule(xg + (((size_t)par * NS + src) * 16 + es) * H + gu, tag, A.ctl + 2);
+                for (int src = 0; src < NS; ++src) s += pv[src];
                 carry = s;
             }
         }
