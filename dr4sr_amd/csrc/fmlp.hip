@@ -255,9 +255,15 @@ struct FFiltArgs {
     int B, L; float eps; const int* state; uint64_t seed; float p; int training; uint32_t site;
 };
 
-// one workgroup per sequence; thread (d = lane, g = wave) owns rows l = g, g+4, ...
+// One workgroup per sequence.  Thread (dq = tid & 15, rg = tid >> 4) owns the feature quad d = 4dq..4dq+3 of rows l = rg + 16 i:
+// every LDS access of the L x L circular-convolution loops is a conflict-free ds_read_b128 feeding 4 FMAs (one b32 load per
+// FMA was LDS-issue bound: 36 / 111 us), and a row's LayerNorm statistics reduce over the 16 lanes of a row group.
+__device__ __forceinline__ void fma4(float4& a, const float4& m, const float4& x) {
+    a.x = fmaf(m.x, x.x, a.x); a.y = fmaf(m.y, x.y, a.y); a.z = fmaf(m.z, x.z, a.z); a.w = fmaf(m.w, x.w, a.w);
+}
+
 __global__ __launch_bounds__(256) void k_fmlp_filter_fwd(const FFiltArgs A) {
-    const int L = A.L, b = blockIdx.x, d = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int L = A.L, b = blockIdx.x, dq = threadIdx.x & 15, rg = threadIdx.x >> 4, c = 4 * dq;
     float* ML = smem;                          // [L][64]
     float* X2 = ML + L * FM_D;                 // [2L][64]   x twice: x[(l-r) mod L] = X2[l - r + L]
     const float* xb = A.x + (size_t)b * L * FM_D;
@@ -268,53 +274,54 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_fwd(const FFiltArgs A) {
         st4(X2 + L * FM_D + 4 * i, v);
     }
     __syncthreads();
-    float acc[13];
+    float4 acc[4];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = 0; r < L; ++r) {
-        const float mr = ML[r * FM_D + d];
+        const float4 mr = ld4(ML + r * FM_D + c);
 #pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            const int l = g + 4 * i;
-            if (l < L) acc[i] += mr * X2[(l - r + L) * FM_D + d];
+        for (int i = 0; i < 4; ++i) {
+            const int l = rg + 16 * i;
+            if (l < L) fma4(acc[i], mr, ld4(X2 + (l - r + L) * FM_D + c));
         }
     }
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
-    const float gam = A.lnw[d], bet = A.lnb[d];
+    const float4 gam = ld4(A.lnw + c), bet = ld4(A.lnb + c);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        const int l = g + 4 * i;
-        if (l < L) {                               // wave-uniform
+    for (int i = 0; i < 4; ++i) {
+        const int l = rg + 16 * i;
+        if (l < L) {                               // uniform over the 16 lanes of a row group
             const size_t t = (size_t)b * L + l;
-            float y = acc[i];
-            if (dodrop) y *= drop1(rk, A.site, (uint64_t)t * FM_D + d);
-            const float u = y + X2[l * FM_D + d];
-            const float mean = wave_sum(u) * (1.0f / FM_D);
-            const float dv = u - mean;
-            const float rstd = 1.0f / sqrtf(wave_sum(dv * dv) * (1.0f / FM_D) + A.eps);
-            A.uf[t * FM_D + d] = u;
-            A.xf[t * FM_D + d] = dv * rstd * gam + bet;
-            if (d == 0) { A.stf[2 * t] = mean; A.stf[2 * t + 1] = rstd; }
+            float4 y = acc[i];
+            if (dodrop) { const float4 m = drop4(rk, A.site, (uint64_t)t * FM_D + c); y.x *= m.x; y.y *= m.y; y.z *= m.z; y.w *= m.w; }
+            const float4 x0 = ld4(X2 + l * FM_D + c);
+            const float4 u = make_float4(y.x + x0.x, y.y + x0.y, y.z + x0.z, y.w + x0.w);
+            const float mean = group16_sum((u.x + u.y) + (u.z + u.w)) * (1.0f / FM_D);
+            const float4 dv = make_float4(u.x - mean, u.y - mean, u.z - mean, u.w - mean);
+            const float rstd = 1.0f / sqrtf(group16_sum((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w)) * (1.0f / FM_D) + A.eps);
+            st4(A.uf + t * FM_D + c, u);
+            st4(A.xf + t * FM_D + c, make_float4(dv.x * rstd * gam.x + bet.x, dv.y * rstd * gam.y + bet.y, dv.z * rstd * gam.z + bet.z,
+                                                 dv.w * rstd * gam.w + bet.w));
+            if (dq == 0) { A.stf[2 * t] = mean; A.stf[2 * t + 1] = rstd; }
         }
     }
 }
 
-// backward; block-strided over sequences so that dm and the LN affine grads cost one atomic per block
+// backward; block-strided over sequences so that dm and the LN affine grads cost one atomic per element per block
 __global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
-    const int L = A.L, d = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int L = A.L, dq = threadIdx.x & 15, rg = threadIdx.x >> 4, c = 4 * dq;
     float* ML = smem;                          // [L][64]
     float* X2 = ML + L * FM_D;                 // [2L][64]
     float* DY2 = X2 + 2 * L * FM_D;            // [2L][64]  dy twice: dy[(l'+r) mod L] = DY2[l' + r]
-    float* red = DY2 + 2 * L * FM_D;           // [4][2][64]
+    float* red = DY2 + 2 * L * FM_D;           // [16][2][64]
     for (int i = threadIdx.x; i < L * FM_D / 4; i += 256) st4(ML + 4 * i, ld4(A.m + 4 * i));
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
-    const float gam = A.lnw[d];
-    float dgam = 0.f, dbet = 0.f;
-    float dmacc[13];
+    const float4 gam = ld4(A.lnw + c);
+    float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam, dmacc[4];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) dmacc[i] = 0.f;
+    for (int i = 0; i < 4; ++i) dmacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
         __syncthreads();                           // previous iteration finished with X2 / DY2
         const float* xb = A.x + (size_t)b * L * FM_D;
@@ -323,67 +330,74 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
             st4(X2 + 4 * i, v);
             st4(X2 + L * FM_D + 4 * i, v);
         }
-        float du[13];
+        float4 du[4];
 #pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            const int l = g + 4 * i;
-            du[i] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int l = rg + 16 * i;
+            du[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (l < L) {
                 const size_t t = (size_t)b * L + l;
-                const float dz = A.dxf[t * FM_D + d];
+                const float4 dz = ld4(A.dxf + t * FM_D + c), uu = ld4(A.uf + t * FM_D + c);
                 const float mean = A.stf[2 * t], rstd = A.stf[2 * t + 1];
-                const float xh = (A.uf[t * FM_D + d] - mean) * rstd;
-                const float gg = dz * gam;
-                const float s1 = wave_sum(gg) * (1.0f / FM_D), s2 = wave_sum(gg * xh) * (1.0f / FM_D);
-                dgam += dz * xh;
-                dbet += dz;
-                du[i] = rstd * (gg - s1 - xh * s2);
-                float dy = du[i];
-                if (dodrop) dy *= drop1(rk, A.site, (uint64_t)t * FM_D + d);
-                DY2[l * FM_D + d] = dy;
-                DY2[(l + L) * FM_D + d] = dy;
+                const float4 xh = make_float4((uu.x - mean) * rstd, (uu.y - mean) * rstd, (uu.z - mean) * rstd, (uu.w - mean) * rstd);
+                const float4 gg = make_float4(dz.x * gam.x, dz.y * gam.y, dz.z * gam.z, dz.w * gam.w);
+                const float s1 = group16_sum((gg.x + gg.y) + (gg.z + gg.w)) * (1.0f / FM_D);
+                const float s2 = group16_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * (1.0f / FM_D);
+                dgam.x += dz.x * xh.x; dgam.y += dz.y * xh.y; dgam.z += dz.z * xh.z; dgam.w += dz.w * xh.w;
+                dbet.x += dz.x; dbet.y += dz.y; dbet.z += dz.z; dbet.w += dz.w;
+                du[i] = make_float4(rstd * (gg.x - s1 - xh.x * s2), rstd * (gg.y - s1 - xh.y * s2), rstd * (gg.z - s1 - xh.z * s2),
+                                    rstd * (gg.w - s1 - xh.w * s2));
+                float4 dy = du[i];
+                if (dodrop) { const float4 m = drop4(rk, A.site, (uint64_t)t * FM_D + c); dy.x *= m.x; dy.y *= m.y; dy.z *= m.z; dy.w *= m.w; }
+                st4(DY2 + l * FM_D + c, dy);
+                st4(DY2 + (l + L) * FM_D + c, dy);
             }
         }
         __syncthreads();
         // dx[l'] = du[l'] + sum_r m[r] dy[(l'+r) mod L]
-        float acc[13];
+        float4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 13; ++i) acc[i] = du[i];
+        for (int i = 0; i < 4; ++i) acc[i] = du[i];
         for (int r = 0; r < L; ++r) {
-            const float mr = ML[r * FM_D + d];
+            const float4 mr = ld4(ML + r * FM_D + c);
 #pragma unroll
-            for (int i = 0; i < 13; ++i) {
-                const int l = g + 4 * i;
-                if (l < L) acc[i] += mr * DY2[(l + r) * FM_D + d];
+            for (int i = 0; i < 4; ++i) {
+                const int l = rg + 16 * i;
+                if (l < L) fma4(acc[i], mr, ld4(DY2 + (l + r) * FM_D + c));
             }
         }
 #pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            const int l = g + 4 * i;
-            if (l < L) A.dx[((size_t)b * L + l) * FM_D + d] = acc[i];
+        for (int i = 0; i < 4; ++i) {
+            const int l = rg + 16 * i;
+            if (l < L) st4(A.dx + ((size_t)b * L + l) * FM_D + c, acc[i]);
         }
-        // dm[r] += sum_l dy[l] x[(l-r) mod L]   (this thread owns r = g + 4i)
+        // dm[r] += sum_l dy[l] x[(l-r) mod L]   (this thread owns r = rg + 16 i)
         for (int l = 0; l < L; ++l) {
-            const float dyl = DY2[l * FM_D + d];
+            const float4 dyl = ld4(DY2 + l * FM_D + c);
 #pragma unroll
-            for (int i = 0; i < 13; ++i) {
-                const int r = g + 4 * i;
-                if (r < L) dmacc[i] += dyl * X2[(l - r + L) * FM_D + d];
+            for (int i = 0; i < 4; ++i) {
+                const int r = rg + 16 * i;
+                if (r < L) fma4(dmacc[i], dyl, ld4(X2 + (l - r + L) * FM_D + c));
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        const int r = g + 4 * i;
-        if (r < L) unsafeAtomicAdd(A.dm + r * FM_D + d, dmacc[i]);
+    for (int i = 0; i < 4; ++i) {
+        const int r = rg + 16 * i;
+        if (r < L) {
+            float* d = A.dm + r * FM_D + c;
+            unsafeAtomicAdd(d, dmacc[i].x); unsafeAtomicAdd(d + 1, dmacc[i].y); unsafeAtomicAdd(d + 2, dmacc[i].z); unsafeAtomicAdd(d + 3, dmacc[i].w);
+        }
     }
     __syncthreads();
-    red[(g * 2) * FM_D + d] = dgam;
-    red[(g * 2 + 1) * FM_D + d] = dbet;
+    st4(red + (rg * 2) * FM_D + c, dgam);
+    st4(red + (rg * 2 + 1) * FM_D + c, dbet);
     __syncthreads();
     if (threadIdx.x < 2 * FM_D) {
         const int which = threadIdx.x >> 6, dd = threadIdx.x & 63;
-        const float v = (red[(0 + which) * FM_D + dd] + red[(2 + which) * FM_D + dd]) + (red[(4 + which) * FM_D + dd] + red[(6 + which) * FM_D + dd]);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[(k * 2 + which) * FM_D + dd];
         unsafeAtomicAdd((which == 0 ? A.dlnw : A.dlnb) + dd, v);
     }
 }
@@ -499,7 +513,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         Fa.dxf = w.dxf; Fa.dx = ws.dX[l]; Fa.dlnw = p->grads + foff(ws, l, FP_FLN_W); Fa.dlnb = p->grads + foff(ws, l, FP_FLN_B);
         Fa.B = p->B; Fa.L = L; Fa.eps = p->ln_eps; Fa.state = p->state; Fa.seed = p->seed; Fa.p = p->p_drop; Fa.training = training;
         Fa.site = FS_FILT(l);
-        const size_t lds = sizeof(float) * (5 * L * FM_D + 8 * FM_D);
+        const size_t lds = sizeof(float) * (5 * L * FM_D + 32 * FM_D);
         big_lds(k_fmlp_filter_bwd, lds);
         const int gb = p->B < 128 ? p->B : 128;
         hipLaunchKernelGGL(k_fmlp_filter_bwd, dim3(gb), dim3(256), lds, s, Fa);
