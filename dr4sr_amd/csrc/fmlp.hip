@@ -114,7 +114,7 @@ __global__ __launch_bounds__(1024) void k_fmlp_prep(int* __restrict__ state, int
         st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-// m[l][r][d] from complex_weight[k][d][2]; also zeroes dm.  grid = n_layer, 256 threads.
+// m[l][r][d] from complex_weight[k][d][2]; also zeroes dm.  grid = (n_layer, ceil(L*64/256)), one output per thread.
 __global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ params, int64_t o_cw0, int64_t layer_stride,
                                                    float* __restrict__ m, float* __restrict__ dm, int L) {
     __shared__ float ct[64], sn[64];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ par
     if ((int)threadIdx.x < L) sincospif(2.0f * threadIdx.x / (float)L, &sn[threadIdx.x], &ct[threadIdx.x]);
     __syncthreads();
     const float* cw = params + o_cw0 + layer * layer_stride;
-    for (int i = threadIdx.x; i < L * FM_D; i += 256) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < L * FM_D; i += gridDim.y * 256) {
         const int r = i / FM_D, d = i % FM_D;
         float acc = 0.f;
         for (int k = 0; k < K; ++k) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_fmlp_coef_bwd(float* __restrict__ grads
     __syncthreads();
     float* g = grads + o_cw0 + layer * layer_stride;
     const float* dml = dm + (size_t)layer * L * FM_D;
-    for (int i = threadIdx.x; i < K * FM_D; i += 256) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < K * FM_D; i += gridDim.y * 256) {
         const int k = i / FM_D, d = i % FM_D;
         float gr = 0.f, gi = 0.f;
         for (int r = 0; r < L; ++r) {
@@ -466,7 +466,7 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
     int zb = (int)((n4 + 1023) / 1024); if (zb > 255) zb = 255;
     hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb), dim3(1024), 0, s, p->state, ws.Tn, training ? 1 : 0, zero_grads ? p->grads : nullptr, n4);
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
-    hipLaunchKernelGGL(k_fmlp_coef, dim3(nl), dim3(256), 0, s, p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L);
+    hipLaunchKernelGGL(k_fmlp_coef, dim3(nl, (L * FM_D + 255) / 256), dim3(256), 0, s, p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L);
     FEmbArgs E{};
     E.E = p->params + ws.off[0]; E.P = p->params + ws.off[1]; E.lnw = p->params + ws.off[2]; E.lnb = p->params + ws.off[3];
     E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0; E.x0 = ws.X[0];
@@ -515,7 +515,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         Fa.site = FS_FILT(l);
         const size_t lds = sizeof(float) * (5 * L * FM_D + 32 * FM_D);
         big_lds(k_fmlp_filter_bwd, lds);
-        const int gb = p->B < 128 ? p->B : 128;
+        const int gb = p->B < 256 ? p->B : 256;
         hipLaunchKernelGGL(k_fmlp_filter_bwd, dim3(gb), dim3(256), lds, s, Fa);
     }
     FEmbArgs E{};
@@ -524,7 +524,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
     hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < 64 ? p->B : 64), dim3(256), 0, s, E);
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
-    hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
+    hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl, ((L / 2 + 1) * FM_D + 255) / 256), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
     WgradArgs W{};
     for (int l = 0; l < nl; ++l) {
         const FmlpLayerWs& w = ws.layer[l];
