@@ -76,7 +76,7 @@ static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tn * D); ws->dX[i] = take(Tn * D); }
     ws->m = take((int64_t)p->n_layer * p->L * D); ws->dm = take((int64_t)p->n_layer * p->L * D);
     ws->score_part = take(2LL * p->B);
-    ws->ln_part = take((int64_t)p->n_layer * ((Tn + 63) / 64) * 4 * D);
+    ws->ln_part = take((int64_t)p->n_layer * ((Tn + 31) / 32) * 4 * D);        // sized for the smallest FFN tile
     for (int l = 0; l < p->n_layer; ++l) {
         FmlpLayerWs& w = ws->layer[l];
         w.uf = take(Tn * D); w.stf = take(Tn * 2); w.xf = take(Tn * D);
@@ -496,7 +496,7 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
 
 static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int with_score, hipStream_t s) {
     const int L = p->L, nl = p->n_layer;
-    const int ntiles = (ws.Tn + 63) / 64;
+    const int bm = ffn_tile_rows(ws.Tn), ntiles = (ws.Tn + bm - 1) / bm;
     for (int l = nl - 1; l >= 0; --l) {
         const FmlpLayerWs& w = ws.layer[l];
         PostArgs A{};
@@ -536,7 +536,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         J2.dW = p->grads + foff(ws, l, FP_W2); J2.db = p->grads + foff(ws, l, FP_B2);
     }
     W.state = p->state; W.seed = p->seed; W.p = p->p_drop; W.training = training;
-    W.ln_part = ws.ln_part; W.ln_layer_stride = (int64_t)ntiles * 4 * FM_D; W.grads = p->grads;
+    W.ln_part = ws.ln_part; W.ln_layer_stride = (int64_t)ntiles * 4 * FM_D; W.grads = p->grads; W.ln_tile_rows = bm;
     W.o_ln1_w = foff(ws, 0, FP_ILN_W); W.layer_stride = lstride;
     W.score_part = with_score ? ws.score_part : nullptr; W.tail = p->grads + ws.n_params; W.B = p->B; W.D = FM_D;
     RC(launch_fmlp_wgrad(W, ws.Tn, nl, s));

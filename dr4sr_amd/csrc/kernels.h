@@ -87,6 +87,7 @@ struct WgradArgs {
     int ln_tile_rows;                          // token rows per LayerNorm-partial row (tile size of the post kernels)
 };
 
+int ffn_tile_rows(int Tmax);
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s);

@@ -660,18 +660,22 @@ int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, 
 }
 
 // FMLP Intermediate block (module/layers.py:761-779): linear1 -> GELU -> linear2 -> dropout -> +x -> LayerNorm, D=64, F=256
+// token rows per workgroup of the FMLP Intermediate kernels (ln_part rows follow the same tiling)
+int ffn_tile_rows(int Tmax) { return Tmax <= 16384 ? 32 : 64; }
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s) {
-    dim3 grid((Tmax + 63) / 64), blk(256);
-    const size_t lds = post_lds(64, 256);
-    big_lds(k_post_fwd<64, 64, 256, true>, lds);
-    hipLaunchKernelGGL((k_post_fwd<64, 64, 256, true>), grid, blk, lds, s, A);
+    const int bm = ffn_tile_rows(Tmax);
+    dim3 grid((Tmax + bm - 1) / bm), blk(256);
+    const size_t lds = post_lds(64, 256, bm);
+    if (bm == 32) { big_lds(k_post_fwd<32, 64, 256, true>, lds); hipLaunchKernelGGL((k_post_fwd<32, 64, 256, true>), grid, blk, lds, s, A); }
+    else { big_lds(k_post_fwd<64, 64, 256, true>, lds); hipLaunchKernelGGL((k_post_fwd<64, 64, 256, true>), grid, blk, lds, s, A); }
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s) {
-    dim3 grid((Tmax + 63) / 64), blk(256);
-    const size_t lds = post_lds(64, 256);
-    big_lds(k_post_bwd<64, 64, 256, true>, lds);
-    hipLaunchKernelGGL((k_post_bwd<64, 64, 256, true>), grid, blk, lds, s, A);
+    const int bm = ffn_tile_rows(Tmax);
+    dim3 grid((Tmax + bm - 1) / bm), blk(256);
+    const size_t lds = post_lds(64, 256, bm);
+    if (bm == 32) { big_lds(k_post_bwd<32, 64, 256, true>, lds); hipLaunchKernelGGL((k_post_bwd<32, 64, 256, true>), grid, blk, lds, s, A); }
+    else { big_lds(k_post_bwd<64, 64, 256, true>, lds); hipLaunchKernelGGL((k_post_bwd<64, 64, 256, true>), grid, blk, lds, s, A); }
     return DR4SR_LAUNCH_CHECK();
 }
 
@@ -937,7 +941,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A) {
 
 // ---- FMLP: weight gradients of the Intermediate blocks (dense_1, dense_2) + LayerNorm / scorer partial reductions
 __device__ __forceinline__ void reduce_jobs_fmlp(const WgradArgs& A) {
-    const int T = A.state[DR4SR_STATE_T], ntiles = (T + 63) / 64, D = A.D, layer = blockIdx.z;
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + A.ln_tile_rows - 1) / A.ln_tile_rows, D = A.D, layer = blockIdx.z;
     const float* part = A.ln_part + (size_t)layer * A.ln_layer_stride;          // [ntiles][4][D], rows 0,1 = (d ln_w, d ln_b)
     float* g = A.grads + A.o_ln1_w + (size_t)layer * A.layer_stride;           // intermediate.LayerNorm.weight | .bias
     for (int c = threadIdx.x; c < 2 * D; c += 256) {
