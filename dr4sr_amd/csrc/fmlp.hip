@@ -15,6 +15,7 @@ extern __shared__ __attribute__((aligned(16))) float smem[];
 
 #define FM_D 64
 #define FM_F 256
+#define FM_DMBLK 256                           // workgroups of k_fmlp_filter_bwd (= rows of dm_part per layer)
 #define FS_EMB 0u
 #define FS_FILT(l) (1u + 2u * (l))
 #define FS_FFN(l) (2u + 2u * (l))
@@ -31,6 +32,7 @@ struct FmlpWs {
     float* e0; float* st0;
     float* X[DR4SR_MAX_LAYERS + 1]; float* dX[DR4SR_MAX_LAYERS + 1];
     float* m; float* dm;                      // [n_layer][L][D]
+    float* dm_part;                           // [n_layer][FM_DMBLK][L][D] per-block partials of dm (summed by k_fmlp_dm_reduce)
     float* score_part; float* ln_part;        // [B][2]; [n_layer][ntiles][4][D]
     FmlpLayerWs layer[DR4SR_MAX_LAYERS];
     int64_t bytes;
@@ -75,6 +77,7 @@ static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
     ws->e0 = take(Tn * D); ws->st0 = take(Tn * 2);
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tn * D); ws->dX[i] = take(Tn * D); }
     ws->m = take((int64_t)p->n_layer * p->L * D); ws->dm = take((int64_t)p->n_layer * p->L * D);
+    ws->dm_part = take((int64_t)p->n_layer * FM_DMBLK * p->L * D);
     ws->score_part = take(2LL * p->B);
     ws->ln_part = take((int64_t)p->n_layer * ((Tn + 31) / 32) * 4 * D);        // sized for the smallest FFN tile
     for (int l = 0; l < p->n_layer; ++l) {
@@ -133,6 +136,15 @@ __global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ par
         m[(size_t)layer * L * FM_D + i] = acc / (float)L;
         dm[(size_t)layer * L * FM_D + i] = 0.f;
     }
+}
+// dm[layer][i] = sum over the nblk per-workgroup partials written by k_fmlp_filter_bwd (fixed order)
+__global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict__ part, float* __restrict__ dm, int nblk, int n) {
+    const int layer = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = part + (size_t)layer * FM_DMBLK * n + i;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += p[(size_t)b * n];
+    dm[(size_t)layer * n + i] = s;
 }
 // d(complex_weight) += fold(dm)
 __global__ __launch_bounds__(256) void k_fmlp_coef_bwd(float* __restrict__ grads, int64_t o_cw0, int64_t layer_stride,
@@ -382,12 +394,9 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {                  // deterministic: one partial [L][64] per workgroup, summed by k_fmlp_dm_reduce
         const int r = rg + 16 * i;
-        if (r < L) {
-            float* d = A.dm + r * FM_D + c;
-            unsafeAtomicAdd(d, dmacc[i].x); unsafeAtomicAdd(d + 1, dmacc[i].y); unsafeAtomicAdd(d + 2, dmacc[i].z); unsafeAtomicAdd(d + 3, dmacc[i].w);
-        }
+        if (r < L) st4(A.dm + ((size_t)blockIdx.x * L + r) * FM_D + c, dmacc[i]);
     }
     __syncthreads();
     st4(red + (rg * 2) * FM_D + c, dgam);
@@ -508,14 +517,14 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr; A.rd = nullptr; A.n_head = 1;
         RC(launch_ffn_bwd(A, ws.Tn, s));
         FFiltArgs Fa{};
-        Fa.m = ws.m + (size_t)l * L * FM_D; Fa.dm = ws.dm + (size_t)l * L * FM_D; Fa.x = ws.X[l];
+        Fa.m = ws.m + (size_t)l * L * FM_D; Fa.dm = ws.dm_part + (size_t)l * FM_DMBLK * L * FM_D; Fa.x = ws.X[l];
         Fa.lnw = p->params + foff(ws, l, FP_FLN_W); Fa.uf = w.uf; Fa.stf = w.stf;
         Fa.dxf = w.dxf; Fa.dx = ws.dX[l]; Fa.dlnw = p->grads + foff(ws, l, FP_FLN_W); Fa.dlnb = p->grads + foff(ws, l, FP_FLN_B);
         Fa.B = p->B; Fa.L = L; Fa.eps = p->ln_eps; Fa.state = p->state; Fa.seed = p->seed; Fa.p = p->p_drop; Fa.training = training;
         Fa.site = FS_FILT(l);
         const size_t lds = sizeof(float) * (5 * L * FM_D + 32 * FM_D);
         big_lds(k_fmlp_filter_bwd, lds);
-        const int gb = p->B < 256 ? p->B : 256;
+        const int gb = p->B < FM_DMBLK ? p->B : FM_DMBLK;
         hipLaunchKernelGGL(k_fmlp_filter_bwd, dim3(gb), dim3(256), lds, s, Fa);
     }
     FEmbArgs E{};
@@ -524,6 +533,8 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
     hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < 64 ? p->B : 64), dim3(256), 0, s, E);
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
+    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3((L * FM_D + 255) / 256, nl), dim3(256), 0, s, ws.dm_part, ws.dm,
+                       p->B < FM_DMBLK ? p->B : FM_DMBLK, L * FM_D);
     hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl, ((L / 2 + 1) * FM_D + 255) / 256), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
     WgradArgs W{};
     for (int l = 0; l < nl; ++l) {
