@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void k_wgrad64(const Wg64Args A) {
         }
     };
     int tt = blockIdx.x;
-    if (tt < ntiles) issue(tt);
+    if (tt >= ntiles) return;                            // worst-case grid: a workgroup without a token tile has nothing to add
+    issue(tt);
     for (; tt < ntiles; tt += gridDim.x) {
         lds_barrier();
 #pragma unroll

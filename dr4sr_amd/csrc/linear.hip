@@ -854,7 +854,8 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
         }
     };
     int tt = blockIdx.x;
-    if (tt < ntiles) issue(tt);
+    if (tt >= ntiles) return;                            // the grid covers the worst case B*L tokens: no tile, nothing to add
+    issue(tt);
     for (; tt < ntiles; tt += gridDim.x) {
         lds_barrier();                                   // previous MFMA phase has finished reading LDS
         commit(tt);
