@@ -122,18 +122,29 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float
     const float nvalid = G[n];
     const float gs = nvalid > 0.f ? 1.0f / nvalid : 0.f;
     const int64_t n4 = n / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 p = ld4(P + 4 * i), m = ld4(M + 4 * i), v = ld4(V + 4 * i);
+    auto upd = [&](float& pe, float& me, float& ve, float ge) {
+        const float g = ge * gs + wd * pe;
+        me = me + (g - me) * (1.0f - b1);
+        ve = ve * b2 + (1.0f - b2) * g * g;
+        const float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
+        pe = pe - step_size * (me / denom);
+    };
+    // two independent float4 groups per thread per iteration: 8 loads in flight instead of 4 (the loop is latency-, not
+    // bandwidth-bound at 3 iterations per thread)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * stride) {
+        const int64_t j = i + stride;
+        const bool two = j < n4;
+        float4 p0 = ld4(P + 4 * i), m0 = ld4(M + 4 * i), v0 = ld4(V + 4 * i);
         const float4 g0 = ld4(G + 4 * i);
-        auto upd = [&](float& pe, float& me, float& ve, float ge) {
-            const float g = ge * gs + wd * pe;
-            me = me + (g - me) * (1.0f - b1);
-            ve = ve * b2 + (1.0f - b2) * g * g;
-            const float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
-            pe = pe - step_size * (me / denom);
-        };
-        upd(p.x, m.x, v.x, g0.x); upd(p.y, m.y, v.y, g0.y); upd(p.z, m.z, v.z, g0.z); upd(p.w, m.w, v.w, g0.w);
-        st4(P + 4 * i, p); st4(M + 4 * i, m); st4(V + 4 * i, v);
+        float4 p1 = p0, m1 = m0, v1 = v0, g1 = g0;
+        if (two) { p1 = ld4(P + 4 * j); m1 = ld4(M + 4 * j); v1 = ld4(V + 4 * j); g1 = ld4(G + 4 * j); }
+        upd(p0.x, m0.x, v0.x, g0.x); upd(p0.y, m0.y, v0.y, g0.y); upd(p0.z, m0.z, v0.z, g0.z); upd(p0.w, m0.w, v0.w, g0.w);
+        st4(P + 4 * i, p0); st4(M + 4 * i, m0); st4(V + 4 * i, v0);
+        if (two) {
+            upd(p1.x, m1.x, v1.x, g1.x); upd(p1.y, m1.y, v1.y, g1.y); upd(p1.z, m1.z, v1.z, g1.z); upd(p1.w, m1.w, v1.w, g1.w);
+            st4(P + 4 * j, p1); st4(M + 4 * j, m1); st4(V + 4 * j, v1);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {                    // no fence needed: the kernel boundary publishes the parameter writes
