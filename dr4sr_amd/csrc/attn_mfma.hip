@@ -197,8 +197,12 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
     }
     lds_barrier();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1;
-    const int half = NW == 8 ? (w >> 1) & 1 : 0;            // NW = 8: two waves per (phase, head); NW = 4 (short variant): one
-    const bool phaseB = w >= NW / 2;
+    // NW = 8: phases on separate wave quads (latency regime);  ROWS = 64 with NW = 4: every wave runs phase A then phase B
+    // (throughput regime: 4 workgroups' worth of waves per CU instead of 2, no A/B load imbalance);  short variant: one wave per
+    // (phase, head)
+    constexpr bool SEQ = ROWS == 64 && NT == 256;
+    const int half = (NW == 8 || SEQ) ? (w >> 1) & 1 : 0;
+    const bool phaseB = !SEQ && w >= NW / 2;
     const int i16 = lane & 15, g = lane >> 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
@@ -206,7 +210,7 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
     const float scale = 1.0f / sqrtf((float)DH);
     const int ntile = (n + 15) >> 4;
 
-    if (!phaseB) {
+    if (SEQ || !phaseB) {
         // ---- phase A: query tiles (transposed orientation: lane i = l&15, j = 4g+r) -> dQ
 #pragma unroll
         for (int pass = 0; pass < (MT == 1 ? 1 : 2); ++pass) {
@@ -251,7 +255,7 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
                 if (i < n) st4(A.dqkv + (size_t)(t0 + i) * 3 * D + h * DH + fb * 16 + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
             }
         }
-        return;
+        if (!SEQ) return;
     }
     // ---- phase B: key tiles (natural orientation: lane j = l&15, i = 4g+r) -> dK, dV
 #pragma unroll
@@ -345,15 +349,16 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
         else { big_lds(k_attn2_fwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A); }
         return DR4SR_LAUNCH_CHECK();
     }
-    const int gs = B < 256 * 8 ? B : 256 * 8, gl = B < 256 * 2 ? B : 256 * 2;
+    const int gs = B < 256 * 8 ? B : 256 * 8;                                // persistent grids: workgroups per CU that fit by LDS
+    const int glmax = bwd ? 256 * 2 : 256 * 3, gl = B < glmax ? B : glmax;
     AttnArgs2 S = A, Lg = A;
     S.list = ws.seq_class + 2; S.list_count = ws.seq_class;
     Lg.list = ws.seq_class + 2 + B; Lg.list_count = ws.seq_class + 1;
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
     if (bwd) {
         hipLaunchKernelGGL((k_attn2_bwd<DH, 16, 256>), dim3(gs), dim3(256), lds_s, s, S);
-        big_lds(k_attn2_bwd<DH, 64, 512>, lds_l);
-        hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512>), dim3(gl), dim3(512), lds_l, s, Lg);
+        big_lds(k_attn2_bwd<DH, 64, 256>, lds_l);
+        hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(gl), dim3(256), lds_l, s, Lg);
     } else {
         hipLaunchKernelGGL((k_attn2_fwd<DH, 16, 128>), dim3(gs), dim3(128), lds_s, s, S);
         big_lds(k_attn2_fwd<DH, 64, 256>, lds_l);
