@@ -345,7 +345,10 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? 4 : 3) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
     if (!split_by_length(ws)) {
         const size_t lds = lds_of(64);
-        if (bwd) { big_lds(k_attn2_bwd<DH, 64, 512>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512>), dim3(B), dim3(512), lds, s, A); }
+        if (bwd && DH == 32) { big_lds(k_attn2_bwd<DH, 64, 512>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512>), dim3(B), dim3(512), lds, s, A); }
+        else if (bwd) {                              // head_dim 64: the 8-wave variant would spill (256-VGPR cap at 512 threads)
+            big_lds(k_attn2_bwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A);
+        }
         else { big_lds(k_attn2_fwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A); }
         return DR4SR_LAUNCH_CHECK();
     }
