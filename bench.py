@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--steps-per-graph", type=int, default=5, help="whole training steps captured per HIP graph (single GPU)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
     ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp", "metamodel", "cl4srec"],
@@ -309,10 +310,15 @@ def main():
             stream.synchronize()
             use_graph = not args.no_graph
             if use_graph and world == 1:
+                # batch selection runs on the device, so consecutive training steps need no host work at all: `group` whole steps
+                # are captured into one graph (a graph launch costs ~6 us of idle GPU between replays at this step size)
+                group = max(1, min(args.steps_per_graph, steps)) if steps % max(1, args.steps_per_graph) == 0 and \
+                    warmup % max(1, args.steps_per_graph) == 0 else 1
                 g_all = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_all, stream=stream, capture_error_mode="thread_local"):
-                    select()
-                    eng.train_step(plan)
+                    for _ in range(group):
+                        select()
+                        eng.train_step(plan)
                 run = g_all.replay
             elif use_graph:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -328,8 +334,9 @@ def main():
                     g_b.replay()
             else:
                 run = step_eager
+            group = group if (use_graph and world == 1) else 1
 
-            for _ in range(warmup):
+            for _ in range(warmup // group):
                 run()
             stream.synchronize()
             if world > 1:
@@ -338,7 +345,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             e0.record()
-            for _ in range(steps):
+            for _ in range(steps // group):
                 run()
             e1.record()
             torch.cuda.synchronize()
@@ -370,7 +377,7 @@ def main():
                 "config": {"workload": "%s, B=%d rows/GPU/step, %s seqlen" %
                                        (model_desc, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
                            "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
-                           "hip_graph": bool(use_graph)},
+                           "hip_graph": bool(use_graph), "steps_per_graph": group},
                 "gpu_ms_per_step_events": gpu_ms / steps, "final_loss": loss, "valid_tokens_last_step": T_last,
             }
 
