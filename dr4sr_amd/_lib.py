@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdr4sr_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GRAD_TAIL = 4
 STATE_WORDS = 16
 STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
@@ -44,6 +44,7 @@ class SasrecPlan(C.Structure):
         ("weight_decay", C.c_float),
         ("perm", _i64p), ("n_perm", C.c_int64), ("perm_stride", C.c_int64), ("perm_offset", C.c_int64),
         ("perm_counter", C.c_void_p),
+        ("loss_log", _f32p),
     ]
 
 

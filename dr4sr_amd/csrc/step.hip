@@ -109,7 +109,8 @@ static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
 // t = state[STEP]+1; the last block to finish bumps state[STEP] (ticket in state[8]).
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M,
                                               float* __restrict__ V, int64_t n, int* __restrict__ state, float lr, float b1,
-                                              float b2, float eps, float wd) {
+                                              float b2, float eps, float wd, float* __restrict__ loss_log,
+                                              const int* __restrict__ log_index) {
     __shared__ float sh[2];
     const int t = state[DR4SR_STATE_STEP] + 1;
     if (threadIdx.x == 0) {               // double-precision bias corrections, once per block
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float
     const float step_size = sh[0], inv_sqrt_bc2 = sh[1];
     const float nvalid = G[n];
     const float gs = nvalid > 0.f ? 1.0f / nvalid : 0.f;
+    if (loss_log && blockIdx.x == 0 && threadIdx.x == 0) loss_log[log_index ? max(*log_index - 1, 0) : 0] = G[n + 1] * gs;
     const int64_t n4 = n / 4;
     auto upd = [&](float& pe, float& me, float& ve, float ge) {
         const float g = ge * gs + wd * pe;
@@ -154,17 +156,17 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, const float
 }
 
 int launch_adam_flat(float* P, const float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2,
-                     float eps, float wd, hipStream_t s) {
+                     float eps, float wd, hipStream_t s, float* loss_log, const int* log_index) {
     if (!P || !G || !M || !V || !state || n <= 0 || (n & 3)) return DR4SR_E_ARG;
     int64_t blocks = (n / 4 + 255) / 256;
     static const int cap = getenv("DR4SR_ADAM_BLOCKS") ? atoi(getenv("DR4SR_ADAM_BLOCKS")) : 256;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index);
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s) {
     return launch_adam_flat(p->params, p->grads, p->adam_m, p->adam_v, p->n_params, p->state, p->lr, p->beta1, p->beta2,
-                            p->adam_eps, p->weight_decay, s);
+                            p->adam_eps, p->weight_decay, s, p->loss_log, p->perm ? p->perm_counter : nullptr);
 }
 
 extern "C" int dr4sr_adam_step(const dr4sr_sasrec_plan* plan, void* stream) {

@@ -92,7 +92,7 @@ class SasrecEngine:
         self._keep = []          # tensors referenced by the last plan
 
     # ------------------------------------------------------------------------------------------
-    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True, perm_sel=None, slot=0):
+    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True, perm_sel=None, slot=0, loss_log=None):
         p = _lib.SasrecPlan()
         p.abi_version = _lib.ABI_VERSION
         p.B, p.L, p.D, p.H, p.F, p.n_layer, p.n_items = B, self.L, self.D, self.H, self.F, self.n_layer, self.n_items
@@ -118,10 +118,13 @@ class SasrecEngine:
             assert rows is not None and perm.dtype == torch.int64 and counter.dtype == torch.int32
             p.perm, p.n_perm, p.perm_stride, p.perm_offset = perm.data_ptr(), int(perm.shape[0]), int(stride), int(offset)
             p.perm_counter = counter.data_ptr()
-        self._keep = [in_item_id, item_id, seqlen, rows, neg_item, perm_sel]
+        if loss_log is not None:           # float32 device buffer: the step's mean loss lands at [batch index] (see dr4sr_hip.h)
+            assert loss_log.dtype == torch.float32
+            p.loss_log = loss_log.data_ptr()
+        self._keep = [in_item_id, item_id, seqlen, rows, neg_item, perm_sel, loss_log]
         return p
 
-    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None, slot=0):
+    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None, slot=0, loss_log=None):
         """rows=None: the tensors ARE the batch ([B,L]/[B]); else they are dataset tensors indexed by rows[B].
         perm_sel: fused device-side batch selection (include/dr4sr_hip.h: dr4sr_sasrec_plan.perm)."""
         B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
@@ -131,7 +134,7 @@ class SasrecEngine:
             sample_neg = neg_item is None
         if neg_item is None:
             neg_item = self.neg_scratch
-        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, perm_sel=perm_sel, slot=slot)
+        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, perm_sel=perm_sel, slot=slot, loss_log=loss_log)
 
     # ------------------------------------------------------------------------------------------
     def fwd_bwd(self, plan):

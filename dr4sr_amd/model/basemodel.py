@@ -254,15 +254,17 @@ class BaseModel(nn.Module):
     # ------------------------------------------------------------------------------------------ fast path (fused HIP graph per batch)
     _supports_perm_sel = False
 
-    def _step_graph(self, fields, bl, perm_sel=None):
+    def _step_graph(self, fields, bl, perm_sel=None, group=1, loss_log=None):
         """captured HIP graph(s) for a local batch of `bl` rows addressed through self._rows_buf[:bl]; with perm_sel =
-        (perm, global batch, rank offset, counter) the rows are selected on the device by the step's first kernel"""
-        key = (fields["in_item_id"].data_ptr(), bl, None if perm_sel is None else (perm_sel[0].data_ptr(), perm_sel[1], perm_sel[2]))
+        (perm, global batch, rank offset, counter) the rows are selected on the device by the step's first kernel, which makes
+        consecutive steps host-free: `group` whole steps go into ONE graph and each writes its mean loss to loss_log[batch index]"""
+        key = (fields["in_item_id"].data_ptr(), bl, group, None if loss_log is None else loss_log.data_ptr(),
+               None if perm_sel is None else (perm_sel[0].data_ptr(), perm_sel[1], perm_sel[2]))
         if key in self._graphs:
             return self._graphs[key]
         eng = self.engine
         plan = self._train_plan(fields, self._rows_buf[:bl]) if perm_sel is None else \
-            self._train_plan(fields, self._rows_buf[:bl], perm_sel=perm_sel)
+            self._train_plan(fields, self._rows_buf[:bl], perm_sel=perm_sel, loss_log=loss_log)
         use_graph = bool(self.config["train"].get("hip_graph", True))
         undo = [eng.params, eng.adam_m, eng.adam_v, eng.state] + ([perm_sel[3]] if perm_sel is not None else [])
 
@@ -276,12 +278,13 @@ class BaseModel(nn.Module):
 
         if self.world_size == 1:
             def eager():
-                eng.train_step(plan)
+                for _ in range(group):
+                    eng.train_step(plan)
             if use_graph:
                 warm_up(eager)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):       # other threads (RCCL watchdog) may touch the device
-                    eng.train_step(plan)
+                    eager()
                 run = g.replay
             else:
                 run = eager
@@ -316,7 +319,9 @@ class BaseModel(nn.Module):
         if W > 1:
             import torch.distributed as dist
             dist.broadcast(perm, src=0)
-        losses = torch.empty(nb, dtype=torch.float32, device=self.device)
+        if getattr(self, "_loss_log", None) is None or self._loss_log.shape[0] != nb:
+            self._loss_log = torch.empty(nb, dtype=torch.float32, device=self.device)     # persistent: graphs hold its address
+        losses = self._loss_log
         tail = eng.grads[eng.n_params:eng.n_params + 2]
         fused_sel = self._supports_perm_sel
         if fused_sel:                                       # a1 on the device: one permutation upload per EPOCH, no per-step copy
@@ -325,15 +330,23 @@ class BaseModel(nn.Module):
                 self._perm_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._perm_buf.copy_(perm)
             self._perm_counter.zero_()
-        for i in range(nb):
+        group = int(self.config["train"].get("steps_per_graph", 4)) if (fused_sel and W == 1) else 1
+        i = 0
+        while i < nb:
             lo, hi = shard_bounds(i, B, n, W, r)
             bl = hi - lo
             if bl > 0 and fused_sel:
                 if i == nb - 1 and W > 1:
                     self._perm_counter.fill_(i)             # a rank whose earlier tail slice was empty re-aligns its batch index
-                run, _ = self._step_graph(loader.fields, bl, (self._perm_buf, B, lo - i * B, self._perm_counter))
+                sel = (self._perm_buf, B, lo - i * B, self._perm_counter)
+                k = group if (i + group <= nb and shard_bounds(i + group - 1, B, n, W, r)[1] - shard_bounds(i + group - 1, B, n, W, r)[0] == bl) else 1
+                run, _ = self._step_graph(loader.fields, bl, sel, group=k, loss_log=losses if W == 1 else None)
                 run()
-            elif bl > 0:
+                if W > 1:
+                    losses[i] = tail[1] / tail[0]
+                i += k
+                continue
+            if bl > 0:
                 self._rows_buf[:bl].copy_(perm[lo:hi])
                 run, _ = self._step_graph(loader.fields, bl)
                 run()
@@ -342,7 +355,8 @@ class BaseModel(nn.Module):
                 allreduce_flat(eng.grads)
                 eng.adam_step(self._api_plan())
             losses[i] = tail[1] / tail[0]
-        return [{"loss_0": losses}]
+            i += 1
+        return [{"loss_0": losses.clone()}]
 
     def training_epoch(self, nepoch):
         loader = self.current_epoch_trainloaders(nepoch)

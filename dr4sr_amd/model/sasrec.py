@@ -187,6 +187,6 @@ class SASRec(BaseModel):
 
     _supports_perm_sel = True          # batch selection fused into the step's first kernel (no per-step rows copy)
 
-    def _train_plan(self, fields, rows, perm_sel=None):
+    def _train_plan(self, fields, rows, perm_sel=None, loss_log=None):
         return self.engine.make_plan(fields["in_item_id"], fields["item_id"], fields["seqlen"], rows=rows,
-                                     neg_item=self._neg_buf, sample_neg=True, perm_sel=perm_sel)
+                                     neg_item=self._neg_buf, sample_neg=True, perm_sel=perm_sel, loss_log=loss_log)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DR4SR_ABI_VERSION 2
+#define DR4SR_ABI_VERSION 3
 
 #define DR4SR_E_ARG      (-1)   /* null pointer / bad size                                   */
 #define DR4SR_E_SHAPE    (-2)   /* unsupported D / H / F / L combination     */
@@ -100,6 +100,9 @@ typedef struct dr4sr_sasrec_plan {
     int64_t  perm_stride;           /* global batch size                                          */
     int64_t  perm_offset;           /* this rank's offset inside the global batch                 */
     int32_t* perm_counter;          /* device int32: batch index within the epoch                 */
+    /* ---- optional per-step loss log: dr4sr_adam_step / _train_step write loss_log[slot] = loss_sum / n_valid of the step with
+     *      slot = *perm_counter - 1 when perm != NULL (the batch index just consumed), else slot = 0.  NULL = off. ---- */
+    float*   loss_log;
 } dr4sr_sasrec_plan;
 
 /* -------------------------------------------------------------------------------------------- */
