@@ -266,8 +266,6 @@ struct GruRecArgs {
 };
 
 __device__ __forceinline__ f32x4 mfma16g(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_f(float x) { const float e = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - e) / (1.0f + e), x); }
 
 // 16 sequences per workgroup, 8 waves; wave w owns hidden units [w*H/8, (w+1)*H/8) of all three gates, so the gate math of a
 // unit is register-local (C-layout fragments of the r, z and n tiles coincide: lane = (sequence 4g+q, unit l&15)).

@@ -38,8 +38,6 @@ struct CoopArgs {
 };
 
 __device__ __forceinline__ f32x4 mfma16c(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_f(float x) { const float e = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - e) / (1.0f + e), x); }
 
 __device__ __forceinline__ void put_granule(u64* g, unsigned tag, float v) {
     __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
