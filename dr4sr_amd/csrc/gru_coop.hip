@@ -95,7 +95,11 @@ __global__ __launch_bounds__(H * 2) void k_gru_fwd_coop(const CoopArgs A) {
     float* hA = Ws + 3 * US * LDW;                        // [16][LDH]    h_{t-1} of the group's 16 sequences
     float* part = hA + 16 * LDH;                          // [4 kq][3][16][US]
     int* meta = reinterpret_cast<int*>(part + 4 * 3 * 16 * US);       // [16] t0, [16] n
-    const int grp = blockIdx.x / NS, sl = blockIdx.x % NS, b0 = grp * 16;
+    // speed-only placement (block b is observed on XCD b % 8): the 8 slices of a group sit on ONE XCD, so their per-step exchange
+    // stays inside that XCD's L2; correctness does not depend on it (agent-scope granules)
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int grp = (jx / NS) * 8 + xcd, sl = jx % NS, b0 = grp * 16;
+    if (b0 >= A.B) { finish_launch(A.ctl); return; }
     if (threadIdx.x < 16) {
         const int b = b0 + threadIdx.x;
         meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
@@ -183,7 +187,11 @@ __global__ __launch_bounds__(H * 2) void k_gru_bwd_coop(const CoopArgs A) {
     float* Ws = smem;                                     // [3*US][LDW]
     float* dgl = Ws + 3 * US * LDW;                       // [16][LDG]  dgh tile of this slice (A operand)
     int* meta = reinterpret_cast<int*>(dgl + 16 * LDG);
-    const int grp = blockIdx.x / NS, sl = blockIdx.x % NS, b0 = grp * 16;
+    // speed-only placement (block b is observed on XCD b % 8): the 8 slices of a group sit on ONE XCD, so their per-step exchange
+    // stays inside that XCD's L2; correctness does not depend on it (agent-scope granules)
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int grp = (jx / NS) * 8 + xcd, sl = jx % NS, b0 = grp * 16;
+    if (b0 >= A.B) { finish_launch(A.ctl); return; }
     if (threadIdx.x < 16) {
         const int b = b0 + threadIdx.x;
         meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
@@ -277,7 +285,7 @@ template <int H> size_t coop_lds(bool bwd) {
 // granule words needed by the cooperative path for a batch of B sequences (0 = the batch does not qualify)
 int64_t gru_coop_words(int B, int H) {
     const int groups = (B + 15) / 16;
-    if (groups * NS > 192 || getenv("DR4SR_GRU_NOCOOP")) return 0;
+    if (((groups + 7) / 8) * 8 * NS > 192 || getenv("DR4SR_GRU_NOCOOP")) return 0;
     return (int64_t)groups * 2 * NS * 16 * H;
 }
 
@@ -289,7 +297,8 @@ int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float*
     CoopArgs A;
     A.gi = gi; A.whh = whh; A.cu = cu; A.r = r; A.z = z; A.n = n; A.ghn = ghn; A.hprev = hprev; A.hout = hout;
     A.dhout = dhout; A.dgi = dgi; A.dgh = dgh; A.xch = xch; A.ctl = ctl; A.B = B;
-    dim3 grid(((B + 15) / 16) * NS), blk(H * 2);
+    const int groups = (B + 15) / 16;
+    dim3 grid(((groups + 7) / 8) * 8 * NS), blk(H * 2);          // groups rounded up to a multiple of 8 (XCD placement); extra blocks exit
     if (H == 256) {
         const size_t lds = coop_lds<256>(bwd);
         if (!bwd) { big_lds(k_gru_fwd_coop<256>, lds); hipLaunchKernelGGL(k_gru_fwd_coop<256>, grid, blk, lds, s, A); }
