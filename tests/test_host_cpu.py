@@ -61,6 +61,37 @@ def test_plan_validation_errors():
     assert lib.dr4sr_sasrec_fwd_bwd(C.byref(p), None) == -1            # no workspace
     assert lib.dr4sr_neg_sample(None, 4, 10, 0, 0, None) == -1
     assert lib.dr4sr_dropout_mask(None, 8, 0.5, 0, 0, 0, None) == -1
+    # fused batch selection needs a writable rows buffer and a counter
+    p.workspace, p.workspace_bytes, p.grads, p.item_id, p.neg_item = 1, 1 << 40, 1, 1, 1
+    p.n_params = lib.dr4sr_sasrec_param_layout(100, 50, 64, 128, 2, None)
+    p.perm, p.n_perm = 1, 10
+    assert lib.dr4sr_sasrec_fwd_bwd(C.byref(p), None) == -1            # perm without rows / perm_counter
+
+
+def test_argument_validation_of_the_widening_entry_points():
+    """MetaModel / CL4SRec / GRU entry points reject bad arguments before touching the device (ctypes, no GPU needed)"""
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    one = C.c_void_p(16)
+    assert lib.dr4sr_meta_param_count(64) == 64 * 64 + 64 + 2 * 64 + 2 and lib.dr4sr_meta_param_count(96) == -2
+    assert lib.dr4sr_meta_select_workspace_floats(12800) > 0
+    assert lib.dr4sr_meta_select_fwd(None, one, None, 0, 0, None, 1.0, None, one, 4, 50, 64, None, None, one, None) == -1      # no query
+    assert lib.dr4sr_meta_select_fwd(one, one, None, 0, 0, None, 0.0, None, one, 4, 50, 64, None, None, one, None) == -1       # tau <= 0
+    assert lib.dr4sr_meta_select_fwd(one, one, None, 0, 0, None, 1.0, None, one, 4, 50, 128, None, None, one, None) == -2      # D != 64
+    assert lib.dr4sr_meta_select_bwd(one, one, None, 0, 0, None, 1.0, None, one, 4, 50, 64, None, one, None, None, one, None, None) == -1
+    assert lib.dr4sr_fd_step_size(None, one, 8, 1e-3, one, None) == -1 and lib.dr4sr_fd_shift(one, one, one, None, 1.0, 8, None) == -1
+    assert lib.dr4sr_meta_sgd_step(one, one, one, 0, 1e-3, 0.9, 0.0, 10.0, one, None, None) == -1
+    assert lib.dr4sr_cl_augment(one, one, one, one, 4, 80, 0, 0.2, 0.7, 0.2, 10, 0, 0, None) == -1                              # L > 64
+    assert lib.dr4sr_cl_augment(one, one, one, one, 4, 50, 7, 0.2, 0.7, 0.2, 10, 0, 0, None) == -1                              # bad mode
+    assert lib.dr4sr_cl_augment(one, one, one, one, 0, 50, 0, 0.2, 0.7, 0.2, 10, 0, 0, None) == 0                               # empty batch
+    assert lib.dr4sr_infonce_fwd(one, one, None, 8, 96, 1.0, one, one, one, None) == -2                                         # D
+    assert lib.dr4sr_infonce_fwd(one, one, None, 8, 64, 0.0, one, one, one, None) == -1                                         # temperature
+    assert lib.dr4sr_infonce_bwd(one, one, None, 8, 64, 1.0, None, None, one, one, None) == -1
+    assert lib.dr4sr_neg_sample_dev(one, 8, 10, 0, None, None) == -1
+    g = _lib.GruPlan()
+    assert lib.dr4sr_gru4rec_fwd_bwd(C.byref(g), None) == -1
+    f = _lib.FmlpPlan()
+    assert lib.dr4sr_fmlp_fwd_bwd(C.byref(f), None) == -1
 
 
 def test_load_config_three_way_merge(tmp_path, monkeypatch):
