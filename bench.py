@@ -102,17 +102,39 @@ def bench_metamodel(args):
     perm = model._perm(loader)
     nb = len(loader)
 
-    def step(i):
-        return model._train_batch(model._local_batch(loader, perm, i % (nb - 1)), 0)      # skip the ragged last batch
+    fused = world == 1 and model._fused_ok()
+    if fused:
+        # the model's own epoch machinery (dr4sr_amd/model/metamodel.py:_fused_meta_epoch) on full batches only: selection, negatives,
+        # weighting, backward, Adam and the loss log on the device, several steps per graph, outer loop every `interval` steps
+        B = loader.batch_size
+        n_full = (loader.n // B) * B
+        model._perm_buf = perm[:n_full].clone()
+        model._perm_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        model._loss_log = torch.zeros(args.warmup + args.steps + 8, dtype=torch.float32, device=dev)
+        group, interval = int(cfg["train"].get("steps_per_graph", 4)), int(cfg["train"]["interval"])
 
-    for i in range(args.warmup):
-        step(i)
+        def run(nsteps):
+            i = 0
+            while i < nsteps:
+                k = max(1, min(group, interval - model.step_counter % interval, nsteps - i))
+                model._meta_step_graph(loader.fields, B, k)()
+                model.step_counter += k
+                i += k
+                if model.step_counter % interval == 0:
+                    model._outter_loop(0)
+            return model._loss_log[int(model._perm_counter) - 1]
+    else:
+        def run(nsteps):
+            for i in range(nsteps):
+                loss = model._train_batch(model._local_batch(loader, perm, (model.step_counter + 1) % (nb - 1)), 0)   # skip the ragged last batch
+            return loss
+
+    run(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
+    loss = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -141,7 +163,7 @@ def bench_metamodel(args):
             "config": {"workload": "MetaModel (DR4SR+) around SASRec on amazon-toys-shaped synthetic rows (BASELINE configs[4]): weighted "
                                    "inner step every step + hyper-gradient outer step every %d steps, B=%d rows/GPU/step, dropout %.2f"
                                    % (args.interval, B, args.dropout),
-                       "global_batch": B * world, "seq_len": 50, "parallelism": "dp%d" % world, "hip_graph": False},
+                       "global_batch": B * world, "seq_len": 50, "parallelism": "dp%d" % world, "hip_graph": True},
             "outer_step_ms": outer_ms, "final_loss": float(loss)}))
     if world > 1:
         dist.destroy_process_group()

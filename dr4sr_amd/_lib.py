@@ -48,6 +48,12 @@ class SasrecPlan(C.Structure):
     ]
 
 
+class MetaWeighting(C.Structure):
+    """mirror of `dr4sr_meta_weighting` (include/dr4sr_hip.h)"""
+    _fields_ = [("phi", _f32p), ("gumbel", _f32p), ("user_id", _i64p), ("gate_in", C.c_void_p), ("gate_out", C.c_void_p),
+                ("weight_out", _f32p), ("tau", C.c_float)]
+
+
 class FmlpPlan(C.Structure):
     """mirror of `dr4sr_fmlp_plan` (include/dr4sr_hip.h)"""
     _fields_ = [
@@ -96,6 +102,7 @@ SYMBOLS = {
     "dr4sr_sasrec_workspace_bytes": (C.c_int64, [_PLANP]),
     "dr4sr_sasrec_fwd_bwd": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_adam_step": (C.c_int, [_PLANP, C.c_void_p]),
+    "dr4sr_sasrec_fwd_bwd_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_void_p]),
     "dr4sr_sasrec_train_step": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_sasrec_encode": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_sasrec_encode_bwd": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),

@@ -504,6 +504,11 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
 struct ScoreTileArgs {
     const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq; int64_t* neg_item; float* part;
     int sample_neg, n_items, B, L;
+    // MetaModel (DR4SR+) weighted loss, fused: weight_t = selection(z_t; phi) with the masks of metamodel.py:180-185; the loss
+    // becomes sum_t weight_t loss_t and dz gains loss_t * d weight_t / d z_t.  phi == NULL: plain BCE.  (d phi is NOT produced
+    // here: the inner step never uses it and the hyper-gradient takes it from the deterministic dr4sr_meta_select_bwd.)
+    const float* phi; const float* gumbel; const int64_t* user_id; const unsigned long long* gate_in; unsigned long long* gate_out;
+    float* w_out; float inv_tau; uint64_t meta_seed;
 };
 template <int LPT>
 __device__ __forceinline__ float lane_group_sum(float v) {
@@ -511,6 +516,84 @@ __device__ __forceinline__ float lane_group_sum(float v) {
     for (int o = LPT / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// MetaModel.selection for ONE token inside the scorer (D = 64: 16 lanes per token, lane l holds z[4l..4l+3] and owns hidden units
+// 4l..4l+3 of the 64->64->2 MLP; W1 is read from L1/L2 — phi is 17 KB).  Returns weight_t and, in dzw, loss_t * d weight_t / d z
+// for this lane's 4 features.  Same noise / mask conventions as csrc/meta.hip (position index p = b*L + pos).
+__device__ __forceinline__ float meta_weight_token(const ScoreTileArgs& S, const float4& q, float lt, int b, int pos, int64_t row, int t,
+                                                   int sub, uint32_t step, float4& dzw) {
+    constexpr int MD = 64;
+    const float* W1 = S.phi;
+    const float* b1 = S.phi + MD * MD;
+    const float* W2 = b1 + MD;                               // [2][64]
+    const float* b2 = W2 + 2 * MD;
+    float pre[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pre[k] = b1[4 * sub + k];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                           // z[4s..4s+3] from lane s of the group
+        const float z0 = __shfl(q.x, s, 16), z1 = __shfl(q.y, s, 16), z2 = __shfl(q.z, s, 16), z3 = __shfl(q.w, s, 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 wv = ld4(W1 + (size_t)(4 * sub + k) * MD + 4 * s);
+            pre[k] = fmaf(wv.x, z0, fmaf(wv.y, z1, fmaf(wv.z, z2, fmaf(wv.w, z3, pre[k]))));
+        }
+    }
+    unsigned long long gate;
+    if (S.gate_in) gate = S.gate_in[t];
+    else {
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine |= (unsigned long long)(pre[k] > 0.f) << (4 * sub + k);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mine |= __shfl_xor(mine, o, 16);
+        gate = mine;
+    }
+    float h[4], s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = 4 * sub + k;
+        h[k] = ((gate >> j) & 1ull) ? pre[k] : 0.f;
+        s0 = fmaf(W2[j], h[k], s0);
+        s1 = fmaf(W2[MD + j], h[k], s1);
+    }
+    s0 = lane_group_sum<16>(s0) + b2[0];
+    s1 = lane_group_sum<16>(s1) + b2[1];
+    float g0, g1;
+    const int64_t p = (int64_t)b * S.L + pos;
+    if (S.gumbel) { g0 = S.gumbel[2 * p]; g1 = S.gumbel[2 * p + 1]; }
+    else {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)p, (uint32_t)(p >> 32), 0x6D657461u, step),
+                                      make_uint2((uint32_t)S.meta_seed, (uint32_t)(S.meta_seed >> 32)));
+        const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        g0 = -logf(-logf(u0)); g1 = -logf(-logf(u1));
+    }
+    const float y = 1.0f / (1.0f + expf(-((s0 + g0) - (s1 + g1)) * S.inv_tau));
+    const bool forced = S.user_id && S.user_id[row] == 0;        // metamodel.py:180-183: pattern rows -> weight 1
+    const float wt = forced ? 1.0f : y;
+    if (sub == 0) {
+        if (S.w_out) S.w_out[t] = wt;
+        if (S.gate_out) S.gate_out[t] = gate;
+    }
+    dzw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!forced) {
+        const float dzl = lt * y * (1.0f - y) * S.inv_tau;
+        float dh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = 4 * sub + k; dh[k] = ((gate >> j) & 1ull) ? (W2[j] - W2[MD + j]) * dzl : 0.f; }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                       // d z[4 sub..] += sum_j W1[j][4 sub..] dh_j, units j = 4s..4s+3 from lane s
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dj = __shfl(dh[k], s, 16);
+                const float4 wv = ld4(W1 + (size_t)(4 * s + k) * MD + 4 * sub);
+                dzw.x = fmaf(wv.x, dj, dzw.x); dzw.y = fmaf(wv.y, dj, dzw.y); dzw.z = fmaf(wv.z, dj, dzw.z); dzw.w = fmaf(wv.w, dj, dzw.w);
+            }
+        }
+    }
+    return wt;
+}
+
 template <int BM, int D>
 __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile) {
     constexpr int LPT = D / 4, TPB = 256 / LPT;
@@ -538,9 +621,16 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
                 const float4 q = ld4(A.z + (size_t)t * D + c), ep = ld4(S.E + tgt * D + c), en = ld4(S.E + ng * D + c);
                 const float sp = lane_group_sum<LPT>(q.x * ep.x + q.y * ep.y + q.z * ep.z + q.w * ep.w);
                 const float sn = lane_group_sum<LPT>(q.x * en.x + q.y * en.y + q.z * en.z + q.w * en.w);
-                if (sub == 0) { lsum += softplus_f(-sp) + softplus_f(sn); cnt += 1.f; }
-                const float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn);
-                dz = make_float4(dpos * ep.x + dneg * en.x, dpos * ep.y + dneg * en.y, dpos * ep.z + dneg * en.z, dpos * ep.w + dneg * en.w);
+                const float lt = softplus_f(-sp) + softplus_f(sn);
+                float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn), wt = 1.0f;
+                float4 dzw = make_float4(0.f, 0.f, 0.f, 0.f);          // loss_t * d weight_t / d z_t
+                if constexpr (D == 64) {
+                    if (S.phi) wt = meta_weight_token(S, q, lt, b, pos, row, t, sub, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], dzw);
+                }
+                if (sub == 0) { lsum += wt * lt; cnt += 1.f; }
+                dpos *= wt; dneg *= wt;
+                dz = make_float4(dpos * ep.x + dneg * en.x + dzw.x, dpos * ep.y + dneg * en.y + dzw.y, dpos * ep.z + dneg * en.z + dzw.z,
+                                 dpos * ep.w + dneg * en.w + dzw.w);
                 float* gp = S.dE + tgt * D + c;
                 float* gn = S.dE + ng * D + c;
                 unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
@@ -639,12 +729,18 @@ static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const Po
     return DR4SR_LAUNCH_CHECK();
 }
 // post_fwd + scorer/BCE fwd+bwd + post_bwd of the LAST layer in one launch (training step only)
-int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s, const dr4sr_meta_weighting* mw) {
     const int layer = p->n_layer - 1;
     const PostArgs A = make_post_args(p, ws, layer, training);
     ScoreTileArgs S;
     S.E = p->params + ws.off[0]; S.dE = p->grads + ws.off[0]; S.target = p->item_id; S.rows = p->rows; S.cu = ws.cu; S.tile_seq = ws.tile_seq;
     S.neg_item = p->neg_item; S.part = ws.score_part; S.sample_neg = p->sample_neg; S.n_items = p->n_items; S.B = p->B; S.L = p->L;
+    S.phi = nullptr; S.gumbel = nullptr; S.user_id = nullptr; S.gate_in = nullptr; S.gate_out = nullptr; S.w_out = nullptr; S.inv_tau = 1.f;
+    S.meta_seed = p->seed;
+    if (mw) {
+        S.phi = mw->phi; S.gumbel = mw->gumbel; S.user_id = mw->user_id; S.gate_in = (const unsigned long long*)mw->gate_in;
+        S.gate_out = (unsigned long long*)mw->gate_out; S.w_out = mw->weight_out; S.inv_tau = 1.0f / mw->tau;
+    }
     const int bm = tile_rows(ws);
     return bm == 16 ? post_mid_bm<16>(p, ws, A, S, s) : bm == 32 ? post_mid_bm<32>(p, ws, A, S, s) : post_mid_bm<64>(p, ws, A, S, s);
 }

@@ -246,6 +246,28 @@ class MetaModel(BaseModel):
         tail[1:2].copy_(torch.dot(w, lp).view(1))      # reported loss only
         return w, lp
 
+    def _fused_ok(self) -> bool:
+        """SASRec sub-model with d = 64: the weighting runs inside the fused training step (dr4sr_sasrec_fwd_bwd_weighted)"""
+        import os
+        from .sasrec import SASRec
+        return isinstance(self.sub_model, SASRec) and self.embed_dim == 64 and not os.environ.get("DR4SR_META_DENSE")
+
+    def _fused_weighted(self, batch, gate_in=None, gate_out=None, weight_out=None):
+        """un-normalised d/dW of sum_p weight_p loss_p through the 12-launch fused step (no d/dphi: see include/dr4sr_hip.h)"""
+        eng = self.engine
+        plan = self.sub_model._batch_plan(batch)
+        mw = _lib.MetaWeighting()
+        mw.phi = self._phi.params.data_ptr()
+        mw.gumbel = self._gumbel.data_ptr() if self._gumbel is not None else None
+        uid = batch["user_id"].contiguous()
+        mw.user_id = uid.data_ptr()
+        for name, t in (("gate_in", gate_in), ("gate_out", gate_out), ("weight_out", weight_out)):
+            if t is not None:
+                setattr(mw, name, t.data_ptr())
+        mw.tau = self._tau_eff()
+        _lib.check(self.lib.dr4sr_sasrec_fwd_bwd_weighted(C.byref(plan), C.byref(mw), _lib.cur_stream()), "dr4sr_sasrec_fwd_bwd_weighted")
+        self._keep_mw = (uid, gate_in, gate_out, weight_out)
+
     def _reduce_grads(self):
         if self.world_size > 1:
             allreduce_flat(self.engine.grads)
@@ -274,10 +296,65 @@ class MetaModel(BaseModel):
             return out
         perm = self._perm(loader)
         nb = len(loader)
+        if self._fused_ok() and self.world_size == 1 and bool(self.config["train"].get("hip_graph", True)):
+            return [[{"loss_0": self._fused_meta_epoch(loader, perm, nepoch)}]]
         losses = torch.empty(nb, dtype=torch.float32, device=self.device)
         for i in range(nb):
             losses[i] = self._train_batch(self._local_batch(loader, perm, i), nepoch)
         return [[{"loss_0": losses}]]
+
+    def _fused_meta_epoch(self, loader, perm, nepoch):
+        """weighted epoch with NO per-step host work: batch selection, negatives, Gumbel noise, weighting, backward, Adam and the
+        loss log all run on the device, `steps_per_graph` steps per captured graph; graphs never straddle an outer-loop boundary"""
+        sub, eng = self.sub_model, self.engine
+        B, n, nb = loader.batch_size, loader.n, len(loader)
+        if getattr(self, "_perm_buf", None) is None or self._perm_buf.shape[0] != n:
+            self._perm_buf = torch.empty(n, dtype=torch.int64, device=self.device)
+            self._perm_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if getattr(self, "_loss_log", None) is None or self._loss_log.shape[0] != nb:
+            self._loss_log = torch.empty(nb, dtype=torch.float32, device=self.device)
+        self._perm_buf.copy_(perm)
+        self._perm_counter.zero_()
+        group, interval = int(self.config["train"].get("steps_per_graph", 4)), int(self.config["train"]["interval"])
+        i = 0
+        while i < nb:
+            bl = min(B, n - i * B)
+            full_left = (n // B) - i if bl == B else 1          # equally sized batches ahead (the ragged tail runs alone)
+            k = max(1, min(group, interval - self.step_counter % interval, full_left))
+            self._meta_step_graph(loader.fields, bl, k)()
+            self.counter += k
+            self.step_counter += k
+            i += k
+            if self.step_counter % interval == 0:
+                self._outter_loop(nepoch)
+        return self._loss_log.clone()
+
+    def _meta_step_graph(self, fields, bl, k):
+        key = ("inner", fields["in_item_id"].data_ptr(), bl, k)
+        if key in self._graphs:
+            return self._graphs[key]
+        sub, eng, lib = self.sub_model, self.engine, self.lib
+        plan = sub._train_plan(fields, sub._rows_buf[:bl], perm_sel=(self._perm_buf, self.config["train"]["batch_size"], 0, self._perm_counter),
+                               loss_log=self._loss_log)
+        mw = _lib.MetaWeighting()
+        mw.phi, mw.user_id, mw.tau = self._phi.params.data_ptr(), fields["user_id"].data_ptr(), self._tau_eff()
+        self._keep_inner = getattr(self, "_keep_inner", []) + [plan, mw]
+
+        def body():
+            for _ in range(k):
+                _lib.check(lib.dr4sr_sasrec_fwd_bwd_weighted(C.byref(plan), C.byref(mw), _lib.cur_stream()), "fwd_bwd_weighted")
+                eng.adam_step(plan)
+        undo = [eng.params, eng.adam_m, eng.adam_v, eng.state, self._perm_counter]
+        snap = [t.clone() for t in undo]
+        body()                                             # warm-up outside capture, side effects undone
+        torch.cuda.synchronize()
+        for dst, src in zip(undo, snap):
+            dst.copy_(src)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            body()
+        self._graphs[key] = g.replay
+        return g.replay
 
     def _train_batch(self, batch, nepoch):
         """one post-warm-up iteration of metamodel.py:101-120: weighted step, sub-model Adam, outer loop on the interval"""
@@ -291,7 +368,10 @@ class MetaModel(BaseModel):
         else:
             if bl > 0:
                 batch["neg_item"] = self._neg_sampling(batch)
-                self._weighted_fwd_bwd(batch)
+                if self._fused_ok():
+                    self._fused_weighted(batch)
+                else:
+                    self._weighted_fwd_bwd(batch)
             else:                                          # a rank whose slice of the tail batch is empty contributes zeros
                 eng.grads.zero_()
                 self._phi.grads.zero_()
@@ -323,7 +403,10 @@ class MetaModel(BaseModel):
         def fwd_bwd():
             _lib.check(lib.dr4sr_neg_sample_dev(_lib.ptr(st["neg_item"]), tgt.numel(), self.num_items, eng.seed ^ 0x5DEECE66D,
                                                 _lib.ptr(self._noise_step()), _lib.cur_stream()), "neg_sample_dev")
-            self._weighted_fwd_bwd(st)
+            if self._fused_ok():
+                self._fused_weighted(st)
+            else:
+                self._weighted_fwd_bwd(st)
 
         def adam():
             eng.adam_step(sub._api_plan())
@@ -390,12 +473,22 @@ class MetaModel(BaseModel):
         gate = self._buf("gate", bt[self.fiid].numel(), torch.int64)
         q0 = sub._encode_raw(bt, True)
         self._select_fwd(q0, bt["user_id"].contiguous(), bt[self.fiid].contiguous(), self._gumbel, None, gate)
+        fused = self._fused_ok()
+        gate_packed = None
+        if fused:                                          # the same frozen pattern in the fused step's packed-token order
+            gate_packed = self._buf("gate_packed", bt[self.fiid].numel(), torch.int64)
+            eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0)
+            self._fused_weighted(bt, gate_out=gate_packed)
 
-        def probe(direction, sign):
+        def probe(direction, sign, need_phi=False):
+            """d/dW (and, for the two mixed-derivative probes, the deterministic d/dphi) of L_train at W0 + sign * e * direction"""
             _lib.check(lib.dr4sr_fd_shift(_lib.ptr(eng.params), _lib.ptr(theta0), _lib.ptr(direction), _lib.ptr(self._e), sign, n,
                                           st()), "fd_shift")
             eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0)
-            self._weighted_fwd_bwd(bt, gate_in=gate)
+            if fused and not need_phi:
+                self._fused_weighted(bt, gate_in=gate_packed)
+            else:
+                self._weighted_fwd_bwd(bt, gate_in=gate)
             self._reduce_grads()
 
         for _ in range(mo.truncate_iter):                                                             # utils.py:180-205
@@ -408,10 +501,10 @@ class MetaModel(BaseModel):
         # mixed second derivative d/dphi (dL_train/dW . p)                                               utils.py:170-178
         _lib.check(lib.dr4sr_fd_step_size(_lib.ptr(theta0), _lib.ptr(pacc), n, rel, _lib.ptr(self._e), st()), "fd_step_size")
         fp = self._buf("fp", nphi)
-        probe(pacc, 1.0)
+        probe(pacc, 1.0, need_phi=True)
         fp.copy_(self._phi.grads)
         self._tail_p.copy_(eng.grads[n:n + _lib.GRAD_TAIL])
-        probe(pacc, -1.0)
+        probe(pacc, -1.0, need_phi=True)
         hyper = self._buf("hyper", nphi)
         _lib.check(lib.dr4sr_fd_diff(_lib.ptr(hyper), _lib.ptr(fp), _lib.ptr(self._phi.grads), _lib.ptr(self._tail_p[0:1]),
                                      _lib.ptr(eng.grads[n:n + 1]), _lib.ptr(self._e), -1.0, nphi, st()), "fd_diff")

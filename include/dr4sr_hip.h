@@ -290,6 +290,23 @@ int dr4sr_meta_select_bwd(const float* query, const float* phi, const float* gum
                           const uint64_t* gate_in, const float* d_weight, const float* scale, float* d_query, float* d_phi,
                           float* workspace, void* stream);
 
+/* MetaModel's weighted loss fused into the SASRec training step (the fast path of dr4sr_amd/model/metamodel.py): the per-token
+ * scorer computes weight_t = selection(z_t; phi) itself (same masks, noise keyed by (plan->seed, state[RNGSTEP], b*L+pos) exactly
+ * like dr4sr_meta_select_fwd with step_dev = &state[RNGSTEP]) and back-propagates sum_t weight_t loss_t including
+ * loss_t * d weight_t / d z_t.  grads tail = {n_valid, sum_t weight_t loss_t}.  d phi is NOT produced (the inner step never uses it;
+ * the hyper-gradient takes it from dr4sr_meta_select_bwd).  gate_in / gate_out / weight_out are indexed by PACKED token
+ * (workspace order: sequence by sequence, valid positions only), [B*L] words are enough.  D = 64 only. */
+typedef struct dr4sr_meta_weighting {
+    const float*   phi;             /* flat meta parameters (dr4sr_meta_param_count floats)                      */
+    const float*   gumbel;          /* [B,L,2] explicit noise or NULL (Philox)                                   */
+    const int64_t* user_id;         /* [U] addressed like the other dataset tensors (through plan->rows), or NULL */
+    const uint64_t* gate_in;        /* frozen ReLU pattern per packed token, or NULL                             */
+    uint64_t*      gate_out;        /* pattern used, per packed token, or NULL                                   */
+    float*         weight_out;      /* weight per packed token, or NULL                                          */
+    float          tau;             /* clip(tau, tau_min)                                                        */
+} dr4sr_meta_weighting;
+int dr4sr_sasrec_fwd_bwd_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream);
+
 /* Hypergrad.grad (utils/utils.py:145-205) from FIRST-ORDER gradients: with G(W) = dL_train/dW (this library's backward),
  *     H v            = [G(W + e v) - G(W - e v)] / 2e                      (Neumann terms; scaled by hpo_lr, :196-203)
  *     d/dphi (G . p) = [dL_train/dphi(W + e p) - dL_train/dphi(W - e p)] / 2e   (:170-175)

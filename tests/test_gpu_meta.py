@@ -156,6 +156,44 @@ def test_inner_weighted_step_matches_reference(golden_dir, monkeypatch):
         assert rel((p.grad / nv).cpu().numpy(), z["inner.meta_grad." + n]) < 3e-4, n
 
 
+def test_fused_weighted_step_matches_reference_and_dense_path(golden_dir, monkeypatch):
+    """dr4sr_sasrec_fwd_bwd_weighted (selection + weighting inside the 12-launch fused step) == the reference's inner step on the
+    golden batch, and == the dense C-ABI composition under dropout with Philox Gumbel noise (same RNG step)"""
+    from dr4sr_amd import _lib
+    z = np.load(os.path.join(golden_dir, "metamodel_sasrec.npz"))
+    ds, model = build(make_config(int(z["meta.num_items"])), monkeypatch)
+    z, bt, bv = load_golden(golden_dir, model)
+    model.train()
+    sub, eng = model.sub_model, model.engine
+    assert model._fused_ok()
+    B, L = bt["item_id"].shape
+    w = torch.zeros(B * L, device=model.device)
+    model._fused_weighted(bt, weight_out=w)
+    nv = float(eng.grads[eng.n_params])
+    assert nv == float((bt["item_id"] != 0).sum())
+    assert abs(float(eng.grads[eng.n_params + 1]) / nv - float(z["inner.loss"])) < 3e-6
+    valid = (bt["item_id"] != 0).cpu().numpy()
+    np.testing.assert_allclose(w.cpu().numpy()[:int(valid.sum())], z["inner.weight"][valid], rtol=1e-4, atol=1e-6)   # packed order
+    for n, p in sub.named_parameters():
+        ref = z["inner.grad." + n]
+        assert rel((p.grad / nv).cpu().numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-7, n
+    # dropout + in-kernel Gumbel noise: fused == dense composition when both start from the same RNG step
+    cfg = make_config(int(z["meta.num_items"]), dropout=0.3)
+    ds2, m2 = build(cfg, monkeypatch)
+    m2.train()
+    e2 = m2.engine
+    bt2 = {k: v.clone() for k, v in bt.items()}
+    rng = e2.state[3:4].clone()
+    m2._fused_weighted(bt2)
+    g_fused = e2.grads.clone()
+    e2.state[3:4].copy_(rng)
+    m2._weighted_fwd_bwd(bt2)
+    g_dense = e2.grads.clone()
+    n = e2.n_params
+    assert float(g_fused[n]) == float(g_dense[n]) and abs(float(g_fused[n + 1]) - float(g_dense[n + 1])) < 1e-3
+    assert rel(g_fused[:n].cpu().numpy(), g_dense[:n].cpu().numpy()) < 1e-4
+
+
 def test_hypergradient_and_meta_sgd_match_reference(golden_dir, monkeypatch):
     z = np.load(os.path.join(golden_dir, "metamodel_sasrec.npz"))
     ds, model = build(make_config(int(z["meta.num_items"])), monkeypatch)
