@@ -85,6 +85,9 @@ struct WgradArgs {
     const float* score_part; float* tail; int B; int D;
     int score_tiles;                           // 1: score_part holds one (count, loss) pair per token tile instead of per sequence
     int ln_tile_rows;                          // token rows per LayerNorm-partial row (tile size of the post kernels)
+    // embedding scatter job (blockIdx.y == 7, large batches; sc_g == NULL: none)
+    const float* sc_g; const int64_t* sc_idx; const int64_t* sc_rows; const int* sc_tile_seq; const int* cu;
+    float* sc_dE; float* sc_dP; int sc_L; int sc_n_items;
 };
 
 int ffn_tile_rows(int Tmax);

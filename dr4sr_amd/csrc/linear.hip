@@ -67,6 +67,12 @@ int tile_rows(const Workspace& ws) {
     if (forced == 16 || forced == 32 || forced == 64) return forced;
     return ws.Tmax <= 16384 ? 16 : 32;
 }
+// large batches: the table-gradient scatter of the embedding stage (T x D fp32 atomics, ~55 G/s: 0.47 ms of the dense B=8192 step
+// when it sits at the end of k_qkv_embed_bwd) runs as an extra job of k_wgrad, where it overlaps the MFMA-bound weight-gradient jobs
+static bool scatter_in_wgrad(const Workspace& ws) {
+    static const bool off = getenv("DR4SR_SCATTER_INLINE") != nullptr || getenv("DR4SR_NO_FUSE") != nullptr;
+    return !off && ws.Tmax > 16384;
+}
 #define BM_DISPATCH(bm, CALL) do { if ((bm) == 16) { CALL(16); } else if ((bm) == 32) { CALL(32); } else { CALL(64); } } while (0)
 
 int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s) {
@@ -594,7 +600,8 @@ __device__ __forceinline__ float meta_weight_token(const ScoreTileArgs& S, const
     return wt;
 }
 
-template <int BM, int D>
+// META: with the MetaModel selection weight (a separate instantiation — its registers cost the plain kernel an occupancy step)
+template <int BM, int D, bool META>
 __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile) {
     constexpr int LPT = D / 4, TPB = 256 / LPT;
     const int c = (threadIdx.x % LPT) * 4, sub = threadIdx.x % LPT;
@@ -624,7 +631,7 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
                 const float lt = softplus_f(-sp) + softplus_f(sn);
                 float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn), wt = 1.0f;
                 float4 dzw = make_float4(0.f, 0.f, 0.f, 0.f);          // loss_t * d weight_t / d z_t
-                if constexpr (D == 64) {
+                if constexpr (D == 64 && META) {
                     if (S.phi) wt = meta_weight_token(S, q, lt, b, pos, row, t, sub, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], dzw);
                 }
                 if (sub == 0) { lsum += wt * lt; cnt += 1.f; }
@@ -658,13 +665,13 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
     }
 }
 
-template <int BM, int D, int F>
+template <int BM, int D, int F, bool META>
 __global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) {
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
     post_fwd_body<BM, D, F, false>(A, t0, T);
     __syncthreads();                                   // z rows of this tile are visible to the whole workgroup
-    score_tile<BM, D>(A, S, t0, T, blockIdx.x);
+    score_tile<BM, D, META>(A, S, t0, T, blockIdx.x);
     __syncthreads();                                   // dz rows written, LDS scratch free again
     post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x);
 }
@@ -720,7 +727,12 @@ template <int BM>
 static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, const ScoreTileArgs& S, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
     const size_t lds = post_lds(p->D, p->F, BM);
-#define PM(D_, F_) do { big_lds(k_post_mid<BM, D_, F_>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_>), grid, blk, lds, s, A, S); } while (0)
+#define PM(D_, F_) do { big_lds(k_post_mid<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_, false>), grid, blk, lds, s, A, S); } while (0)
+    if (S.phi) {                                       // MetaModel weighting: D = 64 only (checked by the entry point)
+        if (p->D != 64 || p->F != 128) return DR4SR_E_SHAPE;
+        big_lds(k_post_mid<BM, 64, 128, true>, lds); hipLaunchKernelGGL((k_post_mid<BM, 64, 128, true>), grid, blk, lds, s, A, S);
+        return DR4SR_LAUNCH_CHECK();
+    }
     if (p->D == 64 && p->F == 128) PM(64, 128);
     else if (p->D == 128 && p->F == 128) PM(128, 128);
     else if (p->D == 64 && p->F == 256) PM(64, 256);
@@ -823,6 +835,7 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 struct QkvEmbBwdArgs {
     const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
     float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
+    float* gout;                 // large batches: masked dx0 rows are stored here and scattered by a job of k_wgrad (overlaps its MFMA work)
 };
 template <int BM, int D>
 __global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
@@ -856,6 +869,7 @@ __global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
                 const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * A.L + pos) * D + c);
                 g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
             }
+            if (A.gout) { st4(A.gout + (size_t)t * D + c, g); continue; }
             float* a = accP + pos * D + c;
             atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); atomicAdd(a + 3, g.w);
             const int64_t id = A.idx[row * A.L + pos];
@@ -865,6 +879,7 @@ __global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
             }
         }
     }
+    if (A.gout) return;
     __syncthreads();
     for (int i = threadIdx.x; i < A.L * D; i += 256) {
         const float v = accP[i];
@@ -881,6 +896,7 @@ int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int tr
     A.dQKV = lw.dqkv; A.W = p->params + poff(ws, 0, P_IN_W); A.dU1 = lw.du1; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu; A.tile_seq = ws.tile_seq;
     A.dE = p->grads + ws.off[0]; A.dP = p->grads + ws.off[1]; A.state = p->state; A.B = p->B; A.L = p->L; A.n_items = p->n_items;
     A.training = training; A.seed = p->seed; A.p = p->p_drop;
+    A.gout = scatter_in_wgrad(ws) ? ws.dX[0] : nullptr;
 #define QE(B_) do { if (D == 64) { big_lds(k_qkv_embed_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 64>), grid, blk, lds, s, A); } \
                     else { big_lds(k_qkv_embed_bwd<B_, 128>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 128>), grid, blk, lds, s, A); } } while (0)
     BM_DISPATCH(bm, QE);
@@ -1025,10 +1041,50 @@ __device__ __forceinline__ void reduce_jobs(const WgradArgs& A) {
     }
 }
 
-// blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2, 6: reductions), blockIdx.z = layer
+// a3 backward for large batches: dE[idx[t]] += g[t] (not PAD), dP[pos[t]] += g[t] with g = masked dx0 rows left by
+// k_qkv_embed_bwd.  16 lanes per token; dP accumulates in LDS and is flushed once per workgroup.
+template <int D>
+__device__ __forceinline__ void scatter_job(const WgradArgs& A) {
+    constexpr int LPT = D / 4, TPB = 256 / LPT;
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + 63) / 64;
+    if ((int)blockIdx.x >= ntiles) return;
+    float* accP = smem;                                   // [L][D]
+    for (int i = threadIdx.x; i < A.sc_L * D; i += 256) accP[i] = 0.f;
+    __syncthreads();
+    const int c = (threadIdx.x % LPT) * 4;
+    for (int tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += TPB) {
+            const int t = tt * 64 + r0 + threadIdx.x / LPT;
+            if (t < T) {
+                const int b = find_seq_from(A.cu, A.B, t, A.sc_tile_seq[t >> 4]), pos = t - A.cu[b];
+                const int64_t row = A.sc_rows ? A.sc_rows[b] : b;
+                const int64_t id = A.sc_idx[row * A.sc_L + pos];
+                const float4 g = ld4(A.sc_g + (size_t)t * D + c);
+                float* a = accP + pos * D + c;
+                atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); atomicAdd(a + 3, g.w);
+                if (id > 0 && id < A.sc_n_items) {
+                    float* d = A.sc_dE + id * D + c;
+                    unsafeAtomicAdd(d, g.x); unsafeAtomicAdd(d + 1, g.y); unsafeAtomicAdd(d + 2, g.z); unsafeAtomicAdd(d + 3, g.w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.sc_L * D; i += 256) {
+        const float v = accP[i];
+        if (v != 0.f) unsafeAtomicAdd(A.sc_dP + i, v);
+    }
+}
+
+// blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2, 6: reductions; with the embedding scatter: y = 0 is the scatter
+// [layer 0 only] and the others shift by one), blockIdx.z = layer
 template <int D, int F>
 __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A) {
-    const int j = blockIdx.y;
+    // the scatter blocks come FIRST in dispatch order (y = 0): the other jobs are persistent loops, so blocks dispatched after
+    // the first resident wave would only start when those finish — no overlap
+    const int j = A.sc_g ? (int)blockIdx.y - 1 : (int)blockIdx.y;
+    if (j < 0) { if (blockIdx.z == 0) scatter_job<D>(A); return; }
     if (j == 6) { reduce_jobs(A); return; }
     const WgradJob& J = A.job[blockIdx.z * 6 + j];
     if (j < 4) wgrad_body<D, D>(J, A);
@@ -1110,8 +1166,15 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 48;   // tuning knob
     int gw_t = ntiles / 16 > gw_max ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : gw_max;   // >= 16 token tiles per workgroup at scale
     int gw = ntiles < gw_t ? ntiles : gw_t;
-    dim3 grid(gw, 7, p->n_layer), blk(256);
-    const size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
+    A.sc_g = nullptr;
+    const bool scatter = scatter_in_wgrad(ws) && with_score != 1;       // paired with launch_qkv_embed_bwd (not the unfused debug path)
+    if (scatter) {
+        A.sc_g = ws.dX[0]; A.sc_idx = p->in_item_id; A.sc_rows = p->rows; A.sc_tile_seq = ws.tile_seq; A.cu = ws.cu;
+        A.sc_dE = G + ws.off[0]; A.sc_dP = G + ws.off[1]; A.sc_L = p->L; A.sc_n_items = p->n_items;
+    }
+    dim3 grid(gw, scatter ? 8 : 7, p->n_layer), blk(256);
+    size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
+    if (scatter && sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;
     if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A); }
     else if (D == 128 && F == 128) { big_lds(k_wgrad<128, 128>, lds); hipLaunchKernelGGL((k_wgrad<128, 128>), grid, blk, lds, s, A); }
     else if (D == 64 && F == 256) { big_lds(k_wgrad<64, 256>, lds); hipLaunchKernelGGL((k_wgrad<64, 256>), grid, blk, lds, s, A); }
