@@ -331,17 +331,28 @@ def main():
                 step_eager()
             stream.synchronize()
             use_graph = not args.no_graph
+            group = 1
             if use_graph and world == 1:
                 # batch selection runs on the device, so consecutive training steps need no host work at all: `group` whole steps
-                # are captured into one graph (a graph launch costs ~6 us of idle GPU between replays at this step size)
-                group = max(1, min(args.steps_per_graph, steps)) if steps % max(1, args.steps_per_graph) == 0 and \
-                    warmup % max(1, args.steps_per_graph) == 0 else 1
-                g_all = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_all, stream=stream, capture_error_mode="thread_local"):
-                    for _ in range(group):
-                        select()
-                        eng.train_step(plan)
-                run = g_all.replay
+                # are captured into one graph (a graph launch costs ~8 us of idle GPU between replays at this step size); any K / W
+                # is served by that graph plus a one-step graph for the remainder
+                group = max(1, min(args.steps_per_graph, steps))
+
+                def capture(n):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                        for _ in range(n):
+                            select()
+                            eng.train_step(plan)
+                    return g
+                g_all = capture(group)
+                g_one = capture(1) if group > 1 else g_all
+
+                def run_steps(n):
+                    for _ in range(n // group):
+                        g_all.replay()
+                    for _ in range(n % group):
+                        g_one.replay()
             elif use_graph:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):
@@ -350,16 +361,17 @@ def main():
                 with torch.cuda.graph(g_b, stream=stream, capture_error_mode="thread_local"):
                     eng.adam_step(plan)
 
-                def run():
-                    g_a.replay()
-                    dist.all_reduce(eng.grads)
-                    g_b.replay()
+                def run_steps(n):
+                    for _ in range(n):
+                        g_a.replay()
+                        dist.all_reduce(eng.grads)
+                        g_b.replay()
             else:
-                run = step_eager
-            group = group if (use_graph and world == 1) else 1
+                def run_steps(n):
+                    for _ in range(n):
+                        step_eager()
 
-            for _ in range(warmup // group):
-                run()
+            run_steps(warmup)
             stream.synchronize()
             if world > 1:
                 dist.barrier()
@@ -367,8 +379,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             e0.record()
-            for _ in range(steps // group):
-                run()
+            run_steps(steps)
             e1.record()
             torch.cuda.synchronize()
             if world > 1:

@@ -1,5 +1,5 @@
 """Timeline of ONE steady-state training step from a rocprofv3 --kernel-trace database: per kernel start offset, duration
-and the idle gap before it (averaged over the last `n` steps).  A step = the launches from one k_prep to the next.
+and the idle gap before it (MEDIAN over the last `n` steps: eager warm-up steps and graph-launch boundaries do not smear in).  A step = the launches from one k_prep to the next.
 usage: python tools/ktimeline.py <results.db> [n_steps]"""
 import sqlite3
 import sys
@@ -15,19 +15,22 @@ for a, b in steps:
         lens[b - a] = lens.get(b - a, 0) + 1
 L = max(lens, key=lens.get)                      # the graph-replayed training step (most frequent multi-launch period)
 steps = [(a, b) for a, b in steps if b - a == L][-n_steps:]
-acc = [[0.0, 0.0, 0.0] for _ in range(L)]
-total = 0.0
+import statistics
+cols = [[[], [], []] for _ in range(L)]
+periods = []
 for a, b in steps:
     t0 = rows[a][1]
     for k in range(L):
         name, st, en = rows[a + k]
         prev_end = rows[a + k - 1][2] if k else st
-        acc[k][0] += st - t0
-        acc[k][1] += en - st
-        acc[k][2] += st - prev_end
-    total += rows[b][1] - t0
-n = len(steps)
-print(f"# {n} steps of {L} launches; step period {total / n / 1e3:.2f} us")
+        cols[k][0].append(st - t0)
+        cols[k][1].append(en - st)
+        cols[k][2].append(st - prev_end)
+    periods.append(rows[b][1] - t0)
+n = 1
+acc = [[statistics.median(c[0]), statistics.median(c[1]), statistics.median(c[2])] for c in cols]
+total = statistics.mean(periods)
+print(f"# {len(steps)} steps of {L} launches; mean step period {total / 1e3:.2f} us (includes graph-launch boundaries), median {statistics.median(periods) / 1e3:.2f} us")
 print(f"{'#':>2s} {'kernel':52s} {'start_us':>9s} {'dur_us':>8s} {'gap_us':>7s}")
 busy = 0.0
 for k in range(L):
