@@ -341,9 +341,12 @@ def main():
                 def capture(n):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                        for _ in range(n):
-                            select()
-                            eng.train_step(plan)
+                        if args.model == "sasrec":
+                            eng.train_steps(plan, n)         # one prep per graph; each optimizer launch prepares the next step
+                        else:
+                            for _ in range(n):
+                                select()
+                                eng.train_step(plan)
                     return g
                 g_all = capture(group)
                 g_one = capture(1) if group > 1 else g_all

@@ -48,83 +48,15 @@ extern "C" int dr4sr_embed_gather_posadd(const float* E, const float* P, const i
 // Also bumps the RNG step so that every fwd_bwd draws fresh dropout masks / negatives.
 // Blocks 1.. of the same launch zero the flat gradient (+tail) when `zero` is given (saves a launch per step; a
 // hipMemsetAsync graph node is NOT used: on ROCm 7.2 its replay was observed to fill the last 16 bytes with a stale pattern).
-struct PermSel { const int64_t* perm; int64_t n, stride, offset; int* counter; };
-
-__global__ __launch_bounds__(1024) void k_prep(const int64_t* __restrict__ seqlen, const int64_t* rows,
-                                               int* __restrict__ cu, int* __restrict__ state, int B, int L,
-                                               int bump_rng, float* __restrict__ zero, int64_t zero_n4, PermSel sel,
-                                               int* __restrict__ tile_seq, int* __restrict__ seq_class) {
+#include "prep_body.h"
+__global__ __launch_bounds__(1024) void k_prep(const PrepArgs P, float* __restrict__ zero, int64_t zero_n4) {
     if (blockIdx.x > 0) {
         for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n4; i += (int64_t)(gridDim.x - 1) * 1024)
             st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         return;
     }
-    // one packed scan: bits 0-31 tokens, 32-47 short sequences (1..16 tokens), 48-63 long sequences
     __shared__ unsigned long long part[1024];
-    const int tid = threadIdx.x;
-    if (sel.perm) {                                     // a1: this step's batch = a slice of the epoch permutation
-        const int64_t c = *sel.counter;
-        int64_t* rw = const_cast<int64_t*>(rows);
-        for (int i = tid; i < B; i += 1024) rw[i] = sel.perm[(c * sel.stride + sel.offset + i) % sel.n];
-        __syncthreads();
-        if (tid == 0) *sel.counter = (int)(c + 1);
-    }
-    const int per = (B + 1023) / 1024;
-    const int b0 = tid * per, b1 = min(B, b0 + per);
-    unsigned long long s = 0;
-    constexpr int KEEP = 8;                             // lengths of the first 8 sequences of the chunk stay in registers (B <= 8192):
-    int keep[KEEP];                                     // independent loads issued together instead of 3 x per dependent chains
-#pragma unroll
-    for (int k = 0; k < KEEP; ++k) {
-        int nn = 0;
-        if (b0 + k < b1) {
-            const int64_t n = seqlen[rows ? rows[b0 + k] : b0 + k];
-            nn = (int)(n < 0 ? 0 : (n > L ? L : n));
-        }
-        keep[k] = nn;
-    }
-    auto len_of = [&](int b) -> int {
-        const int k = b - b0;
-        if (k < KEEP) {
-            int v = 0;
-#pragma unroll
-            for (int q = 0; q < KEEP; ++q) v = k == q ? keep[q] : v;
-            return v;
-        }
-        const int64_t n = seqlen[rows ? rows[b] : b];
-        return (int)(n < 0 ? 0 : (n > L ? L : n));
-    };
-    for (int b = b0; b < b1; ++b) {
-        const int nn = len_of(b);
-        s += (unsigned long long)nn + (nn > 0 && nn <= 16 ? (1ull << 32) : 0ull) + (nn > 16 ? (1ull << 48) : 0ull);
-    }
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {               // Hillis-Steele inclusive scan
-        const unsigned long long v = tid >= o ? part[tid - o] : 0ull;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    const unsigned long long ex = part[tid] - s;        // exclusive prefix of this thread's chunk
-    int run = (int)(ex & 0xffffffffull), ns = (int)((ex >> 32) & 0xffff), nl = (int)(ex >> 48);
-    for (int b = b0; b < b1; ++b) {
-        cu[b] = run;
-        const int nn = len_of(b);
-        if (tile_seq)                                   // sequence slot of the first token of every 16-token tile it starts
-            for (int k = (run + 15) >> 4; (k << 4) < run + nn; ++k) tile_seq[k] = b;
-        if (seq_class && nn > 0) {                      // length classes for the split attention launches
-            if (nn <= 16) seq_class[2 + ns++] = b; else seq_class[2 + B + nl++] = b;
-        }
-        run += nn;
-    }
-    if (tid == 1023) {
-        const unsigned long long tot = part[1023];
-        cu[B] = (int)(tot & 0xffffffffull);
-        state[DR4SR_STATE_T] = (int)(tot & 0xffffffffull);
-        if (bump_rng) state[DR4SR_STATE_RNGSTEP] += 1;
-        if (seq_class) { seq_class[0] = (int)((tot >> 32) & 0xffff); seq_class[1] = (int)(tot >> 48); }
-    }
+    prep_body<1024>(P, part);
 }
 
 static int launch_prep_sel(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
@@ -132,21 +64,29 @@ static int launch_prep_sel(const int64_t* seqlen, const int64_t* rows, int* cu, 
     const int64_t n4 = zero ? zero_floats / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024);
     if (zb > 255) zb = 255;
-    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, seqlen, rows, cu, state, B, L, bump_rng, zero, n4, sel, tile_seq, seq_class);
+    const PrepArgs P{seqlen, rows, cu, state, B, L, bump_rng, sel, tile_seq, seq_class};
+    hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, P, zero, n4);
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
                     int64_t zero_floats, hipStream_t s) {
     return launch_prep_sel(seqlen, rows, cu, state, B, L, bump_rng, zero, zero_floats, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, s);
 }
-int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
+int make_prep_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, PrepArgs* out) {
     PermSel sel{nullptr, 0, 0, 0, nullptr};
     if (p->perm && bump_rng) {                          // selection only in the calls that start a new step
         if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
         sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
     }
+    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, sel, ws.tile_seq, ws.seq_class};
+    return 0;
+}
+int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
+    PrepArgs P;
+    const int rc = make_prep_args(p, ws, bump_rng, &P);
+    if (rc) return rc;
     return launch_prep_sel(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, zero_grads ? p->grads : nullptr,
-                           ws.n_params + DR4SR_GRAD_TAIL, sel, ws.tile_seq, ws.seq_class, s);
+                           ws.n_params + DR4SR_GRAD_TAIL, P.sel, ws.tile_seq, ws.seq_class, s);
 }
 
 // ------------------------------------------------------------------------------------------------

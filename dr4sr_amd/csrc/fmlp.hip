@@ -568,7 +568,7 @@ extern "C" int dr4sr_fmlp_fwd_bwd(const dr4sr_fmlp_plan* plan, void* stream) {
 
 extern "C" int dr4sr_adam_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,
                                float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
-    return launch_adam_flat(params, grads, adam_m, adam_v, n, state, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+    return launch_adam_flat(params, const_cast<float*>(grads), adam_m, adam_v, n, state, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);   // (written only when a next-step prep is fused)
 }
 
 extern "C" int dr4sr_fmlp_train_step(const dr4sr_fmlp_plan* plan, void* stream) {

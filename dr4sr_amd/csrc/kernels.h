@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/dr4sr_hip.h"
+#include "prep_body.h"
 
 #define DR4SR_MAX_LAYERS 8
 
@@ -94,12 +95,13 @@ int ffn_tile_rows(int Tmax);
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s);
-int launch_adam_flat(float* P, const float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2, float eps, float wd, hipStream_t s,
-                     float* loss_log = nullptr, const int* log_index = nullptr);
+int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2, float eps, float wd, hipStream_t s,
+                     float* loss_log = nullptr, const int* log_index = nullptr, const PrepArgs* next = nullptr);
 
 int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws);   // fills ws from p->workspace (or sizes only if NULL)
 
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s);
+int make_prep_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, PrepArgs* out);
 int launch_embed_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int mode, hipStream_t s);
@@ -135,4 +137,4 @@ int launch_attn2_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer,
 int launch_attn2_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 
 int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
-int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s);
+int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s, const PrepArgs* next = nullptr);

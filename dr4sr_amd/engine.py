@@ -146,6 +146,10 @@ class SasrecEngine:
     def train_step(self, plan):
         _lib.check(self.lib.dr4sr_sasrec_train_step(C.byref(plan), _lib.cur_stream()), "dr4sr_sasrec_train_step")
 
+    def train_steps(self, plan, n: int):
+        """n consecutive steps (consecutive batches of plan.perm): one prep launch, the optimizer launches prepare the next step"""
+        _lib.check(self.lib.dr4sr_sasrec_train_steps(C.byref(plan), int(n), _lib.cur_stream()), "dr4sr_sasrec_train_steps")
+
     def encode(self, plan, training: bool, pooling: int, out: Optional[torch.Tensor] = None):
         B = plan.B
         shape = (B, self.D) if pooling in (_lib.POOL_LAST, _lib.POOL_MEAN) else (B, self.L, self.D)

@@ -278,8 +278,11 @@ class BaseModel(nn.Module):
 
         if self.world_size == 1:
             def eager():
-                for _ in range(group):
-                    eng.train_step(plan)
+                if group > 1 and hasattr(eng, "train_steps"):
+                    eng.train_steps(plan, group)             # one prep launch per graph (the optimizer launches prepare the next step)
+                else:
+                    for _ in range(group):
+                        eng.train_step(plan)
             if use_graph:
                 warm_up(eager)
                 g = torch.cuda.CUDAGraph()

@@ -126,6 +126,13 @@ int dr4sr_adam_step(const dr4sr_sasrec_plan* plan, void* stream);
 /* fwd_bwd + adam in one call (single-GPU fast path). */
 int dr4sr_sasrec_train_step(const dr4sr_sasrec_plan* plan, void* stream);
 
+/* n_steps iterations of the loop body of BaseModel.training_epoch (basemodel.py:193-199) in one call: with plan->perm set,
+ * consecutive batches of the epoch permutation (perm_counter advances n_steps times), each with fresh dropout masks and
+ * negatives.  Same results as n_steps calls of dr4sr_sasrec_train_step; the optimizer launch of every step but the last
+ * also prepares the step that follows (batch selection, sequence offsets, zeroed gradients), so the call enqueues one prep
+ * kernel instead of n_steps.  After the call plan->grads holds the last step's gradients. */
+int dr4sr_sasrec_train_steps(const dr4sr_sasrec_plan* plan, int32_t n_steps, void* stream);
+
 /* SASRecQueryEncoder.forward + SeqPoolingLayer (sasrec.py:39-75, layers.py:41-50/:69-73).
  * training != 0 applies dropout (RNG step = state[RNGSTEP]) and keeps activations in the
  * workspace for dr4sr_sasrec_encode_bwd.  out: [B,L,D] (NONE/ORIGIN; NONE leaves rows >= seqlen

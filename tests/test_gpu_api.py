@@ -207,3 +207,42 @@ def test_gru4rec_model_api_and_fast_path(golden_dir, tmp_path, monkeypatch):
     cfg2["train"]["weight_decay"] = 1e-4
     out = quickstart.run(cfg2)
     assert {"ndcg@20", "recall@20"} <= set(out) and all(np.isfinite(v) for v in out.values())
+
+
+@pytest.mark.gpu
+def test_train_steps_equals_repeated_train_step():
+    """dr4sr_sasrec_train_steps (one prep, optimizer launches prepare the next step) == k x dr4sr_sasrec_train_step, over
+    consecutive batches of a permutation, with dropout and in-kernel negatives (same RNG steps on both sides)."""
+    import numpy as np
+    from dr4sr_amd.engine import SasrecEngine
+    from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
+    dev = torch.device("cuda", 0)
+    B, L, U, k = 64, 50, 640, 4
+    rows = make_rows(n_rows=U, n_items=TOYS_N_ITEMS, seed=11)
+    data = {n: torch.from_numpy(rows[n]).to(dev) for n in ("in_item_id", "item_id", "seqlen")}
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(U)).to(dev)
+    out = []
+    for fused in (False, True):
+        eng = SasrecEngine(TOYS_N_ITEMS, L, 64, 2, 128, 2, 1e-12, 0.5, B, dev, seed=77, lr=1e-3)
+        g = torch.Generator().manual_seed(5)
+        for kname, v in eng.views.items():
+            v.copy_(torch.ones(v.shape) if "norm" in kname and kname.endswith("weight") else 0.05 * torch.randn(v.shape, generator=g))
+        eng.views["item_embedding.weight"][0] = 0
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        log = torch.zeros(16, dtype=torch.float32, device=dev)
+        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=torch.zeros(B, dtype=torch.int64, device=dev),
+                             neg_item=torch.zeros(B, L, dtype=torch.int64, device=dev), sample_neg=True,
+                             perm_sel=(perm, B, 0, counter), loss_log=log)
+        if fused:
+            eng.train_steps(plan, k)
+            eng.train_steps(plan, 1)
+        else:
+            for _ in range(k + 1):
+                eng.train_step(plan)
+        torch.cuda.synchronize()
+        assert int(counter) == k + 1 and int(eng.state[0]) == k + 1 and int(eng.state[3]) == k + 1
+        out.append((eng.params.clone(), log.clone(), eng.grads.clone()))
+    (p0, l0, g0), (p1, l1, g1) = out
+    assert float(l0[:k + 1].min()) > 0 and torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
+    assert float((p0 - p1).abs().max()) < 2e-5           # fp32 atomics order only
+    assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max())
