@@ -137,14 +137,25 @@ __global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ par
         dm[(size_t)layer * L * FM_D + i] = 0.f;
     }
 }
-// dm[layer][i] = sum over the nblk per-workgroup partials written by k_fmlp_filter_bwd (fixed order)
+// dm[layer][i] = sum over the nblk per-workgroup partials written by k_fmlp_filter_bwd (fixed order -> deterministic).
+// 64 columns per workgroup, the partials split over its 4 waves, 8 independent loads in flight per thread: the first version (one
+// thread walking all 256 partials of a column, 26 workgroups) was a 60 us chain of dependent-latency loads.
 __global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict__ part, float* __restrict__ dm, int nblk, int n) {
-    const int layer = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float* p = part + (size_t)layer * FM_DMBLK * n + i;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += p[(size_t)b * n];
-    dm[(size_t)layer * n + i] = s;
+    __shared__ float red[4][64];
+    const int layer = blockIdx.y, c = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (i < n) {
+        const float* p = part + (size_t)layer * FM_DMBLK * n + i;
+        for (int b = w * 8; b < nblk; b += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (b + u < nblk) acc[u] += p[(size_t)(b + u) * n];
+        }
+    }
+    red[w][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w == 0 && i < n) dm[(size_t)layer * n + i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 // d(complex_weight) += fold(dm)
 __global__ __launch_bounds__(256) void k_fmlp_coef_bwd(float* __restrict__ grads, int64_t o_cw0, int64_t layer_stride,
@@ -533,7 +544,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
     hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < 64 ? p->B : 64), dim3(256), 0, s, E);
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
-    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3((L * FM_D + 255) / 256, nl), dim3(256), 0, s, ws.dm_part, ws.dm,
+    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3((L * FM_D + 63) / 64, nl), dim3(256), 0, s, ws.dm_part, ws.dm,
                        p->B < FM_DMBLK ? p->B : FM_DMBLK, L * FM_D);
     hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl, ((L / 2 + 1) * FM_D + 255) / 256), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
     WgradArgs W{};

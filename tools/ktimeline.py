@@ -1,5 +1,6 @@
 """Timeline of ONE steady-state training step from a rocprofv3 --kernel-trace database: per kernel start offset, duration
-and the idle gap before it (MEDIAN over the last `n` steps: eager warm-up steps and graph-launch boundaries do not smear in).  A step = the launches from one k_prep to the next.
+and the idle gap before it (MEDIAN over the last `n` steps: eager warm-up steps and graph-launch boundaries do not smear in).  A step = the launches after one k_adam up to the next k_adam; the most frequent launch count is shown (steps that carry
+their own k_prep — the first of each graph — have one more).
 usage: python tools/ktimeline.py <results.db> [n_steps]"""
 import sqlite3
 import sys
@@ -7,8 +8,9 @@ import sys
 c = sqlite3.connect(sys.argv[1])
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
-starts = [i for i, r in enumerate(rows) if r[0].startswith("k_prep")]
-steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
+# a step ends with its optimizer launch (k_adam); since dr4sr_sasrec_train_steps only the first step of a graph has its own k_prep
+ends = [i for i, r in enumerate(rows) if r[0].startswith("k_adam")]
+steps = [(ends[i] + 1, ends[i + 1] + 1) for i in range(len(ends) - 1)]
 lens = {}
 for a, b in steps:
     if b - a > 1:
@@ -26,7 +28,7 @@ for a, b in steps:
         cols[k][0].append(st - t0)
         cols[k][1].append(en - st)
         cols[k][2].append(st - prev_end)
-    periods.append(rows[b][1] - t0)
+    periods.append(rows[min(b, len(rows) - 1)][1] - t0)
 n = 1
 acc = [[statistics.median(c[0]), statistics.median(c[1]), statistics.median(c[2])] for c in cols]
 total = statistics.mean(periods)
