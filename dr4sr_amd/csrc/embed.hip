@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void k_embed_dense(const float* __restrict__ E
         const int l = (int)(t % L);
         const float4 e = ld4(E + id * D + c);
         const float4 p = ld4(P + (size_t)l * D + c);
-        st4(out + t * D + c, make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w));
+        // streaming output: non-temporal store, so the 4.3 GB of rows written per launch do not evict the 3 MB table from L2 / MALL
+        const f32x4 v = {e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + t * D + c));
     }
 }
 
