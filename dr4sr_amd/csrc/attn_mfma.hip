@@ -52,6 +52,24 @@ __device__ __forceinline__ void load_frag(float (&f)[DH / 4], const float* __res
     }
 }
 
+// the same fragment straight from global rows (row stride ld floats), rows >= n read as zero: operands that are used once per
+// tile need no LDS copy — and every array not staged is a workgroup more per CU
+template <int DH>
+__device__ __forceinline__ void load_frag_g(float (&f)[DH / 4], const float* __restrict__ base, int ld, int row0, int n) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    if (row0 + r16 < n) {
+        const float* p = base + (size_t)(row0 + r16) * ld + g * (DH / 4);
+#pragma unroll
+        for (int c = 0; c < DH / 4; c += 4) {
+            const float4 v = ld4(p + c);
+            f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) f[c] = 0.f;
+    }
+}
+
 // C[16x16] += A_rows . B_rows^T over DH features (both given as row fragments)
 template <int DH>
 __device__ __forceinline__ f32x4 mma_rows(const float (&a)[DH / 4], const float (&b)[DH / 4]) {
@@ -77,13 +95,11 @@ __device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
     constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16;
     const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
     if (n <= 0) return;
-    float* Qs = smem;                    // [ROWS][LD]
-    float* Ks = Qs + ROWS * LD;
+    float* Ks = smem;                    // [ROWS][LD]   (Q fragments come straight from global: used once per query tile)
     float* Vs = Ks + ROWS * LD;
     int* kpad = reinterpret_cast<int*>(Vs + ROWS * LD);      // [64]
     const int64_t row = A.rows ? A.rows[b] : b;
     const float* src = A.qkv + (size_t)t0 * 3 * D;
-    stage_rows<D, ROWS, NT>(Qs, LD, src, 3 * D, n);
     stage_rows<D, ROWS, NT>(Ks, LD, src + D, 3 * D, n);
     stage_rows<D, ROWS, NT>(Vs, LD, src + 2 * D, 3 * D, n);
     if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
@@ -101,7 +117,7 @@ __device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
         if (it >= ntile) continue;
         const int i = it * 16 + i16;                       // this lane's query row
         float qf[DH / 4];
-        load_frag<DH>(qf, Qs, LD, it * 16, h * DH);
+        load_frag_g<DH>(qf, src + h * DH, 3 * D, it * 16, n);
         f32x4 s[MT];
         float m = -INFINITY;
 #pragma unroll
@@ -173,17 +189,15 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
     constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16, NW = NT / 64;
     const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
     if (n <= 0) return;
-    float* Qs = smem;
+    float* Qs = smem;                                       // (V is only ever used as a row fragment: read from global)
     float* Ks = Qs + ROWS * LD;
-    float* Vs = Ks + ROWS * LD;
-    float* Cs = Vs + ROWS * LD;                             // dctx rows
+    float* Cs = Ks + ROWS * LD;                             // dctx rows
     float* stat = Cs + ROWS * LD;                           // [H][ROWS][3]  row max, 1/sum, sum_j P dP
     int* kpad = reinterpret_cast<int*>(stat + H * ROWS * 3);
     const int64_t row = A.rows ? A.rows[b] : b;
     const float* src = A.qkv + (size_t)t0 * 3 * D;
     stage_rows<D, ROWS, NT>(Qs, LD, src, 3 * D, n);
     stage_rows<D, ROWS, NT>(Ks, LD, src + D, 3 * D, n);
-    stage_rows<D, ROWS, NT>(Vs, LD, src + 2 * D, 3 * D, n);
     stage_rows<D, ROWS, NT>(Cs, LD, A.dctx + (size_t)t0 * D, D, n);
     if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
     for (int i = threadIdx.x; i < H * ROWS; i += NT) {      // (h, row) -> m, 1/sum, rowdot
@@ -230,7 +244,7 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
                     float kf[DH / 4];
                     load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
                     const f32x4 s = mma_rows<DH>(kf, qf);
-                    load_frag<DH>(kf, Vs, LD, jt * 16, h * DH);
+                    load_frag_g<DH>(kf, src + 2 * D + h * DH, 3 * D, jt * 16, n);
                     const f32x4 dp = mma_rows<DH>(kf, cf);         // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
                     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
@@ -265,7 +279,7 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
         const int j = jt * 16 + i16;                       // this lane's key row
         float kf[DH / 4], vf[DH / 4];
         load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
-        load_frag<DH>(vf, Vs, LD, jt * 16, h * DH);
+        load_frag_g<DH>(vf, src + 2 * D + h * DH, 3 * D, jt * 16, n);
         const bool jok = j < n && !kpad[j];
         f32x4 dk[DH / 16], dv[DH / 16];
 #pragma unroll
@@ -342,7 +356,7 @@ static bool split_by_length(const Workspace& ws) { return ws.Tmax > 16384 && !ge
 template <int DH>
 static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArgs2 A, bool bwd, hipStream_t s) {
     const int D = p->D, B = p->B;
-    auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? 4 : 3) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
+    auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? 3 : 2) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
     if (!split_by_length(ws)) {
         const size_t lds = lds_of(64);
         if (bwd && DH == 32) { big_lds(k_attn2_bwd<DH, 64, 512>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512>), dim3(B), dim3(512), lds, s, A); }
