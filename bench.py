@@ -479,7 +479,7 @@ def main():
                 gbytes = Bg * L * (8 + 8 * D) / 1e9
                 traffic = None                      # HBM bytes per launch from the PMC passes kept under profiles/ (separate runs)
                 pj = os.path.join(ROOT, "profiles", "round1_gather_pmc.json")
-                if os.path.exists(pj):
+                if os.path.exists(pj) and D == 64:          # the PMC passes were taken on the d=64 kernel
                     pm = json.load(open(pj))
                     traffic = Bg * L * (pm["fetch_bytes_per_token_corrected"] + pm["write_bytes_per_token"])
                 # `achieved` follows SURVEY §8(d): ALGORITHMIC bytes (idx + table row + output row per token) / launch time.  The table
