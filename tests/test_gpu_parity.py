@@ -187,12 +187,13 @@ def test_fwd_bwd_with_dropout_matches_oracle_with_same_masks(dev, golden_dir, na
 
 
 # ------------------------------------------------------------------------------------------------
-def _toys_batch(B, dense, seed):
+def _toys_batch(B, dense, seed, n_items=None):
     from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
-    rows = make_rows(n_rows=B, n_items=TOYS_N_ITEMS, seed=seed, dense=dense)
+    N = n_items or TOYS_N_ITEMS
+    rows = make_rows(n_rows=B, n_items=N, seed=seed, dense=dense)
     b = {k: torch.from_numpy(rows[k]) for k in ("in_item_id", "item_id", "seqlen")}
-    b["neg_item"] = torch.randint(1, TOYS_N_ITEMS, (B, 50, 1), generator=torch.Generator().manual_seed(seed))
-    return b, TOYS_N_ITEMS
+    b["neg_item"] = torch.randint(1, N, (B, 50, 1), generator=torch.Generator().manual_seed(seed))
+    return b, N
 
 
 def _random_params(n_items, D, F, n_layer, L=50, seed=0):
@@ -211,14 +212,15 @@ def _random_params(n_items, D, F, n_layer, L=50, seed=0):
     return p
 
 
-@pytest.mark.parametrize("dense", [False, True])
-def test_full_size_batch_vs_oracle(dev, dense):
-    """BASELINE config 2 at its real size: B=256, N=11925, L=50, d=64 (toys-shaped and all-dense)."""
+@pytest.mark.parametrize("dense,D,n_items", [(False, 64, None), (True, 64, None), (False, 128, 20034)])
+def test_full_size_batch_vs_oracle(dev, dense, D, n_items):
+    """BASELINE configs[1] at its real size: B=256, N=11925, L=50, d=64 (toys-shaped and all-dense), and configs[3]'s shape
+    (yelp: N=20034, d=128)."""
     from dr4sr_amd.engine import SasrecEngine
     B = 256
-    b, N = _toys_batch(B, dense, seed=5)
-    params = _random_params(N, 64, 128, 2, seed=1)
-    eng = SasrecEngine(N, 50, 64, 2, 128, 2, 1e-12, 0.0, B, "cuda")
+    b, N = _toys_batch(B, dense, seed=5, n_items=n_items)
+    params = _random_params(N, D, 128, 2, seed=1)
+    eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, 0.0, B, "cuda")
     eng.load_named(params)
     plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
                          neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
