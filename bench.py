@@ -192,14 +192,13 @@ def bench_cl4srec(args):
         if len(batches) == 16:
             break
 
+    graph = model._api_graph_ok() and not args.no_graph
+
     def step(i):
         batch = dict(batches[i % len(batches)])
-        batch["neg_item"] = model._neg_sampling(batch)
-        model.optimizer.zero_grad()
-        loss = model.training_step(batch)
-        loss.backward()
-        model.optimizer.step()
-        return loss
+        if graph:                                        # the loop body below, captured once and replayed (BaseModel._api_step_graph)
+            return model._api_step_graph(batch)
+        return model._api_step_body(batch)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -213,8 +212,8 @@ def bench_cl4srec(args):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CL4SRec (item_random augmentation, cl_weight 0.1) on amazon-toys-shaped synthetic rows, B=%d, dropout %.2f: "
-                               "three encoder passes + InfoNCE per step, eager API path" % (args.batch, args.dropout),
-                   "global_batch": args.batch, "seq_len": 50, "parallelism": "dp1", "hip_graph": False},
+                               "three encoder passes + InfoNCE per step, API path%s" % (args.batch, args.dropout, " replayed as one HIP graph" if graph else ", eager"),
+                   "global_batch": args.batch, "seq_len": 50, "parallelism": "dp1", "hip_graph": bool(graph)},
         "final_loss": float(loss.detach())}))
 
 

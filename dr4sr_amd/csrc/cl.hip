@@ -22,9 +22,10 @@ __device__ __forceinline__ int rand_below(uint32_t r, int n) { return (int)__umu
 // one thread per sequence; mode 0 crop (tau), 1 mask (gamma), 2 reorder (beta), 3 = one of the three drawn per CALL (Item_Random)
 __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __restrict__ seqlen, int64_t* __restrict__ out,
                              int64_t* __restrict__ out_len, int B, int L, int mode, double tau, double gamma, double beta,
-                             int64_t mask_id, uint64_t seed, uint32_t step) {
+                             int64_t mask_id, uint64_t seed, uint32_t step, const int32_t* __restrict__ step_dev) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (step_dev) step += (uint32_t)*step_dev;             // graph replays: the call counter lives on the device
     const RngKey rk = make_rng(seed, step, 0.f);
     if (mode == 3) mode = rand_below(aug_rand(rk, 0xffffffu, 0), 3);          // data_augmentation.py:95: one method for the whole batch
     int n = (int)seqlen[b];
@@ -167,7 +168,16 @@ extern "C" int dr4sr_cl_augment(const int64_t* seq, const int64_t* seqlen, int64
     if (!seq || !seqlen || !out || !out_len || B < 0 || L <= 0 || L > 64 || mode < 0 || mode > 3) return DR4SR_E_ARG;
     if (B == 0) return 0;
     hipLaunchKernelGGL(k_cl_augment, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, seq, seqlen, out, out_len, B, L, mode, tau,
-                       gamma, beta, mask_id, seed, step);
+                       gamma, beta, mask_id, seed, step, (const int32_t*)nullptr);
+    return DR4SR_LAUNCH_CHECK();
+}
+extern "C" int dr4sr_cl_augment_dev(const int64_t* seq, const int64_t* seqlen, int64_t* out, int64_t* out_len, int32_t B, int32_t L,
+                                    int32_t mode, double tau, double gamma, double beta, int64_t mask_id, uint64_t seed,
+                                    const int32_t* step_dev, uint32_t step_offset, void* stream) {
+    if (!seq || !seqlen || !out || !out_len || !step_dev || B < 0 || L <= 0 || L > 64 || mode < 0 || mode > 3) return DR4SR_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_cl_augment, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, seq, seqlen, out, out_len, B, L, mode, tau,
+                       gamma, beta, mask_id, seed, step_offset, step_dev);
     return DR4SR_LAUNCH_CHECK();
 }
 

@@ -55,7 +55,7 @@ class FusedAdam:
 
     def step(self):
         eng = self.model.engine
-        eng.grads[eng.n_params] = 1.0                 # API path: the loss is already normalised
+        eng.grads[eng.n_params:eng.n_params + 1].fill_(1.0)      # API path: the loss is already normalised (fill_: capturable)
         eng.adam_step(self.model._api_plan())
 
     def state_dict(self):
@@ -168,6 +168,12 @@ class BaseModel(nn.Module):
         n = tgt.numel()
         out = torch.empty(n, dtype=torch.int64, device=tgt.device)
         eng = self.engine
+        step_dev = getattr(self, "_neg_step_dev", None)
+        if step_dev is not None:                          # captured API step: the call counter lives on the device
+            step_dev.add_(1)
+            _lib.check(eng.lib.dr4sr_neg_sample_dev(_lib.ptr(out), n, self.num_items, eng.seed ^ 0x5DEECE66D, _lib.ptr(step_dev),
+                                                    _lib.cur_stream()), "neg_sample_dev")
+            return out.view(*tgt.shape, 1)
         self._neg_calls = getattr(self, "_neg_calls", 0) + 1
         _lib.check(eng.lib.dr4sr_neg_sample(_lib.ptr(out), n, self.num_items, eng.seed ^ 0x5DEECE66D, self._neg_calls,
                                             _lib.cur_stream()), "neg_sample")
@@ -366,6 +372,8 @@ class BaseModel(nn.Module):
         if self._fast_path_ok():
             return [self._fused_epoch(loader)]
         outputs = []
+        if self._api_graph_ok():
+            return [[{"loss_0": self._api_step_graph(batch)} for batch in loader]]
         for batch in loader:                                        # API path (reference loop, basemodel.py:192-200)
             batch["neg_item"] = self._neg_sampling(batch)
             self.optimizer.zero_grad()
@@ -374,6 +382,63 @@ class BaseModel(nn.Module):
             self.optimizer.step()
             outputs.append({"loss_0": loss.detach()})
         return [outputs]
+
+    # ---- API path under a HIP graph: models whose step is a composition of C-ABI calls behind autograd (CL4SRec) are host-bound when
+    # run eagerly (≈100 launches + autograd bookkeeping per step); the loop body of basemodel.py:192-200 is captured once per batch
+    # size over static copies of the batch tensors and replayed.  Host-side call counters (negative sampler, augmentations) move to
+    # device words for the duration.
+    def _api_graph_ok(self) -> bool:
+        return False
+
+    def _api_graph_state(self):
+        """tensors a warm-up run must not change"""
+        eng = self.engine
+        return [eng.params, eng.adam_m, eng.adam_v] + list(getattr(eng, "states", [eng.state]))
+
+    def _api_step_body(self, batch):
+        batch["neg_item"] = self._neg_sampling(batch)
+        self.optimizer.zero_grad()
+        loss = self.training_step(batch=batch)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _api_step_graph(self, batch):
+        if not hasattr(self, "_api_graphs"):
+            self._api_graphs = {}
+            self._neg_step_dev = torch.full((1,), getattr(self, "_neg_calls", 0), dtype=torch.int32, device=self.device)
+            self._api_graph_begin()
+        bl = int(batch[self.fuid].shape[0])
+        ent = self._api_graphs.get(bl)
+        if ent is None:
+            static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+            undo = self._api_graph_state() + self._api_graph_counters()
+            snap = [t.clone() for t in undo]
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                        # warm-up outside capture (code objects, allocator pools)
+                    self._api_step_body(dict(static))
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for dst, src in zip(undo, snap):
+                dst.copy_(src)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._api_step_body(dict(static))
+            ent = self._api_graphs[bl] = (g, static, out)
+        g, static, out = ent
+        for k, v in static.items():
+            if k in batch:
+                v.copy_(batch[k])
+        g.replay()
+        return out.clone()
+
+    def _api_graph_begin(self):
+        pass
+
+    def _api_graph_counters(self):
+        return [self._neg_step_dev]
 
     def training_epoch_end(self, output_list):
         output_list = output_list if isinstance(output_list, list) else [output_list]

@@ -23,12 +23,29 @@ class _DeviceAugmentation(torch.nn.Module):
         super().__init__()
         self.mask_id, self.tao, self.gamma, self.beta, self.seed = int(mask_id), float(tao), float(gamma), float(beta), int(seed)
         self.calls = 0
+        self.step_dev = None        # int32[1] device copy of `calls` while a captured training step is being built / replayed
+        self._in_step = 0
+
+    def begin_step(self):
+        """captured steps: call at the top of the step body; the k-th forward() of the step draws stream step_dev + k, and
+        end_step() advances the device counter (all of it recorded into the graph)"""
+        self._in_step = 0
+
+    def end_step(self):
+        if self.step_dev is not None:
+            self.step_dev.add_(self._in_step)
 
     def forward(self, sequences, seq_lens):
         lib = _lib.load()
         seq, sl = sequences.contiguous(), seq_lens.contiguous()
         B, L = seq.shape
         out, out_len = torch.empty_like(seq), torch.empty_like(sl)
+        if self.step_dev is not None:
+            self._in_step += 1
+            _lib.check(lib.dr4sr_cl_augment_dev(_lib.ptr(seq), _lib.ptr(sl), _lib.ptr(out), _lib.ptr(out_len), B, L, self.mode, self.tao,
+                                                self.gamma, self.beta, self.mask_id, self.seed, _lib.ptr(self.step_dev), self._in_step,
+                                                _lib.cur_stream()), "dr4sr_cl_augment_dev")
+            return out, out_len
         self.calls += 1
         _lib.check(lib.dr4sr_cl_augment(_lib.ptr(seq), _lib.ptr(sl), _lib.ptr(out), _lib.ptr(out_len), B, L, self.mode, self.tao,
                                         self.gamma, self.beta, self.mask_id, self.seed, self.calls, _lib.cur_stream()), "dr4sr_cl_augment")

@@ -353,6 +353,10 @@ int dr4sr_meta_sgd_step(float* phi, const float* grad, float* momentum_buf, int3
  * dr4sr_infonce_bwd — d(sum loss_row) * (*scale) accumulated into dxi, dxj [B,D]. */
 int dr4sr_cl_augment(const int64_t* seq, const int64_t* seqlen, int64_t* out, int64_t* out_len, int32_t B, int32_t L, int32_t mode,
                      double tau, double gamma, double beta, int64_t mask_id, uint64_t seed, uint32_t step, void* stream);
+/* the same with step = *step_dev + step_offset read at run time (graph replays of a training step) */
+int dr4sr_cl_augment_dev(const int64_t* seq, const int64_t* seqlen, int64_t* out, int64_t* out_len, int32_t B, int32_t L, int32_t mode,
+                         double tau, double gamma, double beta, int64_t mask_id, uint64_t seed, const int32_t* step_dev,
+                         uint32_t step_offset, void* stream);
 int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature, float* lse,
                       float* loss_row, float* stats, void* stream);
 int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,

@@ -165,3 +165,33 @@ def test_cl4srec_fit_end_to_end(tmp_path, monkeypatch):
     from dr4sr_amd import quickstart
     out = quickstart.run(make_config(150, n_rows=300, batch=64, epochs=2, dropout=0.5))
     assert {"ndcg@20", "recall@20"} <= set(out) and all(np.isfinite(v) for v in out.values())
+
+
+def test_cl4srec_graph_replayed_epoch_equals_eager_epoch(monkeypatch):
+    """the HIP-graph replay of the API step (BaseModel._api_step_graph: device-side call counters for the negative sampler and the
+    augmentations) trains exactly like the eager loop: same batches, same draws, same dropout masks"""
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
+    res = []
+    for graph in (False, True):
+        config = make_config(150, n_rows=200, batch=64, epochs=1, dropout=0.5)
+        config["train"]["hip_graph"] = graph
+        seed_everything(config["train"]["seed"])
+        ds = prepare_datasets(config)
+        model = prepare_model(config, ds)
+        model._init_model(ds[0])
+        model.train()
+        assert model._api_graph_ok() == graph
+        loader = ds[0].get_loader(shuffle=False)
+        losses = []
+        for _ in range(2):                                  # 2 epochs x (3 full batches + 1 partial): graphs are re-used across epochs
+            for batch in loader:
+                if graph:
+                    losses.append(float(model._api_step_graph(batch)))
+                else:
+                    losses.append(float(model._api_step_body(batch)))
+        res.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (la, pa), (lb, pb) = res
+    assert len(la) == 8 and np.allclose(la, lb, rtol=2e-4, atol=1e-5), (la, lb)
+    for n in pa:
+        assert float((pa[n] - pb[n]).abs().max()) < 5e-4, n     # 8 Adam steps of lr 1e-3: fp32 atomics order, nothing systematic
