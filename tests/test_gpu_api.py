@@ -246,3 +246,19 @@ def test_train_steps_equals_repeated_train_step():
     assert float(l0[:k + 1].min()) > 0 and torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
     assert float((p0 - p1).abs().max()) < 2e-4           # same trajectory: fp32 atomics order only, amplified by Adam (lr 1e-3 per step)
     assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max())
+
+
+@pytest.mark.gpu
+def test_data_parallel_ranks_equal_single_rank():
+    """2 ranks (gloo, sharing cuda:0) sharding every global batch + one sum-all-reduce of the flat gradient and its {n_valid, loss}
+    tail == a single rank on the full batches (tools/dp_check.py); replicas stay bit-identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(root, "tools", "dp_check.py")], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CHECK")]
+    assert out.returncode == 0 and len(lines) == 2, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "replica checksums equal: True" in lines[1]
