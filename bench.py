@@ -246,6 +246,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DR4SR_BENCH_FORCE_DP=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path — process group, split graphs,
+    # all-reduce between them — with a single rank; exercises the RCCL + graph-capture interplay on a 1-GPU box
+    dp = world > 1 or bool(os.environ.get("DR4SR_BENCH_FORCE_DP"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -253,7 +256,7 @@ def main():
     dev = torch.device("cuda", 0 if os.environ.get("DR4SR_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
-    if world > 1:
+    if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("DR4SR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -318,7 +321,7 @@ def main():
 
         def step_eager():
             select()
-            if world == 1:
+            if not dp:
                 eng.train_step(plan)
             else:
                 eng.fwd_bwd(plan)
@@ -331,7 +334,7 @@ def main():
             stream.synchronize()
             use_graph = not args.no_graph
             group = 1
-            if use_graph and world == 1:
+            if use_graph and not dp:
                 # batch selection runs on the device, so consecutive training steps need no host work at all: `group` whole steps
                 # are captured into one graph (a graph launch costs ~8 us of idle GPU between replays at this step size); any K / W
                 # is served by that graph plus a one-step graph for the remainder
@@ -375,7 +378,7 @@ def main():
 
             run_steps(warmup)
             stream.synchronize()
-            if world > 1:
+            if dp:
                 dist.barrier()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,11 +387,11 @@ def main():
             run_steps(steps)
             e1.record()
             torch.cuda.synchronize()
-            if world > 1:
+            if dp:
                 dist.barrier()
             wall = time.perf_counter() - t0
             gpu_ms = e0.elapsed_time(e1)
-            if world > 1:
+            if dp:
                 tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 wall = float(tmax)
@@ -502,7 +505,7 @@ def main():
             out["throughput_mode"] = {k: tm[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline",
                                                           "kernel_us_per_step", "valid_tokens_last_step") if k in tm}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.model == "sasrec":
+        if not dp and not args.no_cpu_baseline and args.model == "sasrec":
             from oracle.ref_trainer import time_training
             r = time_training(rows_np, N, batch_size=256, warmup=3, max_steps=40, max_seconds=20.0, anomaly=True, p=args.dropout)
             out["cpu_baseline"] = {"value": r["seq_per_s"], "unit": "sequences/s", "cores": r["threads"], "kind": "port",
@@ -511,7 +514,7 @@ def main():
                                              "Adam, anomaly detection ON as utils/utils.py:11) on the same synthetic rows; "
                                              "host has %d logical CPUs" % (r["steps"], r["seconds"], os.cpu_count() or 0)}
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

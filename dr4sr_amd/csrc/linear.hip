@@ -838,10 +838,8 @@ struct QkvEmbBwdArgs {
     float* gout;                 // large batches: masked dx0 rows are stored here and scattered by a job of k_wgrad (overlaps its MFMA work)
 };
 template <int BM, int D>
-__global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
+__device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const int t0, const int T) {
     constexpr int K = 3 * D, LDA = K + 4, LDC = D + 4, LPT = D / 4, TPB = 256 / LPT;
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
-    if (t0 >= T) return;
     float* As = smem;
     float* Cs = As + BM * LDA;
     float* accP = Cs + BM * LDC;                        // [L][D]
@@ -886,17 +884,34 @@ __global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
         if (v != 0.f) unsafeAtomicAdd(A.dP + i, v);
     }
 }
+template <int BM, int D>
+__global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    if (t0 >= T) return;
+    qkv_embed_bwd_body<BM, D>(A, t0, T);
+}
 
-int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
-    const int D = p->D, bm = tile_rows(ws);
-    const size_t lds = sizeof(float) * (bm * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D);
-    dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
+static QkvEmbBwdArgs make_qeb_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int training) {
     const LayerWs& lw = ws.layer[0];
     QkvEmbBwdArgs A;
     A.dQKV = lw.dqkv; A.W = p->params + poff(ws, 0, P_IN_W); A.dU1 = lw.du1; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu; A.tile_seq = ws.tile_seq;
     A.dE = p->grads + ws.off[0]; A.dP = p->grads + ws.off[1]; A.state = p->state; A.B = p->B; A.L = p->L; A.n_items = p->n_items;
     A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.gout = scatter_in_wgrad(ws) ? ws.dX[0] : nullptr;
+    return A;
+}
+// latency regime: k_qkv_embed_bwd and k_wgrad are independent (the weight gradients read dqkv / X, not dx0), so the embedding tiles
+// run as the first plane of the k_wgrad launch: one launch boundary less per step and the two overlap
+bool qeb_in_wgrad(const Workspace& ws) {
+    static const bool off = getenv("DR4SR_QEB_SEPARATE") != nullptr || getenv("DR4SR_NO_FUSE") != nullptr;
+    return !off && tile_rows(ws) == 16;
+}
+
+int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
+    const int D = p->D, bm = tile_rows(ws);
+    const size_t lds = sizeof(float) * (bm * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D);
+    dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
+    const QkvEmbBwdArgs A = make_qeb_args(p, ws, training);
 #define QE(B_) do { if (D == 64) { big_lds(k_qkv_embed_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 64>), grid, blk, lds, s, A); } \
                     else { big_lds(k_qkv_embed_bwd<B_, 128>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 128>), grid, blk, lds, s, A); } } while (0)
     BM_DISPATCH(bm, QE);
@@ -1016,8 +1031,8 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
 // sum per-token-tile LayerNorm partials [ntiles][4][D] (rows: ln2_w, ln2_b, ln1_w, ln1_b) into the flat gradient
 // (layout ln1_w | ln1_b | ln2_w | ln2_b), tiles strided over gridDim.x blocks; block (0, layer 0) also folds the
 // scorer's per-sequence (count, loss) partials into the gradient tail.
-__device__ __forceinline__ void reduce_jobs(const WgradArgs& A) {
-    const int T = A.state[DR4SR_STATE_T], ntiles = (T + A.ln_tile_rows - 1) / A.ln_tile_rows, D = A.D, layer = blockIdx.z;
+__device__ __forceinline__ void reduce_jobs(const WgradArgs& A, const int layer) {
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + A.ln_tile_rows - 1) / A.ln_tile_rows, D = A.D;
     const float* part = A.ln_part + (size_t)layer * A.ln_layer_stride;
     float* g = A.grads + A.o_ln1_w + (size_t)layer * A.layer_stride;
     for (int c = threadIdx.x; c < 4 * D; c += 256) {
@@ -1080,13 +1095,23 @@ __device__ __forceinline__ void scatter_job(const WgradArgs& A) {
 // blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2, 6: reductions; with the embedding scatter: y = 0 is the scatter
 // [layer 0 only] and the others shift by one), blockIdx.z = layer
 template <int D, int F>
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A) {
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A, const QkvEmbBwdArgs Q) {
+    // latency regime (A.qeb_plane): plane z = 0 of the grid is k_qkv_embed_bwd's work (16-row tiles, block-strided), layers shift by one
+    const int layer = A.qeb_plane ? (int)blockIdx.z - 1 : (int)blockIdx.z;
+    if (layer < 0) {
+        const int T = A.state[DR4SR_STATE_T], nblk = gridDim.x * gridDim.y;
+        for (int tile = blockIdx.y * gridDim.x + blockIdx.x; tile * 16 < T; tile += nblk) {
+            qkv_embed_bwd_body<16, D>(Q, tile * 16, T);
+            __syncthreads();
+        }
+        return;
+    }
     // the scatter blocks come FIRST in dispatch order (y = 0): the other jobs are persistent loops, so blocks dispatched after
     // the first resident wave would only start when those finish — no overlap
     const int j = A.sc_g ? (int)blockIdx.y - 1 : (int)blockIdx.y;
-    if (j < 0) { if (blockIdx.z == 0) scatter_job<D>(A); return; }
-    if (j == 6) { reduce_jobs(A); return; }
-    const WgradJob& J = A.job[blockIdx.z * 6 + j];
+    if (j < 0) { if (layer == 0) scatter_job<D>(A); return; }
+    if (j == 6) { reduce_jobs(A, layer); return; }
+    const WgradJob& J = A.job[layer * 6 + j];
     if (j < 4) wgrad_body<D, D>(J, A);
     else if (j == 4) wgrad_body<F, D>(J, A);
     else wgrad_body<D, F>(J, A);
@@ -1132,7 +1157,7 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
     return DR4SR_LAUNCH_CHECK();
 }
 
-int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s) {
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb) {
     WgradArgs A;
     const int D = p->D, F = p->F;
     float* G = p->grads;
@@ -1172,12 +1197,16 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
         A.sc_g = ws.dX[0]; A.sc_idx = p->in_item_id; A.sc_rows = p->rows; A.sc_tile_seq = ws.tile_seq; A.cu = ws.cu;
         A.sc_dE = G + ws.off[0]; A.sc_dP = G + ws.off[1]; A.sc_L = p->L; A.sc_n_items = p->n_items;
     }
-    dim3 grid(gw, scatter ? 8 : 7, p->n_layer), blk(256);
+    A.qeb_plane = (qeb && qeb_in_wgrad(ws)) ? 1 : 0;
+    const QkvEmbBwdArgs Q = make_qeb_args(p, ws, training);
+    dim3 grid(gw, scatter ? 8 : 7, p->n_layer + A.qeb_plane), blk(256);
     size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
     if (scatter && sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;
-    if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A); }
-    else if (D == 128 && F == 128) { big_lds(k_wgrad<128, 128>, lds); hipLaunchKernelGGL((k_wgrad<128, 128>), grid, blk, lds, s, A); }
-    else if (D == 64 && F == 256) { big_lds(k_wgrad<64, 256>, lds); hipLaunchKernelGGL((k_wgrad<64, 256>), grid, blk, lds, s, A); }
+    const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D);
+    if (A.qeb_plane && lds_q > lds) lds = lds_q;
+    if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A, Q); }
+    else if (D == 128 && F == 128) { big_lds(k_wgrad<128, 128>, lds); hipLaunchKernelGGL((k_wgrad<128, 128>), grid, blk, lds, s, A, Q); }
+    else if (D == 64 && F == 256) { big_lds(k_wgrad<64, 256>, lds); hipLaunchKernelGGL((k_wgrad<64, 256>), grid, blk, lds, s, A, Q); }
     else return DR4SR_E_SHAPE;
     return DR4SR_LAUNCH_CHECK();
 }

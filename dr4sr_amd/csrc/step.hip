@@ -247,8 +247,8 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
         if (getenv("DR4SR_NO_FUSE")) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
     }
     if (getenv("DR4SR_NO_FUSE")) RC(launch_embed_bwd(p, ws, training, s));
-    else RC(launch_qkv_embed_bwd(p, ws, training, s));
-    RC(launch_wgrad(p, ws, training, with_score, s));
+    else if (!qeb_in_wgrad(ws)) RC(launch_qkv_embed_bwd(p, ws, training, s));
+    RC(launch_wgrad(p, ws, training, with_score, s, !getenv("DR4SR_NO_FUSE")));
     return 0;
 }
 
