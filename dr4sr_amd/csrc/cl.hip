@@ -117,46 +117,79 @@ __global__ __launch_bounds__(256) void k_infonce_fwd(const float* __restrict__ x
 // d loss_sum / d x  scaled by *scale (device scalar or NULL):  with P = softmax(logits) (rows = valid i)
 //   dxi[i] += sum_j P1_ij xj[j] + sum_{j!=i} P2_ij xi[j] - xj[i]        (row pass, this kernel, role 0)
 //   dxj[j] += sum_i P1_ij xi[i] - xi[j] ;  dxi[j] += sum_{i!=j} P2_ij xi[i]   (column pass, role 1)
-// One wave per (row | column), lanes over D (D/64 floats per lane), the other index looped: O(B^2 D), fine for B <= 1024.
+// One wave per (row | column) a.  The other index o is walked in blocks of 64 in two phases: lanes over o compute the two logits of
+// (a, o) as full dot products and leave the probabilities in LDS; lanes over D then accumulate the 64 weighted rows (coalesced).
+// No cross-lane reduction inside the loop (the first version had two wave reductions per o: a 115 us dependent chain at B = 256).
 template <int D>
 __global__ __launch_bounds__(256) void k_infonce_bwd(const float* __restrict__ xi, const float* __restrict__ xj,
                                                      const uint8_t* __restrict__ valid, int B, float inv_t,
                                                      const float* __restrict__ lse, const float* __restrict__ scale,
                                                      float* __restrict__ dxi, float* __restrict__ dxj) {
-    constexpr int NV = D / 64;
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= 2 * B) return;
-    const int role = item >= B, a = role ? item - B : item;
-    if (valid && !valid[a]) return;
+    constexpr int NV = D / 64, LDR = D + 1;                  // +1: the dot phase reads row `lane`, conflict-free with an odd row stride
+    __shared__ float ps[4][2][64];
+    __shared__ float xa[4][2][D];
+    __shared__ float xo[2][64 * LDR];                        // rows o0 .. o0+63 of xi / xj, staged once per block for all 4 waves
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + w;
+    const bool live = item < 2 * B;
+    const int role = live && item >= B, a = live ? (role ? item - B : item) : 0;
+    const bool act = live && (!valid || valid[a]);          // inactive waves still take the barriers
     const float sc = (scale ? *scale : 1.0f) * inv_t;
-    float acc_i[NV], acc_j[NV], xa_i[NV], xa_j[NV];
+    float acc_i[NV], acc_j[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { acc_i[v] = 0.f; acc_j[v] = 0.f; xa_i[v] = xi[(size_t)a * D + lane + 64 * v]; xa_j[v] = xj[(size_t)a * D + lane + 64 * v]; }
-    for (int o = 0; o < B; ++o) {
-        if (valid && !valid[o]) continue;
-        float xo_i[NV], xo_j[NV];
-        float d1 = 0.f, d2 = 0.f;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            xo_i[v] = xi[(size_t)o * D + lane + 64 * v]; xo_j[v] = xj[(size_t)o * D + lane + 64 * v];
-            if (!role) { d1 += xa_i[v] * xo_j[v]; d2 += xa_i[v] * xo_i[v]; }      // logits of row a: sim_ij[a][o], sim_ii[a][o]
-            else { d1 += xo_i[v] * xa_j[v]; d2 += xo_i[v] * xa_i[v]; }            // logits of row o at column a
+    for (int v = 0; v < NV; ++v) {
+        acc_i[v] = 0.f; acc_j[v] = 0.f;
+        xa[w][0][lane + 64 * v] = xi[(size_t)a * D + lane + 64 * v];
+        xa[w][1][lane + 64 * v] = xj[(size_t)a * D + lane + 64 * v];
+    }
+    const float la = lse[a];
+    for (int o0 = 0; o0 < B; o0 += 64) {
+        const int n = B - o0 < 64 ? B - o0 : 64;
+        __syncthreads();                                     // previous block's rows are no longer read
+        for (int e = threadIdx.x; e < 64 * D; e += 256) {    // coalesced: consecutive threads walk a row
+            const int r = e / D, c = e % D;
+            const bool ok = r < n;
+            xo[0][r * LDR + c] = ok ? xi[(size_t)(o0 + r) * D + c] : 0.f;
+            xo[1][r * LDR + c] = ok ? xj[(size_t)(o0 + r) * D + c] : 0.f;
         }
-        d1 = wave_sum(d1); d2 = wave_sum(d2);
-        const float l = role ? lse[o] : lse[a];
-        const float p1 = __expf(d1 * inv_t - l), p2 = o == a ? 0.f : __expf(d2 * inv_t - l);
+        __syncthreads();
+        const int o = o0 + lane;
+        float p1 = 0.f, p2 = 0.f;
+        if (act && o < B && (!valid || valid[o])) {
+            float d1 = 0.f, d2 = 0.f;
+            const float* oi = &xo[0][lane * LDR];
+            const float* oj = &xo[1][lane * LDR];
+#pragma unroll 8
+            for (int c = 0; c < D; ++c) {
+                const float ai = xa[w][0][c];
+                d2 += oi[c] * ai;                                        // sim_ii[a][o] (symmetric)
+                d1 += role ? oi[c] * xa[w][1][c] : ai * oj[c];           // sim_ij[o][a] : sim_ij[a][o]
+            }
+            const float l = role ? lse[o] : la;
+            p1 = __expf(d1 * inv_t - l);
+            p2 = o == a ? 0.f : __expf(d2 * inv_t - l);
+        }
+        ps[w][0][lane] = p1; ps[w][1][lane] = p2;
+        __syncthreads();
+        if (act) {
+            for (int k = 0; k < n; ++k) {
+                const float q1 = ps[w][0][k], q2 = ps[w][1][k];
+                if (q1 == 0.f && q2 == 0.f) continue;                     // masked-out row (uniform over the wave)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (!role) acc_i[v] += p1 * xo_j[v] + p2 * xo_i[v];
-            else { acc_j[v] += p1 * xo_i[v]; acc_i[v] += p2 * xo_i[v]; }
+                for (int v = 0; v < NV; ++v) {
+                    const float oi = xo[0][k * LDR + lane + 64 * v];
+                    if (!role) acc_i[v] += q1 * xo[1][k * LDR + lane + 64 * v] + q2 * oi;
+                    else { acc_j[v] += q1 * oi; acc_i[v] += q2 * oi; }
+                }
+            }
         }
     }
+    if (!act) return;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const size_t e = (size_t)a * D + lane + 64 * v;
-        if (!role) unsafeAtomicAdd(dxi + e, sc * (acc_i[v] - xa_j[v]));
-        else { unsafeAtomicAdd(dxj + e, sc * (acc_j[v] - xa_i[v])); unsafeAtomicAdd(dxi + e, sc * acc_i[v]); }
+        if (!role) unsafeAtomicAdd(dxi + e, sc * (acc_i[v] - xa[w][1][lane + 64 * v]));
+        else { unsafeAtomicAdd(dxj + e, sc * (acc_j[v] - xa[w][0][lane + 64 * v])); unsafeAtomicAdd(dxi + e, sc * acc_i[v]); }
     }
 }
 
