@@ -167,9 +167,14 @@ __global__ __launch_bounds__(256) void k_score_dense_fwd(const float* __restrict
         }
         if (!pad) { lsum += lp; cnt += 1.f; }
     }
-    if (stats && lane == 0 && cnt > 0.f) {
-        unsafeAtomicAdd(stats + 0, cnt);
-        unsafeAtomicAdd(stats + 1, lsum);
+    // one atomic pair per WORKGROUP: same-address fp32 atomics serialise at ~12 ns each (one pair per wave was the whole 36 us of
+    // this kernel at B*L = 12 800)
+    __shared__ float red[8];
+    if (lane == 0) { red[2 * (threadIdx.x >> 6)] = cnt; red[2 * (threadIdx.x >> 6) + 1] = lsum; }
+    __syncthreads();
+    if (stats && threadIdx.x == 0) {
+        const float c = (red[0] + red[2]) + (red[4] + red[6]), l = (red[1] + red[3]) + (red[5] + red[7]);
+        if (c > 0.f) { unsafeAtomicAdd(stats + 0, c); unsafeAtomicAdd(stats + 1, l); }
     }
 }
 
@@ -221,7 +226,7 @@ extern "C" int dr4sr_score_bce_fwd(const float* query, const float* E, const int
     const int64_t npos = B * L;
     if (npos == 0) return 0;
     int64_t blocks = (npos + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 512) blocks = 512;
     hipStream_t s = (hipStream_t)stream;
     if (D == 64) hipLaunchKernelGGL(k_score_dense_fwd<64>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
     else hipLaunchKernelGGL(k_score_dense_fwd<128>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
