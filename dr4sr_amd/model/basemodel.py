@@ -411,7 +411,8 @@ class BaseModel(nn.Module):
         bl = int(batch[self.fuid].shape[0])
         ent = self._api_graphs.get(bl)
         if ent is None:
-            static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+            keep = self._api_graph_fields()
+            static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v) and (keep is None or k in keep)}
             undo = self._api_graph_state() + self._api_graph_counters()
             snap = [t.clone() for t in undo]
             side = torch.cuda.Stream(device=self.device)
@@ -436,6 +437,10 @@ class BaseModel(nn.Module):
 
     def _api_graph_begin(self):
         pass
+
+    def _api_graph_fields(self):
+        """batch fields the step reads (None = all): each one is a device copy per replay"""
+        return None
 
     def _api_graph_counters(self):
         return [self._neg_step_dev]

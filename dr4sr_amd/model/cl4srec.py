@@ -33,6 +33,9 @@ class CL4SRec(SASRec):
         if hasattr(aug, "calls"):
             aug.step_dev = torch.full((1,), aug.calls, dtype=torch.int32, device=self.device)
 
+    def _api_graph_fields(self):
+        return {"in_" + self.fiid, self.fiid, "seqlen", self.fuid}
+
     def _api_graph_counters(self):
         sd = getattr(self.augmentation_model.augmentation, "step_dev", None)
         return super()._api_graph_counters() + ([sd] if sd is not None else [])
