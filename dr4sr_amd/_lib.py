@@ -150,6 +150,9 @@ SYMBOLS = {
     "dr4sr_infonce_fwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_infonce_bwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_full_score_topk_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "dr4sr_full_score_topk_ws": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           _f32p, C.c_int64, C.c_void_p]),
 }
 
 _lib = None

@@ -3,9 +3,16 @@
 // Reference: BaseModel.topk (model/basemodel.py:354-365): real_score = query @ E[:N].T; non-domain
 // items (incl. PAD column 0) and the user's history are set to -inf; torch.topk(k).
 //
-// v1: one workgroup per query row; the N scores of the row live in LDS (N*4 B <= 150 KiB), the top-k
-// is k rounds of block-wide arg-max (ties -> lower id).  The [B,N] score matrix (97.7 MB per 2048-row
-// batch in the reference) is never materialised.
+// dr4sr_full_score_topk (no workspace): one workgroup per query row; the N scores of the row live in LDS (N*4 B <= 150 KiB),
+// the top-k is k rounds of block-wide arg-max (ties -> lower id).  Simple, but every row re-reads the whole table from L2 and the
+// k serial arg-max rounds cost ~3 us each: 1.7 ms per 2048-row batch, more than a training epoch's worth per validation pass.
+//
+// dr4sr_full_score_topk_ws (with a [B, Npad] fp32 workspace): two launches.
+//   k_score_gemm : S = Q E^T on MFMA 32x32x2 (64 rows x 64 items per workgroup: the table is read B/64 times, not B times),
+//                  PAD column -> -inf, streamed out with non-temporal stores;
+//   k_topk_select: one workgroup per row: row -> LDS as order-preserving uint keys (history -> -inf), 4-pass radix select of the
+//                  k-th largest key (256-bin LDS histograms), compaction of the keys above it (+ the lowest-index ties), bitonic
+//                  sort of the <= 128 candidates by (score desc, id asc).  Same results as the arg-max rounds, ~15x faster.
 #include "common.h"
 #include "kernels.h"
 
@@ -68,6 +75,171 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ Q, const
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------ two-phase path
+template <int D>
+__global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Q, const float* __restrict__ E, float* __restrict__ S,
+                                                    int B, int n_items, int lds_s) {
+    constexpr int LD = D + 1;                              // odd stride: the 32 lanes of an MFMA operand read 32 different rows
+    float* Qs = smem;                                      // [64][LD]
+    float* Es = smem + 64 * LD;                            // [64][LD]
+    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * (D / 4); e += 256) {
+        const int r = e / (D / 4), c = (e % (D / 4)) * 4;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), ev = qv;
+        if (b0 + r < B) qv = ld4(Q + (size_t)(b0 + r) * D + c);
+        if (n0 + r < n_items) ev = ld4(E + (size_t)(n0 + r) * D + c);
+        float* qd = Qs + r * LD + c; qd[0] = qv.x; qd[1] = qv.y; qd[2] = qv.z; qd[3] = qv.w;
+        float* ed = Es + r * LD + c; ed[0] = ev.x; ed[1] = ev.y; ed[2] = ev.z; ed[3] = ev.w;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, g = lane >> 5;
+    const int rt = w >> 1, ct = w & 1;                     // wave -> 32x32 quadrant (rows rt, items ct)
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float* ap = Qs + (rt * 32 + r) * LD + g;
+    const float* bp = Es + (ct * 32 + r) * LD + g;
+#pragma unroll 8
+    for (int sidx = 0; sidx < D / 2; ++sidx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sidx], bp[2 * sidx], acc, 0, 0, 0);
+    const int n = n0 + ct * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int b = b0 + rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+        if (b < B && n < lds_s) __builtin_nontemporal_store(n == 0 || n >= n_items ? -INFINITY : acc[e], S + (size_t)b * lds_s + n);
+    }
+}
+
+__device__ __forceinline__ unsigned f2key(float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ __launch_bounds__(256) void k_topk_select(const float* __restrict__ S, const int64_t* __restrict__ hist,
+                                                     float* __restrict__ out_score, int64_t* __restrict__ out_item, int n_items,
+                                                     int lds_s, int Lh, int k) {
+    unsigned* key = reinterpret_cast<unsigned*>(smem);     // [n_items]
+    int* hst = reinterpret_cast<int*>(key + ((n_items + 3) & ~3));       // [256] digit histogram
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(hst + 256 + 8);     // [128] (key << 32) | ~id
+    int* ctl = hst + 256;                                  // [0] selected digit, [1] remaining rank, [2] candidate count, [3] ties taken
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* row = S + (size_t)b * lds_s;
+    for (int n = tid; n < n_items; n += 256) key[n] = f2key(row[n]);
+    __syncthreads();
+    const unsigned kneg = f2key(-INFINITY);
+    for (int j = tid; j < Lh; j += 256) {
+        const int64_t id = hist[(size_t)b * Lh + j];
+        if (id >= 0 && id < n_items) key[id] = kneg;
+    }
+    if (tid == 0) { ctl[1] = k < n_items ? k : n_items; ctl[2] = 0; ctl[3] = 0; }
+    // ---- radix select: the key T of rank ctl[1] (1-based, from the top)
+    unsigned prefix = 0, pmask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hst[tid] = 0;
+        __syncthreads();
+        for (int n = tid; n < n_items; n += 256) {
+            const unsigned kv = key[n];
+            if ((kv & pmask) == prefix) atomicAdd(&hst[(kv >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {                                    // wave 0: suffix sums over the 256 bins, 4 bins per lane (descending digits)
+            const int rank = ctl[1];
+            const int d0 = 255 - 4 * lane;                 // this lane's bins: d0, d0-1, d0-2, d0-3
+            const int c0 = hst[d0], c1 = hst[d0 - 1], c2 = hst[d0 - 2], c3 = hst[d0 - 3];
+            int tot = c0 + c1 + c2 + c3, incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+            const int before = incl - tot;                 // keys in strictly higher bins than d0
+            if (before < rank && rank <= incl) {           // the rank-th key falls into one of this lane's bins
+                int acc = before, dsel = d0, rem = rank - before;
+                if (acc + c0 >= rank) { dsel = d0; rem = rank - acc; }
+                else if (acc + c0 + c1 >= rank) { dsel = d0 - 1; rem = rank - acc - c0; }
+                else if (acc + c0 + c1 + c2 >= rank) { dsel = d0 - 2; rem = rank - acc - c0 - c1; }
+                else { dsel = d0 - 3; rem = rank - acc - c0 - c1 - c2; }
+                ctl[0] = dsel; ctl[1] = rem;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)ctl[0] << shift;
+        pmask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned T = prefix;                             // exactly the k-th largest key; ctl[1] = how many keys == T belong to the top-k
+    const int need_eq = ctl[1];
+    // ---- candidates: every key above T (any order), then the need_eq lowest-index keys equal to T
+    for (int n = tid; n < n_items; n += 256) {
+        const unsigned kv = key[n];
+        if (kv > T) { const int p = atomicAdd(&ctl[2], 1); cand[p] = ((unsigned long long)kv << 32) | (unsigned)(~(unsigned)n); }
+    }
+    __syncthreads();
+    const int ngt = ctl[2];
+    {   // ordered compaction of the ties (usually exactly need_eq of them: one chunk pass finds them)
+        int taken = 0;
+        for (int n0 = 0; n0 < n_items && taken < need_eq; n0 += 256) {
+            const int n = n0 + tid;
+            const bool eq = n < n_items && key[n] == T;
+            const unsigned long long bal = __ballot(eq);
+            const int inwave = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) hst[tid >> 6] = __popcll(bal);
+            __syncthreads();
+            const int w = tid >> 6;
+            int off = 0;
+            for (int x = 0; x < w; ++x) off += hst[x];
+            const int tot = hst[0] + hst[1] + hst[2] + hst[3];
+            const int rnk = taken + off + inwave;
+            if (eq && rnk < need_eq) cand[ngt + rnk] = ((unsigned long long)T << 32) | (unsigned)(~(unsigned)n);
+            taken += tot;
+            __syncthreads();
+        }
+    }
+    const int nc = ngt + need_eq;                          // = min(k, n_items)
+    for (int i = nc + tid; i < 128; i += 256) cand[i] = 0ull;
+    __syncthreads();
+    // ---- bitonic sort of 128 composite keys, descending: score desc, then id asc (~id desc)
+    for (int sz = 2; sz <= 128; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            if (tid < 64) {
+                const int i = 2 * tid - (tid & (st - 1));   // lower element of the pair
+                const int j = i + st;
+                const bool desc = ((i & sz) == 0);
+                const unsigned long long a = cand[i], c = cand[j];
+                if ((a < c) == desc) { cand[i] = c; cand[j] = a; }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < k; r += 256) {
+        float fv = -INFINITY;
+        int64_t fi = 0;
+        if (r < nc) { const unsigned long long c = cand[r]; fv = key2f((unsigned)(c >> 32)); fi = (int64_t)(~(unsigned)c); }
+        out_score[(size_t)b * k + r] = fv;
+        out_item[(size_t)b * k + r] = fi;
+    }
+}
+
+extern "C" int64_t dr4sr_full_score_topk_workspace_bytes(int64_t B, int32_t n_items) {
+    if (B < 0 || n_items < 2) return DR4SR_E_ARG;
+    return B * (int64_t)((n_items + 63) / 64 * 64) * 4;
+}
+
+extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const int64_t* hist, float* out_score, int64_t* out_item,
+                                        int64_t B, int32_t D, int32_t n_items, int32_t Lh, int32_t k, float* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    if (!q || !E || !out_score || !out_item || !workspace || B < 0 || n_items < 2 || k <= 0 || k > 128 || Lh < 0 || (Lh > 0 && !hist))
+        return DR4SR_E_ARG;
+    if (D != 64 && D != 128) return DR4SR_E_SHAPE;
+    const int lds_s = (n_items + 63) / 64 * 64;
+    if (workspace_bytes < B * (int64_t)lds_s * 4) return DR4SR_E_WS;
+    const size_t lds_sel = sizeof(unsigned) * ((n_items + 3) & ~3) + sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 128;
+    if (lds_sel > 150 * 1024) return DR4SR_E_SHAPE;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(lds_s / 64, (unsigned)((B + 63) / 64));
+    const size_t lds_g = sizeof(float) * 2 * 64 * (D + 1);
+    if (D == 64) hipLaunchKernelGGL(k_score_gemm<64>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s);
+    else { big_lds(k_score_gemm<128>, lds_g); hipLaunchKernelGGL(k_score_gemm<128>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s); }
+    big_lds(k_topk_select, lds_sel);
+    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)B), dim3(256), lds_sel, s, workspace, hist, out_score, out_item, n_items, lds_s, Lh, k);
+    return DR4SR_LAUNCH_CHECK();
 }
 
 extern "C" int dr4sr_full_score_topk(const float* q, const float* E, const int64_t* hist, float* out_score,

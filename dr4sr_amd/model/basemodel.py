@@ -515,9 +515,14 @@ class BaseModel(nn.Module):
         score = torch.empty(B, k, dtype=torch.float32, device=query.device)
         ids = torch.empty(B, k, dtype=torch.int64, device=query.device)
         eng = self.engine
-        _lib.check(eng.lib.dr4sr_full_score_topk(_lib.ptr(query), _lib.ptr(self.item_embedding.weight), _lib.ptr(hist),
-                                                 _lib.ptr(score), _lib.ptr(ids), B, eng.D, self.num_items,
-                                                 hist.shape[1] if hist is not None else 0, k, _lib.cur_stream()), "topk")
+        need = int(eng.lib.dr4sr_full_score_topk_workspace_bytes(B, self.num_items))      # [B, N] scores: one MFMA GEMM + radix select
+        ws = getattr(self, "_topk_ws", None)
+        if ws is None or ws.numel() * 4 < need:
+            ws = self._topk_ws = torch.empty(need // 4, dtype=torch.float32, device=query.device)
+        _lib.check(eng.lib.dr4sr_full_score_topk_ws(_lib.ptr(query), _lib.ptr(self.item_embedding.weight), _lib.ptr(hist),
+                                                    _lib.ptr(score), _lib.ptr(ids), B, eng.D, self.num_items,
+                                                    hist.shape[1] if hist is not None else 0, k, _lib.ptr(ws), ws.numel() * 4,
+                                                    _lib.cur_stream()), "topk")
         return score, ids
 
     def set_eval_domain(self, domain):

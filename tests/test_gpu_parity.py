@@ -428,3 +428,50 @@ def test_topk_vs_golden(dev, golden_dir, name):
     assert (it.cpu().numpy() == g["eval.topk_items"]).mean() > 0.99
     hit = torch.from_numpy(g["eval.item_id"]).view(-1, 1) == it.cpu()
     np.testing.assert_allclose(O.ndcg_at(hit, 20).numpy(), g["eval.ndcg@20"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,k,Lh", [(37, 50, 100, 20), (130, 2000, 20, 50), (64, 11925, 100, 50)])
+def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
+    """dr4sr_full_score_topk_ws (MFMA score GEMM + radix select) returns what the per-row arg-max kernel returns: same ids wherever the
+    scores are not within rounding of each other, scores of the returned ids, order, -inf handling (PAD, history, k > valid items)"""
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + N)
+    q = torch.randn(B, 64, generator=g).to(dev)
+    E = (0.1 * torch.randn(N, 64, generator=g)).to(dev)
+    E[0] = 0
+    E[5] = E[7]                                                      # an exact tie: lower id first
+    hist = torch.randint(0, N, (B, Lh), generator=g).to(dev)
+    outs = []
+    for ws_path in (False, True):
+        sc = torch.empty(B, k, device=dev)
+        it = torch.empty(B, k, dtype=torch.int64, device=dev)
+        if ws_path:
+            nb = int(lib.dr4sr_full_score_topk_workspace_bytes(B, N))
+            ws = torch.empty(nb // 4, device=dev)
+            _lib.check(lib.dr4sr_full_score_topk_ws(_lib.ptr(q), _lib.ptr(E), _lib.ptr(hist), _lib.ptr(sc), _lib.ptr(it), B, 64, N, Lh, k,
+                                                    _lib.ptr(ws), nb, _lib.cur_stream()), "topk_ws")
+        else:
+            _lib.check(lib.dr4sr_full_score_topk(_lib.ptr(q), _lib.ptr(E), _lib.ptr(hist), _lib.ptr(sc), _lib.ptr(it), B, 64, N, Lh, k,
+                                                 _lib.cur_stream()), "topk")
+        outs.append((sc.cpu(), it.cpu()))
+    (sa, ia), (sb, ib) = outs
+    fin = torch.isfinite(sa)
+    assert bool((fin == torch.isfinite(sb)).all())
+    assert float((sa[fin] - sb[fin]).abs().max()) < 1e-5
+    assert float((ia == ib).float().mean()) > 0.999                 # fp32 summation order can swap near-ties only
+    s = (q @ E.T).cpu()
+    s[:, 0] = float("-inf")
+    s.scatter_(1, hist.cpu(), float("-inf"))
+    kk = min(k, N)
+    assert float((s.gather(1, ib[:, :kk]) - sb[:, :kk])[torch.isfinite(sb[:, :kk])].abs().max()) < 1e-5
+    assert bool((sb[:, 1:] <= sb[:, :-1]).all())
+    srt = ib[:, :kk].sort(1)[0]
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                   # no id twice
+    if k > N:
+        assert bool((ib[:, N:] == 0).all()) and bool(torch.isinf(sb[:, N:]).all())
+    both = (ib == 5) | (ib == 7)                                     # the tie: whenever both ids are returned, 5 comes first
+    for r in range(B):
+        pos = both[r].nonzero().flatten().tolist()
+        if len(pos) == 2 and bool(torch.isfinite(sb[r, pos]).all()):            # (not when the history masks one of them)
+            assert int(ib[r, pos[0]]) == 5 and pos[1] == pos[0] + 1
