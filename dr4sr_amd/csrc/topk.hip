@@ -114,22 +114,11 @@ __global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Q,
 __device__ __forceinline__ unsigned f2key(float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-__global__ __launch_bounds__(256) void k_topk_select(const float* __restrict__ S, const int64_t* __restrict__ hist,
-                                                     float* __restrict__ out_score, int64_t* __restrict__ out_item, int n_items,
-                                                     int lds_s, int Lh, int k) {
-    unsigned* key = reinterpret_cast<unsigned*>(smem);     // [n_items]
-    int* hst = reinterpret_cast<int*>(key + ((n_items + 3) & ~3));       // [256] digit histogram
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(hst + 256 + 8);     // [128] (key << 32) | ~id
-    int* ctl = hst + 256;                                  // [0] selected digit, [1] remaining rank, [2] candidate count, [3] ties taken
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const float* row = S + (size_t)b * lds_s;
-    for (int n = tid; n < n_items; n += 256) key[n] = f2key(row[n]);
+// exact selection by radix: the key T of rank kk (4 passes of 256-bin LDS histograms), then every key above T and the lowest-index
+// keys equal to T.  Slow path (the histograms contend on a few bins) — used when ties make the fast path's candidate set overflow.
+__device__ __forceinline__ int select_radix(const unsigned* key, int* hst, int* ctl, unsigned long long* cand, int n_items, int k) {
+    const int tid = threadIdx.x, lane = tid & 63;
     __syncthreads();
-    const unsigned kneg = f2key(-INFINITY);
-    for (int j = tid; j < Lh; j += 256) {
-        const int64_t id = hist[(size_t)b * Lh + j];
-        if (id >= 0 && id < n_items) key[id] = kneg;
-    }
     if (tid == 0) { ctl[1] = k < n_items ? k : n_items; ctl[2] = 0; ctl[3] = 0; }
     // ---- radix select: the key T of rank ctl[1] (1-based, from the top)
     unsigned prefix = 0, pmask = 0;
@@ -192,21 +181,76 @@ __global__ __launch_bounds__(256) void k_topk_select(const float* __restrict__ S
             __syncthreads();
         }
     }
-    const int nc = ngt + need_eq;                          // = min(k, n_items)
-    for (int i = nc + tid; i < 128; i += 256) cand[i] = 0ull;
-    __syncthreads();
-    // ---- bitonic sort of 128 composite keys, descending: score desc, then id asc (~id desc)
-    for (int sz = 2; sz <= 128; sz <<= 1)
+    return ngt + need_eq;
+}
+
+template <int NS>
+__device__ __forceinline__ void bitonic_desc(unsigned long long* a) {      // NS power of two <= 512, 256 threads
+    const int tid = threadIdx.x;
+    for (int sz = 2; sz <= NS; sz <<= 1)
         for (int st = sz >> 1; st > 0; st >>= 1) {
-            if (tid < 64) {
-                const int i = 2 * tid - (tid & (st - 1));   // lower element of the pair
-                const int j = i + st;
+            if (tid < NS / 2) {
+                const int i = 2 * tid - (tid & (st - 1)), j = i + st;
                 const bool desc = ((i & sz) == 0);
-                const unsigned long long a = cand[i], c = cand[j];
-                if ((a < c) == desc) { cand[i] = c; cand[j] = a; }
+                const unsigned long long x = a[i], y = a[j];
+                if ((x < y) == desc) { a[i] = y; a[j] = x; }
             }
             __syncthreads();
         }
+}
+
+// One workgroup per row.  Fast path: the k-th largest of the 256 per-thread maxima is a lower bound of the k-th largest score, so
+// only the keys >= that bound (~1.3 k of them for unstructured scores) are candidates; they are sorted as (key, ~id) composites,
+// which also orders ties by id.  No histogram, no contended atomics: ~80 barriers per row.
+__global__ __launch_bounds__(256) void k_topk_select(const float* __restrict__ S, const int64_t* __restrict__ hist,
+                                                     float* __restrict__ out_score, int64_t* __restrict__ out_item, int n_items,
+                                                     int lds_s, int Lh, int k) {
+    constexpr int CAP = 512;
+    unsigned* key = reinterpret_cast<unsigned*>(smem);     // [n_items]
+    int* hst = reinterpret_cast<int*>(key + ((n_items + 3) & ~3));       // [256] digit histogram (radix path)
+    int* ctl = hst + 256;                                  // [8]
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(hst + 256 + 8);     // [CAP] (key << 32) | ~id
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = S + (size_t)b * lds_s;
+    for (int n = tid; n < n_items; n += 256) key[n] = f2key(row[n]);
+    __syncthreads();
+    const unsigned kneg = f2key(-INFINITY);
+    for (int j = tid; j < Lh; j += 256) {
+        const int64_t id = hist[(size_t)b * Lh + j];
+        if (id >= 0 && id < n_items) key[id] = kneg;
+    }
+    if (tid == 0) ctl[4] = 0;
+    __syncthreads();
+    const int kk = k < n_items ? k : n_items;
+    unsigned lm = 0;
+    for (int n = tid; n < n_items; n += 256) lm = max(lm, key[n]);
+    cand[tid] = (unsigned long long)lm << 32;
+    __syncthreads();
+    bitonic_desc<256>(cand);
+    const unsigned bound = (unsigned)(cand[kk - 1] >> 32);  // at least kk keys are >= bound (kk distinct thread maxima)
+    __syncthreads();
+    for (int n = tid; n < n_items; n += 256) {
+        const unsigned kv = key[n];
+        if (kv >= bound && bound != 0u) {
+            const int p = atomicAdd(&ctl[4], 1);
+            if (p < CAP) cand[p] = ((unsigned long long)kv << 32) | (unsigned)(~(unsigned)n);
+        }
+    }
+    __syncthreads();
+    int nc = ctl[4];
+    if (nc > CAP || bound == 0u) {                         // ties piled up at the bound (e.g. k > number of unmasked items): exact radix path
+        nc = select_radix(key, hst, ctl, cand, n_items, k);
+        for (int i = nc + tid; i < 128; i += 256) cand[i] = 0ull;
+        __syncthreads();
+        bitonic_desc<128>(cand);
+    } else {
+        int ns = 128;
+        while (ns < nc) ns <<= 1;
+        for (int i = nc + tid; i < ns; i += 256) cand[i] = 0ull;
+        __syncthreads();
+        if (ns == 128) bitonic_desc<128>(cand); else if (ns == 256) bitonic_desc<256>(cand); else bitonic_desc<512>(cand);
+        nc = kk;
+    }
     for (int r = tid; r < k; r += 256) {
         float fv = -INFINITY;
         int64_t fi = 0;
@@ -229,7 +273,7 @@ extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const in
     if (D != 64 && D != 128) return DR4SR_E_SHAPE;
     const int lds_s = (n_items + 63) / 64 * 64;
     if (workspace_bytes < B * (int64_t)lds_s * 4) return DR4SR_E_WS;
-    const size_t lds_sel = sizeof(unsigned) * ((n_items + 3) & ~3) + sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 128;
+    const size_t lds_sel = sizeof(unsigned) * ((n_items + 3) & ~3) + sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 512;
     if (lds_sel > 150 * 1024) return DR4SR_E_SHAPE;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;

@@ -430,7 +430,7 @@ def test_topk_vs_golden(dev, golden_dir, name):
     np.testing.assert_allclose(O.ndcg_at(hit, 20).numpy(), g["eval.ndcg@20"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,N,k,Lh", [(37, 50, 100, 20), (130, 2000, 20, 50), (64, 11925, 100, 50)])
+@pytest.mark.parametrize("B,N,k,Lh", [(37, 50, 100, 20), (130, 2000, 20, 50), (64, 11925, 100, 50), (33, 3000, 100, 7)])
 def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
     """dr4sr_full_score_topk_ws (MFMA score GEMM + radix select) returns what the per-row arg-max kernel returns: same ids wherever the
     scores are not within rounding of each other, scores of the returned ids, order, -inf handling (PAD, history, k > valid items)"""
@@ -441,6 +441,9 @@ def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
     E = (0.1 * torch.randn(N, 64, generator=g)).to(dev)
     E[0] = 0
     E[5] = E[7]                                                      # an exact tie: lower id first
+    if N == 3000:
+        E[100:2500] = E[100]                                         # 2400-way tie: the candidate set overflows -> exact radix path
+        q[::2] = E[100] * 50                                         # ... and it sits at the top for every other row
     hist = torch.randint(0, N, (B, Lh), generator=g).to(dev)
     outs = []
     for ws_path in (False, True):
