@@ -204,18 +204,40 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
     return t;
 }
 
-// e = rel * sqrt( sum theta^2 over {dir != 0} / sum dir^2 )      (single block: deterministic)
-__global__ __launch_bounds__(1024) void k_fd_step_size(const float* __restrict__ theta, const float* __restrict__ dir, int64_t n,
-                                                      float rel, float* __restrict__ out_e) {
+// e = rel * sqrt( sum theta^2 over {dir != 0} / sum dir^2 ).  Deterministic two-level sum: FD_BLOCKS workgroups leave one partial pair
+// each, the last one to finish (ticket) adds them in index order.  (The first version walked all 833 k parameters in ONE workgroup:
+// 320 us per call, four calls per outer step.)
+constexpr int FD_BLOCKS = 256;
+__device__ float g_fd_part[2 * FD_BLOCKS];
+__device__ int g_fd_ticket;
+__global__ __launch_bounds__(256) void k_fd_step_size(const float* __restrict__ theta, const float* __restrict__ dir, int64_t n,
+                                                     float rel, float* __restrict__ out_e) {
     __shared__ float sm[16];
+    __shared__ int last;
     float st = 0.f, sd = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float d = dir[i];
-        if (d != 0.f) { const float t = theta[i]; st = fmaf(t, t, st); sd = fmaf(d, d, sd); }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)FD_BLOCKS * 256) {
+        const float d = dir[i], t = theta[i];
+        if (d != 0.f) { st = fmaf(t, t, st); sd = fmaf(d, d, sd); }
     }
     st = block_sum(st, sm);
     sd = block_sum(sd, sm);
-    if (threadIdx.x == 0) out_e[0] = sd > 0.f ? rel * sqrtf(st / sd) : 0.f;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&g_fd_part[2 * blockIdx.x], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g_fd_part[2 * blockIdx.x + 1], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(&g_fd_ticket, 1) == FD_BLOCKS - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float pt = 0.f, pd = 0.f;
+    if (threadIdx.x < FD_BLOCKS) {
+        pt = __hip_atomic_load(&g_fd_part[2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pd = __hip_atomic_load(&g_fd_part[2 * threadIdx.x + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    pt = block_sum(pt, sm);                                // fixed reduction tree over the partials: run-to-run identical
+    pd = block_sum(pd, sm);
+    if (threadIdx.x == 0) { out_e[0] = pd > 0.f ? rel * sqrtf(pt / pd) : 0.f; g_fd_ticket = 0; }
 }
 
 // out = x + sign * e * dir
@@ -319,7 +341,7 @@ extern "C" int dr4sr_meta_select_bwd(const float* query, const float* phi, const
 
 extern "C" int dr4sr_fd_step_size(const float* theta, const float* dir, int64_t n, float rel_step, float* out_e, void* stream) {
     if (!theta || !dir || !out_e || n <= 0) return DR4SR_E_ARG;
-    hipLaunchKernelGGL(k_fd_step_size, dim3(1), dim3(1024), 0, (hipStream_t)stream, theta, dir, n, rel_step, out_e);
+    hipLaunchKernelGGL(k_fd_step_size, dim3(FD_BLOCKS), dim3(256), 0, (hipStream_t)stream, theta, dir, n, rel_step, out_e);
     return (int)hipGetLastError();
 }
 
