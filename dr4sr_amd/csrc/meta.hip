@@ -184,12 +184,21 @@ __global__ __launch_bounds__(SEL_WAVES * 64) void k_meta_select_bwd(SelArgs A) {
 }
 
 // d_phi[i] += sum over blocks (fixed order)
-__global__ void k_meta_reduce(const float* __restrict__ part, int nblk, float* __restrict__ d_phi) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N_PHI) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * N_PHI + i];
-    d_phi[i] += s;
+// 64 columns per workgroup, the partial rows split over its 4 waves with 8 independent loads in flight (a single thread walking
+// all rows of a column is a chain of dependent-latency loads: 32 us for 4 290 columns)
+__global__ __launch_bounds__(256) void k_meta_reduce(const float* __restrict__ part, int nblk, float* __restrict__ d_phi) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (i < N_PHI)
+        for (int b = w * 8; b < nblk; b += 32)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (b + u < nblk) acc[u] += part[(size_t)(b + u) * N_PHI + i];
+    red[w][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w == 0 && i < N_PHI) d_phi[i] += (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // ------------------------------------------------------------------------------------------------ FD helpers
@@ -335,7 +344,7 @@ extern "C" int dr4sr_meta_select_bwd(const float* query, const float* phi, const
     A.seed = seed; A.step = step; A.step_dev = step_dev;
     const int g = sel_grid(n);
     hipLaunchKernelGGL(k_meta_select_bwd, dim3(g), dim3(SEL_WAVES * 64), 0, (hipStream_t)stream, A);
-    hipLaunchKernelGGL(k_meta_reduce, dim3((N_PHI + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, g, d_phi);
+    hipLaunchKernelGGL(k_meta_reduce, dim3((N_PHI + 63) / 64), dim3(256), 0, (hipStream_t)stream, workspace, g, d_phi);
     return (int)hipGetLastError();
 }
 
