@@ -112,11 +112,16 @@ __global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Q,
 }
 
 __device__ __forceinline__ unsigned f2key(float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+// the selection reads the row either from LDS (catalogs up to ~37 k items) or straight from the score workspace (any size)
+struct RowKeys {
+    const unsigned* lds; const float* glb;
+    __device__ __forceinline__ unsigned operator[](int n) const { return lds ? lds[n] : f2key(glb[n]); }
+};
 __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 // exact selection by radix: the key T of rank kk (4 passes of 256-bin LDS histograms), then every key above T and the lowest-index
 // keys equal to T.  Slow path (the histograms contend on a few bins) — used when ties make the fast path's candidate set overflow.
-__device__ __forceinline__ int select_radix(const unsigned* key, int* hst, int* ctl, unsigned long long* cand, int n_items, int k) {
+__device__ __forceinline__ int select_radix(const RowKeys key, int* hst, int* ctl, unsigned long long* cand, int n_items, int k) {
     const int tid = threadIdx.x, lane = tid & 63;
     __syncthreads();
     if (tid == 0) { ctl[1] = k < n_items ? k : n_items; ctl[2] = 0; ctl[3] = 0; }
@@ -202,25 +207,29 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long* a) {      // NS
 // One workgroup per row.  Fast path: the k-th largest of the 256 per-thread maxima is a lower bound of the k-th largest score, so
 // only the keys >= that bound (~1.3 k of them for unstructured scores) are candidates; they are sorted as (key, ~id) composites,
 // which also orders ties by id.  No histogram, no contended atomics: ~80 barriers per row.
-__global__ __launch_bounds__(256) void k_topk_select(const float* __restrict__ S, const int64_t* __restrict__ hist,
+template <bool LDSROW>
+__global__ __launch_bounds__(256) void k_topk_select(float* __restrict__ S, const int64_t* __restrict__ hist,
                                                      float* __restrict__ out_score, int64_t* __restrict__ out_item, int n_items,
                                                      int lds_s, int Lh, int k) {
     constexpr int CAP = 512;
-    unsigned* key = reinterpret_cast<unsigned*>(smem);     // [n_items]
-    int* hst = reinterpret_cast<int*>(key + ((n_items + 3) & ~3));       // [256] digit histogram (radix path)
+    unsigned* keyl = reinterpret_cast<unsigned*>(smem);    // [n_items] (LDSROW only)
+    int* hst = reinterpret_cast<int*>(keyl + (LDSROW ? ((n_items + 3) & ~3) : 0));       // [256] digit histogram (radix path)
     int* ctl = hst + 256;                                  // [8]
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(hst + 256 + 8);     // [CAP] (key << 32) | ~id
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* row = S + (size_t)b * lds_s;
-    for (int n = tid; n < n_items; n += 256) key[n] = f2key(row[n]);
-    __syncthreads();
+    float* row = S + (size_t)b * lds_s;
     const unsigned kneg = f2key(-INFINITY);
-    for (int j = tid; j < Lh; j += 256) {
+    if (LDSROW) {
+        for (int n = tid; n < n_items; n += 256) keyl[n] = f2key(row[n]);
+        __syncthreads();
+    }
+    for (int j = tid; j < Lh; j += 256) {                  // history -> -inf (in the LDS copy, or in the workspace row itself)
         const int64_t id = hist[(size_t)b * Lh + j];
-        if (id >= 0 && id < n_items) key[id] = kneg;
+        if (id >= 0 && id < n_items) { if (LDSROW) keyl[id] = kneg; else row[id] = -INFINITY; }
     }
     if (tid == 0) ctl[4] = 0;
     __syncthreads();
+    const RowKeys key{LDSROW ? keyl : nullptr, row};
     const int kk = k < n_items ? k : n_items;
     unsigned lm = 0;
     for (int n = tid; n < n_items; n += 256) lm = max(lm, key[n]);
@@ -273,16 +282,21 @@ extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const in
     if (D != 64 && D != 128) return DR4SR_E_SHAPE;
     const int lds_s = (n_items + 63) / 64 * 64;
     if (workspace_bytes < B * (int64_t)lds_s * 4) return DR4SR_E_WS;
-    const size_t lds_sel = sizeof(unsigned) * ((n_items + 3) & ~3) + sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 512;
-    if (lds_sel > 150 * 1024) return DR4SR_E_SHAPE;
+    const size_t lds_fix = sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 512;
+    const size_t lds_row = sizeof(unsigned) * ((n_items + 3) & ~3) + lds_fix;
+    const bool ldsrow = lds_row <= 64 * 1024;               // (above that the LDS copy costs more occupancy than the second row read)
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(lds_s / 64, (unsigned)((B + 63) / 64));
     const size_t lds_g = sizeof(float) * 2 * 64 * (D + 1);
     if (D == 64) hipLaunchKernelGGL(k_score_gemm<64>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s);
     else { big_lds(k_score_gemm<128>, lds_g); hipLaunchKernelGGL(k_score_gemm<128>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s); }
-    big_lds(k_topk_select, lds_sel);
-    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)B), dim3(256), lds_sel, s, workspace, hist, out_score, out_item, n_items, lds_s, Lh, k);
+    if (ldsrow) {
+        big_lds(k_topk_select<true>, lds_row);
+        hipLaunchKernelGGL(k_topk_select<true>, dim3((unsigned)B), dim3(256), lds_row, s, workspace, hist, out_score, out_item, n_items, lds_s, Lh, k);
+    } else {
+        hipLaunchKernelGGL(k_topk_select<false>, dim3((unsigned)B), dim3(256), lds_fix, s, workspace, hist, out_score, out_item, n_items, lds_s, Lh, k);
+    }
     return DR4SR_LAUNCH_CHECK();
 }
 

@@ -190,7 +190,8 @@ int dr4sr_full_score_topk(const float* q, const float* E, const int64_t* hist, f
                           int32_t k, void* stream);
 /* the same through a [B, round_up(n_items, 64)] fp32 score workspace (dr4sr_full_score_topk_workspace_bytes): the scores come from
  * one MFMA GEMM instead of B passes over the table and the top-k from a radix select — identical results, ~15x faster at the
- * reference's eval shape (2048 x 11925, k = 100). */
+ * reference's eval shape (2048 x 11925, k = 100); no limit on n_items (rows that do not fit LDS are selected from the workspace, whose
+ * history columns are then overwritten with -inf). */
 int64_t dr4sr_full_score_topk_workspace_bytes(int64_t B, int32_t n_items);
 int dr4sr_full_score_topk_ws(const float* q, const float* E, const int64_t* hist, float* out_score, int64_t* out_item, int64_t B,
                              int32_t D, int32_t n_items, int32_t Lh, int32_t k, float* workspace, int64_t workspace_bytes,

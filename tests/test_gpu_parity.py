@@ -430,7 +430,7 @@ def test_topk_vs_golden(dev, golden_dir, name):
     np.testing.assert_allclose(O.ndcg_at(hit, 20).numpy(), g["eval.ndcg@20"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,N,k,Lh", [(37, 50, 100, 20), (130, 2000, 20, 50), (64, 11925, 100, 50), (33, 3000, 100, 7)])
+@pytest.mark.parametrize("B,N,k,Lh", [(37, 50, 100, 20), (130, 2000, 20, 50), (64, 11925, 100, 50), (33, 3000, 100, 7), (40, 20034, 100, 50)])
 def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
     """dr4sr_full_score_topk_ws (MFMA score GEMM + radix select) returns what the per-row arg-max kernel returns: same ids wherever the
     scores are not within rounding of each other, scores of the returned ids, order, -inf handling (PAD, history, k > valid items)"""
@@ -478,3 +478,29 @@ def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
         pos = both[r].nonzero().flatten().tolist()
         if len(pos) == 2 and bool(torch.isfinite(sb[r, pos]).all()):            # (not when the history masks one of them)
             assert int(ib[r, pos[0]]) == 5 and pos[1] == pos[0] + 1
+
+
+def test_topk_workspace_path_large_catalog(dev):
+    """N = 70 000 items: beyond what fits an LDS row — the selection reads the score workspace directly (history masked in place)"""
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    B, N, k, Lh = 24, 70000, 100, 50
+    g = torch.Generator().manual_seed(12)
+    q = torch.randn(B, 64, generator=g).to(dev)
+    E = (0.1 * torch.randn(N, 64, generator=g)).to(dev)
+    hist = torch.randint(0, N, (B, Lh), generator=g).to(dev)
+    sc = torch.empty(B, k, device=dev)
+    it = torch.empty(B, k, dtype=torch.int64, device=dev)
+    nb = int(lib.dr4sr_full_score_topk_workspace_bytes(B, N))
+    ws = torch.empty(nb // 4, device=dev)
+    _lib.check(lib.dr4sr_full_score_topk_ws(_lib.ptr(q), _lib.ptr(E), _lib.ptr(hist), _lib.ptr(sc), _lib.ptr(it), B, 64, N, Lh, k,
+                                            _lib.ptr(ws), nb, _lib.cur_stream()), "topk_ws")
+    s = q @ E.T
+    s[:, 0] = float("-inf")
+    s.scatter_(1, hist, float("-inf"))
+    rs, ri = torch.topk(s, k, dim=1)
+    assert float((rs - sc).abs().max()) < 1e-5
+    assert float((ri == it).float().mean()) > 0.995
+    assert float((s.gather(1, it) - sc).abs().max()) < 1e-5 and bool((sc[:, 1:] <= sc[:, :-1]).all())
+    for r in range(B):
+        assert not bool(torch.isin(it[r], hist[r]).any())          # no history item is ever recommended
