@@ -494,6 +494,29 @@ def main():
                                           "hbm_traffic_rate": None if traffic is None else traffic / 1e9 / (us * 1e-6),
                                           "hbm_traffic_frac": None if traffic is None else traffic / 1e9 / (us * 1e-6) / HBM_PEAK_GBS}
                 del outbuf, idx_big
+                # ---- eval hot loop: full-item scores + top-100 of one 2048-row eval batch (basemodel.py:337-365)
+                Be, ke = 2048, 100
+                qe = torch.randn(Be, D, device=dev)
+                hist_e = torch.randint(0, N, (Be, L), device=dev)
+                sc_e = torch.empty(Be, ke, device=dev)
+                it_e = torch.empty(Be, ke, dtype=torch.int64, device=dev)
+                wsb = int(lib.dr4sr_full_score_topk_workspace_bytes(Be, N))
+                ws_e = torch.empty(wsb // 4, device=dev)
+
+                def topk_once():
+                    _lib.check(lib.dr4sr_full_score_topk_ws(_lib.ptr(qe), _lib.ptr(E), _lib.ptr(hist_e), _lib.ptr(sc_e), _lib.ptr(it_e), Be, D, N,
+                                                            L, ke, _lib.ptr(ws_e), wsb, _lib.cur_stream()), "topk_ws")
+                for _ in range(3):
+                    topk_once()
+                a.record()
+                for _ in range(10):
+                    topk_once()
+                b.record()
+                b.synchronize()
+                ms_e = a.elapsed_time(b) / 10
+                out["eval_topk"] = {"rows": Be, "n_items": N, "k": ke, "ms_per_batch": ms_e, "rows_per_s": Be / (ms_e * 1e-3),
+                                    "kernels": "k_score_gemm (MFMA) + k_topk_select"}
+                del ws_e
 
         return out, rows_np, N
 
