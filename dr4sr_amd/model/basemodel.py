@@ -304,8 +304,12 @@ class BaseModel(nn.Module):
                 eng.fwd_bwd(plan)
                 allreduce_flat(eng.grads)                 # RCCL sum: gradients + {n_valid, loss_sum} tail
                 eng.adam_step(plan)
+
+            def local_only():                             # warm-up must NOT enter a collective: ranks create their graphs at different
+                eng.fwd_bwd(plan)                         # steps (a tail batch gives some ranks a new slice size, others an old or empty one)
+                eng.adam_step(plan)
             if use_graph:
-                warm_up(eager)
+                warm_up(local_only)
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     eng.fwd_bwd(plan)

@@ -412,9 +412,8 @@ class MetaModel(BaseModel):
             eng.adam_step(sub._api_plan())
         undo = [eng.params, eng.adam_m, eng.adam_v, eng.state]
         snap = [t.clone() for t in undo]
-        fwd_bwd()                                          # warm-up outside capture (allocates the persistent scratch buffers)
-        self._reduce_grads()
-        adam()
+        fwd_bwd()                                          # warm-up outside capture (allocates the persistent scratch buffers);
+        adam()                                             # no collective here: ranks build their graphs at different steps
         torch.cuda.synchronize()
         for dst, src in zip(undo, snap):
             dst.copy_(src)

@@ -262,3 +262,18 @@ def test_data_parallel_ranks_equal_single_rank():
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CHECK")]
     assert out.returncode == 0 and len(lines) == 2, out.stdout[-2000:] + out.stderr[-2000:]
     assert "replica checksums equal: True" in lines[1]
+
+
+@pytest.mark.gpu
+def test_data_parallel_fit_end_to_end():
+    """fit() under 2 ranks (gloo, sharing cuda:0) on a dataset whose tail batch splits unevenly (13 rows: rank 0 gets a new slice size,
+    rank 1 an empty one): every rank must enter the same collectives (graph warm-ups stay local) and the replicas stay bit-identical"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29571", os.path.join(root, "tools", "dp_fit_check.py")], capture_output=True, text=True,
+                         timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "replicas identical: True; finite: True" in lines[0] and "steps=27" in lines[0]
