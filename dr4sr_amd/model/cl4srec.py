@@ -17,6 +17,9 @@ class CL4SRec(SASRec):
         return 3                               # main pass + two views
 
     def _init_model(self, train_data):
+        if self.world_size > 1:
+            raise NotImplementedError("CL4SRec trains through the API path, which has no gradient all-reduce: single GPU only "
+                                      "(data parallelism covers SASRec / GRU4Rec / FMLP / MetaModel)")
         super()._init_model(train_data)
         self.augmentation_model = data_augmentation.CL4SRecAugmentation(self.config["model"], train_data,
                                                                        seed=int(self.config["train"]["seed"]) + 104729 * self.rank)

@@ -12,17 +12,15 @@ os.makedirs("/tmp/dpfit%d" % rank, exist_ok=True)
 os.chdir("/tmp/dpfit%d" % rank)
 logging.getLogger("CDR").setLevel(logging.WARNING)
 dist.init_process_group("gloo")
-from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
-cfg = {
-    "data": {"dataset": "synthetic-toys", "domain_name_list": ["toy"], "max_seq_len": 50, "dataset_class": "synthetic",
-             "train_file": "", "n_items": 300, "n_rows": 1000 + 37, "n_eval_rows": 256, "seed": 5},
-    "model": {"model": "SASRec", "embed_dim": 64, "loss_fn": "bce", "hidden_size": 128, "layer_num": 2, "head_num": 2,
-              "dropout_rate": 0.2, "activation": "gelu", "layer_norm_eps": 1e-12},
-    "train": {"batch_size": 128, "early_stop_mode": "max", "early_stop_patience": 20, "epochs": 3, "device": "cuda:0",
-              "optimizer": "adam", "learning_rate": 0.001, "weight_decay": 0, "num_neg": 1, "seed": 2023, "hip_graph": True},
-    "eval": {"batch_size": 128, "cutoff": [20, 10], "val_metrics": ["ndcg", "recall"], "test_metrics": ["ndcg", "recall"],
-             "topk": 100, "save_path": "./saved/"},
-}
+from dr4sr_amd.utils import load_config, prepare_datasets, prepare_model, seed_everything
+MODEL = os.environ.get("MODEL", "SASRec")
+cfg = load_config({"model": MODEL, "dataset": "synthetic-toys"})
+cfg["data"].update({"n_items": 300, "n_rows": 1000 + 37, "n_eval_rows": 256, "seed": 5})
+cfg["model"]["dropout_rate"] = 0.2
+cfg["train"].update({"batch_size": 128, "epochs": 3, "device": "cuda:0", "hip_graph": True})
+if "interval" in cfg["train"]:
+    cfg["train"]["interval"] = 4                          # MetaModel: several outer steps per epoch
+cfg["eval"]["batch_size"] = 128
 seed_everything(cfg["train"]["seed"])
 ds = prepare_datasets(cfg)
 model = prepare_model(cfg, ds)
@@ -52,6 +50,6 @@ lst = [torch.zeros_like(chk) for _ in range(world)]
 dist.all_gather(lst, chk)
 if rank == 0:
     same = all(bool((x == lst[0]).all()) for x in lst)
-    print("DP_FIT world=%d steps=%d replicas identical: %s; finite: %s; train loss %.4f" %
+    print("DP_FIT model=" + MODEL + " world=%d steps=%d replicas identical: %s; finite: %s; train loss %.4f" %
           (world, int(model.engine.state[0]), same, bool(torch.isfinite(p).all()), float(model.logged_metrics.get("train_loss_0", float("nan")))))
 dist.destroy_process_group()
