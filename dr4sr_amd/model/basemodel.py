@@ -376,6 +376,9 @@ class BaseModel(nn.Module):
         if self._fast_path_ok():
             return [self._fused_epoch(loader)]
         outputs = []
+        if self.world_size > 1:
+            raise NotImplementedError("the API path (DR4SR_NO_FAST_PATH / non-BCE loss) has no gradient all-reduce: data parallelism "
+                                      "needs the fused path")
         if self._api_graph_ok():
             return [[{"loss_0": self._api_step_graph(batch)} for batch in loader]]
         for batch in loader:                                        # API path (reference loop, basemodel.py:192-200)
