@@ -538,6 +538,9 @@ class BaseModel(nn.Module):
     def evaluate(self) -> Dict:
         test_data = self.dataset_list[-1]
         output = defaultdict(float)
+        if self.world_size > 1:                            # rank 0 writes the checkpoint at the end of fit(): wait for the file
+            import torch.distributed as dist
+            dist.barrier()
         self.load_checkpoint(os.path.join(self.config["eval"]["save_path"], self.ckpt_path))
         self.eval()
         for domain in self.domain_name_list:

@@ -8,8 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-os.makedirs("/tmp/dpfit%d" % rank, exist_ok=True)
-os.chdir("/tmp/dpfit%d" % rank)
+os.makedirs("/tmp/dpfit", exist_ok=True)            # one working directory: rank 0 writes the checkpoint, every rank loads it
+os.chdir("/tmp/dpfit")
 logging.getLogger("CDR").setLevel(logging.WARNING)
 dist.init_process_group("gloo")
 from dr4sr_amd.utils import load_config, prepare_datasets, prepare_model, seed_everything
@@ -43,6 +43,7 @@ def _host_broadcast(t, src=0, **kw):
         _bc(t, src=src, **kw)
 dist.broadcast = _host_broadcast
 model.fit()
+test = model.evaluate()
 torch.cuda.synchronize()
 p = model.engine.params
 chk = torch.tensor([float(p.double().sum()), float(p.double().abs().sum())], dtype=torch.float64)
@@ -50,6 +51,6 @@ lst = [torch.zeros_like(chk) for _ in range(world)]
 dist.all_gather(lst, chk)
 if rank == 0:
     same = all(bool((x == lst[0]).all()) for x in lst)
-    print("DP_FIT model=" + MODEL + " world=%d steps=%d replicas identical: %s; finite: %s; train loss %.4f" %
+    print("DP_FIT model=" + MODEL + " test " + str({k: round(float(v), 4) for k, v in list(test.items())[:2]}) + " world=%d steps=%d replicas identical: %s; finite: %s; train loss %.4f" %
           (world, int(model.engine.state[0]), same, bool(torch.isfinite(p).all()), float(model.logged_metrics.get("train_loss_0", float("nan")))))
 dist.destroy_process_group()
