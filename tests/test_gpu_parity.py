@@ -504,3 +504,13 @@ def test_topk_workspace_path_large_catalog(dev):
     assert float((s.gather(1, it) - sc).abs().max()) < 1e-5 and bool((sc[:, 1:] <= sc[:, :-1]).all())
     for r in range(B):
         assert not bool(torch.isin(it[r], hist[r]).any())          # no history item is ever recommended
+
+
+def test_fuzz_odd_batches_vs_oracle(dev):
+    """random odd batch sizes (1 .. 100), item counts down to 2, both widths, random lengths and PAD targets: tools/fuzz_parity.py"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, TRIALS="10", SEED="3"), cwd=root)
+    assert out.returncode == 0 and "FUZZ ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
