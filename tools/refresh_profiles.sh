@@ -15,6 +15,9 @@ trace sasrec_B256 --steps 200 --warmup 20
 trace sasrec_dense_B256 --steps 200 --warmup 20 --dense
 trace sasrec_B8192 --steps 60 --warmup 10 --batch 8192
 trace sasrec_dense_B8192 --steps 40 --warmup 10 --batch 8192 --dense
+# the literal rocprofv3 --stats summary of the default bench command
+rm -rf /tmp/st_default; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_default -o d -- python $R/bench.py --no-cpu-baseline --no-throughput-mode > /tmp/st_default.log 2>&1
+cp $(find /tmp/st_default -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_default.csv
 cd $R
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 timeout 300 python bench.py --dense --no-cpu-baseline --no-throughput-mode 2>/dev/null | tail -1 > $O/bench_sasrec_dense.json
