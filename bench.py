@@ -358,6 +358,28 @@ def main():
                         g_all.replay()
                     for _ in range(n % group):
                         g_one.replay()
+            elif use_graph and os.environ.get("DR4SR_DP_GRAPH_ALLREDUCE"):
+                # opt-in: the RCCL all-reduce captured INSIDE the step graph (k whole DP steps per replay, no host work between them).
+                # Verified here only with one RCCL rank (DR4SR_BENCH_FORCE_DP); off by default until it has run on a multi-GPU node.
+                group = max(1, min(args.steps_per_graph, steps))
+
+                def capture_dp(n):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                        for _ in range(n):
+                            select()
+                            eng.fwd_bwd(plan)
+                            dist.all_reduce(eng.grads)
+                            eng.adam_step(plan)
+                    return g
+                g_all = capture_dp(group)
+                g_one = capture_dp(1) if group > 1 else g_all
+
+                def run_steps(n):
+                    for _ in range(n // group):
+                        g_all.replay()
+                    for _ in range(n % group):
+                        g_one.replay()
             elif use_graph:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):
