@@ -380,6 +380,24 @@ def main():
                         g_all.replay()
                     for _ in range(n % group):
                         g_one.replay()
+            elif use_graph and args.model == "sasrec" and B <= 1024:
+                # two graphs around the all-reduce; the optimizer graph also prepares the next batch, so only the first step of a
+                # run carries its own prep launch
+                g_first, g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_first, stream=stream, capture_error_mode="thread_local"):
+                    eng.fwd_bwd(plan)
+                with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):
+                    eng.fwd_bwd_prepared(plan)
+                with torch.cuda.graph(g_b, stream=stream, capture_error_mode="thread_local"):
+                    eng.adam_step_prepare_next(plan)
+                prepared = [False]
+
+                def run_steps(n):
+                    for _ in range(n):
+                        (g_a if prepared[0] else g_first).replay()
+                        dist.all_reduce(eng.grads)
+                        g_b.replay()
+                        prepared[0] = True
             elif use_graph:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):

@@ -105,6 +105,8 @@ SYMBOLS = {
     "dr4sr_sasrec_fwd_bwd_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_void_p]),
     "dr4sr_sasrec_train_step": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_sasrec_train_steps": (C.c_int, [_PLANP, C.c_int32, C.c_void_p]),
+    "dr4sr_sasrec_fwd_bwd_prepared": (C.c_int, [_PLANP, C.c_void_p]),
+    "dr4sr_adam_step_prepare_next": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_sasrec_encode": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_sasrec_encode_bwd": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_select_rows": (C.c_int, [_i64p, C.c_int64, _i64p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -294,6 +294,23 @@ extern "C" int dr4sr_sasrec_train_step(const dr4sr_sasrec_plan* plan, void* stre
     return dr4sr_adam_step(plan, stream);
 }
 
+// The two halves of a data-parallel step whose prep rides on the PREVIOUS step's optimizer launch (the all-reduce of plan->grads goes
+// between them): fwd_bwd on a batch that is already prepared, and Adam + preparation of the next batch.
+extern "C" int dr4sr_sasrec_fwd_bwd_prepared(const dr4sr_sasrec_plan* plan, void* stream) {
+    Workspace ws;
+    RC(get_ws(plan, &ws));
+    if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
+    return fwd_bwd_core(plan, ws, (hipStream_t)stream);
+}
+extern "C" int dr4sr_adam_step_prepare_next(const dr4sr_sasrec_plan* plan, void* stream) {
+    Workspace ws;
+    RC(get_ws(plan, &ws));
+    if (!plan->grads || plan->n_params != ws.n_params) return DR4SR_E_ARG;
+    PrepArgs next;
+    RC(make_prep_args(plan, ws, 1, &next));
+    return launch_adam(plan, (hipStream_t)stream, &next);
+}
+
 // n consecutive training steps (consecutive batches of plan->perm when it is set): one k_prep for the first step, every optimizer
 // launch but the last also prepares the step that follows it.
 extern "C" int dr4sr_sasrec_train_steps(const dr4sr_sasrec_plan* plan, int32_t n_steps, void* stream) {

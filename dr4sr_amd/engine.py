@@ -146,6 +146,12 @@ class SasrecEngine:
     def train_step(self, plan):
         _lib.check(self.lib.dr4sr_sasrec_train_step(C.byref(plan), _lib.cur_stream()), "dr4sr_sasrec_train_step")
 
+    def fwd_bwd_prepared(self, plan):
+        _lib.check(self.lib.dr4sr_sasrec_fwd_bwd_prepared(C.byref(plan), _lib.cur_stream()), "dr4sr_sasrec_fwd_bwd_prepared")
+
+    def adam_step_prepare_next(self, plan):
+        _lib.check(self.lib.dr4sr_adam_step_prepare_next(C.byref(plan), _lib.cur_stream()), "dr4sr_adam_step_prepare_next")
+
     def train_steps(self, plan, n: int):
         """n consecutive steps (consecutive batches of plan.perm): one prep launch, the optimizer launches prepare the next step"""
         _lib.check(self.lib.dr4sr_sasrec_train_steps(C.byref(plan), int(n), _lib.cur_stream()), "dr4sr_sasrec_train_steps")

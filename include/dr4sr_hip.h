@@ -133,6 +133,15 @@ int dr4sr_sasrec_train_step(const dr4sr_sasrec_plan* plan, void* stream);
  * kernel instead of n_steps.  After the call plan->grads holds the last step's gradients. */
 int dr4sr_sasrec_train_steps(const dr4sr_sasrec_plan* plan, int32_t n_steps, void* stream);
 
+/* The same fusion for a data-parallel loop, where the all-reduce of plan->grads sits between the two halves of a step:
+ *   dr4sr_sasrec_fwd_bwd(plan)                                    first step (runs its own prep)
+ *   all-reduce ; dr4sr_adam_step_prepare_next(plan)               optimizer + prep of the next batch (selection, offsets, zeroed grads)
+ *   dr4sr_sasrec_fwd_bwd_prepared(plan) ; all-reduce ; dr4sr_adam_step_prepare_next(plan) ; ...
+ * Finish with dr4sr_adam_step to leave no batch prepared (harmless if not: the next dr4sr_sasrec_fwd_bwd prepares again, but a
+ * plan->perm counter has then advanced once more). */
+int dr4sr_sasrec_fwd_bwd_prepared(const dr4sr_sasrec_plan* plan, void* stream);
+int dr4sr_adam_step_prepare_next(const dr4sr_sasrec_plan* plan, void* stream);
+
 /* SASRecQueryEncoder.forward + SeqPoolingLayer (sasrec.py:39-75, layers.py:41-50/:69-73).
  * training != 0 applies dropout (RNG step = state[RNGSTEP]) and keeps activations in the
  * workspace for dr4sr_sasrec_encode_bwd.  out: [B,L,D] (NONE/ORIGIN; NONE leaves rows >= seqlen
