@@ -222,7 +222,7 @@ def test_train_steps_equals_repeated_train_step():
     data = {n: torch.from_numpy(rows[n]).to(dev) for n in ("in_item_id", "item_id", "seqlen")}
     perm = torch.from_numpy(np.random.default_rng(3).permutation(U)).to(dev)
     out = []
-    for fused in (False, True):
+    for fused in (False, True, "split"):
         eng = SasrecEngine(TOYS_N_ITEMS, L, 64, 2, 128, 2, 1e-12, 0.5, B, dev, seed=77, lr=1e-3)
         g = torch.Generator().manual_seed(5)
         for kname, v in eng.views.items():
@@ -233,7 +233,13 @@ def test_train_steps_equals_repeated_train_step():
         plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=torch.zeros(B, dtype=torch.int64, device=dev),
                              neg_item=torch.zeros(B, L, dtype=torch.int64, device=dev), sample_neg=True,
                              perm_sel=(perm, B, 0, counter), loss_log=log)
-        if fused:
+        if fused == "split":                                # the data-parallel form: halves of a step around (here: no) all-reduce
+            eng.fwd_bwd(plan)
+            for _ in range(k):
+                eng.adam_step_prepare_next(plan)
+                eng.fwd_bwd_prepared(plan)
+            eng.adam_step(plan)
+        elif fused:
             eng.train_steps(plan, k)
             eng.train_steps(plan, 1)
         else:
@@ -242,7 +248,8 @@ def test_train_steps_equals_repeated_train_step():
         torch.cuda.synchronize()
         assert int(counter) == k + 1 and int(eng.state[0]) == k + 1 and int(eng.state[3]) == k + 1
         out.append((eng.params.clone(), log.clone(), eng.grads.clone()))
-    (p0, l0, g0), (p1, l1, g1) = out
+    (p0, l0, g0), (p1, l1, g1), (p2, l2, g2) = out
+    assert torch.allclose(l0, l2, rtol=1e-5, atol=1e-6) and float((p0 - p2).abs().max()) < 2e-4
     assert float(l0[:k + 1].min()) > 0 and torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
     assert float((p0 - p1).abs().max()) < 2e-4           # same trajectory: fp32 atomics order only, amplified by Adam (lr 1e-3 per step)
     assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max())
