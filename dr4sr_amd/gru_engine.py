@@ -116,7 +116,15 @@ class GruEngine:
         _lib.check(self.lib.dr4sr_gru4rec_encode_bwd(C.byref(plan), int(training), pooling, _lib.ptr(d_out.contiguous()),
                                                      _lib.cur_stream()), "dr4sr_gru4rec_encode_bwd")
 
+    def check_coop(self):
+        """the cooperative recurrence never hangs: a wait that runs out sets a sticky error word (int32 word 2 of the workspace,
+        include/dr4sr_hip.h) and the results of that launch are garbage — turn it into an exception (host sync: call per epoch)"""
+        if int(self.workspace[:16].view(torch.int32)[2]) != 0:
+            raise _lib.Dr4srError("cooperative GRU recurrence: an exchange wait timed out (workgroups not co-resident?); "
+                                  "set DR4SR_GRU_NOCOOP=1 to use the single-workgroup recurrence")
+
     def loss_and_count(self):
+        self.check_coop()
         tail = self.grads[self.n_params:self.n_params + 2].tolist()
         return (tail[1] / tail[0] if tail[0] > 0 else float("nan")), int(tail[0])
 

@@ -73,6 +73,10 @@ class GRU4Rec(BaseModel):
         self._rows_buf = torch.zeros(int(tc["batch_size"]), dtype=torch.int64, device=self.device)
         self._neg_buf = torch.zeros(int(tc["batch_size"]) * self.max_seq_len, dtype=torch.int64, device=self.device)
 
+    def training_epoch_end(self, output_list):
+        self.engine.check_coop()                   # fail loudly if the multi-CU recurrence ever timed out during the epoch
+        return super().training_epoch_end(output_list)
+
     def forward(self, batch, need_pooling=True):
         pooling = _lib.POOL_NONE if not need_pooling else (_lib.POOL_ORIGIN if self.training else _lib.POOL_LAST)
         return _Encode.apply(self, self.item_embedding.weight, batch["in_" + self.fiid], batch["seqlen"], bool(self.training), pooling)

@@ -279,7 +279,10 @@ int     dr4sr_gru4rec_plan_sizeof(void);
 int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_t H, int32_t n_layer, int64_t* offsets);
 /* The workspace must be ZERO-initialised once by the caller (hipMemset at allocation): for small batches (8*ceil(B/16) <= 192
  * workgroups) the recurrences run cooperatively over 8 CUs per 16 sequences and keep their exchange granules and a launch counter
- * there (csrc/gru_coop.hip); `DR4SR_GRU_NOCOOP=1` forces the single-workgroup recurrence. */
+ * there (csrc/gru_coop.hip); `DR4SR_GRU_NOCOOP=1` forces the single-workgroup recurrence.  The waits of that exchange are bounded:
+ * a wait that runs out never hangs the GPU but sets a sticky error flag — the int32 word 2 of the workspace (words 0, 1: launch
+ * counter, finish ticket) — and leaves garbage; the caller should read that word whenever it synchronises anyway (per epoch) and
+ * treat non-zero as a failed run. */
 int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan);
 int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream);       /* basemodel.py:193-198, un-normalised grads */
 int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream);    /* + dense Adam */
