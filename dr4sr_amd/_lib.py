@@ -103,6 +103,7 @@ SYMBOLS = {
     "dr4sr_sasrec_fwd_bwd": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_adam_step": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_sasrec_fwd_bwd_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_void_p]),
+    "dr4sr_sasrec_fwd_bwd_weighted_prepared": (C.c_int, [_PLANP, C.c_void_p, C.c_void_p]),
     "dr4sr_sasrec_train_step": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_sasrec_train_steps": (C.c_int, [_PLANP, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_fwd_bwd_prepared": (C.c_int, [_PLANP, C.c_void_p]),

@@ -275,18 +275,25 @@ extern "C" int dr4sr_sasrec_fwd_bwd(const dr4sr_sasrec_plan* plan, void* stream)
     return fwd_bwd_core(plan, ws, s);
 }
 
-extern "C" int dr4sr_sasrec_fwd_bwd_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream) {
+static int fwd_bwd_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream, bool prepared) {
     Workspace ws;
     RC(get_ws(plan, &ws));
     if (!mw || !mw->phi || !(mw->tau > 0.f) || !plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params)
         return DR4SR_E_ARG;
     if (plan->D != 64) return DR4SR_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    RC(launch_prep(plan, ws, 1, 1, s));
+    if (!prepared) RC(launch_prep(plan, ws, 1, 1, s));
     RC(forward_layers(plan, ws, 1, s, true));
     RC(launch_post_mid(plan, ws, 1, s, mw));
     RC(backward_layers(plan, ws, 1, 2, s, true));
     return 0;
+}
+extern "C" int dr4sr_sasrec_fwd_bwd_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream) {
+    return fwd_bwd_weighted(plan, mw, stream, false);
+}
+// on a batch prepared by dr4sr_adam_step_prepare_next
+extern "C" int dr4sr_sasrec_fwd_bwd_weighted_prepared(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream) {
+    return fwd_bwd_weighted(plan, mw, stream, true);
 }
 
 extern "C" int dr4sr_sasrec_train_step(const dr4sr_sasrec_plan* plan, void* stream) {

@@ -340,10 +340,16 @@ class MetaModel(BaseModel):
         mw.phi, mw.user_id, mw.tau = self._phi.params.data_ptr(), fields["user_id"].data_ptr(), self._tau_eff()
         self._keep_inner = getattr(self, "_keep_inner", []) + [plan, mw]
 
+        fuse_prep = bl <= 1024                              # the optimizer launch of step i prepares step i+1 (one prep launch per graph)
+
         def body():
-            for _ in range(k):
-                _lib.check(lib.dr4sr_sasrec_fwd_bwd_weighted(C.byref(plan), C.byref(mw), _lib.cur_stream()), "fwd_bwd_weighted")
-                eng.adam_step(plan)
+            for j in range(k):
+                fn = lib.dr4sr_sasrec_fwd_bwd_weighted_prepared if (fuse_prep and j > 0) else lib.dr4sr_sasrec_fwd_bwd_weighted
+                _lib.check(fn(C.byref(plan), C.byref(mw), _lib.cur_stream()), "fwd_bwd_weighted")
+                if fuse_prep and j < k - 1:
+                    eng.adam_step_prepare_next(plan)
+                else:
+                    eng.adam_step(plan)
         undo = [eng.params, eng.adam_m, eng.adam_v, eng.state, self._perm_counter]
         snap = [t.clone() for t in undo]
         body()                                             # warm-up outside capture, side effects undone

@@ -333,6 +333,8 @@ typedef struct dr4sr_meta_weighting {
     float          tau;             /* clip(tau, tau_min)                                                        */
 } dr4sr_meta_weighting;
 int dr4sr_sasrec_fwd_bwd_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream);
+/* the same on a batch already prepared by dr4sr_adam_step_prepare_next (k-step graphs of the MetaModel inner loop) */
+int dr4sr_sasrec_fwd_bwd_weighted_prepared(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream);
 
 /* Hypergrad.grad (utils/utils.py:145-205) from FIRST-ORDER gradients: with G(W) = dL_train/dW (this library's backward),
  *     H v            = [G(W + e v) - G(W - e v)] / 2e                      (Neumann terms; scaled by hpo_lr, :196-203)
