@@ -84,3 +84,39 @@ def test_gru4rec_full_size_vs_oracle(dense):
     for _ in range(20):
         eng.train_step(plan)
     assert eng.loss_and_count()[0] < first and int(eng.state[0]) == 20
+
+
+@pytest.mark.parametrize("B", [1, 3, 17, 40, 100])
+def test_gru4rec_odd_batch_sizes_vs_oracle(B):
+    """batch sizes that are not multiples of the 16-sequence groups of the cooperative recurrence (partial last group, single
+    sequence), random lengths including 1 and L"""
+    from dr4sr_amd.gru_engine import GruEngine, gru_param_names, gru_param_shapes
+    N, H, L = 200, 256, 50
+    gen = torch.Generator().manual_seed(B)
+    sl = torch.randint(1, L + 1, (B,), generator=gen)
+    sl[0] = 1
+    sl[-1] = L
+    inp = torch.zeros(B, L, dtype=torch.int64)
+    tgt = torch.zeros(B, L, dtype=torch.int64)
+    for r in range(B):
+        n = int(sl[r])
+        inp[r, :n] = torch.randint(1, N, (n,), generator=gen)
+        tgt[r, :n] = torch.randint(0, N, (n,), generator=gen)
+    b = {"in_item_id": inp, "item_id": tgt, "seqlen": sl, "neg_item": torch.randint(1, N, (B, L, 1), generator=gen)}
+    params = {}
+    for nme, shp in zip(gru_param_names(2), gru_param_shapes(N, 64, H, 2)):
+        params[nme] = 0.08 * torch.randn(shp, generator=gen)
+    params["item_embedding.weight"][0] = 0
+    eng = GruEngine(N, L, 64, H, 2, 0.0, B, "cuda", seed=5)
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                         neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    op = dict(params)
+    op["query_encoder.0.1.weight"] = params["item_embedding.weight"]
+    loss_o, _, grads_o = GO.grads_of(op, b, 2)
+    loss, n = eng.loss_and_count()
+    assert n == int((b["item_id"] != 0).sum()) and abs(loss - float(loss_o)) < 3e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, grads_o[k]) < REL, k
