@@ -116,3 +116,31 @@ def test_fmlp_full_size_and_training_decreases_loss():
     plan2 = eng.make_plan(idx.to(dev), tgt.to(dev))
     eng.fwd_bwd(plan2)
     assert int(eng.neg_scratch[:B].min()) >= 1 and int(eng.neg_scratch[:B].max()) < N
+
+
+@pytest.mark.parametrize("B", [1, 3, 33, 100])
+def test_fmlp_odd_batch_sizes_vs_oracle(B):
+    """batch sizes that do not fill the 32-row token tiles / the 256 partial-sum blocks of the filter backward"""
+    from dr4sr_amd.fmlp_engine import FmlpEngine, fmlp_param_names, fmlp_param_shapes
+    L, N = 50, 150
+    gen = torch.Generator().manual_seed(100 + B)
+    idx = torch.zeros(B, L, dtype=torch.long)
+    for i in range(B):
+        n = int(torch.randint(1, L + 1, (1,), generator=gen))
+        idx[i, L - n:] = torch.randint(1, N, (n,), generator=gen)
+    tgt = torch.randint(1, N, (B,), generator=gen)
+    neg = torch.randint(1, N, (B, 1), generator=gen)
+    params = {}
+    for nme, shp in zip(fmlp_param_names(2), fmlp_param_shapes(N, L, 64, 256, 2)):
+        params[nme] = (1.0 if nme.endswith("LayerNorm.weight") else 0.0) + 0.05 * torch.randn(shp, generator=gen)
+    params["item_embedding.weight"][0] = 0
+    eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.0, B, "cuda")
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(idx.to(dev), tgt.to(dev), neg_item=neg.view(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    loss_o, _, grads_o = FO.grads_of(params, {"in_item_id": idx, "item_id": tgt, "neg_item": neg}, 2)
+    loss, n = eng.loss_and_count()
+    assert n == B and abs(loss - float(loss_o)) < 3e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, grads_o[k]) < REL, k
