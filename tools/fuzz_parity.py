@@ -12,7 +12,7 @@ for trial in range(int(os.environ.get("TRIALS", "12"))):
     B = int(rng.choice([1, 2, 3, 5, 17, 31, 64, 100]))
     N = int(rng.choice([2, 3, 50, 300]))
     D = int(rng.choice([64, 128]))
-    L = 50
+    L = int(rng.choice([8, 50, 64]))
     sl = rng.integers(1, L + 1, size=B)
     sl[rng.integers(0, B)] = 1
     inp = np.zeros((B, L), dtype=np.int64); tgt = np.zeros((B, L), dtype=np.int64)
@@ -22,7 +22,7 @@ for trial in range(int(os.environ.get("TRIALS", "12"))):
     neg = rng.integers(1, N, size=(B, L, 1))
     b_ = {"in_item_id": torch.from_numpy(inp), "item_id": torch.from_numpy(tgt), "seqlen": torch.from_numpy(sl.astype(np.int64)),
           "neg_item": torch.from_numpy(neg)}
-    params = _random_params(N, D, 128, 2, seed=trial)
+    params = _random_params(N, D, 128, 2, L=L, seed=trial)
     eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, 0.0, B, dev)
     eng.load_named(params)
     plan = eng.make_plan(b_["in_item_id"].to(dev), b_["item_id"].to(dev), b_["seqlen"].to(dev),
@@ -38,6 +38,6 @@ for trial in range(int(os.environ.get("TRIALS", "12"))):
     e = abs(loss - float(loss_o))
     g = max(relerr(v, grads_o[k]) for k, v in eng.normalized_grads().items())
     worst = max(worst, g)
-    print("trial %2d B=%3d N=%3d D=%3d T=%4d n_valid=%4d  |dloss| %.1e  max grad relerr %.1e" % (trial, B, N, D, int(sl.sum()), nv, e, g))
+    print("trial %2d L=%2d B=%3d N=%3d D=%3d T=%4d n_valid=%4d  |dloss| %.1e  max grad relerr %.1e" % (trial, L, B, N, D, int(sl.sum()), nv, e, g))
     assert e < 3e-5 and g < 5e-4
 print("FUZZ ok, worst grad relerr %.2e" % worst)
