@@ -15,6 +15,7 @@
 //                  sort of the <= 128 candidates by (score desc, id asc).  Same results as the arg-max rounds, ~15x faster.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -284,7 +285,8 @@ extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const in
     if (workspace_bytes < B * (int64_t)lds_s * 4) return DR4SR_E_WS;
     const size_t lds_fix = sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 512;
     const size_t lds_row = sizeof(unsigned) * ((n_items + 3) & ~3) + lds_fix;
-    const bool ldsrow = lds_row <= 64 * 1024;               // (above that the LDS copy costs more occupancy than the second row read)
+    static const int lds_max_kb = getenv("DR4SR_TOPK_LDS_KB") ? atoi(getenv("DR4SR_TOPK_LDS_KB")) : 24;      // measured: above ~4 k items the LDS copy costs more occupancy than the second row read (0.120 vs 0.104 ms at N = 11 925)
+    const bool ldsrow = lds_row <= (size_t)lds_max_kb * 1024;               // (above that the LDS copy costs more occupancy than the second row read)
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(lds_s / 64, (unsigned)((B + 63) / 64));
