@@ -462,6 +462,14 @@ def main():
             if rank == 0 and args.model == "sasrec" and extras:
                 # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
                 seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
+                # whole-step MFMA roofline: algorithmic flops of ONE rank's step on the tokens it really holds (linear layers fwd + data
+                # grads + weight grads = 3 x, causal attention n(n+1)/2 pairs x {QK^T, PV} x 3.5 for fwd + bwd) over the measured step time
+                lin = 3.0 * NL * (2 * D * 3 * D + 2 * D * D + 4 * D * F) * float(seqlen_last.sum())
+                att = 3.5 * NL * 2 * 2 * D * float((seqlen_last.astype(np.float64) * (seqlen_last + 1) / 2).sum())
+                step_s = wall / steps
+                out["roofline_step"] = {"bound": "mfma", "achieved": (lin + att) / step_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                        "frac": (lin + att) / step_s / 1e12 / MFMA_F32_PEAK_TF, "flops_per_step": lin + att,
+                                        "note": "all kernels of the step, last batch's token count"}
                 kinds = ["embed_fwd", "qkv_fwd", "attn_fwd", "post_fwd", "score", "transpose", "post_bwd", "attn_bwd",
                          "qkv_bwd", "embed_bwd", "wgrad", "zero_grads", "prep", "adam"]
                 per_step_launches = {"qkv_fwd": NL, "attn_fwd": NL, "post_fwd": NL, "post_bwd": NL, "attn_bwd": NL, "qkv_bwd": NL}
@@ -566,7 +574,7 @@ def main():
         tm, _, _ = measure(8192, max(20, min(100, args.steps)), 10, "kernels")
         if rank == 0:
             out["throughput_mode"] = {k: tm[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline",
-                                                          "kernel_us_per_step", "valid_tokens_last_step") if k in tm}
+                                                          "kernel_us_per_step", "valid_tokens_last_step", "roofline_step") if k in tm}
     if rank == 0:
         if not dp and not args.no_cpu_baseline and args.model == "sasrec":
             from oracle.ref_trainer import time_training
