@@ -176,7 +176,7 @@ class SeparateDataset(BaseDataset):
 
 
 class SyntheticDataset(BaseDataset):
-    """Amazon-toys-shaped synthetic rows (no files).  data.n_rows / data.n_items / data.dense / data.seed optional."""
+    """Amazon-toys-shaped synthetic rows (no files).  data.n_rows / data.n_items / data.dense / data.seed / data.markov optional."""
 
     def _load_datasets(self):
         from .synthetic import TOYS_N_ITEMS, TOYS_N_ROWS
@@ -200,11 +200,11 @@ class SyntheticDataset(BaseDataset):
         dev = self.device
         prefix = bool(d.get("prefix_rows", False))          # FMLP format: left-padded prefix, scalar target
         if self.phase == "train" and not prefix:
-            r = make_rows(self._n_rows, self._num_items, L, seed, bool(d.get("dense", False)))
+            r = make_rows(self._n_rows, self._num_items, L, seed, bool(d.get("dense", False)), float(d.get("markov", 0.0)))
             self._data = tuple(torch.from_numpy(r[k]).to(dev) for k in FIELDS_TRAIN)
             return
         if self.phase == "train":
-            r = make_rows(self._n_rows, self._num_items, L, seed, bool(d.get("dense", False)))
+            r = make_rows(self._n_rows, self._num_items, L, seed, bool(d.get("dense", False)), float(d.get("markov", 0.0)))
             sl = torch.from_numpy(r["seqlen"])
             hist = torch.from_numpy(r["in_item_id"])
             shift = (L - sl).view(-1, 1)                                            # roll the valid prefix to the right edge
@@ -215,7 +215,7 @@ class SyntheticDataset(BaseDataset):
                           torch.ones_like(sl).to(dev), torch.zeros_like(hist).to(dev))
             return
         n_eval = int(d.get("n_eval_rows", min(self._n_rows, 4096)))
-        r = make_rows(n_eval, self._num_items, L, seed + (1 if self.phase == "val" else 2), False)
+        r = make_rows(n_eval, self._num_items, L, seed + (1 if self.phase == "val" else 2), False, float(d.get("markov", 0.0)))
         hist = torch.from_numpy(r["in_item_id"]).to(dev)
         sl = torch.from_numpy(r["seqlen"]).to(dev)
         tgt_all = torch.from_numpy(r["item_id"]).to(dev)

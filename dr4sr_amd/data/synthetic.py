@@ -28,7 +28,7 @@ def item_popularity(n_items: int, exponent: float = 0.66, shift: float = 50.0) -
 
 
 def make_rows(n_rows: int = TOYS_N_ROWS, n_items: int = TOYS_N_ITEMS, L: int = MAX_SEQ_LEN, seed: int = 2024,
-              dense: bool = False):
+              dense: bool = False, markov: float = 0.0):
     """Returns dict of int64 numpy arrays in the layout of SeparateDataset.unpack
     (/root/reference data/dataset.py:79-91): user_id[U], in_item_id[U,L], item_id[U,L], seqlen[U],
     label[U,L], domain_id[U,L]."""
@@ -46,10 +46,18 @@ def make_rows(n_rows: int = TOYS_N_ROWS, n_items: int = TOYS_N_ITEMS, L: int = M
     in_item = np.zeros((n_rows, L), dtype=np.int64)
     tgt = np.zeros((n_rows, L), dtype=np.int64)
     label = np.zeros((n_rows, L), dtype=np.int64)
+    # markov > 0: with that probability the next item is a fixed function of the current one (the same function for every split
+    # of a dataset) — a signal a sequential recommender can learn, for end-to-end sanity checks; 0 = i.i.d. popularity draws
+    succ = np.random.default_rng(12345).permutation(n_items - 1) + 1 if markov > 0 else None
     o = 0
     for u in range(n_rows):
         n = int(seqlen[u])
-        s = draws[o:o + n + 1]
+        s = draws[o:o + n + 1].copy()
+        if succ is not None:
+            follow = rng.random(n + 1) < markov
+            for t in range(1, n + 1):
+                if follow[t]:
+                    s[t] = succ[s[t - 1] - 1]
         o += n + 1
         in_item[u, :n] = s[:n]
         tgt[u, :n] = s[1:n + 1]

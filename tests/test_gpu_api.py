@@ -284,3 +284,21 @@ def test_data_parallel_fit_end_to_end():
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
     assert "replicas identical: True; finite: True" in lines[0] and "steps=27" in lines[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["SASRec", "GRU4Rec"])
+def test_fit_learns_a_sequential_signal(tmp_path, monkeypatch, model_name):
+    """end-to-end sanity of the whole loop (targets shifted by one, masks, negatives, optimizer, top-k with history masking, metrics):
+    on data whose next item follows the current one through a fixed map 90 % of the time, a few epochs must lift recall@20 far above
+    the popularity baseline (20 / 300 items = 0.07)"""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    from dr4sr_amd import quickstart
+    from dr4sr_amd.utils import load_config
+    cfg = load_config({"model": model_name, "dataset": "synthetic-toys"})
+    cfg["data"].update({"n_items": 300, "n_rows": 4000, "n_eval_rows": 512, "markov": 0.9, "seed": 3})
+    cfg["train"].update({"device": "cuda", "epochs": 12 if model_name == "SASRec" else 30, "batch_size": 128})
+    cfg["eval"]["batch_size"] = 512
+    out = quickstart.run(cfg)
+    assert out["recall@20"] > 0.5 and out["ndcg@20"] > 0.2, out
