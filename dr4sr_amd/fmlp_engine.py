@@ -92,6 +92,13 @@ class FmlpEngine:
         B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
         if B > self.max_batch:
             raise _lib.Dr4srError(f"batch {B} > max_batch {self.max_batch}")
+        if in_item_id.dim() != 2 or int(in_item_id.shape[1]) != self.L:
+            raise _lib.Dr4srError(f"FMLP: in_item_id must be [rows, {self.L}], got {tuple(in_item_id.shape)}")
+        if item_id is not None and item_id.dim() != 1:
+            # model/fmlp.py:38 keeps ONE query per row (transformer_out[:, -1]); against [B, L] targets the reference's
+            # (query * item_embedding(target)).sum(-1) (basemodel.py:182) cannot broadcast
+            raise _lib.Dr4srError(f"FMLP scores one query per row: item_id must be [rows], got {tuple(item_id.shape)} "
+                                  "(use the prefix-row data format: data.prefix_rows / configs/synthetic-toys-prefix.yaml)")
         if sample_neg is None:
             sample_neg = neg_item is None
         if neg_item is None:

@@ -230,6 +230,9 @@ class MetaModel(BaseModel):
         self._phi.grads.zero_()
         self._stats.zero_()
         q = sub._encode_raw(batch, True)
+        if q.numel() != B * L * eng.D:
+            raise _lib.Dr4srError(f"MetaModel: the sub-model returns {q.numel() // eng.D} queries for {B * L} targets "
+                                  f"(targets {tuple(tgt.shape)}); a one-query-per-row sub-model (FMLP) needs the prefix-row data format")
         lp = self._buf("lp", B * L)
         E = self.item_embedding.weight
         _lib.check(lib.dr4sr_score_bce_fwd(_lib.ptr(q), _lib.ptr(E), _lib.ptr(tgt), _lib.ptr(neg), None, None, _lib.ptr(lp),

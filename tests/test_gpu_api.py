@@ -287,7 +287,7 @@ def test_data_parallel_fit_end_to_end():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["SASRec", "GRU4Rec"])
+@pytest.mark.parametrize("model_name", ["SASRec", "GRU4Rec", "FMLP", "MetaModel"])
 def test_fit_learns_a_sequential_signal(tmp_path, monkeypatch, model_name):
     """end-to-end sanity of the whole loop (targets shifted by one, masks, negatives, optimizer, top-k with history masking, metrics):
     on data whose next item follows the current one through a fixed map 90 % of the time, a few epochs must lift recall@20 far above
@@ -300,5 +300,23 @@ def test_fit_learns_a_sequential_signal(tmp_path, monkeypatch, model_name):
     cfg["data"].update({"n_items": 300, "n_rows": 4000, "n_eval_rows": 512, "markov": 0.9, "seed": 3})
     cfg["train"].update({"device": "cuda", "epochs": 12 if model_name == "SASRec" else 30, "batch_size": 128})
     cfg["eval"]["batch_size"] = 512
+    if model_name in ("FMLP", "MetaModel"):                 # FMLP (MetaModel's default sub-model) keeps one query per row: prefix-row format
+        cfg["data"]["prefix_rows"] = True
     out = quickstart.run(cfg)
     assert out["recall@20"] > 0.5 and out["ndcg@20"] > 0.2, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["FMLP", "MetaModel"])
+def test_one_query_per_row_models_reject_per_position_targets(tmp_path, monkeypatch, model_name):
+    """FMLP on [rows, L] targets cannot broadcast in the reference (model/fmlp.py:38 vs basemodel.py:182); here it must fail loudly,
+    not read the target table with the wrong stride"""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    from dr4sr_amd import quickstart, _lib
+    from dr4sr_amd.utils import load_config
+    cfg = load_config({"model": model_name, "dataset": "synthetic-toys"})
+    cfg["data"].update({"n_items": 300, "n_rows": 512, "n_eval_rows": 128})
+    cfg["train"].update({"device": "cuda", "epochs": 2, "batch_size": 128, "warmup_epoch": -1})
+    with pytest.raises(_lib.Dr4srError, match="one query per row|one-query-per-row"):
+        quickstart.run(cfg)
