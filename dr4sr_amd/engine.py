@@ -130,6 +130,14 @@ class SasrecEngine:
         B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
         if B > self.max_batch:
             raise _lib.Dr4srError(f"batch {B} > max_batch {self.max_batch}")
+        if in_item_id.dim() != 2 or int(in_item_id.shape[1]) != self.L:
+            raise _lib.Dr4srError(f"SASRec: in_item_id must be [rows, {self.L}], got {tuple(in_item_id.shape)}")
+        if item_id is not None and item_id.shape != in_item_id.shape:
+            # pooling 'origin' keeps one query per position: (query * item_embedding(target)).sum(-1) (basemodel.py:182) needs [rows, L] targets
+            raise _lib.Dr4srError(f"SASRec scores one query per position: item_id must be {tuple(in_item_id.shape)}, got {tuple(item_id.shape)} "
+                                  "(prefix-row data is the one-query-per-row models' format)")
+        if seqlen is not None and (seqlen.dim() != 1 or seqlen.shape[0] != in_item_id.shape[0]):
+            raise _lib.Dr4srError(f"SASRec: seqlen must be [{int(in_item_id.shape[0])}], got {tuple(seqlen.shape)}")
         if sample_neg is None:
             sample_neg = neg_item is None
         if neg_item is None:

@@ -307,16 +307,17 @@ def test_fit_learns_a_sequential_signal(tmp_path, monkeypatch, model_name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["FMLP", "MetaModel"])
-def test_one_query_per_row_models_reject_per_position_targets(tmp_path, monkeypatch, model_name):
-    """FMLP on [rows, L] targets cannot broadcast in the reference (model/fmlp.py:38 vs basemodel.py:182); here it must fail loudly,
+@pytest.mark.parametrize("model_name,prefix", [("FMLP", False), ("MetaModel", False), ("SASRec", True), ("GRU4Rec", True)])
+def test_models_reject_the_other_target_format(tmp_path, monkeypatch, model_name, prefix):
+    """FMLP keeps one query per row (model/fmlp.py:38), SASRec / GRU4Rec one per position (pooling 'origin'); against the other target
+    format the reference's (query * item_embedding(target)).sum(-1) (basemodel.py:182) cannot broadcast.  Here it must fail loudly,
     not read the target table with the wrong stride"""
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
     from dr4sr_amd import quickstart, _lib
     from dr4sr_amd.utils import load_config
     cfg = load_config({"model": model_name, "dataset": "synthetic-toys"})
-    cfg["data"].update({"n_items": 300, "n_rows": 512, "n_eval_rows": 128})
+    cfg["data"].update({"n_items": 300, "n_rows": 512, "n_eval_rows": 128, "prefix_rows": prefix})
     cfg["train"].update({"device": "cuda", "epochs": 2, "batch_size": 128, "warmup_epoch": -1})
-    with pytest.raises(_lib.Dr4srError, match="one query per row|one-query-per-row"):
+    with pytest.raises(_lib.Dr4srError, match="one query per|one-query-per-row"):
         quickstart.run(cfg)
