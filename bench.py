@@ -284,14 +284,14 @@ def main():
         counter = torch.zeros(1, dtype=torch.int32, device=dev)
         negbuf = torch.zeros(B, L, dtype=torch.int64, device=dev)
         if args.model == "sasrec":
-            eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023, lr=1e-3)
+            eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, args.dropout, B, dev, seed=2023 + 7919 * rank, lr=1e-3)     # per-rank dropout / negative streams, as model/sasrec.py
             init_params_like_reference(eng, 2023)
             # a1 fused: rows_buf is filled by the step's first kernel from (perm, counter); no separate selection launch
             plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True,
                                  perm_sel=(perm, B * world, rank * B, counter))
         elif args.model == "gru4rec":
             from dr4sr_amd.gru_engine import GruEngine
-            eng = GruEngine(N, L, D, 256, 2, 0.2, B, dev, seed=2023, lr=1e-3, weight_decay=1e-4)
+            eng = GruEngine(N, L, D, 256, 2, 0.2, B, dev, seed=2023 + 7919 * rank, lr=1e-3, weight_decay=1e-4)
             g = torch.Generator().manual_seed(2023)
             for k, v in eng.views.items():
                 v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / 16.0 if "gru" in k else 0.02 * torch.randn(v.shape, generator=g))
@@ -304,7 +304,7 @@ def main():
             shift = (L - sl).view(-1, 1)
             data["in_item_id"] = torch.where(ar >= shift, hist.gather(1, (ar - shift) % L), torch.zeros_like(hist)).contiguous()
             data["item_id"] = data["item_id"].gather(1, (sl - 1).clamp(min=0).view(-1, 1)).squeeze(1).contiguous()
-            eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.5, B, dev, seed=2023, lr=1e-3)
+            eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.5, B, dev, seed=2023 + 7919 * rank, lr=1e-3)
             g = torch.Generator().manual_seed(2023)
             for k, v in eng.views.items():
                 v.copy_(torch.ones(v.shape) if k.endswith("LayerNorm.weight") else (torch.zeros(v.shape) if k.endswith("bias") else 0.02 * torch.randn(v.shape, generator=g)))
@@ -504,6 +504,16 @@ def main():
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                    "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "us_per_launch": ktime[dom],
                                    "flops_per_launch": fl}
+                # the ragged layout leaves the attention kernels far below the MFMA ridge (157.3 TF / 8 TB/s = 19.7 flop/B): also report
+                # the kernel against the sloped part of the roofline, min(MFMA peak, intensity x HBM peak), from its algorithmic bytes
+                # (forward: q, k, v in + ctx out; backward: q, k, v, dctx in + dq, dk, dv out; 4*D bytes per token each)
+                arrays = {"attn_fwd": 4, "attn_bwd": 7}.get(dom)
+                if arrays:
+                    ab = float(arrays * T_last * D * 4)
+                    ceil_tf = min(MFMA_F32_PEAK_TF, fl / ab * HBM_PEAK_GBS / 1e3)
+                    out["roofline"].update({"algorithmic_bytes_per_launch": ab, "flop_per_byte": fl / ab, "ceiling_at_intensity": ceil_tf,
+                                            "frac_of_ceiling": ach / ceil_tf,
+                                            "hbm_rate": ab / (ktime[dom] * 1e-6) / 1e9, "hbm_frac": ab / (ktime[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS})
                 out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
 
                 if extras != "full":
