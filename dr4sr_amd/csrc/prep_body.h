@@ -16,15 +16,13 @@ __device__ __forceinline__ void prep_body(const PrepArgs& P, unsigned long long*
     const PermSel sel = P.sel; int* __restrict__ tile_seq = P.tile_seq; int* __restrict__ seq_class = P.seq_class;
     // one packed scan: bits 0-31 tokens, 32-47 short sequences (1..16 tokens), 48-63 long sequences
     const int tid = threadIdx.x;
-    if (sel.perm) {                                     // a1: this step's batch = a slice of the epoch permutation
-        const int64_t c = *sel.counter;
-        int64_t* rw = const_cast<int64_t*>(rows);
-        for (int i = tid; i < B; i += NT) rw[i] = sel.perm[(c * sel.stride + sel.offset + i) % sel.n];
-        __syncthreads();
-        if (tid == 0) *sel.counter = (int)(c + 1);
-    }
     const int per = (B + NT - 1) / NT;
     const int b0 = tid * per, b1 = min(B, b0 + per);
+    if (sel.perm) {                                     // a1: this step's batch = a slice of the epoch permutation.  Every thread
+        const int64_t c = *sel.counter;                 // selects the rows of ITS chunk (it is their only reader below): no barrier,
+        int64_t* rw = const_cast<int64_t*>(rows);       // no second round trip; the counter is bumped behind the scan's barrier
+        for (int b = b0; b < b1; ++b) rw[b] = sel.perm[(c * sel.stride + sel.offset + b) % sel.n];
+    }
     unsigned long long s = 0;
     constexpr int KEEP = 8;                             // lengths of the first 8 sequences of the chunk stay in registers (B <= 8192):
     int keep[KEEP];                                     // independent loads issued together instead of 3 x per dependent chains
@@ -52,15 +50,25 @@ __device__ __forceinline__ void prep_body(const PrepArgs& P, unsigned long long*
         const int nn = len_of(b);
         s += (unsigned long long)nn + (nn > 0 && nn <= 16 ? (1ull << 32) : 0ull) + (nn > 16 ? (1ull << 48) : 0ull);
     }
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < NT; o <<= 1) {               // Hillis-Steele inclusive scan
-        const unsigned long long v = tid >= o ? part[tid - o] : 0ull;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // inclusive scan: shuffles inside the wave, then the <= 16 wave totals through LDS (one barrier instead of 2 log2(NT))
+    const int lane = tid & 63, wv = tid >> 6;
+    unsigned long long inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
     }
-    const unsigned long long ex = part[tid] - s;        // exclusive prefix of this thread's chunk
+    if (lane == 63) part[wv] = inc;
+    __syncthreads();
+    if (sel.perm && tid == 0) *sel.counter = *sel.counter + 1;      // every thread has read the counter before the barrier
+    unsigned long long before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const unsigned long long v = part[w];
+        before += w < wv ? v : 0ull;
+        tot += v;
+    }
+    const unsigned long long ex = before + inc - s;     // exclusive prefix of this thread's chunk
     int run = (int)(ex & 0xffffffffull), ns = (int)((ex >> 32) & 0xffff), nl = (int)(ex >> 48);
     for (int b = b0; b < b1; ++b) {
         cu[b] = run;
@@ -73,7 +81,6 @@ __device__ __forceinline__ void prep_body(const PrepArgs& P, unsigned long long*
         run += nn;
     }
     if (tid == NT - 1) {
-        const unsigned long long tot = part[NT - 1];
         cu[B] = (int)(tot & 0xffffffffull);
         state[DR4SR_STATE_T] = (int)(tot & 0xffffffffull);
         if (bump_rng) state[DR4SR_STATE_RNGSTEP] += 1;
