@@ -91,6 +91,7 @@ static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
 
 extern "C" int64_t dr4sr_fmlp_workspace_bytes(const dr4sr_fmlp_plan* plan) {
     if (!plan || plan->B <= 0 || plan->L <= 0 || plan->n_layer <= 0 || plan->n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    if (plan->D != FM_D || plan->F != FM_F || plan->L > 50 || (plan->L & 1)) return DR4SR_E_SHAPE;       // as fmlp_check
     dr4sr_fmlp_plan q = *plan;
     q.workspace = nullptr;
     FmlpWs ws;

@@ -97,6 +97,7 @@ static void gru_carve(const dr4sr_gru4rec_plan* p, GruWs* ws) {
 
 extern "C" int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan) {
     if (!plan || plan->B <= 0 || plan->L <= 0 || plan->n_layer <= 0 || plan->n_layer > GRU_MAX_LAYERS) return DR4SR_E_ARG;
+    if (plan->D != 64 || (plan->H != 128 && plan->H != 256) || plan->L > 64) return DR4SR_E_SHAPE;       // as gru_check
     dr4sr_gru4rec_plan q = *plan;
     q.workspace = nullptr;
     GruWs ws;

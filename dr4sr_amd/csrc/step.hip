@@ -40,12 +40,22 @@ extern "C" int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t
     return o;
 }
 
-static int check_plan(const dr4sr_sasrec_plan* p) {
-    if (!p || p->abi_version != DR4SR_ABI_VERSION) return DR4SR_E_ARG;
-    if (p->B <= 0 || p->L <= 0 || p->n_items < 2 || p->n_layer <= 0 || p->n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+// the encoder shapes the kernels are instantiated for (anything else is refused before a workspace is sized or a kernel launched)
+static int check_shape(const dr4sr_sasrec_plan* p) {
     if (p->L > 64) return DR4SR_E_SHAPE;
     if (!((p->D == 64 && (p->F == 128 || p->F == 256)) || (p->D == 128 && p->F == 128))) return DR4SR_E_SHAPE;
     if (p->H <= 0 || p->H > 4 || p->D % p->H || (p->D / p->H != 32 && p->D / p->H != 64)) return DR4SR_E_SHAPE;
+    // head counts other than 2 run the one-wave-per-head kernels of attn.hip, whose backward keeps q|k|v|dctx and two score
+    // planes per head in LDS: reject the shapes that do not fit the 160 KB of a CU instead of failing at the launch
+    if (p->H != 2 && sizeof(float) * (4LL * p->L * p->D + 2LL * p->H * p->L * (p->L + 1) + p->L) > 160 * 1024) return DR4SR_E_SHAPE;
+    return 0;
+}
+
+static int check_plan(const dr4sr_sasrec_plan* p) {
+    if (!p || p->abi_version != DR4SR_ABI_VERSION) return DR4SR_E_ARG;
+    if (p->B <= 0 || p->L <= 0 || p->n_items < 2 || p->n_layer <= 0 || p->n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    const int rc = check_shape(p);
+    if (rc) return rc;
     if (!(p->p_drop >= 0.f && p->p_drop < 1.f)) return DR4SR_E_ARG;
     if (!p->params || !p->state || !p->in_item_id || !p->seqlen) return DR4SR_E_ARG;
     return 0;
@@ -88,6 +98,7 @@ extern "C" int64_t dr4sr_sasrec_workspace_bytes(const dr4sr_sasrec_plan* plan) {
     dr4sr_sasrec_plan q = *plan;
     q.workspace = nullptr;
     if (q.B <= 0 || q.L <= 0 || q.n_layer <= 0 || q.n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    if (check_shape(&q)) return DR4SR_E_SHAPE;
     Workspace ws;
     carve_workspace(&q, &ws);
     return ws.bytes;

@@ -82,7 +82,9 @@ class SasrecEngine:
         probe = self._plan(max_batch, None, None, None, None, None, False, with_ws=False)
         self.ws_bytes = int(self.lib.dr4sr_sasrec_workspace_bytes(C.byref(probe)))
         if self.ws_bytes <= 0:
-            raise _lib.Dr4srError(f"workspace_bytes failed ({self.ws_bytes})")
+            raise _lib.Dr4srError(f"SASRec encoder shape L={L} D={D} H={H} F={F} layers={n_layer}: dr4sr_sasrec_workspace_bytes failed: "
+                                  + _lib._ERR.get(self.ws_bytes, str(self.ws_bytes))
+                                  + " — built for L <= 64, (D, F) in {(64, 128), (64, 256), (128, 128)}, head_dim 32 or 64")
         # slot = (workspace, state words): several forward passes can be alive before their backward passes (CL4SRec encodes
         # three views per step); slot 0 is the default and the one the optimizer's step counter lives in
         self.workspaces = [torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) for _ in range(n_slots)]

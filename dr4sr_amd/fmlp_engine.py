@@ -65,7 +65,8 @@ class FmlpEngine:
         probe = self._plan(max_batch, None, None, None, None, False, with_ws=False)
         self.ws_bytes = int(self.lib.dr4sr_fmlp_workspace_bytes(C.byref(probe)))
         if self.ws_bytes <= 0:
-            raise _lib.Dr4srError(f"fmlp workspace_bytes failed ({self.ws_bytes})")
+            raise _lib.Dr4srError(f"FMLP shape L={self.L} D={self.D} F={self.F} layers={self.n_layer}: dr4sr_fmlp_workspace_bytes failed: "
+                                  + _lib._ERR.get(self.ws_bytes, str(self.ws_bytes)) + " — built for even L <= 50, D = 64, F = 256")
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.neg_scratch = torch.zeros(max_batch, dtype=torch.int64, device=dev)
 

@@ -59,7 +59,8 @@ class GruEngine:
         probe = self._plan(max_batch, None, None, None, None, None, False, with_ws=False)
         self.ws_bytes = int(self.lib.dr4sr_gru4rec_workspace_bytes(C.byref(probe)))
         if self.ws_bytes <= 0:
-            raise _lib.Dr4srError(f"gru4rec workspace_bytes failed ({self.ws_bytes})")
+            raise _lib.Dr4srError(f"GRU4Rec shape L={self.L} D={self.D} hidden={self.H} layers={self.n_layer}: dr4sr_gru4rec_workspace_bytes failed: "
+                                  + _lib._ERR.get(self.ws_bytes, str(self.ws_bytes)) + " — built for L <= 64, D = 64, hidden 128 or 256")
         self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)     # zero ONCE: the cooperative recurrence's
         #                                                                               granule tags / launch counter live in it
         self.neg_scratch = torch.zeros(max_batch * L, dtype=torch.int64, device=dev)

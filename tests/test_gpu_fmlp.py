@@ -121,8 +121,26 @@ def test_fmlp_full_size_and_training_decreases_loss():
 @pytest.mark.parametrize("B", [1, 3, 33, 100])
 def test_fmlp_odd_batch_sizes_vs_oracle(B):
     """batch sizes that do not fill the 32-row token tiles / the 256 partial-sum blocks of the filter backward"""
+    _fmlp_case(B, 2, 50)
+
+
+@pytest.mark.parametrize("NL,L", [(1, 50), (3, 50), (2, 20), (4, 8), (2, 2)])
+def test_fmlp_every_accepted_shape_vs_oracle(NL, L):
+    """1-4 filter layers, even sequence lengths from 2 to 50 (the plan check of csrc/fmlp.hip): loss and every gradient vs the oracle"""
+    _fmlp_case(29, NL, L)
+
+
+@pytest.mark.parametrize("L", [49, 64])
+def test_fmlp_unsupported_lengths_are_refused(L):
+    from dr4sr_amd.fmlp_engine import FmlpEngine
+    from dr4sr_amd import _lib
+    with pytest.raises(_lib.Dr4srError):
+        FmlpEngine(150, L, 64, 256, 2, 1e-12, 0.0, 8, "cuda")
+
+
+def _fmlp_case(B, NL, L):
     from dr4sr_amd.fmlp_engine import FmlpEngine, fmlp_param_names, fmlp_param_shapes
-    L, N = 50, 150
+    N = 150
     gen = torch.Generator().manual_seed(100 + B)
     idx = torch.zeros(B, L, dtype=torch.long)
     for i in range(B):
@@ -131,15 +149,15 @@ def test_fmlp_odd_batch_sizes_vs_oracle(B):
     tgt = torch.randint(1, N, (B,), generator=gen)
     neg = torch.randint(1, N, (B, 1), generator=gen)
     params = {}
-    for nme, shp in zip(fmlp_param_names(2), fmlp_param_shapes(N, L, 64, 256, 2)):
+    for nme, shp in zip(fmlp_param_names(NL), fmlp_param_shapes(N, L, 64, 256, NL)):
         params[nme] = (1.0 if nme.endswith("LayerNorm.weight") else 0.0) + 0.05 * torch.randn(shp, generator=gen)
     params["item_embedding.weight"][0] = 0
-    eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.0, B, "cuda")
+    eng = FmlpEngine(N, L, 64, 256, NL, 1e-12, 0.0, B, "cuda")
     eng.load_named(params)
     dev = eng.device
     plan = eng.make_plan(idx.to(dev), tgt.to(dev), neg_item=neg.view(-1).contiguous().to(dev), sample_neg=False)
     eng.fwd_bwd(plan)
-    loss_o, _, grads_o = FO.grads_of(params, {"in_item_id": idx, "item_id": tgt, "neg_item": neg}, 2)
+    loss_o, _, grads_o = FO.grads_of(params, {"in_item_id": idx, "item_id": tgt, "neg_item": neg}, NL)
     loss, n = eng.loss_and_count()
     assert n == B and abs(loss - float(loss_o)) < 3e-5
     for k, gv in eng.normalized_grads().items():

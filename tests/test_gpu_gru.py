@@ -90,8 +90,26 @@ def test_gru4rec_full_size_vs_oracle(dense):
 def test_gru4rec_odd_batch_sizes_vs_oracle(B):
     """batch sizes that are not multiples of the 16-sequence groups of the cooperative recurrence (partial last group, single
     sequence), random lengths including 1 and L"""
+    _gru_case(B, 256, 2, 50)
+
+
+@pytest.mark.parametrize("H,NL,L", [(128, 2, 50), (256, 1, 50), (256, 3, 20), (128, 1, 64), (256, 2, 1), (128, 3, 7)])
+def test_gru4rec_every_accepted_shape_vs_oracle(H, NL, L):
+    """hidden 128 / 256, 1-3 stacked layers, L from 1 to 64: whatever the plan check of csrc/gru.hip accepts must reproduce the oracle"""
+    _gru_case(37, H, NL, L)
+
+
+@pytest.mark.parametrize("H,NL,L", [(64, 2, 50), (512, 2, 50), (256, 2, 100)])
+def test_gru4rec_unsupported_shapes_are_refused(H, NL, L):
+    from dr4sr_amd.gru_engine import GruEngine
+    from dr4sr_amd import _lib
+    with pytest.raises(_lib.Dr4srError):
+        GruEngine(200, L, 64, H, NL, 0.0, 8, "cuda", seed=5)
+
+
+def _gru_case(B, H, NL, L):
     from dr4sr_amd.gru_engine import GruEngine, gru_param_names, gru_param_shapes
-    N, H, L = 200, 256, 50
+    N = 200
     gen = torch.Generator().manual_seed(B)
     sl = torch.randint(1, L + 1, (B,), generator=gen)
     sl[0] = 1
@@ -104,10 +122,10 @@ def test_gru4rec_odd_batch_sizes_vs_oracle(B):
         tgt[r, :n] = torch.randint(0, N, (n,), generator=gen)
     b = {"in_item_id": inp, "item_id": tgt, "seqlen": sl, "neg_item": torch.randint(1, N, (B, L, 1), generator=gen)}
     params = {}
-    for nme, shp in zip(gru_param_names(2), gru_param_shapes(N, 64, H, 2)):
+    for nme, shp in zip(gru_param_names(NL), gru_param_shapes(N, 64, H, NL)):
         params[nme] = 0.08 * torch.randn(shp, generator=gen)
     params["item_embedding.weight"][0] = 0
-    eng = GruEngine(N, L, 64, H, 2, 0.0, B, "cuda", seed=5)
+    eng = GruEngine(N, L, 64, H, NL, 0.0, B, "cuda", seed=5)
     eng.load_named(params)
     dev = eng.device
     plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
@@ -115,7 +133,7 @@ def test_gru4rec_odd_batch_sizes_vs_oracle(B):
     eng.fwd_bwd(plan)
     op = dict(params)
     op["query_encoder.0.1.weight"] = params["item_embedding.weight"]
-    loss_o, _, grads_o = GO.grads_of(op, b, 2)
+    loss_o, _, grads_o = GO.grads_of(op, b, NL)
     loss, n = eng.loss_and_count()
     assert n == int((b["item_id"] != 0).sum()) and abs(loss - float(loss_o)) < 3e-5
     for k, gv in eng.normalized_grads().items():

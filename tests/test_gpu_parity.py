@@ -550,3 +550,47 @@ def test_training_trajectory_matches_oracle(dev):
         # Adam's normalised update amplifies fp32 noise where the true gradient is ~0 (e.g. the key part of in_proj_bias, exactly 0 by
         # softmax shift invariance: +-lr per step on both sides): bound the bulk tightly, the tail loosely
         assert float(d.mean()) < 1e-4 and float(d.max()) < 5e-3, (k, float(d.mean()), float(d.max()))
+
+
+_SHAPES_OK = [(64, 1, 128, 2, 50), (64, 2, 256, 2, 50), (64, 1, 256, 1, 50), (128, 2, 128, 2, 50), (64, 2, 128, 1, 50), (64, 2, 128, 3, 50),
+              (64, 2, 128, 4, 20), (64, 2, 128, 2, 1), (64, 2, 128, 2, 3), (128, 4, 128, 2, 20)]
+_SHAPES_REFUSED = [(128, 4, 128, 2, 50), (64, 4, 128, 2, 50), (32, 2, 128, 2, 50), (64, 2, 64, 2, 50), (128, 2, 256, 2, 50),
+                   (64, 2, 128, 2, 100), (128, 1, 128, 2, 50)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,F,NL,L", _SHAPES_OK)
+def test_every_accepted_encoder_shape_matches_oracle(D, H, F, NL, L):
+    """head counts 1 / 2 / 4 (one-wave-per-head kernels next to the 2-head MFMA attention), FFN 128 / 256, 1-4 layers, L from 1 to 50:
+    whatever check_shape (csrc/step.hip) accepts must reproduce the oracle's loss and every gradient (tools/config_probe.py)"""
+    from dr4sr_amd.engine import SasrecEngine
+    rng = np.random.default_rng(D + H + F + NL + L)
+    B, N = 37, 211
+    sl = rng.integers(1, L + 1, size=B); sl[0] = 1; sl[1] = L
+    inp = np.zeros((B, L), dtype=np.int64); tgt = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        inp[b, :sl[b]] = rng.integers(1, N, size=sl[b]); tgt[b, :sl[b]] = rng.integers(0, N, size=sl[b])
+    batch = {"in_item_id": torch.from_numpy(inp), "item_id": torch.from_numpy(tgt), "seqlen": torch.from_numpy(sl.astype(np.int64)),
+             "neg_item": torch.from_numpy(rng.integers(1, N, size=(B, L, 1)))}
+    params = _random_params(N, D, F, NL, L=L, seed=7)
+    eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, 0.0, B, "cuda")
+    eng.load_named(params)
+    plan = eng.make_plan(batch["in_item_id"].cuda(), batch["item_id"].cuda(), batch["seqlen"].cuda(),
+                         neg_item=batch["neg_item"].squeeze(-1).contiguous().cuda(), sample_neg=False)
+    eng.fwd_bwd(plan)
+    loss, n = eng.loss_and_count()
+    loss_o, _, grads_o = O.grads_of(params, batch, H, NL, 1e-12)
+    assert n == int((batch["item_id"] != 0).sum())
+    assert abs(loss - float(loss_o)) < 3e-5
+    for k, v in eng.normalized_grads().items():
+        assert relerr(v, grads_o[k]) < 5e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,F,NL,L", _SHAPES_REFUSED)
+def test_unsupported_encoder_shapes_are_refused_up_front(D, H, F, NL, L):
+    """a shape without kernels is an error when the engine is built — not a failed launch, never a wrong number"""
+    from dr4sr_amd.engine import SasrecEngine
+    from dr4sr_amd import _lib
+    with pytest.raises(_lib.Dr4srError, match="DR4SR_E_SHAPE"):
+        SasrecEngine(211, L, D, H, F, NL, 1e-12, 0.0, 8, "cuda")
