@@ -594,3 +594,33 @@ def test_unsupported_encoder_shapes_are_refused_up_front(D, H, F, NL, L):
     from dr4sr_amd import _lib
     with pytest.raises(_lib.Dr4srError, match="DR4SR_E_SHAPE"):
         SasrecEngine(211, L, D, H, F, NL, 1e-12, 0.0, 8, "cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,F,NL,L", [(64, 1, 128, 2, 50), (64, 2, 256, 3, 50), (128, 4, 128, 2, 20), (64, 2, 128, 1, 50), (64, 2, 128, 4, 20)])
+def test_dropout_sites_of_every_shape_match_oracle_with_same_masks(D, H, F, NL, L):
+    """the dropout sites (embedding, attention probabilities, projection, activation, FFN: 4 per layer) of the shapes beyond the golden
+    fixtures' 2 layers x 2 heads: the library's own Philox masks, materialised through dr4sr_dropout_mask, fed to the oracle"""
+    from dr4sr_amd.engine import SasrecEngine
+    rng = np.random.default_rng(11 * D + H + F + NL + L)
+    B, N, p = 23, 157, 0.3
+    sl = rng.integers(1, L + 1, size=B); sl[0] = 1; sl[1] = L
+    inp = np.zeros((B, L), dtype=np.int64); tgt = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        inp[b, :sl[b]] = rng.integers(1, N, size=sl[b]); tgt[b, :sl[b]] = rng.integers(1, N, size=sl[b])
+    batch = {"in_item_id": torch.from_numpy(inp), "item_id": torch.from_numpy(tgt), "seqlen": torch.from_numpy(sl.astype(np.int64)),
+             "neg_item": torch.from_numpy(rng.integers(1, N, size=(B, L, 1)))}
+    params = _random_params(N, D, F, NL, L=L, seed=3)
+    eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, p, B, "cuda", seed=99)
+    eng.load_named(params)
+    plan = eng.make_plan(batch["in_item_id"].cuda(), batch["item_id"].cuda(), batch["seqlen"].cuda(),
+                         neg_item=batch["neg_item"].squeeze(-1).contiguous().cuda(), sample_neg=False)
+    eng.fwd_bwd(plan)
+    step = int(eng.state[3])
+    cu = torch.cat([torch.zeros(1, dtype=torch.long), batch["seqlen"].cumsum(0)])
+    masks = _masks_from_engine(eng, cu, batch["seqlen"], B, L, D, H, F, NL, step)
+    loss_o, _, grads_o = O.grads_of(params, batch, H, NL, 1e-12, masks=masks, pdrop=p)
+    loss, n = eng.loss_and_count()
+    assert abs(loss - float(loss_o)) < 2e-5 * max(1.0, abs(float(loss_o)))
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, grads_o[k]) < REL, k

@@ -1,0 +1,11 @@
+run() { echo "== $*"; env "$@" timeout 300 python tools/learn_probe.py 2>&1 | grep -v "^  File" | grep -E "^\{|Error|error|fault" | tail -2 | cut -c1-260; }
+run MODEL=SASRec EPOCHS=10 'OVERRIDES={"model":{"layer_num":3,"head_num":1,"hidden_size":256}}'
+run MODEL=SASRec EPOCHS=10 'OVERRIDES={"model":{"layer_num":1,"embed_dim":128,"hidden_size":128},"data":{"max_seq_len":20}}'
+run MODEL=SASRec EPOCHS=10 'OVERRIDES={"model":{"dropout_rate":0.0},"train":{"batch_size":1000,"hip_graph":false}}'
+run MODEL=SASRec EPOCHS=10 'OVERRIDES={"train":{"batch_size":5000},"eval":{"batch_size":64}}'
+run MODEL=GRU4Rec EPOCHS=25 'OVERRIDES={"model":{"hidden_size":128,"layer_num":1}}'
+run MODEL=GRU4Rec EPOCHS=25 'OVERRIDES={"model":{"layer_num":3},"train":{"batch_size":500}}'
+run MODEL=FMLP EPOCHS=25 PREFIX=1 'OVERRIDES={"model":{"layer_num":1}}'
+run MODEL=MetaModel SUB=SASRec EPOCHS=14 'OVERRIDES={"train":{"interval":7,"warmup_epoch":3}}'
+run MODEL=MetaModel SUB=GRU4Rec EPOCHS=25 WARM=5 
+run MODEL=CL4SRec EPOCHS=10

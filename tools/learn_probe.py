@@ -21,5 +21,9 @@ if E("INTERVAL"):
 if E("SUB"):
     cfg["model"]["sub_model"] = E("SUB")
 cfg["eval"]["batch_size"] = 512
+if E("OVERRIDES"):                                    # JSON {section: {key: value}}
+    import json
+    for sec, kv in json.loads(E("OVERRIDES")).items():
+        cfg[sec].update(kv)
 out = quickstart.run(cfg)
 print({k: round(float(v), 4) for k, v in out.items()})
