@@ -89,25 +89,59 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, int ld, cons
     }
 }
 
+// the same rows in two halves — global -> registers (issue only), registers -> LDS — for the persistent list kernels, which
+// request the NEXT sequence's rows before computing the current one
+template <int D, int ROWS, int NT, int PER>
+__device__ __forceinline__ void rows_to_regs(float4 (&v)[PER], const float* __restrict__ src, int src_ld, int n) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = threadIdx.x + q * NT, r = i / (D / 4), c = (i % (D / 4)) * 4;
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < ROWS * (D / 4) && r < n) v[q] = ld4(src + (size_t)r * src_ld + c);
+    }
+}
+template <int D, int ROWS, int NT, int PER>
+__device__ __forceinline__ void regs_to_rows(float* __restrict__ dst, int ld, const float4 (&v)[PER]) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = threadIdx.x + q * NT, r = i / (D / 4), c = (i % (D / 4)) * 4;
+        if (i < ROWS * (D / 4)) st4(dst + r * ld + c, v[q]);
+    }
+}
+// In the pipelined loops a value requested in iteration i is first TOUCHED in iteration i+1: the compiler places the vmcnt wait at
+// the first use, and returns are in order — one early use (a subtraction, a compare) would drain every load requested before it.
+struct SeqRaw { int b, c0, c1; int64_t row; };          // exactly what was loaded
+struct SeqMeta { int b, t0, n; int64_t row; };
+// The words are wave-uniform, and the compiler would move a uniform load's result to an SGPR (v_readfirstlane) right behind the load
+// — a use, hence a wait.  `z` is a zero it cannot see through: the addresses look divergent, the results stay in VGPRs until
+// seq_final() makes them scalar one iteration later.
+__device__ __forceinline__ int opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+__device__ __forceinline__ int list_raw(const AttnArgs2& A, int k, int z) { return A.list[k + z]; }
+__device__ __forceinline__ SeqRaw seq_raw(const AttnArgs2& A, int b_raw, int z) {
+    const int b = __builtin_amdgcn_readfirstlane(b_raw);
+    SeqRaw m;
+    m.b = b; m.c0 = A.cu[b + z]; m.c1 = A.cu[b + 1 + z]; m.row = A.rows ? A.rows[b + z] : (int64_t)b;
+    return m;
+}
+__device__ __forceinline__ SeqMeta seq_final(const SeqRaw& r) {
+    const int c0 = __builtin_amdgcn_readfirstlane(r.c0), c1 = __builtin_amdgcn_readfirstlane(r.c1);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)r.row), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)r.row >> 32));
+    return SeqMeta{r.b, c0, c1 - c0, (int64_t)(((uint64_t)hi << 32) | lo)};
+}
+
 // ------------------------------------------------------------------------------------------------ forward
+// K, V and the key-padding flags of the sequence are in LDS (and a barrier has passed)
 template <int DH, int ROWS, int NT>
-__device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
+__device__ __forceinline__ void attn_fwd_compute(const AttnArgs2& A, const int b, const int t0, const int n, const uint32_t rngstep) {
     constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16;
-    const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
-    if (n <= 0) return;
     float* Ks = smem;                    // [ROWS][LD]   (Q fragments come straight from global: used once per query tile)
     float* Vs = Ks + ROWS * LD;
     int* kpad = reinterpret_cast<int*>(Vs + ROWS * LD);      // [64]
-    const int64_t row = A.rows ? A.rows[b] : b;
     const float* src = A.qkv + (size_t)t0 * 3 * D;
-    stage_rows<D, ROWS, NT>(Ks, LD, src + D, 3 * D, n);
-    stage_rows<D, ROWS, NT>(Vs, LD, src + 2 * D, 3 * D, n);
-    if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
-    lds_barrier();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1;
     const int i16 = lane & 15, g = lane >> 4;
     const bool dodrop = A.training && A.p > 0.f;
-    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const RngKey rk = make_rng(A.seed, rngstep, A.p);
     const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
     const float scale = 1.0f / sqrtf((float)DH);
     const int ntile = (n + 15) >> 4;
@@ -170,13 +204,77 @@ __device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
 
 
 template <int DH, int ROWS, int NT>
-__global__ __launch_bounds__(NT) void k_attn2_fwd(const AttnArgs2 A) {
-    if (!A.list) { attn_fwd_seq<DH, ROWS, NT>(A, blockIdx.x); return; }
-    const int cnt = *A.list_count;
-    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
-        attn_fwd_seq<DH, ROWS, NT>(A, A.list[k]);
-        __syncthreads();                                   // LDS is reused by the next sequence
+__device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
+    constexpr int D = 2 * DH, LD = D + 4;
+    const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
+    if (n <= 0) return;
+    float* Ks = smem;
+    float* Vs = Ks + ROWS * LD;
+    int* kpad = reinterpret_cast<int*>(Vs + ROWS * LD);
+    const int64_t row = A.rows ? A.rows[b] : b;
+    const float* src = A.qkv + (size_t)t0 * 3 * D;
+    stage_rows<D, ROWS, NT>(Ks, LD, src + D, 3 * D, n);
+    stage_rows<D, ROWS, NT>(Vs, LD, src + 2 * D, 3 * D, n);
+    if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
+    lds_barrier();
+    attn_fwd_compute<DH, ROWS, NT>(A, b, t0, n, (uint32_t)A.state[DR4SR_STATE_RNGSTEP]);
+}
+
+// Persistent loop over a length-class list, software-pipelined three deep: while sequence i is computed, the rows of sequence i+1
+// are in flight to registers, the (cu, rows) words of i+2 and the list entry of i+3 are requested — the dependent chain
+// list -> cu -> rows of a sequence never sits in front of its compute phase.
+template <int DH, int ROWS, int NT>
+__device__ __forceinline__ void attn_fwd_list(const AttnArgs2& A) {
+    constexpr int D = 2 * DH, LD = D + 4, PER = (ROWS * (D / 4) + NT - 1) / NT;
+    const int cnt = *A.list_count, G = gridDim.x;
+    if ((int)blockIdx.x >= cnt) return;
+    const uint32_t rngstep = (uint32_t)A.state[DR4SR_STATE_RNGSTEP];
+    float* Ks = smem;
+    float* Vs = Ks + ROWS * LD;
+    int* kpad = reinterpret_cast<int*>(Vs + ROWS * LD);
+    float4 rk[PER], rv[PER];
+    int64_t ridx = 1;                                    // raw item id of key position threadIdx.x (1 = "not PAD" placeholder)
+    bool rin = false;
+    auto request = [&](const SeqMeta& m) {
+        const float* src = A.qkv + (size_t)m.t0 * 3 * D;
+        rows_to_regs<D, ROWS, NT, PER>(rk, src + D, 3 * D, m.n);
+        rows_to_regs<D, ROWS, NT, PER>(rv, src + 2 * D, 3 * D, m.n);
+        rin = threadIdx.x < 64 && (int)threadIdx.x < m.n;
+        if (rin) ridx = A.idx[m.row * A.L + threadIdx.x];
+    };
+    const int z = opaque_zero();
+    SeqMeta cur = seq_final(seq_raw(A, list_raw(A, blockIdx.x, z), z));
+    request(cur);
+    int k1 = blockIdx.x + G, k2 = k1 + G;
+    bool has1 = k1 < cnt, has2 = k2 < cnt;
+    SeqRaw nxt_raw = SeqRaw{0, 0, 0, 0};
+    if (has1) nxt_raw = seq_raw(A, list_raw(A, k1, z), z);
+    int b2 = has2 ? list_raw(A, k2, z) : 0;
+    for (;;) {
+        regs_to_rows<D, ROWS, NT, PER>(Ks, LD, rk);
+        regs_to_rows<D, ROWS, NT, PER>(Vs, LD, rv);
+        if (threadIdx.x < 64) kpad[threadIdx.x] = rin ? (ridx == 0) : 1;
+        lds_barrier();
+        const SeqMeta nxt = seq_final(nxt_raw);                              // loaded one iteration ago
+        if (has1) request(nxt);                                              // rows of i+1
+        SeqRaw nn_raw = nxt_raw;
+        if (has2) nn_raw = seq_raw(A, b2, z);                                // cu / rows words of i+2
+        const int k3 = k2 + G;
+        const bool has3 = k3 < cnt;
+        const int b3 = has3 ? list_raw(A, k3, z) : 0;                        // list entry of i+3
+        attn_fwd_compute<DH, ROWS, NT>(A, cur.b, cur.t0, cur.n, rngstep);
+        lds_barrier();                                                       // LDS is reused by the next sequence
+        if (!has1) break;
+        cur = nxt; nxt_raw = nn_raw; has1 = has2; has2 = has3; b2 = b3; k2 = k3;
     }
+}
+
+// LIST = false: workgroup b = sequence b;  true: persistent loop over a length-class list (separate instantiations: the
+// pipelined loop's staging registers must not weigh on the one-sequence form)
+template <int DH, int ROWS, int NT, bool LIST>
+__global__ __launch_bounds__(NT) void k_attn2_fwd(const AttnArgs2 A) {
+    if constexpr (!LIST) attn_fwd_seq<DH, ROWS, NT>(A, blockIdx.x);
+    else attn_fwd_list<DH, ROWS, NT>(A);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -184,42 +282,39 @@ __global__ __launch_bounds__(NT) void k_attn2_fwd(const AttnArgs2 A) {
 // (per head; also true under dropout) comes from k_post_bwd.  dQ (phase A, query-tile owners) and dK/dV (phase B, key-tile
 // owners) are therefore independent and run CONCURRENTLY on two halves of the workgroup: waves [0, NT/128) do phase A,
 // waves [NT/128, NT/64) phase B — half the serial chain of a long sequence, twice the waves per workgroup to hide latency.
-template <int DH, int ROWS, int NT>
-__device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
-    constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16, NW = NT / 64;
-    const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
-    if (n <= 0) return;
-    float* Qs = smem;                                       // (V is only ever used as a row fragment: read from global)
-    float* Ks = Qs + ROWS * LD;
-    float* Cs = Ks + ROWS * LD;                             // dctx rows
-    float* stat = Cs + ROWS * LD;                           // [H][ROWS][3]  row max, 1/sum, sum_j P dP
-    int* kpad = reinterpret_cast<int*>(stat + H * ROWS * 3);
-    const int64_t row = A.rows ? A.rows[b] : b;
-    const float* src = A.qkv + (size_t)t0 * 3 * D;
-    stage_rows<D, ROWS, NT>(Qs, LD, src, 3 * D, n);
-    stage_rows<D, ROWS, NT>(Ks, LD, src + D, 3 * D, n);
-    stage_rows<D, ROWS, NT>(Cs, LD, A.dctx + (size_t)t0 * D, D, n);
-    if (threadIdx.x < 64) kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
-    for (int i = threadIdx.x; i < H * ROWS; i += NT) {      // (h, row) -> m, 1/sum, rowdot
-        const int hh = i / ROWS, r = i % ROWS;
-        float m = 0.f, inv = 0.f, rdot = 0.f;
-        if (r < n) {
-            const float* st = A.stat + ((size_t)(t0 + r) * H + hh) * 2;
-            m = st[0]; inv = st[1]; rdot = A.rd[(size_t)(t0 + r) * H + hh];
-        }
-        stat[i * 3] = m; stat[i * 3 + 1] = inv; stat[i * 3 + 2] = rdot;
+// LDS map of the backward: Q, K, dctx rows (+ V rows for the 16-row variant, whose LDS budget allows it: one dependent global
+// round trip less inside each phase), the per-row statistics and the key-padding flags
+template <int DH, int ROWS>
+struct BwdLds {
+    static constexpr int D = 2 * DH, LD = D + 4, H = 2;
+    static constexpr bool VLDS = ROWS == 16;
+    float *Qs, *Ks, *Cs, *Vs, *stat; int* kpad;
+    __device__ __forceinline__ BwdLds() {
+        Qs = smem; Ks = Qs + ROWS * LD; Cs = Ks + ROWS * LD;
+        Vs = Cs + ROWS * LD;
+        stat = Vs + (VLDS ? ROWS * LD : 0);                 // [H][ROWS][3]  row max, 1/sum, sum_j P dP
+        kpad = reinterpret_cast<int*>(stat + H * ROWS * 3);
     }
-    lds_barrier();
+};
+
+// everything of the sequence is in LDS (and a barrier has passed)
+template <int DH, int ROWS, int NT>
+__device__ __forceinline__ void attn_bwd_compute(const AttnArgs2& A, const int b, const int t0, const int n, const uint32_t rngstep) {
+    constexpr int D = 2 * DH, LD = D + 4, H = 2, MT = ROWS / 16, NW = NT / 64;
+    constexpr bool VLDS = BwdLds<DH, ROWS>::VLDS;
+    const BwdLds<DH, ROWS> S;
+    float* Qs = S.Qs; float* Ks = S.Ks; float* Cs = S.Cs; float* Vs = S.Vs; float* stat = S.stat; int* kpad = S.kpad;
+    const float* src = A.qkv + (size_t)t0 * 3 * D;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1;
     // NW = 8: phases on separate wave quads (latency regime);  ROWS = 64 with NW = 4: every wave runs phase A then phase B
     // (throughput regime: 4 workgroups' worth of waves per CU instead of 2, no A/B load imbalance);  short variant: one wave per
     // (phase, head)
-    constexpr bool SEQ = ROWS == 64 && NT == 256;
+    constexpr bool SEQ = (ROWS == 64 && NT == 256) || (ROWS == 16 && NT == 128);
     const int half = (NW == 8 || SEQ) ? (w >> 1) & 1 : 0;
     const bool phaseB = !SEQ && w >= NW / 2;
     const int i16 = lane & 15, g = lane >> 4;
     const bool dodrop = A.training && A.p > 0.f;
-    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const RngKey rk = make_rng(A.seed, rngstep, A.p);
     const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
     const float scale = 1.0f / sqrtf((float)DH);
     const int ntile = (n + 15) >> 4;
@@ -244,7 +339,8 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
                     float kf[DH / 4];
                     load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
                     const f32x4 s = mma_rows<DH>(kf, qf);
-                    load_frag_g<DH>(kf, src + 2 * D + h * DH, 3 * D, jt * 16, n);
+                    if constexpr (VLDS) load_frag<DH>(kf, Vs, LD, jt * 16, h * DH);
+                    else load_frag_g<DH>(kf, src + 2 * D + h * DH, 3 * D, jt * 16, n);
                     const f32x4 dp = mma_rows<DH>(kf, cf);         // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
                     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
@@ -279,7 +375,8 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
         const int j = jt * 16 + i16;                       // this lane's key row
         float kf[DH / 4], vf[DH / 4];
         load_frag<DH>(kf, Ks, LD, jt * 16, h * DH);
-        load_frag_g<DH>(vf, src + 2 * D + h * DH, 3 * D, jt * 16, n);
+        if constexpr (VLDS) load_frag<DH>(vf, Vs, LD, jt * 16, h * DH);
+        else load_frag_g<DH>(vf, src + 2 * D + h * DH, 3 * D, jt * 16, n);
         const bool jok = j < n && !kpad[j];
         f32x4 dk[DH / 16], dv[DH / 16];
 #pragma unroll
@@ -329,12 +426,101 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
 }
 
 template <int DH, int ROWS, int NT>
+__device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
+    constexpr int D = 2 * DH, LD = D + 4, H = 2;
+    const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
+    if (n <= 0) return;
+    const BwdLds<DH, ROWS> S;
+    const int64_t row = A.rows ? A.rows[b] : b;
+    const float* src = A.qkv + (size_t)t0 * 3 * D;
+    stage_rows<D, ROWS, NT>(S.Qs, LD, src, 3 * D, n);
+    stage_rows<D, ROWS, NT>(S.Ks, LD, src + D, 3 * D, n);
+    stage_rows<D, ROWS, NT>(S.Cs, LD, A.dctx + (size_t)t0 * D, D, n);
+    if constexpr (BwdLds<DH, ROWS>::VLDS) stage_rows<D, ROWS, NT>(S.Vs, LD, src + 2 * D, 3 * D, n);
+    if (threadIdx.x < 64) S.kpad[threadIdx.x] = threadIdx.x < n ? (A.idx[row * A.L + threadIdx.x] == 0) : 1;
+    for (int i = threadIdx.x; i < H * ROWS; i += NT) {      // (h, row) -> m, 1/sum, rowdot
+        const int hh = i / ROWS, r = i % ROWS;
+        float m = 0.f, inv = 0.f, rdot = 0.f;
+        if (r < n) {
+            const float* st = A.stat + ((size_t)(t0 + r) * H + hh) * 2;
+            m = st[0]; inv = st[1]; rdot = A.rd[(size_t)(t0 + r) * H + hh];
+        }
+        S.stat[i * 3] = m; S.stat[i * 3 + 1] = inv; S.stat[i * 3 + 2] = rdot;
+    }
+    lds_barrier();
+    attn_bwd_compute<DH, ROWS, NT>(A, b, t0, n, (uint32_t)A.state[DR4SR_STATE_RNGSTEP]);
+}
+
+// persistent list loop, software-pipelined like attn_fwd_list (rows and statistics of sequence i+1 in flight during sequence i)
+template <int DH, int ROWS, int NT>
+__device__ __forceinline__ void attn_bwd_list(const AttnArgs2& A) {
+    constexpr int D = 2 * DH, LD = D + 4, H = 2, PER = (ROWS * (D / 4) + NT - 1) / NT;
+    constexpr bool VLDS = BwdLds<DH, ROWS>::VLDS;
+    static_assert(H * ROWS <= NT, "one statistics triple per thread");
+    const int cnt = *A.list_count, G = gridDim.x;
+    if ((int)blockIdx.x >= cnt) return;
+    const uint32_t rngstep = (uint32_t)A.state[DR4SR_STATE_RNGSTEP];
+    const BwdLds<DH, ROWS> S;
+    float4 rq[PER], rk[PER], rc[PER], rv[VLDS ? PER : 1];
+    float2 sst = make_float2(0.f, 0.f);
+    float sr = 0.f;
+    int64_t ridx = 1;
+    bool rin = false;
+    auto request = [&](const SeqMeta& m) {
+        const float* src = A.qkv + (size_t)m.t0 * 3 * D;
+        rows_to_regs<D, ROWS, NT, PER>(rq, src, 3 * D, m.n);
+        rows_to_regs<D, ROWS, NT, PER>(rk, src + D, 3 * D, m.n);
+        rows_to_regs<D, ROWS, NT, PER>(rc, A.dctx + (size_t)m.t0 * D, D, m.n);
+        if constexpr (VLDS) rows_to_regs<D, ROWS, NT, PER>(rv, src + 2 * D, 3 * D, m.n);
+        rin = threadIdx.x < 64 && (int)threadIdx.x < m.n;
+        if (rin) ridx = A.idx[m.row * A.L + threadIdx.x];
+        sst = make_float2(0.f, 0.f); sr = 0.f;
+        const int hh = threadIdx.x / ROWS, r = threadIdx.x % ROWS;
+        if ((int)threadIdx.x < H * ROWS && r < m.n) {
+            sst = *reinterpret_cast<const float2*>(A.stat + ((size_t)(m.t0 + r) * H + hh) * 2);
+            sr = A.rd[(size_t)(m.t0 + r) * H + hh];
+        }
+    };
+    const int z = opaque_zero();
+    SeqMeta cur = seq_final(seq_raw(A, list_raw(A, blockIdx.x, z), z));
+    request(cur);
+    int k1 = blockIdx.x + G, k2 = k1 + G;
+    bool has1 = k1 < cnt, has2 = k2 < cnt;
+    SeqRaw nxt_raw = SeqRaw{0, 0, 0, 0};
+    if (has1) nxt_raw = seq_raw(A, list_raw(A, k1, z), z);
+    int b2 = has2 ? list_raw(A, k2, z) : 0;
+    for (;;) {
+        regs_to_rows<D, ROWS, NT, PER>(S.Qs, LD, rq);
+        regs_to_rows<D, ROWS, NT, PER>(S.Ks, LD, rk);
+        regs_to_rows<D, ROWS, NT, PER>(S.Cs, LD, rc);
+        if constexpr (VLDS) regs_to_rows<D, ROWS, NT, PER>(S.Vs, LD, rv);
+        if (threadIdx.x < 64) S.kpad[threadIdx.x] = rin ? (ridx == 0) : 1;
+        if ((int)threadIdx.x < H * ROWS) { S.stat[threadIdx.x * 3] = sst.x; S.stat[threadIdx.x * 3 + 1] = sst.y; S.stat[threadIdx.x * 3 + 2] = sr; }
+        lds_barrier();
+        const SeqMeta nxt = seq_final(nxt_raw);
+        if (has1) request(nxt);
+        SeqRaw nn_raw = nxt_raw;
+        if (has2) nn_raw = seq_raw(A, b2, z);
+        const int k3 = k2 + G;
+        const bool has3 = k3 < cnt;
+        const int b3 = has3 ? list_raw(A, k3, z) : 0;
+        attn_bwd_compute<DH, ROWS, NT>(A, cur.b, cur.t0, cur.n, rngstep);
+        lds_barrier();
+        if (!has1) break;
+        cur = nxt; nxt_raw = nn_raw; has1 = has2; has2 = has3; b2 = b3; k2 = k3;
+    }
+}
+
+template <int DH, int ROWS, int NT, bool LIST>
 __global__ __launch_bounds__(NT) void k_attn2_bwd(const AttnArgs2 A) {
-    if (!A.list) { attn_bwd_seq<DH, ROWS, NT>(A, blockIdx.x); return; }
-    const int cnt = *A.list_count;
-    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
-        attn_bwd_seq<DH, ROWS, NT>(A, A.list[k]);
-        __syncthreads();
+    if constexpr (!LIST) attn_bwd_seq<DH, ROWS, NT>(A, blockIdx.x);
+    else if constexpr (ROWS == 16) attn_bwd_list<DH, ROWS, NT>(A);
+    else {                                   // 64-row sequences: the staging registers of the pipelined loop would cost a wave per SIMD
+        const int cnt = *A.list_count;
+        for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+            attn_bwd_seq<DH, ROWS, NT>(A, A.list[k]);
+            lds_barrier();                   // LDS is reused by the next sequence
+        }
     }
 }
 
@@ -353,33 +539,57 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
 // workgroup per sequence with worst-case LDS.  seq_class = [n_short, n_long, short_list[B], long_list[B]].
 static bool split_by_length(const Workspace& ws) { return ws.Tmax > 16384 && !getenv("DR4SR_ATTN_NOSPLIT"); }
 
+// short sequences, backward: one wave per head runs phase A then phase B (2 waves per sequence, twice the sequences per CU of the
+// 4-wave form — the kernel is bound by how many sequences are in flight, not by issue slots)
+constexpr int SHORT_BWD_NT = 256;
+
+// workgroups of `kernel` that fit one CU (fallback: the hand-computed figure)
+static int resident_per_cu(const void* kernel, int threads, size_t lds, int fallback) {
+    if (getenv("DR4SR_ATTN_GRID_FIXED")) return fallback;
+    if (lds > 48 * 1024) big_lds_impl(kernel, lds);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fallback; }
+    return n;
+}
+
 template <int DH>
 static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArgs2 A, bool bwd, hipStream_t s) {
     const int D = p->D, B = p->B;
-    auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? 3 : 2) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
+    auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? (rows == 16 ? 4 : 3) : 2) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
     if (!split_by_length(ws)) {
         const size_t lds = lds_of(64);
-        if (bwd && DH == 32) { big_lds(k_attn2_bwd<DH, 64, 512>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512>), dim3(B), dim3(512), lds, s, A); }
+        if (bwd && DH == 32) { big_lds(k_attn2_bwd<DH, 64, 512, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512, false>), dim3(B), dim3(512), lds, s, A); }
         else if (bwd) {                              // head_dim 64: the 8-wave variant would spill (256-VGPR cap at 512 threads)
-            big_lds(k_attn2_bwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A);
+            big_lds(k_attn2_bwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A);
         }
-        else { big_lds(k_attn2_fwd<DH, 64, 256>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256>), dim3(B), dim3(256), lds, s, A); }
+        else { big_lds(k_attn2_fwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
         return DR4SR_LAUNCH_CHECK();
     }
-    const int gs = B < 256 * 8 ? B : 256 * 8;                                // persistent grids: workgroups per CU that fit by LDS
-    const int glmax = bwd ? 256 * 2 : 256 * 3, gl = B < glmax ? B : glmax;
+    // persistent grids = what is really co-resident (registers, LDS and wave slots, as the runtime computes it): a larger grid
+    // runs in two rounds with an unbalanced tail, a smaller one leaves latency-hiding slots empty
+    static int per_cu[2][2];                                                 // [bwd][long], per head width
+    if (!per_cu[bwd][0]) {
+        per_cu[bwd][1] = bwd ? resident_per_cu((const void*)k_attn2_bwd<DH, 64, 256, true>, 256, lds_of(64), 2)
+                             : resident_per_cu((const void*)k_attn2_fwd<DH, 64, 256, true>, 256, lds_of(64), 3);
+        per_cu[bwd][0] = bwd ? resident_per_cu((const void*)k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>, SHORT_BWD_NT, lds_of(16), 4)
+                             : resident_per_cu((const void*)k_attn2_fwd<DH, 16, 128, true>, 128, lds_of(16), 8);
+        if (getenv("DR4SR_ATTN_GRID_PRINT")) fprintf(stderr, "attention grids (DH %d, %s): %d short / %d long workgroups per CU\n", DH, bwd ? "bwd" : "fwd", per_cu[bwd][0], per_cu[bwd][1]);
+    }
+    const int per_cu_s = per_cu[bwd][0], per_cu_l = per_cu[bwd][1];
+    const int gs = B < 256 * per_cu_s ? B : 256 * per_cu_s;
+    const int gl = B < 256 * per_cu_l ? B : 256 * per_cu_l;
     AttnArgs2 S = A, Lg = A;
     S.list = ws.seq_class + 2; S.list_count = ws.seq_class;
     Lg.list = ws.seq_class + 2 + B; Lg.list_count = ws.seq_class + 1;
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
     if (bwd) {
-        hipLaunchKernelGGL((k_attn2_bwd<DH, 16, 256>), dim3(gs), dim3(256), lds_s, s, S);
-        big_lds(k_attn2_bwd<DH, 64, 256>, lds_l);
-        hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256>), dim3(gl), dim3(256), lds_l, s, Lg);
+        hipLaunchKernelGGL((k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>), dim3(gs), dim3(SHORT_BWD_NT), lds_s, s, S);
+        big_lds(k_attn2_bwd<DH, 64, 256, true>, lds_l);
+        hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
     } else {
-        hipLaunchKernelGGL((k_attn2_fwd<DH, 16, 128>), dim3(gs), dim3(128), lds_s, s, S);
-        big_lds(k_attn2_fwd<DH, 64, 256>, lds_l);
-        hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256>), dim3(gl), dim3(256), lds_l, s, Lg);
+        hipLaunchKernelGGL((k_attn2_fwd<DH, 16, 128, true>), dim3(gs), dim3(128), lds_s, s, S);
+        big_lds(k_attn2_fwd<DH, 64, 256, true>, lds_l);
+        hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
     }
     return DR4SR_LAUNCH_CHECK();
 }
