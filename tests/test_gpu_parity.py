@@ -624,3 +624,29 @@ def test_dropout_sites_of_every_shape_match_oracle_with_same_masks(D, H, F, NL, 
     assert abs(loss - float(loss_o)) < 2e-5 * max(1.0, abs(float(loss_o)))
     for k, gv in eng.normalized_grads().items():
         assert relerr(gv, grads_o[k]) < REL, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,p", [(8192, 64, 0.0), (8192, 64, 0.5), (4096, 128, 0.3)])
+def test_persistent_attention_lists_longer_than_the_grid(dev, monkeypatch, B, D, p):
+    """thousands of sequences per length class: every workgroup of the persistent attention launches walks SEVERAL list entries, i.e.
+    the software-pipelined loop (rows of i+1 / cu words of i+2 / list entry of i+3 in flight) runs its steady state and its drain.
+    Checked against the one-workgroup-per-sequence launch of the same step (itself checked against the oracle above); with dropout the
+    two draw identical masks (element-indexed Philox)."""
+    from dr4sr_amd.engine import SasrecEngine
+    b, N = _toys_batch(B, False, seed=21)
+    params = _random_params(N, D, 128, 2, seed=4)
+    eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, p, B, "cuda", seed=11)
+    eng.load_named(params)
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                         neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    loss_a, n_a = eng.loss_and_count()
+    ga = {k: v.clone() for k, v in eng.normalized_grads().items()}
+    eng.state[3] -= 1                                             # replay the same RNG step
+    monkeypatch.setenv("DR4SR_ATTN_NOSPLIT", "1")
+    eng.fwd_bwd(plan)
+    loss_b, n_b = eng.loss_and_count()
+    assert n_a == n_b == int((b["item_id"] != 0).sum()) and abs(loss_a - loss_b) < 1e-6
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, ga[k].cpu()) < 1e-5, k
