@@ -111,6 +111,9 @@ int  dr4sr_sasrec_plan_sizeof(void);   /* sizeof(dr4sr_sasrec_plan) as compiled:
 /* Fills offsets[0]=E, [1]=P, [2+12*i+j] = j-th tensor of layer i (order above); returns n_params. */
 int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
                                   int64_t* offsets /* [2+12*n_layer] or NULL */);
+/* Bytes of scratch a plan of this shape needs (plan->workspace may be NULL here), or a negative DR4SR_E_* code: DR4SR_E_SHAPE for an
+ * encoder shape without kernels — L > 64; (D, F) outside {(64,128), (64,256), (128,128)}; head_dim other than 32 / 64; a head count != 2
+ * whose one-wave-per-head attention would not fit 160 KB of LDS — so an unsupported configuration is refused when the engine is built. */
 int64_t dr4sr_sasrec_workspace_bytes(const dr4sr_sasrec_plan* plan);
 
 /* One reference training step minus the optimizer:  basemodel.py:193-198
@@ -235,6 +238,7 @@ typedef struct dr4sr_fmlp_plan {
 int     dr4sr_fmlp_plan_sizeof(void);
 /* offsets[0]=E [1]=P [2]=ln_w [3]=ln_b, [4+9*i+j] = j-th tensor of layer i in the order above; returns n_params */
 int64_t dr4sr_fmlp_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer, int64_t* offsets);
+/* bytes, or DR4SR_E_SHAPE unless D = 64, F = 256, L even and <= 50 */
 int64_t dr4sr_fmlp_workspace_bytes(const dr4sr_fmlp_plan* plan);
 /* basemodel.py:193-198 for model = FMLP: negatives, forward, scorer + BCE (1-D targets), backward; un-normalised grads */
 int dr4sr_fmlp_fwd_bwd(const dr4sr_fmlp_plan* plan, void* stream);
@@ -283,6 +287,7 @@ int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_t H, int32_
  * a wait that runs out never hangs the GPU but sets a sticky error flag — the int32 word 2 of the workspace (words 0, 1: launch
  * counter, finish ticket) — and leaves garbage; the caller should read that word whenever it synchronises anyway (per epoch) and
  * treat non-zero as a failed run. */
+/* bytes, or DR4SR_E_SHAPE unless D = 64, H in {128, 256}, L <= 64 */
 int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan);
 int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream);       /* basemodel.py:193-198, un-normalised grads */
 int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream);    /* + dense Adam */
