@@ -227,7 +227,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--steps-per-graph", type=int, default=5, help="whole training steps captured per HIP graph (single GPU)")
+    ap.add_argument("--steps-per-graph", type=int, default=10, help="whole training steps captured per HIP graph (single GPU)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
     ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp", "metamodel", "cl4srec"],
