@@ -507,11 +507,11 @@ def test_topk_workspace_path_large_catalog(dev):
 
 
 def test_fuzz_odd_batches_vs_oracle(dev):
-    """random odd batch sizes (1 .. 100), item counts down to 2, both widths, random lengths and PAD targets: tools/fuzz_parity.py"""
+    """random odd batch sizes (1 .. 100), item counts down to 2, both widths, random lengths and PAD targets: tests/fuzz_parity.py"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], capture_output=True, text=True, timeout=600,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py")], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, TRIALS="10", SEED="3"), cwd=root)
     assert out.returncode == 0 and "FUZZ ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
@@ -562,7 +562,7 @@ _SHAPES_REFUSED = [(128, 4, 128, 2, 50), (64, 4, 128, 2, 50), (32, 2, 128, 2, 50
 @pytest.mark.parametrize("D,H,F,NL,L", _SHAPES_OK)
 def test_every_accepted_encoder_shape_matches_oracle(D, H, F, NL, L):
     """head counts 1 / 2 / 4 (one-wave-per-head kernels next to the 2-head MFMA attention), FFN 128 / 256, 1-4 layers, L from 1 to 50:
-    whatever check_shape (csrc/step.hip) accepts must reproduce the oracle's loss and every gradient (tools/config_probe.py)"""
+    whatever check_shape (csrc/step.hip) accepts must reproduce the oracle's loss and every gradient (tests/config_probe.py)"""
     from dr4sr_amd.engine import SasrecEngine
     rng = np.random.default_rng(D + H + F + NL + L)
     B, N = 37, 211
