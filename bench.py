@@ -2,6 +2,7 @@
 """bench.py — training sequences/sec of the SASRec hot path (BASELINE.json metric) on N MI355X.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...                          (stand-alone: re-executes itself under torch.distributed.run, N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -27,6 +28,7 @@ import ctypes as C  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+PROFILE_ROUND = 2              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
@@ -55,11 +57,13 @@ def init_params_like_reference(eng, seed):
 def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen):
     """ALGORITHMIC flops of one launch on the packed batch: 2*M*N*K per GEMM over the T valid tokens."""
     if kind in ("post_fwd", "post_bwd"):
-        return 2.0 * T * (D * D + 2 * D * F)
-    if kind in ("qkv_fwd", "qkv_bwd"):
+        return 2.0 * T * (D * D + 2 * D * F) + (2.0 * T * 3 * D * D if n_layer > 1 else 0.0)   # + the next layer's qkv projection
+    if kind == "post_mid":
+        return 2.0 * 2.0 * T * (D * D + 2 * D * F)          # post_fwd + post_bwd of the last layer (scorer: VALU dots, not counted)
+    if kind in ("qkv_fwd", "qkv_bwd", "embqkv_fwd", "qkv_embed_bwd"):
         return 2.0 * T * 3 * D * D
-    if kind == "wgrad":
-        return 2.0 * T * (4 * D * D + 2 * D * F) * n_layer
+    if kind in ("wgrad", "wgrad_fused"):
+        return 2.0 * T * (4 * D * D + 2 * D * F) * n_layer + (2.0 * T * 3 * D * D if kind == "wgrad_fused" and B * L <= 16384 else 0.0)
     if kind in ("attn_fwd", "attn_bwd"):
         pairs = float((seqlen * (seqlen + 1) // 2).sum())
         return (2.0 if kind == "attn_fwd" else 5.0) * 2.0 * pairs * D      # QK^T + PV (fwd); +dP, dQ, dK, dV (bwd)
@@ -217,6 +221,29 @@ def bench_cl4srec(args):
         "final_loss": float(loss.detach())}))
 
 
+def relaunch_under_torchrun(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU, RCCL)
+    and pass their exit code on; rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    share = bool(os.environ.get("DR4SR_BENCH_SHARE_GPU"))
+    have = torch.cuda.device_count()
+    if have < n_gpus and not share:
+        sys.exit("bench.py --gpus %d: this node exposes %d GPU(s).  (DR4SR_BENCH_SHARE_GPU=1 runs the N-rank code path on one GPU over "
+                 "the gloo transport — a functional check, not a measurement.)" % (n_gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    if share:
+        env.setdefault("DR4SR_DP_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +256,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--steps-per-graph", type=int, default=10, help="whole training steps captured per HIP graph (single GPU)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
+    ap.add_argument("--strong-global-batch", type=int, nargs="*", default=[8192, 32768],
+                    help="fixed GLOBAL batch sizes of the strong-scaling runs reported as `strong` (per-rank batch = global / N)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling runs")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
     ap.add_argument("--model", default="sasrec", choices=["sasrec", "gru4rec", "fmlp", "metamodel", "cl4srec"],
                     help="sasrec = BASELINE headline (configs[1]); gru4rec = configs[2] (beauty-sized table, dropout 0.2, wd 1e-4); "
@@ -249,28 +279,30 @@ def main():
     # DR4SR_BENCH_FORCE_DP=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path — process group, split graphs,
     # all-reduce between them — with a single rank; exercises the RCCL + graph-capture interplay on a 1-GPU box
     dp = world > 1 or bool(os.environ.get("DR4SR_BENCH_FORCE_DP"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)                 # does not return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    # DR4SR_BENCH_SHARE_GPU=1 + DR4SR_BENCH_BACKEND=gloo: debug knobs that run the N-rank code path on ONE GPU (functional check only)
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # DR4SR_BENCH_SHARE_GPU=1 (+ DR4SR_DP_BACKEND=gloo): run the N-rank code path on ONE GPU (functional check only)
     dev = torch.device("cuda", 0 if os.environ.get("DR4SR_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
+    from dr4sr_amd import parallel
     if dp:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("DR4SR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        parallel.init_distributed(dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from dr4sr_amd import _lib
     from dr4sr_amd.data.synthetic import TOYS_N_ITEMS, make_rows
     from dr4sr_amd.engine import SasrecEngine
     lib = _lib.load()
 
-    def measure(B_arg, steps, warmup, extras):
-        """one timed run of the training step at B_arg rows per GPU; extras = per-kernel launch times + the K1 gather microbench"""
+    def measure(B_arg, steps, warmup, extras, dp=dp):
+        """one timed run of the training step at B_arg rows per GPU; extras = per-kernel launch times + the K1 gather microbench.
+        dp=False under a multi-rank launch: every rank runs the single-GPU step on its own (no collective) — the 1-GPU reference
+        of the strong-scaling runs."""
+        world = int(os.environ.get("WORLD_SIZE", "1")) if dp else 1
+        rank = int(os.environ.get("RANK", "0")) if dp else 0
         B, L, D, H, F, NL, N = B_arg, 50, 64, 2, 128, 2, TOYS_N_ITEMS
         if args.model == "gru4rec":
             N = 12102                                       # amazon-beauty item count (2.Pretrain_regenerator.py:37-42)
@@ -319,21 +351,26 @@ def main():
             _lib.check(lib.dr4sr_select_rows(_lib.ptr(perm), U, _lib.ptr(rows_buf), B, B * world, rank * B, _lib.ptr(counter),
                                              _lib.cur_stream()), "select_rows")
 
+        def reduce_grads():
+            parallel.allreduce_flat(eng.grads)             # sum over ranks: grads + {n_valid, loss_sum, poison} tail
+
         def step_eager():
             select()
             if not dp:
                 eng.train_step(plan)
             else:
                 eng.fwd_bwd(plan)
-                dist.all_reduce(eng.grads)                 # sum over ranks: grads + {n_valid, loss_sum} tail
+                reduce_grads()
                 eng.adam_step(plan)
 
+        collective = None
         with torch.cuda.stream(stream):
             for _ in range(3):
                 step_eager()
             stream.synchronize()
             use_graph = not args.no_graph
             group = 1
+            run_steps = None
             if use_graph and not dp:
                 # batch selection runs on the device, so consecutive training steps need no host work at all: `group` whole steps
                 # are captured into one graph (a graph launch costs ~8 us of idle GPU between replays at this step size); any K / W
@@ -358,31 +395,45 @@ def main():
                         g_all.replay()
                     for _ in range(n % group):
                         g_one.replay()
-            elif use_graph and os.environ.get("DR4SR_DP_GRAPH_ALLREDUCE"):
-                # opt-in: the RCCL all-reduce captured INSIDE the step graph (k whole DP steps per replay, no host work between them).
-                # Verified here only with one RCCL rank (DR4SR_BENCH_FORCE_DP); off by default until it has run on a multi-GPU node.
+            elif use_graph and parallel.can_capture() and not os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
+                # DEFAULT data-parallel form: the RCCL all-reduce is captured INSIDE the step graph — k whole DP steps per replay, no
+                # host work between backward, collective and optimizer; as on one GPU the optimizer launch of step j prepares step
+                # j+1 (B <= 1024).  Any capture failure falls through to the host-launched collective below.
                 group = max(1, min(args.steps_per_graph, steps))
+                fuse_prep = args.model == "sasrec" and B <= 1024
 
                 def capture_dp(n):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                        for _ in range(n):
+                        for j in range(n):
                             select()
-                            eng.fwd_bwd(plan)
-                            dist.all_reduce(eng.grads)
-                            eng.adam_step(plan)
+                            if fuse_prep and j > 0:
+                                eng.fwd_bwd_prepared(plan)
+                            else:
+                                eng.fwd_bwd(plan)
+                            reduce_grads()
+                            if fuse_prep and j < n - 1:
+                                eng.adam_step_prepare_next(plan)
+                            else:
+                                eng.adam_step(plan)
                     return g
-                g_all = capture_dp(group)
-                g_one = capture_dp(1) if group > 1 else g_all
+                try:
+                    g_all = capture_dp(group)
+                    g_one = capture_dp(1) if group > 1 else g_all
 
-                def run_steps(n):
-                    for _ in range(n // group):
-                        g_all.replay()
-                    for _ in range(n % group):
-                        g_one.replay()
-            elif use_graph and args.model == "sasrec" and B <= 1024:
-                # two graphs around the all-reduce; the optimizer graph also prepares the next batch, so only the first step of a
-                # run carries its own prep launch
+                    def run_steps(n):
+                        for _ in range(n // group):
+                            g_all.replay()
+                        for _ in range(n % group):
+                            g_one.replay()
+                    collective = "rccl all-reduce captured in the step graph (%d steps per graph)" % group
+                except Exception as e:      # noqa: BLE001
+                    print("bench.py: in-graph all-reduce capture failed (%s: %s); host-launched collective instead" % (type(e).__name__, e),
+                          file=sys.stderr)
+                    run_steps, group = None, 1
+            if run_steps is None and use_graph and dp and args.model == "sasrec" and B <= 1024:
+                # two graphs around a host-launched all-reduce; the optimizer graph also prepares the next batch, so only the first
+                # step of a run carries its own prep launch
                 g_first, g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_first, stream=stream, capture_error_mode="thread_local"):
                     eng.fwd_bwd(plan)
@@ -395,10 +446,11 @@ def main():
                 def run_steps(n):
                     for _ in range(n):
                         (g_a if prepared[0] else g_first).replay()
-                        dist.all_reduce(eng.grads)
+                        reduce_grads()
                         g_b.replay()
                         prepared[0] = True
-            elif use_graph:
+                collective = "%s all-reduce launched by the host between two graphs" % parallel.backend_name()
+            elif run_steps is None and use_graph and dp:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):
                     select()
@@ -409,12 +461,14 @@ def main():
                 def run_steps(n):
                     for _ in range(n):
                         g_a.replay()
-                        dist.all_reduce(eng.grads)
+                        reduce_grads()
                         g_b.replay()
-            else:
+                collective = "%s all-reduce launched by the host between two graphs" % parallel.backend_name()
+            elif run_steps is None:
                 def run_steps(n):
                     for _ in range(n):
                         step_eager()
+                collective = ("%s all-reduce, eager" % parallel.backend_name()) if dp else None
 
             run_steps(warmup)
             stream.synchronize()
@@ -455,7 +509,7 @@ def main():
                 "config": {"workload": "%s, B=%d rows/GPU/step, %s seqlen" %
                                        (model_desc, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
                            "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
-                           "hip_graph": bool(use_graph), "steps_per_graph": group},
+                           "hip_graph": bool(use_graph), "steps_per_graph": group, "collective": collective},
                 "gpu_ms_per_step_events": gpu_ms / steps, "final_loss": loss, "valid_tokens_last_step": T_last,
             }
 
@@ -470,23 +524,30 @@ def main():
                 out["roofline_step"] = {"bound": "mfma", "achieved": (lin + att) / step_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                         "frac": (lin + att) / step_s / 1e12 / MFMA_F32_PEAK_TF, "flops_per_step": lin + att,
                                         "note": "all kernels of the step, last batch's token count"}
-                kinds = ["embed_fwd", "qkv_fwd", "attn_fwd", "post_fwd", "score", "transpose", "post_bwd", "attn_bwd",
-                         "qkv_bwd", "embed_bwd", "wgrad", "zero_grads", "prep", "adam"]
-                per_step_launches = {"qkv_fwd": NL, "attn_fwd": NL, "post_fwd": NL, "post_bwd": NL, "attn_bwd": NL, "qkv_bwd": NL}
+                # the launches dr4sr_sasrec_train_steps really enqueues per step: (kind, layer argument, launches / step).
+                # post_fwd / post_bwd at layer 0 are the fused forms (they carry layer 1's qkv projection / its backward); the last
+                # layer's post_fwd + scorer + post_bwd is ONE launch (post_mid).  In the latency regime (packed tokens <= 16384) the
+                # embedding-stage backward rides in the k_wgrad launch (`wgrad_fused`), above it is a launch of its own.
+                big = B * L > 16384
+                launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1), ("attn_fwd", NL - 1, NL), ("post_fwd", 0, NL - 1),
+                            ("post_mid", 0, 1), ("attn_bwd", NL - 1, NL), ("post_bwd", 0, NL - 1)]
+                launches += ([("qkv_embed_bwd", 0, 1)] if big else []) + [("wgrad_fused", 0, 1), ("adam", 0, 1)]
+                per_step_launches = {k: n for k, _, n in launches}
                 ktime = {}
                 reps = 50
-                for kind in kinds:
+                for kind, layer, _ in launches:
                     kid = _lib.KERNEL_IDS[kind]
                     for _ in range(5):
-                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), kind)
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
                     for _ in range(reps):
-                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, NL - 1, _lib.cur_stream()), kind)
+                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), kind)
                     b.record()
                     b.synchronize()
                     ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
                 step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
+                # the dominant kernel = the kind with the largest share of the step (attention: both layers' launches)
                 dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last) > 0), key=lambda k: step_us[k])
                 fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last)
                 ach = fl / (ktime[dom] * 1e-6) / 1e12
@@ -494,16 +555,25 @@ def main():
                 # gfx950 correction + WRITE_SIZE, separate rocprofv3 runs); only for the workloads that were profiled
                 traffic = None
                 tag = {(256, False): "B256_toys", (8192, False): "B8192_toys", (8192, True): "B8192_dense"}.get((B, bool(args.dense)))
-                pj = os.path.join(ROOT, "profiles", "round1_pmc_traffic_%s.json" % tag) if tag and D == 64 else None
-                if pj and os.path.exists(pj):
-                    pm = json.load(open(pj))
-                    prefix = {"attn_fwd": "k_attn2_fwd", "attn_bwd": "k_attn2_bwd", "post_fwd": "k_post_fwd", "post_bwd": "k_post_bwd",
-                              "qkv_fwd": "k_qkv_fwd", "qkv_bwd": "k_qkv_bwd", "wgrad": "k_wgrad"}[dom]
-                    hits = [v["hbm_bytes_per_launch"] for k, v in pm.items() if k.startswith(prefix)]
-                    traffic = float(sum(hits)) if hits else None
+                traffic_src = None
+                for rnd in (PROFILE_ROUND, PROFILE_ROUND - 1):
+                    pj = os.path.join(ROOT, "profiles", "round%d_pmc_traffic_%s.json" % (rnd, tag)) if tag and D == 64 else None
+                    if pj and os.path.exists(pj):
+                        pm = json.load(open(pj))
+                        prefix = {"attn_fwd": "k_attn", "attn_bwd": "k_attn", "post_fwd": "k_post_fwd", "post_bwd": "k_post_bwd",
+                                  "post_mid": "k_post_mid", "wgrad_fused": "k_wgrad", "embqkv_fwd": "k_embqkv_fwd",
+                                  "qkv_embed_bwd": "k_qkv_embed_bwd"}[dom]
+                        want_bwd = dom == "attn_bwd"
+                        hits = [v["hbm_bytes_per_launch"] for k, v in pm.items()
+                                if k.startswith(prefix) and (not dom.startswith("attn") or (("_bwd" in k) == want_bwd))]
+                        if hits:
+                            traffic, traffic_src = float(sum(hits)), os.path.relpath(pj, ROOT)
+                            break
+                # `traffic` is NOT measured by this run: rocprofv3 --pmc passes cannot run inside the bench; it is the per-launch HBM
+                # byte count of the same kernel on the same workload from the committed PMC profile named in `traffic_source`
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "us_per_launch": ktime[dom],
-                                   "flops_per_launch": fl}
+                                   "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
+                                   "us_per_launch": ktime[dom], "flops_per_launch": fl}
                 # the ragged layout leaves the attention kernels far below the MFMA ridge (157.3 TF / 8 TB/s = 19.7 flop/B): also report
                 # the kernel against the sloped part of the roofline, min(MFMA peak, intensity x HBM peak), from its algorithmic bytes
                 # (forward: q, k, v in + ctx out; backward: q, k, v, dctx in + dq, dk, dv out; 4*D bytes per token each)

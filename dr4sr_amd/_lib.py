@@ -20,7 +20,8 @@ POOL_NONE, POOL_ORIGIN, POOL_LAST, POOL_MEAN = 0, 1, 2, 3
 SITE_EMB, SITE_ATTN, SITE_PROJ, SITE_ACT, SITE_FFN = 0, 1, 2, 3, 4
 
 KERNEL_IDS = {"prep": 0, "embed_fwd": 1, "qkv_fwd": 2, "attn_fwd": 3, "post_fwd": 4, "score": 5, "transpose": 6,
-              "post_bwd": 7, "attn_bwd": 8, "qkv_bwd": 9, "embed_bwd": 10, "wgrad": 11, "adam": 12, "zero_grads": 13}
+              "post_bwd": 7, "attn_bwd": 8, "qkv_bwd": 9, "embed_bwd": 10, "wgrad": 11, "adam": 12, "zero_grads": 13,
+              "embqkv_fwd": 14, "post_mid": 15, "qkv_embed_bwd": 16, "wgrad_fused": 17}
 
 _f32p = C.c_void_p
 _i64p = C.c_void_p
@@ -127,6 +128,7 @@ SYMBOLS = {
     "dr4sr_gru4rec_plan_sizeof": (C.c_int, []),
     "dr4sr_gru4rec_param_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_gru4rec_workspace_bytes": (C.c_int64, [_GPLANP]),
+    "dr4sr_gru4rec_uses_cooperative": (C.c_int, [C.c_int32, C.c_int32]),
     "dr4sr_gru4rec_fwd_bwd": (C.c_int, [_GPLANP, C.c_void_p]),
     "dr4sr_gru4rec_train_step": (C.c_int, [_GPLANP, C.c_void_p]),
     "dr4sr_gru4rec_encode": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),

@@ -459,7 +459,9 @@ static int launch_gru_rec(const GruRecArgs& A, int H, bool bwd, hipStream_t s, u
 }
 
 // tail[0..1] += sum of the scorer's per-sequence (count, loss) partials
-__global__ __launch_bounds__(256) void k_sum_score_part(const float* __restrict__ part, float* __restrict__ tail, int B) {
+// tail[2] += the cooperative recurrence's sticky error word (the optimizer's poison word, csrc/step.hip k_adam)
+__global__ __launch_bounds__(256) void k_sum_score_part(const float* __restrict__ part, float* __restrict__ tail, int B,
+                                                        const int* __restrict__ err_word) {
     __shared__ float red[512];
     float c = 0.f, l = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) { c += part[2 * b]; l += part[2 * b + 1]; }
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void k_sum_score_part(const float* __restrict_
         if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { tail[0] += red[0]; tail[1] += red[256]; }
+    if (threadIdx.x == 0) { tail[0] += red[0]; tail[1] += red[256]; if (err_word && *err_word) tail[2] += 1.0f; }
 }
 
 // ------------------------------------------------------------------------------------------------ orchestration
@@ -530,7 +532,8 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     int gw = ntiles / 16 > 8 ? (ntiles / 16 > 32 ? 32 : ntiles / 16) : 8;
     if (gw > ntiles) gw = ntiles;
     hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
-    if (with_score) hipLaunchKernelGGL(k_sum_score_part, dim3(1), dim3(256), 0, s, ws.score_part, p->grads + ws.n_params, p->B);
+    // with_score == 0 (autograd path): no scorer partials to add, the launch only forwards the recurrence's error word
+    hipLaunchKernelGGL(k_sum_score_part, dim3(1), dim3(256), 0, s, ws.score_part, p->grads + ws.n_params, with_score ? p->B : 0, ws.ctl + 2);
     return DR4SR_LAUNCH_CHECK();
 }
 

@@ -19,6 +19,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
 namespace {
@@ -282,12 +286,34 @@ template <int H> size_t coop_lds(bool bwd) {
 
 }  // namespace
 
+// Workgroups the cooperative recurrence may use on the CURRENT device: every one of them must be resident at once (one per CU,
+// ~140 KB of LDS each), so the budget follows the device's CU count — three quarters of it, at most 192 — instead of assuming a
+// full 256-CU MI355X (a CPX / DPX partition or a smaller part gets a smaller budget or none).  Cached per device.
+static int coop_block_budget() {
+    static int budget[64];
+    static bool known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!known[dev]) {
+        hipDeviceProp_t prop;
+        int b = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            b = (prop.multiProcessorCount * 3) / 4;
+            if (b > 192) b = 192;
+        }
+        budget[dev] = b;
+        known[dev] = true;
+    }
+    return budget[dev];
+}
+
 // granule words needed by the cooperative path for a batch of B sequences (0 = the batch does not qualify)
 int64_t gru_coop_words(int B, int H) {
     const int groups = (B + 15) / 16;
-    if (((groups + 7) / 8) * 8 * NS > 192 || getenv("DR4SR_GRU_NOCOOP")) return 0;
+    if (getenv("DR4SR_GRU_NOCOOP") || ((groups + 7) / 8) * 8 * NS > coop_block_budget()) return 0;
     return (int64_t)groups * 2 * NS * 16 * H;
 }
+extern "C" int dr4sr_gru4rec_uses_cooperative(int32_t B, int32_t H) { return (H == 128 || H == 256) && gru_coop_words(B, H) != 0; }
 
 // returns -100 when the batch does not qualify (caller falls back to the single-workgroup recurrence)
 int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float* r, float* z, float* n, float* ghn, float* hprev,
@@ -299,14 +325,26 @@ int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float*
     A.dhout = dhout; A.dgi = dgi; A.dgh = dgh; A.xch = xch; A.ctl = ctl; A.B = B;
     const int groups = (B + 15) / 16;
     dim3 grid(((groups + 7) / 8) * 8 * NS), blk(H * 2);          // groups rounded up to a multiple of 8 (XCD placement); extra blocks exit
+    // the runtime must be able to place one such workgroup on a CU at all (register / LDS limits of THIS device); asked once per kernel
+    auto resident = [&](const void* k, size_t lds) {
+        static std::unordered_map<const void*, int> okmap;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = okmap.find(k);
+        if (it != okmap.end()) return it->second > 0;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, H * 2, lds) != hipSuccess) nb = 0;
+        okmap[k] = nb;
+        return nb > 0;
+    };
     if (H == 256) {
         const size_t lds = coop_lds<256>(bwd);
-        if (!bwd) { big_lds(k_gru_fwd_coop<256>, lds); hipLaunchKernelGGL(k_gru_fwd_coop<256>, grid, blk, lds, s, A); }
-        else { big_lds(k_gru_bwd_coop<256>, lds); hipLaunchKernelGGL(k_gru_bwd_coop<256>, grid, blk, lds, s, A); }
+        if (!bwd) { big_lds(k_gru_fwd_coop<256>, lds); if (!resident((const void*)k_gru_fwd_coop<256>, lds)) return -100; hipLaunchKernelGGL(k_gru_fwd_coop<256>, grid, blk, lds, s, A); }
+        else { big_lds(k_gru_bwd_coop<256>, lds); if (!resident((const void*)k_gru_bwd_coop<256>, lds)) return -100; hipLaunchKernelGGL(k_gru_bwd_coop<256>, grid, blk, lds, s, A); }
     } else if (H == 128) {
         const size_t lds = coop_lds<128>(bwd);
-        if (!bwd) { big_lds(k_gru_fwd_coop<128>, lds); hipLaunchKernelGGL(k_gru_fwd_coop<128>, grid, blk, lds, s, A); }
-        else { big_lds(k_gru_bwd_coop<128>, lds); hipLaunchKernelGGL(k_gru_bwd_coop<128>, grid, blk, lds, s, A); }
+        if (!bwd) { big_lds(k_gru_fwd_coop<128>, lds); if (!resident((const void*)k_gru_fwd_coop<128>, lds)) return -100; hipLaunchKernelGGL(k_gru_fwd_coop<128>, grid, blk, lds, s, A); }
+        else { big_lds(k_gru_bwd_coop<128>, lds); if (!resident((const void*)k_gru_bwd_coop<128>, lds)) return -100; hipLaunchKernelGGL(k_gru_bwd_coop<128>, grid, blk, lds, s, A); }
     } else return DR4SR_E_SHAPE;
     return DR4SR_LAUNCH_CHECK();
 }

@@ -40,6 +40,11 @@ extern "C" int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t
     return o;
 }
 
+// LDS footprint of the one-wave-per-head VALU attention backward (attn.hip): q|k|v|dctx rows and two score planes per head
+static bool valu_attn_fits(const dr4sr_sasrec_plan* p) {
+    return sizeof(float) * (4LL * p->L * p->D + 2LL * p->H * p->L * (p->L + 1) + p->L) <= 160 * 1024;
+}
+
 // the encoder shapes the kernels are instantiated for (anything else is refused before a workspace is sized or a kernel launched)
 static int check_shape(const dr4sr_sasrec_plan* p) {
     if (p->L > 64) return DR4SR_E_SHAPE;
@@ -47,7 +52,7 @@ static int check_shape(const dr4sr_sasrec_plan* p) {
     if (p->H <= 0 || p->H > 4 || p->D % p->H || (p->D / p->H != 32 && p->D / p->H != 64)) return DR4SR_E_SHAPE;
     // head counts other than 2 run the one-wave-per-head kernels of attn.hip, whose backward keeps q|k|v|dctx and two score
     // planes per head in LDS: reject the shapes that do not fit the 160 KB of a CU instead of failing at the launch
-    if (p->H != 2 && sizeof(float) * (4LL * p->L * p->D + 2LL * p->H * p->L * (p->L + 1) + p->L) > 160 * 1024) return DR4SR_E_SHAPE;
+    if (p->H != 2 && !valu_attn_fits(p)) return DR4SR_E_SHAPE;
     return 0;
 }
 
@@ -118,6 +123,10 @@ static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
 //   g = grad/n_valid + wd*p ; m += (g-m)(1-b1) ; v = b2 v + (1-b2) g^2
 //   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // t = state[STEP]+1; the last block to finish bumps state[STEP] (ticket in state[8]).
+// grads[n + 2] is a POISON word: non-zero means some producer of this gradient failed on the device (today: an exchange timeout of
+// the cooperative GRU recurrence, csrc/gru_coop.hip) — the step is then skipped entirely (parameters, moments and the step counter
+// stay as they were).  It lives in the gradient tail so that a data-parallel sum-all-reduce carries it to every replica and all of
+// them skip the same step.
 // `next` (optional): the launch also prepares the NEXT training step of the same plan — its workgroup 0 runs the prep (batch
 // selection, prefix scan, RNG step), every thread zeroes the gradient words it has consumed and the last workgroup to finish
 // zeroes the {n_valid, loss} tail — so a k-step graph needs one k_prep, not k (a launch boundary + a single-workgroup
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
     const int t = state[DR4SR_STATE_STEP] + 1;
     const float nvalid = G[n];
     const float gs = nvalid > 0.f ? 1.0f / nvalid : 0.f;
+    const bool poisoned = G[n + 2] != 0.f;
     const int nblk = next.enable ? (int)gridDim.x - 1 : (int)gridDim.x, blk = next.enable ? (int)blockIdx.x - 1 : (int)blockIdx.x;
     if (blk < 0) {                                         // dispatched first: the next step's prep (and this step's loss-log entry,
         const float lossv = G[n + 1] * gs;                 //  whose index the prep is about to advance)
@@ -162,6 +172,10 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
         for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n4; i += 2 * stride) {
             const int64_t j = i + stride;
             const bool two = j < n4;
+            if (poisoned) {                                // skipped step: only the next step's zeroed gradient is still owed
+                if (next.enable) { st4(G + 4 * i, z4); if (two) st4(G + 4 * j, z4); }
+                continue;
+            }
             float4 p0 = ld4(P + 4 * i), m0 = ld4(M + 4 * i), v0 = ld4(V + 4 * i);
             const float4 g0 = ld4(G + 4 * i);
             float4 p1 = p0, m1 = m0, v1 = v0, g1 = g0;
@@ -180,7 +194,8 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
     if (threadIdx.x == 0) {                    // no fence needed: the kernel boundary publishes the parameter writes
         const int ticket = atomicAdd(&state[8], 1);
         if (ticket == (int)gridDim.x - 1) {    // every workgroup has read the tail and state[STEP] by now
-            state[8] = 0; state[DR4SR_STATE_STEP] = t;
+            state[8] = 0;
+            if (!poisoned) state[DR4SR_STATE_STEP] = t;
             if (next.enable) { G[n] = 0.f; G[n + 1] = 0.f; G[n + 2] = 0.f; G[n + 3] = 0.f; }
         }
     }
@@ -228,7 +243,7 @@ static int launch_zero_grads(const dr4sr_sasrec_plan* p, int64_t n_params, hipSt
 // MFMA attention needs exactly 2 heads (one wave pair per head); other head counts use the VALU kernels.
 static bool use_mfma_attn(const dr4sr_sasrec_plan* p) {
     static const bool off = getenv("DR4SR_ATTN_VALU") != nullptr;
-    return p->H == 2 && !off;
+    return p->H == 2 && (!off || !valu_attn_fits(p));       // the cross-check switch applies where the VALU kernels can run
 }
 static int attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int training, hipStream_t s) {
     return use_mfma_attn(p) ? launch_attn2_fwd(p, ws, l, training, s) : launch_attn_fwd(p, ws, l, training, s);
@@ -395,6 +410,11 @@ extern "C" int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t
         case DR4SR_K_WGRAD: return launch_wgrad(plan, ws, 1, 1, s);
         case DR4SR_K_ADAM: return launch_adam(plan, s);
         case DR4SR_K_ZERO_GRADS: return launch_zero_grads(plan, ws.n_params, s);
+        // the launches of the FUSED step (what dr4sr_sasrec_train_step really enqueues)
+        case DR4SR_K_EMBQKV_FWD: return launch_embqkv_fwd(plan, ws, 1, s);
+        case DR4SR_K_POST_MID: return launch_post_mid(plan, ws, 1, s);
+        case DR4SR_K_QKV_EMBED_BWD: return launch_qkv_embed_bwd(plan, ws, 1, s);
+        case DR4SR_K_WGRAD_FUSED: return launch_wgrad(plan, ws, 1, 2, s, true);
         default: return DR4SR_E_ARG;
     }
 }

@@ -61,8 +61,9 @@ def write_packed(path: str, arrays: Dict[str, np.ndarray], L: int, src: str) -> 
     os.replace(tmp, path)                      # atomic: concurrent ranks either see the old file or the complete new one
 
 
-def read_packed(path: str, src: str = None) -> Dict[str, np.ndarray]:
-    """memory-map a packed image; returns None if it is missing, malformed or stale w.r.t. `src`"""
+def read_packed(path: str, src: str = None, L: int = None) -> Dict[str, np.ndarray]:
+    """memory-map a packed image; returns None if it is missing, malformed, stale w.r.t. `src`, or was written for another
+    max_seq_len than the `L` asked for (the image is then rebuilt from the .pth, whose rows are checked against L)"""
     try:
         with open(path, "rb") as f:
             hdr = f.read(HEADER)
@@ -70,9 +71,9 @@ def read_packed(path: str, src: str = None) -> Dict[str, np.ndarray]:
         return None
     if len(hdr) < HEADER or hdr[:8] != MAGIC:
         return None
-    ver, L, n, tvec, lvec = struct.unpack("<IIQII", hdr[8:32])
+    ver, hdr_L, n, tvec, lvec = struct.unpack("<IIQII", hdr[8:32])
     size, mtime = struct.unpack("<QQ", hdr[32:48])
-    if ver != 1:
+    if ver != 1 or (L is not None and int(hdr_L) != int(L)):
         return None
     if src is not None:
         try:
@@ -81,7 +82,7 @@ def read_packed(path: str, src: str = None) -> Dict[str, np.ndarray]:
             st = None                            # source gone: the packed image is all there is
         if st is not None and (st.st_size != size or st.st_mtime_ns != mtime):
             return None
-    lay = _layout(n, L, bool(tvec), bool(lvec))
+    lay = _layout(n, hdr_L, bool(tvec), bool(lvec))
     need = HEADER + 4 * sum(int(np.prod(s)) for _, s in lay)
     if os.path.getsize(path) != need:
         return None
@@ -98,7 +99,7 @@ def load_split(pth_path: str, L: int, use_cache: bool = True) -> Dict[str, np.nd
     """arrays of one split: packed image if fresh, else unpickle the reference's .pth (and refresh the image)"""
     pk = pth_path + ".dr4srpk"
     if use_cache:
-        got = read_packed(pk, pth_path)
+        got = read_packed(pk, pth_path, L)
         if got is not None:
             return got
     import torch

@@ -132,6 +132,12 @@ class GruEngine:
             raise _lib.Dr4srError("cooperative GRU recurrence: an exchange wait timed out (workgroups not co-resident?); "
                                   "set DR4SR_GRU_NOCOOP=1 to use the single-workgroup recurrence")
 
+    check_device_error = check_coop
+
+    def uses_cooperative(self, B: int) -> bool:
+        """True when a batch of B sequences runs the multi-CU cooperative recurrence on this device (csrc/gru_coop.hip)"""
+        return bool(self.lib.dr4sr_gru4rec_uses_cooperative(int(B), int(self.H)))
+
     def loss_and_count(self):
         self.check_coop()
         tail = self.grads[self.n_params:self.n_params + 2].tolist()

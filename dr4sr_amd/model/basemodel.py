@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from .. import _lib, evaluation
 from ..data.dataset import BaseDataset, SeparateDataset, SyntheticDataset
+from .. import parallel
 from ..parallel import allreduce_flat, shard_bounds
 from ..utils import callbacks
 from .loss_func import BinaryCrossEntropyLoss, BPRLoss
@@ -142,8 +143,8 @@ class BaseModel(nn.Module):
 
     def _sync_replicas(self):
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.broadcast(self.engine.params, src=0)
+            parallel.init_distributed(self.device)
+            parallel.broadcast(self.engine.params, src=0)
 
     def _get_optimizers(self):
         name = self.config["train"]["optimizer"].lower()
@@ -298,30 +299,56 @@ class BaseModel(nn.Module):
             else:
                 run = eager
         else:
-            import torch.distributed as dist
+            # Data parallel: the sum-all-reduce of the flat gradient sits between backward and optimizer.  With RCCL it is captured
+            # INSIDE the step graph (no host work between the two halves, `group` whole steps per replay, the optimizer launch of
+            # step j preparing step j+1 exactly as on one GPU); a transport that cannot be captured (gloo checks on one GPU) or a
+            # failed capture falls back to two graphs around a host-launched collective.
+            has_prep = perm_sel is not None and hasattr(eng, "fwd_bwd_prepared") and bl <= 1024
 
-            def eager():
-                eng.fwd_bwd(plan)
-                allreduce_flat(eng.grads)                 # RCCL sum: gradients + {n_valid, loss_sum} tail
-                eng.adam_step(plan)
+            def body(reduce):
+                for j in range(group):
+                    if has_prep and j > 0:
+                        eng.fwd_bwd_prepared(plan)
+                    else:
+                        eng.fwd_bwd(plan)
+                    reduce()
+                    if has_prep and j < group - 1:
+                        eng.adam_step_prepare_next(plan)
+                    else:
+                        eng.adam_step(plan)
 
-            def local_only():                             # warm-up must NOT enter a collective: ranks create their graphs at different
-                eng.fwd_bwd(plan)                         # steps (a tail batch gives some ranks a new slice size, others an old or empty one)
-                eng.adam_step(plan)
+            def do_reduce():
+                allreduce_flat(eng.grads)                 # RCCL sum: gradients + {n_valid, loss_sum, poison} tail
+
+            run = None
             if use_graph:
-                warm_up(local_only)
-                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    eng.fwd_bwd(plan)
-                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                    eng.adam_step(plan)
+                # warm-up must NOT enter a collective: ranks create their graphs at different steps (a tail batch gives some ranks a
+                # new slice size, others an old or empty one)
+                warm_up(lambda: body(lambda: None))
+                if parallel.can_capture() and not os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            body(do_reduce)
+                        run = g.replay
+                    except Exception as e:                # noqa: BLE001 — any capture failure: keep training with the split form
+                        self.logger.warning(f"in-graph all-reduce capture failed ({type(e).__name__}: {e}); using host-launched collectives")
+                        run = None
+                if run is None:
+                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                        eng.fwd_bwd(plan)
+                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                        eng.adam_step(plan)
 
-                def run():
-                    ga.replay()
-                    allreduce_flat(eng.grads)
-                    gb.replay()
+                    def run():
+                        for _ in range(group):
+                            ga.replay()
+                            do_reduce()
+                            gb.replay()
             else:
-                run = eager
+                def run():
+                    body(do_reduce)
         self._graphs[key] = (run, plan)
         return self._graphs[key]
 
@@ -330,8 +357,7 @@ class BaseModel(nn.Module):
         B, n, nb = loader.batch_size, loader.n, len(loader)
         perm = loader.permutation()
         if W > 1:
-            import torch.distributed as dist
-            dist.broadcast(perm, src=0)
+            parallel.broadcast(perm, src=0)
         if getattr(self, "_loss_log", None) is None or self._loss_log.shape[0] != nb:
             self._loss_log = torch.empty(nb, dtype=torch.float32, device=self.device)     # persistent: graphs hold its address
         losses = self._loss_log
@@ -343,7 +369,7 @@ class BaseModel(nn.Module):
                 self._perm_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._perm_buf.copy_(perm)
             self._perm_counter.zero_()
-        group = int(self.config["train"].get("steps_per_graph", 4)) if (fused_sel and W == 1) else 1
+        group = int(self.config["train"].get("steps_per_graph", 4)) if fused_sel else 1      # DP: k steps AND their k collectives per graph
         i = 0
         while i < nb:
             lo, hi = shard_bounds(i, B, n, W, r)
@@ -353,10 +379,8 @@ class BaseModel(nn.Module):
                     self._perm_counter.fill_(i)             # a rank whose earlier tail slice was empty re-aligns its batch index
                 sel = (self._perm_buf, B, lo - i * B, self._perm_counter)
                 k = group if (i + group <= nb and shard_bounds(i + group - 1, B, n, W, r)[1] - shard_bounds(i + group - 1, B, n, W, r)[0] == bl) else 1
-                run, _ = self._step_graph(loader.fields, bl, sel, group=k, loss_log=losses if W == 1 else None)
+                run, _ = self._step_graph(loader.fields, bl, sel, group=k, loss_log=losses)      # k_adam logs the (all-reduced) mean loss
                 run()
-                if W > 1:
-                    losses[i] = tail[1] / tail[0]
                 i += k
                 continue
             if bl > 0:
@@ -539,8 +563,7 @@ class BaseModel(nn.Module):
         test_data = self.dataset_list[-1]
         output = defaultdict(float)
         if self.world_size > 1:                            # rank 0 writes the checkpoint at the end of fit(): wait for the file
-            import torch.distributed as dist
-            dist.barrier()
+            parallel.barrier()
         self.load_checkpoint(os.path.join(self.config["eval"]["save_path"], self.ckpt_path))
         self.eval()
         for domain in self.domain_name_list:

@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from .. import parallel
 from ..parallel import allreduce_flat, shard_bounds
 from ..utils.config import get_model_class, load_config
 from .basemodel import BaseModel, normal_initialization
@@ -121,8 +122,7 @@ class MetaModel(BaseModel):
         self.meta_module: nn.Module = self._register_meta_modules()
         self.meta_module.apply(normal_initialization)
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.broadcast(self._phi.params, src=0)
+            parallel.broadcast(self._phi.params, src=0)
         self.meta_optimizer = self._get_meta_optimizers()
         self.metaloader_iter = iter(self.current_epoch_metaloaders(nepoch=0))
         n = self.engine.n_params
@@ -140,7 +140,12 @@ class MetaModel(BaseModel):
         for sec, kv in (self.config["model"].get("sub_overrides") or {}).items():     # extension: e.g. {'model': {'dropout_rate': 0}}
             sub_cfg[sec].update(kv)
         self.logger.info(sub_cfg)
-        return get_model_class(sub_cfg["model"]["model"])(sub_cfg, self.dataset_list)
+        name = sub_cfg["model"]["model"]
+        if name not in ("SASRec", "GRU4Rec", "FMLP"):
+            # the reference also accepts tuple-loss sub-models (metamodel.py:186-192: CL4SRec's (loss, cl_loss)); the weighted
+            # steps here back-propagate the BCE term only, so anything else would silently train a different objective
+            raise NotImplementedError(f"MetaModel sub_model {name!r}: the HIP path implements SASRec, GRU4Rec and FMLP sub-models")
+        return get_model_class(name)(sub_cfg, self.dataset_list)
 
     def _register_meta_modules(self) -> nn.Module:
         D = self.embed_dim
@@ -253,7 +258,8 @@ class MetaModel(BaseModel):
         """SASRec sub-model with d = 64: the weighting runs inside the fused training step (dr4sr_sasrec_fwd_bwd_weighted)"""
         import os
         from .sasrec import SASRec
-        return isinstance(self.sub_model, SASRec) and self.embed_dim == 64 and not os.environ.get("DR4SR_META_DENSE")
+        # exactly SASRec: a subclass with extra loss terms (CL4SRec's contrastive loss) must not take the plain weighted step
+        return type(self.sub_model) is SASRec and self.embed_dim == 64 and not os.environ.get("DR4SR_META_DENSE")
 
     def _fused_weighted(self, batch, gate_in=None, gate_out=None, weight_out=None):
         """un-normalised d/dW of sum_p weight_p loss_p through the 12-launch fused step (no d/dphi: see include/dr4sr_hip.h)"""
@@ -286,8 +292,7 @@ class MetaModel(BaseModel):
     def _perm(self, loader):
         perm = loader.permutation()
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.broadcast(perm, src=0)
+            parallel.broadcast(perm, src=0)
         return perm
 
     def training_epoch(self, nepoch):
@@ -333,7 +338,10 @@ class MetaModel(BaseModel):
         return self._loss_log.clone()
 
     def _meta_step_graph(self, fields, bl, k):
-        key = ("inner", fields["in_item_id"].data_ptr(), bl, k)
+        # every device address the captured plan bakes in is part of the key (the loss log / permutation buffers are re-allocated
+        # when the train split changes size)
+        key = ("inner", fields["in_item_id"].data_ptr(), bl, k, self._loss_log.data_ptr(), self._perm_buf.data_ptr(),
+               self._perm_counter.data_ptr())
         if key in self._graphs:
             return self._graphs[key]
         sub, eng, lib = self.sub_model, self.engine, self.lib

@@ -6,8 +6,23 @@ import os
 from ..utils import get_logger, prepare_datasets, prepare_model
 
 
-def run(config: dict):
+def _shared_stamp(device=None) -> str:
+    """One log / checkpoint stem for the whole job.  EarlyStopping names the best checkpoint after the log file
+    (utils/callbacks.py:18-25 of the reference) and only rank 0 writes it, so under torch.distributed.run every rank must use
+    RANK 0's stamp — a per-process microsecond stamp would make ranks > 0 look for a checkpoint that was never written."""
     stamp = datetime.datetime.now().strftime("%Y-%m-%d-%H-%M-%S-%f")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        from ..parallel import init_distributed
+        init_distributed(device)
+        box = [stamp]
+        dist.broadcast_object_list(box, src=0)
+        stamp = box[0]
+    return stamp
+
+
+def run(config: dict):
+    stamp = _shared_stamp(config["train"].get("device"))
     log_path = f"{config['model']['model']}/{config['data']['dataset']}/{stamp}.log"
     logger = get_logger(log_path)
     logger.info("PID of this process: {}".format(os.getpid()))

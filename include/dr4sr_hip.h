@@ -58,7 +58,8 @@ extern "C" {
  * (names: item_embedding.weight, query_encoder.position_emb.weight,
  *  query_encoder.transformer_layer.layers.{i}.{self_attn.in_proj_weight, ...} — SURVEY.md §8a)
  * The grads buffer has DR4SR_GRAD_TAIL extra floats after n_params:
- *   grads[n_params+0] = number of loss positions (as float), grads[n_params+1] = loss SUM.
+ *   grads[n_params+0] = number of loss positions (as float), grads[n_params+1] = loss SUM,
+ *   grads[n_params+2] = poison word (non-zero: a producer of this gradient failed on the device; the optimizer skips the step).
  * Gradients are accumulated UN-normalised (d loss_sum); dr4sr_adam_step divides by
  * grads[n_params+0], so that under data parallelism ONE sum-all-reduce of the whole buffer yields
  * the reference's global-batch normalisation (loss_func.py:18-19, :29-30). */
@@ -289,6 +290,12 @@ int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_t H, int32_
  * treat non-zero as a failed run. */
 /* bytes, or DR4SR_E_SHAPE unless D = 64, H in {128, 256}, L <= 64 */
 int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan);
+/* 1 when a batch of B sequences takes the cooperative multi-CU recurrence on the CURRENT device (its 8*ceil(B/16) workgroups must be
+ * co-resident: the budget is 3/4 of the device's compute units, at most 192, and 0 under DR4SR_GRU_NOCOOP), 0 for the
+ * single-workgroup recurrence.  A timeout of the cooperative exchange also POISONS the step: the gradient tail word grads[n_params+2]
+ * becomes non-zero and dr4sr_adam_flat / dr4sr_gru4rec_train_step then leave parameters, moments and the step counter untouched
+ * (under data parallelism the all-reduced tail poisons every replica alike). */
+int dr4sr_gru4rec_uses_cooperative(int32_t B, int32_t H);
 int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream);       /* basemodel.py:193-198, un-normalised grads */
 int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream);    /* + dense Adam */
 int dr4sr_gru4rec_encode(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, float* out, void* stream);
@@ -389,8 +396,9 @@ int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, in
 int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
                       const float* lse, const float* scale, float* dxi, float* dxj, void* stream);
 
-/* Measurement hook: enqueue ONE kernel of the training step (on the state the last fwd_bwd left in
- * the workspace) so bench.py can bracket it with HIP events.  Not part of the reference surface. */
+/* ---- TEST / MEASUREMENT HOOKS — not part of the product surface (nothing in dr4sr_amd/ calls them): dr4sr_dropout_mask above
+ * (tests: lets the oracle run with the library's masks) and dr4sr_sasrec_launch_kernel below (bench.py: enqueues ONE kernel of the
+ * training step, on the state the last fwd_bwd left in the workspace, so that it can be bracketed with HIP events). ---- */
 #define DR4SR_K_PREP       0
 #define DR4SR_K_EMBED_FWD  1
 #define DR4SR_K_QKV_FWD    2
@@ -405,6 +413,13 @@ int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, in
 #define DR4SR_K_WGRAD      11
 #define DR4SR_K_ADAM       12
 #define DR4SR_K_ZERO_GRADS 13
+/* launches of the fused step (dr4sr_sasrec_train_step): gather + qkv of layer 0; post_fwd + scorer + post_bwd of the last layer;
+ * qkv backward of layer 0 + table scatter; weight gradients with the step's extra planes / jobs.  (DR4SR_K_POST_FWD / _BWD with a
+ * layer below the last one already are the fused forms: they carry the next layer's qkv projection / its backward.) */
+#define DR4SR_K_EMBQKV_FWD     14
+#define DR4SR_K_POST_MID       15
+#define DR4SR_K_QKV_EMBED_BWD  16
+#define DR4SR_K_WGRAD_FUSED    17
 int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, int32_t layer, void* stream);
 
 #ifdef __cplusplus

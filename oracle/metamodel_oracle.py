@@ -56,6 +56,28 @@ def sasrec_losses(cfg) -> Callable:
     return f
 
 
+def gru4rec_losses(n_layer: int) -> Callable:
+    """f(p, batch, reduce) for a GRU4Rec sub-model (model/gru4rec.py:12-34, 'origin' pooling, dropout 0); the scorer is
+    BaseModel.training_step's (basemodel.py:204-214), shared by every sub-model"""
+    from . import gru4rec_oracle as go
+
+    def f(p, batch, reduce):
+        q = go.gru4rec_encode(p, batch["in_item_id"], batch["seqlen"], n_layer, "origin")
+        loss, _, _ = so.score_bce(q, p["item_embedding.weight"], batch["item_id"], batch["neg_item"], reduce)
+        return loss, q
+    return f
+
+
+def fmlp_losses(n_layer: int, eps: float = 1e-12) -> Callable:
+    """f(p, batch, reduce) for an FMLP sub-model (model/fmlp.py:18-39: one query per prefix row, scalar target, dropout 0)"""
+    from . import fmlp_oracle as fo
+
+    def f(p, batch, reduce):
+        loss, q, _, _ = fo.training_step(p, batch, n_layer, eps, reduce=reduce)
+        return loss, q
+    return f
+
+
 def train_loss(f, p, meta, bt, gumbel, tau, tau_min, relu_gate=None):
     lp, q = f(p, bt, False)
     return weighted_loss(lp, q, meta, gumbel, tau, tau_min, bt["user_id"], bt["item_id"], relu_gate)[0]

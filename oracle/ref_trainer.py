@@ -105,10 +105,15 @@ class RefLikeSASRec(nn.Module):
 
 
 def time_training(rows: dict, n_items: int, batch_size=256, warmup=3, max_steps=60, max_seconds=25.0, anomaly=True,
-                  seed=2023, p=0.5):
-    """seq/s of the reference-equivalent CPU step (batch build + neg sampling + fwd + bwd + Adam)."""
+                  seed=2023, p=0.5, threads=None):
+    """seq/s of the reference-equivalent CPU step (batch build + neg sampling + fwd + bwd + Adam).
+    threads: torch intra-op threads for this run (None = leave as is); the reference sets nothing, i.e. torch's default = all
+    cores, which on a 128-core host is slower than 8-32 threads for these microsecond-sized ops — bench.py sweeps and reports."""
     torch.manual_seed(seed)
     prev = torch.is_anomaly_enabled()
+    prev_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(int(threads))
     torch.autograd.set_detect_anomaly(anomaly)
     try:
         model = RefLikeSASRec(n_items, p=p)
@@ -139,3 +144,4 @@ def time_training(rows: dict, n_items: int, batch_size=256, warmup=3, max_steps=
                             "threads": torch.get_num_threads(), "anomaly": anomaly}
     finally:
         torch.autograd.set_detect_anomaly(prev)
+        torch.set_num_threads(prev_threads)

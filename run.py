@@ -13,7 +13,7 @@ if __name__ == "__main__":
     config = load_config(config)
     setup_environment(config["train"])
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
+        from dr4sr_amd.parallel import init_distributed
         torch.cuda.set_device(config["train"]["device"])
-        dist.init_process_group("nccl", device_id=torch.device(config["train"]["device"]))
+        init_distributed(config["train"]["device"])
     quickstart.run(config)
