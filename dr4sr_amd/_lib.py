@@ -115,6 +115,10 @@ SYMBOLS = {
     "dr4sr_embed_gather_posadd": (C.c_int, [_f32p, _f32p, _i64p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_score_bce_fwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_score_bce_bwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_score_bpr_fwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_score_bpr_bwd": (C.c_int, [_f32p, _f32p, _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_loss_from_scores_fwd": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, _f32p, _f32p, C.c_void_p]),
+    "dr4sr_loss_from_scores_bwd": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_neg_sample": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p]),
     "dr4sr_neg_sample_dev": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "dr4sr_dropout_mask": (C.c_int, [_f32p, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
@@ -156,6 +160,8 @@ SYMBOLS = {
     "dr4sr_infonce_bwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_full_score_topk_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "dr4sr_full_score_topk_masked_ws": (C.c_int, [_f32p, _f32p, _i64p, C.c_void_p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                  C.c_int32, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_full_score_topk_ws": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            _f32p, C.c_int64, C.c_void_p]),
 }

@@ -138,8 +138,10 @@ int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStre
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense API scorer (query [B,L,D]); one wave per position.
-template <int D>
+// Dense API scorer (query [B,L,D]); one wave per position.  BPR = false: BinaryCrossEntropyLoss (loss_func.py:9-38, masked
+// branch): -logsigmoid(pos) + softplus(neg);  BPR = true: BPRLoss (loss_func.py:40-48, K = 1 so softmax(ones) = 1):
+// -logsigmoid(pos - neg) = softplus(neg - pos).
+template <int D, bool BPR>
 __global__ __launch_bounds__(256) void k_score_dense_fwd(const float* __restrict__ Q, const float* __restrict__ E,
                                                          const int64_t* __restrict__ target, const int64_t* __restrict__ neg,
                                                          float* __restrict__ pos_score, float* __restrict__ neg_score,
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_score_dense_fwd(const float* __restrict
         sp = wave_sum(sp);
         sn = wave_sum(sn);
         const bool pad = tgt == 0;
-        const float lp = pad ? 0.f : softplus_f(-sp) + softplus_f(sn);
+        const float lp = pad ? 0.f : (BPR ? softplus_f(sn - sp) : softplus_f(-sp) + softplus_f(sn));
         if (lane == 0) {
             if (pos_score) pos_score[i] = pad ? -INFINITY : sp;
             if (neg_score) neg_score[i] = sn;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_score_dense_fwd(const float* __restrict
     }
 }
 
-template <int D>
+template <int D, bool BPR>
 __global__ __launch_bounds__(256) void k_score_dense_bwd(const float* __restrict__ Q, const float* __restrict__ E,
                                                          const int64_t* __restrict__ target, const int64_t* __restrict__ neg,
                                                          const float* __restrict__ wgt, const float* __restrict__ scale,
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(256) void k_score_dense_bwd(const float* __restrict
         sp = wave_sum(sp);
         sn = wave_sum(sn);
         const float up = sc * (wgt ? wgt[i] : 1.f);
-        const float dpos = -sigmoid_f(-sp) * up, dneg = sigmoid_f(sn) * up;
+        const float dneg = (BPR ? sigmoid_f(sn - sp) : sigmoid_f(sn)) * up;
+        const float dpos = BPR ? -dneg : -sigmoid_f(-sp) * up;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             dQ[i * D + lane + 64 * j] = dpos * ep[j] + dneg * en[j];
@@ -218,9 +221,10 @@ __global__ __launch_bounds__(256) void k_score_dense_bwd(const float* __restrict
     }
 }
 
-extern "C" int dr4sr_score_bce_fwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
-                                   float* pos_score, float* neg_score, float* loss_pos, float* stats, int64_t B,
-                                   int32_t L, int32_t D, void* stream) {
+template <bool BPR>
+static int score_dense_fwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                           float* pos_score, float* neg_score, float* loss_pos, float* stats, int64_t B,
+                           int32_t L, int32_t D, void* stream) {
     if (!query || !E || !target || !neg || B < 0 || L <= 0) return DR4SR_E_ARG;
     if (D != 64 && D != 128) return DR4SR_E_SHAPE;
     const int64_t npos = B * L;
@@ -228,14 +232,25 @@ extern "C" int dr4sr_score_bce_fwd(const float* query, const float* E, const int
     int64_t blocks = (npos + 3) / 4;
     if (blocks > 512) blocks = 512;
     hipStream_t s = (hipStream_t)stream;
-    if (D == 64) hipLaunchKernelGGL(k_score_dense_fwd<64>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
-    else hipLaunchKernelGGL(k_score_dense_fwd<128>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
+    if (D == 64) hipLaunchKernelGGL((k_score_dense_fwd<64, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
+    else hipLaunchKernelGGL((k_score_dense_fwd<128, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, pos_score, neg_score, loss_pos, stats, npos);
     return DR4SR_LAUNCH_CHECK();
 }
+extern "C" int dr4sr_score_bce_fwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                                   float* pos_score, float* neg_score, float* loss_pos, float* stats, int64_t B,
+                                   int32_t L, int32_t D, void* stream) {
+    return score_dense_fwd<false>(query, E, target, neg, pos_score, neg_score, loss_pos, stats, B, L, D, stream);
+}
+extern "C" int dr4sr_score_bpr_fwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                                   float* pos_score, float* neg_score, float* loss_pos, float* stats, int64_t B,
+                                   int32_t L, int32_t D, void* stream) {
+    return score_dense_fwd<true>(query, E, target, neg, pos_score, neg_score, loss_pos, stats, B, L, D, stream);
+}
 
-extern "C" int dr4sr_score_bce_bwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
-                                   const float* w, const float* scale, float* d_query, float* dE, int64_t B, int32_t L,
-                                   int32_t D, void* stream) {
+template <bool BPR>
+static int score_dense_bwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                           const float* w, const float* scale, float* d_query, float* dE, int64_t B, int32_t L,
+                           int32_t D, void* stream) {
     if (!query || !E || !target || !neg || !d_query || B < 0 || L <= 0) return DR4SR_E_ARG;
     if (D != 64 && D != 128) return DR4SR_E_SHAPE;
     const int64_t npos = B * L;
@@ -243,7 +258,84 @@ extern "C" int dr4sr_score_bce_bwd(const float* query, const float* E, const int
     int64_t blocks = (npos + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
-    if (D == 64) hipLaunchKernelGGL(k_score_dense_bwd<64>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
-    else hipLaunchKernelGGL(k_score_dense_bwd<128>, dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
+    if (D == 64) hipLaunchKernelGGL((k_score_dense_bwd<64, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
+    else hipLaunchKernelGGL((k_score_dense_bwd<128, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
+    return DR4SR_LAUNCH_CHECK();
+}
+extern "C" int dr4sr_score_bce_bwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                                   const float* w, const float* scale, float* d_query, float* dE, int64_t B, int32_t L,
+                                   int32_t D, void* stream) {
+    return score_dense_bwd<false>(query, E, target, neg, w, scale, d_query, dE, B, L, D, stream);
+}
+extern "C" int dr4sr_score_bpr_bwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
+                                   const float* w, const float* scale, float* d_query, float* dE, int64_t B, int32_t L,
+                                   int32_t D, void* stream) {
+    return score_dense_bwd<true>(query, E, target, neg, w, scale, d_query, dE, B, L, D, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The two loss modules on SCORE tensors (model/loss_func.py called directly, outside training_step): pos [n] (-inf = padded
+// position), neg [n, K].  kind 0 = BinaryCrossEntropyLoss.forward, masked branch (:26-31): -logsigmoid(pos) + sum_k softplus(neg_k)/K;
+// kind 1 = BPRLoss.forward (:44-49): -sum_k logsigmoid(pos - neg_k) * softmax(ones)_k = sum_k softplus(neg_k - pos) / K.
+// loss_pos [n] UN-normalised per position (0 at padded positions); stats[0] += #valid, stats[1] += sum.  Backward: upstream
+// g[n] per position (NULL = 1) times *scale (NULL = 1): d_pos [n], d_neg [n, K] written.
+__global__ __launch_bounds__(256) void k_loss_scores_fwd(const float* __restrict__ pos, const float* __restrict__ neg, int K, int kind,
+                                                         float* __restrict__ loss_pos, float* __restrict__ stats, int64_t n) {
+    float lsum = 0.f, cnt = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float sp = pos[i];
+        const bool pad = isinf(sp);
+        float l = 0.f;
+        if (!pad) {
+            float a = 0.f;
+            for (int k = 0; k < K; ++k) a += kind ? softplus_f(neg[i * K + k] - sp) : softplus_f(neg[i * K + k]);
+            l = a / (float)K + (kind ? 0.f : softplus_f(-sp));
+            lsum += l; cnt += 1.f;
+        }
+        if (loss_pos) loss_pos[i] = l;
+    }
+    __shared__ float red[8];
+    lsum = wave_sum(lsum); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = cnt; red[2 * (threadIdx.x >> 6) + 1] = lsum; }
+    __syncthreads();
+    if (stats && threadIdx.x == 0) {
+        const float c = (red[0] + red[2]) + (red[4] + red[6]), l = (red[1] + red[3]) + (red[5] + red[7]);
+        if (c > 0.f) { unsafeAtomicAdd(stats + 0, c); unsafeAtomicAdd(stats + 1, l); }
+    }
+}
+__global__ __launch_bounds__(256) void k_loss_scores_bwd(const float* __restrict__ pos, const float* __restrict__ neg, int K, int kind,
+                                                         const float* __restrict__ g, const float* __restrict__ scale,
+                                                         float* __restrict__ d_pos, float* __restrict__ d_neg, int64_t n) {
+    const float sc = scale ? *scale : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float sp = pos[i];
+        const bool pad = isinf(sp);
+        const float up = pad ? 0.f : sc * (g ? g[i] : 1.f);
+        float dp = (kind || pad) ? 0.f : -sigmoid_f(-sp) * up;
+        for (int k = 0; k < K; ++k) {
+            const float x = neg[i * K + k];
+            const float dn = pad ? 0.f : (kind ? sigmoid_f(x - sp) : sigmoid_f(x)) * up / (float)K;
+            d_neg[i * K + k] = dn;
+            if (kind) dp -= dn;
+        }
+        d_pos[i] = dp;
+    }
+}
+extern "C" int dr4sr_loss_from_scores_fwd(const float* pos, const float* neg, int64_t n, int32_t K, int32_t kind, float* loss_pos,
+                                          float* stats, void* stream) {
+    if (!pos || !neg || n < 0 || K <= 0 || kind < 0 || kind > 1) return DR4SR_E_ARG;
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_loss_scores_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos, neg, K, kind, loss_pos, stats, n);
+    return DR4SR_LAUNCH_CHECK();
+}
+extern "C" int dr4sr_loss_from_scores_bwd(const float* pos, const float* neg, int64_t n, int32_t K, int32_t kind, const float* g,
+                                          const float* scale, float* d_pos, float* d_neg, void* stream) {
+    if (!pos || !neg || !d_pos || !d_neg || n < 0 || K <= 0 || kind < 0 || kind > 1) return DR4SR_E_ARG;
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_loss_scores_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos, neg, K, kind, g, scale, d_pos, d_neg, n);
     return DR4SR_LAUNCH_CHECK();
 }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ Q, const
 // ------------------------------------------------------------------------------------------------ two-phase path
 template <int D>
 __global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Q, const float* __restrict__ E, float* __restrict__ S,
-                                                    int B, int n_items, int lds_s) {
+                                                    int B, int n_items, int lds_s, const uint8_t* __restrict__ blocked) {
     constexpr int LD = D + 1;                              // odd stride: the 32 lanes of an MFMA operand read 32 different rows
     float* Qs = smem;                                      // [64][LD]
     float* Es = smem + 64 * LD;                            // [64][LD]
@@ -105,10 +105,12 @@ __global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Q,
 #pragma unroll 8
     for (int sidx = 0; sidx < D / 2; ++sidx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sidx], bp[2 * sidx], acc, 0, 0, 0);
     const int n = n0 + ct * 32 + r;
+    // basemodel.py:358-360: every item outside the evaluated domain (PAD column 0 is never in a domain's item list) -> -inf
+    const bool off = n == 0 || n >= n_items || (blocked && blocked[n]);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int b = b0 + rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-        if (b < B && n < lds_s) __builtin_nontemporal_store(n == 0 || n >= n_items ? -INFINITY : acc[e], S + (size_t)b * lds_s + n);
+        if (b < B && n < lds_s) __builtin_nontemporal_store(off ? -INFINITY : acc[e], S + (size_t)b * lds_s + n);
     }
 }
 
@@ -275,9 +277,9 @@ extern "C" int64_t dr4sr_full_score_topk_workspace_bytes(int64_t B, int32_t n_it
     return B * (int64_t)((n_items + 63) / 64 * 64) * 4;
 }
 
-extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const int64_t* hist, float* out_score, int64_t* out_item,
-                                        int64_t B, int32_t D, int32_t n_items, int32_t Lh, int32_t k, float* workspace,
-                                        int64_t workspace_bytes, void* stream) {
+static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, const uint8_t* blocked, float* out_score, int64_t* out_item,
+                        int64_t B, int32_t D, int32_t n_items, int32_t Lh, int32_t k, float* workspace,
+                        int64_t workspace_bytes, void* stream) {
     if (!q || !E || !out_score || !out_item || !workspace || B < 0 || n_items < 2 || k <= 0 || k > 128 || Lh < 0 || (Lh > 0 && !hist))
         return DR4SR_E_ARG;
     if (D != 64 && D != 128) return DR4SR_E_SHAPE;
@@ -291,8 +293,8 @@ extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const in
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(lds_s / 64, (unsigned)((B + 63) / 64));
     const size_t lds_g = sizeof(float) * 2 * 64 * (D + 1);
-    if (D == 64) hipLaunchKernelGGL(k_score_gemm<64>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s);
-    else { big_lds(k_score_gemm<128>, lds_g); hipLaunchKernelGGL(k_score_gemm<128>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s); }
+    if (D == 64) hipLaunchKernelGGL(k_score_gemm<64>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s, blocked);
+    else { big_lds(k_score_gemm<128>, lds_g); hipLaunchKernelGGL(k_score_gemm<128>, grid, dim3(256), lds_g, s, q, E, workspace, (int)B, n_items, lds_s, blocked); }
     if (ldsrow) {
         big_lds(k_topk_select<true>, lds_row);
         hipLaunchKernelGGL(k_topk_select<true>, dim3((unsigned)B), dim3(256), lds_row, s, workspace, hist, out_score, out_item, n_items, lds_s, Lh, k);
@@ -300,6 +302,17 @@ extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const in
         hipLaunchKernelGGL(k_topk_select<false>, dim3((unsigned)B), dim3(256), lds_fix, s, workspace, hist, out_score, out_item, n_items, lds_s, Lh, k);
     }
     return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_full_score_topk_ws(const float* q, const float* E, const int64_t* hist, float* out_score, int64_t* out_item,
+                                        int64_t B, int32_t D, int32_t n_items, int32_t Lh, int32_t k, float* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    return topk_ws_impl(q, E, hist, nullptr, out_score, out_item, B, D, n_items, Lh, k, workspace, workspace_bytes, stream);
+}
+extern "C" int dr4sr_full_score_topk_masked_ws(const float* q, const float* E, const int64_t* hist, const uint8_t* item_blocked,
+                                               float* out_score, int64_t* out_item, int64_t B, int32_t D, int32_t n_items, int32_t Lh,
+                                               int32_t k, float* workspace, int64_t workspace_bytes, void* stream) {
+    return topk_ws_impl(q, E, hist, item_blocked, out_score, out_item, B, D, n_items, Lh, k, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dr4sr_full_score_topk(const float* q, const float* E, const int64_t* hist, float* out_score,

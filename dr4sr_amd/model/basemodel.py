@@ -65,19 +65,22 @@ class FusedAdam:
 
 
 class _ScoreBCE(torch.autograd.Function):
-    """basemodel.py:204-214 + loss_func.py:9-38 on the dense query through dr4sr_score_bce_fwd/bwd."""
+    """basemodel.py:204-214 + the configured loss (loss_func.py:9-38 BCE, :40-48 BPR) on the dense query through
+    dr4sr_score_bce_fwd/bwd resp. dr4sr_score_bpr_fwd/bwd."""
 
     @staticmethod
     def forward(ctx, model, query, table, target, neg, reduce):
         lib, eng = model.engine.lib, model.engine
+        bpr = isinstance(model.loss_fn, BPRLoss)
+        ctx.fns = (lib.dr4sr_score_bpr_fwd, lib.dr4sr_score_bpr_bwd) if bpr else (lib.dr4sr_score_bce_fwd, lib.dr4sr_score_bce_bwd)
         B = target.shape[0]
         L = target.shape[1] if target.dim() == 2 else 1
         q = query.contiguous()
         tgt, ng = target.contiguous().view(-1), neg.contiguous().view(-1)
         lp = torch.empty(B * L, dtype=torch.float32, device=q.device)
         stats = torch.zeros(2, dtype=torch.float32, device=q.device)
-        _lib.check(lib.dr4sr_score_bce_fwd(_lib.ptr(q), _lib.ptr(table), _lib.ptr(tgt), _lib.ptr(ng), None, None,
-                                           _lib.ptr(lp), _lib.ptr(stats), B, L, eng.D, _lib.cur_stream()), "score_bce_fwd")
+        _lib.check(ctx.fns[0](_lib.ptr(q), _lib.ptr(table), _lib.ptr(tgt), _lib.ptr(ng), None, None,
+                              _lib.ptr(lp), _lib.ptr(stats), B, L, eng.D, _lib.cur_stream()), "score_loss_fwd")
         ctx.model, ctx.reduce, ctx.shape = model, reduce, (B, L)
         ctx.save_for_backward(q, table, tgt, ng, stats)
         if reduce:
@@ -96,9 +99,9 @@ class _ScoreBCE(torch.autograd.Function):
         else:
             w, scale = gout.contiguous().view(-1).float(), (1.0 / stats[0]).reshape(1).contiguous()
         dE = eng.grad_views["item_embedding.weight"]
-        _lib.check(lib.dr4sr_score_bce_bwd(_lib.ptr(q), _lib.ptr(table), _lib.ptr(tgt), _lib.ptr(ng), _lib.ptr(w),
-                                           _lib.ptr(scale), _lib.ptr(dq), _lib.ptr(dE), B, L, eng.D, _lib.cur_stream()),
-                   "score_bce_bwd")
+        _lib.check(ctx.fns[1](_lib.ptr(q), _lib.ptr(table), _lib.ptr(tgt), _lib.ptr(ng), _lib.ptr(w),
+                              _lib.ptr(scale), _lib.ptr(dq), _lib.ptr(dE), B, L, eng.D, _lib.cur_stream()),
+                   "score_loss_bwd")
         return None, dq, None, None, None, None
 
 
@@ -161,6 +164,7 @@ class BaseModel(nn.Module):
             return BinaryCrossEntropyLoss()
         if name == "bpr":
             return BPRLoss()
+        raise NotImplementedError(f"loss_fn '{name}': 'bce' and 'bpr' (basemodel.py:100-104)")
 
     # ------------------------------------------------------------------------------------------ sampling / steps
     def _neg_sampling(self, batch):
@@ -187,7 +191,11 @@ class BaseModel(nn.Module):
         raise NotImplementedError
 
     def training_step(self, batch, reduce=True, return_query=False):
-        if not isinstance(self.loss_fn, BinaryCrossEntropyLoss):
+        """basemodel.py:204-214.  loss_fn 'bpr': the reference calls self.loss_fn(pos, neg, reduce=reduce) and BPRLoss.forward has
+        no such parameter (loss_func.py:44), i.e. it raises TypeError for every call; here the scalar BPR loss (what BPRLoss.forward
+        computes, loss_func.py:45-49) is produced for reduce=True, and reduce=False — which has no BPR definition in the reference —
+        keeps the reference's TypeError."""
+        if isinstance(self.loss_fn, BPRLoss) and not reduce:
             raise TypeError("BPRLoss.forward() got an unexpected keyword argument 'reduce'")   # as the reference would
         query = self.forward(batch)
         loss = _ScoreBCE.apply(self, query, self.item_embedding.weight, batch[self.fiid], batch["neg_item"], reduce)
@@ -537,9 +545,7 @@ class BaseModel(nn.Module):
 
     def topk(self, batch, k, user_h=None):
         """full-item scores with PAD + history masked, top-k — basemodel.py:354-365 via dr4sr_full_score_topk"""
-        items = self.domain_item_mapping[self.eval_domain]
-        if len(items) != self.num_items - 1:
-            raise NotImplementedError("multi-domain item masks are outside the HIP hot path (single-domain configs only)")
+        blocked = self._domain_blocked(self.eval_domain)        # basemodel.py:358-360 domain_mask (None: every item 1..N-1 is in the domain)
         query = self.forward(batch).contiguous()
         B = query.shape[0]
         hist = user_h.contiguous() if user_h is not None else None
@@ -550,11 +556,25 @@ class BaseModel(nn.Module):
         ws = getattr(self, "_topk_ws", None)
         if ws is None or ws.numel() * 4 < need:
             ws = self._topk_ws = torch.empty(need // 4, dtype=torch.float32, device=query.device)
-        _lib.check(eng.lib.dr4sr_full_score_topk_ws(_lib.ptr(query), _lib.ptr(self.item_embedding.weight), _lib.ptr(hist),
-                                                    _lib.ptr(score), _lib.ptr(ids), B, eng.D, self.num_items,
-                                                    hist.shape[1] if hist is not None else 0, k, _lib.ptr(ws), ws.numel() * 4,
-                                                    _lib.cur_stream()), "topk")
+        _lib.check(eng.lib.dr4sr_full_score_topk_masked_ws(_lib.ptr(query), _lib.ptr(self.item_embedding.weight), _lib.ptr(hist),
+                                                           _lib.ptr(blocked), _lib.ptr(score), _lib.ptr(ids), B, eng.D, self.num_items,
+                                                           hist.shape[1] if hist is not None else 0, k, _lib.ptr(ws), ws.numel() * 4,
+                                                           _lib.cur_stream()), "topk")
         return score, ids
+
+    def _domain_blocked(self, domain):
+        """uint8 [num_items], 1 = item outside `domain` (device tensor, cached per domain); None when the domain holds every item"""
+        cache = self.__dict__.setdefault("_blocked_cache", {})
+        if domain not in cache:
+            items = torch.as_tensor(self.domain_item_mapping[domain], dtype=torch.int64)
+            items = items[(items > 0) & (items < self.num_items)].unique()
+            if int(items.numel()) == self.num_items - 1:
+                cache[domain] = None
+            else:
+                m = torch.ones(self.num_items, dtype=torch.uint8)
+                m[items] = 0
+                cache[domain] = m.to(self.device)
+        return cache[domain]
 
     def set_eval_domain(self, domain):
         self.eval_domain = domain

@@ -183,6 +183,23 @@ int dr4sr_score_bce_bwd(const float* query, const float* E, const int64_t* targe
                         const int64_t* neg, const float* w, const float* scale, float* d_query,
                         float* dE, int64_t B, int32_t L, int32_t D, void* stream);
 
+/* a8: the same two entry points for BPRLoss (loss_func.py:40-48; selected by loss_fn: 'bpr', basemodel.py:103-104): per position
+ * -logsigmoid(pos - neg) (K = 1: softmax(ones) = 1), same masks, same outputs, same normalisation contract (stats / upstream w). */
+int dr4sr_score_bpr_fwd(const float* query, const float* E, const int64_t* target,
+                        const int64_t* neg, float* pos_score, float* neg_score, float* loss_pos,
+                        float* stats, int64_t B, int32_t L, int32_t D, void* stream);
+int dr4sr_score_bpr_bwd(const float* query, const float* E, const int64_t* target,
+                        const int64_t* neg, const float* w, const float* scale, float* d_query,
+                        float* dE, int64_t B, int32_t L, int32_t D, void* stream);
+/* The loss modules called on SCORE tensors (model/loss_func.py used outside training_step): pos [n] (-inf marks a padded position),
+ * neg [n,K].  kind 0: BinaryCrossEntropyLoss.forward masked branch (:12-31) -logsigmoid(pos) + sum_k softplus(neg_k)/K;
+ * kind 1: BPRLoss.forward (:44-49) -sum_k logsigmoid(pos - neg_k)/K.  loss_pos [n] per position UN-normalised (0 at padded
+ * positions, NULL ok); stats[0] += #valid, stats[1] += loss sum.  Backward: upstream g[n] (NULL = 1) times *scale (NULL = 1). */
+int dr4sr_loss_from_scores_fwd(const float* pos, const float* neg, int64_t n, int32_t K, int32_t kind, float* loss_pos,
+                               float* stats, void* stream);
+int dr4sr_loss_from_scores_bwd(const float* pos, const float* neg, int64_t n, int32_t K, int32_t kind, const float* g,
+                               const float* scale, float* d_pos, float* d_neg, void* stream);
+
 /* K0: _neg_sampling (basemodel.py:50-61): uniform on 1..n_items-1 with replacement, never PAD.
  * out [n] int64.  Stream (seed, step) is the one dr4sr_sasrec_fwd_bwd uses for sample_neg=1. */
 int dr4sr_neg_sample(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, uint32_t step,
@@ -209,6 +226,12 @@ int64_t dr4sr_full_score_topk_workspace_bytes(int64_t B, int32_t n_items);
 int dr4sr_full_score_topk_ws(const float* q, const float* E, const int64_t* hist, float* out_score, int64_t* out_item, int64_t B,
                              int32_t D, int32_t n_items, int32_t Lh, int32_t k, float* workspace, int64_t workspace_bytes,
                              void* stream);
+
+/* the multi-domain form of basemodel.py:354-365: item_blocked [n_items] bytes, 1 = the item is NOT in domain_item_mapping[eval_domain]
+ * (its score becomes -inf exactly like the reference's domain_mask, :358-360); NULL = single domain (only PAD is blocked). */
+int dr4sr_full_score_topk_masked_ws(const float* q, const float* E, const int64_t* hist, const uint8_t* item_blocked,
+                                    float* out_score, int64_t* out_item, int64_t B, int32_t D, int32_t n_items, int32_t Lh,
+                                    int32_t k, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FMLP (model/fmlp.py:18-39, module/layers.py:740-807): embedding + position -> LayerNorm -> dropout ->

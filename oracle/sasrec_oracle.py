@@ -128,6 +128,35 @@ def score_bce(query, E, target, neg, reduce=True):
     return loss, pos, ng
 
 
+def bce_from_scores(pos, neg, reduce=True):
+    """BinaryCrossEntropyLoss.forward (loss_func.py:9-38), masked branch, on score tensors: pos [...] with -inf at padded positions,
+    neg [..., K] weighted 1/K (_cal_weight :40-41)."""
+    pad = torch.isinf(pos)
+    n = (~pad).sum()
+    pos_l = F.logsigmoid(pos).masked_fill(pad, 0.0)
+    neg_l = (F.softplus(neg) / neg.shape[-1]).sum(-1).masked_fill(pad, 0.0)
+    if reduce:
+        return -pos_l.sum() / n + neg_l.sum() / n
+    return -pos_l / n + neg_l / n
+
+
+def bpr_from_scores(pos, neg):
+    """BPRLoss.forward (loss_func.py:44-49): -sum_k logsigmoid(pos - neg_k) * softmax(ones)_k summed over unpadded positions / their
+    count.  No `reduce` parameter exists (loss_func.py:44)."""
+    pad = torch.isinf(pos)
+    d = torch.where(pad.unsqueeze(-1), torch.zeros_like(neg), pos.masked_fill(pad, 0.0).unsqueeze(-1) - neg)
+    l = F.logsigmoid(d).masked_fill(pad.unsqueeze(-1), 0.0)
+    return -(l / neg.shape[-1]).sum(-1).sum() / (~pad).sum()
+
+
+def score_bpr(query, E, target, neg):
+    """BaseModel.training_step scorer (basemodel.py:204-208) + BPRLoss (loss_func.py:44-49).  Returns (loss, pos, neg scores)."""
+    pos = (query * E[target]).sum(-1)
+    ng = (query.unsqueeze(-2) * E[neg]).sum(-1)
+    pos = pos.masked_fill(target == 0, float("-inf"))
+    return bpr_from_scores(pos, ng), pos, ng
+
+
 def adam_step(params, grads, m, v, t: int, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
     """torch.optim.Adam single-tensor formula (basemodel.py:86, :199; L2 weight_decay folded into g)."""
     out = {}
@@ -180,18 +209,21 @@ def neg_sample_reference_like(B, L, N, generator=None, two_d=True):
 
 
 # ------------------------------------------------------------------------------------------------
-def training_step(p, batch, H, n_layer, eps, masks=None, pdrop=0.0, reduce=True):
+def training_step(p, batch, H, n_layer, eps, masks=None, pdrop=0.0, reduce=True, loss_fn="bce"):
     """fwd of one reference training step on parameter dict `p` (leaf tensors may require grad)."""
     q = sasrec_encode(p, batch["in_item_id"], batch["seqlen"], H, n_layer, eps, "origin", masks, pdrop)
-    loss, pos, ng = score_bce(q, p["item_embedding.weight"], batch["item_id"], batch["neg_item"], reduce)
+    if loss_fn == "bpr":
+        loss, pos, ng = score_bpr(q, p["item_embedding.weight"], batch["item_id"], batch["neg_item"])
+    else:
+        loss, pos, ng = score_bce(q, p["item_embedding.weight"], batch["item_id"], batch["neg_item"], reduce)
     return loss, q, pos, ng
 
 
-def grads_of(p, batch, H, n_layer, eps, masks=None, pdrop=0.0, dtype=torch.float32):
+def grads_of(p, batch, H, n_layer, eps, masks=None, pdrop=0.0, dtype=torch.float32, loss_fn="bce"):
     """loss + d loss / d param for every parameter, via autograd on the restatement."""
     leaf = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in p.items()
             if k != "query_encoder.item_encoder.weight"}
-    loss, q, pos, ng = training_step(leaf, batch, H, n_layer, eps, masks, pdrop)
+    loss, q, pos, ng = training_step(leaf, batch, H, n_layer, eps, masks, pdrop, loss_fn=loss_fn)
     loss.backward()
     g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
     return loss.detach(), q.detach(), g

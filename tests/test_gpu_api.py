@@ -272,7 +272,7 @@ def test_data_parallel_ranks_equal_single_rank():
 
 
 @pytest.mark.gpu
-def test_data_parallel_fit_end_to_end():
+def test_data_parallel_fit_end_to_end(tmp_path):
     """fit() under 2 ranks (gloo, sharing cuda:0) on a dataset whose tail batch splits unevenly (13 rows: rank 0 gets a new slice size,
     rank 1 an empty one): every rank must enter the same collectives (graph warm-ups stay local) and the replicas stay bit-identical"""
     import subprocess
@@ -280,10 +280,53 @@ def test_data_parallel_fit_end_to_end():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29571", os.path.join(root, "tools", "dp_fit_check.py")], capture_output=True, text=True,
-                         timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), cwd=root)
+                         timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path)), cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
     assert "replicas identical: True; finite: True" in lines[0] and "steps=27" in lines[0]
+    # quickstart.run under W ranks: ONE log / checkpoint stem (rank 0's), every rank loaded rank 0's best checkpoint in evaluate()
+    assert "one ckpt stem: True" in lines[0]
+    assert len(list((tmp_path / "saved" / "SASRec" / "synthetic-toys").glob("*.ckpt"))) == 1
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_n_ranks_on_a_shared_gpu():
+    """`python bench.py --gpus 2` stand-alone: re-executes itself under torch.distributed.run, both ranks take the data-parallel
+    step (DR4SR_BENCH_SHARE_GPU: one GPU, gloo transport — RCCL refuses two ranks on one device), rank 0 prints ONE JSON line with
+    n_gpus = 2, a weak-scaled headline value and the strong-scaling object"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--no-throughput-mode", "--strong-global-batch", "512"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, DR4SR_BENCH_SHARE_GPU="1"), cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 512 and j["config"]["parallelism"] == "dp2"
+    assert "gloo" in j["config"]["collective"] and j["value"] > 0 and j["scaling"] == "weak"
+    st = j["strong"][0]
+    assert st["global_batch"] == 512 and st["per_gpu_batch"] == 256 and st["n_gpus"] == 2 and st["speedup"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_rccl_in_graph_allreduce():
+    """the default N-rank form — RCCL all-reduce captured inside the k-step graph — exercised with the one rank a 1-GPU box has
+    (DR4SR_BENCH_FORCE_DP); asserts that RCCL, not a fallback, carried the reduce"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--no-throughput-mode", "--no-strong", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, DR4SR_BENCH_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert "rccl all-reduce captured in the step graph" in j["config"]["collective"], j["config"]
+    assert j["final_loss"] == j["final_loss"] and 0.5 < j["final_loss"] < 2.0
 
 
 @pytest.mark.gpu
@@ -321,3 +364,59 @@ def test_models_reject_the_other_target_format(tmp_path, monkeypatch, model_name
     cfg["train"].update({"device": "cuda", "epochs": 2, "batch_size": 128, "warmup_epoch": -1})
     with pytest.raises(_lib.Dr4srError, match="one query per|one-query-per-row"):
         quickstart.run(cfg)
+
+
+@pytest.mark.gpu
+def test_loss_modules_on_score_tensors_match_reference(golden_dir):
+    """model.loss_func.{BinaryCrossEntropyLoss, BPRLoss}.forward on score tensors (dr4sr_loss_from_scores_*) vs the reference's two
+    loss classes run on the same scores (tests/golden/loss_modules.npz): loss, d pos, d neg; 1-D / 2-D positives, K = 1 and 3"""
+    from dr4sr_amd.model.loss_func import BinaryCrossEntropyLoss, BPRLoss
+    z = np.load(os.path.join(golden_dir, "loss_modules.npz"))
+    for tag in ("a", "b", "c"):
+        for name in ("bce", "bce_nr", "bpr"):
+            p = torch.from_numpy(z[f"{tag}.pos"]).cuda().requires_grad_(True)
+            n = torch.from_numpy(z[f"{tag}.neg"]).cuda().requires_grad_(True)
+            loss = BPRLoss()(p, n) if name == "bpr" else BinaryCrossEntropyLoss()(p, n, reduce=(name == "bce"))
+            np.testing.assert_allclose(loss.detach().cpu().numpy(), z[f"{tag}.{name}.loss"], rtol=1e-5, atol=1e-7)
+            (loss * torch.from_numpy(z[f"{tag}.{name}.up"]).cuda()).sum().backward()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), z[f"{tag}.{name}.dpos"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(n.grad.cpu().numpy(), z[f"{tag}.{name}.dneg"], rtol=1e-5, atol=1e-7)
+    with pytest.raises(TypeError):
+        BPRLoss()(torch.zeros(2).cuda(), torch.zeros(2, 1).cuda(), reduce=True)       # loss_func.py:44: no such parameter
+
+
+@pytest.mark.gpu
+def test_bpr_loss_training_step_matches_oracle_and_trains(golden_dir):
+    """a8: loss_fn 'bpr' (basemodel.py:103-104).  training_step = encoder + tied scorer + BPRLoss (loss_func.py:44-49): loss and every
+    parameter gradient vs the oracle (whose BPR restatement is pinned on the reference's BPRLoss, test_oracle_loss_modules_match_reference),
+    reduce=False keeps the reference's TypeError, and fit() runs on the API path"""
+    z = np.load(os.path.join(golden_dir, "sasrec_d64.npz"))
+    cfg = make_config(n_items=int(z["meta.num_items"]))
+    cfg["model"]["loss_fn"] = "bpr"
+    ds, model = build(cfg)
+    model._init_model(ds[0])
+    ref = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    model.load_state_dict(ref, strict=True)
+    batch_cpu = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("batch.")}
+    batch = {k: v.cuda() for k, v in batch_cpu.items()}
+    model.train()
+    model.optimizer.zero_grad()
+    loss = model.training_step(batch)
+    loss.backward()
+    loss_o, _, grads_o = O.grads_of(ref, batch_cpu, int(z["meta.head_num"]), int(z["meta.layer_num"]), float(z["meta.layer_norm_eps"]),
+                                    loss_fn="bpr")
+    assert abs(float(loss) - float(loss_o)) < 2e-6 * max(1.0, abs(float(loss_o)))
+    for k, g in model.engine.grad_views.items():
+        ref_g = grads_o[k]
+        err = float((g.cpu() - ref_g).abs().max() / max(1e-12, float(ref_g.abs().max())))
+        assert err < 2e-4, (k, err)
+    with pytest.raises(TypeError):
+        model.training_step(batch, reduce=False)
+    # a few optimizer steps through the API loop reduce the loss
+    first = float(loss)
+    for _ in range(15):
+        model.optimizer.zero_grad()
+        l2 = model.training_step(batch)
+        l2.backward()
+        model.optimizer.step()
+    assert float(l2) < first

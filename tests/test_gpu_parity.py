@@ -506,6 +506,39 @@ def test_topk_workspace_path_large_catalog(dev):
         assert not bool(torch.isin(it[r], hist[r]).any())          # no history item is ever recommended
 
 
+@pytest.mark.parametrize("N,frac", [(3000, 0.5), (11925, 0.1), (500, 0.98)])
+def test_topk_domain_item_mask_vs_oracle(dev, N, frac):
+    """basemodel.py:358-360: items outside domain_item_mapping[eval_domain] are masked to -inf before the top-k (multi-domain
+    datasets); item_blocked bytes through dr4sr_full_score_topk_masked_ws vs the oracle's full_score_topk(domain_items=...), incl. a
+    domain with fewer than k items left"""
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    B, k, Lh, D = 37, 100, 20, 64
+    g = torch.Generator().manual_seed(N)
+    q = torch.randn(B, D, generator=g)
+    E = 0.1 * torch.randn(N, D, generator=g)
+    hist = torch.randint(0, N, (B, Lh), generator=g)
+    domain = torch.randperm(N - 1, generator=g)[:max(1, int((N - 1) * (1 - frac)))] + 1       # the items OF the domain (never PAD)
+    blocked = torch.ones(N, dtype=torch.uint8)
+    blocked[domain] = 0
+    sc = torch.empty(B, k, device=dev)
+    it = torch.empty(B, k, dtype=torch.int64, device=dev)
+    nb = int(lib.dr4sr_full_score_topk_workspace_bytes(B, N))
+    ws = torch.empty(nb // 4, device=dev)
+    qd, Ed, hd, bd = q.to(dev), E.to(dev), hist.to(dev), blocked.to(dev)          # keep the device copies alive across the async launch
+    _lib.check(lib.dr4sr_full_score_topk_masked_ws(_lib.ptr(qd), _lib.ptr(Ed), _lib.ptr(hd), _lib.ptr(bd),
+                                                   _lib.ptr(sc), _lib.ptr(it), B, D, N, Lh, k, _lib.ptr(ws), nb, _lib.cur_stream()), "topk_masked")
+    rs, ri = O.full_score_topk(q, E, hist, k, domain_items=domain)
+    sc_c, it_c = sc.cpu(), it.cpu()
+    finite = torch.isfinite(rs)
+    assert torch.equal(torch.isfinite(sc_c), finite)
+    assert float((rs[finite] - sc_c[finite]).abs().max()) < 1e-5
+    assert float((ri[finite] == it_c[finite]).float().mean()) > 0.995, float((ri[finite] == it_c[finite]).float().mean())
+    allowed = torch.zeros(N, dtype=torch.bool)
+    allowed[domain] = True
+    assert bool(allowed[it_c[finite]].all())                       # nothing outside the domain is ever recommended
+
+
 def test_fuzz_odd_batches_vs_oracle(dev):
     """random odd batch sizes (1 .. 100), item counts down to 2, both widths, random lengths and PAD targets: tests/fuzz_parity.py"""
     import subprocess

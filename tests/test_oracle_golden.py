@@ -124,3 +124,19 @@ def test_ref_like_trainer_matches_golden(golden_dir, name):
     for n, prm in m.named_parameters():
         ref = g["grad." + n]
         assert float(np.abs(prm.grad.numpy() - ref).max()) <= 2e-5 * max(1e-8, float(np.abs(ref).max())) + 1e-9, n
+
+
+def test_oracle_loss_modules_match_reference(golden_dir):
+    """oracle bce_from_scores / bpr_from_scores vs the reference's BinaryCrossEntropyLoss / BPRLoss run on fixed scores
+    (tests/golden/loss_modules.npz, made by tools/make_golden.py loss_module_vectors): loss and both gradients"""
+    z = np.load(os.path.join(golden_dir, "loss_modules.npz"))
+    assert "unexpected keyword argument 'reduce'" in str(z["bpr.reduce_kwarg_error"])       # a8: the reference cannot call BPR from training_step
+    for tag in ("a", "b", "c"):
+        pos0, neg0 = torch.from_numpy(z[f"{tag}.pos"]), torch.from_numpy(z[f"{tag}.neg"])
+        for name in ("bce", "bce_nr", "bpr"):
+            p, n = pos0.clone().requires_grad_(True), neg0.clone().requires_grad_(True)
+            loss = O.bpr_from_scores(p, n) if name == "bpr" else O.bce_from_scores(p, n, reduce=(name == "bce"))
+            np.testing.assert_allclose(loss.detach().numpy(), z[f"{tag}.{name}.loss"], rtol=2e-6, atol=1e-7)
+            (loss * torch.from_numpy(z[f"{tag}.{name}.up"])).sum().backward()
+            np.testing.assert_allclose(torch.nan_to_num(p.grad, nan=0.0).numpy(), z[f"{tag}.{name}.dpos"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(n.grad.numpy(), z[f"{tag}.{name}.dneg"], rtol=1e-5, atol=1e-7)

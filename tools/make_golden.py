@@ -555,6 +555,42 @@ def neg_sampler_stats(out_dir):
           "min/max over 1..N-1:", cnt[1:].min(), cnt[1:].max())
 
 
+def loss_module_vectors(out_dir):
+    """model/loss_func.py:9-49 by RUNNING both loss classes on fixed score tensors (2-D and 1-D positives, K = 1 and K = 3 negatives,
+    padded positions marked -inf exactly as basemodel.py:208 does), with autograd gradients.  Also records that the reference's
+    training_step cannot call BPRLoss (basemodel.py:210 passes reduce=; loss_func.py:44 takes none): the TypeError text."""
+    import torch
+    import model.loss_func as lf
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    for tag, shape, K in (("a", (6, 50), 1), ("b", (9,), 1), ("c", (4, 7), 3)):
+        pos = torch.randn(shape, generator=g) * 2.0
+        neg = torch.randn(*shape, K, generator=g) * 2.0
+        pad = torch.rand(shape, generator=g) < 0.4
+        pad.view(-1)[0] = False
+        pos = pos.masked_fill(pad, float("-inf"))
+        out[f"{tag}.pos"], out[f"{tag}.neg"] = pos.numpy().copy(), neg.numpy().copy()
+        for name, mod, kw in (("bce", lf.BinaryCrossEntropyLoss(), {"reduce": True}), ("bce_nr", lf.BinaryCrossEntropyLoss(), {"reduce": False}),
+                              ("bpr", lf.BPRLoss(), {})):
+            p = pos.clone().requires_grad_(True)
+            n = neg.clone().requires_grad_(True)
+            loss = mod(p, n, **kw)
+            up = torch.ones_like(loss) if loss.dim() == 0 else torch.randn(loss.shape, generator=g)
+            (loss * up).sum().backward()
+            out[f"{tag}.{name}.loss"] = loss.detach().numpy().copy()
+            out[f"{tag}.{name}.up"] = up.numpy().copy()
+            out[f"{tag}.{name}.dpos"] = torch.nan_to_num(p.grad, nan=0.0).numpy().copy()     # -inf rows: grad is nan/0 in torch, 0 by definition
+            out[f"{tag}.{name}.dneg"] = n.grad.numpy().copy()
+    try:
+        lf.BPRLoss()(torch.zeros(2), torch.zeros(2, 1), reduce=True)
+        msg = ""
+    except TypeError as e:
+        msg = str(e)
+    out["bpr.reduce_kwarg_error"] = np.array(msg)
+    np.savez_compressed(os.path.join(out_dir, "loss_modules.npz"), **out)
+    print("wrote loss_modules.npz; BPRLoss(reduce=) ->", msg)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -566,6 +602,9 @@ def main():
     sys.path.insert(0, REF)
     seqlens = [1, 2, 3, 5, 8, 13, 21, 34, 47, 49, 50, 4, 2, 50]
     only = os.environ.get("GOLDEN_ONLY")
+    if only == "loss":
+        loss_module_vectors(out_dir)
+        return
     if only == "cl":
         run_cl_case(out_dir, "cl4srec_d64", n_items=173, seqlens=seqlens, seed=16)
         return
@@ -584,6 +623,7 @@ def main():
     run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
     run_cl_case(out_dir, "cl4srec_d64", n_items=173, seqlens=seqlens, seed=16)
     neg_sampler_stats(out_dir)
+    loss_module_vectors(out_dir)
 
 
 if __name__ == "__main__":
