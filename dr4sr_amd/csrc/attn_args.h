@@ -1,0 +1,19 @@
+// attn_args.h — argument block shared by the MFMA attention kernels (attn_mfma.hip) and the tiny-sequence VALU class (attn_tiny.hip)
+#pragma once
+#include <stdint.h>
+
+struct AttnArgs2 {
+    const float* qkv; float* ctx;
+    const float* dctx; float* dqkv;
+    const int64_t* idx; const int64_t* rows; const int* cu;
+    const int* state; uint64_t seed; float p; int layer; int training; int L;
+    float* stat;                 // [T][H][2]  softmax row max, 1/row sum: written by the forward, read by the backward
+    const float* rd;             // [T][H]     sum_j P dP = <dctx, ctx> per head, from the epilogue of k_post_bwd
+    // large batches: sequences are split by length class (k_prep's seq_class lists) into a short kernel (n <= 16: 16 LDS rows,
+    // 2 waves, ~9 workgroups per CU) and a long kernel, each a persistent loop over its list.  list == NULL: block b = sequence b.
+    const int* list; const int* list_count;
+    const int* desc;             // tiny class: int4 {t0, n, slot, dataset row} per list entry (k_prep), 16-byte aligned
+};
+
+// tiny-sequence class (1..DR4SR_TINY_MAX tokens), attn_tiny.hip: one wave per 4 list entries
+int launch_attn_tiny(const AttnArgs2& A, int DH, int B, bool bwd, hipStream_t s);

@@ -14,20 +14,10 @@
 // probabilities.  Dropout element index ((b*H+h)*64 + i)*64 + j, 4 consecutive j per Philox call (= one lane's r=0..3).
 #include "common.h"
 #include "kernels.h"
+#include "attn_args.h"
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
-struct AttnArgs2 {
-    const float* qkv; float* ctx;
-    const float* dctx; float* dqkv;
-    const int64_t* idx; const int64_t* rows; const int* cu;
-    const int* state; uint64_t seed; float p; int layer; int training; int L;
-    float* stat;                 // [T][H][2]  softmax row max, 1/row sum: written by the forward, read by the backward
-    const float* rd;             // [T][H]     sum_j P dP = <dctx, ctx> per head, from the epilogue of k_post_bwd
-    // large batches: sequences are split by length class (k_prep's seq_class lists) into a short kernel (n <= 16: 16 LDS rows,
-    // 2 waves, ~9 workgroups per CU) and a long kernel, each a persistent loop over its list.  list == NULL: block b = sequence b.
-    const int* list; const int* list_count;
-};
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -531,12 +521,12 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
     A.qkv = lw.qkv; A.ctx = lw.ctx; A.dctx = ws.dctx; A.dqkv = lw.dqkv;
     A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.layer = layer; A.training = training; A.L = p->L;
-    A.list = nullptr; A.list_count = nullptr; A.stat = lw.attn_st; A.rd = ws.attn_rd;
+    A.list = nullptr; A.list_count = nullptr; A.desc = nullptr; A.stat = lw.attn_st; A.rd = ws.attn_rd;
     return A;
 }
 
 // Large batches (same threshold as tile_rows): two persistent launches over k_prep's length-class lists instead of one
-// workgroup per sequence with worst-case LDS.  seq_class = [n_short, n_long, short_list[B], long_list[B]].
+// workgroup per sequence with worst-case LDS.  seq_class = [n_short, n_long, n_tiny, - | tiny_desc[B] int4 | short_list[B] | long_list[B] | tiny_list[B]].
 static bool split_by_length(const Workspace& ws) { return ws.Tmax > 16384 && !getenv("DR4SR_ATTN_NOSPLIT"); }
 
 // short sequences, backward: one wave per head runs phase A then phase B (2 waves per sequence, twice the sequences per CU of the
@@ -578,10 +568,17 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     const int per_cu_s = per_cu[bwd][0], per_cu_l = per_cu[bwd][1];
     const int gs = B < 256 * per_cu_s ? B : 256 * per_cu_s;
     const int gl = B < 256 * per_cu_l ? B : 256 * per_cu_l;
-    AttnArgs2 S = A, Lg = A;
-    S.list = ws.seq_class + 2; S.list_count = ws.seq_class;
-    Lg.list = ws.seq_class + 2 + B; Lg.list_count = ws.seq_class + 1;
+    AttnArgs2 S = A, Lg = A, Tn = A;
+    S.list = ws.seq_class + 4 + 4 * B; S.list_count = ws.seq_class;
+    Lg.list = ws.seq_class + 4 + 5 * B; Lg.list_count = ws.seq_class + 1;
+    Tn.list = ws.seq_class + 4 + 6 * B; Tn.list_count = ws.seq_class + 2; Tn.desc = ws.seq_class + 4;
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
+    // third class, 1..8 tokens: VALU kernels (attn_tiny.hip).  DR4SR_ATTN_NOTINY (cross-check): the same list through the 16-row MFMA kernels
+    if (!getenv("DR4SR_ATTN_NOTINY")) {
+        const int rc = launch_attn_tiny(Tn, DH, B, bwd, s);
+        if (rc) return rc;
+    } else if (bwd) hipLaunchKernelGGL((k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>), dim3(gs), dim3(SHORT_BWD_NT), lds_s, s, Tn);
+    else hipLaunchKernelGGL((k_attn2_fwd<DH, 16, 128, true>), dim3(gs), dim3(128), lds_s, s, Tn);
     if (bwd) {
         hipLaunchKernelGGL((k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>), dim3(gs), dim3(SHORT_BWD_NT), lds_s, s, S);
         big_lds(k_attn2_bwd<DH, 64, 256, true>, lds_l);

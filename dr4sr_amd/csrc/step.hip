@@ -79,7 +79,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     };
     ws->cu = (int*)take(p->B + 1);
     ws->tile_seq = (int*)take((Tmax + 15) / 16 + 1);
-    ws->seq_class = (int*)take(2 + 2LL * p->B);
+    ws->seq_class = (int*)take(4 + 7LL * p->B);
     ws->attn_rd = take(Tmax * p->H);
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
     ws->dctx = take(Tmax * D);

@@ -130,6 +130,46 @@ def test_sasrec_throughput_mode_B8192_vs_oracle(dense):
     print("SASRec B=%d dense=%s worst grad relerr %.2e" % (B, dense, worst))
 
 
+@pytest.mark.parametrize("D,B,p", [(64, 2048, 0.0), (64, 2048, 0.5), (128, 1024, 0.3)])
+def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, D, B, p):
+    """sequences of 1..8 tokens run on the VALU kernels of csrc/attn_tiny.hip in the split launches; DR4SR_ATTN_NOTINY sends the same
+    list through the 16-row MFMA kernels: identical statistics / dropout element indexing, so losses and gradients agree to fp32
+    summation order — also with dropout ON (the two classes regenerate the same Philox masks).  Batch with every length 1..8
+    present, PAD items inside sequences (key-padding mask) and both head widths."""
+    from test_gpu_parity import _random_params, _toys_batch
+    from dr4sr_amd.engine import SasrecEngine
+    b, N = _toys_batch(B, False, seed=33, n_items=3000)
+    for r, n in enumerate([1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17]):       # both sides of every class boundary
+        b["seqlen"][r] = n
+        b["in_item_id"][r] = 0
+        b["item_id"][r] = 0
+        b["in_item_id"][r, :n] = torch.arange(1, n + 1)
+        b["item_id"][r, :n] = torch.arange(2, n + 2)
+    b["in_item_id"][4, 1] = 0                                         # a PAD id INSIDE a 5-token sequence: key 1 is masked for every query
+    b["in_item_id"][7, 3] = 0
+    params = _random_params(N, D, 128, 2, seed=6)
+    eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, p, B, "cuda", seed=9)
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                         neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    loss_t, n_t = eng.loss_and_count()
+    g_tiny = {k: v.clone() for k, v in eng.normalized_grads().items()}
+    if p == 0.0:
+        loss_o, _, grads_o = O.grads_of(params, b, 2, 2, 1e-12)
+        assert abs(loss_t - float(loss_o)) < 2e-5
+        for k, gv in g_tiny.items():
+            assert relerr(gv, grads_o[k]) < 2e-4, k
+    eng.state[3] -= 1                                                 # replay the same RNG step
+    monkeypatch.setenv("DR4SR_ATTN_NOTINY", "1")
+    eng.fwd_bwd(plan)
+    loss_m, n_m = eng.loss_and_count()
+    assert n_m == n_t and abs(loss_m - loss_t) < 1e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, g_tiny[k].cpu()) < 2e-5, k
+
+
 # ------------------------------------------------------------------------------------------------ static getenv switches
 _SWITCH_CASES = [
     # (environment, pytest -k expression over tests/test_gpu_parity.py / test_gpu_api.py): oracle-backed tests that reach the switch
