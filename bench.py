@@ -293,6 +293,7 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from dr4sr_amd import _lib
+    from dr4sr_amd.utils.graphs import capture as graph_capture
     from dr4sr_amd.data.synthetic import TOYS_N_ITEMS, make_rows
     from dr4sr_amd.engine import SasrecEngine
     lib = _lib.load()
@@ -379,7 +380,7 @@ def main():
 
                 def capture(n):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                    with graph_capture(g, stream=stream):
                         if args.model == "sasrec":
                             eng.train_steps(plan, n)         # one prep per graph; each optimizer launch prepares the next step
                         else:
@@ -404,7 +405,7 @@ def main():
 
                 def capture_dp(n):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                    with graph_capture(g, stream=stream):
                         for j in range(n):
                             select()
                             if fuse_prep and j > 0:
@@ -435,11 +436,11 @@ def main():
                 # two graphs around a host-launched all-reduce; the optimizer graph also prepares the next batch, so only the first
                 # step of a run carries its own prep launch
                 g_first, g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_first, stream=stream, capture_error_mode="thread_local"):
+                with graph_capture(g_first, stream=stream):
                     eng.fwd_bwd(plan)
-                with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):
+                with graph_capture(g_a, stream=stream):
                     eng.fwd_bwd_prepared(plan)
-                with torch.cuda.graph(g_b, stream=stream, capture_error_mode="thread_local"):
+                with graph_capture(g_b, stream=stream):
                     eng.adam_step_prepare_next(plan)
                 prepared = [False]
 
@@ -452,10 +453,10 @@ def main():
                 collective = "%s all-reduce launched by the host between two graphs" % parallel.backend_name()
             elif run_steps is None and use_graph and dp:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_a, stream=stream, capture_error_mode="thread_local"):
+                with graph_capture(g_a, stream=stream):
                     select()
                     eng.fwd_bwd(plan)
-                with torch.cuda.graph(g_b, stream=stream, capture_error_mode="thread_local"):
+                with graph_capture(g_b, stream=stream):
                     eng.adam_step(plan)
 
                 def run_steps(n):

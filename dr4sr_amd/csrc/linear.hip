@@ -157,12 +157,14 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
 // a thread issued together (loads first, then four independent reduction chains, then stores) so that the single wave
 // per SIMD overlaps global-load / shuffle / Philox latencies across rows instead of serialising them.
 //   v = res + drop(C)  -> U (global);  LN(v) -> OUT (global) [+ LDS copy];  (mean, rstd) -> ST
+//   yreg (optional): the LayerNorm output rows of THIS thread ([pass][D/64] float4, zero beyond T) — with OUT == NULL nothing of
+//   them goes to global memory (the fused last layer hands them to the scorer in registers)
 template <int BM, int D, bool RES_IN_LDS, bool COPY_LDS>
 __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc, const float* res, int ldres,
                                            const float* __restrict__ lnw, const float* __restrict__ lnb, float eps,
                                            float* __restrict__ U, float* __restrict__ OUT, float* __restrict__ ST,
                                            float* Ls, int ldl, int t0, int T, bool dodrop, const RngKey& rk,
-                                           uint32_t site) {
+                                           uint32_t site, float4 (*yreg)[D / 64] = nullptr) {
     constexpr int NV = D / 64, PASSES = BM / 16;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     float4 gam[NV], bet[NV], v[PASSES][NV];
@@ -197,7 +199,8 @@ __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc
             const float m = mean[ps], rs = rstd[ps];
             const float4 yv = make_float4((v[ps][j].x - m) * rs * gam[j].x + bet[j].x, (v[ps][j].y - m) * rs * gam[j].y + bet[j].y,
                                           (v[ps][j].z - m) * rs * gam[j].z + bet[j].z, (v[ps][j].w - m) * rs * gam[j].w + bet[j].w);
-            if (ok) st4(OUT + (size_t)t * D + c, yv);
+            if (ok && OUT) st4(OUT + (size_t)t * D + c, yv);
+            if (yreg) yreg[ps][j] = ok ? yv : make_float4(0.f, 0.f, 0.f, 0.f);
             if (COPY_LDS) st4(Ls + row * ldl + c, ok ? yv : make_float4(0.f, 0.f, 0.f, 0.f));
         }
         if (ok && l16 == 0) { ST[2 * (size_t)t] = mean[ps]; ST[2 * (size_t)t + 1] = rstd[ps]; }
@@ -205,7 +208,7 @@ __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc
 }
 
 template <int BM, int D, int F, bool FFN_ONLY>
-__device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, const int T) {
+__device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, const int T, float4 (*zreg)[D / 64] = nullptr) {
     constexpr int LD = D + 4, LF = F + 4, NVF = F / 64, PASSES = BM / 16;
     float* R0 = smem;                 // [64][LD]  ctx tile, later linear2 output
     float* R1 = R0 + BM * LD;         // [64][LD]  y tile
@@ -296,7 +299,8 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         else tile_mma_xwT<BM, D, 3 * D>(R1, LD, A.nx_in_w, D, acc);
         tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
     } else {
-        ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF);
+        ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, zreg ? nullptr : A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF,
+                                       zreg);
     }
     STAMP(15);
 }
@@ -338,7 +342,8 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
                                                const float* __restrict__ ST, const float* __restrict__ lnw,
                                                float* __restrict__ DUg, float* DUl, float* __restrict__ DMg,
                                                float* DMl, float4 (&dgam)[D / 64], float4 (&dbet)[D / 64],
-                                               int t0, int T, bool dodrop, const RngKey& rk, uint32_t site) {
+                                               int t0, int T, bool dodrop, const RngKey& rk, uint32_t site,
+                                               const float4 (*greg)[D / 64] = nullptr) {
     constexpr int NV = D / 64, PASSES = BM / 16;
     const int l16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     float4 gam[NV], g[PASSES][NV], u[PASSES][NV];
@@ -361,6 +366,7 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             u[ps][j] = ok ? ld4(Ug + (size_t)t * D + c) : z4;
             if (SRC == 0) g[ps][j] = ok ? ld4(Gg + (size_t)t * D + c) : z4;
+            else if (SRC == 3) g[ps][j] = ok ? greg[ps][j] : z4;     // this thread's rows, straight from the scorer (registers)
             else {
                 const float4 p0 = ld4(La + row * ldl + c);
                 float4 p1 = z4;
@@ -391,7 +397,8 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
 }
 
 template <int BM, int D, int F, bool FFN_ONLY>
-__device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, const int T, const int tile) {
+__device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, const int T, const int tile,
+                                              const float4 (*dzreg)[D / 64] = nullptr) {
     constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64, PASSES = BM / 16;
     float* R1 = smem;                          // R1 first: R0 and R2 are contiguous and together hold a [64][3D+4] dqkv tile
     float* R0 = R1 + BM * LD;
@@ -416,6 +423,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         tile_to_lds<BM, D>(acc, R1, LD, nullptr);
         lds_barrier();
         ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
+    } else if (dzreg) {
+        ln_bwd_rowpass<BM, D, 3>(nullptr, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF, dzreg);
     } else {
         ln_bwd_rowpass<BM, D, 0>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
     }
@@ -665,15 +674,119 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
     }
 }
 
+__host__ __device__ constexpr int post_lds_floats(int D, int F, int bm) {
+    return bm * ((D + 4) + ((D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4));     // R0+R2 must hold a [BM][3D+4] tile
+}
+// D = 64: the row passes of the post kernels and the scorer use the SAME thread -> (row, 4 columns) map (16 lanes per token), so the
+// query row goes from LayerNorm2 to the scorer and dz from the scorer to LayerNorm2's backward IN REGISTERS: no global round trip
+// of z / dz, no vmcnt-draining workgroup barriers around the scorer (each was ~1-2 us of the latency-bound B = 256 launch).  The
+// index chain of the scorer (tile hint -> cu -> rows -> target / negative -> two table rows) does not depend on any activation: it is
+// requested BEFORE the forward half (ScorePre) and has landed long before the scorer needs it.
+template <int BM>
+struct ScorePre {
+    static constexpr int PASSES = BM / 16;
+    int b[PASSES], pos[PASSES], n[PASSES]; int64_t row[PASSES], tgt[PASSES], ng[PASSES]; float4 ep[PASSES], en[PASSES]; bool ok[PASSES];
+};
+template <int BM>
+__device__ __forceinline__ void score_prefetch(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, ScorePre<BM>& P) {
+    constexpr int D = 64;
+    const int c = (threadIdx.x & 15) * 4, sub = threadIdx.x & 15;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
+    const int bh = S.tile_seq[t0 >> 4];
+#pragma unroll
+    for (int ps = 0; ps < ScorePre<BM>::PASSES; ++ps) {
+        const int t = t0 + ps * 16 + (threadIdx.x >> 4);
+        P.ok[ps] = t < T;
+        P.b[ps] = 0; P.pos[ps] = 0; P.n[ps] = 0; P.row[ps] = 0; P.tgt[ps] = 0; P.ng[ps] = 0;
+        P.ep[ps] = make_float4(0.f, 0.f, 0.f, 0.f); P.en[ps] = P.ep[ps];
+        if (P.ok[ps]) {
+            const int b = find_seq_from(S.cu, S.B, t, bh), c0 = S.cu[b];
+            P.b[ps] = b; P.pos[ps] = t - c0; P.n[ps] = S.cu[b + 1] - c0;
+            P.row[ps] = S.rows ? S.rows[b] : b;
+            P.tgt[ps] = S.target[P.row[ps] * S.L + P.pos[ps]];
+            int64_t ng;
+            if (S.sample_neg) {
+                ng = sample_neg_id(rk, (uint64_t)b * S.L + P.pos[ps], S.n_items);
+                if (sub == 0) S.neg_item[(size_t)b * S.L + P.pos[ps]] = ng;
+            } else {
+                ng = S.neg_item[(size_t)b * S.L + P.pos[ps]];
+            }
+            P.ng[ps] = ng < 0 ? 0 : (ng >= S.n_items ? S.n_items - 1 : ng);
+            if (P.tgt[ps] > 0 && P.tgt[ps] < S.n_items) { P.ep[ps] = ld4(S.E + P.tgt[ps] * D + c); P.en[ps] = ld4(S.E + P.ng[ps] * D + c); }
+        }
+    }
+}
+// the scorer on register rows: q = zreg[pass][0] in, dz out; same arithmetic as score_tile
+template <int BM, bool META>
+__device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile,
+                                                const ScorePre<BM>& P, const float4 (*zreg)[1], float4 (*dzreg)[1], float* red) {
+    constexpr int D = 64, LPT = 16;
+    const int c = (threadIdx.x & 15) * 4, sub = threadIdx.x & 15;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
+    float lsum = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < ScorePre<BM>::PASSES; ++ps) {
+        float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.ok[ps]) {
+            const int t = t0 + ps * 16 + (threadIdx.x >> 4), b = P.b[ps], pos = P.pos[ps], n = P.n[ps];
+            const int64_t row = P.row[ps], tgt = P.tgt[ps], ng = P.ng[ps];
+            if (tgt > 0 && tgt < S.n_items) {
+                const float4 q = zreg[ps][0], ep = P.ep[ps], en = P.en[ps];
+                const float sp = lane_group_sum<LPT>(q.x * ep.x + q.y * ep.y + q.z * ep.z + q.w * ep.w);
+                const float sn = lane_group_sum<LPT>(q.x * en.x + q.y * en.y + q.z * en.z + q.w * en.w);
+                const float lt = softplus_f(-sp) + softplus_f(sn);
+                float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn), wt = 1.0f;
+                float4 dzw = make_float4(0.f, 0.f, 0.f, 0.f);          // loss_t * d weight_t / d z_t
+                if constexpr (META) {
+                    if (S.phi) wt = meta_weight_token(S, q, lt, b, pos, row, t, sub, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], dzw);
+                }
+                if (sub == 0) { lsum += wt * lt; cnt += 1.f; }
+                dpos *= wt; dneg *= wt;
+                dz = make_float4(dpos * ep.x + dneg * en.x + dzw.x, dpos * ep.y + dneg * en.y + dzw.y, dpos * ep.z + dneg * en.z + dzw.z,
+                                 dpos * ep.w + dneg * en.w + dzw.w);
+                float* gp = S.dE + tgt * D + c;
+                float* gn = S.dE + ng * D + c;
+                unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
+                unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
+            }
+            if (pos == n - 1) {                               // tail positions of this sequence (zero query): loss terms only
+                for (int l = n + sub; l < S.L; l += LPT) {
+                    const int64_t tl = S.target[row * S.L + l];
+                    if (S.sample_neg) S.neg_item[(size_t)b * S.L + l] = sample_neg_id(rk, (uint64_t)b * S.L + l, S.n_items);
+                    if (tl > 0 && tl < S.n_items) { lsum += 2.0f * 0.69314718055994530942f; cnt += 1.f; }
+                }
+            }
+        }
+        dzreg[ps][0] = dz;
+    }
+    // workgroup reduction of (cnt, lsum) -> one partial per tile; `red` is scratch no tile region overlaps
+    cnt = wave_sum(cnt); lsum = wave_sum(lsum);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = cnt; red[2 * (threadIdx.x >> 6) + 1] = lsum; }
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        S.part[2 * tile] = (red[0] + red[2]) + (red[4] + red[6]);
+        S.part[2 * tile + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
 template <int BM, int D, int F, bool META>
 __global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) {
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
-    post_fwd_body<BM, D, F, false>(A, t0, T);
-    __syncthreads();                                   // z rows of this tile are visible to the whole workgroup
-    score_tile<BM, D, META>(A, S, t0, T, blockIdx.x);
-    __syncthreads();                                   // dz rows written, LDS scratch free again
-    post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x);
+    if constexpr (D == 64) {
+        ScorePre<BM> P;
+        score_prefetch<BM>(A, S, t0, T, P);
+        float4 zreg[BM / 16][1], dzreg[BM / 16][1];
+        post_fwd_body<BM, D, F, false>(A, t0, T, zreg);
+        score_tile_regs<BM, META>(A, S, t0, T, blockIdx.x, P, zreg, dzreg, smem + post_lds_floats(D, F, BM));
+        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, dzreg);
+    } else {
+        post_fwd_body<BM, D, F, false>(A, t0, T);
+        __syncthreads();                               // z rows of this tile are visible to the whole workgroup
+        score_tile<BM, D, META>(A, S, t0, T, blockIdx.x);
+        __syncthreads();                               // dz rows written, LDS scratch free again
+        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x);
+    }
 }
 
 static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
@@ -705,10 +818,7 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     return A;
 }
 
-static size_t post_lds(int D, int F, int bm = 64) {
-    const int rest = (D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4;     // R0+R2 must hold a [BM][3D+4] tile
-    return sizeof(float) * bm * ((D + 4) + rest);
-}
+static size_t post_lds(int D, int F, int bm = 64) { return sizeof(float) * post_lds_floats(D, F, bm); }
 
 template <int BM>
 static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, bool bwd, hipStream_t s) {
@@ -726,7 +836,7 @@ static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const
 template <int BM>
 static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, const ScoreTileArgs& S, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
-    const size_t lds = post_lds(p->D, p->F, BM);
+    const size_t lds = post_lds(p->D, p->F, BM) + 8 * sizeof(float);       // + the scorer's (count, loss) reduction scratch
 #define PM(D_, F_) do { big_lds(k_post_mid<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_, false>), grid, blk, lds, s, A, S); } while (0)
     if (S.phi) {                                       // MetaModel weighting: D = 64 only (checked by the entry point)
         if (p->D != 64 || p->F != 128) return DR4SR_E_SHAPE;

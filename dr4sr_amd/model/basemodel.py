@@ -25,6 +25,7 @@ from .. import _lib, evaluation
 from ..data.dataset import BaseDataset, SeparateDataset, SyntheticDataset
 from .. import parallel
 from ..parallel import allreduce_flat, shard_bounds
+from ..utils.graphs import capture
 from ..utils import callbacks
 from .loss_func import BinaryCrossEntropyLoss, BPRLoss
 
@@ -301,7 +302,7 @@ class BaseModel(nn.Module):
             if use_graph:
                 warm_up(eager)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):       # other threads (RCCL watchdog) may touch the device
+                with capture(g):       # other threads (RCCL watchdog) may touch the device
                     eager()
                 run = g.replay
             else:
@@ -336,7 +337,7 @@ class BaseModel(nn.Module):
                 if parallel.can_capture() and not os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
                     try:
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        with capture(g):
                             body(do_reduce)
                         run = g.replay
                     except Exception as e:                # noqa: BLE001 — any capture failure: keep training with the split form
@@ -344,9 +345,9 @@ class BaseModel(nn.Module):
                         run = None
                 if run is None:
                     ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    with capture(ga):
                         eng.fwd_bwd(plan)
-                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                    with capture(gb):
                         eng.adam_step(plan)
 
                     def run():
@@ -464,7 +465,7 @@ class BaseModel(nn.Module):
             for dst, src in zip(undo, snap):
                 dst.copy_(src)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with capture(g):
                 out = self._api_step_body(dict(static))
             ent = self._api_graphs[bl] = (g, static, out)
         g, static, out = ent

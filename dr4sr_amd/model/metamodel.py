@@ -30,6 +30,7 @@ import torch.nn as nn
 from .. import _lib
 from .. import parallel
 from ..parallel import allreduce_flat, shard_bounds
+from ..utils.graphs import capture
 from ..utils.config import get_model_class, load_config
 from .basemodel import BaseModel, normal_initialization
 from .sasrec import _Linear
@@ -368,7 +369,7 @@ class MetaModel(BaseModel):
         for dst, src in zip(undo, snap):
             dst.copy_(src)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with capture(g):
             body()
         self._graphs[key] = g.replay
         return g.replay
@@ -436,15 +437,15 @@ class MetaModel(BaseModel):
             dst.copy_(src)
         if self.world_size == 1:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with capture(g):
                 fwd_bwd()
                 adam()
             run = g.replay
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            with capture(ga):
                 fwd_bwd()
-            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+            with capture(gb):
                 adam()
 
             def run():
