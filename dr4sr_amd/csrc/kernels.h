@@ -38,6 +38,8 @@ struct Workspace {
     float* X[DR4SR_MAX_LAYERS + 1];            // X[0] = embedding stage output, X[i+1] = output of layer i
     float* dX[DR4SR_MAX_LAYERS + 1];           // gradients w.r.t. X[i]
     float* dctx;                               // [T,D] scratch
+    int4* de_rec;                              // [Tmax] scorer records {target id or 0, negative id, d pos score, d neg score} of the owner-computes table gradient
+    int* idx32;                                // [Tmax] input item id per packed token (0 = contributes nothing), written by k_embqkv_fwd
     float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
     int64_t wT_stride;                         // floats per layer in wT
     float* score_part;                         // [B][2]  per-sequence (count, loss sum) of the scorer
@@ -90,6 +92,9 @@ struct WgradArgs {
     // embedding scatter job (blockIdx.y == 7, large batches; sc_g == NULL: none)
     const float* sc_g; const int64_t* sc_idx; const int64_t* sc_rows; const int* sc_tile_seq; const int* cu;
     float* sc_dE; float* sc_dP; int sc_L; int sc_n_items;
+    // owner-computes table gradient (large batches; ow_rec == NULL: the scorer / scatter job use fp32 atomics instead): blockIdx.y <
+    // ow_planes are the owner workgroups, owner o = y * gridDim.x + x accumulates the rows {id : id mod 2^ow_logG == o}
+    int ow_on; const int4* ow_rec; const int* ow_idx32; const float* ow_z; int ow_logG, ow_planes, ow_rpo;     // ow_rec == NULL: no scorer stream (autograd path)
 };
 
 int ffn_tile_rows(int Tmax);

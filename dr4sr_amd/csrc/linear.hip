@@ -73,6 +73,10 @@ static bool scatter_in_wgrad(const Workspace& ws) {
     static const bool off = getenv("DR4SR_SCATTER_INLINE") != nullptr || getenv("DR4SR_NO_FUSE") != nullptr;
     return !off && ws.Tmax > 16384;
 }
+// large batches: the item-table gradient is NOT accumulated with fp32 atomics (scorer: 2 rows per token, embedding stage: 1) but
+// summed row by row by owner workgroups inside k_wgrad (owner_job): deterministic, and ~55 us of a toys-shaped B = 8192 step
+// cheaper.  DR4SR_DE_ATOMIC (read per call) restores the atomics as a cross-check.
+static bool de_owner_mode(const Workspace& ws) { return scatter_in_wgrad(ws) && !getenv("DR4SR_DE_ATOMIC"); }
 #define BM_DISPATCH(bm, CALL) do { if ((bm) == 16) { CALL(16); } else if ((bm) == 32) { CALL(32); } else { CALL(64); } } while (0)
 
 int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s) {
@@ -96,6 +100,7 @@ struct EmbQkvArgs {
     const float* E; const float* P; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq; float* X;
     const float* W; const float* bias; float* QKV; const int* state;
     int B, L, n_items, training; uint64_t seed; float p;
+    int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
 };
 template <int BM, int D>
 __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
                 const int b = find_seq_from(A.cu, A.B, t, bh), pos = t - A.cu[b];
                 const int64_t row = A.rows ? A.rows[b] : b;
                 int64_t id = A.idx[row * A.L + pos];
+                if (A.idx32 && c == 0) A.idx32[t] = (id > 0 && id < A.n_items) ? (int)id : 0;      // as the backward's scatter tests it
                 id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
                 o = ld4(A.E + id * D + c);
                 const float4 pe = ld4(A.P + (size_t)pos * D + c);
@@ -144,6 +150,7 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.E = p->params + ws.off[0]; A.P = p->params + ws.off[1]; A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu; A.tile_seq = ws.tile_seq; A.X = ws.X[0];
     A.W = p->params + poff(ws, 0, P_IN_W); A.bias = p->params + poff(ws, 0, P_IN_B); A.QKV = ws.layer[0].qkv; A.state = p->state;
     A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
+    A.idx32 = de_owner_mode(ws) ? ws.idx32 : nullptr;
 #define EQ(B_) do { if (D == 64) hipLaunchKernelGGL((k_embqkv_fwd<B_, 64>), grid, blk, lds, s, A); \
                     else hipLaunchKernelGGL((k_embqkv_fwd<B_, 128>), grid, blk, lds, s, A); } while (0)
     BM_DISPATCH(bm, EQ);
@@ -299,8 +306,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         else tile_mma_xwT<BM, D, 3 * D>(R1, LD, A.nx_in_w, D, acc);
         tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
     } else {
-        ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, zreg ? nullptr : A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF,
-                                       zreg);
+        ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF, zreg);
     }
     STAMP(15);
 }
@@ -519,6 +525,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
 struct ScoreTileArgs {
     const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq; int64_t* neg_item; float* part;
     int sample_neg, n_items, B, L;
+    int4* rec;                                 // owner-computes table gradient: per-token records instead of atomics into dE (NULL: atomics)
     // MetaModel (DR4SR+) weighted loss, fused: weight_t = selection(z_t; phi) with the masks of metamodel.py:180-185; the loss
     // becomes sum_t weight_t loss_t and dz gains loss_t * d weight_t / d z_t.  phi == NULL: plain BCE.  (d phi is NOT produced
     // here: the inner step never uses it and the hyper-gradient takes it from the deterministic dr4sr_meta_select_bwd.)
@@ -649,9 +656,11 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
                                  dpos * ep.w + dneg * en.w + dzw.w);
                 float* gp = S.dE + tgt * D + c;
                 float* gn = S.dE + ng * D + c;
-                unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
-                unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
-            }
+                if (!S.rec) {
+                    unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
+                    unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
+                } else if (sub == 0) S.rec[t] = make_int4((int)tgt, (int)ng, __float_as_int(dpos), __float_as_int(dneg));
+            } else if (S.rec && sub == 0) S.rec[t] = make_int4(0, 0, 0, 0);
             st4(dZ + (size_t)t * D + c, dz);
             if (pos == n - 1) {                               // tail positions of this sequence (zero query): loss terms only
                 for (int l = n + sub; l < S.L; l += LPT) {
@@ -729,6 +738,7 @@ __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTi
         float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
         if (P.ok[ps]) {
             const int t = t0 + ps * 16 + (threadIdx.x >> 4), b = P.b[ps], pos = P.pos[ps], n = P.n[ps];
+            int4 rec = make_int4(0, 0, 0, 0);
             const int64_t row = P.row[ps], tgt = P.tgt[ps], ng = P.ng[ps];
             if (tgt > 0 && tgt < S.n_items) {
                 const float4 q = zreg[ps][0], ep = P.ep[ps], en = P.en[ps];
@@ -746,9 +756,14 @@ __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTi
                                  dpos * ep.w + dneg * en.w + dzw.w);
                 float* gp = S.dE + tgt * D + c;
                 float* gn = S.dE + ng * D + c;
-                unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
-                unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
+                if (!S.rec) {
+                    unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
+                    unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
+                } else if (sub == 0) {                    // owner-computes mode: one 16-byte record per token, the table rows are summed by k_wgrad's owner job
+                    rec = make_int4((int)tgt, (int)ng, __float_as_int(dpos), __float_as_int(dneg));
+                }
             }
+            if (S.rec && sub == 0) S.rec[t] = rec;
             if (pos == n - 1) {                               // tail positions of this sequence (zero query): loss terms only
                 for (int l = n + sub; l < S.L; l += LPT) {
                     const int64_t tl = S.target[row * S.L + l];
@@ -775,9 +790,12 @@ __global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreT
     if (t0 >= T) return;
     if constexpr (D == 64) {
         ScorePre<BM> P;
-        score_prefetch<BM>(A, S, t0, T, P);
+        if constexpr (BM == 16) score_prefetch<BM>(A, S, t0, T, P);             // latency regime: ahead of the forward half
         float4 zreg[BM / 16][1], dzreg[BM / 16][1];
-        post_fwd_body<BM, D, F, false>(A, t0, T, zreg);
+        PostArgs Af = A;
+        if (!S.rec) Af.z = nullptr;                          // the query rows leave the kernel only when the owner job will gather them
+        post_fwd_body<BM, D, F, false>(Af, t0, T, zreg);
+        if constexpr (BM != 16) score_prefetch<BM>(A, S, t0, T, P);             // occupancy regime: its registers would cost a workgroup per CU
         score_tile_regs<BM, META>(A, S, t0, T, blockIdx.x, P, zreg, dzreg, smem + post_lds_floats(D, F, BM));
         post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, dzreg);
     } else {
@@ -857,6 +875,7 @@ int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int trainin
     ScoreTileArgs S;
     S.E = p->params + ws.off[0]; S.dE = p->grads + ws.off[0]; S.target = p->item_id; S.rows = p->rows; S.cu = ws.cu; S.tile_seq = ws.tile_seq;
     S.neg_item = p->neg_item; S.part = ws.score_part; S.sample_neg = p->sample_neg; S.n_items = p->n_items; S.B = p->B; S.L = p->L;
+    S.rec = de_owner_mode(ws) ? ws.de_rec : nullptr;
     S.phi = nullptr; S.gumbel = nullptr; S.user_id = nullptr; S.gate_in = nullptr; S.gate_out = nullptr; S.w_out = nullptr; S.inv_tau = 1.f;
     S.meta_seed = p->seed;
     if (mw) {
@@ -1188,7 +1207,7 @@ __device__ __forceinline__ void scatter_job(const WgradArgs& A) {
                 const float4 g = ld4(A.sc_g + (size_t)t * D + c);
                 float* a = accP + pos * D + c;
                 atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); atomicAdd(a + 3, g.w);
-                if (id > 0 && id < A.sc_n_items) {
+                if (id > 0 && id < A.sc_n_items && !A.ow_on) {
                     float* d = A.sc_dE + id * D + c;
                     unsafeAtomicAdd(d, g.x); unsafeAtomicAdd(d + 1, g.y); unsafeAtomicAdd(d + 2, g.z); unsafeAtomicAdd(d + 3, g.w);
                 }
@@ -1199,6 +1218,104 @@ __device__ __forceinline__ void scatter_job(const WgradArgs& A) {
     for (int i = threadIdx.x; i < A.sc_L * D; i += 256) {
         const float v = accP[i];
         if (v != 0.f) unsafeAtomicAdd(A.sc_dP + i, v);
+    }
+}
+
+// Owner-computes item-table gradient (large batches).  dE[r] = sum_{t: target_t = r} dpos_t z_t + sum_{t: neg_t = r} dneg_t z_t
+//                                                               + sum_{t: idx_t = r} dx0_t
+// Owner workgroup o holds the rows {r : r mod G == o} (G = 2^logG; round-robin so that the Zipf-popular low ids spread over the
+// owners) as fp32 accumulators in LDS, ONE PRIVATE COPY PER WAVE.  Wave w scans a contiguous quarter of the packed tokens — the
+// scorer's 16-byte records {target, negative, dpos, dneg} and the input ids — in order, queues its matches sixteen at a time (so the
+// sixteen 256-byte row gathers are in flight together) and adds them to its own copy; at the end the four copies are summed in a
+// fixed order and the owner writes its rows.  No atomics anywhere: the result is a pure function of the batch (bit-reproducible),
+// and the 8.5 M conflicting fp32 atomics of a toys-shaped B = 8192 step (memory-side, ~55 G/s) are gone.
+template <int D>
+__device__ __forceinline__ void owner_job(const WgradArgs& A, const int owner) {
+    constexpr int NW = 4, VPL = D / 64, QN = 16;
+    const int G = 1 << A.ow_logG;
+    if (owner >= G) return;
+    const int T = A.state[DR4SR_STATE_T], lane = threadIdx.x & 63, w = threadIdx.x >> 6, rpo = A.ow_rpo;
+    float* acc = smem + (size_t)w * rpo * D;
+    int* qw = reinterpret_cast<int*>(smem + (size_t)NW * rpo * D) + w * QN * 4;        // per-wave queue: {token, local row, coef bits, source}
+    for (int i = lane; i < rpo * D; i += 64) acc[i] = 0.f;
+    const int Tq = ((T + NW * 64 - 1) / (NW * 64)) * 64, ta = w * Tq, tb = min(T, ta + Tq);
+    int qn = 0;
+    auto flush = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float v[QN][VPL]; int lr[QN]; float cf[QN];
+#pragma unroll
+        for (int k = 0; k < QN; ++k) {
+            lr[k] = 0; cf[k] = 0.f;
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) v[k][u] = 0.f;
+            if (k < qn) {
+                const int tok = qw[4 * k]; lr[k] = qw[4 * k + 1]; cf[k] = __int_as_float(qw[4 * k + 2]);
+                const float* src = (qw[4 * k + 3] ? A.sc_g : A.ow_z) + (size_t)tok * D + lane;
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) v[k][u] = src[64 * u];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QN; ++k)
+            if (k < qn) {
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) acc[lr[k] * D + lane + 64 * u] = fmaf(cf[k], v[k][u], acc[lr[k] * D + lane + 64 * u]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        qn = 0;
+    };
+    auto push = [&](int tok, int id, int cfbits, int which) {
+        if (lane == 0) { qw[4 * qn] = tok; qw[4 * qn + 1] = id >> A.ow_logG; qw[4 * qn + 2] = cfbits; qw[4 * qn + 3] = which; }
+        if (++qn == QN) flush();
+    };
+    constexpr int CH = 8;                                   // 64-token slices requested together: one memory round trip per 512 tokens (16: slower)
+    if (A.ow_rec) {                                         // stream 1: the scorer's records (fused training step only)
+        for (int base = ta; base < tb; base += 64 * CH) {
+            int4 r[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                r[k] = make_int4(0, 0, 0, 0);
+                if (base + 64 * k + lane < tb) r[k] = A.ow_rec[base + 64 * k + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                unsigned long long m = __ballot(r[k].x > 0 && (r[k].x & (G - 1)) == owner);
+                while (m) {
+                    const int L = __ffsll((long long)m) - 1; m &= m - 1;
+                    push(base + 64 * k + L, __builtin_amdgcn_readlane(r[k].x, L), __builtin_amdgcn_readlane(r[k].z, L), 0);
+                }
+                m = __ballot(r[k].x > 0 && r[k].y > 0 && (r[k].y & (G - 1)) == owner);
+                while (m) {
+                    const int L = __ffsll((long long)m) - 1; m &= m - 1;
+                    push(base + 64 * k + L, __builtin_amdgcn_readlane(r[k].y, L), __builtin_amdgcn_readlane(r[k].w, L), 0);
+                }
+            }
+        }
+    }
+    {                                                       // stream 2: the embedding stage (masked dx0 rows left by k_qkv_embed_bwd)
+        for (int base = ta; base < tb; base += 64 * CH) {
+            int r[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                r[k] = 0;
+                if (base + 64 * k + lane < tb) r[k] = A.ow_idx32[base + 64 * k + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                unsigned long long m = __ballot(r[k] > 0 && (r[k] & (G - 1)) == owner);
+                while (m) {
+                    const int L = __ffsll((long long)m) - 1; m &= m - 1;
+                    push(base + 64 * k + L, __builtin_amdgcn_readlane(r[k], L), __float_as_int(1.0f), 1);
+                }
+            }
+        }
+    }
+    flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < rpo * D; i += 256) {
+        const float sum = (smem[i] + smem[(size_t)rpo * D + i]) + (smem[(size_t)2 * rpo * D + i] + smem[(size_t)3 * rpo * D + i]);
+        const int id = ((i / D) << A.ow_logG) | owner;
+        if (sum != 0.f && id < A.sc_n_items) A.sc_dE[(size_t)id * D + (i % D)] += sum;
     }
 }
 
@@ -1218,7 +1335,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A, const QkvEmbBw
     }
     // the scatter blocks come FIRST in dispatch order (y = 0): the other jobs are persistent loops, so blocks dispatched after
     // the first resident wave would only start when those finish — no overlap
-    const int j = A.sc_g ? (int)blockIdx.y - 1 : (int)blockIdx.y;
+    // (owner planes first, then the dP / atomic scatter plane)
+    if (A.ow_on && (int)blockIdx.y < A.ow_planes) { if (layer == 0) owner_job<D>(A, blockIdx.y * gridDim.x + blockIdx.x); return; }
+    const int j = (int)blockIdx.y - (A.ow_on ? A.ow_planes : 0) - (A.sc_g ? 1 : 0);
     if (j < 0) { if (layer == 0) scatter_job<D>(A); return; }
     if (j == 6) { reduce_jobs(A, layer); return; }
     const WgradJob& J = A.job[layer * 6 + j];
@@ -1309,9 +1428,18 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     }
     A.qeb_plane = (qeb && qeb_in_wgrad(ws)) ? 1 : 0;
     const QkvEmbBwdArgs Q = make_qeb_args(p, ws, training);
-    dim3 grid(gw, scatter ? 8 : 7, p->n_layer + A.qeb_plane), blk(256);
     size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
     if (scatter && sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;
+    A.ow_on = 0; A.ow_rec = nullptr; A.ow_idx32 = nullptr; A.ow_z = nullptr; A.ow_logG = 0; A.ow_planes = 0; A.ow_rpo = 0;
+    if (scatter && de_owner_mode(ws)) {
+        // owners = the smallest power of two (>= 256) whose rows fit the launch's LDS four times (one private copy per wave) + queues
+        int logG = getenv("DR4SR_OWNER_LOGG") ? atoi(getenv("DR4SR_OWNER_LOGG")) : 8;      // tuning knob
+        auto rpo_of = [&](int lg) { return (p->n_items + (1 << lg) - 1) >> lg; };
+        while (sizeof(float) * 4 * rpo_of(logG) * D + 4 * 16 * 4 * sizeof(int) > lds && logG < 20) ++logG;
+        A.ow_on = 1; A.ow_logG = logG; A.ow_rpo = rpo_of(logG); A.ow_planes = ((1 << logG) + gw - 1) / gw;
+        A.ow_rec = with_score == 2 ? ws.de_rec : nullptr; A.ow_idx32 = ws.idx32; A.ow_z = ws.X[p->n_layer];
+    }
+    dim3 grid(gw, (scatter ? 8 : 7) + A.ow_planes, p->n_layer + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D);
     if (A.qeb_plane && lds_q > lds) lds = lds_q;
     if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A, Q); }

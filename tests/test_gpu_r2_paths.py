@@ -170,6 +170,47 @@ def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, D, B, p):
         assert relerr(gv, g_tiny[k].cpu()) < 2e-5, k
 
 
+@pytest.mark.parametrize("D,B,p,n_items", [(64, 2048, 0.0, 3000), (64, 4096, 0.5, 11925), (128, 1024, 0.2, 20034), (64, 1024, 0.0, 70000)])
+def test_owner_computed_table_gradient(monkeypatch, D, B, p, n_items):
+    """large batches: the item-table gradient is summed row by row by owner workgroups inside k_wgrad (csrc/linear.hip owner_job)
+    instead of fp32 atomics from the scorer and the embedding scatter.  (1) it equals the atomic path (DR4SR_DE_ATOMIC) to fp32
+    summation order — with dropout too; (2) it is a pure function of the batch: two replays give BIT-identical table gradients
+    (the reference asks cudnn for determinism, utils/utils.py:19); (3) PAD row and untouched rows stay exactly zero; (4) vs the oracle"""
+    from test_gpu_parity import _random_params, _toys_batch
+    from dr4sr_amd.engine import SasrecEngine
+    b, N = _toys_batch(B, False, seed=41, n_items=n_items)
+    params = _random_params(N, D, 128, 2, seed=8)
+    eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, p, B, "cuda", seed=3)
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                         neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    g1 = eng.grads.clone()
+    eng.state[3] -= 1
+    eng.fwd_bwd(plan)
+    g2 = eng.grads.clone()
+    nE = N * D
+    assert torch.equal(g1[:nE], g2[:nE]), "owner-computed dE must be bit-reproducible"
+    gE = g1[:nE].view(N, D).cpu()
+    touched = torch.zeros(N, dtype=torch.bool)
+    valid = b["item_id"] != 0
+    touched[b["item_id"][valid]] = True
+    touched[b["neg_item"].squeeze(-1)[valid]] = True
+    touched[b["in_item_id"][b["in_item_id"] != 0]] = True
+    assert float(gE[0].abs().max()) == 0.0 and float(gE[~touched].abs().max()) == 0.0
+    if p == 0.0 and N <= 20034:
+        loss_o, _, grads_o = O.grads_of(params, b, 2, 2, 1e-12)
+        for k, gv in eng.normalized_grads().items():
+            assert relerr(gv, grads_o[k]) < 2e-4, k
+    eng.state[3] -= 1
+    monkeypatch.setenv("DR4SR_DE_ATOMIC", "1")
+    eng.fwd_bwd(plan)
+    ga = eng.grads.clone()
+    assert relerr(g1[:nE], ga[:nE].cpu()) < 2e-5
+    assert relerr(g1[nE:], ga[nE:].cpu()) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ static getenv switches
 _SWITCH_CASES = [
     # (environment, pytest -k expression over tests/test_gpu_parity.py / test_gpu_api.py): oracle-backed tests that reach the switch
