@@ -420,3 +420,53 @@ def test_bpr_loss_training_step_matches_oracle_and_trains(golden_dir):
         l2.backward()
         model.optimizer.step()
     assert float(l2) < first
+
+
+@pytest.mark.gpu
+def test_torch_custom_ops_match_oracle_and_autograd(golden_dir):
+    """torch.ops.dr4sr_hip.* (dr4sr_amd/ops.py): the registered ops run the HIP kernels and differentiate through
+    torch.autograd like the reference's plain-torch expressions (basemodel.py:204-214, loss_func.py): gather bit-exact, scorer
+    loss / d query / d E vs the oracle, top-k vs the oracle, fused Adam vs the oracle's Adam step"""
+    import dr4sr_amd.ops  # noqa: F401  (registers the ops)
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    N, D, B, L = 300, 64, 9, 50
+    E = (0.1 * torch.randn(N, D, generator=g))
+    E[0] = 0
+    P = 0.1 * torch.randn(L, D, generator=g)
+    idx = torch.randint(0, N, (B, L), generator=g)
+    x = torch.ops.dr4sr_hip.embed_gather_posadd(E.to(dev), P.to(dev), idx.to(dev))
+    assert torch.equal(x.cpu(), E[idx] + P.unsqueeze(0))                      # one IEEE add: bit-exact
+    q = torch.randn(B, L, D, generator=g)
+    tgt = torch.randint(0, N, (B, L), generator=g)
+    neg = torch.randint(1, N, (B, L), generator=g)
+    for name, ofn in (("score_bce", lambda qq, ee: O.score_bce(qq, ee, tgt, neg.unsqueeze(-1), True)[0]),
+                      ("score_bpr", lambda qq, ee: O.score_bpr(qq, ee, tgt, neg.unsqueeze(-1))[0])):
+        qd, Ed = q.to(dev).requires_grad_(True), E.to(dev).requires_grad_(True)
+        lp, st = getattr(torch.ops.dr4sr_hip, name)(qd, Ed, tgt.to(dev), neg.to(dev))
+        loss = lp.sum() / st[0]
+        loss.backward()
+        qo, Eo = q.clone().requires_grad_(True), E.clone().requires_grad_(True)
+        lo = ofn(qo, Eo)
+        lo.backward()
+        assert abs(float(loss) - float(lo)) < 2e-6 * max(1.0, abs(float(lo))), name
+        assert float((qd.grad.cpu() - qo.grad).abs().max()) < 2e-6 * float(qo.grad.abs().max()) + 1e-9, name
+        assert float((Ed.grad.cpu() - Eo.grad).abs().max()) < 2e-5 * float(Eo.grad.abs().max()) + 1e-9, name
+    hist = torch.randint(0, N, (B, 7), generator=g)
+    sc, it = torch.ops.dr4sr_hip.full_score_topk(q[:, 0].contiguous().to(dev), E.to(dev), hist.to(dev), None, 20)
+    rs, ri = O.full_score_topk(q[:, 0], E, hist, 20)
+    assert float((sc.cpu() - rs).abs().max()) < 1e-5 and float((it.cpu() == ri).float().mean()) > 0.99
+    ids = torch.ops.dr4sr_hip.neg_sample(4096, N, 7, 3, E.to(dev))
+    assert int(ids.min()) >= 1 and int(ids.max()) <= N - 1
+    # fused Adam on flat buffers vs the oracle's torch.optim.Adam formula (two steps)
+    n = 1024
+    p0 = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g)
+    pd, m, v = p0.to(dev).clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    gbuf = torch.cat([gr, torch.tensor([1.0, 0.0, 0.0, 0.0])]).to(dev)
+    state = torch.zeros(16, dtype=torch.int32, device=dev)
+    po, mo, vo = {"w": p0.clone()}, {"w": torch.zeros(n)}, {"w": torch.zeros(n)}
+    for t in (1, 2):
+        torch.ops.dr4sr_hip.fused_adam_(pd, gbuf, m, v, state, 1e-3, 0.9, 0.999, 1e-8, 0.0)
+        po = O.adam_step(po, {"w": gr}, mo, vo, t)
+    assert int(state[0]) == 2 and float((pd.cpu() - po["w"]).abs().max()) < 1e-6

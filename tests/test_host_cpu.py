@@ -298,3 +298,25 @@ def test_data_parallel_math_gloo_world2(golden_dir):
         got = flat[o:o + ref.size].reshape(ref.shape) / n
         o += ref.size
         assert np.abs(got - ref).max() <= 2e-4 * max(1e-8, np.abs(ref).max()), k
+
+
+def test_torch_ops_are_registered_with_schemas_and_fake_kernels():
+    """dr4sr_amd/ops.py: the dense C-ABI entry points are dispatcher ops (torch.ops.dr4sr_hip.*) with schemas and shape-inference
+    (fake) kernels — checkable without a GPU; the real kernels refuse CPU tensors (no CPU path)"""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import dr4sr_amd.ops as ops
+    from dr4sr_amd._lib import Dr4srError
+    for n in ops.OPS:
+        assert hasattr(torch.ops.dr4sr_hip, n), n
+    assert "Tensor(a0!) params" in str(torch.ops.dr4sr_hip.fused_adam_.default._schema)
+    with FakeTensorMode():
+        E, P = torch.empty(100, 64), torch.empty(50, 64)
+        idx = torch.empty(8, 50, dtype=torch.int64)
+        assert torch.ops.dr4sr_hip.embed_gather_posadd(E, P, idx).shape == (8, 50, 64)
+        lp, st = torch.ops.dr4sr_hip.score_bce(torch.empty(8, 50, 64), E, idx, idx)
+        assert lp.shape == (8, 50) and st.shape == (2,)
+        sc, it = torch.ops.dr4sr_hip.full_score_topk(torch.empty(8, 64), E, idx, None, 20)
+        assert sc.shape == (8, 20) and it.dtype == torch.int64
+    with pytest.raises(Dr4srError):
+        torch.ops.dr4sr_hip.embed_gather_posadd(torch.zeros(10, 64), torch.zeros(50, 64), torch.zeros(2, 50, dtype=torch.int64))
