@@ -565,8 +565,11 @@ def main():
                                   "post_mid": "k_post_mid", "wgrad_fused": "k_wgrad", "embqkv_fwd": "k_embqkv_fwd",
                                   "qkv_embed_bwd": "k_qkv_embed_bwd"}[dom]
                         want_bwd = dom == "attn_bwd"
+
+                        def is_bwd(k):                     # k_attn2_bwd<...> / k_attn_tiny<DH, true>
+                            return "_bwd" in k or (k.startswith("k_attn_tiny") and k.rstrip(">").endswith("true"))
                         hits = [v["hbm_bytes_per_launch"] for k, v in pm.items()
-                                if k.startswith(prefix) and (not dom.startswith("attn") or (("_bwd" in k) == want_bwd))]
+                                if k.startswith(prefix) and (not dom.startswith("attn") or is_bwd(k) == want_bwd)]
                         if hits:
                             traffic, traffic_src = float(sum(hits)), os.path.relpath(pj, ROOT)
                             break

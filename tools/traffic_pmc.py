@@ -22,11 +22,11 @@ f = per_kernel(sys.argv[1], "FETCH_SIZE")
 w = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
 for name in sorted(set(f) | set(w)):
-    if not name.startswith(("void k_", "k_")):
+    if "k_" not in name or "at::native" in name:
         continue
     fk, n = f.get(name, (0.0, 0))
     wk, _ = w.get(name, (0.0, 0))
-    short = name.replace("void ", "").split("(")[0]
+    short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     out[short] = {"dispatches": n, "FETCH_SIZE_KB_raw": round(fk, 2), "WRITE_SIZE_KB": round(wk, 2),
                   "hbm_bytes_per_launch": round((2.0 * fk + wk) * 1024.0)}
 print(json.dumps(out, indent=1))
