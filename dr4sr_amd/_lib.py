@@ -146,6 +146,8 @@ SYMBOLS = {
     "dr4sr_meta_select_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,
                                         C.c_int32, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_fd_step_size": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_float, _f32p, C.c_void_p]),
+    "dr4sr_fd_step_size_scratch_floats": (C.c_int64, []),
+    "dr4sr_fd_step_size_ws": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_float, _f32p, _f32p, C.c_void_p]),
     "dr4sr_fd_shift": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
     "dr4sr_fd_neumann": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
     "dr4sr_fd_diff": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),

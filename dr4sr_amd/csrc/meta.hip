@@ -220,7 +220,7 @@ constexpr int FD_BLOCKS = 256;
 __device__ float g_fd_part[2 * FD_BLOCKS];
 __device__ int g_fd_ticket;
 __global__ __launch_bounds__(256) void k_fd_step_size(const float* __restrict__ theta, const float* __restrict__ dir, int64_t n,
-                                                     float rel, float* __restrict__ out_e) {
+                                                     float rel, float* __restrict__ out_e, float* __restrict__ part, int* __restrict__ ticket) {
     __shared__ float sm[16];
     __shared__ int last;
     float st = 0.f, sd = 0.f;
@@ -231,22 +231,22 @@ __global__ __launch_bounds__(256) void k_fd_step_size(const float* __restrict__ 
     st = block_sum(st, sm);
     sd = block_sum(sd, sm);
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&g_fd_part[2 * blockIdx.x], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&g_fd_part[2 * blockIdx.x + 1], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[2 * blockIdx.x], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[2 * blockIdx.x + 1], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        last = atomicAdd(&g_fd_ticket, 1) == FD_BLOCKS - 1;
+        last = atomicAdd(ticket, 1) == FD_BLOCKS - 1;
     }
     __syncthreads();
     if (!last) return;
     __threadfence();
     float pt = 0.f, pd = 0.f;
     if (threadIdx.x < FD_BLOCKS) {
-        pt = __hip_atomic_load(&g_fd_part[2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pd = __hip_atomic_load(&g_fd_part[2 * threadIdx.x + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pt = __hip_atomic_load(&part[2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pd = __hip_atomic_load(&part[2 * threadIdx.x + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     pt = block_sum(pt, sm);                                // fixed reduction tree over the partials: run-to-run identical
     pd = block_sum(pd, sm);
-    if (threadIdx.x == 0) { out_e[0] = pd > 0.f ? rel * sqrtf(pt / pd) : 0.f; g_fd_ticket = 0; }
+    if (threadIdx.x == 0) { out_e[0] = pd > 0.f ? rel * sqrtf(pt / pd) : 0.f; *ticket = 0; }
 }
 
 // out = x + sign * e * dir
@@ -348,9 +348,23 @@ extern "C" int dr4sr_meta_select_bwd(const float* query, const float* phi, const
     return (int)hipGetLastError();
 }
 
+extern "C" int64_t dr4sr_fd_step_size_scratch_floats(void) { return 2 * FD_BLOCKS + 4; }
+// re-entrant form: the caller owns the reduction scratch (dr4sr_fd_step_size_scratch_floats() floats, zeroed once; one per
+// concurrently running call)
+extern "C" int dr4sr_fd_step_size_ws(const float* theta, const float* dir, int64_t n, float rel_step, float* out_e, float* scratch,
+                                     void* stream) {
+    if (!theta || !dir || !out_e || !scratch || n <= 0) return DR4SR_E_ARG;
+    hipLaunchKernelGGL(k_fd_step_size, dim3(FD_BLOCKS), dim3(256), 0, (hipStream_t)stream, theta, dir, n, rel_step, out_e, scratch,
+                       reinterpret_cast<int*>(scratch + 2 * FD_BLOCKS));
+    return (int)hipGetLastError();
+}
+// convenience form on a module-level scratch: NOT re-entrant (two calls must not run concurrently on different streams)
 extern "C" int dr4sr_fd_step_size(const float* theta, const float* dir, int64_t n, float rel_step, float* out_e, void* stream) {
     if (!theta || !dir || !out_e || n <= 0) return DR4SR_E_ARG;
-    hipLaunchKernelGGL(k_fd_step_size, dim3(FD_BLOCKS), dim3(256), 0, (hipStream_t)stream, theta, dir, n, rel_step, out_e);
+    float* part = nullptr; int* ticket = nullptr;
+    if (hipGetSymbolAddress((void**)&part, HIP_SYMBOL(g_fd_part)) != hipSuccess || hipGetSymbolAddress((void**)&ticket, HIP_SYMBOL(g_fd_ticket)) != hipSuccess)
+        return (int)hipGetLastError();
+    hipLaunchKernelGGL(k_fd_step_size, dim3(FD_BLOCKS), dim3(256), 0, (hipStream_t)stream, theta, dir, n, rel_step, out_e, part, ticket);
     return (int)hipGetLastError();
 }
 

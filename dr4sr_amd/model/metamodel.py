@@ -131,6 +131,7 @@ class MetaModel(BaseModel):
             int(self.config["train"]["batch_size"]) * self.max_seq_len)), dtype=torch.float32, device=self.device)
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._e = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._fd_scratch = torch.zeros(int(self.lib.dr4sr_fd_step_size_scratch_floats()), dtype=torch.float32, device=self.device)
         self._tail_p = torch.zeros(_lib.GRAD_TAIL, dtype=torch.float32, device=self.device)
 
     def _register_sub_model(self) -> BaseModel:
@@ -509,14 +510,16 @@ class MetaModel(BaseModel):
             self._reduce_grads()
 
         for _ in range(mo.truncate_iter):                                                             # utils.py:180-205
-            _lib.check(lib.dr4sr_fd_step_size(_lib.ptr(theta0), _lib.ptr(v), n, rel, _lib.ptr(self._e), st()), "fd_step_size")
+            _lib.check(lib.dr4sr_fd_step_size_ws(_lib.ptr(theta0), _lib.ptr(v), n, rel, _lib.ptr(self._e), _lib.ptr(self._fd_scratch), st()),
+                       "fd_step_size")
             probe(v, 1.0)
             gp.copy_(eng.grads)
             probe(v, -1.0)
             _lib.check(lib.dr4sr_fd_neumann(_lib.ptr(v), _lib.ptr(pacc), _lib.ptr(gp), _lib.ptr(eng.grads), _lib.ptr(gp[n:n + 1]),
                                             _lib.ptr(eng.grads[n:n + 1]), _lib.ptr(self._e), mo.hpo_lr, n, st()), "fd_neumann")
         # mixed second derivative d/dphi (dL_train/dW . p)                                               utils.py:170-178
-        _lib.check(lib.dr4sr_fd_step_size(_lib.ptr(theta0), _lib.ptr(pacc), n, rel, _lib.ptr(self._e), st()), "fd_step_size")
+        _lib.check(lib.dr4sr_fd_step_size_ws(_lib.ptr(theta0), _lib.ptr(pacc), n, rel, _lib.ptr(self._e), _lib.ptr(self._fd_scratch), st()),
+                   "fd_step_size")
         fp = self._buf("fp", nphi)
         probe(pacc, 1.0, need_phi=True)
         fp.copy_(self._phi.grads)

@@ -382,6 +382,10 @@ int dr4sr_sasrec_fwd_bwd_weighted_prepared(const dr4sr_sasrec_plan* plan, const 
  *   diff     : out = coef * (fp / *np - fm / *nm) / (2 * *e)
  *   scale_by : out = x / *den */
 int dr4sr_fd_step_size(const float* theta, const float* dir, int64_t n, float rel_step, float* out_e, void* stream);
+/* the same with a caller-owned reduction scratch (dr4sr_fd_step_size_scratch_floats() floats, zeroed once): re-entrant, which the
+ * form above — it reduces through a module-level scratch — is not */
+int64_t dr4sr_fd_step_size_scratch_floats(void);
+int dr4sr_fd_step_size_ws(const float* theta, const float* dir, int64_t n, float rel_step, float* out_e, float* scratch, void* stream);
 int dr4sr_fd_shift(float* out, const float* x, const float* dir, const float* e, float sign, int64_t n, void* stream);
 int dr4sr_fd_neumann(float* v, float* pacc, const float* gp, const float* gm, const float* np, const float* nm, const float* e,
                      float lr, int64_t n, void* stream);

@@ -272,6 +272,24 @@ def test_data_parallel_ranks_equal_single_rank():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["GRU4Rec", "FMLP", "MetaModel"])
+def test_data_parallel_fit_other_models(tmp_path, model_name):
+    """the same end-to-end run (quickstart.run under 2 ranks sharing the GPU, uneven tail batch) for the other DP-capable models:
+    GRU4Rec / FMLP step through their engines' two-graph form, MetaModel all-reduces both flat buffers and runs its outer loop"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29581", os.path.join(root, "tools", "dp_fit_check.py")], capture_output=True, text=True,
+                         timeout=500, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path),
+                                               MODEL=model_name), cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT ")]
+    err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.returncode == 0 and len(lines) == 1, err
+    assert "replicas identical: True; finite: True" in lines[0] and "one ckpt stem: True" in lines[0], lines[0]
+
+
+@pytest.mark.gpu
 def test_data_parallel_fit_end_to_end(tmp_path):
     """fit() under 2 ranks (gloo, sharing cuda:0) on a dataset whose tail batch splits unevenly (13 rows: rank 0 gets a new slice size,
     rank 1 an empty one): every rank must enter the same collectives (graph warm-ups stay local) and the replicas stay bit-identical"""

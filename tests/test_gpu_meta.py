@@ -225,3 +225,31 @@ def test_metamodel_fit_end_to_end(tmp_path, monkeypatch, sub):
         cfg["model"]["sub_overrides"]["model"]["hidden_size"] = 128
     out = quickstart.run(cfg)
     assert {"ndcg@20", "recall@20"} <= set(out) and all(np.isfinite(v) for v in out.values())
+
+
+def test_fused_weighted_step_at_scale_matches_dense_path(monkeypatch):
+    """B = 512 (T_max > 16 384): the weighted fused step runs with 32-row token tiles, the length-class attention launches (tiny VALU
+    class included) and the owner-computed table gradient (scorer records carry weight * dpos / weight * dneg) — it must equal the
+    dense C-ABI composition started from the same RNG step, with dropout and in-kernel Gumbel noise"""
+    cfg = make_config(400, dropout=0.3, n_rows=1536, batch=512)
+    ds, m = build(cfg, monkeypatch)
+    m.train()
+    e = m.engine
+    loader = ds[0].get_loader()
+    bt = m._local_batch(loader, m._perm(loader), 0)
+    bt["neg_item"] = m._neg_sampling(bt)
+    assert int(bt["item_id"].shape[0]) == 512
+    rng = e.state[3:4].clone()
+    m._fused_weighted(bt)
+    g_fused = e.grads.clone()
+    e.state[3:4].copy_(rng)
+    m._weighted_fwd_bwd(bt)
+    g_dense = e.grads.clone()
+    n = e.n_params
+    assert float(g_fused[n]) == float(g_dense[n]) and abs(float(g_fused[n + 1]) - float(g_dense[n + 1])) < 2e-3 * max(1.0, abs(float(g_dense[n + 1])))
+    assert rel(g_fused[:n].cpu().numpy(), g_dense[:n].cpu().numpy()) < 1e-4
+    # and the owner-computed table gradient of the weighted step is reproducible bit for bit
+    e.state[3:4].copy_(rng)
+    m._fused_weighted(bt)
+    nE = e.n_items * e.D
+    assert torch.equal(e.grads[:nE], g_fused[:nE])

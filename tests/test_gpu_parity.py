@@ -120,8 +120,10 @@ def test_fwd_bwd_and_adam_vs_golden(dev, golden_dir, name):
     for k, v in eng.views.items():
         well = np.abs(g["grad." + k]) > 1e-5
         d = (v.cpu().numpy() - g["adam1." + k])
-        assert np.abs(d[well]).max(initial=0) < 5e-6, k
-        assert np.abs(d).max() < 2e-4, k
+        assert np.abs(d[well]).max(initial=0) < 5e-6, (k, float(np.abs(d[well]).max(initial=0)))
+        # where |g| <~ adam_eps the update lr * m / (sqrt(v) + eps) amplifies a 1e-9 gradient difference (fp32 atomics order) to O(lr):
+        # the bound is lr / 5, the observed worst value is reported on failure
+        assert np.abs(d).max() < 2e-4, (k, "worst |param - reference| %.3e on near-zero-gradient elements" % float(np.abs(d).max()))
     eng.fwd_bwd(plan)
     loss2, _ = eng.loss_and_count()
     assert abs(loss2 - float(g["out.loss_step2"])) < 2e-5
@@ -130,8 +132,8 @@ def test_fwd_bwd_and_adam_vs_golden(dev, golden_dir, name):
     for k, v in eng.views.items():
         well = np.abs(g["grad." + k]) > 1e-5
         d = (v.cpu().numpy() - g["adam2." + k])
-        assert np.abs(d[well]).max(initial=0) < 1e-5, k
-        assert np.abs(d).max() < 4e-4, k
+        assert np.abs(d[well]).max(initial=0) < 1e-5, (k, float(np.abs(d[well]).max(initial=0)))
+        assert np.abs(d).max() < 4e-4, (k, "worst |param - reference| %.3e after two steps (near-zero-gradient elements)" % float(np.abs(d).max()))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -425,7 +427,9 @@ def test_topk_vs_golden(dev, golden_dir, name):
     _lib.check(lib.dr4sr_full_score_topk(_lib.ptr(q), _lib.ptr(E), _lib.ptr(hist), _lib.ptr(sc), _lib.ptr(it), B, D,
                                          E.shape[0], hist.shape[1], k, _lib.cur_stream()), "topk")
     assert relerr(sc, g["eval.topk_score"]) < 1e-5
-    assert (it.cpu().numpy() == g["eval.topk_items"]).mean() > 0.99
+    same = float((it.cpu().numpy() == g["eval.topk_items"]).mean())
+    # ids may only differ where two scores are equal to fp32 rounding (the GEMM sums in a different order than torch's matmul)
+    assert same > 0.99, "top-k ids equal on %.4f of the positions (worst case allowed 0.99)" % same
     hit = torch.from_numpy(g["eval.item_id"]).view(-1, 1) == it.cpu()
     np.testing.assert_allclose(O.ndcg_at(hit, 20).numpy(), g["eval.ndcg@20"], rtol=1e-6)
 

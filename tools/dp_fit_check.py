@@ -21,6 +21,10 @@ from dr4sr_amd.utils import load_config, seed_everything
 MODEL = os.environ.get("MODEL", "SASRec")
 cfg = load_config({"model": MODEL, "dataset": "synthetic-toys"})
 cfg["data"].update({"n_items": 300, "n_rows": 1000 + 37, "n_eval_rows": 256, "seed": 5})
+if MODEL == "MetaModel":
+    cfg["model"]["sub_model"] = "SASRec"                  # BASELINE configs[4]; configs/metamodel.yaml's default sub-model is FMLP (prefix rows)
+if MODEL == "FMLP":
+    cfg["data"]["prefix_rows"] = True                     # one query per row: left-padded prefixes with scalar targets (model/fmlp.py:38)
 cfg["model"]["dropout_rate"] = 0.2
 cfg["train"].update({"batch_size": 128, "epochs": 3, "device": "cuda:0", "hip_graph": True})
 if "interval" in cfg["train"]:
@@ -35,7 +39,12 @@ def _keep_model(config, ds):                              # only to read the tra
     holder["model"] = _prep(config, ds)
     return holder["model"]
 quickstart.run.__globals__["prepare_model"] = _keep_model
-test = quickstart.run(cfg)
+try:
+    test = quickstart.run(cfg)
+except BaseException as e:                                  # the launcher's error page hides the child's traceback: say it on stdout
+    import traceback
+    print("DP_FIT_ERROR rank %d: %s\n%s" % (rank, repr(e), "".join(traceback.format_exc().splitlines(True)[-12:])), flush=True)
+    raise
 logging.getLogger("CDR").setLevel(logging.WARNING)
 model = holder["model"]
 torch.cuda.synchronize()
