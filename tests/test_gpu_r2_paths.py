@@ -211,6 +211,15 @@ def test_owner_computed_table_gradient(monkeypatch, D, B, p, n_items):
     assert relerr(g1[nE:], ga[nE:].cpu()) < 2e-5
 
 
+def test_fuzz_large_batches_vs_oracle():
+    """tests/fuzz_scale.py: random at-scale batches (all-tiny / all-long / class-boundary / toys-like length mixes, catalogs of 2 ..
+    11 925 items, both widths, PAD targets, PAD ids inside sequences) through the fused step vs the oracle"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_scale.py")], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, TRIALS="8", SEED="5"), cwd=root)
+    assert out.returncode == 0 and "FUZZ-SCALE ok" in out.stdout, out.stdout[-2500:] + out.stderr[-1500:]
+
+
 # ------------------------------------------------------------------------------------------------ static getenv switches
 _SWITCH_CASES = [
     # (environment, pytest -k expression over tests/test_gpu_parity.py / test_gpu_api.py): oracle-backed tests that reach the switch
