@@ -68,7 +68,7 @@ static int launch_prep_sel(const int64_t* seqlen, const int64_t* rows, int* cu, 
     const int64_t n4 = zero ? zero_floats / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024);
     if (zb > 255) zb = 255;
-    const PrepArgs P{seqlen, rows, cu, state, B, L, bump_rng, sel, tile_seq, seq_class};
+    const PrepArgs P{seqlen, rows, cu, state, B, L, bump_rng, sel, tile_seq, seq_class, nullptr};
     hipLaunchKernelGGL(k_prep, dim3(1 + zb), dim3(1024), 0, s, P, zero, n4);
     return DR4SR_LAUNCH_CHECK();
 }
@@ -82,7 +82,7 @@ int make_prep_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng
         if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
         sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
     }
-    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, sel, ws.tile_seq, ws.seq_class};
+    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, sel, ws.tile_seq, ws.seq_class, ws.len_buf};
     return 0;
 }
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {

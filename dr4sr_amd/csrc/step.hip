@@ -80,6 +80,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->cu = (int*)take(p->B + 1);
     ws->tile_seq = (int*)take((Tmax + 15) / 16 + 1);
     ws->seq_class = (int*)take(4 + 7LL * p->B);
+    ws->len_buf = (int*)take(p->B);
     ws->attn_rd = take(Tmax * p->H);
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
     ws->dctx = take(Tmax * D);
@@ -131,7 +132,10 @@ static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
 // `next` (optional): the launch also prepares the NEXT training step of the same plan — its workgroup 0 runs the prep (batch
 // selection, prefix scan, RNG step), every thread zeroes the gradient words it has consumed and the last workgroup to finish
 // zeroes the {n_valid, loss} tail — so a k-step graph needs one k_prep, not k (a launch boundary + a single-workgroup
-// latency chain per step saved).
+// latency chain per step saved).  enable = 1 (B <= 1024): an extra workgroup, dispatched first, runs the whole prep.  enable = 2
+// (larger batches): EVERY workgroup first runs its share of the selection + seqlen gather (prep_select: coalesced over the grid,
+// in flight while the Adam loop runs) and the LAST workgroup to finish runs the scan part (prep_body<256, true>) — as a launch of
+// its own the single-workgroup prep of 8 192 sequences cost 41 us per step.
 struct AdamNext { int enable; PrepArgs prep; };
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __restrict__ G, float* __restrict__ M,
                                               float* __restrict__ V, int64_t n, int* __restrict__ state, float lr, float b1,
@@ -143,7 +147,11 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
     const float nvalid = G[n];
     const float gs = nvalid > 0.f ? 1.0f / nvalid : 0.f;
     const bool poisoned = G[n + 2] != 0.f;
-    const int nblk = next.enable ? (int)gridDim.x - 1 : (int)gridDim.x, blk = next.enable ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    const int nblk = next.enable == 1 ? (int)gridDim.x - 1 : (int)gridDim.x, blk = next.enable == 1 ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    if (next.enable == 2) {                                // two-phase prep, phase 1 (+ this step's loss-log entry, before the batch index moves)
+        if (loss_log && blk == 0 && threadIdx.x == 0) loss_log[log_index ? max(*log_index - 1, 0) : 0] = G[n + 1] * gs;
+        prep_select<256>(next.prep, blk, nblk);
+    }
     if (blk < 0) {                                         // dispatched first: the next step's prep (and this step's loss-log entry,
         const float lossv = G[n + 1] * gs;                 //  whose index the prep is about to advance)
         if (loss_log && threadIdx.x == 0) loss_log[log_index ? max(*log_index - 1, 0) : 0] = lossv;
@@ -191,14 +199,20 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
             }
         }
     }
-    __syncthreads();
+    __shared__ int s_last;
+    __syncthreads();                           // (also drains every wave's stores: prep_select's write-through stores are out)
     if (threadIdx.x == 0) {                    // no fence needed: the kernel boundary publishes the parameter writes
         const int ticket = atomicAdd(&state[8], 1);
-        if (ticket == (int)gridDim.x - 1) {    // every workgroup has read the tail and state[STEP] by now
+        s_last = ticket == (int)gridDim.x - 1;
+        if (s_last) {                          // every workgroup has read the tail and state[STEP] by now
             state[8] = 0;
             if (!poisoned) state[DR4SR_STATE_STEP] = t;
             if (next.enable) { G[n] = 0.f; G[n + 1] = 0.f; G[n + 2] = 0.f; G[n + 3] = 0.f; }
         }
+    }
+    if (next.enable == 2) {                    // two-phase prep, phase 2: by the last workgroup, from agent-scope loads of what phase 1 published
+        __syncthreads();
+        if (s_last) prep_body<256, true>(next.prep, part);
     }
 }
 
@@ -209,9 +223,9 @@ int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* sta
     static const int cap = getenv("DR4SR_ADAM_BLOCKS") ? atoi(getenv("DR4SR_ADAM_BLOCKS")) : 256;
     if (blocks > cap) blocks = cap;
     AdamNext nx;
-    nx.enable = next ? 1 : 0;
-    if (next) nx.prep = *next; else nx.prep = PrepArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr};
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks + (next ? 1 : 0)), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx);
+    nx.enable = next ? (next->B > 1024 && next->len_buf ? 2 : 1) : 0;
+    if (next) nx.prep = *next; else nx.prep = PrepArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks + (nx.enable == 1 ? 1 : 0)), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx);
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s, const PrepArgs* next) {
@@ -351,9 +365,10 @@ extern "C" int dr4sr_sasrec_train_steps(const dr4sr_sasrec_plan* plan, int32_t n
     Workspace ws;
     RC(get_ws(plan, &ws));
     if (n_steps <= 0 || !plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
-    // the 256-thread prep inside the optimizer launch pays up to B = 1024 (measured: +2.7 % at 256, +1 % at 1024, -1 % at 2048)
+    // B <= 1024: the whole prep as an extra 256-thread workgroup of the optimizer launch (+2.7 % at 256, +1 % at 1024; -1 % at 2048);
+    // above: the two-phase form (selection spread over the optimizer launch's workgroups, scan by the last one to finish)
     static const bool nofuse_env = getenv("DR4SR_NO_PREP_FUSE") != nullptr;
-    const bool nofuse = nofuse_env || plan->B > 1024;
+    const bool nofuse = nofuse_env;
     hipStream_t s = (hipStream_t)stream;
     PrepArgs next;
     RC(make_prep_args(plan, ws, 1, &next));

@@ -210,14 +210,17 @@ def test_gru4rec_model_api_and_fast_path(golden_dir, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_train_steps_equals_repeated_train_step():
+@pytest.mark.parametrize("B,U", [(64, 640), (2048, 19412), (9000, 19412)])
+def test_train_steps_equals_repeated_train_step(B, U):
     """dr4sr_sasrec_train_steps (one prep, optimizer launches prepare the next step) == k x dr4sr_sasrec_train_step, over
-    consecutive batches of a permutation, with dropout and in-kernel negatives (same RNG steps on both sides)."""
+    consecutive batches of a permutation, with dropout and in-kernel negatives (same RNG steps on both sides).  B = 64: the next
+    step's prep is an extra workgroup of the optimizer launch; B = 2048 / 9000 (> 1024; 9000 > one 8192-sequence chunk and wraps the
+    permutation): the two-phase form — selection spread over the optimizer launch's workgroups, scan by the last one to finish."""
     import numpy as np
     from dr4sr_amd.engine import SasrecEngine
     from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
     dev = torch.device("cuda", 0)
-    B, L, U, k = 64, 50, 640, 4
+    L, k = 50, 4
     rows = make_rows(n_rows=U, n_items=TOYS_N_ITEMS, seed=11)
     data = {n: torch.from_numpy(rows[n]).to(dev) for n in ("in_item_id", "item_id", "seqlen")}
     perm = torch.from_numpy(np.random.default_rng(3).permutation(U)).to(dev)
@@ -233,7 +236,11 @@ def test_train_steps_equals_repeated_train_step():
         plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=torch.zeros(B, dtype=torch.int64, device=dev),
                              neg_item=torch.zeros(B, L, dtype=torch.int64, device=dev), sample_neg=True,
                              perm_sel=(perm, B, 0, counter), loss_log=log)
-        if fused == "split":                                # the data-parallel form: halves of a step around (here: no) all-reduce
+        if fused == "split" and B > 1024:                   # (the split form prepares inside the optimizer launch up to B = 1024 only)
+            for _ in range(k + 1):
+                eng.fwd_bwd(plan)
+                eng.adam_step(plan)
+        elif fused == "split":                              # the data-parallel form: halves of a step around (here: no) all-reduce
             eng.fwd_bwd(plan)
             for _ in range(k):
                 eng.adam_step_prepare_next(plan)
