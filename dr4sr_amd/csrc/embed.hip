@@ -82,7 +82,8 @@ int make_prep_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng
         if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
         sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
     }
-    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, sel, ws.tile_seq, ws.seq_class, ws.len_buf};
+    // the length-class lists are only read by the at-scale attention launches (attn_mfma.hip: split_by_length)
+    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, sel, ws.tile_seq, ws.Tmax > 16384 ? ws.seq_class : nullptr, ws.len_buf};
     return 0;
 }
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {
@@ -90,7 +91,7 @@ int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, i
     const int rc = make_prep_args(p, ws, bump_rng, &P);
     if (rc) return rc;
     return launch_prep_sel(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, zero_grads ? p->grads : nullptr,
-                           ws.n_params + DR4SR_GRAD_TAIL, P.sel, ws.tile_seq, ws.seq_class, s);
+                           ws.n_params + DR4SR_GRAD_TAIL, P.sel, ws.tile_seq, P.seq_class, s);
 }
 
 // ------------------------------------------------------------------------------------------------

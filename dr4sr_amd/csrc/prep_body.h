@@ -50,8 +50,11 @@ __device__ __forceinline__ void prep_body(const PrepArgs& P, unsigned long long*
     int64_t* rw = const_cast<int64_t*>(rows);
     unsigned long long carry = 0;                       // running totals of the chunks already done (block-uniform)
     unsigned int carry2 = 0;
-    for (int chunk0 = 0; chunk0 < B; chunk0 += NT * KEEP) {
-        const int b0 = chunk0 + tid * KEEP, b1 = min(B, b0 + KEEP);
+    // sequences per thread per chunk: as few as the batch allows (B <= NT: ONE per thread — at B = 256 this workgroup is the critical
+    // path of the optimizer launch, and 8 per thread would leave 7/8 of it idle behind 8-long serial chains)
+    const int kr = min(KEEP, (B + NT - 1) / NT);
+    for (int chunk0 = 0; chunk0 < B; chunk0 += NT * kr) {
+        const int b0 = chunk0 + tid * kr, b1 = min(B, b0 + kr);
         int keep[KEEP]; int64_t krow[KEEP];
 #pragma unroll
         for (int k = 0; k < KEEP; ++k) {
