@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdr4sr_hip.so")
+LIB_PATH = os.environ.get("DR4SR_LIB_PATH") or os.path.join(_HERE, "csrc", "libdr4sr_hip.so")     # override: A/B runs of two builds on one box
 
 ABI_VERSION = 3
 GRAD_TAIL = 4

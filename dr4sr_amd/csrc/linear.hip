@@ -725,31 +725,142 @@ __device__ __forceinline__ void score_prefetch(const PostArgs& A, const ScoreTil
         }
     }
 }
-// the scorer on register rows: q = zreg[pass][0] in, dz out; same arithmetic as score_tile
+// the scorer on register rows: q = zreg[pass][0] in, dz out; same arithmetic as score_tile.
+// META (MetaModel weighting, metamodel.py:169-194): the 64 -> 64 -> 2 selection MLP of the tile's tokens runs as two small MFMA GEMMs on
+// the workgroup's LDS tile instead of per-lane dot loops (each token's 16 lanes read all of W1 twice from L1: +11.5 us on the
+// 24 us launch at B = 256): pre = Z W1^T + b1 [BM x 64], then the per-token gate / softmax weight / d hidden, then dzw = dh W1.
+// `tile` points at two [BM][68] LDS tiles (the post kernels' regions are free between the two halves).
 template <int BM, bool META>
 __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile,
-                                                const ScorePre<BM>& P, const float4 (*zreg)[1], float4 (*dzreg)[1], float* red) {
-    constexpr int D = 64, LPT = 16;
+                                                const ScorePre<BM>& P, const float4 (*zreg)[1], float4 (*dzreg)[1], float* red, float* lds_tile) {
+    constexpr int D = 64, LPT = 16, LD = D + 4, PASSES = ScorePre<BM>::PASSES;
     const int c = (threadIdx.x & 15) * 4, sub = threadIdx.x & 15;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
     float lsum = 0.f, cnt = 0.f;
+    float lt_[PASSES], dpos_[PASSES], dneg_[PASSES], wt_[PASSES];
+    bool on_[PASSES];
+    float4 dzw_[PASSES];
+    // ---- pass 1: scores and loss terms (needs nothing but the query row)
+    auto terms = [&](const int ps, float& lt, float& dpos, float& dneg) {
+        const float4 q = zreg[ps][0], ep = P.ep[ps], en = P.en[ps];
+        const float sp = lane_group_sum<LPT>(q.x * ep.x + q.y * ep.y + q.z * ep.z + q.w * ep.w);
+        const float sn = lane_group_sum<LPT>(q.x * en.x + q.y * en.y + q.z * en.z + q.w * en.w);
+        lt = softplus_f(-sp) + softplus_f(sn);
+        dpos = -sigmoid_f(-sp); dneg = sigmoid_f(sn);
+    };
+    auto pass1 = [&](const int ps) {
+        on_[ps] = false; lt_[ps] = 0.f; dpos_[ps] = 0.f; dneg_[ps] = 0.f; wt_[ps] = 1.0f; dzw_[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.ok[ps] && P.tgt[ps] > 0 && P.tgt[ps] < S.n_items) { terms(ps, lt_[ps], dpos_[ps], dneg_[ps]); on_[ps] = true; }
+    };
+    if constexpr (META) {
 #pragma unroll
-    for (int ps = 0; ps < ScorePre<BM>::PASSES; ++ps) {
+        for (int ps = 0; ps < PASSES; ++ps) pass1(ps);
+    }
+    if constexpr (META) {
+        if (S.phi) {
+            constexpr int MD = 64;
+            const float* W1 = S.phi;
+            const float* b1 = S.phi + MD * MD;
+            const float* W2 = b1 + MD;                           // [2][64]
+            const float* b2 = W2 + 2 * MD;
+            float* Zs = lds_tile;                                // [BM][LD] query rows, later d hidden
+            float* Ps = lds_tile + BM * LD;                      // [BM][LD] pre-activations, later dzw
+            const uint32_t step = (uint32_t)A.state[DR4SR_STATE_RNGSTEP];
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) st4(Zs + (ps * 16 + (threadIdx.x >> 4)) * LD + c, zreg[ps][0]);      // rows beyond T are zero
+            lds_barrier();
+            {
+                TileAcc<BM, MD> acc;
+                tile_zero(acc);
+                tile_mma_xwT<BM, MD, MD>(Zs, LD, W1, MD, acc);
+                tile_to_lds<BM, MD>(acc, Ps, LD, b1);
+            }
+            lds_barrier();
+            float4 dh4[PASSES];
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                dh4[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on_[ps]) {
+                    const int row = ps * 16 + (threadIdx.x >> 4), t = t0 + row, b = P.b[ps], pos = P.pos[ps];
+                    const float4 pre4 = ld4(Ps + row * LD + c);
+                    const float pre[4] = {pre4.x, pre4.y, pre4.z, pre4.w};
+                    unsigned long long gate;
+                    if (S.gate_in) gate = S.gate_in[t];
+                    else {
+                        unsigned long long mine = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) mine |= (unsigned long long)(pre[k] > 0.f) << (4 * sub + k);
+#pragma unroll
+                        for (int o = 8; o > 0; o >>= 1) mine |= __shfl_xor(mine, o, 16);
+                        gate = mine;
+                    }
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = 4 * sub + k;
+                        const float h = ((gate >> j) & 1ull) ? pre[k] : 0.f;
+                        s0 = fmaf(W2[j], h, s0);
+                        s1 = fmaf(W2[MD + j], h, s1);
+                    }
+                    s0 = lane_group_sum<16>(s0) + b2[0];
+                    s1 = lane_group_sum<16>(s1) + b2[1];
+                    float g0, g1;
+                    const int64_t pidx = (int64_t)b * S.L + pos;
+                    if (S.gumbel) { g0 = S.gumbel[2 * pidx]; g1 = S.gumbel[2 * pidx + 1]; }
+                    else {
+                        const uint4 r = philox4x32_10(make_uint4((uint32_t)pidx, (uint32_t)(pidx >> 32), 0x6D657461u, step),
+                                                      make_uint2((uint32_t)S.meta_seed, (uint32_t)(S.meta_seed >> 32)));
+                        const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                        g0 = -logf(-logf(u0)); g1 = -logf(-logf(u1));
+                    }
+                    const float y = 1.0f / (1.0f + expf(-((s0 + g0) - (s1 + g1)) * S.inv_tau));
+                    const bool forced = S.user_id && S.user_id[P.row[ps]] == 0;        // metamodel.py:180-183: pattern rows -> weight 1
+                    wt_[ps] = forced ? 1.0f : y;
+                    if (sub == 0) {
+                        if (S.w_out) S.w_out[t] = wt_[ps];
+                        if (S.gate_out) S.gate_out[t] = gate;
+                    }
+                    if (!forced) {
+                        const float dzl = lt_[ps] * y * (1.0f - y) * S.inv_tau;
+                        float dh[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const int j = 4 * sub + k; dh[k] = ((gate >> j) & 1ull) ? (W2[j] - W2[MD + j]) * dzl : 0.f; }
+                        dh4[ps] = make_float4(dh[0], dh[1], dh[2], dh[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) st4(Zs + (ps * 16 + (threadIdx.x >> 4)) * LD + c, dh4[ps]);       // Zs: the pre GEMM has consumed it
+            lds_barrier();
+            {
+                TileAcc<BM, MD> acc;                             // dzw[t][i] = sum_j dh[t][j] W1[j][i]   (x W form, W1 [out = j][in = i])
+                tile_zero(acc);
+                tile_mma_xw<BM, MD, MD>(Zs, LD, W1, MD, acc);
+                tile_to_lds<BM, MD>(acc, Ps, LD, nullptr);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps)
+                if (on_[ps]) dzw_[ps] = ld4(Ps + (ps * 16 + (threadIdx.x >> 4)) * LD + c);
+        }
+    }
+    // ---- pass 2: dz, table gradient, loss partials.  Without the selection MLP the loss terms are computed here, inside the same
+    // branch (one pass, the control flow and register budget of the plain instantiations are those of the form without META)
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
         float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
         if (P.ok[ps]) {
             const int t = t0 + ps * 16 + (threadIdx.x >> 4), b = P.b[ps], pos = P.pos[ps], n = P.n[ps];
-            int4 rec = make_int4(0, 0, 0, 0);
             const int64_t row = P.row[ps], tgt = P.tgt[ps], ng = P.ng[ps];
-            if (tgt > 0 && tgt < S.n_items) {
+            int4 rec = make_int4(0, 0, 0, 0);
+            bool on;
+            if constexpr (META) on = on_[ps]; else on = tgt > 0 && tgt < S.n_items;
+            if (on) {
                 const float4 q = zreg[ps][0], ep = P.ep[ps], en = P.en[ps];
-                const float sp = lane_group_sum<LPT>(q.x * ep.x + q.y * ep.y + q.z * ep.z + q.w * ep.w);
-                const float sn = lane_group_sum<LPT>(q.x * en.x + q.y * en.y + q.z * en.z + q.w * en.w);
-                const float lt = softplus_f(-sp) + softplus_f(sn);
-                float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn), wt = 1.0f;
+                float lt, dpos, dneg, wt = 1.0f;
                 float4 dzw = make_float4(0.f, 0.f, 0.f, 0.f);          // loss_t * d weight_t / d z_t
-                if constexpr (META) {
-                    if (S.phi) wt = meta_weight_token(S, q, lt, b, pos, row, t, sub, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], dzw);
-                }
+                if constexpr (META) { lt = lt_[ps]; dpos = dpos_[ps]; dneg = dneg_[ps]; wt = wt_[ps]; dzw = dzw_[ps]; }
+                else terms(ps, lt, dpos, dneg);
                 if (sub == 0) { lsum += wt * lt; cnt += 1.f; }
                 dpos *= wt; dneg *= wt;
                 dz = make_float4(dpos * ep.x + dneg * en.x + dzw.x, dpos * ep.y + dneg * en.y + dzw.y, dpos * ep.z + dneg * en.z + dzw.z,
@@ -796,7 +907,8 @@ __global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreT
         if (!S.rec) Af.z = nullptr;                          // the query rows leave the kernel only when the owner job will gather them
         post_fwd_body<BM, D, F, false>(Af, t0, T, zreg);
         if constexpr (BM != 16) score_prefetch<BM>(A, S, t0, T, P);             // occupancy regime: its registers would cost a workgroup per CU
-        score_tile_regs<BM, META>(A, S, t0, T, blockIdx.x, P, zreg, dzreg, smem + post_lds_floats(D, F, BM));
+        if constexpr (META) lds_barrier();                   // every wave is past the forward half's last LDS reads: the tiles are free
+        score_tile_regs<BM, META>(A, S, t0, T, blockIdx.x, P, zreg, dzreg, smem + post_lds_floats(D, F, BM), smem);
         post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, dzreg);
     } else {
         post_fwd_body<BM, D, F, false>(A, t0, T);
