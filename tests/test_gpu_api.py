@@ -495,3 +495,64 @@ def test_torch_custom_ops_match_oracle_and_autograd(golden_dir):
         torch.ops.dr4sr_hip.fused_adam_(pd, gbuf, m, v, state, 1e-3, 0.9, 0.999, 1e-8, 0.0)
         po = O.adam_step(po, {"w": gr}, mo, vo, t)
     assert int(state[0]) == 2 and float((pd.cpu() - po["w"]).abs().max()) < 1e-6
+
+
+def _write_reference_files(root, n_users=300, n_items=120, L=50, seed=3):
+    """a dataset directory in the REFERENCE's on-disk row format (data/dataset.py:56-65: torch-pickled row lists + inter.csv),
+    toys-like lengths; returns the rows"""
+    d = os.path.join(root, "dataset", "disk-toys", "toy")
+    os.makedirs(d)
+    rng = np.random.default_rng(seed)
+    pad = lambda s: list(s) + [0] * (L - len(s))
+    train, val, test = [], [], []
+    for u in range(1, n_users + 1):
+        sl = int(min(L, 1 + rng.geometric(0.18)))
+        full = rng.integers(1, n_items, sl + 3).tolist()
+        train.append([u, pad(full[:sl]), pad(full[1:sl + 1]), sl, [1] * sl + [0] * (L - sl), [0] * L])
+        hv = full[:min(L, sl + 1)]
+        val.append([u, pad(hv), full[len(hv)], len(hv), 1, [0] * L, pad(hv)])
+        ht = full[:min(L, sl + 2)]
+        test.append([u, pad(ht), full[len(ht)], len(ht), 1, [0] * L, pad(ht)])
+    torch.save(train, os.path.join(d, "train_ori.pth"))
+    torch.save(val, os.path.join(d, "val.pth"))
+    torch.save(test, os.path.join(d, "test.pth"))
+    with open(os.path.join(d, "inter.csv"), "w") as f:
+        f.write("user_id,item_id,rating,timestamp,domain\n")
+        for i in range(1, n_items):
+            f.write(f"{(i - 1) % n_users + 1},{i},1.0,{i},0\n")
+    return train, val, test
+
+
+@pytest.mark.parametrize("model_name", ["SASRec", "GRU4Rec"])
+def test_fit_from_reference_on_disk_files(tmp_path, monkeypatch, model_name):
+    """§8(f)-2 on the GPU: `quickstart.run` on a dataset directory in the reference's own file format (`dataset_class: general`,
+    train_ori.pth / val.pth / test.pth / inter.csv) — first run parses the pickles and writes the packed images, second run trains
+    from the images; both see the same rows (same seed -> the same metrics up to the fp32 order of the table-gradient atomics),
+    checkpoints land where the reference puts them"""
+    from dr4sr_amd.quickstart import run
+    from dr4sr_amd.utils import load_config
+    train, val, test = _write_reference_files(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+
+    def cfg():
+        c = load_config({"model": model_name, "dataset": "amazon-toys"})
+        c["data"].update({"dataset": "disk-toys", "domain_name_list": ["toy"], "train_file": "_ori"})
+        c["train"].update({"epochs": 3, "batch_size": 64, "device": "cuda", "seed": 11})
+        c["eval"].update({"batch_size": 128})
+        return c
+
+    from dr4sr_amd.utils import seed_everything
+    seed_everything(11)                                        # the reference's run.py entry does this (utils/utils.py:14-20)
+    out1 = run(cfg())
+    d = tmp_path / "dataset" / "disk-toys" / "toy"
+    assert (d / "train_ori.pth.dr4srpk").exists() and (d / "val.pth.dr4srpk").exists() and (d / "test.pth.dr4srpk").exists()
+    calls = []
+    real_load = torch.load
+    monkeypatch.setattr(torch, "load", lambda *a, **k: calls.append(str(a[0])) or real_load(*a, **k))
+    seed_everything(11)
+    out2 = run(cfg())
+    assert not [c for c in calls if c.endswith(".pth")], calls           # the second run never unpickles the row lists
+    assert set(out1) == set(out2) and all(np.isfinite(v) for v in out1.values())
+    assert all(abs(out1[k] - out2[k]) < 0.03 for k in out1), (out1, out2)
+    assert len(list((tmp_path / "saved" / model_name / "disk-toys").glob("*.ckpt"))) == 2
