@@ -41,6 +41,8 @@ struct Workspace {
     float* dctx;                               // [T,D] scratch
     int4* de_rec;                              // [Tmax] scorer records {target id or 0, negative id, d pos score, d neg score} of the owner-computes table gradient
     int* idx32;                                // [Tmax] input item id per packed token (0 = contributes nothing), written by k_embqkv_fwd
+    int4* de_ent;                              // [3 Tmax] table-gradient entries of each token tile sorted by owner (linear.hip tile_sort)
+    unsigned char* de_off;                     // [Tmax / 32 + 1][1028] start offsets of the owners' buckets inside each tile's entries
     float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
     int64_t wT_stride;                         // floats per layer in wT
     float* score_part;                         // [B][2]  per-sequence (count, loss sum) of the scorer
@@ -95,6 +97,7 @@ struct WgradArgs {
     float* sc_dE; float* sc_dP; int sc_L; int sc_n_items;
     // owner-computes table gradient (large batches; ow_rec == NULL: the scorer / scatter job use fp32 atomics instead): blockIdx.y <
     // ow_planes are the owner workgroups, owner o = y * gridDim.x + x accumulates the rows {id : id mod 2^ow_logG == o}
+    const int4* ow_ent; const unsigned char* ow_off;     // per-tile entries sorted by owner + byte offset tables (k_post_mid's tile_sort); NULL: scan
     int ow_on; const int4* ow_rec; const int* ow_idx32; const float* ow_z; int ow_logG, ow_planes, ow_rpo;     // ow_rec == NULL: no scorer stream (autograd path)
 };
 

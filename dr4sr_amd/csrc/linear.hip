@@ -77,6 +77,25 @@ static bool scatter_in_wgrad(const Workspace& ws) {
 // summed row by row by owner workgroups inside k_wgrad (owner_job): deterministic, and ~55 us of a toys-shaped B = 8192 step
 // cheaper.  DR4SR_DE_ATOMIC (read per call) restores the atomics as a cross-check.
 static bool de_owner_mode(const Workspace& ws) { return scatter_in_wgrad(ws) && !getenv("DR4SR_DE_ATOMIC"); }
+// Owner geometry of the table gradient: G = 2^logG owners, the smallest power of two (>= 256) whose rows fit k_wgrad's LDS four
+// times (one private copy per wave) plus the queues.  Shared by the scorer launch (tile_sort needs G) and the k_wgrad launch.
+static size_t wgrad_lds_base(const dr4sr_sasrec_plan* p) {
+    const size_t D = p->D, F = p->F;
+    size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
+    if (sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;       // the scatter job's position-table accumulator
+    return lds;
+}
+static int owner_logG(const dr4sr_sasrec_plan* p) {
+    int logG = getenv("DR4SR_OWNER_LOGG") ? atoi(getenv("DR4SR_OWNER_LOGG")) : 8;      // tuning knob
+    const size_t lds = wgrad_lds_base(p);
+    while (sizeof(float) * 4 * (size_t)((p->n_items + (1 << logG) - 1) >> logG) * p->D + 4 * 16 * 4 * sizeof(int) > lds && logG < 20) ++logG;
+    return logG;
+}
+// tiles hand their entries over sorted by owner (tile_sort / owner_job_sorted) when the offset tables are byte-sized and small:
+// 32- or 64-row tiles, at most 1024 owners.  DR4SR_OWNER_SCAN (read per call) keeps the scanning owners as a cross-check.
+static bool owner_sorted(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    return de_owner_mode(ws) && tile_rows(ws) != 16 && owner_logG(p) <= 10 && !getenv("DR4SR_OWNER_SCAN");
+}
 #define BM_DISPATCH(bm, CALL) do { if ((bm) == 16) { CALL(16); } else if ((bm) == 32) { CALL(32); } else { CALL(64); } } while (0)
 
 int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s) {
@@ -526,6 +545,9 @@ struct ScoreTileArgs {
     const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq; int64_t* neg_item; float* part;
     int sample_neg, n_items, B, L;
     int4* rec;                                 // owner-computes table gradient: per-token records instead of atomics into dE (NULL: atomics)
+    // ... and the tile's table-gradient entries sorted by owner (tile_sort): ent [tiles][3 BM] int4, off [tiles][G + 4] bytes; NULL: the
+    // owners scan rec / idx32 themselves
+    int4* ent; unsigned char* off; const int* idx32; int logG;
     // MetaModel (DR4SR+) weighted loss, fused: weight_t = selection(z_t; phi) with the masks of metamodel.py:180-185; the loss
     // becomes sum_t weight_t loss_t and dz gains loss_t * d weight_t / d z_t.  phi == NULL: plain BCE.  (d phi is NOT produced
     // here: the inner step never uses it and the hyper-gradient takes it from the deterministic dr4sr_meta_select_bwd.)
@@ -618,13 +640,14 @@ __device__ __forceinline__ float meta_weight_token(const ScoreTileArgs& S, const
 
 // META: with the MetaModel selection weight (a separate instantiation — its registers cost the plain kernel an occupancy step)
 template <int BM, int D, bool META>
-__device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile) {
+__device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile, float* lrec_base) {
     constexpr int LPT = D / 4, TPB = 256 / LPT;
     const int c = (threadIdx.x % LPT) * 4, sub = threadIdx.x % LPT;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
     float lsum = 0.f, cnt = 0.f;
     float* dZ = const_cast<float*>(A.dz);
     const int bh = S.tile_seq[t0 >> 4];
+    int4* lrec = reinterpret_cast<int4*>(lrec_base);
 #pragma unroll
     for (int r0 = 0; r0 < BM; r0 += TPB) {
         const int r = r0 + threadIdx.x / LPT, t = t0 + r;
@@ -640,6 +663,7 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
             }
             ng = ng < 0 ? 0 : (ng >= S.n_items ? S.n_items - 1 : ng);
             float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (S.ent && sub == 1) reinterpret_cast<int*>(lrec + BM)[r] = S.idx32[t];
             if (tgt > 0 && tgt < S.n_items) {
                 const float4 q = ld4(A.z + (size_t)t * D + c), ep = ld4(S.E + tgt * D + c), en = ld4(S.E + ng * D + c);
                 const float sp = lane_group_sum<LPT>(q.x * ep.x + q.y * ep.y + q.z * ep.z + q.w * ep.w);
@@ -659,8 +683,11 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
                 if (!S.rec) {
                     unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
                     unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
-                } else if (sub == 0) S.rec[t] = make_int4((int)tgt, (int)ng, __float_as_int(dpos), __float_as_int(dneg));
-            } else if (S.rec && sub == 0) S.rec[t] = make_int4(0, 0, 0, 0);
+                } else if (sub == 0) {
+                    const int4 rec = make_int4((int)tgt, (int)ng, __float_as_int(dpos), __float_as_int(dneg));
+                    if (S.ent) lrec[r] = rec; else S.rec[t] = rec;
+                }
+            } else if (S.rec && sub == 0) { if (S.ent) lrec[r] = make_int4(0, 0, 0, 0); else S.rec[t] = make_int4(0, 0, 0, 0); }
             st4(dZ + (size_t)t * D + c, dz);
             if (pos == n - 1) {                               // tail positions of this sequence (zero query): loss terms only
                 for (int l = n + sub; l < S.L; l += LPT) {
@@ -683,6 +710,74 @@ __device__ __forceinline__ void score_tile(const PostArgs& A, const ScoreTileArg
     }
 }
 
+// Owner-computes table gradient, producer side.  A token tile contributes up to 3 BM rows to dE — (target, d pos score, z_t),
+// (negative, d neg score, z_t), (input id, 1, dx0_t) — and each belongs to the owner workgroup `id & (G - 1)` of k_wgrad's owner job.
+// Instead of every owner scanning every token of the batch (G x T record reads: the instruction-issue cost of that scan was
+// ~20 % of k_wgrad at B = 8192), the tile leaves its entries SORTED BY OWNER plus a [G + 1] table of start offsets (bytes: a
+// tile has at most 192 entries), so an owner reads two bytes per tile and then exactly its own entries: O(T) in total.  The
+// order inside a bucket is the entry index (token-major), a pure function of the batch: the gradient stays bit-reproducible.
+//   entry = {packed token, id >> logG (the owner's local row), coefficient bits, source (0: query rows z, 1: dx0 rows)}
+// Runs between the two halves of k_post_mid: the tile regions of LDS are free, `scratch` = their base.
+// LDS of tile_sort, private to it (behind the scorer's reduction scratch): [BM] int4 records | [BM] int input ids | [G + 4] int histogram / offsets | [4] int
+__host__ __device__ constexpr int tile_sort_lds_bytes(int bm, int G) { return bm * 20 + (G + 4 + 4) * 4; }
+template <int BM>
+__device__ __forceinline__ void tile_sort_init(const ScoreTileArgs& S, float* area) {     // at kernel start: nothing else touches the area
+    int* hist = reinterpret_cast<int*>(area) + 5 * BM;
+    for (int g = threadIdx.x; g < (1 << S.logG) + 4; g += 256) hist[g] = 0;
+}
+template <int BM>
+__device__ __forceinline__ void tile_sort(const ScoreTileArgs& S, const int tile, const int t0, const int T, float* area) {
+    constexpr int E = 3 * BM, EPL = (E + 63) / 64;        // wave 0 takes every entry: EPL per lane, in entry order
+    static_assert(E <= 255, "byte offsets");
+    const int G = 1 << S.logG, per = G >> 8;              // G in {256, 512, 1024}: `per` consecutive buckets per thread in the scan
+    const int4* lrec = reinterpret_cast<const int4*>(area);
+    const int* lidx = reinterpret_cast<const int*>(area) + 4 * BM;
+    int* hist = reinterpret_cast<int*>(area) + 5 * BM;    // [G + 4], zero since tile_sort_init
+    int* wsum = hist + G + 4;                             // [4]
+    const bool w0 = threadIdx.x < 64;
+    lds_barrier();                                        // the scorer's records and input ids are in LDS (LDS-only hand-offs: no vmcnt drain)
+    // rank inside the bucket = value returned by the LDS counter: the entries of one instruction are served in lane order and the
+    // instructions of the one wave in program order, so the order is the entry index (a function of the batch; checked by the
+    // bit-reproducibility tests)
+    int4 ent[EPL]; int k[EPL], rank[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int e = threadIdx.x + 64 * j, r = e / 3, kind = e % 3, t = t0 + r;
+        k[j] = -1; rank[j] = 0; ent[j] = make_int4(0, 0, 0, 0);
+        if (w0 && e < E && t < T) {
+            int id = kind == 2 ? lidx[r] : 0, cf = __float_as_int(1.0f);
+            if (kind < 2) {
+                const int4 rec = lrec[r];
+                id = rec.x > 0 ? (kind ? rec.y : rec.x) : 0; cf = kind ? rec.w : rec.z;
+            }
+            if (id > 0) { k[j] = id & (G - 1); ent[j] = make_int4(t, id >> S.logG, cf, kind == 2); rank[j] = atomicAdd(&hist[k[j]], 1); }
+        }
+    }
+    lds_barrier();
+    // exclusive scan of hist[0..G) -> start offsets (in place), hist[G] = the tile's entry count
+    int loc[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { loc[j] = j < per ? hist[threadIdx.x * per + j] : 0; sum += loc[j]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += u; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    lds_barrier();
+    int ex = incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) ex += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < per) { hist[threadIdx.x * per + j] = ex; ex += loc[j]; }
+    if (threadIdx.x == 255) hist[G] = ex;
+    lds_barrier();
+    unsigned* offw = reinterpret_cast<unsigned*>(S.off + (size_t)tile * (G + 4));
+    for (int q = threadIdx.x; q < (G + 4) / 4; q += 256)
+        offw[q] = (unsigned)hist[4 * q] | ((unsigned)hist[4 * q + 1] << 8) | ((unsigned)hist[4 * q + 2] << 16) | ((unsigned)hist[4 * q + 3] << 24);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j)
+        if (k[j] >= 0) S.ent[(size_t)tile * E + hist[k[j]] + rank[j]] = ent[j];
+    // the area stays private to the next tile_sort of this workgroup (one tile per workgroup: none)
+}
+
 __host__ __device__ constexpr int post_lds_floats(int D, int F, int bm) {
     return bm * ((D + 4) + ((D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4));     // R0+R2 must hold a [BM][3D+4] tile
 }
@@ -694,7 +789,7 @@ __host__ __device__ constexpr int post_lds_floats(int D, int F, int bm) {
 template <int BM>
 struct ScorePre {
     static constexpr int PASSES = BM / 16;
-    int b[PASSES], pos[PASSES], n[PASSES]; int64_t row[PASSES], tgt[PASSES], ng[PASSES]; float4 ep[PASSES], en[PASSES]; bool ok[PASSES];
+    int b[PASSES], pos[PASSES], n[PASSES], idin[PASSES]; int64_t row[PASSES], tgt[PASSES], ng[PASSES]; float4 ep[PASSES], en[PASSES]; bool ok[PASSES];
 };
 template <int BM>
 __device__ __forceinline__ void score_prefetch(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, ScorePre<BM>& P) {
@@ -707,6 +802,7 @@ __device__ __forceinline__ void score_prefetch(const PostArgs& A, const ScoreTil
         const int t = t0 + ps * 16 + (threadIdx.x >> 4);
         P.ok[ps] = t < T;
         P.b[ps] = 0; P.pos[ps] = 0; P.n[ps] = 0; P.row[ps] = 0; P.tgt[ps] = 0; P.ng[ps] = 0;
+        P.idin[ps] = (S.ent && P.ok[ps]) ? S.idx32[t] : 0;
         P.ep[ps] = make_float4(0.f, 0.f, 0.f, 0.f); P.en[ps] = P.ep[ps];
         if (P.ok[ps]) {
             const int b = find_seq_from(S.cu, S.B, t, bh), c0 = S.cu[b];
@@ -733,6 +829,7 @@ __device__ __forceinline__ void score_prefetch(const PostArgs& A, const ScoreTil
 template <int BM, bool META>
 __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTileArgs& S, const int t0, const int T, const int tile,
                                                 const ScorePre<BM>& P, const float4 (*zreg)[1], float4 (*dzreg)[1], float* red, float* lds_tile) {
+    int4* lrec = reinterpret_cast<int4*>(red + 8);        // [BM] the tile's records for tile_sort (S.ent), instead of S.rec in global memory
     constexpr int D = 64, LPT = 16, LD = D + 4, PASSES = ScorePre<BM>::PASSES;
     const int c = (threadIdx.x & 15) * 4, sub = threadIdx.x & 15;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
@@ -874,7 +971,8 @@ __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTi
                     rec = make_int4((int)tgt, (int)ng, __float_as_int(dpos), __float_as_int(dneg));
                 }
             }
-            if (S.rec && sub == 0) S.rec[t] = rec;
+            if (S.rec && sub == 0) { if (S.ent) lrec[ps * 16 + (threadIdx.x >> 4)] = rec; else S.rec[t] = rec; }
+            if (S.ent && sub == 1) reinterpret_cast<int*>(lrec + BM)[ps * 16 + (threadIdx.x >> 4)] = P.idin[ps];
             if (pos == n - 1) {                               // tail positions of this sequence (zero query): loss terms only
                 for (int l = n + sub; l < S.L; l += LPT) {
                     const int64_t tl = S.target[row * S.L + l];
@@ -899,6 +997,7 @@ template <int BM, int D, int F, bool META>
 __global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) {
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
+    if constexpr (BM != 16) { if (S.ent) tile_sort_init<BM>(S, smem + post_lds_floats(D, F, BM) + 8); }
     if constexpr (D == 64) {
         ScorePre<BM> P;
         if constexpr (BM == 16) score_prefetch<BM>(A, S, t0, T, P);             // latency regime: ahead of the forward half
@@ -909,11 +1008,13 @@ __global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreT
         if constexpr (BM != 16) score_prefetch<BM>(A, S, t0, T, P);             // occupancy regime: its registers would cost a workgroup per CU
         if constexpr (META) lds_barrier();                   // every wave is past the forward half's last LDS reads: the tiles are free
         score_tile_regs<BM, META>(A, S, t0, T, blockIdx.x, P, zreg, dzreg, smem + post_lds_floats(D, F, BM), smem);
+        if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, blockIdx.x, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
         post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, dzreg);
     } else {
         post_fwd_body<BM, D, F, false>(A, t0, T);
         __syncthreads();                               // z rows of this tile are visible to the whole workgroup
-        score_tile<BM, D, META>(A, S, t0, T, blockIdx.x);
+        score_tile<BM, D, META>(A, S, t0, T, blockIdx.x, smem + post_lds_floats(D, F, BM) + 8);
+        if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, blockIdx.x, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
         __syncthreads();                               // dz rows written, LDS scratch free again
         post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x);
     }
@@ -966,7 +1067,7 @@ static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const
 template <int BM>
 static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, const ScoreTileArgs& S, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
-    const size_t lds = post_lds(p->D, p->F, BM) + 8 * sizeof(float);       // + the scorer's (count, loss) reduction scratch
+    const size_t lds = post_lds(p->D, p->F, BM) + 8 * sizeof(float) + (S.ent ? tile_sort_lds_bytes(BM, 1 << S.logG) : 0);   // + the scorer's (count, loss) reduction scratch + tile_sort's records
 #define PM(D_, F_) do { big_lds(k_post_mid<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_, false>), grid, blk, lds, s, A, S); } while (0)
     if (S.phi) {                                       // MetaModel weighting: D = 64 only (checked by the entry point)
         if (p->D != 64 || p->F != 128) return DR4SR_E_SHAPE;
@@ -988,6 +1089,8 @@ int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int trainin
     S.E = p->params + ws.off[0]; S.dE = p->grads + ws.off[0]; S.target = p->item_id; S.rows = p->rows; S.cu = ws.cu; S.tile_seq = ws.tile_seq;
     S.neg_item = p->neg_item; S.part = ws.score_part; S.sample_neg = p->sample_neg; S.n_items = p->n_items; S.B = p->B; S.L = p->L;
     S.rec = de_owner_mode(ws) ? ws.de_rec : nullptr;
+    S.ent = nullptr; S.off = nullptr; S.idx32 = ws.idx32; S.logG = 0;
+    if (owner_sorted(p, ws)) { S.ent = ws.de_ent; S.off = ws.de_off; S.logG = owner_logG(p); }
     S.phi = nullptr; S.gumbel = nullptr; S.user_id = nullptr; S.gate_in = nullptr; S.gate_out = nullptr; S.w_out = nullptr; S.inv_tau = 1.f;
     S.meta_seed = p->seed;
     if (mw) {
@@ -1431,6 +1534,81 @@ __device__ __forceinline__ void owner_job(const WgradArgs& A, const int owner) {
     }
 }
 
+// The same owner job fed by k_post_mid's tile_sort: wave w walks a quarter of the token TILES reading, per tile, the two bytes that
+// bracket this owner's bucket (64 tiles per load instruction, CH instructions in flight), then exactly its own entries.  An entry
+// is requested by lane `qn` the moment it is queued, so its round trip overlaps the rest of the scan; the flush hands the queued
+// entries to every lane through LDS and gathers the sixteen source rows together, as above.  Work per owner: T / BM offset pairs +
+// 3 T / G entries instead of T records.
+template <int D>
+__device__ __forceinline__ void owner_job_sorted(const WgradArgs& A, const int owner) {
+    constexpr int NW = 4, VPL = D / 64, QN = 16;
+    const int G = 1 << A.ow_logG;
+    if (owner >= G) return;
+    const int T = A.state[DR4SR_STATE_T], lane = threadIdx.x & 63, w = threadIdx.x >> 6, rpo = A.ow_rpo;
+    const int bm = A.ln_tile_rows, E = 3 * bm, ntiles = (T + bm - 1) / bm, OS = G + 4;
+    float* acc = smem + (size_t)w * rpo * D;
+    int4* qw = reinterpret_cast<int4*>(smem + (size_t)NW * rpo * D) + w * QN;          // per-wave queue of entries
+    for (int i = lane; i < rpo * D; i += 64) acc[i] = 0.f;
+    const int Tq = ((ntiles + NW * 64 - 1) / (NW * 64)) * 64, ia = w * Tq, ib = min(ntiles, ia + Tq);
+    int qn = 0;
+    int4 pend = make_int4(0, 0, 0, 0);
+    auto flush = [&]() {
+        if (lane < qn) qw[lane] = pend;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float v[QN][VPL]; int lr[QN]; float cf[QN];
+#pragma unroll
+        for (int k = 0; k < QN; ++k) {
+            lr[k] = 0; cf[k] = 0.f;
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) v[k][u] = 0.f;
+            if (k < qn) {
+                const int4 e = qw[k];
+                lr[k] = e.y; cf[k] = __int_as_float(e.z);
+                const float* src = (e.w ? A.sc_g : A.ow_z) + (size_t)e.x * D + lane;
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) v[k][u] = src[64 * u];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QN; ++k)
+            if (k < qn) {
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) acc[lr[k] * D + lane + 64 * u] = fmaf(cf[k], v[k][u], acc[lr[k] * D + lane + 64 * u]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        qn = 0;
+    };
+    constexpr int CH = 4;
+    for (int base = ia; base < ib; base += 64 * CH) {
+        int lo[CH], hi[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int i = base + 64 * k + lane;
+            lo[k] = 0; hi[k] = 0;
+            if (i < ib) { const unsigned char* o = A.ow_off + (size_t)i * OS + owner; lo[k] = o[0]; hi[k] = o[1]; }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            unsigned long long m = __ballot(hi[k] > lo[k]);
+            while (m) {
+                const int L = __ffsll((long long)m) - 1; m &= m - 1;
+                const int tile = base + 64 * k + L, e0 = __builtin_amdgcn_readlane(lo[k], L), e1 = __builtin_amdgcn_readlane(hi[k], L);
+                for (int e = e0; e < e1; ++e) {
+                    if (lane == qn) pend = A.ow_ent[(size_t)tile * E + e];
+                    if (++qn == QN) flush();
+                }
+            }
+        }
+    }
+    flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < rpo * D; i += 256) {
+        const float sum = (smem[i] + smem[(size_t)rpo * D + i]) + (smem[(size_t)2 * rpo * D + i] + smem[(size_t)3 * rpo * D + i]);
+        const int id = ((i / D) << A.ow_logG) | owner;
+        if (sum != 0.f && id < A.sc_n_items) A.sc_dE[(size_t)id * D + (i % D)] += sum;
+    }
+}
+
 // blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2, 6: reductions; with the embedding scatter: y = 0 is the scatter
 // [layer 0 only] and the others shift by one), blockIdx.z = layer
 template <int D, int F>
@@ -1448,7 +1626,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A, const QkvEmbBw
     // the scatter blocks come FIRST in dispatch order (y = 0): the other jobs are persistent loops, so blocks dispatched after
     // the first resident wave would only start when those finish — no overlap
     // (owner planes first, then the dP / atomic scatter plane)
-    if (A.ow_on && (int)blockIdx.y < A.ow_planes) { if (layer == 0) owner_job<D>(A, blockIdx.y * gridDim.x + blockIdx.x); return; }
+    if (A.ow_on && (int)blockIdx.y < A.ow_planes) {
+        if (layer == 0) { if (A.ow_ent) owner_job_sorted<D>(A, blockIdx.y * gridDim.x + blockIdx.x); else owner_job<D>(A, blockIdx.y * gridDim.x + blockIdx.x); }
+        return;
+    }
     const int j = (int)blockIdx.y - (A.ow_on ? A.ow_planes : 0) - (A.sc_g ? 1 : 0);
     if (j < 0) { if (layer == 0) scatter_job<D>(A); return; }
     if (j == 6) { reduce_jobs(A, layer); return; }
@@ -1542,14 +1723,14 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     const QkvEmbBwdArgs Q = make_qeb_args(p, ws, training);
     size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
     if (scatter && sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;
+    A.ow_ent = nullptr; A.ow_off = nullptr;
     A.ow_on = 0; A.ow_rec = nullptr; A.ow_idx32 = nullptr; A.ow_z = nullptr; A.ow_logG = 0; A.ow_planes = 0; A.ow_rpo = 0;
     if (scatter && de_owner_mode(ws)) {
         // owners = the smallest power of two (>= 256) whose rows fit the launch's LDS four times (one private copy per wave) + queues
-        int logG = getenv("DR4SR_OWNER_LOGG") ? atoi(getenv("DR4SR_OWNER_LOGG")) : 8;      // tuning knob
-        auto rpo_of = [&](int lg) { return (p->n_items + (1 << lg) - 1) >> lg; };
-        while (sizeof(float) * 4 * rpo_of(logG) * D + 4 * 16 * 4 * sizeof(int) > lds && logG < 20) ++logG;
-        A.ow_on = 1; A.ow_logG = logG; A.ow_rpo = rpo_of(logG); A.ow_planes = ((1 << logG) + gw - 1) / gw;
+        const int logG = owner_logG(p);
+        A.ow_on = 1; A.ow_logG = logG; A.ow_rpo = (p->n_items + (1 << logG) - 1) >> logG; A.ow_planes = ((1 << logG) + gw - 1) / gw;
         A.ow_rec = with_score == 2 ? ws.de_rec : nullptr; A.ow_idx32 = ws.idx32; A.ow_z = ws.X[p->n_layer];
+        if (with_score == 2 && owner_sorted(p, ws)) { A.ow_ent = ws.de_ent; A.ow_off = ws.de_off; }
     }
     dim3 grid(gw, (scatter ? 8 : 7) + A.ow_planes, p->n_layer + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D);

@@ -85,6 +85,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
     ws->dctx = take(Tmax * D);
     ws->de_rec = (int4*)take(Tmax * 4); ws->idx32 = (int*)take(Tmax);
+    ws->de_ent = (int4*)take(Tmax * 12); ws->de_off = (unsigned char*)take((Tmax / 32 + 1) * 257);
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
     ws->score_part = take(2LL * (p->B > (Tmax + 15) / 16 ? p->B : (Tmax + 15) / 16));   // per sequence, or per token tile (fused last layer)

@@ -170,7 +170,8 @@ def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, D, B, p):
         assert relerr(gv, g_tiny[k].cpu()) < 2e-5, k
 
 
-@pytest.mark.parametrize("D,B,p,n_items", [(64, 2048, 0.0, 3000), (64, 4096, 0.5, 11925), (128, 1024, 0.2, 20034), (64, 1024, 0.0, 70000)])
+@pytest.mark.parametrize("D,B,p,n_items", [(64, 2048, 0.0, 3000), (64, 4096, 0.5, 11925), (128, 1024, 0.2, 20034), (64, 1024, 0.0, 70000),
+                                           (64, 2048, 0.0, 30000)])
 def test_owner_computed_table_gradient(monkeypatch, D, B, p, n_items):
     """large batches: the item-table gradient is summed row by row by owner workgroups inside k_wgrad (csrc/linear.hip owner_job)
     instead of fp32 atomics from the scorer and the embedding scatter.  (1) it equals the atomic path (DR4SR_DE_ATOMIC) to fp32
@@ -209,6 +210,27 @@ def test_owner_computed_table_gradient(monkeypatch, D, B, p, n_items):
     ga = eng.grads.clone()
     assert relerr(g1[:nE], ga[:nE].cpu()) < 2e-5
     assert relerr(g1[nE:], ga[nE:].cpu()) < 2e-5
+    # (5) the two feeds of the owner job — entries sorted by owner per token tile (k_post_mid's tile_sort, the default up to 1024
+    # owners) and owners scanning every record (DR4SR_OWNER_SCAN; the only form above 1024 owners: the 70 000-item case) — agree
+    monkeypatch.delenv("DR4SR_DE_ATOMIC")
+    monkeypatch.setenv("DR4SR_OWNER_SCAN", "1")
+    eng.state[3] -= 1
+    eng.fwd_bwd(plan)
+    gs = eng.grads.clone()
+    eng.state[3] -= 1
+    eng.fwd_bwd(plan)
+    assert torch.equal(gs[:nE], eng.grads[:nE]), "scanning owners must be bit-reproducible too"
+    assert relerr(g1[:nE], gs[:nE].cpu()) < 2e-5 and relerr(g1[nE:], gs[nE:].cpu()) < 2e-5
+
+
+def test_owner_sorted_entries_with_64_row_tiles():
+    """DR4SR_BM=64 (static switch: subprocess): tile_sort with 192 entries per tile (three per lane of the sorting wave) at scale"""
+    e = dict(os.environ, DR4SR_BM="64")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "test_owner_computed_table_gradient and (3000 or 11925)", os.path.abspath(__file__)],
+                       env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0 and "3 passed" in r.stdout, tail           # the 3000-, 11925- and 30000-item cases
 
 
 def test_fuzz_large_batches_vs_oracle():
