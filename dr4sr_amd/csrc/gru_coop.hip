@@ -27,7 +27,10 @@ extern __shared__ __attribute__((aligned(16))) float smem[];
 
 namespace {
 
-constexpr int NS = 8;                           // slices (workgroups) per group of 16 sequences
+// slices (workgroups) per group of 16 sequences: 8, or 16 when the batch has at most 16 groups and H = 256 (a step's MFMA chain —
+// 6.3 MFLOP on one group's CUs, 1.28 us on 8 of them — is the largest item of the 3.5 us step; 16 groups x 16 slices = one
+// workgroup per CU of an MI355X)
+constexpr int coop_threads(int H, int NS) { return ((H / NS) / 16) * 4 * 64; }
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 typedef unsigned long long u64;
@@ -91,10 +94,10 @@ __device__ __forceinline__ void finish_launch(int* ctl) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int H>
-__global__ __launch_bounds__(H * 2) void k_gru_fwd_coop(const CoopArgs A) {
+template <int H, int NS>
+__global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_fwd_coop(const CoopArgs A) {
     constexpr int US = H / NS, UTL = US / 16, NW = UTL * 4, NT = NW * 64, LDW = H + 4, LDH = H + 4;
-    static_assert(NT == H * 2, "thread count");
+    static_assert(US % 16 == 0 && NT == coop_threads(H, NS) && 16 * US <= NT && (16 * H) % NT == 0, "slice geometry");
     float* Ws = smem;                                     // [3*US][LDW]  this slice's rows of W_hh (gate-major)
     float* hA = Ws + 3 * US * LDW;                        // [16][LDH]    h_{t-1} of the group's 16 sequences
     float* part = hA + 16 * LDH;                          // [4 kq][3][16][US]
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(H * 2) void k_gru_fwd_coop(const CoopArgs A) {
 // Per step (t descending): dh = dhout[t] + carry for the slice's own units; gate derivatives -> the slice's dgh tile [16][3*US]
 // (LDS) and dgi/dgh rows (global); partial[16][H] = dgh_tile . W_hh[slice rows][:] on MFMA (W rows read column-wise);
 // reduce-scatter over the 8 slices: carry'[own units] = dh*z + sum_slices partial[:, own units].
-template <int H>
-__global__ __launch_bounds__(H * 2) void k_gru_bwd_coop(const CoopArgs A) {
+template <int H, int NS>
+__global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_bwd_coop(const CoopArgs A) {
     constexpr int US = H / NS, UTL = US / 16, NW = UTL * 4, NT = NW * 64, LDW = H + 4, KL = 3 * US, LDG = KL + 4;
     constexpr int CTW = (H / 16) / NW;                    // output column tiles per wave
     float* Ws = smem;                                     // [3*US][LDW]
@@ -279,72 +282,84 @@ __global__ __launch_bounds__(H * 2) void k_gru_bwd_coop(const CoopArgs A) {
     finish_launch(A.ctl);
 }
 
-template <int H> size_t coop_lds(bool bwd) {
+template <int H, int NS> size_t coop_lds(bool bwd) {
     constexpr int US = H / NS;
     return sizeof(float) * (3 * US * (H + 4) + (bwd ? 16 * (3 * US + 4) : 16 * (H + 4) + 4 * 3 * 16 * US)) + 32 * sizeof(int);
 }
 
 }  // namespace
 
-// Workgroups the cooperative recurrence may use on the CURRENT device: every one of them must be resident at once (one per CU,
-// ~140 KB of LDS each), so the budget follows the device's CU count — three quarters of it, at most 192 — instead of assuming a
-// full 256-CU MI355X (a CPX / DPX partition or a smaller part gets a smaller budget or none).  Cached per device.
-static int coop_block_budget() {
-    static int budget[64];
+// Compute units of the CURRENT device (cached): the cooperative recurrence needs every workgroup of the launch resident at once,
+// so its budget follows the device — a CPX / DPX partition or a smaller part gets a smaller budget or none.
+static int device_cus() {
+    static int cus[64];
     static bool known[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     if (!known[dev]) {
         hipDeviceProp_t prop;
-        int b = 0;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-            b = (prop.multiProcessorCount * 3) / 4;
-            if (b > 192) b = 192;
-        }
-        budget[dev] = b;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
         known[dev] = true;
     }
-    return budget[dev];
+    return cus[dev];
+}
+// Slices per group for a batch (0 = the batch does not qualify for the cooperative path).
+//   16 slices (H = 256, at most 16 groups): 79 KB of LDS per workgroup, two fit a CU, so 256 workgroups are resident on a 256-CU
+//     device with room to spare (budget: one per CU);
+//    8 slices: 140 KB, one per CU — budget three quarters of the CUs, at most 192 workgroups (24 groups).
+static int coop_slices(int B, int H) {
+    if (getenv("DR4SR_GRU_NOCOOP") || (H != 128 && H != 256)) return 0;
+    const int groups = (B + 15) / 16, g8 = ((groups + 7) / 8) * 8, cus = device_cus();
+    static const bool no16 = getenv("DR4SR_GRU_NS8") != nullptr;             // cross-check switch: always 8 slices
+    if (H == 256 && !no16 && g8 * 16 <= cus) return 16;
+    int b8 = cus * 3 / 4;
+    if (b8 > 192) b8 = 192;
+    return g8 * 8 <= b8 ? 8 : 0;
 }
 
 // granule words needed by the cooperative path for a batch of B sequences (0 = the batch does not qualify)
 int64_t gru_coop_words(int B, int H) {
-    const int groups = (B + 15) / 16;
-    if (getenv("DR4SR_GRU_NOCOOP") || ((groups + 7) / 8) * 8 * NS > coop_block_budget()) return 0;
-    return (int64_t)groups * 2 * NS * 16 * H;
+    const int groups = (B + 15) / 16, ns = coop_slices(B, H);
+    return (int64_t)groups * 2 * ns * 16 * H;
 }
-extern "C" int dr4sr_gru4rec_uses_cooperative(int32_t B, int32_t H) { return (H == 128 || H == 256) && gru_coop_words(B, H) != 0; }
+extern "C" int dr4sr_gru4rec_uses_cooperative(int32_t B, int32_t H) { return gru_coop_words(B, H) != 0; }
 
 // returns -100 when the batch does not qualify (caller falls back to the single-workgroup recurrence)
 int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float* r, float* z, float* n, float* ghn, float* hprev,
                         float* hout, const float* dhout, float* dgi, float* dgh, unsigned long long* xch, int* ctl, int B, int H, bool bwd,
                         hipStream_t s) {
-    if (!xch || !ctl || gru_coop_words(B, H) == 0) return -100;
+    const int ns = coop_slices(B, H);
+    if (!xch || !ctl || ns == 0) return -100;
     CoopArgs A;
     A.gi = gi; A.whh = whh; A.cu = cu; A.r = r; A.z = z; A.n = n; A.ghn = ghn; A.hprev = hprev; A.hout = hout;
     A.dhout = dhout; A.dgi = dgi; A.dgh = dgh; A.xch = xch; A.ctl = ctl; A.B = B;
     const int groups = (B + 15) / 16;
-    dim3 grid(((groups + 7) / 8) * 8 * NS), blk(H * 2);          // groups rounded up to a multiple of 8 (XCD placement); extra blocks exit
-    // the runtime must be able to place one such workgroup on a CU at all (register / LDS limits of THIS device); asked once per kernel
-    auto resident = [&](const void* k, size_t lds) {
+    dim3 grid(((groups + 7) / 8) * 8 * ns), blk(coop_threads(H, ns));       // groups rounded up to a multiple of 8 (XCD placement); extra blocks exit
+    // the runtime must be able to place such workgroups on a CU at all (register / LDS limits of THIS device); asked once per kernel
+    auto resident = [&](const void* k, size_t lds, int per_cu) {
         static std::unordered_map<const void*, int> okmap;
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
         auto it = okmap.find(k);
-        if (it != okmap.end()) return it->second > 0;
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, H * 2, lds) != hipSuccess) nb = 0;
-        okmap[k] = nb;
-        return nb > 0;
+        if (it == okmap.end()) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, blk.x, lds) != hipSuccess) nb = 0;
+            it = okmap.emplace(k, nb).first;
+        }
+        return it->second >= per_cu;
     };
-    if (H == 256) {
-        const size_t lds = coop_lds<256>(bwd);
-        if (!bwd) { big_lds(k_gru_fwd_coop<256>, lds); if (!resident((const void*)k_gru_fwd_coop<256>, lds)) return -100; hipLaunchKernelGGL(k_gru_fwd_coop<256>, grid, blk, lds, s, A); }
-        else { big_lds(k_gru_bwd_coop<256>, lds); if (!resident((const void*)k_gru_bwd_coop<256>, lds)) return -100; hipLaunchKernelGGL(k_gru_bwd_coop<256>, grid, blk, lds, s, A); }
-    } else if (H == 128) {
-        const size_t lds = coop_lds<128>(bwd);
-        if (!bwd) { big_lds(k_gru_fwd_coop<128>, lds); if (!resident((const void*)k_gru_fwd_coop<128>, lds)) return -100; hipLaunchKernelGGL(k_gru_fwd_coop<128>, grid, blk, lds, s, A); }
-        else { big_lds(k_gru_bwd_coop<128>, lds); if (!resident((const void*)k_gru_bwd_coop<128>, lds)) return -100; hipLaunchKernelGGL(k_gru_bwd_coop<128>, grid, blk, lds, s, A); }
-    } else return DR4SR_E_SHAPE;
+#define COOP_LAUNCH(H_, NS_, PER_CU) do { \
+        const size_t lds = coop_lds<H_, NS_>(bwd); \
+        if (!bwd) { big_lds(k_gru_fwd_coop<H_, NS_>, lds); if (!resident((const void*)k_gru_fwd_coop<H_, NS_>, lds, PER_CU)) return -100; \
+                    hipLaunchKernelGGL((k_gru_fwd_coop<H_, NS_>), grid, blk, lds, s, A); } \
+        else { big_lds(k_gru_bwd_coop<H_, NS_>, lds); if (!resident((const void*)k_gru_bwd_coop<H_, NS_>, lds, PER_CU)) return -100; \
+               hipLaunchKernelGGL((k_gru_bwd_coop<H_, NS_>), grid, blk, lds, s, A); } } while (0)
+    // 16 slices: the budget counted one workgroup per CU, but the launch must not depend on a perfectly even placement: require
+    // room for two per CU
+    if (H == 256 && ns == 16) COOP_LAUNCH(256, 16, 2);
+    else if (H == 256) COOP_LAUNCH(256, 8, 1);
+    else if (H == 128) COOP_LAUNCH(128, 8, 1);
+    else return DR4SR_E_SHAPE;
+#undef COOP_LAUNCH
     return DR4SR_LAUNCH_CHECK();
 }

@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 Tmax = B * L
 r = lambda nfl: (nfl * 4 + 255) // 256 * 256
-off = r(B + 1) + r((Tmax + 15) // 16 + 1) + 2 * (NL + 1) * r(Tmax * D)
+off = r(B + 1) + r((Tmax + 15) // 16 + 1) + r(4 + 7 * B) + r(B) + r(Tmax * H) + 2 * (NL + 1) * r(Tmax * D)      # csrc/step.hip carve_workspace: ... -> dctx
 os.environ["DR4SR_STAMPS"] = "1"
 for kind, layer in (("post_fwd", 0), ("post_fwd", 1)):
     kid = _lib.KERNEL_IDS[kind]
@@ -31,5 +31,6 @@ for kind, layer in (("post_fwd", 0), ("post_fwd", 1)):
         _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), kind)
     b.record(); b.synchronize()
     st = eng.workspace[off:off + 16 * 8].view(torch.int64).cpu().numpy()
+    assert st[15] > st[0], "stamp buffer offset is stale"
     d = np.diff(st[[0, 1, 2, 3, 4, 5, 6, 15]])
     print(kind, layer, "us/launch %.2f" % (a.elapsed_time(b) * 1e3 / 20), "phase ticks", d.tolist(), "total", int(st[15] - st[0]))
