@@ -2,10 +2,12 @@
 //
 // The single-workgroup recurrence of gru.hip (16 sequences per workgroup, W_hh streamed from L2) is bound by one CU's fp32
 // MFMA pipe: 6.3 MFLOP per time step = ~11 us, and a B = 256 batch occupies 16 of the 256 CUs.  Here a group of 16 sequences
-// is spread over NS = 8 workgroups (8 CUs): slice s owns hidden units [s*H/8, (s+1)*H/8) of all three gates, keeps its
-// 3*H/8 rows of W_hh RESIDENT in LDS for the whole launch (98 KB at H = 256) and needs 1/8 of the MFMA work per step; the
-// price is one all-gather of h_t (forward) / one reduce-scatter of the dh partials (backward) per time step between the 8
-// workgroups of a group, INSIDE the launch.
+// is spread over NS workgroups (NS CUs): slice s owns hidden units [s*H/NS, (s+1)*H/NS) of all three gates, keeps its
+// 3*H/NS rows of W_hh RESIDENT in LDS for the whole launch and needs 1/NS of the MFMA work per step; the price is one
+// all-gather of h_t (forward) / one reduce-scatter of the dh partials (backward) per time step between the NS workgroups of a
+// group, INSIDE the launch.  NS = 8 (98 KB of weights per slice, one workgroup per CU, up to 24 groups) or, for batches of at
+// most 16 groups at H = 256, NS = 16 (49 KB, 4 waves per slice): the step's MFMA chain halves (1.28 -> 0.64 us of a 3.5 us
+// step) and 16 groups x 16 slices put one workgroup on every CU of an MI355X — B = 256: 288 k -> 343 k sequences/s.
 //
 // Exchange protocol (cdna_hip_programming.md §6 Guideline 16, form R2 "the data is the flag"): every exchanged float travels
 // as ONE aligned 8-byte granule {tag, value} written with a relaxed agent-scope store (sc1, write-through) and polled with
@@ -13,9 +15,9 @@
 // placement of the workgroups over XCDs.  Two granule buffers alternate by step parity (a slice can only produce step t+2
 // after every slice has consumed step t).  Epochs are unique across launches: epoch = 64 * launch_counter + step + 1 with the
 // launch counter kept in a device word that the last workgroup to finish increments, so nothing has to be re-zeroed per call
-// (the exchange area must be zero once, when the workspace is created).  All 8*ceil(B/16) workgroups must be co-resident
-// (one per CU, ~140 KB LDS): the launcher only takes this path when they fit with margin; spins are bounded and a timeout
-// raises a device error word instead of hanging.
+// (the exchange area must be zero once, when the workspace is created).  All NS*ceil(B/16) workgroups must be co-resident
+// (NS = 8: one per CU, ~140 KB LDS; NS = 16: 79 KB, two fit a CU): the launcher only takes this path when they fit with
+// margin (coop_slices); spins are bounded and a timeout raises a device error word instead of hanging.
 #include "common.h"
 #include "kernels.h"
 
