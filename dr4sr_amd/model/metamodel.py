@@ -256,6 +256,24 @@ class MetaModel(BaseModel):
         tail[1:2].copy_(torch.dot(w, lp).view(1))      # reported loss only
         return w, lp
 
+    def _phi_only(self, batch, gate_in):
+        """d/dphi of sum_p weight_p loss_p at the current sub-model parameters, WITHOUT the encoder's backward: d weight_p / d phi
+        needs the query rows and the per-position losses only.  The two mixed-derivative probes of the hyper-gradient
+        (utils/utils.py:170-178) want exactly this; d/dW of those evaluations was computed and thrown away before.  Leaves
+        d/dphi in self._phi.grads and n_valid in the gradient tail (everything else in engine.grads is zero)."""
+        sub, eng, lib = self.sub_model, self.engine, self.lib
+        tgt, neg, uid = batch[self.fiid].contiguous(), batch["neg_item"].contiguous(), batch["user_id"].contiguous()
+        B, L = self._bl(tgt)
+        eng.grads.zero_()
+        self._phi.grads.zero_()
+        self._stats.zero_()
+        q = sub._encode_raw(batch, True)
+        lp = self._buf("lp", B * L)
+        _lib.check(lib.dr4sr_score_bce_fwd(_lib.ptr(q), _lib.ptr(self.item_embedding.weight), _lib.ptr(tgt), _lib.ptr(neg), None, None,
+                                           _lib.ptr(lp), _lib.ptr(self._stats), B, L, eng.D, _lib.cur_stream()), "score_bce_fwd")
+        self._select_bwd(q, uid, tgt, self._gumbel, gate_in, lp, None)
+        eng.grads[eng.n_params:eng.n_params + 1].copy_(self._stats[0:1])
+
     def _fused_ok(self) -> bool:
         """SASRec sub-model with d = 64: the weighting runs inside the fused training step (dr4sr_sasrec_fwd_bwd_weighted)"""
         import os
@@ -503,7 +521,9 @@ class MetaModel(BaseModel):
             _lib.check(lib.dr4sr_fd_shift(_lib.ptr(eng.params), _lib.ptr(theta0), _lib.ptr(direction), _lib.ptr(self._e), sign, n,
                                           st()), "fd_shift")
             eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0)
-            if fused and not need_phi:
+            if need_phi:
+                self._phi_only(bt, gate)
+            elif fused:
                 self._fused_weighted(bt, gate_in=gate_packed)
             else:
                 self._weighted_fwd_bwd(bt, gate_in=gate)
