@@ -256,7 +256,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--steps-per-graph", type=int, default=10, help="whole training steps captured per HIP graph (single GPU)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
-    ap.add_argument("--strong-global-batch", type=int, nargs="*", default=[8192, 32768],
+    ap.add_argument("--strong-global-batch", type=int, nargs="*", default=[8192, 32768, 131072],
                     help="fixed GLOBAL batch sizes of the strong-scaling runs reported as `strong` (per-rank batch = global / N)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling runs")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
