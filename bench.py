@@ -115,7 +115,7 @@ def bench_metamodel(args):
         model._perm_buf = perm[:n_full].clone()
         model._perm_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         model._loss_log = torch.zeros(args.warmup + args.steps + 8, dtype=torch.float32, device=dev)
-        group, interval = int(cfg["train"].get("steps_per_graph", 4)), int(cfg["train"]["interval"])
+        group, interval = int(cfg["train"].get("steps_per_graph", 16)), int(cfg["train"]["interval"])
 
         def run(nsteps):
             i = 0
@@ -254,7 +254,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--steps-per-graph", type=int, default=10, help="whole training steps captured per HIP graph (single GPU)")
+    ap.add_argument("--steps-per-graph", type=int, default=30, help="whole training steps captured per HIP graph (single GPU)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
     ap.add_argument("--strong-global-batch", type=int, nargs="*", default=[8192, 32768, 131072],
                     help="fixed GLOBAL batch sizes of the strong-scaling runs reported as `strong` (per-rank batch = global / N)")

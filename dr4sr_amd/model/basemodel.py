@@ -378,7 +378,7 @@ class BaseModel(nn.Module):
                 self._perm_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._perm_buf.copy_(perm)
             self._perm_counter.zero_()
-        group = int(self.config["train"].get("steps_per_graph", 4)) if fused_sel else 1      # DP: k steps AND their k collectives per graph
+        group = int(self.config["train"].get("steps_per_graph", 16)) if fused_sel else 1      # DP: k steps AND their k collectives per graph
         i = 0
         while i < nb:
             lo, hi = shard_bounds(i, B, n, W, r)

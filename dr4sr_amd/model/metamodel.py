@@ -343,7 +343,7 @@ class MetaModel(BaseModel):
             self._loss_log = torch.empty(nb, dtype=torch.float32, device=self.device)
         self._perm_buf.copy_(perm)
         self._perm_counter.zero_()
-        group, interval = int(self.config["train"].get("steps_per_graph", 4)), int(self.config["train"]["interval"])
+        group, interval = int(self.config["train"].get("steps_per_graph", 16)), int(self.config["train"]["interval"])
         i = 0
         while i < nb:
             bl = min(B, n - i * B)
