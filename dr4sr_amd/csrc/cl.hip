@@ -22,9 +22,11 @@ __device__ __forceinline__ int rand_below(uint32_t r, int n) { return (int)__umu
 // one thread per sequence; mode 0 crop (tau), 1 mask (gamma), 2 reorder (beta), 3 = one of the three drawn per CALL (Item_Random)
 __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __restrict__ seqlen, int64_t* __restrict__ out,
                              int64_t* __restrict__ out_len, int B, int L, int mode, double tau, double gamma, double beta,
-                             int64_t mask_id, uint64_t seed, uint32_t step, const int32_t* __restrict__ step_dev) {
+                             int64_t mask_id, uint64_t seed, uint32_t step, const int32_t* __restrict__ step_dev,
+                             int64_t* __restrict__ out2, int64_t* __restrict__ out_len2) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (blockIdx.y) { out = out2; out_len = out_len2; step += 1; }     // second view of the same launch = the next call's draw
     if (step_dev) step += (uint32_t)*step_dev;             // graph replays: the call counter lives on the device
     const RngKey rk = make_rng(seed, step, 0.f);
     if (mode == 3) mode = rand_below(aug_rand(rk, 0xffffffu, 0), 3);          // data_augmentation.py:95: one method for the whole batch
@@ -201,7 +203,7 @@ extern "C" int dr4sr_cl_augment(const int64_t* seq, const int64_t* seqlen, int64
     if (!seq || !seqlen || !out || !out_len || B < 0 || L <= 0 || L > 64 || mode < 0 || mode > 3) return DR4SR_E_ARG;
     if (B == 0) return 0;
     hipLaunchKernelGGL(k_cl_augment, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, seq, seqlen, out, out_len, B, L, mode, tau,
-                       gamma, beta, mask_id, seed, step, (const int32_t*)nullptr);
+                       gamma, beta, mask_id, seed, step, (const int32_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
     return DR4SR_LAUNCH_CHECK();
 }
 extern "C" int dr4sr_cl_augment_dev(const int64_t* seq, const int64_t* seqlen, int64_t* out, int64_t* out_len, int32_t B, int32_t L,
@@ -210,7 +212,52 @@ extern "C" int dr4sr_cl_augment_dev(const int64_t* seq, const int64_t* seqlen, i
     if (!seq || !seqlen || !out || !out_len || !step_dev || B < 0 || L <= 0 || L > 64 || mode < 0 || mode > 3) return DR4SR_E_ARG;
     if (B == 0) return 0;
     hipLaunchKernelGGL(k_cl_augment, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, seq, seqlen, out, out_len, B, L, mode, tau,
-                       gamma, beta, mask_id, seed, step_offset, step_dev);
+                       gamma, beta, mask_id, seed, step_offset, step_dev, (int64_t*)nullptr, (int64_t*)nullptr);
+    return DR4SR_LAUNCH_CHECK();
+}
+// two views in ONE launch: view 0 = the draw of call (*step_dev + step_offset), view 1 = that of the next call — what two consecutive
+// dr4sr_cl_augment_dev calls with step_offset, step_offset + 1 produce (the kernel is one serial chain per sequence: the launches add)
+extern "C" int dr4sr_cl_augment2_dev(const int64_t* seq, const int64_t* seqlen, int64_t* out_i, int64_t* len_i, int64_t* out_j,
+                                     int64_t* len_j, int32_t B, int32_t L, int32_t mode, double tau, double gamma, double beta,
+                                     int64_t mask_id, uint64_t seed, const int32_t* step_dev, uint32_t step_offset, void* stream) {
+    if (!seq || !seqlen || !out_i || !len_i || !out_j || !len_j || !step_dev || B < 0 || L <= 0 || L > 64 || mode < 0 || mode > 3)
+        return DR4SR_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_cl_augment, dim3((B + 63) / 64, 2), dim3(64), 0, (hipStream_t)stream, seq, seqlen, out_i, len_i, B, L, mode, tau,
+                       gamma, beta, mask_id, seed, step_offset, step_dev, out_j, len_j);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// ---- glue of the direct CL4SRec step (model/cl4srec.py: _api_step_body), one launch each instead of a handful of elementwise ones
+namespace {
+__global__ __launch_bounds__(256) void k_cl_prepare(const int64_t* __restrict__ seqlen, int B, uint8_t* __restrict__ valid,
+                                                    float* __restrict__ stats, float* __restrict__ zero, int64_t nzero) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    if (i < B) valid[i] = seqlen[i] != 1;                  // data_augmentation.py:613-615: sequences of length 1 are dropped
+    if (i < 2) stats[i] = 0.f;
+    for (int64_t k = i; k < nzero; k += stride) zero[k] = 0.f;
+}
+__global__ void k_cl_scalars(const float* __restrict__ tail, const float* __restrict__ stats, float clw, float* __restrict__ scale_out,
+                             float* __restrict__ loss_out) {
+    const float nv = tail[0], rows = stats[0];
+    if (scale_out) *scale_out = rows > 0.f ? clw * nv / rows : 0.f;
+    if (loss_out) *loss_out = tail[1] / nv + (rows > 0.f ? clw * stats[1] / rows : 0.f);
+}
+}  // namespace
+/* valid[b] = seqlen[b] != 1, stats[0..1] = 0, zero[0..nzero) = 0 */
+extern "C" int dr4sr_cl_prepare(const int64_t* seqlen, int32_t B, uint8_t* valid, float* stats, float* zero, int64_t nzero, void* stream) {
+    if (!seqlen || !valid || !stats || B <= 0 || nzero < 0 || (nzero && !zero)) return DR4SR_E_ARG;
+    int64_t nb = ((nzero > B ? nzero : B) + 255) / 256;
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(k_cl_prepare, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, seqlen, B, valid, stats, zero, nzero);
+    return DR4SR_LAUNCH_CHECK();
+}
+/* the two device scalars of a step whose main pass left {n_valid, loss_sum} in `tail` and whose InfoNCE forward left {rows, loss_sum}
+ * in `stats`:  *scale_out = cl_weight * n_valid / rows  (InfoNCE backward scale under an optimizer that divides by n_valid);
+ *              *loss_out  = loss_sum / n_valid + cl_weight * stats[1] / rows.   Either output may be NULL. */
+extern "C" int dr4sr_cl_scalars(const float* tail, const float* stats, float cl_weight, float* scale_out, float* loss_out, void* stream) {
+    if (!tail || !stats || (!scale_out && !loss_out)) return DR4SR_E_ARG;
+    hipLaunchKernelGGL(k_cl_scalars, dim3(1), dim3(1), 0, (hipStream_t)stream, tail, stats, cl_weight, scale_out, loss_out);
     return DR4SR_LAUNCH_CHECK();
 }
 

@@ -35,6 +35,20 @@ class _DeviceAugmentation(torch.nn.Module):
         if self.step_dev is not None:
             self.step_dev.add_(self._in_step)
 
+    def two_views(self, sequences, seq_lens):
+        """the two consecutive draws of a CL4SRec step in ONE launch (captured steps; eager: two forward() calls)"""
+        if self.step_dev is None:
+            return self.forward(sequences, seq_lens), self.forward(sequences, seq_lens)
+        lib = _lib.load()
+        seq, sl = sequences.contiguous(), seq_lens.contiguous()
+        B, L = seq.shape
+        oi, li, oj, lj = torch.empty_like(seq), torch.empty_like(sl), torch.empty_like(seq), torch.empty_like(sl)
+        _lib.check(lib.dr4sr_cl_augment2_dev(_lib.ptr(seq), _lib.ptr(sl), _lib.ptr(oi), _lib.ptr(li), _lib.ptr(oj), _lib.ptr(lj), B, L, self.mode,
+                                             self.tao, self.gamma, self.beta, self.mask_id, self.seed, _lib.ptr(self.step_dev),
+                                             self._in_step + 1, _lib.cur_stream()), "dr4sr_cl_augment2_dev")
+        self._in_step += 2
+        return (oi, li), (oj, lj)
+
     def forward(self, sequences, seq_lens):
         lib = _lib.load()
         seq, sl = sequences.contiguous(), seq_lens.contiguous()

@@ -195,3 +195,33 @@ def test_cl4srec_graph_replayed_epoch_equals_eager_epoch(monkeypatch):
     assert len(la) == 8 and np.allclose(la, lb, rtol=2e-4, atol=1e-5), (la, lb)
     for n in pa:
         assert float((pa[n] - pb[n]).abs().max()) < 5e-4, n     # 8 Adam steps of lr 1e-3: fp32 atomics order, nothing systematic
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.5])
+def test_cl4srec_direct_step_equals_autograd_step(monkeypatch, dropout):
+    """the step body the captured graph replays composes the C-ABI calls directly (fused main pass on the batch's negatives, InfoNCE
+    backward scaled on the device, encoder backward passes of the two views accumulating into the flat gradient, Adam dividing by
+    n_valid); DR4SR_CL_AUTOGRAD=1 runs the reference-shaped loop body (training_step -> loss.backward() -> optimizer.step()): same
+    negatives, same views, same dropout masks, same losses and parameters"""
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
+    res = []
+    for autograd in (True, False):
+        if autograd:
+            monkeypatch.setenv("DR4SR_CL_AUTOGRAD", "1")
+        else:
+            monkeypatch.delenv("DR4SR_CL_AUTOGRAD")
+        config = make_config(150, n_rows=200, batch=64, epochs=1, dropout=dropout)
+        config["train"]["hip_graph"] = False
+        seed_everything(config["train"]["seed"])
+        ds = prepare_datasets(config)
+        model = prepare_model(config, ds)
+        model._init_model(ds[0])
+        model.train()
+        assert model._direct_step_ok() == (not autograd)
+        losses = [float(model._api_step_body(batch)) for _ in range(2) for batch in ds[0].get_loader(shuffle=False)]
+        res.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (la, pa), (lb, pb) = res
+    assert len(la) == 8 and np.allclose(la, lb, rtol=2e-4, atol=1e-5), (la, lb)
+    for n in pa:
+        assert float((pa[n] - pb[n]).abs().max()) < 5e-4, n
