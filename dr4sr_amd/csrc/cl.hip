@@ -66,21 +66,39 @@ __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __r
     }
 }
 
-// ---- InfoNCE.  One wave per row i: lane j-strided over the 2B logits, dot products over D from global (B*D floats: L2 resident).
+// ---- InfoNCE('inner_product', 'batch_both') on MFMA (v_mfma_f32_16x16x4_f32, exact fp32).
+// logits[i] = [x_i . xj_j | x_i . xi_j, diagonal -inf] / temperature over the 2B "columns" j (first the other view, then the own one).
+// One workgroup per 16-row tile; its 4 waves split the column tiles.  Logit tiles are computed TRANSPOSED, S^T[j][i] (A = the 16
+// column rows, B = the 16 query rows), so a lane holds four j of ONE i (i = lane & 15, j = 4 (lane >> 4) + r): the softmax statistics
+// of a row reduce in-lane and over the 4 lane groups (two shuffles), and the probabilities are, as they stand, the B operand of the
+// next product out^T[d][i] = sum_j X[j][d] P[i][j] (lane group g supplies j = 4g + s at step s) — the scheme of csrc/attn_mfma.hip.
+// (The first versions walked rows with per-lane dot products: 26 us forward / 48 us backward at B = 256, now 14 / 23.)
+__device__ __forceinline__ f32x4 cl_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// fragment of 16 rows [r0, r0 + 16) of a [n][D] matrix: lane (l16 = lane & 15, g = lane >> 4) holds features g*D/4 .. of row r0 + l16
 template <int D>
-__device__ __forceinline__ float dot_rows(const float* __restrict__ a, const float* __restrict__ b) {
-    float s = 0.f;
+__device__ __forceinline__ void cl_frag(float (&f)[D / 4], const float* __restrict__ x, int r0, int n) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, g = lane >> 4;
+    if (r0 + l16 < n) {
+        const float* p = x + (size_t)(r0 + l16) * D + g * (D / 4);
 #pragma unroll
-    for (int c = 0; c < D; c += 4) {
-        const float4 x = ld4(a + c), y = ld4(b + c);
-        s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        for (int c = 0; c < D / 4; c += 4) { const float4 v = ld4(p + c); f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < D / 4; ++c) f[c] = 0.f;
     }
-    return s;
 }
-__device__ __forceinline__ float wave_max(float v) {
+template <int D>
+__device__ __forceinline__ f32x4 cl_dots(const float (&a)[D / 4], const float (&b)[D / 4]) {      // C[ra][rb] = <row ra of a, row rb of b>
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int s = 0; s < D / 4; ++s) acc = cl_mfma(a[s], b[s], acc);
+    return acc;
+}
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+    m = mn;
 }
 
 // lse[i] = logsumexp_j logits[i][j], loss_row[i] = lse[i] - logits[i][i] (0 for invalid rows); stats += {n_valid rows, sum loss_row}
@@ -88,110 +106,155 @@ template <int D>
 __global__ __launch_bounds__(256) void k_infonce_fwd(const float* __restrict__ xi, const float* __restrict__ xj,
                                                      const uint8_t* __restrict__ valid, int B, float inv_t, float* __restrict__ lse,
                                                      float* __restrict__ loss_row, float* __restrict__ stats) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= B) return;
-    if (valid && !valid[i]) { if (lane == 0) { lse[i] = 0.f; loss_row[i] = 0.f; } return; }
-    const float* qi = xi + (size_t)i * D;
-    float m = -INFINITY, s = 0.f, pos = 0.f;
-    for (int j = lane; j < 2 * B; j += 64) {
-        const int jj = j < B ? j : j - B;
-        if (valid && !valid[jj]) continue;
-        if (j >= B && jj == i) continue;                            // sim_ii diagonal = -inf
-        const float v = dot_rows<D>(qi, (j < B ? xj : xi) + (size_t)jj * D) * inv_t;
-        if (j == i) pos = v;
-        const float mn = fmaxf(m, v);
-        s = s * __expf(m - mn) + __expf(v - mn);
-        m = mn;
+    __shared__ float red[4][3][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const int i0 = blockIdx.x * 16, i = i0 + l16, T1 = (B + 15) / 16;
+    const bool vi = i < B && (!valid || valid[i]);
+    float q[D / 4], a[D / 4];
+    cl_frag<D>(q, xi, i0, B);
+    float m = -INFINITY, sum = 0.f, pos = 0.f;
+    for (int t = w; t < 2 * T1; t += 4) {
+        const bool own = t >= T1;                          // second half: the own view's rows, diagonal excluded
+        const int j0 = (own ? t - T1 : t) * 16;
+        cl_frag<D>(a, own ? xi : xj, j0, B);
+        bool vj[4];                                        // requested with the rows, ahead of the MFMA chain
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int j = j0 + 4 * g + r; vj[r] = j < B && (!valid || valid[j]); }
+        const f32x4 acc = cl_dots<D>(a, q);                // acc[r] = <X[j0 + 4g + r], xi[i]>
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 4 * g + r;
+            if (vi && vj[r] && !(own && j == i)) {
+                const float v = acc[r] * inv_t;
+                if (!own && j == i) pos = v;
+                const float mn = fmaxf(m, v);
+                sum = sum * __expf(m - mn) + __expf(v - mn);
+                m = mn;
+            }
+        }
     }
-    const float mg = wave_max(m);
-    s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - mg));
-    pos = wave_sum(pos);
-    if (lane == 0) {
-        const float l = mg + logf(s);
-        lse[i] = l;
-        loss_row[i] = l - pos;
-        unsafeAtomicAdd(stats, 1.0f);
-        unsafeAtomicAdd(stats + 1, l - pos);
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {                    // the 4 lane groups of a column i
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sum, o, 64);
+        lse_merge(m, sum, m2, s2);
+        pos += __shfl_xor(pos, o, 64);
+    }
+    if (g == 0) { red[w][0][l16] = m; red[w][1][l16] = sum; red[w][2][l16] = pos; }
+    __syncthreads();
+    if (w == 0 && g == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { lse_merge(m, sum, red[k][0][l16], red[k][1][l16]); pos += red[k][2][l16]; }
+        float l = 0.f, lr = 0.f;
+        if (vi) { l = m + logf(sum); lr = l - pos; }
+        if (i < B) { lse[i] = l; loss_row[i] = lr; }
+        float cnt = vi ? 1.f : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); lr += __shfl_xor(lr, o, 64); }
+        if (l16 == 0 && cnt > 0.f) { unsafeAtomicAdd(stats, cnt); unsafeAtomicAdd(stats + 1, lr); }
     }
 }
 
 // d loss_sum / d x  scaled by *scale (device scalar or NULL):  with P = softmax(logits) (rows = valid i)
-//   dxi[i] += sum_j P1_ij xj[j] + sum_{j!=i} P2_ij xi[j] - xj[i]        (row pass, this kernel, role 0)
-//   dxj[j] += sum_i P1_ij xi[i] - xi[j] ;  dxi[j] += sum_{i!=j} P2_ij xi[i]   (column pass, role 1)
-// One wave per (row | column) a.  The other index o is walked in blocks of 64 in two phases: lanes over o compute the two logits of
-// (a, o) as full dot products and leave the probabilities in LDS; lanes over D then accumulate the 64 weighted rows (coalesced).
-// No cross-lane reduction inside the loop (the first version had two wave reductions per o: a 115 us dependent chain at B = 256).
+//   dxi[i] += sum_j P1_ij xj[j] + sum_{j!=i} P2_ij xi[j] - xj[i]        (row tiles: blockIdx.x < T1)
+//   dxj[j] += sum_i P1_ij xi[i] - xi[j] ;  dxi[j] += sum_{i!=j} P2_ij xi[i]   (column tiles: blockIdx.x >= T1)
+// Row tile: S^T[j][i] tiles as in the forward, P^T = exp(S^T / t - lse_i) is the B operand of out^T[d][i] += X[j][d] P^T[j][i].
+// Column tile: S[i][j] tiles (A = query rows i, B = the tile's 16 column rows j), P[i][j] with lse of the REGISTER's row
+// i = 4g + r, then out^T[d][j] += xi[i][d] P[i][j].  The 4 waves split the other index; their out^T accumulators meet in LDS.
 template <int D>
 __global__ __launch_bounds__(256) void k_infonce_bwd(const float* __restrict__ xi, const float* __restrict__ xj,
                                                      const uint8_t* __restrict__ valid, int B, float inv_t,
                                                      const float* __restrict__ lse, const float* __restrict__ scale,
                                                      float* __restrict__ dxi, float* __restrict__ dxj) {
-    constexpr int NV = D / 64, LDR = D + 1;                  // +1: the dot phase reads row `lane`, conflict-free with an odd row stride
-    __shared__ float ps[4][2][64];
-    __shared__ float xa[4][2][D];
-    __shared__ float xo[2][64 * LDR];                        // rows o0 .. o0+63 of xi / xj, staged once per block for all 4 waves
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + w;
-    const bool live = item < 2 * B;
-    const int role = live && item >= B, a = live ? (role ? item - B : item) : 0;
-    const bool act = live && (!valid || valid[a]);          // inactive waves still take the barriers
+    constexpr int DT = D / 16;
+    __shared__ float red[2][4][DT][4][64];                 // [accumulator][wave][d tile][r][lane]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const int T1 = (B + 15) / 16;
+    const bool colpass = (int)blockIdx.x >= T1;
+    const int c0 = (colpass ? blockIdx.x - T1 : blockIdx.x) * 16, c = c0 + l16;        // this lane's row (row pass) / column (column pass)
+    const bool vc = c < B && (!valid || valid[c]);
     const float sc = (scale ? *scale : 1.0f) * inv_t;
-    float acc_i[NV], acc_j[NV];
+    float fa[D / 4], fb[D / 4], fq[D / 4];
+    f32x4 acc0[DT], acc1[DT];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        acc_i[v] = 0.f; acc_j[v] = 0.f;
-        xa[w][0][lane + 64 * v] = xi[(size_t)a * D + lane + 64 * v];
-        xa[w][1][lane + 64 * v] = xj[(size_t)a * D + lane + 64 * v];
-    }
-    const float la = lse[a];
-    for (int o0 = 0; o0 < B; o0 += 64) {
-        const int n = B - o0 < 64 ? B - o0 : 64;
-        __syncthreads();                                     // previous block's rows are no longer read
-        for (int e = threadIdx.x; e < 64 * D; e += 256) {    // coalesced: consecutive threads walk a row
-            const int r = e / D, c = e % D;
-            const bool ok = r < n;
-            xo[0][r * LDR + c] = ok ? xi[(size_t)(o0 + r) * D + c] : 0.f;
-            xo[1][r * LDR + c] = ok ? xj[(size_t)(o0 + r) * D + c] : 0.f;
-        }
-        __syncthreads();
-        const int o = o0 + lane;
-        float p1 = 0.f, p2 = 0.f;
-        if (act && o < B && (!valid || valid[o])) {
-            float d1 = 0.f, d2 = 0.f;
-            const float* oi = &xo[0][lane * LDR];
-            const float* oj = &xo[1][lane * LDR];
-#pragma unroll 8
-            for (int c = 0; c < D; ++c) {
-                const float ai = xa[w][0][c];
-                d2 += oi[c] * ai;                                        // sim_ii[a][o] (symmetric)
-                d1 += role ? oi[c] * xa[w][1][c] : ai * oj[c];           // sim_ij[o][a] : sim_ij[a][o]
+    for (int dt = 0; dt < DT; ++dt) { acc0[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[dt] = acc0[dt]; }
+    if (!colpass) {
+        cl_frag<D>(fq, xi, c0, B);
+        const float la = vc ? lse[c] : 0.f;
+        for (int t = w; t < 2 * T1; t += 4) {
+            const bool own = t >= T1;
+            const int j0 = (own ? t - T1 : t) * 16;
+            const float* X = own ? xi : xj;
+            cl_frag<D>(fa, X, j0, B);
+            bool vj[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int j = j0 + 4 * g + r; vj[r] = j < B && (!valid || valid[j]); }
+            const f32x4 s = cl_dots<D>(fa, fq);            // S^T[j0 + 4g + r][c]
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + 4 * g + r;
+                p[r] = (vc && vj[r] && !(own && j == c)) ? __expf(s[r] * inv_t - la) : 0.f;
             }
-            const float l = role ? lse[o] : la;
-            p1 = __expf(d1 * inv_t - l);
-            p2 = o == a ? 0.f : __expf(d2 * inv_t - l);
-        }
-        ps[w][0][lane] = p1; ps[w][1][lane] = p2;
-        __syncthreads();
-        if (act) {
-            for (int k = 0; k < n; ++k) {
-                const float q1 = ps[w][0][k], q2 = ps[w][1][k];
-                if (q1 == 0.f && q2 == 0.f) continue;                     // masked-out row (uniform over the wave)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float oi = xo[0][k * LDR + lane + 64 * v];
-                    if (!role) acc_i[v] += q1 * xo[1][k * LDR + lane + 64 * v] + q2 * oi;
-                    else { acc_j[v] += q1 * oi; acc_i[v] += q2 * oi; }
+            for (int r = 0; r < 4; ++r) {                  // out^T[d][c] += X[j0 + 4g + r][d] * P^T[j0 + 4g + r][c]
+                const int j = j0 + 4 * g + r;
+                const float* xr = X + (size_t)(j < B ? j : 0) * D + l16;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) acc0[dt] = cl_mfma(j < B ? xr[16 * dt] : 0.f, p[r], acc0[dt]);
+            }
+        }
+    } else {
+        cl_frag<D>(fq, xj, c0, B);                         // column rows of the other view (P1) ...
+        cl_frag<D>(fb, xi, c0, B);                         // ... and of the own view (P2)
+        for (int t = w; t < T1; t += 4) {
+            const int i0 = t * 16;
+            cl_frag<D>(fa, xi, i0, B);
+            float li[4]; bool ok[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * g + r;
+                ok[r] = vc && i < B && (!valid || valid[i]);
+                li[r] = ok[r] ? lse[i] : 0.f;
+            }
+            const f32x4 s1 = cl_dots<D>(fa, fq), s2 = cl_dots<D>(fa, fb);       // S1[i0 + 4g + r][c], S2[...]
+            float p1[4], p2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * g + r;
+                p1[r] = ok[r] ? __expf(s1[r] * inv_t - li[r]) : 0.f;
+                p2[r] = (ok[r] && i != c) ? __expf(s2[r] * inv_t - li[r]) : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                  // out^T[d][c] += xi[i0 + 4g + r][d] * P[i0 + 4g + r][c]
+                const int i = i0 + 4 * g + r;
+                const float* xr = xi + (size_t)(i < B ? i : 0) * D + l16;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const float xv = i < B ? xr[16 * dt] : 0.f;
+                    acc0[dt] = cl_mfma(xv, p1[r], acc0[dt]);
+                    acc1[dt] = cl_mfma(xv, p2[r], acc1[dt]);
                 }
             }
         }
     }
-    if (!act) return;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const size_t e = (size_t)a * D + lane + 64 * v;
-        if (!role) unsafeAtomicAdd(dxi + e, sc * (acc_i[v] - xa[w][1][lane + 64 * v]));
-        else { unsafeAtomicAdd(dxj + e, sc * (acc_j[v] - xa[w][0][lane + 64 * v])); unsafeAtomicAdd(dxi + e, sc * acc_i[v]); }
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[0][w][dt][r][lane] = acc0[dt][r]; red[1][w][dt][r][lane] = acc1[dt][r]; }
+    __syncthreads();
+    // element (d = 16 dt + 4 g + r, column l16) of out^T: wave w finishes d tile w (D = 128: tiles w and w + 4)
+    for (int dt = w; dt < DT; dt += 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float o0 = (red[0][0][dt][r][lane] + red[0][1][dt][r][lane]) + (red[0][2][dt][r][lane] + red[0][3][dt][r][lane]);
+            const float o1 = (red[1][0][dt][r][lane] + red[1][1][dt][r][lane]) + (red[1][2][dt][r][lane] + red[1][3][dt][r][lane]);
+            const int d = 16 * dt + 4 * g + r;
+            if (vc) {
+                const size_t e = (size_t)c * D + d;
+                if (!colpass) unsafeAtomicAdd(dxi + e, sc * (o0 - xj[e]));
+                else { unsafeAtomicAdd(dxj + e, sc * (o0 - xi[e])); unsafeAtomicAdd(dxi + e, sc * o1); }
+            }
+        }
     }
 }
 
@@ -264,7 +327,7 @@ extern "C" int dr4sr_cl_scalars(const float* tail, const float* stats, float cl_
 extern "C" int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
                                  float* lse, float* loss_row, float* stats, void* stream) {
     if (!xi || !xj || !lse || !loss_row || !stats || B <= 0 || !(temperature > 0.f)) return DR4SR_E_ARG;
-    dim3 grid((B + 3) / 4), blk(256);
+    dim3 grid((B + 15) / 16), blk(256);
     if (D == 64) hipLaunchKernelGGL(k_infonce_fwd<64>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, loss_row, stats);
     else if (D == 128) hipLaunchKernelGGL(k_infonce_fwd<128>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, loss_row, stats);
     else return DR4SR_E_SHAPE;
@@ -274,7 +337,7 @@ extern "C" int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t
 extern "C" int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
                                  const float* lse, const float* scale, float* dxi, float* dxj, void* stream) {
     if (!xi || !xj || !lse || !dxi || !dxj || B <= 0 || !(temperature > 0.f)) return DR4SR_E_ARG;
-    dim3 grid((2 * B + 3) / 4), blk(256);
+    dim3 grid(2 * ((B + 15) / 16)), blk(256);
     if (D == 64) hipLaunchKernelGGL(k_infonce_bwd<64>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, scale, dxi, dxj);
     else if (D == 128) hipLaunchKernelGGL(k_infonce_bwd<128>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, scale, dxi, dxj);
     else return DR4SR_E_SHAPE;
