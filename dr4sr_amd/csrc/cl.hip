@@ -68,7 +68,7 @@ __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __r
 
 // ---- InfoNCE('inner_product', 'batch_both') on MFMA (v_mfma_f32_16x16x4_f32, exact fp32).
 // logits[i] = [x_i . xj_j | x_i . xi_j, diagonal -inf] / temperature over the 2B "columns" j (first the other view, then the own one).
-// One workgroup per 16-row tile; its 4 waves split the column tiles.  Logit tiles are computed TRANSPOSED, S^T[j][i] (A = the 16
+// One workgroup per 16-row tile; its waves (16 forward, 8 / 4 backward) split the column tiles.  Logit tiles are computed TRANSPOSED, S^T[j][i] (A = the 16
 // column rows, B = the 16 query rows), so a lane holds four j of ONE i (i = lane & 15, j = 4 (lane >> 4) + r): the softmax statistics
 // of a row reduce in-lane and over the 4 lane groups (two shuffles), and the probabilities are, as they stand, the B operand of the
 // next product out^T[d][i] = sum_j X[j][d] P[i][j] (lane group g supplies j = 4g + s at step s) — the scheme of csrc/attn_mfma.hip.
@@ -102,18 +102,19 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
 }
 
 // lse[i] = logsumexp_j logits[i][j], loss_row[i] = lse[i] - logits[i][i] (0 for invalid rows); stats += {n_valid rows, sum loss_row}
+constexpr int CL_FW = 16;                                  // waves per forward workgroup: the column tiles of a row tile are a latency chain
 template <int D>
-__global__ __launch_bounds__(256) void k_infonce_fwd(const float* __restrict__ xi, const float* __restrict__ xj,
+__global__ __launch_bounds__(CL_FW * 64) void k_infonce_fwd(const float* __restrict__ xi, const float* __restrict__ xj,
                                                      const uint8_t* __restrict__ valid, int B, float inv_t, float* __restrict__ lse,
                                                      float* __restrict__ loss_row, float* __restrict__ stats) {
-    __shared__ float red[4][3][16];
+    __shared__ float red[CL_FW][3][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const int i0 = blockIdx.x * 16, i = i0 + l16, T1 = (B + 15) / 16;
     const bool vi = i < B && (!valid || valid[i]);
     float q[D / 4], a[D / 4];
     cl_frag<D>(q, xi, i0, B);
     float m = -INFINITY, sum = 0.f, pos = 0.f;
-    for (int t = w; t < 2 * T1; t += 4) {
+    for (int t = w; t < 2 * T1; t += CL_FW) {
         const bool own = t >= T1;                          // second half: the own view's rows, diagonal excluded
         const int j0 = (own ? t - T1 : t) * 16;
         cl_frag<D>(a, own ? xi : xj, j0, B);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void k_infonce_fwd(const float* __restrict__ x
     __syncthreads();
     if (w == 0 && g == 0) {
 #pragma unroll
-        for (int k = 1; k < 4; ++k) { lse_merge(m, sum, red[k][0][l16], red[k][1][l16]); pos += red[k][2][l16]; }
+        for (int k = 1; k < CL_FW; ++k) { lse_merge(m, sum, red[k][0][l16], red[k][1][l16]); pos += red[k][2][l16]; }
         float l = 0.f, lr = 0.f;
         if (vi) { l = m + logf(sum); lr = l - pos; }
         if (i < B) { lse[i] = l; loss_row[i] = lr; }
@@ -161,12 +162,12 @@ __global__ __launch_bounds__(256) void k_infonce_fwd(const float* __restrict__ x
 // Column tile: S[i][j] tiles (A = query rows i, B = the tile's 16 column rows j), P[i][j] with lse of the REGISTER's row
 // i = 4g + r, then out^T[d][j] += xi[i][d] P[i][j].  The 4 waves split the other index; their out^T accumulators meet in LDS.
 template <int D>
-__global__ __launch_bounds__(256) void k_infonce_bwd(const float* __restrict__ xi, const float* __restrict__ xj,
+__global__ __launch_bounds__(D == 64 ? 512 : 256) void k_infonce_bwd(const float* __restrict__ xi, const float* __restrict__ xj,
                                                      const uint8_t* __restrict__ valid, int B, float inv_t,
                                                      const float* __restrict__ lse, const float* __restrict__ scale,
                                                      float* __restrict__ dxi, float* __restrict__ dxj) {
-    constexpr int DT = D / 16;
-    __shared__ float red[2][4][DT][4][64];                 // [accumulator][wave][d tile][r][lane]
+    constexpr int DT = D / 16, NW = D == 64 ? 8 : 4;       // 64 KB of LDS for the accumulators of all waves either way
+    __shared__ float red[2][NW][DT][4][64];                // [accumulator][wave][d tile][r][lane]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const int T1 = (B + 15) / 16;
     const bool colpass = (int)blockIdx.x >= T1;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void k_infonce_bwd(const float* __restrict__ x
     if (!colpass) {
         cl_frag<D>(fq, xi, c0, B);
         const float la = vc ? lse[c] : 0.f;
-        for (int t = w; t < 2 * T1; t += 4) {
+        for (int t = w; t < 2 * T1; t += NW) {
             const bool own = t >= T1;
             const int j0 = (own ? t - T1 : t) * 16;
             const float* X = own ? xi : xj;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_infonce_bwd(const float* __restrict__ x
     } else {
         cl_frag<D>(fq, xj, c0, B);                         // column rows of the other view (P1) ...
         cl_frag<D>(fb, xi, c0, B);                         // ... and of the own view (P2)
-        for (int t = w; t < T1; t += 4) {
+        for (int t = w; t < T1; t += NW) {
             const int i0 = t * 16;
             cl_frag<D>(fa, xi, i0, B);
             float li[4]; bool ok[4];
@@ -242,12 +243,13 @@ __global__ __launch_bounds__(256) void k_infonce_bwd(const float* __restrict__ x
 #pragma unroll
         for (int r = 0; r < 4; ++r) { red[0][w][dt][r][lane] = acc0[dt][r]; red[1][w][dt][r][lane] = acc1[dt][r]; }
     __syncthreads();
-    // element (d = 16 dt + 4 g + r, column l16) of out^T: wave w finishes d tile w (D = 128: tiles w and w + 4)
-    for (int dt = w; dt < DT; dt += 4) {
+    // element (d = 16 dt + 4 g + r, column l16) of out^T: wave w finishes d tile w (D = 128 with 4 waves: tiles w and w + 4)
+    for (int dt = w; dt < DT; dt += NW) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float o0 = (red[0][0][dt][r][lane] + red[0][1][dt][r][lane]) + (red[0][2][dt][r][lane] + red[0][3][dt][r][lane]);
-            const float o1 = (red[1][0][dt][r][lane] + red[1][1][dt][r][lane]) + (red[1][2][dt][r][lane] + red[1][3][dt][r][lane]);
+            float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { o0 += red[0][k][dt][r][lane]; o1 += red[1][k][dt][r][lane]; }
             const int d = 16 * dt + 4 * g + r;
             if (vc) {
                 const size_t e = (size_t)c * D + d;
@@ -327,7 +329,7 @@ extern "C" int dr4sr_cl_scalars(const float* tail, const float* stats, float cl_
 extern "C" int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
                                  float* lse, float* loss_row, float* stats, void* stream) {
     if (!xi || !xj || !lse || !loss_row || !stats || B <= 0 || !(temperature > 0.f)) return DR4SR_E_ARG;
-    dim3 grid((B + 15) / 16), blk(256);
+    dim3 grid((B + 15) / 16), blk(CL_FW * 64);
     if (D == 64) hipLaunchKernelGGL(k_infonce_fwd<64>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, loss_row, stats);
     else if (D == 128) hipLaunchKernelGGL(k_infonce_fwd<128>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, loss_row, stats);
     else return DR4SR_E_SHAPE;
@@ -337,7 +339,7 @@ extern "C" int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t
 extern "C" int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
                                  const float* lse, const float* scale, float* dxi, float* dxj, void* stream) {
     if (!xi || !xj || !lse || !dxi || !dxj || B <= 0 || !(temperature > 0.f)) return DR4SR_E_ARG;
-    dim3 grid(2 * ((B + 15) / 16)), blk(256);
+    dim3 grid(2 * ((B + 15) / 16)), blk(D == 64 ? 512 : 256);
     if (D == 64) hipLaunchKernelGGL(k_infonce_bwd<64>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, scale, dxi, dxj);
     else if (D == 128) hipLaunchKernelGGL(k_infonce_bwd<128>, grid, blk, 0, (hipStream_t)stream, xi, xj, valid, B, 1.0f / temperature, lse, scale, dxi, dxj);
     else return DR4SR_E_SHAPE;
