@@ -54,7 +54,7 @@ def init_params_like_reference(eng, seed):
     eng.load_named(sd)
 
 
-def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen):
+def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen, big=None):
     """ALGORITHMIC flops of one launch on the packed batch: 2*M*N*K per GEMM over the T valid tokens."""
     if kind in ("post_fwd", "post_bwd"):
         return 2.0 * T * (D * D + 2 * D * F) + (2.0 * T * 3 * D * D if n_layer > 1 else 0.0)   # + the next layer's qkv projection
@@ -63,7 +63,7 @@ def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen):
     if kind in ("qkv_fwd", "qkv_bwd", "embqkv_fwd", "qkv_embed_bwd"):
         return 2.0 * T * 3 * D * D
     if kind in ("wgrad", "wgrad_fused"):
-        return 2.0 * T * (4 * D * D + 2 * D * F) * n_layer + (2.0 * T * 3 * D * D if kind == "wgrad_fused" and B * L <= 16384 else 0.0)
+        return 2.0 * T * (4 * D * D + 2 * D * F) * n_layer + (2.0 * T * 3 * D * D if kind == "wgrad_fused" and not (B * L > 16384 if big is None else big) else 0.0)
     if kind in ("attn_fwd", "attn_bwd"):
         pairs = float((seqlen * (seqlen + 1) // 2).sum())
         return (2.0 if kind == "attn_fwd" else 5.0) * 2.0 * pairs * D      # QK^T + PV (fwd); +dP, dQ, dK, dV (bwd)
@@ -527,9 +527,10 @@ def main():
                                         "note": "all kernels of the step, last batch's token count"}
                 # the launches dr4sr_sasrec_train_steps really enqueues per step: (kind, layer argument, launches / step).
                 # post_fwd / post_bwd at layer 0 are the fused forms (they carry layer 1's qkv projection / its backward); the last
-                # layer's post_fwd + scorer + post_bwd is ONE launch (post_mid).  In the latency regime (packed tokens <= 16384) the
-                # embedding-stage backward rides in the k_wgrad launch (`wgrad_fused`), above it is a launch of its own.
-                big = B * L > 16384
+                # layer's post_fwd + scorer + post_bwd is ONE launch (post_mid).  In the latency regime (expected tokens of the plan
+                # <= ~10 k: dr4sr_sasrec_at_scale) the embedding-stage backward rides in the k_wgrad launch (`wgrad_fused`), at scale
+                # it is a launch of its own.
+                big = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)))
                 launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1), ("attn_fwd", NL - 1, NL), ("post_fwd", 0, NL - 1),
                             ("post_mid", 0, 1), ("attn_bwd", NL - 1, NL), ("post_bwd", 0, NL - 1)]
                 launches += ([("qkv_embed_bwd", 0, 1)] if big else []) + [("wgrad_fused", 0, 1), ("adam", 0, 1)]
@@ -549,8 +550,8 @@ def main():
                     ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
                 step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
                 # the dominant kernel = the kind with the largest share of the step (attention: both layers' launches)
-                dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last) > 0), key=lambda k: step_us[k])
-                fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last)
+                dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last, big) > 0), key=lambda k: step_us[k])
+                fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last, big)
                 ach = fl / (ktime[dom] * 1e-6) / 1e12
                 # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (tools/traffic_pmc.sh: FETCH_SIZE x2
                 # gfx950 correction + WRITE_SIZE, separate rocprofv3 runs); only for the workloads that were profiled

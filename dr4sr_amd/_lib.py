@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR4SR_LIB_PATH") or os.path.join(_HERE, "csrc", "libdr4sr_hip.so")     # override: A/B runs of two builds on one box
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 GRAD_TAIL = 4
 STATE_WORDS = 16
 STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
@@ -46,6 +46,7 @@ class SasrecPlan(C.Structure):
         ("perm", _i64p), ("n_perm", C.c_int64), ("perm_stride", C.c_int64), ("perm_offset", C.c_int64),
         ("perm_counter", C.c_void_p),
         ("loss_log", _f32p),
+        ("expected_tokens", C.c_int32),
     ]
 
 
@@ -101,6 +102,7 @@ SYMBOLS = {
     "dr4sr_sasrec_plan_sizeof": (C.c_int, []),
     "dr4sr_sasrec_param_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_workspace_bytes": (C.c_int64, [_PLANP]),
+    "dr4sr_sasrec_at_scale": (C.c_int, [C.c_void_p]),
     "dr4sr_sasrec_fwd_bwd": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_adam_step": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_sasrec_fwd_bwd_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_void_p]),

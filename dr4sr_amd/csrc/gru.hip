@@ -171,7 +171,7 @@ static int launch_gemm(const float* A, int lda, const float* W, int ldw, const f
                        bool colmode, int Tmax, const int* state, hipStream_t s) {
     const size_t lds = sizeof(float) * 64 * 68;
     dim3 blk(256);
-    if (colmode && !bias && Tmax <= 16384 && (K == 768 || K == 384) && N % 64 == 0) {      // small batch, K = 3H: latency tiles
+    if (colmode && !bias && !at_scale(Tmax) && (K == 768 || K == 384) && N % 64 == 0) {      // small batch, K = 3H: latency tiles
         const size_t l16 = sizeof(float) * 16 * (K + 4);
         dim3 grid((Tmax + 15) / 16, N / 64);
         if (K == 768) { big_lds(k_gemm16_col<768>, l16); hipLaunchKernelGGL(k_gemm16_col<768>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }

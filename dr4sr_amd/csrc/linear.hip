@@ -62,16 +62,20 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ X, co
 
 // tile rows per workgroup for the token-tile kernels: 16 while the whole batch is small (latency regime: 4x shorter MFMA
 // chains, every CU gets work), 32 at scale (occupancy regime: 4 workgroups per CU interleave their latency chains).
+int latency_tmax() {
+    static const int v = getenv("DR4SR_LATENCY_TMAX") ? atoi(getenv("DR4SR_LATENCY_TMAX")) : 16384;
+    return v;
+}
 int tile_rows(const Workspace& ws) {
     static const int forced = getenv("DR4SR_BM") ? atoi(getenv("DR4SR_BM")) : 0;
     if (forced == 16 || forced == 32 || forced == 64) return forced;
-    return ws.Tmax <= 16384 ? 16 : 32;
+    return ws.scale ? 32 : 16;
 }
 // large batches: the table-gradient scatter of the embedding stage (T x D fp32 atomics, ~55 G/s: 0.47 ms of the dense B=8192 step
 // when it sits at the end of k_qkv_embed_bwd) runs as an extra job of k_wgrad, where it overlaps the MFMA-bound weight-gradient jobs
 static bool scatter_in_wgrad(const Workspace& ws) {
     static const bool off = getenv("DR4SR_SCATTER_INLINE") != nullptr || getenv("DR4SR_NO_FUSE") != nullptr;
-    return !off && ws.Tmax > 16384;
+    return !off && ws.scale;
 }
 // large batches: the item-table gradient is NOT accumulated with fp32 atomics (scorer: 2 rows per token, embedding stage: 1) but
 // summed row by row by owner workgroups inside k_wgrad (owner_job): deterministic, and ~55 us of a toys-shaped B = 8192 step
@@ -1113,7 +1117,7 @@ int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, 
 
 // FMLP Intermediate block (module/layers.py:761-779): linear1 -> GELU -> linear2 -> dropout -> +x -> LayerNorm, D=64, F=256
 // token rows per workgroup of the FMLP Intermediate kernels (ln_part rows follow the same tiling)
-int ffn_tile_rows(int Tmax) { return Tmax <= 16384 ? 32 : 64; }
+int ffn_tile_rows(int Tmax) { return at_scale(Tmax) ? 64 : 32; }
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s) {
     const int bm = ffn_tile_rows(Tmax);
     dim3 grid((Tmax + bm - 1) / bm), blk(256);

@@ -70,6 +70,12 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     const int64_t D = p->D, F = p->F, Tmax = (int64_t)p->B * p->L;
     ws->n_params = dr4sr_sasrec_param_layout(p->n_items, p->L, p->D, p->F, p->n_layer, ws->off);
     ws->Tmax = (int)Tmax;
+    {
+        static const bool forced = getenv("DR4SR_LATENCY_TMAX") != nullptr;           // sweeps: the capacity rule with a moved boundary
+        const int64_t hint = p->expected_tokens < Tmax ? p->expected_tokens : Tmax;
+        ws->scale = (hint > 0 && !forced) ? hint > DR4SR_SCALE_TOKENS : at_scale((int)Tmax);
+        if (const char* f = getenv("DR4SR_FORCE_SCALE")) ws->scale = atoi(f) != 0;    // tests (read per call): 1 = at-scale forms, 0 = latency forms
+    }
     char* base = (char*)p->workspace;
     int64_t o = 0;
     auto take = [&](int64_t nfloat) -> float* {
@@ -110,6 +116,17 @@ extern "C" int64_t dr4sr_sasrec_workspace_bytes(const dr4sr_sasrec_plan* plan) {
     Workspace ws;
     carve_workspace(&q, &ws);
     return ws.bytes;
+}
+
+extern "C" int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan) {
+    if (!plan) return DR4SR_E_ARG;
+    dr4sr_sasrec_plan q = *plan;
+    q.workspace = nullptr;
+    if (q.B <= 0 || q.L <= 0 || q.n_layer <= 0 || q.n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    if (check_shape(&q)) return DR4SR_E_SHAPE;
+    Workspace ws;
+    carve_workspace(&q, &ws);
+    return ws.scale ? 1 : 0;
 }
 
 static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {

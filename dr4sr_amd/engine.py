@@ -59,6 +59,8 @@ class SasrecEngine:
         self.ln_eps, self.p_drop, self.seed = float(ln_eps), float(p_drop), int(seed)
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         self.max_batch = max_batch
+        self.mean_len = None                     # mean valid length of the training split, set by the model (regime hint)
+        self._mean_len = {}
         noff = 2 + 12 * n_layer
         off = (C.c_int64 * noff)()
         self.n_params = int(self.lib.dr4sr_sasrec_param_layout(n_items, L, D, F, n_layer, off))
@@ -123,8 +125,29 @@ class SasrecEngine:
         if loss_log is not None:           # float32 device buffer: the step's mean loss lands at [batch index] (see dr4sr_hip.h)
             assert loss_log.dtype == torch.float32
             p.loss_log = loss_log.data_ptr()
+        p.expected_tokens = self._expected_tokens(B, seqlen, rows is not None)
         self._keep = [in_item_id, item_id, seqlen, rows, neg_item, perm_sel, loss_log]
         return p
+
+    def _expected_tokens(self, B, seqlen, dataset_tensor: bool) -> int:
+        """regime hint of the plan (include/dr4sr_hip.h: expected_tokens) = B * mean(min(seqlen, L)).  Dataset tensors (batches are
+        rows[] of them): one device reduction + host read per tensor, cached.  Per-batch tensors (API path): `self.mean_len` when the
+        model set it from its training split (no synchronisation per step), else measured — except inside a graph capture, where an
+        unknown tensor leaves the hint at 0 = capacity rule."""
+        if seqlen is None:
+            return 0
+        key = (seqlen.data_ptr(), int(seqlen.shape[0]))
+        mean = self._mean_len.get(key)
+        if mean is None and not dataset_tensor and self.mean_len is not None:
+            mean = self.mean_len
+        elif mean is None:
+            if torch.cuda.is_current_stream_capturing():
+                return 0
+            mean = float(seqlen.clamp(0, self.L).float().mean()) if seqlen.numel() else 0.0
+            if len(self._mean_len) > 64:
+                self._mean_len.clear()
+            self._mean_len[key] = mean
+        return max(1, int(B * mean))
 
     def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None, slot=0, loss_log=None):
         """rows=None: the tensors ARE the batch ([B,L]/[B]); else they are dataset tensors indexed by rows[B].

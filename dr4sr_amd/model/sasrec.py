@@ -146,6 +146,11 @@ class SASRec(BaseModel):
                                    seed=int(tc["seed"]) + 7919 * self.rank, lr=float(tc["learning_rate"]),
                                    weight_decay=float(tc["weight_decay"]), n_slots=self._n_slots())
         self.device = self.engine.device
+        try:                                   # regime hint for plans on per-batch tensors (engine._expected_tokens): mean valid length
+            sl = dataset_list[0].fields()["seqlen"]
+            self.engine.mean_len = float(sl.clamp(0, self.max_seq_len).float().mean()) if sl.numel() else None
+        except Exception:                      # a dataset class without resident fields: plans measure their own tensors
+            self.engine.mean_len = None
         self.item_embedding = _Embedding(self.engine, "item_embedding.weight", self._table_rows(), self.embed_dim, padding_idx=0)
         self.query_encoder = SASRecQueryEncoder(self.fiid, self.embed_dim, self.max_seq_len, mc["head_num"], mc["hidden_size"],
                                                 mc["dropout_rate"], mc["activation"], mc["layer_norm_eps"], mc["layer_num"],

@@ -17,3 +17,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def at_scale(monkeypatch):
+    """the at-scale launch forms (32-row tiles, length-class attention lists, scatter / owner jobs in k_wgrad) whatever the batch's
+    expected token count: the library picks its regime from the plan's expected_tokens hint (csrc/kernels.h), which would send the
+    smaller at-scale test batches down the latency forms"""
+    monkeypatch.setenv("DR4SR_FORCE_SCALE", "1")

@@ -556,3 +556,31 @@ def test_fit_from_reference_on_disk_files(tmp_path, monkeypatch, model_name):
     assert set(out1) == set(out2) and all(np.isfinite(v) for v in out1.values())
     assert all(abs(out1[k] - out2[k]) < 0.03 for k in out1), (out1, out2)
     assert len(list((tmp_path / "saved" / model_name / "disk-toys").glob("*.ckpt"))) == 2
+
+
+def test_regime_follows_the_expected_token_hint(monkeypatch):
+    """include/dr4sr_hip.h dr4sr_sasrec_plan.expected_tokens: the launch forms follow the host's estimate of VALID tokens (boundary
+    ~10 k, the measured crossover of tools/regime_sweep.sh), not the capacity B * L; 0 = unknown keeps the capacity rule (16 384);
+    DR4SR_FORCE_SCALE overrides both.  The engine fills the hint from the seqlen tensor of the plan."""
+    import ctypes as C
+    from dr4sr_amd import _lib
+    from dr4sr_amd.engine import SasrecEngine
+    lib = _lib.load()
+    eng = SasrecEngine(500, 50, 64, 2, 128, 2, 1e-12, 0.0, 4096, "cuda")
+    dev = eng.device
+    ids = torch.ones(4096, 50, dtype=torch.int64, device=dev)
+
+    def scale(B, lens, hint=None):
+        plan = eng.make_plan(ids[:B], ids[:B], lens[:B].contiguous())
+        if hint is not None:
+            plan.expected_tokens = hint
+        return int(lib.dr4sr_sasrec_at_scale(C.byref(plan)))
+    short, full = torch.full((4096,), 5, dtype=torch.int64, device=dev), torch.full((4096,), 50, dtype=torch.int64, device=dev)
+    assert scale(256, short) == 0 and scale(1024, short) == 0 and scale(2000, short) == 0      # 10 000 expected tokens
+    assert scale(2100, short) == 1 and scale(4096, short) == 1
+    assert scale(128, full) == 0 and scale(256, full) == 1                                     # 6 400 / 12 800 tokens
+    assert scale(256, short, hint=0) == 0 and scale(400, short, hint=0) == 1                   # unknown: capacity 12 800 / 20 000
+    monkeypatch.setenv("DR4SR_FORCE_SCALE", "1")
+    assert scale(64, short) == 1
+    monkeypatch.setenv("DR4SR_FORCE_SCALE", "0")
+    assert scale(4096, full) == 0

@@ -227,7 +227,7 @@ def test_metamodel_fit_end_to_end(tmp_path, monkeypatch, sub):
     assert {"ndcg@20", "recall@20"} <= set(out) and all(np.isfinite(v) for v in out.values())
 
 
-def test_fused_weighted_step_at_scale_matches_dense_path(monkeypatch):
+def test_fused_weighted_step_at_scale_matches_dense_path(monkeypatch, at_scale):
     """B = 512 (T_max > 16 384): the weighted fused step runs with 32-row token tiles, the length-class attention launches (tiny VALU
     class included) and the owner-computed table gradient (scorer records carry weight * dpos / weight * dneg) — it must equal the
     dense C-ABI composition started from the same RNG step, with dropout and in-kernel Gumbel noise"""

@@ -250,7 +250,7 @@ def test_full_size_batch_vs_oracle(dev, dense, D, n_items):
         assert relerr(v, g1[k].cpu()) < 1e-5, k
 
 
-def test_large_batch_length_split_attention(dev, monkeypatch):
+def test_large_batch_length_split_attention(dev, monkeypatch, at_scale):
     """B = 1024 (T_max > 16384): BM = 32 token tiles and the attention split into a short-sequence (n <= 16) and a long-sequence
     persistent launch over k_prep's length-class lists.  Checked against the oracle and against the unsplit launch."""
     from dr4sr_amd.engine import SasrecEngine
@@ -665,7 +665,7 @@ def test_dropout_sites_of_every_shape_match_oracle_with_same_masks(D, H, F, NL, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,D,p", [(8192, 64, 0.0), (8192, 64, 0.5), (4096, 128, 0.3)])
-def test_persistent_attention_lists_longer_than_the_grid(dev, monkeypatch, B, D, p):
+def test_persistent_attention_lists_longer_than_the_grid(dev, monkeypatch, at_scale, B, D, p):
     """thousands of sequences per length class: every workgroup of the persistent attention launches walks SEVERAL list entries, i.e.
     the software-pipelined loop (rows of i+1 / cu words of i+2 / list entry of i+3 in flight) runs its steady state and its drain.
     Checked against the one-workgroup-per-sequence launch of the same step (itself checked against the oracle above); with dropout the

@@ -103,7 +103,7 @@ def test_gru4rec_nocoop_switch_small_batch_vs_oracle(monkeypatch):
 
 # ------------------------------------------------------------------------------------------------ SASRec throughput mode
 @pytest.mark.parametrize("dense", [False, True])
-def test_sasrec_throughput_mode_B8192_vs_oracle(dense):
+def test_sasrec_throughput_mode_B8192_vs_oracle(dense, at_scale):
     """B = 8192 (toys histogram: 44 k tokens; dense: 410 k tokens): BM = 32 token tiles, persistent short / long attention lists
     walked several entries per workgroup, embedding scatter as a k_wgrad job — loss and EVERY gradient against the dense
     oracle's autograd (128 host threads: seconds)"""
@@ -131,7 +131,7 @@ def test_sasrec_throughput_mode_B8192_vs_oracle(dense):
 
 
 @pytest.mark.parametrize("D,B,p", [(64, 2048, 0.0), (64, 2048, 0.5), (128, 1024, 0.3)])
-def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, D, B, p):
+def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, at_scale, D, B, p):
     """sequences of 1..8 tokens run on the VALU kernels of csrc/attn_tiny.hip in the split launches; DR4SR_ATTN_NOTINY sends the same
     list through the 16-row MFMA kernels: identical statistics / dropout element indexing, so losses and gradients agree to fp32
     summation order — also with dropout ON (the two classes regenerate the same Philox masks).  Batch with every length 1..8
@@ -172,7 +172,7 @@ def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, D, B, p):
 
 @pytest.mark.parametrize("D,B,p,n_items", [(64, 2048, 0.0, 3000), (64, 4096, 0.5, 11925), (128, 1024, 0.2, 20034), (64, 1024, 0.0, 70000),
                                            (64, 2048, 0.0, 30000)])
-def test_owner_computed_table_gradient(monkeypatch, D, B, p, n_items):
+def test_owner_computed_table_gradient(monkeypatch, at_scale, D, B, p, n_items):
     """large batches: the item-table gradient is summed row by row by owner workgroups inside k_wgrad (csrc/linear.hip owner_job)
     instead of fp32 atomics from the scorer and the embedding scatter.  (1) it equals the atomic path (DR4SR_DE_ATOMIC) to fp32
     summation order — with dropout too; (2) it is a pure function of the batch: two replays give BIT-identical table gradients
@@ -225,7 +225,7 @@ def test_owner_computed_table_gradient(monkeypatch, D, B, p, n_items):
 
 def test_owner_sorted_entries_with_64_row_tiles():
     """DR4SR_BM=64 (static switch: subprocess): tile_sort with 192 entries per tile (three per lane of the sorting wave) at scale"""
-    e = dict(os.environ, DR4SR_BM="64")
+    e = dict(os.environ, DR4SR_BM="64", DR4SR_FORCE_SCALE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
                         "test_owner_computed_table_gradient and (3000 or 11925)", os.path.abspath(__file__)],
                        env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -238,7 +238,7 @@ def test_fuzz_large_batches_vs_oracle():
     11 925 items, both widths, PAD targets, PAD ids inside sequences) through the fused step vs the oracle"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_scale.py")], capture_output=True, text=True, timeout=900,
-                         env=dict(os.environ, TRIALS="8", SEED="5"), cwd=root)
+                         env=dict(os.environ, TRIALS="8", SEED="5", DR4SR_FORCE_SCALE="1"), cwd=root)
     assert out.returncode == 0 and "FUZZ-SCALE ok" in out.stdout, out.stdout[-2500:] + out.stderr[-1500:]
 
 
