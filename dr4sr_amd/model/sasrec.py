@@ -140,7 +140,7 @@ class SASRec(BaseModel):
     def __init__(self, config, dataset_list) -> None:
         super().__init__(config, dataset_list)
         mc, tc = config["model"], config["train"]
-        max_b = max(int(tc["batch_size"]), int(config["eval"]["batch_size"]))
+        max_b = self._max_batch(config)
         self.engine = SasrecEngine(self._table_rows(), self.max_seq_len, self.embed_dim, mc["head_num"], mc["hidden_size"],
                                    mc["layer_num"], mc["layer_norm_eps"], mc["dropout_rate"], max_b, self.device,
                                    seed=int(tc["seed"]) + 7919 * self.rank, lr=float(tc["learning_rate"]),
@@ -161,6 +161,9 @@ class SASRec(BaseModel):
 
     def _table_rows(self) -> int:          # rows of the item table (CL4SRec adds the mask item)
         return self.num_items
+
+    def _max_batch(self, config) -> int:   # rows the engine's workspaces are sized for
+        return max(int(config["train"]["batch_size"]), int(config["eval"]["batch_size"]))
 
     def _n_slots(self) -> int:             # forward passes alive per step
         return 1

@@ -36,13 +36,17 @@ class _DeviceAugmentation(torch.nn.Module):
             self.step_dev.add_(self._in_step)
 
     def two_views(self, sequences, seq_lens):
-        """the two consecutive draws of a CL4SRec step in ONE launch (captured steps; eager: two forward() calls)"""
-        if self.step_dev is None:
-            return self.forward(sequences, seq_lens), self.forward(sequences, seq_lens)
-        lib = _lib.load()
+        """the two consecutive draws of a CL4SRec step in ONE launch (captured steps; eager: two forward() calls).  The two views are
+        the halves of ONE [2B, L] / [2B] pair of tensors, so that a caller may also encode them as one batch of 2B sequences."""
         seq, sl = sequences.contiguous(), seq_lens.contiguous()
         B, L = seq.shape
-        oi, li, oj, lj = torch.empty_like(seq), torch.empty_like(sl), torch.empty_like(seq), torch.empty_like(sl)
+        out, out_len = seq.new_empty(2 * B, L), sl.new_empty(2 * B)
+        oi, li, oj, lj = out[:B], out_len[:B], out[B:], out_len[B:]
+        if self.step_dev is None:
+            (a, la), (b, lb) = self.forward(sequences, seq_lens), self.forward(sequences, seq_lens)
+            oi.copy_(a); li.copy_(la); oj.copy_(b); lj.copy_(lb)
+            return (oi, li), (oj, lj)
+        lib = _lib.load()
         _lib.check(lib.dr4sr_cl_augment2_dev(_lib.ptr(seq), _lib.ptr(sl), _lib.ptr(oi), _lib.ptr(li), _lib.ptr(oj), _lib.ptr(lj), B, L, self.mode,
                                              self.tao, self.gamma, self.beta, self.mask_id, self.seed, _lib.ptr(self.step_dev),
                                              self._in_step + 1, _lib.cur_stream()), "dr4sr_cl_augment2_dev")

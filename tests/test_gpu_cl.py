@@ -197,13 +197,17 @@ def test_cl4srec_graph_replayed_epoch_equals_eager_epoch(monkeypatch):
         assert float((pa[n] - pb[n]).abs().max()) < 5e-4, n     # 8 Adam steps of lr 1e-3: fp32 atomics order, nothing systematic
 
 
-@pytest.mark.parametrize("dropout", [0.0, 0.5])
-def test_cl4srec_direct_step_equals_autograd_step(monkeypatch, dropout):
+@pytest.mark.parametrize("dropout,two_pass", [(0.0, False), (0.0, True), (0.5, True)])
+def test_cl4srec_direct_step_equals_autograd_step(monkeypatch, dropout, two_pass):
     """the step body the captured graph replays composes the C-ABI calls directly (fused main pass on the batch's negatives, InfoNCE
     backward scaled on the device, encoder backward passes of the two views accumulating into the flat gradient, Adam dividing by
     n_valid); DR4SR_CL_AUTOGRAD=1 runs the reference-shaped loop body (training_step -> loss.backward() -> optimizer.step()): same
-    negatives, same views, same dropout masks, same losses and parameters"""
+    negatives, same views, same dropout masks, same losses and parameters.  By default the direct body encodes the two views as ONE
+    batch of 2B sequences (exactly the same arithmetic; with dropout the masks come from one stream instead of two, so the
+    bit-level comparison with dropout on uses DR4SR_CL_TWO_PASS = one pass per view)"""
     monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    if two_pass:
+        monkeypatch.setenv("DR4SR_CL_TWO_PASS", "1")
     from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
     res = []
     for autograd in (True, False):
