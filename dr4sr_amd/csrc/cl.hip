@@ -24,6 +24,7 @@ __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __r
                              int64_t* __restrict__ out_len, int B, int L, int mode, double tau, double gamma, double beta,
                              int64_t mask_id, uint64_t seed, uint32_t step, const int32_t* __restrict__ step_dev,
                              int64_t* __restrict__ out2, int64_t* __restrict__ out_len2) {
+    __shared__ unsigned char perm_lds[64 * 64];            // blockDim.x = 64 threads x up to 64 segment positions
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if (blockIdx.y) { out = out2; out_len = out_len2; step += 1; }     // second view of the same launch = the next call's draw
@@ -41,27 +42,26 @@ __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __r
         for (int l = 0; l < L; ++l) dst[l] = l < sub ? src[start + l] : 0;
         out_len[b] = sub;
     } else if (mode == 1) {                            // Item_Mask :44-62: int(gamma n) distinct positions -> mask_id
-        const int sub = (int)(gamma * (double)n);
-        int pos[64];
-        for (int l = 0; l < n; ++l) pos[l] = l;
-        for (int k = 0; k < sub; ++k) {                // partial Fisher-Yates = np.random.choice(n, sub, replace=False)
-            const int j = k + rand_below(aug_rand(rk, st, k), n - k);
-            const int t = pos[k]; pos[k] = pos[j]; pos[j] = t;
+        // a uniformly random subset of size sub = np.random.choice(n, sub, replace=False) as a SET (every member gets mask_id, so
+        // the order of the draw is immaterial): selection sampling, position l is taken with probability needed / remaining.
+        // No per-thread index array: the Fisher-Yates form kept one in scratch memory, a ~1 us dependent access per swap.
+        int need = (int)(gamma * (double)n);
+        for (int l = 0; l < L; ++l) {
+            int64_t v = src[l];
+            if (l < n && need > 0 && rand_below(aug_rand(rk, st, l), n - l) < need) { v = mask_id; --need; }
+            dst[l] = v;
         }
-        for (int l = 0; l < L; ++l) dst[l] = src[l];
-        for (int k = 0; k < sub; ++k) dst[pos[k]] = mask_id;
         out_len[b] = n;
     } else {                                           // Item_Reorder :65-85: shuffle a contiguous segment of length int(beta n)
         const int sub = (int)(beta * (double)n);
         const int start = rand_below(aug_rand(rk, st, 0), n - sub + 1);
-        int idx[64];
-        for (int k = 0; k < sub; ++k) idx[k] = k;
+        unsigned char* idx = perm_lds + threadIdx.x * 64;                // this thread's permutation of the segment (LDS, not scratch)
+        for (int k = 0; k < sub; ++k) idx[k] = (unsigned char)k;
         for (int k = sub - 1; k > 0; --k) {            // Fisher-Yates = random.shuffle
             const int j = rand_below(aug_rand(rk, st, 1 + k), k + 1);
-            const int t = idx[k]; idx[k] = idx[j]; idx[j] = t;
+            const unsigned char t = idx[k]; idx[k] = idx[j]; idx[j] = t;
         }
-        for (int l = 0; l < L; ++l) dst[l] = src[l];
-        for (int k = 0; k < sub; ++k) dst[start + k] = src[start + idx[k]];
+        for (int l = 0; l < L; ++l) dst[l] = (l >= start && l < start + sub) ? src[start + idx[l - start]] : src[l];
         out_len[b] = n;
     }
 }
