@@ -98,12 +98,16 @@ __device__ __forceinline__ void finish_launch(int* ctl) {
 // ------------------------------------------------------------------------------------------------ forward
 template <int H, int NS>
 __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_fwd_coop(const CoopArgs A) {
-    constexpr int US = H / NS, UTL = US / 16, NW = UTL * 4, NT = NW * 64, LDW = H + 4, LDH = H + 4;
+    constexpr int US = H / NS, UTL = US / 16, NW = UTL * 4, NT = NW * 64, LDW = H + 4;
     static_assert(US % 16 == 0 && NT == coop_threads(H, NS) && 16 * US <= NT && (16 * H) % NT == 0, "slice geometry");
     float* Ws = smem;                                     // [3*US][LDW]  this slice's rows of W_hh (gate-major)
-    float* hA = Ws + 3 * US * LDW;                        // [16][LDH]    h_{t-1} of the group's 16 sequences
-    float* part = hA + 16 * LDH;                          // [4 kq][3][16][US]
-    int* meta = reinterpret_cast<int*>(part + 4 * 3 * 16 * US);       // [16] t0, [16] n
+    // one unit tile per slice (UTL == 1: every h value is multiplied by exactly one wave): the waves poll their own A fragments;
+    // two unit tiles (H = 256 on 8 slices): h_t is gathered once per workgroup into LDS (two waves would poll each granule)
+    constexpr bool DIRECT = UTL == 1;
+    constexpr int LDH = H + 4;
+    float* hA = Ws + 3 * US * LDW;                        // !DIRECT: [16][LDH] h_{t-1} of the group's 16 sequences
+    float* part = DIRECT ? hA : hA + 16 * LDH;            // DIRECT: [2 parity][4 kq][3][16][US], else [4 kq][3][16][US]
+    int* meta = reinterpret_cast<int*>(part + (DIRECT ? 2 : 1) * 4 * 3 * 16 * US);   // [16] t0, [16] n
     // speed-only placement (block b is observed on XCD b % 8): the 8 slices of a group sit on ONE XCD, so their per-step exchange
     // stays inside that XCD's L2; correctness does not depend on it (agent-scope granules)
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -114,11 +118,16 @@ __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_fwd_coop(const Coop
         meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
         meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
     }
-    for (int i = threadIdx.x; i < 3 * US * (H / 4); i += NT) {
-        const int lr = i / (H / 4), c = (i % (H / 4)) * 4, gate = lr / US, u = lr % US;
-        st4(Ws + lr * LDW + c, ld4(A.whh + (size_t)(gate * H + sl * US + u) * H + c));
+    // W_hh rows of the slice.  DIRECT: columns PERMUTED inside each K quarter of H/4 — the MFMA step s of lane group g multiplies K
+    // index kq H/4 + 4 s + g (so that the h granules one poll instruction reads are 64 consecutive ones, below); a lane's float4
+    // number c must then hold the columns 16 c + 4 j + g, j = 0..3, at position g H/16 + 4 c + j.
+    for (int i = threadIdx.x; i < 3 * US * H; i += NT) {
+        const int lr = i / H, k = i % H, gate = lr / US, u = lr % US;
+        const int kq_ = k / (H / 4), kl = k % (H / 4), cc = kl / 16, jj = (kl % 16) / 4, gg = kl % 4;
+        const int pos = DIRECT ? kq_ * (H / 4) + gg * (H / 16) + 4 * cc + jj : k;
+        Ws[lr * LDW + pos] = A.whh[(size_t)(gate * H + sl * US + u) * H + k];
     }
-    for (int i = threadIdx.x; i < 16 * LDH; i += NT) hA[i] = 0.f;
+    if constexpr (!DIRECT) { for (int i = threadIdx.x; i < 16 * LDH; i += NT) hA[i] = 0.f; }
     __syncthreads();
     int nmax = 0;
 #pragma unroll
@@ -132,55 +141,110 @@ __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_fwd_coop(const Coop
     const int tq = meta[es], nq = own ? meta[16 + es] : 0, gu = sl * US + eu;     // global unit
     float hown = 0.f;
     u64* xg = A.xch + (size_t)grp * 2 * 16 * H;
-    for (int t = 0; t < nmax; ++t) {
-        const bool act = t < nq;
-        float gir = 0.f, giz = 0.f, gin = 0.f;
-        if (act) { const float* gip = A.gi + (size_t)(tq + t) * 3 * H + gu; gir = gip[0]; giz = gip[H]; gin = gip[2 * H]; }
-        // gh partial over this wave's K quarter for its 16 units, all three gates
-        f32x4 acc[3];
-#pragma unroll
-        for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* ar = hA + l16 * LDH + kq * (H / 4) + g * (H / 16);
-        const float* br = Ws + (ct * 16 + l16) * LDW + kq * (H / 4) + g * (H / 16);
-#pragma unroll
-        for (int c = 0; c < H / 16; c += 4) {
-            const float4 a = ld4(ar + c);
-#pragma unroll
-            for (int q3 = 0; q3 < 3; ++q3) {
-                const float4 b = ld4(br + q3 * US * LDW + c);
-                acc[q3] = mfma16c(a.x, b.x, acc[q3]); acc[q3] = mfma16c(a.y, b.y, acc[q3]);
-                acc[q3] = mfma16c(a.z, b.z, acc[q3]); acc[q3] = mfma16c(a.w, b.w, acc[q3]);
+    if constexpr (DIRECT) {
+        // A operand of the step's MFMAs, in registers: lane (l16, g) of K-quarter wave kq supplies h_{t-1}[sequence l16][kq H/4 + 4 s + g]
+        // at MFMA step s — sixteen granules of the exchange buffer, 64 apart.  Each wave polls exactly the granules it multiplies with (no
+        // staging of h in LDS, no second barrier per step); the `part` tiles alternate by step parity so ONE barrier per step is enough.
+        constexpr int KV = H / 16;
+        float hv[KV];
+    #pragma unroll
+        for (int k = 0; k < KV; ++k) hv[k] = 0.f;
+        for (int t = 0; t < nmax; ++t) {
+            const bool act = t < nq;
+            float gir = 0.f, giz = 0.f, gin = 0.f;
+            if (act) { const float* gip = A.gi + (size_t)(tq + t) * 3 * H + gu; gir = gip[0]; giz = gip[H]; gin = gip[2 * H]; }
+            if (t > 0)                                         // all-gather of h_{t-1}: this lane's slice of the A operand
+                sweep_granules<KV>(xg + (size_t)((t - 1) & 1) * 16 * H + (size_t)(kq * (H / 16) * 16 + l16) * 4 + g, 64, base + t, hv, A.ctl + 2);
+            // gh partial over this wave's K quarter for its 16 units, all three gates
+            f32x4 acc[3];
+    #pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* br = Ws + (ct * 16 + l16) * LDW + kq * (H / 4) + g * KV;
+    #pragma unroll
+            for (int c = 0; c < KV; c += 4) {
+    #pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3) {
+                    const float4 b = ld4(br + q3 * US * LDW + c);
+                    acc[q3] = mfma16c(hv[c], b.x, acc[q3]); acc[q3] = mfma16c(hv[c + 1], b.y, acc[q3]);
+                    acc[q3] = mfma16c(hv[c + 2], b.z, acc[q3]); acc[q3] = mfma16c(hv[c + 3], b.w, acc[q3]);
+                }
+            }
+            float* pt = part + (t & 1) * (4 * 3 * 16 * US);
+    #pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) pt[((kq * 3 + q3) * 16 + 4 * g + r) * US + ct * 16 + l16] = acc[q3][r];
+            __syncthreads();
+            if (own) {
+                float gh[3];
+    #pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3) {
+                    const float* pp = pt + (q3 * 16 + es) * US + eu;
+                    gh[q3] = (pp[0] + pp[3 * 16 * US]) + (pp[2 * 3 * 16 * US] + pp[3 * 3 * 16 * US]);
+                }
+                if (act) {
+                    const float rr = sigm(gir + gh[0]), zz = sigm(giz + gh[1]), nn = tanh_f(gin + rr * gh[2]);
+                    const float hnew = (1.0f - zz) * nn + zz * hown;
+                    const size_t o = (size_t)(tq + t) * H + gu;
+                    A.r[o] = rr; A.z[o] = zz; A.n[o] = nn; A.ghn[o] = gh[2]; A.hprev[o] = hown; A.hout[o] = hnew;
+                    hown = hnew;
+                }
+                // exchange layout [K / 4][sequence][K % 4]: the 64 lanes of a poll instruction (16 sequences x 4 lane groups, one MFMA
+                // step) read 512 contiguous bytes
+                if (t + 1 < nmax) put_granule(xg + (size_t)(t & 1) * 16 * H + (size_t)((gu >> 2) * 16 + es) * 4 + (gu & 3), base + t + 1, hown);
             }
         }
-#pragma unroll
-        for (int q3 = 0; q3 < 3; ++q3)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[((kq * 3 + q3) * 16 + 4 * g + r) * US + ct * 16 + l16] = acc[q3][r];
-        __syncthreads();
-        if (own) {
-            float gh[3];
-#pragma unroll
-            for (int q3 = 0; q3 < 3; ++q3) {
-                const float* pp = part + (q3 * 16 + es) * US + eu;
-                gh[q3] = (pp[0] + pp[3 * 16 * US]) + (pp[2 * 3 * 16 * US] + pp[3 * 3 * 16 * US]);
+    } else {
+        for (int t = 0; t < nmax; ++t) {
+            const bool act = t < nq;
+            float gir = 0.f, giz = 0.f, gin = 0.f;
+            if (act) { const float* gip = A.gi + (size_t)(tq + t) * 3 * H + gu; gir = gip[0]; giz = gip[H]; gin = gip[2 * H]; }
+            // gh partial over this wave's K quarter for its 16 units, all three gates
+            f32x4 acc[3];
+    #pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* ar = hA + l16 * LDH + kq * (H / 4) + g * (H / 16);
+            const float* br = Ws + (ct * 16 + l16) * LDW + kq * (H / 4) + g * (H / 16);
+    #pragma unroll
+            for (int c = 0; c < H / 16; c += 4) {
+                const float4 a = ld4(ar + c);
+    #pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3) {
+                    const float4 b = ld4(br + q3 * US * LDW + c);
+                    acc[q3] = mfma16c(a.x, b.x, acc[q3]); acc[q3] = mfma16c(a.y, b.y, acc[q3]);
+                    acc[q3] = mfma16c(a.z, b.z, acc[q3]); acc[q3] = mfma16c(a.w, b.w, acc[q3]);
+                }
             }
-            if (act) {
-                const float rr = sigm(gir + gh[0]), zz = sigm(giz + gh[1]), nn = tanh_f(gin + rr * gh[2]);
-                const float hnew = (1.0f - zz) * nn + zz * hown;
-                const size_t o = (size_t)(tq + t) * H + gu;
-                A.r[o] = rr; A.z[o] = zz; A.n[o] = nn; A.ghn[o] = gh[2]; A.hprev[o] = hown; A.hout[o] = hnew;
-                hown = hnew;
+    #pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) part[((kq * 3 + q3) * 16 + 4 * g + r) * US + ct * 16 + l16] = acc[q3][r];
+            __syncthreads();
+            if (own) {
+                float gh[3];
+    #pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3) {
+                    const float* pp = part + (q3 * 16 + es) * US + eu;
+                    gh[q3] = (pp[0] + pp[3 * 16 * US]) + (pp[2 * 3 * 16 * US] + pp[3 * 3 * 16 * US]);
+                }
+                if (act) {
+                    const float rr = sigm(gir + gh[0]), zz = sigm(giz + gh[1]), nn = tanh_f(gin + rr * gh[2]);
+                    const float hnew = (1.0f - zz) * nn + zz * hown;
+                    const size_t o = (size_t)(tq + t) * H + gu;
+                    A.r[o] = rr; A.z[o] = zz; A.n[o] = nn; A.ghn[o] = gh[2]; A.hprev[o] = hown; A.hout[o] = hnew;
+                    hown = hnew;
+                }
+                if (t + 1 < nmax) put_granule(xg + ((size_t)(t & 1) * 16 + es) * H + gu, base + t + 1, hown);
             }
-            if (t + 1 < nmax) put_granule(xg + ((size_t)(t & 1) * 16 + es) * H + gu, base + t + 1, hown);
+            if (t + 1 < nmax) {                                // all-gather h_t of the 8 slices into the A operand tile
+                const u64* src = xg + (size_t)(t & 1) * 16 * H;
+                float hv[(16 * H) / NT];                       // 8 granules per thread, stride NT
+                sweep_granules<(16 * H) / NT>(src + threadIdx.x, NT, base + t + 1, hv, A.ctl + 2);
+    #pragma unroll
+                for (int k = 0; k < (16 * H) / NT; ++k) { const int i = threadIdx.x + k * NT; hA[(i / H) * LDH + (i % H)] = hv[k]; }
+            }
+            __syncthreads();
         }
-        if (t + 1 < nmax) {                                // all-gather h_t of the 8 slices into the A operand tile
-            const u64* src = xg + (size_t)(t & 1) * 16 * H;
-            float hv[(16 * H) / NT];                       // 8 granules per thread, stride NT
-            sweep_granules<(16 * H) / NT>(src + threadIdx.x, NT, base + t + 1, hv, A.ctl + 2);
-#pragma unroll
-            for (int k = 0; k < (16 * H) / NT; ++k) { const int i = threadIdx.x + k * NT; hA[(i / H) * LDH + (i % H)] = hv[k]; }
-        }
-        __syncthreads();
     }
     finish_launch(A.ctl);
 }
@@ -286,7 +350,7 @@ __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_bwd_coop(const Coop
 
 template <int H, int NS> size_t coop_lds(bool bwd) {
     constexpr int US = H / NS;
-    return sizeof(float) * (3 * US * (H + 4) + (bwd ? 16 * (3 * US + 4) : 16 * (H + 4) + 4 * 3 * 16 * US)) + 32 * sizeof(int);
+    return sizeof(float) * (3 * US * (H + 4) + (bwd ? 16 * (3 * US + 4) : (US == 16 ? 2 * 4 * 3 * 16 * US : 16 * (H + 4) + 4 * 3 * 16 * US))) + 32 * sizeof(int);
 }
 
 }  // namespace
