@@ -32,7 +32,7 @@ struct FmlpWs {
     float* e0; float* st0;
     float* X[DR4SR_MAX_LAYERS + 1]; float* dX[DR4SR_MAX_LAYERS + 1];
     float* m; float* dm;                      // [n_layer][L][D]
-    float* dm_part;                           // [n_layer][FM_DMBLK][L][D] per-block partials of dm (summed by k_fmlp_dm_reduce)
+    float* dm_part;                           // [n_layer + 1][FM_DMBLK][L][D] per-block partials of dm, last slab: of dP (summed by k_fmlp_dm_reduce)
     float* score_part; float* ln_part;        // [B][2]; [n_layer][ntiles][4][D]
     FmlpLayerWs layer[DR4SR_MAX_LAYERS];
     int64_t bytes;
@@ -77,7 +77,7 @@ static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
     ws->e0 = take(Tn * D); ws->st0 = take(Tn * 2);
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tn * D); ws->dX[i] = take(Tn * D); }
     ws->m = take((int64_t)p->n_layer * p->L * D); ws->dm = take((int64_t)p->n_layer * p->L * D);
-    ws->dm_part = take((int64_t)p->n_layer * FM_DMBLK * p->L * D);
+    ws->dm_part = take((int64_t)(p->n_layer + 1) * FM_DMBLK * p->L * D);
     ws->score_part = take(2LL * p->B);
     ws->ln_part = take((int64_t)p->n_layer * ((Tn + 31) / 32) * 4 * D);        // sized for the smallest FFN tile
     for (int l = 0; l < p->n_layer; ++l) {
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ par
 // dm[layer][i] = sum over the nblk per-workgroup partials written by k_fmlp_filter_bwd (fixed order -> deterministic).
 // 64 columns per workgroup, the partials split over its 4 waves, 8 independent loads in flight per thread: the first version (one
 // thread walking all 256 partials of a column, 26 workgroups) was a 60 us chain of dependent-latency loads.
-__global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict__ part, float* __restrict__ dm, int nblk, int n) {
+// blockIdx.y == n_layer: the slab of the position-table gradient partials left by k_fmlp_embed_bwd -> dP (this launch is its only writer)
+__global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict__ part, float* __restrict__ dm, int nblk, int n,
+                                                        float* __restrict__ dP, int n_layer) {
     __shared__ float red[4][64];
     const int layer = blockIdx.y, c = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
     float acc[8];
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict_
     }
     red[w][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    if (w == 0 && i < n) dm[(size_t)layer * n + i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (w == 0 && i < n) (layer == n_layer ? dP : dm + (size_t)layer * n)[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 // d(complex_weight) += fold(dm)
 __global__ __launch_bounds__(256) void k_fmlp_coef_bwd(float* __restrict__ grads, int64_t o_cw0, int64_t layer_stride,
@@ -248,12 +250,9 @@ __global__ __launch_bounds__(256) void k_fmlp_embed_bwd(const FEmbArgs A) {
         }
     }
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int l = ps * 16 + rsub;
-        if (l < A.L) {
-            float* d = A.dP + (size_t)l * FM_D + c;
-            unsafeAtomicAdd(d, accP[ps].x); unsafeAtomicAdd(d + 1, accP[ps].y); unsafeAtomicAdd(d + 2, accP[ps].z); unsafeAtomicAdd(d + 3, accP[ps].w);
-        }
+    for (int ps = 0; ps < 4; ++ps) {                   // deterministic: one dP partial [L][64] per workgroup, summed by k_fmlp_dm_reduce
+        const int l = ps * 16 + rsub;                  // (atomics from 64 workgroups into the 3 200 dP words were 2/3 of this launch)
+        if (l < A.L) st4(A.dP + ((size_t)blockIdx.x * A.L + l) * FM_D + c, accP[ps]);
     }
     // fold the 16 row groups -> one [2*D] row in LDS, then one atomic per column per block
     {
@@ -541,12 +540,12 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     }
     FEmbArgs E{};
     E.lnw = p->params + ws.off[2]; E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0;
-    E.dx0 = ws.dX[0]; E.dE = p->grads + ws.off[0]; E.dP = p->grads + ws.off[1]; E.dlnw = p->grads + ws.off[2]; E.dlnb = p->grads + ws.off[3];
+    E.dx0 = ws.dX[0]; E.dE = p->grads + ws.off[0]; E.dP = ws.dm_part + (size_t)nl * FM_DMBLK * L * FM_D; E.dlnw = p->grads + ws.off[2]; E.dlnb = p->grads + ws.off[3];
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
-    hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < 64 ? p->B : 64), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < FM_DMBLK ? p->B : FM_DMBLK), dim3(256), 0, s, E);    // one dP partial per workgroup
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
-    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3((L * FM_D + 63) / 64, nl), dim3(256), 0, s, ws.dm_part, ws.dm,
-                       p->B < FM_DMBLK ? p->B : FM_DMBLK, L * FM_D);
+    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3((L * FM_D + 63) / 64, nl + 1), dim3(256), 0, s, ws.dm_part, ws.dm,
+                       p->B < FM_DMBLK ? p->B : FM_DMBLK, L * FM_D, p->grads + ws.off[1], nl);
     hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl, ((L / 2 + 1) * FM_D + 255) / 256), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
     WgradArgs W{};
     for (int l = 0; l < nl; ++l) {
