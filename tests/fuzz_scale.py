@@ -1,6 +1,8 @@
-"""random LARGE batches (T_max > 16 384: 32-row tiles, length-class attention launches with the VALU class for 1..8 tokens, owner-computed
-table gradient) through the fused step vs the oracle: random batch size, catalog size, length mix (incl. all-tiny, all-long, lengths at
-every class boundary), PAD targets, PAD ids inside sequences"""
+"""random LARGE batches (B = 330 .. 3000) through the fused step vs the oracle: random batch size, catalog size (down to 2 items: every
+token hits the same table rows), length mix (incl. all-tiny, all-long, lengths at every class boundary), PAD targets, PAD ids inside
+sequences.  With DR4SR_FORCE_SCALE=1 (how tests/test_gpu_r2_paths.py runs it) every trial takes the at-scale forms — 32-row tiles,
+length-class attention launches with the VALU class for 1..8 tokens, owner-computed table gradient; without it the regime follows the
+batch's expected tokens, so the same trials also drive the latency forms at batch sizes far above the reference's 256."""
 import os, sys, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
