@@ -998,7 +998,7 @@ __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTi
 }
 
 template <int BM, int D, int F, bool META>
-__global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) {
+__device__ __forceinline__ void post_mid_body(const PostArgs& A, const ScoreTileArgs& S) {
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
     if constexpr (BM != 16) { if (S.ent) tile_sort_init<BM>(S, smem + post_lds_floats(D, F, BM) + 8); }
@@ -1022,6 +1022,16 @@ __global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreT
         __syncthreads();                               // dz rows written, LDS scratch free again
         post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x);
     }
+}
+template <int BM, int D, int F, bool META>
+__global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) { post_mid_body<BM, D, F, META>(A, S); }
+// The 32-row (at-scale) form with its registers capped at 128: the fused kernel carries the query / dz rows and the scorer's prefetch
+// across its two halves (160 VGPRs: 3 waves per SIMD, where k_post_fwd / k_post_bwd run 4); capped it allocates 119 without a
+// vector spill and the fourth workgroup per CU (LDS: 4 x 36 KB) is worth 3 % (toys) to 6 % (dense) of the launch at B = 8192.
+// (d = 64, plain scorer only: the MetaModel weighting and d = 128 spill under the cap.)
+template <int D, int F>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_post_mid32(const PostArgs A, const ScoreTileArgs S) {
+    post_mid_body<32, D, F, false>(A, S);
 }
 
 static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
@@ -1072,7 +1082,8 @@ template <int BM>
 static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, const ScoreTileArgs& S, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
     const size_t lds = post_lds(p->D, p->F, BM) + 8 * sizeof(float) + (S.ent ? tile_sort_lds_bytes(BM, 1 << S.logG) : 0);   // + the scorer's (count, loss) reduction scratch + tile_sort's records
-#define PM(D_, F_) do { big_lds(k_post_mid<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_, false>), grid, blk, lds, s, A, S); } while (0)
+#define PM(D_, F_) do { if constexpr (BM == 32 && D_ == 64) { big_lds(k_post_mid32<D_, F_>, lds); hipLaunchKernelGGL((k_post_mid32<D_, F_>), grid, blk, lds, s, A, S); } \
+                        else { big_lds(k_post_mid<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_, false>), grid, blk, lds, s, A, S); } } while (0)
     if (S.phi) {                                       // MetaModel weighting: D = 64 only (checked by the entry point)
         if (p->D != 64 || p->F != 128) return DR4SR_E_SHAPE;
         big_lds(k_post_mid<BM, 64, 128, true>, lds); hipLaunchKernelGGL((k_post_mid<BM, 64, 128, true>), grid, blk, lds, s, A, S);
