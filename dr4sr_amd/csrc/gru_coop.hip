@@ -258,8 +258,8 @@ __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_bwd_coop(const Coop
     constexpr int US = H / NS, UTL = US / 16, NW = UTL * 4, NT = NW * 64, LDW = H + 4, KL = 3 * US, LDG = KL + 4;
     constexpr int CTW = (H / 16) / NW;                    // output column tiles per wave
     float* Ws = smem;                                     // [3*US][LDW]
-    float* dgl = Ws + 3 * US * LDW;                       // [16][LDG]  dgh tile of this slice (A operand)
-    int* meta = reinterpret_cast<int*>(dgl + 16 * LDG);
+    float* dgl0 = Ws + 3 * US * LDW;                      // [2 parity][16][LDG]  dgh tile of this slice (A operand): two tiles by step
+    int* meta = reinterpret_cast<int*>(dgl0 + 2 * 16 * LDG);   // parity, so that ONE barrier per time step is enough
     // speed-only placement (block b is observed on XCD b % 8): the 8 slices of a group sit on ONE XCD, so their per-step exchange
     // stays inside that XCD's L2; correctness does not depend on it (agent-scope granules)
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_bwd_coop(const Coop
     for (int t = nmax - 1; t >= 0; --t) {
         const unsigned tag = base + (unsigned)(nmax - 1 - t) + 1u;
         const int par = (nmax - 1 - t) & 1;
+        float* dgl = dgl0 + par * 16 * LDG;
         float keep = 0.f;
         if (own) {
             float dr = 0.f, dz = 0.f, dnr = 0.f;
@@ -343,14 +344,13 @@ __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_bwd_coop(const Coop
                 carry = s;
             }
         }
-        __syncthreads();
     }
     finish_launch(A.ctl);
 }
 
 template <int H, int NS> size_t coop_lds(bool bwd) {
     constexpr int US = H / NS;
-    return sizeof(float) * (3 * US * (H + 4) + (bwd ? 16 * (3 * US + 4) : (US == 16 ? 2 * 4 * 3 * 16 * US : 16 * (H + 4) + 4 * 3 * 16 * US))) + 32 * sizeof(int);
+    return sizeof(float) * (3 * US * (H + 4) + (bwd ? 2 * 16 * (3 * US + 4) : (US == 16 ? 2 * 4 * 3 * 16 * US : 16 * (H + 4) + 4 * 3 * 16 * US))) + 32 * sizeof(int);
 }
 
 }  // namespace
