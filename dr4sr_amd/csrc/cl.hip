@@ -4,7 +4,9 @@
 //                    Python with torch/numpy/random generators; the DISTRIBUTION is reproduced with Philox, not the streams).
 //   k_infonce_*    : InfoNCELoss(sim_method='inner_product', neg_type='batch_both'): logits = [x_i x_j^T | x_i x_i^T (diag -inf)] / T,
 //                    cross-entropy against the diagonal of the first block; rows with valid[b] == 0 are removed from rows AND
-//                    columns (the reference drops sequences of length 1 before the loss, data_augmentation.py:613-615).
+//                    columns (the reference drops sequences of length 1 before the loss, data_augmentation.py:613-615).  On MFMA tiles.
+//   k_cl_prepare / k_cl_scalars : glue of the step composed without autograd (model/cl4srec.py:_api_step_body): valid mask + zeroing;
+//                    the device scalars {InfoNCE backward scale, reported loss}.
 #include "common.h"
 #include "kernels.h"
 

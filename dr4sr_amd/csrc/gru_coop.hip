@@ -7,7 +7,9 @@
 // all-gather of h_t (forward) / one reduce-scatter of the dh partials (backward) per time step between the NS workgroups of a
 // group, INSIDE the launch.  NS = 8 (98 KB of weights per slice, one workgroup per CU, up to 24 groups) or, for batches of at
 // most 16 groups at H = 256, NS = 16 (49 KB, 4 waves per slice): the step's MFMA chain halves (1.28 -> 0.64 us of a 3.5 us
-// step) and 16 groups x 16 slices put one workgroup on every CU of an MI355X — B = 256: 288 k -> 343 k sequences/s.
+// step) and 16 groups x 16 slices put one workgroup on every CU of an MI355X — B = 256: 288 k -> 343 k sequences/s.  When a slice
+// has ONE 16-unit tile (NS = 16 at H = 256, NS = 8 at H = 128) the forward does not stage h in LDS at all: every wave polls the
+// granules that are its MFMA A fragments (355 k sequences/s); both kernels need one workgroup barrier per time step.
 //
 // Exchange protocol (cdna_hip_programming.md §6 Guideline 16, form R2 "the data is the flag"): every exchanged float travels
 // as ONE aligned 8-byte granule {tag, value} written with a relaxed agent-scope store (sc1, write-through) and polled with
