@@ -139,26 +139,38 @@ __global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ par
     }
 }
 // dm[layer][i] = sum over the nblk per-workgroup partials written by k_fmlp_filter_bwd (fixed order -> deterministic).
-// 64 columns per workgroup, the partials split over its 4 waves, 8 independent loads in flight per thread: the first version (one
-// thread walking all 256 partials of a column, 26 workgroups) was a 60 us chain of dependent-latency loads.
+// History of this launch: one thread walking all 256 partials of a column (26 workgroups): 60 us of dependent-latency loads; 64
+// columns per workgroup, partials split over 4 waves, 8 four-byte loads in flight per thread: 19.5 us; now 6.1 us (below).
 // blockIdx.y == n_layer: the slab of the position-table gradient partials left by k_fmlp_embed_bwd -> dP (this launch is its only writer)
+// Thread = (4 columns, one of 16 partial sub-rows): 16-byte loads, 4 in flight per thread (16 KB per workgroup: the launch is bound
+// by the bytes it keeps in flight, 9.8 MB through ~2 us round trips), then the 16 sub-rows meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict__ part, float* __restrict__ dm, int nblk, int n,
                                                         float* __restrict__ dP, int n_layer) {
-    __shared__ float red[4][64];
-    const int layer = blockIdx.y, c = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
-    float acc[8];
+    __shared__ float4 red[16][16];
+    const int layer = blockIdx.y, c4 = threadIdx.x & 15, sub = threadIdx.x >> 4, i = blockIdx.x * 64 + 4 * c4;
+    float4 acc[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-    if (i < n) {
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {                                           // n is a multiple of 64 (L * 64 columns)
         const float* p = part + (size_t)layer * FM_DMBLK * n + i;
-        for (int b = w * 8; b < nblk; b += 32) {
+        for (int b = sub; b < nblk; b += 64) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (b + u < nblk) acc[u] += p[(size_t)(b + u) * n];
+            for (int u = 0; u < 4; ++u)
+                if (b + 16 * u < nblk) {
+                    const float4 v = ld4(p + (size_t)(b + 16 * u) * n);
+                    acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+                }
         }
     }
-    red[w][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    red[sub][c4] = make_float4((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                               (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
     __syncthreads();
-    if (w == 0 && i < n) (layer == n_layer ? dP : dm + (size_t)layer * n)[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (sub == 0 && i < n) {
+        float4 s4 = red[0][c4];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[k][c4]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+        st4((layer == n_layer ? dP : dm + (size_t)layer * n) + i, s4);
+    }
 }
 // d(complex_weight) += fold(dm)
 __global__ __launch_bounds__(256) void k_fmlp_coef_bwd(float* __restrict__ grads, int64_t o_cw0, int64_t layer_stride,
