@@ -355,7 +355,7 @@ def test_bench_single_rank_rccl_in_graph_allreduce():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["SASRec", "GRU4Rec", "FMLP", "MetaModel"])
+@pytest.mark.parametrize("model_name", ["SASRec", "GRU4Rec", "FMLP", "MetaModel", "CL4SRec"])
 def test_fit_learns_a_sequential_signal(tmp_path, monkeypatch, model_name):
     """end-to-end sanity of the whole loop (targets shifted by one, masks, negatives, optimizer, top-k with history masking, metrics):
     on data whose next item follows the current one through a fixed map 90 % of the time, a few epochs must lift recall@20 far above
@@ -366,7 +366,7 @@ def test_fit_learns_a_sequential_signal(tmp_path, monkeypatch, model_name):
     from dr4sr_amd.utils import load_config
     cfg = load_config({"model": model_name, "dataset": "synthetic-toys"})
     cfg["data"].update({"n_items": 300, "n_rows": 4000, "n_eval_rows": 512, "markov": 0.9, "seed": 3})
-    cfg["train"].update({"device": "cuda", "epochs": 12 if model_name == "SASRec" else 30, "batch_size": 128})
+    cfg["train"].update({"device": "cuda", "epochs": 12 if model_name in ("SASRec", "CL4SRec") else 30, "batch_size": 128})
     cfg["eval"]["batch_size"] = 512
     if model_name in ("FMLP", "MetaModel"):                 # FMLP (MetaModel's default sub-model) keeps one query per row: prefix-row format
         cfg["data"]["prefix_rows"] = True
