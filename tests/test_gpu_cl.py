@@ -229,3 +229,27 @@ def test_cl4srec_direct_step_equals_autograd_step(monkeypatch, dropout, two_pass
     assert len(la) == 8 and np.allclose(la, lb, rtol=2e-4, atol=1e-5), (la, lb)
     for n in pa:
         assert float((pa[n] - pb[n]).abs().max()) < 5e-4, n
+
+
+@pytest.mark.parametrize("cls,kw", [("Item_Crop", dict(tao=0.2)), ("Item_Mask", dict(mask_id=1000, gamma=0.7)),
+                                    ("Item_Reorder", dict(beta=0.2)), ("Item_Random", dict(mask_id=1000))])
+def test_two_views_in_one_launch_equal_two_calls(cls, kw):
+    """dr4sr_cl_augment2_dev (both views of a CL4SRec step from ONE launch, written into the halves of one [2B, L] tensor) draws what
+    two consecutive dr4sr_cl_augment_dev calls draw (device call counter: the captured-step form)"""
+    from dr4sr_amd.module import data_augmentation as DA
+    torch.manual_seed(3)
+    B, L = 300, 50
+    sl = torch.randint(1, 51, (B,), device="cuda")
+    seq = torch.randint(1, 900, (B, L), device="cuda") * (torch.arange(L, device="cuda")[None, :] < sl[:, None])
+    a, b = getattr(DA, cls)(**kw), getattr(DA, cls)(**kw)
+    for aug in (a, b):
+        aug.step_dev = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+        aug.begin_step()
+    (v1, l1), (v2, l2) = a.two_views(seq, sl)
+    w1, m1 = b(seq, sl)
+    w2, m2 = b(seq, sl)
+    assert v1.data_ptr() + v1.numel() * 8 == v2.data_ptr()              # halves of one tensor: encodable as one batch of 2B sequences
+    assert torch.equal(v1, w1) and torch.equal(l1, m1) and torch.equal(v2, w2) and torch.equal(l2, m2)
+    assert not torch.equal(v1, v2) or cls == "Item_Reorder"             # two different draws (a reorder of tiny segments may coincide)
+    a.end_step(); b.end_step()
+    assert int(a.step_dev) == int(b.step_dev) == 9
