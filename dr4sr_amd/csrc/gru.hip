@@ -163,14 +163,49 @@ __global__ __launch_bounds__(256) void k_gemm16_col(const float* __restrict__ A,
     lds_barrier();
     TileAcc<16, 64> acc;
     tile_zero(acc);
-    tile_mma_xw<16, K, 64>(As, LDA, W + n0, ldw, acc);
+    if constexpr (K <= 256) {                           // weight fragments up front where they fit the registers (K / 4 floats per lane)
+        WFragC<K, 64> f;
+        wfrag_load(f, W + n0, ldw);
+        tile_mma_frag<16, K, 64>(As, LDA, f, acc);
+    } else tile_mma_xw<16, K, 64>(As, LDA, W + n0, ldw, acc);
     tile_to_global<16, 64>(acc, C + n0, ldc, nullptr, t0, T);
+}
+
+// ... and of the forward linear C[T x N] = A[T x K] W^T + bias (W [N][ldw]): gi = x W_ih^T (K = D or H, N = 3H) and the output
+// projection (K = H, N = D) ran on 21 x N/128 workgroups of 64 rows with K walked in 64-chunks (25 us for 0.5 GFLOP at B = 256).
+template <int K>
+__global__ __launch_bounds__(256) void k_gemm16_row(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                    const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                    const int* __restrict__ state) {
+    constexpr int LDA = K + 4;
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 16;
+    if (t0 >= T) return;
+    const int n0 = blockIdx.y * 64;
+    float* As = smem;                                   // [16][LDA]
+    WFragT<K, 64> f;                                    // the workgroup's 64 x K weight rows: every fragment requested up front, their
+    wfrag_load(f, W + (size_t)n0 * ldw, ldw);           // L2 round trips overlap each other and the A tile's (else K / 16 dependent ones)
+    load_tile_bm<16, K>(As, LDA, A, lda, t0, T);
+    lds_barrier();
+    TileAcc<16, 64> acc;
+    tile_zero(acc);
+    tile_mma_frag<16, K, 64>(As, LDA, f, acc);
+    tile_to_global<16, 64>(acc, C + n0, ldc, bias ? bias + n0 : nullptr, t0, T);
 }
 
 static int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K, int N,
                        bool colmode, int Tmax, const int* state, hipStream_t s) {
     const size_t lds = sizeof(float) * 64 * 68;
     dim3 blk(256);
+    static const bool no16 = getenv("DR4SR_GRU_GEMM64") != nullptr;          // cross-check switch: 64-row tiles everywhere
+    if (!no16 && !at_scale(Tmax) && N % 64 == 0 && ((colmode && !bias && K == 64) || (!colmode && (K == 64 || K == 128 || K == 256)))) {
+        const size_t l16 = sizeof(float) * 16 * (K + 4);
+        dim3 grid((Tmax + 15) / 16, N / 64);
+        if (colmode) hipLaunchKernelGGL(k_gemm16_col<64>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state);
+        else if (K == 64) hipLaunchKernelGGL(k_gemm16_row<64>, grid, blk, l16, s, A, lda, W, ldw, bias, C, ldc, state);
+        else if (K == 128) hipLaunchKernelGGL(k_gemm16_row<128>, grid, blk, l16, s, A, lda, W, ldw, bias, C, ldc, state);
+        else hipLaunchKernelGGL(k_gemm16_row<256>, grid, blk, l16, s, A, lda, W, ldw, bias, C, ldc, state);
+        return DR4SR_LAUNCH_CHECK();
+    }
     if (colmode && !bias && !at_scale(Tmax) && (K == 768 || K == 384) && N % 64 == 0) {      // small batch, K = 3H: latency tiles
         const size_t l16 = sizeof(float) * 16 * (K + 4);
         dim3 grid((Tmax + 15) / 16, N / 64);
