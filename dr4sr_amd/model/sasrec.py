@@ -191,7 +191,11 @@ class SASRec(BaseModel):
                                      neg_item=batch["neg_item"].contiguous().view(-1), sample_neg=False)
 
     def _api_plan(self):
-        return self.engine.make_plan(self._dummy.view(1, 1).expand(1, self.max_seq_len).contiguous(), None, self._dummy)
+        """plan of a bare optimizer step (no batch): a 1-row dummy; its id tensor is built once (expand().contiguous() is a copy
+        kernel — inside a captured step it would be replayed every time)"""
+        if getattr(self, "_dummy_ids", None) is None:
+            self._dummy_ids = self._dummy.view(1, 1).expand(1, self.max_seq_len).contiguous()
+        return self.engine.make_plan(self._dummy_ids, None, self._dummy)
 
     _supports_perm_sel = True          # batch selection fused into the step's first kernel (no per-step rows copy)
 
