@@ -530,7 +530,7 @@ def main():
                 # layer's post_fwd + scorer + post_bwd is ONE launch (post_mid).  In the latency regime (expected tokens of the plan
                 # <= ~10 k: dr4sr_sasrec_at_scale) the embedding-stage backward rides in the k_wgrad launch (`wgrad_fused`), at scale
                 # it is a launch of its own.
-                big = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)))
+                big = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 1)
                 launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1), ("attn_fwd", NL - 1, NL), ("post_fwd", 0, NL - 1),
                             ("post_mid", 0, 1), ("attn_bwd", NL - 1, NL), ("post_bwd", 0, NL - 1)]
                 launches += ([("qkv_embed_bwd", 0, 1)] if big else []) + [("wgrad_fused", 0, 1), ("adam", 0, 1)]

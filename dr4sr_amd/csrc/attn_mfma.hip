@@ -527,7 +527,7 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
 
 // Large batches (same threshold as tile_rows): two persistent launches over k_prep's length-class lists instead of one
 // workgroup per sequence with worst-case LDS.  seq_class = [n_short, n_long, n_tiny, - | tiny_desc[B] int4 | short_list[B] | long_list[B] | tiny_list[B]].
-static bool split_by_length(const Workspace& ws) { return ws.scale && !getenv("DR4SR_ATTN_NOSPLIT"); }
+static bool split_by_length(const Workspace& ws) { return ws.attn_split && !getenv("DR4SR_ATTN_NOSPLIT"); }
 
 // short sequences, backward: one wave per head runs phase A then phase B (2 waves per sequence, twice the sequences per CU of the
 // 4-wave form — the kernel is bound by how many sequences are in flight, not by issue slots)

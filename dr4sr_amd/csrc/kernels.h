@@ -32,7 +32,7 @@ struct Workspace {
     int64_t n_params;
     int Tmax;
     int* cu;                                   // [B+1] packed row offset of each sequence slot
-    bool scale;                                // at-scale launch forms for this plan (see at_scale below)
+    bool scale, attn_split;                    // at-scale token-tile forms / length-class attention lists for this plan (see at_scale below)
     int* len_buf;                              // [B] clamped sequence lengths published by the two-phase prep (prep_body.h)
     int* seq_class;                            // [4 + 7B] n_short, n_long, n_tiny, - | tiny_desc[B] int4 {t0, n, slot, row} | short_list[B] (9..16) | long_list[B] (> 16) | tiny_list[B] (1..8)  (k_prep)
     float* attn_rd;                            // [Tmax][H] <dctx, ctx> per (token, head): softmax-backward row term, from k_post_bwd
@@ -56,15 +56,17 @@ struct Workspace {
 // index of tensor j of layer i in Workspace::off
 enum { P_IN_W = 0, P_IN_B, P_OUT_W, P_OUT_B, P_W1, P_B1, P_W2, P_B2, P_LN1_W, P_LN1_B, P_LN2_W, P_LN2_B };
 static inline int64_t poff(const Workspace& ws, int layer, int j) { return ws.off[2 + 12 * layer + j]; }
-// Two regimes of the SASRec step (Workspace::scale, set by carve_workspace from the plan).  Latency regime: 16-row token tiles, one
-// attention workgroup per sequence, atomics for the table gradient — every CU gets work, 4x shorter MFMA chains.  At scale: 32-row
-// tiles, length-class attention lists, scatter / owner jobs inside k_wgrad.  Measured crossover (tools/regime_sweep.sh): ~10-11 k
-// VALID tokens per step, on toys-shaped batches (B = 2048) and dense ones (B = 256) alike — so the choice follows the plan's
-// expected_tokens hint (boundary 10 240) and only falls back to the capacity B * L (boundary latency_tmax() = 16 384, the pre-hint
-// rule: DR4SR_LATENCY_TMAX moves it) when the host gave none.  GRU4Rec / FMLP keep the capacity rule (at_scale(Tmax)).
+// Launch forms of the SASRec step, set by carve_workspace from the plan (Workspace::scale, Workspace::attn_split).
+//   token-tile kernels — latency forms: 16-row tiles, atomics for the table gradient, embedding-stage backward inside k_wgrad (every CU
+//     gets work, 4x shorter MFMA chains); at scale (`scale`): 32-row tiles, scatter / owner jobs inside k_wgrad.
+//   attention — one workgroup per sequence, or (`attn_split`) the length-class lists walked by persistent launches.
+// Measured crossovers (tools/regime_sweep.sh + per-kernel times, toys-shaped and dense batches alike): the tile kernels' at-scale forms
+// win from ~5.5 k VALID tokens per step, the attention lists from ~14 k.  Only the host knows the dataset's lengths before the launch, so
+// the choice follows the plan's expected_tokens hint and falls back to the capacity B * L (boundary latency_tmax() = 16 384 for both,
+// the pre-hint rule; DR4SR_LATENCY_TMAX moves it) when there is none.  GRU4Rec / FMLP keep the capacity rule (at_scale(Tmax)).
 int latency_tmax();
 static inline bool at_scale(int Tmax) { return Tmax > latency_tmax(); }
-constexpr int DR4SR_SCALE_TOKENS = 10240;
+constexpr int DR4SR_SCALE_TOKENS = 5632, DR4SR_ATTN_SPLIT_TOKENS = 14336;
 
 // argument blocks shared by the tile kernels of linear.hip (SASRec layer) and their FMLP re-use
 struct PostArgs {

@@ -73,8 +73,12 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     {
         static const bool forced = getenv("DR4SR_LATENCY_TMAX") != nullptr;           // sweeps: the capacity rule with a moved boundary
         const int64_t hint = p->expected_tokens < Tmax ? p->expected_tokens : Tmax;
-        ws->scale = (hint > 0 && !forced) ? hint > DR4SR_SCALE_TOKENS : at_scale((int)Tmax);
-        if (const char* f = getenv("DR4SR_FORCE_SCALE")) ws->scale = atoi(f) != 0;    // tests (read per call): 1 = at-scale forms, 0 = latency forms
+        const bool known = hint > 0 && !forced;
+        ws->scale = known ? hint > DR4SR_SCALE_TOKENS : at_scale((int)Tmax);
+        ws->attn_split = known ? hint > DR4SR_ATTN_SPLIT_TOKENS : at_scale((int)Tmax);
+        // tests (read per call): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
+        if (const char* f = getenv("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
+        if (const char* f = getenv("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
     }
     char* base = (char*)p->workspace;
     int64_t o = 0;
@@ -126,7 +130,7 @@ extern "C" int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan) {
     if (check_shape(&q)) return DR4SR_E_SHAPE;
     Workspace ws;
     carve_workspace(&q, &ws);
-    return ws.scale ? 1 : 0;
+    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0);
 }
 
 static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {

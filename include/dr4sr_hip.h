@@ -105,10 +105,10 @@ typedef struct dr4sr_sasrec_plan {
      *      slot = *perm_counter - 1 when perm != NULL (the batch index just consumed), else slot = 0.  NULL = off. ---- */
     float*   loss_log;
     /* ---- regime hint (ABI 4): the host's estimate of the VALID tokens of a batch of B rows (B * mean(min(seqlen, L)) of the
-     *      dataset).  The launchers pick their regime from it — up to ~10 k packed tokens: 16-row tiles, one attention workgroup per
-     *      sequence, atomics for the table gradient; above: 32-row tiles, length-class attention lists, scatter / owner jobs — because
-     *      the real count lives on the device.  0 = unknown: the capacity B * L decides (boundary 16 384), as before ABI 4.  A wrong
-     *      hint costs speed, never correctness. ---- */
+     *      dataset).  The launchers pick their forms from it — token-tile kernels: 16-row tiles + atomics for the table gradient up to
+     *      ~5.5 k packed tokens, 32-row tiles + scatter / owner jobs above; attention: one workgroup per sequence up to ~14 k tokens,
+     *      length-class lists above — because the real count lives on the device.  0 = unknown: the capacity B * L decides (boundary
+     *      16 384 for both), as before ABI 4.  A wrong hint costs speed, never correctness. ---- */
     int32_t  expected_tokens;
 } dr4sr_sasrec_plan;
 
@@ -122,7 +122,8 @@ int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t
  * encoder shape without kernels — L > 64; (D, F) outside {(64,128), (64,256), (128,128)}; head_dim other than 32 / 64; a head count != 2
  * whose one-wave-per-head attention would not fit 160 KB of LDS — so an unsupported configuration is refused when the engine is built. */
 int64_t dr4sr_sasrec_workspace_bytes(const dr4sr_sasrec_plan* plan);
-/* 1 when a step of this plan takes the at-scale launch forms (see expected_tokens), 0 for the latency forms, < 0: DR4SR_E_* */
+/* launch forms a step of this plan takes (see expected_tokens): bit 0 = at-scale token-tile kernels (32-row tiles, scatter / owner jobs),
+ * bit 1 = length-class attention lists; 0 = the latency forms; < 0: DR4SR_E_* */
 int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan);
 
 /* One reference training step minus the optimizer:  basemodel.py:193-198

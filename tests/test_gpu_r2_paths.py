@@ -255,6 +255,12 @@ _SWITCH_CASES = [
     ({"DR4SR_ATTN_GRID_FIXED": "1"}, "test_large_batch_length_split_attention"),
     ({"DR4SR_BM": "32"}, "test_full_size_batch_vs_oracle or test_fuzz_odd_batches_vs_oracle"),      # the at-scale tile on small batches
     ({"DR4SR_BM": "64"}, "test_full_size_batch_vs_oracle"),           # tuning-only tile (d=128 fits it up to L = 57: fuzz draws L = 64)
+    # the middle regime (~5.5 k .. 14 k expected tokens): at-scale token-tile kernels with one attention workgroup per sequence
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_FORCE_ATTN_SPLIT": "0"},
+     "test_full_size_batch_vs_oracle or test_fuzz_odd_batches_vs_oracle or test_fwd_bwd_with_dropout_matches_oracle_with_same_masks "
+     "or test_training_trajectory_matches_oracle or test_train_steps_equals_repeated_train_step"),
+    # ... and the converse (never chosen by the hint, must still be right): latency tiles with the length-class attention lists
+    ({"DR4SR_FORCE_SCALE": "0", "DR4SR_FORCE_ATTN_SPLIT": "1"}, "test_full_size_batch_vs_oracle or test_fuzz_odd_batches_vs_oracle"),
 ]
 
 
