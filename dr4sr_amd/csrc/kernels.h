@@ -61,12 +61,12 @@ static inline int64_t poff(const Workspace& ws, int layer, int j) { return ws.of
 //     gets work, 4x shorter MFMA chains); at scale (`scale`): 32-row tiles, scatter / owner jobs inside k_wgrad.
 //   attention — one workgroup per sequence, or (`attn_split`) the length-class lists walked by persistent launches.
 // Measured crossovers (tools/regime_sweep.sh + per-kernel times, toys-shaped and dense batches alike): the tile kernels' at-scale forms
-// win from ~5.5 k VALID tokens per step, the attention lists from ~14 k.  Only the host knows the dataset's lengths before the launch, so
+// win from ~5.5 k (toys-shaped) to ~8 k (dense) VALID tokens per step — boundary 7 k —, the attention lists from ~14 k.  Only the host knows the dataset's lengths before the launch, so
 // the choice follows the plan's expected_tokens hint and falls back to the capacity B * L (boundary latency_tmax() = 16 384 for both,
 // the pre-hint rule; DR4SR_LATENCY_TMAX moves it) when there is none.  GRU4Rec / FMLP keep the capacity rule (at_scale(Tmax)).
 int latency_tmax();
 static inline bool at_scale(int Tmax) { return Tmax > latency_tmax(); }
-constexpr int DR4SR_SCALE_TOKENS = 5632, DR4SR_ATTN_SPLIT_TOKENS = 14336;
+constexpr int DR4SR_SCALE_TOKENS = 7168, DR4SR_ATTN_SPLIT_TOKENS = 14336;
 
 // argument blocks shared by the tile kernels of linear.hip (SASRec layer) and their FMLP re-use
 struct PostArgs {

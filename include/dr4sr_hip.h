@@ -106,7 +106,7 @@ typedef struct dr4sr_sasrec_plan {
     float*   loss_log;
     /* ---- regime hint (ABI 4): the host's estimate of the VALID tokens of a batch of B rows (B * mean(min(seqlen, L)) of the
      *      dataset).  The launchers pick their forms from it — token-tile kernels: 16-row tiles + atomics for the table gradient up to
-     *      ~5.5 k packed tokens, 32-row tiles + scatter / owner jobs above; attention: one workgroup per sequence up to ~14 k tokens,
+     *      ~7 k packed tokens, 32-row tiles + scatter / owner jobs above; attention: one workgroup per sequence up to ~14 k tokens,
      *      length-class lists above — because the real count lives on the device.  0 = unknown: the capacity B * L decides (boundary
      *      16 384 for both), as before ABI 4.  A wrong hint costs speed, never correctness. ---- */
     int32_t  expected_tokens;

@@ -560,7 +560,7 @@ def test_fit_from_reference_on_disk_files(tmp_path, monkeypatch, model_name):
 
 def test_regime_follows_the_expected_token_hint(monkeypatch):
     """include/dr4sr_hip.h dr4sr_sasrec_plan.expected_tokens: the launch forms follow the host's estimate of VALID tokens (the measured
-    crossovers of tools/regime_sweep.sh: ~5.5 k for the token-tile kernels, ~14 k for the attention lists), not the capacity B * L;
+    crossovers of tools/regime_sweep.sh: ~7 k for the token-tile kernels, ~14 k for the attention lists), not the capacity B * L;
     0 = unknown keeps the capacity rule (16 384); DR4SR_FORCE_SCALE / DR4SR_FORCE_ATTN_SPLIT override.  The engine fills the hint
     from the seqlen tensor of the plan."""
     import ctypes as C
@@ -577,11 +577,11 @@ def test_regime_follows_the_expected_token_hint(monkeypatch):
             plan.expected_tokens = hint
         return int(lib.dr4sr_sasrec_at_scale(C.byref(plan)))
     short, full = torch.full((4096,), 5, dtype=torch.int64, device=dev), torch.full((4096,), 50, dtype=torch.int64, device=dev)
-    # bit 0: at-scale token-tile kernels (> ~5.5 k expected tokens), bit 1: length-class attention lists (> ~14 k)
-    assert scale(256, short) == 0 and scale(1100, short) == 0                                  # 1 280 / 5 500 expected tokens
-    assert scale(1200, short) == 1 and scale(2800, short) == 1                                 # 6 000 / 14 000: tiles at scale, attention per sequence
+    # bit 0: at-scale token-tile kernels (> ~7 k expected tokens), bit 1: length-class attention lists (> ~14 k)
+    assert scale(256, short) == 0 and scale(1400, short) == 0                                  # 1 280 / 7 000 expected tokens
+    assert scale(1500, short) == 1 and scale(2800, short) == 1                                 # 7 500 / 14 000: tiles at scale, attention per sequence
     assert scale(2900, short) == 3 and scale(4096, short) == 3
-    assert scale(100, full) == 0 and scale(128, full) == 1 and scale(300, full) == 3           # 5 000 / 6 400 / 15 000 tokens
+    assert scale(128, full) == 0 and scale(160, full) == 1 and scale(300, full) == 3           # 6 400 / 8 000 / 15 000 tokens
     assert scale(256, short, hint=0) == 0 and scale(400, short, hint=0) == 3                   # unknown: capacity 12 800 / 20 000 decides both
     monkeypatch.setenv("DR4SR_FORCE_SCALE", "1")
     assert scale(64, short) == 3
