@@ -279,17 +279,21 @@ def test_data_parallel_ranks_equal_single_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["GRU4Rec", "FMLP", "MetaModel"])
+@pytest.mark.parametrize("model_name", ["GRU4Rec", "FMLP", "MetaModel", "SASRec-d128"])
 def test_data_parallel_fit_other_models(tmp_path, model_name):
     """the same end-to-end run (quickstart.run under 2 ranks sharing the GPU, uneven tail batch) for the other DP-capable models:
-    GRU4Rec / FMLP step through their engines' two-graph form, MetaModel all-reduces both flat buffers and runs its outer loop"""
+    GRU4Rec / FMLP step through their engines' two-graph form, MetaModel all-reduces both flat buffers and runs its outer loop;
+    SASRec at d = 128 (BASELINE configs[3]'s width: DR4SR_EMBED_DIM, the override utils/config.py:load_config honours)"""
+    extra = {}
+    if model_name == "SASRec-d128":
+        model_name, extra = "SASRec", {"DR4SR_EMBED_DIM": "128"}
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29581", os.path.join(root, "tools", "dp_fit_check.py")], capture_output=True, text=True,
                          timeout=500, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path),
-                                               MODEL=model_name), cwd=root)
+                                               MODEL=model_name, **extra), cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT ")]
     err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]
     assert out.returncode == 0 and len(lines) == 1, err
