@@ -66,7 +66,7 @@ static inline int64_t poff(const Workspace& ws, int layer, int j) { return ws.of
 // the pre-hint rule; DR4SR_LATENCY_TMAX moves it) when there is none.  GRU4Rec / FMLP keep the capacity rule (at_scale(Tmax)).
 int latency_tmax();
 static inline bool at_scale(int Tmax) { return Tmax > latency_tmax(); }
-constexpr int DR4SR_SCALE_TOKENS = 7168, DR4SR_ATTN_SPLIT_TOKENS = 14336;
+constexpr int DR4SR_SCALE_TOKENS = 7168, DR4SR_ATTN_SPLIT_TOKENS = 14336;      // at d = 64; scaled by 64 / d
 
 // argument blocks shared by the tile kernels of linear.hip (SASRec layer) and their FMLP re-use
 struct PostArgs {

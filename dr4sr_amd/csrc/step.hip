@@ -74,8 +74,9 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         static const bool forced = getenv("DR4SR_LATENCY_TMAX") != nullptr;           // sweeps: the capacity rule with a moved boundary
         const int64_t hint = p->expected_tokens < Tmax ? p->expected_tokens : Tmax;
         const bool known = hint > 0 && !forced;
-        ws->scale = known ? hint > DR4SR_SCALE_TOKENS : at_scale((int)Tmax);
-        ws->attn_split = known ? hint > DR4SR_ATTN_SPLIT_TOKENS : at_scale((int)Tmax);
+        // boundaries measured at d = 64; at d = 128 both crossovers sit at half the token count (4 k / 7 k): the work per token doubles
+        ws->scale = known ? hint * D > (int64_t)DR4SR_SCALE_TOKENS * 64 : at_scale((int)Tmax);
+        ws->attn_split = known ? hint * D > (int64_t)DR4SR_ATTN_SPLIT_TOKENS * 64 : at_scale((int)Tmax);
         // tests (read per call): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
         if (const char* f = getenv("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
         if (const char* f = getenv("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;

@@ -108,7 +108,8 @@ typedef struct dr4sr_sasrec_plan {
      *      dataset).  The launchers pick their forms from it — token-tile kernels: 16-row tiles + atomics for the table gradient up to
      *      ~7 k packed tokens, 32-row tiles + scatter / owner jobs above; attention: one workgroup per sequence up to ~14 k tokens,
      *      length-class lists above — because the real count lives on the device.  0 = unknown: the capacity B * L decides (boundary
-     *      16 384 for both), as before ABI 4.  A wrong hint costs speed, never correctness. ---- */
+     *      16 384 for both), as before ABI 4.  (Boundaries quoted for d = 64; they scale with 64 / d.)  A wrong hint costs speed, never
+     *      correctness. ---- */
     int32_t  expected_tokens;
 } dr4sr_sasrec_plan;
 
