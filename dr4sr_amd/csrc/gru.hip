@@ -564,7 +564,10 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     add(ws.dY, D, D, ws.layer[nl - 1].hout, H, H, Gd + ws.off_ow, Gd + ws.off_ob);
     WA.state = p->state;
     const int ntiles = (ws.Tmax + 63) / 64;
-    int gw = ntiles / 16 > 8 ? (ntiles / 16 > 32 ? 32 : ntiles / 16) : 8;
+    static const int gwf = getenv("DR4SR_GRU_WGRAD_GW") ? atoi(getenv("DR4SR_GRU_WGRAD_GW")) : 0;     // tuning knob
+    // token-tile splits per 64x64 output tile: every split ends in 4 096 atomics, so fewer, longer splits at small batches (B = 256: 6
+    // instead of 12 is worth 0.8 % of the step; 2 is too few workgroups)
+    int gw = gwf > 0 ? gwf : (ntiles / 32 > 6 ? (ntiles / 32 > 32 ? 32 : ntiles / 32) : 6);
     if (gw > ntiles) gw = ntiles;
     hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
     // with_score == 0 (autograd path): no scorer partials to add, the launch only forwards the recurrence's error word
