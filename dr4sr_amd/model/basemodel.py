@@ -413,6 +413,12 @@ class BaseModel(nn.Module):
             raise NotImplementedError("the API path (DR4SR_NO_FAST_PATH / non-BCE loss) has no gradient all-reduce: data parallelism "
                                       "needs the fused path")
         if self._api_graph_ok():
+            fields = getattr(loader, "fields", None)
+            if fields is not None and hasattr(loader, "permutation"):
+                # the loader's own batches are 7 gathers + 3 copies into the graph's static tensors per step; gather the fields the
+                # step reads straight into the static tensors instead (same permutation, same batches)
+                perm, bs = loader.permutation(), loader.batch_size
+                return [[{"loss_0": self._api_step_graph(None, fields, perm[i:i + bs])} for i in range(0, loader.n, bs)]]
             return [[{"loss_0": self._api_step_graph(batch)} for batch in loader]]
         for batch in loader:                                        # API path (reference loop, basemodel.py:192-200)
             batch["neg_item"] = self._neg_sampling(batch)
@@ -443,7 +449,20 @@ class BaseModel(nn.Module):
         self.optimizer.step()
         return loss.detach()
 
-    def _api_step_graph(self, batch):
+    def _api_step_graph(self, batch, fields=None, rows=None):
+        """one captured step on `batch`, or (batch None) on rows `rows` of the device-resident dataset tensors `fields`"""
+        if batch is None:
+            keep = self._api_graph_fields()
+            bl = int(rows.shape[0])
+            ent = getattr(self, "_api_graphs", {}).get(bl)
+            if ent is None:                                # first step of this batch size: build the graph from a materialised batch
+                return self._api_step_graph({k: v.index_select(0, rows) for k, v in fields.items() if keep is None or k in keep or k == self.fuid})
+            g, static, out = ent
+            for k, v in static.items():
+                if k in fields:
+                    torch.index_select(fields[k], 0, rows, out=v)
+            g.replay()
+            return out.clone()
         if not hasattr(self, "_api_graphs"):
             self._api_graphs = {}
             self._neg_step_dev = torch.full((1,), getattr(self, "_neg_calls", 0), dtype=torch.int32, device=self.device)
