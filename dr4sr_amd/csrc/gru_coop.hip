@@ -1,4 +1,4 @@
-// gru_coop.hip — multi-CU cooperative GRU recurrence for SMALL batches (B <= 384): latency instead of throughput.
+// gru_coop.hip — multi-CU cooperative GRU recurrence for SMALL batches (B <= 384 per launch, up to 1536 in chunks): latency instead of throughput.
 //
 // The single-workgroup recurrence of gru.hip (16 sequences per workgroup, W_hh streamed from L2) is bound by one CU's fp32
 // MFMA pipe: 6.3 MFLOP per time step = ~11 us, and a B = 256 batch occupies 16 of the 256 CUs.  Here a group of 16 sequences
@@ -385,9 +385,22 @@ static int coop_slices(int B, int H) {
     return g8 * 8 <= b8 ? 8 : 0;
 }
 
+// Sequences per cooperative launch for a batch of B (0 = the batch takes the single-workgroup recurrence).  A batch that does not fit
+// one cooperative launch runs as CONSECUTIVE launches over chunks of 256 sequences while that beats the single-workgroup form:
+// a launch of either kind lasts (longest sequence) x (time per step), 21 us per step for a single workgroup streaming W_hh from L2
+// against ~3 us cooperatively, so up to 6 chunks (B <= 1536) win — B = 512 trains at the speed of B = 256 instead of 2.8x slower.
+constexpr int COOP_CHUNK = 256, COOP_MAX_CHUNKS = 6;
+static int coop_chunk(int B, int H) {
+    if (coop_slices(B, H)) return B;
+    static const bool nochunk = getenv("DR4SR_GRU_NOCHUNK") != nullptr;         // cross-check switch
+    if (!nochunk && B <= COOP_CHUNK * COOP_MAX_CHUNKS && coop_slices(COOP_CHUNK, H)) return COOP_CHUNK;
+    return 0;
+}
 // granule words needed by the cooperative path for a batch of B sequences (0 = the batch does not qualify)
 int64_t gru_coop_words(int B, int H) {
-    const int groups = (B + 15) / 16, ns = coop_slices(B, H);
+    const int cb = coop_chunk(B, H);
+    if (!cb) return 0;
+    const int groups = (cb + 15) / 16, ns = coop_slices(cb, H);
     return (int64_t)groups * 2 * ns * 16 * H;
 }
 extern "C" int dr4sr_gru4rec_uses_cooperative(int32_t B, int32_t H) { return gru_coop_words(B, H) != 0; }
@@ -396,8 +409,16 @@ extern "C" int dr4sr_gru4rec_uses_cooperative(int32_t B, int32_t H) { return gru
 int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float* r, float* z, float* n, float* ghn, float* hprev,
                         float* hout, const float* dhout, float* dgi, float* dgh, unsigned long long* xch, int* ctl, int B, int H, bool bwd,
                         hipStream_t s) {
+    const int cb = coop_chunk(B, H);
+    if (!xch || !ctl || cb == 0) return -100;
+    if (cb < B) {                                          // consecutive launches over chunks of sequences (same granule area: epochs are per launch)
+        for (int c0 = 0; c0 < B; c0 += cb) {
+            const int rc = launch_gru_rec_coop(gi, whh, cu + c0, r, z, n, ghn, hprev, hout, dhout, dgi, dgh, xch, ctl, B - c0 < cb ? B - c0 : cb, H, bwd, s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     const int ns = coop_slices(B, H);
-    if (!xch || !ctl || ns == 0) return -100;
     CoopArgs A;
     A.gi = gi; A.whh = whh; A.cu = cu; A.r = r; A.z = z; A.n = n; A.ghn = ghn; A.hprev = hprev; A.hout = hout;
     A.dhout = dhout; A.dgi = dgi; A.dgh = dgh; A.xch = xch; A.ctl = ctl; A.B = B;

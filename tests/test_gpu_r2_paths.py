@@ -82,11 +82,22 @@ def test_gru4rec_cooperative_second_bank_vs_oracle(B):
 
 
 @pytest.mark.parametrize("B,H,toys", [(400, 256, True), (1024, 256, True), (448, 128, False)])
-def test_gru4rec_single_workgroup_recurrence_vs_oracle(B, H, toys):
-    """more than 24 groups: k_gru_fwd / k_gru_bwd (csrc/gru.hip), W_hh streamed from L2 — the path behind every B > 384 number"""
+def test_gru4rec_single_workgroup_recurrence_vs_oracle(monkeypatch, B, H, toys):
+    """k_gru_fwd / k_gru_bwd (csrc/gru.hip), W_hh streamed from L2: the recurrence of every batch above 1536 sequences (and of any batch
+    under DR4SR_GRU_NOCOOP, read per call — how these sizes reach it here)"""
+    monkeypatch.setenv("DR4SR_GRU_NOCOOP", "1")
     eng, worst = _gru_vs_oracle(B, H, 2, toys=toys)
     assert not eng.uses_cooperative(B)
     print("GRU single-workgroup B=%d H=%d worst grad relerr %.2e" % (B, H, worst))
+
+
+@pytest.mark.parametrize("B,H,toys", [(400, 256, True), (1024, 256, True), (448, 128, False), (1536, 256, True)])
+def test_gru4rec_chunked_cooperative_recurrence_vs_oracle(B, H, toys):
+    """more than 24 groups, at most 1536 sequences: consecutive cooperative launches over chunks of 256 sequences (csrc/gru_coop.hip
+    coop_chunk) — full chunks, a ragged last chunk (400 = 256 + 144, 448 = 256 + 192), the largest chunk count (6)"""
+    eng, worst = _gru_vs_oracle(B, H, 2, toys=toys)
+    assert eng.uses_cooperative(B)
+    print("GRU chunked cooperative B=%d H=%d worst grad relerr %.2e" % (B, H, worst))
 
 
 def test_gru4rec_nocoop_switch_small_batch_vs_oracle(monkeypatch):
