@@ -290,11 +290,44 @@ struct FFiltArgs {
     int B, L; float eps; const int* state; uint64_t seed; float p; int training; uint32_t site;
 };
 
-// One workgroup per sequence.  Thread (dq = tid & 15, rg = tid >> 4) owns the feature quad d = 4dq..4dq+3 of rows l = rg + 16 i:
+// One workgroup per sequence.  Thread (dq = tid & 15, rg = tid >> 4) owns the feature quad d = 4dq..4dq+3 of rows l = 4 rg + i:
 // every LDS access of the L x L circular-convolution loops is a conflict-free ds_read_b128 feeding 4 FMAs (one b32 load per
 // FMA was LDS-issue bound: 36 / 111 us), and a row's LayerNorm statistics reduce over the 16 lanes of a row group.
 __device__ __forceinline__ void fma4(float4& a, const float4& m, const float4& x) {
     a.x = fmaf(m.x, x.x, a.x); a.y = fmaf(m.y, x.y, a.y); a.z = fmaf(m.z, x.z, a.z); a.w = fmaf(m.w, x.w, a.w);
+}
+
+// Four CONSECUTIVE rows per thread and a sliding window: acc[i] += C(s) * V(s + off_i), off_i = i (or 3 - i), s = 0 .. S-1.  Row i at
+// step s and row i -/+ 1 at step s + 1 read the same V, so a 4-slot circular register window needs ONE new value per step: 2 LDS
+// reads (coefficient + new value) per 16 FMAs instead of 5 with rows 16 apart — these kernels run one wave per SIMD and were bound by
+// LDS bandwidth / latency (k_fmlp_filter_fwd 14.4 us, _bwd 28.8 us at B = 256).  V and C must be safe (in bounds, any value) for s up to S + 10.
+template <bool REV, class VF, class CF>
+__device__ __forceinline__ void conv4(float4 (&acc)[4], const int S, VF V, CF C) {
+    float4 w[4], nv[4], nc[4];
+    w[0] = V(0); w[1] = V(1); w[2] = V(2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { nv[j] = V(3 + j); nc[j] = C(j); }
+    const int S4 = S & ~3;
+    for (int s0 = 0; s0 < S4; s0 += 4) {
+        float4 cv[4], cc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cv[j] = nv[j]; cc[j] = nc[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { nv[j] = V(s0 + 7 + j); nc[j] = C(s0 + 4 + j); }   // the next 4 steps' reads fly over these 64 FMAs:
+#pragma unroll                                                                          // one wave per SIMD hides no LDS latency itself
+        for (int j = 0; j < 4; ++j) {
+            w[(j + 3) & 3] = cv[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fma4(acc[i], cc[j], w[(j + (REV ? 3 - i : i)) & 3]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)                    // the S & 3 tail steps (their operands are already in nv / nc)
+        if (S4 + j < S) {
+            w[(j + 3) & 3] = nv[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fma4(acc[i], nc[j], w[(j + (REV ? 3 - i : i)) & 3]);
+        }
 }
 
 __global__ __launch_bounds__(256) void k_fmlp_filter_fwd(const FFiltArgs A) {
@@ -302,30 +335,30 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_fwd(const FFiltArgs A) {
     float* ML = smem;                          // [L][64]
     float* X2 = ML + L * FM_D;                 // [2L][64]   x twice: x[(l-r) mod L] = X2[l - r + L]
     const float* xb = A.x + (size_t)b * L * FM_D;
-    for (int i = threadIdx.x; i < L * FM_D / 4; i += 256) {
-        st4(ML + 4 * i, ld4(A.m + 4 * i));
-        const float4 v = ld4(xb + 4 * i);
-        st4(X2 + 4 * i, v);
-        st4(X2 + L * FM_D + 4 * i, v);
+    float4 mreg[4], xreg[4];                   // L <= 64: at most 4 quads per thread; every global read is issued before the first wait
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = min((int)threadIdx.x + 256 * k, L * FM_D / 4 - 1);
+        mreg[k] = ld4(A.m + 4 * i); xreg[k] = ld4(xb + 4 * i);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < L * FM_D / 4) { st4(ML + 4 * i, mreg[k]); st4(X2 + 4 * i, xreg[k]); st4(X2 + L * FM_D + 4 * i, xreg[k]); }
     }
     __syncthreads();
     float4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < L; ++r) {
-        const float4 mr = ld4(ML + r * FM_D + c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int l = rg + 16 * i;
-            if (l < L) fma4(acc[i], mr, ld4(X2 + (l - r + L) * FM_D + c));
-        }
-    }
+    const int l0 = 4 * rg;                     // this thread's rows l0 .. l0 + 3: y[l0 + i] = sum_r m[r] x[(l0 + i - r) mod L]
+    conv4<true>(acc, L, [&](int k) { return ld4(X2 + min(max(l0 + 3 + L - k, 0), 2 * L - 1) * FM_D + c); },
+                [&](int r) { return ld4(ML + min(r, 3 * L - 1) * FM_D + c); });
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     const float4 gam = ld4(A.lnw + c), bet = ld4(A.lnb + c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int l = rg + 16 * i;
+        const int l = l0 + i;
         if (l < L) {                               // uniform over the 16 lanes of a row group
             const size_t t = (size_t)b * L + l;
             float4 y = acc[i];
@@ -350,7 +383,9 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
     float* X2 = ML + L * FM_D;                 // [2L][64]
     float* DY2 = X2 + 2 * L * FM_D;            // [2L][64]  dy twice: dy[(l'+r) mod L] = DY2[l' + r]
     float* red = DY2 + 2 * L * FM_D;           // [16][2][64]
-    for (int i = threadIdx.x; i < L * FM_D / 4; i += 256) st4(ML + 4 * i, ld4(A.m + 4 * i));
+    float4 mreg[4];                            // stored to LDS once the first sequence's reads are in flight too
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mreg[k] = ld4(A.m + 4 * min((int)threadIdx.x + 256 * k, L * FM_D / 4 - 1));
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     const float4 gam = ld4(A.lnw + c);
@@ -360,20 +395,33 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
     for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
         __syncthreads();                           // previous iteration finished with X2 / DY2
         const float* xb = A.x + (size_t)b * L * FM_D;
-        for (int i = threadIdx.x; i < L * FM_D / 4; i += 256) {
-            const float4 v = ld4(xb + 4 * i);
-            st4(X2 + 4 * i, v);
-            st4(X2 + L * FM_D + 4 * i, v);
+        const int l0 = 4 * rg;                     // this thread's rows (dx) / filter taps (dm): l0 .. l0 + 3
+        float4 xreg[4], dzv[4], uuv[4], du[4];
+        float2 stv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xreg[k] = ld4(xb + 4 * min((int)threadIdx.x + 256 * k, L * FM_D / 4 - 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {              // unconditional (clamped) so that all of them are in flight together
+            const size_t t = (size_t)b * L + min(l0 + i, L - 1);
+            dzv[i] = ld4(A.dxf + t * FM_D + c); uuv[i] = ld4(A.uf + t * FM_D + c);
+            stv[i] = *reinterpret_cast<const float2*>(A.stf + 2 * t);
         }
-        float4 du[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < L * FM_D / 4) {
+                if (b == (int)blockIdx.x) st4(ML + 4 * i, mreg[k]);
+                st4(X2 + 4 * i, xreg[k]); st4(X2 + L * FM_D + 4 * i, xreg[k]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int l = rg + 16 * i;
+            const int l = l0 + i;
             du[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (l < L) {
                 const size_t t = (size_t)b * L + l;
-                const float4 dz = ld4(A.dxf + t * FM_D + c), uu = ld4(A.uf + t * FM_D + c);
-                const float mean = A.stf[2 * t], rstd = A.stf[2 * t + 1];
+                const float4 dz = dzv[i], uu = uuv[i];
+                const float mean = stv[i].x, rstd = stv[i].y;
                 const float4 xh = make_float4((uu.x - mean) * rstd, (uu.y - mean) * rstd, (uu.z - mean) * rstd, (uu.w - mean) * rstd);
                 const float4 gg = make_float4(dz.x * gam.x, dz.y * gam.y, dz.z * gam.z, dz.w * gam.w);
                 const float s1 = group16_sum((gg.x + gg.y) + (gg.z + gg.w)) * (1.0f / FM_D);
@@ -393,32 +441,20 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
         float4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = du[i];
-        for (int r = 0; r < L; ++r) {
-            const float4 mr = ld4(ML + r * FM_D + c);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = rg + 16 * i;
-                if (l < L) fma4(acc[i], mr, ld4(DY2 + (l + r) * FM_D + c));
-            }
-        }
+        conv4<false>(acc, L, [&](int k) { return ld4(DY2 + min(l0 + k, 2 * L - 1) * FM_D + c); },
+                     [&](int r) { return ld4(ML + min(r, 3 * L - 1) * FM_D + c); });
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int l = rg + 16 * i;
+            const int l = l0 + i;
             if (l < L) st4(A.dx + ((size_t)b * L + l) * FM_D + c, acc[i]);
         }
-        // dm[r] += sum_l dy[l] x[(l-r) mod L]   (this thread owns r = rg + 16 i)
-        for (int l = 0; l < L; ++l) {
-            const float4 dyl = ld4(DY2 + l * FM_D + c);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = rg + 16 * i;
-                if (r < L) fma4(dmacc[i], dyl, ld4(X2 + (l - r + L) * FM_D + c));
-            }
-        }
+        // dm[r] += sum_l dy[l] x[(l-r) mod L]   (this thread owns the taps r = l0 + i)
+        conv4<true>(dmacc, L, [&](int k) { return ld4(X2 + min(max(k + L - l0 - 3, 0), 2 * L - 1) * FM_D + c); },
+                    [&](int l) { return ld4(DY2 + min(l, 2 * L - 1) * FM_D + c); });
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                  // deterministic: one partial [L][64] per workgroup, summed by k_fmlp_dm_reduce
-        const int r = rg + 16 * i;
+        const int r = 4 * rg + i;
         if (r < L) st4(A.dm + ((size_t)blockIdx.x * L + r) * FM_D + c, dmacc[i]);
     }
     __syncthreads();
