@@ -33,6 +33,7 @@ struct FmlpWs {
     float* X[DR4SR_MAX_LAYERS + 1]; float* dX[DR4SR_MAX_LAYERS + 1];
     float* m; float* dm;                      // [n_layer][L][D]
     float* dm_part;                           // [n_layer + 1][FM_DMBLK][L][D] per-block partials of dm, last slab: of dP (summed by k_fmlp_dm_reduce)
+    float* ln_wg;                             // [n_layer + 1][FM_DMBLK][2][D] per-block partials of the filter LayerNorms' (last slab: the embedding LayerNorm's) d weight | d bias
     float* score_part; float* ln_part;        // [B][2]; [n_layer][ntiles][4][D]
     FmlpLayerWs layer[DR4SR_MAX_LAYERS];
     int64_t bytes;
@@ -78,6 +79,7 @@ static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tn * D); ws->dX[i] = take(Tn * D); }
     ws->m = take((int64_t)p->n_layer * p->L * D); ws->dm = take((int64_t)p->n_layer * p->L * D);
     ws->dm_part = take((int64_t)(p->n_layer + 1) * FM_DMBLK * p->L * D);
+    ws->ln_wg = take((int64_t)(p->n_layer + 1) * FM_DMBLK * 2 * D);
     ws->score_part = take(2LL * p->B);
     ws->ln_part = take((int64_t)p->n_layer * ((Tn + 31) / 32) * 4 * D);        // sized for the smallest FFN tile
     for (int l = 0; l < p->n_layer; ++l) {
@@ -144,15 +146,23 @@ __global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ par
 // blockIdx.y == n_layer: the slab of the position-table gradient partials left by k_fmlp_embed_bwd -> dP (this launch is its only writer)
 // Thread = (4 columns, one of 16 partial sub-rows): 16-byte loads, 4 in flight per thread (16 KB per workgroup: the launch is bound
 // by the bytes it keeps in flight, 9.8 MB through ~2 us round trips), then the 16 sub-rows meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict__ part, float* __restrict__ dm, int nblk, int n,
-                                                        float* __restrict__ dP, int n_layer) {
+// blockIdx.x >= nx (two more blocks per slab): the LayerNorm weight | bias partials of the same workgroups (ln_wg) -> grads; 256
+// workgroups adding into the same 128 words were 6 of k_fmlp_filter_bwd's 18.4 us.
+struct FDmRedArgs {
+    const float* part; float* dm; float* dP; const float* ln_wg; float* grads;
+    int64_t o_fln_w, o_fln_b, layer_stride, o_eln_w, o_eln_b;
+    int nblk, n, n_layer, nx;
+};
+__global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const FDmRedArgs A) {
     __shared__ float4 red[16][16];
-    const int layer = blockIdx.y, c4 = threadIdx.x & 15, sub = threadIdx.x >> 4, i = blockIdx.x * 64 + 4 * c4;
+    const int layer = blockIdx.y, c4 = threadIdx.x & 15, sub = threadIdx.x >> 4, nblk = A.nblk;
+    const bool ln = (int)blockIdx.x >= A.nx;
+    const int n = ln ? 2 * FM_D : A.n, i = (ln ? (int)blockIdx.x - A.nx : (int)blockIdx.x) * 64 + 4 * c4;
     float4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {                                           // n is a multiple of 64 (L * 64 columns)
-        const float* p = part + (size_t)layer * FM_DMBLK * n + i;
+        const float* p = (ln ? A.ln_wg : A.part) + (size_t)layer * FM_DMBLK * n + i;
         for (int b = sub; b < nblk; b += 64) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -169,7 +179,13 @@ __global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const float* __restrict_
         float4 s4 = red[0][c4];
 #pragma unroll
         for (int k = 1; k < 16; ++k) { const float4 v = red[k][c4]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
-        st4((layer == n_layer ? dP : dm + (size_t)layer * n) + i, s4);
+        if (!ln) st4((layer == A.n_layer ? A.dP : A.dm + (size_t)layer * n) + i, s4);
+        else {                                             // this launch is the only writer of these rows of the step's gradient
+            const bool wgt = i < FM_D;
+            float* g = A.grads + (layer == A.n_layer ? (wgt ? A.o_eln_w : A.o_eln_b) : (wgt ? A.o_fln_w : A.o_fln_b) + layer * A.layer_stride) + (wgt ? i : i - FM_D);
+            const float4 o = ld4(g);
+            st4(g, make_float4(o.x + s4.x, o.y + s4.y, o.z + s4.z, o.w + s4.w));
+        }
     }
 }
 // d(complex_weight) += fold(dm)
@@ -201,7 +217,7 @@ struct FEmbArgs {
     const float* E; const float* P; const float* lnw; const float* lnb;
     const int64_t* idx; const int64_t* rows;
     float* e0; float* st0; float* x0;
-    const float* dx0; float* dE; float* dP; float* dlnw; float* dlnb;
+    const float* dx0; float* dE; float* dP; float* ln_wg;
     int B, L, n_items; float eps; const int* state; uint64_t seed; float p; int training;
 };
 
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(256) void k_fmlp_embed_bwd(const FEmbArgs A) {
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * FM_D; i += 256) {
             const float v = (scr[i] + scr[2 * FM_D + i]) + (scr[4 * FM_D + i] + scr[6 * FM_D + i]);
-            unsafeAtomicAdd((i < FM_D ? A.dlnw : A.dlnb - FM_D) + i, v);
+            A.ln_wg[(size_t)blockIdx.x * 2 * FM_D + i] = v;            // summed by k_fmlp_dm_reduce
         }
     }
 }
@@ -286,7 +302,7 @@ struct FFiltArgs {
     const float* m; float* dm;                 // this layer's [L][D]
     const float* x; const float* lnw; const float* lnb;
     float* uf; float* stf; float* xf;          // forward outputs
-    const float* dxf; float* dx; float* dlnw; float* dlnb;   // backward
+    const float* dxf; float* dx; float* ln_wg;               // backward
     int B, L; float eps; const int* state; uint64_t seed; float p; int training; uint32_t site;
 };
 
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(256) void k_fmlp_filter_bwd(const FFiltArgs A) {
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += red[(k * 2 + which) * FM_D + dd];
-        unsafeAtomicAdd((which == 0 ? A.dlnw : A.dlnb) + dd, v);
+        A.ln_wg[(size_t)blockIdx.x * 2 * FM_D + threadIdx.x] = v;          // [d weight | d bias], summed by k_fmlp_dm_reduce
     }
 }
 
@@ -578,7 +594,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         FFiltArgs Fa{};
         Fa.m = ws.m + (size_t)l * L * FM_D; Fa.dm = ws.dm_part + (size_t)l * FM_DMBLK * L * FM_D; Fa.x = ws.X[l];
         Fa.lnw = p->params + foff(ws, l, FP_FLN_W); Fa.uf = w.uf; Fa.stf = w.stf;
-        Fa.dxf = w.dxf; Fa.dx = ws.dX[l]; Fa.dlnw = p->grads + foff(ws, l, FP_FLN_W); Fa.dlnb = p->grads + foff(ws, l, FP_FLN_B);
+        Fa.dxf = w.dxf; Fa.dx = ws.dX[l]; Fa.ln_wg = ws.ln_wg + (size_t)l * FM_DMBLK * 2 * FM_D;
         Fa.B = p->B; Fa.L = L; Fa.eps = p->ln_eps; Fa.state = p->state; Fa.seed = p->seed; Fa.p = p->p_drop; Fa.training = training;
         Fa.site = FS_FILT(l);
         const size_t lds = sizeof(float) * (5 * L * FM_D + 32 * FM_D);
@@ -588,12 +604,15 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     }
     FEmbArgs E{};
     E.lnw = p->params + ws.off[2]; E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0;
-    E.dx0 = ws.dX[0]; E.dE = p->grads + ws.off[0]; E.dP = ws.dm_part + (size_t)nl * FM_DMBLK * L * FM_D; E.dlnw = p->grads + ws.off[2]; E.dlnb = p->grads + ws.off[3];
+    E.dx0 = ws.dX[0]; E.dE = p->grads + ws.off[0]; E.dP = ws.dm_part + (size_t)nl * FM_DMBLK * L * FM_D; E.ln_wg = ws.ln_wg + (size_t)nl * FM_DMBLK * 2 * FM_D;
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
     hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < FM_DMBLK ? p->B : FM_DMBLK), dim3(256), 0, s, E);    // one dP partial per workgroup
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
-    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3((L * FM_D + 63) / 64, nl + 1), dim3(256), 0, s, ws.dm_part, ws.dm,
-                       p->B < FM_DMBLK ? p->B : FM_DMBLK, L * FM_D, p->grads + ws.off[1], nl);
+    FDmRedArgs R{};
+    R.part = ws.dm_part; R.dm = ws.dm; R.dP = p->grads + ws.off[1]; R.ln_wg = ws.ln_wg; R.grads = p->grads;
+    R.o_fln_w = foff(ws, 0, FP_FLN_W); R.o_fln_b = foff(ws, 0, FP_FLN_B); R.layer_stride = lstride; R.o_eln_w = ws.off[2]; R.o_eln_b = ws.off[3];
+    R.nblk = p->B < FM_DMBLK ? p->B : FM_DMBLK; R.n = L * FM_D; R.n_layer = nl; R.nx = (L * FM_D + 63) / 64;
+    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3(R.nx + 2, nl + 1), dim3(256), 0, s, R);
     hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl, ((L / 2 + 1) * FM_D + 255) / 256), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
     WgradArgs W{};
     for (int l = 0; l < nl; ++l) {
