@@ -92,8 +92,6 @@ struct WgradJob {
     const float* G; int ldg; int gcol;        // G rows start at column gcol
     const float* X; int ldx;
     float* dW; float* db;
-    uint32_t gsite; int gmode;                // 1: G *= dropout keep factor at element t*ldg + col
-    uint32_t xsite; int xmode;                // 1: X = gelu(X) * keep factor
 };
 struct WgradArgs {
     WgradJob job[6 * DR4SR_MAX_LAYERS];

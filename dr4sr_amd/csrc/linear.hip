@@ -1318,8 +1318,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
     float* Gs = smem;                 // [64][NG]
     float* Xs = smem + 64 * NG;       // [64][KX]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, g = lane >> 5;
-    const bool dodrop = A.training && A.p > 0.f;
-    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     f32x16 acc[TPW];
     acc_zero(acc);
     float bsum[(NG + 255) / 256];
@@ -1327,40 +1325,35 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
     for (int i = 0; i < (NG + 255) / 256; ++i) bsum[i] = 0.f;
 
     // software pipeline (async-STAGE split): the global loads of the NEXT token tile are issued into registers
-    // before the MFMA phase of the current one and committed (dropout / GELU applied) to LDS after it.
+    // before the MFMA phase of the current one and committed to LDS after it (plain stores: the operands are the saved activations —
+    // the recompute modes this commit once had cost ~200 ISA lines per vector even when skipped).
     constexpr int GQ = NG / 16, XQ = KX / 16;      // float4 per thread per tile
     float4 gq[GQ], xq[XQ];
-    auto issue = [&](int tt) {
+    auto issue = [&](int tt) {                       // rows past T: the last row again (unconditional loads issue back to back), zeroed in commit
         const int t0 = tt * 64;
 #pragma unroll
         for (int u = 0; u < GQ; ++u) {
-            const int i = threadIdx.x + 256 * u, row = i / (NG / 4), c = (i % (NG / 4)) * 4, t = t0 + row;
-            gq[u] = t < T ? ld4(J.G + (size_t)t * J.ldg + J.gcol + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = threadIdx.x + 256 * u, row = i / (NG / 4), c = (i % (NG / 4)) * 4, t = min(t0 + row, T - 1);
+            gq[u] = ld4(J.G + (size_t)t * J.ldg + J.gcol + c);
         }
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
-            const int i = threadIdx.x + 256 * u, row = i / (KX / 4), c = (i % (KX / 4)) * 4, t = t0 + row;
-            xq[u] = t < T ? ld4(J.X + (size_t)t * J.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = threadIdx.x + 256 * u, row = i / (KX / 4), c = (i % (KX / 4)) * 4, t = min(t0 + row, T - 1);
+            xq[u] = ld4(J.X + (size_t)t * J.ldx + c);
         }
     };
     auto commit = [&](int tt) {
         const int t0 = tt * 64;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < GQ; ++u) {
-            const int i = threadIdx.x + 256 * u, row = i / (NG / 4), c = (i % (NG / 4)) * 4, t = t0 + row;
-            float4 v = gq[u];
-            if (J.gmode && dodrop && t < T) { const float4 m = drop4(rk, J.gsite, (uint64_t)t * J.ldg + J.gcol + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
-            st4(Gs + row * NG + c, v);
+            const int i = threadIdx.x + 256 * u, row = i / (NG / 4), c = (i % (NG / 4)) * 4;
+            st4(Gs + row * NG + c, t0 + row < T ? gq[u] : z4);
         }
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
-            const int i = threadIdx.x + 256 * u, row = i / (KX / 4), c = (i % (KX / 4)) * 4, t = t0 + row;
-            float4 v = xq[u];
-            if (J.xmode && t < T) {
-                v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-                if (dodrop) { const float4 m = drop4(rk, J.xsite, (uint64_t)t * J.ldx + c); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
-            }
-            st4(Xs + row * KX + c, v);
+            const int i = threadIdx.x + 256 * u, row = i / (KX / 4), c = (i % (KX / 4)) * 4;
+            st4(Xs + row * KX + c, t0 + row < T ? xq[u] : z4);
         }
     };
     int tt = blockIdx.x;
@@ -1727,21 +1720,21 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
         const LayerWs& lw = ws.layer[l];
         for (int part = 0; part < 3; ++part) {          // in_proj rows [part*D, (part+1)*D)
             WgradJob& J = A.job[l * 6 + part];
-            J.G = lw.dqkv; J.ldg = 3 * D; J.gcol = part * D; J.gsite = 0; J.gmode = 0;
-            J.X = ws.X[l]; J.ldx = D; J.xsite = 0; J.xmode = 0;
+            J.G = lw.dqkv; J.ldg = 3 * D; J.gcol = part * D;
+            J.X = ws.X[l]; J.ldx = D;
             J.dW = G + poff(ws, l, P_IN_W) + (int64_t)part * D * D; J.db = G + poff(ws, l, P_IN_B) + part * D;
         }
         { WgradJob& J = A.job[l * 6 + 3];                 // out_proj: G = dout (= du1 * mask_proj), X = ctx
-          J.G = lw.dout; J.ldg = D; J.gcol = 0; J.gsite = 0; J.gmode = 0;
-          J.X = lw.ctx; J.ldx = D; J.xsite = 0; J.xmode = 0;
+          J.G = lw.dout; J.ldg = D; J.gcol = 0;
+          J.X = lw.ctx; J.ldx = D;
           J.dW = G + poff(ws, l, P_OUT_W); J.db = G + poff(ws, l, P_OUT_B); }
         { WgradJob& J = A.job[l * 6 + 4];                 // linear1: G = da, X = y
-          J.G = lw.da; J.ldg = F; J.gcol = 0; J.gsite = 0; J.gmode = 0;
-          J.X = lw.y; J.ldx = D; J.xsite = 0; J.xmode = 0;
+          J.G = lw.da; J.ldg = F; J.gcol = 0;
+          J.X = lw.y; J.ldx = D;
           J.dW = G + poff(ws, l, P_W1); J.db = G + poff(ws, l, P_B1); }
         { WgradJob& J = A.job[l * 6 + 5];                 // linear2: G = df (= du2 * mask_ffn), X = h = drop(gelu(a))
-          J.G = lw.df; J.ldg = D; J.gcol = 0; J.gsite = 0; J.gmode = 0;
-          J.X = lw.h; J.ldx = F; J.xsite = 0; J.xmode = 0;
+          J.G = lw.df; J.ldg = D; J.gcol = 0;
+          J.X = lw.h; J.ldx = F;
           J.dW = G + poff(ws, l, P_W2); J.db = G + poff(ws, l, P_B2); }
     }
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.training = training;
