@@ -1744,7 +1744,13 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
     A.score_tiles = with_score == 2;
     static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 48;   // tuning knob
-    int gw_t = ntiles / 16 > gw_max ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : gw_max;   // >= 16 token tiles per workgroup at scale
+    // token splits per job at scale: 160 up to ~2 500 expected 64-token tiles, then tiles / 16 up to 320 (measured: toys B = 8 192,
+    // 1 170 tiles: 128 / 160 / 224 splits -> 120.9 / 117.3 / 121.4 us; dense B = 8 192, 6 400 tiles: 160 / 224 / 320 / 448 -> 905 / 868 /
+    // 840 / 854 us; toys B = 32 768: 160 -> 256 splits +1.4 % step).  Without a hint the capacity counts as before (cap 160).
+    static const int gw_cap_env = getenv("DR4SR_WGRAD_GW_CAP") ? atoi(getenv("DR4SR_WGRAD_GW_CAP")) : 0;
+    const int hint_tiles = p->expected_tokens > 0 ? (int)((p->expected_tokens < ws.Tmax ? p->expected_tokens : ws.Tmax) / 64) : 0;
+    const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > 320 ? 320 : hint_tiles / 16) : 160);
+    int gw_t = ntiles / 16 > gw_max ? (ntiles / 16 > gw_cap ? gw_cap : ntiles / 16) : gw_max;   // >= 16 token tiles per workgroup at scale
     int gw = ntiles < gw_t ? ntiles : gw_t;
     A.sc_g = nullptr;
     const bool scatter = scatter_in_wgrad(ws) && with_score != 1;       // paired with launch_qkv_embed_bwd (not the unfused debug path)
