@@ -6,7 +6,7 @@
 // (irfft ignores the imaginary part of the DC and Nyquist bins).  k_fmlp_coef builds m from the complex weight once per
 // step; k_fmlp_filter_fwd/bwd apply it (and its transpose) with the whole [L x 64] sequence tile resident in LDS, fused
 // with dropout + residual + LayerNorm; the weight gradient is accumulated as dm and folded back to d(complex weight) by
-// k_fmlp_coef_bwd.  The Intermediate block re-uses the MFMA tile kernels of linear.hip (FFN_ONLY instantiation, F = 256).
+// fmlp_coef_bwd_job (linear.hip, inside k_fmlp_wgrad).  The Intermediate block re-uses the MFMA tile kernels of linear.hip (FFN_ONLY instantiation, F = 256).
 // All B*L positions are computed: FMLP rows are left-padded prefixes and the filter mixes every position.
 #include "common.h"
 #include "kernels.h"
@@ -110,34 +110,39 @@ static int fmlp_ws(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
 }
 
 // ------------------------------------------------------------------------------------------------ prep + coefficients
-// block 0: state[T] = B*L, RNG bump; blocks 1..: zero the flat gradient (+tail)
-__global__ __launch_bounds__(1024) void k_fmlp_prep(int* __restrict__ state, int Tn, int bump, float* __restrict__ zero, int64_t n4) {
+// block 0: state[T] = B*L, RNG bump; blocks 1 .. zb: zero the flat gradient (+tail); the last n_layer * FM_COEF_BLK blocks:
+// m[l][r][d] from complex_weight[k][d][2] (one output per thread) and dm = 0 — a launch of its own (4.9 us) before.
+#define FM_COEF_BLK 4                          // x 1024 threads >= L * 64 outputs per layer (L <= 50)
+struct FPrepArgs {
+    int* state; int Tn, bump; float* zero; int64_t n4; int zb;
+    const float* params; int64_t o_cw0, layer_stride; float* m; float* dm; int L;
+};
+__global__ __launch_bounds__(1024) void k_fmlp_prep(const FPrepArgs A) {
     if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) { state[DR4SR_STATE_T] = Tn; if (bump) state[DR4SR_STATE_RNGSTEP] += 1; }
+        if (threadIdx.x == 0) { A.state[DR4SR_STATE_T] = A.Tn; if (A.bump) A.state[DR4SR_STATE_RNGSTEP] += 1; }
         return;
     }
-    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < n4; i += (int64_t)(gridDim.x - 1) * 1024)
-        st4(zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
-}
-
-// m[l][r][d] from complex_weight[k][d][2]; also zeroes dm.  grid = (n_layer, ceil(L*64/256)), one output per thread.
-__global__ __launch_bounds__(256) void k_fmlp_coef(const float* __restrict__ params, int64_t o_cw0, int64_t layer_stride,
-                                                   float* __restrict__ m, float* __restrict__ dm, int L) {
+    if ((int)blockIdx.x <= A.zb) {
+        for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < A.n4; i += (int64_t)A.zb * 1024)
+            st4(A.zero + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
     __shared__ float ct[64], sn[64];
-    const int layer = blockIdx.x, K = L / 2 + 1;
+    const int c = blockIdx.x - 1 - A.zb, layer = c / FM_COEF_BLK, L = A.L, K = L / 2 + 1;
     if ((int)threadIdx.x < L) sincospif(2.0f * threadIdx.x / (float)L, &sn[threadIdx.x], &ct[threadIdx.x]);
     __syncthreads();
-    const float* cw = params + o_cw0 + layer * layer_stride;
-    for (int i = blockIdx.y * 256 + threadIdx.x; i < L * FM_D; i += gridDim.y * 256) {
-        const int r = i / FM_D, d = i % FM_D;
+    const float* cw = A.params + A.o_cw0 + layer * A.layer_stride;
+    const int i = (c % FM_COEF_BLK) * 1024 + threadIdx.x;
+    if (i < L * FM_D) {
         float acc = 0.f;
+        const int r = i / FM_D, d = i % FM_D;
         for (int k = 0; k < K; ++k) {
             const int j = (k * r) % L;
-            const float c = (k == 0 || 2 * k == L) ? 1.f : 2.f;
-            acc += c * (cw[(k * FM_D + d) * 2] * ct[j] - cw[(k * FM_D + d) * 2 + 1] * sn[j]);
+            const float cf = (k == 0 || 2 * k == L) ? 1.f : 2.f;
+            acc += cf * (cw[(k * FM_D + d) * 2] * ct[j] - cw[(k * FM_D + d) * 2 + 1] * sn[j]);
         }
-        m[(size_t)layer * L * FM_D + i] = acc / (float)L;
-        dm[(size_t)layer * L * FM_D + i] = 0.f;
+        A.m[(size_t)layer * L * FM_D + i] = acc / (float)L;
+        A.dm[(size_t)layer * L * FM_D + i] = 0.f;
     }
 }
 // dm[layer][i] = sum over the nblk per-workgroup partials written by k_fmlp_filter_bwd (fixed order -> deterministic).
@@ -188,30 +193,6 @@ __global__ __launch_bounds__(256) void k_fmlp_dm_reduce(const FDmRedArgs A) {
         }
     }
 }
-// d(complex_weight) += fold(dm)
-__global__ __launch_bounds__(256) void k_fmlp_coef_bwd(float* __restrict__ grads, int64_t o_cw0, int64_t layer_stride,
-                                                       const float* __restrict__ dm, int L) {
-    __shared__ float ct[64], sn[64];
-    const int layer = blockIdx.x, K = L / 2 + 1;
-    if ((int)threadIdx.x < L) sincospif(2.0f * threadIdx.x / (float)L, &sn[threadIdx.x], &ct[threadIdx.x]);
-    __syncthreads();
-    float* g = grads + o_cw0 + layer * layer_stride;
-    const float* dml = dm + (size_t)layer * L * FM_D;
-    for (int i = blockIdx.y * 256 + threadIdx.x; i < K * FM_D; i += gridDim.y * 256) {
-        const int k = i / FM_D, d = i % FM_D;
-        float gr = 0.f, gi = 0.f;
-        for (int r = 0; r < L; ++r) {
-            const int j = (k * r) % L;
-            const float v = dml[r * FM_D + d];
-            gr += ct[j] * v;
-            gi -= sn[j] * v;
-        }
-        const float c = ((k == 0 || 2 * k == L) ? 1.f : 2.f) / (float)L;
-        g[(k * FM_D + d) * 2] += c * gr;
-        g[(k * FM_D + d) * 2 + 1] += c * gi;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ embedding + LayerNorm
 struct FEmbArgs {
     const float* E; const float* P; const float* lnw; const float* lnb;
@@ -548,9 +529,10 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
     const int L = p->L, nl = p->n_layer;
     const int64_t n4 = zero_grads ? (ws.n_params + DR4SR_GRAD_TAIL) / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024); if (zb > 255) zb = 255;
-    hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb), dim3(1024), 0, s, p->state, ws.Tn, training ? 1 : 0, zero_grads ? p->grads : nullptr, n4);
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
-    hipLaunchKernelGGL(k_fmlp_coef, dim3(nl, (L * FM_D + 255) / 256), dim3(256), 0, s, p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L);
+    const FPrepArgs PA{p->state, ws.Tn, training ? 1 : 0, zero_grads ? p->grads : nullptr, n4, zb,
+                       p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L};
+    hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb + nl * FM_COEF_BLK), dim3(1024), 0, s, PA);
     FEmbArgs E{};
     E.E = p->params + ws.off[0]; E.P = p->params + ws.off[1]; E.lnw = p->params + ws.off[2]; E.lnb = p->params + ws.off[3];
     E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0; E.x0 = ws.X[0];
@@ -613,7 +595,6 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     R.o_fln_w = foff(ws, 0, FP_FLN_W); R.o_fln_b = foff(ws, 0, FP_FLN_B); R.layer_stride = lstride; R.o_eln_w = ws.off[2]; R.o_eln_b = ws.off[3];
     R.nblk = p->B < FM_DMBLK ? p->B : FM_DMBLK; R.n = L * FM_D; R.n_layer = nl; R.nx = (L * FM_D + 63) / 64;
     hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3(R.nx + 2, nl + 1), dim3(256), 0, s, R);
-    hipLaunchKernelGGL(k_fmlp_coef_bwd, dim3(nl, ((L / 2 + 1) * FM_D + 255) / 256), dim3(256), 0, s, p->grads, foff(ws, 0, FP_CW), lstride, ws.dm, L);
     WgradArgs W{};
     for (int l = 0; l < nl; ++l) {
         const FmlpLayerWs& w = ws.layer[l];
@@ -628,6 +609,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     W.ln_part = ws.ln_part; W.ln_layer_stride = (int64_t)ntiles * 4 * FM_D; W.grads = p->grads; W.ln_tile_rows = bm;
     W.o_ln1_w = foff(ws, 0, FP_ILN_W); W.layer_stride = lstride;
     W.score_part = with_score ? ws.score_part : nullptr; W.tail = p->grads + ws.n_params; W.B = p->B; W.D = FM_D;
+    W.fc_dm = ws.dm; W.fc_o_cw = foff(ws, 0, FP_CW); W.fc_L = L;      // d(complex_weight) = fold(dm) rides in the reduce blocks
     RC(launch_fmlp_wgrad(W, ws.Tn, nl, s));
     return DR4SR_LAUNCH_CHECK();
 }

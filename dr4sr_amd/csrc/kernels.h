@@ -102,6 +102,7 @@ struct WgradArgs {
     int score_tiles;                           // 1: score_part holds one (count, loss) pair per token tile instead of per sequence
     int ln_tile_rows;                          // token rows per LayerNorm-partial row (tile size of the post kernels)
     int qeb_plane;                             // 1: grid plane z = 0 runs the embedding-stage backward tiles, layers are z - 1
+    const float* fc_dm; int64_t fc_o_cw; int fc_L;     // FMLP: filter-coefficient backward as part of the reduce blocks (fc_dm == NULL: none)
     // embedding scatter job (blockIdx.y == 7, large batches; sc_g == NULL: none)
     const float* sc_g; const int64_t* sc_idx; const int64_t* sc_rows; const int* sc_tile_seq; const int* cu;
     float* sc_dE; float* sc_dP; int sc_L; int sc_n_items;

@@ -1694,9 +1694,33 @@ __device__ __forceinline__ void reduce_jobs_fmlp(const WgradArgs& A) {
         if (threadIdx.x == 0) { A.tail[0] += red[0]; A.tail[1] += red[256]; }
     }
 }
+// d(complex_weight)[k][d][2] += fold(dm) (fmlp.hip: k_fmlp_coef is the forward): the first blocks of each layer's reduce row, one
+// (k, d) pair per thread — a 6.5 us launch of its own before.  This launch is the only writer of those gradient rows.
+__device__ __forceinline__ void fmlp_coef_bwd_job(const WgradArgs& A) {
+    __shared__ float ct[64], sn[64];
+    const int layer = blockIdx.z, L = A.fc_L, K = L / 2 + 1, D = A.D;
+    if ((int)blockIdx.x * 256 >= K * D) return;
+    if ((int)threadIdx.x < L) sincospif(2.0f * threadIdx.x / (float)L, &sn[threadIdx.x], &ct[threadIdx.x]);
+    lds_barrier();
+    float* g = A.grads + A.fc_o_cw + layer * A.layer_stride;
+    const float* dml = A.fc_dm + (size_t)layer * L * D;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < K * D; i += gridDim.x * 256) {      // (tiny batches run fewer blocks than pairs / 256)
+        const int k = i / D, d = i % D;
+        float gr = 0.f, gi = 0.f;
+        for (int r = 0; r < L; ++r) {
+            const int j = (k * r) % L;
+            const float v = dml[r * D + d];
+            gr += ct[j] * v;
+            gi -= sn[j] * v;
+        }
+        const float c = ((k == 0 || 2 * k == L) ? 1.f : 2.f) / (float)L;
+        g[(k * D + d) * 2] += c * gr;
+        g[(k * D + d) * 2 + 1] += c * gi;
+    }
+}
 __global__ __launch_bounds__(256) void k_fmlp_wgrad(const WgradArgs A) {
     const int j = blockIdx.y;
-    if (j == 2) { reduce_jobs_fmlp(A); return; }
+    if (j == 2) { reduce_jobs_fmlp(A); if (A.fc_dm) fmlp_coef_bwd_job(A); return; }
     const WgradJob& J = A.job[blockIdx.z * 6 + 4 + j];
     if (j == 0) wgrad_body<256, 64>(J, A);
     else wgrad_body<64, 256>(J, A);
