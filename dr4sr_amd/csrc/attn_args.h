@@ -1,4 +1,4 @@
-// attn_args.h — argument block shared by the MFMA attention kernels (attn_mfma.hip) and the tiny-sequence VALU class (attn_tiny.hip)
+// attn_args.h — argument block shared by the MFMA attention kernels (attn_mfma.hip) and the tiny-sequence VALU class (attn_tiny_body.h)
 #pragma once
 #include <stdint.h>
 
@@ -15,5 +15,5 @@ struct AttnArgs2 {
     const int* desc;             // tiny class: int4 {t0, n, slot, dataset row} per list entry (k_prep), 16-byte aligned
 };
 
-// tiny-sequence class (1..DR4SR_TINY_MAX tokens), attn_tiny.hip: one wave per 4 list entries
+// tiny-sequence class (1..DR4SR_TINY_MAX tokens), attn_tiny_body.h: one wave per 4 list entries
 int launch_attn_tiny(const AttnArgs2& A, int DH, int B, bool bwd, hipStream_t s);

@@ -214,10 +214,10 @@ __device__ __forceinline__ void attn_fwd_seq(const AttnArgs2& A, const int b) {
 // are in flight to registers, the (cu, rows) words of i+2 and the list entry of i+3 are requested — the dependent chain
 // list -> cu -> rows of a sequence never sits in front of its compute phase.
 template <int DH, int ROWS, int NT>
-__device__ __forceinline__ void attn_fwd_list(const AttnArgs2& A) {
+__device__ __forceinline__ void attn_fwd_list(const AttnArgs2& A, const int bid, const int G) {
     constexpr int D = 2 * DH, LD = D + 4, PER = (ROWS * (D / 4) + NT - 1) / NT;
-    const int cnt = *A.list_count, G = gridDim.x;
-    if ((int)blockIdx.x >= cnt) return;
+    const int cnt = *A.list_count;
+    if (bid >= cnt) return;
     const uint32_t rngstep = (uint32_t)A.state[DR4SR_STATE_RNGSTEP];
     float* Ks = smem;
     float* Vs = Ks + ROWS * LD;
@@ -233,9 +233,9 @@ __device__ __forceinline__ void attn_fwd_list(const AttnArgs2& A) {
         if (rin) ridx = A.idx[m.row * A.L + threadIdx.x];
     };
     const int z = opaque_zero();
-    SeqMeta cur = seq_final(seq_raw(A, list_raw(A, blockIdx.x, z), z));
+    SeqMeta cur = seq_final(seq_raw(A, list_raw(A, bid, z), z));
     request(cur);
-    int k1 = blockIdx.x + G, k2 = k1 + G;
+    int k1 = bid + G, k2 = k1 + G;
     bool has1 = k1 < cnt, has2 = k2 < cnt;
     SeqRaw nxt_raw = SeqRaw{0, 0, 0, 0};
     if (has1) nxt_raw = seq_raw(A, list_raw(A, k1, z), z);
@@ -264,7 +264,7 @@ __device__ __forceinline__ void attn_fwd_list(const AttnArgs2& A) {
 template <int DH, int ROWS, int NT, bool LIST>
 __global__ __launch_bounds__(NT) void k_attn2_fwd(const AttnArgs2 A) {
     if constexpr (!LIST) attn_fwd_seq<DH, ROWS, NT>(A, blockIdx.x);
-    else attn_fwd_list<DH, ROWS, NT>(A);
+    else attn_fwd_list<DH, ROWS, NT>(A, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -443,12 +443,12 @@ __device__ __forceinline__ void attn_bwd_seq(const AttnArgs2& A, const int b) {
 
 // persistent list loop, software-pipelined like attn_fwd_list (rows and statistics of sequence i+1 in flight during sequence i)
 template <int DH, int ROWS, int NT>
-__device__ __forceinline__ void attn_bwd_list(const AttnArgs2& A) {
+__device__ __forceinline__ void attn_bwd_list(const AttnArgs2& A, const int bid, const int G) {
     constexpr int D = 2 * DH, LD = D + 4, H = 2, PER = (ROWS * (D / 4) + NT - 1) / NT;
     constexpr bool VLDS = BwdLds<DH, ROWS>::VLDS;
     static_assert(H * ROWS <= NT, "one statistics triple per thread");
-    const int cnt = *A.list_count, G = gridDim.x;
-    if ((int)blockIdx.x >= cnt) return;
+    const int cnt = *A.list_count;
+    if (bid >= cnt) return;
     const uint32_t rngstep = (uint32_t)A.state[DR4SR_STATE_RNGSTEP];
     const BwdLds<DH, ROWS> S;
     float4 rq[PER], rk[PER], rc[PER], rv[VLDS ? PER : 1];
@@ -472,9 +472,9 @@ __device__ __forceinline__ void attn_bwd_list(const AttnArgs2& A) {
         }
     };
     const int z = opaque_zero();
-    SeqMeta cur = seq_final(seq_raw(A, list_raw(A, blockIdx.x, z), z));
+    SeqMeta cur = seq_final(seq_raw(A, list_raw(A, bid, z), z));
     request(cur);
-    int k1 = blockIdx.x + G, k2 = k1 + G;
+    int k1 = bid + G, k2 = k1 + G;
     bool has1 = k1 < cnt, has2 = k2 < cnt;
     SeqRaw nxt_raw = SeqRaw{0, 0, 0, 0};
     if (has1) nxt_raw = seq_raw(A, list_raw(A, k1, z), z);
@@ -504,7 +504,7 @@ __device__ __forceinline__ void attn_bwd_list(const AttnArgs2& A) {
 template <int DH, int ROWS, int NT, bool LIST>
 __global__ __launch_bounds__(NT) void k_attn2_bwd(const AttnArgs2 A) {
     if constexpr (!LIST) attn_bwd_seq<DH, ROWS, NT>(A, blockIdx.x);
-    else if constexpr (ROWS == 16) attn_bwd_list<DH, ROWS, NT>(A);
+    else if constexpr (ROWS == 16) attn_bwd_list<DH, ROWS, NT>(A, blockIdx.x, gridDim.x);
     else {                                   // 64-row sequences: the staging registers of the pipelined loop would cost a wave per SIMD
         const int cnt = *A.list_count;
         for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
@@ -512,6 +512,43 @@ __global__ __launch_bounds__(NT) void k_attn2_bwd(const AttnArgs2 A) {
             lds_barrier();                   // LDS is reused by the next sequence
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ the two short classes in ONE launch
+#include "attn_tiny_body.h"
+// At scale an attention call was three launches (1..8 tokens: VALU; 9..16: 16-row MFMA list; longer: 64-row list) whose durations add
+// (toys B = 8192: 12 + 7 + 12 us forward, 19 + 10 + 27 us backward), each bound by the latency chains of the sequences in flight,
+// not by issue slots.  Graph-level parallel branches cost more in fork / join than they win; here the first gs blocks of
+// one launch run the persistent 16-row list loop over gs workgroups and the rest are the tiny-class blocks (one wave each: the other
+// waves of such a block exit at once), so the two classes share the CUs without a launch boundary between them.  The 64-row class
+// keeps its own launch (its 54 KB of LDS per workgroup would cap the residency of the small ones).
+template <int DH>
+__global__ __launch_bounds__(128, DH == 32 ? 4 : 2) void k_attn_small_fwd(const AttnArgs2 S, const AttnArgs2 Tn, const int gs) {
+    if ((int)blockIdx.x < gs) attn_fwd_list<DH, 16, 128>(S, blockIdx.x, gs);
+    else if (threadIdx.x < tiny::NT) tiny::fwd_body<DH>(Tn, blockIdx.x - gs);
+}
+constexpr int SHORT_BWD_NT_ = 256;
+template <int DH>
+__global__ __launch_bounds__(SHORT_BWD_NT_) void k_attn_small_bwd(const AttnArgs2 S, const AttnArgs2 Tn, const int gs) {
+    if ((int)blockIdx.x < gs) attn_bwd_list<DH, 16, SHORT_BWD_NT_>(S, blockIdx.x, gs);
+    else if (threadIdx.x < tiny::NT) tiny::bwd_body<DH>(Tn, blockIdx.x - gs);
+}
+
+// grid = worst case (every sequence of the batch tiny); workgroups beyond the list's device-side count exit at once
+int launch_attn_tiny(const AttnArgs2& A, int DH, int B, bool bwd, hipStream_t s) {
+    using namespace tiny;
+    if (!A.desc || !A.list_count) return DR4SR_E_ARG;
+    dim3 grid((B + SPB - 1) / SPB), blk(NT);
+    if (DH == 32) {
+        const size_t lds = TinyLds<32>::bytes(bwd);
+        if (bwd) { big_lds(k_attn_tiny_bwd<32>, lds); hipLaunchKernelGGL(k_attn_tiny_bwd<32>, grid, blk, lds, s, A); }
+        else hipLaunchKernelGGL(k_attn_tiny_fwd<32>, grid, blk, lds, s, A);
+    } else if (DH == 64) {
+        const size_t lds = TinyLds<64>::bytes(bwd);
+        if (bwd) { big_lds(k_attn_tiny_bwd<64>, lds); hipLaunchKernelGGL(k_attn_tiny_bwd<64>, grid, blk, lds, s, A); }
+        else { big_lds(k_attn_tiny_fwd<64>, lds); hipLaunchKernelGGL(k_attn_tiny_fwd<64>, grid, blk, lds, s, A); }
+    } else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -573,7 +610,36 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     Lg.list = ws.seq_class + 4 + 5 * B; Lg.list_count = ws.seq_class + 1;
     Tn.list = ws.seq_class + 4 + 6 * B; Tn.list_count = ws.seq_class + 2; Tn.desc = ws.seq_class + 4;
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
-    // third class, 1..8 tokens: VALU kernels (attn_tiny.hip).  DR4SR_ATTN_NOTINY (cross-check): the same list through the 16-row MFMA kernels
+    // default: the 1..8-token and 9..16-token classes as ONE launch (k_attn_small_*), then the 64-row list.  DR4SR_ATTN_NOMERGE: one
+    // launch per class (cross-check, read per call like DR4SR_ATTN_NOTINY)
+    if (!getenv("DR4SR_ATTN_NOTINY") && !getenv("DR4SR_ATTN_NOMERGE")) {
+        static const int dv = getenv("DR4SR_ATTN_SMALL_DIV") ? atoi(getenv("DR4SR_ATTN_SMALL_DIV")) : 2;      // share of the residency left to the tiny blocks (tuning)
+        const int gsm = gs / (dv > 0 ? dv : 1) > 0 ? gs / (dv > 0 ? dv : 1) : 1;
+        const size_t lds_t = tiny::TinyLds<DH>::bytes(bwd), lds_m = lds_s > lds_t ? lds_s : lds_t;
+        dim3 grid(gsm + (B + tiny::SPB - 1) / tiny::SPB);
+        static const bool merge_bwd = getenv("DR4SR_ATTN_MERGE_BWD") != nullptr;
+        if (bwd && !merge_bwd) {
+            // backward: NOT merged by default — the tiny class needs 192 VGPRs, the 16-row list 120; at the merged kernel's 208 the list's
+            // workgroups fill the register file two per CU and the tiny blocks queue behind them (32.7 us against 19.2 + 9.8)
+            const int rc = launch_attn_tiny(Tn, DH, B, true, s);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>), dim3(gs), dim3(SHORT_BWD_NT), lds_s, s, S);
+            big_lds(k_attn2_bwd<DH, 64, 256, true>, lds_l);
+            hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
+        } else if (bwd) {
+            big_lds(k_attn_small_bwd<DH>, lds_m);
+            hipLaunchKernelGGL((k_attn_small_bwd<DH>), grid, dim3(SHORT_BWD_NT), lds_m, s, S, Tn, gsm);
+            big_lds(k_attn2_bwd<DH, 64, 256, true>, lds_l);
+            hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
+        } else {
+            big_lds(k_attn_small_fwd<DH>, lds_m);
+            hipLaunchKernelGGL((k_attn_small_fwd<DH>), grid, dim3(128), lds_m, s, S, Tn, gsm);
+            big_lds(k_attn2_fwd<DH, 64, 256, true>, lds_l);
+            hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
+        }
+        return DR4SR_LAUNCH_CHECK();
+    }
+    // third class, 1..8 tokens: VALU kernels (attn_tiny_body.h).  DR4SR_ATTN_NOTINY (cross-check): the same list through the 16-row MFMA kernels
     if (!getenv("DR4SR_ATTN_NOTINY")) {
         const int rc = launch_attn_tiny(Tn, DH, B, bwd, s);
         if (rc) return rc;

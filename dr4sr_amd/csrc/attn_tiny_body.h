@@ -1,4 +1,4 @@
-// attn_tiny.hip — causal 2-head self-attention for sequences of 1..8 tokens, on the VALU: the third length class of the split launches.
+// attn_tiny_body.h (included by attn_mfma.hip) — causal 2-head self-attention for sequences of 1..8 tokens, on the VALU: the third length class of the split launches.
 //
 // Why: two thirds of the Amazon-toys sequences have at most 4 tokens and 85 % at most 8, yet the MFMA kernels (attn_mfma.hip) spend a
 // full 16x16 tile chain — 16 MFMAs per (sequence, head) forward, 56 backward, plus LDS staging and two barriers — on each of them
@@ -16,13 +16,14 @@
 // :48, scale 1/sqrt(head_dim), dropout on the probabilities); saved statistics, dropout element indexing
 // ((b*H+h)*64 + i)*64 + j and the <dctx, ctx> row term are those of attn_mfma.hip, so the two classes are interchangeable per
 // sequence (tests: DR4SR_ATTN_NOTINY runs the tiny list through the 16-row MFMA kernels instead).
+#pragma once
 #include "common.h"
 #include "kernels.h"
 #include "attn_args.h"
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
-namespace {
+namespace tiny {
 
 constexpr int NMAX = DR4SR_TINY_MAX;            // 8 rows = 8 lanes per (sequence, head)
 static_assert(NMAX == 8, "lane layout: 8 lanes per (sequence, head)");
@@ -69,10 +70,10 @@ __device__ __forceinline__ void axpy_row(float (&acc)[DH], float a, const float*
 // Workgroup prologue: the (t0, n, b) words of the block's 8 sequences, then their K | V rows (contiguous in a qkv row: one coalesced
 // 2D-float run per token) into LDS, rows >= n zero-filled.  Returns the largest n of the block (the row loops stop there).
 template <int DH>
-__device__ __forceinline__ int tiny_stage(const AttnArgs2& A, const TinyLds<DH>& S, int cnt, unsigned& padbits) {
+__device__ __forceinline__ int tiny_stage(const AttnArgs2& A, const TinyLds<DH>& S, int cnt, unsigned& padbits, const int bid) {
     constexpr int D = 2 * DH, LD = D + 4, ROWS = SPB * NMAX, F4 = 2 * D / 4;      // float4 per staged row (K | V)
     if (threadIdx.x < SPB) {                    // ONE 16-byte load per sequence (k_prep's descriptor) instead of list -> cu -> rows
-        const int k = blockIdx.x * SPB + threadIdx.x;
+        const int k = bid * SPB + threadIdx.x;
         int4 d = make_int4(0, 0, 0, 0);
         if (k < cnt) d = reinterpret_cast<const int4*>(A.desc)[k];
         S.meta[threadIdx.x] = d.x; S.meta[SPB + threadIdx.x] = d.y; S.meta[2 * SPB + threadIdx.x] = d.z; S.meta[3 * SPB + threadIdx.x] = d.w;
@@ -109,15 +110,16 @@ __device__ __forceinline__ int tiny_stage(const AttnArgs2& A, const TinyLds<DH>&
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// (bodies take the workgroup index: the same code runs as its own launch and as the tail blocks of k_attn_small_*, attn_mfma.hip)
 template <int DH>
-__global__ __launch_bounds__(NT) void k_attn_tiny_fwd(const AttnArgs2 A) {
+__device__ __forceinline__ void fwd_body(const AttnArgs2& A, const int bid) {
     constexpr int D = 2 * DH, H = 2, LD = D + 4;
     const int cnt = *A.list_count;
-    if ((int)blockIdx.x * SPB >= cnt) return;
+    if (bid * SPB >= cnt) return;
     const TinyLds<DH> S(false);
     const int i = threadIdx.x & 7, h = (threadIdx.x >> 3) & 1, sq = threadIdx.x >> 4;
     unsigned padmask;
-    const int nmax = tiny_stage<DH>(A, S, cnt, padmask);
+    const int nmax = tiny_stage<DH>(A, S, cnt, padmask, bid);
     const int t0 = S.meta[sq], n = S.meta[SPB + sq], b = S.meta[2 * SPB + sq];
     const bool act = i < n;
     float q[DH];
@@ -176,14 +178,14 @@ __global__ __launch_bounds__(NT) void k_attn_tiny_fwd(const AttnArgs2 A) {
 // LDS and phase B (lane = key row j) forms dK_j = sum_i dS[i][j] Q_i, dV_j = sum_i P~[i][j] dctx_i — nothing is recomputed, no
 // second round of Philox.
 template <int DH>
-__global__ __launch_bounds__(NT) void k_attn_tiny_bwd(const AttnArgs2 A) {
+__device__ __forceinline__ void bwd_body(const AttnArgs2& A, const int bid) {
     constexpr int D = 2 * DH, H = 2, LD = D + 4;
     const int cnt = *A.list_count;
-    if ((int)blockIdx.x * SPB >= cnt) return;
+    if (bid * SPB >= cnt) return;
     const TinyLds<DH> S(true);
     const int i = threadIdx.x & 7, grp = threadIdx.x >> 3, h = grp & 1, sq = threadIdx.x >> 4;
     unsigned padmask;
-    const int nmax = tiny_stage<DH>(A, S, cnt, padmask);
+    const int nmax = tiny_stage<DH>(A, S, cnt, padmask, bid);
     const int t0 = S.meta[sq], n = S.meta[SPB + sq], b = S.meta[2 * SPB + sq];
     const bool act = i < n;
     float q[DH], cf[DH];
@@ -269,20 +271,7 @@ __global__ __launch_bounds__(NT) void k_attn_tiny_bwd(const AttnArgs2 A) {
     }
 }
 
-}  // namespace
+template <int DH> __global__ __launch_bounds__(NT) void k_attn_tiny_fwd(const AttnArgs2 A) { fwd_body<DH>(A, blockIdx.x); }
+template <int DH> __global__ __launch_bounds__(NT) void k_attn_tiny_bwd(const AttnArgs2 A) { bwd_body<DH>(A, blockIdx.x); }
 
-// grid = worst case (every sequence of the batch tiny); workgroups beyond the list's device-side count exit at once
-int launch_attn_tiny(const AttnArgs2& A, int DH, int B, bool bwd, hipStream_t s) {
-    if (!A.desc || !A.list_count) return DR4SR_E_ARG;
-    dim3 grid((B + SPB - 1) / SPB), blk(NT);
-    if (DH == 32) {
-        const size_t lds = TinyLds<32>::bytes(bwd);
-        if (bwd) { big_lds(k_attn_tiny_bwd<32>, lds); hipLaunchKernelGGL(k_attn_tiny_bwd<32>, grid, blk, lds, s, A); }
-        else hipLaunchKernelGGL(k_attn_tiny_fwd<32>, grid, blk, lds, s, A);
-    } else if (DH == 64) {
-        const size_t lds = TinyLds<64>::bytes(bwd);
-        if (bwd) { big_lds(k_attn_tiny_bwd<64>, lds); hipLaunchKernelGGL(k_attn_tiny_bwd<64>, grid, blk, lds, s, A); }
-        else { big_lds(k_attn_tiny_fwd<64>, lds); hipLaunchKernelGGL(k_attn_tiny_fwd<64>, grid, blk, lds, s, A); }
-    } else return DR4SR_E_SHAPE;
-    return DR4SR_LAUNCH_CHECK();
-}
+}  // namespace tiny

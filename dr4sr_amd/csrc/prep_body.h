@@ -43,7 +43,7 @@ __device__ __forceinline__ void prep_body(const PrepArgs& P, unsigned long long*
     int* __restrict__ cu = P.cu; int* __restrict__ state = P.state; const int B = P.B, L = P.L, bump_rng = P.bump_rng;
     const PermSel sel = P.sel; int* __restrict__ tile_seq = P.tile_seq; int* __restrict__ seq_class = P.seq_class;
     // one packed scan: bits 0-31 tokens, 32-47 short sequences (9..16 tokens), 48-63 long sequences; a second word counts the tiny
-    // sequences (1..8 tokens: the VALU attention class, attn_tiny.hip)
+    // sequences (1..8 tokens: the VALU attention class, attn_tiny_body.h)
     constexpr int KEEP = 8, NWV = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t c = (sel.perm && !PRE) ? (int64_t)*sel.counter : 0;       // a1: this step's batch = a slice of the epoch permutation

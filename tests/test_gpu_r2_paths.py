@@ -143,7 +143,7 @@ def test_sasrec_throughput_mode_B8192_vs_oracle(dense, at_scale):
 
 @pytest.mark.parametrize("D,B,p", [(64, 2048, 0.0), (64, 2048, 0.5), (128, 1024, 0.3)])
 def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, at_scale, D, B, p):
-    """sequences of 1..8 tokens run on the VALU kernels of csrc/attn_tiny.hip in the split launches; DR4SR_ATTN_NOTINY sends the same
+    """sequences of 1..8 tokens run on the VALU kernels of csrc/attn_tiny_body.h in the split launches; DR4SR_ATTN_NOTINY sends the same
     list through the 16-row MFMA kernels: identical statistics / dropout element indexing, so losses and gradients agree to fp32
     summation order — also with dropout ON (the two classes regenerate the same Philox masks).  Batch with every length 1..8
     present, PAD items inside sequences (key-padding mask) and both head widths."""
@@ -177,6 +177,15 @@ def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, at_scale, D, B, p
     eng.fwd_bwd(plan)
     loss_m, n_m = eng.loss_and_count()
     assert n_m == n_t and abs(loss_m - loss_t) < 1e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, g_tiny[k].cpu()) < 2e-5, k
+    # the forward runs the 1..8- and 9..16-token classes as ONE launch (k_attn_small_fwd); DR4SR_ATTN_NOMERGE: one launch per class
+    monkeypatch.delenv("DR4SR_ATTN_NOTINY")
+    monkeypatch.setenv("DR4SR_ATTN_NOMERGE", "1")
+    eng.state[3] -= 1
+    eng.fwd_bwd(plan)
+    loss_s, n_s = eng.loss_and_count()
+    assert n_s == n_t and abs(loss_s - loss_t) < 1e-6
     for k, gv in eng.normalized_grads().items():
         assert relerr(gv, g_tiny[k].cpu()) < 2e-5, k
 
