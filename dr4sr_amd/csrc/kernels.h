@@ -33,7 +33,7 @@ struct Workspace {
     int Tmax;
     int* cu;                                   // [B+1] packed row offset of each sequence slot
     bool scale, attn_split;                    // at-scale token-tile forms / length-class attention lists for this plan (see at_scale below)
-    int* len_buf;                              // [B] clamped sequence lengths published by the two-phase prep (prep_body.h)
+    int* len_buf;                              // scratch of the two-phase prep (prep_body.h: 16 B per sequence + 16 B per optimizer workgroup)
     int* seq_class;                            // [4 + 7B] n_short, n_long, n_tiny, - | tiny_desc[B] int4 {t0, n, slot, row} | short_list[B] (9..16) | long_list[B] (> 16) | tiny_list[B] (1..8)  (k_prep)
     float* attn_rd;                            // [Tmax][H] <dctx, ctx> per (token, head): softmax-backward row term, from k_post_bwd
     int* tile_seq;                             // [ceil(Tmax/16)] sequence slot of token 16*i (k_prep), search hint of the token-tile kernels

@@ -91,7 +91,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->cu = (int*)take(p->B + 1);
     ws->tile_seq = (int*)take((Tmax + 15) / 16 + 1);
     ws->seq_class = (int*)take(4 + 7LL * p->B);
-    ws->len_buf = (int*)take(p->B);
+    ws->len_buf = (int*)take(4 * (int64_t)p->B + 4 * PREP_MAX_BLK);      // two-phase prep: 16 B per sequence + 16 B per workgroup of the optimizer launch
     ws->attn_rd = take(Tmax * p->H);
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
     ws->dctx = take(Tmax * D);
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
                                               const int* __restrict__ log_index, const AdamNext next) {
     __shared__ float sh[2];
     __shared__ unsigned long long part[256];
+    __shared__ int4 boff[PREP_MAX_BLK];            // two-phase prep: token / class offsets of the workgroups' sequence ranges
     const int t = state[DR4SR_STATE_STEP] + 1;
     const float nvalid = G[n];
     const float gs = nvalid > 0.f ? 1.0f / nvalid : 0.f;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
     const int nblk = next.enable == 1 ? (int)gridDim.x - 1 : (int)gridDim.x, blk = next.enable == 1 ? (int)blockIdx.x - 1 : (int)blockIdx.x;
     if (next.enable == 2) {                                // two-phase prep, phase 1 (+ this step's loss-log entry, before the batch index moves)
         if (loss_log && blk == 0 && threadIdx.x == 0) loss_log[log_index ? max(*log_index - 1, 0) : 0] = G[n + 1] * gs;
-        prep_select<256>(next.prep, blk, nblk);
+        prep_phase1<256>(next.prep, blk, nblk, part);
     }
     if (blk < 0) {                                         // dispatched first: the next step's prep (and this step's loss-log entry,
         const float lossv = G[n + 1] * gs;                 //  whose index the prep is about to advance)
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
         }
     }
     __shared__ int s_last;
-    __syncthreads();                           // (also drains every wave's stores: prep_select's write-through stores are out)
+    __syncthreads();                           // (also drains every wave's stores: prep_phase1's write-through stores are out)
     if (threadIdx.x == 0) {                    // no fence needed: the kernel boundary publishes the parameter writes
         const int ticket = atomicAdd(&state[8], 1);
         s_last = ticket == (int)gridDim.x - 1;
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
         }
     }
     if (next.enable == 2) {                    // two-phase prep, phase 2: by the last workgroup, from agent-scope loads of what phase 1 published
-        __syncthreads();
-        if (s_last) prep_body<256, true>(next.prep, part);
+        __syncthreads();                       // (run right after phase 1 instead, behind an agent-scope fence and a ticket of its own, the
+        if (s_last) prep_phase2<256>(next.prep, (int)gridDim.x, part, boff);     //  launch got longer: 32 -> 43 us at B = 8 192)
     }
 }
 
@@ -246,7 +247,7 @@ int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* sta
     static const int cap = getenv("DR4SR_ADAM_BLOCKS") ? atoi(getenv("DR4SR_ADAM_BLOCKS")) : 256;
     if (blocks > cap) blocks = cap;
     AdamNext nx;
-    nx.enable = next ? (next->B > 1024 && next->len_buf ? 2 : 1) : 0;
+    nx.enable = next ? (next->B > 1024 && next->len_buf && blocks <= PREP_MAX_BLK && (next->B + blocks - 1) / blocks < 65536 ? 2 : 1) : 0;
     if (next) nx.prep = *next; else nx.prep = PrepArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks + (nx.enable == 1 ? 1 : 0)), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx);
     return DR4SR_LAUNCH_CHECK();
