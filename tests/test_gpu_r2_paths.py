@@ -281,6 +281,9 @@ _SWITCH_CASES = [
      "or test_training_trajectory_matches_oracle or test_train_steps_equals_repeated_train_step"),
     # ... and the converse (never chosen by the hint, must still be right): latency tiles with the length-class attention lists
     ({"DR4SR_FORCE_SCALE": "0", "DR4SR_FORCE_ATTN_SPLIT": "1"}, "test_full_size_batch_vs_oracle or test_fuzz_odd_batches_vs_oracle"),
+    # two-phase next-step prep with FOUR optimizer workgroups: each owns 512 / 2 250 consecutive sequences, i.e. several 256-sequence
+    # rounds with carried totals inside one workgroup (256 workgroups own 8 / 36) — what B > 65 536 does with the default grid
+    ({"DR4SR_ADAM_BLOCKS": "4"}, "test_train_steps_equals_repeated_train_step"),
 ]
 
 
