@@ -1774,7 +1774,11 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     static const int gw_cap_env = getenv("DR4SR_WGRAD_GW_CAP") ? atoi(getenv("DR4SR_WGRAD_GW_CAP")) : 0;
     const int hint_tiles = p->expected_tokens > 0 ? (int)((p->expected_tokens < ws.Tmax ? p->expected_tokens : ws.Tmax) / 64) : 0;
     const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > 320 ? 320 : hint_tiles / 16) : 160);
-    int gw_t = ntiles / 16 > gw_max ? (ntiles / 16 > gw_cap ? gw_cap : ntiles / 16) : gw_max;   // >= 16 token tiles per workgroup at scale
+    // floor: 48 splits (36 real tiles at the toys B = 256 batch: one each), 64 once the batch is expected to hold >= 100 tiles
+    // (dense B = 256, 200 tiles: k_wgrad 49.4 -> 44.2 us; 80 splits: 44.8)
+    static const bool gw_env = getenv("DR4SR_WGRAD_GW") != nullptr;
+    const int gw_floor = !gw_env && hint_tiles >= 100 && gw_max < 64 ? 64 : gw_max;
+    int gw_t = ntiles / 16 > gw_floor ? (ntiles / 16 > gw_cap ? gw_cap : ntiles / 16) : gw_floor;   // >= 16 token tiles per workgroup at scale
     int gw = ntiles < gw_t ? ntiles : gw_t;
     A.sc_g = nullptr;
     const bool scatter = scatter_in_wgrad(ws) && with_score != 1;       // paired with launch_qkv_embed_bwd (not the unfused debug path)
