@@ -28,7 +28,7 @@ import ctypes as C  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PROFILE_ROUND = 2              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
+PROFILE_ROUND = 3              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
@@ -68,6 +68,161 @@ def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen, big=None):
         pairs = float((seqlen * (seqlen + 1) // 2).sum())
         return (2.0 if kind == "attn_fwd" else 5.0) * 2.0 * pairs * D      # QK^T + PV (fwd); +dP, dQ, dK, dV (bwd)
     return 0.0
+
+
+def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_last, seqlen_last, group, step_s, dev):
+    """per-kernel launch durations (HIP events on the launch stream, on the state the last step left in the workspace) of the fused
+    SASRec step -> out["roofline"] (dominant MFMA kernel), out["roofline_step"], out["kernel_us_per_step"].  mw: ctypes
+    dr4sr_meta_weighting for the MetaModel's weighted step (model/metamodel.py:174-194), else None."""
+    # whole-step MFMA roofline: algorithmic flops of ONE rank's step on the tokens it really holds (linear layers fwd + data
+    # grads + weight grads = 3 x, causal attention n(n+1)/2 pairs x {QK^T, PV} x 3.5 for fwd + bwd) over the measured step time
+    lin = 3.0 * NL * (2 * D * 3 * D + 2 * D * D + 4 * D * F) * float(seqlen_last.sum())
+    att = 3.5 * NL * 2 * 2 * D * float((seqlen_last.astype(np.float64) * (seqlen_last + 1) / 2).sum())
+    out["roofline_step"] = {"bound": "mfma", "achieved": (lin + att) / step_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": (lin + att) / step_s / 1e12 / MFMA_F32_PEAK_TF, "flops_per_step": lin + att,
+                            "note": "all kernels of the step, last batch's token count"}
+    # the launches dr4sr_sasrec_train_steps really enqueues per step (DESIGN.md §4): (kind, layer argument, launches / step).
+    # post_fwd / post_bwd at layer 0 are the fused forms (they carry layer 1's qkv projection / its backward); the last
+    # layer's post_fwd + scorer + post_bwd is ONE launch (post_mid).  In the latency regime (expected tokens of the plan
+    # <= ~10 k: dr4sr_sasrec_at_scale) the embedding-stage backward rides in the k_wgrad launch (`wgrad_fused`), at scale
+    # it is a launch of its own.
+    big = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 1)
+    launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1), ("attn_fwd", NL - 1, NL), ("post_fwd", 0, NL - 1),
+                ("post_mid", 0, 1), ("attn_bwd", NL - 1, NL), ("post_bwd", 0, NL - 1)]
+    launches += ([("qkv_embed_bwd", 0, 1)] if big else []) + [("wgrad_fused", 0, 1), ("adam", 0, 1)]
+    per_step_launches = {k: n for k, _, n in launches}
+    mwp = C.byref(mw) if mw is not None else None
+
+    def launch(kind, layer):
+        _lib.check(lib.dr4sr_sasrec_launch_kernel_weighted(C.byref(plan), mwp, _lib.KERNEL_IDS[kind], layer, _lib.cur_stream()), kind)
+    ktime = {}
+    reps = 50
+    for kind, layer, _ in launches:
+        for _ in range(5):
+            launch(kind, layer)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            launch(kind, layer)
+        b.record()
+        b.synchronize()
+        ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
+    step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
+    # the dominant kernel = the kind with the largest share of the step (attention: both layers' launches)
+    dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last, big) > 0), key=lambda k: step_us[k])
+    fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last, big)
+    ach = fl / (ktime[dom] * 1e-6) / 1e12
+    # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (tools/traffic_pmc.sh: FETCH_SIZE x2
+    # gfx950 correction + WRITE_SIZE, separate rocprofv3 runs); only for the workloads that were profiled
+    traffic = None
+    tag = {(256, False): "B256_toys", (8192, False): "B8192_toys", (8192, True): "B8192_dense"}.get((B, bool(args.dense)))
+    if mw is not None:
+        tag = None                                         # the PMC passes were taken on the plain step
+    traffic_src = None
+    for rnd in range(PROFILE_ROUND, 0, -1):
+        pj = os.path.join(ROOT, "profiles", "round%d_pmc_traffic_%s.json" % (rnd, tag)) if tag and D == 64 else None
+        if pj and os.path.exists(pj):
+            pm = json.load(open(pj))
+            prefix = {"attn_fwd": "k_attn", "attn_bwd": "k_attn", "post_fwd": "k_post_fwd", "post_bwd": "k_post_bwd",
+                      "post_mid": "k_post_mid", "wgrad_fused": "k_wgrad", "embqkv_fwd": "k_embqkv_fwd",
+                      "qkv_embed_bwd": "k_qkv_embed_bwd"}[dom]
+            want_bwd = dom == "attn_bwd"
+
+            def is_bwd(k):                     # k_attn2_bwd<...> / k_attn_tiny<DH, true>
+                return "_bwd" in k or (k.startswith("k_attn_tiny") and k.rstrip(">").endswith("true"))
+            hits = [v["hbm_bytes_per_launch"] for k, v in pm.items()
+                    if k.startswith(prefix) and (not dom.startswith("attn") or is_bwd(k) == want_bwd)]
+            if hits:
+                traffic, traffic_src = float(sum(hits)), os.path.relpath(pj, ROOT)
+                break
+    # `traffic` is NOT measured by this run: rocprofv3 --pmc passes cannot run inside the bench; it is the per-launch HBM
+    # byte count of the same kernel on the same workload from the committed PMC profile named in `traffic_source`
+    out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
+                       "us_per_launch": ktime[dom], "flops_per_launch": fl}
+    # the ragged layout leaves the attention kernels far below the MFMA ridge (157.3 TF / 8 TB/s = 19.7 flop/B): also report
+    # the kernel against the sloped part of the roofline, min(MFMA peak, intensity x HBM peak), from its algorithmic bytes
+    # (forward: q, k, v in + ctx out; backward: q, k, v, dctx in + dq, dk, dv out; 4*D bytes per token each)
+    arrays = {"attn_fwd": 4, "attn_bwd": 7}.get(dom)
+    if arrays:
+        ab = float(arrays * T_last * D * 4)
+        ceil_tf = min(MFMA_F32_PEAK_TF, fl / ab * HBM_PEAK_GBS / 1e3)
+        out["roofline"].update({"algorithmic_bytes_per_launch": ab, "flop_per_byte": fl / ab, "ceiling_at_intensity": ceil_tf,
+                                "frac_of_ceiling": ach / ceil_tf,
+                                "hbm_rate": ab / (ktime[dom] * 1e-6) / 1e9, "hbm_frac": ab / (ktime[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS})
+    out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
+    return ktime
+
+
+def gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, Hh, NLg, step_s):
+    """GRU4Rec (model/gru4rec.py:12-34, module/layers.py:117-136): launch durations of the recurrence kernels (the dominant launches of
+    the step: the cooperative multi-CU recurrence at B <= 1536, the single-workgroup one above) by HIP events on the launch stream ->
+    out["roofline"] on the recurrent GEMM's algorithmic flops over the valid tokens (gh = h W_hh^T: 2*3H*H per token forward,
+    dh = dgh W_hh the same backward), out["roofline_step"] on SURVEY §8(d)'s 3 x (gi + gh + out projection) per valid token."""
+    def launch(kid, layer):
+        _lib.check(lib.dr4sr_gru4rec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), "gru4rec_launch_kernel")
+    ktime = {}
+    reps = 20
+    for name, kid in (("rec_fwd", 0), ("rec_bwd", 1), ("gemm_in", 2)):
+        tot = 0.0
+        for layer in range(NLg):
+            for _ in range(3):
+                launch(kid, layer)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                launch(kid, layer)
+            b.record()
+            b.synchronize()
+            tot += a.elapsed_time(b) * 1e3 / reps
+        ktime[name] = tot / NLg                              # us per launch, mean over the layers
+    dom = "rec_bwd" if ktime["rec_bwd"] >= ktime["rec_fwd"] else "rec_fwd"
+    fl = 2.0 * T_last * 3 * Hh * Hh
+    ach = fl / (ktime[dom] * 1e-6) / 1e12
+    coop = bool(lib.dr4sr_gru4rec_uses_cooperative(int(plan.B), Hh))
+    out["roofline"] = {"kernel": ("k_gru_%s_coop" if coop else "k_gru_%s") % ("bwd" if dom == "rec_bwd" else "fwd"), "bound": "mfma",
+                       "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                       "traffic_source": None, "us_per_launch": ktime[dom], "flops_per_launch": fl, "launches_per_step": NLg,
+                       "note": "recurrent GEMM of one layer on the valid tokens; the launch is a chain of max(seqlen) dependent "
+                               "time steps (latency-bound, SURVEY §8d), not an MFMA-throughput kernel"}
+    per_tok = 3.0 * (2 * 3 * Hh * D + (NLg - 1) * 2 * 3 * Hh * Hh + NLg * 2 * 3 * Hh * Hh + 2 * Hh * D)
+    out["roofline_step"] = {"bound": "mfma", "achieved": per_tok * T_last / step_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": per_tok * T_last / step_s / 1e12 / MFMA_F32_PEAK_TF, "flops_per_step": per_tok * T_last,
+                            "note": "3 x (input GEMMs + recurrent GEMMs + output projection) on the last batch's valid tokens"}
+    out["kernel_us_per_step"] = {k: round(v * NLg, 2) for k, v in ktime.items()}
+
+
+def cpu_baseline_leg(rows_np, N, model_kind, p, interval=30):
+    """the reference-equivalent CPU step (oracle/ref_trainer.py) on this box's host cores.  torch's default (all
+    cores) is the slowest choice for these microsecond-sized ops on a 128-core host, so 8 / 16 / 32 intra-op threads are probed and
+    the best is timed with anomaly detection ON (utils/utils.py:11 sets it globally — the reference's real configuration, reported as
+    `value`) and OFF as the second column."""
+    from oracle.ref_trainer import time_training
+    quick = model_kind == "sasrec"
+    kw = {"p": p, "model_kind": model_kind, "interval": interval}
+    probes = {}
+    for th in (8, 16, 32):
+        if th <= (os.cpu_count() or 1):
+            probes[th] = time_training(rows_np, N, batch_size=256, warmup=2 if quick else 1, max_steps=6 if quick else 3, max_seconds=6.0,
+                                       anomaly=True, threads=th, **kw)["seq_per_s"]
+    best = max(probes, key=probes.get) if probes else None
+    # MetaModel: the timed window must hold whole outer-loop periods (one Hypergrad.grad per `interval` steps)
+    steps_on = 50 if quick else (2 * interval if model_kind == "metamodel" else 20)
+    r = time_training(rows_np, N, batch_size=256, warmup=3 if quick else 1, max_steps=steps_on, max_seconds=40.0, anomaly=True, threads=best, **kw)
+    r_off = time_training(rows_np, N, batch_size=256, warmup=3 if quick else 1, max_steps=30 if quick else (interval if model_kind == "metamodel" else 10),
+                          max_seconds=15.0, anomaly=False, threads=best, **kw)
+    what = {"sasrec": "nn.TransformerEncoder, multinomial sampler, per-sample DataLoader, Adam",
+            "gru4rec": "torch.nn.GRU(bias=False, 2 x 256) behind Dropout(0.2), multinomial sampler, per-sample DataLoader, Adam(weight_decay 1e-4) "
+                       "(model/gru4rec.py:12-34, module/layers.py:117-136)",
+            "metamodel": "SASRec sub-model + gumbel-softmax selection MLP weighting every step, Hypergrad.grad (double backward, 3 Neumann terms) "
+                         "+ clip + SGD every %d steps (model/metamodel.py:95-194, utils/utils.py:134-252); %d outer steps fell into the window"
+                         % (interval, r.get("outer_steps", 0))}[model_kind]
+    return {"value": r["seq_per_s"], "unit": "sequences/s", "cores": r["threads"], "kind": "port",
+            "anomaly_off_value": r_off["seq_per_s"], "thread_probe_seq_per_s": {str(k): v for k, v in probes.items()},
+            "sample": "%d steps of B=256 (%.1f s) of oracle/ref_trainer.py: the reference's torch op sequence (%s) on the same synthetic "
+                      "rows, anomaly detection ON as utils/utils.py:11 (`anomaly_off_value`: %d steps with it off); %d intra-op threads = "
+                      "the best of a 8/16/32 probe; host has %d logical CPUs"
+                      % (r["steps"], r["seconds"], what, r_off["steps"], r["threads"], os.cpu_count() or 0)}
 
 
 def bench_metamodel(args):
@@ -158,9 +313,33 @@ def bench_metamodel(args):
         tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax)
+    extra = {}
+    if rank == 0 and fused:
+        # roofline of the weighted inner step's dominant kernel, measured live: the launches of dr4sr_sasrec_fwd_bwd_weighted re-enqueued
+        # one by one on the state the last hyper-gradient probe left in the workspace (batch bt), HIP events on the launch stream
+        from dr4sr_amd import _lib
+        eng = model.engine
+        plan = model.sub_model._batch_plan(bt)
+        mw = _lib.MetaWeighting()
+        mw.phi = model._phi.params.data_ptr()
+        uid = bt["user_id"].contiguous()
+        mw.user_id = uid.data_ptr()
+        mw.tau = model._tau_eff()
+        model._fused_weighted(bt)
+        torch.cuda.synchronize()
+        sl = bt["seqlen"].clamp(0, eng.L).cpu().numpy()
+        sasrec_kernel_rooflines(eng.lib, _lib, plan, mw, extra, args, int(sl.shape[0]), eng.L, eng.D, eng.F, eng.n_layer, int(sl.sum()), sl,
+                                int(cfg["train"].get("steps_per_graph", 16)), wall / args.steps, dev)
+        extra["roofline_step"]["note"] = ("inner weighted step's flops only (the outer loop's 7 forward+backward and 2 forward evaluations "
+                                          "every %d steps are in the time, not in the flops)" % args.interval)
+        if not args.no_cpu_baseline and world == 1:
+            from dr4sr_amd.data.synthetic import make_rows
+            rows_np = make_rows(n_items=eng.n_items, seed=2024, dense=args.dense)
+            extra["cpu_baseline"] = cpu_baseline_leg(rows_np, eng.n_items, "metamodel", args.dropout, interval=args.interval)
     if rank == 0:
         B = args.batch
         print(json.dumps({
+            **extra,
             "metric": "training sequences/sec, MetaModel(SASRec) d=64 L=50", "value": world * B * args.steps / wall,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -418,19 +597,27 @@ def main():
                             else:
                                 eng.adam_step(plan)
                     return g
+                ok = 1
                 try:
                     g_all = capture_dp(group)
                     g_one = capture_dp(1) if group > 1 else g_all
-
+                except Exception as e:      # noqa: BLE001
+                    print("bench.py: in-graph all-reduce capture failed on rank %d (%s: %s); host-launched collective instead"
+                          % (rank, type(e).__name__, e), file=sys.stderr)
+                    ok = 0
+                # every rank takes the same form: a capture that failed on ANY rank sends all of them to the host-launched collective
+                # (ranks mixing in-graph and host-launched collectives would deadlock the communicator)
+                flag = torch.tensor([float(ok)], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                stream.synchronize()
+                if float(flag) >= 1.0:
                     def run_steps(n):
                         for _ in range(n // group):
                             g_all.replay()
                         for _ in range(n % group):
                             g_one.replay()
                     collective = "rccl all-reduce captured in the step graph (%d steps per graph)" % group
-                except Exception as e:      # noqa: BLE001
-                    print("bench.py: in-graph all-reduce capture failed (%s: %s); host-launched collective instead" % (type(e).__name__, e),
-                          file=sys.stderr)
+                else:
                     run_steps, group = None, 1
             if run_steps is None and use_graph and dp and args.model == "sasrec" and B <= 1024:
                 # two graphs around a host-launched all-reduce; the optimizer graph also prepares the next batch, so only the first
@@ -486,10 +673,28 @@ def main():
                 dist.barrier()
             wall = time.perf_counter() - t0
             gpu_ms = e0.elapsed_time(e1)
+            per_rank_ms, coll_us = None, None
             if dp:
+                # this rank's own GPU time per step (events); gloo (shared-GPU functional runs) gathers host tensors only
+                mine = torch.tensor([gpu_ms / steps], device=dev if parallel.can_capture() else "cpu", dtype=torch.float64)
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                per_rank_ms = [round(float(x), 5) for x in allr]
                 tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 wall = float(tmax)
+                # the collective alone: the same flat buffer all-reduced back to back, HIP events around the host-launched form
+                # (every rank enters the same count; the gradient buffer is garbage afterwards — nothing reads it before the next step)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(3):
+                    reduce_grads()
+                ea.record()
+                for _ in range(20):
+                    reduce_grads()
+                eb.record()
+                eb.synchronize()
+                coll_us = ea.elapsed_time(eb) * 1e3 / 20
+                eng.grads.zero_()
             loss, nvalid = eng.loss_and_count()
             T_last = int(eng.state[_lib.STATE_T])
             model_desc = {"sasrec": ("SASRec on yelp-sized synthetic rows (BASELINE configs[3] shape): N=20034, L=50, d=128, 2 layers, 2 heads, "
@@ -513,84 +718,17 @@ def main():
                            "hip_graph": bool(use_graph), "steps_per_graph": group, "collective": collective},
                 "gpu_ms_per_step_events": gpu_ms / steps, "final_loss": loss, "valid_tokens_last_step": T_last,
             }
+            if dp:
+                out["per_rank_gpu_ms_per_step"] = per_rank_ms
+                out["allreduce_us_standalone"] = coll_us
+                out["allreduce_bytes"] = int(eng.grads.numel()) * 4
 
+            if rank == 0 and args.model == "gru4rec" and extras:
+                gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, 256, 2, wall / steps)
             if rank == 0 and args.model == "sasrec" and extras:
                 # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
                 seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
-                # whole-step MFMA roofline: algorithmic flops of ONE rank's step on the tokens it really holds (linear layers fwd + data
-                # grads + weight grads = 3 x, causal attention n(n+1)/2 pairs x {QK^T, PV} x 3.5 for fwd + bwd) over the measured step time
-                lin = 3.0 * NL * (2 * D * 3 * D + 2 * D * D + 4 * D * F) * float(seqlen_last.sum())
-                att = 3.5 * NL * 2 * 2 * D * float((seqlen_last.astype(np.float64) * (seqlen_last + 1) / 2).sum())
-                step_s = wall / steps
-                out["roofline_step"] = {"bound": "mfma", "achieved": (lin + att) / step_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                        "frac": (lin + att) / step_s / 1e12 / MFMA_F32_PEAK_TF, "flops_per_step": lin + att,
-                                        "note": "all kernels of the step, last batch's token count"}
-                # the launches dr4sr_sasrec_train_steps really enqueues per step: (kind, layer argument, launches / step).
-                # post_fwd / post_bwd at layer 0 are the fused forms (they carry layer 1's qkv projection / its backward); the last
-                # layer's post_fwd + scorer + post_bwd is ONE launch (post_mid).  In the latency regime (expected tokens of the plan
-                # <= ~10 k: dr4sr_sasrec_at_scale) the embedding-stage backward rides in the k_wgrad launch (`wgrad_fused`), at scale
-                # it is a launch of its own.
-                big = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 1)
-                launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1), ("attn_fwd", NL - 1, NL), ("post_fwd", 0, NL - 1),
-                            ("post_mid", 0, 1), ("attn_bwd", NL - 1, NL), ("post_bwd", 0, NL - 1)]
-                launches += ([("qkv_embed_bwd", 0, 1)] if big else []) + [("wgrad_fused", 0, 1), ("adam", 0, 1)]
-                per_step_launches = {k: n for k, _, n in launches}
-                ktime = {}
-                reps = 50
-                for kind, layer, _ in launches:
-                    kid = _lib.KERNEL_IDS[kind]
-                    for _ in range(5):
-                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), kind)
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    for _ in range(reps):
-                        _lib.check(lib.dr4sr_sasrec_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), kind)
-                    b.record()
-                    b.synchronize()
-                    ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
-                step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
-                # the dominant kernel = the kind with the largest share of the step (attention: both layers' launches)
-                dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last, big) > 0), key=lambda k: step_us[k])
-                fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last, big)
-                ach = fl / (ktime[dom] * 1e-6) / 1e12
-                # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (tools/traffic_pmc.sh: FETCH_SIZE x2
-                # gfx950 correction + WRITE_SIZE, separate rocprofv3 runs); only for the workloads that were profiled
-                traffic = None
-                tag = {(256, False): "B256_toys", (8192, False): "B8192_toys", (8192, True): "B8192_dense"}.get((B, bool(args.dense)))
-                traffic_src = None
-                for rnd in (PROFILE_ROUND, PROFILE_ROUND - 1):
-                    pj = os.path.join(ROOT, "profiles", "round%d_pmc_traffic_%s.json" % (rnd, tag)) if tag and D == 64 else None
-                    if pj and os.path.exists(pj):
-                        pm = json.load(open(pj))
-                        prefix = {"attn_fwd": "k_attn", "attn_bwd": "k_attn", "post_fwd": "k_post_fwd", "post_bwd": "k_post_bwd",
-                                  "post_mid": "k_post_mid", "wgrad_fused": "k_wgrad", "embqkv_fwd": "k_embqkv_fwd",
-                                  "qkv_embed_bwd": "k_qkv_embed_bwd"}[dom]
-                        want_bwd = dom == "attn_bwd"
-
-                        def is_bwd(k):                     # k_attn2_bwd<...> / k_attn_tiny<DH, true>
-                            return "_bwd" in k or (k.startswith("k_attn_tiny") and k.rstrip(">").endswith("true"))
-                        hits = [v["hbm_bytes_per_launch"] for k, v in pm.items()
-                                if k.startswith(prefix) and (not dom.startswith("attn") or is_bwd(k) == want_bwd)]
-                        if hits:
-                            traffic, traffic_src = float(sum(hits)), os.path.relpath(pj, ROOT)
-                            break
-                # `traffic` is NOT measured by this run: rocprofv3 --pmc passes cannot run inside the bench; it is the per-launch HBM
-                # byte count of the same kernel on the same workload from the committed PMC profile named in `traffic_source`
-                out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
-                                   "us_per_launch": ktime[dom], "flops_per_launch": fl}
-                # the ragged layout leaves the attention kernels far below the MFMA ridge (157.3 TF / 8 TB/s = 19.7 flop/B): also report
-                # the kernel against the sloped part of the roofline, min(MFMA peak, intensity x HBM peak), from its algorithmic bytes
-                # (forward: q, k, v in + ctx out; backward: q, k, v, dctx in + dq, dk, dv out; 4*D bytes per token each)
-                arrays = {"attn_fwd": 4, "attn_bwd": 7}.get(dom)
-                if arrays:
-                    ab = float(arrays * T_last * D * 4)
-                    ceil_tf = min(MFMA_F32_PEAK_TF, fl / ab * HBM_PEAK_GBS / 1e3)
-                    out["roofline"].update({"algorithmic_bytes_per_launch": ab, "flop_per_byte": fl / ab, "ceiling_at_intensity": ceil_tf,
-                                            "frac_of_ceiling": ach / ceil_tf,
-                                            "hbm_rate": ab / (ktime[dom] * 1e-6) / 1e9, "hbm_frac": ab / (ktime[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS})
-                out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
-
+                ktime = sasrec_kernel_rooflines(lib, _lib, plan, None, out, args, B, L, D, F, NL, T_last, seqlen_last, group, wall / steps, dev)
                 if extras != "full":
                     return out, rows_np, N
                 # ---- K1 gather microbench (HBM roofline of the embedding gather): large launch
@@ -619,7 +757,7 @@ def main():
                 hbm_bytes = Bg * L * (8 + 4 * D)
                 rate = hbm_bytes / 1e9 / (us * 1e-6)
                 traffic, traffic_src = None, None   # HBM bytes per launch from the PMC passes kept under profiles/ (separate runs)
-                for rnd in (PROFILE_ROUND, PROFILE_ROUND - 1):
+                for rnd in range(PROFILE_ROUND, 0, -1):
                     pj = os.path.join(ROOT, "profiles", "round%d_gather_pmc.json" % rnd)
                     if os.path.exists(pj) and D == 64:          # the PMC passes were taken on the d=64 kernel
                         pm = json.load(open(pj))
@@ -693,33 +831,14 @@ def main():
             strong.append({"global_batch": G, "per_gpu_batch": G // world, "n_gpus": world, "value": st_n["value"], "unit": "sequences/s",
                            "ms_per_step": st_n["ms_per_step"], "single_gpu_value": one["value"], "single_gpu_ms_per_step": one["ms_per_step"],
                            "speedup": st_n["value"] / one["value"], "efficiency": st_n["value"] / one["value"] / world,
-                           "collective": st_n["config"].get("collective")})
+                           "collective": st_n["config"].get("collective"),
+                           "per_rank_gpu_ms_per_step": st_n.get("per_rank_gpu_ms_per_step"),
+                           "allreduce_us_standalone": st_n.get("allreduce_us_standalone")})
         if rank == 0:
             out["strong"] = strong
     if rank == 0:
-        if not dp and not args.no_cpu_baseline and args.model == "sasrec":
-            # the reference-equivalent CPU step on this box's host cores.  torch's default (all cores) is the
-            # slowest choice for these microsecond-sized ops on a 128-core host, so 8 / 16 / 32 intra-op threads are probed
-            # (6 steps each) and the best is timed: >= 50 steps with anomaly detection ON (utils/utils.py:11 sets it globally — the
-            # reference's real configuration, reported as `value`) and 30 steps with it OFF as the second column.
-            from oracle.ref_trainer import time_training
-            probes = {}
-            for th in (8, 16, 32):
-                if th <= (os.cpu_count() or 1):
-                    probes[th] = time_training(rows_np, N, batch_size=256, warmup=2, max_steps=6, max_seconds=6.0, anomaly=True,
-                                               p=args.dropout, threads=th)["seq_per_s"]
-            best = max(probes, key=probes.get) if probes else None
-            r = time_training(rows_np, N, batch_size=256, warmup=3, max_steps=50, max_seconds=40.0, anomaly=True, p=args.dropout, threads=best)
-            r_off = time_training(rows_np, N, batch_size=256, warmup=3, max_steps=30, max_seconds=15.0, anomaly=False, p=args.dropout,
-                                  threads=best)
-            out["cpu_baseline"] = {"value": r["seq_per_s"], "unit": "sequences/s", "cores": r["threads"], "kind": "port",
-                                   "anomaly_off_value": r_off["seq_per_s"], "thread_probe_seq_per_s": {str(k): v for k, v in probes.items()},
-                                   "sample": "%d steps of B=256 (%.1f s) of oracle/ref_trainer.py: the reference's torch op "
-                                             "sequence (nn.TransformerEncoder, multinomial sampler, per-sample DataLoader, "
-                                             "Adam) on the same synthetic rows, anomaly detection ON as utils/utils.py:11 "
-                                             "(`anomaly_off_value`: %d steps with it off); %d intra-op threads = the best of a "
-                                             "8/16/32 probe; host has %d logical CPUs"
-                                             % (r["steps"], r["seconds"], r_off["steps"], r["threads"], os.cpu_count() or 0)}
+        if not dp and not args.no_cpu_baseline and args.model in ("sasrec", "gru4rec"):
+            out["cpu_baseline"] = cpu_baseline_leg(rows_np, N, args.model, 0.2 if args.model == "gru4rec" else args.dropout)
         print(json.dumps(out))
     if dp:
         dist.destroy_process_group()

@@ -96,7 +96,7 @@ _PLANP = C.POINTER(SasrecPlan)
 _FPLANP = C.POINTER(FmlpPlan)
 _GPLANP = C.POINTER(GruPlan)
 
-# name -> (restype, argtypes); every symbol include/dr4sr_hip.h declares
+# name -> (restype, argtypes); every symbol include/dr4sr_hip.h and include/dr4sr_hip_hooks.h (test / measurement hooks) declare
 SYMBOLS = {
     "dr4sr_abi_version": (C.c_int, []),
     "dr4sr_sasrec_plan_sizeof": (C.c_int, []),
@@ -141,6 +141,8 @@ SYMBOLS = {
     "dr4sr_gru4rec_encode_bwd": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_adam_flat": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_sasrec_launch_kernel_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_gru4rec_launch_kernel": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_meta_param_count": (C.c_int64, [C.c_int32]),
     "dr4sr_meta_select_workspace_floats": (C.c_int64, [C.c_int64]),
     "dr4sr_meta_select_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,

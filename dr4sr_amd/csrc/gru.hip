@@ -611,3 +611,27 @@ extern "C" int dr4sr_gru4rec_encode_bwd(const dr4sr_gru4rec_plan* plan, int32_t 
     RC(launch_pack_raw(d_out, ws.cu, ws.dY, plan->B, plan->L, plan->D, pooling == DR4SR_POOL_LAST, s));
     return gru_backward(plan, ws, training, 0, s);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Measurement hook (bench.py, include/dr4sr_hip_hooks.h): enqueue ONE kernel of the GRU4Rec step on the state the last fwd_bwd left
+// in the workspace, so that its launch duration can be bracketed with HIP events on the caller's stream.
+extern "C" int dr4sr_gru4rec_launch_kernel(const dr4sr_gru4rec_plan* plan, int32_t kernel, int32_t layer, void* stream) {
+    GruWs ws;
+    RC(gru_ws(plan, &ws));
+    if (layer < 0 || layer >= plan->n_layer) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = plan->D, H = plan->H;
+    const GruLayerWs& w = ws.layer[layer];
+    GruRecArgs A{};
+    A.whh = plan->params + ws.off_whh[layer]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn; A.hprev = w.hprev; A.B = plan->B;
+    switch (kernel) {
+        case DR4SR_GK_REC_FWD: A.gi = w.gi; A.hout = w.hout; return launch_gru_rec(A, H, false, s, ws.xch, ws.ctl);
+        case DR4SR_GK_REC_BWD: A.dhout = ws.dH; A.dgi = w.dgi; A.dgh = w.dgh; return launch_gru_rec(A, H, true, s, ws.xch, ws.ctl);
+        case DR4SR_GK_GEMM_IN: {
+            const float* in = layer == 0 ? ws.X0 : ws.layer[layer - 1].hout;
+            const int K = layer == 0 ? D : H;
+            return launch_gemm(in, K, plan->params + ws.off_wih[layer], K, nullptr, w.gi, 3 * H, K, 3 * H, false, ws.Tmax, plan->state, s);
+        }
+        default: return DR4SR_E_ARG;
+    }
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/dr4sr_hip.h"
+#include "../../include/dr4sr_hip_hooks.h"
 #include "prep_body.h"
 
 #define DR4SR_MAX_LAYERS 8

@@ -224,7 +224,12 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
         }
     }
     __shared__ int s_last;
-    __syncthreads();                           // (also drains every wave's stores: prep_phase1's write-through stores are out)
+    // two-phase prep: phase 1's words were published with agent-scope (sc1, write-through) stores and phase 2 reads them with
+    // agent-scope loads in the LAST workgroup.  The hand-off is the guide's "sc1 payload -> vmcnt(0) -> flag" form: every wave drains
+    // its own stores EXPLICITLY before the barrier in front of the ticket (inline asm: the compiler cannot drop it, and the barrier
+    // alone is not required to drain vmcnt) — no L2 write-back fence, which would cost the launch ~6 us.
+    if (next.enable == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {                    // no fence needed: the kernel boundary publishes the parameter writes
         const int ticket = atomicAdd(&state[8], 1);
         s_last = ticket == (int)gridDim.x - 1;
@@ -431,6 +436,10 @@ extern "C" int dr4sr_sasrec_encode_bwd(const dr4sr_sasrec_plan* plan, int32_t tr
 // Measurement hook (bench.py / profiles): enqueue ONE kernel of the step so that its launch duration can
 // be bracketed with HIP events on the caller's stream.  Uses whatever the last fwd_bwd left in the workspace.
 extern "C" int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, int32_t layer, void* stream) {
+    return dr4sr_sasrec_launch_kernel_weighted(plan, nullptr, kernel, layer, stream);
+}
+extern "C" int dr4sr_sasrec_launch_kernel_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, int32_t kernel,
+                                                   int32_t layer, void* stream) {
     Workspace ws;
     RC(get_ws(plan, &ws));
     if (layer < 0 || layer >= plan->n_layer) return DR4SR_E_ARG;
@@ -452,7 +461,7 @@ extern "C" int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t
         case DR4SR_K_ZERO_GRADS: return launch_zero_grads(plan, ws.n_params, s);
         // the launches of the FUSED step (what dr4sr_sasrec_train_step really enqueues)
         case DR4SR_K_EMBQKV_FWD: return launch_embqkv_fwd(plan, ws, 1, s);
-        case DR4SR_K_POST_MID: return launch_post_mid(plan, ws, 1, s);
+        case DR4SR_K_POST_MID: return launch_post_mid(plan, ws, 1, s, mw);
         case DR4SR_K_QKV_EMBED_BWD: return launch_qkv_embed_bwd(plan, ws, 1, s);
         case DR4SR_K_WGRAD_FUSED: return launch_wgrad(plan, ws, 1, 2, s, true);
         default: return DR4SR_E_ARG;

@@ -96,7 +96,8 @@ class SasrecEngine:
         self._keep = []          # tensors referenced by the last plan
 
     # ------------------------------------------------------------------------------------------
-    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True, perm_sel=None, slot=0, loss_log=None):
+    def _plan(self, B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, with_ws=True, perm_sel=None, slot=0, loss_log=None,
+              expected_tokens=None):
         p = _lib.SasrecPlan()
         p.abi_version = _lib.ABI_VERSION
         p.B, p.L, p.D, p.H, p.F, p.n_layer, p.n_items = B, self.L, self.D, self.H, self.F, self.n_layer, self.n_items
@@ -125,33 +126,48 @@ class SasrecEngine:
         if loss_log is not None:           # float32 device buffer: the step's mean loss lands at [batch index] (see dr4sr_hip.h)
             assert loss_log.dtype == torch.float32
             p.loss_log = loss_log.data_ptr()
-        p.expected_tokens = self._expected_tokens(B, seqlen, rows is not None)
+        p.expected_tokens = int(expected_tokens) if expected_tokens is not None else self._expected_tokens(B, seqlen, rows is not None)
         self._keep = [in_item_id, item_id, seqlen, rows, neg_item, perm_sel, loss_log]
         return p
 
     def _expected_tokens(self, B, seqlen, dataset_tensor: bool) -> int:
-        """regime hint of the plan (include/dr4sr_hip.h: expected_tokens) = B * mean(min(seqlen, L)).  Dataset tensors (batches are
-        rows[] of them): one device reduction + host read per tensor, cached.  Per-batch tensors (API path): `self.mean_len` when the
-        model set it from its training split (no synchronisation per step), else measured — except inside a graph capture, where an
-        unknown tensor leaves the hint at 0 = capacity rule."""
+        """regime hint of the plan (include/dr4sr_hip.h: expected_tokens) = B * mean(min(seqlen, L)) when the caller gave none.
+        Dataset tensors (batches are rows[] of them; they live as long as the dataset): one device reduction + host read per
+        tensor, cached by (address, length, a checksum-free generation = the tensor's _version).  Per-batch tensors are transient —
+        the allocator re-uses their memory for batches of other lengths, so they are NEVER cached: `self.mean_len` (the training
+        split's mean, set by the model) when known, else measured (one synchronisation; not possible inside a graph capture, where
+        the hint stays 0 = capacity rule and a warning says so once)."""
         if seqlen is None:
             return 0
-        key = (seqlen.data_ptr(), int(seqlen.shape[0]))
-        mean = self._mean_len.get(key)
-        if mean is None and not dataset_tensor and self.mean_len is not None:
+        if dataset_tensor:
+            key = (seqlen.data_ptr(), int(seqlen.shape[0]), int(seqlen._version))
+            mean = self._mean_len.get(key)
+            if mean is None:
+                if torch.cuda.is_current_stream_capturing():
+                    return 0
+                mean = float(seqlen.clamp(0, self.L).float().mean()) if seqlen.numel() else 0.0
+                if len(self._mean_len) > 64:
+                    self._mean_len.clear()
+                self._mean_len[key] = mean
+        elif self.mean_len is not None:
             mean = self.mean_len
-        elif mean is None:
-            if torch.cuda.is_current_stream_capturing():
-                return 0
+        elif torch.cuda.is_current_stream_capturing():
+            if not getattr(self, "_warned_no_hint", False):
+                self._warned_no_hint = True
+                import logging
+                logging.getLogger("CDR").warning("dr4sr_amd: no expected_tokens hint for a per-batch plan inside a graph capture "
+                                                 "(engine.mean_len unset): launch forms follow the capacity rule")
+            return 0
+        else:
             mean = float(seqlen.clamp(0, self.L).float().mean()) if seqlen.numel() else 0.0
-            if len(self._mean_len) > 64:
-                self._mean_len.clear()
-            self._mean_len[key] = mean
         return max(1, int(B * mean))
 
-    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None, slot=0, loss_log=None):
+    def make_plan(self, in_item_id, item_id, seqlen, rows=None, neg_item=None, sample_neg=None, perm_sel=None, slot=0, loss_log=None,
+                  expected_tokens=None):
         """rows=None: the tensors ARE the batch ([B,L]/[B]); else they are dataset tensors indexed by rows[B].
-        perm_sel: fused device-side batch selection (include/dr4sr_hip.h: dr4sr_sasrec_plan.perm)."""
+        perm_sel: fused device-side batch selection (include/dr4sr_hip.h: dr4sr_sasrec_plan.perm).
+        expected_tokens: the regime hint, when the caller knows the batch's valid-token count better than the engine's default
+        (eval split, augmented views: CL4SRec's crops are much shorter than the training rows)."""
         B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
         if B > self.max_batch:
             raise _lib.Dr4srError(f"batch {B} > max_batch {self.max_batch}")
@@ -167,7 +183,8 @@ class SasrecEngine:
             sample_neg = neg_item is None
         if neg_item is None:
             neg_item = self.neg_scratch
-        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, perm_sel=perm_sel, slot=slot, loss_log=loss_log)
+        return self._plan(B, in_item_id, item_id, seqlen, rows, neg_item, sample_neg, perm_sel=perm_sel, slot=slot, loss_log=loss_log,
+                          expected_tokens=expected_tokens)
 
     # ------------------------------------------------------------------------------------------
     def fwd_bwd(self, plan):

@@ -270,12 +270,24 @@ class BaseModel(nn.Module):
     # ------------------------------------------------------------------------------------------ fast path (fused HIP graph per batch)
     _supports_perm_sel = False
 
-    def _step_graph(self, fields, bl, perm_sel=None, group=1, loss_log=None):
+    def _dp_in_graph(self) -> bool:
+        """Data parallel: capture the RCCL all-reduce INSIDE the k-step graph?  Opt-in (`train.dp_graph_allreduce: true` or
+        DR4SR_DP_GRAPH_ALLREDUCE=1): the default is the host-launched collective between two graphs, the form every multi-rank test
+        covers — the in-graph form has only ever run with one RCCL rank (a 1-GPU box cannot host two), so it is not the default
+        until a multi-GPU run has covered it.  DR4SR_DP_HOST_ALLREDUCE forces the host form."""
+        if os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
+            return False
+        on = bool(self.config["train"].get("dp_graph_allreduce", False)) or bool(os.environ.get("DR4SR_DP_GRAPH_ALLREDUCE"))
+        return on and parallel.can_capture()
+
+    def _step_graph(self, fields, bl, perm_sel=None, group=1, loss_log=None, in_graph=False):
         """captured HIP graph(s) for a local batch of `bl` rows addressed through self._rows_buf[:bl]; with perm_sel =
         (perm, global batch, rank offset, counter) the rows are selected on the device by the step's first kernel, which makes
-        consecutive steps host-free: `group` whole steps go into ONE graph and each writes its mean loss to loss_log[batch index]"""
+        consecutive steps host-free: `group` whole steps go into ONE graph and each writes its mean loss to loss_log[batch index].
+        in_graph (data parallel only): the caller decided — from GLOBAL quantities, so every rank decides alike — that this step's
+        collective is captured inside the graph."""
         key = (fields["in_item_id"].data_ptr(), bl, group, None if loss_log is None else loss_log.data_ptr(),
-               None if perm_sel is None else (perm_sel[0].data_ptr(), perm_sel[1], perm_sel[2]))
+               None if perm_sel is None else (perm_sel[0].data_ptr(), perm_sel[1], perm_sel[2]), bool(in_graph))
         if key in self._graphs:
             return self._graphs[key]
         eng = self.engine
@@ -308,10 +320,13 @@ class BaseModel(nn.Module):
             else:
                 run = eager
         else:
-            # Data parallel: the sum-all-reduce of the flat gradient sits between backward and optimizer.  With RCCL it is captured
-            # INSIDE the step graph (no host work between the two halves, `group` whole steps per replay, the optimizer launch of
-            # step j preparing step j+1 exactly as on one GPU); a transport that cannot be captured (gloo checks on one GPU) or a
-            # failed capture falls back to two graphs around a host-launched collective.
+            # Data parallel: the sum-all-reduce of the flat gradient sits between backward and optimizer.
+            #   default      two graphs (backward | optimizer) around a HOST-launched collective, `group` times per call;
+            #   in_graph     (opt-in, RCCL) the collective captured inside ONE graph of `group` whole steps — no host work between
+            #                backward, collective and optimizer, the optimizer launch of step j preparing step j+1 as on one GPU.
+            # Every rank takes the same form for the same global batch: `in_graph` and `group` come from global quantities
+            # (_fused_epoch), and a capture that fails on ANY rank sends ALL ranks to the host form (the success flag is reduced
+            # with MIN before the form is chosen — mixing in-graph and host-launched collectives would deadlock the communicator).
             has_prep = perm_sel is not None and hasattr(eng, "fwd_bwd_prepared") and bl <= 1024
 
             def body(reduce):
@@ -334,27 +349,51 @@ class BaseModel(nn.Module):
                 # warm-up must NOT enter a collective: ranks create their graphs at different steps (a tail batch gives some ranks a
                 # new slice size, others an old or empty one)
                 warm_up(lambda: body(lambda: None))
-                if parallel.can_capture() and not os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
+                if in_graph:
+                    ok, g = 1, None
                     try:
                         g = torch.cuda.CUDAGraph()
                         with capture(g):
                             body(do_reduce)
-                        run = g.replay
                     except Exception as e:                # noqa: BLE001 — any capture failure: keep training with the split form
                         self.logger.warning(f"in-graph all-reduce capture failed ({type(e).__name__}: {e}); using host-launched collectives")
-                        run = None
+                        ok, g = 0, None
+                    flag = torch.tensor([float(ok)], device=self.device)
+                    import torch.distributed as dist
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # every rank reaches this point for the same global batch
+                    if float(flag) >= 1.0:
+                        run = g.replay
+                    elif ok:
+                        self.logger.warning("in-graph all-reduce capture failed on another rank; using host-launched collectives")
                 if run is None:
-                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                    with capture(ga):
-                        eng.fwd_bwd(plan)
-                    with capture(gb):
-                        eng.adam_step(plan)
+                    if has_prep and group > 1:
+                        g_first, ga, gb, gl = (torch.cuda.CUDAGraph() for _ in range(4))
+                        with capture(g_first):
+                            eng.fwd_bwd(plan)
+                        with capture(ga):
+                            eng.fwd_bwd_prepared(plan)
+                        with capture(gb):
+                            eng.adam_step_prepare_next(plan)
+                        with capture(gl):
+                            eng.adam_step(plan)
 
-                    def run():
-                        for _ in range(group):
-                            ga.replay()
-                            do_reduce()
-                            gb.replay()
+                        def run():
+                            for j in range(group):
+                                (ga if j > 0 else g_first).replay()
+                                do_reduce()
+                                (gb if j < group - 1 else gl).replay()
+                    else:
+                        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                        with capture(ga):
+                            eng.fwd_bwd(plan)
+                        with capture(gb):
+                            eng.adam_step(plan)
+
+                        def run():
+                            for _ in range(group):
+                                ga.replay()
+                                do_reduce()
+                                gb.replay()
             else:
                 def run():
                     body(do_reduce)
@@ -387,8 +426,14 @@ class BaseModel(nn.Module):
                 if i == nb - 1 and W > 1:
                     self._perm_counter.fill_(i)             # a rank whose earlier tail slice was empty re-aligns its batch index
                 sel = (self._perm_buf, B, lo - i * B, self._perm_counter)
-                k = group if (i + group <= nb and shard_bounds(i + group - 1, B, n, W, r)[1] - shard_bounds(i + group - 1, B, n, W, r)[0] == bl) else 1
-                run, _ = self._step_graph(loader.fields, bl, sel, group=k, loss_log=losses)      # k_adam logs the (all-reduced) mean loss
+                # k and the collective's form are functions of GLOBAL quantities only, so that every rank replays the same shape for
+                # the same global batches: k = group while the next `group` global batches are all full (every rank's slice size is
+                # then constant over them), else 1; a partial tail batch — where some ranks' slices are short or empty and take the
+                # host all-reduce below — always uses the host-launched collective
+                k = group if (i + group) * B <= n else 1
+                full = (i + 1) * B <= n
+                run, _ = self._step_graph(loader.fields, bl, sel, group=k, loss_log=losses,      # k_adam logs the (all-reduced) mean loss
+                                          in_graph=W > 1 and full and self._dp_in_graph())
                 run()
                 i += k
                 continue

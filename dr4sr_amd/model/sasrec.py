@@ -146,11 +146,15 @@ class SASRec(BaseModel):
                                    seed=int(tc["seed"]) + 7919 * self.rank, lr=float(tc["learning_rate"]),
                                    weight_decay=float(tc["weight_decay"]), n_slots=self._n_slots())
         self.device = self.engine.device
-        try:                                   # regime hint for plans on per-batch tensors (engine._expected_tokens): mean valid length
-            sl = dataset_list[0].fields()["seqlen"]
-            self.engine.mean_len = float(sl.clamp(0, self.max_seq_len).float().mean()) if sl.numel() else None
-        except Exception:                      # a dataset class without resident fields: plans measure their own tensors
-            self.engine.mean_len = None
+        # regime hint for plans on per-batch tensors (engine._expected_tokens): mean valid length of the training split
+        self.engine.mean_len = None
+        fields = getattr(dataset_list[0], "fields", None)
+        sl = fields().get("seqlen") if callable(fields) else None
+        if sl is not None and sl.numel():
+            self.engine.mean_len = float(sl.clamp(0, self.max_seq_len).float().mean())
+        else:                                  # a dataset class without resident fields: per-batch plans measure their own tensors
+            self.logger.info("SASRec: the training split exposes no resident seqlen tensor; per-batch plans measure their own "
+                             "lengths (one synchronisation per new batch)")
         self.item_embedding = _Embedding(self.engine, "item_embedding.weight", self._table_rows(), self.embed_dim, padding_idx=0)
         self.query_encoder = SASRecQueryEncoder(self.fiid, self.embed_dim, self.max_seq_len, mc["head_num"], mc["hidden_size"],
                                                 mc["dropout_rate"], mc["activation"], mc["layer_norm_eps"], mc["layer_num"],

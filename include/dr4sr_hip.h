@@ -217,11 +217,6 @@ int dr4sr_neg_sample(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, ui
 /* the same with the step read from a device word at run time (graph replays) */
 int dr4sr_neg_sample_dev(int64_t* out, int64_t n, int32_t n_items, uint64_t seed, const int32_t* step_dev, void* stream);
 
-/* Materialise the keep-mask (1.0 / 0.0) the kernels use for (seed, step, site) over n elements
- * (n multiple of 4).  Test hook: lets the oracle run with the library's exact dropout masks. */
-int dr4sr_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint32_t step, uint32_t site,
-                       void* stream);
-
 /* BaseModel.topk (basemodel.py:354-365) for the single-domain case: scores = q @ E[:n_items]^T,
  * column 0 (PAD) and every id in hist[b,:] set to -inf, top-k (k <= 128) by score, ties -> lower id.
  * q [B,D], hist [B,Lh] int64, out_score [B,k] fp32, out_item [B,k] int64. */
@@ -444,31 +439,8 @@ int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, in
 int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
                       const float* lse, const float* scale, float* dxi, float* dxj, void* stream);
 
-/* ---- TEST / MEASUREMENT HOOKS — not part of the product surface (nothing in dr4sr_amd/ calls them): dr4sr_dropout_mask above
- * (tests: lets the oracle run with the library's masks) and dr4sr_sasrec_launch_kernel below (bench.py: enqueues ONE kernel of the
- * training step, on the state the last fwd_bwd left in the workspace, so that it can be bracketed with HIP events). ---- */
-#define DR4SR_K_PREP       0
-#define DR4SR_K_EMBED_FWD  1
-#define DR4SR_K_QKV_FWD    2
-#define DR4SR_K_ATTN_FWD   3
-#define DR4SR_K_POST_FWD   4
-#define DR4SR_K_SCORE      5
-#define DR4SR_K_TRANSPOSE  6
-#define DR4SR_K_POST_BWD   7
-#define DR4SR_K_ATTN_BWD   8
-#define DR4SR_K_QKV_BWD    9
-#define DR4SR_K_EMBED_BWD  10
-#define DR4SR_K_WGRAD      11
-#define DR4SR_K_ADAM       12
-#define DR4SR_K_ZERO_GRADS 13
-/* launches of the fused step (dr4sr_sasrec_train_step): gather + qkv of layer 0; post_fwd + scorer + post_bwd of the last layer;
- * qkv backward of layer 0 + table scatter; weight gradients with the step's extra planes / jobs.  (DR4SR_K_POST_FWD / _BWD with a
- * layer below the last one already are the fused forms: they carry the next layer's qkv projection / its backward.) */
-#define DR4SR_K_EMBQKV_FWD     14
-#define DR4SR_K_POST_MID       15
-#define DR4SR_K_QKV_EMBED_BWD  16
-#define DR4SR_K_WGRAD_FUSED    17
-int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, int32_t layer, void* stream);
+/* Test / measurement hooks (dr4sr_dropout_mask, dr4sr_*_launch_kernel) are NOT part of this product surface: they are declared in
+ * include/dr4sr_hip_hooks.h, and nothing under dr4sr_amd/ calls them. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,57 @@
+/* dr4sr_hip_hooks.h — TEST / MEASUREMENT hooks of libdr4sr_hip.so.
+ *
+ * Kept apart from the product ABI (include/dr4sr_hip.h): nothing under dr4sr_amd/ calls these.  Users: tests/ (the oracle runs with
+ * the library's own dropout masks) and bench.py / tools/ (ONE kernel of a training step enqueued on the state the last fwd_bwd left
+ * in the workspace, so that its launch duration can be bracketed with HIP events on the caller's stream — the `roofline` object).
+ */
+#ifndef DR4SR_HIP_HOOKS_H
+#define DR4SR_HIP_HOOKS_H
+#include "dr4sr_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Materialise the keep-mask (1.0 / 0.0) the kernels use for (seed, step, site) over n elements
+ * (n multiple of 4).  Test hook: lets the oracle run with the library's exact dropout masks. */
+int dr4sr_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint32_t step, uint32_t site,
+                       void* stream);
+
+/* SASRec step (model/sasrec.py:39-75 under model/basemodel.py:193-199): kernel ids of dr4sr_sasrec_launch_kernel */
+#define DR4SR_K_PREP       0
+#define DR4SR_K_EMBED_FWD  1
+#define DR4SR_K_QKV_FWD    2
+#define DR4SR_K_ATTN_FWD   3
+#define DR4SR_K_POST_FWD   4
+#define DR4SR_K_SCORE      5
+#define DR4SR_K_TRANSPOSE  6
+#define DR4SR_K_POST_BWD   7
+#define DR4SR_K_ATTN_BWD   8
+#define DR4SR_K_QKV_BWD    9
+#define DR4SR_K_EMBED_BWD  10
+#define DR4SR_K_WGRAD      11
+#define DR4SR_K_ADAM       12
+#define DR4SR_K_ZERO_GRADS 13
+/* launches of the fused step (dr4sr_sasrec_train_step): gather + qkv of layer 0; post_fwd + scorer + post_bwd of the last layer;
+ * qkv backward of layer 0 + table scatter; weight gradients with the step's extra planes / jobs.  (DR4SR_K_POST_FWD / _BWD with a
+ * layer below the last one already are the fused forms: they carry the next layer's qkv projection / its backward.) */
+#define DR4SR_K_EMBQKV_FWD     14
+#define DR4SR_K_POST_MID       15
+#define DR4SR_K_QKV_EMBED_BWD  16
+#define DR4SR_K_WGRAD_FUSED    17
+int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, int32_t layer, void* stream);
+
+/* the same with the MetaModel weighting (model/metamodel.py:174-194) on the launches that carry it (DR4SR_K_POST_MID); mw may be NULL */
+int dr4sr_sasrec_launch_kernel_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, int32_t kernel, int32_t layer,
+                                        void* stream);
+
+/* GRU4Rec step (model/gru4rec.py:12-34, module/layers.py:117-136): the recurrence of one layer (forward: h_t from gi and W_hh;
+ * backward: BPTT from the saved gates) and the input GEMM gi = in W_ih^T */
+#define DR4SR_GK_REC_FWD  0
+#define DR4SR_GK_REC_BWD  1
+#define DR4SR_GK_GEMM_IN  2
+int dr4sr_gru4rec_launch_kernel(const dr4sr_gru4rec_plan* plan, int32_t kernel, int32_t layer, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DR4SR_HIP_HOOKS_H */

@@ -11,6 +11,14 @@ Mirrors (file:line under /root/reference):
   model/basemodel.py:193-199        zero_grad / backward / Adam(lr=1e-3).step()
   utils/utils.py:11                 torch.autograd.set_detect_anomaly(True) is ON in the reference (flag here)
 State-dict names equal the reference's, so golden parameters load with strict=True.
+
+Round 3 — the other two BASELINE workloads that bench.py times get the same kind of CPU leg:
+  model/gru4rec.py:12-34, module/layers.py:117-136   RefLikeGRU4Rec: Embedding -> Dropout(0.2) -> torch.nn.GRU(bias=False, 2 x 256) -> Linear,
+                                                     Adam(lr 1e-3, weight_decay 1e-4) (configs/gru4rec.yaml)
+  model/metamodel.py:95-194, utils/utils.py:134-252  RefLikeMetaModel: weighted inner step every step (gumbel_softmax selection of a
+                                                     64->64->2 MLP on the query rows, pattern rows -> 1, PAD -> 0) and, every
+                                                     `interval` steps, the outer loop: Hypergrad.grad (Neumann series by double backward,
+                                                     truncate_iter 3, hpo_lr 1e-3) -> clip_grad_norm_(10) -> SGD(momentum 0.9)
 """
 from __future__ import annotations
 
@@ -88,24 +96,113 @@ class RefLikeSASRec(nn.Module):
         neg = torch.multinomial(w, self.L, replacement=True)
         return neg.reshape_as(batch["item_id"]).unsqueeze(-1)
 
-    def training_step(self, batch):
+    def training_step(self, batch, reduce=True, return_query=False):
         q = self.query_encoder(batch, True)
-        W = self.item_embedding.weight
-        pos = (q * W[batch["item_id"]]).sum(-1)
-        neg = (q.unsqueeze(-2) * W[batch["neg_item"]]).sum(-1)
-        pos[batch["item_id"] == 0] = -torch.inf
-        pad = torch.isinf(pos)
-        pos_l = F.logsigmoid(pos)
-        pos_l.masked_fill_(pad, 0.0)
-        pos_l = pos_l.sum() / (~pad).sum()
-        neg_l = (F.softplus(neg) * (torch.ones_like(neg) / neg.size(-1))).sum(-1)
-        neg_l.masked_fill_(pad, 0.0)
-        neg_l = neg_l.sum() / (~pad).sum()
-        return -pos_l + neg_l
+        loss = bce_scorer(q, self.item_embedding.weight, batch, reduce)
+        return (loss, q) if return_query else loss
+
+
+def bce_scorer(q, W, batch, reduce=True):
+    """model/basemodel.py:204-214 (tied scorer, pos[target == 0] = -inf) + model/loss_func.py:9-38 (masked branch, both reduce forms)"""
+    pos = (q * W[batch["item_id"]]).sum(-1)
+    neg = (q.unsqueeze(-2) * W[batch["neg_item"]]).sum(-1)
+    pos[batch["item_id"] == 0] = -torch.inf
+    pad = torch.isinf(pos)
+    pos_l = F.logsigmoid(pos)
+    pos_l.masked_fill_(pad, 0.0)
+    pos_l = pos_l.sum() / (~pad).sum() if reduce else pos_l / (~pad).sum()
+    neg_l = (F.softplus(neg) * (torch.ones_like(neg) / neg.size(-1))).sum(-1)
+    neg_l.masked_fill_(pad, 0.0)
+    neg_l = neg_l.sum() / (~pad).sum() if reduce else neg_l / (~pad).sum()
+    return -pos_l + neg_l
+
+
+class RefLikeGRU4Rec(nn.Module):
+    """model/gru4rec.py:12-34: item_embedding -> Dropout -> GRULayer (torch.nn.GRU, bias=False, batch_first: module/layers.py:117-136) ->
+    Linear(hidden, D); 'origin' pooling in training.  normal_initialization touches the Embedding and the Linear only: the GRU keeps
+    torch's U(-1/sqrt(H), 1/sqrt(H))."""
+
+    def __init__(self, n_items, D=64, hidden=256, n_layer=2, p=0.2, L=50):
+        super().__init__()
+        self.n_items, self.L = n_items, L
+        self.item_embedding = nn.Embedding(n_items, D, padding_idx=0)
+        self.drop = nn.Dropout(p)
+        self.gru = nn.GRU(input_size=D, hidden_size=hidden, num_layers=n_layer, bias=False, batch_first=True, bidirectional=False)
+        self.out = nn.Linear(hidden, D)
+        self.apply(RefLikeSASRec._init)
+
+    neg_sampling = RefLikeSASRec.neg_sampling
+
+    def training_step(self, batch, reduce=True, return_query=False):
+        y = self.out(self.gru(self.drop(self.item_embedding(batch["in_item_id"])))[0])
+        L = y.size(1)
+        m = torch.arange(L).unsqueeze(0).unsqueeze(2).expand(y.size(0), -1, y.size(2))
+        q = y.masked_fill(m >= batch["seqlen"].view(-1, 1, 1), 0.0)
+        loss = bce_scorer(q, self.item_embedding.weight, batch, reduce)
+        return (loss, q) if return_query else loss
+
+
+class RefLikeMetaModel(nn.Module):
+    """model/metamodel.py: a trainer around a sub-model.  training_step = :174-194, the outer loop = :123-166 with utils/utils.py's
+    Hypergrad (:134-205) and MetaOptimizer (:207-252) restated inline (same autograd.grad calls, same order)."""
+
+    def __init__(self, sub: nn.Module, D=64, tau_min=1.0, meta_lr=1e-3, hpo_lr=1e-3, meta_wd=1e-3, truncate_iter=3, max_grad_norm=10.0):
+        super().__init__()
+        self.sub = sub
+        self.meta_module = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, 2))
+        self.meta_module.apply(RefLikeSASRec._init)
+        self.tau = nn.Parameter(torch.ones(1) * 10)
+        self.tau_min, self.hpo_lr, self.truncate_iter, self.max_grad_norm = tau_min, hpo_lr, truncate_iter, max_grad_norm
+        self.meta_opt = torch.optim.SGD(self.meta_module.parameters(), lr=meta_lr, momentum=0.9, weight_decay=meta_wd)
+
+    gumbel = None                                       # tests: explicit Gumbel noise [..., 2] instead of torch's draw (golden vectors)
+
+    def selection(self, query):
+        logits = self.meta_module(query)
+        tau = torch.clip(self.tau, min=self.tau_min)
+        if self.gumbel is not None:                        # F.gumbel_softmax(hard=False) = softmax((logits + g) / tau)
+            return ((logits + self.gumbel) / tau).softmax(-1)[..., 0].squeeze()
+        return F.gumbel_softmax(logits, tau=tau, dim=-1, hard=False)[..., 0].squeeze()
+
+    def training_step(self, batch):
+        loss_value, query = self.sub.training_step(batch, reduce=False, return_query=True)
+        weight = self.selection(query)
+        mask = batch["user_id"] == 0
+        if weight.dim() == 2:
+            mask = mask.unsqueeze(-1)
+        weight = weight.masked_fill(mask, 1)
+        weight = weight.masked_fill(batch["item_id"] == 0, 0)
+        return (loss_value * weight).sum()
+
+    def outer_loop(self, batch_val, batch_train):
+        # torch >= 2.x routes nn.MultiheadAttention to a fused CPU flash kernel that has no double backward (the reference's torch
+        # 1.13 had only the math path): the two forward passes whose graph is differentiated twice run under the MATH backend, as
+        # tools/make_golden.py does when it runs the reference's own outer loop
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+        with sdpa_kernel(SDPBackend.MATH):
+            val_loss = self.sub.training_step(batch_val)
+            train_loss = self.training_step(batch_train)
+        params, aux = list(self.sub.parameters()), list(self.meta_module.parameters())
+        self.meta_opt.zero_grad()
+        dval = torch.autograd.grad(val_loss, params, retain_graph=True, allow_unused=True)
+        dtrain = torch.autograd.grad(train_loss, params, allow_unused=True, create_graph=True)
+        keep = [i for i, (a, b) in enumerate(zip(dval, dtrain)) if a is not None and b is not None]
+        dval, dtrain, params = [dval[i] for i in keep], [dtrain[i] for i in keep], [params[i] for i in keep]
+        p = v = dval
+        for _ in range(self.truncate_iter):
+            g = torch.autograd.grad(dtrain, params, grad_outputs=v, retain_graph=True, allow_unused=True)
+            g = [torch.zeros_like(x) if gi is None else gi * self.hpo_lr for gi, x in zip(g, params)]
+            v = [cv - cg for cv, cg in zip(v, g)]
+            p = [cp + cv for cp, cv in zip(p, v)]
+        v3 = torch.autograd.grad(dtrain, aux, grad_outputs=p, allow_unused=True)
+        for a, g in zip(aux, v3):
+            a.grad = -g
+        torch.nn.utils.clip_grad_norm_(aux, max_norm=self.max_grad_norm)
+        self.meta_opt.step()
 
 
 def time_training(rows: dict, n_items: int, batch_size=256, warmup=3, max_steps=60, max_seconds=25.0, anomaly=True,
-                  seed=2023, p=0.5, threads=None):
+                  seed=2023, p=0.5, threads=None, model_kind="sasrec", interval=30):
     """seq/s of the reference-equivalent CPU step (batch build + neg sampling + fwd + bwd + Adam).
     threads: torch intra-op threads for this run (None = leave as is); the reference sets nothing, i.e. torch's default = all
     cores, which on a 128-core host is slower than 8-32 threads for these microsecond-sized ops — bench.py sweeps and reports."""
@@ -116,9 +213,17 @@ def time_training(rows: dict, n_items: int, batch_size=256, warmup=3, max_steps=
         torch.set_num_threads(int(threads))
     torch.autograd.set_detect_anomaly(anomaly)
     try:
-        model = RefLikeSASRec(n_items, p=p)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)
+        meta = None
+        if model_kind == "gru4rec":                        # configs/gru4rec.yaml: dropout 0.2, Adam weight_decay 1e-4
+            model = RefLikeGRU4Rec(n_items, p=p)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        else:
+            model = RefLikeSASRec(n_items, p=p)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)
+            if model_kind == "metamodel":                  # past warm-up (metamodel.py:110-112): weighted steps + outer loop on the interval
+                meta = RefLikeMetaModel(model)
         model.train()
+        outer = 0
         loader = DataLoader(RowDataset(rows), batch_size, shuffle=True)
         it = iter(loader)
         done, nseq, t0 = 0, 0, None
@@ -132,16 +237,21 @@ def time_training(rows: dict, n_items: int, batch_size=256, warmup=3, max_steps=
                 t0 = time.perf_counter()
             batch["neg_item"] = model.neg_sampling(batch)
             opt.zero_grad()
-            loss = model.training_step(batch)
+            loss = meta.training_step(batch) if meta is not None else model.training_step(batch)
             loss.backward()
             opt.step()
             done += 1
+            if meta is not None and done % interval == 0:  # metamodel.py:117-120: fresh meta batch + fresh train batch
+                bv, bt = next(iter(loader)), next(iter(loader))
+                bv["neg_item"], bt["neg_item"] = model.neg_sampling(bv), model.neg_sampling(bt)
+                meta.outer_loop(bv, bt)
+                outer += 1
             if done > warmup:
                 nseq += batch["seqlen"].shape[0]
                 el = time.perf_counter() - t0
                 if done - warmup >= max_steps or el >= max_seconds:
                     return {"seq_per_s": nseq / el, "steps": done - warmup, "seconds": el, "loss": float(loss.detach()),
-                            "threads": torch.get_num_threads(), "anomaly": anomaly}
+                            "threads": torch.get_num_threads(), "anomaly": anomaly, "outer_steps": outer}
     finally:
         torch.autograd.set_detect_anomaly(prev)
         torch.set_num_threads(prev_threads)

@@ -129,11 +129,14 @@ def score_bce(query, E, target, neg, reduce=True):
 
 
 def bce_from_scores(pos, neg, reduce=True):
-    """BinaryCrossEntropyLoss.forward (loss_func.py:9-38), masked branch, on score tensors: pos [...] with -inf at padded positions,
-    neg [..., K] weighted 1/K (_cal_weight :40-41)."""
+    """BinaryCrossEntropyLoss.forward (loss_func.py:9-38) on score tensors: pos [...] with -inf at padded positions, neg [..., K]
+    weighted 1/K (_cal_weight :40-41) — the masked branch — or neg of pos's rank ([B, K]): the plain-mean branch (:32-33)."""
     pad = torch.isinf(pos)
     n = (~pad).sum()
     pos_l = F.logsigmoid(pos).masked_fill(pad, 0.0)
+    if pos.dim() == neg.dim():                              # loss_func.py:32-33: plain mean of the negatives' term, no padding mask
+        neg_m = (F.softplus(neg) / neg.shape[-1]).sum(-1).mean()
+        return (-pos_l.sum() / n if reduce else -pos_l / n) + neg_m
     neg_l = (F.softplus(neg) / neg.shape[-1]).sum(-1).masked_fill(pad, 0.0)
     if reduce:
         return -pos_l.sum() / n + neg_l.sum() / n

@@ -401,8 +401,8 @@ def test_loss_modules_on_score_tensors_match_reference(golden_dir):
     loss classes run on the same scores (tests/golden/loss_modules.npz): loss, d pos, d neg; 1-D / 2-D positives, K = 1 and 3"""
     from dr4sr_amd.model.loss_func import BinaryCrossEntropyLoss, BPRLoss
     z = np.load(os.path.join(golden_dir, "loss_modules.npz"))
-    for tag in ("a", "b", "c"):
-        for name in ("bce", "bce_nr", "bpr"):
+    for tag in ("a", "b", "c", "d"):                     # d: the plain-mean branch (loss_func.py:32-33), BCE only
+        for name in (("bce", "bce_nr") if tag == "d" else ("bce", "bce_nr", "bpr")):
             p = torch.from_numpy(z[f"{tag}.pos"]).cuda().requires_grad_(True)
             n = torch.from_numpy(z[f"{tag}.neg"]).cuda().requires_grad_(True)
             loss = BPRLoss()(p, n) if name == "bpr" else BinaryCrossEntropyLoss()(p, n, reduce=(name == "bce"))
@@ -412,6 +412,12 @@ def test_loss_modules_on_score_tensors_match_reference(golden_dir):
             np.testing.assert_allclose(n.grad.cpu().numpy(), z[f"{tag}.{name}.dneg"], rtol=1e-5, atol=1e-7)
     with pytest.raises(TypeError):
         BPRLoss()(torch.zeros(2).cuda(), torch.zeros(2, 1).cuda(), reduce=True)       # loss_func.py:44: no such parameter
+    # reduced-precision score tensors: the kernels compute in fp32, the gradients come back in the inputs' dtypes (autograd contract)
+    for neg_shape in ((4, 5, 2), (4, 3)):                   # masked branch / plain-mean branch
+        ph = torch.randn(4, 5, device="cuda").to(torch.bfloat16).requires_grad_(True)
+        nh = torch.randn(*neg_shape, device="cuda").to(torch.float16).requires_grad_(True)
+        BinaryCrossEntropyLoss()(ph, nh).backward()
+        assert ph.grad.dtype == torch.bfloat16 and nh.grad.dtype == torch.float16 and bool(torch.isfinite(nh.grad.float()).all())
 
 
 @pytest.mark.gpu

@@ -43,9 +43,9 @@ def _gru_batch(B, N, L, seed, toys=True):
     return b, gen
 
 
-def _gru_vs_oracle(B, H, NL, seed=11, toys=True, rel=3e-4):
+def _gru_vs_oracle(B, H, NL, seed=11, toys=True, rel=3e-4, N=2000):
     from dr4sr_amd.gru_engine import GruEngine, gru_param_names, gru_param_shapes
-    N, L = 2000, 50
+    L = 50
     b, gen = _gru_batch(B, N, L, seed, toys)
     params = {}
     for nme, shp in zip(gru_param_names(NL), gru_param_shapes(N, 64, H, NL)):

@@ -126,14 +126,61 @@ def test_ref_like_trainer_matches_golden(golden_dir, name):
         assert float(np.abs(prm.grad.numpy() - ref).max()) <= 2e-5 * max(1e-8, float(np.abs(ref).max())) + 1e-9, n
 
 
+def test_ref_like_gru4rec_trainer_matches_golden(golden_dir):
+    """bench.py --model gru4rec's cpu_baseline leg (oracle/ref_trainer.RefLikeGRU4Rec: torch.nn.GRU, as module/layers.py:117-136)
+    reproduces the reference's GRU4Rec loss and gradients"""
+    from oracle.ref_trainer import RefLikeGRU4Rec
+    z = np.load(os.path.join(golden_dir, "gru4rec_d64.npz"))
+    g = {k: z[k] for k in z.files}
+    m = RefLikeGRU4Rec(int(g["meta.num_items"]), D=int(g["meta.embed_dim"]), hidden=int(g["meta.hidden_size"]), n_layer=int(g["meta.layer_num"]), p=0.0)
+    names = {"item_embedding.weight": "item_embedding.weight", "out.weight": "query_encoder.1.weight", "out.bias": "query_encoder.1.bias"}
+    for l in range(int(g["meta.layer_num"])):
+        names[f"gru.weight_ih_l{l}"] = f"query_encoder.0.3.gru.weight_ih_l{l}"
+        names[f"gru.weight_hh_l{l}"] = f"query_encoder.0.3.gru.weight_hh_l{l}"
+    m.load_state_dict({k: torch.from_numpy(g["param." + v]) for k, v in names.items()}, strict=True)
+    m.train()
+    b = {k[len("batch."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("batch.")}
+    loss = m.training_step(b)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["out.loss"]), rtol=1e-6)
+    for n, prm in m.named_parameters():
+        ref = g["grad." + names[n]]
+        assert float(np.abs(prm.grad.numpy() - ref).max()) <= 2e-5 * max(1e-8, float(np.abs(ref).max())) + 1e-9, n
+
+
+def test_ref_like_metamodel_trainer_matches_golden(golden_dir):
+    """bench.py --model metamodel's cpu_baseline leg (oracle/ref_trainer.RefLikeMetaModel) reproduces the reference's weighted inner
+    loss and, after one outer loop (Hypergrad.grad -> clip -> SGD momentum), its meta-module parameters (metamodel_sasrec.npz)"""
+    from oracle.ref_trainer import RefLikeMetaModel, RefLikeSASRec
+    z = np.load(os.path.join(golden_dir, "metamodel_sasrec.npz"))
+    g = {k: z[k] for k in z.files}
+    pick = lambda pre: {k[len(pre):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre)}
+    p, bt, bv = pick("param."), pick("train."), pick("val.")
+    N, D = p["item_embedding.weight"].shape
+    sub = RefLikeSASRec(N, D=D, H=int(g["meta.head_num"]), Fh=int(g["meta.hidden_size"]), p=0.0, eps=float(g["meta.layer_norm_eps"]),
+                        n_layer=int(g["meta.layer_num"]))
+    sub.load_state_dict(p, strict=True)
+    mm = RefLikeMetaModel(sub, D=D, tau_min=float(g["meta.tau_min"]), meta_lr=float(g["meta.meta_learning_rate"]),
+                          hpo_lr=float(g["meta.hpo_learning_rate"]), meta_wd=float(g["meta.meta_weight_decay"]))
+    mm.meta_module.load_state_dict(pick("meta_param."), strict=True)
+    with torch.no_grad():
+        mm.tau.copy_(torch.from_numpy(g["meta.tau"]))
+    mm.gumbel = torch.from_numpy(g["inner.gumbel"])
+    mm.train()
+    np.testing.assert_allclose(float(mm.training_step(bt).detach()), float(g["inner.loss"]), rtol=2e-6)
+    mm.outer_loop(bv, bt)
+    for k, v in mm.meta_module.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g["outer.step1." + k], rtol=1e-5, atol=2e-7)
+
+
 def test_oracle_loss_modules_match_reference(golden_dir):
     """oracle bce_from_scores / bpr_from_scores vs the reference's BinaryCrossEntropyLoss / BPRLoss run on fixed scores
     (tests/golden/loss_modules.npz, made by tools/make_golden.py loss_module_vectors): loss and both gradients"""
     z = np.load(os.path.join(golden_dir, "loss_modules.npz"))
     assert "unexpected keyword argument 'reduce'" in str(z["bpr.reduce_kwarg_error"])       # a8: the reference cannot call BPR from training_step
-    for tag in ("a", "b", "c"):
+    for tag in ("a", "b", "c", "d"):                     # d: the plain-mean branch (loss_func.py:32-33), BCE only
         pos0, neg0 = torch.from_numpy(z[f"{tag}.pos"]), torch.from_numpy(z[f"{tag}.neg"])
-        for name in ("bce", "bce_nr", "bpr"):
+        for name in (("bce", "bce_nr") if tag == "d" else ("bce", "bce_nr", "bpr")):
             p, n = pos0.clone().requires_grad_(True), neg0.clone().requires_grad_(True)
             loss = O.bpr_from_scores(p, n) if name == "bpr" else O.bce_from_scores(p, n, reduce=(name == "bce"))
             np.testing.assert_allclose(loss.detach().numpy(), z[f"{tag}.{name}.loss"], rtol=2e-6, atol=1e-7)

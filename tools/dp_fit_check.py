@@ -26,7 +26,7 @@ if MODEL == "MetaModel":
 if MODEL == "FMLP":
     cfg["data"]["prefix_rows"] = True                     # one query per row: left-padded prefixes with scalar targets (model/fmlp.py:38)
 cfg["model"]["dropout_rate"] = 0.2
-cfg["train"].update({"batch_size": 128, "epochs": 3, "device": "cuda:0", "hip_graph": True})
+cfg["train"].update({"batch_size": 128, "epochs": 3, "device": "cuda:0", "hip_graph": True, "steps_per_graph": 3})   # 8 full batches: groups of 3, 3, then singles
 if "interval" in cfg["train"]:
     cfg["train"]["interval"] = 4                          # MetaModel: several outer steps per epoch
 cfg["eval"]["batch_size"] = 128

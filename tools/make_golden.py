@@ -581,6 +581,24 @@ def loss_module_vectors(out_dir):
             out[f"{tag}.{name}.up"] = up.numpy().copy()
             out[f"{tag}.{name}.dpos"] = torch.nan_to_num(p.grad, nan=0.0).numpy().copy()     # -inf rows: grad is nan/0 in torch, 0 by definition
             out[f"{tag}.{name}.dneg"] = n.grad.numpy().copy()
+    # loss_func.py:32-33, the plain-mean branch of BinaryCrossEntropyLoss: pos [B, L] with neg [B, K] of the SAME rank (no padding mask on
+    # the negatives, their term is one scalar mean).  Drawn AFTER a / b / c so that those vectors keep their values.
+    pos = torch.randn(5, 11, generator=g) * 2.0
+    neg = torch.randn(5, 4, generator=g) * 2.0
+    pad = torch.rand(5, 11, generator=g) < 0.4
+    pad.view(-1)[0] = False
+    pos = pos.masked_fill(pad, float("-inf"))
+    out["d.pos"], out["d.neg"] = pos.numpy().copy(), neg.numpy().copy()
+    for name, kw in (("bce", {"reduce": True}), ("bce_nr", {"reduce": False})):
+        p = pos.clone().requires_grad_(True)
+        n = neg.clone().requires_grad_(True)
+        loss = lf.BinaryCrossEntropyLoss()(p, n, **kw)
+        up = torch.ones_like(loss) if loss.dim() == 0 else torch.randn(loss.shape, generator=g)
+        (loss * up).sum().backward()
+        out[f"d.{name}.loss"] = loss.detach().numpy().copy()
+        out[f"d.{name}.up"] = up.numpy().copy()
+        out[f"d.{name}.dpos"] = torch.nan_to_num(p.grad, nan=0.0).numpy().copy()
+        out[f"d.{name}.dneg"] = n.grad.numpy().copy()
     try:
         lf.BPRLoss()(torch.zeros(2), torch.zeros(2, 1), reduce=True)
         msg = ""
