@@ -674,6 +674,7 @@ def main():
             wall = time.perf_counter() - t0
             gpu_ms = e0.elapsed_time(e1)
             per_rank_ms, coll_us = None, None
+            loss, nvalid = eng.loss_and_count()             # (before the stand-alone collective timing below overwrites the gradient tail)
             if dp:
                 # this rank's own GPU time per step (events); gloo (shared-GPU functional runs) gathers host tensors only
                 mine = torch.tensor([gpu_ms / steps], device=dev if parallel.can_capture() else "cpu", dtype=torch.float64)
@@ -695,7 +696,6 @@ def main():
                 eb.synchronize()
                 coll_us = ea.elapsed_time(eb) * 1e3 / 20
                 eng.grads.zero_()
-            loss, nvalid = eng.loss_and_count()
             T_last = int(eng.state[_lib.STATE_T])
             model_desc = {"sasrec": ("SASRec on yelp-sized synthetic rows (BASELINE configs[3] shape): N=20034, L=50, d=128, 2 layers, 2 heads, "
                                      if D == 128 else
