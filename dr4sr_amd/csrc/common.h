@@ -29,7 +29,7 @@ struct RngKey {
     uint32_t seed_lo, seed_hi, step;
     float p;           // drop probability
     float scale;       // 1/(1-p)
-    uint32_t thresh;   // keep iff r >= thresh
+    uint32_t thresh;   // 16-bit decisions: keep iff r16 >= thresh (thresh = round(p * 65536), <= 65535)
 };
 
 __device__ __forceinline__ RngKey make_rng(uint64_t seed, uint32_t step, float p) {
@@ -39,30 +39,46 @@ __device__ __forceinline__ RngKey make_rng(uint64_t seed, uint32_t step, float p
     k.step = step;
     k.p = p;
     k.scale = 1.0f / (1.0f - p);
-    double t = (double)p * 4294967296.0;
-    k.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    const float t = p * 65536.0f + 0.5f;
+    k.thresh = t >= 65535.0f ? 65535u : (uint32_t)t;
     return k;
 }
 
-// random words for elements [4*call, 4*call+3] of stream (site)
+// random words of call `call` of stream (site)
 __device__ __forceinline__ uint4 rng_call(const RngKey& k, uint32_t site, uint64_t call) {
     return philox4x32_10(make_uint4((uint32_t)call, (uint32_t)(call >> 32), site, k.step),
                          make_uint2(k.seed_lo, k.seed_hi));
 }
 
-// multiplicative keep factors (0 or 1/(1-p)) for 4 consecutive elements starting at e (e % 4 == 0)
+// Dropout decisions are 16 bits wide (round 3): one Philox call covers EIGHT consecutive elements — element e takes half (e & 1) of
+// word ((e >> 1) & 3) of call e >> 3 — instead of four 32-bit ones.  Philox is the largest VALU item of the token-tile kernels
+// (40 quarter-rate integer multiplies per call; fp32 MFMA and VALU share a SIMD's datapath on gfx950 — tools/probes/
+// mfma_valu_overlap_probe.hip — so every VALU cycle is a cycle the matrix pipe idles): kernels whose lanes own 8 consecutive
+// columns (csrc/linear_wave.hip) halve their calls, the float4 kernels keep one call per float4.  The drop probability is quantised
+// to 1 / 65 536 (|p' - p| < 8e-6; p = 0.5 exact); the keep scale stays the reference's 1 / (1 - p).
+__device__ __forceinline__ float keep16(const RngKey& k, uint32_t w, int half) {
+    return ((half ? (w >> 16) : (w & 0xffffu)) >= k.thresh) ? k.scale : 0.f;
+}
+// multiplicative keep factors (0 or 1/(1-p)) for 8 consecutive elements starting at e (e % 8 == 0): lo = e..e+3, hi = e+4..e+7
+__device__ __forceinline__ void drop8(const RngKey& k, uint32_t site, uint64_t e, float4& lo, float4& hi) {
+    const uint4 r = rng_call(k, site, e >> 3);
+    lo = make_float4(keep16(k, r.x, 0), keep16(k, r.x, 1), keep16(k, r.y, 0), keep16(k, r.y, 1));
+    hi = make_float4(keep16(k, r.z, 0), keep16(k, r.z, 1), keep16(k, r.w, 0), keep16(k, r.w, 1));
+}
+// ... for 4 consecutive elements starting at e (e % 4 == 0): the matching half of the call
 __device__ __forceinline__ float4 drop4(const RngKey& k, uint32_t site, uint64_t e) {
-    const uint4 r = rng_call(k, site, e >> 2);
-    return make_float4(r.x >= k.thresh ? k.scale : 0.f, r.y >= k.thresh ? k.scale : 0.f,
-                       r.z >= k.thresh ? k.scale : 0.f, r.w >= k.thresh ? k.scale : 0.f);
+    const uint4 r = rng_call(k, site, e >> 3);
+    const bool up = (e >> 2) & 1;
+    const uint32_t w0 = up ? r.z : r.x, w1 = up ? r.w : r.y;
+    return make_float4(keep16(k, w0, 0), keep16(k, w0, 1), keep16(k, w1, 0), keep16(k, w1, 1));
 }
 
 // keep factor of a single element (recomputes the shared call; use only off the hot path)
 __device__ __forceinline__ float drop1(const RngKey& k, uint32_t site, uint64_t e) {
-    const uint4 r = rng_call(k, site, e >> 2);
-    const uint32_t c = (uint32_t)(e & 3);
+    const uint4 r = rng_call(k, site, e >> 3);
+    const uint32_t c = (uint32_t)((e >> 1) & 3);
     const uint32_t w = c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w;
-    return w >= k.thresh ? k.scale : 0.f;
+    return keep16(k, w, (int)(e & 1));
 }
 
 // a2 negative sampler (basemodel.py:50-61): element e of the (seed, step) stream

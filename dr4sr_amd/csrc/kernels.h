@@ -89,6 +89,21 @@ struct PostArgs {
     const float* up_dqkv; const float* up_in_w; const float* up_du1;   // bwd: dz = up_dqkv W_in(layer+1) + up_du1 instead of reading A.dz
 };
 
+// scorer half of the fused last-layer launch (k_post_mid / k_wt_post_mid)
+struct ScoreTileArgs {
+    const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq; int64_t* neg_item; float* part;
+    int sample_neg, n_items, B, L;
+    int4* rec;                                 // owner-computes table gradient: per-token records instead of atomics into dE (NULL: atomics)
+    // ... and the tile's table-gradient entries sorted by owner (tile_sort): ent [tiles][3 BM] int4, off [tiles][G + 4] bytes; NULL: the
+    // owners scan rec / idx32 themselves
+    int4* ent; unsigned char* off; const int* idx32; int logG;
+    // MetaModel (DR4SR+) weighted loss, fused: weight_t = selection(z_t; phi) with the masks of metamodel.py:180-185; the loss
+    // becomes sum_t weight_t loss_t and dz gains loss_t * d weight_t / d z_t.  phi == NULL: plain BCE.  (d phi is NOT produced
+    // here: the inner step never uses it and the hyper-gradient takes it from the deterministic dr4sr_meta_select_bwd.)
+    const float* phi; const float* gumbel; const int64_t* user_id; const unsigned long long* gate_in; unsigned long long* gate_out;
+    float* w_out; float inv_tau; uint64_t meta_seed;
+};
+
 struct WgradJob {
     const float* G; int ldg; int gcol;        // G rows start at column gcol
     const float* X; int ldx;
@@ -101,7 +116,8 @@ struct WgradArgs {
     const float* ln_part; int64_t ln_layer_stride; float* grads; int64_t o_ln1_w; int64_t layer_stride;   // ln1_w,ln1_b,ln2_w,ln2_b contiguous
     const float* score_part; float* tail; int B; int D;
     int score_tiles;                           // 1: score_part holds one (count, loss) pair per token tile instead of per sequence
-    int ln_tile_rows;                          // token rows per LayerNorm-partial row (tile size of the post kernels)
+    int ln_tile_rows;                          // token rows per tile of the LAST layer's post kernel (LayerNorm partials, owner-sorted entries)
+    int ln_rows[DR4SR_MAX_LAYERS];             // token rows per LayerNorm-partial row, per layer (wave-tile kernels: 16)
     int qeb_plane;                             // 1: grid plane z = 0 runs the embedding-stage backward tiles, layers are z - 1
     const float* fc_dm; int64_t fc_o_cw; int fc_L;     // FMLP: filter-coefficient backward as part of the reduce blocks (fc_dm == NULL: none)
     // embedding scatter job (blockIdx.y == 7, large batches; sc_g == NULL: none)
@@ -112,6 +128,14 @@ struct WgradArgs {
     const int4* ow_ent; const unsigned char* ow_off;     // per-tile entries sorted by owner + byte offset tables (k_post_mid's tile_sort); NULL: scan
     int ow_on; const int4* ow_rec; const int* ow_idx32; const float* ow_z; int ow_logG, ow_planes, ow_rpo;     // ow_rec == NULL: no scorer stream (autograd path)
 };
+
+// linear_wave.hip: wave-autonomous 16-token tiles with LDS-resident weights (at scale, d = 64 / FFN 128)
+bool wave_tiles(const dr4sr_sasrec_plan* p, const Workspace& ws);
+bool wt_bwd_on();                               // the backward wave-tile kernels too (DR4SR_WT_FWD_ONLY: forward only)
+int launch_wt_post_fwd(const PostArgs& A, int Tmax, hipStream_t s);
+int launch_wt_post_bwd(const PostArgs& A, int Tmax, hipStream_t s);     // writes ln_part rows per 16-token tile
+
+int launch_wt_post_mid(const PostArgs& A, const ScoreTileArgs& S, int Tmax, hipStream_t s);   // score_part / entries per 16-token tile
 
 int ffn_tile_rows(int Tmax);
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);
@@ -137,7 +161,8 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s);
-int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb = false);
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb = false,
+                 bool meta = false);     // meta: the fused last-layer launch carried the MetaModel weighting (its tile size differs)
 bool qeb_in_wgrad(const Workspace& ws);         // latency regime: k_qkv_embed_bwd's tiles run as the first plane of the k_wgrad launch
 
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);

@@ -97,8 +97,11 @@ static int owner_logG(const dr4sr_sasrec_plan* p) {
 }
 // tiles hand their entries over sorted by owner (tile_sort / owner_job_sorted) when the offset tables are byte-sized and small:
 // 32- or 64-row tiles, at most 1024 owners.  DR4SR_OWNER_SCAN (read per call) keeps the scanning owners as a cross-check.
-static bool owner_sorted(const dr4sr_sasrec_plan* p, const Workspace& ws) {
-    return de_owner_mode(ws) && tile_rows(ws) != 16 && owner_logG(p) <= 10 && !getenv("DR4SR_OWNER_SCAN");
+// the fused last-layer launch takes the wave-tile form (csrc/linear_wave.hip: 16-token tiles) — not for the MetaModel weighting
+static bool wt_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta) { return wave_tiles(p, ws) && wt_bwd_on() && !meta; }
+static int mid_tile_rows(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta) { return wt_mid(p, ws, meta) ? 16 : tile_rows(ws); }
+static bool owner_sorted(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta = false) {
+    return de_owner_mode(ws) && (tile_rows(ws) != 16 || wt_mid(p, ws, meta)) && owner_logG(p) <= 10 && !getenv("DR4SR_OWNER_SCAN");
 }
 #define BM_DISPATCH(bm, CALL) do { if ((bm) == 16) { CALL(16); } else if ((bm) == 32) { CALL(32); } else { CALL(64); } } while (0)
 
@@ -545,19 +548,6 @@ __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
 // products by lane-group shuffles, un-normalised dz + table-gradient atomics; the tile's (count, loss) partial goes to
 // part[2*tile] (summed by k_wgrad's reduce job).  Valid targets at positions >= seqlen (query row is zero there) are
 // counted by the sequence's last token, as the per-sequence scorer does.
-struct ScoreTileArgs {
-    const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq; int64_t* neg_item; float* part;
-    int sample_neg, n_items, B, L;
-    int4* rec;                                 // owner-computes table gradient: per-token records instead of atomics into dE (NULL: atomics)
-    // ... and the tile's table-gradient entries sorted by owner (tile_sort): ent [tiles][3 BM] int4, off [tiles][G + 4] bytes; NULL: the
-    // owners scan rec / idx32 themselves
-    int4* ent; unsigned char* off; const int* idx32; int logG;
-    // MetaModel (DR4SR+) weighted loss, fused: weight_t = selection(z_t; phi) with the masks of metamodel.py:180-185; the loss
-    // becomes sum_t weight_t loss_t and dz gains loss_t * d weight_t / d z_t.  phi == NULL: plain BCE.  (d phi is NOT produced
-    // here: the inner step never uses it and the hyper-gradient takes it from the deterministic dr4sr_meta_select_bwd.)
-    const float* phi; const float* gumbel; const int64_t* user_id; const unsigned long long* gate_in; unsigned long long* gate_out;
-    float* w_out; float inv_tau; uint64_t meta_seed;
-};
 template <int LPT>
 __device__ __forceinline__ float lane_group_sum(float v) {
 #pragma unroll
@@ -1105,23 +1095,26 @@ int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int trainin
     S.neg_item = p->neg_item; S.part = ws.score_part; S.sample_neg = p->sample_neg; S.n_items = p->n_items; S.B = p->B; S.L = p->L;
     S.rec = de_owner_mode(ws) ? ws.de_rec : nullptr;
     S.ent = nullptr; S.off = nullptr; S.idx32 = ws.idx32; S.logG = 0;
-    if (owner_sorted(p, ws)) { S.ent = ws.de_ent; S.off = ws.de_off; S.logG = owner_logG(p); }
+    if (owner_sorted(p, ws, mw != nullptr)) { S.ent = ws.de_ent; S.off = ws.de_off; S.logG = owner_logG(p); }
     S.phi = nullptr; S.gumbel = nullptr; S.user_id = nullptr; S.gate_in = nullptr; S.gate_out = nullptr; S.w_out = nullptr; S.inv_tau = 1.f;
     S.meta_seed = p->seed;
     if (mw) {
         S.phi = mw->phi; S.gumbel = mw->gumbel; S.user_id = mw->user_id; S.gate_in = (const unsigned long long*)mw->gate_in;
         S.gate_out = (unsigned long long*)mw->gate_out; S.w_out = mw->weight_out; S.inv_tau = 1.0f / mw->tau;
     }
+    if (wt_mid(p, ws, mw != nullptr)) return launch_wt_post_mid(A, S, ws.Tmax, s);
     const int bm = tile_rows(ws);
     return bm == 16 ? post_mid_bm<16>(p, ws, A, S, s) : bm == 32 ? post_mid_bm<32>(p, ws, A, S, s) : post_mid_bm<64>(p, ws, A, S, s);
 }
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const PostArgs A = make_post_args(p, ws, layer, training);
+    if (wave_tiles(p, ws) && !A.stamps) return launch_wt_post_fwd(A, ws.Tmax, s);
     const int bm = tile_rows(ws);
     return bm == 16 ? post_launch_bm<16>(p, ws, A, false, s) : bm == 32 ? post_launch_bm<32>(p, ws, A, false, s) : post_launch_bm<64>(p, ws, A, false, s);
 }
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     const PostArgs A = make_post_args(p, ws, layer, training);
+    if (wave_tiles(p, ws) && wt_bwd_on() && layer + 1 < p->n_layer) return launch_wt_post_bwd(A, ws.Tmax, s);
     const int bm = tile_rows(ws);
     return bm == 16 ? post_launch_bm<16>(p, ws, A, true, s) : bm == 32 ? post_launch_bm<32>(p, ws, A, true, s) : post_launch_bm<64>(p, ws, A, true, s);
 }
@@ -1408,7 +1401,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
 // (layout ln1_w | ln1_b | ln2_w | ln2_b), tiles strided over gridDim.x blocks; block (0, layer 0) also folds the
 // scorer's per-sequence (count, loss) partials into the gradient tail.
 __device__ __forceinline__ void reduce_jobs(const WgradArgs& A, const int layer) {
-    const int T = A.state[DR4SR_STATE_T], ntiles = (T + A.ln_tile_rows - 1) / A.ln_tile_rows, D = A.D;
+    const int T = A.state[DR4SR_STATE_T], ntiles = (T + A.ln_rows[layer] - 1) / A.ln_rows[layer], D = A.D;
     const float* part = A.ln_part + (size_t)layer * A.ln_layer_stride;
     float* g = A.grads + A.o_ln1_w + (size_t)layer * A.layer_stride;
     for (int c = threadIdx.x; c < 4 * D; c += 256) {
@@ -1420,7 +1413,7 @@ __device__ __forceinline__ void reduce_jobs(const WgradArgs& A, const int layer)
     if (blockIdx.x == 0 && layer == 0 && A.score_part) {
         __shared__ float red[512];
         float c = 0.f, l = 0.f;
-        const int nsc = A.score_tiles ? ntiles : A.B;             // per-tile partials (fused last layer) or per-sequence
+        const int nsc = A.score_tiles ? (T + A.ln_tile_rows - 1) / A.ln_tile_rows : A.B;      // per-tile partials (fused last layer) or per-sequence
         for (int b = threadIdx.x; b < nsc; b += 256) { c += A.score_part[2 * b]; l += A.score_part[2 * b + 1]; }
         red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
         lds_barrier();
@@ -1736,7 +1729,7 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
     return DR4SR_LAUNCH_CHECK();
 }
 
-int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb) {
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb, bool meta) {
     WgradArgs A;
     const int D = p->D, F = p->F;
     float* G = p->grads;
@@ -1763,7 +1756,10 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     }
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.training = training;
     const int ntiles = (ws.Tmax + 63) / 64;
-    A.ln_part = ws.ln_part; A.ln_layer_stride = (int64_t)((ws.Tmax + 15) / 16) * 4 * D; A.grads = G; A.ln_tile_rows = tile_rows(ws);
+    A.ln_part = ws.ln_part; A.ln_layer_stride = (int64_t)((ws.Tmax + 15) / 16) * 4 * D; A.grads = G; A.ln_tile_rows = with_score == 2 ? mid_tile_rows(p, ws, meta) : tile_rows(ws);
+    // per-layer partial rows: the wave-tile backward (layers below the last, fused step) leaves one row per 16 tokens
+    for (int l = 0; l < p->n_layer; ++l)
+        A.ln_rows[l] = (l + 1 < p->n_layer && wave_tiles(p, ws) && wt_bwd_on()) ? 16 : A.ln_tile_rows;
     A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
     A.score_tiles = with_score == 2;
@@ -1797,7 +1793,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
         const int logG = owner_logG(p);
         A.ow_on = 1; A.ow_logG = logG; A.ow_rpo = (p->n_items + (1 << logG) - 1) >> logG; A.ow_planes = ((1 << logG) + gw - 1) / gw;
         A.ow_rec = with_score == 2 ? ws.de_rec : nullptr; A.ow_idx32 = ws.idx32; A.ow_z = ws.X[p->n_layer];
-        if (with_score == 2 && owner_sorted(p, ws)) { A.ow_ent = ws.de_ent; A.ow_off = ws.de_off; }
+        if (with_score == 2 && owner_sorted(p, ws, meta)) { A.ow_ent = ws.de_ent; A.ow_off = ws.de_off; }
     }
     dim3 grid(gw, (scatter ? 8 : 7) + A.ow_planes, p->n_layer + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D + 16);

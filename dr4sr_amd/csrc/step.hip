@@ -96,7 +96,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
     ws->dctx = take(Tmax * D);
     ws->de_rec = (int4*)take(Tmax * 4); ws->idx32 = (int*)take(Tmax);
-    ws->de_ent = (int4*)take(Tmax * 12); ws->de_off = (unsigned char*)take((Tmax / 32 + 1) * 257);
+    ws->de_ent = (int4*)take(Tmax * 12); ws->de_off = (unsigned char*)take((Tmax / 16 + 1) * 257);     // [tiles of >= 16 tokens][G + 4 <= 1028 bytes]
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
     ws->score_part = take(2LL * (p->B > (Tmax + 15) / 16 ? p->B : (Tmax + 15) / 16));   // per sequence, or per token tile (fused last layer)
@@ -310,7 +310,7 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
 }
 
 static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s,
-                           bool mid_fused = false) {
+                           bool mid_fused = false, bool meta = false) {
     for (int l = p->n_layer - 1; l >= 0; --l) {
         if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_bwd(p, ws, l, training, s));
         RC(attn_bwd(p, ws, l, training, s));
@@ -318,7 +318,7 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
     }
     if (getenv("DR4SR_NO_FUSE")) RC(launch_embed_bwd(p, ws, training, s));
     else if (!qeb_in_wgrad(ws)) RC(launch_qkv_embed_bwd(p, ws, training, s));
-    RC(launch_wgrad(p, ws, training, with_score, s, !getenv("DR4SR_NO_FUSE")));
+    RC(launch_wgrad(p, ws, training, with_score, s, !getenv("DR4SR_NO_FUSE"), meta));
     return 0;
 }
 
@@ -355,7 +355,7 @@ static int fwd_bwd_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weig
     if (!prepared) RC(launch_prep(plan, ws, 1, 1, s));
     RC(forward_layers(plan, ws, 1, s, true));
     RC(launch_post_mid(plan, ws, 1, s, mw));
-    RC(backward_layers(plan, ws, 1, 2, s, true));
+    RC(backward_layers(plan, ws, 1, 2, s, true, true));
     return 0;
 }
 extern "C" int dr4sr_sasrec_fwd_bwd_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, void* stream) {
@@ -463,7 +463,7 @@ extern "C" int dr4sr_sasrec_launch_kernel_weighted(const dr4sr_sasrec_plan* plan
         case DR4SR_K_EMBQKV_FWD: return launch_embqkv_fwd(plan, ws, 1, s);
         case DR4SR_K_POST_MID: return launch_post_mid(plan, ws, 1, s, mw);
         case DR4SR_K_QKV_EMBED_BWD: return launch_qkv_embed_bwd(plan, ws, 1, s);
-        case DR4SR_K_WGRAD_FUSED: return launch_wgrad(plan, ws, 1, 2, s, true);
+        case DR4SR_K_WGRAD_FUSED: return launch_wgrad(plan, ws, 1, 2, s, true, mw != nullptr);
         default: return DR4SR_E_ARG;
     }
 }

@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTI
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/sq_$i
   timeout 400 rocprofv3 --pmc $set --kernel-trace -d /tmp/sq_$i -o t -- \
-    python $R/bench.py --steps 6 --warmup 2 --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --batch 8192 > /tmp/sq_$i.log 2>&1
+    python $R/bench.py --steps 6 --warmup 2 --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --batch 8192 $SQ_EXTRA > /tmp/sq_$i.log 2>&1
   db=$(find /tmp/sq_$i -name "*.db" | head -1)
   [ -n "$db" ] && python - "$db" >> $O/sq_pmc_B8192_toys.txt <<'PY'
 import sqlite3, sys, collections
@@ -20,9 +20,9 @@ per = collections.defaultdict(lambda: collections.defaultdict(list))
 for name, did, cn, s in rows:
     per[name][cn].append(s)
 for name, cs in sorted(per.items()):
-    if not any(f in name for f in ("k_post", "k_wgrad", "k_attn", "k_embqkv", "k_qkv_embed")):
+    if not any(f in name for f in ("k_post", "k_wgrad", "k_attn", "k_embqkv", "k_qkv_embed", "k_wt_")):
         continue
-    print(name[:60].ljust(60), " ".join(f"{k}={sum(v)/len(v):.4g}" for k, v in sorted(cs.items())))
+    print(name[:72].ljust(72), " ".join(f"{k}={sum(v)/len(v):.4g}" for k, v in sorted(cs.items())))
 PY
 done
 cat $O/sq_pmc_B8192_toys.txt
