@@ -89,6 +89,19 @@ struct PostArgs {
     const float* up_dqkv; const float* up_in_w; const float* up_du1;   // bwd: dz = up_dqkv W_in(layer+1) + up_du1 instead of reading A.dz
 };
 
+// layer-0 fusions (linear.hip k_embqkv_fwd / k_qkv_embed_bwd and their wave-tile forms)
+struct EmbQkvArgs {
+    const float* E; const float* P; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq; float* X;
+    const float* W; const float* bias; float* QKV; const int* state;
+    int B, L, n_items, training; uint64_t seed; float p;
+    int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
+};
+struct QkvEmbBwdArgs {
+    const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
+    float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
+    float* gout;                 // large batches: masked dx0 rows are stored here and scattered by a job of k_wgrad (overlaps its MFMA work)
+};
+
 // scorer half of the fused last-layer launch (k_post_mid / k_wt_post_mid)
 struct ScoreTileArgs {
     const float* E; float* dE; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq; int64_t* neg_item; float* part;
@@ -135,7 +148,9 @@ bool wt_bwd_on();                               // the backward wave-tile kernel
 int launch_wt_post_fwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_wt_post_bwd(const PostArgs& A, int Tmax, hipStream_t s);     // writes ln_part rows per 16-token tile
 
-int launch_wt_post_mid(const PostArgs& A, const ScoreTileArgs& S, int Tmax, hipStream_t s);   // score_part / entries per 16-token tile
+int launch_wt_post_mid(const PostArgs& A, const ScoreTileArgs& S, int Tmax, hipStream_t s);
+int launch_wt_embqkv_fwd(const EmbQkvArgs& A, int Tmax, hipStream_t s);
+int launch_wt_qkv_embed_bwd(const QkvEmbBwdArgs& A, int Tmax, hipStream_t s);          // gout form only (the scatter is a k_wgrad job)   // score_part / entries per 16-token tile
 
 int ffn_tile_rows(int Tmax);
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);

@@ -122,12 +122,6 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // Layer-0 fusion: the token tile is gathered straight from the item/position tables (a3: sasrec.py:42-48,:61-66 —
 // x = drop(E[idx] + P[pos]), 16 lanes per token, sequence slot by binary search in cu[]) into LDS, written once to X[0]
 // (residual + weight-gradient input) and multiplied by W_in in the same launch.
-struct EmbQkvArgs {
-    const float* E; const float* P; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq; float* X;
-    const float* W; const float* bias; float* QKV; const int* state;
-    int B, L, n_items, training; uint64_t seed; float p;
-    int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
-};
 template <int BM, int D>
 __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     constexpr int N = 3 * D, LDA = D + 4, LPT = D / 4, TPB = 256 / LPT;
@@ -177,6 +171,7 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.W = p->params + poff(ws, 0, P_IN_W); A.bias = p->params + poff(ws, 0, P_IN_B); A.QKV = ws.layer[0].qkv; A.state = p->state;
     A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.idx32 = de_owner_mode(ws) ? ws.idx32 : nullptr;
+    if (wave_tiles(p, ws)) return launch_wt_embqkv_fwd(A, ws.Tmax, s);
 #define EQ(B_) do { if (D == 64) hipLaunchKernelGGL((k_embqkv_fwd<B_, 64>), grid, blk, lds, s, A); \
                     else hipLaunchKernelGGL((k_embqkv_fwd<B_, 128>), grid, blk, lds, s, A); } while (0)
     BM_DISPATCH(bm, EQ);
@@ -1184,11 +1179,6 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // Layer-0 fusion of the backward tail: dx0 = dqkv W_in + du1 stays in LDS and is scattered straight into the tables
 // (a3 backward: g = dx0 * mask_emb; dE[idx] += g except padding_idx 0; dP[pos] += g), 16 lanes per token; dP is first
 // accumulated in LDS and flushed with one atomic per touched element per workgroup.
-struct QkvEmbBwdArgs {
-    const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
-    float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
-    float* gout;                 // large batches: masked dx0 rows are stored here and scattered by a job of k_wgrad (overlaps its MFMA work)
-};
 template <int BM, int D>
 __device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const int t0, const int T) {
     constexpr int K = 3 * D, LDA = K + 4, LDC = D + 4, LPT = D / 4, TPB = 256 / LPT;
@@ -1288,6 +1278,7 @@ int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int tr
     const size_t lds = sizeof(float) * (bm * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D + bm);
     dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
     const QkvEmbBwdArgs A = make_qeb_args(p, ws, training);
+    if (wave_tiles(p, ws) && wt_bwd_on() && A.gout) return launch_wt_qkv_embed_bwd(A, ws.Tmax, s);
 #define QE(B_) do { if (D == 64) { big_lds(k_qkv_embed_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 64>), grid, blk, lds, s, A); } \
                     else { big_lds(k_qkv_embed_bwd<B_, 128>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 128>), grid, blk, lds, s, A); } } while (0)
     BM_DISPATCH(bm, QE);

@@ -735,6 +735,84 @@ __global__ __launch_bounds__(WT_WAVES * 64) void k_wt_post_mid(const PostArgs A,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ layer-0 fusions, wave tiles
+// k_embqkv_fwd: x = drop(E[idx] + P[pos]) gathered straight into registers (a3: sasrec.py:42-48,:61-66), written once to X[0], and
+// multiplied by W_in in the same pass.  LDS: the in_proj image only (55 KB).
+template <int D, int WT_WAVES>
+__global__ __launch_bounds__(WT_WAVES * 64) void k_wt_embqkv_fwd(const EmbQkvArgs A) {
+    typedef WtImg<true, 3 * D, D> In;
+    constexpr int DT = D / 16, QT = 3 * D / 16;
+    const int T = A.state[DR4SR_STATE_T];
+    if ((int)blockIdx.x * 16 >= T) return;
+    char* lds = reinterpret_cast<char*>(smem);
+    float* vec = reinterpret_cast<float*>(lds + In::bytes);
+    In::load(lds, A.W);
+    wt_load_v(vec, A.bias, 3 * D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+#pragma unroll 1
+    for (int tile = w * (int)gridDim.x + (int)blockIdx.x; tile * 16 < T; tile += (int)gridDim.x * WT_WAVES) {
+        const int oz = wt_opaque_zero();
+        const int t = tile * 16 + r16;
+        const bool ok = t < T;
+        const int tt = ok ? t : T - 1;
+        const int b = find_seq_from(A.cu, A.B, tt, A.tile_seq[tile]), pos = tt - A.cu[b];
+        const int64_t row = A.rows ? A.rows[b] : b;
+        int64_t id = A.idx[row * A.L + pos];
+        if (A.idx32 && ok && g == 0) A.idx32[t] = (id > 0 && id < A.n_items) ? (int)id : 0;      // as the backward's scatter tests it
+        id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
+        f32x4 x[DT], pe[DT];
+        wt_row_load<D>(x, A.E + (size_t)id * D, g);
+        wt_row_load<D>(pe, A.P + (size_t)pos * D, g);
+#pragma unroll
+        for (int j = 0; j < DT; ++j) x[j] += pe[j];
+        if (dodrop) wt_row_drop<D>(x, rk, DR4SR_SITE_EMB, ((uint64_t)b * A.L + pos) * D, g);
+        if (ok) wt_row_store<D>(A.X + (size_t)t * D, x, g);
+        f32x4 q[QT];
+#pragma unroll
+        for (int j = 0; j < QT; ++j) q[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        In::gemm(lds + oz, x, q);
+        f32x4 bias[QT];
+        wt_row_load<3 * D>(bias, vec + oz, g);
+#pragma unroll
+        for (int j = 0; j < QT; ++j) q[j] += bias[j];
+        if (ok) wt_row_store<3 * D>(A.QKV + (size_t)t * 3 * D, q, g);
+    }
+}
+
+// k_qkv_embed_bwd (at-scale form): dx0 = dqkv W_in + du1, times the embedding-stage dropout mask, stored for k_wgrad's scatter / owner job
+template <int D, int WT_WAVES>
+__global__ __launch_bounds__(WT_WAVES * 64) void k_wt_qkv_embed_bwd(const QkvEmbBwdArgs A) {
+    typedef WtImg<true, 3 * D, D> In;
+    constexpr int DT = D / 16, QT = 3 * D / 16;
+    const int T = A.state[DR4SR_STATE_T];
+    if ((int)blockIdx.x * 16 >= T) return;
+    char* lds = reinterpret_cast<char*>(smem);
+    In::load(lds, A.W);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+#pragma unroll 1
+    for (int tile = w * (int)gridDim.x + (int)blockIdx.x; tile * 16 < T; tile += (int)gridDim.x * WT_WAVES) {
+        const int oz = wt_opaque_zero();
+        const int t = tile * 16 + r16;
+        const bool ok = t < T;
+        const int tt = ok ? t : T - 1;
+        f32x4 dq[QT], gx[DT];
+        wt_row_load<3 * D>(dq, A.dQKV + (size_t)tt * 3 * D, g);
+        wt_row_load<D>(gx, A.dU1 + (size_t)tt * D, g);
+        wt_gemm_xw<3 * D, D>(lds + oz, dq, gx);
+        if (dodrop) {
+            const int b = find_seq_from(A.cu, A.B, tt, A.tile_seq[tile]), pos = tt - A.cu[b];
+            wt_row_drop<D>(gx, rk, DR4SR_SITE_EMB, ((uint64_t)b * A.L + pos) * D, g);
+        }
+        if (ok) wt_row_store<D>(A.gout + (size_t)t * D, gx, g);
+    }
+}
+
 int wt_grid() {                                             // one workgroup per CU
     static int n = 0;
     if (!n) {
@@ -780,6 +858,21 @@ int wt_post_mid_launch(const PostArgs& A, const ScoreTileArgs& S, int grid, hipS
     return DR4SR_LAUNCH_CHECK();
 }
 
+template <int W>
+int wt_embqkv_launch(const EmbQkvArgs& A, int grid, hipStream_t s) {
+    const size_t lds = WtImg<true, 192, 64>::bytes + 4 * 192;
+    big_lds(k_wt_embqkv_fwd<64, W>, lds);
+    hipLaunchKernelGGL((k_wt_embqkv_fwd<64, W>), dim3(grid), dim3(W * 64), lds, s, A);
+    return DR4SR_LAUNCH_CHECK();
+}
+template <int W>
+int wt_qeb_launch(const QkvEmbBwdArgs& A, int grid, hipStream_t s) {
+    const size_t lds = WtImg<true, 192, 64>::bytes;
+    big_lds(k_wt_qkv_embed_bwd<64, W>, lds);
+    hipLaunchKernelGGL((k_wt_qkv_embed_bwd<64, W>), dim3(grid), dim3(W * 64), lds, s, A);
+    return DR4SR_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 // the wave-tile forms serve the at-scale regime of the d = 64 / FFN 128 encoder (their LDS image of a d = 128 layer does not fit a CU)
@@ -816,4 +909,19 @@ int launch_wt_post_mid(const PostArgs& A, const ScoreTileArgs& S, int Tmax, hipS
     if (grid > tiles) grid = tiles;
     static const int wm = wt_waves("DR4SR_WT_MID_WAVES", 8);
     return wm == 16 ? wt_post_mid_launch<16>(A, S, grid, s) : wm == 12 ? wt_post_mid_launch<12>(A, S, grid, s) : wt_post_mid_launch<8>(A, S, grid, s);
+}
+
+int launch_wt_embqkv_fwd(const EmbQkvArgs& A, int Tmax, hipStream_t s) {
+    int grid = wt_grid();
+    const int tiles = (Tmax + 15) / 16;
+    if (grid > tiles) grid = tiles;
+    static const int W = wt_waves("DR4SR_WT_EMB_WAVES", 16);
+    return W == 16 ? wt_embqkv_launch<16>(A, grid, s) : W == 12 ? wt_embqkv_launch<12>(A, grid, s) : wt_embqkv_launch<8>(A, grid, s);
+}
+int launch_wt_qkv_embed_bwd(const QkvEmbBwdArgs& A, int Tmax, hipStream_t s) {
+    int grid = wt_grid();
+    const int tiles = (Tmax + 15) / 16;
+    if (grid > tiles) grid = tiles;
+    static const int W = wt_waves("DR4SR_WT_EMB_WAVES", 16);
+    return W == 16 ? wt_qeb_launch<16>(A, grid, s) : W == 12 ? wt_qeb_launch<12>(A, grid, s) : wt_qeb_launch<8>(A, grid, s);
 }
