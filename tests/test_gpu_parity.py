@@ -434,10 +434,18 @@ def test_topk_vs_golden(dev, golden_dir, name):
     np.testing.assert_allclose(O.ndcg_at(hit, 20).numpy(), g["eval.ndcg@20"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,N,k,Lh", [(37, 50, 100, 20), (130, 2000, 20, 50), (64, 11925, 100, 50), (33, 3000, 100, 7), (40, 20034, 100, 50)])
-def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
-    """dr4sr_full_score_topk_ws (MFMA score GEMM + radix select) returns what the per-row arg-max kernel returns: same ids wherever the
-    scores are not within rounding of each other, scores of the returned ids, order, -inf handling (PAD, history, k > valid items)"""
+@pytest.mark.parametrize("B,N,k,Lh", [(37, 50, 100, 20), (130, 2000, 20, 50), (64, 11925, 100, 50), (33, 3000, 100, 7), (40, 20034, 100, 50),
+                                      (48, 6000, 100, 50), (70, 4096, 128, 50)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_topk_workspace_path_equals_per_row_path(dev, monkeypatch, B, N, k, Lh, fused):
+    """dr4sr_full_score_topk_ws returns what the per-row arg-max kernel returns: same ids wherever the scores are not within rounding of
+    each other, scores of the returned ids, order, -inf handling (PAD, history, k > valid items).  fused (DR4SR_TOPK_FUSED, catalogs of
+    >= 4 096 items): subset bound -> filtered emission -> wave-per-row candidate select instead of the [B, N] score matrix; N = 6000
+    carries a 5 400-way tie at the top of every other row: the candidate buffers overflow and the batch falls back to the two kernels."""
+    if fused:
+        if N < 4096:
+            pytest.skip("the fused form serves catalogs of >= 4096 items")
+        monkeypatch.setenv("DR4SR_TOPK_FUSED", "1")
     from dr4sr_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(B + N)
@@ -445,8 +453,8 @@ def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
     E = (0.1 * torch.randn(N, 64, generator=g)).to(dev)
     E[0] = 0
     E[5] = E[7]                                                      # an exact tie: lower id first
-    if N == 3000:
-        E[100:2500] = E[100]                                         # 2400-way tie: the candidate set overflows -> exact radix path
+    if N in (3000, 6000):
+        E[100:N - 500] = E[100]                                      # 2400- / 5400-way tie: the candidate set overflows -> exact radix path
         q[::2] = E[100] * 50                                         # ... and it sits at the top for every other row
     hist = torch.randint(0, N, (B, Lh), generator=g).to(dev)
     outs = []
@@ -484,10 +492,13 @@ def test_topk_workspace_path_equals_per_row_path(dev, B, N, k, Lh):
             assert int(ib[r, pos[0]]) == 5 and pos[1] == pos[0] + 1
 
 
-def test_topk_workspace_path_large_catalog(dev):
+@pytest.mark.parametrize("fused", [False, True])
+def test_topk_workspace_path_large_catalog(dev, monkeypatch, fused):
     """N = 70 000 items: beyond what fits an LDS row — the selection reads the score workspace directly (history masked in place)"""
     from dr4sr_amd import _lib
     lib = _lib.load()
+    if fused:
+        monkeypatch.setenv("DR4SR_TOPK_FUSED", "1")
     B, N, k, Lh = 24, 70000, 100, 50
     g = torch.Generator().manual_seed(12)
     q = torch.randn(B, 64, generator=g).to(dev)
