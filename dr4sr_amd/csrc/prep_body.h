@@ -85,8 +85,12 @@ __device__ __forceinline__ void prep_phase1(const PrepArgs& P, const int blk, co
     if (threadIdx.x == 0) { prep_pub(pre + 2 * (size_t)(B + blk), carry); prep_pub(pre + 2 * (size_t)(B + blk) + 1, carry2); }
 }
 
+// wg / nwg: the per-sequence part is strided over nwg workgroups (k_prep_phase2: a launch of its own spread over the device — as the tail
+// of the optimizer launch, on ONE workgroup, it was 22 us of a B = 8 192 step and 68 us of a B = 32 768 step: one CU's scattered-store
+// rate); every workgroup repeats the (cheap) scan of the <= 1 024 totals, workgroup 0 writes the scalars.
 template <int NT>
-__device__ __forceinline__ void prep_phase2(const PrepArgs& P, const int nblk, unsigned long long* part, int4* boff) {
+__device__ __forceinline__ void prep_phase2(const PrepArgs& P, const int nblk, unsigned long long* part, int4* boff, const int wg = 0,
+                                            const int nwg = 1) {
     const int B = P.B, C = (B + nblk - 1) / nblk;
     const unsigned long long* pre = reinterpret_cast<const unsigned long long*>(P.len_buf);
     int* __restrict__ cu = P.cu; int* __restrict__ tile_seq = P.tile_seq; int* __restrict__ seq_class = P.seq_class;
@@ -107,7 +111,7 @@ __device__ __forceinline__ void prep_phase2(const PrepArgs& P, const int nblk, u
     __syncthreads();
     const bool need_row = seq_class != nullptr && (P.sel.perm || rw);
     constexpr int U = 8;                                    // sequences per thread per round: their agent-scope loads fly together (32: no faster — one CU's scattered stores bound this loop)
-    for (int b0 = threadIdx.x; b0 < B; b0 += U * NT) {
+    for (int b0 = wg * U * NT + threadIdx.x; b0 < B; b0 += nwg * U * NT) {
         unsigned long long w0[U], w1[U]; int64_t rowv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -137,6 +141,7 @@ __device__ __forceinline__ void prep_phase2(const PrepArgs& P, const int nblk, u
             }
         }
     }
+    if (wg != 0) return;
     if (P.sel.perm && threadIdx.x == 0) *P.sel.counter = *P.sel.counter + 1;       // every reader of the counter is past its launch's ticket
     if (threadIdx.x == NT - 1) {
         const int T = (int)(carry & 0xffffffffull);

@@ -159,7 +159,7 @@ static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
 // (larger batches): EVERY workgroup first runs its share of the selection + seqlen gather (prep_select: coalesced over the grid,
 // in flight while the Adam loop runs) and the LAST workgroup to finish runs the scan part (prep_body<256, true>) — as a launch of
 // its own the single-workgroup prep of 8 192 sequences cost 41 us per step.
-struct AdamNext { int enable; PrepArgs prep; };
+struct AdamNext { int enable; int phase2_launch; PrepArgs prep; };
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __restrict__ G, float* __restrict__ M,
                                               float* __restrict__ V, int64_t n, int* __restrict__ state, float lr, float b1,
                                               float b2, float eps, float wd, float* __restrict__ loss_log,
@@ -239,10 +239,17 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
             if (next.enable) { G[n] = 0.f; G[n + 1] = 0.f; G[n + 2] = 0.f; G[n + 3] = 0.f; }
         }
     }
-    if (next.enable == 2) {                    // two-phase prep, phase 2: by the last workgroup, from agent-scope loads of what phase 1 published
+    if (next.enable == 2 && !next.phase2_launch) {   // two-phase prep, phase 2: by the last workgroup, from agent-scope loads of what phase 1 published
         __syncthreads();                       // (run right after phase 1 instead, behind an agent-scope fence and a ticket of its own, the
         if (s_last) prep_phase2<256>(next.prep, (int)gridDim.x, part, boff);     //  launch got longer: 32 -> 43 us at B = 8 192)
     }
+}
+
+// phase 2 of the two-phase prep as a launch of its own, spread over the device (round 3): +1 launch boundary, -(one CU's scattered stores)
+__global__ __launch_bounds__(256) void k_prep_phase2(const PrepArgs P, const int nblk) {
+    __shared__ unsigned long long part[256];
+    __shared__ int4 boff[PREP_MAX_BLK];
+    prep_phase2<256>(P, nblk, part, boff, (int)blockIdx.x, (int)gridDim.x);
 }
 
 int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2,
@@ -253,8 +260,17 @@ int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* sta
     if (blocks > cap) blocks = cap;
     AdamNext nx;
     nx.enable = next ? (next->B > 1024 && next->len_buf && blocks <= PREP_MAX_BLK && (next->B + blocks - 1) / blocks < 65536 ? 2 : 1) : 0;
+    nx.phase2_launch = 0;
     if (next) nx.prep = *next; else nx.prep = PrepArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, nullptr};
+    static const bool p2_inline = getenv("DR4SR_PREP2_INLINE") != nullptr;      // cross-check: phase 2 as the tail of the optimizer launch
+    nx.phase2_launch = nx.enable == 2 && !p2_inline;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks + (nx.enable == 1 ? 1 : 0)), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx);
+    if (nx.phase2_launch) {
+        const int B = next->B, per = 8 * 256;
+        int g2 = (B + per - 1) / per;
+        if (g2 > 256) g2 = 256;
+        hipLaunchKernelGGL(k_prep_phase2, dim3(g2), dim3(256), 0, s, nx.prep, (int)blocks);
+    }
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s, const PrepArgs* next) {

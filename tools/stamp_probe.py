@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 Tmax = B * L
 r = lambda nfl: (nfl * 4 + 255) // 256 * 256
-off = r(B + 1) + r((Tmax + 15) // 16 + 1) + r(4 + 7 * B) + r(B) + r(Tmax * H) + 2 * (NL + 1) * r(Tmax * D)      # csrc/step.hip carve_workspace: ... -> dctx
+off = r(B + 1) + r((Tmax + 15) // 16 + 1) + r(4 + 7 * B) + r(4 * B + 4 * 1024) + r(Tmax * H) + 2 * (NL + 1) * r(Tmax * D)      # csrc/step.hip carve_workspace: ... -> dctx
 os.environ["DR4SR_STAMPS"] = "1"
 for kind, layer in (("post_fwd", 0), ("post_fwd", 1)):
     kid = _lib.KERNEL_IDS[kind]
