@@ -165,7 +165,7 @@ __device__ __forceinline__ void attn_fwd_compute(const AttnArgs2& A, const int b
         for (int jt = 0; jt < MT; ++jt)
             if (jt <= it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
+                for (int r = 0; r < 4; ++r) { const float e = __expf(s[jt][r] - m); s[jt][r] = e; sum += e; }
         sum = xgroup_sum(sum);
         const float inv = 1.0f / sum;
         if (g == 0 && i < n) { float* st = A.stat + ((size_t)(t0 + i) * H + h) * 2; st[0] = m; st[1] = inv; }
@@ -338,7 +338,7 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnArgs2& A, const int b
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int j = jt * 16 + 4 * g + r;
-                        const float p = (j <= i && j < n && !kpad[j]) ? expf(s[r] * scale - mi) * inv : 0.f;
+                        const float p = (j <= i && j < n && !kpad[j]) ? __expf(s[r] * scale - mi) * inv : 0.f;
                         ds[jt][r] = p * (dp[r] * mkv[r] - rdot) * scale;   // dS^T[j][i]
                     }
                 }
@@ -386,7 +386,7 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnArgs2& A, const int b
                     float p = 0.f, mkv = 1.f, rd = 0.f;
                     if (i < n) {
                         const float* st = stat + (h * ROWS + i) * 3;
-                        if (jok && j <= i) p = expf(s[r] * scale - st[0]) * st[1];
+                        if (jok && j <= i) p = __expf(s[r] * scale - st[0]) * st[1];
                         rd = st[2];
                         if (dodrop) mkv = drop1(rk, site, ((uint64_t)(b * H + h) * 64 + i) * 64 + j);
                     }

@@ -156,7 +156,7 @@ __device__ __forceinline__ void fwd_body(const AttnArgs2& A, const int bid) {
     if (!act) m = 0.f;
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) { s[j] = expf(s[j] - m); sum += s[j]; }
+    for (int j = 0; j < NMAX; ++j) { s[j] = __expf(s[j] - m); sum += s[j]; }
     const float inv = act ? 1.0f / sum : 0.f;
     if (act) { float* st = A.stat + ((size_t)(t0 + i) * H + h) * 2; st[0] = m; st[1] = inv; }
     float o[DH];
@@ -225,7 +225,7 @@ __device__ __forceinline__ void bwd_body(const AttnArgs2& A, const int bid) {
             if (j < nmax) {
                 const float sc = dot_row<DH>(q, Kr + j * LD) * scale;
                 const float dp = dot_row<DH>(cf, Vr + j * LD);
-                const float p = (act && j <= i && !((padmask >> j) & 1u)) ? expf(sc - mi) * inv : 0.f;
+                const float p = (act && j <= i && !((padmask >> j) & 1u)) ? __expf(sc - mi) * inv : 0.f;
                 ds = p * (dp * mk[j] - rdot) * scale;
                 pt = p * mk[j];
                 axpy_row<DH>(dq, ds, Kr + j * LD);
