@@ -132,6 +132,7 @@ struct WgradArgs {
     int ln_tile_rows;                          // token rows per tile of the LAST layer's post kernel (LayerNorm partials, owner-sorted entries)
     int ln_rows[DR4SR_MAX_LAYERS];             // token rows per LayerNorm-partial row, per layer (wave-tile kernels: 16)
     int qeb_plane;                             // 1: grid plane z = 0 runs the embedding-stage backward tiles, layers are z - 1
+    int bf16x3;                                // 1: weight-gradient GEMMs as a 3-term bf16 split (wgrad_body_bf)
     const float* fc_dm; int64_t fc_o_cw; int fc_L;     // FMLP: filter-coefficient backward as part of the reduce blocks (fc_dm == NULL: none)
     // embedding scatter job (blockIdx.y == 7, large batches; sc_g == NULL: none)
     const float* sc_g; const int64_t* sc_idx; const int64_t* sc_rows; const int* sc_tile_seq; const int* cu;

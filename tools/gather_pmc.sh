@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM bytes of the K1 gather microbench: two PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) -> gpurun_out/r<ROUND>/gather_pmc_raw.txt
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-2}; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-3}; mkdir -p $O
 : > $O/gather_pmc_raw.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pg_$c

@@ -2,14 +2,14 @@
 # Where do the waves of the at-scale step kernels spend their cycles?  Several --pmc passes (4 counters each) over the B = 8192 toys bench
 # -> gpurun_out/r<ROUND>/sq_pmc_B8192_toys.txt  (per kernel: mean per dispatch of each counter, summed over SEs / XCCs)
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-2}; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-3}; mkdir -p $O
 : > $O/sq_pmc_B8192_toys.txt
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/sq_$i
-  timeout 400 rocprofv3 --pmc $set --kernel-trace -d /tmp/sq_$i -o t -- \
+  timeout 300 rocprofv3 --pmc $set --kernel-trace -d /tmp/sq_$i -o t -- \
     python $R/bench.py --steps 6 --warmup 2 --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --batch 8192 $SQ_EXTRA > /tmp/sq_$i.log 2>&1
   db=$(find /tmp/sq_$i -name "*.db" | head -1)
   [ -n "$db" ] && python - "$db" >> $O/sq_pmc_B8192_toys.txt <<'PY'
