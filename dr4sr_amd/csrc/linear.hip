@@ -1751,8 +1751,8 @@ __device__ __forceinline__ void owner_job_sorted(const WgradArgs& A, const int o
 
 // blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2, 6: reductions; with the embedding scatter: y = 0 is the scatter
 // [layer 0 only] and the others shift by one), blockIdx.z = layer
-template <int D, int F>
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A, const QkvEmbBwdArgs Q) {
+template <int D, int F, bool BF>
+__device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvEmbBwdArgs& Q) {
     // latency regime (A.qeb_plane): plane z = 0 of the grid is k_qkv_embed_bwd's work (16-row tiles, block-strided), layers shift by one
     const int layer = A.qeb_plane ? (int)blockIdx.z - 1 : (int)blockIdx.z;
     if (layer < 0) {
@@ -1774,16 +1774,22 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A, const QkvEmbBw
     if (j < 0) { if (layer == 0) scatter_job<D>(A); return; }
     if (j == 6) { reduce_jobs(A, layer); return; }
     const WgradJob& J = A.job[layer * 6 + j];
-    if (A.bf16x3) {
+    if constexpr (BF) {
         if (j < 4) wgrad_body_bf<D, D>(J, A);
         else if (j == 4) wgrad_body_bf<F, D>(J, A);
         else wgrad_body_bf<D, F>(J, A);
-        return;
+    } else {
+        if (j < 4) wgrad_body<D, D>(J, A);
+        else if (j == 4) wgrad_body<F, D>(J, A);
+        else wgrad_body<D, F>(J, A);
     }
-    if (j < 4) wgrad_body<D, D>(J, A);
-    else if (j == 4) wgrad_body<F, D>(J, A);
-    else wgrad_body<D, F>(J, A);
 }
+template <int D, int F>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, false>(A, Q); }
+// the at-scale form with the weight-gradient GEMMs on the bf16 matrix cores (a separate kernel: its registers must not weigh on the fp32 one)
+template <int D, int F>
+__global__ __launch_bounds__(256) void k_wgrad_bf(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, true>(A, Q); }
+
 
 // ---- FMLP: weight gradients of the Intermediate blocks (dense_1, dense_2) + LayerNorm / scorer partial reductions
 __device__ __forceinline__ void reduce_jobs_fmlp(const WgradArgs& A) {
@@ -1921,9 +1927,12 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     dim3 grid(gw, (scatter ? 8 : 7) + A.ow_planes, p->n_layer + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D + 16);
     if (A.qeb_plane && lds_q > lds) lds = lds_q;
-    if (D == 64 && F == 128) { big_lds(k_wgrad<64, 128>, lds); hipLaunchKernelGGL((k_wgrad<64, 128>), grid, blk, lds, s, A, Q); }
-    else if (D == 128 && F == 128) { big_lds(k_wgrad<128, 128>, lds); hipLaunchKernelGGL((k_wgrad<128, 128>), grid, blk, lds, s, A, Q); }
-    else if (D == 64 && F == 256) { big_lds(k_wgrad<64, 256>, lds); hipLaunchKernelGGL((k_wgrad<64, 256>), grid, blk, lds, s, A, Q); }
+#define WG(D_, F_) do { if (A.bf16x3) { big_lds(k_wgrad_bf<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_bf<D_, F_>), grid, blk, lds, s, A, Q); } \
+                        else { big_lds(k_wgrad<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad<D_, F_>), grid, blk, lds, s, A, Q); } } while (0)
+    if (D == 64 && F == 128) WG(64, 128);
+    else if (D == 128 && F == 128) WG(128, 128);
+    else if (D == 64 && F == 256) WG(64, 256);
     else return DR4SR_E_SHAPE;
+#undef WG
     return DR4SR_LAUNCH_CHECK();
 }
