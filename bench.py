@@ -151,6 +151,20 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
                                 "frac_of_ceiling": ach / ceil_tf,
                                 "hbm_rate": ab / (ktime[dom] * 1e-6) / 1e9, "hbm_frac": ab / (ktime[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS})
     out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
+    # the token-tile kernels against BOTH roofs: at scale they are bound by the saved-activation stream (HBM), not by the matrix pipe
+    both = {}
+    for k, us in ktime.items():
+        kb = kernel_bytes(k, T_last, D, F, NL)
+        if kb is None:
+            continue
+        fk = kernel_flops(k, T_last, B, L, D, F, NL, seqlen_last, big)
+        both[k] = {"us_per_launch": round(us, 2), "hbm_frac": round(kb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                   "mfma_f32_frac": round(fk / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4), "algorithmic_bytes": kb}
+    out["roofline_tile_kernels"] = both
+    if dom in both and both[dom]["hbm_frac"] > out["roofline"]["frac"]:
+        r = out["roofline"]
+        r.update({"bound": "hbm", "achieved": both[dom]["algorithmic_bytes"] / (ktime[dom] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": both[dom]["hbm_frac"], "mfma_f32_frac": both[dom]["mfma_f32_frac"], "algorithmic_bytes_per_launch": both[dom]["algorithmic_bytes"]})
     return ktime
 
 
@@ -223,6 +237,17 @@ def cpu_baseline_leg(rows_np, N, model_kind, p, interval=30):
                       "rows, anomaly detection ON as utils/utils.py:11 (`anomaly_off_value`: %d steps with it off); %d intra-op threads = "
                       "the best of a 8/16/32 probe; host has %d logical CPUs"
                       % (r["steps"], r["seconds"], what, r_off["steps"], r["threads"], os.cpu_count() or 0)}
+
+
+def kernel_bytes(kind, T, D, F, n_layer):
+    """ALGORITHMIC HBM bytes of one launch of the fused step's token-tile kernels: every saved activation / gradient row the launch has
+    to read or write once, fp32; table rows and weights are cache-resident and not counted."""
+    per = {"post_fwd": 9 * D + 2 * F + 4,                  # ctx, x in; u1, y, a, h, u2, z, next qkv, LayerNorm statistics out
+           "post_bwd": (7 * D + F + 4) + (4 * D + F + 2),  # upper dqkv, du1, u2, a, u1, ctx, statistics in; df, da, du1, dout, dctx, rd out
+           "post_mid": (5 * D + F) + (9 * D + 3 * F),      # forward + backward of the last layer around the scorer
+           "wgrad_fused": (10 * D + 2 * F) * n_layer,      # six (G, X) operand pairs per layer
+           "embqkv_fwd": 4 * D + 3, "qkv_embed_bwd": 5 * D}.get(kind)
+    return None if per is None else 4.0 * per * T
 
 
 def bench_metamodel(args):
