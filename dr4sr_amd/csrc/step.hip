@@ -76,7 +76,10 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         const bool known = hint > 0 && !forced;
         // boundaries measured at d = 64; at d = 128 both crossovers sit at half the token count (4 k / 7 k): the work per token doubles
         ws->scale = known ? hint * D > (int64_t)DR4SR_SCALE_TOKENS * 64 : at_scale((int)Tmax);
-        ws->attn_split = known ? hint * D > (int64_t)DR4SR_ATTN_SPLIT_TOKENS * 64 : at_scale((int)Tmax);
+        // the length-class lists pay off through their short classes (1..8-token VALU class, 16-row tiles); a batch of LONG sequences
+        // runs faster as one 8-wave workgroup per sequence at every size (round 3, all-50 batches: B = 2 048 0.929 vs 0.990 ms,
+        // B = 8 192 3.36 vs 3.62 ms), so the lists also need an expected mean length of at most 16 tokens
+        ws->attn_split = known ? (hint * D > (int64_t)DR4SR_ATTN_SPLIT_TOKENS * 64 && hint <= 16 * (int64_t)p->B) : at_scale((int)Tmax);
         // tests (read per call): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
         if (const char* f = getenv("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
         if (const char* f = getenv("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
