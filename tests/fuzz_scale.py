@@ -16,6 +16,7 @@ for trial in range(int(os.environ.get("TRIALS", "8"))):
     B = int(rng.choice([330, 400, 777, 1500, 3000]))
     N = int(rng.choice([2, 40, 3000, 11925]))
     D = int(rng.choice([64, 128]))
+    NL = int(rng.choice([1, 2, 2, 3]))                               # 1: only the fused last layer; 3: a middle layer with both boundary fusions
     L = 50
     mix = int(rng.integers(0, 4))
     if mix == 0: sl = rng.integers(1, 9, size=B)                       # all tiny
@@ -31,19 +32,19 @@ for trial in range(int(os.environ.get("TRIALS", "8"))):
     neg = rng.integers(1, N, size=(B, L, 1))
     b_ = {"in_item_id": torch.from_numpy(inp), "item_id": torch.from_numpy(tgt), "seqlen": torch.from_numpy(sl.astype(np.int64)),
           "neg_item": torch.from_numpy(neg)}
-    params = _random_params(N, D, 128, 2, L=L, seed=trial)
-    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, 0.0, B, dev)
+    params = _random_params(N, D, 128, NL, L=L, seed=trial)
+    eng = SasrecEngine(N, L, D, 2, 128, NL, 1e-12, 0.0, B, dev)
     eng.load_named(params)
     plan = eng.make_plan(b_["in_item_id"].to(dev), b_["item_id"].to(dev), b_["seqlen"].to(dev),
                          neg_item=b_["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
     eng.fwd_bwd(plan)
     loss, n = eng.loss_and_count()
     nv = int((b_["item_id"] != 0).sum())
-    loss_o, _, grads_o = O.grads_of(params, b_, 2, 2, 1e-12)
+    loss_o, _, grads_o = O.grads_of(params, b_, 2, NL, 1e-12)
     assert n == nv, (n, nv)
     e = abs(loss - float(loss_o))
     g = max(relerr(v, grads_o[k]) for k, v in eng.normalized_grads().items())
     worst = max(worst, g)
-    print("trial %2d B=%4d N=%5d D=%3d mix=%d T=%6d n_valid=%6d  |dloss| %.1e  max grad relerr %.1e" % (trial, B, N, D, mix, int(sl.sum()), nv, e, g))
+    print("trial %2d B=%4d N=%5d D=%3d mix=%d T=%6d n_valid=%6d  |dloss| %.1e  max grad relerr %.1e" % (trial, B, N, D, mix, int(sl.sum()), nv, e, g), "layers", NL)
     assert e < 3e-5 and g < 5e-4
 print("FUZZ-SCALE ok, worst grad relerr %.2e" % worst)

@@ -258,7 +258,7 @@ def test_fuzz_large_batches_vs_oracle():
     11 925 items, both widths, PAD targets, PAD ids inside sequences) through the fused step vs the oracle"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_scale.py")], capture_output=True, text=True, timeout=900,
-                         env=dict(os.environ, TRIALS="8", SEED="5", DR4SR_FORCE_SCALE="1"), cwd=root)
+                         env=dict(os.environ, TRIALS="10", SEED="5", DR4SR_FORCE_SCALE="1"), cwd=root)
     assert out.returncode == 0 and "FUZZ-SCALE ok" in out.stdout, out.stdout[-2500:] + out.stderr[-1500:]
 
 
@@ -284,6 +284,16 @@ _SWITCH_CASES = [
     # two-phase next-step prep with FOUR optimizer workgroups: each owns 512 / 2 250 consecutive sequences, i.e. several 256-sequence
     # rounds with carried totals inside one workgroup (256 workgroups own 8 / 36) — what B > 65 536 does with the default grid
     ({"DR4SR_ADAM_BLOCKS": "4"}, "test_train_steps_equals_repeated_train_step"),
+    # round 3 — the at-scale forms of csrc/linear_wave.hip and their cross-checks, each against the oracle (dropout test included: the
+    # wave tiles draw 8 decisions per Philox call, the 256-thread kernels 4 of the same 8)
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_NO_WAVE_TILES": "1"},
+     "test_full_size_batch_vs_oracle or test_fuzz_odd_batches_vs_oracle or test_fwd_bwd_with_dropout_matches_oracle_with_same_masks"),
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_FWD_ONLY": "1"}, "test_full_size_batch_vs_oracle or test_fwd_bwd_with_dropout_matches_oracle_with_same_masks"),
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WGRAD_F32": "1"}, "test_full_size_batch_vs_oracle or test_training_trajectory_matches_oracle"),
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_BF16X3": "1"}, "test_full_size_batch_vs_oracle or test_fwd_bwd_with_dropout_matches_oracle_with_same_masks"),
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_FWD_WAVES": "16", "DR4SR_WT_BWD_WAVES": "8", "DR4SR_WT_MID_WAVES": "12", "DR4SR_WT_EMB_WAVES": "12"},
+     "test_full_size_batch_vs_oracle or test_fuzz_odd_batches_vs_oracle"),
+    ({"DR4SR_PREP2_INLINE": "1"}, "test_train_steps_equals_repeated_train_step"),
 ]
 
 
