@@ -380,15 +380,23 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnArgs2& A, const int b
                 load_frag<DH>(qf, Cs, LD, it * 16, h * DH);
                 f32x4 dp = mma_rows<DH>(qf, vf);           // dP~[i][j] = sum_d dctx[i][d] V[j][d]
                 f32x4 pt, ds;
+                // dropout decisions of this (query tile, key tile): element (i, j) sits in lane j, rows i = 4 g + r — eight lanes would
+                // each recompute the Philox call that covers (i, 8 keys).  Instead lane j computes ONE call, that of query row
+                // 4 g + (j & 3) and key half (j >> 2) & 1, and the four decisions a lane needs come from its 16-lane row by ds_bpermute
+                // (round 3: one call per lane and tile instead of four — drop1 per element was 60 % of this phase's VALU work).
+                unsigned m8 = 0xffu;
+                if (dodrop)
+                    m8 = drop_bits8(rk, site, ((uint64_t)(b * H + h) * 64 + (it * 16 + 4 * g + (i16 & 3))) * 64 + jt * 16 + 8 * ((i16 >> 2) & 1));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = it * 16 + 4 * g + r;
                     float p = 0.f, mkv = 1.f, rd = 0.f;
+                    const unsigned mm = __shfl(m8, (lane & 48) | (r + 4 * (i16 >> 3)), 64);
+                    if (dodrop) mkv = ((mm >> (i16 & 7)) & 1u) ? rk.scale : 0.f;
                     if (i < n) {
                         const float* st = stat + (h * ROWS + i) * 3;
                         if (jok && j <= i) p = __expf(s[r] * scale - st[0]) * st[1];
                         rd = st[2];
-                        if (dodrop) mkv = drop1(rk, site, ((uint64_t)(b * H + h) * 64 + i) * 64 + j);
                     }
                     pt[r] = p * mkv;                       // P~[i][j]
                     ds[r] = p * (dp[r] * mkv - rd) * scale;

@@ -73,6 +73,17 @@ __device__ __forceinline__ float4 drop4(const RngKey& k, uint32_t site, uint64_t
     return make_float4(keep16(k, w0, 0), keep16(k, w0, 1), keep16(k, w1, 0), keep16(k, w1, 1));
 }
 
+// the 8 keep decisions of the call that covers elements e..e+7 (e % 8 == 0) as a bit mask: bit k = element e + k is kept
+__device__ __forceinline__ unsigned drop_bits8(const RngKey& k, uint32_t site, uint64_t e) {
+    const uint4 r = rng_call(k, site, e >> 3);
+    unsigned m = 0;
+    m |= ((r.x & 0xffffu) >= k.thresh) ? 1u : 0u;   m |= ((r.x >> 16) >= k.thresh) ? 2u : 0u;
+    m |= ((r.y & 0xffffu) >= k.thresh) ? 4u : 0u;   m |= ((r.y >> 16) >= k.thresh) ? 8u : 0u;
+    m |= ((r.z & 0xffffu) >= k.thresh) ? 16u : 0u;  m |= ((r.z >> 16) >= k.thresh) ? 32u : 0u;
+    m |= ((r.w & 0xffffu) >= k.thresh) ? 64u : 0u;  m |= ((r.w >> 16) >= k.thresh) ? 128u : 0u;
+    return m;
+}
+
 // keep factor of a single element (recomputes the shared call; use only off the hot path)
 __device__ __forceinline__ float drop1(const RngKey& k, uint32_t site, uint64_t e) {
     const uint4 r = rng_call(k, site, e >> 3);
