@@ -119,6 +119,35 @@ __device__ __forceinline__ SeqMeta seq_final(const SeqRaw& r) {
     return SeqMeta{r.b, c0, c1 - c0, (int64_t)(((uint64_t)hi << 32) | lo)};
 }
 
+// Dropout keep factors of one query tile's probabilities in the transposed orientation (lane (i, g) holds keys jt * 16 + 4 g + 0..3 of
+// query row i, for every key tile jt <= it).  The four keys of a lane are HALF of a Philox call (16-bit decisions, 8 per call) and lanes
+// g, g ^ 1 would both compute it; with four key tiles, lane (i, g) instead computes the call of key tile 2 round + (g & 1), key half
+// g >> 1, and the 8-bit masks are exchanged inside the lanes of query row i (ds_bpermute): ceil((it + 1) / 2) calls per lane instead of
+// it + 1.  MT == 1 (16-row kernels): one tile, nothing to share.
+template <int MT>
+__device__ __forceinline__ void attn_keep_masks(float4 (&mk)[MT], const RngKey& rk, const uint32_t site, const uint64_t ebase, const int it,
+                                                const int lane, const bool dodrop) {
+    const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) mk[jt] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (!dodrop) return;
+    if constexpr (MT == 1) { mk[0] = drop4(rk, site, ebase + 4 * g); return; }
+    else {
+#pragma unroll
+        for (int rnd = 0; rnd < MT / 2; ++rnd) {
+            if (2 * rnd <= it) {                            // wave-uniform
+                const unsigned m8 = drop_bits8(rk, site, ebase + (2 * rnd + (g & 1)) * 16 + 8 * (g >> 1));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int jt = 2 * rnd + q;
+                    const unsigned mm = __shfl(m8, i16 | ((2 * (g >> 1) + q) << 4), 64) >> (4 * (g & 1));
+                    mk[jt] = make_float4((mm & 1u) ? rk.scale : 0.f, (mm & 2u) ? rk.scale : 0.f, (mm & 4u) ? rk.scale : 0.f, (mm & 8u) ? rk.scale : 0.f);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // K, V and the key-padding flags of the sequence are in LDS (and a barrier has passed)
 template <int DH, int ROWS, int NT>
@@ -170,11 +199,12 @@ __device__ __forceinline__ void attn_fwd_compute(const AttnArgs2& A, const int b
         const float inv = 1.0f / sum;
         if (g == 0 && i < n) { float* st = A.stat + ((size_t)(t0 + i) * H + h) * 2; st[0] = m; st[1] = inv; }
         const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
+        float4 mkt[MT];
+        attn_keep_masks<MT>(mkt, rk, site, ebase, it, lane, dodrop);
 #pragma unroll
         for (int jt = 0; jt < MT; ++jt)
             if (jt <= it) {
-                float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
+                const float4 mk = mkt[jt];
                 s[jt][0] *= inv * mk.x; s[jt][1] *= inv * mk.y; s[jt][2] *= inv * mk.z; s[jt][3] *= inv * mk.w;
             }
         // out^T[d][i] = sum_j V[j][d] P~[i][j]
@@ -323,6 +353,8 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnArgs2& A, const int b
             const float mi = sti[0], inv = sti[1], rdot = sti[2];
             const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
             f32x4 ds[MT];
+            float4 mkt[MT];
+            attn_keep_masks<MT>(mkt, rk, site, ebase, it, lane, dodrop);
 #pragma unroll
             for (int jt = 0; jt < MT; ++jt)
                 if (jt <= it) {
@@ -332,8 +364,7 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnArgs2& A, const int b
                     if constexpr (VLDS) load_frag<DH>(kf, Vs, LD, jt * 16, h * DH);
                     else load_frag_g<DH>(kf, src + 2 * D + h * DH, 3 * D, jt * 16, n);
                     const f32x4 dp = mma_rows<DH>(kf, cf);         // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
-                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (dodrop) mk = drop4(rk, site, ebase + jt * 16 + 4 * g);
+                    const float4 mk = mkt[jt];
                     const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
