@@ -190,13 +190,31 @@ def gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, Hh, NLg, step_s):
             b.synchronize()
             tot += a.elapsed_time(b) * 1e3 / reps
         ktime[name] = tot / NLg                              # us per launch, mean over the layers
+    # two-layer plans: both forward recurrences (and layer 2's input projection) are ONE launch, the layer wavefront of csrc/gru_coop.hip
+    wave = bool(lib.dr4sr_gru4rec_uses_wavefront(int(plan.B), Hh, NLg, int(plan.L)))
+    if wave:
+        for _ in range(3):
+            launch(3, 0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            launch(3, 0)
+        b.record()
+        b.synchronize()
+        ktime["rec_fwd_one_launch_per_layer"] = ktime["rec_fwd"]
+        ktime["rec_fwd"] = a.elapsed_time(b) * 1e3 / reps / NLg          # per layer, as the other entries
     dom = "rec_bwd" if ktime["rec_bwd"] >= ktime["rec_fwd"] else "rec_fwd"
     fl = 2.0 * T_last * 3 * Hh * Hh
     ach = fl / (ktime[dom] * 1e-6) / 1e12
     coop = bool(lib.dr4sr_gru4rec_uses_cooperative(int(plan.B), Hh))
-    out["roofline"] = {"kernel": ("k_gru_%s_coop" if coop else "k_gru_%s") % ("bwd" if dom == "rec_bwd" else "fwd"), "bound": "mfma",
+    if wave and dom == "rec_fwd":                           # the one-launch forward: 2 recurrent GEMMs + layer 2's input GEMM, whole launch
+        fl, ktime_dom, nlaunch, kname = 3.0 * fl, ktime[dom] * NLg, 1, "k_gru_fwd_wave"
+        ach = fl / (ktime_dom * 1e-6) / 1e12
+    else:
+        ktime_dom, nlaunch, kname = ktime[dom], NLg, ("k_gru_%s_coop" if coop else "k_gru_%s") % ("bwd" if dom == "rec_bwd" else "fwd")
+    out["roofline"] = {"kernel": kname, "bound": "mfma",
                        "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                       "traffic_source": None, "us_per_launch": ktime[dom], "flops_per_launch": fl, "launches_per_step": NLg,
+                       "traffic_source": None, "us_per_launch": ktime_dom, "flops_per_launch": fl, "launches_per_step": nlaunch,
                        "note": "recurrent GEMM of one layer on the valid tokens; the launch is a chain of max(seqlen) dependent "
                                "time steps (latency-bound, SURVEY §8d), not an MFMA-throughput kernel"}
     per_tok = 3.0 * (2 * 3 * Hh * D + (NLg - 1) * 2 * 3 * Hh * Hh + NLg * 2 * 3 * Hh * Hh + 2 * Hh * D)
@@ -204,6 +222,9 @@ def gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, Hh, NLg, step_s):
                             "frac": per_tok * T_last / step_s / 1e12 / MFMA_F32_PEAK_TF, "flops_per_step": per_tok * T_last,
                             "note": "3 x (input GEMMs + recurrent GEMMs + output projection) on the last batch's valid tokens"}
     out["kernel_us_per_step"] = {k: round(v * NLg, 2) for k, v in ktime.items()}
+    if wave:
+        out["kernel_us_per_step"]["note"] = ("rec_fwd = k_gru_fwd_wave: both layers' forward recurrences + gi_2 in one launch "
+                                             "(gemm_in then only runs for layer 1: half the figure above)")
 
 
 def cpu_baseline_leg(rows_np, N, model_kind, p, interval=30):

@@ -135,6 +135,7 @@ SYMBOLS = {
     "dr4sr_gru4rec_param_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_gru4rec_workspace_bytes": (C.c_int64, [_GPLANP]),
     "dr4sr_gru4rec_uses_cooperative": (C.c_int, [C.c_int32, C.c_int32]),
+    "dr4sr_gru4rec_uses_wavefront": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dr4sr_gru4rec_fwd_bwd": (C.c_int, [_GPLANP, C.c_void_p]),
     "dr4sr_gru4rec_train_step": (C.c_int, [_GPLANP, C.c_void_p]),
     "dr4sr_gru4rec_encode": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),

@@ -133,9 +133,9 @@ __device__ __forceinline__ void fwd_body(const AttnArgs2& A, const int bid) {
         const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
         const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
         const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
-        const float4 m0 = drop4(rk, site, ebase);
-        mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w;
-        if (nmax > 4) { const float4 m1 = drop4(rk, site, ebase + 4); mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w; }
+        float4 m0, m1;                                                         // keys 0..7 of query row i: ONE Philox call
+        drop8(rk, site, ebase, m0, m1);
+        mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
     }
     lds_barrier();
     const float scale = 1.0f / sqrtf((float)DH);
@@ -206,9 +206,9 @@ __device__ __forceinline__ void bwd_body(const AttnArgs2& A, const int bid) {
         const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
         const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
         const uint64_t ebase = ((uint64_t)(b * H + h) * 64 + i) * 64;
-        const float4 m0 = drop4(rk, site, ebase);
-        mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w;
-        if (nmax > 4) { const float4 m1 = drop4(rk, site, ebase + 4); mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w; }
+        float4 m0, m1;                                                         // keys 0..7 of query row i: ONE Philox call
+        drop8(rk, site, ebase, m0, m1);
+        mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
     }
     lds_barrier();
     const float scale = 1.0f / sqrtf((float)DH);

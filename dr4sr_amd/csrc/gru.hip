@@ -26,6 +26,8 @@ int64_t gru_coop_words(int B, int H);
 int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float* r, float* z, float* n, float* ghn, float* hprev,
                         float* hout, const float* dhout, float* dgi, float* dgh, unsigned long long* xch, int* ctl, int B, int H, bool bwd,
                         hipStream_t s);
+int64_t gru_wave_words(int B, int H, int L, int n_layer);
+int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int B, int H, int L, bool bwd, hipStream_t s);
 
 struct GruLayerWs {
     float* gi; float* r; float* z; float* n; float* ghn; float* hprev; float* hout;
@@ -83,7 +85,12 @@ static void gru_carve(const dr4sr_gru4rec_plan* p, GruWs* ws) {
     };
     // control words and granules FIRST: their offsets must not move with B (they hold state that survives across calls)
     ws->ctl = (int*)take(4);
-    { const int64_t words = gru_coop_words(p->B, p->H); ws->xch = words ? (unsigned long long*)take(2 * words) : nullptr; }
+    {
+        int64_t words = gru_coop_words(p->B, p->H);
+        const int64_t ww = gru_wave_words(p->B, p->H, p->L, p->n_layer);       // two-layer wavefront: per-step slots + both layers' rings
+        if (ww > words) words = ww;
+        ws->xch = words ? (unsigned long long*)take(2 * words) : nullptr;
+    }
     ws->cu = (int*)take(p->B + 1);
     ws->X0 = take(Tmax * D); ws->dX0 = take(Tmax * D); ws->Y = take(Tmax * D); ws->dY = take(Tmax * D); ws->dH = take(Tmax * H);
     ws->score_part = take(2LL * p->B);
@@ -510,6 +517,17 @@ __global__ __launch_bounds__(256) void k_sum_score_part(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ orchestration
+static GruWaveArgs wave_args(const dr4sr_gru4rec_plan* p, const GruWs& ws) {
+    GruWaveArgs G{};
+    G.gi1 = ws.layer[0].gi; G.wih2 = p->params + ws.off_wih[1]; G.cu = ws.cu; G.dhout = ws.dH;
+    for (int l = 0; l < 2; ++l) {
+        const GruLayerWs& w = ws.layer[l];
+        G.whh[l] = p->params + ws.off_whh[l];
+        G.r[l] = w.r; G.z[l] = w.z; G.n[l] = w.n; G.ghn[l] = w.ghn; G.hprev[l] = w.hprev; G.hout[l] = w.hout; G.dgi[l] = w.dgi; G.dgh[l] = w.dgh;
+    }
+    return G;
+}
+
 static int gru_forward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int zero_grads, hipStream_t s) {
     const int D = p->D, H = p->H;
     RC(launch_prep_raw(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, training ? 1 : 0, zero_grads ? p->grads : nullptr,
@@ -518,9 +536,18 @@ static int gru_forward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int trainin
                             p->seed, p->p_drop, training, s));
     const float* in = ws.X0;
     int K = D;
+    if (p->n_layer == 2) {                                  // both layers' recurrences in one launch (gru_coop.hip, layer wavefront)
+        RC(launch_gemm(in, K, p->params + ws.off_wih[0], K, nullptr, ws.layer[0].gi, 3 * H, K, 3 * H, false, ws.Tmax, p->state, s));
+        const int rc = launch_gru_wave(wave_args(p, ws), ws.xch, ws.ctl, p->B, H, p->L, false, s);
+        if (rc != -100) {
+            RC(rc);
+            return launch_gemm(ws.layer[1].hout, H, p->params + ws.off_ow, H, p->params + ws.off_ob, ws.Y, D, H, D, false, ws.Tmax, p->state, s);
+        }
+    }
     for (int l = 0; l < p->n_layer; ++l) {
         const GruLayerWs& w = ws.layer[l];
-        RC(launch_gemm(in, K, p->params + ws.off_wih[l], K, nullptr, w.gi, 3 * H, K, 3 * H, false, ws.Tmax, p->state, s));
+        if (!(l == 0 && p->n_layer == 2))                  // (two layers: gi_1 is there already, see above)
+            RC(launch_gemm(in, K, p->params + ws.off_wih[l], K, nullptr, w.gi, 3 * H, K, 3 * H, false, ws.Tmax, p->state, s));
         GruRecArgs A{};
         A.gi = w.gi; A.whh = p->params + ws.off_whh[l]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn;
         A.hprev = w.hprev; A.hout = w.hout; A.B = p->B;
@@ -535,7 +562,16 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     const int D = p->D, H = p->H, nl = p->n_layer;
     // dH_top = dY W_out
     RC(launch_gemm(ws.dY, D, p->params + ws.off_ow, H, nullptr, ws.dH, H, D, H, true, ws.Tmax, p->state, s));
-    for (int l = nl - 1; l >= 0; --l) {
+    int l_top = nl - 1;
+    if (nl == 2) {                                          // both BPTTs in one launch; dh_1 = dgi_2 W_ih2 is formed inside it
+        const int rc = launch_gru_wave(wave_args(p, ws), ws.xch, ws.ctl, p->B, H, p->L, true, s);
+        if (rc != -100) {
+            RC(rc);
+            RC(launch_gemm(ws.layer[0].dgi, 3 * H, p->params + ws.off_wih[0], D, nullptr, ws.dX0, D, 3 * H, D, true, ws.Tmax, p->state, s));
+            l_top = -1;
+        }
+    }
+    for (int l = l_top; l >= 0; --l) {
         const GruLayerWs& w = ws.layer[l];
         GruRecArgs A{};
         A.whh = p->params + ws.off_whh[l]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn; A.hprev = w.hprev;
@@ -632,6 +668,8 @@ extern "C" int dr4sr_gru4rec_launch_kernel(const dr4sr_gru4rec_plan* plan, int32
             const int K = layer == 0 ? D : H;
             return launch_gemm(in, K, plan->params + ws.off_wih[layer], K, nullptr, w.gi, 3 * H, K, 3 * H, false, ws.Tmax, plan->state, s);
         }
+        case DR4SR_GK_WAVE_FWD: { const int rc = launch_gru_wave(wave_args(plan, ws), ws.xch, ws.ctl, plan->B, H, plan->L, false, s); return rc == -100 ? DR4SR_E_ARG : rc; }
+        case DR4SR_GK_WAVE_BWD: { const int rc = launch_gru_wave(wave_args(plan, ws), ws.xch, ws.ctl, plan->B, H, plan->L, true, s); return rc == -100 ? DR4SR_E_ARG : rc; }
         default: return DR4SR_E_ARG;
     }
 }

@@ -89,6 +89,22 @@ __device__ __forceinline__ void sweep_granules(const u64* g, int stride, unsigne
     }
 }
 
+__device__ __forceinline__ void sleep_units(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }   // n x 64 cycles
+// Cheap "probably there" wait of a whole wave on ONE granule (one 8-byte request per pass instead of a sweep's 8 KB), with sleeps: used
+// by the follower layer of the wavefront kernels, which has a step of slack.  Only a hint: the tag-checked sweep still follows.
+__device__ __forceinline__ void wait_hint(const u64* g, unsigned tag, int* err) {
+    unsigned spins = 0;
+    for (;;) {
+        const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == tag) return;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255u) == 0) {
+            if (spins >= SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        }
+    }
+}
+
 __device__ __forceinline__ void finish_launch(int* ctl) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -350,6 +366,538 @@ __global__ __launch_bounds__(coop_threads(H, NS)) void k_gru_bwd_coop(const Coop
     finish_launch(A.ctl);
 }
 
+// ------------------------------------------------------------------------------------------------ two layers, one launch (layer wavefront)
+// With two GRU layers the step ran four cooperative recurrences one after the other (2 x 131 us forward, 2 x 144 us backward at
+// B = 256, max length 50) although layer 2's step t only needs layer 1's step t.  Here ONE launch holds both layers' workgroups
+// (16 groups x 16 slices x 2 layers = 512 workgroups of 4 waves, two per CU): the second layer runs behind the first and takes its
+// input from the granules layer 1 publishes for its own all-gather, so the chain is max(seqlen) + 2 steps instead of 2 max(seqlen),
+// and the token-parallel GEMMs between the layers (gi_2 = h_1 W_ih2^T forward, dh_1 = dgi_2 W_ih2 backward) disappear:
+//   forward : layer-2 slice = its 48 rows of W_hh2 AND of W_ih2 as MFMA B operands in REGISTERS; acc = W_ih2 x_t (x_t = h_1[t],
+//             polled) + W_hh2 h_2[t-1];
+//   backward: layer 2 leads and publishes its dgi_2[t] (three granules per owner thread); the layer-1 slice forms
+//             dh_1[t][own 16 units] = dgi_2[t][0..3H) W_ih2[:, own units] (K = 3H split over its 4 waves, B operand in registers)
+//             while its own partials of step t + 1 are in flight.
+// The follower only READS what the leader wrote, into per-time-step slots (no ring, no back-pressure: 16 H granules per step and
+// group forward, 48 H backward), so the leader never waits for the follower and a follower whose workgroups become resident late
+// (or after the leader has finished) still completes: no circular wait between the layers.
+// Both layers at once are 302 MFLOP per time step: on v_mfma_f32_16x16x4_f32 (157 TF/s) that alone is 1.9 us per step — the
+// first version of this kernel (fp32 MFMA) ran at 4.4 us per step, slower than two launches.  The products therefore run on the
+// bf16 matrix cores as a 3-term split (x = hi + lo, hi = bf16(x), lo = bf16(x - hi); x w ~ lo hi + hi lo + hi hi with fp32
+// accumulation: 3 v_mfma_f32_16x16x32_bf16 per 32 k against 8 fp32 ones, error 2^-16 per product, as k_wgrad_bf): weights split
+// once into registers (same 48 VGPRs as fp32), the polled A operands split per step.  Exchange layouts follow that instruction's
+// operand shape (a lane owns 8 consecutive k of one sequence): granule (k, seq) of a step sits at
+// ((k / 32) 8 + k % 8) 64 + ((k / 8) % 4) 16 + seq, so the 64 lanes of one poll instruction read 512 contiguous bytes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_bf(const bf16x8& a, const bf16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void split8(const float* x, bf16x8& hi, bf16x8& lo) {     // x: 8 values in registers (constant indices)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const __bf16 h = (__bf16)x[i]; hi[i] = h; lo[i] = (__bf16)(x[i] - (float)h); }
+}
+__device__ __forceinline__ f32x4 mfma_x3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 c) {
+    c = mfma_bf(al, bh, c); c = mfma_bf(ah, bl, c); return mfma_bf(ah, bh, c);
+}
+// Exchanged activations travel ALREADY SPLIT: the granule's 32-bit payload is bf16 hi | bf16 lo << 16 of the value (the producer splits
+// once; every consumer — 16 slices — would otherwise spend three VALU instructions per polled value on it)
+__device__ __forceinline__ unsigned pack_split(float x) {
+    const __bf16 h = (__bf16)x, l = (__bf16)(x - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+// eight payloads -> the hi and lo bf16x8 operands (v_perm_b32 per pair)
+__device__ __forceinline__ void unpack8(const unsigned* v, bf16x8& hi, bf16x8& lo) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = __builtin_amdgcn_perm(v[2 * i + 1], v[2 * i], 0x05040100u);     // lo halves of the two words
+        l[i] = __builtin_amdgcn_perm(v[2 * i + 1], v[2 * i], 0x07060302u);     // hi halves
+    }
+    hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
+}
+__device__ __forceinline__ void put_granule_u(u64* g, unsigned tag, unsigned payload) {
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sweep of N payloads (as sweep_granules, raw 32-bit payloads)
+template <int N>
+__device__ __forceinline__ void sweep_payloads(const u64* g, int stride, unsigned tag, unsigned (&v)[N], int* err) {
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const u64 x = __hip_atomic_load(g + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = (unsigned)x;
+            ok &= (unsigned)(x >> 32) == tag;
+        }
+        if (ok) return;
+        if ((++spins & 255u) == 0) {
+            if (spins >= SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+// two sets in ONE pass (their round trips overlap): set A is re-read only until it is complete
+template <int N>
+__device__ __forceinline__ void sweep_payloads2(const u64* ga, unsigned taga, unsigned (&va)[N], const u64* gb, unsigned tagb, unsigned (&vb)[N],
+                                                int stride, int* err) {
+    unsigned spins = 0;
+    bool adone = false;
+    for (;;) {
+        bool oka = true, okb = true;
+        if (!adone) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const u64 x = __hip_atomic_load(ga + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                va[k] = (unsigned)x;
+                oka &= (unsigned)(x >> 32) == taga;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const u64 x = __hip_atomic_load(gb + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vb[k] = (unsigned)x;
+            okb &= (unsigned)(x >> 32) == tagb;
+        }
+        adone = adone || __all(oka);
+        if (adone && okb) return;
+        if ((++spins & 255u) == 0) {
+            if (spins >= SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+__device__ __forceinline__ size_t gran_idx(int k, int seq) { return (size_t)(((k >> 5) * 8 + (k & 7)) * 64 + ((k >> 3) & 3) * 16 + seq); }
+
+struct WaveArgs {
+    const float* gi1;                                     // layer-1 input projection [T][3H]
+    const float* whh[2]; const float* wih2;
+    const int* cu;
+    float* r[2]; float* z[2]; float* n[2]; float* ghn[2]; float* hprev[2]; float* hout[2];
+    const float* dhout; float* dgi[2]; float* dgh[2];     // backward: dL/d(top output), gate gradients
+    u64* xch; int* ctl; int B; int L;
+    int presleep, solo, stamp;                                   // tuning / diagnosis (DR4SR_GRU_WAVE_PRESLEEP, DR4SR_GRU_WAVE_SOLO)
+};
+// granules per group: per-step slots [L][16 H] (forward: h_1[t]; backward: dL/dh_1[t]) | forward h_2 ring [2][16 H] | backward: layer-2
+// partial ring [2][NS][16][H] | layer-1 partial ring [2][NS][16][H] | input-gradient partial ring [3][NS][16][H]
+template <int H, int NS> struct WaveArea {
+    static constexpr size_t SLOT = (size_t)16 * H, PR = (size_t)NS * 16 * H;
+    static constexpr size_t ring_f(int L) { return (size_t)L * SLOT; }
+    static constexpr size_t ring_b(int L, int layer) { return ring_f(L) + 2 * SLOT + (size_t)(1 - layer) * 2 * PR; }   // layer 1 (the leader) first
+    static constexpr size_t ring_i(int L) { return ring_f(L) + 2 * SLOT + 4 * PR; }
+    static constexpr size_t words(int L) { return ring_i(L) + 3 * PR; }
+};
+template <int H, int NS> constexpr size_t wave_group_words(int L) { return WaveArea<H, NS>::words(L); }
+
+// role / group / slice of a workgroup: 8 consecutive blocks = 8 XCDs (speed-only placement, as above).  Blocks jx and jx + 32 of an XCD
+// land on the same CU (32 CUs per XCD, round-robin): roles alternate with jx / NS so that a CU holds one leader and one follower
+// slice (the follower issues twice the matrix work of the leader)
+// DR4SR_GRU_WAVE_STAMP (tools/gru_stamp_probe.py): shader-clock stamps of one middle time step of group 0, slice 0, wave 0, into the
+// control block's spare words: ctl[8 + 16 role + i]
+#define WAVE_STAMP(i) do { if (A.stamp && st_on) { if (lane == 0) A.ctl[8 + 16 * who.role + (i)] = (int)__builtin_amdgcn_s_memtime(); } } while (0)
+struct WaveWho { int grp, sl, role; };
+template <int NS> __device__ __forceinline__ WaveWho wave_who() {
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, q = jx / NS;         // q: 0..3 per 8 groups = (group half, role)
+    WaveWho w;
+    w.sl = jx % NS;
+    w.grp = ((q >> 2) * 2 + ((q >> 1) & 1)) * 8 + xcd;
+    w.role = (q ^ (q >> 1)) & 1;                           // q = 0, 1, 2, 3 -> leader, follower, follower, leader
+    return w;
+}
+
+template <int H, int NS>
+__global__ __launch_bounds__(256, 2) void k_gru_fwd_wave(const WaveArgs A) {
+    constexpr int US = H / NS;
+    static_assert(US == 16 && H == 256, "one 16-unit tile per slice, four K-quarter waves of two 32-k MFMAs");
+    float* part = smem;                                   // [2 parity][4 kq][4][16 unit][16 seq]
+    int* meta = reinterpret_cast<int*>(part + 2 * 4 * 4 * 16 * 16);
+    const WaveWho who = wave_who<NS>();
+    const int grp = who.grp, sl = who.sl, b0 = grp * 16, layer = who.role;       // forward: layer 1 leads
+    if (b0 >= A.B || (A.solo == 1 && who.role)) { finish_launch(A.ctl); return; }
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    if (A.stamp && threadIdx.x == 0 && blockIdx.x < 24) {   // where the dispatcher put the first 24 blocks: XCC id (HW_REG_XCC_ID = 20), CU / SE id (HW_REG_HW_ID = 4)
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        A.ctl[40 + blockIdx.x] = (int)((xcc & 0xf) | (hw << 4));
+    }
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    // B operands: lane (l16, g) of K-quarter wave kq holds W[gate row of unit l16][kq 64 + 32 m + 8 g + j], j = 0..7, split hi | lo
+    bf16x8 whh[3][2], whl[3][2], wih[3][2], wil[3][2];
+#pragma unroll
+    for (int q3 = 0; q3 < 3; ++q3)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const size_t o = (size_t)(q3 * H + sl * US + l16) * H + kq * 64 + m * 32 + 8 * g;
+            float x[8];
+            { const float4 a = ld4(A.whh[layer] + o), b = ld4(A.whh[layer] + o + 4); x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w; }
+            split8(x, whh[q3][m], whl[q3][m]);
+            if (layer) { const float4 a = ld4(A.wih2 + o), b = ld4(A.wih2 + o + 4); x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w; }
+            split8(x, wih[q3][m], wil[q3][m]);
+        }
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const unsigned base = (unsigned)A.ctl[0] * 64u;
+    const int es = threadIdx.x & 15, eu = threadIdx.x >> 4;                       // gate math: (sequence, unit of the slice); sequences fastest:
+    const int tq = meta[es], nq = meta[16 + es], gu = sl * US + eu;               // a wave's granule store is four full 128-byte lines
+    u64* xg = A.xch + (size_t)grp * wave_group_words<H, NS>(A.L);
+    u64* slots = xg;                                       // h_1[t]: slot t
+    u64* ring = xg + WaveArea<H, NS>::ring_f(A.L);         // h_2[t]: [2][16 H]
+    const size_t lane_off = (size_t)kq * 1024 + lane;      // + 64 (8 m + j): k = kq 64 + 32 m + 8 g + j of sequence l16
+    const size_t own_off = gran_idx(gu, es);
+    constexpr size_t SLOT = WaveArea<H, NS>::SLOT;
+    float* const R = A.r[layer]; float* const Z = A.z[layer]; float* const N = A.n[layer]; float* const G = A.ghn[layer];
+    float* const HP = A.hprev[layer]; float* const HO = A.hout[layer];
+    float hown = 0.f;
+    unsigned hv[16];
+    if (layer == 0) {
+        for (int t = 0; t < nmax; ++t) {
+            const bool act = t < nq;
+            float gir = 0.f, giz = 0.f, gin = 0.f;
+            if (act) { const float* gip = A.gi1 + (size_t)(tq + t) * 3 * H + gu; gir = gip[0]; giz = gip[H]; gin = gip[2 * H]; }
+            f32x4 acc[3];
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bool st_on = grp == 0 && sl == 0 && kq == 0 && t == nmax / 2;
+            WAVE_STAMP(0);
+            if (t > 0) {
+                if (A.presleep) sleep_units(A.presleep);
+                sweep_payloads<16>(slots + (size_t)(t - 1) * SLOT + lane_off, 64, base + t, hv, A.ctl + 2);
+                WAVE_STAMP(1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf16x8 ah, al;
+                    unpack8(hv + 8 * m, ah, al);
+#pragma unroll
+                    for (int q3 = 0; q3 < 3; ++q3) acc[q3] = mfma_x3(ah, al, whh[q3][m], whl[q3][m], acc[q3]);
+                }
+            }
+            float* pt = part + (t & 1) * (4 * 4 * 256);
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) *reinterpret_cast<f32x4*>(pt + ((kq * 4 + q3) * 16 + l16) * 16 + 4 * g) = acc[q3];
+            WAVE_STAMP(2);
+            __syncthreads();
+            WAVE_STAMP(3);
+            float gh[3];
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) {
+                const float* pp = pt + (q3 * 16 + eu) * 16 + es;
+                gh[q3] = (pp[0] + pp[4 * 256]) + (pp[2 * 4 * 256] + pp[3 * 4 * 256]);
+            }
+            float rr = 0.f, zz = 0.f, nn = 0.f;
+            const float hold = hown;
+            if (act) {
+                rr = sigm(gir + gh[0]); zz = sigm(giz + gh[1]); nn = tanh_f(gin + rr * gh[2]);
+                hown = (1.0f - zz) * nn + zz * hold;
+            }
+            // the exchange first (the other slices wait for it), the saved tensors of the backward after it
+            put_granule_u(slots + (size_t)t * SLOT + own_off, base + t + 1, pack_split(hown));      // also the last step: layer 2 reads it
+            WAVE_STAMP(4);
+            if (act) {
+                const size_t o = (size_t)(tq + t) * H + gu;
+                R[o] = rr; Z[o] = zz; N[o] = nn; G[o] = gh[2]; HP[o] = hold; HO[o] = hown;
+            }
+            WAVE_STAMP(5);
+        }
+    } else {
+        unsigned xv[16];
+        for (int t = 0; t < nmax; ++t) {
+            const bool act = t < nq;
+            const bool st_on = grp == 0 && sl == 0 && kq == 0 && t == nmax / 2;
+            WAVE_STAMP(0);
+            // x_t = h_1[t] (normally long there: layer 1 does not wait for this layer) and h_2[t-1] (what this step waits for) are polled
+            // in ONE pass, so their round trips overlap
+            if (t > 0) {
+                if (A.presleep) sleep_units(A.presleep);
+                sweep_payloads2<16>(slots + (size_t)t * SLOT + lane_off, base + t + 1, xv, ring + (size_t)((t - 1) & 1) * 16 * H + lane_off, base + t, hv,
+                                    64, A.ctl + 2);
+            } else sweep_payloads<16>(slots + (size_t)t * SLOT + lane_off, 64, base + t + 1, xv, A.ctl + 2);
+            WAVE_STAMP(1);
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                bf16x8 ah, al;
+                unpack8(xv + 8 * m, ah, al);
+                acc[0] = mfma_x3(ah, al, wih[0][m], wil[0][m], acc[0]);
+                acc[1] = mfma_x3(ah, al, wih[1][m], wil[1][m], acc[1]);
+                acc[3] = mfma_x3(ah, al, wih[2][m], wil[2][m], acc[3]);
+            }
+            if (t > 0) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf16x8 ah, al;
+                    unpack8(hv + 8 * m, ah, al);
+#pragma unroll
+                    for (int q3 = 0; q3 < 3; ++q3) acc[q3] = mfma_x3(ah, al, whh[q3][m], whl[q3][m], acc[q3]);
+                }
+            }
+            float* pt = part + (t & 1) * (4 * 4 * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(pt + ((kq * 4 + q) * 16 + l16) * 16 + 4 * g) = acc[q];
+            WAVE_STAMP(2);
+            __syncthreads();
+            WAVE_STAMP(3);
+            float gs[4];                                   // r and z pre-activations (input + recurrent), gh_n, gi_n
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* pp = pt + (q * 16 + eu) * 16 + es;
+                gs[q] = (pp[0] + pp[4 * 256]) + (pp[2 * 4 * 256] + pp[3 * 4 * 256]);
+            }
+            float rr = 0.f, zz = 0.f, nn = 0.f;
+            const float hold = hown;
+            if (act) {
+                rr = sigm(gs[0]); zz = sigm(gs[1]); nn = tanh_f(gs[3] + rr * gs[2]);
+                hown = (1.0f - zz) * nn + zz * hold;
+            }
+            if (t + 1 < nmax) put_granule_u(ring + (size_t)(t & 1) * 16 * H + own_off, base + t + 1, pack_split(hown));
+            WAVE_STAMP(4);
+            if (act) {
+                const size_t o = (size_t)(tq + t) * H + gu;
+                R[o] = rr; Z[o] = zz; N[o] = nn; G[o] = gs[2]; HP[o] = hold; HO[o] = hown;
+            }
+            WAVE_STAMP(5);
+        }
+    }
+    finish_launch(A.ctl);
+}
+
+// Backward.  Leader = layer 2: the cooperative BPTT above (W_hh2 slice in registers), and besides its recurrent partials
+// dgh_2 W_hh2 the slice forms the INPUT-gradient partials dgi_2[t][its 48 rows] W_ih2[those rows][0..H) the same way; its owner
+// threads sum the 16 slices' input partials one step later (off the recurrent chain) and publish dL/dh_1[t] as one granule per
+// (sequence, unit) into the slot of step t.  Follower = layer 1: the same BPTT, whose owners poll that one granule together with their
+// own 16 partials — dL/dh_1 never exists as a tensor and the follower does no extra matrix work.  A first version had the follower
+// form dL/dh_1 itself from 48 polled dgi_2 granules per lane: 7 us per follower step (three dependent round trips), slower than two launches.
+// The slice's 48 local rows (K of the partial products) are padded to 64 = two 32-k MFMAs; tile columns: dr | dz | dn r | dn.
+template <int H, int NS>
+__global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
+    constexpr int US = H / NS, KL = 3 * US, LDG = 4 * US + 4, CTW = (H / 16) / 4;
+    static_assert(US == 16 && CTW == 4 && H == 256, "slice geometry");
+    using Area = WaveArea<H, NS>;
+    float* dgl0 = smem;                                   // [2 parity][16][LDG]   gate-gradient tile of this slice (A operands)
+    int* meta = reinterpret_cast<int*>(dgl0 + 2 * 16 * LDG);
+    const WaveWho who = wave_who<NS>();
+    const int grp = who.grp, sl = who.sl, b0 = grp * 16, layer = 1 - who.role;   // backward: layer 2 leads
+    if (b0 >= A.B || (A.solo == 1 && who.role)) { finish_launch(A.ctl); return; }
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    // B operands: partial[16][col] = tile[16][KL] . W[slice rows][col]: lane (l16, g) holds local rows 32 m + 8 g + j (zero beyond KL:
+    // the slice's 48 rows are padded to two 32-k MFMAs — v_mfma_f32_16x16x16_bf16 for the last 16 rows saves 32 VGPRs but is
+    // miscompiled on gfx950 in a dependent chain behind a 32-k MFMA (tools/probes/mfma16_layout_probe.hip), see NOTEBOOK)
+    // of column (4 w + ci) 16 + l16.  W_hh of this layer in registers (both roles: the recurrent chain); W_ih2 (leader, off the chain)
+    // in LDS, one 16-byte slot per lane and operand.
+    bf16x8 wbh[CTW][2], wbl[CTW][2];
+    bf16x8* wimg = reinterpret_cast<bf16x8*>(dgl0 + 2 * 16 * LDG + 32);        // [ci][m][hi | lo][256 lanes]
+#pragma unroll
+    for (int ci = 0; ci < CTW; ++ci)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float x[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int lr = 32 * m + 8 * g + j, gate = lr / US, u = lr % US;
+                const size_t o = (size_t)(gate * H + sl * US + u) * H + (w * CTW + ci) * 16 + l16;
+                x[j] = lr < KL ? A.whh[layer][o] : 0.f;
+                y[j] = (lr < KL && layer == 1) ? A.wih2[o] : 0.f;
+            }
+            split8(x, wbh[ci][m], wbl[ci][m]);
+            if (layer == 1) {
+                bf16x8 yh, yl;
+                split8(y, yh, yl);
+                wimg[((ci * 2 + m) * 2 + 0) * 256 + threadIdx.x] = yh;
+                wimg[((ci * 2 + m) * 2 + 1) * 256 + threadIdx.x] = yl;
+            }
+        }
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const unsigned base = (unsigned)A.ctl[0] * 64u;
+    const int es = threadIdx.x / US, eu = threadIdx.x % US;
+    const int tq = meta[es], nq = meta[16 + es], gu = sl * US + eu;
+    u64* xg = A.xch + (size_t)grp * Area::words(A.L);
+    u64* slots = xg;                                       // dL/dh_1[t]: slot t, granule seq H + unit
+    u64* ring = xg + Area::ring_b(A.L, layer);             // this layer's recurrent partial ring [2][NS][16][H]
+    u64* ringi = xg + Area::ring_i(A.L);                   // input-gradient partials [3][NS][16][H]
+    const float* const Rr = A.r[layer]; const float* const Zz = A.z[layer]; const float* const Nn = A.n[layer];
+    const float* const Gh = A.ghn[layer]; const float* const Hp = A.hprev[layer];
+    float* const DGI = A.dgi[layer]; float* const DGH = A.dgh[layer];
+    float carry = 0.f, keep = 0.f;
+    float sv[6];
+    auto load_saved = [&](int t) {
+        const bool a = t >= 0 && t < nq;
+        const size_t o = (size_t)(tq + (a ? t : 0)) * H + gu;
+        sv[0] = (a && layer == 1) ? A.dhout[o] : 0.f; sv[1] = a ? Rr[o] : 0.f; sv[2] = a ? Zz[o] : 0.f;
+        sv[3] = a ? Nn[o] : 0.f; sv[4] = a ? Gh[o] : 0.f; sv[5] = a ? Hp[o] : 0.f;
+    };
+    // one BPTT step's gate derivatives for this thread's (sequence, unit); returns dh z (the part of the carry that needs no exchange)
+    auto gates = [&](int t, float dh, float* dgl) -> float {
+        float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, kp = 0.f;
+        if (t < nq) {
+            const float rr = sv[1], zz = sv[2], nn = sv[3], gh = sv[4], hp = sv[5];
+            dn = dh * (1.0f - zz) * (1.0f - nn * nn);
+            dz = dh * (hp - nn) * zz * (1.0f - zz);
+            dr = dn * gh * rr * (1.0f - rr);
+            dnr = dn * rr;
+            kp = dh * zz;
+            float* gp = DGI + (size_t)(tq + t) * 3 * H + gu;
+            gp[0] = dr; gp[H] = dz; gp[2 * H] = dn;
+            float* hp2 = DGH + (size_t)(tq + t) * 3 * H + gu;
+            hp2[0] = dr; hp2[H] = dz; hp2[2 * H] = dnr;
+        }
+        float* row = dgl + es * LDG + eu;
+        row[0] = dr; row[US] = dz; row[2 * US] = dnr; row[3 * US] = dn;
+        return kp;
+    };
+    // A operands of the slice's tile: columns 0..31 = (dr, dz) for both products; then dn r (recurrent) or dn (input), zero-padded to 32
+    auto tile_frag = [&](const float* dgl, int coff, bf16x8& hi, bf16x8& lo) {
+        float x[8];
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
+        if (coff >= 0) { a = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + coff); b = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + coff + 4); }
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+        split8(x, hi, lo);
+    };
+    // partial[16][H] = A-fragments . B operand -> granules of `dst` ([NS][16][H] block), tag.  LDSB: the B operand comes from the LDS image
+    auto partials = [&](const bf16x8& a0h, const bf16x8& a0l, const bf16x8& a1h, const bf16x8& a1l, const bool ldsb, u64* dst, unsigned tag) {
+#pragma unroll
+        for (int ci = 0; ci < CTW; ++ci) {
+            const int col = (w * CTW + ci) * 16 + l16;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ldsb) {
+                const bf16x8 b0h = wimg[((ci * 2 + 0) * 2 + 0) * 256 + threadIdx.x], b0l = wimg[((ci * 2 + 0) * 2 + 1) * 256 + threadIdx.x];
+                const bf16x8 b1h = wimg[((ci * 2 + 1) * 2 + 0) * 256 + threadIdx.x], b1l = wimg[((ci * 2 + 1) * 2 + 1) * 256 + threadIdx.x];
+                acc = mfma_x3(a0h, a0l, b0h, b0l, acc);
+                acc = mfma_x3(a1h, a1l, b1h, b1l, acc);
+            } else {
+                acc = mfma_x3(a0h, a0l, wbh[ci][0], wbl[ci][0], acc);
+                acc = mfma_x3(a1h, a1l, wbh[ci][1], wbl[ci][1], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put_granule(dst + ((size_t)sl * 16 + 4 * g + r) * H + col, tag, acc[r]);
+        }
+    };
+    auto sum16 = [&](const float (&pv)[NS]) -> float {
+        float s = 0.f;
+#pragma unroll
+        for (int src = 0; src < NS; ++src) s += pv[src];
+        return s;
+    };
+    const size_t own_par = (size_t)es * H + gu;            // this thread's (sequence, unit) inside a [16][H] block
+    if (layer == 1) {
+        load_saved(nmax - 1);
+        for (int t = nmax - 1; t >= 0; --t) {
+            const int idx = nmax - 1 - t, par = idx & 1;
+            const unsigned tag = base + (unsigned)idx + 1u;
+            float* dgl = dgl0 + par * 16 * LDG;
+            const bool st_on = grp == 0 && sl == 0 && w == 0 && t == nmax / 2;
+            WAVE_STAMP(0);
+            keep = gates(t, sv[0] + carry, dgl);
+            WAVE_STAMP(1);
+            __syncthreads();
+            WAVE_STAMP(2);
+            load_saved(t - 1);
+            bf16x8 a0h, a0l, a1h, a1l;
+            tile_frag(dgl, 8 * g, a0h, a0l);
+            if (t > 0) {                                    // the recurrent chain first
+                tile_frag(dgl, g < 2 ? 2 * US + 8 * g : -1, a1h, a1l);
+                partials(a0h, a0l, a1h, a1l, false, ring + (size_t)par * Area::PR, tag);
+            }
+            WAVE_STAMP(3);
+            tile_frag(dgl, g < 2 ? 3 * US + 8 * g : -1, a1h, a1l);
+            partials(a0h, a0l, a1h, a1l, true, ringi + (size_t)(idx % 3) * Area::PR, tag);
+            WAVE_STAMP(4);
+            // ONE pass polls the previous step's input-gradient partials (long there) and this step's recurrent partials (what the step
+            // waits for): dL/dh_1[t + 1] costs the recurrent chain no round trip of its own
+            unsigned pa[NS], pb[NS];
+            float pv[NS];
+            if (A.presleep) sleep_units(A.presleep);
+            if (idx > 0 && t > 0)
+                sweep_payloads2<NS>(ringi + (size_t)((idx - 1) % 3) * Area::PR + own_par, tag - 1u, pa, ring + (size_t)par * Area::PR + own_par, tag, pb,
+                                    16 * H, A.ctl + 2);
+            else if (t > 0) sweep_payloads<NS>(ring + (size_t)par * Area::PR + own_par, 16 * H, tag, pb, A.ctl + 2);
+            else if (idx > 0) sweep_payloads<NS>(ringi + (size_t)((idx - 1) % 3) * Area::PR + own_par, 16 * H, tag - 1u, pa, A.ctl + 2);
+            if (t > 0) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) pv[k] = __uint_as_float(pb[k]);
+                carry = keep + sum16(pv);
+            }
+            WAVE_STAMP(5);
+            if (idx > 0) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) pv[k] = __uint_as_float(pa[k]);
+                put_granule(slots + (size_t)(t + 1) * Area::SLOT + own_par, tag - 1u, sum16(pv));
+            }
+            WAVE_STAMP(6);
+        }
+        {
+            float pv[NS];
+            const unsigned tag = base + (unsigned)nmax;     // step t = 0 (idx = nmax - 1)
+            sweep_granules<NS>(ringi + (size_t)((nmax - 1) % 3) * Area::PR + own_par, 16 * H, tag, pv, A.ctl + 2);
+            put_granule(slots + own_par, tag, sum16(pv));
+        }
+    } else {
+        load_saved(nmax - 1);
+        float dh1 = get_granule(slots + (size_t)(nmax - 1) * Area::SLOT + own_par, base + 1u, A.ctl + 2);
+        for (int t = nmax - 1; t >= 0; --t) {
+            const int idx = nmax - 1 - t, par = idx & 1;
+            const unsigned tag = base + (unsigned)idx + 1u;
+            float* dgl = dgl0 + par * 16 * LDG;
+            const bool st_on = grp == 0 && sl == 0 && w == 0 && t == nmax / 2;
+            WAVE_STAMP(0);
+            keep = gates(t, dh1 + carry, dgl);
+            WAVE_STAMP(1);
+            __syncthreads();
+            WAVE_STAMP(2);
+            load_saved(t - 1);
+            if (t > 0) {
+                bf16x8 a0h, a0l, a1h, a1l;
+                tile_frag(dgl, 8 * g, a0h, a0l);
+                tile_frag(dgl, g < 2 ? 2 * US + 8 * g : -1, a1h, a1l);
+                partials(a0h, a0l, a1h, a1l, false, ring + (size_t)par * Area::PR, tag);
+                WAVE_STAMP(3);
+                // the 16 partials and the next step's dL/dh_1 granule in one pass
+                if (A.presleep) sleep_units(A.presleep);
+                float pv[NS];
+                unsigned spins = 0;
+                const u64* gp = ring + (size_t)par * Area::PR + own_par;
+                const u64* gd = slots + (size_t)(t - 1) * Area::SLOT + own_par;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const u64 x = __hip_atomic_load(gp + (size_t)k * 16 * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pv[k] = __uint_as_float((unsigned)x);
+                        ok &= (unsigned)(x >> 32) == tag;
+                    }
+                    const u64 xd = __hip_atomic_load(gd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dh1 = __uint_as_float((unsigned)xd);
+                    ok &= (unsigned)(xd >> 32) == tag + 1u;
+                    if (ok) break;
+                    if ((++spins & 255u) == 0) {
+                        if (spins >= SPIN_LIMIT) atomicExch(A.ctl + 2, 1);
+                        if (__hip_atomic_load(A.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                carry = keep + sum16(pv);
+                WAVE_STAMP(4);
+            }
+        }
+    }
+    finish_launch(A.ctl);
+}
+
 template <int H, int NS> size_t coop_lds(bool bwd) {
     constexpr int US = H / NS;
     return sizeof(float) * (3 * US * (H + 4) + (bwd ? 2 * 16 * (3 * US + 4) : (US == 16 ? 2 * 4 * 3 * 16 * US : 16 * (H + 4) + 4 * 3 * 16 * US))) + 32 * sizeof(int);
@@ -452,3 +1000,55 @@ int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float*
 #undef COOP_LAUNCH
     return DR4SR_LAUNCH_CHECK();
 }
+
+// ------------------------------------------------------------------------------------------------ two-layer wavefront launch
+// Applies to n_layer == 2, H == 256 and batches the 16-slice cooperative form takes (at most 16 groups per launch: B <= 256, or chunks of
+// 256 up to 1536): 2 layers x 16 groups x 16 slices = 512 workgroups, two per CU.  DR4SR_GRU_NOWAVE (cross-check): one launch per layer.
+static bool wave_ok(int B, int H, int n_layer, int L) {
+    static const bool off = getenv("DR4SR_GRU_NOWAVE") != nullptr;
+    if (off || n_layer != 2 || H != 256 || L > 64) return false;
+    const int cb = coop_chunk(B, H);
+    return cb != 0 && coop_slices(cb, H) == 16 && 2 * 16 * (((cb + 15) / 16 + 7) / 8) * 8 <= 2 * device_cus();
+}
+int64_t gru_wave_words(int B, int H, int L, int n_layer) {
+    if (!wave_ok(B, H, n_layer, L)) return 0;
+    const int cb = coop_chunk(B, H), groups = (cb + 15) / 16;
+    return (int64_t)groups * (int64_t)wave_group_words<256, 16>(L);
+}
+// returns -100 when the plan does not qualify (caller: one cooperative launch per layer)
+int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int B, int H, int L, bool bwd, hipStream_t s) {
+    if (!xch || !ctl || !wave_ok(B, H, 2, L)) return -100;
+    static const bool wave_bwd = getenv("DR4SR_GRU_WAVE_BWD") != nullptr;
+    if (bwd && !wave_bwd) return -100;
+    const int cb = coop_chunk(B, H);
+    WaveArgs A;
+    A.gi1 = G.gi1; A.wih2 = G.wih2; A.dhout = G.dhout; A.xch = xch; A.ctl = ctl; A.L = L;
+    static const int presleep = getenv("DR4SR_GRU_WAVE_PRESLEEP") ? atoi(getenv("DR4SR_GRU_WAVE_PRESLEEP")) : 0;
+    static const int solo = getenv("DR4SR_GRU_WAVE_SOLO") ? atoi(getenv("DR4SR_GRU_WAVE_SOLO")) : 0;            // diagnosis only: the follower layer does not run (wrong results)
+    static const int stamp = getenv("DR4SR_GRU_WAVE_STAMP") ? 1 : 0;
+    A.presleep = presleep; A.solo = solo; A.stamp = stamp;
+    for (int l = 0; l < 2; ++l) {
+        A.whh[l] = G.whh[l]; A.r[l] = G.r[l]; A.z[l] = G.z[l]; A.n[l] = G.n[l]; A.ghn[l] = G.ghn[l]; A.hprev[l] = G.hprev[l]; A.hout[l] = G.hout[l];
+        A.dgi[l] = G.dgi[l]; A.dgh[l] = G.dgh[l];
+    }
+    const size_t lds = bwd ? sizeof(float) * (2 * 16 * (4 * 16 + 4)) + 32 * sizeof(int) + (size_t)16 * 256 * 16
+                           : sizeof(float) * (2 * 4 * 4 * 16 * 16) + 32 * sizeof(int);
+    const void* k = bwd ? (const void*)k_gru_bwd_wave<256, 16> : (const void*)k_gru_fwd_wave<256, 16>;
+    static int fits[2] = {-1, -1};                          // both layers' workgroups of a CU must be resident together: two per CU
+    if (bwd) big_lds(k_gru_bwd_wave<256, 16>, lds); else big_lds(k_gru_fwd_wave<256, 16>, lds);
+    if (fits[bwd] < 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        fits[bwd] = nb >= 2;
+    }
+    if (!fits[bwd]) return -100;
+    for (int c0 = 0; c0 < B; c0 += cb) {                    // chunks of sequences: consecutive launches on the same granule area (epochs are per launch)
+        A.cu = G.cu + c0; A.B = B - c0 < cb ? B - c0 : cb;
+        const int groups = (A.B + 15) / 16;
+        dim3 grid(((groups + 7) / 8) * 8 * 2 * 16), blk(256);
+        if (bwd) hipLaunchKernelGGL((k_gru_bwd_wave<256, 16>), grid, blk, lds, s, A);
+        else hipLaunchKernelGGL((k_gru_fwd_wave<256, 16>), grid, blk, lds, s, A);
+    }
+    return DR4SR_LAUNCH_CHECK();
+}
+extern "C" int dr4sr_gru4rec_uses_wavefront(int32_t B, int32_t H, int32_t n_layer, int32_t L) { return wave_ok(B, H, n_layer, L) ? 1 : 0; }

@@ -184,6 +184,12 @@ bool qeb_in_wgrad(const Workspace& ws);         // latency regime: k_qkv_embed_b
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 
+// two-layer GRU wavefront (gru_coop.hip): per-layer tensors of both layers, [0] = first layer
+struct GruWaveArgs {
+    const float* gi1; const float* whh[2]; const float* wih2; const int* cu;
+    float* r[2]; float* z[2]; float* n[2]; float* ghn[2]; float* hprev[2]; float* hout[2];
+    const float* dhout; float* dgi[2]; float* dgh[2];
+};
 // raw (plan-independent) launchers shared with the GRU4Rec path
 int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
                     int64_t zero_floats, hipStream_t s);

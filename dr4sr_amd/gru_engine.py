@@ -138,6 +138,11 @@ class GruEngine:
         """True when a batch of B sequences runs the multi-CU cooperative recurrence on this device (csrc/gru_coop.hip)"""
         return bool(self.lib.dr4sr_gru4rec_uses_cooperative(int(B), int(self.H)))
 
+    def uses_wavefront(self, B: int) -> bool:
+        """True when a batch of B sequences runs both layers' forward recurrences in ONE launch, the second layer behind the first
+        (csrc/gru_coop.hip k_gru_fwd_wave: two layers, hidden 256, batches the 16-slice cooperative form takes)"""
+        return bool(self.lib.dr4sr_gru4rec_uses_wavefront(int(B), int(self.H), int(self.n_layer), int(self.L)))
+
     def loss_and_count(self):
         self.check_coop()
         tail = self.grads[self.n_params:self.n_params + 2].tolist()

@@ -324,6 +324,9 @@ int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan);
  * becomes non-zero and dr4sr_adam_flat / dr4sr_gru4rec_train_step then leave parameters, moments and the step counter untouched
  * (under data parallelism the all-reduced tail poisons every replica alike). */
 int dr4sr_gru4rec_uses_cooperative(int32_t B, int32_t H);
+/* 1 when a two-layer plan runs BOTH layers' recurrences in one launch, the second layer one time step behind the first (layer
+ * wavefront, csrc/gru_coop.hip: n_layer == 2, H == 256, batches the 16-slice cooperative form takes; 0 under DR4SR_GRU_NOWAVE) */
+int dr4sr_gru4rec_uses_wavefront(int32_t B, int32_t H, int32_t n_layer, int32_t L);
 int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream);       /* basemodel.py:193-198, un-normalised grads */
 int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream);    /* + dense Adam */
 int dr4sr_gru4rec_encode(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, float* out, void* stream);

@@ -49,6 +49,8 @@ int dr4sr_sasrec_launch_kernel_weighted(const dr4sr_sasrec_plan* plan, const dr4
 #define DR4SR_GK_REC_FWD  0
 #define DR4SR_GK_REC_BWD  1
 #define DR4SR_GK_GEMM_IN  2
+#define DR4SR_GK_WAVE_FWD 3   /* both layers' recurrences as ONE launch (two-layer plans the wavefront takes; `layer` ignored) */
+#define DR4SR_GK_WAVE_BWD 4
 int dr4sr_gru4rec_launch_kernel(const dr4sr_gru4rec_plan* plan, int32_t kernel, int32_t layer, void* stream);
 
 #ifdef __cplusplus

@@ -112,7 +112,25 @@ def test_gru4rec_baseline_config2_exact_size_vs_oracle():
     from test_gpu_r2_paths import _gru_vs_oracle
     eng, worst = _gru_vs_oracle(256, 256, 2, N=12102)
     assert eng.uses_cooperative(256)
+    assert eng.uses_wavefront(256) == (os.environ.get("DR4SR_GRU_NOWAVE") is None)
     print("GRU4Rec B=256 N=12102 worst grad relerr %.2e" % worst)
+
+
+@pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}], ids=["one-launch-per-layer", "backward-wavefront"])
+def test_gru4rec_wavefront_switches_vs_oracle(env):
+    """Two-layer plans run both forward recurrences in one launch by default (layer wavefront, csrc/gru_coop.hip); DR4SR_GRU_NOWAVE = the
+    one-launch-per-layer form, DR4SR_GRU_WAVE_BWD = the (opt-in, not faster) one-launch backward.  Both are `static` switches: the oracle
+    tests that reach them — BASELINE configs[2] exactly, partial groups, chunks of 256 with a ragged last chunk — re-run in a fresh interpreter"""
+    e = dict(os.environ)
+    e.update(env)
+    expr = ("test_gru4rec_baseline_config2_exact_size_vs_oracle or test_gru4rec_odd_batch_sizes_vs_oracle or "
+            "(test_gru4rec_chunked_cooperative_recurrence_vs_oracle and 400) or (test_gru4rec_cooperative_second_bank_vs_oracle and 130)")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", expr, "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_r3_paths.py"), os.path.join(ROOT, "tests", "test_gpu_gru.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_r2_paths.py")], env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
 
 
 def test_metamodel_outer_step_two_ranks_equal_single_rank():
