@@ -436,6 +436,64 @@ __device__ __forceinline__ void sweep_payloads(const u64* g, int stride, unsigne
         }
     }
 }
+// ... keeping the granules themselves (the payload is the low word: no second register per value)
+template <int N>
+__device__ __forceinline__ void sweep_u64(const u64* g, int stride, unsigned tag, u64 (&x)[N], int* err) {
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            x[k] = __hip_atomic_load(g + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok &= (unsigned)(x[k] >> 32) == tag;
+        }
+        if (ok) return;
+        if ((++spins & 255u) == 0) {
+            if (spins >= SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+// two sets (own strides and tags) in ONE pass: set A is re-read only until it is complete
+template <int NA, int NB>
+__device__ __forceinline__ void sweep_u64_2(const u64* ga, int stridea, unsigned taga, u64 (&xa)[NA], const u64* gb, int strideb, unsigned tagb, u64 (&xb)[NB],
+                                            int* err) {
+    unsigned spins = 0;
+    bool adone = false;
+    for (;;) {
+        bool oka = true, okb = true;
+        if (!adone) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {
+                xa[k] = __hip_atomic_load(ga + (size_t)k * stridea, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                oka &= (unsigned)(xa[k] >> 32) == taga;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            xb[k] = __hip_atomic_load(gb + (size_t)k * strideb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            okb &= (unsigned)(xb[k] >> 32) == tagb;
+        }
+        adone = adone || __all(oka);
+        if (adone && okb) return;
+        if ((++spins & 255u) == 0) {
+            if (spins >= SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+__device__ __forceinline__ void unpack8(const u64* v, bf16x8& hi, bf16x8& lo) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = __builtin_amdgcn_perm((unsigned)v[2 * i + 1], (unsigned)v[2 * i], 0x05040100u);
+        l[i] = __builtin_amdgcn_perm((unsigned)v[2 * i + 1], (unsigned)v[2 * i], 0x07060302u);
+    }
+    hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
+}
 // two sets in ONE pass (their round trips overlap): set A is re-read only until it is complete
 template <int N>
 __device__ __forceinline__ void sweep_payloads2(const u64* ga, unsigned taga, unsigned (&va)[N], const u64* gb, unsigned tagb, unsigned (&vb)[N],
@@ -478,14 +536,13 @@ struct WaveArgs {
     u64* xch; int* ctl; int B; int L;
     int presleep, solo, stamp;                                   // tuning / diagnosis (DR4SR_GRU_WAVE_PRESLEEP, DR4SR_GRU_WAVE_SOLO)
 };
-// granules per group: per-step slots [L][16 H] (forward: h_1[t]; backward: dL/dh_1[t]) | forward h_2 ring [2][16 H] | backward: layer-2
-// partial ring [2][NS][16][H] | layer-1 partial ring [2][NS][16][H] | input-gradient partial ring [3][NS][16][H]
+// granules per group: per-step slots [L][48 H] (forward: h_1[t] in the first 16 H; backward: dgi_2[t], all 3H gate rows) | forward h_2
+// ring [2][16 H] | backward: layer-2 partial ring [2][NS][16][H] | layer-1 partial ring [2][NS][16][H]
 template <int H, int NS> struct WaveArea {
-    static constexpr size_t SLOT = (size_t)16 * H, PR = (size_t)NS * 16 * H;
+    static constexpr size_t SLOT = (size_t)16 * 3 * H, PR = (size_t)NS * 16 * H;
     static constexpr size_t ring_f(int L) { return (size_t)L * SLOT; }
-    static constexpr size_t ring_b(int L, int layer) { return ring_f(L) + 2 * SLOT + (size_t)(1 - layer) * 2 * PR; }   // layer 1 (the leader) first
-    static constexpr size_t ring_i(int L) { return ring_f(L) + 2 * SLOT + 4 * PR; }
-    static constexpr size_t words(int L) { return ring_i(L) + 3 * PR; }
+    static constexpr size_t ring_b(int L, int layer) { return ring_f(L) + 2 * 16 * H + (size_t)(1 - layer) * 2 * PR; }   // layer 1 (the leader) first
+    static constexpr size_t words(int L) { return ring_f(L) + 2 * 16 * H + 4 * PR; }
 };
 template <int H, int NS> constexpr size_t wave_group_words(int L) { return WaveArea<H, NS>::words(L); }
 
@@ -669,20 +726,25 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd_wave(const WaveArgs A) {
     finish_launch(A.ctl);
 }
 
-// Backward.  Leader = layer 2: the cooperative BPTT above (W_hh2 slice in registers), and besides its recurrent partials
-// dgh_2 W_hh2 the slice forms the INPUT-gradient partials dgi_2[t][its 48 rows] W_ih2[those rows][0..H) the same way; its owner
-// threads sum the 16 slices' input partials one step later (off the recurrent chain) and publish dL/dh_1[t] as one granule per
-// (sequence, unit) into the slot of step t.  Follower = layer 1: the same BPTT, whose owners poll that one granule together with their
-// own 16 partials — dL/dh_1 never exists as a tensor and the follower does no extra matrix work.  A first version had the follower
-// form dL/dh_1 itself from 48 polled dgi_2 granules per lane: 7 us per follower step (three dependent round trips), slower than two launches.
-// The slice's 48 local rows (K of the partial products) are padded to 64 = two 32-k MFMAs; tile columns: dr | dz | dn r | dn.
+// Backward.  Leader = layer 2: the cooperative BPTT above (W_hh2 slice in registers), whose owner threads also publish their three
+// dgi_2[t] values (split, as the forward's h) into the slot of step t.  Follower = layer 1: dL/dh_1[t] never exists in memory — the
+// slice forms its 16 columns dgi_2[t][0..3H) W_ih2[:, own units] from ONE sweep of 48 polled granules per lane (K = 3H over its 4
+// waves, B operand = 48 KB LDS image: the registers are needed for the sweep) while its own partials of step t + 1 are in flight.
+// Two other forms were built and measured first (NOTEBOOK): the same with fp32 granules, a hint wait and two 24-granule sweeps
+// (three dependent round trips: 7 us per follower step), and the leader forming input-gradient partials next to its recurrent
+// ones (twice the exchange volume on the leading chain: 6.3 us per leader step).
+// The slice's 48 local rows (K of the recurrent partial product) are padded to 64 = two 32-k MFMAs (v_mfma_f32_16x16x16_bf16 for
+// the last 16 rows is miscompiled behind a 32-k MFMA on gfx950: tools/probes/mfma16_layout_probe.hip).
 template <int H, int NS>
 __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
-    constexpr int US = H / NS, KL = 3 * US, LDG = 4 * US + 4, CTW = (H / 16) / 4;
+    constexpr int US = H / NS, KL = 3 * US, LDG = KL + 4, CTW = (H / 16) / 4, NM = 3 * H / 4 / 32;      // NM: 32-k MFMAs of a wave's quarter of K = 3H
     static_assert(US == 16 && CTW == 4 && H == 256, "slice geometry");
     using Area = WaveArea<H, NS>;
-    float* dgl0 = smem;                                   // [2 parity][16][LDG]   gate-gradient tile of this slice (A operands)
-    int* meta = reinterpret_cast<int*>(dgl0 + 2 * 16 * LDG);
+    float* dgl0 = smem;                                   // [2 parity][16][LDG]   dgh tile of this slice (A operand)
+    float* part2 = dgl0 + 2 * 16 * LDG;                   // [2 parity][4 waves][16][US]   layer 1: K-quarter partials of dh_1
+    int* meta = reinterpret_cast<int*>(part2 + 2 * 4 * 16 * US);
+    bf16x8* wimg = reinterpret_cast<bf16x8*>(meta + 32);  // layer 1: W_ih2 operands [m][hi | lo][256 lanes]
+    bf16x8* wimg2 = wimg + 2 * NM * 256;                  // layer 1: the padded second half of the W_hh operands [ci][hi | lo][128 lanes with g < 2]
     const WaveWho who = wave_who<NS>();
     const int grp = who.grp, sl = who.sl, b0 = grp * 16, layer = 1 - who.role;   // backward: layer 2 leads
     if (b0 >= A.B || (A.solo == 1 && who.role)) { finish_launch(A.ctl); return; }
@@ -692,33 +754,40 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
         meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
-    // B operands: partial[16][col] = tile[16][KL] . W[slice rows][col]: lane (l16, g) holds local rows 32 m + 8 g + j (zero beyond KL:
-    // the slice's 48 rows are padded to two 32-k MFMAs — v_mfma_f32_16x16x16_bf16 for the last 16 rows saves 32 VGPRs but is
-    // miscompiled on gfx950 in a dependent chain behind a 32-k MFMA (tools/probes/mfma16_layout_probe.hip), see NOTEBOOK)
-    // of column (4 w + ci) 16 + l16.  W_hh of this layer in registers (both roles: the recurrent chain); W_ih2 (leader, off the chain)
-    // in LDS, one 16-byte slot per lane and operand.
+    // recurrent B operand: partial[16][col] = dgl[16][KL] . W_hh[slice rows][col]: lane (l16, g) holds local rows 32 m + 8 g + j (zero
+    // beyond KL) of column (4 w + ci) 16 + l16
     bf16x8 wbh[CTW][2], wbl[CTW][2];
-    bf16x8* wimg = reinterpret_cast<bf16x8*>(dgl0 + 2 * 16 * LDG + 32);        // [ci][m][hi | lo][256 lanes]
 #pragma unroll
     for (int ci = 0; ci < CTW; ++ci)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            float x[8], y[8];
+            float x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int lr = 32 * m + 8 * g + j, gate = lr / US, u = lr % US;
-                const size_t o = (size_t)(gate * H + sl * US + u) * H + (w * CTW + ci) * 16 + l16;
-                x[j] = lr < KL ? A.whh[layer][o] : 0.f;
-                y[j] = (lr < KL && layer == 1) ? A.wih2[o] : 0.f;
+                x[j] = lr < KL ? A.whh[layer][(size_t)(gate * H + sl * US + u) * H + (w * CTW + ci) * 16 + l16] : 0.f;
             }
             split8(x, wbh[ci][m], wbl[ci][m]);
-            if (layer == 1) {
-                bf16x8 yh, yl;
-                split8(y, yh, yl);
-                wimg[((ci * 2 + m) * 2 + 0) * 256 + threadIdx.x] = yh;
-                wimg[((ci * 2 + m) * 2 + 1) * 256 + threadIdx.x] = yl;
+            // layer 1 needs its registers for the 48-granule sweep: the second (half empty) operand pair goes to LDS, lanes g < 2 only
+            if (layer == 0 && m == 1 && g < 2) {
+                wimg2[(2 * ci) * 128 + w * 32 + (lane & 31)] = wbh[ci][1];
+                wimg2[(2 * ci + 1) * 128 + w * 32 + (lane & 31)] = wbl[ci][1];
             }
         }
+    if (layer == 0) {
+        // input-gradient B operand: dh_1[16][own units] = dgi_2[16][3H] . W_ih2[3H][own units], K split over the 4 waves:
+        // lane (l16, g) of wave w holds rows w 3H/4 + 32 m + 8 g + j of column sl US + l16
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = A.wih2[(size_t)(w * (3 * H / 4) + 32 * m + 8 * g + j) * H + sl * US + l16];
+            bf16x8 xh, xl;
+            split8(x, xh, xl);
+            wimg[(2 * m) * 256 + threadIdx.x] = xh;
+            wimg[(2 * m + 1) * 256 + threadIdx.x] = xl;
+        }
+    }
     __syncthreads();
     int nmax = 0;
 #pragma unroll
@@ -727,9 +796,8 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
     const int es = threadIdx.x / US, eu = threadIdx.x % US;
     const int tq = meta[es], nq = meta[16 + es], gu = sl * US + eu;
     u64* xg = A.xch + (size_t)grp * Area::words(A.L);
-    u64* slots = xg;                                       // dL/dh_1[t]: slot t, granule seq H + unit
-    u64* ring = xg + Area::ring_b(A.L, layer);             // this layer's recurrent partial ring [2][NS][16][H]
-    u64* ringi = xg + Area::ring_i(A.L);                   // input-gradient partials [3][NS][16][H]
+    u64* slots = xg;                                       // dgi_2[t]: granule (k, seq), k in [0, 3H)
+    u64* ring = xg + Area::ring_b(A.L, layer);             // this layer's partial ring [2][NS][16][H]
     const float* const Rr = A.r[layer]; const float* const Zz = A.z[layer]; const float* const Nn = A.n[layer];
     const float* const Gh = A.ghn[layer]; const float* const Hp = A.hprev[layer];
     float* const DGI = A.dgi[layer]; float* const DGH = A.dgh[layer];
@@ -742,8 +810,9 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
         sv[3] = a ? Nn[o] : 0.f; sv[4] = a ? Gh[o] : 0.f; sv[5] = a ? Hp[o] : 0.f;
     };
     // one BPTT step's gate derivatives for this thread's (sequence, unit); returns dh z (the part of the carry that needs no exchange)
-    auto gates = [&](int t, float dh, float* dgl) -> float {
-        float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, kp = 0.f;
+    auto gates = [&](int t, float dh, float* dgl, float& dr, float& dz, float& dn) -> float {
+        float dnr = 0.f, kp = 0.f;
+        dr = 0.f; dz = 0.f; dn = 0.f;
         if (t < nq) {
             const float rr = sv[1], zz = sv[2], nn = sv[3], gh = sv[4], hp = sv[5];
             dn = dh * (1.0f - zz) * (1.0f - nn * nn);
@@ -757,43 +826,45 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
             hp2[0] = dr; hp2[H] = dz; hp2[2 * H] = dnr;
         }
         float* row = dgl + es * LDG + eu;
-        row[0] = dr; row[US] = dz; row[2 * US] = dnr; row[3 * US] = dn;
+        row[0] = dr; row[US] = dz; row[2 * US] = dnr;
         return kp;
     };
-    // A operands of the slice's tile: columns 0..31 = (dr, dz) for both products; then dn r (recurrent) or dn (input), zero-padded to 32
-    auto tile_frag = [&](const float* dgl, int coff, bf16x8& hi, bf16x8& lo) {
-        float x[8];
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
-        if (coff >= 0) { a = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + coff); b = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + coff + 4); }
-        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
-        split8(x, hi, lo);
-    };
-    // partial[16][H] = A-fragments . B operand -> granules of `dst` ([NS][16][H] block), tag.  LDSB: the B operand comes from the LDS image
-    auto partials = [&](const bf16x8& a0h, const bf16x8& a0l, const bf16x8& a1h, const bf16x8& a1l, const bool ldsb, u64* dst, unsigned tag) {
+    // partial[16][H] of this slice's dgh tile -> granules of ring[par]
+    auto rec_partials = [&](const float* dgl, int par, unsigned tag) {
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float x[8];
+            const int k0 = 32 * m + 8 * g;                  // A operand: dgl[sequence l16][k0 .. k0 + 8), zero beyond KL
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
+            if (k0 < KL) { a = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + k0); b = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + k0 + 4); }
+            x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+            split8(x, ah[m], al[m]);
+        }
 #pragma unroll
         for (int ci = 0; ci < CTW; ++ci) {
             const int col = (w * CTW + ci) * 16 + l16;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ldsb) {
-                const bf16x8 b0h = wimg[((ci * 2 + 0) * 2 + 0) * 256 + threadIdx.x], b0l = wimg[((ci * 2 + 0) * 2 + 1) * 256 + threadIdx.x];
-                const bf16x8 b1h = wimg[((ci * 2 + 1) * 2 + 0) * 256 + threadIdx.x], b1l = wimg[((ci * 2 + 1) * 2 + 1) * 256 + threadIdx.x];
-                acc = mfma_x3(a0h, a0l, b0h, b0l, acc);
-                acc = mfma_x3(a1h, a1l, b1h, b1l, acc);
-            } else {
-                acc = mfma_x3(a0h, a0l, wbh[ci][0], wbl[ci][0], acc);
-                acc = mfma_x3(a1h, a1l, wbh[ci][1], wbl[ci][1], acc);
+            acc = mfma_x3(ah[0], al[0], wbh[ci][0], wbl[ci][0], acc);
+            if (layer == 1) acc = mfma_x3(ah[1], al[1], wbh[ci][1], wbl[ci][1], acc);
+            else {
+                bf16x8 bh = ah[1], bl = ah[1];               // lanes g >= 2: A is zero there, any finite B will do
+                if (g < 2) { bh = wimg2[(2 * ci) * 128 + w * 32 + (lane & 31)]; bl = wimg2[(2 * ci + 1) * 128 + w * 32 + (lane & 31)]; }
+                acc = mfma_x3(ah[1], al[1], bh, bl, acc);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) put_granule(dst + ((size_t)sl * 16 + 4 * g + r) * H + col, tag, acc[r]);
+            for (int r = 0; r < 4; ++r) put_granule(ring + (((size_t)par * NS + sl) * 16 + 4 * g + r) * H + col, tag, acc[r]);
         }
     };
-    auto sum16 = [&](const float (&pv)[NS]) -> float {
+    auto sweep_partials = [&](int par, unsigned tag) -> float {
+        float pv[NS];
+        if (A.presleep) sleep_units(A.presleep);
+        sweep_granules<NS>(ring + ((size_t)par * NS * 16 + es) * H + gu, 16 * H, tag, pv, A.ctl + 2);
         float s = 0.f;
 #pragma unroll
         for (int src = 0; src < NS; ++src) s += pv[src];
         return s;
     };
-    const size_t own_par = (size_t)es * H + gu;            // this thread's (sequence, unit) inside a [16][H] block
     if (layer == 1) {
         load_saved(nmax - 1);
         for (int t = nmax - 1; t >= 0; --t) {
@@ -802,97 +873,95 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
             float* dgl = dgl0 + par * 16 * LDG;
             const bool st_on = grp == 0 && sl == 0 && w == 0 && t == nmax / 2;
             WAVE_STAMP(0);
-            keep = gates(t, sv[0] + carry, dgl);
+            float dr, dz, dn;
+            keep = gates(t, sv[0] + carry, dgl, dr, dz, dn);
             WAVE_STAMP(1);
             __syncthreads();
             WAVE_STAMP(2);
             load_saved(t - 1);
-            bf16x8 a0h, a0l, a1h, a1l;
-            tile_frag(dgl, 8 * g, a0h, a0l);
-            if (t > 0) {                                    // the recurrent chain first
-                tile_frag(dgl, g < 2 ? 2 * US + 8 * g : -1, a1h, a1l);
-                partials(a0h, a0l, a1h, a1l, false, ring + (size_t)par * Area::PR, tag);
-            }
+            if (t > 0) rec_partials(dgl, par, tag);         // the recurrent chain first
             WAVE_STAMP(3);
-            tile_frag(dgl, g < 2 ? 3 * US + 8 * g : -1, a1h, a1l);
-            partials(a0h, a0l, a1h, a1l, true, ringi + (size_t)(idx % 3) * Area::PR, tag);
+            {   // dgi_2[t] of this (sequence, unit), all three gates (zeros beyond the sequence's length): what layer 1 contracts with W_ih2
+                u64* sl_t = slots + (size_t)t * Area::SLOT;
+                put_granule_u(sl_t + gran_idx(gu, es), tag, pack_split(dr));
+                put_granule_u(sl_t + gran_idx(H + gu, es), tag, pack_split(dz));
+                put_granule_u(sl_t + gran_idx(2 * H + gu, es), tag, pack_split(dn));
+            }
+            if (t > 0) carry = keep + sweep_partials(par, tag);
             WAVE_STAMP(4);
-            // ONE pass polls the previous step's input-gradient partials (long there) and this step's recurrent partials (what the step
-            // waits for): dL/dh_1[t + 1] costs the recurrent chain no round trip of its own
-            unsigned pa[NS], pb[NS];
-            float pv[NS];
-            if (A.presleep) sleep_units(A.presleep);
-            if (idx > 0 && t > 0)
-                sweep_payloads2<NS>(ringi + (size_t)((idx - 1) % 3) * Area::PR + own_par, tag - 1u, pa, ring + (size_t)par * Area::PR + own_par, tag, pb,
-                                    16 * H, A.ctl + 2);
-            else if (t > 0) sweep_payloads<NS>(ring + (size_t)par * Area::PR + own_par, 16 * H, tag, pb, A.ctl + 2);
-            else if (idx > 0) sweep_payloads<NS>(ringi + (size_t)((idx - 1) % 3) * Area::PR + own_par, 16 * H, tag - 1u, pa, A.ctl + 2);
-            if (t > 0) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) pv[k] = __uint_as_float(pb[k]);
-                carry = keep + sum16(pv);
-            }
-            WAVE_STAMP(5);
-            if (idx > 0) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) pv[k] = __uint_as_float(pa[k]);
-                put_granule(slots + (size_t)(t + 1) * Area::SLOT + own_par, tag - 1u, sum16(pv));
-            }
-            WAVE_STAMP(6);
-        }
-        {
-            float pv[NS];
-            const unsigned tag = base + (unsigned)nmax;     // step t = 0 (idx = nmax - 1)
-            sweep_granules<NS>(ringi + (size_t)((nmax - 1) % 3) * Area::PR + own_par, 16 * H, tag, pv, A.ctl + 2);
-            put_granule(slots + own_par, tag, sum16(pv));
         }
     } else {
+        const size_t lane_off = (size_t)w * NM * 8 * 64 + lane;                 // + 64 (8 m + j): K index w 3H/4 + 32 m + 8 g + j of sequence l16
+        // dh_1[t] partials of this wave's K quarter, in two halves of 24 granules (48 eight-byte loads in flight at once do not fit the
+        // registers next to the W_hh operands); the second half is polled in the same pass as the step's own partials
+        f32x4 acc0, acc1;
+        auto half_mma = [&](const u64* xv, int hf) {
+#pragma unroll
+            for (int m = 0; m < NM / 2; ++m) {
+                bf16x8 ah, al;
+                unpack8(xv + 8 * m, ah, al);
+                const int mm = hf * (NM / 2) + m;
+                const bf16x8 bh = wimg[(2 * mm) * 256 + threadIdx.x], bl = wimg[(2 * mm + 1) * 256 + threadIdx.x];
+                acc1 = mfma_bf(al, bh, acc1); acc1 = mfma_bf(ah, bl, acc1);       // two chains: the small terms, the hi hi term
+                acc0 = mfma_bf(ah, bh, acc0);
+            }
+        };
+        auto first_half = [&](int t) {
+            u64 xv[NM * 4];
+            acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+            sweep_u64<NM * 4>(slots + (size_t)t * Area::SLOT + lane_off, 64, base + (unsigned)(nmax - 1 - t) + 1u, xv, A.ctl + 2);
+            half_mma(xv, 0);
+        };
+        auto store_part = [&](int t) {
+            float* p2 = part2 + ((t & 1) * 4 + w) * 16 * US;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p2[(4 * g + r) * US + l16] = acc0[r] + acc1[r];
+        };
+        {
+            first_half(nmax - 1);
+            u64 xv[NM * 4];
+            sweep_u64<NM * 4>(slots + (size_t)(nmax - 1) * Area::SLOT + lane_off + (size_t)(NM * 4) * 64, 64, base + 1u, xv, A.ctl + 2);
+            half_mma(xv, 1);
+            store_part(nmax - 1);
+        }
         load_saved(nmax - 1);
-        float dh1 = get_granule(slots + (size_t)(nmax - 1) * Area::SLOT + own_par, base + 1u, A.ctl + 2);
+        __syncthreads();
         for (int t = nmax - 1; t >= 0; --t) {
             const int idx = nmax - 1 - t, par = idx & 1;
             const unsigned tag = base + (unsigned)idx + 1u;
             float* dgl = dgl0 + par * 16 * LDG;
             const bool st_on = grp == 0 && sl == 0 && w == 0 && t == nmax / 2;
             WAVE_STAMP(0);
-            keep = gates(t, dh1 + carry, dgl);
+            if (t > 0) first_half(t - 1);                   // while the partials of step t + 1 are in flight
             WAVE_STAMP(1);
-            __syncthreads();
-            WAVE_STAMP(2);
-            load_saved(t - 1);
-            if (t > 0) {
-                bf16x8 a0h, a0l, a1h, a1l;
-                tile_frag(dgl, 8 * g, a0h, a0l);
-                tile_frag(dgl, g < 2 ? 2 * US + 8 * g : -1, a1h, a1l);
-                partials(a0h, a0l, a1h, a1l, false, ring + (size_t)par * Area::PR, tag);
-                WAVE_STAMP(3);
-                // the 16 partials and the next step's dL/dh_1 granule in one pass
-                if (A.presleep) sleep_units(A.presleep);
-                float pv[NS];
-                unsigned spins = 0;
-                const u64* gp = ring + (size_t)par * Area::PR + own_par;
-                const u64* gd = slots + (size_t)(t - 1) * Area::SLOT + own_par;
-                for (;;) {
-                    bool ok = true;
+            if (A.presleep) sleep_units(A.presleep);
+            if (t > 0 && idx > 0) {
+                u64 xv[NM * 4], pv[NS];
+                sweep_u64_2<NM * 4, NS>(slots + (size_t)(t - 1) * Area::SLOT + lane_off + (size_t)(NM * 4) * 64, 64, tag + 1u, xv,
+                                        ring + ((size_t)(par ^ 1) * NS * 16 + es) * H + gu, 16 * H, tag - 1u, pv, A.ctl + 2);
+                float sum = 0.f;
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        const u64 x = __hip_atomic_load(gp + (size_t)k * 16 * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pv[k] = __uint_as_float((unsigned)x);
-                        ok &= (unsigned)(x >> 32) == tag;
-                    }
-                    const u64 xd = __hip_atomic_load(gd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    dh1 = __uint_as_float((unsigned)xd);
-                    ok &= (unsigned)(xd >> 32) == tag + 1u;
-                    if (ok) break;
-                    if ((++spins & 255u) == 0) {
-                        if (spins >= SPIN_LIMIT) atomicExch(A.ctl + 2, 1);
-                        if (__hip_atomic_load(A.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                carry = keep + sum16(pv);
-                WAVE_STAMP(4);
-            }
+                for (int k = 0; k < NS; ++k) sum += __uint_as_float((unsigned)pv[k]);
+                carry = keep + sum;
+                half_mma(xv, 1);
+                store_part(t - 1);
+            } else if (t > 0) {
+                u64 xv[NM * 4];
+                sweep_u64<NM * 4>(slots + (size_t)(t - 1) * Area::SLOT + lane_off + (size_t)(NM * 4) * 64, 64, tag + 1u, xv, A.ctl + 2);
+                half_mma(xv, 1);
+                store_part(t - 1);
+            } else if (idx > 0) carry = keep + sweep_partials(par ^ 1, tag - 1u);
+            WAVE_STAMP(2);
+            const float* p2 = part2 + (t & 1) * 4 * 16 * US + es * US + eu;
+            const float dh1 = (p2[0] + p2[16 * US]) + (p2[2 * 16 * US] + p2[3 * 16 * US]);
+            float dr, dz, dn;
+            keep = gates(t, dh1 + carry, dgl, dr, dz, dn);
+            WAVE_STAMP(3);
+            __syncthreads();
+            WAVE_STAMP(4);
+            load_saved(t - 1);
+            if (t > 0) rec_partials(dgl, par, tag);
+            WAVE_STAMP(5);
         }
     }
     finish_launch(A.ctl);
@@ -1031,7 +1100,7 @@ int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int
         A.whh[l] = G.whh[l]; A.r[l] = G.r[l]; A.z[l] = G.z[l]; A.n[l] = G.n[l]; A.ghn[l] = G.ghn[l]; A.hprev[l] = G.hprev[l]; A.hout[l] = G.hout[l];
         A.dgi[l] = G.dgi[l]; A.dgh[l] = G.dgh[l];
     }
-    const size_t lds = bwd ? sizeof(float) * (2 * 16 * (4 * 16 + 4)) + 32 * sizeof(int) + (size_t)16 * 256 * 16
+    const size_t lds = bwd ? sizeof(float) * (2 * 16 * (3 * 16 + 4) + 2 * 4 * 16 * 16) + 32 * sizeof(int) + (size_t)12 * 256 * 16 + (size_t)8 * 128 * 16
                            : sizeof(float) * (2 * 4 * 4 * 16 * 16) + 32 * sizeof(int);
     const void* k = bwd ? (const void*)k_gru_bwd_wave<256, 16> : (const void*)k_gru_fwd_wave<256, 16>;
     static int fits[2] = {-1, -1};                          // both layers' workgroups of a CU must be resident together: two per CU

@@ -22,7 +22,7 @@ cd $R
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 timeout 300 python bench.py --dense --no-cpu-baseline --no-throughput-mode --no-strong 2>/dev/null | tail -1 > $O/bench_sasrec_dense.json
 timeout 300 python bench.py --batch 8192 --dense --no-cpu-baseline --steps 60 2>/dev/null | tail -1 > $O/bench_sasrec_B8192_dense.json
-timeout 300 python bench.py --model gru4rec --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_gru4rec.json
+timeout 400 python bench.py --model gru4rec 2>/dev/null | tail -1 > $O/bench_gru4rec.json
 timeout 300 python bench.py --model fmlp --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fmlp.json
 timeout 300 python bench.py --model metamodel 2>/dev/null | tail -1 > $O/bench_metamodel.json
 timeout 300 python bench.py --model cl4srec 2>/dev/null | tail -1 > $O/bench_cl4srec.json
