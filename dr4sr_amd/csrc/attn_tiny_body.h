@@ -174,7 +174,7 @@ __device__ __forceinline__ void fwd_body(const AttnArgs2& A, const int bid) {
 
 // ------------------------------------------------------------------------------------------------ backward
 // Phase A (lane = query row i): P from the saved statistics, dP~ = V dctx_i, dS = P (dP~ mask - <dctx_i, ctx_i>) scale, dQ_i += dS K_j;
-// dS and P~ = P mask go to the (sequence, head)'s 8x8 LDS tile, transposed.  Then the lanes' own Q and dctx rows replace K and V in
+// dS and P~ = P mask go to the (sequence, head)'s 8x8 LDS tile, transposed.  The lanes' own dctx and Q rows replace V and K in
 // LDS and phase B (lane = key row j) forms dK_j = sum_i dS[i][j] Q_i, dV_j = sum_i P~[i][j] dctx_i — nothing is recomputed, no
 // second round of Philox.
 template <int DH>
@@ -215,35 +215,43 @@ __device__ __forceinline__ void bwd_body(const AttnArgs2& A, const int bid) {
     float* Kr = S.Ks + (sq * NMAX) * LD + h * DH;
     float* Vr = S.Vs + (sq * NMAX) * LD + h * DH;
     float* X = S.X + grp * XS;
+    // Phase A in two passes so that q, dctx and dq are never live together (192 -> under 128 VGPRs: the kernel can then share a launch
+    // with the 16-row list class, attn_mfma.hip k_attn_small_bwd): A1 forms dS and P~ (q and dctx_i live), then dctx_i takes V's place
+    // in LDS; A2 accumulates dQ_i = sum_j dS[i][j] K_j (q and dq live), then q takes K's place.  The workgroup is ONE wave: the extra
+    // barriers cost nothing.
+    float ds[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        float pt = 0.f;
+        ds[j] = 0.f;
+        if (j < nmax) {
+            const float sc = dot_row<DH>(q, Kr + j * LD) * scale;
+            const float dp = dot_row<DH>(cf, Vr + j * LD);
+            const float p = (act && j <= i && !((padmask >> j) & 1u)) ? __expf(sc - mi) * inv : 0.f;
+            ds[j] = p * (dp * mk[j] - rdot) * scale;
+            pt = p * mk[j];
+        }
+        X[j * NMAX + i] = ds[j]; X[NMAX * NMAX + j * NMAX + i] = pt;            // transposed: key lane j reads its 8 query entries contiguously
+    }
+    lds_barrier();                              // every lane is done with V: the lanes' own dctx rows take its place
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) st4(Vr + i * LD + c, make_float4(cf[c], cf[c + 1], cf[c + 2], cf[c + 3]));
     {
         float dq[DH];
 #pragma unroll
         for (int c = 0; c < DH; ++c) dq[c] = 0.f;
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            float ds = 0.f, pt = 0.f;
-            if (j < nmax) {
-                const float sc = dot_row<DH>(q, Kr + j * LD) * scale;
-                const float dp = dot_row<DH>(cf, Vr + j * LD);
-                const float p = (act && j <= i && !((padmask >> j) & 1u)) ? __expf(sc - mi) * inv : 0.f;
-                ds = p * (dp * mk[j] - rdot) * scale;
-                pt = p * mk[j];
-                axpy_row<DH>(dq, ds, Kr + j * LD);
-            }
-            X[j * NMAX + i] = ds; X[NMAX * NMAX + j * NMAX + i] = pt;            // transposed: key lane j reads its 8 query entries contiguously
-        }
+        for (int j = 0; j < NMAX; ++j)
+            if (j < nmax) axpy_row<DH>(dq, ds[j], Kr + j * LD);
         if (act) {
             float* dst = A.dqkv + (size_t)(t0 + i) * 3 * D + h * DH;
 #pragma unroll
             for (int c = 0; c < DH; c += 4) st4(dst + c, make_float4(dq[c], dq[c + 1], dq[c + 2], dq[c + 3]));
         }
     }
-    lds_barrier();                              // every lane is done with K, V: the lanes' own Q / dctx rows take their place
+    lds_barrier();                              // every lane is done with K: the lanes' own Q rows take its place
 #pragma unroll
-    for (int c = 0; c < DH; c += 4) {
-        st4(Kr + i * LD + c, make_float4(q[c], q[c + 1], q[c + 2], q[c + 3]));
-        st4(Vr + i * LD + c, make_float4(cf[c], cf[c + 1], cf[c + 2], cf[c + 3]));
-    }
+    for (int c = 0; c < DH; c += 4) st4(Kr + i * LD + c, make_float4(q[c], q[c + 1], q[c + 2], q[c + 3]));
     lds_barrier();
     {
         float dsr[NMAX], ptr[NMAX];
