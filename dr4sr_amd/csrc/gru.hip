@@ -26,7 +26,7 @@ int64_t gru_coop_words(int B, int H);
 int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float* r, float* z, float* n, float* ghn, float* hprev,
                         float* hout, const float* dhout, float* dgi, float* dgh, unsigned long long* xch, int* ctl, int B, int H, bool bwd,
                         hipStream_t s);
-int64_t gru_wave_words(int B, int H, int L, int n_layer);
+int64_t gru_xch_words(int B, int H, int L, int n_layer);
 int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int B, int H, int L, bool bwd, hipStream_t s);
 
 struct GruLayerWs {
@@ -85,10 +85,8 @@ static void gru_carve(const dr4sr_gru4rec_plan* p, GruWs* ws) {
     };
     // control words and granules FIRST: their offsets must not move with B (they hold state that survives across calls)
     ws->ctl = (int*)take(4);
-    {
-        int64_t words = gru_coop_words(p->B, p->H);
-        const int64_t ww = gru_wave_words(p->B, p->H, p->L, p->n_layer);       // two-layer wavefront: per-step slots + both layers' rings
-        if (ww > words) words = ww;
+    {   // (an upper bound over every batch size up to B: a partial last batch runs in the workspace sized for the full one)
+        const int64_t words = gru_xch_words(p->B, p->H, p->L, p->n_layer);
         ws->xch = words ? (unsigned long long*)take(2 * words) : nullptr;
     }
     ws->cu = (int*)take(p->B + 1);

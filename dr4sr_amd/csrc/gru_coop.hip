@@ -1079,10 +1079,15 @@ static bool wave_ok(int B, int H, int n_layer, int L) {
     const int cb = coop_chunk(B, H);
     return cb != 0 && coop_slices(cb, H) == 16 && 2 * 16 * (((cb + 15) / 16 + 7) / 8) * 8 <= 2 * device_cus();
 }
-int64_t gru_wave_words(int B, int H, int L, int n_layer) {
-    if (!wave_ok(B, H, n_layer, L)) return 0;
-    const int cb = coop_chunk(B, H), groups = (cb + 15) / 16;
-    return (int64_t)groups * (int64_t)wave_group_words<256, 16>(L);
+// Granule words the workspace reserves for a plan of at most B sequences: an upper bound of what ANY batch of at most B sequences needs
+// (a smaller batch can need more than a larger one — 256 sequences take 16 slices per group and the wavefront's per-step slots, 300 take
+// 8 slices and no wavefront — and the last batch of an epoch runs in the workspace sized for the full one), monotone in B.
+int64_t gru_xch_words(int B, int H, int L, int n_layer) {
+    if (gru_coop_words(B < 16 ? B : 16, H) == 0) return 0;                     // no cooperative path at all on this device / under DR4SR_GRU_NOCOOP
+    const int64_t g = (B + 15) / 16;
+    const int64_t coop = (g < 24 ? g : 24) * 2 * 16 * 16 * H;                  // at most 24 groups per launch, at most 16 slices per group
+    const int64_t wave = wave_ok(B < 256 ? B : 256, H, n_layer, L) ? (g < 16 ? g : 16) * (int64_t)wave_group_words<256, 16>(L) : 0;
+    return coop > wave ? coop : wave;
 }
 // returns -100 when the plan does not qualify (caller: one cooperative launch per layer)
 int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int B, int H, int L, bool bwd, hipStream_t s) {

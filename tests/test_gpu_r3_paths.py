@@ -116,6 +116,33 @@ def test_gru4rec_baseline_config2_exact_size_vs_oracle():
     print("GRU4Rec B=256 N=12102 worst grad relerr %.2e" % worst)
 
 
+def test_gru4rec_partial_batch_in_the_workspace_of_a_larger_one():
+    """An engine built for batches of 300 (8 slices per group, no wavefront) must run a batch of 256 (16 slices per group + the
+    wavefront's per-step slots: a LARGER exchange area) in the same workspace — the last batch of an epoch; the reservation is an upper
+    bound over every batch size up to the engine's (csrc/gru_coop.hip gru_xch_words)"""
+    from dr4sr_amd.gru_engine import GruEngine, gru_param_names, gru_param_shapes
+    from test_gpu_r2_paths import _gru_batch, relerr
+    N, L, H, NL = 2000, 50, 256, 2
+    gen = torch.Generator().manual_seed(3)
+    params = {n: 0.08 * torch.randn(s_, generator=gen) for n, s_ in zip(gru_param_names(NL), gru_param_shapes(N, 64, H, NL))}
+    params["item_embedding.weight"][0] = 0
+    out = {}
+    for maxb in (300, 256):
+        eng = GruEngine(N, L, 64, H, NL, 0.0, maxb, "cuda", seed=5)
+        eng.load_named(params)
+        for B in ((300, 256) if maxb == 300 else (256,)):
+            b, _ = _gru_batch(B, N, L, 11)
+            dev = eng.device
+            plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                                 neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+            eng.fwd_bwd(plan)
+            eng.check_device_error()
+            out[(maxb, B)] = {k: v.detach().cpu().clone() for k, v in eng.normalized_grads().items()}
+    assert eng.uses_wavefront(256) and not eng.uses_wavefront(300)
+    for k, v in out[(256, 256)].items():
+        assert relerr(out[(300, 256)][k], v) < 2e-5, k
+
+
 @pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}], ids=["one-launch-per-layer", "backward-wavefront"])
 def test_gru4rec_wavefront_switches_vs_oracle(env):
     """Two-layer plans run both forward recurrences in one launch by default (layer wavefront, csrc/gru_coop.hip); DR4SR_GRU_NOWAVE = the
