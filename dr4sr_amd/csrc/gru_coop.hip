@@ -97,7 +97,7 @@ __device__ __forceinline__ void wait_hint(const u64* g, unsigned tag, int* err) 
     for (;;) {
         const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(x >> 32) == tag) return;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(8);
         if ((++spins & 255u) == 0) {
             if (spins >= SPIN_LIMIT) atomicExch(err, 1);
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
@@ -726,34 +726,46 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd_wave(const WaveArgs A) {
     finish_launch(A.ctl);
 }
 
-// Backward.  Leader = layer 2: the cooperative BPTT above (W_hh2 slice in registers), whose owner threads also publish their three
-// dgi_2[t] values (split, as the forward's h) into the slot of step t.  Follower = layer 1: dL/dh_1[t] never exists in memory — the
-// slice forms its 16 columns dgi_2[t][0..3H) W_ih2[:, own units] from ONE sweep of 48 polled granules per lane (K = 3H over its 4
-// waves, B operand = 48 KB LDS image: the registers are needed for the sweep) while its own partials of step t + 1 are in flight.
-// Two other forms were built and measured first (NOTEBOOK): the same with fp32 granules, a hint wait and two 24-granule sweeps
-// (three dependent round trips: 7 us per follower step), and the leader forming input-gradient partials next to its recurrent
-// ones (twice the exchange volume on the leading chain: 6.3 us per leader step).
+// Backward: ONE workgroup of 8 waves per CU holds a slice of BOTH layers — waves 0..3 the slice of layer 2 (the leader: the cooperative
+// BPTT above with its W_hh2 operands in registers; its owner threads also publish their three dgi_2[t] values, split as the forward's
+// h, into the slot of step t), waves 4..7 the same slice of layer 1 (the follower).  dL/dh_1[t] never exists in memory: the follower
+// forms its 16 columns dgi_2[t][0..3H) W_ih2[:, own units] from 48 polled granules per lane (K = 3H over its 4 waves) while its own
+// partials of step t + 1 are in flight.  That needs the registers for the sweep, so BOTH of the follower's B operands are LDS images
+// (W_hh1 64 KB padded, W_ih2 48 KB) — which is why the two slices share a workgroup: as two workgroups per CU (the first three forms,
+// NOTEBOOK) the kernel-wide LDS size would have to hold the images twice.  The halves never wait for each other inside the loop:
+// each has its own 4-wave barrier (an LDS counter; s_barrier is workgroup-wide on gfx950).
 // The slice's 48 local rows (K of the recurrent partial product) are padded to 64 = two 32-k MFMAs (v_mfma_f32_16x16x16_bf16 for
 // the last 16 rows is miscompiled behind a 32-k MFMA on gfx950: tools/probes/mfma16_layout_probe.hip).
+__device__ __forceinline__ void group_barrier(int* cnt, int& target) {          // the 4 waves that share `cnt`
+    target += 4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <int H, int NS>
-__global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
+__global__ __launch_bounds__(512) void k_gru_bwd_pair(const WaveArgs A) {
     constexpr int US = H / NS, KL = 3 * US, LDG = KL + 4, CTW = (H / 16) / 4, NM = 3 * H / 4 / 32;      // NM: 32-k MFMAs of a wave's quarter of K = 3H
     static_assert(US == 16 && CTW == 4 && H == 256, "slice geometry");
     using Area = WaveArea<H, NS>;
-    float* dgl0 = smem;                                   // [2 parity][16][LDG]   dgh tile of this slice (A operand)
-    float* part2 = dgl0 + 2 * 16 * LDG;                   // [2 parity][4 waves][16][US]   layer 1: K-quarter partials of dh_1
+    float* dglb = smem;                                   // [2 roles][2 parity][16][LDG]   dgh tiles (A operands)
+    float* part2 = dglb + 2 * 2 * 16 * LDG;               // [2 parity][4 waves][16][US]   layer 1: K-quarter partials of dh_1
     int* meta = reinterpret_cast<int*>(part2 + 2 * 4 * 16 * US);
-    bf16x8* wimg = reinterpret_cast<bf16x8*>(meta + 32);  // layer 1: W_ih2 operands [m][hi | lo][256 lanes]
-    bf16x8* wimg2 = wimg + 2 * NM * 256;                  // layer 1: the padded second half of the W_hh operands [ci][hi | lo][128 lanes with g < 2]
-    const WaveWho who = wave_who<NS>();
-    const int grp = who.grp, sl = who.sl, b0 = grp * 16, layer = 1 - who.role;   // backward: layer 2 leads
-    if (b0 >= A.B || (A.solo == 1 && who.role)) { finish_launch(A.ctl); return; }
+    int* bar = meta + 32;                                 // [2] the halves' barrier counters
+    bf16x8* wimg = reinterpret_cast<bf16x8*>(bar + 4);    // layer 1: W_ih2 operands [m][hi | lo][256 lanes]
+    bf16x8* wbimg = wimg + 2 * NM * 256;                  // layer 1: W_hh1 operands [ci][m][hi | lo][256 lanes]
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int grp = (jx / NS) * 8 + xcd, sl = jx % NS, b0 = grp * 16;
+    const int role = threadIdx.x >> 8, layer = 1 - role, tid = threadIdx.x & 255;      // waves 0..3: layer 2 (leads)
+    if (b0 >= A.B) { finish_launch(A.ctl); return; }
     if (threadIdx.x < 16) {
         const int b = b0 + threadIdx.x;
         meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
         meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    if (threadIdx.x < 2) bar[threadIdx.x] = 0;
+    const int lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
     // recurrent B operand: partial[16][col] = dgl[16][KL] . W_hh[slice rows][col]: lane (l16, g) holds local rows 32 m + 8 g + j (zero
     // beyond KL) of column (4 w + ci) 16 + l16
     bf16x8 wbh[CTW][2], wbl[CTW][2];
@@ -768,13 +780,12 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
                 x[j] = lr < KL ? A.whh[layer][(size_t)(gate * H + sl * US + u) * H + (w * CTW + ci) * 16 + l16] : 0.f;
             }
             split8(x, wbh[ci][m], wbl[ci][m]);
-            // layer 1 needs its registers for the 48-granule sweep: the second (half empty) operand pair goes to LDS, lanes g < 2 only
-            if (layer == 0 && m == 1 && g < 2) {
-                wimg2[(2 * ci) * 128 + w * 32 + (lane & 31)] = wbh[ci][1];
-                wimg2[(2 * ci + 1) * 128 + w * 32 + (lane & 31)] = wbl[ci][1];
+            if (role == 1) {
+                wbimg[((ci * 2 + m) * 2) * 256 + tid] = wbh[ci][m];
+                wbimg[((ci * 2 + m) * 2 + 1) * 256 + tid] = wbl[ci][m];
             }
         }
-    if (layer == 0) {
+    if (role == 1) {
         // input-gradient B operand: dh_1[16][own units] = dgi_2[16][3H] . W_ih2[3H][own units], K split over the 4 waves:
         // lane (l16, g) of wave w holds rows w 3H/4 + 32 m + 8 g + j of column sl US + l16
 #pragma unroll
@@ -784,8 +795,8 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
             for (int j = 0; j < 8; ++j) x[j] = A.wih2[(size_t)(w * (3 * H / 4) + 32 * m + 8 * g + j) * H + sl * US + l16];
             bf16x8 xh, xl;
             split8(x, xh, xl);
-            wimg[(2 * m) * 256 + threadIdx.x] = xh;
-            wimg[(2 * m + 1) * 256 + threadIdx.x] = xl;
+            wimg[(2 * m) * 256 + tid] = xh;
+            wimg[(2 * m + 1) * 256 + tid] = xl;
         }
     }
     __syncthreads();
@@ -793,11 +804,14 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
     const unsigned base = (unsigned)A.ctl[0] * 64u;
-    const int es = threadIdx.x / US, eu = threadIdx.x % US;
+    const int es = tid / US, eu = tid % US;
     const int tq = meta[es], nq = meta[16 + es], gu = sl * US + eu;
     u64* xg = A.xch + (size_t)grp * Area::words(A.L);
     u64* slots = xg;                                       // dgi_2[t]: granule (k, seq), k in [0, 3H)
     u64* ring = xg + Area::ring_b(A.L, layer);             // this layer's partial ring [2][NS][16][H]
+    float* dgl0 = dglb + role * 2 * 16 * LDG;
+    int* mybar = bar + role;
+    int btarget = 0;
     const float* const Rr = A.r[layer]; const float* const Zz = A.z[layer]; const float* const Nn = A.n[layer];
     const float* const Gh = A.ghn[layer]; const float* const Hp = A.hprev[layer];
     float* const DGI = A.dgi[layer]; float* const DGH = A.dgh[layer];
@@ -829,8 +843,8 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
         row[0] = dr; row[US] = dz; row[2 * US] = dnr;
         return kp;
     };
-    // partial[16][H] of this slice's dgh tile -> granules of ring[par]
-    auto rec_partials = [&](const float* dgl, int par, unsigned tag) {
+    // partial[16][H] of this slice's dgh tile -> granules of ring[par]; LDSB: the B operands come from the LDS image (layer 1)
+    auto rec_partials = [&](const float* dgl, int par, unsigned tag, const bool ldsb) {
         bf16x8 ah[2], al[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -845,12 +859,10 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
         for (int ci = 0; ci < CTW; ++ci) {
             const int col = (w * CTW + ci) * 16 + l16;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc = mfma_x3(ah[0], al[0], wbh[ci][0], wbl[ci][0], acc);
-            if (layer == 1) acc = mfma_x3(ah[1], al[1], wbh[ci][1], wbl[ci][1], acc);
-            else {
-                bf16x8 bh = ah[1], bl = ah[1];               // lanes g >= 2: A is zero there, any finite B will do
-                if (g < 2) { bh = wimg2[(2 * ci) * 128 + w * 32 + (lane & 31)]; bl = wimg2[(2 * ci + 1) * 128 + w * 32 + (lane & 31)]; }
-                acc = mfma_x3(ah[1], al[1], bh, bl, acc);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (ldsb) acc = mfma_x3(ah[m], al[m], wbimg[((ci * 2 + m) * 2) * 256 + tid], wbimg[((ci * 2 + m) * 2 + 1) * 256 + tid], acc);
+                else acc = mfma_x3(ah[m], al[m], wbh[ci][m], wbl[ci][m], acc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) put_granule(ring + (((size_t)par * NS + sl) * 16 + 4 * g + r) * H + col, tag, acc[r]);
@@ -865,22 +877,23 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
         for (int src = 0; src < NS; ++src) s += pv[src];
         return s;
     };
-    if (layer == 1) {
+#define PAIR_STAMP(i) do { if (A.stamp && st_on) { if (lane == 0) A.ctl[8 + 16 * role + (i)] = (int)__builtin_amdgcn_s_memtime(); } } while (0)
+    if (role == 0) {
         load_saved(nmax - 1);
         for (int t = nmax - 1; t >= 0; --t) {
             const int idx = nmax - 1 - t, par = idx & 1;
             const unsigned tag = base + (unsigned)idx + 1u;
             float* dgl = dgl0 + par * 16 * LDG;
             const bool st_on = grp == 0 && sl == 0 && w == 0 && t == nmax / 2;
-            WAVE_STAMP(0);
+            PAIR_STAMP(0);
             float dr, dz, dn;
             keep = gates(t, sv[0] + carry, dgl, dr, dz, dn);
-            WAVE_STAMP(1);
-            __syncthreads();
-            WAVE_STAMP(2);
+            PAIR_STAMP(1);
+            group_barrier(mybar, btarget);
+            PAIR_STAMP(2);
             load_saved(t - 1);
-            if (t > 0) rec_partials(dgl, par, tag);         // the recurrent chain first
-            WAVE_STAMP(3);
+            if (t > 0) rec_partials(dgl, par, tag, false);  // the recurrent chain first
+            PAIR_STAMP(3);
             {   // dgi_2[t] of this (sequence, unit), all three gates (zeros beyond the sequence's length): what layer 1 contracts with W_ih2
                 u64* sl_t = slots + (size_t)t * Area::SLOT;
                 put_granule_u(sl_t + gran_idx(gu, es), tag, pack_split(dr));
@@ -888,82 +901,68 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_wave(const WaveArgs A) {
                 put_granule_u(sl_t + gran_idx(2 * H + gu, es), tag, pack_split(dn));
             }
             if (t > 0) carry = keep + sweep_partials(par, tag);
-            WAVE_STAMP(4);
+            PAIR_STAMP(4);
         }
     } else {
         const size_t lane_off = (size_t)w * NM * 8 * 64 + lane;                 // + 64 (8 m + j): K index w 3H/4 + 32 m + 8 g + j of sequence l16
-        // dh_1[t] partials of this wave's K quarter, in two halves of 24 granules (48 eight-byte loads in flight at once do not fit the
-        // registers next to the W_hh operands); the second half is polled in the same pass as the step's own partials
-        f32x4 acc0, acc1;
-        auto half_mma = [&](const u64* xv, int hf) {
+        // dh_1[t] partials of this wave's K quarter from ONE sweep of 48 granules
+        auto input_part = [&](int t) {
+            u64 xv[NM * 8];
+            {   // one optimistic pass; when layer 2 has not published the step yet, wait on ONE granule with sleeps (a spinning 48-granule
+                // sweep on every lane starves the leader half on the same SIMDs), then read again
+                const u64* gs = slots + (size_t)t * Area::SLOT + lane_off;
+                const unsigned tg = base + (unsigned)(nmax - 1 - t) + 1u;
+                for (int pass = 0;; ++pass) {
+                    bool ok = true;
 #pragma unroll
-            for (int m = 0; m < NM / 2; ++m) {
+                    for (int k = 0; k < NM * 8; ++k) {
+                        xv[k] = __hip_atomic_load(gs + (size_t)k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned)(xv[k] >> 32) == tg;
+                    }
+                    if (__all(ok)) break;
+                    if (pass > 64 && __hip_atomic_load(A.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    wait_hint(slots + (size_t)t * Area::SLOT + gran_idx(sl * US + 4 * w, 15), tg, A.ctl + 2);
+                }
+            }
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
                 bf16x8 ah, al;
                 unpack8(xv + 8 * m, ah, al);
-                const int mm = hf * (NM / 2) + m;
-                const bf16x8 bh = wimg[(2 * mm) * 256 + threadIdx.x], bl = wimg[(2 * mm + 1) * 256 + threadIdx.x];
+                const bf16x8 bh = wimg[(2 * m) * 256 + tid], bl = wimg[(2 * m + 1) * 256 + tid];
                 acc1 = mfma_bf(al, bh, acc1); acc1 = mfma_bf(ah, bl, acc1);       // two chains: the small terms, the hi hi term
                 acc0 = mfma_bf(ah, bh, acc0);
             }
-        };
-        auto first_half = [&](int t) {
-            u64 xv[NM * 4];
-            acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
-            sweep_u64<NM * 4>(slots + (size_t)t * Area::SLOT + lane_off, 64, base + (unsigned)(nmax - 1 - t) + 1u, xv, A.ctl + 2);
-            half_mma(xv, 0);
-        };
-        auto store_part = [&](int t) {
             float* p2 = part2 + ((t & 1) * 4 + w) * 16 * US;
 #pragma unroll
             for (int r = 0; r < 4; ++r) p2[(4 * g + r) * US + l16] = acc0[r] + acc1[r];
         };
-        {
-            first_half(nmax - 1);
-            u64 xv[NM * 4];
-            sweep_u64<NM * 4>(slots + (size_t)(nmax - 1) * Area::SLOT + lane_off + (size_t)(NM * 4) * 64, 64, base + 1u, xv, A.ctl + 2);
-            half_mma(xv, 1);
-            store_part(nmax - 1);
-        }
+        input_part(nmax - 1);
         load_saved(nmax - 1);
-        __syncthreads();
+        group_barrier(mybar, btarget);
         for (int t = nmax - 1; t >= 0; --t) {
             const int idx = nmax - 1 - t, par = idx & 1;
             const unsigned tag = base + (unsigned)idx + 1u;
             float* dgl = dgl0 + par * 16 * LDG;
             const bool st_on = grp == 0 && sl == 0 && w == 0 && t == nmax / 2;
-            WAVE_STAMP(0);
-            if (t > 0) first_half(t - 1);                   // while the partials of step t + 1 are in flight
-            WAVE_STAMP(1);
-            if (A.presleep) sleep_units(A.presleep);
-            if (t > 0 && idx > 0) {
-                u64 xv[NM * 4], pv[NS];
-                sweep_u64_2<NM * 4, NS>(slots + (size_t)(t - 1) * Area::SLOT + lane_off + (size_t)(NM * 4) * 64, 64, tag + 1u, xv,
-                                        ring + ((size_t)(par ^ 1) * NS * 16 + es) * H + gu, 16 * H, tag - 1u, pv, A.ctl + 2);
-                float sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) sum += __uint_as_float((unsigned)pv[k]);
-                carry = keep + sum;
-                half_mma(xv, 1);
-                store_part(t - 1);
-            } else if (t > 0) {
-                u64 xv[NM * 4];
-                sweep_u64<NM * 4>(slots + (size_t)(t - 1) * Area::SLOT + lane_off + (size_t)(NM * 4) * 64, 64, tag + 1u, xv, A.ctl + 2);
-                half_mma(xv, 1);
-                store_part(t - 1);
-            } else if (idx > 0) carry = keep + sweep_partials(par ^ 1, tag - 1u);
-            WAVE_STAMP(2);
+            PAIR_STAMP(0);
+            if (t > 0) input_part(t - 1);                   // while the partials of step t + 1 are in flight
+            PAIR_STAMP(1);
+            if (idx > 0) carry = keep + sweep_partials(par ^ 1, tag - 1u);
+            PAIR_STAMP(2);
             const float* p2 = part2 + (t & 1) * 4 * 16 * US + es * US + eu;
             const float dh1 = (p2[0] + p2[16 * US]) + (p2[2 * 16 * US] + p2[3 * 16 * US]);
             float dr, dz, dn;
             keep = gates(t, dh1 + carry, dgl, dr, dz, dn);
-            WAVE_STAMP(3);
-            __syncthreads();
-            WAVE_STAMP(4);
+            PAIR_STAMP(3);
+            group_barrier(mybar, btarget);
+            PAIR_STAMP(4);
             load_saved(t - 1);
-            if (t > 0) rec_partials(dgl, par, tag);
-            WAVE_STAMP(5);
+            if (t > 0) rec_partials(dgl, par, tag, true);
+            PAIR_STAMP(5);
         }
     }
+#undef PAIR_STAMP
     finish_launch(A.ctl);
 }
 
@@ -1105,23 +1104,23 @@ int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int
         A.whh[l] = G.whh[l]; A.r[l] = G.r[l]; A.z[l] = G.z[l]; A.n[l] = G.n[l]; A.ghn[l] = G.ghn[l]; A.hprev[l] = G.hprev[l]; A.hout[l] = G.hout[l];
         A.dgi[l] = G.dgi[l]; A.dgh[l] = G.dgh[l];
     }
-    const size_t lds = bwd ? sizeof(float) * (2 * 16 * (3 * 16 + 4) + 2 * 4 * 16 * 16) + 32 * sizeof(int) + (size_t)12 * 256 * 16 + (size_t)8 * 128 * 16
+    const size_t lds = bwd ? sizeof(float) * (2 * 2 * 16 * (3 * 16 + 4) + 2 * 4 * 16 * 16) + 36 * sizeof(int) + (size_t)(12 + 16) * 256 * 16
                            : sizeof(float) * (2 * 4 * 4 * 16 * 16) + 32 * sizeof(int);
-    const void* k = bwd ? (const void*)k_gru_bwd_wave<256, 16> : (const void*)k_gru_fwd_wave<256, 16>;
-    static int fits[2] = {-1, -1};                          // both layers' workgroups of a CU must be resident together: two per CU
-    if (bwd) big_lds(k_gru_bwd_wave<256, 16>, lds); else big_lds(k_gru_fwd_wave<256, 16>, lds);
+    const void* k = bwd ? (const void*)k_gru_bwd_pair<256, 16> : (const void*)k_gru_fwd_wave<256, 16>;
+    // forward: both layers' workgroups of a CU must be resident together, two per CU; backward: one 8-wave workgroup per CU
+    static int fits[2] = {-1, -1};
+    if (bwd) big_lds(k_gru_bwd_pair<256, 16>, lds); else big_lds(k_gru_fwd_wave<256, 16>, lds);
     if (fits[bwd] < 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-        fits[bwd] = nb >= 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, bwd ? 512 : 256, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        fits[bwd] = nb >= (bwd ? 1 : 2);
     }
     if (!fits[bwd]) return -100;
     for (int c0 = 0; c0 < B; c0 += cb) {                    // chunks of sequences: consecutive launches on the same granule area (epochs are per launch)
         A.cu = G.cu + c0; A.B = B - c0 < cb ? B - c0 : cb;
-        const int groups = (A.B + 15) / 16;
-        dim3 grid(((groups + 7) / 8) * 8 * 2 * 16), blk(256);
-        if (bwd) hipLaunchKernelGGL((k_gru_bwd_wave<256, 16>), grid, blk, lds, s, A);
-        else hipLaunchKernelGGL((k_gru_fwd_wave<256, 16>), grid, blk, lds, s, A);
+        const int groups = (A.B + 15) / 16, g8 = ((groups + 7) / 8) * 8;
+        if (bwd) hipLaunchKernelGGL((k_gru_bwd_pair<256, 16>), dim3(g8 * 16), dim3(512), lds, s, A);
+        else hipLaunchKernelGGL((k_gru_fwd_wave<256, 16>), dim3(g8 * 2 * 16), dim3(256), lds, s, A);
     }
     return DR4SR_LAUNCH_CHECK();
 }
