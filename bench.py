@@ -212,6 +212,9 @@ def gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, Hh, NLg, step_s):
         ach = fl / (ktime_dom * 1e-6) / 1e12
     else:
         ktime_dom, nlaunch, kname = ktime[dom], NLg, ("k_gru_%s_coop" if coop else "k_gru_%s") % ("bwd" if dom == "rec_bwd" else "fwd")
+        if coop and dom == "rec_bwd" and Hh == 256 and int(plan.B) <= 1536 and not os.environ.get("DR4SR_GRU_BWD_F32") \
+                and bool(lib.dr4sr_gru4rec_uses_cooperative(min(int(plan.B), 256), Hh)) and min(int(plan.B), 256) <= 256:
+            kname = "k_gru_bwd_coop_bf"                   # 16 slices per group: the bf16x3 BPTT with W_hh in registers (csrc/gru_coop.hip)
     out["roofline"] = {"kernel": kname, "bound": "mfma",
                        "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
                        "traffic_source": None, "us_per_launch": ktime_dom, "flops_per_launch": fl, "launches_per_step": nlaunch,

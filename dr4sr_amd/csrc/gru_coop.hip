@@ -726,6 +726,113 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd_wave(const WaveArgs A) {
     finish_launch(A.ctl);
 }
 
+// Single-layer BPTT of the 16-slice form on the bf16 matrix cores: k_gru_bwd_coop with the slice's W_hh rows as split (hi | lo) MFMA B
+// operands in REGISTERS instead of an fp32 LDS image read column-wise (48 ds_read_b32 per lane and step on the recurrent chain) and the
+// partial product as 3-term bf16 (24 MFMAs of 8 passes instead of 48).  Same exchange, same granules, same ring.
+template <int H, int NS>
+__global__ __launch_bounds__(256) void k_gru_bwd_coop_bf(const CoopArgs A) {
+    constexpr int US = H / NS, KL = 3 * US, LDG = KL + 4, CTW = (H / 16) / 4;
+    static_assert(US == 16 && CTW == 4 && H == 256, "slice geometry");
+    float* dgl0 = smem;                                   // [2 parity][16][LDG]   dgh tile of this slice (A operand)
+    int* meta = reinterpret_cast<int*>(dgl0 + 2 * 16 * LDG);
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int grp = (jx / NS) * 8 + xcd, sl = jx % NS, b0 = grp * 16;
+    if (b0 >= A.B) { finish_launch(A.ctl); return; }
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    bf16x8 wbh[CTW][2], wbl[CTW][2];                      // local rows 32 m + 8 g + j (zero beyond KL) of column (4 w + ci) 16 + l16
+#pragma unroll
+    for (int ci = 0; ci < CTW; ++ci)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int lr = 32 * m + 8 * g + j, gate = lr / US, u = lr % US;
+                x[j] = lr < KL ? A.whh[(size_t)(gate * H + sl * US + u) * H + (w * CTW + ci) * 16 + l16] : 0.f;
+            }
+            split8(x, wbh[ci][m], wbl[ci][m]);
+        }
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const unsigned base = (unsigned)A.ctl[0] * 64u;
+    const int es = threadIdx.x / US, eu = threadIdx.x % US;
+    const int tq = meta[es], nq = meta[16 + es], gu = sl * US + eu;
+    float carry = 0.f;
+    u64* xg = A.xch + (size_t)grp * 2 * NS * 16 * H;
+    float sv[6];
+    auto load_saved = [&](int t) {
+        const bool a = t >= 0 && t < nq;
+        const size_t o = (size_t)(tq + (a ? t : 0)) * H + gu;
+        sv[0] = a ? A.dhout[o] : 0.f; sv[1] = a ? A.r[o] : 0.f; sv[2] = a ? A.z[o] : 0.f;
+        sv[3] = a ? A.n[o] : 0.f; sv[4] = a ? A.ghn[o] : 0.f; sv[5] = a ? A.hprev[o] : 0.f;
+    };
+    load_saved(nmax - 1);
+    for (int t = nmax - 1; t >= 0; --t) {
+        const unsigned tag = base + (unsigned)(nmax - 1 - t) + 1u;
+        const int par = (nmax - 1 - t) & 1;
+        float* dgl = dgl0 + par * 16 * LDG;
+        float keep = 0.f, dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f;
+        if (t < nq) {
+            const float dh = sv[0] + carry, rr = sv[1], zz = sv[2], nn = sv[3], gh = sv[4], hp = sv[5];
+            dn = dh * (1.0f - zz) * (1.0f - nn * nn);
+            dz = dh * (hp - nn) * zz * (1.0f - zz);
+            dr = dn * gh * rr * (1.0f - rr);
+            dnr = dn * rr;
+            keep = dh * zz;
+        }
+        {
+            float* row = dgl + es * LDG + eu;
+            row[0] = dr; row[US] = dz; row[2 * US] = dnr;
+        }
+        __syncthreads();
+        if (t > 0) {
+            // partial[16][H] = dgl[16][KL] . W_hh[slice rows][:], the exchange first, the saved gate gradients after it
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float x[8];
+                const int k0 = 32 * m + 8 * g;
+                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
+                if (k0 < KL) { a = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + k0); b = *reinterpret_cast<const f32x4*>(dgl + l16 * LDG + k0 + 4); }
+                x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+                split8(x, ah[m], al[m]);
+            }
+#pragma unroll
+            for (int ci = 0; ci < CTW; ++ci) {
+                const int col = (w * CTW + ci) * 16 + l16;
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc = mfma_x3(ah[m], al[m], wbh[ci][m], wbl[ci][m], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put_granule(xg + (((size_t)par * NS + sl) * 16 + 4 * g + r) * H + col, tag, acc[r]);
+            }
+        }
+        if (t < nq) {
+            float* gp = A.dgi + (size_t)(tq + t) * 3 * H + gu;
+            gp[0] = dr; gp[H] = dz; gp[2 * H] = dn;
+            float* hp2 = A.dgh + (size_t)(tq + t) * 3 * H + gu;
+            hp2[0] = dr; hp2[H] = dz; hp2[2 * H] = dnr;
+        }
+        load_saved(t - 1);
+        if (t > 0) {
+            float pv[NS];
+            sweep_granules<NS>(xg + ((size_t)par * NS * 16 + es) * H + gu, 16 * H, tag, pv, A.ctl + 2);
+            float s = keep;
+#pragma unroll
+            for (int src = 0; src < NS; ++src) s += pv[src];
+            carry = s;
+        }
+    }
+    finish_launch(A.ctl);
+}
+
 // Backward: ONE workgroup of 8 waves per CU holds a slice of BOTH layers — waves 0..3 the slice of layer 2 (the leader: the cooperative
 // BPTT above with its W_hh2 operands in registers; its owner threads also publish their three dgi_2[t] values, split as the forward's
 // h, into the slot of step t), waves 4..7 the same slice of layer 1 (the follower).  dL/dh_1[t] never exists in memory: the follower
@@ -1061,7 +1168,12 @@ int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float*
                hipLaunchKernelGGL((k_gru_bwd_coop<H_, NS_>), grid, blk, lds, s, A); } } while (0)
     // 16 slices: the budget counted one workgroup per CU, but the launch must not depend on a perfectly even placement: require
     // room for two per CU
-    if (H == 256 && ns == 16) COOP_LAUNCH(256, 16, 2);
+    static const bool bwd_f32 = getenv("DR4SR_GRU_BWD_F32") != nullptr;         // cross-check switch: the fp32-MFMA BPTT with W_hh in LDS
+    if (H == 256 && ns == 16 && bwd && !bwd_f32) {
+        const size_t lds = sizeof(float) * 2 * 16 * (3 * 16 + 4) + 32 * sizeof(int);
+        if (!resident((const void*)k_gru_bwd_coop_bf<256, 16>, lds, 1)) return -100;
+        hipLaunchKernelGGL((k_gru_bwd_coop_bf<256, 16>), grid, blk, lds, s, A);
+    } else if (H == 256 && ns == 16) COOP_LAUNCH(256, 16, 2);
     else if (H == 256) COOP_LAUNCH(256, 8, 1);
     else if (H == 128) COOP_LAUNCH(128, 8, 1);
     else return DR4SR_E_SHAPE;
