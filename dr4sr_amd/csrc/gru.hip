@@ -235,9 +235,33 @@ static int launch_gemm(const float* A, int lda, const float* W, int ldw, const f
 // gridDim.x workgroups, fp32 atomics at the end);  db[n0..] += column sums of G when db != NULL.
 struct Wg64Job { const float* G; int ldg; int gcol; const float* X; int ldx; int xcol; float* dW; int ldw; float* db; };
 struct Wg64Mat { const float* G; const float* X; float* dW; float* db; int ldg, NG, ldx, KX, start; };   // dW is [NG][KX]
-struct Wg64Args { Wg64Mat mat[2 * GRU_MAX_LAYERS + 1]; int nmat; const int* state; };
+struct Wg64Args {
+    Wg64Mat mat[2 * GRU_MAX_LAYERS + 1]; int nmat; const int* state;
+    // one extra job (blockIdx.y == njobs, x == 0): tail[0..1] += the scorer's per-sequence (count, loss) partials, tail[2] += the
+    // cooperative recurrence's error word — was a launch of its own (k_sum_score_part, 4.7 us of a 0.49 ms step)
+    int njobs; const float* score_part; float* tail; int nscore; const int* err_word;
+};
+
+// tail[0..1] += sum of the scorer's per-sequence (count, loss) partials
+// tail[2] += the cooperative recurrence's sticky error word (the optimizer's poison word, csrc/step.hip k_adam)
+__device__ __forceinline__ void sum_score_part(const float* __restrict__ part, float* __restrict__ tail, int B, const int* __restrict__ err_word,
+                                               float* red) {                 // red: 512 floats of LDS
+    float c = 0.f, l = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) { c += part[2 * b]; l += part[2 * b + 1]; }
+    red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { tail[0] += red[0]; tail[1] += red[256]; if (err_word && *err_word) tail[2] += 1.0f; }
+}
 
 __global__ __launch_bounds__(256) void k_wgrad64(const Wg64Args A) {
+    if ((int)blockIdx.y == A.njobs) {
+        if (blockIdx.x == 0) sum_score_part(A.score_part, A.tail, A.nscore, A.err_word, smem);
+        return;
+    }
     int mi = 0;
     for (int m = 1; m < A.nmat; ++m) if ((int)blockIdx.y >= A.mat[m].start) mi = m;
     const Wg64Mat M = A.mat[mi];
@@ -498,22 +522,6 @@ static int launch_gru_rec(const GruRecArgs& A, int H, bool bwd, hipStream_t s, u
     return DR4SR_LAUNCH_CHECK();
 }
 
-// tail[0..1] += sum of the scorer's per-sequence (count, loss) partials
-// tail[2] += the cooperative recurrence's sticky error word (the optimizer's poison word, csrc/step.hip k_adam)
-__global__ __launch_bounds__(256) void k_sum_score_part(const float* __restrict__ part, float* __restrict__ tail, int B,
-                                                        const int* __restrict__ err_word) {
-    __shared__ float red[512];
-    float c = 0.f, l = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) { c += part[2 * b]; l += part[2 * b + 1]; }
-    red[threadIdx.x] = c; red[256 + threadIdx.x] = l;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { tail[0] += red[0]; tail[1] += red[256]; if (err_word && *err_word) tail[2] += 1.0f; }
-}
-
 // ------------------------------------------------------------------------------------------------ orchestration
 static GruWaveArgs wave_args(const dr4sr_gru4rec_plan* p, const GruWs& ws) {
     GruWaveArgs G{};
@@ -603,9 +611,9 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     // instead of 12 is worth 0.8 % of the step; 2 is too few workgroups)
     int gw = gwf > 0 ? gwf : (ntiles / 32 > 6 ? (ntiles / 32 > 32 ? 32 : ntiles / 32) : 6);
     if (gw > ntiles) gw = ntiles;
-    hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
-    // with_score == 0 (autograd path): no scorer partials to add, the launch only forwards the recurrence's error word
-    hipLaunchKernelGGL(k_sum_score_part, dim3(1), dim3(256), 0, s, ws.score_part, p->grads + ws.n_params, with_score ? p->B : 0, ws.ctl + 2);
+    // with_score == 0 (autograd path): no scorer partials to add, the extra job only forwards the recurrence's error word
+    WA.njobs = nj; WA.score_part = ws.score_part; WA.tail = p->grads + ws.n_params; WA.nscore = with_score ? p->B : 0; WA.err_word = ws.ctl + 2;
+    hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj + 1), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
     return DR4SR_LAUNCH_CHECK();
 }
 
