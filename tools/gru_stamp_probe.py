@@ -1,6 +1,6 @@
 """Per-phase shader-clock stamps of one middle time step of the two-layer GRU wavefront kernels (csrc/gru_coop.hip, WAVE_STAMP).
-   DR4SR_GRU_WAVE_STAMP=1 python tools/gru_stamp_probe.py [fwd|bwd]   (the stamps of the LAST launch survive: fwd_bwd leaves the backward's;
-   `fwd` runs the forward hook alone afterwards)"""
+   python tools/gru_stamp_probe.py [fwd|bwd]   (the stamps of the LAST stamped launch survive; `fwd` runs the forward hook alone after
+   three steps; `bwd` needs DR4SR_GRU_WAVE_BWD=1: only the opt-in one-launch backward, k_gru_bwd_pair, carries stamps)"""
 import os, sys
 os.environ["DR4SR_GRU_WAVE_STAMP"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
