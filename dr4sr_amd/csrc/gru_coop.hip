@@ -726,6 +726,88 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd_wave(const WaveArgs A) {
     finish_launch(A.ctl);
 }
 
+// Single-layer forward of the 16-slice form on the bf16 matrix cores (= the layer-1 half of k_gru_fwd_wave with a two-entry ring instead
+// of per-step slots): plans the wavefront does not take (one, three or four layers; DR4SR_GRU_NOWAVE).  k_gru_fwd_coop<256, 16> is the
+// fp32 form (DR4SR_GRU_FWD_F32).
+template <int H, int NS>
+__global__ __launch_bounds__(256) void k_gru_fwd_coop_bf(const CoopArgs A) {
+    constexpr int US = H / NS;
+    static_assert(US == 16 && H == 256, "one 16-unit tile per slice, four K-quarter waves of two 32-k MFMAs");
+    float* part = smem;                                   // [2 parity][4 kq][3][16 unit][16 seq]
+    int* meta = reinterpret_cast<int*>(part + 2 * 4 * 3 * 256);
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int grp = (jx / NS) * 8 + xcd, sl = jx % NS, b0 = grp * 16;
+    if (b0 >= A.B) { finish_launch(A.ctl); return; }
+    if (threadIdx.x < 16) {
+        const int b = b0 + threadIdx.x;
+        meta[threadIdx.x] = b < A.B ? A.cu[b] : 0;
+        meta[16 + threadIdx.x] = b < A.B ? A.cu[b + 1] - A.cu[b] : 0;
+    }
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    bf16x8 whh[3][2], whl[3][2];                          // W_hh[gate row of unit l16][kq 64 + 32 m + 8 g + j], split hi | lo
+#pragma unroll
+    for (int q3 = 0; q3 < 3; ++q3)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const size_t o = (size_t)(q3 * H + sl * US + l16) * H + kq * 64 + m * 32 + 8 * g;
+            float x[8];
+            const float4 a = ld4(A.whh + o), b = ld4(A.whh + o + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            split8(x, whh[q3][m], whl[q3][m]);
+        }
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) nmax = max(nmax, meta[16 + s]);
+    const unsigned base = (unsigned)A.ctl[0] * 64u;
+    const int es = threadIdx.x & 15, eu = threadIdx.x >> 4;
+    const int tq = meta[es], nq = meta[16 + es], gu = sl * US + eu;
+    u64* ring = A.xch + (size_t)grp * 2 * 16 * H;         // h[t]: [2][16 H], granule (k, seq) at gran_idx
+    const size_t lane_off = (size_t)kq * 1024 + lane, own_off = gran_idx(gu, es);
+    float hown = 0.f;
+    unsigned hv[16];
+    for (int t = 0; t < nmax; ++t) {
+        const bool act = t < nq;
+        float gir = 0.f, giz = 0.f, gin = 0.f;
+        if (act) { const float* gip = A.gi + (size_t)(tq + t) * 3 * H + gu; gir = gip[0]; giz = gip[H]; gin = gip[2 * H]; }
+        f32x4 acc[3];
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3) acc[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            sweep_payloads<16>(ring + (size_t)((t - 1) & 1) * 16 * H + lane_off, 64, base + t, hv, A.ctl + 2);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                bf16x8 ah, al;
+                unpack8(hv + 8 * m, ah, al);
+#pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3) acc[q3] = mfma_x3(ah, al, whh[q3][m], whl[q3][m], acc[q3]);
+            }
+        }
+        float* pt = part + (t & 1) * (4 * 3 * 256);
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3) *reinterpret_cast<f32x4*>(pt + ((kq * 3 + q3) * 16 + l16) * 16 + 4 * g) = acc[q3];
+        __syncthreads();
+        float gh[3];
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3) {
+            const float* pp = pt + (q3 * 16 + eu) * 16 + es;
+            gh[q3] = (pp[0] + pp[3 * 256]) + (pp[2 * 3 * 256] + pp[3 * 3 * 256]);
+        }
+        float rr = 0.f, zz = 0.f, nn = 0.f;
+        const float hold = hown;
+        if (act) {
+            rr = sigm(gir + gh[0]); zz = sigm(giz + gh[1]); nn = tanh_f(gin + rr * gh[2]);
+            hown = (1.0f - zz) * nn + zz * hold;
+        }
+        if (t + 1 < nmax) put_granule_u(ring + (size_t)(t & 1) * 16 * H + own_off, base + t + 1, pack_split(hown));     // the exchange first
+        if (act) {
+            const size_t o = (size_t)(tq + t) * H + gu;
+            A.r[o] = rr; A.z[o] = zz; A.n[o] = nn; A.ghn[o] = gh[2]; A.hprev[o] = hold; A.hout[o] = hown;
+        }
+    }
+    finish_launch(A.ctl);
+}
+
 // Single-layer BPTT of the 16-slice form on the bf16 matrix cores: k_gru_bwd_coop with the slice's W_hh rows as split (hi | lo) MFMA B
 // operands in REGISTERS instead of an fp32 LDS image read column-wise (48 ds_read_b32 per lane and step on the recurrent chain) and the
 // partial product as 3-term bf16 (24 MFMAs of 8 passes instead of 48).  Same exchange, same granules, same ring.
@@ -1169,7 +1251,12 @@ int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float*
     // 16 slices: the budget counted one workgroup per CU, but the launch must not depend on a perfectly even placement: require
     // room for two per CU
     static const bool bwd_f32 = getenv("DR4SR_GRU_BWD_F32") != nullptr;         // cross-check switch: the fp32-MFMA BPTT with W_hh in LDS
-    if (H == 256 && ns == 16 && bwd && !bwd_f32) {
+    static const bool fwd_f32 = getenv("DR4SR_GRU_FWD_F32") != nullptr;         // ... and the fp32-MFMA forward
+    if (H == 256 && ns == 16 && !bwd && !fwd_f32) {
+        const size_t lds = sizeof(float) * 2 * 4 * 3 * 256 + 32 * sizeof(int);
+        if (!resident((const void*)k_gru_fwd_coop_bf<256, 16>, lds, 1)) return -100;
+        hipLaunchKernelGGL((k_gru_fwd_coop_bf<256, 16>), grid, blk, lds, s, A);
+    } else if (H == 256 && ns == 16 && bwd && !bwd_f32) {
         const size_t lds = sizeof(float) * 2 * 16 * (3 * 16 + 4) + 32 * sizeof(int);
         if (!resident((const void*)k_gru_bwd_coop_bf<256, 16>, lds, 1)) return -100;
         hipLaunchKernelGGL((k_gru_bwd_coop_bf<256, 16>), grid, blk, lds, s, A);

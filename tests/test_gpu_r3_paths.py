@@ -143,12 +143,12 @@ def test_gru4rec_partial_batch_in_the_workspace_of_a_larger_one():
         assert relerr(out[(300, 256)][k], v) < 2e-5, k
 
 
-@pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_BWD_F32": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1"}],
+@pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_BWD_F32": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1", "DR4SR_GRU_FWD_F32": "1"}],
                          ids=["one-launch-per-layer", "backward-wavefront", "fp32-bptt", "round-2-kernels"])
 def test_gru4rec_wavefront_switches_vs_oracle(env):
     """Two-layer plans run both forward recurrences in one launch by default (layer wavefront, csrc/gru_coop.hip); DR4SR_GRU_NOWAVE = the
     one-launch-per-layer form, DR4SR_GRU_WAVE_BWD = the (opt-in, not faster) one-launch backward, DR4SR_GRU_BWD_F32 = the fp32-MFMA BPTT with
-    W_hh in LDS instead of the bf16x3 one with W_hh in registers (k_gru_bwd_coop_bf).  All are `static` switches: the oracle
+    W_hh in LDS instead of the bf16x3 one with W_hh in registers (k_gru_bwd_coop_bf; DR4SR_GRU_FWD_F32 likewise for the single-layer forward).  All are `static` switches: the oracle
     tests that reach them — BASELINE configs[2] exactly, partial groups, chunks of 256 with a ragged last chunk — re-run in a fresh interpreter"""
     e = dict(os.environ)
     e.update(env)
