@@ -624,10 +624,11 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     auto lds_of = [&](int rows) { return sizeof(float) * ((bwd ? (rows == 16 ? 4 : 3) : 2) * rows * (D + 4) + (bwd ? 2 * rows * 3 : 0) + 64); };
     if (!split_by_length(ws)) {
         const size_t lds = lds_of(64);
-        if (bwd && DH == 32) { big_lds(k_attn2_bwd<DH, 64, 512, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512, false>), dim3(B), dim3(512), lds, s, A); }
-        else if (bwd) {                              // head_dim 64: the 8-wave variant would spill (256-VGPR cap at 512 threads)
-            big_lds(k_attn2_bwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A);
-        }
+        // backward: 8 waves per sequence for both head widths (head_dim 64 needed 187 VGPRs and ran with 4 waves until the dropout decisions
+        // came from one Philox call per lane and tile: 118 now; d = 128, B = 256: 2 x 19.4 -> 2 x 14.7 us).  DR4SR_ATTN_BWD_4WAVE: cross-check
+        static const bool four = getenv("DR4SR_ATTN_BWD_4WAVE") != nullptr;
+        if (bwd && !four) { big_lds(k_attn2_bwd<DH, 64, 512, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512, false>), dim3(B), dim3(512), lds, s, A); }
+        else if (bwd) { big_lds(k_attn2_bwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
         else { big_lds(k_attn2_fwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
         return DR4SR_LAUNCH_CHECK();
     }

@@ -294,6 +294,8 @@ _SWITCH_CASES = [
     ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_FWD_WAVES": "16", "DR4SR_WT_BWD_WAVES": "8", "DR4SR_WT_MID_WAVES": "12", "DR4SR_WT_EMB_WAVES": "12"},
      "test_full_size_batch_vs_oracle or test_fuzz_odd_batches_vs_oracle"),
     ({"DR4SR_PREP2_INLINE": "1"}, "test_train_steps_equals_repeated_train_step"),
+    # the 4-wave per-sequence attention backward (head_dim 64 ran on it until round 3)
+    ({"DR4SR_ATTN_BWD_4WAVE": "1"}, "test_full_size_batch_vs_oracle or test_fwd_bwd_with_dropout_matches_oracle_with_same_masks"),
 ]
 
 
