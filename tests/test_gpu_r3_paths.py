@@ -143,8 +143,8 @@ def test_gru4rec_partial_batch_in_the_workspace_of_a_larger_one():
         assert relerr(out[(300, 256)][k], v) < 2e-5, k
 
 
-@pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_BWD_F32": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1", "DR4SR_GRU_FWD_F32": "1"}],
-                         ids=["one-launch-per-layer", "backward-wavefront", "fp32-bptt", "round-2-kernels"])
+@pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1", "DR4SR_GRU_FWD_F32": "1"}],
+                         ids=["one-launch-per-layer", "backward-wavefront", "round-2-kernels"])
 def test_gru4rec_wavefront_switches_vs_oracle(env):
     """Two-layer plans run both forward recurrences in one launch by default (layer wavefront, csrc/gru_coop.hip); DR4SR_GRU_NOWAVE = the
     one-launch-per-layer form, DR4SR_GRU_WAVE_BWD = the (opt-in, not faster) one-launch backward, DR4SR_GRU_BWD_F32 = the fp32-MFMA BPTT with
