@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR4SR_LIB_PATH") or os.path.join(_HERE, "csrc", "libdr4sr_hip.so")     # override: A/B runs of two builds on one box
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 GRAD_TAIL = 4
 STATE_WORDS = 16
 STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
@@ -141,6 +141,7 @@ SYMBOLS = {
     "dr4sr_gru4rec_encode": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_gru4rec_encode_bwd": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_adam_flat": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "dr4sr_reload_env": (C.c_int, []),
     "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_launch_kernel_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_gru4rec_launch_kernel": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, C.c_void_p]),
@@ -156,6 +157,7 @@ SYMBOLS = {
     "dr4sr_fd_shift": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
     "dr4sr_fd_neumann": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
     "dr4sr_fd_diff": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
+    "dr4sr_fd_diff4": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
     "dr4sr_scale_by": (C.c_int, [_f32p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_meta_sgd_step": (C.c_int, [_f32p, _f32p, _f32p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                       _f32p, C.c_void_p]),

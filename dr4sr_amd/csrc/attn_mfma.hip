@@ -603,7 +603,7 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
 
 // Large batches (same threshold as tile_rows): two persistent launches over k_prep's length-class lists instead of one
 // workgroup per sequence with worst-case LDS.  seq_class = [n_short, n_long, n_tiny, - | tiny_desc[B] int4 | short_list[B] | long_list[B] | tiny_list[B]].
-static bool split_by_length(const Workspace& ws) { return ws.attn_split && !getenv("DR4SR_ATTN_NOSPLIT"); }
+static bool split_by_length(const Workspace& ws) { return ws.attn_split && !DR4SR_ENV("DR4SR_ATTN_NOSPLIT"); }
 
 // short sequences, backward: one wave per head runs phase A then phase B (2 waves per sequence, twice the sequences per CU of the
 // 4-wave form — the kernel is bound by how many sequences are in flight, not by issue slots)
@@ -611,7 +611,7 @@ constexpr int SHORT_BWD_NT = 256;
 
 // workgroups of `kernel` that fit one CU (fallback: the hand-computed figure)
 static int resident_per_cu(const void* kernel, int threads, size_t lds, int fallback) {
-    if (getenv("DR4SR_ATTN_GRID_FIXED")) return fallback;
+    if (DR4SR_ENV("DR4SR_ATTN_GRID_FIXED")) return fallback;
     if (lds > 48 * 1024) big_lds_impl(kernel, lds);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fallback; }
@@ -626,7 +626,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
         const size_t lds = lds_of(64);
         // backward: 8 waves per sequence for both head widths (head_dim 64 needed 187 VGPRs and ran with 4 waves until the dropout decisions
         // came from one Philox call per lane and tile: 118 now; d = 128, B = 256: 2 x 19.4 -> 2 x 14.7 us).  DR4SR_ATTN_BWD_4WAVE: cross-check
-        static const bool four = getenv("DR4SR_ATTN_BWD_4WAVE") != nullptr;
+        const bool four = DR4SR_ENV("DR4SR_ATTN_BWD_4WAVE") != nullptr;
         if (bwd && !four) { big_lds(k_attn2_bwd<DH, 64, 512, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512, false>), dim3(B), dim3(512), lds, s, A); }
         else if (bwd) { big_lds(k_attn2_bwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
         else { big_lds(k_attn2_fwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
@@ -635,12 +635,14 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     // persistent grids = what is really co-resident (registers, LDS and wave slots, as the runtime computes it): a larger grid
     // runs in two rounds with an unbalanced tail, a smaller one leaves latency-hiding slots empty
     static int per_cu[2][2];                                                 // [bwd][long], per head width
+    static int per_cu_gen[2] = {-1, -1};                                     // DR4SR_ATTN_GRID_FIXED may have changed (dr4sr_reload_env)
+    if (per_cu_gen[bwd] != dr4sr_env_generation()) { per_cu[bwd][0] = 0; per_cu_gen[bwd] = dr4sr_env_generation(); }
     if (!per_cu[bwd][0]) {
         per_cu[bwd][1] = bwd ? resident_per_cu((const void*)k_attn2_bwd<DH, 64, 256, true>, 256, lds_of(64), 2)
                              : resident_per_cu((const void*)k_attn2_fwd<DH, 64, 256, true>, 256, lds_of(64), 3);
         per_cu[bwd][0] = bwd ? resident_per_cu((const void*)k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>, SHORT_BWD_NT, lds_of(16), 4)
                              : resident_per_cu((const void*)k_attn2_fwd<DH, 16, 128, true>, 128, lds_of(16), 8);
-        if (getenv("DR4SR_ATTN_GRID_PRINT")) fprintf(stderr, "attention grids (DH %d, %s): %d short / %d long workgroups per CU\n", DH, bwd ? "bwd" : "fwd", per_cu[bwd][0], per_cu[bwd][1]);
+        if (DR4SR_ENV("DR4SR_ATTN_GRID_PRINT")) fprintf(stderr, "attention grids (DH %d, %s): %d short / %d long workgroups per CU\n", DH, bwd ? "bwd" : "fwd", per_cu[bwd][0], per_cu[bwd][1]);
     }
     const int per_cu_s = per_cu[bwd][0], per_cu_l = per_cu[bwd][1];
     const int gs = B < 256 * per_cu_s ? B : 256 * per_cu_s;
@@ -652,12 +654,12 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
     // default: the 1..8-token and 9..16-token classes as ONE launch (k_attn_small_*), then the 64-row list.  DR4SR_ATTN_NOMERGE: one
     // launch per class (cross-check, read per call like DR4SR_ATTN_NOTINY)
-    if (!getenv("DR4SR_ATTN_NOTINY") && !getenv("DR4SR_ATTN_NOMERGE")) {
-        static const int dv = getenv("DR4SR_ATTN_SMALL_DIV") ? atoi(getenv("DR4SR_ATTN_SMALL_DIV")) : 2;      // share of the residency left to the tiny blocks (tuning)
+    if (!DR4SR_ENV("DR4SR_ATTN_NOTINY") && !DR4SR_ENV("DR4SR_ATTN_NOMERGE")) {
+        const int dv = DR4SR_ENV("DR4SR_ATTN_SMALL_DIV") ? atoi(DR4SR_ENV("DR4SR_ATTN_SMALL_DIV")) : 2;      // share of the residency left to the tiny blocks (tuning)
         const int gsm = gs / (dv > 0 ? dv : 1) > 0 ? gs / (dv > 0 ? dv : 1) : 1;
         const size_t lds_t = tiny::TinyLds<DH>::bytes(bwd), lds_m = lds_s > lds_t ? lds_s : lds_t;
         dim3 grid(gsm + (B + tiny::SPB - 1) / tiny::SPB);
-        static const bool merge_bwd = getenv("DR4SR_ATTN_MERGE_BWD") != nullptr;
+        const bool merge_bwd = DR4SR_ENV("DR4SR_ATTN_MERGE_BWD") != nullptr;
         if (bwd && !merge_bwd) {
             // backward: NOT merged by default — the tiny class needs 192 VGPRs, the 16-row list 120; at the merged kernel's 208 the list's
             // workgroups fill the register file two per CU and the tiny blocks queue behind them (32.7 us against 19.2 + 9.8)
@@ -680,7 +682,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
         return DR4SR_LAUNCH_CHECK();
     }
     // third class, 1..8 tokens: VALU kernels (attn_tiny_body.h).  DR4SR_ATTN_NOTINY (cross-check): the same list through the 16-row MFMA kernels
-    if (!getenv("DR4SR_ATTN_NOTINY")) {
+    if (!DR4SR_ENV("DR4SR_ATTN_NOTINY")) {
         const int rc = launch_attn_tiny(Tn, DH, B, bwd, s);
         if (rc) return rc;
     } else if (bwd) hipLaunchKernelGGL((k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>), dim3(gs), dim3(SHORT_BWD_NT), lds_s, s, Tn);

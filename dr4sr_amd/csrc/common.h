@@ -4,6 +4,19 @@
 #include <stdint.h>
 #include "../../include/dr4sr_hip.h"
 #include "../../include/dr4sr_hip_hooks.h"
+#include <stdlib.h>
+#include <string.h>
+
+// Environment switches: every site caches its variable's value and re-reads it when dr4sr_reload_env() (hooks header) has bumped the
+// generation — process-lifetime constants in production, switchable in-process by the tests.  The value is COPIED (a later setenv may
+// free the string getenv returned).  DR4SR_ENV("X") -> const char* or nullptr.
+int dr4sr_env_generation();                                   // step.hip
+#define DR4SR_ENV(NAME) ([]() -> const char* {                                                   \
+    static int gen_ = -1; static bool set_ = false; static char buf_[64];                        \
+    const int cur_ = dr4sr_env_generation();                                                     \
+    if (gen_ != cur_) { const char* e_ = getenv(NAME); set_ = e_ != nullptr;                     \
+        if (e_) { strncpy(buf_, e_, sizeof(buf_) - 1); buf_[sizeof(buf_) - 1] = 0; } gen_ = cur_; } \
+    return set_ ? buf_ : nullptr; }())
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -201,7 +201,7 @@ static int launch_gemm(const float* A, int lda, const float* W, int ldw, const f
                        bool colmode, int Tmax, const int* state, hipStream_t s) {
     const size_t lds = sizeof(float) * 64 * 68;
     dim3 blk(256);
-    static const bool no16 = getenv("DR4SR_GRU_GEMM64") != nullptr;          // cross-check switch: 64-row tiles everywhere
+    const bool no16 = DR4SR_ENV("DR4SR_GRU_GEMM64") != nullptr;          // cross-check switch: 64-row tiles everywhere
     if (!no16 && !at_scale(Tmax) && N % 64 == 0 && ((colmode && !bias && K == 64) || (!colmode && (K == 64 || K == 128 || K == 256)))) {
         const size_t l16 = sizeof(float) * 16 * (K + 4);
         dim3 grid((Tmax + 15) / 16, N / 64);
@@ -606,7 +606,7 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     add(ws.dY, D, D, ws.layer[nl - 1].hout, H, H, Gd + ws.off_ow, Gd + ws.off_ob);
     WA.state = p->state;
     const int ntiles = (ws.Tmax + 63) / 64;
-    static const int gwf = getenv("DR4SR_GRU_WGRAD_GW") ? atoi(getenv("DR4SR_GRU_WGRAD_GW")) : 0;     // tuning knob
+    const int gwf = DR4SR_ENV("DR4SR_GRU_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_GRU_WGRAD_GW")) : 0;     // tuning knob
     // token-tile splits per 64x64 output tile: every split ends in 4 096 atomics, so fewer, longer splits at small batches (B = 256: 6
     // instead of 12 is worth 0.8 % of the step; 2 is too few workgroups)
     int gw = gwf > 0 ? gwf : (ntiles / 32 > 6 ? (ntiles / 32 > 32 ? 32 : ntiles / 32) : 6);

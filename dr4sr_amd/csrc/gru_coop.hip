@@ -1181,9 +1181,9 @@ static int device_cus() {
 //     device with room to spare (budget: one per CU);
 //    8 slices: 140 KB, one per CU — budget three quarters of the CUs, at most 192 workgroups (24 groups).
 static int coop_slices(int B, int H) {
-    if (getenv("DR4SR_GRU_NOCOOP") || (H != 128 && H != 256)) return 0;
+    if (DR4SR_ENV("DR4SR_GRU_NOCOOP") || (H != 128 && H != 256)) return 0;
     const int groups = (B + 15) / 16, g8 = ((groups + 7) / 8) * 8, cus = device_cus();
-    static const bool no16 = getenv("DR4SR_GRU_NS8") != nullptr;             // cross-check switch: always 8 slices
+    const bool no16 = DR4SR_ENV("DR4SR_GRU_NS8") != nullptr;             // cross-check switch: always 8 slices
     if (H == 256 && !no16 && g8 * 16 <= cus) return 16;
     int b8 = cus * 3 / 4;
     if (b8 > 192) b8 = 192;
@@ -1197,7 +1197,7 @@ static int coop_slices(int B, int H) {
 constexpr int COOP_CHUNK = 256, COOP_MAX_CHUNKS = 6;
 static int coop_chunk(int B, int H) {
     if (coop_slices(B, H)) return B;
-    static const bool nochunk = getenv("DR4SR_GRU_NOCHUNK") != nullptr;         // cross-check switch
+    const bool nochunk = DR4SR_ENV("DR4SR_GRU_NOCHUNK") != nullptr;         // cross-check switch
     if (!nochunk && B <= COOP_CHUNK * COOP_MAX_CHUNKS && coop_slices(COOP_CHUNK, H)) return COOP_CHUNK;
     return 0;
 }
@@ -1250,8 +1250,8 @@ int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float*
                hipLaunchKernelGGL((k_gru_bwd_coop<H_, NS_>), grid, blk, lds, s, A); } } while (0)
     // 16 slices: the budget counted one workgroup per CU, but the launch must not depend on a perfectly even placement: require
     // room for two per CU
-    static const bool bwd_f32 = getenv("DR4SR_GRU_BWD_F32") != nullptr;         // cross-check switch: the fp32-MFMA BPTT with W_hh in LDS
-    static const bool fwd_f32 = getenv("DR4SR_GRU_FWD_F32") != nullptr;         // ... and the fp32-MFMA forward
+    const bool bwd_f32 = DR4SR_ENV("DR4SR_GRU_BWD_F32") != nullptr;         // cross-check switch: the fp32-MFMA BPTT with W_hh in LDS
+    const bool fwd_f32 = DR4SR_ENV("DR4SR_GRU_FWD_F32") != nullptr;         // ... and the fp32-MFMA forward
     if (H == 256 && ns == 16 && !bwd && !fwd_f32) {
         const size_t lds = sizeof(float) * 2 * 4 * 3 * 256 + 32 * sizeof(int);
         if (!resident((const void*)k_gru_fwd_coop_bf<256, 16>, lds, 1)) return -100;
@@ -1272,7 +1272,7 @@ int launch_gru_rec_coop(const float* gi, const float* whh, const int* cu, float*
 // Applies to n_layer == 2, H == 256 and batches the 16-slice cooperative form takes (at most 16 groups per launch: B <= 256, or chunks of
 // 256 up to 1536): 2 layers x 16 groups x 16 slices = 512 workgroups, two per CU.  DR4SR_GRU_NOWAVE (cross-check): one launch per layer.
 static bool wave_ok(int B, int H, int n_layer, int L) {
-    static const bool off = getenv("DR4SR_GRU_NOWAVE") != nullptr;
+    const bool off = DR4SR_ENV("DR4SR_GRU_NOWAVE") != nullptr;
     if (off || n_layer != 2 || H != 256 || L > 64) return false;
     const int cb = coop_chunk(B, H);
     return cb != 0 && coop_slices(cb, H) == 16 && 2 * 16 * (((cb + 15) / 16 + 7) / 8) * 8 <= 2 * device_cus();
@@ -1290,14 +1290,14 @@ int64_t gru_xch_words(int B, int H, int L, int n_layer) {
 // returns -100 when the plan does not qualify (caller: one cooperative launch per layer)
 int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int B, int H, int L, bool bwd, hipStream_t s) {
     if (!xch || !ctl || !wave_ok(B, H, 2, L)) return -100;
-    static const bool wave_bwd = getenv("DR4SR_GRU_WAVE_BWD") != nullptr;
+    const bool wave_bwd = DR4SR_ENV("DR4SR_GRU_WAVE_BWD") != nullptr;
     if (bwd && !wave_bwd) return -100;
     const int cb = coop_chunk(B, H);
     WaveArgs A;
     A.gi1 = G.gi1; A.wih2 = G.wih2; A.dhout = G.dhout; A.xch = xch; A.ctl = ctl; A.L = L;
-    static const int presleep = getenv("DR4SR_GRU_WAVE_PRESLEEP") ? atoi(getenv("DR4SR_GRU_WAVE_PRESLEEP")) : 0;
-    static const int solo = getenv("DR4SR_GRU_WAVE_SOLO") ? atoi(getenv("DR4SR_GRU_WAVE_SOLO")) : 0;            // diagnosis only: the follower layer does not run (wrong results)
-    static const int stamp = getenv("DR4SR_GRU_WAVE_STAMP") ? 1 : 0;
+    const int presleep = DR4SR_ENV("DR4SR_GRU_WAVE_PRESLEEP") ? atoi(DR4SR_ENV("DR4SR_GRU_WAVE_PRESLEEP")) : 0;
+    const int solo = DR4SR_ENV("DR4SR_GRU_WAVE_SOLO") ? atoi(DR4SR_ENV("DR4SR_GRU_WAVE_SOLO")) : 0;            // diagnosis only: the follower layer does not run (wrong results)
+    const int stamp = DR4SR_ENV("DR4SR_GRU_WAVE_STAMP") ? 1 : 0;
     A.presleep = presleep; A.solo = solo; A.stamp = stamp;
     for (int l = 0; l < 2; ++l) {
         A.whh[l] = G.whh[l]; A.r[l] = G.r[l]; A.z[l] = G.z[l]; A.n[l] = G.n[l]; A.ghn[l] = G.ghn[l]; A.hprev[l] = G.hprev[l]; A.hout[l] = G.hout[l];

@@ -63,24 +63,24 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ X, co
 // tile rows per workgroup for the token-tile kernels: 16 while the whole batch is small (latency regime: 4x shorter MFMA
 // chains, every CU gets work), 32 at scale (occupancy regime: 4 workgroups per CU interleave their latency chains).
 int latency_tmax() {
-    static const int v = getenv("DR4SR_LATENCY_TMAX") ? atoi(getenv("DR4SR_LATENCY_TMAX")) : 16384;
+    const int v = DR4SR_ENV("DR4SR_LATENCY_TMAX") ? atoi(DR4SR_ENV("DR4SR_LATENCY_TMAX")) : 16384;
     return v;
 }
 int tile_rows(const Workspace& ws) {
-    static const int forced = getenv("DR4SR_BM") ? atoi(getenv("DR4SR_BM")) : 0;
+    const int forced = DR4SR_ENV("DR4SR_BM") ? atoi(DR4SR_ENV("DR4SR_BM")) : 0;
     if (forced == 16 || forced == 32 || forced == 64) return forced;
     return ws.scale ? 32 : 16;
 }
 // large batches: the table-gradient scatter of the embedding stage (T x D fp32 atomics, ~55 G/s: 0.47 ms of the dense B=8192 step
 // when it sits at the end of k_qkv_embed_bwd) runs as an extra job of k_wgrad, where it overlaps the MFMA-bound weight-gradient jobs
 static bool scatter_in_wgrad(const Workspace& ws) {
-    static const bool off = getenv("DR4SR_SCATTER_INLINE") != nullptr || getenv("DR4SR_NO_FUSE") != nullptr;
+    const bool off = DR4SR_ENV("DR4SR_SCATTER_INLINE") != nullptr || DR4SR_ENV("DR4SR_NO_FUSE") != nullptr;
     return !off && ws.scale;
 }
 // large batches: the item-table gradient is NOT accumulated with fp32 atomics (scorer: 2 rows per token, embedding stage: 1) but
 // summed row by row by owner workgroups inside k_wgrad (owner_job): deterministic, and ~55 us of a toys-shaped B = 8192 step
 // cheaper.  DR4SR_DE_ATOMIC (read per call) restores the atomics as a cross-check.
-static bool de_owner_mode(const Workspace& ws) { return scatter_in_wgrad(ws) && !getenv("DR4SR_DE_ATOMIC"); }
+static bool de_owner_mode(const Workspace& ws) { return scatter_in_wgrad(ws) && !DR4SR_ENV("DR4SR_DE_ATOMIC"); }
 // Owner geometry of the table gradient: G = 2^logG owners, the smallest power of two (>= 256) whose rows fit k_wgrad's LDS four
 // times (one private copy per wave) plus the queues.  Shared by the scorer launch (tile_sort needs G) and the k_wgrad launch.
 static size_t wgrad_lds_base(const dr4sr_sasrec_plan* p) {
@@ -90,7 +90,7 @@ static size_t wgrad_lds_base(const dr4sr_sasrec_plan* p) {
     return lds;
 }
 static int owner_logG(const dr4sr_sasrec_plan* p) {
-    int logG = getenv("DR4SR_OWNER_LOGG") ? atoi(getenv("DR4SR_OWNER_LOGG")) : 8;      // tuning knob
+    int logG = DR4SR_ENV("DR4SR_OWNER_LOGG") ? atoi(DR4SR_ENV("DR4SR_OWNER_LOGG")) : 8;      // tuning knob
     const size_t lds = wgrad_lds_base(p);
     while (sizeof(float) * 4 * (size_t)((p->n_items + (1 << logG) - 1) >> logG) * p->D + 4 * 16 * 4 * sizeof(int) > lds && logG < 20) ++logG;
     return logG;
@@ -101,7 +101,7 @@ static int owner_logG(const dr4sr_sasrec_plan* p) {
 static bool wt_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta) { return wave_tiles(p, ws) && wt_bwd_on() && !meta; }
 static int mid_tile_rows(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta) { return wt_mid(p, ws, meta) ? 16 : tile_rows(ws); }
 static bool owner_sorted(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta = false) {
-    return de_owner_mode(ws) && (tile_rows(ws) != 16 || wt_mid(p, ws, meta)) && owner_logG(p) <= 10 && !getenv("DR4SR_OWNER_SCAN");
+    return de_owner_mode(ws) && (tile_rows(ws) != 16 || wt_mid(p, ws, meta)) && owner_logG(p) <= 10 && !DR4SR_ENV("DR4SR_OWNER_SCAN");
 }
 #define BM_DISPATCH(bm, CALL) do { if ((bm) == 16) { CALL(16); } else if ((bm) == 32) { CALL(32); } else { CALL(64); } } while (0)
 
@@ -1040,11 +1040,11 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = layer; A.training = training;
     A.sP = DR4SR_SITE_PROJ + 4 * layer; A.sA = DR4SR_SITE_ACT + 4 * layer; A.sF = DR4SR_SITE_FFN + 4 * layer;
     A.nx_in_w = A.nx_in_b = nullptr; A.nx_qkv = nullptr; A.up_dqkv = A.up_in_w = A.up_du1 = nullptr;
-    if (layer + 1 < p->n_layer && !getenv("DR4SR_NO_FUSE")) {
+    if (layer + 1 < p->n_layer && !DR4SR_ENV("DR4SR_NO_FUSE")) {
         A.nx_in_w = P + poff(ws, layer + 1, P_IN_W); A.nx_in_b = P + poff(ws, layer + 1, P_IN_B); A.nx_qkv = ws.layer[layer + 1].qkv;
         A.up_dqkv = ws.layer[layer + 1].dqkv; A.up_in_w = P + poff(ws, layer + 1, P_IN_W); A.up_du1 = ws.layer[layer + 1].du1;
     }
-    A.stamps = getenv("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
+    A.stamps = DR4SR_ENV("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
     return A;
 }
 
@@ -1269,7 +1269,7 @@ static QkvEmbBwdArgs make_qeb_args(const dr4sr_sasrec_plan* p, const Workspace& 
 // latency regime: k_qkv_embed_bwd and k_wgrad are independent (the weight gradients read dqkv / X, not dx0), so the embedding tiles
 // run as the first plane of the k_wgrad launch: one launch boundary less per step and the two overlap
 bool qeb_in_wgrad(const Workspace& ws) {
-    static const bool off = getenv("DR4SR_QEB_SEPARATE") != nullptr || getenv("DR4SR_NO_FUSE") != nullptr;
+    const bool off = DR4SR_ENV("DR4SR_QEB_SEPARATE") != nullptr || DR4SR_ENV("DR4SR_NO_FUSE") != nullptr;
     return !off && tile_rows(ws) == 16;
 }
 
@@ -1847,7 +1847,7 @@ __global__ __launch_bounds__(256) void k_fmlp_wgrad(const WgradArgs A) {
 }
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) {
     const int ntiles = (Tmax + 63) / 64;
-    static const int gwf = getenv("DR4SR_FMLP_WGRAD_GW") ? atoi(getenv("DR4SR_FMLP_WGRAD_GW")) : 0;     // tuning knob
+    const int gwf = DR4SR_ENV("DR4SR_FMLP_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_FMLP_WGRAD_GW")) : 0;     // tuning knob
     int gw_t = gwf > 0 ? gwf : (ntiles / 16 > 64 ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : 64);   // 64: every CU holds one heavy workgroup at B = 256 (48: 37.6 us, 64: 35.4)
     int gw = ntiles < gw_t ? ntiles : gw_t;
     const size_t lds = sizeof(float) * 64 * (64 + 256);
@@ -1890,16 +1890,16 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
     A.score_tiles = with_score == 2;
-    static const int gw_max = getenv("DR4SR_WGRAD_GW") ? atoi(getenv("DR4SR_WGRAD_GW")) : 48;   // tuning knob
+    const int gw_max = DR4SR_ENV("DR4SR_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_WGRAD_GW")) : 48;   // tuning knob
     // token splits per job at scale: 160 up to ~2 500 expected 64-token tiles, then tiles / 16 up to 320 (measured: toys B = 8 192,
     // 1 170 tiles: 128 / 160 / 224 splits -> 120.9 / 117.3 / 121.4 us; dense B = 8 192, 6 400 tiles: 160 / 224 / 320 / 448 -> 905 / 868 /
     // 840 / 854 us; toys B = 32 768: 160 -> 256 splits +1.4 % step).  Without a hint the capacity counts as before (cap 160).
-    static const int gw_cap_env = getenv("DR4SR_WGRAD_GW_CAP") ? atoi(getenv("DR4SR_WGRAD_GW_CAP")) : 0;
+    const int gw_cap_env = DR4SR_ENV("DR4SR_WGRAD_GW_CAP") ? atoi(DR4SR_ENV("DR4SR_WGRAD_GW_CAP")) : 0;
     const int hint_tiles = p->expected_tokens > 0 ? (int)((p->expected_tokens < ws.Tmax ? p->expected_tokens : ws.Tmax) / 64) : 0;
     const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > 320 ? 320 : hint_tiles / 16) : 160);
     // floor: 48 splits (36 real tiles at the toys B = 256 batch: one each), 64 once the batch is expected to hold >= 100 tiles
     // (dense B = 256, 200 tiles: k_wgrad 49.4 -> 44.2 us; 80 splits: 44.8)
-    static const bool gw_env = getenv("DR4SR_WGRAD_GW") != nullptr;
+    const bool gw_env = DR4SR_ENV("DR4SR_WGRAD_GW") != nullptr;
     const int gw_floor = !gw_env && hint_tiles >= 100 && gw_max < 64 ? 64 : gw_max;
     int gw_t = ntiles / 16 > gw_floor ? (ntiles / 16 > gw_cap ? gw_cap : ntiles / 16) : gw_floor;   // >= 16 token tiles per workgroup at scale
     int gw = ntiles < gw_t ? ntiles : gw_t;
@@ -1910,7 +1910,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
         A.sc_dE = G + ws.off[0]; A.sc_dP = G + ws.off[1]; A.sc_L = p->L; A.sc_n_items = p->n_items;
     }
     A.qeb_plane = (qeb && qeb_in_wgrad(ws)) ? 1 : 0;
-    static const bool wg_f32 = getenv("DR4SR_WGRAD_F32") != nullptr;
+    const bool wg_f32 = DR4SR_ENV("DR4SR_WGRAD_F32") != nullptr;
     A.bf16x3 = (ws.scale && !wg_f32) ? 1 : 0;              // at scale: weight gradients on the bf16 matrix cores (3-term split)
     const QkvEmbBwdArgs Q = make_qeb_args(p, ws, training);
     size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);

@@ -824,13 +824,12 @@ int wt_grid() {                                             // one workgroup per
     return n;
 }
 // waves per workgroup of each kernel (one workgroup per CU): 8 = 2 per SIMD (256 VGPRs), 12 = 3 (168), 16 = 4 (128); tuning knobs
-int wt_waves(const char* env, int dflt) {
-    const char* e = getenv(env);
+int wt_waves(const char* e, int dflt) {
     const int v = e ? atoi(e) : dflt;
     return v == 16 ? 16 : v == 12 ? 12 : 8;
 }
 bool wt_exact() {                                           // DR4SR_WT_BF16X3: the bf16x3 split instead of fp32 MFMA (forward kernel only)
-    static const bool v = getenv("DR4SR_WT_BF16X3") == nullptr;
+    const bool v = DR4SR_ENV("DR4SR_WT_BF16X3") == nullptr;
     return v;
 }
 
@@ -877,12 +876,12 @@ int wt_qeb_launch(const QkvEmbBwdArgs& A, int grid, hipStream_t s) {
 
 // the wave-tile forms serve the at-scale regime of the d = 64 / FFN 128 encoder (their LDS image of a d = 128 layer does not fit a CU)
 bool wave_tiles(const dr4sr_sasrec_plan* p, const Workspace& ws) {
-    static const bool off = getenv("DR4SR_NO_WAVE_TILES") != nullptr || getenv("DR4SR_NO_FUSE") != nullptr;
+    const bool off = DR4SR_ENV("DR4SR_NO_WAVE_TILES") != nullptr || DR4SR_ENV("DR4SR_NO_FUSE") != nullptr;
     return !off && ws.scale && p->D == 64 && p->F == 128;
 }
 
 bool wt_bwd_on() {
-    static const bool v = getenv("DR4SR_WT_FWD_ONLY") == nullptr;
+    const bool v = DR4SR_ENV("DR4SR_WT_FWD_ONLY") == nullptr;
     return v;
 }
 
@@ -890,7 +889,7 @@ int launch_wt_post_fwd(const PostArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    static const int W = wt_waves("DR4SR_WT_FWD_WAVES", 12);
+    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_FWD_WAVES"), 12);
     if (wt_exact()) return W == 16 ? wt_post_fwd_launch<16, true>(A, grid, s) : W == 12 ? wt_post_fwd_launch<12, true>(A, grid, s) : wt_post_fwd_launch<8, true>(A, grid, s);
     return W == 16 ? wt_post_fwd_launch<16, false>(A, grid, s) : W == 12 ? wt_post_fwd_launch<12, false>(A, grid, s) : wt_post_fwd_launch<8, false>(A, grid, s);
 }
@@ -899,7 +898,7 @@ int launch_wt_post_bwd(const PostArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    static const int W = wt_waves("DR4SR_WT_BWD_WAVES", 12);
+    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_BWD_WAVES"), 12);
     return W == 16 ? wt_post_bwd_launch<16>(A, grid, s) : W == 12 ? wt_post_bwd_launch<12>(A, grid, s) : wt_post_bwd_launch<8>(A, grid, s);
 }
 
@@ -907,7 +906,7 @@ int launch_wt_post_mid(const PostArgs& A, const ScoreTileArgs& S, int Tmax, hipS
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    static const int wm = wt_waves("DR4SR_WT_MID_WAVES", 8);
+    const int wm = wt_waves(DR4SR_ENV("DR4SR_WT_MID_WAVES"), 8);
     return wm == 16 ? wt_post_mid_launch<16>(A, S, grid, s) : wm == 12 ? wt_post_mid_launch<12>(A, S, grid, s) : wt_post_mid_launch<8>(A, S, grid, s);
 }
 
@@ -915,13 +914,13 @@ int launch_wt_embqkv_fwd(const EmbQkvArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    static const int W = wt_waves("DR4SR_WT_EMB_WAVES", 16);
+    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_EMB_WAVES"), 16);
     return W == 16 ? wt_embqkv_launch<16>(A, grid, s) : W == 12 ? wt_embqkv_launch<12>(A, grid, s) : wt_embqkv_launch<8>(A, grid, s);
 }
 int launch_wt_qkv_embed_bwd(const QkvEmbBwdArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    static const int W = wt_waves("DR4SR_WT_EMB_WAVES", 16);
+    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_EMB_WAVES"), 16);
     return W == 16 ? wt_qeb_launch<16>(A, grid, s) : W == 12 ? wt_qeb_launch<12>(A, grid, s) : wt_qeb_launch<8>(A, grid, s);
 }

@@ -279,6 +279,18 @@ __global__ void k_fd_diff(float* __restrict__ out, const float* __restrict__ fp,
     out[i] = ee > 0.f ? coef * (fp[i] / np[0] - fm[i] / nm[0]) / (2.0f * ee) : 0.f;
 }
 
+// Richardson-extrapolated central difference from the probes at +-e and +-2e: (4 D(e) - D(2e)) / 3, D(h) = (f(+h) - f(-h)) / 2h
+__global__ void k_fd_diff4(float* __restrict__ out, const float* __restrict__ fp1, const float* __restrict__ fm1,
+                           const float* __restrict__ fp2, const float* __restrict__ fm2, const float* __restrict__ nv,
+                           const float* __restrict__ e, float coef, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ee = e[0];
+    const float d1 = (fp1[i] / nv[0] - fm1[i] / nv[1]) / (2.0f * ee);
+    const float d2 = (fp2[i] / nv[2] - fm2[i] / nv[3]) / (4.0f * ee);
+    out[i] = ee > 0.f ? coef * (4.0f * d1 - d2) * (1.0f / 3.0f) : 0.f;
+}
+
 // out = x / *den
 __global__ void k_scale_by(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ den, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,6 +399,14 @@ extern "C" int dr4sr_fd_diff(float* out, const float* fp, const float* fm, const
     if (!out || !fp || !fm || !np || !nm || !e || n <= 0) return DR4SR_E_ARG;
     hipLaunchKernelGGL(k_fd_diff, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, fp, fm, np, nm, e,
                        coef, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dr4sr_fd_diff4(float* out, const float* fp1, const float* fm1, const float* fp2, const float* fm2, const float* nv4,
+                              const float* e, float coef, int64_t n, void* stream) {
+    if (!out || !fp1 || !fm1 || !fp2 || !fm2 || !nv4 || !e || n <= 0) return DR4SR_E_ARG;
+    hipLaunchKernelGGL(k_fd_diff4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, fp1, fm1, fp2, fm2,
+                       nv4, e, coef, n);
     return (int)hipGetLastError();
 }
 

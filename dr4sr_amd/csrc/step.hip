@@ -21,6 +21,10 @@ void big_lds_impl(const void* kernel, size_t bytes) {
 }
 
 extern "C" int dr4sr_abi_version(void) { return DR4SR_ABI_VERSION; }
+
+static int g_env_generation = 0;
+int dr4sr_env_generation() { return g_env_generation; }
+extern "C" int dr4sr_reload_env(void) { return ++g_env_generation; }
 extern "C" int dr4sr_sasrec_plan_sizeof(void) { return (int)sizeof(dr4sr_sasrec_plan); }
 
 extern "C" int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
@@ -71,7 +75,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->n_params = dr4sr_sasrec_param_layout(p->n_items, p->L, p->D, p->F, p->n_layer, ws->off);
     ws->Tmax = (int)Tmax;
     {
-        static const bool forced = getenv("DR4SR_LATENCY_TMAX") != nullptr;           // sweeps: the capacity rule with a moved boundary
+        const bool forced = DR4SR_ENV("DR4SR_LATENCY_TMAX") != nullptr;           // sweeps: the capacity rule with a moved boundary
         const int64_t hint = p->expected_tokens < Tmax ? p->expected_tokens : Tmax;
         const bool known = hint > 0 && !forced;
         // boundaries measured at d = 64; at d = 128 both crossovers sit at half the token count (4 k / 7 k): the work per token doubles
@@ -81,8 +85,8 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // B = 8 192 3.36 vs 3.62 ms), so the lists also need an expected mean length of at most 16 tokens
         ws->attn_split = known ? (hint * D > (int64_t)DR4SR_ATTN_SPLIT_TOKENS * 64 && hint <= 16 * (int64_t)p->B) : at_scale((int)Tmax);
         // tests (read per call): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
-        if (const char* f = getenv("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
-        if (const char* f = getenv("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
+        if (const char* f = DR4SR_ENV("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
+        if (const char* f = DR4SR_ENV("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
     }
     char* base = (char*)p->workspace;
     int64_t o = 0;
@@ -259,13 +263,13 @@ int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* sta
                      float eps, float wd, hipStream_t s, float* loss_log, const int* log_index, const PrepArgs* next) {
     if (!P || !G || !M || !V || !state || n <= 0 || (n & 3)) return DR4SR_E_ARG;
     int64_t blocks = (n / 4 + 255) / 256;
-    static const int cap = getenv("DR4SR_ADAM_BLOCKS") ? atoi(getenv("DR4SR_ADAM_BLOCKS")) : 256;
+    const int cap = DR4SR_ENV("DR4SR_ADAM_BLOCKS") ? atoi(DR4SR_ENV("DR4SR_ADAM_BLOCKS")) : 256;
     if (blocks > cap) blocks = cap;
     AdamNext nx;
     nx.enable = next ? (next->B > 1024 && next->len_buf && blocks <= PREP_MAX_BLK && (next->B + blocks - 1) / blocks < 65536 ? 2 : 1) : 0;
     nx.phase2_launch = 0;
     if (next) nx.prep = *next; else nx.prep = PrepArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, nullptr};
-    static const bool p2_inline = getenv("DR4SR_PREP2_INLINE") != nullptr;      // cross-check: phase 2 as the tail of the optimizer launch
+    const bool p2_inline = DR4SR_ENV("DR4SR_PREP2_INLINE") != nullptr;      // cross-check: phase 2 as the tail of the optimizer launch
     nx.phase2_launch = nx.enable == 2 && !p2_inline;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks + (nx.enable == 1 ? 1 : 0)), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx);
     if (nx.phase2_launch) {
@@ -305,7 +309,7 @@ static int launch_zero_grads(const dr4sr_sasrec_plan* p, int64_t n_params, hipSt
 
 // MFMA attention needs exactly 2 heads (one wave pair per head); other head counts use the VALU kernels.
 static bool use_mfma_attn(const dr4sr_sasrec_plan* p) {
-    static const bool off = getenv("DR4SR_ATTN_VALU") != nullptr;
+    const bool off = DR4SR_ENV("DR4SR_ATTN_VALU") != nullptr;
     return p->H == 2 && (!off || !valu_attn_fits(p));       // the cross-check switch applies where the VALU kernels can run
 }
 static int attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int training, hipStream_t s) {
@@ -317,7 +321,7 @@ static int attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int 
 
 // mid_fused: the last layer's post_fwd / scorer / post_bwd run as ONE launch (launch_post_mid) between the two halves
 static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s, bool mid_fused = false) {
-    static const bool fuse = getenv("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1),
+    const bool fuse = DR4SR_ENV("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1),
     if (fuse) RC(launch_embqkv_fwd(p, ws, training, s));             // qkv of layer 0 by the embedding gather
     else RC(launch_embed_fwd(p, ws, training, s));
     for (int l = 0; l < p->n_layer; ++l) {
@@ -333,17 +337,17 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
     for (int l = p->n_layer - 1; l >= 0; --l) {
         if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_bwd(p, ws, l, training, s));
         RC(attn_bwd(p, ws, l, training, s));
-        if (getenv("DR4SR_NO_FUSE")) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
+        if (DR4SR_ENV("DR4SR_NO_FUSE")) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
     }
-    if (getenv("DR4SR_NO_FUSE")) RC(launch_embed_bwd(p, ws, training, s));
+    if (DR4SR_ENV("DR4SR_NO_FUSE")) RC(launch_embed_bwd(p, ws, training, s));
     else if (!qeb_in_wgrad(ws)) RC(launch_qkv_embed_bwd(p, ws, training, s));
-    RC(launch_wgrad(p, ws, training, with_score, s, !getenv("DR4SR_NO_FUSE"), meta));
+    RC(launch_wgrad(p, ws, training, with_score, s, !DR4SR_ENV("DR4SR_NO_FUSE"), meta));
     return 0;
 }
 
 // everything of a training step between the prep and the optimizer
 static int fwd_bwd_core(const dr4sr_sasrec_plan* plan, const Workspace& ws, hipStream_t s) {
-    if (!getenv("DR4SR_NO_FUSE")) {
+    if (!DR4SR_ENV("DR4SR_NO_FUSE")) {
         RC(forward_layers(plan, ws, 1, s, true));
         RC(launch_post_mid(plan, ws, 1, s));
         RC(backward_layers(plan, ws, 1, 2, s, true));
@@ -415,7 +419,7 @@ extern "C" int dr4sr_sasrec_train_steps(const dr4sr_sasrec_plan* plan, int32_t n
     if (n_steps <= 0 || !plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
     // B <= 1024: the whole prep as an extra 256-thread workgroup of the optimizer launch (+2.7 % at 256, +1 % at 1024; -1 % at 2048);
     // above: the two-phase form (selection spread over the optimizer launch's workgroups, scan by the last one to finish)
-    static const bool nofuse_env = getenv("DR4SR_NO_PREP_FUSE") != nullptr;
+    const bool nofuse_env = DR4SR_ENV("DR4SR_NO_PREP_FUSE") != nullptr;
     const bool nofuse = nofuse_env;
     hipStream_t s = (hipStream_t)stream;
     PrepArgs next;

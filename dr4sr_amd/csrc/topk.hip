@@ -583,7 +583,7 @@ static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, con
     if (workspace_bytes < B * (int64_t)lds_s * 4) return DR4SR_E_WS;
     const size_t lds_fix = sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 512;
     const size_t lds_row = sizeof(unsigned) * ((n_items + 3) & ~3) + lds_fix;
-    static const int lds_max_kb = getenv("DR4SR_TOPK_LDS_KB") ? atoi(getenv("DR4SR_TOPK_LDS_KB")) : 24;      // measured: above ~4 k items the LDS copy costs more occupancy than the second row read (0.120 vs 0.104 ms at N = 11 925)
+    const int lds_max_kb = DR4SR_ENV("DR4SR_TOPK_LDS_KB") ? atoi(DR4SR_ENV("DR4SR_TOPK_LDS_KB")) : 24;      // measured: above ~4 k items the LDS copy costs more occupancy than the second row read (0.120 vs 0.104 ms at N = 11 925)
     const bool ldsrow = lds_row <= (size_t)lds_max_kb * 1024;               // (above that the LDS copy costs more occupancy than the second row read)
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -595,7 +595,7 @@ static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, con
     // two-kernel form's 104 us (subset pass 38, emit 85, candidate select 40: per-row LDS counters in the GEMM epilogue and 2048 small
     // selection waves cost more than the 97 MB matrix round trip at 3.2 TB/s); at N = 200 000 1.3-1.8 ms against 1.55 ms.  It is
     // therefore OPT-IN (DR4SR_TOPK_FUSED=1, read per call) until the emit epilogue is cheaper; the tests run both forms.
-    const bool unfused = getenv("DR4SR_TOPK_FUSED") == nullptr;
+    const bool unfused = DR4SR_ENV("DR4SR_TOPK_FUSED") == nullptr;
     constexpr int CAPC = 2048;
     const int stride = 8, n_sub = (n_items - 1 + stride - 1) / stride, sub_s = (n_sub + 63) / 64 * 64;
     const int64_t need = B * ((int64_t)sub_s * 4 + (int64_t)CAPC * 8 + 8) + 256;
@@ -614,7 +614,7 @@ static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, con
         if (D == 64) hipLaunchKernelGGL(k_score_gemm<64>, gsub, dim3(256), lds_g, s, q, E, sub, (int)B, n_items, sub_s, blocked, Fz);
         else { big_lds(k_score_gemm<128>, lds_g); hipLaunchKernelGGL(k_score_gemm<128>, gsub, dim3(256), lds_g, s, q, E, sub, (int)B, n_items, sub_s, blocked, Fz); }
         hipLaunchKernelGGL(k_subset_bound_w, dim3((unsigned)B), dim3(64), 0, s, sub, hist, n_sub, sub_s, Lh, k, stride, bound, cnt);
-        static const int dbg = getenv("DR4SR_TOPK_DBG") ? atoi(getenv("DR4SR_TOPK_DBG")) : 0;      // timing probe: stop after pass 1 / 2 / 3
+        const int dbg = DR4SR_ENV("DR4SR_TOPK_DBG") ? atoi(DR4SR_ENV("DR4SR_TOPK_DBG")) : 0;      // timing probe: stop after pass 1 / 2 / 3
         if (dbg == 1) return DR4SR_LAUNCH_CHECK();
         {
             dim3 ge((unsigned)((lds_s / 64 + EMIT_TILES - 1) / EMIT_TILES), (unsigned)((B + 63) / 64));

@@ -11,10 +11,11 @@ implicit-differentiation optimiser of utils/utils.py:134-252 (Hypergrad, MetaOpt
 Second order WITHOUT double-backward kernels: the library's hand-written first-order backward G(W) = dL_train/dW is
 differentiated by central differences along the needed directions only (dr4sr_fd_* in include/dr4sr_hip.h):
       H v            = [G(W + e v) - G(W - e v)] / 2e            (x hpo_lr = 1e-3 inside the Neumann recursion)
-      d/dphi (G . p) = [dL_train/dphi(W + e p) - dL_train/dphi(W - e p)] / 2e
+      d/dphi (G . p) = (4 D(e) - D(2e)) / 3,  D(h) = [dL_train/dphi(W + h p) - dL_train/dphi(W - h p)] / 2h   (Richardson, O(e^4))
 with identical dropout masks, negatives and Gumbel noise in every evaluation and the meta module's ReLU pattern frozen at
 W (autograd's ReLU'' = 0).  tests/test_meta_oracle.py shows this form within 2e-4 of the reference's double-backward result
-(golden vectors from RUNNING the reference), tests/test_gpu_meta.py checks the HIP path against the same vectors.
+(golden vectors from RUNNING the reference), tests/test_gpu_meta.py checks the HIP path against the same vectors, and
+tests/test_oracle_trained.py / tests/test_gpu_trained.py do both at the reference's SHIPPED trained checkpoint on real toys rows.
 
 All arithmetic runs in libdr4sr_hip.so; torch provides buffers, copies and torch.distributed.
 """
@@ -540,14 +541,27 @@ class MetaModel(BaseModel):
         # mixed second derivative d/dphi (dL_train/dW . p)                                               utils.py:170-178
         _lib.check(lib.dr4sr_fd_step_size_ws(_lib.ptr(theta0), _lib.ptr(pacc), n, rel, _lib.ptr(self._e), _lib.ptr(self._fd_scratch), st()),
                    "fd_step_size")
-        fp = self._buf("fp", nphi)
-        probe(pacc, 1.0, need_phi=True)
-        fp.copy_(self._phi.grads)
-        self._tail_p.copy_(eng.grads[n:n + _lib.GRAD_TAIL])
-        probe(pacc, -1.0, need_phi=True)
+        # Richardson-extrapolated central difference over the probes at +-e and +-2e (the probes are forward-only, _phi_only): this
+        # term IS the hyper-gradient up to O(hpo_lr), and on TRAINED weights its plain two-point difference carries a truncation
+        # error of 1e-3 of the reference's double-backward (tests/test_oracle_trained.py: same figure in fp32 and fp64, i.e. not
+        # rounding) — the four-point form 1e-5.  train.hypergrad_richardson: false = the two-point form.
         hyper = self._buf("hyper", nphi)
-        _lib.check(lib.dr4sr_fd_diff(_lib.ptr(hyper), _lib.ptr(fp), _lib.ptr(self._phi.grads), _lib.ptr(self._tail_p[0:1]),
-                                     _lib.ptr(eng.grads[n:n + 1]), _lib.ptr(self._e), -1.0, nphi, st()), "fd_diff")
+        if bool(self.config["train"].get("hypergrad_richardson", True)):
+            f4, nv4 = self._buf("f4", 4 * nphi).view(4, nphi), self._buf("nv4", 4)
+            for j, sign in enumerate((1.0, -1.0, 2.0, -2.0)):
+                probe(pacc, sign, need_phi=True)
+                f4[j].copy_(self._phi.grads)
+                nv4[j:j + 1].copy_(eng.grads[n:n + 1])
+            _lib.check(lib.dr4sr_fd_diff4(_lib.ptr(hyper), _lib.ptr(f4[0]), _lib.ptr(f4[1]), _lib.ptr(f4[2]), _lib.ptr(f4[3]), _lib.ptr(nv4),
+                                          _lib.ptr(self._e), -1.0, nphi, st()), "fd_diff4")
+        else:
+            fp = self._buf("fp", nphi)
+            probe(pacc, 1.0, need_phi=True)
+            fp.copy_(self._phi.grads)
+            self._tail_p.copy_(eng.grads[n:n + _lib.GRAD_TAIL])
+            probe(pacc, -1.0, need_phi=True)
+            _lib.check(lib.dr4sr_fd_diff(_lib.ptr(hyper), _lib.ptr(fp), _lib.ptr(self._phi.grads), _lib.ptr(self._tail_p[0:1]),
+                                         _lib.ptr(eng.grads[n:n + 1]), _lib.ptr(self._e), -1.0, nphi, st()), "fd_diff")
         eng.params.copy_(theta0)
         eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0 + 1)
         return hyper

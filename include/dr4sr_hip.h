@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DR4SR_ABI_VERSION 4
+#define DR4SR_ABI_VERSION 5
 
 #define DR4SR_E_ARG      (-1)   /* null pointer / bad size                                   */
 #define DR4SR_E_SHAPE    (-2)   /* unsupported D / H / F / L combination     */
@@ -388,6 +388,10 @@ int dr4sr_sasrec_fwd_bwd_weighted_prepared(const dr4sr_sasrec_plan* plan, const 
  *   shift    : out = x + sign * (*e) * dir
  *   neumann  : v -= lr * (gp / *np - gm / *nm) / (2 * *e) ;  pacc += v          (gp, gm un-normalised, np/nm their n_valid)
  *   diff     : out = coef * (fp / *np - fm / *nm) / (2 * *e)
+ *   diff4    : out = coef * (4 D(e) - D(2e)) / 3 with D(h) = (f(+h)/n - f(-h)/n) / 2h from the probes at +-e (fp1, fm1) and +-2e
+ *              (fp2, fm2), nv4 = their four n_valid words {+e, -e, +2e, -2e}: Richardson extrapolation, truncation error O(e^4).
+ *              The mixed term is the whole hyper-gradient up to O(hpo_lr); at TRAINED weights (the reference's shipped checkpoint)
+ *              its plain central difference sits at 1.0e-3 of the reference's double-backward, the extrapolated one at 1e-5.
  *   scale_by : out = x / *den */
 int dr4sr_fd_step_size(const float* theta, const float* dir, int64_t n, float rel_step, float* out_e, void* stream);
 /* the same with a caller-owned reduction scratch (dr4sr_fd_step_size_scratch_floats() floats, zeroed once): re-entrant, which the
@@ -399,6 +403,8 @@ int dr4sr_fd_neumann(float* v, float* pacc, const float* gp, const float* gm, co
                      float lr, int64_t n, void* stream);
 int dr4sr_fd_diff(float* out, const float* fp, const float* fm, const float* np, const float* nm, const float* e, float coef,
                   int64_t n, void* stream);
+int dr4sr_fd_diff4(float* out, const float* fp1, const float* fm1, const float* fp2, const float* fm2, const float* nv4,
+                   const float* e, float coef, int64_t n, void* stream);
 int dr4sr_scale_by(float* out, const float* x, const float* den, int64_t n, void* stream);
 
 /* MetaOptimizer.step tail (utils/utils.py:240-247) for the reference's default meta optimizer (metamodel.py:68-69):

@@ -40,6 +40,12 @@ int dr4sr_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint32_t s
 #define DR4SR_K_WGRAD_FUSED    17
 int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, int32_t layer, void* stream);
 
+/* The DR4SR_* environment switches (cross-checks and tuning knobs) are read ONCE per process — each site caches its
+ * value — and re-read after this call: a test can flip a switch, call dr4sr_reload_env(), and reach the other launch form in the SAME
+ * process.  Returns the new generation number.  Not for production use: graphs captured before the call keep their launch forms, and
+ * a workspace sized under one setting must not be used under another (DR4SR_BM) — build the engine after the reload. */
+int dr4sr_reload_env(void);
+
 /* the same with the MetaModel weighting (model/metamodel.py:174-194) on the launches that carry it (DR4SR_K_POST_MID); mw may be NULL */
 int dr4sr_sasrec_launch_kernel_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, int32_t kernel, int32_t layer,
                                         void* stream);

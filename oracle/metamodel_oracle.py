@@ -112,11 +112,12 @@ def hypergrad_exact(f, p: Dict[str, torch.Tensor], meta: Dict[str, torch.Tensor]
 
 
 def hypergrad_fd(f, p, meta, bt, bv, gumbel, tau, tau_min, hpo_lr: float, truncate_iter: int = 3, rel_step: float = 1e-2,
-                 dtype=torch.float32):
+                 dtype=torch.float32, richardson: bool = False):
     """The same quantity from FIRST-ORDER gradients only (what the HIP path does, dr4sr_amd/model/metamodel.py):
          H v          ~ [G(W + e v) - G(W - e v)] / 2e,        G = dL_train/dW      (Neumann terms, scaled by hpo_lr)
          d/dphi(G.p)  ~ [dL_train/dphi(W + e p) - dL_train/dphi(W - e p)] / 2e
-       with e = rel_step * |W| / |direction| and the meta-module's ReLU pattern frozen at W."""
+       with e = rel_step * |W| / |direction| and the meta-module's ReLU pattern frozen at W.
+       richardson=True (the product's default): the mixed term as (4 D(e) - D(2e)) / 3 over probes at +-e and +-2e."""
     P = {k: v.detach().to(dtype).clone() for k, v in p.items()}
     M = {k: v.detach().to(dtype).clone() for k, v in meta.items()}
     names = list(P)
@@ -149,9 +150,15 @@ def hypergrad_fd(f, p, meta, bt, bv, gumbel, tau, tau_min, hpo_lr: float, trunca
         v = {k: v[k] - hpo_lr * (gp[k] - gm[k]) / (2 * e) for k in names}
         pacc = {k: pacc[k] + v[k] for k in names}
     e = rel_step * wn / max(norm(pacc), 1e-30)
-    _, fp = first_order(shifted(pacc, e), True)
-    _, fm = first_order(shifted(pacc, -e), True)
-    return {k: -(fp[k] - fm[k]) / (2 * e) for k in META_NAMES}, gval, pacc
+    def central(h):
+        _, fp = first_order(shifted(pacc, h), True)
+        _, fm = first_order(shifted(pacc, -h), True)
+        return {k: (fp[k] - fm[k]) / (2 * h) for k in META_NAMES}
+    d1 = central(e)
+    if richardson:
+        d2 = central(2 * e)
+        d1 = {k: (4 * d1[k] - d2[k]) / 3 for k in META_NAMES}
+    return {k: -d1[k] for k in META_NAMES}, gval, pacc
 
 
 # ------------------------------------------------------------------------------------------------ MetaOptimizer

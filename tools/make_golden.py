@@ -283,11 +283,15 @@ def run_case(out_dir, name, model_name, n_items, seqlens, embed_dim, seed, overr
         shutil.rmtree(work, ignore_errors=True)
 
 
-def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed):
+def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed, real=False):
     """MetaModel (DR4SR+): weighted inner step + one outer hyper-gradient step, by RUNNING the reference
     (model/metamodel.py:123-194, utils/utils.py:134-252).  Dropout 0; the Gumbel noise of F.gumbel_softmax is pinned
     by re-seeding torch right before each weighted training_step and is stored (the script asserts that the stored
-    noise reproduces the reference's weights)."""
+    noise reproduces the reference's weights).
+
+    real=True: the sub-model carries the SHIPPED trained toys checkpoint (strict=True) and the two batches are the first 2 x 128 REAL
+    toys rows (build_real_toys); the sub-model's parameters are then not stored (they are sasrec_trained_toys.npz's) and its table
+    gradients travel as (row ids, rows)."""
     import torch
     import torch.nn.functional as F
     rng = np.random.default_rng(seed)
@@ -295,7 +299,10 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed):
     cwd = os.getcwd()
     try:
         os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
-        (build_dataset_fmlp if sub_model == "FMLP" else build_dataset)(work, n_items, seqlens, rng)
+        if real:
+            n_items, _ = build_real_toys(work)
+        else:
+            (build_dataset_fmlp if sub_model == "FMLP" else build_dataset)(work, n_items, seqlens, rng)
         os.chdir(work)
         import utils as rutils
         import model.metamodel as mm
@@ -328,19 +335,22 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed):
                 if isinstance(m, torch.nn.Dropout):
                     m.p = 0.0
         g = torch.Generator().manual_seed(seed + 1)
+        if real:
+            ck = torch.load(os.path.join(TOYS_DIR, "pre-trained_embedding.ckpt"), weights_only=False, map_location="cpu")
+            sub.load_state_dict(ck["parameters"], strict=True)
         with torch.no_grad():
-            for n, p in list(sub.named_parameters()) + list(model.meta_module.named_parameters()):
+            for n, p in ([] if real else list(sub.named_parameters())) + list(model.meta_module.named_parameters()):
                 if "item_embedding" in n or "item_encoder.weight" in n:
                     continue
                 p.add_(0.05 * torch.randn(p.shape, generator=g))
         out = {}
-        for k, v in sub.state_dict().items():
+        for k, v in ({} if real else sub.state_dict()).items():
             out["param." + k] = v.detach().numpy().copy()
         for k, v in model.meta_module.state_dict().items():
             out["meta_param." + k] = v.detach().numpy().copy()
         out["meta.tau"] = model.tau.detach().numpy().copy()
 
-        rows = next(iter(ds[0].get_loader(batch_size=len(ds[0]), shuffle=False)))
+        rows = next(iter(ds[0].get_loader(batch_size=256 if real else len(ds[0]), shuffle=False)))
         nrow = rows["user_id"].shape[0]
         half = nrow // 2
         model.train()
@@ -386,7 +396,11 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed):
         out["inner.weight"] = wm.numpy()
         out["inner.loss"] = loss.detach().numpy()
         for n, p in sub.named_parameters():
-            out["inner.grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            gnp = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            if real and n == "item_embedding.weight":
+                _sparse_rows(out, "inner.grad." + n, gnp)
+            else:
+                out["inner.grad." + n] = gnp
         for n, p in model.meta_module.named_parameters():           # loss.backward() also reaches phi (never stepped by it)
             out["inner.meta_grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
             p.grad = None
@@ -409,7 +423,10 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed):
         out["outer.val_loss"] = ml.detach().numpy()
         gval = torch.autograd.grad(ml, params, retain_graph=True, allow_unused=True)
         for (n, _), gg in zip(sub.named_parameters(), gval):
-            out["outer.grad_val." + n] = gg.numpy().copy()
+            if real and n == "item_embedding.weight":
+                _sparse_rows(out, "outer.grad_val." + n, gg.numpy())
+            else:
+                out["outer.grad_val." + n] = gg.numpy().copy()
         hg = model.meta_optimizer.hypergrad.grad(loss_val=ml, loss_train=mtl, aux_params=aux, params=params)
         for (n, _), gg in zip(model.meta_module.named_parameters(), hg):
             out["outer.hypergrad." + n] = gg.detach().numpy().copy()
@@ -532,6 +549,161 @@ def run_cl_case(out_dir, name, n_items, seqlens, seed, augment_type="item_random
         shutil.rmtree(work, ignore_errors=True)
 
 
+# --------------------------------------------------------------------------- shipped checkpoint + real rows
+TOYS_DIR = os.path.join(REF, "dataset", "amazon-toys", "toy")
+
+
+def build_real_toys(root, seed=2024):
+    """The REAL amazon-toys training rows, rebuilt from the shipped seq2pat_data.pth (= every user's chronological items minus the last
+    two, dataset/preprocess_amazon.ipynb cell 19) with the row recipe of cell 20.  The two held-out items are unknown: two seeded random
+    items stand in for them; they only reach the val / test TARGETS (and the last inputs of the val/test histories) — the train rows do
+    not contain them (history = us[:-3], target = us[1:-2]), so train_ori.pth is exact."""
+    import torch
+    seqs = torch.load(os.path.join(TOYS_DIR, "seq2pat_data.pth"), weights_only=False)
+    n_items = max(max(s) for s in seqs) + 1
+    rng = np.random.default_rng(seed)
+    d = os.path.join(root, "dataset", "amazon-toys", "toy")
+    os.makedirs(d, exist_ok=True)
+    train, val, test = [], [], []
+
+    def top(seq):                                                  # truncate_or_pad of cell 20
+        n = len(seq)
+        return (seq[-L:], L) if n > L else (seq + [0] * (L - n), n)
+    for u, s in enumerate(seqs, start=1):
+        us = (list(s) + rng.integers(1, n_items, size=2).tolist())[-L:]
+        h, sl = top(us[:-1])
+        test.append([u, h, us[-1], sl, 1, [0] * L, h])
+        h, sl = top(us[:-2])
+        val.append([u, h, us[-2], sl, 1, [0] * L, h])
+        h, sl = top(us[:-3])
+        tgt, _ = top(us[-sl - 2:-2])
+        train.append([u, h, tgt, sl, [1] * sl + [0] * (L - sl), [0] * L])
+    torch.save(train, os.path.join(d, "train_ori.pth"))
+    torch.save(val, os.path.join(d, "val.pth"))
+    torch.save(test, os.path.join(d, "test.pth"))
+    with open(os.path.join(d, "inter.csv"), "w") as f:             # every user and every item id (data/dataset.py:56-65)
+        f.write("user_id,item_id,rating,timestamp,domain\n")
+        nu = len(seqs)
+        for i in range(1, n_items):
+            f.write(f"{(i - 1) % nu + 1},{i},1.0,{i},0\n")
+        for u in range(1, nu + 1):
+            f.write(f"{u},{(u % (n_items - 1)) + 1},1.0,{u},0\n")
+    return n_items, len(seqs)
+
+
+def _sparse_rows(out, key, dense, ref=None):
+    """table-shaped arrays travel as (row ids, rows): rows that differ from `ref` (or are non-zero)"""
+    dense = np.asarray(dense)
+    rows = np.nonzero(np.any(dense != (0 if ref is None else ref), axis=1))[0]
+    out[key + ".rows"] = rows.astype(np.int64)
+    out[key + ".vals"] = dense[rows].copy()
+
+
+def run_trained_case(out_dir, name="sasrec_trained_toys", seed=21):
+    """SASRec with the SHIPPED trained weights (dataset/amazon-toys/toy/pre-trained_embedding.ckpt, dict format utils/callbacks.py:70-76,
+    loaded strict=True like model/basemodel.py:404-407) on the REAL toys rows: the first 256 rows and the real odd tail batch
+    (19 412 mod 256 = 212 rows).  training_step / backward / 2 x Adam / topk, dropout 0."""
+    import torch
+    work = tempfile.mkdtemp(prefix="dr4sr_golden_")
+    cwd = os.getcwd()
+    try:
+        os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
+        n_items, n_users = build_real_toys(work)
+        os.chdir(work)
+        from utils import load_config, setup_environment, prepare_datasets, prepare_model
+        config = load_config({"model": "SASRec", "dataset": "amazon-toys"})
+        config["train"]["device"] = "cpu"
+        config["data"]["train_file"] = "_ori"
+        config["model"]["dropout_rate"] = 0.0
+        setup_environment(config["train"])
+        torch.manual_seed(seed)
+        ds = prepare_datasets(config)
+        model = prepare_model(config, ds)
+        model._init_model(ds[0])
+        ck = torch.load(os.path.join(TOYS_DIR, "pre-trained_embedding.ckpt"), weights_only=False, map_location="cpu")
+        model.load_state_dict(ck["parameters"], strict=True)
+        assert model.num_items == n_items == 11925 and len(ds[0]) == n_users == 19412
+        out = {}
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for k, v in sd0.items():
+            if k == "query_encoder.item_encoder.weight":            # the tied table, stored once
+                assert torch.equal(v, sd0["item_embedding.weight"])
+                continue
+            out["param." + k] = v.numpy()
+        out["ckpt.epoch"] = np.int64(ck["epoch"])
+        out["ckpt.metric_keys"] = np.array(sorted(ck["metric"]))
+        out["ckpt.keys"] = np.array(sorted(ck))
+        out["ckpt.val_ndcg20"] = np.float64(float(ck["metric"]["ndcg@20"]))
+
+        full = next(iter(ds[0].get_loader(batch_size=len(ds[0]), shuffle=False)))
+        bs = config["train"]["batch_size"]
+        tail0 = (len(ds[0]) // bs) * bs
+        model.train()
+        for tag, sl in (("b0", slice(0, bs)), ("tail", slice(tail0, len(ds[0])))):
+            model.load_state_dict(sd0)
+            model.optimizer = model._get_optimizers()
+            batch = {k: v[sl].clone() for k, v in full.items()}
+            torch.manual_seed(seed + 2)
+            batch["neg_item"] = model._neg_sampling(batch)
+            for k in ("user_id", "in_item_id", "item_id", "seqlen", "neg_item"):
+                out[f"{tag}.batch.{k}"] = batch[k].numpy().astype(np.int32)      # int32 on disk (ids < 2^31); tests widen
+            model.optimizer.zero_grad()
+            loss, query = model.training_step(batch, reduce=True, return_query=True)
+            loss.backward()
+            out[f"{tag}.query"] = query.detach().numpy()
+            out[f"{tag}.loss"] = loss.detach().numpy()
+            with torch.no_grad():
+                out[f"{tag}.loss_noreduce"] = model.training_step(batch, reduce=False).numpy()
+            for n, p in model.named_parameters():
+                g = p.grad.numpy().copy()
+                if n == "item_embedding.weight":
+                    _sparse_rows(out, f"{tag}.grad.{n}", g)
+                else:
+                    out[f"{tag}.grad.{n}"] = g
+            for step in (1, 2):
+                if step == 2:
+                    model.optimizer.zero_grad()
+                    l2 = model.training_step(batch)
+                    l2.backward()
+                    out[f"{tag}.loss_step2"] = l2.detach().numpy()
+                model.optimizer.step()
+                for n, p in model.named_parameters():
+                    v = p.detach().numpy().copy()
+                    if n == "item_embedding.weight":
+                        if step == 2:                                  # the table after both steps only (fixture size)
+                            _sparse_rows(out, f"{tag}.adam{step}.{n}", v, ref=sd0[n].numpy())
+                    else:
+                        out[f"{tag}.adam{step}.{n}"] = v
+            print(f"{name}/{tag}: rows {sl.start}..{sl.stop}, loss {float(loss.detach()):.6f}, valid {int((batch['item_id'] != 0).sum())}")
+
+        # ---- eval (trained weights): full-item scorer + top-k on the first 256 validation rows -------------
+        model.load_state_dict(sd0)
+        model.eval()
+        ds[1].set_eval_domain("toy")
+        model.set_eval_domain("toy")
+        vb = next(iter(ds[1].get_loader(batch_size=256)))
+        with torch.no_grad():
+            score, items = model.topk(vb, 100, vb["user_hist"])
+            q_last = model.forward(vb)
+        for kk in ("in_item_id", "item_id", "seqlen", "user_hist"):
+            out["eval." + kk] = vb[kk].numpy().astype(np.int32)
+        out["eval.topk_score"], out["eval.topk_items"], out["eval.query_last"] = score.numpy(), items.numpy().astype(np.int32), q_last.numpy()
+        mc = config["model"]
+        out["meta.num_items"], out["meta.embed_dim"] = np.int64(model.num_items), np.int64(mc["embed_dim"])
+        for k in ("head_num", "hidden_size", "layer_num"):
+            out["meta." + k] = np.int64(mc[k])
+        out["meta.layer_norm_eps"] = np.float64(mc.get("layer_norm_eps", 1e-12))
+        out["meta.lr"], out["meta.weight_decay"] = np.float64(config["train"]["learning_rate"]), np.float64(config["train"]["weight_decay"])
+        out["meta.torch_version"] = np.array(torch.__version__)
+        os.chdir(cwd)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def neg_sampler_stats(out_dir):
     """Pin the *distribution* of basemodel.py:50-61 (uniform on 1..N-1, never PAD)."""
     import torch
@@ -629,6 +801,12 @@ def main():
     if only == "meta":
         run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
         return
+    if only == "trained":
+        run_trained_case(out_dir)
+        return
+    if only == "meta_trained":
+        run_meta_case(out_dir, "metamodel_trained_toys", "SASRec", n_items=None, seqlens=None, seed=22, real=True)
+        return
     if only == "fmlp":
         run_case(out_dir, "fmlp_d64", "FMLP", n_items=113, seqlens=[1, 3, 6, 50, 2], embed_dim=64, seed=14)
         return
@@ -642,6 +820,8 @@ def main():
     run_cl_case(out_dir, "cl4srec_d64", n_items=173, seqlens=seqlens, seed=16)
     neg_sampler_stats(out_dir)
     loss_module_vectors(out_dir)
+    run_trained_case(out_dir)
+    run_meta_case(out_dir, "metamodel_trained_toys", "SASRec", n_items=None, seqlens=None, seed=22, real=True)
 
 
 if __name__ == "__main__":
