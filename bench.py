@@ -28,7 +28,7 @@ import ctypes as C  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PROFILE_ROUND = 3              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
+PROFILE_ROUND = 4              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
@@ -494,6 +494,10 @@ def main():
                          "SASRec: weighted inner steps + one hyper-gradient outer step every --interval steps)")
     ap.add_argument("--embed-dim", type=int, default=64, choices=[64, 128],
                     help="sasrec: 128 = BASELINE configs[3] shape (yelp: N=20034 items, d=128, FFN 128)")
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="repetitions of the timed region (each exactly --steps steps): ms_per_step = median, ms_per_step_spread = min / max")
+    ap.add_argument("--in-graph-timeout", type=int, default=150,
+                    help="data parallel: seconds the in-graph-collective attempt (second form) may take before the line is printed without it")
     ap.add_argument("--interval", type=int, default=30, help="metamodel: outer-loop period (configs/metamodel.yaml interval)")
     args = ap.parse_args()
     if args.model == "metamodel":
@@ -526,10 +530,14 @@ def main():
     from dr4sr_amd.engine import SasrecEngine
     lib = _lib.load()
 
-    def measure(B_arg, steps, warmup, extras, dp=dp):
+    def measure(B_arg, steps, warmup, extras, dp=dp, dp_form="host", repeats=None):
         """one timed run of the training step at B_arg rows per GPU; extras = per-kernel launch times + the K1 gather microbench.
         dp=False under a multi-rank launch: every rank runs the single-GPU step on its own (no collective) — the 1-GPU reference
-        of the strong-scaling runs."""
+        of the strong-scaling runs.  dp_form (data parallel): "host" = two graphs around a host-launched all-reduce (the model's
+        default, dr4sr_amd/model/basemodel.py:_step_graph), "in_graph" = the RCCL all-reduce captured inside the k-step graph
+        (returns None when the capture fails on any rank).  The timed region (exactly `steps` steps between barrier + synchronize
+        on both sides, MAX over ranks) is repeated `repeats` times: ms_per_step = the median, ms_per_step_spread = [min, max]."""
+        repeats = max(1, int(repeats if repeats is not None else args.repeats))
         world = int(os.environ.get("WORLD_SIZE", "1")) if dp else 1
         rank = int(os.environ.get("RANK", "0")) if dp else 0
         B, L, D, H, F, NL, N = B_arg, 50, 64, 2, 128, 2, TOYS_N_ITEMS
@@ -624,10 +632,10 @@ def main():
                         g_all.replay()
                     for _ in range(n % group):
                         g_one.replay()
-            elif use_graph and parallel.can_capture() and not os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
-                # DEFAULT data-parallel form: the RCCL all-reduce is captured INSIDE the step graph — k whole DP steps per replay, no
-                # host work between backward, collective and optimizer; as on one GPU the optimizer launch of step j prepares step
-                # j+1 (B <= 1024).  Any capture failure falls through to the host-launched collective below.
+            elif use_graph and dp_form == "in_graph":
+                # opt-in data-parallel form (train.dp_graph_allreduce): the RCCL all-reduce captured INSIDE the step graph — k whole DP
+                # steps per replay, no host work between backward, collective and optimizer; as on one GPU the optimizer launch of
+                # step j prepares step j+1 (B <= 1024).  Measured SECOND, after the host-launched form's numbers are safe (main()).
                 group = max(1, min(args.steps_per_graph, steps))
                 fuse_prep = args.model == "sasrec" and B <= 1024
 
@@ -667,7 +675,7 @@ def main():
                             g_one.replay()
                     collective = "rccl all-reduce captured in the step graph (%d steps per graph)" % group
                 else:
-                    run_steps, group = None, 1
+                    return None                              # the caller reports in_graph: null (capture failed on some rank)
             if run_steps is None and use_graph and dp and args.model == "sasrec" and B <= 1024:
                 # two graphs around a host-launched all-reduce; the optimizer graph also prepares the next batch, so only the first
                 # step of a run carries its own prep launch
@@ -709,19 +717,29 @@ def main():
 
             run_steps(warmup)
             stream.synchronize()
-            if dp:
-                dist.barrier()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            e0.record()
-            run_steps(steps)
-            e1.record()
-            torch.cuda.synchronize()
-            if dp:
-                dist.barrier()
-            wall = time.perf_counter() - t0
-            gpu_ms = e0.elapsed_time(e1)
+            walls, gpus = [], []
+            for _ in range(repeats):
+                if dp:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record()
+                run_steps(steps)
+                e1.record()
+                torch.cuda.synchronize()
+                if dp:
+                    dist.barrier()
+                walls.append(time.perf_counter() - t0)
+                gpus.append(e0.elapsed_time(e1))
+            if dp:                                           # every repetition: the MAX over ranks (one collective for all of them)
+                tmax = torch.tensor(walls, device=dev if parallel.can_capture() else "cpu", dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                walls = [float(x) for x in tmax]
+            order = sorted(range(repeats), key=lambda i: walls[i])
+            mid = order[(repeats - 1) // 2]                  # the median repetition (the lower one of an even count)
+            wall, gpu_ms = walls[mid], gpus[mid]
+            spread = {"repeats": repeats, "median": 1e3 * wall / steps, "min": 1e3 * min(walls) / steps, "max": 1e3 * max(walls) / steps}
             per_rank_ms, coll_us = None, None
             loss, nvalid = eng.loss_and_count()             # (before the stand-alone collective timing below overwrites the gradient tail)
             if dp:
@@ -730,9 +748,6 @@ def main():
                 allr = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(allr, mine)
                 per_rank_ms = [round(float(x), 5) for x in allr]
-                tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                wall = float(tmax)
                 # the collective alone: the same flat buffer all-reduced back to back, HIP events around the host-launched form
                 # (every rank enters the same count; the gradient buffer is garbage afterwards — nothing reads it before the next step)
                 ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -755,12 +770,20 @@ def main():
                           "fmlp": "FMLP on toys-shaped synthetic per-prefix left-padded rows: N=11925, L=50, d=64, 2 x (filter + FFN 256), "
                                   "dropout 0.5, all B*L positions computed"}[args.model]
 
+            # the arithmetic type per launch form: fp32 everywhere in the latency regime; at scale the six weight-gradient GEMMs run as
+            # a 3-term bf16 split with fp32 accumulation (k_wgrad_bf, error 5e-6 against the fp32 kernel: tests), GRU4Rec's
+            # cooperative recurrences likewise (k_gru_fwd_wave / k_gru_bwd_coop_bf)
+            dtype = "f32"
+            if args.model == "sasrec" and bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 1) and not os.environ.get("DR4SR_WGRAD_F32"):
+                dtype = "f32 (weight-gradient GEMMs as bf16x3 split with fp32 accumulation, err 5e-6)"
+            if args.model == "gru4rec" and bool(lib.dr4sr_gru4rec_uses_cooperative(min(B, 256), 256)) and B <= 1536:
+                dtype = "f32 io, bf16x3 recurrent GEMMs with fp32 accumulation (err 2e-6)"
             out = {
                 "metric": "training sequences/sec, %s d=%d L=50" % ({"sasrec": "SASRec", "gru4rec": "GRU4Rec", "fmlp": "FMLP"}[args.model], D),
                 "value": world * B * steps / wall,
                 "unit": "sequences/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-                "ms_per_step": 1e3 * wall / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "ms_per_step": 1e3 * wall / steps, "ms_per_step_spread": spread, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": dtype, "data": "synthetic",
                 "config": {"workload": "%s, B=%d rows/GPU/step, %s seqlen" %
                                        (model_desc, B, "all-50 (dense)" if args.dense else "toys histogram (10.9% valid)"),
                            "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
@@ -778,6 +801,19 @@ def main():
                 # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
                 seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
                 ktime = sasrec_kernel_rooflines(lib, _lib, plan, None, out, args, B, L, D, F, NL, T_last, seqlen_last, group, wall / steps, dev)
+                # the gather the STEP runs: k_embqkv_fwd / k_wt_embqkv_fwd (gather + position add + dropout + qkv projection of layer 0)
+                # on the packed tokens of the last batch: idx read + x row and qkv row written (the table row comes from L2)
+                if "embqkv_fwd" in ktime:
+                    sb = float(T_last) * (8 + 4 * D + 12 * D)
+                    fr = sb / 1e9 / (ktime["embqkv_fwd"] * 1e-6) / HBM_PEAK_GBS
+                    out["roofline_gather_step"] = {"kernel": "k_wt_embqkv_fwd" if (bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 1) and D == 64) else "k_embqkv_fwd",
+                                                   "bound": "hbm", "achieved": sb / 1e9 / (ktime["embqkv_fwd"] * 1e-6),
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr,
+                                                   "us_per_launch": ktime["embqkv_fwd"], "tokens": T_last,
+                                                   "algorithmic_bytes_per_token": 8 + 16 * D,
+                                                   "note": ("launch-latency bound at this size (%d tokens = %.2f MB)" % (T_last, sb / 1e6)) if fr < 0.1 else
+                                                           "the gather fused with layer 0's qkv projection (24.6 kF per token): this, not the K1 microbench "
+                                                           "(roofline_gather), is what a training step runs"}
                 if extras != "full":
                     return out, rows_np, N
                 # ---- K1 gather microbench (HBM roofline of the embedding gather): large launch
@@ -821,16 +857,6 @@ def main():
                                           "pmc_traffic_rate": None if traffic is None else traffic / 1e9 / (us * 1e-6),
                                           "note": "microbench of the dense gather entry point (dr4sr_embed_gather_posadd); the training step "
                                                   "gathers inside k_embqkv_fwd, see roofline_gather_step"}
-                # the gather the STEP runs: k_embqkv_fwd (gather + position add + dropout + qkv projection of layer 0) on the packed
-                # tokens of the last batch: idx read + x row and qkv row written (the table row comes from L2)
-                if "embqkv_fwd" in ktime:
-                    sb = float(T_last) * (8 + 4 * D + 12 * D)
-                    out["roofline_gather_step"] = {"kernel": "k_embqkv_fwd", "bound": "hbm", "achieved": sb / 1e9 / (ktime["embqkv_fwd"] * 1e-6),
-                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": sb / 1e9 / (ktime["embqkv_fwd"] * 1e-6) / HBM_PEAK_GBS,
-                                                   "us_per_launch": ktime["embqkv_fwd"], "tokens": T_last,
-                                                   "algorithmic_bytes_per_token": 8 + 16 * D,
-                                                   "note": "launch-latency bound at this size (%d tokens = %.2f MB)" % (T_last, sb / 1e6)}
                 del outbuf, idx_big
                 # ---- eval hot loop: full-item scores + top-100 of one 2048-row eval batch (basemodel.py:337-365)
                 Be, ke = 2048, 100
@@ -860,35 +886,91 @@ def main():
 
     out, rows_np, N = measure(args.batch, args.steps, args.warmup, "full")
     tm = None
+    sec_rep = max(1, min(args.repeats, 5))                   # the secondary sizes: fewer repetitions of a longer timed region
     if args.model == "sasrec" and args.batch < 8192 and not args.no_throughput_mode:
         # BASELINE.md §3 asks for B=256 (reference batch size) AND B=8192 (throughput / scaling mode); same data, same step.
         # Under a multi-rank launch this run is the single-GPU step on every rank (no collective): the 1-GPU reference of `strong`.
-        tm, _, _ = measure(8192, max(20, min(100, args.steps)), 10, "kernels" if world == 1 else None, dp=False)
+        tm, _, _ = measure(8192, max(20, min(100, args.steps)), 10, "kernels" if world == 1 else None, dp=False, repeats=sec_rep)
         if rank == 0:
-            out["throughput_mode"] = {k: tm[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline",
-                                                          "kernel_us_per_step", "valid_tokens_last_step", "roofline_step") if k in tm}
+            out["throughput_mode"] = {k: tm[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_spread", "steps", "warmup", "dtype", "config",
+                                                          "roofline", "roofline_gather_step", "kernel_us_per_step", "valid_tokens_last_step",
+                                                          "roofline_step", "roofline_tile_kernels") if k in tm}
+    strong = []
     if args.model == "sasrec" and not args.no_strong and args.embed_dim == 64 and not args.dense and args.batch < 8192:
         # STRONG scaling (north_star: ">= 6x at 8 GPUs"): a FIXED global batch G split over the N ranks (G / N rows per rank per
         # step), one all-reduce per step; `single_gpu_value` = the same G on ONE GPU measured in this very run (every rank runs it
         # as an independent replica, rank 0's number is taken), so speedup and efficiency need no second invocation.
-        strong = []
         for G in args.strong_global_batch:
             if G % world or G // world < 1:
                 continue
-            one = tm if (G == 8192 and tm is not None) else measure(G, 20, 5, None, dp=False)[0]
-            st_n = one if world == 1 else measure(G // world, max(20, min(100, args.steps)), 10, None, dp=True)[0]
+            one = tm if (G == 8192 and tm is not None) else measure(G, 20, 5, None, dp=False, repeats=sec_rep)[0]
+            st_n = one if world == 1 else measure(G // world, max(20, min(100, args.steps)), 10, None, dp=True, repeats=sec_rep)[0]
             strong.append({"global_batch": G, "per_gpu_batch": G // world, "n_gpus": world, "value": st_n["value"], "unit": "sequences/s",
-                           "ms_per_step": st_n["ms_per_step"], "single_gpu_value": one["value"], "single_gpu_ms_per_step": one["ms_per_step"],
+                           "ms_per_step": st_n["ms_per_step"], "ms_per_step_spread": st_n.get("ms_per_step_spread"), "dtype": st_n["dtype"],
+                           "single_gpu_value": one["value"], "single_gpu_ms_per_step": one["ms_per_step"],
                            "speedup": st_n["value"] / one["value"], "efficiency": st_n["value"] / one["value"] / world,
                            "collective": st_n["config"].get("collective"),
                            "per_rank_gpu_ms_per_step": st_n.get("per_rank_gpu_ms_per_step"),
                            "allreduce_us_standalone": st_n.get("allreduce_us_standalone")})
         if rank == 0:
             out["strong"] = strong
+    if rank == 0 and not dp and not args.no_cpu_baseline and args.model in ("sasrec", "gru4rec"):
+        out["cpu_baseline"] = cpu_baseline_leg(rows_np, N, args.model, 0.2 if args.model == "gru4rec" else args.dropout)
+
+    # ---- data parallel, second form: the RCCL all-reduce captured INSIDE the k-step graph (the model's opt-in, train.dp_graph_allreduce).
+    # Everything above ran with the host-launched collective — the form every multi-rank test covers — and `out` is complete; the
+    # in-graph form is tried only now, under a watchdog: if it hangs (it has never run with more than one RCCL rank before the first
+    # multi-GPU run), rank 0 prints the line it already has with in_graph: null and every rank leaves through os._exit.
+    if dp:
+        host_ms = out["ms_per_step"]
+        forms = {"host": host_ms, "in_graph": None}
+        out["collective_forms"] = forms
+        if parallel.can_capture() and args.model == "sasrec" and not args.no_graph and not os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
+            import threading
+
+            def give_up():
+                forms["in_graph_error"] = "watchdog: the in-graph form did not finish within %d s" % args.in_graph_timeout
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            dog = threading.Timer(args.in_graph_timeout, give_up)
+            dog.daemon = True
+            dog.start()
+            try:
+                ig = measure(args.batch, args.steps, args.warmup, None, dp=True, dp_form="in_graph")
+                if ig is None:
+                    forms["in_graph_error"] = "graph capture of the collective failed on at least one rank"
+                else:
+                    ig = ig[0]
+                    forms["in_graph"] = ig["ms_per_step"]
+                    forms["in_graph_spread"] = ig["ms_per_step_spread"]
+                    forms["in_graph_collective"] = ig["config"]["collective"]
+                    if ig["ms_per_step"] < host_ms:            # both are complete training steps: report the faster, name it
+                        for k in ("value", "ms_per_step", "ms_per_step_spread", "gpu_ms_per_step_events", "per_rank_gpu_ms_per_step", "final_loss"):
+                            out[k] = ig[k]
+                        out["config"]["collective"] = ig["config"]["collective"]
+                        out["config"]["steps_per_graph"] = ig["config"]["steps_per_graph"]
+                    for ent in strong:                       # every rank walks the same list in the same order
+                        sg = measure(ent["global_batch"] // world, max(20, min(100, args.steps)), 10, None, dp=True, dp_form="in_graph",
+                                     repeats=sec_rep)
+                        if sg is None:
+                            continue
+                        sg = sg[0]
+                        ent["collective_forms"] = {"host": ent["ms_per_step"], "in_graph": sg["ms_per_step"]}
+                        if sg["ms_per_step"] < ent["ms_per_step"]:
+                            one_v = ent["single_gpu_value"]
+                            ent.update({"value": sg["value"], "ms_per_step": sg["ms_per_step"], "ms_per_step_spread": sg["ms_per_step_spread"],
+                                        "speedup": sg["value"] / one_v, "efficiency": sg["value"] / one_v / world,
+                                        "collective": sg["config"]["collective"], "per_rank_gpu_ms_per_step": sg.get("per_rank_gpu_ms_per_step")})
+            except Exception as e:      # noqa: BLE001
+                forms["in_graph_error"] = "%s: %s" % (type(e).__name__, e)
+                dog.cancel()
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)                                  # the communicator may be wedged: do not enter another collective
+            dog.cancel()
     if rank == 0:
-        if not dp and not args.no_cpu_baseline and args.model in ("sasrec", "gru4rec"):
-            out["cpu_baseline"] = cpu_baseline_leg(rows_np, N, args.model, 0.2 if args.model == "gru4rec" else args.dropout)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dp:
         dist.destroy_process_group()
 

@@ -15,6 +15,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: GPU tests with minutes of CPU oracle time; not part of -m gpu (run -m 'gpu or slow')")
 
 
 @pytest.fixture(scope="session")
@@ -57,3 +58,50 @@ def _dr4sr_env_switches_follow_monkeypatch(monkeypatch):
     monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
     yield
     monkeypatch.setenv, monkeypatch.delenv = real_set, real_del
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _memoise_oracle_gradients():
+    """oracle.sasrec_oracle.grads_of(params, batch, ...) of a full-size batch takes seconds of CPU autograd, and the switch matrix
+    (tests/test_gpu_r2_paths.py) asks for the same (parameters, batch) pairs once per switch: keep the results for the session, keyed by
+    the CONTENT of every input tensor (blake2b of the bytes) — a changed parameter or batch is a different key."""
+    import hashlib
+    import torch
+    from oracle import sasrec_oracle as O
+    real = O.grads_of
+    memo = {}
+
+    def digest(d):
+        h = hashlib.blake2b(digest_size=16)
+        for k in sorted(d):
+            t = d[k].detach().contiguous().cpu()
+            h.update(k.encode())
+            h.update(str(tuple(t.shape)).encode())
+            h.update(t.numpy().tobytes())
+        return h.hexdigest()
+
+    def grads_of(params, batch, *args, **kw):
+        if kw.get("masks") is not None or any(torch.is_tensor(a) or isinstance(a, dict) for a in args):
+            return real(params, batch, *args, **kw)          # explicit dropout masks etc.: not memoised
+        key = (digest(params), digest(batch), tuple(args), tuple(sorted(kw.items())))
+        if key not in memo:
+            if len(memo) > 64:
+                memo.clear()
+            memo[key] = real(params, batch, *args, **kw)
+        loss, q, grads = memo[key]
+        return loss, q, dict(grads)
+    O.grads_of = grads_of
+    from oracle import gru4rec_oracle as GO
+    real_gru, memo_gru = GO.grads_of, {}
+
+    def gru_grads_of(params, batch, *args, **kw):
+        key = (digest(params), digest(batch), tuple(args), tuple(sorted(kw.items())))
+        if key not in memo_gru:
+            if len(memo_gru) > 32:
+                memo_gru.clear()
+            memo_gru[key] = real_gru(params, batch, *args, **kw)
+        r = memo_gru[key]
+        return r[0], r[1], dict(r[2])
+    GO.grads_of = gru_grads_of
+    yield
+    O.grads_of, GO.grads_of = real, real_gru

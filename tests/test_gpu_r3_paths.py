@@ -30,8 +30,13 @@ def relerr(a, b):
     return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
 
 
-@pytest.mark.parametrize("B", [32768, 131072])
-def test_sasrec_strong_scaling_batch_sizes_vs_chunked_oracle(B):
+def test_sasrec_strong_scaling_batch_size_32768_vs_chunked_oracle():
+    """B = 32 768 (bench.py's strong[1]); B = 131 072 (strong[2]: 16 chunks of CPU autograd, 150-300 s) is tests/test_slow_gpu.py,
+    selected by `-m slow` (`-m "gpu or slow"` = everything)"""
+    _strong_scaling_batch_vs_chunked_oracle(32768)
+
+
+def _strong_scaling_batch_vs_chunked_oracle(B):
     """bench.py's `strong[1..2]` sizes (16-18 M seq/s claims).  Part 1: dr4sr_sasrec_fwd_bwd on a batch selected on the device from a
     permutation of a U = B + 1000 row dataset — loss and EVERY gradient against the oracle's autograd summed over B / 8192 chunks.
     Part 2: dr4sr_sasrec_train_steps (the optimizer launch prepares the next step in two phases spread over its grid) against
@@ -145,21 +150,21 @@ def test_gru4rec_partial_batch_in_the_workspace_of_a_larger_one():
 
 @pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1", "DR4SR_GRU_FWD_F32": "1"}],
                          ids=["one-launch-per-layer", "backward-wavefront", "round-2-kernels"])
-def test_gru4rec_wavefront_switches_vs_oracle(env):
+def test_gru4rec_wavefront_switches_vs_oracle(env, monkeypatch):
     """Two-layer plans run both forward recurrences in one launch by default (layer wavefront, csrc/gru_coop.hip); DR4SR_GRU_NOWAVE = the
     one-launch-per-layer form, DR4SR_GRU_WAVE_BWD = the (opt-in, not faster) one-launch backward, DR4SR_GRU_BWD_F32 = the fp32-MFMA BPTT with
-    W_hh in LDS instead of the bf16x3 one with W_hh in registers (k_gru_bwd_coop_bf; DR4SR_GRU_FWD_F32 likewise for the single-layer forward).  All are `static` switches: the oracle
-    tests that reach them — BASELINE configs[2] exactly, partial groups, chunks of 256 with a ragged last chunk — re-run in a fresh interpreter"""
-    e = dict(os.environ)
-    e.update(env)
-    expr = ("test_gru4rec_baseline_config2_exact_size_vs_oracle or test_gru4rec_odd_batch_sizes_vs_oracle or "
-            "(test_gru4rec_chunked_cooperative_recurrence_vs_oracle and 400) or (test_gru4rec_cooperative_second_bank_vs_oracle and 130)")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", expr, "-p", "no:cacheprovider",
-                        os.path.join(ROOT, "tests", "test_gpu_r3_paths.py"), os.path.join(ROOT, "tests", "test_gpu_gru.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_r2_paths.py")], env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
-    assert r.returncode == 0, tail
-    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
+    W_hh in LDS instead of the bf16x3 one with W_hh in registers (k_gru_bwd_coop_bf; DR4SR_GRU_FWD_F32 likewise for the single-layer forward).
+    The oracle tests that reach them — BASELINE configs[2] exactly, odd batch sizes, chunks of 256 with a ragged last chunk, the second bank
+    of cooperative groups — re-run in this process with the switch set (dr4sr_reload_env through conftest's monkeypatch hook)"""
+    import test_gpu_gru as G
+    import test_gpu_r2_paths as R2
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    test_gru4rec_baseline_config2_exact_size_vs_oracle()
+    for B in (1, 17, 100):
+        G.test_gru4rec_odd_batch_sizes_vs_oracle(B)
+    R2.test_gru4rec_chunked_cooperative_recurrence_vs_oracle(400, 256, True)
+    R2.test_gru4rec_cooperative_second_bank_vs_oracle(130)
 
 
 def test_metamodel_outer_step_two_ranks_equal_single_rank():
