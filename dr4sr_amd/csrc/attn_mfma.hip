@@ -654,6 +654,9 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
     // default: the 1..8-token and 9..16-token classes as ONE launch (k_attn_small_*), then the 64-row list.  DR4SR_ATTN_NOMERGE: one
     // launch per class (cross-check, read per call like DR4SR_ATTN_NOTINY)
+    // The length classes are disjoint sets of sequences: their launches are independent and go to side streams (parallel branches of a
+    // captured step graph): the class kernels are latency-bound at 1-7 % MFMA utilisation, side by side they take the longest one's time
+    const StepFork& fk = step_fork();
     if (!DR4SR_ENV("DR4SR_ATTN_NOTINY") && !DR4SR_ENV("DR4SR_ATTN_NOMERGE")) {
         const int dv = DR4SR_ENV("DR4SR_ATTN_SMALL_DIV") ? atoi(DR4SR_ENV("DR4SR_ATTN_SMALL_DIV")) : 2;      // share of the residency left to the tiny blocks (tuning)
         const int gsm = gs / (dv > 0 ? dv : 1) > 0 ? gs / (dv > 0 ? dv : 1) : 1;
@@ -663,23 +666,37 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
         if (bwd && !merge_bwd) {
             // backward: NOT merged by default — the tiny class needs 192 VGPRs, the 16-row list 120; at the merged kernel's 208 the list's
             // workgroups fill the register file two per CU and the tiny blocks queue behind them (32.7 us against 19.2 + 9.8)
-            const int rc = launch_attn_tiny(Tn, DH, B, true, s);
+            int rc = fk.fork(s, 0, 2);
             if (rc) return rc;
-            hipLaunchKernelGGL((k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>), dim3(gs), dim3(SHORT_BWD_NT), lds_s, s, S);
+            rc = launch_attn_tiny(Tn, DH, B, true, fk.side(s, 0));
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>), dim3(gs), dim3(SHORT_BWD_NT), lds_s, fk.side(s, 1), S);
             big_lds(k_attn2_bwd<DH, 64, 256, true>, lds_l);
             hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
+            rc = DR4SR_LAUNCH_CHECK();
+            if (rc) return rc;
+            return fk.join(s, 0, 2);
         } else if (bwd) {
+            int rc = fk.fork(s, 0, 1);
+            if (rc) return rc;
             big_lds(k_attn_small_bwd<DH>, lds_m);
-            hipLaunchKernelGGL((k_attn_small_bwd<DH>), grid, dim3(SHORT_BWD_NT), lds_m, s, S, Tn, gsm);
+            hipLaunchKernelGGL((k_attn_small_bwd<DH>), grid, dim3(SHORT_BWD_NT), lds_m, fk.side(s, 0), S, Tn, gsm);
             big_lds(k_attn2_bwd<DH, 64, 256, true>, lds_l);
             hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
+            rc = DR4SR_LAUNCH_CHECK();
+            if (rc) return rc;
+            return fk.join(s, 0, 1);
         } else {
+            int rc = fk.fork(s, 0, 1);
+            if (rc) return rc;
             big_lds(k_attn_small_fwd<DH>, lds_m);
-            hipLaunchKernelGGL((k_attn_small_fwd<DH>), grid, dim3(128), lds_m, s, S, Tn, gsm);
+            hipLaunchKernelGGL((k_attn_small_fwd<DH>), grid, dim3(128), lds_m, fk.side(s, 0), S, Tn, gsm);
             big_lds(k_attn2_fwd<DH, 64, 256, true>, lds_l);
             hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, true>), dim3(gl), dim3(256), lds_l, s, Lg);
+            rc = DR4SR_LAUNCH_CHECK();
+            if (rc) return rc;
+            return fk.join(s, 0, 1);
         }
-        return DR4SR_LAUNCH_CHECK();
     }
     // third class, 1..8 tokens: VALU kernels (attn_tiny_body.h).  DR4SR_ATTN_NOTINY (cross-check): the same list through the 16-row MFMA kernels
     if (!DR4SR_ENV("DR4SR_ATTN_NOTINY")) {

@@ -531,4 +531,23 @@ static inline void big_lds(K kernel, size_t bytes) {
 }
 
 static inline int hip_ret(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+// Fork / join of INDEPENDENT launches of one step onto side streams (step.hip).  The launches of a training step form a chain, but not
+// every link depends on the one before it: the length classes of an attention launch are disjoint sequence sets, the weight gradients of a
+// layer need nothing the layers below still have to compute.  fork(main, first, n) makes side streams first..first+n-1 wait for what `main` holds so far;
+// join(main, first, n) makes `main` wait for them.  Under stream capture the same calls become graph EDGES: the independent launches are
+// parallel branches of the step graph and run concurrently (tools/probes/graph_branch_probe.py: 4 branches of 85 us in 141 us).
+// side() returns `main` itself when side streams are off (the default: DR4SR_STREAMS=1 turns them on — measured slower, step.hip): fork /
+// join are no-ops then.
+struct StepFork {
+    static constexpr int NSIDE = 3;
+    hipStream_t side_[NSIDE];
+    hipEvent_t fork_ev[NSIDE], join_ev[NSIDE];
+    int state;                                              // 0 = not tried, 1 = ready, -1 = unavailable
+    bool on() const;
+    hipStream_t side(hipStream_t main, int i) const { return on() ? side_[i] : main; }
+    int fork(hipStream_t main, int first, int n) const;     // sides first .. first + n - 1 (the attention classes use 0 and 1, the early
+    int join(hipStream_t main, int first, int n) const;     //  weight-gradient launches 2: the two forks nest)
+};
+const StepFork& step_fork();
 #define DR4SR_LAUNCH_CHECK() hip_ret(hipGetLastError())

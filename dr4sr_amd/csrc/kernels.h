@@ -120,10 +120,13 @@ struct ScoreTileArgs {
 struct WgradJob {
     const float* G; int ldg; int gcol;        // G rows start at column gcol
     const float* X; int ldx;
-    float* dW; float* db;
+    float* dW; float* db;                     // db == NULL: no bias sum from this job (a column block of X: the row block's other job adds it)
+    int ldw;                                  // row pitch of dW (0: the job's own KX)
 };
+#define DR4SR_WGRAD_MAX_JOBS 12               // per layer: 6 GEMMs, or their 64 x 64 blocks (d = 64: 4 + 2 F / 64)
 struct WgradArgs {
-    WgradJob job[6 * DR4SR_MAX_LAYERS];
+    WgradJob job[DR4SR_WGRAD_MAX_JOBS * DR4SR_MAX_LAYERS];
+    int jobs_per_layer;                        // stride of job[] (6 unless the launch runs 64 x 64 blocks)
     const int* state; uint64_t seed; float p; int training;
     // reduce jobs (blockIdx.y == 6): LayerNorm affine partials of every layer, scorer partials
     const float* ln_part; int64_t ln_layer_stride; float* grads; int64_t o_ln1_w; int64_t layer_stride;   // ln1_w,ln1_b,ln2_w,ln2_b contiguous
@@ -132,6 +135,7 @@ struct WgradArgs {
     int ln_tile_rows;                          // token rows per tile of the LAST layer's post kernel (LayerNorm partials, owner-sorted entries)
     int ln_rows[DR4SR_MAX_LAYERS];             // token rows per LayerNorm-partial row, per layer (wave-tile kernels: 16)
     int qeb_plane;                             // 1: grid plane z = 0 runs the embedding-stage backward tiles, layers are z - 1
+    int layer0;                                // first layer of this launch (grid z counts from it)
     int bf16x3;                                // 1: weight-gradient GEMMs as a 3-term bf16 split (wgrad_body_bf)
     const float* fc_dm; int64_t fc_o_cw; int fc_L;     // FMLP: filter-coefficient backward as part of the reduce blocks (fc_dm == NULL: none)
     // embedding scatter job (blockIdx.y == 7, large batches; sc_g == NULL: none)
@@ -177,8 +181,11 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, hipStream_t s);
+// layers [l_lo, l_hi) only (l_hi < 0: all): the upper layers' weight gradients need nothing the lower layers' backward still has to
+// compute, so the fused step launches them early on a side stream (step.hip backward_layers); the table-gradient jobs (owner / scatter
+// planes), the embedding-stage plane and the scorer partials belong to the launch that holds layer 0
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb = false,
-                 bool meta = false);     // meta: the fused last-layer launch carried the MetaModel weighting (its tile size differs)
+                 bool meta = false, int l_lo = 0, int l_hi = -1);     // meta: the fused last-layer launch carried the MetaModel weighting (its tile size differs)
 bool qeb_in_wgrad(const Workspace& ws);         // latency regime: k_qkv_embed_bwd's tiles run as the first plane of the k_wgrad launch
 
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);

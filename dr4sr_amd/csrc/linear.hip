@@ -83,9 +83,13 @@ static bool scatter_in_wgrad(const Workspace& ws) {
 static bool de_owner_mode(const Workspace& ws) { return scatter_in_wgrad(ws) && !DR4SR_ENV("DR4SR_DE_ATOMIC"); }
 // Owner geometry of the table gradient: G = 2^logG owners, the smallest power of two (>= 256) whose rows fit k_wgrad's LDS four
 // times (one private copy per wave) plus the queues.  Shared by the scorer launch (tile_sort needs G) and the k_wgrad launch.
-static size_t wgrad_lds_base(const dr4sr_sasrec_plan* p) {
+// at scale with d = 64 the weight-gradient GEMMs run as 64 x 64 blocks (k_wgrad_bf64): 32 KB of operand tiles per workgroup
+static bool wgrad_sub64(const dr4sr_sasrec_plan* p) {
+    return p->D == 64 && 4 + 2 * (p->F / 64) <= DR4SR_WGRAD_MAX_JOBS && !DR4SR_ENV("DR4SR_WGRAD_F32") && !DR4SR_ENV("DR4SR_WGRAD_WIDE");
+}
+static size_t wgrad_lds_base(const dr4sr_sasrec_plan* p) {          // (only the at-scale forms size their owners by it)
     const size_t D = p->D, F = p->F;
-    size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
+    size_t lds = sizeof(float) * 64 * (wgrad_sub64(p) && !DR4SR_ENV("DR4SR_WGRAD_LDS48") ? 2 * D : (D + F > 2 * D ? D + F : 2 * D));
     if (sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;       // the scatter job's position-table accumulator
     return lds;
 }
@@ -1378,13 +1382,13 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-            unsafeAtomicAdd(J.dW + (size_t)row * KX + kt * 32 + r, acc[i][e]);
+            unsafeAtomicAdd(J.dW + (size_t)row * (J.ldw ? J.ldw : KX) + kt * 32 + r, acc[i][e]);
         }
     }
 #pragma unroll
     for (int i = 0; i < (NG + 255) / 256; ++i) {
         const int n = threadIdx.x + 256 * i;
-        if (n < NG) unsafeAtomicAdd(J.db + n, bsum[i]);
+        if (n < NG && J.db) unsafeAtomicAdd(J.db + n, bsum[i]);
     }
 }
 
@@ -1403,7 +1407,9 @@ __device__ __forceinline__ void wg_pack(const float a, const float b, unsigned& 
     const wg_bf16x2 h = {ha, hb}, l = {(__bf16)(a - (float)ha), (__bf16)(b - (float)hb)};
     hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
 }
-template <int NG, int KX>
+// DEEP: the operand rows of TWO token tiles are in flight (two register sets, the loop unrolled by two): with one set the loads of tile
+// i + 1 fly only during the MFMA phase of tile i (a few hundred cycles) and are waited for right behind it
+template <int NG, int KX, bool DEEP = false>
 __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const WgradArgs& A) {
     constexpr int NT = NG / 32, KT = KX / 32, TPW = (NT * KT) / 4;
     static_assert((NT * KT) % 4 == 0, "tile count must split over 4 waves");
@@ -1417,34 +1423,35 @@ __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const WgradArgs
     f32x16 acc[TPW];
     acc_zero(acc);
     constexpr int GP = NG / 32, XP = KX / 32;              // (token pair, 4 columns) items per thread per tile
-    float4 g0[GP], g1[GP], x0[XP], x1[XP];
+    struct LoadSet { float4 g0[GP], g1[GP], x0[XP], x1[XP]; };
+    LoadSet SA, SB;
     float4 bs[GP];
 #pragma unroll
     for (int u = 0; u < GP; ++u) bs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto issue = [&](int tt) {                             // rows past T: the last row again, zeroed in commit
+    auto issue = [&](LoadSet& S, int tt) {                 // rows past T: the last row again, zeroed in commit
         const int t0 = tt * 64;
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
             const int i = threadIdx.x + 256 * u, pr = i / (NG / 4), c = (i % (NG / 4)) * 4;
             const int ta = min(t0 + 2 * pr, T - 1), tb = min(t0 + 2 * pr + 1, T - 1);
-            g0[u] = ld4(J.G + (size_t)ta * J.ldg + J.gcol + c);
-            g1[u] = ld4(J.G + (size_t)tb * J.ldg + J.gcol + c);
+            S.g0[u] = ld4(J.G + (size_t)ta * J.ldg + J.gcol + c);
+            S.g1[u] = ld4(J.G + (size_t)tb * J.ldg + J.gcol + c);
         }
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             const int i = threadIdx.x + 256 * u, pr = i / (KX / 4), c = (i % (KX / 4)) * 4;
             const int ta = min(t0 + 2 * pr, T - 1), tb = min(t0 + 2 * pr + 1, T - 1);
-            x0[u] = ld4(J.X + (size_t)ta * J.ldx + c);
-            x1[u] = ld4(J.X + (size_t)tb * J.ldx + c);
+            S.x0[u] = ld4(J.X + (size_t)ta * J.ldx + c);
+            S.x1[u] = ld4(J.X + (size_t)tb * J.ldx + c);
         }
     };
-    auto commit = [&](int tt) {
+    auto commit = [&](const LoadSet& S, int tt) {
         const int t0 = tt * 64;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
             const int i = threadIdx.x + 256 * u, pr = i / (NG / 4), c = (i % (NG / 4)) * 4;
-            const float4 a = t0 + 2 * pr < T ? g0[u] : z4, b = t0 + 2 * pr + 1 < T ? g1[u] : z4;
+            const float4 a = t0 + 2 * pr < T ? S.g0[u] : z4, b = t0 + 2 * pr + 1 < T ? S.g1[u] : z4;
             bs[u].x += a.x + b.x; bs[u].y += a.y + b.y; bs[u].z += a.z + b.z; bs[u].w += a.w + b.w;
             uint4 h, l;
             wg_pack(a.x, b.x, h.x, l.x); wg_pack(a.y, b.y, h.y, l.y); wg_pack(a.z, b.z, h.z, l.z); wg_pack(a.w, b.w, h.w, l.w);
@@ -1454,7 +1461,7 @@ __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const WgradArgs
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             const int i = threadIdx.x + 256 * u, pr = i / (KX / 4), c = (i % (KX / 4)) * 4;
-            const float4 a = t0 + 2 * pr < T ? x0[u] : z4, b = t0 + 2 * pr + 1 < T ? x1[u] : z4;
+            const float4 a = t0 + 2 * pr < T ? S.x0[u] : z4, b = t0 + 2 * pr + 1 < T ? S.x1[u] : z4;
             uint4 h, l;
             wg_pack(a.x, b.x, h.x, l.x); wg_pack(a.y, b.y, h.y, l.y); wg_pack(a.z, b.z, h.z, l.z); wg_pack(a.w, b.w, h.w, l.w);
             *reinterpret_cast<uint4*>(XH + pr * KX + c) = h;
@@ -1466,14 +1473,7 @@ __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const WgradArgs
         const uint4 v = make_uint4(p[0], p[ld], p[2 * ld], p[3 * ld]);
         return __builtin_bit_cast(wg_bf16x8, v);
     };
-    int tt = blockIdx.x;
-    if (tt >= ntiles) return;
-    issue(tt);
-    for (; tt < ntiles; tt += gridDim.x) {
-        lds_barrier();                                     // previous MFMA phase has finished reading LDS
-        commit(tt);
-        lds_barrier();
-        if (tt + (int)gridDim.x < ntiles) issue(tt + gridDim.x);
+    auto mfma_phase = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -1486,6 +1486,37 @@ __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const WgradArgs
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
             }
         }
+    };
+    int tt = blockIdx.x;
+    if (tt >= ntiles) return;
+    const int st = (int)gridDim.x;
+    issue(SA, tt);
+    if constexpr (DEEP) {
+        if (tt + st < ntiles) issue(SB, tt + st);
+        for (;;) {
+            lds_barrier();                                 // previous MFMA phase has finished reading LDS
+            commit(SA, tt);
+            lds_barrier();
+            if (tt + 2 * st < ntiles) issue(SA, tt + 2 * st);
+            mfma_phase();
+            tt += st;
+            if (tt >= ntiles) break;
+            lds_barrier();
+            commit(SB, tt);
+            lds_barrier();
+            if (tt + 2 * st < ntiles) issue(SB, tt + 2 * st);
+            mfma_phase();
+            tt += st;
+            if (tt >= ntiles) break;
+        }
+    } else {
+        for (; tt < ntiles; tt += st) {
+            lds_barrier();                                 // previous MFMA phase has finished reading LDS
+            commit(SA, tt);
+            lds_barrier();
+            if (tt + st < ntiles) issue(SA, tt + st);
+            mfma_phase();
+        }
     }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -1493,9 +1524,10 @@ __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const WgradArgs
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-            unsafeAtomicAdd(J.dW + (size_t)row * KX + kt * 32 + r, acc[i][e]);
+            unsafeAtomicAdd(J.dW + (size_t)row * (J.ldw ? J.ldw : KX) + kt * 32 + r, acc[i][e]);
         }
     }
+    if (!J.db) return;                                     // (uniform per workgroup)
     // bias: this thread's column sums -> LDS [256 / (NG / 4)][NG] -> one atomic per column
     lds_barrier();
     float* bl = smem;
@@ -1751,11 +1783,15 @@ __device__ __forceinline__ void owner_job_sorted(const WgradArgs& A, const int o
 
 // blockIdx.y = job within layer (0..5: dWq dWk dWv dWo dW1 dW2, 6: reductions; with the embedding scatter: y = 0 is the scatter
 // [layer 0 only] and the others shift by one), blockIdx.z = layer
-template <int D, int F, bool BF>
+// SUB (at scale, d = 64): every GEMM job is a 64 x 64 block of a weight gradient (the 128-wide jobs of linear1 / linear2 are cut in two),
+// so the kernel holds ONE GEMM instantiation of 120 VGPRs instead of the 188 of the <128, 64> / <64, 128> bodies, which capped ALL jobs at
+// 2 waves per SIMD: 61 % of a wave's life was s_waitcnt on the operand loads (SQ_WAIT_ANY, profiles/round4_sq_pmc_B8192_toys.txt) with two
+// workgroups per CU to hide them.  The cut re-reads y and df once more (+512 B per token and layer: algorithmic bytes unchanged).
+template <int D, int F, bool BF, bool SUB = false>
 __device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvEmbBwdArgs& Q) {
     // latency regime (A.qeb_plane): plane z = 0 of the grid is k_qkv_embed_bwd's work (16-row tiles, block-strided), layers shift by one
-    const int layer = A.qeb_plane ? (int)blockIdx.z - 1 : (int)blockIdx.z;
-    if (layer < 0) {
+    const int layer = A.layer0 + (A.qeb_plane ? (int)blockIdx.z - 1 : (int)blockIdx.z);
+    if (!SUB && layer < A.layer0) {
         const int T = A.state[DR4SR_STATE_T], nblk = gridDim.x * gridDim.y;
         for (int tile = blockIdx.y * gridDim.x + blockIdx.x; tile * 16 < T; tile += nblk) {
             qkv_embed_bwd_body<16, D>(Q, tile * 16, T);
@@ -1772,9 +1808,11 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvE
     }
     const int j = (int)blockIdx.y - (A.ow_on ? A.ow_planes : 0) - (A.sc_g ? 1 : 0);
     if (j < 0) { if (layer == 0) scatter_job<D>(A); return; }
-    if (j == 6) { reduce_jobs(A, layer); return; }
-    const WgradJob& J = A.job[layer * 6 + j];
-    if constexpr (BF) {
+    if (j == A.jobs_per_layer) { reduce_jobs(A, layer); return; }
+    const WgradJob& J = A.job[layer * A.jobs_per_layer + j];
+    if constexpr (SUB) {
+        wgrad_body_bf<64, 64>(J, A);       // (DEEP measured: 176 VGPRs -> 2 waves per SIMD again, 88.6 -> 102 us toys, 770 -> 780 us dense)
+    } else if constexpr (BF) {
         if (j < 4) wgrad_body_bf<D, D>(J, A);
         else if (j == 4) wgrad_body_bf<F, D>(J, A);
         else wgrad_body_bf<D, F>(J, A);
@@ -1789,6 +1827,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs A, const QkvEmbBw
 // the at-scale form with the weight-gradient GEMMs on the bf16 matrix cores (a separate kernel: its registers must not weigh on the fp32 one)
 template <int D, int F>
 __global__ __launch_bounds__(256) void k_wgrad_bf(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, true>(A, Q); }
+template <int D, int F>
+__global__ __launch_bounds__(256) void k_wgrad_bf64(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, true, true>(A, Q); }
 
 
 // ---- FMLP: weight gradients of the Intermediate blocks (dense_1, dense_2) + LayerNorm / scorer partial reductions
@@ -1856,30 +1896,55 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
     return DR4SR_LAUNCH_CHECK();
 }
 
-int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb, bool meta) {
+int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb, bool meta,
+                 int l_lo, int l_hi) {
     WgradArgs A;
+    if (l_hi < 0) l_hi = p->n_layer;
+    if (l_lo < 0 || l_lo >= l_hi || l_hi > p->n_layer) return DR4SR_E_ARG;
+    const bool has0 = l_lo == 0;                            // the launch that holds layer 0 also carries the table / embedding-stage jobs
+    A.layer0 = l_lo;
     const int D = p->D, F = p->F;
     float* G = p->grads;
+    const bool wg_f32 = DR4SR_ENV("DR4SR_WGRAD_F32") != nullptr;
+    A.bf16x3 = (ws.scale && !wg_f32) ? 1 : 0;              // at scale: weight gradients on the bf16 matrix cores (3-term split)
+    // at scale with d = 64: 64 x 64 blocks (k_wgrad_bf64, see wgrad_kernel_body); DR4SR_WGRAD_WIDE: the six whole jobs (cross-check)
+    const bool sub64 = A.bf16x3 && wgrad_sub64(p);
+    const int NJ = sub64 ? 4 + 2 * (F / 64) : 6;
+    A.jobs_per_layer = NJ;
     for (int l = 0; l < p->n_layer; ++l) {
         const LayerWs& lw = ws.layer[l];
+        WgradJob* jb = A.job + l * NJ;
         for (int part = 0; part < 3; ++part) {          // in_proj rows [part*D, (part+1)*D)
-            WgradJob& J = A.job[l * 6 + part];
+            WgradJob& J = jb[part];
             J.G = lw.dqkv; J.ldg = 3 * D; J.gcol = part * D;
-            J.X = ws.X[l]; J.ldx = D;
+            J.X = ws.X[l]; J.ldx = D; J.ldw = 0;
             J.dW = G + poff(ws, l, P_IN_W) + (int64_t)part * D * D; J.db = G + poff(ws, l, P_IN_B) + part * D;
         }
-        { WgradJob& J = A.job[l * 6 + 3];                 // out_proj: G = dout (= du1 * mask_proj), X = ctx
+        { WgradJob& J = jb[3];                            // out_proj: G = dout (= du1 * mask_proj), X = ctx
           J.G = lw.dout; J.ldg = D; J.gcol = 0;
-          J.X = lw.ctx; J.ldx = D;
+          J.X = lw.ctx; J.ldx = D; J.ldw = 0;
           J.dW = G + poff(ws, l, P_OUT_W); J.db = G + poff(ws, l, P_OUT_B); }
-        { WgradJob& J = A.job[l * 6 + 4];                 // linear1: G = da, X = y
-          J.G = lw.da; J.ldg = F; J.gcol = 0;
-          J.X = lw.y; J.ldx = D;
-          J.dW = G + poff(ws, l, P_W1); J.db = G + poff(ws, l, P_B1); }
-        { WgradJob& J = A.job[l * 6 + 5];                 // linear2: G = df (= du2 * mask_ffn), X = h = drop(gelu(a))
-          J.G = lw.df; J.ldg = D; J.gcol = 0;
-          J.X = lw.h; J.ldx = F;
-          J.dW = G + poff(ws, l, P_W2); J.db = G + poff(ws, l, P_B2); }
+        if (!sub64) {
+            { WgradJob& J = jb[4];                        // linear1: G = da, X = y
+              J.G = lw.da; J.ldg = F; J.gcol = 0;
+              J.X = lw.y; J.ldx = D; J.ldw = 0;
+              J.dW = G + poff(ws, l, P_W1); J.db = G + poff(ws, l, P_B1); }
+            { WgradJob& J = jb[5];                        // linear2: G = df (= du2 * mask_ffn), X = h = drop(gelu(a))
+              J.G = lw.df; J.ldg = D; J.gcol = 0;
+              J.X = lw.h; J.ldx = F; J.ldw = 0;
+              J.dW = G + poff(ws, l, P_W2); J.db = G + poff(ws, l, P_B2); }
+        } else {
+            for (int b = 0; b < F / 64; ++b) {
+                WgradJob& J1 = jb[4 + b];                 // linear1 rows [64 b, 64 b + 64): G = da[:, 64 b ..], X = y
+                J1.G = lw.da; J1.ldg = F; J1.gcol = 64 * b;
+                J1.X = lw.y; J1.ldx = D; J1.ldw = 0;
+                J1.dW = G + poff(ws, l, P_W1) + (int64_t)64 * b * D; J1.db = G + poff(ws, l, P_B1) + 64 * b;
+                WgradJob& J2 = jb[4 + F / 64 + b];        // linear2 columns [64 b, 64 b + 64): G = df, X = h[:, 64 b ..]
+                J2.G = lw.df; J2.ldg = D; J2.gcol = 0;
+                J2.X = lw.h + 64 * b; J2.ldx = F; J2.ldw = F;
+                J2.dW = G + poff(ws, l, P_W2) + 64 * b; J2.db = b == 0 ? G + poff(ws, l, P_B2) : nullptr;
+            }
+        }
     }
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.training = training;
     const int ntiles = (ws.Tmax + 63) / 64;
@@ -1896,7 +1961,10 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     // 840 / 854 us; toys B = 32 768: 160 -> 256 splits +1.4 % step).  Without a hint the capacity counts as before (cap 160).
     const int gw_cap_env = DR4SR_ENV("DR4SR_WGRAD_GW_CAP") ? atoi(DR4SR_ENV("DR4SR_WGRAD_GW_CAP")) : 0;
     const int hint_tiles = p->expected_tokens > 0 ? (int)((p->expected_tokens < ws.Tmax ? p->expected_tokens : ws.Tmax) / 64) : 0;
-    const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > 320 ? 320 : hint_tiles / 16) : 160);
+    // round 4 (64 x 64 block jobs, four workgroups per CU): dense B = 8 192 128 / 192 / 256 / 320 splits -> 713 / 681 / 680 / 720 us, toys B = 8 192
+    // 96 / 128 / 160 / 192 / 256 -> 92 / 83 / 83 / 89 / 105 us: the upper cap comes down from 320 to 224
+    const int gw_hi = sub64 ? 224 : 320;
+    const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > gw_hi ? gw_hi : hint_tiles / 16) : 160);
     // floor: 48 splits (36 real tiles at the toys B = 256 batch: one each), 64 once the batch is expected to hold >= 100 tiles
     // (dense B = 256, 200 tiles: k_wgrad 49.4 -> 44.2 us; 80 splits: 44.8)
     const bool gw_env = DR4SR_ENV("DR4SR_WGRAD_GW") != nullptr;
@@ -1904,16 +1972,14 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     int gw_t = ntiles / 16 > gw_floor ? (ntiles / 16 > gw_cap ? gw_cap : ntiles / 16) : gw_floor;   // >= 16 token tiles per workgroup at scale
     int gw = ntiles < gw_t ? ntiles : gw_t;
     A.sc_g = nullptr;
-    const bool scatter = scatter_in_wgrad(ws) && with_score != 1;       // paired with launch_qkv_embed_bwd (not the unfused debug path)
+    const bool scatter = has0 && scatter_in_wgrad(ws) && with_score != 1;       // paired with launch_qkv_embed_bwd (not the unfused debug path)
     if (scatter) {
         A.sc_g = ws.dX[0]; A.sc_idx = p->in_item_id; A.sc_rows = p->rows; A.sc_tile_seq = ws.tile_seq; A.cu = ws.cu;
         A.sc_dE = G + ws.off[0]; A.sc_dP = G + ws.off[1]; A.sc_L = p->L; A.sc_n_items = p->n_items;
     }
-    A.qeb_plane = (qeb && qeb_in_wgrad(ws)) ? 1 : 0;
-    const bool wg_f32 = DR4SR_ENV("DR4SR_WGRAD_F32") != nullptr;
-    A.bf16x3 = (ws.scale && !wg_f32) ? 1 : 0;              // at scale: weight gradients on the bf16 matrix cores (3-term split)
+    A.qeb_plane = (has0 && qeb && qeb_in_wgrad(ws)) ? 1 : 0;
     const QkvEmbBwdArgs Q = make_qeb_args(p, ws, training);
-    size_t lds = sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
+    size_t lds = sub64 ? wgrad_lds_base(p) : sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
     if (scatter && sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;
     A.ow_ent = nullptr; A.ow_off = nullptr;
     A.ow_on = 0; A.ow_rec = nullptr; A.ow_idx32 = nullptr; A.ow_z = nullptr; A.ow_logG = 0; A.ow_planes = 0; A.ow_rpo = 0;
@@ -1924,10 +1990,11 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
         A.ow_rec = with_score == 2 ? ws.de_rec : nullptr; A.ow_idx32 = ws.idx32; A.ow_z = ws.X[p->n_layer];
         if (with_score == 2 && owner_sorted(p, ws, meta)) { A.ow_ent = ws.de_ent; A.ow_off = ws.de_off; }
     }
-    dim3 grid(gw, (scatter ? 8 : 7) + A.ow_planes, p->n_layer + A.qeb_plane), blk(256);
+    dim3 grid(gw, NJ + 1 + (scatter ? 1 : 0) + A.ow_planes, (l_hi - l_lo) + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D + 16);
     if (A.qeb_plane && lds_q > lds) lds = lds_q;
-#define WG(D_, F_) do { if (A.bf16x3) { big_lds(k_wgrad_bf<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_bf<D_, F_>), grid, blk, lds, s, A, Q); } \
+#define WG(D_, F_) do { if (sub64) { big_lds(k_wgrad_bf64<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_bf64<D_, F_>), grid, blk, lds, s, A, Q); } \
+                        else if (A.bf16x3) { big_lds(k_wgrad_bf<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_bf<D_, F_>), grid, blk, lds, s, A, Q); } \
                         else { big_lds(k_wgrad<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad<D_, F_>), grid, blk, lds, s, A, Q); } } while (0)
     if (D == 64 && F == 128) WG(64, 128);
     else if (D == 128 && F == 128) WG(128, 128);

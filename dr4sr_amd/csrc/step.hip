@@ -22,6 +22,45 @@ void big_lds_impl(const void* kernel, size_t bytes) {
 
 extern "C" int dr4sr_abi_version(void) { return DR4SR_ABI_VERSION; }
 
+// ---- side streams (common.h StepFork).  Created on the first call from OUTSIDE a stream capture (every caller warms a step up before it
+// captures one: engine.py, basemodel.py, bench.py); a first call from inside a capture leaves them off for that call only.
+static StepFork g_fork = {};
+const StepFork& step_fork() {
+    if (g_fork.state == 0 && DR4SR_ENV("DR4SR_STREAMS")) {
+        bool ok = true;
+        for (int i = 0; i < StepFork::NSIDE && ok; ++i) ok = hipStreamCreateWithFlags(&g_fork.side_[i], hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < StepFork::NSIDE && ok; ++i) ok = hipEventCreateWithFlags(&g_fork.fork_ev[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < StepFork::NSIDE && ok; ++i) ok = hipEventCreateWithFlags(&g_fork.join_ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        g_fork.state = ok ? 1 : -1;
+    }
+    return g_fork;
+}
+// OPT-IN (DR4SR_STREAMS=1): measured slower on this stack at every size — a fork + join through a captured graph costs ~30 us of cross-queue
+// signalling for two branches (tools/probes/graph_branch_probe.py: two 85 us kernels side by side take 115 us, four 141 us), more than the
+// 10-25 us launches it overlaps; B = 256: 0.1245 -> 0.1443 ms, B = 8 192: 0.523 -> 0.576 ms, B = 131 072: 5.77 -> 6.22 ms (the early
+// weight-gradient launch also takes CUs from the persistent tile kernels).  hipExtAnyOrderLaunch (no barrier bit inside ONE queue) is
+// documented as unsupported on gfx9.  Kept as a switch + test: the dependency analysis is right, the platform's price for it is not.
+bool StepFork::on() const { return state == 1 && DR4SR_ENV("DR4SR_STREAMS") != nullptr; }
+int StepFork::fork(hipStream_t main, int first, int n) const {
+    if (!on()) return 0;
+    hipError_t e = hipSuccess;
+    for (int i = first; i < first + n && e == hipSuccess; ++i) {
+        e = hipEventRecord(fork_ev[i], main);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side_[i], fork_ev[i], 0);
+    }
+    return hip_ret(e);
+}
+int StepFork::join(hipStream_t main, int first, int n) const {
+    if (!on()) return 0;
+    hipError_t e = hipSuccess;
+    for (int i = first; i < first + n && e == hipSuccess; ++i) {
+        e = hipEventRecord(join_ev[i], side_[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main, join_ev[i], 0);
+    }
+    return hip_ret(e);
+}
+
 static int g_env_generation = 0;
 int dr4sr_env_generation() { return g_env_generation; }
 extern "C" int dr4sr_reload_env(void) { return ++g_env_generation; }
@@ -334,14 +373,29 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
 
 static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s,
                            bool mid_fused = false, bool meta = false) {
+    const bool fused = !DR4SR_ENV("DR4SR_NO_FUSE");
+    // The weight gradients of layer l >= 1 need dqkv_l (attention backward of layer l) and nothing that the layers below still have to
+    // compute: their launch goes to a side stream right behind attn_bwd(l) and runs BESIDE post_bwd(l-1) / attn_bwd(l-1) / the embedding
+    // stage — an HBM stream next to latency-bound launches (in a captured step: a parallel branch of the graph).  The launch that
+    // holds layer 0 (table-gradient jobs, embedding-stage plane, scorer partials) stays last, behind the join.  DR4SR_WGRAD_ONE_LAUNCH:
+    // every layer in the last launch, as before round 4 (cross-check).
+    const StepFork& fk = step_fork();
+    const bool early = fused && fk.on() && p->n_layer > 1 && !DR4SR_ENV("DR4SR_WGRAD_ONE_LAUNCH");
+    bool forked = false;
     for (int l = p->n_layer - 1; l >= 0; --l) {
         if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_bwd(p, ws, l, training, s));
         RC(attn_bwd(p, ws, l, training, s));
-        if (DR4SR_ENV("DR4SR_NO_FUSE")) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
+        if (!fused) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
+        if (early && l >= 1) {
+            RC(fk.fork(s, 2, 1));                           // side 2 is a queue: the layers' launches run one after the other on it
+            RC(launch_wgrad(p, ws, training, with_score, fk.side(s, 2), true, meta, l, l + 1));
+            forked = true;
+        }
     }
-    if (DR4SR_ENV("DR4SR_NO_FUSE")) RC(launch_embed_bwd(p, ws, training, s));
+    if (!fused) RC(launch_embed_bwd(p, ws, training, s));
     else if (!qeb_in_wgrad(ws)) RC(launch_qkv_embed_bwd(p, ws, training, s));
-    RC(launch_wgrad(p, ws, training, with_score, s, !DR4SR_ENV("DR4SR_NO_FUSE"), meta));
+    if (forked) RC(fk.join(s, 2, 1));
+    RC(launch_wgrad(p, ws, training, with_score, s, fused, meta, 0, forked ? 1 : -1));
     return 0;
 }
 
