@@ -169,6 +169,7 @@ SYMBOLS = {
                                         C.c_double, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "dr4sr_cl_prepare": (C.c_int, [_i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_cl_scalars": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
+    "dr4sr_cl_scalars_dp": (C.c_int, [_f32p, C.c_int32, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
     "dr4sr_infonce_fwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_infonce_bwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_full_score_topk": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

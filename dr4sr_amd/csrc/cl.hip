@@ -310,6 +310,16 @@ __global__ void k_cl_scalars(const float* __restrict__ tail, const float* __rest
     if (scale_out) *scale_out = rows > 0.f ? clw * nv / rows : 0.f;
     if (loss_out) *loss_out = tail[1] / nv + (rows > 0.f ? clw * stats[1] / rows : 0.f);
 }
+// data-parallel / MetaModel form: n_valid is the SUM of per-rank counts (gathered next to the pooled views), and the contrastive term's
+// share of the reported loss is folded into the local {n_valid, loss_sum} tail so that (all-reduced) tail[1] / tail[0] is the step's loss
+__global__ void k_cl_scalars_dp(const float* __restrict__ nv_parts, int n_parts, int64_t stride, const float* __restrict__ stats, float clw,
+                                float* __restrict__ scale_out, float* __restrict__ tail_local) {
+    float nv = 0.f;
+    for (int r = 0; r < n_parts; ++r) nv += nv_parts[(size_t)r * stride];
+    const float rows = stats[0];
+    if (scale_out) *scale_out = rows > 0.f ? clw * nv / rows : 0.f;
+    if (tail_local) tail_local[1] += (rows > 0.f ? clw * stats[1] / rows : 0.f) * tail_local[0];
+}
 }  // namespace
 /* valid[b] = seqlen[b] != 1, stats[0..1] = 0, zero[0..nzero) = 0 */
 extern "C" int dr4sr_cl_prepare(const int64_t* seqlen, int32_t B, uint8_t* valid, float* stats, float* zero, int64_t nzero, void* stream) {
@@ -325,6 +335,13 @@ extern "C" int dr4sr_cl_prepare(const int64_t* seqlen, int32_t B, uint8_t* valid
 extern "C" int dr4sr_cl_scalars(const float* tail, const float* stats, float cl_weight, float* scale_out, float* loss_out, void* stream) {
     if (!tail || !stats || (!scale_out && !loss_out)) return DR4SR_E_ARG;
     hipLaunchKernelGGL(k_cl_scalars, dim3(1), dim3(1), 0, (hipStream_t)stream, tail, stats, cl_weight, scale_out, loss_out);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+extern "C" int dr4sr_cl_scalars_dp(const float* nv_parts, int32_t n_parts, int64_t stride, const float* stats, float cl_weight,
+                                   float* scale_out, float* tail_local, void* stream) {
+    if (!nv_parts || n_parts <= 0 || stride < 0 || !stats || (!scale_out && !tail_local)) return DR4SR_E_ARG;
+    hipLaunchKernelGGL(k_cl_scalars_dp, dim3(1), dim3(1), 0, (hipStream_t)stream, nv_parts, n_parts, stride, stats, cl_weight, scale_out, tail_local);
     return DR4SR_LAUNCH_CHECK();
 }
 

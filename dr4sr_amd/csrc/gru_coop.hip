@@ -535,6 +535,7 @@ struct WaveArgs {
     const float* dhout; float* dgi[2]; float* dgh[2];     // backward: dL/d(top output), gate gradients
     u64* xch; int* ctl; int B; int L;
     int presleep, solo, stamp;                                   // tuning / diagnosis (DR4SR_GRU_WAVE_PRESLEEP, DR4SR_GRU_WAVE_SOLO)
+    int order;                                                   // block index -> role order (wave_who)
 };
 // granules per group: per-step slots [L][48 H] (forward: h_1[t] in the first 16 H; backward: dgi_2[t], all 3H gate rows) | forward h_2
 // ring [2][16 H] | backward: layer-2 partial ring [2][NS][16][H] | layer-1 partial ring [2][NS][16][H]
@@ -553,12 +554,24 @@ template <int H, int NS> constexpr size_t wave_group_words(int L) { return WaveA
 // control block's spare words: ctl[8 + 16 role + i]
 #define WAVE_STAMP(i) do { if (A.stamp && st_on) { if (lane == 0) A.ctl[8 + 16 * who.role + (i)] = (int)__builtin_amdgcn_s_memtime(); } } while (0)
 struct WaveWho { int grp, sl, role; };
-template <int NS> __device__ __forceinline__ WaveWho wave_who() {
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, q = jx / NS;         // q: 0..3 per 8 groups = (group half, role)
+template <int NS> __device__ __forceinline__ WaveWho wave_who(const int order) {
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, q = jx / NS;         // q: 0..3 per 16 groups = (role, group half)
     WaveWho w;
     w.sl = jx % NS;
-    w.grp = ((q >> 2) * 2 + ((q >> 1) & 1)) * 8 + xcd;
-    w.role = (q ^ (q >> 1)) & 1;                           // q = 0, 1, 2, 3 -> leader, follower, follower, leader
+    // 16 groups: q = 0, 1, 2, 3 -> leader (groups 0..7), leader (8..15), follower (8..15), follower (0..7); 8 groups: leader, follower.
+    // EVERY leader has a lower block index than its follower (workgroups are dispatched in index order, so a follower never holds a
+    // slot its leader still waits for — ADVICE r3; round 3's order leader, follower, follower, leader had the second half's followers
+    // first), and blocks jx / jx + 32 still pair a leader with a follower of the OTHER group half on a CU: a leader sharing its CU with
+    // its own follower (order leader, leader, follower(0..7), follower(8..15)) measured 4 % slower — the two wait for each other, so
+    // their phases never overlap (0.505 against 0.484 ms per GRU4Rec step)
+    const int halves = (int)gridDim.x / (2 * 8 * NS);         // groups of the launch / 8 (grid = 2 roles x 8 halves groups x NS slices)
+    if (order == 0 && halves == 2) {                       // round 3's order: leader, follower, follower, leader
+        w.grp = ((q >> 1) & 1) * 8 + xcd;
+        w.role = (q ^ (q >> 1)) & 1;
+        return w;
+    }
+    w.role = q >= halves;
+    w.grp = (w.role ? (order == 2 ? q - halves : 2 * halves - 1 - q) : q) * 8 + xcd;      // order 2: leader, leader, follower(0..7), follower(8..15)
     return w;
 }
 
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd_wave(const WaveArgs A) {
     static_assert(US == 16 && H == 256, "one 16-unit tile per slice, four K-quarter waves of two 32-k MFMAs");
     float* part = smem;                                   // [2 parity][4 kq][4][16 unit][16 seq]
     int* meta = reinterpret_cast<int*>(part + 2 * 4 * 4 * 16 * 16);
-    const WaveWho who = wave_who<NS>();
+    const WaveWho who = wave_who<NS>(A.order);
     const int grp = who.grp, sl = who.sl, b0 = grp * 16, layer = who.role;       // forward: layer 1 leads
     if (b0 >= A.B || (A.solo == 1 && who.role)) { finish_launch(A.ctl); return; }
     if (threadIdx.x < 16) {
@@ -1299,6 +1312,7 @@ int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int
     const int solo = DR4SR_ENV("DR4SR_GRU_WAVE_SOLO") ? atoi(DR4SR_ENV("DR4SR_GRU_WAVE_SOLO")) : 0;            // diagnosis only: the follower layer does not run (wrong results)
     const int stamp = DR4SR_ENV("DR4SR_GRU_WAVE_STAMP") ? 1 : 0;
     A.presleep = presleep; A.solo = solo; A.stamp = stamp;
+    A.order = DR4SR_ENV("DR4SR_GRU_WAVE_ORDER") ? atoi(DR4SR_ENV("DR4SR_GRU_WAVE_ORDER")) : 1;
     for (int l = 0; l < 2; ++l) {
         A.whh[l] = G.whh[l]; A.r[l] = G.r[l]; A.z[l] = G.z[l]; A.n[l] = G.n[l]; A.ghn[l] = G.ghn[l]; A.hprev[l] = G.hprev[l]; A.hout[l] = G.hout[l];
         A.dgi[l] = G.dgi[l]; A.dgh[l] = G.dgh[l];

@@ -20,7 +20,8 @@
 //     v_mfma_f32_16x16x32_bf16 with fp32 accumulation — 3 matrix instructions of 8 passes per 32 k against 8 fp32 ones of 8 passes: 2.7x less
 //     matrix-pipe time, on a pipe that (unlike the fp32 MFMA) runs BESIDE the VALU.  Max-norm error of a K = 64..192 product:
 //     5e-6 (fp32 MFMA: 4e-7) — the precision class JAX calls HIGH; the parity bar is 1e-3 (north star) / 2e-4 (tests).  The
-//     EXACT instantiations keep v_mfma_f32_16x16x4_f32 on the same data flow (DR4SR_EXACT_F32=1; tests run both);
+//     EXACT instantiations keep v_mfma_f32_16x16x4_f32 on the same data flow and are the DEFAULT (HBM-bound either way);
+//     DR4SR_WT_BF16X3=1 selects the split in the forward kernel (tests run both);
 //   * 8 consecutive columns of a token = ONE Philox call (16-bit dropout decisions, common.h), half the calls of the float4 kernels;
 //   * saved activations keep their [T, *] layouts: each kernel is a drop-in for its linear.hip counterpart (DR4SR_NO_WAVE_TILES
 //     restores those; tests run both).
@@ -351,7 +352,7 @@ __device__ __forceinline__ void wt_fwd_tile(const PostArgs& A, const char* lds, 
             wt_row_load<F>(bias, vec + Lds::v_b1, g);
 #pragma unroll
             for (int j = 0; j < FT; ++j) h[j] += bias[j];
-            if (ok) wt_row_store_nt<F>(A.a + (size_t)t * F, h, g);
+            if (ok && A.a) wt_row_store_nt<F>(A.a + (size_t)t * F, h, g);        // (NULL when the wave-tile backward follows: it recomputes a)
 #pragma unroll
             for (int j = 0; j < FT; ++j) h[j] = (f32x4){gelu_erf(h[j][0]), gelu_erf(h[j][1]), gelu_erf(h[j][2]), gelu_erf(h[j][3])};
             if (actdrop) wt_row_drop<F>(h, rk, sA, (uint64_t)t * F, g);
@@ -439,7 +440,7 @@ template <int D, int F> struct WtBwdLds {
     typedef WtImg<true, D, D> Out;
     typedef WtImg<true, 3 * D, D> Up;
     static constexpr int o_w2 = 0, o_w1 = o_w2 + W2::bytes, o_out = o_w1 + W1::bytes, o_up = o_out + Out::bytes, o_vec = o_up + Up::bytes;
-    static constexpr int v_ln2w = 0, v_ln1w = D, n_vec = 2 * D;           // floats
+    static constexpr int v_ln2w = 0, v_ln1w = D, v_b1 = 2 * D, n_vec = 2 * D + F;           // floats
     static constexpr int total = o_vec + 4 * n_vec;
 };
 
@@ -481,10 +482,20 @@ __device__ __forceinline__ void wt_bwd_tile(const PostArgs& A, const char* lds, 
         wt_gemm_xw<D, F>(lds + Lds::o_w2, df, da);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- da = dh * mask_act * gelu'(a)
+    // ---- da = dh * mask_act * gelu'(a).  a = y W1^T + b1 is RECOMPUTED from the saved LayerNorm1 output (round 4): the forward no
+    // longer writes the [T, F] pre-activations (512 B per token and layer) and this pass reads 256 B of y instead of 512 B of a, for one
+    // more 16 x 64 x 128 GEMM on an image that is in LDS anyway — the kernels are HBM-bound at scale.  Same MFMA sequence
+    // as the forward's: bit-identical a when the forward ran the fp32 form.
     {
         f32x4 av[FT];
-        wt_row_load<F>(av, A.a + tl * F, g);
+        if (A.a) {                                          // (DR4SR_WT_SAVE_A: the stored pre-activations, round 3's form)
+            wt_row_load<F>(av, A.a + tl * F, g);
+        } else {
+            f32x4 yv[DT];
+            wt_row_load<D>(yv, A.y + tl * D, g);
+            wt_row_load<F>(av, vec + Lds::v_b1, g);
+            Lds::W1::gemm(lds + Lds::o_w1, yv, av);
+        }
         if (actdrop) wt_row_drop<F>(da, rk, A.sA, (uint64_t)t * F, g);
 #pragma unroll
         for (int j = 0; j < FT; ++j)
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(WT_WAVES * 64) void k_wt_post_bwd(const PostArgs A)
     Lds::W1::load(lds + Lds::o_w1, A.w1);
     Lds::Out::load(lds + Lds::o_out, A.out_w);
     if (A.up_dqkv) Lds::Up::load(lds + Lds::o_up, A.up_in_w);
-    wt_load_v(vec + Lds::v_ln2w, A.ln2_w, D); wt_load_v(vec + Lds::v_ln1w, A.ln1_w, D);
+    wt_load_v(vec + Lds::v_ln2w, A.ln2_w, D); wt_load_v(vec + Lds::v_ln1w, A.ln1_w, D); wt_load_v(vec + Lds::v_b1, A.b1, F);
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     const bool dodrop = A.training && A.p > 0.f;

@@ -376,7 +376,6 @@ __global__ __launch_bounds__(256) void k_topk_select(float* __restrict__ S, cons
         if (tid == 0) {
             bound_out[b] = (nc >= k && k <= n_items) ? key2f((unsigned)(cand[k - 1] >> 32)) : -INFINITY;
             cnt_out[b] = 0;
-            if (b == 0) cnt_out[gridDim.x] = 0;            // the batch's overflow flag sits behind the counters (no memset node: DESIGN §4a)
         }
         return;
     }
@@ -435,7 +434,8 @@ __device__ __forceinline__ unsigned wave_radix_kth(KeyFn key, const int n, int r
 
 // SUBSET pass, wave per row: bound[b] = the k-th largest valid score among the subset's n_sub columns (history masked in the row)
 __global__ __launch_bounds__(64) void k_subset_bound_w(float* __restrict__ S, const int64_t* __restrict__ hist, int n_sub, int sub_s, int Lh,
-                                                       int k, int stride, float* __restrict__ bound_out, int* __restrict__ cnt_out) {
+                                                       int k, int stride, float* __restrict__ bound_out, int* __restrict__ cnt_out,
+                                                       int* __restrict__ flag_out) {
     __shared__ int hst[256];
     const int b = blockIdx.x, lane = threadIdx.x;
     float* row = S + (size_t)b * sub_s;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64) void k_subset_bound_w(float* __restrict__ S, co
     if (lane == 0) {
         bound_out[b] = key2f(T);
         cnt_out[b] = 0;
-        if (b == 0) cnt_out[gridDim.x] = 0;                // the batch's overflow flag sits behind the counters (no memset node: DESIGN §4a)
+        if (b == 0) *flag_out = 0;                         // the batch's overflow flag (no memset node: DESIGN §4a)
     }
 }
 
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void k_cand_select(const unsigned long long* _
 
 extern "C" int64_t dr4sr_full_score_topk_workspace_bytes(int64_t B, int32_t n_items) {
     if (B < 0 || n_items < 2) return DR4SR_E_ARG;
-    return B * (int64_t)((n_items + 63) / 64 * 64) * 4;
+    return B * (int64_t)((n_items + 63) / 64 * 64) * 4 + 256;     // [B][lds_s] scores + the fused form's overflow flag behind them
 }
 
 static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, const uint8_t* blocked, float* out_score, int64_t* out_item,
@@ -599,32 +599,29 @@ static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, con
     constexpr int CAPC = 2048;
     const int stride = 8, n_sub = (n_items - 1 + stride - 1) / stride, sub_s = (n_sub + 63) / 64 * 64;
     const int64_t need = B * ((int64_t)sub_s * 4 + (int64_t)CAPC * 8 + 8) + 256;
-    const bool fused = !unfused && n_items >= 4096 && need <= workspace_bytes && k * stride * 2 <= CAPC;
+    const int64_t flag_off = B * (int64_t)lds_s * 4;       // BEHIND the [B][lds_s] matrix: the two-kernel fall-back of an overflowed batch
+    const bool fused = !unfused && n_items >= 4096 && need <= flag_off && flag_off + 4 <= workspace_bytes && k * stride * 2 <= CAPC;     //  writes its scores over everything else
     const int* run_if = nullptr;
     if (fused) {
-        // workspace: [B][sub_s] subset scores | [B] bound | [B] counters | flag | [B][CAPC] candidates  (the two-kernel fall-back,
-        // which only runs for an overflowed batch, re-uses the same bytes as its [B][lds_s] score matrix)
+        // workspace: [B][sub_s] subset scores | [B] bound | [B] counters | [B][CAPC] candidates  (the two-kernel fall-back, which only
+        // runs for an overflowed batch, re-uses the same bytes as its [B][lds_s] score matrix) ... | flag at flag_off
         float* sub = workspace;
         float* bound = sub + B * (int64_t)sub_s;
         int* cnt = reinterpret_cast<int*>(bound + B);
-        int* flag = cnt + B;
+        int* flag = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + flag_off);
         unsigned long long* cand = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + ((B * ((int64_t)sub_s * 4 + 8) + 4 + 255) / 256) * 256);
         Fz.stride = stride; Fz.n_sub = n_sub;
         dim3 gsub(sub_s / 64, (unsigned)((B + 63) / 64));
         if (D == 64) hipLaunchKernelGGL(k_score_gemm<64>, gsub, dim3(256), lds_g, s, q, E, sub, (int)B, n_items, sub_s, blocked, Fz);
         else { big_lds(k_score_gemm<128>, lds_g); hipLaunchKernelGGL(k_score_gemm<128>, gsub, dim3(256), lds_g, s, q, E, sub, (int)B, n_items, sub_s, blocked, Fz); }
-        hipLaunchKernelGGL(k_subset_bound_w, dim3((unsigned)B), dim3(64), 0, s, sub, hist, n_sub, sub_s, Lh, k, stride, bound, cnt);
-        const int dbg = DR4SR_ENV("DR4SR_TOPK_DBG") ? atoi(DR4SR_ENV("DR4SR_TOPK_DBG")) : 0;      // timing probe: stop after pass 1 / 2 / 3
-        if (dbg == 1) return DR4SR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_subset_bound_w, dim3((unsigned)B), dim3(64), 0, s, sub, hist, n_sub, sub_s, Lh, k, stride, bound, cnt, flag);
         {
             dim3 ge((unsigned)((lds_s / 64 + EMIT_TILES - 1) / EMIT_TILES), (unsigned)((B + 63) / 64));
             const size_t lds_e = sizeof(float) * (2 * 64 * (D + 1) + 64) + sizeof(int) * 64 + sizeof(unsigned long long) * 64 * EMIT_CAPL;
             if (D == 64) { big_lds(k_score_emit<64>, lds_e); hipLaunchKernelGGL(k_score_emit<64>, ge, dim3(256), lds_e, s, q, E, (int)B, n_items, blocked, bound, cnt, cand, CAPC, flag); }
             else { big_lds(k_score_emit<128>, lds_e); hipLaunchKernelGGL(k_score_emit<128>, ge, dim3(256), lds_e, s, q, E, (int)B, n_items, blocked, bound, cnt, cand, CAPC, flag); }
         }
-        if (dbg == 2) return DR4SR_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_cand_select_w<CAPC>, dim3((unsigned)B), dim3(64), 0, s, cand, cnt, hist, out_score, out_item, Lh, k, flag);
-        if (dbg == 3) return DR4SR_LAUNCH_CHECK();
         run_if = flag;                                     // the two launches below exit at once unless a row overflowed
         Fz = FuseArgs{};
     }

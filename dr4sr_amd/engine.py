@@ -7,6 +7,7 @@ Replaces, on the device: one iteration of BaseModel.training_epoch
 """
 from __future__ import annotations
 
+import logging
 import ctypes as C
 from collections import OrderedDict
 from typing import Dict, Optional
@@ -154,7 +155,6 @@ class SasrecEngine:
         elif torch.cuda.is_current_stream_capturing():
             if not getattr(self, "_warned_no_hint", False):
                 self._warned_no_hint = True
-                import logging
                 logging.getLogger("CDR").warning("dr4sr_amd: no expected_tokens hint for a per-batch plan inside a graph capture "
                                                  "(engine.mean_len unset): launch forms follow the capacity rule")
             return 0

@@ -20,9 +20,6 @@ class CL4SRec(SASRec):
         return max(super()._max_batch(config), 2 * int(config["train"]["batch_size"]))     # both views as one batch of 2B sequences
 
     def _init_model(self, train_data):
-        if self.world_size > 1:
-            raise NotImplementedError("CL4SRec trains through the API path, which has no gradient all-reduce: single GPU only "
-                                      "(data parallelism covers SASRec / GRU4Rec / FMLP / MetaModel)")
         super()._init_model(train_data)
         self.augmentation_model = data_augmentation.CL4SRecAugmentation(self.config["model"], train_data,
                                                                        seed=int(self.config["train"]["seed"]) + 104729 * self.rank)
@@ -63,65 +60,167 @@ class CL4SRec(SASRec):
             return super()._api_step_body(batch)
         from .. import _lib
         eng, lib = self.engine, self.engine.lib
-        am = self.augmentation_model
-        aug = am.augmentation
         ids, tgt, lens = batch["in_" + self.fiid], batch[self.fiid], batch["seqlen"]
         batch["neg_item"] = self._neg_sampling(batch)
-        if hasattr(aug, "begin_step"):
-            aug.begin_step()
         n = eng.n_params
         # main pass: prep zeroes the flat gradient, fused forward + scorer + backward
         eng.fwd_bwd(eng.make_plan(ids, tgt, lens, neg_item=batch["neg_item"].contiguous().view(-1), sample_neg=False))
-        # two views through the same encoder (mean pooling fused), one workspace slot each
-        if hasattr(aug, "two_views"):
-            (aug_i, len_i), (aug_j, len_j) = aug.two_views(ids, lens)
-        else:
-            (aug_i, len_i), (aug_j, len_j) = aug(ids, lens), aug(ids, lens)
-        # The views are independent sequences through one encoder: by default they run as ONE batch of 2B sequences (the halves of
-        # two_views()' tensors are contiguous) — at these sizes a pass costs its launch chain, not its tokens, so one pass of 2B is
-        # ~1.15x a pass of B instead of 2x.  DR4SR_CL_TWO_PASS keeps one pass per view in slots 1 and 2: the dropout streams of the
-        # autograd body (the batched pass draws independent masks too, from one stream keyed by the row index in 2B).
-        import os
-        B = int(ids.shape[0])
-        batched = (hasattr(aug, "two_views") and 2 * B <= eng.max_batch and aug_i.data_ptr() + aug_i.numel() * 8 == aug_j.data_ptr()
-                   and not os.environ.get("DR4SR_CL_TWO_PASS"))
-        if batched:
-            ids2 = torch.as_strided(aug_i, (2 * B, aug_i.shape[1]), aug_i.stride())
-            len2 = torch.as_strided(len_i, (2 * B,), len_i.stride())
-            plan_v = eng.make_plan(ids2, None, len2, slot=1)
-            q = eng.encode(plan_v, True, _lib.POOL_MEAN)
-            q_i, q_j = q[:B], q[B:]
-        else:
-            plan_i, plan_j = eng.make_plan(aug_i, None, len_i, slot=1), eng.make_plan(aug_j, None, len_j, slot=2)
-            q_i, q_j = eng.encode(plan_i, True, _lib.POOL_MEAN), eng.encode(plan_j, True, _lib.POOL_MEAN)
-        if hasattr(aug, "end_step"):
-            aug.end_step()
-        B, D = q_i.shape
-        dev = self.device
-        valid, stats = torch.empty(B, dtype=torch.uint8, device=dev), torch.empty(2, dtype=torch.float32, device=dev)
-        lse, loss_row = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
-        dq = torch.empty(2, B, D, dtype=torch.float32, device=dev)
-        sc = torch.empty(2, dtype=torch.float32, device=dev)               # {InfoNCE backward scale, reported loss}
-        st = _lib.cur_stream
-        _lib.check(lib.dr4sr_cl_prepare(_lib.ptr(lens.contiguous()), B, _lib.ptr(valid), _lib.ptr(stats), _lib.ptr(dq), dq.numel(), st()),
-                   "dr4sr_cl_prepare")
-        temp = float(am.InfoNCE_loss_fn.temperature)
-        _lib.check(lib.dr4sr_infonce_fwd(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(loss_row),
-                                         _lib.ptr(stats), st()), "dr4sr_infonce_fwd")
-        clw = float(self.config["model"]["cl_weight"])
-        tail = eng.grads[n:n + 2]
-        _lib.check(lib.dr4sr_cl_scalars(_lib.ptr(tail), _lib.ptr(stats), clw, _lib.ptr(sc[0:1]), None, st()), "dr4sr_cl_scalars")
-        _lib.check(lib.dr4sr_infonce_bwd(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(sc[0:1]),
-                                         _lib.ptr(dq[0]), _lib.ptr(dq[1]), st()), "dr4sr_infonce_bwd")
-        if batched:
-            eng.encode_bwd(plan_v, True, _lib.POOL_MEAN, dq.view(2 * B, D))
-        else:
-            eng.encode_bwd(plan_i, True, _lib.POOL_MEAN, dq[0])
-            eng.encode_bwd(plan_j, True, _lib.POOL_MEAN, dq[1])
-        _lib.check(lib.dr4sr_cl_scalars(_lib.ptr(tail), _lib.ptr(stats), clw, None, _lib.ptr(sc[1:2]), st()), "dr4sr_cl_scalars")
-        loss = sc[1]
+        stats = self._cl_term(ids, lens)
+        sc = torch.empty(1, dtype=torch.float32, device=self.device)               # the reported loss
+        _lib.check(lib.dr4sr_cl_scalars(_lib.ptr(eng.grads[n:n + 2]), _lib.ptr(stats), float(self.config["model"]["cl_weight"]), None,
+                                        _lib.ptr(sc), _lib.cur_stream()), "dr4sr_cl_scalars")
         eng.adam_step(self._api_plan())
-        return loss
+        return sc[0]
+
+    def _cl_term(self, ids, lens, views=None, dp_counts=None, fold_loss=False):
+        """cl_weight * mean InfoNCE between two augmented views of the rows (cl4srec.py:52-55, data_augmentation.py:595-619), composed
+        from C-ABI calls without autograd: its gradient is ACCUMULATED into engine.grads scaled by cl_weight * n_valid / rows, so that
+        an optimizer (or a hyper-gradient probe) dividing the flat gradient by the tail's n_valid is left with exactly
+        cl_weight * d(mean InfoNCE).  The main pass must have left {n_valid, loss_sum} in the gradient tail.  Returns InfoNCE's
+        device stats {kept rows, sum of row losses}.
+
+        views: ((seq_i, len_i), (seq_j, len_j)) to encode instead of drawing new ones (MetaModel's hyper-gradient probes evaluate one
+        draw at several parameter points; tests).
+        dp_counts: data parallel — rows held by each rank for this global batch (parallel.shard_bounds).  InfoNCE's negatives are the
+        other rows of the BATCH ('batch_both'), so every rank all-gathers the pooled views (+ its n_valid, + the length-1 mask),
+        evaluates the loss of the GLOBAL batch and back-propagates the rows it owns: the sum over ranks of the local gradients is
+        the single-process gradient of the concatenated batch (tools/dp_cl_check.py; tests/test_host_cpu.py restates the scheme on
+        the oracle).  A rank with no rows still takes part in the gather.
+        fold_loss: also add the term's share cl_weight * mean InfoNCE * n_valid(local) to the tail's loss_sum (MetaModel / DP log the
+        step's loss as tail[1] / tail[0])."""
+        import os
+        from .. import _lib, parallel
+        eng, lib = self.engine, self.engine.lib
+        am = self.augmentation_model
+        aug = am.augmentation
+        B, D, dev, n = int(ids.shape[0]), eng.D, self.device, eng.n_params
+        st = _lib.cur_stream
+        clw, temp = float(self.config["model"]["cl_weight"]), float(am.InfoNCE_loss_fn.temperature)
+        tail = eng.grads[n:n + 2]
+        plans = ()
+        if B > 0:
+            if views is None:
+                if hasattr(aug, "begin_step"):
+                    aug.begin_step()
+                if hasattr(aug, "two_views"):
+                    (aug_i, len_i), (aug_j, len_j) = aug.two_views(ids, lens)
+                else:
+                    (aug_i, len_i), (aug_j, len_j) = aug(ids, lens), aug(ids, lens)
+            else:
+                (aug_i, len_i), (aug_j, len_j) = views
+            # The views are independent sequences through one encoder: by default they run as ONE batch of 2B sequences (the halves of
+            # two_views()' tensors are contiguous) — at these sizes a pass costs its launch chain, not its tokens, so one pass of 2B is
+            # ~1.15x a pass of B instead of 2x.  DR4SR_CL_TWO_PASS keeps one pass per view in slots 1 and 2: the dropout streams of the
+            # autograd body (the batched pass draws independent masks too, from one stream keyed by the row index in 2B).
+            batched = (2 * B <= eng.max_batch and aug_i.is_contiguous() and aug_j.is_contiguous() and len_i.is_contiguous()
+                       and aug_i.data_ptr() + aug_i.numel() * 8 == aug_j.data_ptr() and len_i.data_ptr() + len_i.numel() * 8 == len_j.data_ptr()
+                       and not os.environ.get("DR4SR_CL_TWO_PASS"))
+            # regime hint of the views' plans: crops are shorter than the rows they come from (engine.make_plan: expected_tokens)
+            fac = aug.expected_len_factor() if hasattr(aug, "expected_len_factor") else 1.0
+            exp_v = max(1, int(B * eng.mean_len * fac)) if eng.mean_len is not None else None
+            if batched:
+                ids2 = torch.as_strided(aug_i, (2 * B, aug_i.shape[1]), aug_i.stride())
+                len2 = torch.as_strided(len_i, (2 * B,), len_i.stride())
+                plans = (eng.make_plan(ids2, None, len2, slot=1, expected_tokens=None if exp_v is None else 2 * exp_v),)
+                q = eng.encode(plans[0], True, _lib.POOL_MEAN)
+                q_i, q_j = q[:B], q[B:]
+            else:
+                plans = (eng.make_plan(aug_i.contiguous(), None, len_i.contiguous(), slot=1, expected_tokens=exp_v),
+                         eng.make_plan(aug_j.contiguous(), None, len_j.contiguous(), slot=2, expected_tokens=exp_v))
+                q_i, q_j = eng.encode(plans[0], True, _lib.POOL_MEAN), eng.encode(plans[1], True, _lib.POOL_MEAN)
+            if views is None and hasattr(aug, "end_step"):
+                aug.end_step()
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        sc = torch.empty(1, dtype=torch.float32, device=dev)               # InfoNCE backward scale
+        if dp_counts is None:
+            valid = torch.empty(B, dtype=torch.uint8, device=dev)
+            lse, loss_row = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
+            dq = torch.empty(2, B, D, dtype=torch.float32, device=dev)
+            _lib.check(lib.dr4sr_cl_prepare(_lib.ptr(lens.contiguous()), B, _lib.ptr(valid), _lib.ptr(stats), _lib.ptr(dq), dq.numel(), st()),
+                       "dr4sr_cl_prepare")
+            _lib.check(lib.dr4sr_infonce_fwd(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(loss_row),
+                                             _lib.ptr(stats), st()), "dr4sr_infonce_fwd")
+            _lib.check(lib.dr4sr_cl_scalars_dp(_lib.ptr(tail), 1, 0, _lib.ptr(stats), clw, _lib.ptr(sc), _lib.ptr(tail) if fold_loss else None,
+                                               st()), "dr4sr_cl_scalars_dp")
+            _lib.check(lib.dr4sr_infonce_bwd(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(sc),
+                                             _lib.ptr(dq[0]), _lib.ptr(dq[1]), st()), "dr4sr_infonce_bwd")
+            dq_i, dq_j = dq[0], dq[1]
+        else:
+            # ---- the global batch: [W][Bmax rows of (q_i | q_j | kept) ... | n_valid]
+            W, r = len(dp_counts), self.rank
+            assert dp_counts[r] == B, (dp_counts, r, B)
+            Bmax, Bg, off = max(dp_counts), sum(dp_counts), sum(dp_counts[:r])
+            RW = 2 * D + 1
+            send = torch.zeros(Bmax * RW + 1, dtype=torch.float32, device=dev)
+            if B > 0:
+                rows = send[:Bmax * RW].view(Bmax, RW)
+                rows[:B, :D].copy_(q_i)
+                rows[:B, D:2 * D].copy_(q_j)
+                rows[:B, 2 * D].copy_(lens != 1)                           # data_augmentation.py:613-615
+            send[Bmax * RW:].copy_(tail[0:1])
+            got = parallel.all_gather_flat(send)                            # [W, Bmax * RW + 1]
+            parts = [got[k, :dp_counts[k] * RW].view(dp_counts[k], RW) for k in range(W) if dp_counts[k] > 0]
+            allr = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
+            xi, xj = allr[:, :D].contiguous(), allr[:, D:2 * D].contiguous()
+            valid = allr[:, 2 * D].to(torch.uint8).contiguous()
+            lse, loss_row = torch.empty(Bg, dtype=torch.float32, device=dev), torch.empty(Bg, dtype=torch.float32, device=dev)
+            dq = torch.zeros(2, Bg, D, dtype=torch.float32, device=dev)
+            stats.zero_()
+            _lib.check(lib.dr4sr_infonce_fwd(_lib.ptr(xi), _lib.ptr(xj), _lib.ptr(valid), Bg, D, temp, _lib.ptr(lse), _lib.ptr(loss_row),
+                                             _lib.ptr(stats), st()), "dr4sr_infonce_fwd")
+            _lib.check(lib.dr4sr_cl_scalars_dp(_lib.ptr(got[0, Bmax * RW:]), W, Bmax * RW + 1, _lib.ptr(stats), clw, _lib.ptr(sc),
+                                               _lib.ptr(tail) if fold_loss else None, st()), "dr4sr_cl_scalars_dp")
+            _lib.check(lib.dr4sr_infonce_bwd(_lib.ptr(xi), _lib.ptr(xj), _lib.ptr(valid), Bg, D, temp, _lib.ptr(lse), _lib.ptr(sc),
+                                             _lib.ptr(dq[0]), _lib.ptr(dq[1]), st()), "dr4sr_infonce_bwd")
+            dq_i, dq_j = dq[0, off:off + B], dq[1, off:off + B]
+        if B > 0:
+            if len(plans) == 1:
+                eng.encode_bwd(plans[0], True, _lib.POOL_MEAN, torch.cat([dq_i, dq_j], 0) if dp_counts is not None else dq.view(2 * B, D))
+            else:
+                eng.encode_bwd(plans[0], True, _lib.POOL_MEAN, dq_i.contiguous())
+                eng.encode_bwd(plans[1], True, _lib.POOL_MEAN, dq_j.contiguous())
+        return stats
+
+    # ---- data parallel (round 4): the fused main pass + the views' passes on this rank's slice of every global batch, the contrastive
+    # term over the gathered global batch (_cl_term), ONE sum-all-reduce of the flat gradient, dense Adam.  Eager launches (two
+    # collectives per step sit between them; the single-GPU path replays one graph per batch size).
+    def training_epoch(self, nepoch):
+        if self.world_size <= 1:
+            return super().training_epoch(nepoch)
+        from .. import parallel
+        from ..parallel import allreduce_flat, shard_bounds
+        if not self._direct_step_ok():
+            raise NotImplementedError("CL4SRec under data parallelism runs the directly composed step (BCE loss, DR4SR_CL_AUTOGRAD unset)")
+        loader = self.current_epoch_trainloaders(nepoch)
+        eng, W, r = self.engine, self.world_size, self.rank
+        B, n, nb = loader.batch_size, loader.n, len(loader)
+        perm = loader.permutation()
+        parallel.broadcast(perm, src=0)
+        losses = torch.empty(nb, dtype=torch.float32, device=self.device)
+        tail = eng.grads[eng.n_params:eng.n_params + 2]
+        keep = self._api_graph_fields()
+        for i in range(nb):
+            bounds = [shard_bounds(i, B, n, W, k) for k in range(W)]
+            lo, hi = bounds[r]
+            rows = perm[lo:hi]
+            batch = {k: v.index_select(0, rows) for k, v in loader.fields.items() if k in keep or k == self.fuid}
+            self._dp_step(batch, [b - a for a, b in bounds])
+            losses[i] = tail[1] / tail[0]
+        return [[{"loss_0": losses}]]
+
+    def _dp_step(self, batch, counts):
+        from ..parallel import allreduce_flat
+        eng = self.engine
+        ids, tgt, lens = batch["in_" + self.fiid], batch[self.fiid], batch["seqlen"]
+        if int(ids.shape[0]) > 0:
+            if "neg_item" not in batch:
+                batch["neg_item"] = self._neg_sampling(batch)
+            eng.fwd_bwd(eng.make_plan(ids, tgt, lens, neg_item=batch["neg_item"].contiguous().view(-1), sample_neg=False))
+        else:
+            eng.grads.zero_()
+        self._cl_term(ids, lens, views=batch.get("_views"), dp_counts=counts, fold_loss=True)
+        allreduce_flat(eng.grads)
+        eng.adam_step(self._api_plan())
 
     def training_step(self, batch, reduce=True, return_query=False, align=False):
         aug = self.augmentation_model.augmentation

@@ -144,11 +144,22 @@ class MetaModel(BaseModel):
             sub_cfg[sec].update(kv)
         self.logger.info(sub_cfg)
         name = sub_cfg["model"]["model"]
-        if name not in ("SASRec", "GRU4Rec", "FMLP"):
-            # the reference also accepts tuple-loss sub-models (metamodel.py:186-192: CL4SRec's (loss, cl_loss)); the weighted
-            # steps here back-propagate the BCE term only, so anything else would silently train a different objective
-            raise NotImplementedError(f"MetaModel sub_model {name!r}: the HIP path implements SASRec, GRU4Rec and FMLP sub-models")
+        if name not in ("SASRec", "GRU4Rec", "FMLP", "CL4SRec"):
+            # tuple-loss sub-models (metamodel.py:186-192) other than CL4SRec would silently train a different objective: the weighted
+            # steps here add CL4SRec's un-weighted contrastive term explicitly (_cl_extra)
+            raise NotImplementedError(f"MetaModel sub_model {name!r}: the HIP path implements SASRec, GRU4Rec, FMLP and CL4SRec sub-models")
         return get_model_class(name)(sub_cfg, self.dataset_list)
+
+    def _cl_sub(self) -> bool:
+        from .cl4srec import CL4SRec
+        return isinstance(self.sub_model, CL4SRec)
+
+    def _cl_extra(self, batch, views=None):
+        """metamodel.py:186-192, the tuple-loss branch: CL4SRec's contrastive rows enter the loss UN-weighted —
+        + cl_weight * sum_rows InfoNCE_row / kept rows.  Accumulated into the flat gradient behind the weighted BCE step (whose
+        {n_valid, weighted loss sum} tail scales it, CL4SRec._cl_term) and folded into the tail's loss."""
+        if self._cl_sub():
+            self.sub_model._cl_term(batch["in_" + self.fiid], batch["seqlen"], views=views, dp_counts=batch.get("_dp_counts"), fold_loss=True)
 
     def _register_meta_modules(self) -> nn.Module:
         D = self.embed_dim
@@ -222,10 +233,25 @@ class MetaModel(BaseModel):
 
     # ------------------------------------------------------------------------------------------ API path (autograd)
     def training_step(self, batch, reduce=True, return_query=True, align=False):
-        loss_value, query = self.sub_model.training_step(batch, reduce=False, return_query=True, align=False)
+        if self._cl_sub():
+            # metamodel.py:186-192: rst = (loss_value[0] * weight).sum() + loss_value[1].sum(), and the contrastive rows of
+            # reduce=False sum to cl_weight * the reduce=True loss (data_augmentation.py:349-353: cross_entropy(reduction='none') /
+            # batch_size) — taken in that form, whose backward the InfoNCE kernel implements
+            from .sasrec import SASRec
+            sub = self.sub_model
+            aug = sub.augmentation_model.augmentation
+            if hasattr(aug, "begin_step"):
+                aug.begin_step()
+            loss_value, query = SASRec.training_step(sub, batch, reduce=False, return_query=True)
+            cl = sub.config["model"]["cl_weight"] * sub.augmentation_model(batch, sub.query_encoder, reduce=True)["cl_loss"]
+            if hasattr(aug, "end_step"):
+                aug.end_step()
+        else:
+            loss_value, query = self.sub_model.training_step(batch, reduce=False, return_query=True, align=False)
+            cl = 0.0
         weight = _Select.apply(self, query, self._phi.params, batch["user_id"].contiguous(), batch[self.fiid].contiguous())
         self.counter += 1
-        return (loss_value * weight).sum()
+        return (loss_value * weight).sum() + cl
 
     # ------------------------------------------------------------------------------------------ fused weighted step
     def _weighted_fwd_bwd(self, batch, gate_in=None, gate_out=None):
@@ -255,6 +281,7 @@ class MetaModel(BaseModel):
         tail = eng.grads[eng.n_params:eng.n_params + 2]
         tail[0:1].copy_(self._stats[0:1])
         tail[1:2].copy_(torch.dot(w, lp).view(1))      # reported loss only
+        self._cl_extra(batch, views=batch.get("_views"))
         return w, lp
 
     def _phi_only(self, batch, gate_in):
@@ -279,10 +306,12 @@ class MetaModel(BaseModel):
         """SASRec sub-model with d = 64: the weighting runs inside the fused training step (dr4sr_sasrec_fwd_bwd_weighted)"""
         import os
         from .sasrec import SASRec
-        # exactly SASRec: a subclass with extra loss terms (CL4SRec's contrastive loss) must not take the plain weighted step
-        return type(self.sub_model) is SASRec and self.embed_dim == 64 and not os.environ.get("DR4SR_META_DENSE")
+        # exactly SASRec or CL4SRec (whose extra contrastive term _cl_extra adds behind the weighted step): any other subclass with
+        # extra loss terms must not take the plain weighted step
+        from .cl4srec import CL4SRec
+        return type(self.sub_model) in (SASRec, CL4SRec) and self.embed_dim == 64 and not os.environ.get("DR4SR_META_DENSE")
 
-    def _fused_weighted(self, batch, gate_in=None, gate_out=None, weight_out=None):
+    def _fused_weighted(self, batch, gate_in=None, gate_out=None, weight_out=None, with_cl=True):
         """un-normalised d/dW of sum_p weight_p loss_p through the 12-launch fused step (no d/dphi: see include/dr4sr_hip.h)"""
         eng = self.engine
         plan = self.sub_model._batch_plan(batch)
@@ -297,6 +326,8 @@ class MetaModel(BaseModel):
         mw.tau = self._tau_eff()
         _lib.check(self.lib.dr4sr_sasrec_fwd_bwd_weighted(C.byref(plan), C.byref(mw), _lib.cur_stream()), "dr4sr_sasrec_fwd_bwd_weighted")
         self._keep_mw = (uid, gate_in, gate_out, weight_out)
+        if with_cl:
+            self._cl_extra(batch, views=batch.get("_views"))
 
     def _reduce_grads(self):
         if self.world_size > 1:
@@ -308,6 +339,9 @@ class MetaModel(BaseModel):
         rows = perm[lo:hi]
         batch = {k: v.index_select(0, rows) for k, v in loader.fields.items()}
         batch["index"] = rows
+        if self.world_size > 1 and self._cl_sub():        # CL4SRec's in-batch negatives span the GLOBAL batch (CL4SRec._cl_term)
+            bs = [shard_bounds(i, loader.batch_size, loader.n, self.world_size, k) for k in range(self.world_size)]
+            batch["_dp_counts"] = [b - a for a, b in bs]
         return batch
 
     def _perm(self, loader):
@@ -325,7 +359,7 @@ class MetaModel(BaseModel):
             return out
         perm = self._perm(loader)
         nb = len(loader)
-        if self._fused_ok() and self.world_size == 1 and bool(self.config["train"].get("hip_graph", True)):
+        if self._fused_ok() and not self._cl_sub() and self.world_size == 1 and bool(self.config["train"].get("hip_graph", True)):
             return [[{"loss_0": self._fused_meta_epoch(loader, perm, nepoch)}]]
         losses = torch.empty(nb, dtype=torch.float32, device=self.device)
         for i in range(nb):
@@ -398,7 +432,8 @@ class MetaModel(BaseModel):
         """one post-warm-up iteration of metamodel.py:101-120: weighted step, sub-model Adam, outer loop on the interval"""
         sub, eng = self.sub_model, self.engine
         bl = int(batch["user_id"].shape[0])
-        if bl > 0 and bool(self.config["train"].get("hip_graph", True)):
+        cl_dp = self._cl_sub() and self.world_size > 1        # the contrastive term gathers the global batch inside the step: eager launches
+        if bl > 0 and bool(self.config["train"].get("hip_graph", True)) and not cl_dp:
             st, run = self._weighted_graph(batch)
             for k in self._STATIC_KEYS:                    # the only per-step host work: four small copies + one graph replay
                 st[k].copy_(batch[k])
@@ -413,6 +448,7 @@ class MetaModel(BaseModel):
             else:                                          # a rank whose slice of the tail batch is empty contributes zeros
                 eng.grads.zero_()
                 self._phi.grads.zero_()
+                self._cl_extra(batch)                      # (... and still takes part in the gather of the global batch)
             self._reduce_grads()
             eng.adam_step(sub._api_plan())
         self.counter += 1
@@ -448,7 +484,12 @@ class MetaModel(BaseModel):
 
         def adam():
             eng.adam_step(sub._api_plan())
-        undo = [eng.params, eng.adam_m, eng.adam_v, eng.state]
+        undo = [eng.params, eng.adam_m, eng.adam_v] + list(getattr(eng, "states", [eng.state]))
+        if self._cl_sub():                                 # the views' draws are keyed by a device counter the graph advances
+            aug = sub.augmentation_model.augmentation
+            if getattr(aug, "step_dev", None) is None:
+                sub._api_graph_begin()
+            undo.append(aug.step_dev)
         snap = [t.clone() for t in undo]
         fwd_bwd()                                          # warm-up outside capture (allocates the persistent scratch buffers);
         adam()                                             # no collective here: ranks build their graphs at different steps
@@ -500,6 +541,7 @@ class MetaModel(BaseModel):
         v, pacc, gp = self._buf("v", n), self._buf("pacc", n), self._buf("gp", n + _lib.GRAD_TAIL)
         # dL_val/dW: plain training_step on the meta batch (fresh dropout masks)                      utils.py:154-159
         eng.fwd_bwd(sub._batch_plan(bv))
+        self._cl_extra(bv, views=bv.get("_views"))          # CL4SRec sub-model: L_val = BCE + cl_weight * InfoNCE on fresh views
         if self.world_size > 1:
             allreduce_flat(eng.grads)
         _lib.check(lib.dr4sr_scale_by(_lib.ptr(v), _lib.ptr(eng.grads), _lib.ptr(eng.grads[n:n + 1]), n, st()), "scale_by")
@@ -515,13 +557,30 @@ class MetaModel(BaseModel):
         if fused:                                          # the same frozen pattern in the fused step's packed-token order
             gate_packed = self._buf("gate_packed", bt[self.fiid].numel(), torch.int64)
             eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0)
-            self._fused_weighted(bt, gate_out=gate_packed)
+            self._fused_weighted(bt, gate_out=gate_packed, with_cl=False)
+        rng_views = None
+        if self._cl_sub():
+            # ONE draw of the train batch's two views (and one set of dropout masks in the views' engine slots) for every evaluation
+            # of L_train: the reference differentiates one graph of loss_train twice (utils/utils.py:161-178)
+            bt = dict(bt)
+            if bt.get("_views") is None and int(bt["seqlen"].shape[0]) > 0:
+                aug = sub.augmentation_model.augmentation
+                if hasattr(aug, "begin_step"):
+                    aug.begin_step()
+                ids_t, len_t = bt["in_" + self.fiid].contiguous(), bt["seqlen"].contiguous()
+                bt["_views"] = aug.two_views(ids_t, len_t) if hasattr(aug, "two_views") else (aug(ids_t, len_t), aug(ids_t, len_t))
+                if hasattr(aug, "end_step"):
+                    aug.end_step()
+            rng_views = [s[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].clone() for s in eng.states[1:]]
 
         def probe(direction, sign, need_phi=False):
             """d/dW (and, for the two mixed-derivative probes, the deterministic d/dphi) of L_train at W0 + sign * e * direction"""
             _lib.check(lib.dr4sr_fd_shift(_lib.ptr(eng.params), _lib.ptr(theta0), _lib.ptr(direction), _lib.ptr(self._e), sign, n,
                                           st()), "fd_shift")
             eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0)
+            if rng_views is not None:
+                for s_, r_ in zip(eng.states[1:], rng_views):
+                    s_[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(r_)
             if need_phi:
                 self._phi_only(bt, gate)
             elif fused:
@@ -564,6 +623,9 @@ class MetaModel(BaseModel):
                                          _lib.ptr(eng.grads[n:n + 1]), _lib.ptr(self._e), -1.0, nphi, st()), "fd_diff")
         eng.params.copy_(theta0)
         eng.state[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(rng0 + 1)
+        if rng_views is not None:
+            for s_, r_ in zip(eng.states[1:], rng_views):
+                s_[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].copy_(r_ + 1)
         return hyper
 
     def hypergrad_step(self, bv, bt):

@@ -26,6 +26,11 @@ class _DeviceAugmentation(torch.nn.Module):
         self.step_dev = None        # int32[1] device copy of `calls` while a captured training step is being built / replayed
         self._in_step = 0
 
+    def expected_len_factor(self) -> float:
+        """mean view length / mean input length (regime hint of the views' encoder plans, engine.make_plan(expected_tokens=...)): a crop
+        keeps a tao share of a sequence, mask and reorder keep its length, 'random' draws the three uniformly"""
+        return {0: self.tao, 1: 1.0, 2: 1.0, 3: (self.tao + 2.0) / 3.0}[self.mode]
+
     def begin_step(self):
         """captured steps: call at the top of the step body; the k-th forward() of the step draws stream step_dev + k, and
         end_step() advances the device counter (all of it recorded into the graph)"""

@@ -85,6 +85,26 @@ def allreduce_flat(grads, group=None):
     return grads
 
 
+def all_gather_flat(t, group=None):
+    """every rank's equally sized flat buffer, as one [world, n] tensor on t's device (CL4SRec: the pooled views + n_valid of each
+    rank — InfoNCE's in-batch negatives are the GLOBAL batch)"""
+    import torch
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    if _staged(t):
+        h = t.cpu()
+        out = torch.empty(W, h.numel(), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h.view(1, -1), group=group) if dist.get_backend() == "nccl" else \
+            dist.all_gather(list(out.unbind(0)), h.view(-1), group=group)
+        return out.to(t.device)
+    out = torch.empty(W, t.numel(), dtype=t.dtype, device=t.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, t.view(1, -1), group=group)
+    else:
+        dist.all_gather(list(out.unbind(0)), t.view(-1), group=group)
+    return out
+
+
 def broadcast(t, src: int = 0, group=None):
     import torch.distributed as dist
     if _staged(t):

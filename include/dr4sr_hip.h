@@ -443,6 +443,13 @@ int dr4sr_cl_augment2_dev(const int64_t* seq, const int64_t* seqlen, int64_t* ou
  *     *loss_out = loss_sum / n_valid + cl_weight * stats[1] / rows;  either output may be NULL. */
 int dr4sr_cl_prepare(const int64_t* seqlen, int32_t B, uint8_t* valid, float* stats, float* zero, int64_t nzero, void* stream);
 int dr4sr_cl_scalars(const float* tail, const float* stats, float cl_weight, float* scale_out, float* loss_out, void* stream);
+/* the same when n_valid is spread over n_parts words nv_parts[r * stride] (data parallel: every rank's count, all-gathered next to its
+ * pooled views — InfoNCE's negatives are the GLOBAL batch; a single part = the local tail itself):
+ *   *scale_out = cl_weight * sum_r nv_parts[r * stride] / rows;
+ *   tail_local[1] += cl_weight * stats[1] / rows * tail_local[0]   (the contrastive term's share of the reported loss, so that the
+ *   all-reduced tail[1] / tail[0] = BCE mean + cl_weight * InfoNCE mean).  Either output may be NULL. */
+int dr4sr_cl_scalars_dp(const float* nv_parts, int32_t n_parts, int64_t stride, const float* stats, float cl_weight, float* scale_out,
+                        float* tail_local, void* stream);
 int dr4sr_infonce_fwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature, float* lse,
                       float* loss_row, float* stats, void* stream);
 int dr4sr_infonce_bwd(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,

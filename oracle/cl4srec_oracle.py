@@ -49,6 +49,19 @@ def training_loss(p, batch, views, cfg, reduce=True):
     return bce + cfg["cl_weight"] * cl, bce, cl, oi, oj
 
 
+def training_loss_q(p, batch, views, cfg, reduce=True):
+    """CL4SRec.training_step(return_query=True) (cl4srec.py:49-73): reduce=True -> (bce + cl_weight * InfoNCE, query); reduce=False ->
+    ((bce per position / n_valid, cl_weight * InfoNCE rows / kept rows), query) — the tuple MetaModel.training_step takes apart
+    (metamodel.py:186-192)"""
+    H, nl, eps = cfg["H"], cfg["n_layer"], cfg["eps"]
+    bce, q, _, _ = so.training_step(p, batch, H, nl, eps, reduce=reduce)
+    (vi, li), (vj, lj) = views
+    oi, oj = view_mean(p, vi, li, H, nl, eps), view_mean(p, vj, lj, H, nl, eps)
+    keep = batch["seqlen"] != 1
+    cl = cfg["cl_weight"] * infonce(oi[keep], oj[keep], cfg["temperature"], reduce)
+    return (bce + cl if reduce else (bce, cl)), q
+
+
 # ---- reference-style augmentations (plain Python), for distribution tests of dr4sr_cl_augment
 def crop_len(n, tau):
     return max(1, int(tau * n))

@@ -4,7 +4,7 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 
-Pinned against tests/golden/metamodel_sasrec.npz (made by RUNNING the reference: tools/make_golden.py
+Pinned against tests/golden/metamodel_sasrec.npz and metamodel_cl4srec.npz (made by RUNNING the reference: tools/make_golden.py
 run_meta_case) by tests/test_meta_oracle.py.  The hyper-gradient here is the reference's exact one (torch
 double-backward through the op-by-op SASRec restatement in sasrec_oracle.py); `hypergrad_fd` is the
 finite-difference formulation the HIP product path uses, kept next to it so their distance can be tested on CPU.
@@ -78,9 +78,22 @@ def fmlp_losses(n_layer: int, eps: float = 1e-12) -> Callable:
     return f
 
 
+def cl4srec_losses(cfg) -> Callable:
+    """f(p, batch, reduce) for a CL4SRec sub-model (model/cl4srec.py:49-73, dropout 0) on RECORDED views batch['_views'] =
+    ((seq_i, len_i), (seq_j, len_j)); reduce=False returns the tuple (bce per position, cl_weight * InfoNCE rows)"""
+    from . import cl4srec_oracle as co
+
+    def f(p, batch, reduce):
+        return co.training_loss_q(p, batch, batch["_views"], cfg, reduce=reduce)
+    return f
+
+
 def train_loss(f, p, meta, bt, gumbel, tau, tau_min, relu_gate=None):
     lp, q = f(p, bt, False)
-    return weighted_loss(lp, q, meta, gumbel, tau, tau_min, bt["user_id"], bt["item_id"], relu_gate)[0]
+    extra = 0.0
+    if isinstance(lp, tuple):                                      # metamodel.py:186-192: CL4SRec's contrastive rows stay un-weighted
+        lp, extra = lp[0], lp[1].sum()
+    return weighted_loss(lp, q, meta, gumbel, tau, tau_min, bt["user_id"], bt["item_id"], relu_gate)[0] + extra
 
 
 def relu_gate_of(f, p, meta, bt):

@@ -279,14 +279,17 @@ def test_data_parallel_ranks_equal_single_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["GRU4Rec", "FMLP", "MetaModel", "SASRec-d128"])
+@pytest.mark.parametrize("model_name", ["GRU4Rec", "FMLP", "MetaModel", "SASRec-d128", "CL4SRec", "MetaModel-CL4SRec"])
 def test_data_parallel_fit_other_models(tmp_path, model_name):
     """the same end-to-end run (quickstart.run under 2 ranks sharing the GPU, uneven tail batch) for the other DP-capable models:
     GRU4Rec / FMLP step through their engines' two-graph form, MetaModel all-reduces both flat buffers and runs its outer loop;
+    CL4SRec (round 4) all-gathers the pooled views of the global batch inside the step (CL4SRec._cl_term);
     SASRec at d = 128 (BASELINE configs[3]'s width: DR4SR_EMBED_DIM, the override utils/config.py:load_config honours)"""
     extra = {}
     if model_name == "SASRec-d128":
         model_name, extra = "SASRec", {"DR4SR_EMBED_DIM": "128"}
+    if model_name == "MetaModel-CL4SRec":                 # round 4: the tuple-loss sub-model, its contrastive term over the gathered global batch
+        model_name, extra = "MetaModel", {"SUB_MODEL": "CL4SRec"}
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

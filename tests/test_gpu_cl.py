@@ -253,3 +253,21 @@ def test_two_views_in_one_launch_equal_two_calls(cls, kw):
     assert not torch.equal(v1, v2) or cls == "Item_Reorder"             # two different draws (a reorder of tiny segments may coincide)
     a.end_step(); b.end_step()
     assert int(a.step_dev) == int(b.step_dev) == 9
+
+
+@pytest.mark.parametrize("tail", [20, 37])
+def test_cl4srec_data_parallel_equals_single_process(tail):
+    """round 4: CL4SRec under DP.  InfoNCE's negatives are the other rows of the BATCH, so the ranks all-gather their
+    pooled views (+ n_valid + the length-1 mask), evaluate the loss of the GLOBAL batch and back-propagate their own rows
+    (CL4SRec._cl_term); 2 ranks sharing the GPU over the gloo transport == one process on the concatenated batches, same negatives,
+    same views (tools/dp_cl_check.py).  tail = rows of the ragged last batch: 20 -> slices of 20 and 0 (an empty rank still takes
+    part in the gather), 37 -> 32 and 5."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29551 + tail), os.path.join(ROOT, "tools", "dp_cl_check.py")], capture_output=True, text=True,
+                         timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_CL_TAIL=str(tail)), cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CL_CHECK")]
+    assert out.returncode == 0 and len(lines) == 2, out.stdout[-2500:] + out.stderr[-2500:]
+    print(lines[0])
+    assert "replica checksums equal: True" in lines[1]

@@ -212,7 +212,95 @@ def test_hypergradient_and_meta_sgd_match_reference(golden_dir, monkeypatch):
             np.testing.assert_allclose(p.detach().cpu().numpy(), z[f"outer.step{s}.{k}"], rtol=2e-5, atol=3e-7)
 
 
-@pytest.mark.parametrize("sub", ["SASRec", "GRU4Rec", "FMLP"])
+def load_golden_cl(golden_dir, model):
+    z = np.load(os.path.join(golden_dir, "metamodel_cl4srec.npz"))
+    sub_sd = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    model.sub_model.load_state_dict(sub_sd, strict=True)
+    model.meta_module.load_state_dict({k[11:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("meta_param.")}, strict=True)
+    dev = model.device
+    bt = {k[6:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("train.")}
+    bv = {k[4:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("val.")}
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    bt["_views"] = ((t("view.train.i"), t("view.train.i_len")), (t("view.train.j"), t("view.train.j_len")))
+    bv["_views"] = ((t("view.val.i"), t("view.val.i_len")), (t("view.val.j"), t("view.val.j_len")))
+    model._gumbel = torch.from_numpy(z["inner.gumbel"]).to(dev).reshape(-1, 2).contiguous()
+    return z, bt, bv
+
+
+def test_cl4srec_sub_model_matches_reference(golden_dir, monkeypatch):
+    """round 4: MetaModel over a TUPLE-loss sub-model, metamodel.py:186-192 — weighted BCE + un-weighted
+    cl_weight * InfoNCE.  Golden vectors from RUNNING the reference's MetaModel(CL4SRec) with its drawn views recorded
+    (tools/make_golden.py run_meta_case): the weighted inner step in the fused, the dense and the autograd form, dL_val/dW, the
+    finite-difference hyper-gradient against the reference's double backward, and two MetaOptimizer steps."""
+    z = np.load(os.path.join(golden_dir, "metamodel_cl4srec.npz"))
+    assert str(z["meta.sub_model"]) == "CL4SRec"
+    ds, model = build(make_config(int(z["meta.num_items"]), sub="CL4SRec"), monkeypatch)
+    z, bt, bv = load_golden_cl(golden_dir, model)
+    model.train()
+    sub, eng = model.sub_model, model.engine
+    assert model._cl_sub() and model._fused_ok()
+    n = eng.n_params
+    # ---- fused weighted step + the contrastive term on the recorded views
+    model._fused_weighted(bt)
+    nv = float(eng.grads[n])
+    assert nv == float((bt["item_id"] != 0).sum())
+    assert abs(float(eng.grads[n + 1]) / nv - float(z["inner.loss"])) < 5e-6 * max(1.0, abs(float(z["inner.loss"])))
+    for k, p in sub.named_parameters():
+        ref = z["inner.grad." + k]
+        assert rel((p.grad / nv).cpu().numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-7, k
+    # ---- dense C-ABI composition: the same, plus d/dphi
+    model._weighted_fwd_bwd(bt)
+    assert abs(float(eng.grads[n + 1]) / nv - float(z["inner.loss"])) < 5e-6 * max(1.0, abs(float(z["inner.loss"])))
+    for k, p in sub.named_parameters():
+        ref = z["inner.grad." + k]
+        assert rel((p.grad / nv).cpu().numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-7, k
+    for k, p in model.meta_module.named_parameters():
+        assert rel((p.grad / nv).cpu().numpy(), z["inner.meta_grad." + k]) < 3e-4, k
+    # ---- API path (autograd over the C ABI), the reference's loop body: loss = model.training_step(batch); loss.backward()
+    views = [bt["_views"][0], bt["_views"][1]]
+
+    class Replay(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.k = 0
+
+        def forward(self, sequences, seq_lens):
+            v = views[self.k % 2]
+            self.k += 1
+            return v[0], v[1]
+    real_aug = sub.augmentation_model.augmentation
+    sub.augmentation_model.augmentation = Replay()
+    sub.optimizer.zero_grad()
+    model.meta_optimizer.zero_grad()
+    loss = model.training_step(batch={k: v for k, v in bt.items() if k != "_views"}, align=False)
+    loss.backward()
+    sub.augmentation_model.augmentation = real_aug
+    assert abs(float(loss) - float(z["inner.loss"])) < 5e-6 * max(1.0, abs(float(z["inner.loss"])))
+    for k, p in sub.named_parameters():
+        ref = z["inner.grad." + k]
+        assert rel(p.grad.cpu().numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-7, k
+    # ---- outer step: dL_val/dW (BCE + cl_weight * InfoNCE on the meta batch's views), hyper-gradient, MetaOptimizer
+    eng.fwd_bwd(sub._batch_plan(bv))
+    model._cl_extra(bv, views=bv["_views"])
+    nvv = float(eng.grads[n])
+    assert abs(float(eng.grads[n + 1]) / nvv - float(z["outer.val_loss"])) < 5e-6 * max(1.0, abs(float(z["outer.val_loss"])))
+    for k, p in sub.named_parameters():
+        ref = z["outer.grad_val." + k]
+        assert rel((p.grad / nvv).cpu().numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-7, k
+    theta = eng.params.clone()
+    hyper = model.hypergrad(bv, bt)
+    assert torch.equal(theta, eng.params)
+    ref = np.concatenate([z["outer.hypergrad." + k].ravel() for k in NAMES])
+    err = rel(hyper.cpu().numpy(), ref)
+    print("MetaModel(CL4SRec) hyper-gradient rel. error vs reference double-backward:", err)
+    assert err < 1e-3, err
+    for s in (1, 2):
+        model.hypergrad_step(bv, bt)
+        for k, p in model.meta_module.named_parameters():
+            np.testing.assert_allclose(p.detach().cpu().numpy(), z[f"outer.step{s}.{k}"], rtol=2e-5, atol=3e-7)
+
+
+@pytest.mark.parametrize("sub", ["SASRec", "GRU4Rec", "FMLP", "CL4SRec"])
 def test_metamodel_fit_end_to_end(tmp_path, monkeypatch, sub):
     """warm-up epoch (plain sub-model steps) then weighted epochs with an outer loop every 2 steps, then evaluate()"""
     monkeypatch.chdir(tmp_path)

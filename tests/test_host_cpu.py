@@ -305,6 +305,77 @@ def test_data_parallel_math_gloo_world2(golden_dir):
         assert np.abs(got - ref).max() <= 2e-4 * max(1e-8, np.abs(ref).max()), k
 
 
+def _dp_cl_worker(rank, world, port, golden_dir, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from oracle import cl4srec_oracle as CO, sasrec_oracle as O
+    from dr4sr_amd.parallel import all_gather_flat, allreduce_flat, shard_bounds
+    from tests.test_cl_oracle import load_cl
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g, p, batch, views, cfg = load_cl(golden_dir)
+    B, D = batch["seqlen"].shape[0], p["item_embedding.weight"].shape[1]
+    bounds = [shard_bounds(0, B, B, world, k) for k in range(world)]
+    counts = [b - a for a, b in bounds]
+    lo, hi = bounds[rank]
+    sl = {k: v[lo:hi] for k, v in batch.items()}
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    bce, _, _, _ = O.training_step(leaf, sl, cfg["H"], cfg["n_layer"], cfg["eps"])
+    n_local = (sl["item_id"] != 0).sum()
+    (vi, li), (vj, lj) = views
+    oi = CO.view_mean(leaf, vi[lo:hi], li[lo:hi], cfg["H"], cfg["n_layer"], cfg["eps"])
+    oj = CO.view_mean(leaf, vj[lo:hi], lj[lo:hi], cfg["H"], cfg["n_layer"], cfg["eps"])
+    # the scheme of CL4SRec._cl_term: [Bmax rows of (q_i | q_j | kept)] + n_valid, all-gathered; own rows keep their graph
+    Bmax, RW = max(counts), 2 * D + 1
+    send = torch.zeros(Bmax * RW + 1)
+    rows = send[:Bmax * RW].view(Bmax, RW)
+    rows[:hi - lo, :D], rows[:hi - lo, D:2 * D], rows[:hi - lo, 2 * D] = oi.detach(), oj.detach(), (sl["seqlen"] != 1).float()
+    send[-1] = float(n_local)
+    got = all_gather_flat(send)
+    parts = [got[k, :counts[k] * RW].view(counts[k], RW) for k in range(world)]
+    xi = torch.cat([oi if k == rank else parts[k][:, :D] for k in range(world)], 0)
+    xj = torch.cat([oj if k == rank else parts[k][:, D:2 * D] for k in range(world)], 0)
+    keep = torch.cat([pt[:, 2 * D] for pt in parts], 0) > 0
+    nv_glob = got[:, -1].sum()
+    cl = CO.infonce(xi[keep], xj[keep], cfg["temperature"])
+    # un-normalised local objective: sum of the local BCE terms + the contrastive mean under the optimizer's 1 / n_valid(global)
+    (bce * n_local + cfg["cl_weight"] * nv_glob * cl).backward()
+    names = sorted(leaf)
+    flat = torch.cat([(leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])).flatten() for k in names]
+                     + [torch.tensor([float(n_local), float(bce * n_local + cfg["cl_weight"] * cl * n_local), 0, 0])])
+    allreduce_flat(flat)
+    if rank == 0:
+        q.put((names, flat.numpy()))
+    dist.destroy_process_group()
+
+
+def test_cl4srec_data_parallel_scheme_gloo_world2(golden_dir):
+    """CL4SRec under DP (round 4): InfoNCE's negatives are the other rows of the GLOBAL batch.  Every rank all-gathers the pooled views
+    (parallel.all_gather_flat), evaluates the global loss with the other ranks' rows as constants and back-propagates its own rows; the
+    sum-all-reduce of those local gradients (scaled cl_weight * n_valid(global), as the optimizer divides by the all-reduced n_valid)
+    == the reference's single-process gradient of the whole batch (golden vectors of tests/golden/cl4srec_d64.npz)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_cl_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    names, flat = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    z = np.load(os.path.join(golden_dir, "cl4srec_d64.npz"))
+    n = flat[-4]
+    assert n == (z["batch.item_id"] != 0).sum()
+    np.testing.assert_allclose(flat[-3] / n, float(z["out.loss"]), rtol=1e-5)
+    o = 0
+    for k in names:
+        ref = z["grad." + k]
+        got = flat[o:o + ref.size].reshape(ref.shape) / n
+        o += ref.size
+        assert np.abs(got - ref).max() <= 2e-4 * max(1e-8, np.abs(ref).max()), k
+
+
 def test_torch_ops_are_registered_with_schemas_and_fake_kernels():
     """dr4sr_amd/ops.py: the dense C-ABI entry points are dispatcher ops (torch.ops.dr4sr_hip.*) with schemas and shape-inference
     (fake) kernels — checkable without a GPU; the real kernels refuse CPU tensors (no CPU path)"""

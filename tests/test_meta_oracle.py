@@ -81,3 +81,45 @@ def test_first_order_formulation_matches_exact(golden_dir, rel_step):
     err = rel(flat({k: v.numpy() for k, v in hg.items()}), ref)
     print("rel_step", rel_step, "hypergrad rel err", err)
     assert err < 3e-4, err
+
+
+# ------------------------------------------------------------------------------------------------ CL4SRec sub-model (round 4)
+def load_meta_cl(golden_dir):
+    g, p, meta, bt, bv, cfg = load_meta(golden_dir, "metamodel_cl4srec")
+    cfg.update(temperature=float(g["meta.temperature"]), cl_weight=float(g["meta.cl_weight"]))
+    t = lambda k: torch.from_numpy(g[k])
+    bt["_views"] = ((t("view.train.i"), t("view.train.i_len")), (t("view.train.j"), t("view.train.j_len")))
+    bv["_views"] = ((t("view.val.i"), t("view.val.i_len")), (t("view.val.j"), t("view.val.j_len")))
+    return g, p, meta, bt, bv, cfg
+
+
+def test_cl4srec_sub_model_weighted_step_and_hypergradient(golden_dir):
+    """MetaModel over a tuple-loss sub-model (metamodel.py:186-192): weighted BCE + UN-weighted cl_weight * InfoNCE, the views the
+    reference drew recorded; inner loss / gradients, dL_val/dW, the double-backward hyper-gradient, and its first-order form"""
+    g, p, meta, bt, bv, cfg = load_meta_cl(golden_dir)
+    f = MO.cl4srec_losses(cfg)
+    gum = torch.from_numpy(g["inner.gumbel"])
+    tau, tmin, hlr = float(g["meta.tau"][0]), float(g["meta.tau_min"]), float(g["meta.hpo_learning_rate"])
+    P = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    M = {k: v.clone().requires_grad_(True) for k, v in meta.items()}
+    (lp, cl_rows), q = f(P, bt, False)
+    np.testing.assert_allclose(lp.detach().numpy(), g["inner.loss_pos"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(cl_rows.detach().numpy(), g["inner.cl_rows"], rtol=2e-5, atol=1e-7)
+    loss = MO.train_loss(f, P, M, bt, gum, tau, tmin)
+    np.testing.assert_allclose(float(loss), float(g["inner.loss"]), rtol=3e-6)
+    loss.backward()
+    for k, v in P.items():
+        assert rel(v.grad.numpy() if v.grad is not None else np.zeros(v.shape), g["inner.grad." + k]) < 2e-4 \
+            or np.abs(g["inner.grad." + k]).max() < 1e-7, k
+    for k, v in M.items():
+        assert rel(v.grad.numpy(), g["inner.meta_grad." + k]) < 2e-4, k
+    hg, gval, _ = MO.hypergrad_exact(f, p, meta, bt, bv, gum, tau, tmin, hlr)
+    for k, v in gval.items():
+        assert rel(v.numpy(), g["outer.grad_val." + k]) < 2e-4 or np.abs(g["outer.grad_val." + k]).max() < 1e-7, k
+    flat = lambda d: np.concatenate([np.asarray(d[k]).ravel() for k in MO.META_NAMES])
+    ref = np.concatenate([g["outer.hypergrad." + k].ravel() for k in MO.META_NAMES])
+    assert rel(flat({k: v.numpy() for k, v in hg.items()}), ref) < 5e-4
+    hf, _, _ = MO.hypergrad_fd(f, p, meta, bt, bv, gum, tau, tmin, hlr, rel_step=5e-4, richardson=True)
+    err = rel(flat({k: v.numpy() for k, v in hf.items()}), ref)
+    print("CL4SRec sub-model: first-order hyper-gradient rel err", err)
+    assert err < 1e-3, err

@@ -22,7 +22,7 @@ MODEL = os.environ.get("MODEL", "SASRec")
 cfg = load_config({"model": MODEL, "dataset": "synthetic-toys"})
 cfg["data"].update({"n_items": 300, "n_rows": 1000 + 37, "n_eval_rows": 256, "seed": 5})
 if MODEL == "MetaModel":
-    cfg["model"]["sub_model"] = "SASRec"                  # BASELINE configs[4]; configs/metamodel.yaml's default sub-model is FMLP (prefix rows)
+    cfg["model"]["sub_model"] = os.environ.get("SUB_MODEL", "SASRec")      # BASELINE configs[4]; configs/metamodel.yaml's default sub-model is FMLP (prefix rows)
 if MODEL == "FMLP":
     cfg["data"]["prefix_rows"] = True                     # one query per row: left-padded prefixes with scalar targets (model/fmlp.py:38)
 cfg["model"]["dropout_rate"] = 0.2

@@ -334,6 +334,31 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed, real=False):
             for m in sub.modules():
                 if isinstance(m, torch.nn.Dropout):
                     m.p = 0.0
+        replay = None
+        if sub_model == "CL4SRec":
+            # the augmentations draw from torch / numpy / random streams: every evaluation of a batch must see the SAME two views (the
+            # reference builds loss_train once and differentiates that one graph twice; this script evaluates it several times), so the
+            # first draw per batch is recorded and replayed — and stored, like run_cl_case's views
+            import random
+            random.seed(seed + 5)
+            np.random.seed(seed + 5)
+            real_aug = sub.augmentation_model.augmentation
+
+            class ReplayAug(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.store, self.mode, self.k = {}, "train", 0
+
+                def forward(self, sequences, seq_lens):
+                    lst = self.store.setdefault(self.mode, [])
+                    i = self.k % 2
+                    self.k += 1
+                    if len(lst) <= i:
+                        sq, ln = real_aug(sequences, seq_lens)
+                        lst.append((sq.clone(), ln.clone()))
+                    return lst[i][0].clone(), lst[i][1].clone()
+            replay = ReplayAug()
+            sub.augmentation_model.augmentation = replay
         g = torch.Generator().manual_seed(seed + 1)
         if real:
             ck = torch.load(os.path.join(TOYS_DIR, "pre-trained_embedding.ckpt"), weights_only=False, map_location="cpu")
@@ -372,6 +397,12 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed, real=False):
             torch.manual_seed(s)
             return -torch.empty(shape).exponential_().log()
 
+        if replay is not None:                                      # draw both batches' views now: the first draw consumes torch's RNG
+            with torch.no_grad():                                   # stream, which the Gumbel noise below is pinned on
+                replay.mode = "val"
+                sub.training_step(batch=bv, align=False)
+                replay.mode = "train"
+                sub.training_step(batch=bt, align=False)
         # ---- inner (weighted) step: metamodel.py:174-194 -----------------------------------------
         sub.optimizer.zero_grad()
         torch.manual_seed(seed + 3)
@@ -389,7 +420,12 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed, real=False):
             assert torch.equal(w, w_ref), "stored Gumbel noise does not reproduce the reference's weights"
             wm = w.masked_fill((bt["user_id"] == 0).unsqueeze(-1) if w.dim() == 2 else (bt["user_id"] == 0), 1.0)
             wm = wm.masked_fill(bt["item_id"] == 0, 0.0)
-            assert torch.allclose((lv * wm).sum(), loss.detach(), rtol=1e-6, atol=1e-7)
+            if isinstance(lv, tuple):                               # CL4SRec sub-model (metamodel.py:186-192): un-weighted contrastive rows
+                out["inner.cl_rows"] = lv[1].numpy()
+                assert torch.allclose((lv[0] * wm).sum() + lv[1].sum(), loss.detach(), rtol=1e-6, atol=1e-7)
+                lv = lv[0]
+            else:
+                assert torch.allclose((lv * wm).sum(), loss.detach(), rtol=1e-6, atol=1e-7)
         out["inner.gumbel"] = gn.numpy()
         out["inner.query"] = query.numpy()
         out["inner.loss_pos"] = lv.numpy()
@@ -415,7 +451,11 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed, real=False):
         ctx.__enter__()
 
         def losses():
+            if replay is not None:
+                replay.mode = "val"
             meta_loss = sub.training_step(batch=bv, align=False)
+            if replay is not None:
+                replay.mode = "train"
             torch.manual_seed(seed + 3)
             meta_train_loss = model.training_step(batch=bt, align=False)
             return meta_loss, meta_train_loss
@@ -448,6 +488,18 @@ def run_meta_case(out_dir, name, sub_model, n_items, seqlens, seed, real=False):
         for k in ("head_num", "hidden_size", "layer_num"):
             out["meta." + k] = np.int64(smc.get(k, 0))
         out["meta.layer_norm_eps"] = np.float64(smc.get("layer_norm_eps", 1e-12))
+        if replay is not None:
+            for k in ("temperature", "cl_weight"):
+                out["meta." + k] = np.float64(smc[k])
+            for k in ("tau", "gamma", "beta"):                       # ('meta.tau' is the MetaModel's Gumbel temperature)
+                out["meta.aug_" + k] = np.float64(smc[k])
+            out["meta.augment_type"] = np.array(smc["augment_type"])
+            for mode, lst in replay.store.items():
+                assert len(lst) == 2, (mode, len(lst))
+                for tag, (sq, ln) in zip("ij", lst):
+                    full = torch.zeros(sq.shape[0], L, dtype=sq.dtype)
+                    full[:, :sq.shape[1]] = sq                        # Item_Crop pads to the longest crop only
+                    out[f"view.{mode}.{tag}"], out[f"view.{mode}.{tag}_len"] = full.numpy(), ln.numpy()
         os.chdir(cwd)
         path = os.path.join(out_dir, name + ".npz")
         np.savez_compressed(path, **out)
@@ -801,6 +853,9 @@ def main():
     if only == "meta":
         run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
         return
+    if only == "meta_cl":
+        run_meta_case(out_dir, "metamodel_cl4srec", "CL4SRec", n_items=137, seqlens=seqlens, seed=23)
+        return
     if only == "trained":
         run_trained_case(out_dir)
         return
@@ -822,6 +877,7 @@ def main():
     loss_module_vectors(out_dir)
     run_trained_case(out_dir)
     run_meta_case(out_dir, "metamodel_trained_toys", "SASRec", n_items=None, seqlens=None, seed=22, real=True)
+    run_meta_case(out_dir, "metamodel_cl4srec", "CL4SRec", n_items=137, seqlens=seqlens, seed=23)
 
 
 if __name__ == "__main__":
