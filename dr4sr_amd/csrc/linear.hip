@@ -1101,9 +1101,9 @@ int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int trainin
         S.phi = mw->phi; S.gumbel = mw->gumbel; S.user_id = mw->user_id; S.gate_in = (const unsigned long long*)mw->gate_in;
         S.gate_out = (unsigned long long*)mw->gate_out; S.w_out = mw->weight_out; S.inv_tau = 1.0f / mw->tau;
     }
-    if (wt_mid(p, ws, mw != nullptr)) {                 // the wave-tile backward half recomputes the linear1 pre-activations: not stored
+    if (wt_mid(p, ws, mw != nullptr)) {                 // DR4SR_WT_RECOMPUTE_A: the backward half recomputes the linear1 pre-activations
         PostArgs Aw = A;
-        if (!DR4SR_ENV("DR4SR_WT_SAVE_A")) Aw.a = nullptr;
+        if (DR4SR_ENV("DR4SR_WT_RECOMPUTE_A")) Aw.a = nullptr;
         return launch_wt_post_mid(Aw, S, ws.Tmax, s);
     }
     const int bm = tile_rows(ws);
@@ -1112,9 +1112,9 @@ int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int trainin
 int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     PostArgs A = make_post_args(p, ws, layer, training);
     if (wave_tiles(p, ws) && !A.stamps) {
-        // the linear1 pre-activations are saved only for a 256-thread backward (last layer of the API path, DR4SR_WT_FWD_ONLY): the
-        // wave-tile backward recomputes them from y (linear_wave.hip wt_bwd_tile)
-        if (wt_bwd_on() && layer + 1 < p->n_layer && !DR4SR_ENV("DR4SR_WT_SAVE_A")) A.a = nullptr;
+        // DR4SR_WT_RECOMPUTE_A (round 4, measured slower, opt-in: linear_wave.hip wt_bwd_tile): the forward does not store the linear1
+        // pre-activations for a wave-tile backward, which recomputes them from y
+        if (wt_bwd_on() && layer + 1 < p->n_layer && DR4SR_ENV("DR4SR_WT_RECOMPUTE_A")) A.a = nullptr;
         return launch_wt_post_fwd(A, ws.Tmax, s);
     }
     const int bm = tile_rows(ws);
@@ -1123,7 +1123,7 @@ int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, 
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     PostArgs A = make_post_args(p, ws, layer, training);
     if (wave_tiles(p, ws) && wt_bwd_on() && layer + 1 < p->n_layer) {
-        if (!DR4SR_ENV("DR4SR_WT_SAVE_A")) A.a = nullptr;          // recompute a = y W1^T + b1 (the forward did not store it)
+        if (DR4SR_ENV("DR4SR_WT_RECOMPUTE_A")) A.a = nullptr;          // recompute a = y W1^T + b1 (the forward did not store it)
         return launch_wt_post_bwd(A, ws.Tmax, s);
     }
     const int bm = tile_rows(ws);

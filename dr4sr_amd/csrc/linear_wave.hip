@@ -352,7 +352,7 @@ __device__ __forceinline__ void wt_fwd_tile(const PostArgs& A, const char* lds, 
             wt_row_load<F>(bias, vec + Lds::v_b1, g);
 #pragma unroll
             for (int j = 0; j < FT; ++j) h[j] += bias[j];
-            if (ok && A.a) wt_row_store_nt<F>(A.a + (size_t)t * F, h, g);        // (NULL when the wave-tile backward follows: it recomputes a)
+            if (ok && A.a) wt_row_store_nt<F>(A.a + (size_t)t * F, h, g);        // (NULL under DR4SR_WT_RECOMPUTE_A: the backward recomputes a)
 #pragma unroll
             for (int j = 0; j < FT; ++j) h[j] = (f32x4){gelu_erf(h[j][0]), gelu_erf(h[j][1]), gelu_erf(h[j][2]), gelu_erf(h[j][3])};
             if (actdrop) wt_row_drop<F>(h, rk, sA, (uint64_t)t * F, g);
@@ -482,13 +482,17 @@ __device__ __forceinline__ void wt_bwd_tile(const PostArgs& A, const char* lds, 
         wt_gemm_xw<D, F>(lds + Lds::o_w2, df, da);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- da = dh * mask_act * gelu'(a).  a = y W1^T + b1 is RECOMPUTED from the saved LayerNorm1 output (round 4): the forward no
-    // longer writes the [T, F] pre-activations (512 B per token and layer) and this pass reads 256 B of y instead of 512 B of a, for one
-    // more 16 x 64 x 128 GEMM on an image that is in LDS anyway — the kernels are HBM-bound at scale.  Same MFMA sequence
-    // as the forward's: bit-identical a when the forward ran the fp32 form.
+    // ---- da = dh * mask_act * gelu'(a).  A.a == NULL (DR4SR_WT_RECOMPUTE_A, round 4 — the review's "recompute instead of store"):
+    // a = y W1^T + b1 is recomputed from the saved LayerNorm1 output (the forward then does not write the [T, F] pre-activations, 512 B
+    // per token and layer, and this pass reads 256 B of y instead of 512 B of a) by the forward's own MFMA sequence on the image that is
+    // in LDS anyway.  MEASURED, same box, dense B = 8 192 / toys B = 131 072 / toys B = 8 192: k_wt_post_fwd 403 -> 377 / 686 -> 645 /
+    // 51 -> 51 us, k_wt_post_bwd 427 -> 463 / 732 -> 798 / 52 -> 58 us, k_wt_post_mid 667 -> 677 / 1297 -> 1326 / 102 -> 105 us; step
+    // 3.32 -> 3.34 / 5.86 -> 5.93 / 0.516 -> 0.520 ms.  The backward pays more for 64 more fp32 MFMAs per tile (they share the SIMD's
+    // datapath with its VALU work, NOTEBOOK) than the forward gains from 15 % fewer bytes: the kernels sit where the HBM stream and
+    // the fp32 datapath are both nearly full, so the saved pre-activations stay (default).
     {
         f32x4 av[FT];
-        if (A.a) {                                          // (DR4SR_WT_SAVE_A: the stored pre-activations, round 3's form)
+        if (A.a) {
             wt_row_load<F>(av, A.a + tl * F, g);
         } else {
             f32x4 yv[DT];

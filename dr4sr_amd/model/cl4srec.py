@@ -112,9 +112,10 @@ class CL4SRec(SASRec):
             # two_views()' tensors are contiguous) — at these sizes a pass costs its launch chain, not its tokens, so one pass of 2B is
             # ~1.15x a pass of B instead of 2x.  DR4SR_CL_TWO_PASS keeps one pass per view in slots 1 and 2: the dropout streams of the
             # autograd body (the batched pass draws independent masks too, from one stream keyed by the row index in 2B).
-            batched = (2 * B <= eng.max_batch and aug_i.is_contiguous() and aug_j.is_contiguous() and len_i.is_contiguous()
-                       and aug_i.data_ptr() + aug_i.numel() * 8 == aug_j.data_ptr() and len_i.data_ptr() + len_i.numel() * 8 == len_j.data_ptr()
-                       and not os.environ.get("DR4SR_CL_TWO_PASS"))
+            def halves(a, b):                          # b is the second half of the tensor a starts (two_views), not merely its neighbour in memory
+                return (a.is_contiguous() and b.is_contiguous() and a.data_ptr() + a.numel() * 8 == b.data_ptr()
+                        and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
+            batched = 2 * B <= eng.max_batch and halves(aug_i, aug_j) and halves(len_i, len_j) and not os.environ.get("DR4SR_CL_TWO_PASS")
             # regime hint of the views' plans: crops are shorter than the rows they come from (engine.make_plan: expected_tokens)
             fac = aug.expected_len_factor() if hasattr(aug, "expected_len_factor") else 1.0
             exp_v = max(1, int(B * eng.mean_len * fac)) if eng.mean_len is not None else None

@@ -268,6 +268,7 @@ def test_cl4srec_data_parallel_equals_single_process(tail):
                           "--master-port", str(29551 + tail), os.path.join(ROOT, "tools", "dp_cl_check.py")], capture_output=True, text=True,
                          timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_CL_TAIL=str(tail)), cwd=ROOT)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CL_CHECK")]
-    assert out.returncode == 0 and len(lines) == 2, out.stdout[-2500:] + out.stderr[-2500:]
+    err = out.stdout[out.stdout.find("DP_CL_ERROR"):][:3000] if "DP_CL_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.returncode == 0 and len(lines) == 2, err
     print(lines[0])
     assert "replica checksums equal: True" in lines[1]

@@ -318,6 +318,8 @@ _SWITCH_CASES = [
     ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_FWD_WAVES": "16", "DR4SR_WT_BWD_WAVES": "8", "DR4SR_WT_MID_WAVES": "12", "DR4SR_WT_EMB_WAVES": "12"},
      "full_size fuzz"),
     ({"DR4SR_PREP2_INLINE": "1"}, "train_steps"),
+    # round 4: the wave-tile backward recomputing the linear1 pre-activations instead of loading them (opt-in: measured slower)
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_RECOMPUTE_A": "1"}, "full_size fuzz dropout"),
     # the 4-wave per-sequence attention backward (head_dim 64 ran on it until round 3)
     ({"DR4SR_ATTN_BWD_4WAVE": "1"}, "full_size dropout"),
 ]

@@ -58,34 +58,45 @@ def batch_of(rows):
     return b
 
 
-losses = []
-for i in range(STEPS):
-    bounds = [shard_bounds(i, B, n, world, k) for k in range(world)]
-    lo, hi = bounds[rank]
-    model._dp_step(batch_of(perm[lo:hi]), [b - a for a, b in bounds])
-    e = model.engine
-    losses.append(float(e.grads[e.n_params + 1] / e.grads[e.n_params]))
-torch.cuda.synchronize()
-p_dp = model.engine.params.clone()
-if rank == 0:
-    os.environ["WORLD_SIZE"] = "1"                      # (BaseModel reads it: a W > 1 model broadcasts its parameters at construction)
-    _, one = build()
-    os.environ["WORLD_SIZE"] = str(world)
-    assert one.world_size == 1 and one.rank == 0
-    eng = one.engine
-    ref_losses = []
-    for i in range(STEPS):
-        b = batch_of(perm[i * B:min((i + 1) * B, n)])
-        eng.fwd_bwd(eng.make_plan(b["in_item_id"], b["item_id"], b["seqlen"], neg_item=b["neg_item"].contiguous().view(-1), sample_neg=False))
-        one._cl_term(b["in_item_id"], b["seqlen"], views=b["_views"], fold_loss=True)
-        ref_losses.append(float(eng.grads[eng.n_params + 1] / eng.grads[eng.n_params]))
-        eng.adam_step(one._api_plan())
-    torch.cuda.synchronize()
-    d = float((p_dp - eng.params).abs().max())
-    dl = max(abs(a - b) for a, b in zip(losses, ref_losses))
-    print("DP_CL_CHECK world=%d tail=%d max|dp - single| = %.3e (max|param| %.3f), max loss diff %.2e, losses %s" %
-          (world, TAIL, d, float(eng.params.abs().max()), dl, [round(x, 5) for x in losses]), flush=True)
-    assert d < 2e-4 and dl < 2e-5, (d, dl)
+import traceback
+
+
+def _report(e):                                          # the launcher's error page hides the child's traceback: say it on stdout
+    print("DP_CL_ERROR rank %d: %s\n%s" % (rank, repr(e), "".join(traceback.format_exc().splitlines(True)[-14:])), flush=True)
+
+
+try:
+  losses = []
+  for i in range(STEPS):
+      bounds = [shard_bounds(i, B, n, world, k) for k in range(world)]
+      lo, hi = bounds[rank]
+      model._dp_step(batch_of(perm[lo:hi]), [b - a for a, b in bounds])
+      e = model.engine
+      losses.append(float(e.grads[e.n_params + 1] / e.grads[e.n_params]))
+  torch.cuda.synchronize()
+  p_dp = model.engine.params.clone()
+  if rank == 0:
+      os.environ["WORLD_SIZE"] = "1"                      # (BaseModel reads it: a W > 1 model broadcasts its parameters at construction)
+      _, one = build()
+      os.environ["WORLD_SIZE"] = str(world)
+      assert one.world_size == 1 and one.rank == 0
+      eng = one.engine
+      ref_losses = []
+      for i in range(STEPS):
+          b = batch_of(perm[i * B:min((i + 1) * B, n)])
+          eng.fwd_bwd(eng.make_plan(b["in_item_id"], b["item_id"], b["seqlen"], neg_item=b["neg_item"].contiguous().view(-1), sample_neg=False))
+          one._cl_term(b["in_item_id"], b["seqlen"], views=b["_views"], fold_loss=True)
+          ref_losses.append(float(eng.grads[eng.n_params + 1] / eng.grads[eng.n_params]))
+          eng.adam_step(one._api_plan())
+      torch.cuda.synchronize()
+      d = float((p_dp - eng.params).abs().max())
+      dl = max(abs(a - b) for a, b in zip(losses, ref_losses))
+      print("DP_CL_CHECK world=%d tail=%d max|dp - single| = %.3e (max|param| %.3f), max loss diff %.2e, losses %s" %
+            (world, TAIL, d, float(eng.params.abs().max()), dl, [round(x, 5) for x in losses]), flush=True)
+      assert d < 2e-4 and dl < 2e-5, (d, dl)
+except BaseException as e:
+    _report(e)
+    raise
 chk = torch.tensor([float(p_dp.double().sum())], dtype=torch.float64)
 lst = [torch.zeros_like(chk) for _ in range(world)]
 dist.all_gather(lst, chk)
