@@ -12,12 +12,34 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR4SR_LIB_PATH") or os.path.join(_HERE, "csrc", "libdr4sr_hip.so")     # override: A/B runs of two builds on one box
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 GRAD_TAIL = 4
 STATE_WORDS = 16
 STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
 POOL_NONE, POOL_ORIGIN, POOL_LAST, POOL_MEAN = 0, 1, 2, 3
 SITE_EMB, SITE_ATTN, SITE_PROJ, SITE_ACT, SITE_FFN = 0, 1, 2, 3, 4
+OPT_ADAM, OPT_SGD, OPT_ADAGRAD, OPT_RMSPROP = 0, 1, 2, 3        # DR4SR_OPT_* (include/dr4sr_hip.h)
+
+
+def optimizer_settings(name: str, weight_decay: float):
+    """/root/reference model/basemodel.py:79-98 -> (DR4SR_OPT_* kind, (beta1, beta2), eps, weight_decay): each optimizer with torch's
+    defaults as the reference constructs it — Adam(lr, weight_decay), SGD(lr, weight_decay) (no momentum), Adagrad(lr, weight_decay)
+    (eps 1e-10, lr_decay 0, accumulator 0), RMSprop(lr, weight_decay) (alpha 0.99 carried in beta2, eps 1e-8, no momentum, not
+    centered); an UNKNOWN name falls back to Adam(lr) without weight decay, as the reference's else branch does.  'sparse_adam': the
+    reference builds torch.optim.SparseAdam over dense nn.Embedding gradients, which raises at its first step — the same RuntimeError
+    is raised here, when the optimizer is built."""
+    n = str(name).lower()
+    if n == "adam":
+        return OPT_ADAM, (0.9, 0.999), 1e-8, float(weight_decay)
+    if n == "sgd":
+        return OPT_SGD, (0.9, 0.999), 1e-8, float(weight_decay)
+    if n == "adagrad":
+        return OPT_ADAGRAD, (0.9, 0.999), 1e-10, float(weight_decay)
+    if n == "rmsprop":
+        return OPT_RMSPROP, (0.9, 0.99), 1e-8, float(weight_decay)
+    if n == "sparse_adam":
+        raise RuntimeError("SparseAdam does not support dense gradients, please consider Adam instead")
+    return OPT_ADAM, (0.9, 0.999), 1e-8, 0.0
 
 KERNEL_IDS = {"prep": 0, "embed_fwd": 1, "qkv_fwd": 2, "attn_fwd": 3, "post_fwd": 4, "score": 5, "transpose": 6,
               "post_bwd": 7, "attn_bwd": 8, "qkv_bwd": 9, "embed_bwd": 10, "wgrad": 11, "adam": 12, "zero_grads": 13,
@@ -47,6 +69,7 @@ class SasrecPlan(C.Structure):
         ("perm_counter", C.c_void_p),
         ("loss_log", _f32p),
         ("expected_tokens", C.c_int32),
+        ("optimizer", C.c_int32),
     ]
 
 
@@ -71,6 +94,7 @@ class FmlpPlan(C.Structure):
         ("state", C.c_void_p),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("weight_decay", C.c_float),
+        ("optimizer", C.c_int32),
     ]
 
 
@@ -89,6 +113,7 @@ class GruPlan(C.Structure):
         ("state", C.c_void_p),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("weight_decay", C.c_float),
+        ("optimizer", C.c_int32),
     ]
 
 
@@ -169,6 +194,8 @@ SYMBOLS = {
                                         C.c_double, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "dr4sr_cl_prepare": (C.c_int, [_i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_cl_scalars": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
+    "dr4sr_optimizer_flat": (C.c_int, [C.c_int32, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_void_p]),
     "dr4sr_cl_scalars_dp": (C.c_int, [_f32p, C.c_int32, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
     "dr4sr_infonce_fwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, C.c_void_p]),
     "dr4sr_infonce_bwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),

@@ -631,10 +631,17 @@ extern "C" int dr4sr_adam_flat(float* params, const float* grads, float* adam_m,
     return launch_adam_flat(params, const_cast<float*>(grads), adam_m, adam_v, n, state, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);   // (written only when a next-step prep is fused)
 }
 
+extern "C" int dr4sr_optimizer_flat(int32_t optimizer, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    return launch_adam_flat(params, const_cast<float*>(grads), adam_m, adam_v, n, state, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream,
+                            nullptr, nullptr, nullptr, optimizer);
+}
+
 extern "C" int dr4sr_fmlp_train_step(const dr4sr_fmlp_plan* plan, void* stream) {
     RC(dr4sr_fmlp_fwd_bwd(plan, stream));
     return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
-                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream);
+                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream, nullptr, nullptr, nullptr,
+                            plan->optimizer);
 }
 
 extern "C" int dr4sr_fmlp_encode(const dr4sr_fmlp_plan* plan, int32_t training, float* out, void* stream) {

@@ -632,7 +632,8 @@ extern "C" int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* strea
 extern "C" int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream) {
     RC(dr4sr_gru4rec_fwd_bwd(plan, stream));
     return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
-                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream);
+                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream, nullptr, nullptr, nullptr,
+                            plan->optimizer);
 }
 
 extern "C" int dr4sr_gru4rec_encode(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, float* out, void* stream) {

@@ -162,7 +162,7 @@ int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s);
 int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2, float eps, float wd, hipStream_t s,
-                     float* loss_log = nullptr, const int* log_index = nullptr, const PrepArgs* next = nullptr);
+                     float* loss_log = nullptr, const int* log_index = nullptr, const PrepArgs* next = nullptr, int opt = DR4SR_OPT_ADAM);
 
 int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws);   // fills ws from p->workspace (or sizes only if NULL)
 

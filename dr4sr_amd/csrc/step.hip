@@ -205,7 +205,13 @@ static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
 // (larger batches): EVERY workgroup first runs its share of the selection + seqlen gather (prep_select: coalesced over the grid,
 // in flight while the Adam loop runs) and the LAST workgroup to finish runs the scan part (prep_body<256, true>) — as a launch of
 // its own the single-workgroup prep of 8 192 sequences cost 41 us per step.
+// OPT (round 4, basemodel.py:79-98: the reference's `optimizer` choices with torch's defaults): DR4SR_OPT_ADAM as above;
+//   DR4SR_OPT_SGD      torch.optim.SGD(lr, weight_decay)        g += wd p ; p -= lr g                         (no momentum; M, V untouched)
+//   DR4SR_OPT_ADAGRAD  torch.optim.Adagrad(lr, weight_decay)    g += wd p ; V += g^2 ; p -= lr g / (sqrt(V) + eps)     (eps 1e-10, lr_decay 0)
+//   DR4SR_OPT_RMSPROP  torch.optim.RMSprop(lr, weight_decay)    g += wd p ; V = b2 V + (1 - b2) g^2 ; p -= lr g / (sqrt(V) + eps)   (b2 = alpha 0.99)
+// The un-normalised gradient, the poison word, the step counter and the fused next-step prep are the same for all four.
 struct AdamNext { int enable; int phase2_launch; PrepArgs prep; };
+template <int OPT>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __restrict__ G, float* __restrict__ M,
                                               float* __restrict__ V, int64_t n, int* __restrict__ state, float lr, float b1,
                                               float b2, float eps, float wd, float* __restrict__ loss_log,
@@ -239,11 +245,22 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
         const int64_t n4 = n / 4;
         auto upd = [&](float& pe, float& me, float& ve, float ge) {
             const float g = ge * gs + wd * pe;
-            me = me + (g - me) * (1.0f - b1);
-            ve = ve * b2 + (1.0f - b2) * g * g;
-            const float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
-            pe = pe - step_size * (me / denom);
+            if constexpr (OPT == DR4SR_OPT_SGD) {
+                pe = pe - lr * g;
+            } else if constexpr (OPT == DR4SR_OPT_ADAGRAD) {
+                ve = ve + g * g;
+                pe = pe - lr * (g / (sqrtf(ve) + eps));
+            } else if constexpr (OPT == DR4SR_OPT_RMSPROP) {
+                ve = ve * b2 + (1.0f - b2) * g * g;
+                pe = pe - lr * (g / (sqrtf(ve) + eps));
+            } else {
+                me = me + (g - me) * (1.0f - b1);
+                ve = ve * b2 + (1.0f - b2) * g * g;
+                const float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
+                pe = pe - step_size * (me / denom);
+            }
         };
+        constexpr bool useM = OPT == DR4SR_OPT_ADAM, useV = OPT != DR4SR_OPT_SGD;      // moment buffers this optimizer keeps
         // two independent float4 groups per thread per iteration: 8 loads in flight instead of 4 (the loop is latency-, not
         // bandwidth-bound at 3 iterations per thread)
         const int64_t stride = (int64_t)nblk * 256;
@@ -255,16 +272,16 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
                 if (next.enable) { st4(G + 4 * i, z4); if (two) st4(G + 4 * j, z4); }
                 continue;
             }
-            float4 p0 = ld4(P + 4 * i), m0 = ld4(M + 4 * i), v0 = ld4(V + 4 * i);
+            float4 p0 = ld4(P + 4 * i), m0 = useM ? ld4(M + 4 * i) : z4, v0 = useV ? ld4(V + 4 * i) : z4;
             const float4 g0 = ld4(G + 4 * i);
             float4 p1 = p0, m1 = m0, v1 = v0, g1 = g0;
-            if (two) { p1 = ld4(P + 4 * j); m1 = ld4(M + 4 * j); v1 = ld4(V + 4 * j); g1 = ld4(G + 4 * j); }
+            if (two) { p1 = ld4(P + 4 * j); if (useM) m1 = ld4(M + 4 * j); if (useV) v1 = ld4(V + 4 * j); g1 = ld4(G + 4 * j); }
             upd(p0.x, m0.x, v0.x, g0.x); upd(p0.y, m0.y, v0.y, g0.y); upd(p0.z, m0.z, v0.z, g0.z); upd(p0.w, m0.w, v0.w, g0.w);
-            st4(P + 4 * i, p0); st4(M + 4 * i, m0); st4(V + 4 * i, v0);
+            st4(P + 4 * i, p0); if (useM) st4(M + 4 * i, m0); if (useV) st4(V + 4 * i, v0);
             if (next.enable) st4(G + 4 * i, z4);
             if (two) {
                 upd(p1.x, m1.x, v1.x, g1.x); upd(p1.y, m1.y, v1.y, g1.y); upd(p1.z, m1.z, v1.z, g1.z); upd(p1.w, m1.w, v1.w, g1.w);
-                st4(P + 4 * j, p1); st4(M + 4 * j, m1); st4(V + 4 * j, v1);
+                st4(P + 4 * j, p1); if (useM) st4(M + 4 * j, m1); if (useV) st4(V + 4 * j, v1);
                 if (next.enable) st4(G + 4 * j, z4);
             }
         }
@@ -299,8 +316,8 @@ __global__ __launch_bounds__(256) void k_prep_phase2(const PrepArgs P, const int
 }
 
 int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2,
-                     float eps, float wd, hipStream_t s, float* loss_log, const int* log_index, const PrepArgs* next) {
-    if (!P || !G || !M || !V || !state || n <= 0 || (n & 3)) return DR4SR_E_ARG;
+                     float eps, float wd, hipStream_t s, float* loss_log, const int* log_index, const PrepArgs* next, int opt) {
+    if (!P || !G || !M || !V || !state || n <= 0 || (n & 3) || opt < DR4SR_OPT_ADAM || opt > DR4SR_OPT_RMSPROP) return DR4SR_E_ARG;
     int64_t blocks = (n / 4 + 255) / 256;
     const int cap = DR4SR_ENV("DR4SR_ADAM_BLOCKS") ? atoi(DR4SR_ENV("DR4SR_ADAM_BLOCKS")) : 256;
     if (blocks > cap) blocks = cap;
@@ -310,7 +327,13 @@ int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* sta
     if (next) nx.prep = *next; else nx.prep = PrepArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, nullptr};
     const bool p2_inline = DR4SR_ENV("DR4SR_PREP2_INLINE") != nullptr;      // cross-check: phase 2 as the tail of the optimizer launch
     nx.phase2_launch = nx.enable == 2 && !p2_inline;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks + (nx.enable == 1 ? 1 : 0)), dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx);
+    const dim3 grid((unsigned)blocks + (nx.enable == 1 ? 1 : 0));
+    switch (opt) {
+        case DR4SR_OPT_SGD: hipLaunchKernelGGL(k_adam<DR4SR_OPT_SGD>, grid, dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx); break;
+        case DR4SR_OPT_ADAGRAD: hipLaunchKernelGGL(k_adam<DR4SR_OPT_ADAGRAD>, grid, dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx); break;
+        case DR4SR_OPT_RMSPROP: hipLaunchKernelGGL(k_adam<DR4SR_OPT_RMSPROP>, grid, dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx); break;
+        default: hipLaunchKernelGGL(k_adam<DR4SR_OPT_ADAM>, grid, dim3(256), 0, s, P, G, M, V, n, state, lr, b1, b2, eps, wd, loss_log, log_index, nx);
+    }
     if (nx.phase2_launch) {
         const int B = next->B, per = 8 * 256;
         int g2 = (B + per - 1) / per;
@@ -321,7 +344,7 @@ int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* sta
 }
 int launch_adam(const dr4sr_sasrec_plan* p, hipStream_t s, const PrepArgs* next) {
     return launch_adam_flat(p->params, p->grads, p->adam_m, p->adam_v, p->n_params, p->state, p->lr, p->beta1, p->beta2,
-                            p->adam_eps, p->weight_decay, s, p->loss_log, p->perm ? p->perm_counter : nullptr, next);
+                            p->adam_eps, p->weight_decay, s, p->loss_log, p->perm ? p->perm_counter : nullptr, next, p->optimizer);
 }
 
 extern "C" int dr4sr_adam_step(const dr4sr_sasrec_plan* plan, void* stream) {

@@ -59,6 +59,7 @@ class SasrecEngine:
         self.n_items, self.L, self.D, self.H, self.F, self.n_layer = n_items, L, D, H, F, n_layer
         self.ln_eps, self.p_drop, self.seed = float(ln_eps), float(p_drop), int(seed)
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        self.optimizer = _lib.OPT_ADAM             # DR4SR_OPT_* (set_optimizer)
         self.max_batch = max_batch
         self.mean_len = None                     # mean valid length of the training split, set by the model (regime hint)
         self._mean_len = {}
@@ -119,6 +120,7 @@ class SasrecEngine:
         else:
             p.state = self.state.data_ptr()
         p.lr, (p.beta1, p.beta2), p.adam_eps, p.weight_decay = self.lr, self.betas, self.adam_eps, self.weight_decay
+        p.optimizer = self.optimizer
         if perm_sel is not None:           # (perm[n], stride, offset, counter[1] int32): rows[] is FILLED by the step's first kernel
             perm, stride, offset, counter = perm_sel
             assert rows is not None and perm.dtype == torch.int64 and counter.dtype == torch.int32

@@ -42,6 +42,7 @@ class FmlpEngine:
         self.n_items, self.L, self.D, self.F, self.n_layer = n_items, L, D, F, n_layer
         self.ln_eps, self.p_drop, self.seed = float(ln_eps), float(p_drop), int(seed)
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        self.optimizer = _lib.OPT_ADAM             # DR4SR_OPT_* (set_optimizer)
         self.max_batch = max_batch
         off = (C.c_int64 * (4 + 9 * n_layer))()
         self.n_params = int(self.lib.dr4sr_fmlp_param_layout(n_items, L, D, F, n_layer, off))
@@ -86,6 +87,7 @@ class FmlpEngine:
             p.workspace, p.workspace_bytes = self.workspace.data_ptr(), self.ws_bytes
         p.state = self.state.data_ptr()
         p.lr, (p.beta1, p.beta2), p.adam_eps, p.weight_decay = self.lr, self.betas, self.adam_eps, self.weight_decay
+        p.optimizer = self.optimizer
         self._keep = [in_item_id, item_id, rows, neg_item]
         return p
 
@@ -113,9 +115,9 @@ class FmlpEngine:
         _lib.check(self.lib.dr4sr_fmlp_train_step(C.byref(plan), _lib.cur_stream()), "dr4sr_fmlp_train_step")
 
     def adam_step(self, plan=None):
-        _lib.check(self.lib.dr4sr_adam_flat(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
-                                            self.n_params, _lib.ptr(self.state), self.lr, self.betas[0], self.betas[1], self.adam_eps,
-                                            self.weight_decay, _lib.cur_stream()), "dr4sr_adam_flat")
+        _lib.check(self.lib.dr4sr_optimizer_flat(self.optimizer, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
+                                                 _lib.ptr(self.adam_v), self.n_params, _lib.ptr(self.state), self.lr, self.betas[0],
+                                                 self.betas[1], self.adam_eps, self.weight_decay, _lib.cur_stream()), "dr4sr_optimizer_flat")
 
     def encode(self, plan, training: bool, out: Optional[torch.Tensor] = None):
         if out is None:

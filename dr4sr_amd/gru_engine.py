@@ -36,6 +36,7 @@ class GruEngine:
         self.n_items, self.L, self.D, self.H, self.n_layer = n_items, L, D, H, n_layer
         self.p_drop, self.seed = float(p_drop), int(seed)
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        self.optimizer = _lib.OPT_ADAM             # DR4SR_OPT_* (set_optimizer)
         self.max_batch = max_batch
         off = (C.c_int64 * (3 + 2 * n_layer))()
         self.n_params = int(self.lib.dr4sr_gru4rec_param_layout(n_items, D, H, n_layer, off))
@@ -81,6 +82,7 @@ class GruEngine:
             p.workspace, p.workspace_bytes = self.workspace.data_ptr(), self.ws_bytes
         p.state = self.state.data_ptr()
         p.lr, (p.beta1, p.beta2), p.adam_eps, p.weight_decay = self.lr, self.betas, self.adam_eps, self.weight_decay
+        p.optimizer = self.optimizer
         self._keep = [in_item_id, item_id, seqlen, rows, neg_item]
         return p
 
@@ -109,9 +111,9 @@ class GruEngine:
         _lib.check(self.lib.dr4sr_gru4rec_train_step(C.byref(plan), _lib.cur_stream()), "dr4sr_gru4rec_train_step")
 
     def adam_step(self, plan=None):
-        _lib.check(self.lib.dr4sr_adam_flat(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
-                                            self.n_params, _lib.ptr(self.state), self.lr, self.betas[0], self.betas[1], self.adam_eps,
-                                            self.weight_decay, _lib.cur_stream()), "dr4sr_adam_flat")
+        _lib.check(self.lib.dr4sr_optimizer_flat(self.optimizer, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
+                                                 _lib.ptr(self.adam_v), self.n_params, _lib.ptr(self.state), self.lr, self.betas[0],
+                                                 self.betas[1], self.adam_eps, self.weight_decay, _lib.cur_stream()), "dr4sr_optimizer_flat")
 
     def encode(self, plan, training: bool, pooling: int, out: Optional[torch.Tensor] = None):
         shape = (plan.B, self.D) if pooling == _lib.POOL_LAST else (plan.B, self.L, self.D)

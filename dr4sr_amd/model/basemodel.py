@@ -151,12 +151,13 @@ class BaseModel(nn.Module):
             parallel.broadcast(self.engine.params, src=0)
 
     def _get_optimizers(self):
-        name = self.config["train"]["optimizer"].lower()
-        if name != "adam":
-            raise NotImplementedError(f"optimizer '{name}': the HIP path implements the shipped configs' Adam only")
+        # basemodel.py:79-98: adam / sgd / adagrad / rmsprop with torch's defaults, an unknown name = Adam without weight decay,
+        # sparse_adam = the RuntimeError torch raises on the reference's dense gradients (_lib.optimizer_settings); all four run as
+        # the one fused flat-buffer launch of csrc/step.hip (k_adam<OPT>), next-step prep and data-parallel tail included
         eng = self.engine
         eng.lr = float(self.config["train"]["learning_rate"])
-        eng.weight_decay = float(self.config["train"]["weight_decay"])
+        eng.optimizer, eng.betas, eng.adam_eps, eng.weight_decay = _lib.optimizer_settings(self.config["train"]["optimizer"],
+                                                                                           self.config["train"]["weight_decay"])
         return FusedAdam(self)
 
     def _get_loss_func(self):

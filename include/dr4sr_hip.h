@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DR4SR_ABI_VERSION 5
+#define DR4SR_ABI_VERSION 6
 
 #define DR4SR_E_ARG      (-1)   /* null pointer / bad size                                   */
 #define DR4SR_E_SHAPE    (-2)   /* unsupported D / H / F / L combination     */
@@ -39,6 +39,12 @@ extern "C" {
 #define DR4SR_SITE_PROJ  2      /* torch TEL      dropout1 after out_proj                    */
 #define DR4SR_SITE_ACT   3      /* torch TEL      dropout after the activation               */
 #define DR4SR_SITE_FFN   4      /* torch TEL      dropout2 after linear2                     */
+
+/* plan->optimizer (ABI 6): basemodel.py:79-98's `optimizer` choices, each with torch's defaults as the reference constructs them */
+#define DR4SR_OPT_ADAM    0     /* torch.optim.Adam(lr, weight_decay); also what an unknown name falls back to (weight_decay 0)   */
+#define DR4SR_OPT_SGD     1     /* torch.optim.SGD(lr, weight_decay): no momentum                                                */
+#define DR4SR_OPT_ADAGRAD 2     /* torch.optim.Adagrad(lr, weight_decay): adam_v = state_sum, adam_eps = 1e-10                    */
+#define DR4SR_OPT_RMSPROP 3     /* torch.optim.RMSprop(lr, weight_decay): adam_v = square_avg, beta2 = alpha 0.99, adam_eps 1e-8  */
 
 #define DR4SR_POOL_NONE   0
 #define DR4SR_POOL_ORIGIN 1     /* module/layers.py:41-50  zero rows >= seqlen  -> [B,L,D]   */
@@ -111,6 +117,7 @@ typedef struct dr4sr_sasrec_plan {
      *      16 384 for both), as before ABI 4.  (Boundaries quoted for d = 64; they scale with 64 / d.)  A wrong hint costs speed, never
      *      correctness. ---- */
     int32_t  expected_tokens;
+    int32_t  optimizer;             /* DR4SR_OPT_* (ABI 6; 0 = Adam)                                                              */
 } dr4sr_sasrec_plan;
 
 /* -------------------------------------------------------------------------------------------- */
@@ -262,6 +269,7 @@ typedef struct dr4sr_fmlp_plan {
     void*    workspace; int64_t workspace_bytes;
     int32_t* state;                 /* [DR4SR_STATE_WORDS]                                          */
     float lr, beta1, beta2, adam_eps, weight_decay;
+    int32_t optimizer;              /* DR4SR_OPT_* (ABI 6)                                          */
 } dr4sr_fmlp_plan;
 
 int     dr4sr_fmlp_plan_sizeof(void);
@@ -280,6 +288,9 @@ int dr4sr_fmlp_encode_bwd(const dr4sr_fmlp_plan* plan, int32_t training, const f
 /* torch.optim.Adam on arbitrary flat buffers (grads[n] = normaliser, as dr4sr_adam_step); state[STEP] is bumped */
 int dr4sr_adam_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* the same for any DR4SR_OPT_* (basemodel.py:79-98) */
+int dr4sr_optimizer_flat(int32_t optimizer, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GRU4Rec (model/gru4rec.py:12-34; module/layers.py:117-136 = torch.nn.GRU(bias=False, batch_first, n_layer) + Linear(H->D)):
@@ -305,6 +316,7 @@ typedef struct dr4sr_gru4rec_plan {
     void*    workspace; int64_t workspace_bytes;
     int32_t* state;
     float lr, beta1, beta2, adam_eps, weight_decay;
+    int32_t optimizer;              /* DR4SR_OPT_* (ABI 6) */
 } dr4sr_gru4rec_plan;
 
 int     dr4sr_gru4rec_plan_sizeof(void);

@@ -607,3 +607,73 @@ def test_regime_follows_the_expected_token_hint(monkeypatch):
     monkeypatch.delenv("DR4SR_FORCE_ATTN_SPLIT")
     monkeypatch.setenv("DR4SR_FORCE_SCALE", "0")
     assert scale(4096, full) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["adam", "sgd", "adagrad", "rmsprop"])
+def test_optimizer_choices_match_torch_optim(kind):
+    """basemodel.py:79-98 (round 4): the reference's `optimizer` choices through the one fused flat-buffer launch (k_adam<OPT>,
+    csrc/step.hip) — dr4sr_optimizer_flat on random buffers, 4 steps with the un-normalised gradient + n_valid tail the training step
+    leaves, against oracle/optim_oracle.py (pinned on torch.optim); and through a SASRec engine's plan (plan->optimizer)"""
+    from dr4sr_amd import _lib
+    from oracle import optim_oracle as OO
+    lib = _lib.load()
+    code, betas, eps, wd = _lib.optimizer_settings(kind, 1e-2)
+    n, lr, nv = 4096 + 8, 1e-2, 37.0
+    gen = torch.Generator().manual_seed(7)
+    p0 = torch.randn(n, generator=gen)
+    P, M, V = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int32, device="cuda")
+    p, st = p0.clone(), OO.init_state(p0)
+    for i in range(4):
+        g = torch.randn(n, generator=gen) * torch.rand(n, generator=gen)
+        G = torch.cat([g * nv, torch.tensor([nv, 0.0, 0.0, 0.0])]).cuda()         # un-normalised sum + {n_valid, loss_sum, poison, -}
+        _lib.check(lib.dr4sr_optimizer_flat(code, _lib.ptr(P), _lib.ptr(G), _lib.ptr(M), _lib.ptr(V), n, _lib.ptr(state), lr, betas[0], betas[1],
+                                            eps, wd, _lib.cur_stream()), "dr4sr_optimizer_flat")
+        p = OO.step(kind, p, g, st, lr, wd)
+        err = float((P.cpu() - p).abs().max())
+        assert err < 3e-6, (kind, i, err)
+    assert int(state[_lib.STATE_STEP]) == 4
+    if kind == "sgd":
+        assert float(M.abs().max()) == 0.0 and float(V.abs().max()) == 0.0        # SGD keeps no moments (and moves no bytes for them)
+    # a poisoned step is skipped by every kind
+    G[n + 2] = 1.0
+    before = P.clone()
+    _lib.check(lib.dr4sr_optimizer_flat(code, _lib.ptr(P), _lib.ptr(G), _lib.ptr(M), _lib.ptr(V), n, _lib.ptr(state), lr, betas[0], betas[1], eps, wd,
+                                        _lib.cur_stream()), "dr4sr_optimizer_flat")
+    assert torch.equal(P, before) and int(state[_lib.STATE_STEP]) == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sgd", "adagrad", "rmsprop", "lamb"])
+def test_model_optimizer_config_trains(tmp_path, monkeypatch, name):
+    """`train.optimizer` of the reference's config (basemodel.py:79-98) through fit(): the fused k-step graphs carry the chosen update;
+    an unknown name ('lamb') falls back to Adam without weight decay as the reference's else branch; 'sparse_adam' raises what torch
+    raises on the reference's dense gradients"""
+    monkeypatch.chdir(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(root, "configs"))
+    from dr4sr_amd import _lib
+    from dr4sr_amd.utils import load_config, prepare_datasets, prepare_model, seed_everything
+    cfg = load_config({"model": "SASRec", "dataset": "synthetic-toys"})
+    cfg["data"].update({"n_items": 200, "n_rows": 512, "n_eval_rows": 64, "seed": 5})
+    cfg["train"].update({"batch_size": 64, "epochs": 1, "device": "cuda", "optimizer": name, "weight_decay": 1e-3,
+                         "learning_rate": {"sgd": 0.5, "adagrad": 0.05, "rmsprop": 0.003, "lamb": 0.003}[name]})
+    seed_everything(cfg["train"]["seed"])
+    ds = prepare_datasets(cfg)
+    model = prepare_model(cfg, ds)
+    model._init_model(ds[0])
+    eng = model.engine
+    want = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "rmsprop": _lib.OPT_RMSPROP, "lamb": _lib.OPT_ADAM}[name]
+    assert eng.optimizer == want and eng.weight_decay == (0.0 if name == "lamb" else 1e-3)
+    model.train()
+    first = last = None
+    for ep in range(6):
+        out = model.training_epoch(ep)
+        loss = float(torch.stack([o["loss_0"].float().mean() if torch.is_tensor(o["loss_0"]) else torch.tensor(o["loss_0"]) for o in out[0]]).mean())
+        first = loss if first is None else first
+        last = loss
+    assert np.isfinite(last) and last < first, (name, first, last)
+    cfg["train"]["optimizer"] = "sparse_adam"
+    with pytest.raises(RuntimeError, match="SparseAdam does not support dense gradients"):
+        prepare_model(cfg, ds)._init_model(ds[0])

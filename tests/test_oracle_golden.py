@@ -187,3 +187,23 @@ def test_oracle_loss_modules_match_reference(golden_dir):
             (loss * torch.from_numpy(z[f"{tag}.{name}.up"])).sum().backward()
             np.testing.assert_allclose(torch.nan_to_num(p.grad, nan=0.0).numpy(), z[f"{tag}.{name}.dpos"], rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(n.grad.numpy(), z[f"{tag}.{name}.dneg"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd", "adagrad", "rmsprop"])
+def test_optimizer_oracle_matches_torch_optim(kind):
+    """oracle/optim_oracle.py restates the optimizers of basemodel.py:79-98 (torch.optim with the defaults the reference constructs them
+    with); pinned against torch.optim itself, 5 steps, with and without weight decay"""
+    from oracle import optim_oracle as OO
+    cls = {"adam": torch.optim.Adam, "sgd": torch.optim.SGD, "adagrad": torch.optim.Adagrad, "rmsprop": torch.optim.RMSprop}[kind]
+    gen = torch.Generator().manual_seed(4)
+    for wd in (0.0, 1e-2):
+        p0 = torch.randn(257, generator=gen)
+        ref = torch.nn.Parameter(p0.clone())
+        opt = cls([ref], lr=1e-2, weight_decay=wd)
+        p, st = p0.clone(), OO.init_state(p0)
+        for _ in range(5):
+            g = torch.randn(257, generator=gen) * torch.rand(257, generator=gen)
+            ref.grad = g.clone()
+            opt.step()
+            p = OO.step(kind, p, g, st, 1e-2, wd)
+            np.testing.assert_allclose(p.numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
