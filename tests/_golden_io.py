@@ -42,3 +42,30 @@ def load_meta_trained(golden_dir):
     for key in ("inner.grad." + TABLE, "outer.grad_val." + TABLE):
         g[key] = _dense(g, key, np.zeros((N, D), np.float32))
     return g, pick("meta_param."), pick("train."), pick("val.")
+
+
+def curve_init(shapes, seed):
+    """deterministic initial parameters from a numpy stream — the function tools/make_golden.py run_curve_case ran inside the reference
+    (same code there), so that no parameter file travels: N(0, 0.02) for every matrix (PAD row zero), LayerNorm (1, 0), biases 0 =
+    the distribution of the reference's utils/utils.py:70-81"""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        if "norm" in k and k.endswith("weight"):
+            out[k] = np.ones(shp, np.float32)
+        elif k.endswith("bias"):
+            out[k] = np.zeros(shp, np.float32)
+        else:
+            out[k] = rng.normal(0.0, 0.02, size=shp).astype(np.float32)
+    out[TABLE][0] = 0
+    return out
+
+
+def load_curve(golden_dir):
+    """tests/golden/sasrec_toys_curve.npz -> (g, rows): the reference's per-epoch mean training losses on the REAL toys rows (two RNG
+    seeds) and those rows as int64 tensors"""
+    z = np.load(os.path.join(golden_dir, "sasrec_toys_curve.npz"))
+    g = {k: z[k] for k in z.files}
+    rows = {k[5:]: torch.from_numpy(g[k].astype(np.int64)) for k in ("rows.in_item_id", "rows.item_id", "rows.seqlen")}
+    return g, rows

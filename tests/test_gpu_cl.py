@@ -265,7 +265,7 @@ def test_cl4srec_data_parallel_equals_single_process(tail):
     import subprocess
     import sys
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(29551 + tail), os.path.join(ROOT, "tools", "dp_cl_check.py")], capture_output=True, text=True,
+                          "--master-port", str(29651 + tail), os.path.join(ROOT, "tools", "dp_cl_check.py")], capture_output=True, text=True,
                          timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_CL_TAIL=str(tail)), cwd=ROOT)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CL_CHECK")]
     err = out.stdout[out.stdout.find("DP_CL_ERROR"):][:3000] if "DP_CL_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]

@@ -223,3 +223,43 @@ def test_hypergradient_on_trained_weights_vs_reference_double_backward(trained, 
         model.hypergrad_step(bv, bt)
         for k, p in model.meta_module.named_parameters():
             np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"outer.step{s}.{k}"], rtol=2e-5, atol=3e-7)
+
+
+def test_training_curve_on_real_toys_rows_matches_the_reference(golden_dir):
+    """END-TO-END, statistical (round 4): four epochs of the full training loop on the 19 412 REAL toys rows — device-side batch selection
+    from a per-epoch permutation, in-kernel negatives, dropout 0.5, the fused step, Adam; last batch of 212 rows — from the deterministic
+    init against the reference's OWN training_epoch on the same rows (tools/make_golden.py run_curve_case: two RNG seeds, per-epoch mean
+    losses 1.3506 / 1.2378 / 1.1780 / 1.1188 and 1.3504 / 1.2368 / 1.1806 / 1.1204).  The random streams differ (Philox here), so the
+    bar is statistical: every epoch mean within 0.5 % of the reference's (its two seeds differ by up to 0.22 %) — a wrong dropout rate,
+    sampler range, loss normalisation, learning rate or a stale-gradient bug moves the curve by several per cent."""
+    from _golden_io import curve_init, load_curve
+    from dr4sr_amd.engine import SasrecEngine, param_names, param_shapes
+    g, rows = load_curve(golden_dir)
+    N, B, L = int(g["meta.num_items"]), int(g["meta.batch_size"]), 50
+    D, H, F, NL = int(g["meta.embed_dim"]), int(g["meta.head_num"]), int(g["meta.hidden_size"]), int(g["meta.layer_num"])
+    eng = SasrecEngine(N, L, D, H, F, NL, float(g["meta.layer_norm_eps"]), float(g["meta.dropout_rate"]), B, "cuda", seed=123,
+                       lr=float(g["meta.lr"]), weight_decay=float(g["meta.weight_decay"]))
+    init = curve_init(dict(zip(param_names(NL), param_shapes(N, L, D, F, NL))), int(g["meta.init_seed"]))
+    eng.load_named({k: torch.from_numpy(v) for k, v in init.items()})
+    dev = eng.device
+    data = {k: v.to(dev) for k, v in rows.items()}
+    n = int(data["seqlen"].shape[0])
+    assert n == 19412 and n % B == 212
+    eng.mean_len = float(data["seqlen"].float().mean())
+    gen = torch.Generator().manual_seed(9)
+    ref = g["curve.epoch_mean_loss"]                                   # [2 seeds, epochs]
+    got = []
+    for ep in range(ref.shape[1]):
+        perm = torch.randperm(n, generator=gen).to(dev)
+        losses = []
+        for i in range(0, n, B):
+            rb = perm[i:i + B].contiguous()
+            plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rb, sample_neg=True)
+            eng.train_step(plan)
+            losses.append(eng.loss_and_count()[0])
+        assert len(losses) == 76
+        got.append(float(np.mean(losses)))
+    print("HIP epoch means", np.round(got, 5).tolist(), "reference", np.round(ref, 5).tolist())
+    for ep, v in enumerate(got):
+        r = ref[:, ep]
+        assert abs(v - r.mean()) < 5e-3 * r.mean(), (ep, v, r.tolist())

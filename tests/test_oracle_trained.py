@@ -121,3 +121,40 @@ def test_meta_first_order_form_on_trained_weights(meta_trained, richardson, rel_
         assert err < 1e-4, err
     else:
         assert 5e-4 < err < 2e-3, err
+
+
+def test_ref_trainer_first_epoch_on_real_rows_matches_the_reference_curve(golden_dir):
+    """END-TO-END statistical pin of oracle/ref_trainer.py (bench.py's cpu_baseline "port"): its training loop on the REAL toys rows
+    from the deterministic init reaches the reference's own first-epoch mean loss (tools/make_golden.py run_curve_case: the reference's
+    training_epoch, two seeds, agree to 0.02 % there).  Other random streams, same distribution."""
+    from _golden_io import curve_init, load_curve
+    from oracle import ref_trainer as RT
+    g, rows = load_curve(golden_dir)
+    torch.manual_seed(5)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    N, B = int(g["meta.num_items"]), int(g["meta.batch_size"])
+    model = RT.RefLikeSASRec(N, D=int(g["meta.embed_dim"]), L=50, H=int(g["meta.head_num"]), Fh=int(g["meta.hidden_size"]),
+                             p=float(g["meta.dropout_rate"]), eps=float(g["meta.layer_norm_eps"]), n_layer=int(g["meta.layer_num"]))
+    sd = model.state_dict()
+    init = curve_init({k: tuple(v.shape) for k, v in sd.items() if k != "query_encoder.item_encoder.weight"}, int(g["meta.init_seed"]))
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            v.copy_(torch.from_numpy(init[k]))
+    opt = torch.optim.Adam(model.parameters(), lr=float(g["meta.lr"]), weight_decay=float(g["meta.weight_decay"]))
+    model.train()
+    n = rows["seqlen"].shape[0]
+    perm = torch.randperm(n)
+    losses = []
+    for i in range(0, n, B):
+        idx = perm[i:i + B]
+        batch = {k: v[idx] for k, v in rows.items()}
+        batch["neg_item"] = model.neg_sampling(batch)
+        opt.zero_grad()
+        loss = model.training_step(batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    ref = g["curve.epoch_mean_loss"][:, 0]
+    got = float(np.mean(losses))
+    print("ref_trainer epoch-0 mean loss %.5f, reference %s" % (got, np.round(ref, 5).tolist()))
+    assert len(losses) == 76 and abs(got - ref.mean()) < 4e-3 * ref.mean(), (got, ref)

@@ -756,6 +756,75 @@ def run_trained_case(out_dir, name="sasrec_trained_toys", seed=21):
         shutil.rmtree(work, ignore_errors=True)
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from _golden_io import curve_init  # noqa: E402  (ONE definition: the GPU / CPU tests rebuild the same initial parameters)
+
+
+def run_curve_case(out_dir, name="sasrec_toys_curve", epochs=4, seeds=(31, 32)):
+    """END-TO-END statistical pin: the reference's own training loop (BaseModel.training_epoch, basemodel.py:176-200: DataLoader shuffle,
+    multinomial negatives, dropout 0.5, Adam) on the REAL toys training rows from a deterministic init, `epochs` epochs, for two RNG
+    seeds; the per-epoch mean training losses are stored together with the rows.  The HIP trainer draws other random streams (Philox),
+    so its curve is compared statistically: it must lie as close to the reference's curves as they lie to each other."""
+    import torch
+    work = tempfile.mkdtemp(prefix="dr4sr_golden_")
+    cwd = os.getcwd()
+    try:
+        os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
+        n_items, n_users = build_real_toys(work)
+        os.chdir(work)
+        from utils import load_config, setup_environment, prepare_datasets, prepare_model
+        curves, first_steps, out = [], [], {}
+        for seed in seeds:
+            config = load_config({"model": "SASRec", "dataset": "amazon-toys"})
+            config["train"]["device"] = "cpu"
+            config["data"]["train_file"] = "_ori"
+            config["train"]["seed"] = seed
+            setup_environment(config["train"])
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            ds = prepare_datasets(config)
+            model = prepare_model(config, ds)
+            model._init_model(ds[0])
+            shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if k != "query_encoder.item_encoder.weight"}
+            init = curve_init(shapes, 77)
+            with torch.no_grad():
+                for k, v in model.named_parameters():
+                    v.copy_(torch.from_numpy(init[k]))
+            model.train()
+            ep = []
+            for e in range(epochs):
+                outs = model.training_epoch(e)
+                ls = [float(o["loss_0"]) for o in outs[0]]
+                if e == 0:
+                    first_steps.append(ls[:20])
+                ep.append(float(np.mean(ls)))
+                print(f"{name}: seed {seed} epoch {e}: mean loss {ep[-1]:.5f} ({len(ls)} steps)", flush=True)
+            curves.append(ep)
+            if "rows.in_item_id" not in out:
+                rows = next(iter(ds[0].get_loader(batch_size=len(ds[0]), shuffle=False)))
+                assert int(rows["in_item_id"].max()) < 32768
+                out["rows.in_item_id"] = rows["in_item_id"].numpy().astype(np.int16)
+                out["rows.item_id"] = rows["item_id"].numpy().astype(np.int16)
+                out["rows.seqlen"] = rows["seqlen"].numpy().astype(np.int8)
+                mc, tc = config["model"], config["train"]
+                out["meta.num_items"] = np.int64(model.num_items)
+                for k in ("embed_dim", "head_num", "hidden_size", "layer_num"):
+                    out["meta." + k] = np.int64(mc[k])
+                for k in ("dropout_rate", "layer_norm_eps"):
+                    out["meta." + k] = np.float64(mc[k])
+                out["meta.lr"], out["meta.weight_decay"], out["meta.batch_size"] = np.float64(tc["learning_rate"]), np.float64(tc["weight_decay"]), np.int64(tc["batch_size"])
+                out["meta.init_seed"] = np.int64(77)
+        out["curve.epoch_mean_loss"] = np.asarray(curves, np.float64)            # [seeds, epochs]
+        out["curve.first_steps"] = np.asarray(first_steps, np.float64)           # [seeds, 20]
+        os.chdir(cwd)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); curves {np.round(out['curve.epoch_mean_loss'], 4).tolist()}")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def neg_sampler_stats(out_dir):
     """Pin the *distribution* of basemodel.py:50-61 (uniform on 1..N-1, never PAD)."""
     import torch
@@ -853,6 +922,9 @@ def main():
     if only == "meta":
         run_meta_case(out_dir, "metamodel_sasrec", "SASRec", n_items=151, seqlens=seqlens, seed=15)
         return
+    if only == "curve":
+        run_curve_case(out_dir)
+        return
     if only == "meta_cl":
         run_meta_case(out_dir, "metamodel_cl4srec", "CL4SRec", n_items=137, seqlens=seqlens, seed=23)
         return
@@ -878,6 +950,7 @@ def main():
     run_trained_case(out_dir)
     run_meta_case(out_dir, "metamodel_trained_toys", "SASRec", n_items=None, seqlens=None, seed=22, real=True)
     run_meta_case(out_dir, "metamodel_cl4srec", "CL4SRec", n_items=137, seqlens=seqlens, seed=23)
+    run_curve_case(out_dir)
 
 
 if __name__ == "__main__":
