@@ -565,7 +565,8 @@ def main():
             for k, v in eng.views.items():
                 v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / 16.0 if "gru" in k else 0.02 * torch.randn(v.shape, generator=g))
             eng.views["item_embedding.weight"][0] = 0
-            plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+            plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, neg_item=negbuf, sample_neg=True,
+                                 perm_sel=(perm, B * world, rank * B, counter))      # a1 fused into the step's first kernel, as SASRec
         else:
             from dr4sr_amd.fmlp_engine import FmlpEngine
             sl, hist = data["seqlen"], data["in_item_id"]                                # roll every row to a left-padded prefix
@@ -583,7 +584,7 @@ def main():
         stream = torch.cuda.Stream(device=dev)
 
         def select():
-            if args.model == "sasrec":
+            if args.model in ("sasrec", "gru4rec"):
                 return
             _lib.check(lib.dr4sr_select_rows(_lib.ptr(perm), U, _lib.ptr(rows_buf), B, B * world, rank * B, _lib.ptr(counter),
                                              _lib.cur_stream()), "select_rows")
@@ -617,7 +618,7 @@ def main():
                 def capture(n):
                     g = torch.cuda.CUDAGraph()
                     with graph_capture(g, stream=stream):
-                        if args.model == "sasrec":
+                        if args.model in ("sasrec", "gru4rec"):
                             eng.train_steps(plan, n)         # one prep per graph; each optimizer launch prepares the next step
                         else:
                             for _ in range(n):

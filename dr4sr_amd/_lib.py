@@ -114,6 +114,9 @@ class GruPlan(C.Structure):
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("weight_decay", C.c_float),
         ("optimizer", C.c_int32),
+        ("perm", _i64p), ("n_perm", C.c_int64), ("perm_stride", C.c_int64), ("perm_offset", C.c_int64),
+        ("perm_counter", C.c_void_p),
+        ("loss_log", _f32p),
     ]
 
 
@@ -194,6 +197,8 @@ SYMBOLS = {
                                         C.c_double, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "dr4sr_cl_prepare": (C.c_int, [_i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_cl_scalars": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
+    "dr4sr_gru4rec_adam_step": (C.c_int, [_GPLANP, C.c_void_p]),
+    "dr4sr_gru4rec_train_steps": (C.c_int, [_GPLANP, C.c_int32, C.c_void_p]),
     "dr4sr_optimizer_flat": (C.c_int, [C.c_int32, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_void_p]),
     "dr4sr_cl_scalars_dp": (C.c_int, [_f32p, C.c_int32, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),

@@ -76,6 +76,12 @@ int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* st
                     int64_t zero_floats, hipStream_t s) {
     return launch_prep_sel(seqlen, rows, cu, state, B, L, bump_rng, zero, zero_floats, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, s);
 }
+// the same with the tile -> sequence hints (tile_seq [ceil(B L / 16) + 1]) and, optionally, the batch selection of the fused step
+// (sel.perm != NULL: rows[] is FILLED from the epoch permutation first) — GRU4Rec's fused glue launches (gru.hip)
+int launch_prep_raw_hints(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
+                          int64_t zero_floats, int* tile_seq, const PermSel& sel, hipStream_t s) {
+    return launch_prep_sel(seqlen, rows, cu, state, B, L, bump_rng, zero, zero_floats, sel, tile_seq, nullptr, s);
+}
 int make_prep_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, PrepArgs* out) {
     PermSel sel{nullptr, 0, 0, 0, nullptr};
     if (p->perm && bump_rng) {                          // selection only in the calls that start a new step

@@ -37,6 +37,7 @@ struct GruWs {
     int64_t off_E, off_wih[GRU_MAX_LAYERS], off_whh[GRU_MAX_LAYERS], off_ow, off_ob, n_params;
     int Tmax;
     int* cu;
+    int* tile_seq;                                            // [ceil(Tmax / 16) + 1] sequence slot of token 16 i (k_prep): search hint of the fused glue kernels
     float* X0; float* dX0; float* Y; float* dY; float* dH;     // dH: grad w.r.t. a layer's output rows [T,H]
     float* score_part;
     unsigned long long* xch; int* ctl;                        // cooperative recurrence (gru_coop.hip): granule area, control words
@@ -90,8 +91,9 @@ static void gru_carve(const dr4sr_gru4rec_plan* p, GruWs* ws) {
         ws->xch = words ? (unsigned long long*)take(2 * words) : nullptr;
     }
     ws->cu = (int*)take(p->B + 1);
+    ws->tile_seq = (int*)take((Tmax + 15) / 16 + 1);
     ws->X0 = take(Tmax * D); ws->dX0 = take(Tmax * D); ws->Y = take(Tmax * D); ws->dY = take(Tmax * D); ws->dH = take(Tmax * H);
-    ws->score_part = take(2LL * p->B);
+    ws->score_part = take(2LL * (p->B > (Tmax + 15) / 16 ? p->B : (Tmax + 15) / 16));     // per sequence, or per 16-token tile (k_gru_mid)
     for (int l = 0; l < p->n_layer; ++l) {
         GruLayerWs& w = ws->layer[l];
         w.gi = take(Tmax * 3 * H); w.r = take(Tmax * H); w.z = take(Tmax * H); w.n = take(Tmax * H); w.ghn = take(Tmax * H);
@@ -176,6 +178,56 @@ __global__ __launch_bounds__(256) void k_gemm16_col(const float* __restrict__ A,
     tile_to_global<16, 64>(acc, C + n0, ldc, nullptr, t0, T);
 }
 
+// Split-K form of the same product for K = 3H (round 4): in k_gemm16_col a wave owns 16 output columns and walks the whole K as ONE
+// dependent chain of K / 4 MFMAs (192 at K = 768: 20.7 us per launch for 0.33 GFLOP).  Here wave w owns the K quarter
+// [w K / 4, (w + 1) K / 4) for all 64 columns — four independent accumulator chains of K / 16 MFMAs — and the four partial tiles meet
+// in LDS; the sum leaves as one float4 per thread in the (row = tid / 16, columns 4 (tid % 16) ..) layout the row epilogues use.
+template <int K>
+__device__ __forceinline__ float4 gemm16_col_splitk(const float* __restrict__ As, int lda, const float* __restrict__ W, int ldw, float* __restrict__ red) {
+    constexpr int KW = K / 4, KWQ = KW / 4, LDR = 68;
+    static_assert(KWQ % 4 == 0, "K must be a multiple of 64");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int kb = w * KW + g * KWQ;
+#pragma unroll 3
+    for (int c = 0; c < KWQ; c += 4) {
+        const float4 a = ld4(As + r16 * lda + kb + c);
+        const float* wp = W + (size_t)(kb + c) * ldw + r16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float b0 = wp[16 * i], b1 = wp[ldw + 16 * i], b2 = wp[2 * ldw + 16 * i], b3 = wp[3 * ldw + 16 * i];
+            acc[i] = mfma16x4(a.x, b0, acc[i]); acc[i] = mfma16x4(a.y, b1, acc[i]);
+            acc[i] = mfma16x4(a.z, b2, acc[i]); acc[i] = mfma16x4(a.w, b3, acc[i]);
+        }
+    }
+    float* mine = red + w * 16 * LDR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine[(4 * g + q) * LDR + 16 * i + r16] = acc[i][q];
+    lds_barrier();
+    const int r = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;
+    const float4 p0 = ld4(red + r * LDR + c), p1 = ld4(red + (16 + r) * LDR + c), p2 = ld4(red + (32 + r) * LDR + c), p3 = ld4(red + (48 + r) * LDR + c);
+    return make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+}
+template <int K>
+__global__ __launch_bounds__(256) void k_gemm16_col_sk(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                       float* __restrict__ C, int ldc, const int* __restrict__ state) {
+    constexpr int LDA = K + 4;
+    const int T = state[DR4SR_STATE_T], t0 = blockIdx.x * 16;
+    if (t0 >= T) return;
+    const int n0 = blockIdx.y * 64;
+    float* As = smem;                                   // [16][LDA]
+    float* red = As + 16 * LDA;                         // [4][16][68]
+    load_tile_bm<16, K>(As, LDA, A, lda, t0, T);
+    lds_barrier();
+    const float4 v = gemm16_col_splitk<K>(As, LDA, W + n0, ldw, red);
+    const int r = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;
+    if (t0 + r < T) st4(C + (size_t)(t0 + r) * ldc + n0 + c, v);
+}
+
 // ... and of the forward linear C[T x N] = A[T x K] W^T + bias (W [N][ldw]): gi = x W_ih^T (K = D or H, N = 3H) and the output
 // projection (K = H, N = D) ran on 21 x N/128 workgroups of 64 rows with K walked in 64-chunks (25 us for 0.5 GFLOP at B = 256).
 template <int K>
@@ -197,6 +249,169 @@ __global__ __launch_bounds__(256) void k_gemm16_row(const float* __restrict__ A,
     tile_to_global<16, 64>(acc, C + n0, ldc, bias ? bias + n0 : nullptr, t0, T);
 }
 
+// ------------------------------------------------------------------------------------------------ fused glue launches (round 4)
+// At B = 256 the GRU4Rec step is 15 launches of which 12 are 5-20 us of glue around the three recurrences (profiles/
+// round3_timeline_gru4rec.txt: 130 of 493 us).  Three fusions in the latency regime (16-row tiles), each removing launch boundaries and
+// a round trip of a [T, D] tensor through global memory; DR4SR_GRU_NOFUSE_GLUE restores the separate launches (cross-check, tested):
+//   k_gru_embed_gi : x = drop(E[idx]) gathered straight into the A tile + gi_1 = x W_ih1^T             (was k_embed_fwd + k_gemm16_row<64>)
+//   k_gru_mid      : y = h_top W_out^T + b  ->  scorer / BCE / d y (model/basemodel.py:204-214, model/loss_func.py:9-38)  ->  d h_top = d y W_out
+//                                                                                                     (was k_gemm16_row<256> + k_score_packed + k_gemm16_col<64>)
+//   k_gru_dx_embed : d x = d gi_1 W_ih1 times the embedding dropout mask, scattered into d E            (was k_gemm16_col<768> + k_embed_bwd)
+struct GruGlueArgs {
+    const float* E; float* dE; const int64_t* idx; const int64_t* target; const int64_t* rows; const int* cu; const int* tile_seq;
+    int64_t* neg_item; int sample_neg; float* part; const int* state; uint64_t seed; float p; int training; int n_items, B, L;
+    const float* W; const float* bias;                        // the launch's weight (W_ih1 / W_out) and bias (W_out only)
+    const float* in; float* out0; float* out1; float* out2;   // kernel-specific tensors, see each kernel
+};
+
+// out0 = X0 [T,64] (written by the blockIdx.y == 0 workgroups), out1 = gi_1 [T, 3H]; W = W_ih1 [3H][64].  grid (tiles, 3H / 64)
+__global__ __launch_bounds__(256) void k_gru_embed_gi(const GruGlueArgs A, const int N3) {
+    constexpr int D = 64, LDA = D + 4;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 16;
+    if (t0 >= T) return;
+    const int n0 = blockIdx.y * 64;
+    float* As = smem;                                   // [16][LDA]
+    WFragT<D, 64> f;
+    wfrag_load(f, A.W + (size_t)n0 * D, D);
+    {
+        const int r = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4, t = t0 + r;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) {
+            const int b = find_seq_from(A.cu, A.B, t, A.tile_seq[t0 >> 4]), pos = t - A.cu[b];
+            const int64_t row = A.rows ? A.rows[b] : b;
+            int64_t id = A.idx[row * A.L + pos];
+            id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
+            o = ld4(A.E + id * D + c);
+            if (A.training && A.p > 0.f) {
+                const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+                const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * A.L + pos) * D + c);
+                o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+            }
+            if (blockIdx.y == 0) st4(A.out0 + (size_t)t * D + c, o);
+        }
+        st4(As + r * LDA + c, o);
+    }
+    lds_barrier();
+    TileAcc<16, 64> acc;
+    tile_zero(acc);
+    tile_mma_frag<16, D, 64>(As, LDA, f, acc);
+    tile_to_global<16, 64>(acc, A.out1 + n0, N3, nullptr, t0, T);
+}
+
+// in = h_top [T,H]; out0 = d y [T,64] (kept for the weight gradient), out1 = d h_top [T,H]; W = W_out [64][H], bias = b_out.  grid (tiles)
+template <int H>
+__global__ __launch_bounds__(256) void k_gru_mid(const GruGlueArgs A) {
+    constexpr int D = 64, LDA = H + 4, LDY = D + 4;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 16, tile = blockIdx.x;
+    if (t0 >= T) return;
+    float* As = smem;                                   // [16][LDA]  h tile
+    float* Ys = As + 16 * LDA;                          // [16][LDY]  y tile, then d y tile
+    float* red = Ys + 16 * LDY;                         // [8]
+    WFragT<H, 64> fy;
+    wfrag_load(fy, A.W, H);
+    load_tile_bm<16, H>(As, LDA, A.in, H, t0, T);
+    lds_barrier();
+    {
+        TileAcc<16, 64> acc;
+        tile_zero(acc);
+        tile_mma_frag<16, H, 64>(As, LDA, fy, acc);
+        tile_to_lds<16, 64>(acc, Ys, LDY, A.bias);
+    }
+    WFragC<D, H> fd;                                    // d h = d y W_out: requested now, the round trip overlaps the scorer
+    wfrag_load(fd, A.W, H);
+    lds_barrier();
+    // ---- scorer: 16 lanes per row (model/basemodel.py:204-214, model/loss_func.py:9-38; same draws / terms as k_score_packed)
+    {
+        const int r = threadIdx.x >> 4, sub = threadIdx.x & 15, c = sub * 4, t = t0 + r;
+        const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], 0.f);
+        float lsum = 0.f, cnt = 0.f;
+        float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) {
+            const int b = find_seq_from(A.cu, A.B, t, A.tile_seq[t0 >> 4]), pos = t - A.cu[b], n = A.cu[b + 1] - A.cu[b];
+            const int64_t row = A.rows ? A.rows[b] : b;
+            const int64_t tgt = A.target[row * A.L + pos];
+            int64_t ng;
+            if (A.sample_neg) {
+                ng = sample_neg_id(rk, (uint64_t)b * A.L + pos, A.n_items);
+                if (sub == 0) A.neg_item[(size_t)b * A.L + pos] = ng;
+            } else {
+                ng = A.neg_item[(size_t)b * A.L + pos];
+            }
+            ng = ng < 0 ? 0 : (ng >= A.n_items ? A.n_items - 1 : ng);
+            if (tgt > 0 && tgt < A.n_items) {
+                const float4 q = ld4(Ys + r * LDY + c), ep = ld4(A.E + tgt * D + c), en = ld4(A.E + ng * D + c);
+                const float sp = group16_sum(q.x * ep.x + q.y * ep.y + q.z * ep.z + q.w * ep.w);
+                const float sn = group16_sum(q.x * en.x + q.y * en.y + q.z * en.z + q.w * en.w);
+                const float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn);
+                if (sub == 0) { lsum += softplus_f(-sp) + softplus_f(sn); cnt += 1.f; }
+                dz = make_float4(dpos * ep.x + dneg * en.x, dpos * ep.y + dneg * en.y, dpos * ep.z + dneg * en.z, dpos * ep.w + dneg * en.w);
+                float* gp = A.dE + tgt * D + c;
+                float* gn = A.dE + ng * D + c;
+                unsafeAtomicAdd(gp, dpos * q.x); unsafeAtomicAdd(gp + 1, dpos * q.y); unsafeAtomicAdd(gp + 2, dpos * q.z); unsafeAtomicAdd(gp + 3, dpos * q.w);
+                unsafeAtomicAdd(gn, dneg * q.x); unsafeAtomicAdd(gn + 1, dneg * q.y); unsafeAtomicAdd(gn + 2, dneg * q.z); unsafeAtomicAdd(gn + 3, dneg * q.w);
+            }
+            st4(A.out0 + (size_t)t * D + c, dz);
+            if (pos == n - 1) {                           // positions behind the sequence (zero query): loss terms only, negatives drawn as the unfused scorer draws them
+                for (int l = n + sub; l < A.L; l += 16) {
+                    const int64_t tl = A.target[row * A.L + l];
+                    if (A.sample_neg) A.neg_item[(size_t)b * A.L + l] = sample_neg_id(rk, (uint64_t)b * A.L + l, A.n_items);
+                    if (tl > 0 && tl < A.n_items) { lsum += 2.0f * 0.69314718055994530942f; cnt += 1.f; }
+                }
+            }
+        }
+        st4(Ys + r * LDY + c, dz);                       // (the lanes of a row have all read their q by now: group16_sum)
+        cnt = wave_sum(cnt); lsum = wave_sum(lsum);
+        if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = cnt; red[2 * (threadIdx.x >> 6) + 1] = lsum; }
+    }
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        A.part[2 * tile] = (red[0] + red[2]) + (red[4] + red[6]);
+        A.part[2 * tile + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+    TileAcc<16, H> acc2;
+    tile_zero(acc2);
+    tile_mma_frag<16, D, H>(Ys, LDY, fd, acc2);
+    tile_to_global<16, H>(acc2, A.out1, H, nullptr, t0, T);
+}
+
+// in = d gi_1 [T, 3H]; W = W_ih1 [3H][64]; scatter into dE.  grid (tiles)
+template <int K>
+__global__ __launch_bounds__(256) void k_gru_dx_embed(const GruGlueArgs A) {
+    constexpr int D = 64, LDA = K + 4;
+    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * 16;
+    if (t0 >= T) return;
+    float* As = smem;                                   // [16][LDA]
+    float* red = As + 16 * LDA;                         // [16][68] the product's tile
+    load_tile_bm<16, K>(As, LDA, A.in, K, t0, T);
+    lds_barrier();
+    {                                                   // (the split-K form measured slower HERE — 19.0 against 15.1 us: 83 workgroups, one per
+        TileAcc<16, 64> acc;                            //  tile, each streaming the whole 196 KB of W_ih1 either way — and faster for the
+        tile_zero(acc);                                 //  N = 256 product between the BPTT launches: 20.7 -> 18.6 us)
+        tile_mma_xw<16, K, 64>(As, LDA, A.W, D, acc);
+        tile_to_lds<16, 64>(acc, red, 68, nullptr);
+    }
+    lds_barrier();
+    const int r = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4, t = t0 + r;
+    float4 g = ld4(red + r * 68 + c);
+    if (t >= T) return;
+    const int b = find_seq_from(A.cu, A.B, t, A.tile_seq[t0 >> 4]), pos = t - A.cu[b];
+    const int64_t row = A.rows ? A.rows[b] : b;
+    const int64_t id = A.idx[row * A.L + pos];
+    if (id <= 0 || id >= A.n_items) return;             // padding_idx / out of range: no gradient row
+    if (A.training && A.p > 0.f) {
+        const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+        const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * A.L + pos) * D + c);
+        g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+    }
+    float* d = A.dE + id * D + c;
+    unsafeAtomicAdd(d, g.x); unsafeAtomicAdd(d + 1, g.y); unsafeAtomicAdd(d + 2, g.z); unsafeAtomicAdd(d + 3, g.w);
+}
+
+// the fused glue applies to what the 16-row latency GEMMs apply to (small batches), D = 64
+static bool gru_glue_fused(const dr4sr_gru4rec_plan* p, int Tmax) {
+    return !DR4SR_ENV("DR4SR_GRU_NOFUSE_GLUE") && !DR4SR_ENV("DR4SR_GRU_GEMM64") && !at_scale(Tmax) && p->D == 64 && (p->H == 128 || p->H == 256);
+}
+
 static int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K, int N,
                        bool colmode, int Tmax, const int* state, hipStream_t s) {
     const size_t lds = sizeof(float) * 64 * 68;
@@ -214,8 +429,12 @@ static int launch_gemm(const float* A, int lda, const float* W, int ldw, const f
     if (colmode && !bias && !at_scale(Tmax) && (K == 768 || K == 384) && N % 64 == 0) {      // small batch, K = 3H: latency tiles
         const size_t l16 = sizeof(float) * 16 * (K + 4);
         dim3 grid((Tmax + 15) / 16, N / 64);
-        if (K == 768) { big_lds(k_gemm16_col<768>, l16); hipLaunchKernelGGL(k_gemm16_col<768>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
-        else { big_lds(k_gemm16_col<384>, l16); hipLaunchKernelGGL(k_gemm16_col<384>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
+        const size_t lsk = l16 + sizeof(float) * 4 * 16 * 68;
+        if (DR4SR_ENV("DR4SR_GRU_NO_SPLITK")) {             // cross-check: one K chain per wave (round 2's kernel)
+            if (K == 768) { big_lds(k_gemm16_col<768>, l16); hipLaunchKernelGGL(k_gemm16_col<768>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
+            else { big_lds(k_gemm16_col<384>, l16); hipLaunchKernelGGL(k_gemm16_col<384>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
+        } else if (K == 768) { big_lds(k_gemm16_col_sk<768>, lsk); hipLaunchKernelGGL(k_gemm16_col_sk<768>, grid, blk, lsk, s, A, lda, W, ldw, C, ldc, state); }
+        else { big_lds(k_gemm16_col_sk<384>, lsk); hipLaunchKernelGGL(k_gemm16_col_sk<384>, grid, blk, lsk, s, A, lda, W, ldw, C, ldc, state); }
         return DR4SR_LAUNCH_CHECK();
     }
     if (N % 128 == 0) {
@@ -240,6 +459,7 @@ struct Wg64Args {
     // one extra job (blockIdx.y == njobs, x == 0): tail[0..1] += the scorer's per-sequence (count, loss) partials, tail[2] += the
     // cooperative recurrence's error word — was a launch of its own (k_sum_score_part, 4.7 us of a 0.49 ms step)
     int njobs; const float* score_part; float* tail; int nscore; const int* err_word;
+    int score_tiles;                                          // 1: one (count, loss) pair per 16-token tile (k_gru_mid) instead of per sequence
 };
 
 // tail[0..1] += sum of the scorer's per-sequence (count, loss) partials
@@ -259,7 +479,7 @@ __device__ __forceinline__ void sum_score_part(const float* __restrict__ part, f
 
 __global__ __launch_bounds__(256) void k_wgrad64(const Wg64Args A) {
     if ((int)blockIdx.y == A.njobs) {
-        if (blockIdx.x == 0) sum_score_part(A.score_part, A.tail, A.nscore, A.err_word, smem);
+        if (blockIdx.x == 0) sum_score_part(A.score_part, A.tail, A.score_tiles && A.nscore ? (A.state[DR4SR_STATE_T] + 15) / 16 : A.nscore, A.err_word, smem);
         return;
     }
     int mi = 0;
@@ -534,25 +754,63 @@ static GruWaveArgs wave_args(const dr4sr_gru4rec_plan* p, const GruWs& ws) {
     return G;
 }
 
-static int gru_forward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int zero_grads, hipStream_t s) {
+static GruGlueArgs glue_args(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training) {
+    GruGlueArgs A{};
+    A.E = p->params + ws.off_E; A.dE = p->grads ? p->grads + ws.off_E : nullptr; A.idx = p->in_item_id; A.target = p->item_id; A.rows = p->rows;
+    A.cu = ws.cu; A.tile_seq = ws.tile_seq; A.neg_item = p->neg_item; A.sample_neg = p->sample_neg; A.part = ws.score_part; A.state = p->state;
+    A.seed = p->seed; A.p = p->p_drop; A.training = training; A.n_items = p->n_items; A.B = p->B; A.L = p->L;
+    return A;
+}
+
+// x = drop(E[idx]) and gi_1 = x W_ih1^T: one launch in the latency regime (k_gru_embed_gi), else gather + GEMM
+static int gru_embed_gi(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, hipStream_t s) {
     const int D = p->D, H = p->H;
-    RC(launch_prep_raw(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, training ? 1 : 0, zero_grads ? p->grads : nullptr,
-                       ws.n_params + DR4SR_GRAD_TAIL, s));
+    if (gru_glue_fused(p, ws.Tmax)) {
+        GruGlueArgs A = glue_args(p, ws, training);
+        A.W = p->params + ws.off_wih[0]; A.out0 = ws.X0; A.out1 = ws.layer[0].gi;
+        hipLaunchKernelGGL(k_gru_embed_gi, dim3((ws.Tmax + 15) / 16, 3 * H / 64), dim3(256), sizeof(float) * 16 * (D + 4), s, A, 3 * H);
+        return DR4SR_LAUNCH_CHECK();
+    }
     RC(launch_embed_fwd_raw(p->params + ws.off_E, nullptr, p->in_item_id, p->rows, ws.cu, ws.X0, p->B, p->L, D, p->n_items, p->state,
                             p->seed, p->p_drop, training, s));
+    return launch_gemm(ws.X0, D, p->params + ws.off_wih[0], D, nullptr, ws.layer[0].gi, 3 * H, D, 3 * H, false, ws.Tmax, p->state, s);
+}
+
+// the step's prep: [batch selection,] prefix scan of the lengths, tile -> sequence hints, RNG step, zeroed gradient
+static int gru_prep_args(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, bool select, PrepArgs* out) {
+    PermSel sel{nullptr, 0, 0, 0, nullptr};
+    if (p->perm && select) {                                // batch selection only in the call that starts a training step
+        if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
+        sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
+    }
+    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, training ? 1 : 0, sel, ws.tile_seq, nullptr, nullptr};
+    return 0;
+}
+static int gru_prep(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int zero_grads, hipStream_t s) {
+    PrepArgs P;
+    RC(gru_prep_args(p, ws, training, training && zero_grads, &P));
+    return launch_prep_raw_hints(p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, P.bump_rng, zero_grads ? p->grads : nullptr,
+                                 ws.n_params + DR4SR_GRAD_TAIL, ws.tile_seq, P.sel, s);
+}
+
+static int gru_forward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int zero_grads, hipStream_t s, bool skip_out = false,
+                       bool prepared = false) {
+    const int D = p->D, H = p->H;
+    if (!prepared) RC(gru_prep(p, ws, training, zero_grads, s));
+    RC(gru_embed_gi(p, ws, training, s));
     const float* in = ws.X0;
     int K = D;
     if (p->n_layer == 2) {                                  // both layers' recurrences in one launch (gru_coop.hip, layer wavefront)
-        RC(launch_gemm(in, K, p->params + ws.off_wih[0], K, nullptr, ws.layer[0].gi, 3 * H, K, 3 * H, false, ws.Tmax, p->state, s));
         const int rc = launch_gru_wave(wave_args(p, ws), ws.xch, ws.ctl, p->B, H, p->L, false, s);
         if (rc != -100) {
             RC(rc);
+            if (skip_out) return 0;                         // (the fused mid launch forms y itself)
             return launch_gemm(ws.layer[1].hout, H, p->params + ws.off_ow, H, p->params + ws.off_ob, ws.Y, D, H, D, false, ws.Tmax, p->state, s);
         }
     }
     for (int l = 0; l < p->n_layer; ++l) {
         const GruLayerWs& w = ws.layer[l];
-        if (!(l == 0 && p->n_layer == 2))                  // (two layers: gi_1 is there already, see above)
+        if (l > 0)                                          // (gi_1 is there already: gru_embed_gi)
             RC(launch_gemm(in, K, p->params + ws.off_wih[l], K, nullptr, w.gi, 3 * H, K, 3 * H, false, ws.Tmax, p->state, s));
         GruRecArgs A{};
         A.gi = w.gi; A.whh = p->params + ws.off_whh[l]; A.cu = ws.cu; A.r = w.r; A.z = w.z; A.n = w.n; A.ghn = w.ghn;
@@ -561,19 +819,55 @@ static int gru_forward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int trainin
         in = w.hout;
         K = H;
     }
+    if (skip_out) return 0;
     return launch_gemm(in, H, p->params + ws.off_ow, H, p->params + ws.off_ob, ws.Y, D, H, D, false, ws.Tmax, p->state, s);
 }
 
-static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int with_score, hipStream_t s) {
+// output projection + scorer / BCE + d h_top in one launch (training step, latency regime); returns -100 when it does not apply
+static int gru_mid(const dr4sr_gru4rec_plan* p, const GruWs& ws, hipStream_t s) {
+    if (!gru_glue_fused(p, ws.Tmax)) return -100;
+    const int H = p->H;
+    GruGlueArgs A = glue_args(p, ws, 1);
+    A.W = p->params + ws.off_ow; A.bias = p->params + ws.off_ob; A.in = ws.layer[p->n_layer - 1].hout; A.out0 = ws.dY; A.out1 = ws.dH;
+    const size_t lds = sizeof(float) * (16 * (H + 4) + 16 * 68 + 8);
+    dim3 grid((ws.Tmax + 15) / 16);
+    if (H == 256) hipLaunchKernelGGL(k_gru_mid<256>, grid, dim3(256), lds, s, A);
+    else hipLaunchKernelGGL(k_gru_mid<128>, grid, dim3(256), lds, s, A);
+    return DR4SR_LAUNCH_CHECK();
+}
+
+// d x = d gi_1 W_ih1 and the embedding-table scatter: one launch in the latency regime (k_gru_dx_embed), else GEMM + scatter
+static int gru_dx_embed(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, hipStream_t s) {
+    const int D = p->D, H = p->H;
+    if (gru_glue_fused(p, ws.Tmax)) {
+        GruGlueArgs A = glue_args(p, ws, training);
+        A.W = p->params + ws.off_wih[0]; A.in = ws.layer[0].dgi;
+        dim3 grid((ws.Tmax + 15) / 16);
+        if (H == 256) {
+            const size_t lds = sizeof(float) * (16 * (768 + 4) + 16 * 68);
+            big_lds(k_gru_dx_embed<768>, lds);
+            hipLaunchKernelGGL(k_gru_dx_embed<768>, grid, dim3(256), lds, s, A);
+        } else {
+            const size_t lds = sizeof(float) * (16 * (384 + 4) + 16 * 68);
+            hipLaunchKernelGGL(k_gru_dx_embed<384>, grid, dim3(256), lds, s, A);
+        }
+        return DR4SR_LAUNCH_CHECK();
+    }
+    RC(launch_gemm(ws.layer[0].dgi, 3 * H, p->params + ws.off_wih[0], D, nullptr, ws.dX0, D, 3 * H, D, true, ws.Tmax, p->state, s));
+    return launch_embed_bwd_raw(ws.dX0, p->in_item_id, p->rows, ws.cu, p->grads + ws.off_E, nullptr, p->B, p->L, D, p->n_items, p->state,
+                                p->seed, p->p_drop, training, s);
+}
+
+// mid_done: d h_top is in ws.dH already and the scorer's partials are per token tile (gru_mid)
+static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, int with_score, hipStream_t s, bool mid_done = false) {
     const int D = p->D, H = p->H, nl = p->n_layer;
     // dH_top = dY W_out
-    RC(launch_gemm(ws.dY, D, p->params + ws.off_ow, H, nullptr, ws.dH, H, D, H, true, ws.Tmax, p->state, s));
+    if (!mid_done) RC(launch_gemm(ws.dY, D, p->params + ws.off_ow, H, nullptr, ws.dH, H, D, H, true, ws.Tmax, p->state, s));
     int l_top = nl - 1;
     if (nl == 2) {                                          // both BPTTs in one launch; dh_1 = dgi_2 W_ih2 is formed inside it
         const int rc = launch_gru_wave(wave_args(p, ws), ws.xch, ws.ctl, p->B, H, p->L, true, s);
         if (rc != -100) {
             RC(rc);
-            RC(launch_gemm(ws.layer[0].dgi, 3 * H, p->params + ws.off_wih[0], D, nullptr, ws.dX0, D, 3 * H, D, true, ws.Tmax, p->state, s));
             l_top = -1;
         }
     }
@@ -585,10 +879,8 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
         RC(launch_gru_rec(A, H, true, s, ws.xch, ws.ctl));
         // d(input of this layer) = dgi W_ih
         if (l > 0) RC(launch_gemm(w.dgi, 3 * H, p->params + ws.off_wih[l], H, nullptr, ws.dH, H, 3 * H, H, true, ws.Tmax, p->state, s));
-        else RC(launch_gemm(w.dgi, 3 * H, p->params + ws.off_wih[0], D, nullptr, ws.dX0, D, 3 * H, D, true, ws.Tmax, p->state, s));
     }
-    RC(launch_embed_bwd_raw(ws.dX0, p->in_item_id, p->rows, ws.cu, p->grads + ws.off_E, nullptr, p->B, p->L, D, p->n_items, p->state,
-                            p->seed, p->p_drop, training, s));
+    RC(gru_dx_embed(p, ws, training, s));
     // weight gradients: one 64x64 output tile per job (jobs decoded in-kernel from per-matrix descriptors)
     Wg64Args WA{};
     int nj = 0;
@@ -613,27 +905,65 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     if (gw > ntiles) gw = ntiles;
     // with_score == 0 (autograd path): no scorer partials to add, the extra job only forwards the recurrence's error word
     WA.njobs = nj; WA.score_part = ws.score_part; WA.tail = p->grads + ws.n_params; WA.nscore = with_score ? p->B : 0; WA.err_word = ws.ctl + 2;
+    WA.score_tiles = mid_done ? 1 : 0;
     hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj + 1), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
     return DR4SR_LAUNCH_CHECK();
 }
 
+// everything of a training step between the prep and the optimizer (prepared: the previous optimizer launch ran this step's prep)
+static int gru_fwd_bwd_core(const dr4sr_gru4rec_plan* plan, const GruWs& ws, hipStream_t s, bool prepared);
 extern "C" int dr4sr_gru4rec_fwd_bwd(const dr4sr_gru4rec_plan* plan, void* stream) {
     GruWs ws;
     RC(gru_ws(plan, &ws));
     if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    RC(gru_forward(plan, ws, 1, 1, s));
+    return gru_fwd_bwd_core(plan, ws, (hipStream_t)stream, false);
+}
+static int gru_fwd_bwd_core(const dr4sr_gru4rec_plan* plan, const GruWs& ws, hipStream_t s, bool prepared) {
+    const bool fused_mid = gru_glue_fused(plan, ws.Tmax);
+    RC(gru_forward(plan, ws, 1, 1, s, fused_mid, prepared));
+    if (fused_mid) {
+        RC(gru_mid(plan, ws, s));
+        return gru_backward(plan, ws, 1, 1, s, true);
+    }
     RC(launch_score_packed_raw(ws.Y, plan->params + ws.off_E, plan->grads + ws.off_E, ws.dY, plan->item_id, plan->rows, ws.cu,
                                plan->neg_item, plan->sample_neg, ws.score_part, plan->state, plan->seed, plan->n_items, plan->B,
                                plan->L, plan->D, s));
     return gru_backward(plan, ws, 1, 1, s);
 }
 
+extern "C" int dr4sr_gru4rec_adam_step(const dr4sr_gru4rec_plan* plan, void* stream) {
+    if (!plan || plan->abi_version != DR4SR_ABI_VERSION || !plan->params || !plan->grads || !plan->state) return DR4SR_E_ARG;
+    return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
+                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream, plan->loss_log,
+                            plan->perm ? plan->perm_counter : nullptr, nullptr, plan->optimizer);
+}
+
 extern "C" int dr4sr_gru4rec_train_step(const dr4sr_gru4rec_plan* plan, void* stream) {
     RC(dr4sr_gru4rec_fwd_bwd(plan, stream));
-    return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
-                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream, nullptr, nullptr, nullptr,
-                            plan->optimizer);
+    return dr4sr_gru4rec_adam_step(plan, stream);
+}
+
+// n consecutive training steps (consecutive batches of plan->perm when it is set): ONE prep launch for the first step, every
+// optimizer launch but the last also prepares the step that follows it (k_adam's extra workgroup: batch selection, prefix scan, hints,
+// RNG step; the gradient words are zeroed as they are consumed) — dr4sr_sasrec_train_steps' contract.  A prep launch per step was
+// 7 us of the 0.47 ms step at B = 256.
+extern "C" int dr4sr_gru4rec_train_steps(const dr4sr_gru4rec_plan* plan, int32_t n_steps, void* stream) {
+    GruWs ws;
+    RC(gru_ws(plan, &ws));
+    if (n_steps <= 0 || !plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PrepArgs next;
+    RC(gru_prep_args(plan, ws, 1, true, &next));
+    const bool fuse = DR4SR_ENV("DR4SR_NO_PREP_FUSE") == nullptr;
+    RC(gru_prep(plan, ws, 1, 1, s));
+    for (int i = 0; i < n_steps; ++i) {
+        RC(gru_fwd_bwd_core(plan, ws, s, i == 0 || fuse));      // (step 0: the launch above; later steps: the previous optimizer launch)
+        const bool last = i == n_steps - 1;
+        RC(launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr, plan->beta1,
+                            plan->beta2, plan->adam_eps, plan->weight_decay, s, plan->loss_log, plan->perm ? plan->perm_counter : nullptr,
+                            (last || !fuse) ? nullptr : &next, plan->optimizer));
+    }
+    return 0;
 }
 
 extern "C" int dr4sr_gru4rec_encode(const dr4sr_gru4rec_plan* plan, int32_t training, int32_t pooling, float* out, void* stream) {

@@ -200,6 +200,8 @@ struct GruWaveArgs {
 // raw (plan-independent) launchers shared with the GRU4Rec path
 int launch_prep_raw(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
                     int64_t zero_floats, hipStream_t s);
+int launch_prep_raw_hints(const int64_t* seqlen, const int64_t* rows, int* cu, int* state, int B, int L, int bump_rng, float* zero,
+                          int64_t zero_floats, int* tile_seq, const PermSel& sel, hipStream_t s);
 int launch_embed_fwd_raw(const float* E, const float* P, const int64_t* idx, const int64_t* rows, const int* cu, float* X, int B,
                          int L, int D, int n_items, const int* state, uint64_t seed, float p, int training, hipStream_t s);
 int launch_embed_bwd_raw(const float* dX, const int64_t* idx, const int64_t* rows, const int* cu, float* dE, float* dP, int B, int L,

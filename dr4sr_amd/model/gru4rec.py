@@ -99,6 +99,8 @@ class GRU4Rec(BaseModel):
     def _api_plan(self):
         return None
 
-    def _train_plan(self, fields, rows):
+    _supports_perm_sel = True          # round 4: batch selection fused into the step's first kernel (k steps per graph, no per-step rows copy)
+
+    def _train_plan(self, fields, rows, perm_sel=None, loss_log=None):
         return self.engine.make_plan(fields["in_item_id"], fields["item_id"], fields["seqlen"], rows=rows, neg_item=self._neg_buf,
-                                     sample_neg=True)
+                                     sample_neg=True, perm_sel=perm_sel, loss_log=loss_log)

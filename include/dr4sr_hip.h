@@ -317,6 +317,11 @@ typedef struct dr4sr_gru4rec_plan {
     int32_t* state;
     float lr, beta1, beta2, adam_eps, weight_decay;
     int32_t optimizer;              /* DR4SR_OPT_* (ABI 6) */
+    /* ---- fused batch selection + per-step loss log (ABI 6; same contract as dr4sr_sasrec_plan's perm / loss_log fields): when
+     *      perm != NULL the step's first kernel FILLS rows[i] = perm[(c * perm_stride + perm_offset + i) mod n_perm] with
+     *      c = *perm_counter and bumps the counter; dr4sr_gru4rec_train_step / _adam_step write loss_log[c] = loss_sum / n_valid ---- */
+    const int64_t* perm; int64_t n_perm; int64_t perm_stride; int64_t perm_offset; int32_t* perm_counter;
+    float* loss_log;
 } dr4sr_gru4rec_plan;
 
 int     dr4sr_gru4rec_plan_sizeof(void);
@@ -330,6 +335,12 @@ int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_t H, int32_
  * treat non-zero as a failed run. */
 /* bytes, or DR4SR_E_SHAPE unless D = 64, H in {128, 256}, L <= 64 */
 int64_t dr4sr_gru4rec_workspace_bytes(const dr4sr_gru4rec_plan* plan);
+/* the optimizer half of dr4sr_gru4rec_train_step on the plan's buffers (plan->optimizer, loss_log): data parallel = fwd_bwd,
+ * all-reduce of plan->grads, this */
+int dr4sr_gru4rec_adam_step(const dr4sr_gru4rec_plan* plan, void* stream);
+/* n consecutive training steps, one prep launch: every optimizer launch but the last prepares the following step (see
+ * dr4sr_sasrec_train_steps) */
+int dr4sr_gru4rec_train_steps(const dr4sr_gru4rec_plan* plan, int32_t n_steps, void* stream);
 /* 1 when a batch of B sequences takes the cooperative multi-CU recurrence on the CURRENT device (its 8*ceil(B/16) workgroups must be
  * co-resident: the budget is 3/4 of the device's compute units, at most 192, and 0 under DR4SR_GRU_NOCOOP), 0 for the
  * single-workgroup recurrence.  A timeout of the cooperative exchange also POISONS the step: the gradient tail word grads[n_params+2]

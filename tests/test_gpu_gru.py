@@ -138,3 +138,43 @@ def _gru_case(B, H, NL, L):
     assert n == int((b["item_id"] != 0).sum()) and abs(loss - float(loss_o)) < 3e-5
     for k, gv in eng.normalized_grads().items():
         assert relerr(gv, grads_o[k]) < REL, k
+
+
+@pytest.mark.parametrize("nofuse", [False, True])
+def test_gru4rec_train_steps_equal_repeated_single_steps(monkeypatch, nofuse):
+    """round 4: dr4sr_gru4rec_train_steps — device-side batch selection from the epoch permutation (plan->perm), ONE prep launch, every
+    optimizer launch preparing the next step, per-step loss log — against n single dr4sr_gru4rec_train_step calls on the same plan
+    (dropout 0.2, in-kernel negatives: same Philox streams); DR4SR_NO_PREP_FUSE = a prep launch per step inside train_steps"""
+    from dr4sr_amd.data.synthetic import make_rows
+    from dr4sr_amd.gru_engine import GruEngine, gru_param_names, gru_param_shapes
+    if nofuse:
+        monkeypatch.setenv("DR4SR_NO_PREP_FUSE", "1")
+    N, U, B, H, n = 3000, 700, 96, 256, 5
+    rows = make_rows(n_rows=U, n_items=N, seed=8)
+    gen = torch.Generator().manual_seed(2)
+    params = {nme: 0.08 * torch.randn(shp, generator=gen) for nme, shp in zip(gru_param_names(2), gru_param_shapes(N, 64, H, 2))}
+    params["item_embedding.weight"][0] = 0
+    out = []
+    for mode in ("steps", "single"):
+        eng = GruEngine(N, 50, 64, H, 2, 0.2, B, "cuda", seed=5, lr=1e-3, weight_decay=1e-4)
+        eng.load_named(params)
+        dev = eng.device
+        data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
+        perm = torch.randperm(U, generator=torch.Generator().manual_seed(3)).to(dev)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        rows_buf = torch.zeros(B, dtype=torch.int64, device=dev)
+        log = torch.zeros(16, dtype=torch.float32, device=dev)
+        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=rows_buf, sample_neg=True,
+                             perm_sel=(perm, B, 0, counter), loss_log=log)
+        if mode == "steps":
+            eng.train_steps(plan, n)
+        else:
+            for _ in range(n):
+                eng.train_step(plan)
+        eng.check_device_error()
+        assert int(counter) == n and int(eng.state[0]) == n
+        assert torch.equal(rows_buf, perm[(n - 1) * B:n * B])              # the last step's batch
+        out.append((eng.params.clone(), log.clone()))
+    (pa, la), (pb, lb) = out
+    assert float(la[:n].min()) > 0 and torch.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
+    assert float((pa - pb).abs().max()) < 2e-5 * float(pb.abs().max())      # fp32 atomics order only

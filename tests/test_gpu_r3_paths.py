@@ -148,18 +148,23 @@ def test_gru4rec_partial_batch_in_the_workspace_of_a_larger_one():
         assert relerr(out[(300, 256)][k], v) < 2e-5, k
 
 
-@pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1", "DR4SR_GRU_FWD_F32": "1"}],
-                         ids=["one-launch-per-layer", "backward-wavefront", "round-2-kernels"])
+@pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1", "DR4SR_GRU_FWD_F32": "1"},
+                                 {"DR4SR_GRU_NOFUSE_GLUE": "1"}, {"DR4SR_GRU_WAVE_ORDER": "0"}],
+                         ids=["one-launch-per-layer", "backward-wavefront", "round-2-kernels", "separate-glue-launches", "round-3-role-order"])
 def test_gru4rec_wavefront_switches_vs_oracle(env, monkeypatch):
     """Two-layer plans run both forward recurrences in one launch by default (layer wavefront, csrc/gru_coop.hip); DR4SR_GRU_NOWAVE = the
     one-launch-per-layer form, DR4SR_GRU_WAVE_BWD = the (opt-in, not faster) one-launch backward, DR4SR_GRU_BWD_F32 = the fp32-MFMA BPTT with
     W_hh in LDS instead of the bf16x3 one with W_hh in registers (k_gru_bwd_coop_bf; DR4SR_GRU_FWD_F32 likewise for the single-layer forward).
     The oracle tests that reach them — BASELINE configs[2] exactly, odd batch sizes, chunks of 256 with a ragged last chunk, the second bank
-    of cooperative groups — re-run in this process with the switch set (dr4sr_reload_env through conftest's monkeypatch hook)"""
+    of cooperative groups — re-run in this process with the switch set (dr4sr_reload_env through conftest's monkeypatch hook).
+    Round 4: DR4SR_GRU_NOFUSE_GLUE = the separate embed / projection / scorer / scatter launches instead of k_gru_embed_gi, k_gru_mid,
+    k_gru_dx_embed; DR4SR_GRU_WAVE_ORDER=0 = round 3's block -> role order of the forward wavefront."""
     import test_gpu_gru as G
     import test_gpu_r2_paths as R2
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    if "DR4SR_GRU_NOFUSE_GLUE" in env:                        # round 4: the fused glue launches are the default; their dropout masks too
+        G.test_gru4rec_full_size_vs_oracle(False)
     test_gru4rec_baseline_config2_exact_size_vs_oracle()
     for B in (1, 17, 100):
         G.test_gru4rec_odd_batch_sizes_vs_oracle(B)

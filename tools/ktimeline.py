@@ -9,7 +9,7 @@ c = sqlite3.connect(sys.argv[1])
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 # a step ends with its optimizer launch (k_adam); since dr4sr_sasrec_train_steps only the first step of a graph has its own k_prep
-ends = [i for i, r in enumerate(rows) if r[0].startswith("k_adam")]
+ends = [i for i, r in enumerate(rows) if r[0].startswith("k_adam") or r[0].startswith("void k_adam")]
 steps = [(ends[i] + 1, ends[i + 1] + 1) for i in range(len(ends) - 1)]
 lens = {}
 for a, b in steps:
