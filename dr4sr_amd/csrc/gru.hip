@@ -15,6 +15,7 @@
 // each step bounds a workgroup at ~10 us per step on the fp32 MFMA pipe.
 #include "common.h"
 #include "kernels.h"
+#include "wgrad_bf.h"
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -477,6 +478,24 @@ __device__ __forceinline__ void sum_score_part(const float* __restrict__ part, f
     if (threadIdx.x == 0) { tail[0] += red[0]; tail[1] += red[256]; if (err_word && *err_word) tail[2] += 1.0f; }
 }
 
+// The same launch with every 64 x 64 job on the bf16 matrix cores as a 3-term split (wgrad_bf.h, round 4): the fp32 form runs 1.7 GFLOP
+// of v_mfma_f32_32x32x2_f32 at B = 256 — 30 us, a third of the fp32 matrix peak — and is the largest launch of the step after the
+// recurrences; max-norm error of the split 5e-6 of the fp32 product (DR4SR_WGRAD_F32 = the fp32 kernel, tested).
+__global__ __launch_bounds__(256) void k_wgrad64_bf(const Wg64Args A) {
+    if ((int)blockIdx.y == A.njobs) {
+        if (blockIdx.x == 0) sum_score_part(A.score_part, A.tail, A.score_tiles && A.nscore ? (A.state[DR4SR_STATE_T] + 15) / 16 : A.nscore, A.err_word, smem);
+        return;
+    }
+    int mi = 0;
+    for (int m = 1; m < A.nmat; ++m) if ((int)blockIdx.y >= A.mat[m].start) mi = m;
+    const Wg64Mat M = A.mat[mi];
+    const int local = blockIdx.y - M.start, nkb = M.KX / 64, n0 = (local / nkb) * 64, k0 = (local % nkb) * 64;
+    WgradJob J;
+    J.G = M.G; J.ldg = M.ldg; J.gcol = n0; J.X = M.X + k0; J.ldx = M.ldx;
+    J.dW = M.dW + (size_t)n0 * M.KX + k0; J.ldw = M.KX; J.db = (M.db && k0 == 0) ? M.db + n0 : nullptr;
+    wgrad_body_bf<64, 64>(J, A.state);
+}
+
 __global__ __launch_bounds__(256) void k_wgrad64(const Wg64Args A) {
     if ((int)blockIdx.y == A.njobs) {
         if (blockIdx.x == 0) sum_score_part(A.score_part, A.tail, A.score_tiles && A.nscore ? (A.state[DR4SR_STATE_T] + 15) / 16 : A.nscore, A.err_word, smem);
@@ -901,12 +920,16 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     const int gwf = DR4SR_ENV("DR4SR_GRU_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_GRU_WGRAD_GW")) : 0;     // tuning knob
     // token-tile splits per 64x64 output tile: every split ends in 4 096 atomics, so fewer, longer splits at small batches (B = 256: 6
     // instead of 12 is worth 0.8 % of the step; 2 is too few workgroups)
-    int gw = gwf > 0 ? gwf : (ntiles / 32 > 6 ? (ntiles / 32 > 32 ? 32 : ntiles / 32) : 6);
+    // (bf16x3 jobs: the MFMA phase is 2.7x shorter, the 4 096-atomic tail is not — half as many splits: B = 256 6 -> 3 is worth 0.7 % of the step)
+    const bool wg_f32 = DR4SR_ENV("DR4SR_WGRAD_F32") != nullptr;
+    const int gdiv = wg_f32 ? 32 : 64, glo = wg_f32 ? 6 : 3;
+    int gw = gwf > 0 ? gwf : (ntiles / gdiv > glo ? (ntiles / gdiv > 32 ? 32 : ntiles / gdiv) : glo);
     if (gw > ntiles) gw = ntiles;
     // with_score == 0 (autograd path): no scorer partials to add, the extra job only forwards the recurrence's error word
     WA.njobs = nj; WA.score_part = ws.score_part; WA.tail = p->grads + ws.n_params; WA.nscore = with_score ? p->B : 0; WA.err_word = ws.ctl + 2;
     WA.score_tiles = mid_done ? 1 : 0;
-    hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj + 1), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
+    if (wg_f32) hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj + 1), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
+    else hipLaunchKernelGGL(k_wgrad64_bf, dim3(gw, nj + 1), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
     return DR4SR_LAUNCH_CHECK();
 }
 

@@ -149,8 +149,9 @@ def test_gru4rec_partial_batch_in_the_workspace_of_a_larger_one():
 
 
 @pytest.mark.parametrize("env", [{"DR4SR_GRU_NOWAVE": "1"}, {"DR4SR_GRU_WAVE_BWD": "1"}, {"DR4SR_GRU_NOWAVE": "1", "DR4SR_GRU_BWD_F32": "1", "DR4SR_GRU_FWD_F32": "1"},
-                                 {"DR4SR_GRU_NOFUSE_GLUE": "1"}, {"DR4SR_GRU_WAVE_ORDER": "0"}],
-                         ids=["one-launch-per-layer", "backward-wavefront", "round-2-kernels", "separate-glue-launches", "round-3-role-order"])
+                                 {"DR4SR_GRU_NOFUSE_GLUE": "1"}, {"DR4SR_GRU_WAVE_ORDER": "0"}, {"DR4SR_WGRAD_F32": "1", "DR4SR_GRU_NO_SPLITK": "1"}],
+                         ids=["one-launch-per-layer", "backward-wavefront", "round-2-kernels", "separate-glue-launches", "round-3-role-order",
+                              "fp32-weight-gradients"])
 def test_gru4rec_wavefront_switches_vs_oracle(env, monkeypatch):
     """Two-layer plans run both forward recurrences in one launch by default (layer wavefront, csrc/gru_coop.hip); DR4SR_GRU_NOWAVE = the
     one-launch-per-layer form, DR4SR_GRU_WAVE_BWD = the (opt-in, not faster) one-launch backward, DR4SR_GRU_BWD_F32 = the fp32-MFMA BPTT with
@@ -158,7 +159,8 @@ def test_gru4rec_wavefront_switches_vs_oracle(env, monkeypatch):
     The oracle tests that reach them — BASELINE configs[2] exactly, odd batch sizes, chunks of 256 with a ragged last chunk, the second bank
     of cooperative groups — re-run in this process with the switch set (dr4sr_reload_env through conftest's monkeypatch hook).
     Round 4: DR4SR_GRU_NOFUSE_GLUE = the separate embed / projection / scorer / scatter launches instead of k_gru_embed_gi, k_gru_mid,
-    k_gru_dx_embed; DR4SR_GRU_WAVE_ORDER=0 = round 3's block -> role order of the forward wavefront."""
+    k_gru_dx_embed; DR4SR_GRU_WAVE_ORDER=0 = round 3's block -> role order of the forward wavefront; DR4SR_WGRAD_F32 = k_wgrad64 on the fp32
+    matrix cores instead of the bf16x3 split, DR4SR_GRU_NO_SPLITK = the one-chain K = 3H data-gradient GEMM."""
     import test_gpu_gru as G
     import test_gpu_r2_paths as R2
     for k, v in env.items():
