@@ -125,12 +125,13 @@ def hypergrad_exact(f, p: Dict[str, torch.Tensor], meta: Dict[str, torch.Tensor]
 
 
 def hypergrad_fd(f, p, meta, bt, bv, gumbel, tau, tau_min, hpo_lr: float, truncate_iter: int = 3, rel_step: float = 1e-2,
-                 dtype=torch.float32, richardson: bool = False):
+                 dtype=torch.float32, richardson: bool = False, forward_hvp: bool = False):
     """The same quantity from FIRST-ORDER gradients only (what the HIP path does, dr4sr_amd/model/metamodel.py):
          H v          ~ [G(W + e v) - G(W - e v)] / 2e,        G = dL_train/dW      (Neumann terms, scaled by hpo_lr)
          d/dphi(G.p)  ~ [dL_train/dphi(W + e p) - dL_train/dphi(W - e p)] / 2e
        with e = rel_step * |W| / |direction| and the meta-module's ReLU pattern frozen at W.
-       richardson=True (the product's default): the mixed term as (4 D(e) - D(2e)) / 3 over probes at +-e and +-2e."""
+       richardson=True (the product's default): the mixed term as (4 D(e) - D(2e)) / 3 over probes at +-e and +-2e.
+       forward_hvp=True (the product's default since round 4): the Neumann terms from ONE-sided differences against G(W)."""
     P = {k: v.detach().to(dtype).clone() for k, v in p.items()}
     M = {k: v.detach().to(dtype).clone() for k, v in meta.items()}
     names = list(P)
@@ -157,10 +158,15 @@ def hypergrad_fd(f, p, meta, bt, bv, gumbel, tau, tau_min, hpo_lr: float, trunca
     wn = norm(P)
     v = {k: g.clone() for k, g in gval.items()}
     pacc = {k: g.clone() for k, g in gval.items()}
+    g0 = first_order(P, False) if forward_hvp else None
     for _ in range(truncate_iter):
         e = rel_step * wn / max(norm(v), 1e-30)
-        gp, gm = first_order(shifted(v, e), False), first_order(shifted(v, -e), False)
-        v = {k: v[k] - hpo_lr * (gp[k] - gm[k]) / (2 * e) for k in names}
+        if forward_hvp:                                    # H v ~ [G(W + e v) - G(W)] / e: one probe per Neumann term (they enter scaled by hpo_lr)
+            gp = first_order(shifted(v, e), False)
+            v = {k: v[k] - hpo_lr * (gp[k] - g0[k]) / e for k in names}
+        else:
+            gp, gm = first_order(shifted(v, e), False), first_order(shifted(v, -e), False)
+            v = {k: v[k] - hpo_lr * (gp[k] - gm[k]) / (2 * e) for k in names}
         pacc = {k: pacc[k] + v[k] for k in names}
     e = rel_step * wn / max(norm(pacc), 1e-30)
     def central(h):

@@ -68,14 +68,16 @@ def test_hypergradient_exact_and_meta_sgd(golden_dir):
             np.testing.assert_allclose(M[k].numpy(), g[f"outer.step{s}.{k}"], rtol=1e-5, atol=2e-7)
 
 
+@pytest.mark.parametrize("forward_hvp", [False, True])
 @pytest.mark.parametrize("rel_step", [3e-4, 1e-3])
-def test_first_order_formulation_matches_exact(golden_dir, rel_step):
-    """the finite-difference form used on the GPU reproduces the reference's double-backward hyper-gradient"""
+def test_first_order_formulation_matches_exact(golden_dir, rel_step, forward_hvp):
+    """the finite-difference form used on the GPU reproduces the reference's double-backward hyper-gradient; forward_hvp (round 4, the
+    product's default for BCE sub-models): the three Neumann terms from one-sided differences against G(W) — they enter scaled by hpo_lr"""
     g, p, meta, bt, bv, cfg = load_meta(golden_dir)
     f = MO.sasrec_losses(cfg)
     gum = torch.from_numpy(g["inner.gumbel"])
     tau, tmin, hlr = float(g["meta.tau"][0]), float(g["meta.tau_min"]), float(g["meta.hpo_learning_rate"])
-    hg, _, pacc = MO.hypergrad_fd(f, p, meta, bt, bv, gum, tau, tmin, hlr, rel_step=rel_step)
+    hg, _, pacc = MO.hypergrad_fd(f, p, meta, bt, bv, gum, tau, tmin, hlr, rel_step=rel_step, forward_hvp=forward_hvp)
     flat = lambda d: np.concatenate([np.asarray(d[k]).ravel() for k in MO.META_NAMES])
     ref = np.concatenate([g["outer.hypergrad." + k].ravel() for k in MO.META_NAMES])
     err = rel(flat({k: v.numpy() for k, v in hg.items()}), ref)
