@@ -1747,14 +1747,44 @@ __global__ __launch_bounds__(256) void k_fmlp_wgrad(const WgradArgs A) {
     if (j == 0) wgrad_body<256, 64>(J, A);
     else wgrad_body<64, 256>(J, A);
 }
+// the two FFN weight-gradient jobs on the bf16 matrix cores as a 3-term split (round 4; wgrad_bf.h): the fp32 form was 37 us of FMLP's
+// 0.215 ms step at B = 256 (12 800 positions).  DR4SR_WGRAD_F32: the fp32 kernel (cross-check)
+__global__ __launch_bounds__(256) void k_fmlp_wgrad_bf(const WgradArgs A) {
+    const int j = blockIdx.y;
+    if (j == 2) { reduce_jobs_fmlp(A); if (A.fc_dm) fmlp_coef_bwd_job(A); return; }
+    const WgradJob& J = A.job[blockIdx.z * 6 + 4 + j];
+    if (j == 0) wgrad_body_bf<256, 64>(J, A.state);
+    else wgrad_body_bf<64, 256>(J, A.state);
+}
+// ... and as 64 x 64 blocks (the k_wgrad_bf64 idea: 32 KB of LDS instead of 80, four workgroups per CU): blockIdx.y 0..3 = the row
+// blocks of dW1 [256 x 64], 4..7 = the column blocks of dW2 [64 x 256], 8 = the reduce jobs
+__global__ __launch_bounds__(256) void k_fmlp_wgrad_bf64(const WgradArgs A) {
+    const int j = blockIdx.y;
+    if (j == 8) { reduce_jobs_fmlp(A); if (A.fc_dm) fmlp_coef_bwd_job(A); return; }
+    WgradJob J = A.job[blockIdx.z * 6 + 4 + (j >= 4 ? 1 : 0)];
+    if (j < 4) { J.gcol += 64 * j; J.dW += (size_t)64 * j * 64; J.ldw = 64; if (J.db) J.db += 64 * j; }
+    else { const int kb = j - 4; J.X += 64 * kb; J.dW += 64 * kb; J.ldw = 256; if (kb) J.db = nullptr; }
+    wgrad_body_bf<64, 64>(J, A.state);
+}
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) {
     const int ntiles = (Tmax + 63) / 64;
     const int gwf = DR4SR_ENV("DR4SR_FMLP_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_FMLP_WGRAD_GW")) : 0;     // tuning knob
     int gw_t = gwf > 0 ? gwf : (ntiles / 16 > 64 ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : 64);   // 64: every CU holds one heavy workgroup at B = 256 (48: 37.6 us, 64: 35.4)
+    // (64 x 64 bf16x3 blocks, the default: 16 block jobs per layer pair instead of 4 whole ones -> fewer token splits: B = 256 measured
+    //  16 / 24 / 32 / 48 / 64 splits = 0.1985 / 0.1926 / 0.1950 / 0.1985 / 0.2015 ms per step)
+    const bool blocks64 = !DR4SR_ENV("DR4SR_WGRAD_F32") && !DR4SR_ENV("DR4SR_FMLP_WGRAD_WIDE");
+    if (blocks64 && gwf <= 0) gw_t = ntiles / 8 > 24 ? (ntiles / 8 > 160 ? 160 : ntiles / 8) : 24;
     int gw = ntiles < gw_t ? ntiles : gw_t;
     const size_t lds = sizeof(float) * 64 * (64 + 256);
-    big_lds(k_fmlp_wgrad, lds);
-    hipLaunchKernelGGL(k_fmlp_wgrad, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
+    if (DR4SR_ENV("DR4SR_WGRAD_F32")) {
+        big_lds(k_fmlp_wgrad, lds);
+        hipLaunchKernelGGL(k_fmlp_wgrad, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
+    } else if (DR4SR_ENV("DR4SR_FMLP_WGRAD_WIDE")) {          // the two whole jobs per layer (cross-check of the 64 x 64 blocks)
+        big_lds(k_fmlp_wgrad_bf, lds);
+        hipLaunchKernelGGL(k_fmlp_wgrad_bf, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
+    } else {
+        hipLaunchKernelGGL(k_fmlp_wgrad_bf64, dim3(gw, 9, n_layer), dim3(256), sizeof(float) * 2 * 64 * 64, s, A);
+    }
     return DR4SR_LAUNCH_CHECK();
 }
 

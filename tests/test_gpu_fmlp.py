@@ -162,3 +162,15 @@ def _fmlp_case(B, NL, L):
     assert n == B and abs(loss - float(loss_o)) < 3e-5
     for k, gv in eng.normalized_grads().items():
         assert relerr(gv, grads_o[k]) < REL, k
+
+
+@pytest.mark.parametrize("env", [{"DR4SR_WGRAD_F32": "1"}, {"DR4SR_FMLP_WGRAD_WIDE": "1"}], ids=["fp32-weight-gradients", "whole-jobs-bf16x3"])
+def test_fmlp_weight_gradient_switches_vs_oracle(env, golden_dir, monkeypatch):
+    """round 4: the FFN weight gradients run as 64 x 64 blocks on the bf16 matrix cores (3-term split, k_fmlp_wgrad_bf64) by default;
+    DR4SR_WGRAD_F32 = the fp32-MFMA kernel, DR4SR_FMLP_WGRAD_WIDE = the split on the two whole jobs per layer.  The golden and
+    oracle tests re-run in this process with the switch set."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    test_fmlp_encode_fwd_bwd_adam_vs_golden(golden_dir)
+    for B in (1, 37):
+        test_fmlp_odd_batch_sizes_vs_oracle(B)
