@@ -130,8 +130,9 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
 
             def is_bwd(k):                     # k_attn2_bwd<...> / k_attn_tiny<DH, true>
                 return "_bwd" in k or (k.startswith("k_attn_tiny") and k.rstrip(">").endswith("true"))
+            # (the at-scale forms of the token-tile kernels are the wave-tile ones of csrc/linear_wave.hip: k_wt_<name>)
             hits = [v["hbm_bytes_per_launch"] for k, v in pm.items()
-                    if k.startswith(prefix) and (not dom.startswith("attn") or is_bwd(k) == want_bwd)]
+                    if (k.startswith(prefix) or k.startswith("k_wt_" + prefix[2:])) and (not dom.startswith("attn") or is_bwd(k) == want_bwd)]
             if hits:
                 traffic, traffic_src = float(sum(hits)), os.path.relpath(pj, ROOT)
                 break
