@@ -108,8 +108,14 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
         b.synchronize()
         ktime[kind] = a.elapsed_time(b) * 1e3 / reps          # us per launch (back-to-back launches)
     step_us = {k: v * per_step_launches.get(k, 1) for k, v in ktime.items()}
-    # the dominant kernel = the kind with the largest share of the step (attention: both layers' launches)
-    dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last, big) > 0), key=lambda k: step_us[k])
+    # the dominant KERNEL = the kernel name with the largest share of the step, as a rocprofv3 --stats table ranks them.  An attention
+    # "kind" is one kernel per layer only while one workgroup per sequence runs; with the length-class lists (plan bit 1) a call is
+    # three different kernels backward (1..8-token VALU class, 16-row, 64-row) and two forward: their summed time is no kernel's share
+    # (round 4: the sum, 2 x 47 us at toys B = 8 192, tied with k_wt_post_mid's 95 us and made a three-kernel "kernel" the roofline's subject)
+    lists = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 2)
+    names_per_kind = {"attn_bwd": 3 if lists else 1, "attn_fwd": 2 if lists else 1}
+    dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last, big) > 0),
+              key=lambda k: step_us[k] / names_per_kind.get(k, 1))
     fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last, big)
     ach = fl / (ktime[dom] * 1e-6) / 1e12
     # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (tools/traffic_pmc.sh: FETCH_SIZE x2

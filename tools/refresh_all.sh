@@ -1,4 +1,4 @@
-export ROUND=${ROUND:-3}
+export ROUND=${ROUND:-4}
 R=$GRAFT_REPO_ROOT
 bash $R/tools/refresh_profiles.sh > /dev/null 2>&1
 bash $R/tools/traffic_pmc.sh > /dev/null 2>&1
