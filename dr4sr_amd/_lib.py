@@ -21,6 +21,19 @@ SITE_EMB, SITE_ATTN, SITE_PROJ, SITE_ACT, SITE_FFN = 0, 1, 2, 3, 4
 OPT_ADAM, OPT_SGD, OPT_ADAGRAD, OPT_RMSPROP = 0, 1, 2, 3        # DR4SR_OPT_* (include/dr4sr_hip.h)
 
 
+def check_ids(idx, n_items: int, what: str = "index"):
+    """raise what torch.nn.Embedding raises for ids outside [0, n_items) — the HIP gathers clamp them (csrc/embed.hip).  One small
+    launch + one host read: for dataset tensors (once) and the dense API op, never inside the fused training step"""
+    import torch
+    if idx is None or idx.numel() == 0:
+        return
+    bad = torch.zeros(1, dtype=torch.int32, device=idx.device)
+    t = idx.contiguous()
+    check(load().dr4sr_check_ids(ptr(t), t.numel(), int(n_items), ptr(bad), cur_stream()), "dr4sr_check_ids")
+    if int(bad):
+        raise IndexError(f"index out of range in self ({what}: {int(bad)} ids outside [0, {int(n_items)}))")
+
+
 def optimizer_settings(name: str, weight_decay: float):
     """/root/reference model/basemodel.py:79-98 -> (DR4SR_OPT_* kind, (beta1, beta2), eps, weight_decay): each optimizer with torch's
     defaults as the reference constructs it — Adam(lr, weight_decay), SGD(lr, weight_decay) (no momentum), Adagrad(lr, weight_decay)
@@ -199,6 +212,7 @@ SYMBOLS = {
     "dr4sr_cl_scalars": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
     "dr4sr_gru4rec_adam_step": (C.c_int, [_GPLANP, C.c_void_p]),
     "dr4sr_gru4rec_train_steps": (C.c_int, [_GPLANP, C.c_int32, C.c_void_p]),
+    "dr4sr_check_ids": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "dr4sr_optimizer_flat": (C.c_int, [C.c_int32, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_void_p]),
     "dr4sr_cl_scalars_dp": (C.c_int, [_f32p, C.c_int32, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),

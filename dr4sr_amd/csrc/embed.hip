@@ -47,6 +47,27 @@ extern "C" int dr4sr_embed_gather_posadd(const float* E, const float* P, const i
     return DR4SR_LAUNCH_CHECK();
 }
 
+// ids outside [0, n_items): torch's nn.Embedding (the reference's gather, model/sasrec.py:43) raises "index out of range in self" for
+// them; the kernels clamp instead (a launch cannot raise), so callers that want the reference's behaviour count the offenders first —
+// dr4sr_amd does it once per dataset tensor (model/basemodel.py) and in the dense dispatcher op (ops.py).  *bad += the count.
+__global__ __launch_bounds__(256) void k_check_ids(const int64_t* __restrict__ idx, int64_t n, int n_items, int* __restrict__ bad) {
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t id = idx[i];
+        c += (id < 0 || id >= n_items) ? 1 : 0;
+    }
+    c = (int)wave_sum((float)c);                        // (<= 64 * iterations per wave: exact in fp32 up to 2^24)
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(bad, c);
+}
+extern "C" int dr4sr_check_ids(const int64_t* idx, int64_t n, int32_t n_items, int32_t* bad_count, void* stream) {
+    if (!idx || !bad_count || n < 0 || n_items <= 0) return DR4SR_E_ARG;
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_check_ids, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, n, n_items, bad_count);
+    return DR4SR_LAUNCH_CHECK();
+}
+
 // ------------------------------------------------------------------------------------------------
 // prep: cu[b] = exclusive prefix sum of clamp(seqlen[row(b)], 0, L); state[T] = total.  One block.
 // Also bumps the RNG step so that every fwd_bwd draws fresh dropout masks / negatives.

@@ -144,6 +144,25 @@ class BaseModel(nn.Module):
         self._sync_replicas()
         self.optimizer = self._get_optimizers()
         self.loss_fn = self._get_loss_func()
+        self._check_dataset_ids()
+
+    def _check_dataset_ids(self):
+        """The reference's nn.Embedding raises IndexError for an item id outside the table; the HIP gathers clamp (a launch cannot raise).
+        The ids of the fused path are the splits' resident tensors, so they are checked ONCE here (dr4sr_check_ids) and the reference's
+        error is raised before any step runs on a malformed dataset."""
+        n = int(getattr(self.engine, "n_items", self.num_items)) if self.engine is not None else self.num_items
+        for ds in self.dataset_list:
+            fields = getattr(ds, "fields", None)
+            try:
+                f = fields() if callable(fields) else None
+            except Exception:      # noqa: BLE001 — an eval split whose domain is not selected yet has no tensors to look at
+                f = None
+            if not f:
+                continue
+            for k in ("in_" + self.fiid, self.fiid):
+                t = f.get(k)
+                if t is not None and t.is_cuda:
+                    _lib.check_ids(t, n, f"{type(ds).__name__}.{k}")
 
     def _sync_replicas(self):
         if self.world_size > 1:

@@ -43,6 +43,7 @@ def embed_gather_posadd(E: torch.Tensor, P: torch.Tensor, idx: torch.Tensor) -> 
     B, L = idx.shape
     N, D = E.shape
     E, P, idx = E.contiguous(), P.contiguous(), idx.contiguous()
+    _lib.check_ids(idx, N, "embed_gather_posadd")          # nn.Embedding's IndexError (the kernel itself clamps)
     out = torch.empty(B, L, D, dtype=torch.float32, device=E.device)
     _lib.check(lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx), _lib.ptr(out), B, L, D, N, _lib.cur_stream()),
                "dr4sr_embed_gather_posadd")

@@ -227,6 +227,12 @@ int dr4sr_neg_sample_dev(int64_t* out, int64_t n, int32_t n_items, uint64_t seed
 /* BaseModel.topk (basemodel.py:354-365) for the single-domain case: scores = q @ E[:n_items]^T,
  * column 0 (PAD) and every id in hist[b,:] set to -inf, top-k (k <= 128) by score, ties -> lower id.
  * q [B,D], hist [B,Lh] int64, out_score [B,k] fp32, out_item [B,k] int64. */
+/* *bad_count += number of ids outside [0, n_items) among idx[0..n) (device int32, zeroed by the caller).  The gather kernels CLAMP
+ * such ids (a launch cannot raise); torch's nn.Embedding — the reference's gather, model/sasrec.py:43 — raises "index out of range in
+ * self": a caller that wants that behaviour checks its id tensors with this (dr4sr_amd: once per dataset tensor, and per call of the
+ * dense dispatcher op). */
+int dr4sr_check_ids(const int64_t* idx, int64_t n, int32_t n_items, int32_t* bad_count, void* stream);
+
 int dr4sr_full_score_topk(const float* q, const float* E, const int64_t* hist, float* out_score,
                           int64_t* out_item, int64_t B, int32_t D, int32_t n_items, int32_t Lh,
                           int32_t k, void* stream);

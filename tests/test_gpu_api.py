@@ -677,3 +677,32 @@ def test_model_optimizer_config_trains(tmp_path, monkeypatch, name):
     cfg["train"]["optimizer"] = "sparse_adam"
     with pytest.raises(RuntimeError, match="SparseAdam does not support dense gradients"):
         prepare_model(cfg, ds)._init_model(ds[0])
+
+
+@pytest.mark.gpu
+def test_out_of_range_item_ids_raise_like_nn_embedding(monkeypatch):
+    """the gather kernels clamp ids outside the table where torch's nn.Embedding (the reference's gather,
+    model/sasrec.py:43) raises IndexError.  dr4sr_check_ids counts the offenders: the dense dispatcher op raises per call, the models
+    raise once when they are initialised on a malformed dataset — before any step runs"""
+    import dr4sr_amd.ops  # noqa: F401
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(root, "configs"))
+    E, P = torch.randn(50, 64, device="cuda"), torch.randn(50, 64, device="cuda")
+    idx = torch.randint(0, 50, (4, 50), device="cuda")
+    torch.ops.dr4sr_hip.embed_gather_posadd(E, P, idx)                   # in range: fine
+    for bad in (50, -1, 10 ** 9):
+        idx2 = idx.clone()
+        idx2[2, 7] = bad
+        with pytest.raises(IndexError, match="index out of range in self"):
+            torch.ops.dr4sr_hip.embed_gather_posadd(E, P, idx2)
+    from dr4sr_amd.utils import load_config, prepare_datasets, prepare_model, seed_everything
+    cfg = load_config({"model": "SASRec", "dataset": "synthetic-toys"})
+    cfg["data"].update({"n_items": 120, "n_rows": 200, "n_eval_rows": 64, "seed": 5})
+    cfg["train"].update({"batch_size": 64, "device": "cuda"})
+    seed_everything(1)
+    ds = prepare_datasets(cfg)
+    prepare_model(cfg, ds)._init_model(ds[0])                            # a well-formed dataset passes
+    f = ds[0].fields()
+    f["in_item_id"][5, 0] = 120                                           # = num_items: one past the table
+    with pytest.raises(IndexError, match="index out of range in self"):
+        prepare_model(cfg, ds)._init_model(ds[0])
