@@ -25,7 +25,7 @@ __device__ __forceinline__ int rand_below(uint32_t r, int n) { return (int)__umu
 __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __restrict__ seqlen, int64_t* __restrict__ out,
                              int64_t* __restrict__ out_len, int B, int L, int mode, double tau, double gamma, double beta,
                              int64_t mask_id, uint64_t seed, uint32_t step, const int32_t* __restrict__ step_dev,
-                             int64_t* __restrict__ out2, int64_t* __restrict__ out_len2) {
+                             int64_t* __restrict__ out2, int64_t* __restrict__ out_len2, const int64_t* __restrict__ rows = nullptr) {
     __shared__ unsigned char perm_lds[64 * 64];            // blockDim.x = 64 threads x up to 64 segment positions
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -33,9 +33,10 @@ __global__ void k_cl_augment(const int64_t* __restrict__ seq, const int64_t* __r
     if (step_dev) step += (uint32_t)*step_dev;             // graph replays: the call counter lives on the device
     const RngKey rk = make_rng(seed, step, 0.f);
     if (mode == 3) mode = rand_below(aug_rand(rk, 0xffffffu, 0), 3);          // data_augmentation.py:95: one method for the whole batch
-    int n = (int)seqlen[b];
+    const int64_t srow = rows ? rows[b] : b;                // rows != NULL: seq / seqlen are dataset tensors, the batch is rows[0..B)
+    int n = (int)seqlen[srow];
     n = n < 0 ? 0 : (n > L ? L : n);
-    const int64_t* src = seq + (size_t)b * L;
+    const int64_t* src = seq + (size_t)srow * L;
     int64_t* dst = out + (size_t)b * L;
     const uint64_t st = (uint64_t)b + 1;
     if (mode == 0) {                                   // Item_Crop :20-41: contiguous sub-sequence of length max(1, int(tau n))
@@ -294,13 +295,28 @@ extern "C" int dr4sr_cl_augment2_dev(const int64_t* seq, const int64_t* seqlen, 
                        gamma, beta, mask_id, seed, step_offset, step_dev, out_j, len_j);
     return DR4SR_LAUNCH_CHECK();
 }
+// the same on rows rows[0..B) of dataset tensors seq [U,L] / seqlen [U] (round 4: the batch of a captured CL4SRec step is selected on the
+// device — dr4sr_sasrec_plan.perm fills rows[] —, so the views are drawn without materialising the batch first); same draws as the
+// [B,L] form on the gathered rows (the stream of a sequence is keyed by its batch slot)
+extern "C" int dr4sr_cl_augment2_rows_dev(const int64_t* seq, const int64_t* seqlen, const int64_t* rows, int64_t* out_i, int64_t* len_i,
+                                          int64_t* out_j, int64_t* len_j, int32_t B, int32_t L, int32_t mode, double tau, double gamma,
+                                          double beta, int64_t mask_id, uint64_t seed, const int32_t* step_dev, uint32_t step_offset,
+                                          void* stream) {
+    if (!seq || !seqlen || !rows || !out_i || !len_i || !out_j || !len_j || !step_dev || B < 0 || L <= 0 || L > 64 || mode < 0 || mode > 3)
+        return DR4SR_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_cl_augment, dim3((B + 63) / 64, 2), dim3(64), 0, (hipStream_t)stream, seq, seqlen, out_i, len_i, B, L, mode, tau,
+                       gamma, beta, mask_id, seed, step_offset, step_dev, out_j, len_j, rows);
+    return DR4SR_LAUNCH_CHECK();
+}
 
 // ---- glue of the direct CL4SRec step (model/cl4srec.py: _api_step_body), one launch each instead of a handful of elementwise ones
 namespace {
 __global__ __launch_bounds__(256) void k_cl_prepare(const int64_t* __restrict__ seqlen, int B, uint8_t* __restrict__ valid,
-                                                    float* __restrict__ stats, float* __restrict__ zero, int64_t nzero) {
+                                                    float* __restrict__ stats, float* __restrict__ zero, int64_t nzero,
+                                                    const int64_t* __restrict__ rows = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
-    if (i < B) valid[i] = seqlen[i] != 1;                  // data_augmentation.py:613-615: sequences of length 1 are dropped
+    if (i < B) valid[i] = seqlen[rows ? rows[i] : i] != 1;  // data_augmentation.py:613-615: sequences of length 1 are dropped
     if (i < 2) stats[i] = 0.f;
     for (int64_t k = i; k < nzero; k += stride) zero[k] = 0.f;
 }
@@ -327,6 +343,15 @@ extern "C" int dr4sr_cl_prepare(const int64_t* seqlen, int32_t B, uint8_t* valid
     int64_t nb = ((nzero > B ? nzero : B) + 255) / 256;
     if (nb > 512) nb = 512;
     hipLaunchKernelGGL(k_cl_prepare, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, seqlen, B, valid, stats, zero, nzero);
+    return DR4SR_LAUNCH_CHECK();
+}
+/* the same with seqlen a dataset tensor addressed through rows[0..B) */
+extern "C" int dr4sr_cl_prepare_rows(const int64_t* seqlen, const int64_t* rows, int32_t B, uint8_t* valid, float* stats, float* zero,
+                                     int64_t nzero, void* stream) {
+    if (!seqlen || !rows || !valid || !stats || B <= 0 || nzero < 0 || (nzero && !zero)) return DR4SR_E_ARG;
+    int64_t nb = ((nzero > B ? nzero : B) + 255) / 256;
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(k_cl_prepare, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, seqlen, B, valid, stats, zero, nzero, rows);
     return DR4SR_LAUNCH_CHECK();
 }
 /* the two device scalars of a step whose main pass left {n_valid, loss_sum} in `tail` and whose InfoNCE forward left {rows, loss_sum}

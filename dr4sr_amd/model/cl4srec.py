@@ -72,7 +72,7 @@ class CL4SRec(SASRec):
         eng.adam_step(self._api_plan())
         return sc[0]
 
-    def _cl_term(self, ids, lens, views=None, dp_counts=None, fold_loss=False):
+    def _cl_term(self, ids, lens, views=None, dp_counts=None, fold_loss=False, rows=None):
         """cl_weight * mean InfoNCE between two augmented views of the rows (cl4srec.py:52-55, data_augmentation.py:595-619), composed
         from C-ABI calls without autograd: its gradient is ACCUMULATED into engine.grads scaled by cl_weight * n_valid / rows, so that
         an optimizer (or a hyper-gradient probe) dividing the flat gradient by the tail's n_valid is left with exactly
@@ -87,13 +87,15 @@ class CL4SRec(SASRec):
         the single-process gradient of the concatenated batch (tools/dp_cl_check.py; tests/test_host_cpu.py restates the scheme on
         the oracle).  A rank with no rows still takes part in the gather.
         fold_loss: also add the term's share cl_weight * mean InfoNCE * n_valid(local) to the tail's loss_sum (MetaModel / DP log the
-        step's loss as tail[1] / tail[0])."""
+        step's loss as tail[1] / tail[0]).
+        rows (int64 [B]): ids / lens are DATASET tensors and the batch is their rows rows[0..B) — the fused epoch's form, where the
+        main pass's first kernel selected the rows on the device and no batch tensor exists."""
         import os
         from .. import _lib, parallel
         eng, lib = self.engine, self.engine.lib
         am = self.augmentation_model
         aug = am.augmentation
-        B, D, dev, n = int(ids.shape[0]), eng.D, self.device, eng.n_params
+        B, D, dev, n = int(rows.shape[0] if rows is not None else ids.shape[0]), eng.D, self.device, eng.n_params
         st = _lib.cur_stream
         clw, temp = float(self.config["model"]["cl_weight"]), float(am.InfoNCE_loss_fn.temperature)
         tail = eng.grads[n:n + 2]
@@ -102,7 +104,9 @@ class CL4SRec(SASRec):
             if views is None:
                 if hasattr(aug, "begin_step"):
                     aug.begin_step()
-                if hasattr(aug, "two_views"):
+                if rows is not None:
+                    (aug_i, len_i), (aug_j, len_j) = aug.two_views(ids, lens, rows=rows)
+                elif hasattr(aug, "two_views"):
                     (aug_i, len_i), (aug_j, len_j) = aug.two_views(ids, lens)
                 else:
                     (aug_i, len_i), (aug_j, len_j) = aug(ids, lens), aug(ids, lens)
@@ -137,8 +141,12 @@ class CL4SRec(SASRec):
             valid = torch.empty(B, dtype=torch.uint8, device=dev)
             lse, loss_row = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
             dq = torch.empty(2, B, D, dtype=torch.float32, device=dev)
-            _lib.check(lib.dr4sr_cl_prepare(_lib.ptr(lens.contiguous()), B, _lib.ptr(valid), _lib.ptr(stats), _lib.ptr(dq), dq.numel(), st()),
-                       "dr4sr_cl_prepare")
+            if rows is not None:
+                _lib.check(lib.dr4sr_cl_prepare_rows(_lib.ptr(lens), _lib.ptr(rows), B, _lib.ptr(valid), _lib.ptr(stats), _lib.ptr(dq), dq.numel(),
+                                                     st()), "dr4sr_cl_prepare_rows")
+            else:
+                _lib.check(lib.dr4sr_cl_prepare(_lib.ptr(lens.contiguous()), B, _lib.ptr(valid), _lib.ptr(stats), _lib.ptr(dq), dq.numel(), st()),
+                           "dr4sr_cl_prepare")
             _lib.check(lib.dr4sr_infonce_fwd(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(loss_row),
                                              _lib.ptr(stats), st()), "dr4sr_infonce_fwd")
             _lib.check(lib.dr4sr_cl_scalars_dp(_lib.ptr(tail), 1, 0, _lib.ptr(stats), clw, _lib.ptr(sc), _lib.ptr(tail) if fold_loss else None,
@@ -148,6 +156,7 @@ class CL4SRec(SASRec):
             dq_i, dq_j = dq[0], dq[1]
         else:
             # ---- the global batch: [W][Bmax rows of (q_i | q_j | kept) ... | n_valid]
+            assert rows is None, "data parallel: the step runs on materialised per-rank batches"
             W, r = len(dp_counts), self.rank
             assert dp_counts[r] == B, (dp_counts, r, B)
             Bmax, Bg, off = max(dp_counts), sum(dp_counts), sum(dp_counts[:r])
@@ -182,11 +191,85 @@ class CL4SRec(SASRec):
                 eng.encode_bwd(plans[1], True, _lib.POOL_MEAN, dq_j.contiguous())
         return stats
 
+    # ---- single GPU, fused epoch (round 4): NO per-step host work.  The step the graph replays selects its batch on the device — the
+    # main pass's first kernel fills rows[] from the epoch permutation (dr4sr_sasrec_plan.perm) and draws the negatives in-kernel, the
+    # views are drawn from the dataset tensors through rows[] (dr4sr_cl_augment2_rows_dev), the optimizer launch writes the step's
+    # loss (BCE mean + cl_weight * InfoNCE mean: _cl_term folds the term into the tail) into loss_log[batch index] — so k whole steps
+    # go into one graph.  The per-batch form (_api_step_graph) copied three gathered fields into static tensors, ran the negative
+    # sampler as two launches and cloned the loss per step: ~35 us of a 0.33 ms step.  train.cl_fused_epoch: false restores it.
+    def _fused_cl_ok(self) -> bool:
+        import os
+        return (self.world_size == 1 and self._direct_step_ok() and bool(self.config["train"].get("hip_graph", True))
+                and bool(self.config["train"].get("cl_fused_epoch", True)) and not os.environ.get("DR4SR_CL_TWO_PASS")
+                and hasattr(self.augmentation_model.augmentation, "two_views"))
+
+    def _cl_rows_step(self, plan, fields, rows):
+        """one step on rows[] of the dataset tensors: fused main pass (+ device-side batch selection / negatives when the plan carries
+        them), the contrastive term through rows[], optimizer (logs the step's loss when the plan has a loss log)"""
+        eng = self.engine
+        eng.fwd_bwd(plan)
+        self._cl_term(fields["in_" + self.fiid], fields["seqlen"], rows=rows, fold_loss=True)
+        eng.adam_step(plan)
+
+    def _fused_cl_graph(self, fields, bl, k):
+        key = ("cl_rows", fields["in_" + self.fiid].data_ptr(), bl, k, self._loss_log.data_ptr(), self._perm_buf.data_ptr())
+        if key in self._graphs:
+            return self._graphs[key]
+        from ..utils.graphs import capture
+        eng = self.engine
+        aug = self.augmentation_model.augmentation
+        if getattr(aug, "step_dev", None) is None:
+            self._api_graph_begin()
+        rows = self._rows_buf[:bl]
+        plan = eng.make_plan(fields["in_" + self.fiid], fields[self.fiid], fields["seqlen"], rows=rows, neg_item=self._neg_buf, sample_neg=True,
+                             perm_sel=(self._perm_buf, int(self.config["train"]["batch_size"]), 0, self._perm_counter), loss_log=self._loss_log)
+
+        def body():
+            for _ in range(k):
+                self._cl_rows_step(plan, fields, rows)
+        undo = [eng.params, eng.adam_m, eng.adam_v, self._perm_counter, aug.step_dev] + list(eng.states)
+        snap = [t.clone() for t in undo]
+        body()                                             # warm-up outside capture, side effects undone
+        torch.cuda.synchronize()
+        for dst, src in zip(undo, snap):
+            dst.copy_(src)
+        g = torch.cuda.CUDAGraph()
+        with capture(g):
+            body()
+        self._graphs[key] = (g.replay, plan)
+        return self._graphs[key]
+
+    def _fused_cl_epoch(self, loader):
+        B, n, nb = loader.batch_size, loader.n, len(loader)
+        dev = self.device
+        if getattr(self, "_perm_buf", None) is None or self._perm_buf.shape[0] != n:
+            self._perm_buf = torch.empty(n, dtype=torch.int64, device=dev)
+            self._perm_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        if getattr(self, "_loss_log", None) is None or self._loss_log.shape[0] != nb:
+            self._loss_log = torch.empty(nb, dtype=torch.float32, device=dev)
+        if getattr(self, "_rows_buf", None) is None or self._rows_buf.shape[0] < B:
+            self._rows_buf = torch.zeros(B, dtype=torch.int64, device=dev)
+            self._neg_buf = torch.zeros(B * self.max_seq_len, dtype=torch.int64, device=dev)
+        self._perm_buf.copy_(loader.permutation())
+        self._perm_counter.zero_()
+        group = int(self.config["train"].get("steps_per_graph", 16))
+        i = 0
+        while i < nb:
+            bl = min(B, n - i * B)
+            k = group if (i + group) * B <= n else 1
+            run, _ = self._fused_cl_graph(loader.fields, bl, k)
+            run()
+            i += k
+        return [{"loss_0": self._loss_log.clone()}]
+
     # ---- data parallel (round 4): the fused main pass + the views' passes on this rank's slice of every global batch, the contrastive
     # term over the gathered global batch (_cl_term), ONE sum-all-reduce of the flat gradient, dense Adam.  Eager launches (two
     # collectives per step sit between them; the single-GPU path replays one graph per batch size).
     def training_epoch(self, nepoch):
         if self.world_size <= 1:
+            loader = self.current_epoch_trainloaders(nepoch)
+            if self._fused_cl_ok() and getattr(loader, "fields", None) is not None and hasattr(loader, "permutation"):
+                return [self._fused_cl_epoch(loader)]
             return super().training_epoch(nepoch)
         from .. import parallel
         from ..parallel import allreduce_flat, shard_bounds

@@ -40,13 +40,24 @@ class _DeviceAugmentation(torch.nn.Module):
         if self.step_dev is not None:
             self.step_dev.add_(self._in_step)
 
-    def two_views(self, sequences, seq_lens):
+    def two_views(self, sequences, seq_lens, rows=None):
         """the two consecutive draws of a CL4SRec step in ONE launch (captured steps; eager: two forward() calls).  The two views are
-        the halves of ONE [2B, L] / [2B] pair of tensors, so that a caller may also encode them as one batch of 2B sequences."""
+        the halves of ONE [2B, L] / [2B] pair of tensors, so that a caller may also encode them as one batch of 2B sequences.
+        rows (int64 [B], captured steps only): sequences / seq_lens are DATASET tensors and the batch is their rows rows[0..B) — the
+        batch a fused step selected on the device is never materialised (dr4sr_cl_augment2_rows_dev; same draws as on the gathered rows)"""
         seq, sl = sequences.contiguous(), seq_lens.contiguous()
-        B, L = seq.shape
+        L = int(seq.shape[1])
+        B = int(rows.shape[0]) if rows is not None else int(seq.shape[0])
         out, out_len = seq.new_empty(2 * B, L), sl.new_empty(2 * B)
         oi, li, oj, lj = out[:B], out_len[:B], out[B:], out_len[B:]
+        if rows is not None:
+            assert self.step_dev is not None, "rows-indirected views are the captured step's form (device call counter)"
+            lib = _lib.load()
+            _lib.check(lib.dr4sr_cl_augment2_rows_dev(_lib.ptr(seq), _lib.ptr(sl), _lib.ptr(rows), _lib.ptr(oi), _lib.ptr(li), _lib.ptr(oj),
+                                                      _lib.ptr(lj), B, L, self.mode, self.tao, self.gamma, self.beta, self.mask_id, self.seed,
+                                                      _lib.ptr(self.step_dev), self._in_step + 1, _lib.cur_stream()), "dr4sr_cl_augment2_rows_dev")
+            self._in_step += 2
+            return (oi, li), (oj, lj)
         if self.step_dev is None:
             (a, la), (b, lb) = self.forward(sequences, seq_lens), self.forward(sequences, seq_lens)
             oi.copy_(a); li.copy_(la); oj.copy_(b); lj.copy_(lb)

@@ -465,12 +465,19 @@ int dr4sr_cl_augment_dev(const int64_t* seq, const int64_t* seqlen, int64_t* out
 int dr4sr_cl_augment2_dev(const int64_t* seq, const int64_t* seqlen, int64_t* out_i, int64_t* len_i, int64_t* out_j, int64_t* len_j,
                           int32_t B, int32_t L, int32_t mode, double tau, double gamma, double beta, int64_t mask_id, uint64_t seed,
                           const int32_t* step_dev, uint32_t step_offset, void* stream);
+/* both views of the batch rows[0..B) of dataset tensors seq [U,L] / seqlen [U] (the batch a captured step selected on the device:
+ * dr4sr_sasrec_plan.perm): the draws of dr4sr_cl_augment2_dev on the gathered rows */
+int dr4sr_cl_augment2_rows_dev(const int64_t* seq, const int64_t* seqlen, const int64_t* rows, int64_t* out_i, int64_t* len_i,
+                               int64_t* out_j, int64_t* len_j, int32_t B, int32_t L, int32_t mode, double tau, double gamma, double beta,
+                               int64_t mask_id, uint64_t seed, const int32_t* step_dev, uint32_t step_offset, void* stream);
 /* glue of a CL4SRec step composed without autograd (model/cl4srec.py:49-73 = BCE + cl_weight * InfoNCE):
  *   dr4sr_cl_prepare: valid[b] = seqlen[b] != 1 (data_augmentation.py:613-615), stats[0..1] = 0, zero[0..nzero) = 0;
  *   dr4sr_cl_scalars: with {n_valid, loss_sum} of the main pass in `tail` and InfoNCE's {rows, loss_sum} in `stats`:
  *     *scale_out = cl_weight * n_valid / rows (the InfoNCE backward scale under an optimizer that divides by n_valid),
  *     *loss_out = loss_sum / n_valid + cl_weight * stats[1] / rows;  either output may be NULL. */
 int dr4sr_cl_prepare(const int64_t* seqlen, int32_t B, uint8_t* valid, float* stats, float* zero, int64_t nzero, void* stream);
+int dr4sr_cl_prepare_rows(const int64_t* seqlen, const int64_t* rows, int32_t B, uint8_t* valid, float* stats, float* zero, int64_t nzero,
+                          void* stream);      /* valid[b] = seqlen[rows[b]] != 1 */
 int dr4sr_cl_scalars(const float* tail, const float* stats, float cl_weight, float* scale_out, float* loss_out, void* stream);
 /* the same when n_valid is spread over n_parts words nv_parts[r * stride] (data parallel: every rank's count, all-gathered next to its
  * pooled views — InfoNCE's negatives are the GLOBAL batch; a single part = the local tail itself):

@@ -272,3 +272,79 @@ def test_cl4srec_data_parallel_equals_single_process(tail):
     assert out.returncode == 0 and len(lines) == 2, err
     print(lines[0])
     assert "replica checksums equal: True" in lines[1]
+
+
+def _cl_model(monkeypatch, dropout, n_rows=200, batch=64, **train):
+    monkeypatch.setenv("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
+    from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
+    config = make_config(150, n_rows=n_rows, batch=batch, epochs=1, dropout=dropout)
+    config["train"].update(train)
+    seed_everything(config["train"]["seed"])
+    ds = prepare_datasets(config)
+    model = prepare_model(config, ds)
+    model._init_model(ds[0])
+    model.train()
+    return ds, model
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.5])
+def test_cl4srec_rows_step_equals_api_step_body(monkeypatch, dropout):
+    """round 4: the step the fused CL4SRec epoch replays works on rows[] of the DATASET tensors (main pass through the plan's rows
+    indirection, views drawn by dr4sr_cl_augment2_rows_dev, length-1 mask by dr4sr_cl_prepare_rows) — no batch tensor exists.  With the
+    same negatives injected it must equal the per-batch step body (_api_step_body on the gathered batch): same views (the device call
+    counter continues the host one), same dropout masks, same losses and parameters; DR4SR_CL_TWO_PASS keeps the bodies' dropout
+    streams identical when dropout is on"""
+    if dropout > 0:
+        monkeypatch.setenv("DR4SR_CL_TWO_PASS", "1")
+    res = []
+    for mode in ("batch", "rows"):
+        ds, model = _cl_model(monkeypatch, dropout)
+        eng = model.engine
+        f = ds[0].get_loader(shuffle=False).fields
+        n, B, L = int(f["seqlen"].shape[0]), 64, model.max_seq_len
+        gen = torch.Generator().manual_seed(11)
+        losses = []
+        if mode == "rows":
+            model._api_graph_begin()                           # device call counter of the augmentations (continues the host count)
+            rows_buf = torch.zeros(B, dtype=torch.int64, device=model.device)
+        for i in range(0, n, B):
+            rows = torch.arange(i, min(i + B, n), device=model.device)
+            bl = int(rows.shape[0])
+            negs = torch.randint(1, model.num_items, (bl, L, 1), generator=gen).to(model.device)
+            if mode == "batch":
+                model._neg_sampling = lambda b, negs=negs: negs
+                batch = {k: f[k].index_select(0, rows) for k in ("in_item_id", "item_id", "seqlen", "user_id")}
+                losses.append(float(model._api_step_body(batch)))
+            else:
+                rows_buf[:bl].copy_(rows)
+                plan = eng.make_plan(f["in_item_id"], f["item_id"], f["seqlen"], rows=rows_buf[:bl], neg_item=negs.view(-1).contiguous(),
+                                     sample_neg=False)
+                model._cl_rows_step(plan, f, rows_buf[:bl])
+                losses.append(float(eng.grads[eng.n_params + 1] / eng.grads[eng.n_params]))
+        res.append((losses, eng.params.clone()))
+    (la, pa), (lb, pb) = res
+    assert len(la) == 4 and np.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
+    assert float((pa - pb).abs().max()) < 5e-4, float((pa - pb).abs().max())      # 4 Adam steps of lr 1e-3: fp32 atomics order where |g| ~ eps
+
+
+def test_cl4srec_fused_epoch_trains_like_the_per_batch_graphs(monkeypatch):
+    """fit()'s epoch with NO per-step host work (CL4SRec._fused_cl_epoch: batch selection, negatives, views, loss log on the device,
+    k steps per graph, ragged last batch) against the per-batch graphs (train.cl_fused_epoch: false): other negative / shuffle
+    streams, so the comparison is statistical — same loss level after the same number of epochs, and it decreases"""
+    curves = {}
+    for fused in (True, False):
+        ds, model = _cl_model(monkeypatch, 0.5, n_rows=1000 + 37, batch=128, cl_fused_epoch=fused, steps_per_graph=3)
+        assert model._fused_cl_ok() == fused
+        means = []
+        for ep in range(6):
+            out = model.training_epoch(ep)
+            l0 = torch.cat([o["loss_0"].reshape(-1).float() for o in out[0]])      # one entry per step (one dict per epoch or per step)
+            assert l0.numel() == 9 and bool(torch.isfinite(l0).all())
+            means.append(float(l0.float().mean()))
+        curves[fused] = means
+        if fused:
+            assert any(isinstance(k, tuple) and k and k[0] == "cl_rows" for k in model._graphs)
+            assert int(model.engine.state[0]) == 6 * 9
+    a, b = curves[True], curves[False]
+    assert a[-1] < a[0] and b[-1] < b[0], (a, b)
+    assert abs(a[-1] - b[-1]) < 0.03 * b[-1] and abs(a[0] - b[0]) < 0.02 * b[0], (a, b)
