@@ -620,11 +620,12 @@ def main():
                 v.copy_(torch.ones(v.shape) if k.endswith("LayerNorm.weight") else (torch.zeros(v.shape) if k.endswith("bias") else 0.02 * torch.randn(v.shape, generator=g)))
             eng.views["item_embedding.weight"][0] = 0
             negbuf = torch.zeros(B, dtype=torch.int64, device=dev)
-            plan = eng.make_plan(data["in_item_id"], data["item_id"], rows=rows_buf, neg_item=negbuf, sample_neg=True)
+            plan = eng.make_plan(data["in_item_id"], data["item_id"], rows=rows_buf, neg_item=negbuf, sample_neg=True,
+                                 perm_sel=(perm, B * world, rank * B, counter))      # a1 inside the step's first launch
         stream = torch.cuda.Stream(device=dev)
 
         def select():
-            if args.model in ("sasrec", "gru4rec"):
+            if args.model in ("sasrec", "gru4rec", "fmlp"):
                 return
             _lib.check(lib.dr4sr_select_rows(_lib.ptr(perm), U, _lib.ptr(rows_buf), B, B * world, rank * B, _lib.ptr(counter),
                                              _lib.cur_stream()), "select_rows")

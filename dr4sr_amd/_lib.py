@@ -108,6 +108,9 @@ class FmlpPlan(C.Structure):
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("weight_decay", C.c_float),
         ("optimizer", C.c_int32),
+        ("perm", _i64p), ("n_perm", C.c_int64), ("perm_stride", C.c_int64), ("perm_offset", C.c_int64),
+        ("perm_counter", C.c_void_p),
+        ("loss_log", _f32p),
     ]
 
 
@@ -213,6 +216,7 @@ SYMBOLS = {
     "dr4sr_cl_prepare": (C.c_int, [_i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_cl_prepare_rows": (C.c_int, [_i64p, _i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_cl_scalars": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
+    "dr4sr_fmlp_adam_step": (C.c_int, [_FPLANP, C.c_void_p]),
     "dr4sr_gru4rec_adam_step": (C.c_int, [_GPLANP, C.c_void_p]),
     "dr4sr_gru4rec_train_steps": (C.c_int, [_GPLANP, C.c_int32, C.c_void_p]),
     "dr4sr_check_ids": (C.c_int, [_i64p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -116,10 +116,17 @@ static int fmlp_ws(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
 struct FPrepArgs {
     int* state; int Tn, bump; float* zero; int64_t n4; int zb;
     const float* params; int64_t o_cw0, layer_stride; float* m; float* dm; int L;
+    PermSel sel; int64_t* rows; int B;                      // round 4: the batch selection of the fused step (sel.perm == NULL: none)
 };
 __global__ __launch_bounds__(1024) void k_fmlp_prep(const FPrepArgs A) {
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) { A.state[DR4SR_STATE_T] = A.Tn; if (A.bump) A.state[DR4SR_STATE_RNGSTEP] += 1; }
+        if (A.sel.perm) {                                   // rows[i] = perm[(c stride + offset + i) mod n]; c++  (was a launch of its own)
+            const int64_t c = *A.sel.counter;
+            for (int i = threadIdx.x; i < A.B; i += 1024) A.rows[i] = A.sel.perm[(c * A.sel.stride + A.sel.offset + i) % A.sel.n];
+            __syncthreads();
+            if (threadIdx.x == 0) *A.sel.counter = (int)(c + 1);
+        }
         return;
     }
     if ((int)blockIdx.x <= A.zb) {
@@ -530,8 +537,13 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
     const int64_t n4 = zero_grads ? (ws.n_params + DR4SR_GRAD_TAIL) / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024); if (zb > 255) zb = 255;
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
+    PermSel sel{nullptr, 0, 0, 0, nullptr};
+    if (p->perm && training && zero_grads) {                // batch selection only in the call that starts a training step
+        if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
+        sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
+    }
     const FPrepArgs PA{p->state, ws.Tn, training ? 1 : 0, zero_grads ? p->grads : nullptr, n4, zb,
-                       p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L};
+                       p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L, sel, const_cast<int64_t*>(p->rows), p->B};
     hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb + nl * FM_COEF_BLK), dim3(1024), 0, s, PA);
     FEmbArgs E{};
     E.E = p->params + ws.off[0]; E.P = p->params + ws.off[1]; E.lnw = p->params + ws.off[2]; E.lnb = p->params + ws.off[3];
@@ -637,11 +649,16 @@ extern "C" int dr4sr_optimizer_flat(int32_t optimizer, float* params, const floa
                             nullptr, nullptr, nullptr, optimizer);
 }
 
+extern "C" int dr4sr_fmlp_adam_step(const dr4sr_fmlp_plan* plan, void* stream) {
+    if (!plan || plan->abi_version != DR4SR_ABI_VERSION || !plan->params || !plan->grads || !plan->state) return DR4SR_E_ARG;
+    return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
+                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream, plan->loss_log,
+                            plan->perm ? plan->perm_counter : nullptr, nullptr, plan->optimizer);
+}
+
 extern "C" int dr4sr_fmlp_train_step(const dr4sr_fmlp_plan* plan, void* stream) {
     RC(dr4sr_fmlp_fwd_bwd(plan, stream));
-    return launch_adam_flat(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->state, plan->lr,
-                            plan->beta1, plan->beta2, plan->adam_eps, plan->weight_decay, (hipStream_t)stream, nullptr, nullptr, nullptr,
-                            plan->optimizer);
+    return dr4sr_fmlp_adam_step(plan, stream);
 }
 
 extern "C" int dr4sr_fmlp_encode(const dr4sr_fmlp_plan* plan, int32_t training, float* out, void* stream) {

@@ -71,7 +71,7 @@ class FmlpEngine:
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.neg_scratch = torch.zeros(max_batch, dtype=torch.int64, device=dev)
 
-    def _plan(self, B, in_item_id, item_id, rows, neg_item, sample_neg, with_ws=True):
+    def _plan(self, B, in_item_id, item_id, rows, neg_item, sample_neg, with_ws=True, perm_sel=None, loss_log=None):
         p = _lib.FmlpPlan()
         p.abi_version = _lib.ABI_VERSION
         p.B, p.L, p.D, p.F, p.n_layer, p.n_items = B, self.L, self.D, self.F, self.n_layer, self.n_items
@@ -88,10 +88,18 @@ class FmlpEngine:
         p.state = self.state.data_ptr()
         p.lr, (p.beta1, p.beta2), p.adam_eps, p.weight_decay = self.lr, self.betas, self.adam_eps, self.weight_decay
         p.optimizer = self.optimizer
-        self._keep = [in_item_id, item_id, rows, neg_item]
+        if perm_sel is not None:           # (perm[n], stride, offset, counter[1] int32): rows[] is FILLED by the step's first kernel
+            perm, stride, offset, counter = perm_sel
+            assert rows is not None and perm.dtype == torch.int64 and counter.dtype == torch.int32
+            p.perm, p.n_perm, p.perm_stride, p.perm_offset = perm.data_ptr(), int(perm.shape[0]), int(stride), int(offset)
+            p.perm_counter = counter.data_ptr()
+        if loss_log is not None:           # float32 device buffer: the step's mean loss lands at [batch index] (include/dr4sr_hip.h)
+            assert loss_log.dtype == torch.float32
+            p.loss_log = loss_log.data_ptr()
+        self._keep = [in_item_id, item_id, rows, neg_item, perm_sel, loss_log]
         return p
 
-    def make_plan(self, in_item_id, item_id, rows=None, neg_item=None, sample_neg=None):
+    def make_plan(self, in_item_id, item_id, rows=None, neg_item=None, sample_neg=None, perm_sel=None, loss_log=None):
         B = int(rows.shape[0] if rows is not None else in_item_id.shape[0])
         if B > self.max_batch:
             raise _lib.Dr4srError(f"batch {B} > max_batch {self.max_batch}")
@@ -106,7 +114,7 @@ class FmlpEngine:
             sample_neg = neg_item is None
         if neg_item is None:
             neg_item = self.neg_scratch
-        return self._plan(B, in_item_id, item_id, rows, neg_item, sample_neg)
+        return self._plan(B, in_item_id, item_id, rows, neg_item, sample_neg, perm_sel=perm_sel, loss_log=loss_log)
 
     def fwd_bwd(self, plan):
         _lib.check(self.lib.dr4sr_fmlp_fwd_bwd(C.byref(plan), _lib.cur_stream()), "dr4sr_fmlp_fwd_bwd")
@@ -115,6 +123,9 @@ class FmlpEngine:
         _lib.check(self.lib.dr4sr_fmlp_train_step(C.byref(plan), _lib.cur_stream()), "dr4sr_fmlp_train_step")
 
     def adam_step(self, plan=None):
+        if plan is not None:               # the plan's optimizer launch: logs the step's loss when the plan carries a loss log
+            _lib.check(self.lib.dr4sr_fmlp_adam_step(C.byref(plan), _lib.cur_stream()), "dr4sr_fmlp_adam_step")
+            return
         _lib.check(self.lib.dr4sr_optimizer_flat(self.optimizer, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
                                                  _lib.ptr(self.adam_v), self.n_params, _lib.ptr(self.state), self.lr, self.betas[0],
                                                  self.betas[1], self.adam_eps, self.weight_decay, _lib.cur_stream()), "dr4sr_optimizer_flat")

@@ -107,5 +107,8 @@ class FMLP(BaseModel):
     def _api_plan(self):
         return None
 
-    def _train_plan(self, fields, rows):
-        return self.engine.make_plan(fields["in_item_id"], fields["item_id"], rows=rows, neg_item=self._neg_buf, sample_neg=True)
+    _supports_perm_sel = True          # round 4: batch selection inside the step's first launch (k steps per graph, no per-step rows copy)
+
+    def _train_plan(self, fields, rows, perm_sel=None, loss_log=None):
+        return self.engine.make_plan(fields["in_item_id"], fields["item_id"], rows=rows, neg_item=self._neg_buf, sample_neg=True,
+                                     perm_sel=perm_sel, loss_log=loss_log)

@@ -276,6 +276,11 @@ typedef struct dr4sr_fmlp_plan {
     int32_t* state;                 /* [DR4SR_STATE_WORDS]                                          */
     float lr, beta1, beta2, adam_eps, weight_decay;
     int32_t optimizer;              /* DR4SR_OPT_* (ABI 6)                                          */
+    /* ---- fused batch selection + per-step loss log (ABI 6; dr4sr_sasrec_plan's contract): perm != NULL -> the step's first kernel FILLS
+     *      rows[i] = perm[(c * perm_stride + perm_offset + i) mod n_perm], c = *perm_counter, and bumps the counter;
+     *      dr4sr_fmlp_train_step / _adam_step write loss_log[c] = loss_sum / n_valid ---- */
+    const int64_t* perm; int64_t n_perm; int64_t perm_stride; int64_t perm_offset; int32_t* perm_counter;
+    float* loss_log;
 } dr4sr_fmlp_plan;
 
 int     dr4sr_fmlp_plan_sizeof(void);
@@ -287,6 +292,8 @@ int64_t dr4sr_fmlp_workspace_bytes(const dr4sr_fmlp_plan* plan);
 int dr4sr_fmlp_fwd_bwd(const dr4sr_fmlp_plan* plan, void* stream);
 /* fwd_bwd + dense Adam */
 int dr4sr_fmlp_train_step(const dr4sr_fmlp_plan* plan, void* stream);
+/* the optimizer half on the plan's buffers (plan->optimizer, loss_log): data parallel = fwd_bwd, all-reduce of plan->grads, this */
+int dr4sr_fmlp_adam_step(const dr4sr_fmlp_plan* plan, void* stream);
 /* FMLP.forward -> out [B,D] (= encoder output at the last position); training != 0 applies dropout */
 int dr4sr_fmlp_encode(const dr4sr_fmlp_plan* plan, int32_t training, float* out, void* stream);
 /* autograd of dr4sr_fmlp_encode: d_out [B,D]; parameter gradients ACCUMULATE into plan->grads */
