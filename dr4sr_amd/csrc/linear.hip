@@ -1649,7 +1649,10 @@ __device__ __forceinline__ void owner_job_sorted(const WgradArgs& A, const int o
 // so the kernel holds ONE GEMM instantiation of 120 VGPRs instead of the 188 of the <128, 64> / <64, 128> bodies, which capped ALL jobs at
 // 2 waves per SIMD: 61 % of a wave's life was s_waitcnt on the operand loads (SQ_WAIT_ANY, profiles/round4_sq_pmc_B8192_toys.txt) with two
 // workgroups per CU to hide them.  The cut re-reads y and df once more (+512 B per token and layer: algorithmic bytes unchanged).
-template <int D, int F, bool BF, bool SUB = false>
+// BLK (fp32, batches below the at-scale forms, d = 128): the six whole jobs are cut into 64 x 64 blocks ON THE DEVICE (blockIdx.y ->
+// job, row block, column block): a [128 x 128] job is 128 MFMAs per wave and 16 384 atomics per workgroup on 24 token tiles —
+// four blocks spread that over four workgroups (measured in DESIGN.md section 5.00, round 4).
+template <int D, int F, bool BF, bool SUB = false, bool BLK = false>
 __device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvEmbBwdArgs& Q) {
     // latency regime (A.qeb_plane): plane z = 0 of the grid is k_qkv_embed_bwd's work (16-row tiles, block-strided), layers shift by one
     const int layer = A.layer0 + (A.qeb_plane ? (int)blockIdx.z - 1 : (int)blockIdx.z);
@@ -1670,6 +1673,20 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvE
     }
     const int j = (int)blockIdx.y - (A.ow_on ? A.ow_planes : 0) - (A.sc_g ? 1 : 0);
     if (j < 0) { if (layer == 0) scatter_job<D>(A); return; }
+    if constexpr (BLK) {
+        constexpr int RD = D / 64, RF = F / 64, NDD = RD * RD, NB = 4 * NDD + 2 * RD * RF;
+        if (j == NB) { reduce_jobs(A, layer); return; }
+        int jj, rb, cb;
+        if (j < 4 * NDD) { jj = j / NDD; rb = (j % NDD) / RD; cb = (j % NDD) % RD; }
+        else if (j < 4 * NDD + RF * RD) { jj = 4; rb = (j - 4 * NDD) / RD; cb = (j - 4 * NDD) % RD; }
+        else { jj = 5; rb = (j - 4 * NDD - RF * RD) / RF; cb = (j - 4 * NDD - RF * RD) % RF; }
+        WgradJob Jb = A.job[layer * A.jobs_per_layer + jj];
+        const int ldw = Jb.ldw ? Jb.ldw : (jj == 5 ? F : D);
+        Jb.gcol += 64 * rb; Jb.X += 64 * cb; Jb.dW += (size_t)64 * rb * ldw + 64 * cb; Jb.ldw = ldw;
+        Jb.db = (Jb.db && cb == 0) ? Jb.db + 64 * rb : nullptr;
+        wgrad_body<64, 64>(Jb, A);
+        return;
+    }
     if (j == A.jobs_per_layer) { reduce_jobs(A, layer); return; }
     const WgradJob& J = A.job[layer * A.jobs_per_layer + j];
     if constexpr (SUB) {
@@ -1691,6 +1708,8 @@ template <int D, int F>
 __global__ __launch_bounds__(256) void k_wgrad_bf(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, true>(A, Q); }
 template <int D, int F>
 __global__ __launch_bounds__(256) void k_wgrad_bf64(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, true, true>(A, Q); }
+template <int D, int F>
+__global__ __launch_bounds__(256) void k_wgrad_blk(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, false, false, true>(A, Q); }
 
 
 // ---- FMLP: weight gradients of the Intermediate blocks (dense_1, dense_2) + LayerNorm / scorer partial reductions
@@ -1882,10 +1901,17 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
         A.ow_rec = with_score == 2 ? ws.de_rec : nullptr; A.ow_idx32 = ws.idx32; A.ow_z = ws.X[p->n_layer];
         if (with_score == 2 && owner_sorted(p, ws, meta)) { A.ow_ent = ws.de_ent; A.ow_off = ws.de_off; }
     }
-    dim3 grid(gw, NJ + 1 + (scatter ? 1 : 0) + A.ow_planes, (l_hi - l_lo) + A.qeb_plane), blk(256);
+    // fp32 jobs as 64 x 64 blocks cut on the device (k_wgrad_blk) below the at-scale forms: toys B = 256 step 0.1234 -> 0.1221 ms at d = 64
+    // (three alternating pairs), 0.2284 -> 0.2152 ms at d = 128 (the [128 x 128] jobs were 42 us of it).  DR4SR_WGRAD_BLK=0: whole jobs
+    const char* blk_env = DR4SR_ENV("DR4SR_WGRAD_BLK");
+    const bool blk64 = !A.bf16x3 && (blk_env ? atoi(blk_env) != 0 : !ws.scale);
+    const int NY = blk64 ? 4 * (D / 64) * (D / 64) + 2 * (D / 64) * (F / 64) : NJ;
+    if (blk64 && !scatter) lds = sizeof(float) * 64 * 128;
+    dim3 grid(gw, NY + 1 + (scatter ? 1 : 0) + A.ow_planes, (l_hi - l_lo) + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D + 16);
     if (A.qeb_plane && lds_q > lds) lds = lds_q;
-#define WG(D_, F_) do { if (sub64) { big_lds(k_wgrad_bf64<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_bf64<D_, F_>), grid, blk, lds, s, A, Q); } \
+#define WG(D_, F_) do { if (blk64) { big_lds(k_wgrad_blk<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_blk<D_, F_>), grid, blk, lds, s, A, Q); } \
+                        else if (sub64) { big_lds(k_wgrad_bf64<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_bf64<D_, F_>), grid, blk, lds, s, A, Q); } \
                         else if (A.bf16x3) { big_lds(k_wgrad_bf<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_bf<D_, F_>), grid, blk, lds, s, A, Q); } \
                         else { big_lds(k_wgrad<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad<D_, F_>), grid, blk, lds, s, A, Q); } } while (0)
     if (D == 64 && F == 128) WG(64, 128);
