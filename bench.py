@@ -54,12 +54,14 @@ def init_params_like_reference(eng, seed):
     eng.load_named(sd)
 
 
-def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen, big=None):
-    """ALGORITHMIC flops of one launch on the packed batch: 2*M*N*K per GEMM over the T valid tokens."""
+def kernel_flops(kind, T, B, L, D, F, n_layer, seqlen, big=None, in_tile=False):
+    """ALGORITHMIC flops of one launch on the packed batch: 2*M*N*K per GEMM over the T valid tokens.
+    in_tile: the attention of the layer runs inside the token-tile launches (csrc/attn_tile.h): forward 2, backward 5 products per pair."""
+    att = 2.0 * float((seqlen * (seqlen + 1) // 2).sum()) * D if in_tile else 0.0
     if kind in ("post_fwd", "post_bwd"):
-        return 2.0 * T * (D * D + 2 * D * F) + (2.0 * T * 3 * D * D if n_layer > 1 else 0.0)   # + the next layer's qkv projection
+        return 2.0 * T * (D * D + 2 * D * F) + (2.0 * T * 3 * D * D if n_layer > 1 else 0.0) + (2.0 if kind == "post_fwd" else 5.0) * att   # + the next layer's qkv projection
     if kind == "post_mid":
-        return 2.0 * 2.0 * T * (D * D + 2 * D * F)          # post_fwd + post_bwd of the last layer (scorer: VALU dots, not counted)
+        return 2.0 * 2.0 * T * (D * D + 2 * D * F) + 7.0 * att          # post_fwd + post_bwd of the last layer (scorer: VALU dots, not counted)
     if kind in ("qkv_fwd", "qkv_bwd", "embqkv_fwd", "qkv_embed_bwd"):
         return 2.0 * T * 3 * D * D
     if kind in ("wgrad", "wgrad_fused"):
@@ -87,8 +89,9 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
     # <= ~10 k: dr4sr_sasrec_at_scale) the embedding-stage backward rides in the k_wgrad launch (`wgrad_fused`), at scale
     # it is a launch of its own.
     big = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 1)
-    launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1), ("attn_fwd", NL - 1, NL), ("post_fwd", 0, NL - 1),
-                ("post_mid", 0, 1), ("attn_bwd", NL - 1, NL), ("post_bwd", 0, NL - 1)]
+    in_tile = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 4)       # latency regime: no attention launches (csrc/attn_tile.h)
+    launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1)] + ([] if in_tile else [("attn_fwd", NL - 1, NL)]) + [("post_fwd", 0, NL - 1),
+                ("post_mid", 0, 1)] + ([] if in_tile else [("attn_bwd", NL - 1, NL)]) + [("post_bwd", 0, NL - 1)]
     launches += ([("qkv_embed_bwd", 0, 1)] if big else []) + [("wgrad_fused", 0, 1), ("adam", 0, 1)]
     per_step_launches = {k: n for k, _, n in launches}
     mwp = C.byref(mw) if mw is not None else None
@@ -116,7 +119,7 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
     names_per_kind = {"attn_bwd": 3 if lists else 1, "attn_fwd": 2 if lists else 1}
     dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last, big) > 0),
               key=lambda k: step_us[k] / names_per_kind.get(k, 1))
-    fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last, big)
+    fl = kernel_flops(dom, T_last, B, L, D, F, NL, seqlen_last, big, in_tile)
     ach = fl / (ktime[dom] * 1e-6) / 1e12
     # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (tools/traffic_pmc.sh: FETCH_SIZE x2
     # gfx950 correction + WRITE_SIZE, separate rocprofv3 runs); only for the workloads that were profiled
@@ -161,10 +164,10 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
     # the token-tile kernels against BOTH roofs: at scale they are bound by the saved-activation stream (HBM), not by the matrix pipe
     both = {}
     for k, us in ktime.items():
-        kb = kernel_bytes(k, T_last, D, F, NL)
+        kb = kernel_bytes(k, T_last, D, F, NL, in_tile)
         if kb is None:
             continue
-        fk = kernel_flops(k, T_last, B, L, D, F, NL, seqlen_last, big)
+        fk = kernel_flops(k, T_last, B, L, D, F, NL, seqlen_last, big, in_tile)
         both[k] = {"us_per_launch": round(us, 2), "hbm_frac": round(kb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                    "mfma_f32_frac": round(fk / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4), "algorithmic_bytes": kb}
     out["roofline_tile_kernels"] = both
@@ -270,9 +273,15 @@ def cpu_baseline_leg(rows_np, N, model_kind, p, interval=30):
                       % (r["steps"], r["seconds"], what, r_off["steps"], r["threads"], os.cpu_count() or 0)}
 
 
-def kernel_bytes(kind, T, D, F, n_layer):
+def kernel_bytes(kind, T, D, F, n_layer, in_tile=False):
     """ALGORITHMIC HBM bytes of one launch of the fused step's token-tile kernels: every saved activation / gradient row the launch has
-    to read or write once, fp32; table rows and weights are cache-resident and not counted."""
+    to read or write once, fp32; table rows and weights are cache-resident and not counted.
+    in_tile (attention inside the launch, csrc/attn_tile.h): + q, k, v in and the statistics out (forward; ctx becomes an output),
+    + q, k, v, statistics in and dq, dk, dv out (backward; dctx no longer leaves the launch)."""
+    if in_tile and kind in ("post_fwd", "post_mid", "post_bwd"):
+        extra = {"post_fwd": 3 * D + 4, "post_bwd": (3 * D + 4) + 3 * D - D, "post_mid": (3 * D + 4) + (3 * D + 3 * D - D)}[kind]
+        base = kernel_bytes(kind, T, D, F, n_layer)
+        return base + 4.0 * extra * T
     per = {"post_fwd": 9 * D + 2 * F + 4,                  # ctx, x in; u1, y, a, h, u2, z, next qkv, LayerNorm statistics out
            "post_bwd": (7 * D + F + 4) + (4 * D + F + 2),  # upper dqkv, du1, u2, a, u1, ctx, statistics in; df, da, du1, dout, dctx, rd out
            "post_mid": (5 * D + F) + (9 * D + 3 * F),      # forward + backward of the last layer around the scorer

@@ -43,6 +43,7 @@ struct Workspace {
     float* dctx;                               // [T,D] scratch
     int4* de_rec;                              // [Tmax] scorer records {target id or 0, negative id, d pos score, d neg score} of the owner-computes table gradient
     int* idx32;                                // [Tmax] input item id per packed token (0 = contributes nothing), written by k_embqkv_fwd
+    int2* tok;                                 // [Tmax] {first token of the token's sequence, sequence slot | sequence length << 20 | PAD << 30}, written by k_embqkv_fwd (attn_tile.h)
     int4* de_ent;                              // [3 Tmax] table-gradient entries of each token tile sorted by owner (linear.hip tile_sort)
     unsigned char* de_off;                     // [Tmax / 32 + 1][1028] start offsets of the owners' buckets inside each tile's entries
     float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
@@ -70,6 +71,12 @@ static inline bool at_scale(int Tmax) { return Tmax > latency_tmax(); }
 constexpr int DR4SR_SCALE_TOKENS = 7168, DR4SR_ATTN_SPLIT_TOKENS = 14336;      // at d = 64; scaled by 64 / d
 
 // argument blocks shared by the tile kernels of linear.hip (SASRec layer) and their FMLP re-use
+// attention inside the 16-token tile kernels of the latency regime (attn_tile.h): this layer's qkv / dqkv / ctx / statistics and the
+// per-token words {first token of the sequence, sequence slot | sequence length << 20 | PAD << 30} the embedding stage wrote
+struct TileAttnArgs {
+    const float* qkv; float* dqkv; float* ctx; float* stat; const int2* tok; int L;
+    int on;                                    // bit 0: on; bit 1 (DR4SR_ATTN_TILE_ATOMICS): no plain stores for tile-private dK | dV rows
+};
 struct PostArgs {
     // forward inputs / saved activations
     const float* ctx; const float* x;
@@ -87,6 +94,8 @@ struct PostArgs {
     // layer-boundary fusions (NULL = not fused)
     const float* nx_in_w; const float* nx_in_b; float* nx_qkv;     // fwd: also emit qkv of layer+1 = z W_in^T + b
     const float* up_dqkv; const float* up_in_w; const float* up_du1;   // bwd: dz = up_dqkv W_in(layer+1) + up_du1 instead of reading A.dz
+    TileAttnArgs at;                           // at.on: the attention of this layer runs inside the tile kernels (no attention launches)
+    float* nx_dqkv_zero;                       // ... and the launch that emits layer+1's qkv zeroes the K | V rows of its dqkv (atomics target)
 };
 
 // layer-0 fusions (linear.hip k_embqkv_fwd / k_qkv_embed_bwd and their wave-tile forms)
@@ -95,6 +104,7 @@ struct EmbQkvArgs {
     const float* W; const float* bias; float* QKV; const int* state;
     int B, L, n_items, training; uint64_t seed; float p;
     int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
+    int2* tok; float* dqkv_zero;               // attention in the tile kernels (attn_tile.h): per-token words out, layer 0's dK | dV rows zeroed
 };
 struct QkvEmbBwdArgs {
     const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
@@ -186,6 +196,7 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // planes), the embedding-stage plane and the scorer partials belong to the launch that holds layer 0
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb = false,
                  bool meta = false, int l_lo = 0, int l_hi = -1);     // meta: the fused last-layer launch carried the MetaModel weighting (its tile size differs)
+bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws);    // latency regime: attention inside k_post_fwd / k_post_mid / k_post_bwd (attn_tile.h)
 bool qeb_in_wgrad(const Workspace& ws);         // latency regime: k_qkv_embed_bwd's tiles run as the first plane of the k_wgrad launch
 
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);

@@ -123,9 +123,31 @@ int launch_qkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 }
 
 
+#include "attn_tile.h"
+__host__ __device__ constexpr int post_lds_floats(int D, int F, int bm) {
+    return bm * ((D + 4) + ((D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4));     // R0+R2 must hold a [BM][3D+4] tile
+}
+// attention inside the tile kernels (attn_tile.h): its LDS area sits behind the post kernels' tiles and the scorer's scratch
+__host__ __device__ constexpr int att_lds_off(int D, int F) { return post_lds_floats(D, F, 16) + 96; }
+static size_t att_lds_bytes(int D) { return sizeof(float) * (D == 64 ? tattn::Lds<64>::floats : tattn::Lds<128>::floats); }
+// Latency regime, two heads, L <= 64: no attention launches.  DR4SR_ATTN_SEPARATE: one workgroup per sequence as before (cross-check)
+bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    if (DR4SR_ENV("DR4SR_ATTN_SEPARATE") || DR4SR_ENV("DR4SR_NO_FUSE") || DR4SR_ENV("DR4SR_ATTN_VALU")) return false;
+    return p->H == 2 && p->L <= 64 && (p->D == 64 || p->D == 128) && tile_rows(ws) == 16 && !ws.attn_split && !wave_tiles(p, ws);
+}
+
 // Layer-0 fusion: the token tile is gathered straight from the item/position tables (a3: sasrec.py:42-48,:61-66 —
 // x = drop(E[idx] + P[pos]), 16 lanes per token, sequence slot by binary search in cu[]) into LDS, written once to X[0]
 // (residual + weight-gradient input) and multiplied by W_in in the same launch.
+// the dK | dV rows of a token tile (attn_tile.h adds into them with atomics two launches later)
+template <int BM, int D>
+__device__ __forceinline__ void zero_kv_rows(float* dqkv, const int t0, const int T) {
+    constexpr int C4 = 2 * D / 4;
+    for (int i = threadIdx.x; i < BM * C4; i += 256) {
+        const int r = i / C4, c = (i % C4) * 4;
+        if (t0 + r < T) st4(dqkv + (size_t)(t0 + r) * 3 * D + D + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
 template <int BM, int D>
 __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     constexpr int N = 3 * D, LDA = D + 4, LPT = D / 4, TPB = 256 / LPT;
@@ -146,6 +168,7 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
                 const int64_t row = A.rows ? A.rows[b] : b;
                 int64_t id = A.idx[row * A.L + pos];
                 if (A.idx32 && c == 0) A.idx32[t] = (id > 0 && id < A.n_items) ? (int)id : 0;      // as the backward's scatter tests it
+                if (A.tok && c == 0) A.tok[t] = make_int2(t - pos, b | ((A.cu[b + 1] - A.cu[b]) << 20) | (id == 0 ? 1 << 30 : 0));
                 id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
                 o = ld4(A.E + id * D + c);
                 const float4 pe = ld4(A.P + (size_t)pos * D + c);
@@ -164,6 +187,7 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     tile_zero(acc);
     tile_mma_xwT<BM, D, N>(As, LDA, A.W, D, acc);
     tile_to_global<BM, N>(acc, A.QKV, N, A.bias, t0, T);
+    if (A.dqkv_zero) zero_kv_rows<BM, D>(A.dqkv_zero, t0, T);
 }
 
 int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
@@ -175,6 +199,8 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.W = p->params + poff(ws, 0, P_IN_W); A.bias = p->params + poff(ws, 0, P_IN_B); A.QKV = ws.layer[0].qkv; A.state = p->state;
     A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.idx32 = de_owner_mode(ws) ? ws.idx32 : nullptr;
+    const bool in_tile = attn_in_tile(p, ws);
+    A.tok = in_tile ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
     if (wave_tiles(p, ws)) return launch_wt_embqkv_fwd(A, ws.Tmax, s);
 #define EQ(B_) do { if (D == 64) hipLaunchKernelGGL((k_embqkv_fwd<B_, 64>), grid, blk, lds, s, A); \
                     else hipLaunchKernelGGL((k_embqkv_fwd<B_, 128>), grid, blk, lds, s, A); } while (0)
@@ -239,8 +265,9 @@ __device__ __forceinline__ void ln_rowpass(const float* __restrict__ Cs, int ldc
     }
 }
 
-template <int BM, int D, int F, bool FFN_ONLY>
-__device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, const int T, float4 (*zreg)[D / 64] = nullptr) {
+template <int BM, int D, int F, bool FFN_ONLY, bool KEEPQ = false>
+__device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, const int T, float4 (*zreg)[D / 64] = nullptr,
+                                              tattn::Keep* keep_out = nullptr) {
     constexpr int LD = D + 4, LF = F + 4, NVF = F / 64, PASSES = BM / 16;
     float* R0 = smem;                 // [64][LD]  ctx tile, later linear2 output
     float* R1 = R0 + BM * LD;         // [64][LD]  y tile
@@ -262,12 +289,21 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
     if (FFN_ONLY) {                            // FMLP Intermediate block: the input tile IS y
         load_tile_bm<BM, D>(R1, LD, A.x, D, t0, T);
     } else {
-        load_tile_bm<BM, D>(R0, LD, A.ctx, D, t0, T);
+        constexpr bool AT = BM == 16 && (D == 64 || D == 128);      // attention of the tile's rows in this launch (attn_tile.h)
+        bool at_on = false;
+        if constexpr (AT) at_on = A.at.on != 0;
+        if (!at_on) load_tile_bm<BM, D>(R0, LD, A.ctx, D, t0, T);
         if constexpr (PF) {
             wfrag_load(f_out, A.out_w, D);
             wfrag_load(f_w1, A.w1, D);
             wfrag_load(f_w2, A.w2, F);
             if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+        }
+        if constexpr (AT) {
+            if (at_on) {
+                const tattn::Keep k = tattn::fwd<D, KEEPQ>(A, t0, T, R0, LD, smem + att_lds_off(D, F));
+                if (keep_out) *keep_out = k;
+            }
         }
         lds_barrier(); STAMP(1);
         {
@@ -330,6 +366,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         if constexpr (PF) tile_mma_frag<BM, D, 3 * D>(R1, LD, f_nx, acc);
         else tile_mma_xwT<BM, D, 3 * D>(R1, LD, A.nx_in_w, D, acc);
         tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
+        if (A.nx_dqkv_zero) zero_kv_rows<BM, D>(A.nx_dqkv_zero, t0, T);
     } else {
         ln_rowpass<BM, D, true, false>(R0, LD, R1, LD, A.ln2_w, A.ln2_b, A.eps, A.u2, A.z, A.st2, nullptr, 0, t0, T, dodrop, rk, sF, zreg);
     }
@@ -429,7 +466,7 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
 
 template <int BM, int D, int F, bool FFN_ONLY>
 __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, const int T, const int tile,
-                                              const float4 (*dzreg)[D / 64] = nullptr) {
+                                              const float4 (*dzreg)[D / 64] = nullptr, const tattn::Keep* att_staged = nullptr) {
     constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64, PASSES = BM / 16;
     float* R1 = smem;                          // R1 first: R0 and R2 are contiguous and together hold a [64][3D+4] dqkv tile
     float* R0 = R1 + BM * LD;
@@ -440,6 +477,26 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     const uint32_t sP = A.sP, sA = A.sA, sF = A.sF;
     const bool actdrop = dodrop && sA != 0xffffffffu;
     float4 dgam[NV], dbet[NV];
+    // attention backward of the tile's rows at the end of this launch (attn_tile.h): its operands are requested first
+    // (att_staged: k_post_mid — the forward half of the launch left window, Q rows, statistics and keep decisions behind)
+    constexpr bool AT = BM == 16 && !FFN_ONLY && (D == 64 || D == 128);
+    bool at_on = false, at_stage = false;
+    tattn::Keep keep{0xffffffffu, 0xffffffffu};
+    tattn::Stage<AT ? D : 64, true, true> att_st;
+    if constexpr (AT) {
+        at_on = A.at.on != 0;
+        at_stage = at_on && !att_staged;
+        if (att_staged) keep = *att_staged;
+        if (at_stage) {
+            const int2 mq = tattn::own_word(A.at, t0, T);
+            att_st.issue(A.at, t0, T);
+            __builtin_amdgcn_sched_barrier(0);
+            keep = tattn::own_keep(A, mq, t0, T);          // Philox calls while the window is in flight
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    STAMP(16);
+    auto att_commit = [&]() { if constexpr (AT) { if (at_stage) att_st.commit(tattn::Lds<D>(smem + att_lds_off(D, F))); } };
 
     // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
     if (!FFN_ONLY && A.up_dqkv) {
@@ -447,6 +504,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         constexpr int LQ = 3 * D + 4;
         float* Aq = R0;                            // [64][LQ] spans R0 + R2 (see post_lds)
         load_tile_bm<BM, 3 * D>(Aq, LQ, A.up_dqkv, 3 * D, t0, T);
+        att_commit();                              // behind this phase's own loads: one round trip for both
         lds_barrier();
         TileAcc<BM, D> acc;
         tile_zero(acc);
@@ -455,8 +513,10 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         lds_barrier();
         ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
     } else if (dzreg) {
+        att_commit();
         ln_bwd_rowpass<BM, D, 3>(nullptr, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF, dzreg);
     } else {
+        att_commit();
         ln_bwd_rowpass<BM, D, 0>(A.dz, nullptr, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
     }
     flush_affine<NV>(dgam, dbet, R2, A.ln_part + (size_t)tile * 4 * D);
@@ -521,7 +581,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         const int row = i / C4, c = (i % C4) * 4;
         const bool ok = t0 + row < T;
         const float4 v = ld4(R0 + row * LD + c);
-        if (ok) st4(A.dctx + (size_t)(t0 + row) * D + c, v);
+        if (ok && !at_on) st4(A.dctx + (size_t)(t0 + row) * D + c, v);        // (in-tile attention: dctx never leaves the launch)
         if (A.rd) {                                    // softmax-backward row term of the attention: sum_j P dP = <dctx, ctx> per head
             const int lph = C4 / A.n_head;             // lanes per head (contiguous, power of two)
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -529,6 +589,15 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
             float d = (v.x * o.x + v.y * o.y) + (v.z * o.z + v.w * o.w);
             for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
             if (ok && (i % C4) % lph == 0) A.rd[(size_t)(t0 + row) * A.n_head + (i % C4) / lph] = d;
+            if constexpr (AT) { if (at_on && (i % C4) % lph == 0) tattn::Lds<D>(smem + att_lds_off(D, F)).rd[row * 2 + (i % C4) / lph] = d; }
+        }
+    }
+    if constexpr (AT) {
+        if (at_on) {
+            STAMP(17);
+            lds_barrier();
+            STAMP(18);
+            tattn::bwd<D>(A, t0, T, R0, LD, smem + att_lds_off(D, F), keep);
         }
     }
 }
@@ -771,9 +840,6 @@ __device__ __forceinline__ void tile_sort(const ScoreTileArgs& S, const int tile
     // the area stays private to the next tile_sort of this workgroup (one tile per workgroup: none)
 }
 
-__host__ __device__ constexpr int post_lds_floats(int D, int F, int bm) {
-    return bm * ((D + 4) + ((D + 4) + (F + 4) > 3 * D + 4 ? (D + 4) + (F + 4) : 3 * D + 4));     // R0+R2 must hold a [BM][3D+4] tile
-}
 // D = 64: the row passes of the post kernels and the scorer use the SAME thread -> (row, 4 columns) map (16 lanes per token), so the
 // query row goes from LayerNorm2 to the scorer and dz from the scorer to LayerNorm2's backward IN REGISTERS: no global round trip
 // of z / dz, no vmcnt-draining workgroup barriers around the scorer (each was ~1-2 us of the latency-bound B = 256 launch).  The
@@ -997,19 +1063,21 @@ __device__ __forceinline__ void post_mid_body(const PostArgs& A, const ScoreTile
         float4 zreg[BM / 16][1], dzreg[BM / 16][1];
         PostArgs Af = A;
         if (!S.rec) Af.z = nullptr;                          // the query rows leave the kernel only when the owner job will gather them
-        post_fwd_body<BM, D, F, false>(Af, t0, T, zreg);
+        tattn::Keep keep{0xffffffffu, 0xffffffffu};
+        post_fwd_body<BM, D, F, false, true>(Af, t0, T, zreg, &keep);
         if constexpr (BM != 16) score_prefetch<BM>(A, S, t0, T, P);             // occupancy regime: its registers would cost a workgroup per CU
         if constexpr (META) lds_barrier();                   // every wave is past the forward half's last LDS reads: the tiles are free
         score_tile_regs<BM, META>(A, S, t0, T, blockIdx.x, P, zreg, dzreg, smem + post_lds_floats(D, F, BM), smem);
         if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, blockIdx.x, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
-        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, dzreg);
+        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, dzreg, &keep);
     } else {
-        post_fwd_body<BM, D, F, false>(A, t0, T);
+        tattn::Keep keep{0xffffffffu, 0xffffffffu};
+        post_fwd_body<BM, D, F, false, true>(A, t0, T, nullptr, &keep);
         __syncthreads();                               // z rows of this tile are visible to the whole workgroup
         score_tile<BM, D, META>(A, S, t0, T, blockIdx.x, smem + post_lds_floats(D, F, BM) + 8);
         if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, blockIdx.x, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
         __syncthreads();                               // dz rows written, LDS scratch free again
-        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x);
+        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, nullptr, &keep);
     }
 }
 template <int BM, int D, int F, bool META>
@@ -1049,6 +1117,10 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
         A.up_dqkv = ws.layer[layer + 1].dqkv; A.up_in_w = P + poff(ws, layer + 1, P_IN_W); A.up_du1 = ws.layer[layer + 1].du1;
     }
     A.stamps = DR4SR_ENV("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
+    A.at.on = attn_in_tile(p, ws) ? 1 : 0;
+    if (A.at.on && DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;       // cross-check: every dK | dV row through atomics (no plain stores)
+    A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L;
+    A.nx_dqkv_zero = (A.at.on && A.nx_qkv) ? ws.layer[layer + 1].dqkv : nullptr;
     return A;
 }
 
@@ -1057,7 +1129,7 @@ static size_t post_lds(int D, int F, int bm = 64) { return sizeof(float) * post_
 template <int BM>
 static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, bool bwd, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
-    const size_t lds = post_lds(p->D, p->F, BM);
+    const size_t lds = (BM == 16 && A.at.on) ? sizeof(float) * att_lds_off(p->D, p->F) + att_lds_bytes(p->D) : post_lds(p->D, p->F, BM);
 #define PL(D_, F_) do { if (bwd) { big_lds(k_post_bwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_bwd<BM, D_, F_, false>), grid, blk, lds, s, A); } \
                         else { big_lds(k_post_fwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_fwd<BM, D_, F_, false>), grid, blk, lds, s, A); } } while (0)
     if (p->D == 64 && p->F == 128) PL(64, 128);
@@ -1070,7 +1142,8 @@ static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const
 template <int BM>
 static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, const ScoreTileArgs& S, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
-    const size_t lds = post_lds(p->D, p->F, BM) + 8 * sizeof(float) + (S.ent ? tile_sort_lds_bytes(BM, 1 << S.logG) : 0);   // + the scorer's (count, loss) reduction scratch + tile_sort's records
+    const size_t lds = (BM == 16 && A.at.on) ? sizeof(float) * att_lds_off(p->D, p->F) + att_lds_bytes(p->D)
+                       : post_lds(p->D, p->F, BM) + 8 * sizeof(float) + (S.ent ? tile_sort_lds_bytes(BM, 1 << S.logG) : 0);   // + the scorer's (count, loss) reduction scratch + tile_sort's records
 #define PM(D_, F_) do { if constexpr (BM == 32 && D_ == 64) { big_lds(k_post_mid32<D_, F_>, lds); hipLaunchKernelGGL((k_post_mid32<D_, F_>), grid, blk, lds, s, A, S); } \
                         else { big_lds(k_post_mid<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_, false>), grid, blk, lds, s, A, S); } } while (0)
     if (S.phi) {                                       // MetaModel weighting: D = 64 only (checked by the entry point)

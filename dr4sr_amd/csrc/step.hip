@@ -141,7 +141,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->attn_rd = take(Tmax * p->H);
     for (int i = 0; i <= p->n_layer; ++i) { ws->X[i] = take(Tmax * D); ws->dX[i] = take(Tmax * D); }
     ws->dctx = take(Tmax * D);
-    ws->de_rec = (int4*)take(Tmax * 4); ws->idx32 = (int*)take(Tmax);
+    ws->de_rec = (int4*)take(Tmax * 4); ws->idx32 = (int*)take(Tmax); ws->tok = (int2*)take(2 * Tmax);
     ws->de_ent = (int4*)take(Tmax * 12); ws->de_off = (unsigned char*)take((Tmax / 16 + 1) * 257);     // [tiles of >= 16 tokens][G + 4 <= 1028 bytes]
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
@@ -177,7 +177,7 @@ extern "C" int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan) {
     if (check_shape(&q)) return DR4SR_E_SHAPE;
     Workspace ws;
     carve_workspace(&q, &ws);
-    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0);
+    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0);     // bit 2: attention inside the tile kernels (attn_tile.h)
 }
 
 static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
@@ -386,9 +386,10 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
     const bool fuse = DR4SR_ENV("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1),
     if (fuse) RC(launch_embqkv_fwd(p, ws, training, s));             // qkv of layer 0 by the embedding gather
     else RC(launch_embed_fwd(p, ws, training, s));
+    const bool in_tile = attn_in_tile(p, ws);                    // the attention runs at the head of post_fwd / post_mid (attn_tile.h)
     for (int l = 0; l < p->n_layer; ++l) {
         if (!fuse) RC(launch_qkv_fwd(p, ws, l, s));
-        RC(attn_fwd(p, ws, l, training, s));
+        if (!in_tile) RC(attn_fwd(p, ws, l, training, s));
         if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_fwd(p, ws, l, training, s));
     }
     return 0;
@@ -407,7 +408,7 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
     bool forked = false;
     for (int l = p->n_layer - 1; l >= 0; --l) {
         if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_bwd(p, ws, l, training, s));
-        RC(attn_bwd(p, ws, l, training, s));
+        if (!attn_in_tile(p, ws)) RC(attn_bwd(p, ws, l, training, s));      // else: the tail of post_bwd / post_mid
         if (!fused) RC(launch_qkv_bwd(p, ws, l, s));      // else folded into post_bwd(l-1) / the embedding scatter
         if (early && l >= 1) {
             RC(fk.fork(s, 2, 1));                           // side 2 is a queue: the layers' launches run one after the other on it

@@ -320,10 +320,14 @@ _SWITCH_CASES = [
     ({"DR4SR_PREP2_INLINE": "1"}, "train_steps"),
     # round 4: the wave-tile backward recomputing the linear1 pre-activations instead of loading them (opt-in: measured slower)
     ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_RECOMPUTE_A": "1"}, "full_size fuzz dropout"),
+    # round 4: attention inside the 16-token tile kernels is the latency regime's default (csrc/attn_tile.h); the one-workgroup-per-sequence
+    # launches as the cross-check, and the tile form with every dK | dV row through atomics
+    ({"DR4SR_ATTN_SEPARATE": "1"}, "full_size dropout"),       # (DR4SR_NO_FUSE / DR4SR_ATTN_VALU above run the separate launches too)
+    ({"DR4SR_ATTN_TILE_ATOMICS": "1"}, "full_size dropout"),
     # round 4: the six whole fp32 weight-gradient jobs per layer instead of their 64 x 64 blocks (k_wgrad instead of k_wgrad_blk)
     ({"DR4SR_WGRAD_BLK": "0"}, "full_size fuzz trajectory"),
     # the 4-wave per-sequence attention backward (head_dim 64 ran on it until round 3)
-    ({"DR4SR_ATTN_BWD_4WAVE": "1"}, "full_size dropout"),
+    ({"DR4SR_ATTN_BWD_4WAVE": "1", "DR4SR_ATTN_SEPARATE": "1"}, "full_size dropout"),
 ]
 
 
