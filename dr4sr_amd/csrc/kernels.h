@@ -69,6 +69,8 @@ static inline int64_t poff(const Workspace& ws, int layer, int j) { return ws.of
 int latency_tmax();
 static inline bool at_scale(int Tmax) { return Tmax > latency_tmax(); }
 constexpr int DR4SR_SCALE_TOKENS = 7168, DR4SR_ATTN_SPLIT_TOKENS = 14336;      // at d = 64; scaled by 64 / d
+constexpr int DR4SR_SCALE_TOKENS_SHORT = 10240, DR4SR_SCALE_TOKENS_LONG = 6144;    // ... with the attention inside the tile kernels: expected mean length <= 16 / above
+bool attn_tile_capable(const dr4sr_sasrec_plan* p);        // shape and switches allow attn_tile.h (the launch forms decide the rest)
 
 // argument blocks shared by the tile kernels of linear.hip (SASRec layer) and their FMLP re-use
 // attention inside the 16-token tile kernels of the latency regime (attn_tile.h): this layer's qkv / dqkv / ctx / statistics and the

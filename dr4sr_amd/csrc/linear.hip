@@ -131,9 +131,12 @@ __host__ __device__ constexpr int post_lds_floats(int D, int F, int bm) {
 __host__ __device__ constexpr int att_lds_off(int D, int F) { return post_lds_floats(D, F, 16) + 96; }
 static size_t att_lds_bytes(int D) { return sizeof(float) * (D == 64 ? tattn::Lds<64>::floats : tattn::Lds<128>::floats); }
 // Latency regime, two heads, L <= 64: no attention launches.  DR4SR_ATTN_SEPARATE: one workgroup per sequence as before (cross-check)
-bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+bool attn_tile_capable(const dr4sr_sasrec_plan* p) {
     if (DR4SR_ENV("DR4SR_ATTN_SEPARATE") || DR4SR_ENV("DR4SR_NO_FUSE") || DR4SR_ENV("DR4SR_ATTN_VALU")) return false;
-    return p->H == 2 && p->L <= 64 && (p->D == 64 || p->D == 128) && tile_rows(ws) == 16 && !ws.attn_split && !wave_tiles(p, ws);
+    return p->H == 2 && p->L <= 64 && (p->D == 64 || p->D == 128);
+}
+bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    return attn_tile_capable(p) && tile_rows(ws) == 16 && !ws.attn_split && !wave_tiles(p, ws);
 }
 
 // Layer-0 fusion: the token tile is gathered straight from the item/position tables (a3: sasrec.py:42-48,:61-66 —
@@ -600,6 +603,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
             tattn::bwd<D>(A, t0, T, R0, LD, smem + att_lds_off(D, F), keep);
         }
     }
+    STAMP(26);
 }
 
 template <int BM, int D, int F, bool FFN_ONLY>

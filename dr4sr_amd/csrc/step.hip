@@ -118,7 +118,11 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         const int64_t hint = p->expected_tokens < Tmax ? p->expected_tokens : Tmax;
         const bool known = hint > 0 && !forced;
         // boundaries measured at d = 64; at d = 128 both crossovers sit at half the token count (4 k / 7 k): the work per token doubles
-        ws->scale = known ? hint * D > (int64_t)DR4SR_SCALE_TOKENS * 64 : at_scale((int)Tmax);
+        // round 4: with the attention inside the 16-token tile kernels (attn_tile.h) the latency forms carry toys-shaped batches further
+        // (B = 1 536, 8.5 k tokens: 0.227 against 0.240 ms; tie at 11 k) and long-sequence batches less far (all-50 rows, 6 400 tokens:
+        // 0.199 against 0.193 ms — every query sees all five key tiles of its window): the boundary follows the expected mean length
+        const int64_t scale_tokens = !attn_tile_capable(p) ? DR4SR_SCALE_TOKENS : (hint <= 16 * (int64_t)p->B ? DR4SR_SCALE_TOKENS_SHORT : DR4SR_SCALE_TOKENS_LONG);
+        ws->scale = known ? hint * D > scale_tokens * 64 : at_scale((int)Tmax);
         // the length-class lists pay off through their short classes (1..8-token VALU class, 16-row tiles); a batch of LONG sequences
         // runs faster as one 8-wave workgroup per sequence at every size (round 3, all-50 batches: B = 2 048 0.929 vs 0.990 ms,
         // B = 8 192 3.36 vs 3.62 ms), so the lists also need an expected mean length of at most 16 tokens

@@ -592,12 +592,12 @@ def test_regime_follows_the_expected_token_hint(monkeypatch):
     short, full = torch.full((4096,), 5, dtype=torch.int64, device=dev), torch.full((4096,), 50, dtype=torch.int64, device=dev)
     # bit 0: at-scale token-tile kernels (> ~7 k expected tokens), bit 1: length-class attention lists (> ~14 k),
     # bit 2 (round 4): the attention runs inside the 16-token tile kernels — the latency regime (neither of the other two)
-    assert scale(256, short) == 4 and scale(1400, short) == 4                                  # 1 280 / 7 000 expected tokens
-    assert scale(1500, short) == 1 and scale(2800, short) == 1                                 # 7 500 / 14 000: tiles at scale, attention per sequence
+    assert scale(256, short) == 4 and scale(1400, short) == 4 and scale(2000, short) == 4      # 1 280 / 7 000 / 10 000 expected tokens
+    assert scale(2100, short) == 1 and scale(2800, short) == 1                                 # 10 500 / 14 000: tiles at scale, attention per sequence
     assert scale(2900, short) == 3 and scale(4096, short) == 3
     # batches of LONG sequences (expected mean length > 16) never take the attention lists: one 8-wave workgroup per sequence is faster
     # at every size (round 3, tools/regime_sweep3.sh --dense)
-    assert scale(128, full) == 4 and scale(160, full) == 1 and scale(300, full) == 1 and scale(4096, full) == 1      # 6 400 / 8 000 / 15 000 / 204 800 tokens
+    assert scale(120, full) == 4 and scale(128, full) == 1 and scale(160, full) == 1 and scale(300, full) == 1 and scale(4096, full) == 1      # 6 000 / 6 400 / 8 000 / 15 000 / 204 800 tokens (long sequences: boundary 6 144)
     mid = torch.full((4096,), 16, dtype=torch.int64, device=dev)
     assert scale(1000, mid) == 3                                                                # 16 000 tokens, mean length 16: lists
     assert scale(256, short, hint=0) == 4 and scale(400, short, hint=0) == 3                   # unknown: capacity 12 800 / 20 000 decides both

@@ -7,7 +7,7 @@ from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
 import bench
 lib = _lib.load()
 dev = torch.device("cuda", 0)
-B, L, D, H, F, NL, N = 256, 50, 64, 2, 128, 2, TOYS_N_ITEMS
+B, L, D, H, F, NL, N = 256, 50, int(os.environ.get("EMBED_DIM", "64")), 2, 128, 2, TOYS_N_ITEMS
 rows = make_rows(n_items=N, seed=2024, dense=bool(int(os.environ.get("DENSE", "0"))))
 data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
 eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, 0.5, B, dev, seed=2023)
@@ -39,3 +39,10 @@ for kind, layer in (("post_fwd", 0), ("post_bwd", 0)):
         idx = [16, 17, 18, 20, 21, 22, 23]
     print(kind, layer, "us/launch %.2f" % (a.elapsed_time(b) * 1e3 / 20), "stamps", idx, "ticks since first", [int(st[i] - st[idx[0]]) for i in idx],
           "phase B (thread 128): start, end", int(st[24] - st[idx[0]]), int(st[25] - st[idx[0]]))
+# ... and the same stamps as the REAL step leaves them (k_post_bwd of layer 0 is the last writer of 16..25)
+for _ in range(3):
+    eng.train_step(plan)
+torch.cuda.synchronize()
+st = eng.workspace[off:off + 32 * 8].view(torch.int64).cpu().numpy()
+idx = [16, 17, 18, 20, 21, 22, 26]
+print("real step, k_post_bwd layer 0: stamps", idx, [int(st[i] - st[16]) for i in idx], "phase B start, end", int(st[24] - st[16]), int(st[25] - st[16]))
