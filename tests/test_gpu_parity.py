@@ -631,6 +631,47 @@ def test_every_accepted_encoder_shape_matches_oracle(D, H, F, NL, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D,L,separate", [(64, 64, False), (64, 64, True), (128, 64, False), (64, 50, False)])
+def test_attention_in_tile_edge_cases(D, L, separate, monkeypatch):
+    """csrc/attn_tile.h (the latency regime's attention, inside the 16-token tile kernels): sequences of the maximum length (the window's
+    first row), lengths around the tile size (15 / 16 / 17 / 31 / 32 / 33: sequences that start or end on a tile boundary), single tokens,
+    PAD ids INSIDE sequences (key_padding_mask, model/sasrec.py:48), and a batch whose token count is not a multiple of 16 — loss and every
+    gradient against the oracle; `separate` = the one-workgroup-per-sequence launches on the same batch (DR4SR_ATTN_SEPARATE)."""
+    import ctypes as C
+    from dr4sr_amd import _lib
+    from dr4sr_amd.engine import SasrecEngine
+    if separate:
+        monkeypatch.setenv("DR4SR_ATTN_SEPARATE", "1")
+    rng = np.random.default_rng(17 + D + L)
+    N, H, F, NL = 157, 2, 128, 2
+    sl = np.array([L, 1, L, 15, 16, 17, 1, 31, 32, 33, L - 1, 2, 16, 16, 1, 48, L, 3, 5, 8, 13], dtype=np.int64)
+    B = len(sl)
+    inp = np.zeros((B, L), dtype=np.int64); tgt = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        inp[b, :sl[b]] = rng.integers(1, N, size=sl[b]); tgt[b, :sl[b]] = rng.integers(0, N, size=sl[b])
+    for b in (0, 3, 7, 16):                                  # PAD keys inside a sequence (never at position 0: that row would be all-masked)
+        pos = rng.choice(np.arange(1, sl[b]), size=min(3, sl[b] - 1), replace=False)
+        inp[b, pos] = 0
+    batch = {"in_item_id": torch.from_numpy(inp), "item_id": torch.from_numpy(tgt), "seqlen": torch.from_numpy(sl),
+             "neg_item": torch.from_numpy(rng.integers(1, N, size=(B, L, 1)))}
+    assert int(sl.sum()) % 16 != 0
+    params = _random_params(N, D, F, NL, L=L, seed=9)
+    eng = SasrecEngine(N, L, D, H, F, NL, 1e-12, 0.0, B, "cuda")
+    eng.load_named(params)
+    plan = eng.make_plan(batch["in_item_id"].cuda(), batch["item_id"].cuda(), batch["seqlen"].cuda(),
+                         neg_item=batch["neg_item"].squeeze(-1).contiguous().cuda(), sample_neg=False)
+    assert bool(int(_lib.load().dr4sr_sasrec_at_scale(C.byref(plan))) & 4) == (not separate)
+    for _ in range(2):                                       # twice: the second pass finds the first one's dK | dV in the workspace
+        eng.fwd_bwd(plan)
+    loss, n = eng.loss_and_count()
+    loss_o, _, grads_o = O.grads_of(params, batch, H, NL, 1e-12)
+    assert n == int((batch["item_id"] != 0).sum())
+    assert abs(loss - float(loss_o)) < 3e-5
+    for k, v in eng.normalized_grads().items():
+        assert relerr(v, grads_o[k]) < 5e-4, k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,H,F,NL,L", _SHAPES_REFUSED)
 def test_unsupported_encoder_shapes_are_refused_up_front(D, H, F, NL, L):
     """a shape without kernels is an error when the engine is built — not a failed launch, never a wrong number"""
