@@ -215,6 +215,9 @@ SYMBOLS = {
                                              C.c_double, C.c_double, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "dr4sr_cl_prepare": (C.c_int, [_i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_cl_prepare_rows": (C.c_int, [_i64p, _i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p]),
+    "dr4sr_cl_prepare_rows_step": (C.c_int, [_i64p, _i64p, C.c_int32, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "dr4sr_infonce_bwd_scaled": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p, C.c_float, C.c_int32,
+                                           _f32p, _f32p, C.c_void_p]),
     "dr4sr_cl_scalars": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
     "dr4sr_fmlp_adam_step": (C.c_int, [_FPLANP, C.c_void_p]),
     "dr4sr_gru4rec_adam_step": (C.c_int, [_GPLANP, C.c_void_p]),

@@ -100,6 +100,7 @@ class CL4SRec(SASRec):
         clw, temp = float(self.config["model"]["cl_weight"]), float(am.InfoNCE_loss_fn.temperature)
         tail = eng.grads[n:n + 2]
         plans = ()
+        step_in_prepare = False
         if B > 0:
             if views is None:
                 if hasattr(aug, "begin_step"):
@@ -133,7 +134,9 @@ class CL4SRec(SASRec):
                 plans = (eng.make_plan(aug_i.contiguous(), None, len_i.contiguous(), slot=1, expected_tokens=exp_v),
                          eng.make_plan(aug_j.contiguous(), None, len_j.contiguous(), slot=2, expected_tokens=exp_v))
                 q_i, q_j = eng.encode(plans[0], True, _lib.POOL_MEAN), eng.encode(plans[1], True, _lib.POOL_MEAN)
-            if views is None and hasattr(aug, "end_step"):
+            # rows-indirected (captured) step: the device call counter is advanced by the dr4sr_cl_prepare_rows_step launch below
+            step_in_prepare = views is None and rows is not None and dp_counts is None and getattr(aug, "step_dev", None) is not None
+            if views is None and hasattr(aug, "end_step") and not step_in_prepare:
                 aug.end_step()
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         sc = torch.empty(1, dtype=torch.float32, device=dev)               # InfoNCE backward scale
@@ -141,7 +144,10 @@ class CL4SRec(SASRec):
             valid = torch.empty(B, dtype=torch.uint8, device=dev)
             lse, loss_row = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
             dq = torch.empty(2, B, D, dtype=torch.float32, device=dev)
-            if rows is not None:
+            if rows is not None and views is None and step_in_prepare:
+                _lib.check(lib.dr4sr_cl_prepare_rows_step(_lib.ptr(lens), _lib.ptr(rows), B, _lib.ptr(valid), _lib.ptr(stats), _lib.ptr(dq),
+                                                          dq.numel(), _lib.ptr(aug.step_dev), int(aug._in_step), st()), "dr4sr_cl_prepare_rows_step")
+            elif rows is not None:
                 _lib.check(lib.dr4sr_cl_prepare_rows(_lib.ptr(lens), _lib.ptr(rows), B, _lib.ptr(valid), _lib.ptr(stats), _lib.ptr(dq), dq.numel(),
                                                      st()), "dr4sr_cl_prepare_rows")
             else:
@@ -149,10 +155,10 @@ class CL4SRec(SASRec):
                            "dr4sr_cl_prepare")
             _lib.check(lib.dr4sr_infonce_fwd(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(loss_row),
                                              _lib.ptr(stats), st()), "dr4sr_infonce_fwd")
-            _lib.check(lib.dr4sr_cl_scalars_dp(_lib.ptr(tail), 1, 0, _lib.ptr(stats), clw, _lib.ptr(sc), _lib.ptr(tail) if fold_loss else None,
-                                               st()), "dr4sr_cl_scalars_dp")
-            _lib.check(lib.dr4sr_infonce_bwd(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(sc),
-                                             _lib.ptr(dq[0]), _lib.ptr(dq[1]), st()), "dr4sr_infonce_bwd")
+            # (the step's two device scalars inside the backward launch: dr4sr_cl_scalars_dp + dr4sr_infonce_bwd were two)
+            _lib.check(lib.dr4sr_infonce_bwd_scaled(_lib.ptr(q_i), _lib.ptr(q_j), _lib.ptr(valid), B, D, temp, _lib.ptr(lse), _lib.ptr(tail),
+                                                    _lib.ptr(stats), clw, 1 if fold_loss else 0, _lib.ptr(dq[0]), _lib.ptr(dq[1]), st()),
+                       "dr4sr_infonce_bwd_scaled")
             dq_i, dq_j = dq[0], dq[1]
         else:
             # ---- the global batch: [W][Bmax rows of (q_i | q_j | kept) ... | n_valid]

@@ -478,6 +478,15 @@ int dr4sr_cl_augment2_dev(const int64_t* seq, const int64_t* seqlen, int64_t* ou
 int dr4sr_cl_augment2_rows_dev(const int64_t* seq, const int64_t* seqlen, const int64_t* rows, int64_t* out_i, int64_t* len_i,
                                int64_t* out_j, int64_t* len_j, int32_t B, int32_t L, int32_t mode, double tau, double gamma, double beta,
                                int64_t mask_id, uint64_t seed, const int32_t* step_dev, uint32_t step_offset, void* stream);
+/* round 4: dr4sr_cl_prepare_rows that also advances the augmentation's device call counter by step_add (module/data_augmentation.py
+ * end_step()), and dr4sr_infonce_bwd with the step's scalars computed inside: backward scale = cl_weight * tail[0] / stats[0], and with
+ * fold_tail != 0 the contrastive term's share of the reported loss folded into tail[1] (what dr4sr_cl_scalars_dp in front of it gives) —
+ * two launches less per CL4SRec step (model/cl4srec.py:_cl_term) */
+int dr4sr_cl_prepare_rows_step(const int64_t* seqlen, const int64_t* rows, int32_t B, uint8_t* valid, float* stats, float* zero,
+                               int64_t nzero, int32_t* step_dev, int32_t step_add, void* stream);
+int dr4sr_infonce_bwd_scaled(const float* xi, const float* xj, const uint8_t* valid, int32_t B, int32_t D, float temperature,
+                             const float* lse, float* tail, const float* stats, float cl_weight, int32_t fold_tail,
+                             float* dxi, float* dxj, void* stream);
 /* glue of a CL4SRec step composed without autograd (model/cl4srec.py:49-73 = BCE + cl_weight * InfoNCE):
  *   dr4sr_cl_prepare: valid[b] = seqlen[b] != 1 (data_augmentation.py:613-615), stats[0..1] = 0, zero[0..nzero) = 0;
  *   dr4sr_cl_scalars: with {n_valid, loss_sum} of the main pass in `tail` and InfoNCE's {rows, loss_sum} in `stats`:
