@@ -32,14 +32,14 @@ constexpr int MT = WR / 16;
 template <int D>
 struct Lds {
     static constexpr int LD = D + 4;
-    static constexpr int floats = 2 * WR * LD + 16 * LD + 64 + 32 + 2 * WR + 4;
+    static constexpr int floats = 2 * WR * LD + 16 * LD + 64 + 32 + 2 * WR + 8;
     float *Kw, *Vw, *Qs, *st, *rd; int2* tok; unsigned* pad;
     __device__ __forceinline__ explicit Lds(float* base) {
         Kw = base; Vw = Kw + WR * LD; Qs = Vw + WR * LD;
         st = Qs + 16 * LD;                                    // [H][16][2] row max, 1 / sum
         rd = st + 64;                                         // [16][H]    <dctx, ctx> per head
         tok = reinterpret_cast<int2*>(rd + 32);               // [WR] {first token of the sequence, slot | length << 20 | PAD << 30}
-        pad = reinterpret_cast<unsigned*>(tok + WR);          // [3] PAD flags of the window rows as bits
+        pad = reinterpret_cast<unsigned*>(tok + WR);          // [MT] PAD flags of the rows of key tile jt as bits
     }
 };
 
@@ -104,10 +104,11 @@ template <int D, bool WITH_Q, bool WITH_STAT>
 struct Stage {
     static constexpr int LD = D + 4, C4 = 2 * D / 4, N4 = WR * C4, PER = (N4 + 255) / 256, QPER = (16 * D / 4) / 256;
     int2 tw; float4 v[PER]; float4 qv[WITH_Q ? QPER : 1]; float2 sv;
-    __device__ __forceinline__ void issue(const TileAttnArgs& A, const int t0, const int T) {
+    // rows [r_lo, r_hi) of the window (multiples of 16: whole key tiles)
+    __device__ __forceinline__ void issue(const TileAttnArgs& A, const int t0, const int T, const int r_lo = 0, const int r_hi = WR) {
         const int wb = t0 - QR0, lo = max(0, t0 - (A.L - 1)), hi = min(T, t0 + 16);
         tw = make_int2(0x7fffffff, 0);
-        if ((int)threadIdx.x < WR) {
+        if ((int)threadIdx.x >= r_lo && (int)threadIdx.x < r_hi) {
             const int tk = wb + (int)threadIdx.x;
             if (tk >= lo && tk < hi) tw = A.tok[tk];
         }
@@ -115,7 +116,7 @@ struct Stage {
         for (int q = 0; q < PER; ++q) {
             const int f = threadIdx.x + 256 * q, r = f / C4, c4 = f % C4, tk = wb + r;
             v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < N4 && tk >= lo && tk < hi) v[q] = ld4(A.qkv + (size_t)tk * 3 * D + D + 4 * c4);
+            if (r >= r_lo && r < r_hi && tk >= lo && tk < hi) v[q] = ld4(A.qkv + (size_t)tk * 3 * D + D + 4 * c4);
         }
         if constexpr (WITH_Q) {
 #pragma unroll
@@ -133,17 +134,21 @@ struct Stage {
             }
         }
     }
-    __device__ __forceinline__ void commit(const Lds<D>& S) const {
-        if ((int)threadIdx.x < WR) S.tok[threadIdx.x] = tw;
+    __device__ __forceinline__ void commit(const Lds<D>& S, const int r_lo = 0, const int r_hi = WR) const {
+        if ((int)threadIdx.x >= r_lo && (int)threadIdx.x < r_hi) S.tok[threadIdx.x] = tw;
         if (threadIdx.x < 128) {                             // waves 0, 1 hold the 80 rows' words
             const unsigned long long bal = __ballot(((tw.y >> 30) & 1) != 0);
-            if (threadIdx.x == 0) { S.pad[0] = (unsigned)bal; S.pad[1] = (unsigned)(bal >> 32); }
-            if (threadIdx.x == 64) S.pad[2] = (unsigned)bal;
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    if (16 * jt >= r_lo && 16 * jt < r_hi) S.pad[jt] = (unsigned)(bal >> (16 * jt)) & 0xffffu;
+            }
+            if (threadIdx.x == 64 && 64 >= r_lo && 64 < r_hi) S.pad[4] = (unsigned)bal & 0xffffu;
         }
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int f = threadIdx.x + 256 * q, r = f / C4, c4 = f % C4;
-            if (f < N4) st4((4 * c4 < D ? S.Kw + r * LD + 4 * c4 : S.Vw + r * LD + 4 * c4 - D), v[q]);
+            if (r >= r_lo && r < r_hi) st4((4 * c4 < D ? S.Kw + r * LD + 4 * c4 : S.Vw + r * LD + 4 * c4 - D), v[q]);
         }
         if constexpr (WITH_Q) {
 #pragma unroll
@@ -160,6 +165,21 @@ struct Stage {
         }
     }
 };
+
+// Short-sequence plans (A.on & 4: the plan expects a mean length of at most 16 tokens) stage the NEAR rows [t0 - 16, t0 + 16) only — half the
+// window's bytes, and at these sizes the staging time is bytes x latency (the rows come from another XCD's launch: 0.9 us of k_post_fwd at
+// d = 64, 4 us at d = 128) — and fetch the far rows in a second round trip in the tiles whose first token's sequence started more than 16
+// tokens earlier (one in ten on a toys-shaped batch).  Call with every thread of the workgroup, behind a barrier that made the near rows'
+// words visible; ends with a barrier when it staged something.
+constexpr int NEAR0 = WR - 32;
+template <int D>
+__device__ __forceinline__ void far_rows_if_needed(const TileAttnArgs& A, const Lds<D>& S, const int t0, const int T) {
+    if (!(A.on & 4) || S.tok[QR0].x >= t0 - 16) return;       // (workgroup-uniform)
+    Stage<D, false, false> st;
+    st.issue(A, t0, T, 0, NEAR0);
+    st.commit(S, 0, NEAR0);
+    lds_barrier();
+}
 
 // keep decisions of this lane's query row (tile row l & 15, head (wave & 1)) from the token's word in GLOBAL memory: requested before the
 // staging loads, computed while they are in flight
@@ -194,16 +214,18 @@ __device__ __forceinline__ Keep fwd(const PostArgs& P, const int t0, const int T
     if constexpr (!KEEP_QS) frag_g<DH>(qf, A.qkv + h * DH, 3 * D, t0, T);       // used once: straight from global
     {
         Stage<D, KEEP_QS, false> st;
-        st.issue(A, t0, T);
+        const int r_lo = (A.on & 4) ? NEAR0 : 0;
+        st.issue(A, t0, T, r_lo, WR);
         // (the Philox calls run while the window is in flight)
         __builtin_amdgcn_sched_barrier(0);
         const Keep k0 = own_keep(P, mq_g, t0, T);
         klo_ = k0.lo; khi_ = k0.hi;
         __builtin_amdgcn_sched_barrier(0);
-        st.commit(S);
+        st.commit(S, r_lo, WR);
     }
     TSTAMP(8, 0);
     lds_barrier();
+    far_rows_if_needed<D>(A, S, t0, T);
     TSTAMP(9, 0);
     if constexpr (KEEP_QS) frag<DH>(qf, S.Qs, LD, 0, h * DH);
     const int tq = t0 + i16, wb = t0 - QR0;
@@ -211,7 +233,6 @@ __device__ __forceinline__ Keep fwd(const PostArgs& P, const int t0, const int T
     const bool qok = tq < T;
     const int qs = mq.x;
     const int jt_lo = (S.tok[QR0].x - wb) >> 4;          // first key tile a query of this tile can see (token t0 < T always)
-    const unsigned pw0 = S.pad[0], pw1 = S.pad[1], pw2 = S.pad[2];
     const float scale = 1.0f / sqrtf((float)DH);
     f32x4 s[MT];
     float m = -INFINITY;
@@ -222,7 +243,7 @@ __device__ __forceinline__ Keep fwd(const PostArgs& P, const int t0, const int T
             float kf[DH / 4];
             frag<DH>(kf, S.Kw, LD, jt * 16, h * DH);
             s[jt] = mma_rows<DH>(kf, qf);
-            const unsigned pw = (jt < 2 ? pw0 : jt < 4 ? pw1 : pw2) >> ((jt & 1) * 16 + 4 * g);
+            const unsigned pw = S.pad[jt] >> (4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tk = wb + jt * 16 + 4 * g + r;
@@ -295,7 +316,6 @@ __device__ __forceinline__ void bwd(const PostArgs& P, const int t0, const int T
     const Lds<D> S(base);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, i16 = lane & 15, g = lane >> 4;
     const int wb = t0 - QR0, wmin = S.tok[QR0].x, jt_lo = (wmin - wb) >> 4, hi = min(T, t0 + 16);
-    const unsigned pw0 = S.pad[0], pw1 = S.pad[1], pw2 = S.pad[2];
     const float scale = 1.0f / sqrtf((float)DH);
     const bool dodrop = P.training && P.p > 0.f;
     const float keepv = dodrop ? 1.0f / (1.0f - P.p) : 1.f;
@@ -319,7 +339,7 @@ __device__ __forceinline__ void bwd(const PostArgs& P, const int t0, const int T
                 const f32x4 s = mma_rows<DH>(kf, qf);
                 frag<DH>(kf, S.Vw, LD, jt * 16, h * DH);
                 const f32x4 dp = mma_rows<DH>(kf, cf);         // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
-                const unsigned pw = (jt < 2 ? pw0 : jt < 4 ? pw1 : pw2) >> ((jt & 1) * 16 + 4 * g);
+                const unsigned pw = S.pad[jt] >> (4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int tk = wb + jt * 16 + 4 * g + r;
@@ -365,7 +385,7 @@ __device__ __forceinline__ void bwd(const PostArgs& P, const int t0, const int T
         const f32x4 dp = mma_rows<DH>(cf, vf);                 // dP~[i][j] = sum_d dctx[i][d] V[j][d]
         const int c = jt * 16 + i16, tk = wb + c;
         const int2 kw = S.tok[c];
-        const bool kok = !(((jt < 2 ? pw0 : jt < 4 ? pw1 : pw2) >> (c & 31)) & 1u);
+        const bool kok = !((S.pad[jt] >> i16) & 1u);
         f32x4 pt, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

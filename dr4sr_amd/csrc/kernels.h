@@ -77,7 +77,7 @@ bool attn_tile_capable(const dr4sr_sasrec_plan* p);        // shape and switches
 // per-token words {first token of the sequence, sequence slot | sequence length << 20 | PAD << 30} the embedding stage wrote
 struct TileAttnArgs {
     const float* qkv; float* dqkv; float* ctx; float* stat; const int2* tok; int L;
-    int on;                                    // bit 0: on; bit 1 (DR4SR_ATTN_TILE_ATOMICS): no plain stores for tile-private dK | dV rows
+    int on;                                    // bit 0: on; bit 1 (DR4SR_ATTN_TILE_ATOMICS): no plain stores for tile-private dK | dV rows; bit 2: near rows first (short-sequence plans)
 };
 struct PostArgs {
     // forward inputs / saved activations

@@ -492,14 +492,14 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         if (att_staged) keep = *att_staged;
         if (at_stage) {
             const int2 mq = tattn::own_word(A.at, t0, T);
-            att_st.issue(A.at, t0, T);
+            att_st.issue(A.at, t0, T, (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR);
             __builtin_amdgcn_sched_barrier(0);
             keep = tattn::own_keep(A, mq, t0, T);          // Philox calls while the window is in flight
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     STAMP(16);
-    auto att_commit = [&]() { if constexpr (AT) { if (at_stage) att_st.commit(tattn::Lds<D>(smem + att_lds_off(D, F))); } };
+    auto att_commit = [&]() { if constexpr (AT) { if (at_stage) att_st.commit(tattn::Lds<D>(smem + att_lds_off(D, F)), (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR); } };
 
     // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
     if (!FFN_ONLY && A.up_dqkv) {
@@ -599,6 +599,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         if (at_on) {
             STAMP(17);
             lds_barrier();
+            if (at_stage) tattn::far_rows_if_needed<D>(A.at, tattn::Lds<D>(smem + att_lds_off(D, F)), t0, T);
             STAMP(18);
             tattn::bwd<D>(A, t0, T, R0, LD, smem + att_lds_off(D, F), keep);
         }
@@ -1122,6 +1123,10 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     }
     A.stamps = DR4SR_ENV("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
     A.at.on = attn_in_tile(p, ws) ? 1 : 0;
+    // short-sequence plans at d = 128 stage the near half of the window first (attn_tile.h far_rows_if_needed): toys B = 256 0.2115 -> 0.2074 ms;
+    // at d = 64 the half window is not worth the second round trip of one tile in ten (0.1049 -> 0.1053).  DR4SR_ATTN_TILE_FULL / _NEAR force
+    const bool near_ok = p->expected_tokens > 0 && p->expected_tokens <= 16 * (int64_t)p->B;
+    if (A.at.on && !DR4SR_ENV("DR4SR_ATTN_TILE_FULL") && ((near_ok && p->D == 128) || DR4SR_ENV("DR4SR_ATTN_TILE_NEAR"))) A.at.on |= 4;
     if (A.at.on && DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;       // cross-check: every dK | dV row through atomics (no plain stores)
     A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L;
     A.nx_dqkv_zero = (A.at.on && A.nx_qkv) ? ws.layer[layer + 1].dqkv : nullptr;

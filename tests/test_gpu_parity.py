@@ -631,12 +631,15 @@ def test_every_accepted_encoder_shape_matches_oracle(D, H, F, NL, L):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,L,separate", [(64, 64, False), (64, 64, True), (128, 64, False), (64, 50, False)])
-def test_attention_in_tile_edge_cases(D, L, separate, monkeypatch):
+@pytest.mark.parametrize("D,L,separate,near", [(64, 64, False, False), (64, 64, True, False), (128, 64, False, False), (64, 50, False, False),
+                                               (64, 64, False, True), (128, 50, False, True)])
+def test_attention_in_tile_edge_cases(D, L, separate, near, monkeypatch):
     """csrc/attn_tile.h (the latency regime's attention, inside the 16-token tile kernels): sequences of the maximum length (the window's
     first row), lengths around the tile size (15 / 16 / 17 / 31 / 32 / 33: sequences that start or end on a tile boundary), single tokens,
     PAD ids INSIDE sequences (key_padding_mask, model/sasrec.py:48), and a batch whose token count is not a multiple of 16 — loss and every
-    gradient against the oracle; `separate` = the one-workgroup-per-sequence launches on the same batch (DR4SR_ATTN_SEPARATE)."""
+    gradient against the oracle; `separate` = the one-workgroup-per-sequence launches on the same batch (DR4SR_ATTN_SEPARATE); `near` = the
+    form short-sequence plans take at d = 128 (forced here: DR4SR_ATTN_TILE_NEAR): the tiles stage the near half of their window first and fetch the far
+    rows on demand — which these long sequences demand in most tiles."""
     import ctypes as C
     from dr4sr_amd import _lib
     from dr4sr_amd.engine import SasrecEngine
@@ -660,6 +663,8 @@ def test_attention_in_tile_edge_cases(D, L, separate, monkeypatch):
     eng.load_named(params)
     plan = eng.make_plan(batch["in_item_id"].cuda(), batch["item_id"].cuda(), batch["seqlen"].cuda(),
                          neg_item=batch["neg_item"].squeeze(-1).contiguous().cuda(), sample_neg=False)
+    if near:
+        monkeypatch.setenv("DR4SR_ATTN_TILE_NEAR", "1")
     assert bool(int(_lib.load().dr4sr_sasrec_at_scale(C.byref(plan))) & 4) == (not separate)
     for _ in range(2):                                       # twice: the second pass finds the first one's dK | dV in the workspace
         eng.fwd_bwd(plan)
