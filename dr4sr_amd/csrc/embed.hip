@@ -270,11 +270,15 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ X, con
 // pack (backward of unpack): dX[cu[b]+l,:] = d_out[b,l,:]  |  LAST: only row n_b-1 gets d_out[b,:]  |  MEAN: every row d_out[b,:]/n_b
 template <int D>
 __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ dout, const int* __restrict__ cu,
-                                              float* __restrict__ dX, int B, int L, int mode) {
+                                              float* __restrict__ dX, int B, int L, int mode, float* __restrict__ zkv = nullptr) {
     constexpr int LPT = D / 4, RPB = 256 / LPT;
     const int sub = threadIdx.x / LPT, c = (threadIdx.x % LPT) * 4;
     const int b = blockIdx.x;
     const int t0 = cu[b], n = cu[b + 1] - t0;
+    // zkv: the last layer's dqkv [T][3D] — its dK | dV rows are ACCUMULATED by the attention backward inside the tile kernels
+    // (attn_tile.h); the first launch of a backward pass zeroes them, so a second backward on one forward starts clean
+    if (zkv) for (int i = threadIdx.x; i < n * (2 * D / 4); i += 256)
+        st4(zkv + (size_t)(t0 + i / (2 * D / 4)) * 3 * D + D + (i % (2 * D / 4)) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     for (int l = sub; l < n; l += RPB) {
         float4 v;
         if (mode == 1) v = (l == n - 1) ? ld4(dout + (size_t)b * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -293,17 +297,20 @@ int launch_unpack_raw(const float* X, const int* cu, float* out, int B, int L, i
     else hipLaunchKernelGGL(k_unpack<128>, grid, blk, 0, s, X, cu, out, B, L, mode);
     return DR4SR_LAUNCH_CHECK();
 }
-int launch_pack_raw(const float* dout, const int* cu, float* dX, int B, int L, int D, int mode, hipStream_t s) {
+static int launch_pack_z(const float* dout, const int* cu, float* dX, int B, int L, int D, int mode, float* zkv, hipStream_t s) {
     dim3 grid(B), blk(256);
-    if (D == 64) hipLaunchKernelGGL(k_pack<64>, grid, blk, 0, s, dout, cu, dX, B, L, mode);
-    else hipLaunchKernelGGL(k_pack<128>, grid, blk, 0, s, dout, cu, dX, B, L, mode);
+    if (D == 64) hipLaunchKernelGGL(k_pack<64>, grid, blk, 0, s, dout, cu, dX, B, L, mode, zkv);
+    else hipLaunchKernelGGL(k_pack<128>, grid, blk, 0, s, dout, cu, dX, B, L, mode, zkv);
     return DR4SR_LAUNCH_CHECK();
+}
+int launch_pack_raw(const float* dout, const int* cu, float* dX, int B, int L, int D, int mode, hipStream_t s) {
+    return launch_pack_z(dout, cu, dX, B, L, D, mode, nullptr, s);
 }
 int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* X, float* out, int mode, hipStream_t s) {
     return launch_unpack_raw(X, ws.cu, out, p->B, p->L, p->D, mode, s);
 }
 int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int mode, hipStream_t s) {
-    return launch_pack_raw(dout, ws.cu, dX, p->B, p->L, p->D, mode, s);
+    return launch_pack_z(dout, ws.cu, dX, p->B, p->L, p->D, mode, attn_in_tile(p, ws) ? ws.layer[p->n_layer - 1].dqkv : nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------------

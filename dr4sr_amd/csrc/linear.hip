@@ -490,6 +490,9 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         at_on = A.at.on != 0;
         at_stage = at_on && !att_staged;
         if (att_staged) keep = *att_staged;
+        // the layer below accumulates its dK | dV in the NEXT launch: zeroed here too (the forward did it once; a second backward pass
+        // on the same forward — dr4sr_sasrec_encode_bwd twice, retain_graph — must not add onto the first)
+        if (at_on && A.dn_dqkv_zero) zero_kv_rows<BM, D>(A.dn_dqkv_zero, t0, T);
         if (at_stage) {
             const int2 mq = tattn::own_word(A.at, t0, T);
             att_st.issue(A.at, t0, T, (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR);
@@ -1130,6 +1133,7 @@ static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, 
     if (A.at.on && DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;       // cross-check: every dK | dV row through atomics (no plain stores)
     A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L;
     A.nx_dqkv_zero = (A.at.on && A.nx_qkv) ? ws.layer[layer + 1].dqkv : nullptr;
+    A.dn_dqkv_zero = (A.at.on && layer > 0) ? ws.layer[layer - 1].dqkv : nullptr;
     return A;
 }
 

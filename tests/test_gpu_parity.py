@@ -677,6 +677,32 @@ def test_attention_in_tile_edge_cases(D, L, separate, near, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_second_backward_on_one_forward_gives_the_same_gradients():
+    """dr4sr_sasrec_encode_bwd twice on one dr4sr_sasrec_encode (autograd's retain_graph case): with the attention inside the tile kernels
+    the dK | dV rows are accumulated with atomics, so every backward pass zeroes them in the launch in front of their accumulation
+    (k_pack for the last layer, k_post_bwd of the layer above for the others)"""
+    from dr4sr_amd import _lib
+    from dr4sr_amd.engine import SasrecEngine
+    rng = np.random.default_rng(5)
+    N, B, L, D = 120, 40, 50, 64
+    sl = rng.integers(1, L + 1, size=B)
+    inp = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        inp[b, :sl[b]] = rng.integers(1, N, size=sl[b])
+    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, 0.0, B, "cuda")
+    eng.load_named(_random_params(N, D, 128, 2, seed=11))
+    plan = eng.make_plan(torch.from_numpy(inp).cuda(), None, torch.from_numpy(sl.astype(np.int64)).cuda())
+    q = eng.encode(plan, True, _lib.POOL_MEAN)
+    g = torch.randn_like(q)
+    grads = []
+    for _ in range(2):
+        eng.grads.zero_()
+        eng.encode_bwd(plan, True, _lib.POOL_MEAN, g)
+        grads.append(eng.grads[:eng.n_params].cpu())
+    assert relerr(grads[1], grads[0]) < 1e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,H,F,NL,L", _SHAPES_REFUSED)
 def test_unsupported_encoder_shapes_are_refused_up_front(D, H, F, NL, L):
     """a shape without kernels is an error when the engine is built — not a failed launch, never a wrong number"""
