@@ -310,7 +310,7 @@ int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* 
     return launch_unpack_raw(X, ws.cu, out, p->B, p->L, p->D, mode, s);
 }
 int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int mode, hipStream_t s) {
-    return launch_pack_z(dout, ws.cu, dX, p->B, p->L, p->D, mode, attn_in_tile(p, ws) ? ws.layer[p->n_layer - 1].dqkv : nullptr, s);
+    return launch_pack_z(dout, ws.cu, dX, p->B, p->L, p->D, mode, (attn_in_tile(p, ws) || ws.attn_tile_sa) ? ws.layer[p->n_layer - 1].dqkv : nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,6 +34,7 @@ struct Workspace {
     int Tmax;
     int* cu;                                   // [B+1] packed row offset of each sequence slot
     bool scale, attn_split;                    // at-scale token-tile forms / length-class attention lists for this plan (see at_scale below)
+    bool attn_tile_sa;                         // ... and, for short-sequence plans at d = 64, the window attention of attn_tile.h as launches of its own INSTEAD of the lists (attn_tile_sa.hip)
     int* len_buf;                              // scratch of the two-phase prep (prep_body.h: 16 B per sequence + 16 B per optimizer workgroup)
     int* seq_class;                            // [4 + 7B] n_short, n_long, n_tiny, - | tiny_desc[B] int4 {t0, n, slot, row} | short_list[B] (9..16) | long_list[B] (> 16) | tiny_list[B] (1..8)  (k_prep)
     float* attn_rd;                            // [Tmax][H] <dctx, ctx> per (token, head): softmax-backward row term, from k_post_bwd
@@ -200,6 +201,11 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb = false,
                  bool meta = false, int l_lo = 0, int l_hi = -1);     // meta: the fused last-layer launch carried the MetaModel weighting (its tile size differs)
 bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws);    // latency regime: attention inside k_post_fwd / k_post_mid / k_post_bwd (attn_tile.h)
+// at scale, short sequences, d = 64 (Workspace::attn_tile_sa): one window-attention launch per layer and direction instead of the
+// two / three length-class list launches (attn_tile_sa.hip; the same tattn::fwd / tattn::bwd bodies as the in-tile form)
+PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training);
+int launch_attn_tile_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
+int launch_attn_tile_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);
 bool qeb_in_wgrad(const Workspace& ws);         // latency regime: k_qkv_embed_bwd's tiles run as the first plane of the k_wgrad launch
 
 int launch_attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);

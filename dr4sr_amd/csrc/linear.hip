@@ -203,7 +203,7 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.idx32 = de_owner_mode(ws) ? ws.idx32 : nullptr;
     const bool in_tile = attn_in_tile(p, ws);
-    A.tok = in_tile ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
+    A.tok = (in_tile || ws.attn_tile_sa) ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
     if (wave_tiles(p, ws)) return launch_wt_embqkv_fwd(A, ws.Tmax, s);
 #define EQ(B_) do { if (D == 64) hipLaunchKernelGGL((k_embqkv_fwd<B_, 64>), grid, blk, lds, s, A); \
                     else hipLaunchKernelGGL((k_embqkv_fwd<B_, 128>), grid, blk, lds, s, A); } while (0)
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     post_mid_body<32, D, F, false>(A, S);
 }
 
-static PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
+PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
     PostArgs A;
     const LayerWs& lw = ws.layer[layer];
     const float* P = p->params;

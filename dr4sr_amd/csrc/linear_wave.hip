@@ -777,6 +777,7 @@ __global__ __launch_bounds__(WT_WAVES * 64) void k_wt_embqkv_fwd(const EmbQkvArg
         const int64_t row = A.rows ? A.rows[b] : b;
         int64_t id = A.idx[row * A.L + pos];
         if (A.idx32 && ok && g == 0) A.idx32[t] = (id > 0 && id < A.n_items) ? (int)id : 0;      // as the backward's scatter tests it
+        if (A.tok && ok && g == 0) A.tok[t] = make_int2(t - pos, b | ((A.cu[b + 1] - A.cu[b]) << 20) | (id == 0 ? 1 << 30 : 0));     // attn_tile_sa.hip
         id = id < 0 ? 0 : (id >= A.n_items ? A.n_items - 1 : id);
         f32x4 x[DT], pe[DT];
         wt_row_load<D>(x, A.E + (size_t)id * D, g);

@@ -130,6 +130,12 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // tests (read per call): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
+        // round 4, opt-in (DR4SR_ATTN_WINDOW=1): where the lists would run on a short-sequence plan at d = 64, the window attention of
+        // attn_tile.h as ONE launch per layer and direction (attn_tile_sa.hip).  Measured slower than the lists (toys B = 8 192: forward
+        // 25 against 24 us per layer, backward 68 against 49; B = 32 768: 92 / 239 against 63 / 159): a 16 x 32 window computes ~9x the
+        // (query, key) pairs the sequences hold and the launch is bound by instruction issue, not by its latency chain — NOTEBOOK round 4
+        ws->attn_tile_sa = DR4SR_ENV("DR4SR_ATTN_WINDOW") && ws->attn_split && p->D == 64 && hint > 0 && hint <= 16 * (int64_t)p->B
+                           && attn_tile_capable(p) && !DR4SR_ENV("DR4SR_ATTN_NOSPLIT");
     }
     char* base = (char*)p->workspace;
     int64_t o = 0;
@@ -181,7 +187,8 @@ extern "C" int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan) {
     if (check_shape(&q)) return DR4SR_E_SHAPE;
     Workspace ws;
     carve_workspace(&q, &ws);
-    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0);     // bit 2: attention inside the tile kernels (attn_tile.h)
+    // bit 2: attention inside the tile kernels (attn_tile.h); bit 3: the same window attention as launches of its own instead of the lists
+    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0) | (ws.attn_tile_sa ? 8 : 0);
 }
 
 static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
@@ -379,9 +386,11 @@ static bool use_mfma_attn(const dr4sr_sasrec_plan* p) {
     return p->H == 2 && (!off || !valu_attn_fits(p));       // the cross-check switch applies where the VALU kernels can run
 }
 static int attn_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int training, hipStream_t s) {
+    if (ws.attn_tile_sa) return launch_attn_tile_fwd(p, ws, l, training, s);
     return use_mfma_attn(p) ? launch_attn2_fwd(p, ws, l, training, s) : launch_attn_fwd(p, ws, l, training, s);
 }
 static int attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int training, hipStream_t s) {
+    if (ws.attn_tile_sa) return launch_attn_tile_bwd(p, ws, l, training, s);
     return use_mfma_attn(p) ? launch_attn2_bwd(p, ws, l, training, s) : launch_attn_bwd(p, ws, l, training, s);
 }
 
