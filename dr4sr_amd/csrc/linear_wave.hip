@@ -753,9 +753,9 @@ __global__ __launch_bounds__(WT_WAVES * 64) void k_wt_post_mid(const PostArgs A,
 // ------------------------------------------------------------------------------------------------ layer-0 fusions, wave tiles
 // k_embqkv_fwd: x = drop(E[idx] + P[pos]) gathered straight into registers (a3: sasrec.py:42-48,:61-66), written once to X[0], and
 // multiplied by W_in in the same pass.  LDS: the in_proj image only (55 KB).
-template <int D, int WT_WAVES>
+template <int D, int WT_WAVES, bool EXACT = true>
 __global__ __launch_bounds__(WT_WAVES * 64) void k_wt_embqkv_fwd(const EmbQkvArgs A) {
-    typedef WtImg<true, 3 * D, D> In;
+    typedef WtImg<EXACT, 3 * D, D> In;
     constexpr int DT = D / 16, QT = 3 * D / 16;
     const int T = A.state[DR4SR_STATE_T];
     if ((int)blockIdx.x * 16 >= T) return;
@@ -876,6 +876,11 @@ int wt_post_mid_launch(const PostArgs& A, const ScoreTileArgs& S, int grid, hipS
 template <int W>
 int wt_embqkv_launch(const EmbQkvArgs& A, int grid, hipStream_t s) {
     const size_t lds = WtImg<true, 192, 64>::bytes + 4 * 192;
+    if (DR4SR_ENV("DR4SR_WT_EMB_BF16X3")) {                 // the in_proj GEMM as a bf16x3 split (same image bytes)
+        big_lds(k_wt_embqkv_fwd<64, W, false>, lds);
+        hipLaunchKernelGGL((k_wt_embqkv_fwd<64, W, false>), dim3(grid), dim3(W * 64), lds, s, A);
+        return DR4SR_LAUNCH_CHECK();
+    }
     big_lds(k_wt_embqkv_fwd<64, W>, lds);
     hipLaunchKernelGGL((k_wt_embqkv_fwd<64, W>), dim3(grid), dim3(W * 64), lds, s, A);
     return DR4SR_LAUNCH_CHECK();
