@@ -71,7 +71,27 @@ int latency_tmax();
 static inline bool at_scale(int Tmax) { return Tmax > latency_tmax(); }
 constexpr int DR4SR_SCALE_TOKENS = 7168, DR4SR_ATTN_SPLIT_TOKENS = 14336;      // at d = 64; scaled by 64 / d
 constexpr int DR4SR_SCALE_TOKENS_SHORT = 10240, DR4SR_SCALE_TOKENS_LONG = 6144;    // ... with the attention inside the tile kernels: expected mean length <= 16 / above
-bool attn_tile_capable(const dr4sr_sasrec_plan* p);        // shape and switches allow attn_tile.h (the launch forms decide the rest)
+bool attn_tile_capable(const dr4sr_sasrec_plan* p);
+// XCD-aware block -> tile order of the 256-thread token-tile kernels when the attention runs inside them (round 4).  A tile's window
+// holds the rows of the tiles in FRONT of it, written by the previous launch: with tile = blockIdx.x those ran on another XCD (block b
+// runs on XCD b % 8 — observed, MI355X_MICROARCH.md "Workgroup dispatch": for speed only, never for correctness) and the window comes
+// through the fabric; with XCD x owning the CONTIGUOUS tiles [x * per, (x + 1) * per) it is in this XCD's L2 except at the 7 seams.
+// Every tile kernel of a step uses the same order, so a tile's own rows stay on one XCD from launch to launch as before.
+bool tile_xcd_order(const dr4sr_sasrec_plan* p, const Workspace& ws);       // DR4SR_TILE_ORDER_PLAIN: tile = blockIdx.x
+// tiles of BM rows per XCD: ceil(tiles / 8), rounded up to whole 64-token tiles (the weight-gradient launch reads 64-token tiles and
+// follows the same order: a workgroup on XCD x sums the tiles XCD x produced — wgrad_body)
+__host__ __device__ inline int xcd_per(const int tiles, const int BM) {
+    const int q = BM < 64 ? 64 / BM : 1, per = (tiles + 7) >> 3;
+    return (per + q - 1) / q * q;
+}
+static inline int xcd_grid(int tiles, int BM) { return 8 * xcd_per(tiles, BM); }
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_tile(const int T, const int BM, const int on) {
+    if (!on) return (int)blockIdx.x;
+    const int nt = (T + BM - 1) / BM, per = xcd_per(nt, BM), x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    return (j < per && x * per + j < nt) ? x * per + j : nt;         // nt: no such tile (the caller's t0 >= T test exits)
+}
+#endif        // shape and switches allow attn_tile.h (the launch forms decide the rest)
 
 // argument blocks shared by the tile kernels of linear.hip (SASRec layer) and their FMLP re-use
 // attention inside the 16-token tile kernels of the latency regime (attn_tile.h): this layer's qkv / dqkv / ctx / statistics and the
@@ -98,6 +118,7 @@ struct PostArgs {
     const float* nx_in_w; const float* nx_in_b; float* nx_qkv;     // fwd: also emit qkv of layer+1 = z W_in^T + b
     const float* up_dqkv; const float* up_in_w; const float* up_du1;   // bwd: dz = up_dqkv W_in(layer+1) + up_du1 instead of reading A.dz
     TileAttnArgs at;                           // at.on: the attention of this layer runs inside the tile kernels (no attention launches)
+    int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
     float* nx_dqkv_zero;                       // ... and the launch that emits layer+1's qkv zeroes the K | V rows of its dqkv (atomics target)
     float* dn_dqkv_zero;                       // backward: the K | V rows of layer-1's dqkv, zeroed by the launch in front of their accumulation
 };
@@ -109,6 +130,7 @@ struct EmbQkvArgs {
     int B, L, n_items, training; uint64_t seed; float p;
     int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
     int2* tok; float* dqkv_zero;               // attention in the tile kernels (attn_tile.h): per-token words out, layer 0's dK | dV rows zeroed
+    int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
 };
 struct QkvEmbBwdArgs {
     const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
@@ -151,6 +173,7 @@ struct WgradArgs {
     int qeb_plane;                             // 1: grid plane z = 0 runs the embedding-stage backward tiles, layers are z - 1
     int layer0;                                // first layer of this launch (grid z counts from it)
     int bf16x3;                                // 1: weight-gradient GEMMs as a 3-term bf16 split (wgrad_body_bf)
+    int xcd;                                   // > 0: the token-tile kernels ran in the XCD-aware order with tiles of this many rows (xcd_tile): wgrad_body follows it
     const float* fc_dm; int64_t fc_o_cw; int fc_L;     // FMLP: filter-coefficient backward as part of the reduce blocks (fc_dm == NULL: none)
     // embedding scatter job (blockIdx.y == 7, large batches; sc_g == NULL: none)
     const float* sc_g; const int64_t* sc_idx; const int64_t* sc_rows; const int* sc_tile_seq; const int* cu;

@@ -138,6 +138,7 @@ bool attn_tile_capable(const dr4sr_sasrec_plan* p) {
 bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws) {
     return attn_tile_capable(p) && tile_rows(ws) == 16 && !ws.attn_split && !wave_tiles(p, ws);
 }
+bool tile_xcd_order(const dr4sr_sasrec_plan* p, const Workspace& ws) { return attn_in_tile(p, ws) && !DR4SR_ENV("DR4SR_TILE_ORDER_PLAIN"); }
 
 // Layer-0 fusion: the token tile is gathered straight from the item/position tables (a3: sasrec.py:42-48,:61-66 —
 // x = drop(E[idx] + P[pos]), 16 lanes per token, sequence slot by binary search in cu[]) into LDS, written once to X[0]
@@ -154,7 +155,7 @@ __device__ __forceinline__ void zero_kv_rows(float* dqkv, const int t0, const in
 template <int BM, int D>
 __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     constexpr int N = 3 * D, LDA = D + 4, LPT = D / 4, TPB = 256 / LPT;
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    const int T = A.state[DR4SR_STATE_T], t0 = xcd_tile(T, BM, A.xcd) * BM;
     if (t0 >= T) return;
     float* As = smem;
     const int c = (threadIdx.x % LPT) * 4;
@@ -204,6 +205,8 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.idx32 = de_owner_mode(ws) ? ws.idx32 : nullptr;
     const bool in_tile = attn_in_tile(p, ws);
     A.tok = (in_tile || ws.attn_tile_sa) ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
+    A.xcd = tile_xcd_order(p, ws) ? 1 : 0;
+    if (A.xcd) grid.x = xcd_grid((int)grid.x, bm);
     if (wave_tiles(p, ws)) return launch_wt_embqkv_fwd(A, ws.Tmax, s);
 #define EQ(B_) do { if (D == 64) hipLaunchKernelGGL((k_embqkv_fwd<B_, 64>), grid, blk, lds, s, A); \
                     else hipLaunchKernelGGL((k_embqkv_fwd<B_, 128>), grid, blk, lds, s, A); } while (0)
@@ -378,7 +381,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
 
 template <int BM, int D, int F, bool FFN_ONLY>
 __global__ __launch_bounds__(256) void k_post_fwd(const PostArgs A) {
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    const int T = A.state[DR4SR_STATE_T], t0 = xcd_tile(T, BM, A.xcd) * BM;
     if (t0 >= T) return;
     post_fwd_body<BM, D, F, FFN_ONLY>(A, t0, T);
 }
@@ -612,9 +615,9 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
 
 template <int BM, int D, int F, bool FFN_ONLY>
 __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    const int T = A.state[DR4SR_STATE_T], bx = xcd_tile(T, BM, A.xcd), t0 = bx * BM;
     if (t0 >= T) return;
-    post_bwd_body<BM, D, F, FFN_ONLY>(A, t0, T, blockIdx.x);
+    post_bwd_body<BM, D, F, FFN_ONLY>(A, t0, T, bx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1062,7 +1065,7 @@ __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTi
 
 template <int BM, int D, int F, bool META>
 __device__ __forceinline__ void post_mid_body(const PostArgs& A, const ScoreTileArgs& S) {
-    const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
+    const int T = A.state[DR4SR_STATE_T], bx = xcd_tile(T, BM, A.xcd), t0 = bx * BM;
     if (t0 >= T) return;
     if constexpr (BM != 16) { if (S.ent) tile_sort_init<BM>(S, smem + post_lds_floats(D, F, BM) + 8); }
     if constexpr (D == 64) {
@@ -1075,17 +1078,17 @@ __device__ __forceinline__ void post_mid_body(const PostArgs& A, const ScoreTile
         post_fwd_body<BM, D, F, false, true>(Af, t0, T, zreg, &keep);
         if constexpr (BM != 16) score_prefetch<BM>(A, S, t0, T, P);             // occupancy regime: its registers would cost a workgroup per CU
         if constexpr (META) lds_barrier();                   // every wave is past the forward half's last LDS reads: the tiles are free
-        score_tile_regs<BM, META>(A, S, t0, T, blockIdx.x, P, zreg, dzreg, smem + post_lds_floats(D, F, BM), smem);
-        if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, blockIdx.x, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
-        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, dzreg, &keep);
+        score_tile_regs<BM, META>(A, S, t0, T, bx, P, zreg, dzreg, smem + post_lds_floats(D, F, BM), smem);
+        if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, bx, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
+        post_bwd_body<BM, D, F, false>(A, t0, T, bx, dzreg, &keep);
     } else {
         tattn::Keep keep{0xffffffffu, 0xffffffffu};
         post_fwd_body<BM, D, F, false, true>(A, t0, T, nullptr, &keep);
         __syncthreads();                               // z rows of this tile are visible to the whole workgroup
-        score_tile<BM, D, META>(A, S, t0, T, blockIdx.x, smem + post_lds_floats(D, F, BM) + 8);
-        if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, blockIdx.x, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
+        score_tile<BM, D, META>(A, S, t0, T, bx, smem + post_lds_floats(D, F, BM) + 8);
+        if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, bx, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
         __syncthreads();                               // dz rows written, LDS scratch free again
-        post_bwd_body<BM, D, F, false>(A, t0, T, blockIdx.x, nullptr, &keep);
+        post_bwd_body<BM, D, F, false>(A, t0, T, bx, nullptr, &keep);
     }
 }
 template <int BM, int D, int F, bool META>
@@ -1126,6 +1129,7 @@ PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int lay
     }
     A.stamps = DR4SR_ENV("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
     A.at.on = attn_in_tile(p, ws) ? 1 : 0;
+    A.xcd = tile_xcd_order(p, ws) ? 1 : 0;
     // short-sequence plans at d = 128 stage the near half of the window first (attn_tile.h far_rows_if_needed): toys B = 256 0.2115 -> 0.2074 ms;
     // at d = 64 the half window is not worth the second round trip of one tile in ten (0.1049 -> 0.1053).  DR4SR_ATTN_TILE_FULL / _NEAR force
     const bool near_ok = p->expected_tokens > 0 && p->expected_tokens <= 16 * (int64_t)p->B;
@@ -1142,6 +1146,7 @@ static size_t post_lds(int D, int F, int bm = 64) { return sizeof(float) * post_
 template <int BM>
 static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, bool bwd, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
+    if (A.xcd) grid.x = xcd_grid((int)grid.x, BM);
     const size_t lds = (BM == 16 && A.at.on) ? sizeof(float) * att_lds_off(p->D, p->F) + att_lds_bytes(p->D) : post_lds(p->D, p->F, BM);
 #define PL(D_, F_) do { if (bwd) { big_lds(k_post_bwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_bwd<BM, D_, F_, false>), grid, blk, lds, s, A); } \
                         else { big_lds(k_post_fwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_fwd<BM, D_, F_, false>), grid, blk, lds, s, A); } } while (0)
@@ -1155,6 +1160,7 @@ static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const
 template <int BM>
 static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const PostArgs& A, const ScoreTileArgs& S, hipStream_t s) {
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
+    if (A.xcd) grid.x = xcd_grid((int)grid.x, BM);
     const size_t lds = (BM == 16 && A.at.on) ? sizeof(float) * att_lds_off(p->D, p->F) + att_lds_bytes(p->D)
                        : post_lds(p->D, p->F, BM) + 8 * sizeof(float) + (S.ent ? tile_sort_lds_bytes(BM, 1 << S.logG) : 0);   // + the scorer's (count, loss) reduction scratch + tile_sort's records
 #define PM(D_, F_) do { if constexpr (BM == 32 && D_ == 64) { big_lds(k_post_mid32<D_, F_>, lds); hipLaunchKernelGGL((k_post_mid32<D_, F_>), grid, blk, lds, s, A, S); } \
@@ -1442,14 +1448,21 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
             st4(Xs + row * KX + c, t0 + row < T ? xq[u] : z4);
         }
     };
-    int tt = blockIdx.x;
+    // token tiles of this workgroup: blockIdx.x, + gridDim.x, ... — or, behind token-tile kernels that ran in the XCD-aware order (A.xcd =
+    // their tile rows, kernels.h xcd_tile), the 64-token tiles XCD (blockIdx.x & 7) produced: the operands are in this XCD's L2
+    const bool xo = A.xcd > 0 && (gridDim.x & 7) == 0;
+    const int p64 = xo ? xcd_per((T + A.xcd - 1) / A.xcd, A.xcd) * A.xcd / 64 : 0, xbase = ((int)blockIdx.x & 7) * p64;
+    const int kstep = xo ? (int)gridDim.x >> 3 : (int)gridDim.x;
+    auto tile_of = [&](int k) { return !xo ? k : (k < p64 ? xbase + k : ntiles); };
+    int k = xo ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
+    int tt = tile_of(k);
     if (tt >= ntiles) return;                            // the grid covers the worst case B*L tokens: no tile, nothing to add
     issue(tt);
-    for (; tt < ntiles; tt += gridDim.x) {
+    for (; tt < ntiles; k += kstep, tt = tile_of(k)) {
         lds_barrier();                                   // previous MFMA phase has finished reading LDS
         commit(tt);
         lds_barrier();
-        if (tt + (int)gridDim.x < ntiles) issue(tt + gridDim.x);
+        { const int tn = tile_of(k + kstep); if (tn < ntiles) issue(tn); }
 #pragma unroll 4
         for (int s = 0; s < 32; ++s) {
             const int t = 2 * s + g;
@@ -1904,6 +1917,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     float* G = p->grads;
     const bool wg_f32 = DR4SR_ENV("DR4SR_WGRAD_F32") != nullptr;
     A.bf16x3 = (ws.scale && !wg_f32) ? 1 : 0;              // at scale: weight gradients on the bf16 matrix cores (3-term split)
+    A.xcd = (tile_xcd_order(p, ws) && !DR4SR_ENV("DR4SR_WGRAD_ORDER_PLAIN")) ? tile_rows(ws) : 0;       // follow the token-tile kernels' XCD-aware order
     // at scale with d = 64: 64 x 64 blocks (k_wgrad_bf64, see wgrad_kernel_body); DR4SR_WGRAD_WIDE: the six whole jobs (cross-check)
     const bool sub64 = A.bf16x3 && wgrad_sub64(p);
     const int NJ = sub64 ? 4 + 2 * (F / 64) : 6;

@@ -326,6 +326,11 @@ _SWITCH_CASES = [
     ({"DR4SR_ATTN_TILE_ATOMICS": "1"}, "full_size dropout"),
     # round 4: the six whole fp32 weight-gradient jobs per layer instead of their 64 x 64 blocks (k_wgrad instead of k_wgrad_blk)
     ({"DR4SR_WGRAD_BLK": "0"}, "full_size fuzz trajectory"),
+    # round 4: the layer-0 in_proj of the wave-tile embedding stage as a bf16x3 split (measured +0.6 %, opt-in)
+    ({"DR4SR_FORCE_SCALE": "1", "DR4SR_WT_EMB_BF16X3": "1"}, "full_size dropout"),
+    # round 4: tile = blockIdx.x instead of the XCD-aware order in the latency regime's tile kernels / in the weight-gradient launch
+    ({"DR4SR_TILE_ORDER_PLAIN": "1"}, "full_size dropout trajectory"),
+    ({"DR4SR_WGRAD_ORDER_PLAIN": "1"}, "full_size fuzz"),
     # the 4-wave per-sequence attention backward (head_dim 64 ran on it until round 3)
     ({"DR4SR_ATTN_BWD_4WAVE": "1", "DR4SR_ATTN_SEPARATE": "1"}, "full_size dropout"),
 ]
