@@ -202,31 +202,53 @@ __device__ __forceinline__ Keep own_keep(const PostArgs& P, const int2 mq, const
 // Wave w: head h = w & 1 (scores and softmax of the 16 query rows, computed by both waves of a head), output columns block(s) w >> 1.
 // Leaves the ctx tile in R0 [16][ldr] (rows >= T zero) and in A.ctx; a workgroup barrier must follow before R0 is read.
 // KEEP_QS: k_post_mid runs the backward of the same tile later in the launch — the Q rows and the statistics stay in LDS for it.
+// The forward in three pieces, so that the caller can put its own long-latency loads BETWEEN them: fwd_issue() requests the window, the
+// tokens' words and the Q rows; fwd_stage() computes the keep decisions while they are in flight and commits the window; fwd_compute().  Loads return in issue
+// order: k_post_fwd / k_post_mid prefetch 128 KB (d = 64) / 200 KB (d = 128) of weight fragments per workgroup for their four GEMMs.  At
+// d = 128 the window goes first (linear.hip post_fwd_body: no register spill that way, step -4.5 %); at d = 64 the order made no difference
+// (measured: NOTEBOOK round 4).
 template <int D, bool KEEP_QS>
-__device__ __forceinline__ Keep fwd(const PostArgs& P, const int t0, const int T, float* R0, const int ldr, float* base) {
-    constexpr int DH = D / 2, LD = D + 4, H = 2;
+struct FwdPre { Stage<D, KEEP_QS, false> st; int2 mq_g; float qf[D / 8]; uint32_t klo, khi; };
+template <int D, bool KEEP_QS>
+__device__ __forceinline__ void fwd_issue(const PostArgs& P, const int t0, const int T, FwdPre<D, KEEP_QS>& F) {
+    constexpr int DH = D / 2;
+    const TileAttnArgs& A = P.at;
+    const int h = (threadIdx.x >> 6) & 1;
+    F.mq_g = own_word(A, t0, T);
+    if constexpr (!KEEP_QS) frag_g<DH>(F.qf, A.qkv + h * DH, 3 * D, t0, T);       // used once: straight from global
+    F.st.issue(A, t0, T, (A.on & 4) ? NEAR0 : 0, WR);
+}
+// ... fwd_stage(): keep decisions (Philox, while the window is in flight), window -> LDS, workgroup barrier, far rows on demand
+template <int D, bool KEEP_QS>
+__device__ __forceinline__ void fwd_stage(const PostArgs& P, const int t0, const int T, float* base, FwdPre<D, KEEP_QS>& F) {
     const TileAttnArgs& A = P.at;
     const Lds<D> S(base);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1, i16 = lane & 15, g = lane >> 4;
-    uint32_t klo_, khi_;
-    float qf[DH / 4];
-    const int2 mq_g = own_word(A, t0, T);
-    if constexpr (!KEEP_QS) frag_g<DH>(qf, A.qkv + h * DH, 3 * D, t0, T);       // used once: straight from global
-    {
-        Stage<D, KEEP_QS, false> st;
-        const int r_lo = (A.on & 4) ? NEAR0 : 0;
-        st.issue(A, t0, T, r_lo, WR);
-        // (the Philox calls run while the window is in flight)
-        __builtin_amdgcn_sched_barrier(0);
-        const Keep k0 = own_keep(P, mq_g, t0, T);
-        klo_ = k0.lo; khi_ = k0.hi;
-        __builtin_amdgcn_sched_barrier(0);
-        st.commit(S, r_lo, WR);
-    }
+    const int r_lo = (A.on & 4) ? NEAR0 : 0;
+    TSTAMP(27, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const Keep k0 = own_keep(P, F.mq_g, t0, T);
+    F.klo = k0.lo; F.khi = k0.hi;
+    __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(28, 0);
+    F.st.commit(S, r_lo, WR);
     TSTAMP(8, 0);
     lds_barrier();
     far_rows_if_needed<D>(A, S, t0, T);
     TSTAMP(9, 0);
+}
+// ... fwd_compute(): scores, softmax, P~ V
+template <int D, bool KEEP_QS>
+__device__ __forceinline__ Keep fwd_compute(const PostArgs& P, const int t0, const int T, float* R0, const int ldr, float* base, FwdPre<D, KEEP_QS>& F) {
+    constexpr int DH = D / 2, LD = D + 4, H = 2;
+    const TileAttnArgs& A = P.at;
+    const Lds<D> S(base);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, half = w >> 1, i16 = lane & 15, g = lane >> 4;
+    const uint32_t klo_ = F.klo, khi_ = F.khi;
+    float qf[DH / 4];
+    if constexpr (!KEEP_QS) {
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) qf[c] = F.qf[c];
+    }
     if constexpr (KEEP_QS) frag<DH>(qf, S.Qs, LD, 0, h * DH);
     const int tq = t0 + i16, wb = t0 - QR0;
     const int2 mq = S.tok[QR0 + i16];
@@ -298,6 +320,13 @@ __device__ __forceinline__ Keep fwd(const PostArgs& P, const int t0, const int T
     }
     TSTAMP(12, 0);
     return Keep{klo, khi};
+}
+template <int D, bool KEEP_QS>
+__device__ __forceinline__ Keep fwd(const PostArgs& P, const int t0, const int T, float* R0, const int ldr, float* base) {
+    FwdPre<D, KEEP_QS> F;
+    fwd_issue<D, KEEP_QS>(P, t0, T, F);
+    fwd_stage<D, KEEP_QS>(P, t0, T, base, F);
+    return fwd_compute<D, KEEP_QS>(P, t0, T, R0, ldr, base, F);
 }
 
 // ------------------------------------------------------------------------------------------------ backward

@@ -299,16 +299,52 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         bool at_on = false;
         if constexpr (AT) at_on = A.at.on != 0;
         if (!at_on) load_tile_bm<BM, D>(R0, LD, A.ctx, D, t0, T);
-        if constexpr (PF) {
-            wfrag_load(f_out, A.out_w, D);
-            wfrag_load(f_w1, A.w1, D);
-            wfrag_load(f_w2, A.w2, F);
-            if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
-        }
-        if constexpr (AT) {
+        // Loads return in issue order and a wave stalls ISSUING when the CU's memory queue is full: the 128 KB (d = 64) / 200 KB (d = 128) of
+        // weight fragments per workgroup took 3.9 us to request in front of the attention (stamps, round 4).  So: the window first, then
+        // out_proj's fragments only; the rest is requested where the attention's arithmetic hides it (DR4SR_WFRAG_UPFRONT: all up front).
+        tattn::FwdPre<AT ? D : 64, KEEPQ> att_pre;
+#ifdef DR4SR_WFRAG_UPFRONT
+        constexpr bool SPREAD = false;
+#else
+        constexpr bool SPREAD = AT && PF;
+#endif
+        if constexpr (SPREAD) {
             if (at_on) {
-                const tattn::Keep k = tattn::fwd<D, KEEPQ>(A, t0, T, R0, LD, smem + att_lds_off(D, F));
+                tattn::fwd_issue<D, KEEPQ>(A, t0, T, att_pre);
+                __builtin_amdgcn_sched_barrier(0);
+                wfrag_load(f_out, A.out_w, D);
+                __builtin_amdgcn_sched_barrier(0);
+                tattn::fwd_stage<D, KEEPQ>(A, t0, T, smem + att_lds_off(D, F), att_pre);
+                __builtin_amdgcn_sched_barrier(0);
+                wfrag_load(f_w1, A.w1, D);
+                wfrag_load(f_w2, A.w2, F);
+                __builtin_amdgcn_sched_barrier(0);
+                const tattn::Keep k = tattn::fwd_compute<D, KEEPQ>(A, t0, T, R0, LD, smem + att_lds_off(D, F), att_pre);
                 if (keep_out) *keep_out = k;
+                __builtin_amdgcn_sched_barrier(0);
+                if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+            } else {
+                wfrag_load(f_out, A.out_w, D);
+                wfrag_load(f_w1, A.w1, D);
+                wfrag_load(f_w2, A.w2, F);
+                if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+            }
+        } else {
+            constexpr bool EARLY = D == 128;               // (window before the fragments: no register spill at d = 128)
+            if constexpr (AT && EARLY) { if (at_on) { tattn::fwd_issue<D, KEEPQ>(A, t0, T, att_pre); __builtin_amdgcn_sched_barrier(0); } }
+            if constexpr (PF) {
+                wfrag_load(f_out, A.out_w, D);
+                wfrag_load(f_w1, A.w1, D);
+                wfrag_load(f_w2, A.w2, F);
+                if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+            }
+            if constexpr (AT) {
+                if (at_on) {
+                    if constexpr (!EARLY) tattn::fwd_issue<D, KEEPQ>(A, t0, T, att_pre);
+                    tattn::fwd_stage<D, KEEPQ>(A, t0, T, smem + att_lds_off(D, F), att_pre);
+                    const tattn::Keep k = tattn::fwd_compute<D, KEEPQ>(A, t0, T, R0, LD, smem + att_lds_off(D, F), att_pre);
+                    if (keep_out) *keep_out = k;
+                }
             }
         }
         lds_barrier(); STAMP(1);
@@ -505,6 +541,18 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         }
     }
     STAMP(16);
+    // latency regime, d = 64 (k_post_bwd: 90 VGPRs without them): the data-gradient GEMMs' weight fragments are requested one phase AHEAD of
+    // the GEMM that consumes them — the L2 round trip of each of the four phases overlaps the phase in front of it (as the forward's do)
+#ifdef DR4SR_BWD_NO_PREFETCH
+    constexpr bool PFB = false;
+#else
+    constexpr bool PFB = BM == 16 && !FFN_ONLY && D == 64;
+#endif
+    WFragC<PFB ? 3 * D : 16, 64> fr_up;
+    WFragC<PFB ? D : 16, PFB ? F : 64> fr_w2;
+    WFragC<PFB ? F : 16, 64> fr_w1;
+    WFragC<PFB ? D : 16, 64> fr_out;
+    if constexpr (PFB) { if (A.up_dqkv) wfrag_load(fr_up, A.up_in_w, D); else wfrag_load(fr_w2, A.w2, F); }
     auto att_commit = [&]() { if constexpr (AT) { if (at_stage) att_st.commit(tattn::Lds<D>(smem + att_lds_off(D, F)), (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR); } };
 
     // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
@@ -517,7 +565,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         lds_barrier();
         TileAcc<BM, D> acc;
         tile_zero(acc);
-        tile_mma_xw<BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, acc);
+        if constexpr (PFB) { wfrag_load(fr_w2, A.w2, F); tile_mma_frag<BM, 3 * D, D>(Aq, LQ, fr_up, acc); }
+        else tile_mma_xw<BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, acc);
         tile_to_lds<BM, D>(acc, R1, LD, nullptr);
         lds_barrier();
         ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
@@ -533,7 +582,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     {
         TileAcc<BM, F> acc;
         tile_zero(acc);
-        tile_mma_xw<BM, D, F>(R0, LD, A.w2, F, acc);
+        if constexpr (PFB) { wfrag_load(fr_w1, A.w1, D); tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); }
+        else tile_mma_xw<BM, D, F>(R0, LD, A.w2, F, acc);
         tile_to_lds<BM, F>(acc, R2, LF, nullptr);
     }
     lds_barrier();
@@ -560,7 +610,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     {
         TileAcc<BM, D> acc;
         tile_zero(acc);
-        tile_mma_xw<BM, F, D>(R2, LF, A.w1, D, acc);
+        if constexpr (PFB) { wfrag_load(fr_out, A.out_w, D); tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); }
+        else tile_mma_xw<BM, F, D>(R2, LF, A.w1, D, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
@@ -581,7 +632,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     {
         TileAcc<BM, D> acc;
         tile_zero(acc);
-        tile_mma_xw<BM, D, D>(R1, LD, A.out_w, D, acc);
+        if constexpr (PFB) tile_mma_frag<BM, D, D>(R1, LD, fr_out, acc);
+        else tile_mma_xw<BM, D, D>(R1, LD, A.out_w, D, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();

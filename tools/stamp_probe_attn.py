@@ -34,7 +34,7 @@ for kind, layer in (("post_fwd", 0), ("post_bwd", 0)):
     b.record(); b.synchronize()
     st = eng.workspace[off:off + 32 * 8].view(torch.int64).cpu().numpy()
     if kind == "post_fwd":
-        idx = [0, 8, 9, 10, 11, 12, 1, 2, 3, 4, 5, 6, 15]
+        idx = [0, 27, 28, 8, 9, 10, 11, 12, 1, 2, 3, 4, 5, 6, 15]
     else:
         idx = [16, 17, 18, 20, 21, 22, 23]
     print(kind, layer, "us/launch %.2f" % (a.elapsed_time(b) * 1e3 / 20), "stamps", idx, "ticks since first", [int(st[i] - st[idx[0]]) for i in idx],
