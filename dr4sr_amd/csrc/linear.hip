@@ -161,6 +161,10 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     const int c = (threadIdx.x % LPT) * 4;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    // latency regime: the in_proj fragments are requested in front of the gather's dependent chain (cu -> idx -> table row)
+    constexpr bool PFE = BM == 16 && D == 64;
+    WFragT<PFE ? D : 16, PFE ? N : 64> f_in;
+    if constexpr (PFE) wfrag_load(f_in, A.W, D);
     const int bh = A.tile_seq[t0 >> 4];
 #pragma unroll
     for (int r0 = 0; r0 < BM; r0 += TPB) {
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     lds_barrier();
     TileAcc<BM, N> acc;
     tile_zero(acc);
-    tile_mma_xwT<BM, D, N>(As, LDA, A.W, D, acc);
+    if constexpr (PFE) tile_mma_frag<BM, D, N>(As, LDA, f_in, acc);
+    else tile_mma_xwT<BM, D, N>(As, LDA, A.W, D, acc);
     tile_to_global<BM, N>(acc, A.QKV, N, A.bias, t0, T);
     if (A.dqkv_zero) zero_kv_rows<BM, D>(A.dqkv_zero, t0, T);
 }
