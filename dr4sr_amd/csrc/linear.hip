@@ -526,26 +526,6 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     float4 dgam[NV], dbet[NV];
     // attention backward of the tile's rows at the end of this launch (attn_tile.h): its operands are requested first
     // (att_staged: k_post_mid — the forward half of the launch left window, Q rows, statistics and keep decisions behind)
-    constexpr bool AT = BM == 16 && !FFN_ONLY && (D == 64 || D == 128);
-    bool at_on = false, at_stage = false;
-    tattn::Keep keep{0xffffffffu, 0xffffffffu};
-    tattn::Stage<AT ? D : 64, true, true> att_st;
-    if constexpr (AT) {
-        at_on = A.at.on != 0;
-        at_stage = at_on && !att_staged;
-        if (att_staged) keep = *att_staged;
-        // the layer below accumulates its dK | dV in the NEXT launch: zeroed here too (the forward did it once; a second backward pass
-        // on the same forward — dr4sr_sasrec_encode_bwd twice, retain_graph — must not add onto the first)
-        if (at_on && A.dn_dqkv_zero) zero_kv_rows<BM, D>(A.dn_dqkv_zero, t0, T);
-        if (at_stage) {
-            const int2 mq = tattn::own_word(A.at, t0, T);
-            att_st.issue(A.at, t0, T, (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR);
-            __builtin_amdgcn_sched_barrier(0);
-            keep = tattn::own_keep(A, mq, t0, T);          // Philox calls while the window is in flight
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    STAMP(16);
     // latency regime, d = 64 (k_post_bwd: 90 VGPRs without them): the data-gradient GEMMs' weight fragments are requested one phase AHEAD of
     // the GEMM that consumes them — the L2 round trip of each of the four phases overlaps the phase in front of it (as the forward's do)
 #ifdef DR4SR_BWD_NO_PREFETCH
@@ -557,7 +537,43 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     WFragC<PFB ? D : 16, PFB ? F : 64> fr_w2;
     WFragC<PFB ? F : 16, 64> fr_w1;
     WFragC<PFB ? D : 16, 64> fr_out;
-    if constexpr (PFB) { if (A.up_dqkv) wfrag_load(fr_up, A.up_in_w, D); else wfrag_load(fr_w2, A.w2, F); }
+    constexpr bool AT = BM == 16 && !FFN_ONLY && (D == 64 || D == 128);
+    bool at_on = false, at_stage = false;
+    tattn::Keep keep{0xffffffffu, 0xffffffffu};
+    tattn::Stage<AT ? D : 64, true, true> att_st;
+    constexpr int UPQ = AT ? (16 * 3 * D / 4) / 256 : 1;
+    float4 updq[UPQ];
+    bool up_pre = false;
+    if constexpr (AT) {
+        at_on = A.at.on != 0;
+        at_stage = at_on && !att_staged;
+        if (att_staged) keep = *att_staged;
+        // the layer below accumulates its dK | dV in the NEXT launch: zeroed here too (the forward did it once; a second backward pass
+        // on the same forward — dr4sr_sasrec_encode_bwd twice, retain_graph — must not add onto the first)
+        if (at_on && A.dn_dqkv_zero) zero_kv_rows<BM, D>(A.dn_dqkv_zero, t0, T);
+        if (at_stage && A.up_dqkv) {
+            // loads return in issue order and the Philox calls below are ~1 us of VALU: the FIRST phase's own tile (layer + 1's dqkv rows)
+            // is requested in front of the attention's window, which is consumed last
+            up_pre = true;
+#pragma unroll
+            for (int q = 0; q < UPQ; ++q) {
+                const int i = threadIdx.x + 256 * q, row = i / (3 * D / 4), c = (i % (3 * D / 4)) * 4;
+                updq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t0 + row < T) updq[q] = ld4(A.up_dqkv + (size_t)(t0 + row) * 3 * D + c);
+            }
+            if constexpr (PFB) wfrag_load(fr_up, A.up_in_w, D);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (at_stage) {
+            const int2 mq = tattn::own_word(A.at, t0, T);
+            att_st.issue(A.at, t0, T, (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR);
+            __builtin_amdgcn_sched_barrier(0);
+            keep = tattn::own_keep(A, mq, t0, T);          // Philox calls while the window is in flight
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    STAMP(16);
+    if constexpr (PFB) { if (!A.up_dqkv) wfrag_load(fr_w2, A.w2, F); else if (!up_pre) wfrag_load(fr_up, A.up_in_w, D); }
     auto att_commit = [&]() { if constexpr (AT) { if (at_stage) att_st.commit(tattn::Lds<D>(smem + att_lds_off(D, F)), (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR); } };
 
     // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
@@ -565,7 +581,13 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         // layer-boundary fusion: dz = dqkv(layer+1) W_in(layer+1) + du1(layer+1), computed here instead of a separate launch
         constexpr int LQ = 3 * D + 4;
         float* Aq = R0;                            // [64][LQ] spans R0 + R2 (see post_lds)
-        load_tile_bm<BM, 3 * D>(Aq, LQ, A.up_dqkv, 3 * D, t0, T);
+        if (AT && up_pre) {
+#pragma unroll
+            for (int q = 0; q < UPQ; ++q) {
+                const int i = threadIdx.x + 256 * q, row = i / (3 * D / 4), c = (i % (3 * D / 4)) * 4;
+                st4(Aq + row * LQ + c, updq[q]);
+            }
+        } else load_tile_bm<BM, 3 * D>(Aq, LQ, A.up_dqkv, 3 * D, t0, T);
         att_commit();                              // behind this phase's own loads: one round trip for both
         lds_barrier();
         TileAcc<BM, D> acc;
