@@ -531,12 +531,15 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
 #ifdef DR4SR_BWD_NO_PREFETCH
     constexpr bool PFB = false;
 #else
-    constexpr bool PFB = BM == 16 && !FFN_ONLY && D == 64;
+    constexpr bool PFB = BM == 16 && !FFN_ONLY && (D == 64 || D == 128);
 #endif
-    WFragC<PFB ? 3 * D : 16, 64> fr_up;
+    // d = 64: requested BEFORE the GEMM in front (two sets in flight); d = 128 (64 VGPRs per set, none to spare): right BEHIND it, one set
+    // in flight while the row pass between two GEMMs runs — and the [3D x D] set of the first phase stays inside its k loop
+    constexpr bool PF64 = PFB && D == 64, PF128 = PFB && D == 128;
+    WFragC<PF64 ? 3 * D : 16, PF64 ? D : 64> fr_up;
     WFragC<PFB ? D : 16, PFB ? F : 64> fr_w2;
-    WFragC<PFB ? F : 16, 64> fr_w1;
-    WFragC<PFB ? D : 16, 64> fr_out;
+    WFragC<PFB ? F : 16, PFB ? D : 64> fr_w1;
+    WFragC<PFB ? D : 16, PFB ? D : 64> fr_out;
     constexpr bool AT = BM == 16 && !FFN_ONLY && (D == 64 || D == 128);
     bool at_on = false, at_stage = false;
     tattn::Keep keep{0xffffffffu, 0xffffffffu};
@@ -561,7 +564,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
                 updq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (t0 + row < T) updq[q] = ld4(A.up_dqkv + (size_t)(t0 + row) * 3 * D + c);
             }
-            if constexpr (PFB) wfrag_load(fr_up, A.up_in_w, D);
+            if constexpr (PF64) wfrag_load(fr_up, A.up_in_w, D);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (at_stage) {
@@ -573,7 +576,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         }
     }
     STAMP(16);
-    if constexpr (PFB) { if (!A.up_dqkv) wfrag_load(fr_w2, A.w2, F); else if (!up_pre) wfrag_load(fr_up, A.up_in_w, D); }
+    if constexpr (PFB) { if (!A.up_dqkv) wfrag_load(fr_w2, A.w2, F); else if (PF64 && !up_pre) wfrag_load(fr_up, A.up_in_w, D); }
     auto att_commit = [&]() { if constexpr (AT) { if (at_stage) att_st.commit(tattn::Lds<D>(smem + att_lds_off(D, F)), (A.at.on & 4) ? tattn::NEAR0 : 0, tattn::WR); } };
 
     // ---- LayerNorm2 backward: du2 -> R1 (residual branch); df = du2*mask -> global + R0
@@ -592,8 +595,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         lds_barrier();
         TileAcc<BM, D> acc;
         tile_zero(acc);
-        if constexpr (PFB) { wfrag_load(fr_w2, A.w2, F); tile_mma_frag<BM, 3 * D, D>(Aq, LQ, fr_up, acc); }
-        else tile_mma_xw<BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, acc);
+        if constexpr (PF64) { wfrag_load(fr_w2, A.w2, F); tile_mma_frag<BM, 3 * D, D>(Aq, LQ, fr_up, acc); }
+        else { tile_mma_xw<BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, acc); if constexpr (PF128) wfrag_load(fr_w2, A.w2, F); }
         tile_to_lds<BM, D>(acc, R1, LD, nullptr);
         lds_barrier();
         ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
@@ -609,7 +612,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     {
         TileAcc<BM, F> acc;
         tile_zero(acc);
-        if constexpr (PFB) { wfrag_load(fr_w1, A.w1, D); tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); }
+        if constexpr (PF64) { wfrag_load(fr_w1, A.w1, D); tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); }
+        else if constexpr (PF128) { tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); wfrag_load(fr_w1, A.w1, D); }
         else tile_mma_xw<BM, D, F>(R0, LD, A.w2, F, acc);
         tile_to_lds<BM, F>(acc, R2, LF, nullptr);
     }
@@ -637,7 +641,8 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
     {
         TileAcc<BM, D> acc;
         tile_zero(acc);
-        if constexpr (PFB) { wfrag_load(fr_out, A.out_w, D); tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); }
+        if constexpr (PF64) { wfrag_load(fr_out, A.out_w, D); tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); }
+        else if constexpr (PF128) { tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); wfrag_load(fr_out, A.out_w, D); }
         else tile_mma_xw<BM, F, D>(R2, LF, A.w1, D, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
