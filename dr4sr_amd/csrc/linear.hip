@@ -1378,12 +1378,17 @@ __device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const
     float* Cs = As + BM * LDA;
     float* accP = Cs + BM * LDC;                        // [L][D]
     int* ids = reinterpret_cast<int*>(accP + A.L * D);  // [BM] item id of each row of the tile (0: contributes nothing to dE)
+    // latency regime, d = 64: the [3D x D] in_proj fragments are requested with the tile (48 VGPRs) instead of inside the k loop
+    constexpr bool PFQ = BM == 16 && D == 64;
+    WFragC<PFQ ? K : 16, 64> f_in;
+    if constexpr (PFQ) wfrag_load(f_in, A.W, D);
     for (int i = threadIdx.x; i < A.L * D; i += 256) accP[i] = 0.f;
     load_tile_bm<BM, K>(As, LDA, A.dQKV, K, t0, T);
     lds_barrier();
     TileAcc<BM, D> acc;
     tile_zero(acc);
-    tile_mma_xw<BM, K, D>(As, LDA, A.W, D, acc);
+    if constexpr (PFQ) tile_mma_frag<BM, K, D>(As, LDA, f_in, acc);
+    else tile_mma_xw<BM, K, D>(As, LDA, A.W, D, acc);
     tile_to_lds<BM, D>(acc, Cs, LDC, nullptr);
     lds_barrier();
     const int c = (threadIdx.x % LPT) * 4;
