@@ -289,8 +289,9 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
     const uint32_t sP = A.sP, sA = A.sA, sF = A.sF;
     const bool actdrop = dodrop && sA != 0xffffffffu;
 
-    // latency regime (BM = 16): every weight fragment is requested before the first barrier, so the four L2 round trips of
-    // the four GEMMs overlap with the phases in front of them instead of each starting after its barrier
+    // latency regime (BM = 16): the weight fragments of the four GEMMs are requested AHEAD of them — not inside their k loops —, so their
+    // L2 round trips overlap with the phases in front.  Not all up front any more (round 4): issuing 128 KB of requests took 3.9 us and
+    // the attention's window queued behind them; they are spread around the attention's pieces below (SPREAD)
     constexpr bool PF = BM == 16 && !FFN_ONLY;
     WFragT<PF ? D : 16, PF ? D : 64> f_out;
     WFragT<PF ? D : 16, PF ? F : 64> f_w1;
