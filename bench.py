@@ -548,6 +548,9 @@ def main():
                     help="repetitions of the timed region (each exactly --steps steps): ms_per_step = median, ms_per_step_spread = min / max")
     ap.add_argument("--in-graph-timeout", type=int, default=150,
                     help="data parallel: seconds the in-graph-collective attempt (second form) may take before the line is printed without it")
+    ap.add_argument("--no-dp-leg", action="store_true",
+                    help="single GPU: skip the 1-rank RCCL runs of the data-parallel step forms (strong[].dp_1rank_rccl)")
+    ap.add_argument("--dp-leg-gpus", type=int, default=8, help="the GPU count whose per-GPU share of each strong-scaling size the 1-rank RCCL leg runs")
     ap.add_argument("--interval", type=int, default=30, help="metamodel: outer-loop period (configs/metamodel.yaml interval)")
     args = ap.parse_args()
     if args.model == "metamodel":
@@ -643,13 +646,18 @@ def main():
         def reduce_grads():
             parallel.allreduce_flat(eng.grads)             # sum over ranks: grads + {n_valid, loss_sum, poison} tail
 
+        # gradient buckets of the data-parallel step (parallel.dp_backward): at scale the item-table gradient is final one launch before
+        # the rest, its all-reduce runs beside that launch and only the 280 KB encoder bucket is exposed; one flat all-reduce in the
+        # latency forms (and for GRU4Rec / FMLP).  Every rank has B rows here, so every rank decides alike.
+        buckets = parallel.grad_buckets(eng, B, data["seqlen"]) if (dp and args.model == "sasrec") else None
+        two = buckets is not None and len(buckets) == 2
+
         def step_eager():
             select()
             if not dp:
                 eng.train_step(plan)
             else:
-                eng.fwd_bwd(plan)
-                reduce_grads()
+                parallel.dp_backward(eng, plan, False, buckets)
                 eng.adam_step(plan)
 
         collective = None
@@ -660,6 +668,10 @@ def main():
             use_graph = not args.no_graph
             group = 1
             run_steps = None
+
+            def finish_steps():                              # (forms that leave a step's optimizer pending redefine it)
+                pass
+            fuse_prep = args.model == "sasrec"              # the optimizer launch of step j prepares step j + 1 (two-phase prep above 1 024 rows)
             if use_graph and not dp:
                 # batch selection runs on the device, so consecutive training steps need no host work at all: `group` whole steps
                 # are captured into one graph (a graph launch costs ~8 us of idle GPU between replays at this step size); any K / W
@@ -685,22 +697,17 @@ def main():
                     for _ in range(n % group):
                         g_one.replay()
             elif use_graph and dp_form == "in_graph":
-                # opt-in data-parallel form (train.dp_graph_allreduce): the RCCL all-reduce captured INSIDE the step graph — k whole DP
+                # opt-in data-parallel form (train.dp_graph_allreduce): the RCCL all-reduce(s) captured INSIDE the step graph — k whole DP
                 # steps per replay, no host work between backward, collective and optimizer; as on one GPU the optimizer launch of
-                # step j prepares step j+1 (B <= 1024).  Measured SECOND, after the host-launched form's numbers are safe (main()).
+                # step j prepares step j+1.  Measured SECOND, after the host-launched form's numbers are safe (main()).
                 group = max(1, min(args.steps_per_graph, steps))
-                fuse_prep = args.model == "sasrec" and B <= 1024
 
                 def capture_dp(n):
                     g = torch.cuda.CUDAGraph()
                     with graph_capture(g, stream=stream):
                         for j in range(n):
                             select()
-                            if fuse_prep and j > 0:
-                                eng.fwd_bwd_prepared(plan)
-                            else:
-                                eng.fwd_bwd(plan)
-                            reduce_grads()
+                            parallel.dp_backward(eng, plan, fuse_prep and j > 0, buckets)
                             if fuse_prep and j < n - 1:
                                 eng.adam_step_prepare_next(plan)
                             else:
@@ -725,28 +732,50 @@ def main():
                             g_all.replay()
                         for _ in range(n % group):
                             g_one.replay()
-                    collective = "rccl all-reduce captured in the step graph (%d steps per graph)" % group
+                    collective = "rccl all-reduce captured in the step graph (%d steps per graph, %s)" % (
+                        group, "2 buckets: table beside the last weight-gradient launch, then encoder + tail" if two else "1 flat bucket")
                 else:
                     return None                              # the caller reports in_graph: null (capture failed on some rank)
-            if run_steps is None and use_graph and dp and args.model == "sasrec" and B <= 1024:
-                # two graphs around a host-launched all-reduce; the optimizer graph also prepares the next batch, so only the first
-                # step of a run carries its own prep launch
-                g_first, g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with graph_capture(g_first, stream=stream):
-                    eng.fwd_bwd(plan)
-                with graph_capture(g_a, stream=stream):
-                    eng.fwd_bwd_prepared(plan)
-                with graph_capture(g_b, stream=stream):
-                    eng.adam_step_prepare_next(plan)
-                prepared = [False]
+            if run_steps is None and use_graph and dp and args.model == "sasrec":
+                # Host-launched collectives between graphs.  The graph that holds the optimizer of step j (which also prepares the
+                # next batch) holds the backward of step j + 1 up to its first collective as well: ONE graph launch per collective.
+                #   one bucket :  [fwd_bwd] AR ([adam+prep | fwd_bwd_prepared] AR)* ...
+                #   two buckets:  [phase 1] AR0 [phase 2] AR1 ([adam+prep | phase 1] AR0 [phase 2] AR1)* ...
+                def graph_of(fn):
+                    g = torch.cuda.CUDAGraph()
+                    with graph_capture(g, stream=stream):
+                        fn()
+                    return g
+                if two:
+                    g_first = graph_of(lambda: eng.fwd_bwd_phase(plan, False, 1))
+                    g_p2 = graph_of(lambda: eng.fwd_bwd_phase(plan, True, 2))
+                    g_mid = graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_phase(plan, True, 1)))
+                    (b0lo, b0hi), (b1lo, b1hi) = buckets
+                else:
+                    g_first = graph_of(lambda: eng.fwd_bwd(plan))
+                    g_mid = graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_prepared(plan)))
+                g_fin = graph_of(lambda: eng.adam_step(plan))
+                pending = [False]                            # a step whose optimizer has not run yet (it rides in the next call's first graph)
 
                 def run_steps(n):
                     for _ in range(n):
-                        (g_a if prepared[0] else g_first).replay()
-                        reduce_grads()
-                        g_b.replay()
-                        prepared[0] = True
-                collective = "%s all-reduce launched by the host between two graphs" % parallel.backend_name()
+                        (g_mid if pending[0] else g_first).replay()
+                        if two:
+                            h0 = parallel.allreduce_begin(eng.grads[b0lo:b0hi])
+                            g_p2.replay()
+                            h1 = parallel.allreduce_begin(eng.grads[b1lo:b1hi])
+                            parallel.allreduce_end(h0)
+                            parallel.allreduce_end(h1)
+                        else:
+                            reduce_grads()
+                        pending[0] = True
+
+                def finish_steps():                          # the last step's optimizer: inside the timed region (main loop below)
+                    if pending[0]:
+                        g_fin.replay()
+                        pending[0] = False
+                collective = "%s all-reduce launched by the host between graphs (%s)" % (
+                    parallel.backend_name(), "2 buckets: table beside the last weight-gradient launch, then encoder + tail" if two else "1 flat bucket")
             elif run_steps is None and use_graph and dp:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with graph_capture(g_a, stream=stream):
@@ -768,6 +797,7 @@ def main():
                 collective = ("%s all-reduce, eager" % parallel.backend_name()) if dp else None
 
             run_steps(warmup)
+            finish_steps()
             stream.synchronize()
             walls, gpus = [], []
             for _ in range(repeats):
@@ -778,6 +808,7 @@ def main():
                 t0 = time.perf_counter()
                 e0.record()
                 run_steps(steps)
+                finish_steps()                               # (host form: the last step's optimizer launch)
                 e1.record()
                 torch.cuda.synchronize()
                 if dp:
@@ -970,6 +1001,51 @@ def main():
             out["strong"] = strong
     if rank == 0 and not dp and not args.no_cpu_baseline and args.model in ("sasrec", "gru4rec"):
         out["cpu_baseline"] = cpu_baseline_leg(rows_np, N, args.model, 0.2 if args.model == "gru4rec" else args.dropout)
+
+    # ---- single GPU: what the DATA-PARALLEL form of the step costs beyond the single-GPU step, measured with the one RCCL rank a 1-GPU
+    # box can host (a process group of one).  For every strong-scaling size G the per-GPU share G / 8 runs (a) as the single-GPU k-step
+    # graph, (b) as the DP step with its collective(s) captured in the graph, (c) with host-launched collectives between graphs.
+    # collective_exposed_us = (b or c) - (a): launch cuts, stream hand-offs and the 1-rank collective kernels — everything of the DP step
+    # that does not shrink with the rank count, EXCEPT the wire time of a real 8-rank all-reduce (nothing on this box can measure that;
+    # the table bucket's share of it runs beside the last weight-gradient launch, whose duration is printed next to it).
+    if world == 1 and not dp and rank == 0 and args.model == "sasrec" and strong and not args.no_dp_leg:
+        try:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ["DR4SR_BENCH_FORCE_DP"] = "1"
+            parallel.init_distributed(dev)
+            Wd = max(2, args.dp_leg_gpus)
+            for ent in strong:
+                G = ent["global_batch"]
+                if G % Wd:
+                    continue
+                per = G // Wd
+                st, wu = max(20, min(100, args.steps)), 10
+                plain = measure(per, st, wu, None, dp=False, repeats=sec_rep)[0]
+                host = measure(per, st, wu, None, dp=True, dp_form="host", repeats=sec_rep)[0]
+                ig = measure(per, st, wu, None, dp=True, dp_form="in_graph", repeats=sec_rep) if parallel.can_capture() else None
+                ig = ig[0] if ig is not None else None
+                best = min(host["ms_per_step"], ig["ms_per_step"]) if ig is not None else host["ms_per_step"]
+                ent["dp_1rank_rccl"] = {
+                    "assumed_gpus": Wd, "per_gpu_batch": per, "single_gpu_form_ms": plain["ms_per_step"],
+                    "dp_host_ms": host["ms_per_step"], "dp_in_graph_ms": None if ig is None else ig["ms_per_step"],
+                    "collective_exposed_us": 1e3 * (best - plain["ms_per_step"]),
+                    "collective_exposed_us_host": 1e3 * (host["ms_per_step"] - plain["ms_per_step"]),
+                    "collective_exposed_us_in_graph": None if ig is None else 1e3 * (ig["ms_per_step"] - plain["ms_per_step"]),
+                    "collective": (ig or host)["config"]["collective"], "allreduce_us_standalone_flat_1rank": host.get("allreduce_us_standalone"),
+                    "projected_speedup_upper_bound": ent["single_gpu_ms_per_step"] / best,
+                    "note": "1 RCCL rank: launch cuts + stream hand-offs + 1-rank collective kernels; the wire time of a real %d-rank all-reduce is "
+                            "NOT in this figure (upper bound of the speedup)" % Wd}
+        except Exception as e:      # noqa: BLE001 — the leg is extra evidence: never lose the line over it
+            out["dp_1rank_rccl_error"] = "%s: %s" % (type(e).__name__, e)
+        finally:
+            os.environ.pop("DR4SR_BENCH_FORCE_DP", None)
+            if dist.is_initialized():
+                print(json.dumps(out), flush=True)
+                dist.destroy_process_group()
+                return
 
     # ---- data parallel, second form: the RCCL all-reduce captured INSIDE the k-step graph (the model's opt-in, train.dp_graph_allreduce).
     # Everything above ran with the host-launched collective — the form every multi-rank test covers — and `out` is complete; the

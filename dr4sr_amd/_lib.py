@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR4SR_LIB_PATH") or os.path.join(_HERE, "csrc", "libdr4sr_hip.so")     # override: A/B runs of two builds on one box
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 GRAD_TAIL = 4
 STATE_WORDS = 16
 STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
@@ -155,6 +155,8 @@ SYMBOLS = {
     "dr4sr_sasrec_train_steps": (C.c_int, [_PLANP, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_fwd_bwd_prepared": (C.c_int, [_PLANP, C.c_void_p]),
     "dr4sr_adam_step_prepare_next": (C.c_int, [_PLANP, C.c_void_p]),
+    "dr4sr_sasrec_grad_buckets": (C.c_int, [_PLANP, C.POINTER(C.c_int64)]),
+    "dr4sr_sasrec_fwd_bwd_phase": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_encode": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_sasrec_encode_bwd": (C.c_int, [_PLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_select_rows": (C.c_int, [_i64p, C.c_int64, _i64p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -222,7 +222,10 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // compute, so the fused step launches them early on a side stream (step.hip backward_layers); the table-gradient jobs (owner / scatter
 // planes), the embedding-stage plane and the scorer partials belong to the launch that holds layer 0
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb = false,
-                 bool meta = false, int l_lo = 0, int l_hi = -1);     // meta: the fused last-layer launch carried the MetaModel weighting (its tile size differs)
+                 bool meta = false, int l_lo = 0, int l_hi = -1, int table = -1);     // meta: the fused last-layer launch carried the MetaModel weighting (its tile size differs)
+// table: -1 = the launch that holds layer 0 carries the item / position table jobs (owner planes, scatter plane); 1 = this launch carries
+// them whatever its layer range (which may be EMPTY: l_lo == l_hi), 0 = it does not — the two-bucket data-parallel step (step.hip)
+bool wgrad_table_jobs(const dr4sr_sasrec_plan* p, const Workspace& ws);      // the table gradient is a set of k_wgrad jobs (at scale, fused step)
 bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws);    // latency regime: attention inside k_post_fwd / k_post_mid / k_post_bwd (attn_tile.h)
 // at scale, short sequences, d = 64 (Workspace::attn_tile_sa): one window-attention launch per layer and direction instead of the
 // two / three length-class list launches (attn_tile_sa.hip; the same tattn::fwd / tattn::bwd bodies as the in-tile form)

@@ -1856,12 +1856,14 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvE
     // the scatter blocks come FIRST in dispatch order (y = 0): the other jobs are persistent loops, so blocks dispatched after
     // the first resident wave would only start when those finish — no overlap
     // (owner planes first, then the dP / atomic scatter plane)
+    // (table jobs: plane z = 0 of the launch that carries them — layer 0's unless the data-parallel step moved them, launch_wgrad `table`)
+    const bool tz = (int)blockIdx.z == A.qeb_plane;
     if (A.ow_on && (int)blockIdx.y < A.ow_planes) {
-        if (layer == 0) { if (A.ow_ent) owner_job_sorted<D>(A, blockIdx.y * gridDim.x + blockIdx.x); else owner_job<D>(A, blockIdx.y * gridDim.x + blockIdx.x); }
+        if (tz) { if (A.ow_ent) owner_job_sorted<D>(A, blockIdx.y * gridDim.x + blockIdx.x); else owner_job<D>(A, blockIdx.y * gridDim.x + blockIdx.x); }
         return;
     }
     const int j = (int)blockIdx.y - (A.ow_on ? A.ow_planes : 0) - (A.sc_g ? 1 : 0);
-    if (j < 0) { if (layer == 0) scatter_job<D>(A); return; }
+    if (j < 0) { if (tz) scatter_job<D>(A); return; }
     if constexpr (BLK) {
         constexpr int RD = D / 64, RF = F / 64, NDD = RD * RD, NB = 4 * NDD + 2 * RD * RF;
         if (j == NB) { reduce_jobs(A, layer); return; }
@@ -1996,12 +1998,17 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
     return DR4SR_LAUNCH_CHECK();
 }
 
+bool wgrad_table_jobs(const dr4sr_sasrec_plan* p, const Workspace& ws) { (void)p; return scatter_in_wgrad(ws); }
+
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb, bool meta,
-                 int l_lo, int l_hi) {
+                 int l_lo, int l_hi, int table) {
     WgradArgs A;
     if (l_hi < 0) l_hi = p->n_layer;
-    if (l_lo < 0 || l_lo >= l_hi || l_hi > p->n_layer) return DR4SR_E_ARG;
-    const bool has0 = l_lo == 0;                            // the launch that holds layer 0 also carries the table / embedding-stage jobs
+    const bool tbl = table < 0 ? l_lo == 0 : table != 0;    // this launch carries the table jobs
+    const bool gemm = l_lo < l_hi;                          // ... and / or weight-gradient jobs of layers [l_lo, l_hi)
+    if (l_lo < 0 || l_lo > l_hi || l_hi > p->n_layer || (!gemm && !(tbl && table > 0))) return DR4SR_E_ARG;
+    if (table >= 0 && (!scatter_in_wgrad(ws) || with_score == 1 || (qeb && qeb_in_wgrad(ws)))) return DR4SR_E_ARG;   // only where the table gradient IS a set of jobs
+    const bool has0 = tbl;                                  // the launch that carries the table / embedding-stage jobs
     A.layer0 = l_lo;
     const int D = p->D, F = p->F;
     float* G = p->grads;
@@ -2097,7 +2104,8 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     const bool blk64 = !A.bf16x3 && (blk_env ? atoi(blk_env) != 0 : !ws.scale);
     const int NY = blk64 ? 4 * (D / 64) * (D / 64) + 2 * (D / 64) * (F / 64) : NJ;
     if (blk64 && !scatter) lds = sizeof(float) * 64 * 128;
-    dim3 grid(gw, NY + 1 + (scatter ? 1 : 0) + A.ow_planes, (l_hi - l_lo) + A.qeb_plane), blk(256);
+    // (a table-only launch has no GEMM / reduce rows: y counts the owner planes and the scatter plane, one z plane)
+    dim3 grid(gw, (gemm ? NY + 1 : 0) + (scatter ? 1 : 0) + A.ow_planes, (gemm ? l_hi - l_lo : 1) + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D + 16);
     if (A.qeb_plane && lds_q > lds) lds = lds_q;
 #define WG(D_, F_) do { if (blk64) { big_lds(k_wgrad_blk<D_, F_>, lds); hipLaunchKernelGGL((k_wgrad_blk<D_, F_>), grid, blk, lds, s, A, Q); } \

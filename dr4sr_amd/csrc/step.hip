@@ -408,9 +408,28 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
     return 0;
 }
 
+// Two-bucket data-parallel step (include/dr4sr_hip.h: dr4sr_sasrec_fwd_bwd_phase).  Where the table gradient is a set of k_wgrad jobs (at
+// scale) the last launch of the backward is cut in two: the FIRST carries the owner / scatter jobs — after it the item and position
+// table gradients [0, off[2]) are final, 3.05 of the 3.33 MB of a toys replica — plus the weight-gradient jobs of layers >= split (their
+// inputs were ready first, and they keep the CUs busy beside the LDS-bound owners exactly as in the one-launch form); the SECOND carries
+// layers < split and the reduce jobs that write the {n_valid, loss_sum} tail.  The caller issues the table bucket's all-reduce between
+// the two, so the collective runs BESIDE the second launch.  split = max(1, n_layer / 2); DR4SR_DP_SPLIT_LAYER overrides (n_layer = a
+// table-only first launch: the longest cover, but the owners run alone; 0 = one launch, one bucket).
+static int dp_split_layer(const dr4sr_sasrec_plan* p) {
+    int v = p->n_layer / 2 > 1 ? p->n_layer / 2 : 1;
+    if (const char* e = DR4SR_ENV("DR4SR_DP_SPLIT_LAYER")) v = atoi(e);
+    return v < 0 ? 0 : (v > p->n_layer ? p->n_layer : v);
+}
+static bool dp_two_buckets(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    return !DR4SR_ENV("DR4SR_NO_FUSE") && !step_fork().on() && wgrad_table_jobs(p, ws) && dp_split_layer(p) > 0;
+}
+
+// phase 0: the whole backward; 1: up to and including the launch that completes the table bucket; 2: what is left (one launch)
 static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s,
-                           bool mid_fused = false, bool meta = false) {
+                           bool mid_fused = false, bool meta = false, int phase = 0) {
     const bool fused = !DR4SR_ENV("DR4SR_NO_FUSE");
+    const bool two = phase != 0 && dp_two_buckets(p, ws);
+    if (phase == 2) return two ? launch_wgrad(p, ws, training, with_score, s, fused, meta, 0, dp_split_layer(p), 0) : 0;
     // The weight gradients of layer l >= 1 need dqkv_l (attention backward of layer l) and nothing that the layers below still have to
     // compute: their launch goes to a side stream right behind attn_bwd(l) and runs BESIDE post_bwd(l-1) / attn_bwd(l-1) / the embedding
     // stage — an HBM stream next to latency-bound launches (in a captured step: a parallel branch of the graph).  The launch that
@@ -432,18 +451,21 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
     if (!fused) RC(launch_embed_bwd(p, ws, training, s));
     else if (!qeb_in_wgrad(ws)) RC(launch_qkv_embed_bwd(p, ws, training, s));
     if (forked) RC(fk.join(s, 2, 1));
+    if (two) return launch_wgrad(p, ws, training, with_score, s, fused, meta, dp_split_layer(p), p->n_layer, 1);
     RC(launch_wgrad(p, ws, training, with_score, s, fused, meta, 0, forked ? 1 : -1));
     return 0;
 }
 
 // everything of a training step between the prep and the optimizer
-static int fwd_bwd_core(const dr4sr_sasrec_plan* plan, const Workspace& ws, hipStream_t s) {
+static int fwd_bwd_core(const dr4sr_sasrec_plan* plan, const Workspace& ws, hipStream_t s, int phase = 0) {
     if (!DR4SR_ENV("DR4SR_NO_FUSE")) {
+        if (phase == 2) return backward_layers(plan, ws, 1, 2, s, true, false, 2);
         RC(forward_layers(plan, ws, 1, s, true));
         RC(launch_post_mid(plan, ws, 1, s));
-        RC(backward_layers(plan, ws, 1, 2, s, true));
+        RC(backward_layers(plan, ws, 1, 2, s, true, false, phase));
         return 0;
     }
+    if (phase == 2) return 0;
     RC(forward_layers(plan, ws, 1, s));
     RC(launch_score_packed(plan, ws, s));
     RC(backward_layers(plan, ws, 1, 1, s));
@@ -492,6 +514,31 @@ extern "C" int dr4sr_sasrec_fwd_bwd_prepared(const dr4sr_sasrec_plan* plan, void
     RC(get_ws(plan, &ws));
     if (!plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
     return fwd_bwd_core(plan, ws, (hipStream_t)stream);
+}
+// ---- the step in two phases around the table bucket's all-reduce (see dp_split_layer above)
+extern "C" int dr4sr_sasrec_grad_buckets(const dr4sr_sasrec_plan* plan, int64_t* bounds) {
+    if (!plan) return DR4SR_E_ARG;
+    dr4sr_sasrec_plan q = *plan;
+    q.workspace = nullptr;
+    if (q.B <= 0 || q.L <= 0 || q.n_layer <= 0 || q.n_layer > DR4SR_MAX_LAYERS) return DR4SR_E_ARG;
+    if (check_shape(&q)) return DR4SR_E_SHAPE;
+    Workspace ws;
+    carve_workspace(&q, &ws);
+    const bool two = dp_two_buckets(&q, ws);
+    if (bounds) {
+        bounds[0] = 0;
+        bounds[1] = two ? ws.off[2] : ws.n_params + DR4SR_GRAD_TAIL;
+        bounds[2] = ws.n_params + DR4SR_GRAD_TAIL;
+    }
+    return two ? 2 : 1;
+}
+extern "C" int dr4sr_sasrec_fwd_bwd_phase(const dr4sr_sasrec_plan* plan, int32_t prepared, int32_t phase, void* stream) {
+    Workspace ws;
+    RC(get_ws(plan, &ws));
+    if (phase < 1 || phase > 2 || !plan->grads || !plan->item_id || !plan->neg_item || plan->n_params != ws.n_params) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (phase == 1 && !prepared) RC(launch_prep(plan, ws, 1, 1, s));
+    return fwd_bwd_core(plan, ws, s, phase);
 }
 extern "C" int dr4sr_adam_step_prepare_next(const dr4sr_sasrec_plan* plan, void* stream) {
     Workspace ws;

@@ -204,6 +204,30 @@ class SasrecEngine:
     def adam_step_prepare_next(self, plan):
         _lib.check(self.lib.dr4sr_adam_step_prepare_next(C.byref(plan), _lib.cur_stream()), "dr4sr_adam_step_prepare_next")
 
+    def grad_buckets(self, plan):
+        """[(lo, hi), ...] float ranges of self.grads that become final one after the other in a step of this plan: one range
+        (everything, tail included) in the latency forms, (item + position table | encoder layers + tail) at scale
+        (include/dr4sr_hip.h: dr4sr_sasrec_grad_buckets)"""
+        b = (C.c_int64 * 3)()
+        n = int(self.lib.dr4sr_sasrec_grad_buckets(C.byref(plan), b))
+        if n < 1:
+            _lib.check(n, "dr4sr_sasrec_grad_buckets")
+        return [(int(b[0]), int(b[1]))] if n == 1 else [(int(b[0]), int(b[1])), (int(b[1]), int(b[2]))]
+
+    def grad_buckets_for(self, rows: int, seqlen=None):
+        """grad_buckets of a training plan of `rows` rows drawn from the dataset tensor `seqlen` (a probe plan: no buffers)"""
+        keep = self._keep
+        probe = self._plan(rows, None, None, None, None, None, False, with_ws=False,
+                           expected_tokens=self._expected_tokens(rows, seqlen, True) if seqlen is not None else
+                           (max(1, int(rows * self.mean_len)) if self.mean_len is not None else 0))
+        self._keep = keep                                    # (the probe references nothing)
+        return self.grad_buckets(probe)
+
+    def fwd_bwd_phase(self, plan, prepared: bool, phase: int):
+        """phase 1: the step up to the launch that completes grad_buckets()[0]; phase 2: the rest (dr4sr_sasrec_fwd_bwd_phase)"""
+        _lib.check(self.lib.dr4sr_sasrec_fwd_bwd_phase(C.byref(plan), int(bool(prepared)), int(phase), _lib.cur_stream()),
+                   "dr4sr_sasrec_fwd_bwd_phase")
+
     def train_steps(self, plan, n: int):
         """n consecutive steps (consecutive batches of plan.perm): one prep launch, the optimizer launches prepare the next step"""
         _lib.check(self.lib.dr4sr_sasrec_train_steps(C.byref(plan), int(n), _lib.cur_stream()), "dr4sr_sasrec_train_steps")

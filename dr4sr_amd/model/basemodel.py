@@ -300,14 +300,16 @@ class BaseModel(nn.Module):
         on = bool(self.config["train"].get("dp_graph_allreduce", False)) or bool(os.environ.get("DR4SR_DP_GRAPH_ALLREDUCE"))
         return on and parallel.can_capture()
 
-    def _step_graph(self, fields, bl, perm_sel=None, group=1, loss_log=None, in_graph=False):
+    def _step_graph(self, fields, bl, perm_sel=None, group=1, loss_log=None, in_graph=False, dp_rows=None):
         """captured HIP graph(s) for a local batch of `bl` rows addressed through self._rows_buf[:bl]; with perm_sel =
         (perm, global batch, rank offset, counter) the rows are selected on the device by the step's first kernel, which makes
         consecutive steps host-free: `group` whole steps go into ONE graph and each writes its mean loss to loss_log[batch index].
         in_graph (data parallel only): the caller decided — from GLOBAL quantities, so every rank decides alike — that this step's
-        collective is captured inside the graph."""
+        collective is captured inside the graph.  dp_rows (data parallel only): the rows of a FULL per-rank slice of this global
+        batch, the same number on every rank — the gradient's bucket count is decided from it, not from this rank's own slice, because
+        ranks that disagreed on the number of collectives of a step would deadlock the communicator; None = one flat all-reduce."""
         key = (fields["in_item_id"].data_ptr(), bl, group, None if loss_log is None else loss_log.data_ptr(),
-               None if perm_sel is None else (perm_sel[0].data_ptr(), perm_sel[1], perm_sel[2]), bool(in_graph))
+               None if perm_sel is None else (perm_sel[0].data_ptr(), perm_sel[1], perm_sel[2]), bool(in_graph), dp_rows)
         if key in self._graphs:
             return self._graphs[key]
         eng = self.engine
@@ -347,34 +349,31 @@ class BaseModel(nn.Module):
             # Every rank takes the same form for the same global batch: `in_graph` and `group` come from global quantities
             # (_fused_epoch), and a capture that fails on ANY rank sends ALL ranks to the host form (the success flag is reduced
             # with MIN before the form is chosen — mixing in-graph and host-launched collectives would deadlock the communicator).
-            has_prep = perm_sel is not None and hasattr(eng, "fwd_bwd_prepared") and bl <= 1024
+            # Gradient buckets (parallel.dp_backward): at scale the table gradient is final one launch before the rest and its all-reduce
+            # runs beside that launch; the latency forms have one bucket = the flat all-reduce.
+            has_prep = perm_sel is not None and hasattr(eng, "fwd_bwd_prepared")      # the optimizer launch of step j prepares step j + 1 (any batch size)
+            buckets = parallel.grad_buckets(eng, dp_rows, fields.get("seqlen"))
+            two = len(buckets) == 2
 
             def body(reduce):
                 for j in range(group):
-                    if has_prep and j > 0:
-                        eng.fwd_bwd_prepared(plan)
-                    else:
-                        eng.fwd_bwd(plan)
-                    reduce()
+                    parallel.dp_backward(eng, plan, has_prep and j > 0, buckets, reduce=reduce)
                     if has_prep and j < group - 1:
                         eng.adam_step_prepare_next(plan)
                     else:
                         eng.adam_step(plan)
 
-            def do_reduce():
-                allreduce_flat(eng.grads)                 # RCCL sum: gradients + {n_valid, loss_sum, poison} tail
-
             run = None
             if use_graph:
                 # warm-up must NOT enter a collective: ranks create their graphs at different steps (a tail batch gives some ranks a
                 # new slice size, others an old or empty one)
-                warm_up(lambda: body(lambda: None))
+                warm_up(lambda: body(False))
                 if in_graph:
                     ok, g = 1, None
                     try:
                         g = torch.cuda.CUDAGraph()
                         with capture(g):
-                            body(do_reduce)
+                            body(True)
                     except Exception as e:                # noqa: BLE001 — any capture failure: keep training with the split form
                         self.logger.warning(f"in-graph all-reduce capture failed ({type(e).__name__}: {e}); using host-launched collectives")
                         ok, g = 0, None
@@ -386,37 +385,46 @@ class BaseModel(nn.Module):
                     elif ok:
                         self.logger.warning("in-graph all-reduce capture failed on another rank; using host-launched collectives")
                 if run is None:
-                    if has_prep and group > 1:
-                        g_first, ga, gb, gl = (torch.cuda.CUDAGraph() for _ in range(4))
-                        with capture(g_first):
-                            eng.fwd_bwd(plan)
-                        with capture(ga):
-                            eng.fwd_bwd_prepared(plan)
-                        with capture(gb):
-                            eng.adam_step_prepare_next(plan)
-                        with capture(gl):
-                            eng.adam_step(plan)
-
-                        def run():
-                            for j in range(group):
-                                (ga if j > 0 else g_first).replay()
-                                do_reduce()
-                                (gb if j < group - 1 else gl).replay()
+                    # Host-launched collectives between graphs.  The graph that holds the optimizer of step j also holds the backward of
+                    # step j + 1 up to its first collective, so a step costs ONE graph launch per collective (round 4: two graphs + one
+                    # collective per step; the extra launch was ~8 us of idle GPU per step at B = 256).
+                    #   one bucket :  [fwd_bwd] AR ([adam+prep | fwd_bwd_prepared] AR)* [adam]
+                    #   two buckets:  [phase 1] AR0 [phase 2] AR1 ([adam+prep | phase 1] AR0 [phase 2] AR1)* [adam]
+                    def graph_of(fn):
+                        g = torch.cuda.CUDAGraph()
+                        with capture(g):
+                            fn()
+                        return g
+                    prep = has_prep and group > 1
+                    if two:
+                        g_first = graph_of(lambda: eng.fwd_bwd_phase(plan, False, 1))
+                        g_p2 = graph_of(lambda: eng.fwd_bwd_phase(plan, prep, 2))         # (phase 2 is the same launch either way)
+                        g_mid = None if group == 1 else \
+                            graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_phase(plan, True, 1))) if prep else \
+                            graph_of(lambda: (eng.adam_step(plan), eng.fwd_bwd_phase(plan, False, 1)))
                     else:
-                        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                        with capture(ga):
-                            eng.fwd_bwd(plan)
-                        with capture(gb):
-                            eng.adam_step(plan)
+                        g_first = graph_of(lambda: eng.fwd_bwd(plan))
+                        g_mid = None if group == 1 else \
+                            graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_prepared(plan))) if prep else \
+                            graph_of(lambda: (eng.adam_step(plan), eng.fwd_bwd(plan)))
+                    g_last = graph_of(lambda: eng.adam_step(plan))
+                    (b0lo, b0hi), (b1lo, b1hi) = buckets[0], buckets[-1]
 
-                        def run():
-                            for _ in range(group):
-                                ga.replay()
-                                do_reduce()
-                                gb.replay()
+                    def run():
+                        for j in range(group):
+                            (g_mid if j > 0 else g_first).replay()
+                            if two:
+                                h0 = parallel.allreduce_begin(eng.grads[b0lo:b0hi])
+                                g_p2.replay()
+                                h1 = parallel.allreduce_begin(eng.grads[b1lo:b1hi])
+                                parallel.allreduce_end(h0)
+                                parallel.allreduce_end(h1)
+                            else:
+                                allreduce_flat(eng.grads)             # RCCL sum: gradients + {n_valid, loss_sum, poison} tail
+                        g_last.replay()
             else:
                 def run():
-                    body(do_reduce)
+                    body(True)
         self._graphs[key] = (run, plan)
         return self._graphs[key]
 
@@ -453,7 +461,8 @@ class BaseModel(nn.Module):
                 k = group if (i + group) * B <= n else 1
                 full = (i + 1) * B <= n
                 run, _ = self._step_graph(loader.fields, bl, sel, group=k, loss_log=losses,      # k_adam logs the (all-reduced) mean loss
-                                          in_graph=W > 1 and full and self._dp_in_graph())
+                                          in_graph=W > 1 and full and self._dp_in_graph(),
+                                          dp_rows=(B + W - 1) // W if (W > 1 and full) else None)
                 run()
                 i += k
                 continue
@@ -461,9 +470,9 @@ class BaseModel(nn.Module):
                 self._rows_buf[:bl].copy_(perm[lo:hi])
                 run, _ = self._step_graph(loader.fields, bl)
                 run()
-            else:                                          # tail batch smaller than the rank count: contribute zeros
-                eng.grads.zero_()
-                allreduce_flat(eng.grads)
+            else:                                          # fewer rows than ranks: contribute zeros to the same collectives as the others
+                full = (i + 1) * B <= n
+                parallel.dp_reduce_empty(eng, parallel.grad_buckets(eng, (B + W - 1) // W if full else None, loader.fields.get("seqlen")))
                 eng.adam_step(self._api_plan())
             losses[i] = tail[1] / tail[0]
             i += 1

@@ -5,10 +5,13 @@ The reference has no distributed path (/root/reference uti
   * one global permutation per epoch (rank 0's, broadcast); the i-th GLOBAL batch of B rows is split into
     contiguous slices of ceil(B/W) rows, rank r takes slice r (`shard_bounds`);
   * each rank accumulates UN-normalised gradients of its slice plus the tail {n_valid, loss_sum, poison}
-    (include/dr4sr_hip.h "Flat parameter layout"), then ONE sum-all-reduce of the whole flat buffer.  It is deliberately not
-    bucketed: every gradient producer of the fused step (weight-gradient GEMMs, embedding scatter, LayerNorm / loss partial
-    reductions) is a job of the step's LAST launch (k_wgrad, csrc/linear.hip), so no bucket is complete before the backward
-    has ended and a second collective would only add its latency (DESIGN.md §6);
+    (include/dr4sr_hip.h "Flat parameter layout"), then sum-all-reduces the flat buffer:
+      - latency launch forms (small per-rank batches): ONE all-reduce of the whole buffer — every gradient producer of the fused step
+        is a job of the step's last launch, nothing is final earlier;
+      - at-scale launch forms: TWO buckets (`dp_backward`, SURVEY.md §8(e) "optionally 2 buckets ... overlapped with backward").  The
+        engine cuts the last backward launch in two (dr4sr_sasrec_fwd_bwd_phase): after the first the item + position table
+        gradient — 92 % of the bytes — is final and its all-reduce is issued asynchronously, so it runs BESIDE the second launch
+        (the remaining weight-gradient GEMMs); the 280 KB encoder bucket + tail follows, and only that one is exposed;
   * dr4sr_adam_step divides by the all-reduced n_valid, i.e. the reference's global-batch normalisation
     (loss_func.py:18-19, :29-30), and every replica takes the bit-identical dense Adam step.
 
@@ -83,6 +86,69 @@ def allreduce_flat(grads, group=None):
     else:
         dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
     return grads
+
+
+def allreduce_begin(t, group=None):
+    """start the sum-all-reduce of `t` (a contiguous slice of the flat gradient); returns a handle for `allreduce_end`.
+    RCCL: asynchronous — the collective is ordered behind everything already enqueued on the current stream and runs on the process
+    group's own stream; the current stream does not wait for it before `allreduce_end`, so kernels enqueued in between run beside it
+    (inside a graph capture the two become parallel branches of the graph).  gloo (functional runs on one GPU): reduced on the spot
+    through the host, handle None."""
+    import torch.distributed as dist
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def allreduce_end(handle):
+    """the current stream waits for the collective started by `allreduce_begin` (no host wait with RCCL)"""
+    if handle is not None:
+        handle.wait()
+
+
+def grad_buckets(eng, rows, seqlen=None):
+    """[(lo, hi), ...] float ranges of eng.grads all-reduced one after the other in a data-parallel step whose FULL per-rank slice holds
+    `rows` rows (the tail sits in the last range).  The answer must be the same on every rank — ranks that disagreed on the number of
+    collectives of a step would deadlock — so it is a function of `rows` (ceil(global batch / world), equal everywhere) and of the
+    replicated dataset's mean length, never of a rank's own (possibly short or empty) slice: a rank whose own slice runs the latency
+    launch forms under a two-bucket decision simply has both buckets final after phase 1 (dp_backward).  One range: rows=None (partial
+    tail batches), engines without the two-phase step (GRU4Rec, FMLP), DR4SR_DP_FLAT (cross-check)."""
+    flat = [(0, int(eng.grads.numel()))]
+    if rows is None or os.environ.get("DR4SR_DP_FLAT") or not hasattr(eng, "grad_buckets_for"):
+        return flat
+    return eng.grad_buckets_for(int(rows), seqlen)
+
+
+def dp_backward(eng, plan, prepared: bool, buckets=None, reduce: bool = True):
+    """backward of one data-parallel step + the sum-all-reduce of its gradient; `buckets` from grad_buckets (None = flat).  One bucket:
+    fwd_bwd[_prepared] then the flat all-reduce.  Two buckets: phase 1 -> all-reduce(table bucket) started -> phase 2 (runs beside it) -> all-reduce(encoder bucket + tail)
+    -> the current stream joins both.  reduce=False: the kernels only (graph warm-ups must not enter a collective)."""
+    if buckets is None or len(buckets) == 1:
+        (eng.fwd_bwd_prepared if prepared else eng.fwd_bwd)(plan)
+        if reduce:
+            allreduce_flat(eng.grads)
+        return
+    eng.fwd_bwd_phase(plan, prepared, 1)
+    h0 = allreduce_begin(eng.grads[buckets[0][0]:buckets[0][1]]) if reduce else None
+    eng.fwd_bwd_phase(plan, prepared, 2)
+    h1 = allreduce_begin(eng.grads[buckets[1][0]:buckets[1][1]]) if reduce else None
+    allreduce_end(h0)
+    allreduce_end(h1)
+
+
+def dp_reduce_empty(eng, buckets=None):
+    """a rank whose slice of this global batch is EMPTY: contribute zeros to the same collectives, in the same order, as the ranks
+    that have rows (`buckets` = the global decision of grad_buckets, like theirs)"""
+    eng.grads.zero_()
+    if buckets is None or len(buckets) == 1:
+        allreduce_flat(eng.grads)
+        return
+    hs = [allreduce_begin(eng.grads[lo:hi]) for lo, hi in buckets]
+    for h in hs:
+        allreduce_end(h)
 
 
 def all_gather_flat(t, group=None):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DR4SR_ABI_VERSION 6
+#define DR4SR_ABI_VERSION 7
 
 #define DR4SR_E_ARG      (-1)   /* null pointer / bad size                                   */
 #define DR4SR_E_SHAPE    (-2)   /* unsupported D / H / F / L combination     */
@@ -163,6 +163,21 @@ int dr4sr_sasrec_train_steps(const dr4sr_sasrec_plan* plan, int32_t n_steps, voi
  * plan->perm counter has then advanced once more). */
 int dr4sr_sasrec_fwd_bwd_prepared(const dr4sr_sasrec_plan* plan, void* stream);
 int dr4sr_adam_step_prepare_next(const dr4sr_sasrec_plan* plan, void* stream);
+
+/* ABI 7 — the data-parallel step with the gradient in TWO buckets that become final at different times ("optionally
+ * 2 buckets ... overlapped with backward"; the reference has no distributed path, /root/reference/utils/callbacks.py:130 is its TODO).
+ *   dr4sr_sasrec_grad_buckets(plan, bounds)  -> number of buckets a step of this plan produces, 1 or 2; bounds[0..2] (floats into
+ *       plan->grads): bucket 0 = [bounds[0], bounds[1]), bucket 1 = [bounds[1], bounds[2]).  Two buckets exist where the item-table
+ *       gradient is a set of jobs of the last backward launch (the at-scale launch forms, dr4sr_sasrec_at_scale bit 0): bucket 0 = the
+ *       item table E and the position table P, [0, offsets[2]) — 92 % of a toys-sized replica's bytes; bucket 1 = the encoder layers and
+ *       the {n_valid, loss_sum, poison, -} tail.  One bucket otherwise (latency forms: every producer is one launch), bounds[1] = bounds[2].
+ *   dr4sr_sasrec_fwd_bwd_phase(plan, prepared, 1, stream)   everything up to and including the launch that makes bucket 0 final
+ *       (prepared = 0: runs its own prep like dr4sr_sasrec_fwd_bwd; != 0: on a batch prepared by dr4sr_adam_step_prepare_next);
+ *   dr4sr_sasrec_fwd_bwd_phase(plan, prepared, 2, stream)   the remaining weight-gradient launch (nothing when there is one bucket).
+ * Caller:  phase 1 ; all-reduce(bucket 0) on a side stream ; phase 2 ; all-reduce(bucket 1) ; join ; dr4sr_adam_step[_prepare_next].
+ * Phase 1 + phase 2 leave exactly what dr4sr_sasrec_fwd_bwd[_prepared] leaves (same kernels, same jobs, cut into two launches). */
+int dr4sr_sasrec_grad_buckets(const dr4sr_sasrec_plan* plan, int64_t* bounds /* [3] or NULL */);
+int dr4sr_sasrec_fwd_bwd_phase(const dr4sr_sasrec_plan* plan, int32_t prepared, int32_t phase, void* stream);
 
 /* SASRecQueryEncoder.forward + SeqPoolingLayer (sasrec.py:39-75, layers.py:41-50/:69-73).
  * training != 0 applies dropout (RNG step = state[RNGSTEP]) and keeps activations in the

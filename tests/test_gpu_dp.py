@@ -1,0 +1,181 @@
+"""Round-5 data-parallel tests (VERDICT r4 "Next round" item 1): the two-bucket step and the rank counts that will really run.
+
+  * dr4sr_sasrec_fwd_bwd_phase (ABI 7): phase 1 + phase 2 leave exactly what dr4sr_sasrec_fwd_bwd leaves — the item-table bucket
+    bit for bit (owner-computed rows: no atomics), the encoder bucket to fp32 summation order; one bucket in the latency forms;
+  * bucketed == flat == single rank over the PRODUCT's reduction path (parallel.grad_buckets / dp_backward) with 2 and 8 gloo ranks
+    sharing the GPU: 32 rows per rank at B = 256 (d = 64 and BASELINE configs[3]'s d = 128), a 212-row tail batch whose slices are uneven
+    and EMPTY, and at-scale per-rank batches where the step has two buckets (tools/dp_check.py);
+  * the two-bucket step with its two RCCL all-reduces captured inside a k-step graph (one RCCL rank — all a 1-GPU box can host): the
+    table bucket's collective is a parallel branch of the graph beside the last weight-gradient launch (tools/dp_graph_check.py);
+  * MetaModel's outer step on 8 ranks (12 and 11-or-12 rows per rank) == single rank (tools/dp_meta_check.py);
+  * `python bench.py --gpus 8` on a shared GPU (gloo).
+
+The reference has no distributed path (/root/reference/utils/callbacks.py:130 is its TODO); the contract is SURVEY.md section 8(e)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _engine(B, D=64, seed=3):
+    from test_gpu_parity import _random_params
+    from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
+    from dr4sr_amd.engine import SasrecEngine
+    dev = torch.device("cuda", 0)
+    L, N = 50, TOYS_N_ITEMS
+    rows = make_rows(n_rows=B, n_items=N, seed=17)
+    data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
+    negs = torch.randint(1, N, (B, L), generator=torch.Generator().manual_seed(8)).to(dev)
+    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, 0.3, B, dev, seed=seed, lr=1e-3)
+    eng.load_named(_random_params(N, D, 128, 2, seed=6))
+    plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], neg_item=negs, sample_neg=False)
+    return eng, plan, data
+
+
+def _grads_of(eng, run):
+    eng.state[3] = 7                                        # same dropout stream for every form (state[RNGSTEP] is bumped by the prep)
+    run()
+    torch.cuda.synchronize()
+    return eng.grads.clone()
+
+
+@pytest.mark.parametrize("split", [None, "2", "1"])
+def test_two_phase_step_equals_one_launch_step_at_scale(monkeypatch, split):
+    """B = 4 096 toys-shaped rows (22 k tokens: the at-scale forms): two buckets, bounds = [0, offsets[2]) | [offsets[2], n + tail);
+    phase 1 + phase 2 == dr4sr_sasrec_fwd_bwd.  split: DR4SR_DP_SPLIT_LAYER (None = default 1: table jobs + layer 1's weight gradients
+    first; 2 = a table-only first launch)"""
+    from dr4sr_amd import _lib
+    if split is not None:
+        monkeypatch.setenv("DR4SR_DP_SPLIT_LAYER", split)
+    eng, plan, _ = _engine(4096)
+    assert int(eng.lib.dr4sr_sasrec_at_scale(_lib.C.byref(plan))) & 1
+    b = eng.grad_buckets(plan)
+    n = eng.n_params
+    assert b == [(0, eng.offsets[2]), (eng.offsets[2], n + _lib.GRAD_TAIL)], b
+    g_one = _grads_of(eng, lambda: eng.fwd_bwd(plan))
+    # the caller's view between the phases: the table bucket is FINAL after phase 1 (that is what lets its all-reduce start there)
+    mid = {}
+
+    def two():
+        eng.fwd_bwd_phase(plan, False, 1)
+        torch.cuda.synchronize()
+        mid["table"] = eng.grads[:b[0][1]].clone()
+        mid["tail"] = eng.grads[n:n + 2].clone()
+        eng.fwd_bwd_phase(plan, False, 2)
+    g_two = _grads_of(eng, two)
+    assert torch.equal(mid["table"], g_two[:b[0][1]])                        # nothing touches the table bucket after phase 1
+    assert torch.equal(g_one[:eng.offsets[1]], g_two[:eng.offsets[1]])      # item table: owner-computed, bit-reproducible
+    assert float(mid["tail"].abs().max()) == 0.0 and float(g_two[n]) > 0     # {n_valid, loss_sum} arrive with the encoder bucket
+    scale = float(g_one.abs().max())
+    assert float((g_one - g_two).abs().max()) <= 1e-6 * scale, float((g_one - g_two).abs().max()) / scale
+    assert float(g_one[n]) == float(g_two[n]) and abs(float(g_one[n + 1]) - float(g_two[n + 1])) <= 1e-6 * abs(float(g_one[n + 1]))
+
+
+def test_two_phase_step_is_the_whole_step_in_the_latency_forms():
+    """B = 256: one bucket; phase 1 runs the whole step, phase 2 nothing — what a rank with a short slice does under a two-bucket decision
+    taken from the full slice size (parallel.grad_buckets: the count must be equal on every rank)"""
+    from dr4sr_amd import _lib
+    eng, plan, data = _engine(256)
+    n = eng.n_params
+    assert eng.grad_buckets(plan) == [(0, n + _lib.GRAD_TAIL)]
+    g_one = _grads_of(eng, lambda: eng.fwd_bwd(plan))
+    g_p1 = _grads_of(eng, lambda: eng.fwd_bwd_phase(plan, False, 1))
+    before = g_p1.clone()
+    eng.fwd_bwd_phase(plan, False, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(before, eng.grads)
+    scale = float(g_one.abs().max())
+    assert float((g_one - g_p1).abs().max()) <= 2e-5 * scale                 # fp32 atomics order (table gradient of the latency forms)
+    # the probe the model decides with: a full slice of 4 096 rows of this dataset -> two buckets, whatever this plan's own size
+    from dr4sr_amd import parallel
+    assert len(parallel.grad_buckets(eng, 4096, data["seqlen"])) == 2 and len(parallel.grad_buckets(eng, 256, data["seqlen"])) == 1
+    assert len(parallel.grad_buckets(eng, None, data["seqlen"])) == 1
+
+
+def _run(cmd, env, timeout=900):
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, MASTER_ADDR="127.0.0.1", **env), cwd=ROOT)
+    return out
+
+
+@pytest.mark.parametrize("W,D,B,U,expect", [
+    (8, 64, 256, 980, "[1]"),            # 32 rows per rank; tail batch 212 rows -> slices 32 x 6, 20, EMPTY
+    (8, 128, 256, 980, "[1]"),           # BASELINE configs[3]'s width
+    (2, 64, 6144, 13288, "[1, 2]"),      # 3 072 rows per rank: at scale -> two buckets on the full batches, flat on the 1 000-row tail
+    (8, 64, 24576, 27576, "[1, 2]"),     # 8 ranks x 3 072 rows, two buckets; tail 3 000 rows -> rank 0 only, seven EMPTY slices
+])
+def test_data_parallel_ranks_equal_single_rank_wide(W, D, B, U, expect):
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(W), "--master-addr", "127.0.0.1",
+                "--master-port", str(29600 + W + D // 64 + B % 97), os.path.join(ROOT, "tools", "dp_check.py")],
+               {"DP_D": str(D), "DP_B": str(B), "DP_U": str(U), "DR4SR_DP_BACKEND": "gloo"})
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CHECK")]
+    assert out.returncode == 0 and len(lines) == 2, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "buckets=" + expect in lines[0], lines[0]
+    assert "replica checksums equal: True" in lines[1]
+    if W == 8:
+        assert "empty slices seen: 0" not in lines[1], lines[1]
+    print(lines[0])
+
+
+@pytest.mark.parametrize("B,buckets", [(8192, 2), (1536, 1)])
+def test_rccl_buckets_inside_k_step_graph(B, buckets):
+    """one RCCL rank: k DP steps per graph, each with its collective(s) captured — at B = 8 192 the table bucket's all-reduce is issued
+    asynchronously after phase 1 and joined before the optimizer (a parallel branch of the graph), the optimizer launches prepare the
+    next batch in two phases — against the un-captured single-GPU loop; B = 1 536 (8.4 k tokens: latency forms above the old 1 024-row limit of the
+    prepared form): one flat bucket"""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(29660 + buckets), os.path.join(ROOT, "tools", "dp_graph_check.py")],
+               {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "DP_GRAPH_B": str(B), "DP_GRAPH_REPLAYS": "6", "DP_GRAPH_K": "3",
+                "DP_GRAPH_EXPECT_BUCKETS": str(buckets)})
+    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    print([l for l in out.stdout.splitlines() if l.startswith("DP_GRAPH ")][0])
+
+
+@pytest.mark.parametrize("B", [96, 90])
+def test_metamodel_outer_step_eight_ranks_equal_single_rank(B):
+    """BASELINE configs[4] is an 8-GPU configuration: the outer step's all-reduces on 8 ranks (12 rows per rank; B = 90: 12 x 7 + 6)"""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                "--master-port", str(29680 + B % 7), os.path.join(ROOT, "tools", "dp_meta_check.py")],
+               {"DR4SR_DP_BACKEND": "gloo", "DP_META_B": str(B)})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("DP_META")]
+    assert line and "world=8" in line[0] and "replicas identical: True" in line[0], out.stdout[-2000:]
+    print(line[0])
+
+
+@pytest.mark.parametrize("model_name", ["SASRec-d128", "MetaModel"])
+def test_data_parallel_fit_eight_ranks(tmp_path, model_name):
+    """quickstart.run under 8 ranks sharing the GPU (gloo): batch 128 -> 16 rows per rank, the 13-row tail batch leaves seven ranks
+    EMPTY; replicas bit-identical, one checkpoint stem (tools/dp_fit_check.py)"""
+    extra = {}
+    if model_name == "SASRec-d128":
+        model_name, extra = "SASRec", {"DR4SR_EMBED_DIM": "128"}
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                "--master-port", "29691", os.path.join(ROOT, "tools", "dp_fit_check.py")],
+               dict(DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path), MODEL=model_name, **extra))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT ")]
+    err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.returncode == 0 and len(lines) == 1, err
+    assert "world=8" in lines[0] and "replicas identical: True; finite: True" in lines[0] and "one ckpt stem: True" in lines[0], lines[0]
+
+
+def test_bench_self_launches_eight_ranks_on_a_shared_gpu():
+    """`python bench.py --gpus 8` (the driver's widest command) on ONE GPU over gloo: every rank takes the data-parallel step, the
+    strong-scaling entry splits 16 384 rows into 2 048 per rank; one JSON line from rank 0"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--repeats", "2",
+                          "--no-throughput-mode", "--strong-global-batch", "16384"], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, DR4SR_BENCH_SHARE_GPU="1", DR4SR_DP_BACKEND="gloo"), cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 2048 and j["config"]["parallelism"] == "dp8"
+    assert "gloo" in j["config"]["collective"] and j["value"] > 0 and j["final_loss"] == j["final_loss"]
+    st = j["strong"][0]
+    assert st["global_batch"] == 16384 and st["per_gpu_batch"] == 2048 and st["n_gpus"] == 8 and st["speedup"] > 0

@@ -396,3 +396,84 @@ def test_torch_ops_are_registered_with_schemas_and_fake_kernels():
         assert sc.shape == (8, 20) and it.dtype == torch.int64
     with pytest.raises(Dr4srError):
         torch.ops.dr4sr_hip.embed_gather_posadd(torch.zeros(10, 64), torch.zeros(50, 64), torch.zeros(2, 50, dtype=torch.int64))
+
+
+class _FakeEngine:
+    """the slice of the engine protocol parallel.dp_backward drives, on CPU tensors: the `gradient` of a rank is a deterministic function of
+    its slice of the global batch, phase 1 fills the table bucket, phase 2 the encoder bucket + tail (a short / empty-regime plan fills
+    everything in phase 1, like a latency-form plan under a two-bucket decision)"""
+    def __init__(self, n, split, two_phase_plan=True):
+        self.grads = torch.zeros(n + 4)
+        self.n, self.split, self.two = n, split, two_phase_plan
+        self.calls = []
+
+    def _contrib(self, plan, lo, hi):
+        g = torch.Generator().manual_seed(1234)
+        base = torch.randn(self.n + 4, generator=g)
+        for r in plan:                                       # plan = the global row ids of this rank's slice
+            self.grads[lo:hi] += base[lo:hi] * float(r + 1)
+
+    def fwd_bwd(self, plan):
+        self.calls.append("flat")
+        self.grads.zero_()
+        self._contrib(plan, 0, self.n + 4)
+    fwd_bwd_prepared = fwd_bwd
+
+    def fwd_bwd_phase(self, plan, prepared, phase):
+        self.calls.append("p%d" % phase)
+        if phase == 1:
+            self.grads.zero_()
+            self._contrib(plan, 0, self.split if self.two else self.n + 4)
+        elif self.two:
+            self._contrib(plan, self.split, self.n + 4)
+
+
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from dr4sr_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n, split, B, U = 1000, 700, 20, 43                       # global batches of 20 rows over 43 rows: tail batch of 3 -> empty slices at 8 ranks
+    res = []
+    for i in range(3):
+        lo, hi = parallel.shard_bounds(i, B, U, world, rank)
+        plan = list(range(lo, hi))
+        full = (i + 1) * B <= U
+        buckets = [(0, split), (split, n + 4)] if full else None       # the decision is global: flat on the partial tail batch
+        # rank 1's own plan is a "latency form" plan (everything final after phase 1) although the global decision is two buckets
+        eng = _FakeEngine(n, split, two_phase_plan=(rank != 1))
+        if plan:
+            parallel.dp_backward(eng, plan, False, buckets)
+        else:                                                # (at 8 ranks also on the FULL batches: 20 rows = 3 x 6 + 2 + 0)
+            parallel.dp_reduce_empty(eng, buckets)
+        flat = _FakeEngine(n, split)
+        flat.fwd_bwd(plan)
+        parallel.allreduce_flat(flat.grads)
+        res.append((eng.grads.clone(), flat.grads.clone(), list(eng.calls), len(plan)))
+    if rank == 0:
+        q.put([(a.numpy(), b.numpy(), c, d) for a, b, c, d in res])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bucketed_allreduce_equals_flat_gloo(world):
+    """parallel.dp_backward: phase 1 -> async all-reduce(table bucket) -> phase 2 -> async all-reduce(encoder bucket + tail) -> join
+    == one flat all-reduce == the single-rank gradient, with 2 and 8 gloo ranks, a rank whose own plan has one phase, and a tail batch
+    that leaves ranks empty (they contribute zeros to a flat all-reduce — every rank enters the same collectives)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for i, (bucketed, flat, calls, nrows) in enumerate(res):
+        np.testing.assert_allclose(bucketed, flat, rtol=1e-6, atol=1e-6)
+        one = _FakeEngine(1000, 700)
+        one.fwd_bwd(list(range(i * 20, min(43, (i + 1) * 20))))         # the single-rank gradient of the whole global batch
+        np.testing.assert_allclose(bucketed, one.grads.numpy(), rtol=1e-5, atol=1e-4)
+        assert calls == ((["p1", "p2"] if i < 2 else ["flat"]) if nrows else [])

@@ -20,7 +20,9 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 parallel.init_distributed(dev)
 assert dist.get_backend() == "nccl" and parallel.can_capture()
-U, B, L, N, K, REPLAYS = 19412, 256, 50, TOYS_N_ITEMS, int(os.environ.get("DP_GRAPH_K", "4")), int(os.environ.get("DP_GRAPH_REPLAYS", "30"))
+# DP_GRAPH_B=8192: the at-scale launch forms -> TWO gradient buckets (parallel.dp_backward: the table bucket's all-reduce is a parallel
+# branch of the captured graph beside the last weight-gradient launch), optimizer launches with the two-phase prep
+U, B, L, N, K, REPLAYS = 19412, int(os.environ.get("DP_GRAPH_B", "256")), 50, TOYS_N_ITEMS, int(os.environ.get("DP_GRAPH_K", "4")), int(os.environ.get("DP_GRAPH_REPLAYS", "30"))
 rows = make_rows(n_rows=U, n_items=N, seed=21)
 data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
 perm = torch.from_numpy(np.random.default_rng(9).permutation(U)).to(dev)
@@ -48,13 +50,22 @@ for _ in range(steps):
 torch.cuda.synchronize()
 # ---- captured: k DP steps + their k RCCL all-reduces in ONE graph
 eng1, plan1, c1, log1 = make()
+buckets = parallel.grad_buckets(eng1, B, data["seqlen"])
+if os.environ.get("DP_GRAPH_EXPECT_BUCKETS"):
+    assert len(buckets) == int(os.environ["DP_GRAPH_EXPECT_BUCKETS"]), buckets
 stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
+    for j in range(2):                                        # warm-up outside the capture (code objects, LDS attributes), then undo it
+        snap = [t.clone() for t in (eng1.params, eng1.adam_m, eng1.adam_v, eng1.state, c1)]
+        parallel.dp_backward(eng1, plan1, False, buckets)
+        eng1.adam_step(plan1)
+        stream.synchronize()
+        for dst, src in zip((eng1.params, eng1.adam_m, eng1.adam_v, eng1.state, c1), snap):
+            dst.copy_(src)
     g = torch.cuda.CUDAGraph()
     with capture(g, stream=stream):
         for j in range(K):
-            (eng1.fwd_bwd_prepared if j > 0 else eng1.fwd_bwd)(plan1)
-            parallel.allreduce_flat(eng1.grads)
+            parallel.dp_backward(eng1, plan1, j > 0, buckets)
             (eng1.adam_step_prepare_next if j < K - 1 else eng1.adam_step)(plan1)
     for _ in range(REPLAYS):
         g.replay()
@@ -64,8 +75,8 @@ assert int(c0) == steps and int(c1) == steps and int(eng1.state[0]) == steps, (i
 d_first = float((log0[:10] - log1[:10]).abs().max())
 d_all = float(((log0 - log1).abs() / log0.abs()).max())
 dp = float((eng0.params - eng1.params).abs().max())
-print("DP_GRAPH rccl in-graph all-reduce: %d steps = %d replays x %d steps/graph; loss log max abs diff first 10 steps %.2e, max rel diff all %.2e, "
-      "final params max abs diff %.2e (|param| max %.3f), loss %.4f -> %.4f" % (steps, REPLAYS, K, d_first, d_all, dp, float(eng0.params.abs().max()),
+print("DP_GRAPH rccl in-graph all-reduce (B = %d, %d bucket(s)): %d steps = %d replays x %d steps/graph; loss log max abs diff first 10 steps %.2e, max rel diff all %.2e, "
+      "final params max abs diff %.2e (|param| max %.3f), loss %.4f -> %.4f" % (B, len(buckets), steps, REPLAYS, K, d_first, d_all, dp, float(eng0.params.abs().max()),
                                                                                  float(log1[0]), float(log1[-1])))
 assert d_first < 2e-5 and d_all < 5e-3 and dp < 5e-3 and float(log1[-1]) < float(log1[0])
 print("DP_GRAPH_OK")

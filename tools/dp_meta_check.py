@@ -22,7 +22,7 @@ cfg = load_config({"model": "MetaModel", "dataset": "synthetic-toys"})
 cfg["data"].update({"n_items": 500, "n_rows": 600, "n_eval_rows": 64, "seed": 5})
 cfg["model"]["sub_model"] = "SASRec"
 cfg["model"]["sub_overrides"] = {"model": {"dropout_rate": 0.0}}
-B = 96
+B = int(os.environ.get("DP_META_B", "96"))                 # 8 ranks: 12 rows per rank; 90 -> 12 x 7 + 6 (uneven slices)
 cfg["train"].update({"batch_size": B, "device": "cuda:0", "interval": 4, "warmup_epoch": -1})
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
