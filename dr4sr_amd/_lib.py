@@ -205,6 +205,8 @@ SYMBOLS = {
     "dr4sr_fd_diff": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
     "dr4sr_fd_diff4": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_void_p]),
     "dr4sr_scale_by": (C.c_int, [_f32p, _f32p, _f32p, C.c_int64, C.c_void_p]),
+    "dr4sr_meta_opt_step": (C.c_int, [C.c_int32, _f32p, _f32p, _f32p, _f32p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_void_p, _f32p, C.c_void_p]),
     "dr4sr_meta_sgd_step": (C.c_int, [_f32p, _f32p, _f32p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                       _f32p, C.c_void_p]),
     "dr4sr_cl_augment": (C.c_int, [_i64p, _i64p, _i64p, _i64p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,

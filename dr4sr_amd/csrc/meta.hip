@@ -317,6 +317,49 @@ __global__ __launch_bounds__(1024) void k_meta_sgd(float* __restrict__ phi, cons
     if (threadIdx.x == 0) { step_count[0] += 1; if (out_norm) out_norm[0] = total; }
 }
 
+// The reference's other meta-optimizer choices (metamodel.py:59-81) behind the same clip_grad_norm_: torch.optim.Adam(lr[, weight_decay
+// in the else branch]), Adagrad(lr), RMSprop(lr) with torch's defaults (the formulas of k_adam<OPT> in step.hip: single-tensor Adam
+// with double-precision bias corrections; Adagrad eps 1e-10, accumulator 0; RMSprop alpha 0.99, eps 1e-8, no momentum, not centered).
+// kind = DR4SR_OPT_*; m / v = the optimizer's state vectors (exp_avg | exp_avg_sq / state_sum / square_avg); step_count = t - 1.
+__global__ __launch_bounds__(1024) void k_meta_opt(int kind, float* __restrict__ phi, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float wd,
+                                                  float max_norm, int* __restrict__ step_count, float* __restrict__ out_norm) {
+    __shared__ float sm[16];
+    __shared__ float bc[2];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s = fmaf(g[i], g[i], s);
+    const float total = sqrtf(block_sum(s, sm));
+    const float coef = max_norm > 0.f ? fminf(max_norm / (total + 1e-6f), 1.0f) : 1.0f;
+    const int t = step_count[0] + 1;
+    if (threadIdx.x == 0) {
+        bc[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+        bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+    }
+    __syncthreads();
+    const float step_size = bc[0], inv_sqrt_bc2 = bc[1];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float pe = phi[i];
+        const float gi = fmaf(wd, pe, g[i] * coef);
+        if (kind == DR4SR_OPT_ADAGRAD) {
+            const float ve = v[i] + gi * gi;
+            v[i] = ve;
+            pe = pe - lr * (gi / (sqrtf(ve) + eps));
+        } else if (kind == DR4SR_OPT_RMSPROP) {
+            const float ve = v[i] * b2 + (1.0f - b2) * gi * gi;
+            v[i] = ve;
+            pe = pe - lr * (gi / (sqrtf(ve) + eps));
+        } else {
+            const float me = m[i] + (gi - m[i]) * (1.0f - b1);
+            const float ve = v[i] * b2 + (1.0f - b2) * gi * gi;
+            m[i] = me; v[i] = ve;
+            pe = pe - step_size * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
+        }
+        phi[i] = pe;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { step_count[0] = t; if (out_norm) out_norm[0] = total; }
+}
+
 int sel_grid(int64_t n) {
     int64_t g = (n + SEL_WAVES * 8 - 1) / (SEL_WAVES * 8);
     return (int)(g < 1 ? 1 : g > 128 ? 128 : g);
@@ -413,6 +456,16 @@ extern "C" int dr4sr_fd_diff4(float* out, const float* fp1, const float* fm1, co
 extern "C" int dr4sr_scale_by(float* out, const float* x, const float* den, int64_t n, void* stream) {
     if (!out || !x || !den || n <= 0) return DR4SR_E_ARG;
     hipLaunchKernelGGL(k_scale_by, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x, den, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dr4sr_meta_opt_step(int32_t optimizer, float* phi, const float* grad, float* state_m, float* state_v, int32_t n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, float max_norm, int32_t* step_count,
+                                   float* out_norm, void* stream) {
+    if (!phi || !grad || !state_m || !state_v || !step_count || n <= 0) return DR4SR_E_ARG;
+    if (optimizer != DR4SR_OPT_ADAM && optimizer != DR4SR_OPT_ADAGRAD && optimizer != DR4SR_OPT_RMSPROP) return DR4SR_E_ARG;   // SGD: dr4sr_meta_sgd_step
+    hipLaunchKernelGGL(k_meta_opt, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)optimizer, phi, grad, state_m, state_v, n, lr, beta1,
+                       beta2, eps, weight_decay, max_norm, step_count, out_norm);
     return (int)hipGetLastError();
 }
 

@@ -78,13 +78,26 @@ class _Select(torch.autograd.Function):
 
 
 class MetaOptimizer:
-    """utils/utils.py:207-255 facade: clip_grad_norm_(10) + the reference's default meta optimizer (SGD momentum 0.9)"""
+    """utils/utils.py:207-255 facade: clip_grad_norm_(10) + the meta optimizer MetaModel._get_meta_optimizers chose
+    (metamodel.py:59-81): 'sgd' = SGD(lr, weight_decay, momentum 0.9) — configs/metamodel.yaml's — through dr4sr_meta_sgd_step; 'adam' =
+    Adam(lr), 'adagrad' = Adagrad(lr), 'rmsprop' = RMSprop(lr), any other name = Adam(lr, weight_decay) through dr4sr_meta_opt_step;
+    'sparse_adam' = torch.optim.SparseAdam, which raises on the dense hyper-gradient in the reference's first outer step — raised here
+    when the optimizer is built."""
 
-    def __init__(self, model, lr, hpo_lr, weight_decay, truncate_iter=3, max_grad_norm=10.0):
-        self.model, self.lr, self.hpo_lr, self.weight_decay = model, lr, hpo_lr, weight_decay
+    def __init__(self, model, lr, hpo_lr, weight_decay, truncate_iter=3, max_grad_norm=10.0, name="sgd"):
+        self.model, self.lr, self.hpo_lr = model, lr, hpo_lr
         self.truncate_iter, self.max_grad_norm, self.momentum = truncate_iter, max_grad_norm, 0.9
+        n = str(name).lower()
+        if n == "sparse_adam":
+            raise RuntimeError("SparseAdam does not support dense gradients, please consider Adam instead")
+        self.kind = {"sgd": _lib.OPT_SGD, "adam": _lib.OPT_ADAM, "adagrad": _lib.OPT_ADAGRAD, "rmsprop": _lib.OPT_RMSPROP}.get(n, _lib.OPT_ADAM)
+        # only SGD and the else branch pass meta_weight_decay to torch (metamodel.py:68-69, :77)
+        self.weight_decay = weight_decay if (n == "sgd" or n not in ("adam", "adagrad", "rmsprop")) else 0.0
+        self.betas = (0.9, 0.99) if self.kind == _lib.OPT_RMSPROP else (0.9, 0.999)
+        self.eps = 1e-10 if self.kind == _lib.OPT_ADAGRAD else 1e-8
         dev = model._phi.params.device
-        self.momentum_buf = torch.zeros_like(model._phi.params)
+        self.momentum_buf = torch.zeros_like(model._phi.params)          # SGD: momentum buffer; Adam: exp_avg
+        self.second_buf = torch.zeros_like(model._phi.params)            # exp_avg_sq / state_sum / square_avg
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
 
@@ -93,11 +106,17 @@ class MetaOptimizer:
 
     def step_with(self, hyper_grad: torch.Tensor):
         phi = self.model._phi
-        _lib.check(self.model.lib.dr4sr_meta_sgd_step(_lib.ptr(phi.params), _lib.ptr(hyper_grad), _lib.ptr(self.momentum_buf), phi.n,
-                                                      self.lr, self.momentum, self.weight_decay,
-                                                      self.max_grad_norm if self.max_grad_norm is not None else 0.0,
-                                                      _lib.ptr(self.step_count), _lib.ptr(self.last_grad_norm), _lib.cur_stream()),
-                   "dr4sr_meta_sgd_step")
+        max_norm = self.max_grad_norm if self.max_grad_norm is not None else 0.0
+        if self.kind == _lib.OPT_SGD:
+            _lib.check(self.model.lib.dr4sr_meta_sgd_step(_lib.ptr(phi.params), _lib.ptr(hyper_grad), _lib.ptr(self.momentum_buf), phi.n,
+                                                          self.lr, self.momentum, self.weight_decay, max_norm,
+                                                          _lib.ptr(self.step_count), _lib.ptr(self.last_grad_norm), _lib.cur_stream()),
+                       "dr4sr_meta_sgd_step")
+        else:
+            _lib.check(self.model.lib.dr4sr_meta_opt_step(self.kind, _lib.ptr(phi.params), _lib.ptr(hyper_grad), _lib.ptr(self.momentum_buf),
+                                                          _lib.ptr(self.second_buf), phi.n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                          self.weight_decay, max_norm, _lib.ptr(self.step_count),
+                                                          _lib.ptr(self.last_grad_norm), _lib.cur_stream()), "dr4sr_meta_opt_step")
 
 
 class MetaModel(BaseModel):
@@ -167,9 +186,8 @@ class MetaModel(BaseModel):
 
     def _get_meta_optimizers(self):
         tc = self.config["train"]
-        if tc["meta_optimizer"].lower() != "sgd":
-            raise NotImplementedError("meta_optimizer: the HIP path implements configs/metamodel.yaml's SGD(momentum 0.9) only")
-        return MetaOptimizer(self, float(tc["meta_learning_rate"]), float(tc["hpo_learning_rate"]), float(tc["meta_weight_decay"]))
+        return MetaOptimizer(self, float(tc["meta_learning_rate"]), float(tc["hpo_learning_rate"]), float(tc["meta_weight_decay"]),
+                             name=tc["meta_optimizer"])
 
     def forward(self, batch):
         return self.sub_model.forward(batch)

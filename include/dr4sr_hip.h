@@ -464,6 +464,15 @@ int dr4sr_scale_by(float* out, const float* x, const float* den, int64_t n, void
  * step_count (device int32) selects the first-step momentum initialisation and is incremented; out_norm (NULL ok) = |grad|. */
 int dr4sr_meta_sgd_step(float* phi, const float* grad, float* momentum_buf, int32_t n, float lr, float momentum,
                         float weight_decay, float max_norm, int32_t* step_count, float* out_norm, void* stream);
+/* ABI 7 — the same tail for the reference's other `meta_optimizer` choices (metamodel.py:59-81): optimizer = DR4SR_OPT_ADAM
+ * ('adam': torch.optim.Adam(lr), weight_decay 0; any unknown name: Adam(lr, weight_decay = meta_weight_decay)), DR4SR_OPT_ADAGRAD
+ * (Adagrad(lr): eps 1e-10, state_v = state_sum), DR4SR_OPT_RMSPROP (RMSprop(lr): beta2 = alpha 0.99, eps 1e-8, state_v = square_avg);
+ * state_m / state_v [n] zero-initialised by the caller; step_count = steps taken so far (bias corrections use step_count + 1).
+ * `tau` sits in the reference's parameter list but never receives a gradient (it is not in aux_params, metamodel.py:142), so torch
+ * skips it: nothing to step.  'sparse_adam' raises in the reference's first step (dense gradients) — the binding raises the same error. */
+int dr4sr_meta_opt_step(int32_t optimizer, float* phi, const float* grad, float* state_m, float* state_v, int32_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, float max_norm, int32_t* step_count,
+                        float* out_norm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CL4SRec (model/cl4srec.py, module/data_augmentation.py:20-95,:305-350,:577-619): two augmented views of every sequence are

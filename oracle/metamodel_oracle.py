@@ -197,3 +197,21 @@ def sgd_momentum_step(params, grads, bufs, lr, momentum=0.9, weight_decay=0.0):
         out_p.append(p - lr * b)
         out_b.append(b)
     return out_p, out_b
+
+
+def meta_optimizer_step(name: str, params, grads, state, lr: float, meta_weight_decay: float, max_norm: float = 10.0):
+    """MetaOptimizer.step's tail (utils/utils.py:242-250) for the optimizer MetaModel._get_meta_optimizers builds from `meta_optimizer`
+    (/root/reference/model/metamodel.py:59-81): clip_grad_norm_(max_norm) over the meta module's gradients, then
+      'adam' -> Adam(lr) | 'sgd' -> SGD(lr, weight_decay, momentum 0.9) | 'adagrad' -> Adagrad(lr) | 'rmsprop' -> RMSprop(lr)
+      | any other name -> Adam(lr, weight_decay).
+    The optimizers' arithmetic is optim_oracle's (pinned on torch.optim); state = {} on the first call.  Returns the new parameters."""
+    from . import optim_oracle as OO
+    n = name.lower()
+    grads, _ = clip_grad_norm_(grads, max_norm)
+    if n == "sgd":
+        new, state["bufs"] = sgd_momentum_step(params, grads, state.get("bufs", [None] * len(params)), lr, 0.9, meta_weight_decay)
+        return new
+    kind = n if n in ("adam", "adagrad", "rmsprop") else "adam"
+    wd = 0.0 if n in ("adam", "adagrad", "rmsprop") else meta_weight_decay
+    sts = state.setdefault("per_param", [OO.init_state(p) for p in params])
+    return [OO.step(kind, p, g, st, lr, wd) for p, g, st in zip(params, grads, sts)]

@@ -341,3 +341,38 @@ def test_fused_weighted_step_at_scale_matches_dense_path(monkeypatch, at_scale):
     m._fused_weighted(bt)
     nE = e.n_items * e.D
     assert torch.equal(e.grads[:nE], g_fused[:nE])
+
+
+@pytest.mark.parametrize("name", ["adam", "adagrad", "rmsprop", "lamb", "sgd"])
+def test_meta_optimizer_choices_match_reference(golden_dir, name):
+    """round 5, /root/reference/model/metamodel.py:59-81: every `meta_optimizer` choice through the product's MetaOptimizer
+    (dr4sr_meta_opt_step / dr4sr_meta_sgd_step: clip_grad_norm_(10) + the optimizer step on the flat meta parameters) against the reference's
+    own MetaOptimizer.step run with that choice (tests/golden/metamodel_optimizers.npz: three fixed hyper-gradients, the second clipped)"""
+    from dr4sr_amd import _lib
+    from dr4sr_amd.model.metamodel import MetaOptimizer, _PhiStore
+    g = np.load(os.path.join(golden_dir, "metamodel_optimizers.npz"))
+    dev = torch.device("cuda", 0)
+
+    class Holder:                                                   # what MetaOptimizer reads of a MetaModel
+        lib = _lib.load()
+    Holder._phi = _PhiStore(Holder.lib, 64, dev)
+    names = list(Holder._phi.views)
+    for k in names:
+        Holder._phi.views[k].copy_(torch.from_numpy(g["phi0." + k]))
+    mo = MetaOptimizer(Holder, float(g["meta.meta_learning_rate"]), float(g["meta.hpo_learning_rate"]), float(g["meta.meta_weight_decay"]), name=name)
+    for s in (1, 2, 3):
+        hg = torch.cat([torch.from_numpy(g[f"grad{s}.{k}"]).reshape(-1) for k in names]).to(dev)
+        mo.step_with(hg)
+        torch.cuda.synchronize()
+        assert abs(float(mo.last_grad_norm) - float(g[f"grad{s}.norm"])) < 1e-4 * float(g[f"grad{s}.norm"])
+        for k in names:
+            np.testing.assert_allclose(Holder._phi.views[k].cpu().numpy(), g[f"{name}.step{s}.{k}"], rtol=2e-5, atol=3e-7)
+    assert int(mo.step_count) == 3
+
+
+def test_meta_optimizer_sparse_adam_raises_like_the_reference(golden_dir):
+    from dr4sr_amd.model.metamodel import MetaOptimizer
+    g = np.load(os.path.join(golden_dir, "metamodel_optimizers.npz"))
+    with pytest.raises(RuntimeError) as e:
+        MetaOptimizer(None, 1e-3, 1e-3, 0.0, name="sparse_adam")
+    assert str(e.value) in str(g["sparse_adam.error"])

@@ -125,3 +125,21 @@ def test_cl4srec_sub_model_weighted_step_and_hypergradient(golden_dir):
     err = rel(flat({k: v.numpy() for k, v in hf.items()}), ref)
     print("CL4SRec sub-model: first-order hyper-gradient rel err", err)
     assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("name", ["adam", "adagrad", "rmsprop", "lamb", "sgd"])
+def test_meta_optimizer_choices_match_reference(golden_dir, name):
+    """metamodel.py:59-81: the oracle's restatement of every `meta_optimizer` choice against the reference's own MetaOptimizer.step run
+    with that choice on three fixed hyper-gradients, the second one clipped (tests/golden/metamodel_optimizers.npz,
+    tools/make_golden.py run_meta_optimizer_case); 'lamb' = an unknown name = the else branch, Adam WITH meta_weight_decay"""
+    g = np.load(os.path.join(golden_dir, "metamodel_optimizers.npz"))
+    assert str(g[name + ".torch_class"]) == {"adam": "Adam", "adagrad": "Adagrad", "rmsprop": "RMSprop", "lamb": "Adam", "sgd": "SGD"}[name]
+    assert float(g["grad2.norm"]) > 10.0 > float(g["grad1.norm"])
+    P = [torch.from_numpy(g["phi0." + k]) for k in MO.META_NAMES]
+    st = {}
+    for s in (1, 2, 3):
+        grads = [torch.from_numpy(g[f"grad{s}.{k}"]) for k in MO.META_NAMES]
+        P = MO.meta_optimizer_step(name, P, grads, st, float(g["meta.meta_learning_rate"]), float(g["meta.meta_weight_decay"]))
+        for k, v in zip(MO.META_NAMES, P):
+            np.testing.assert_allclose(v.numpy(), g[f"{name}.step{s}.{k}"], rtol=1e-5, atol=2e-7)
+    assert "SparseAdam does not support dense gradients" in str(g["sparse_adam.error"])

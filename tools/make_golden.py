@@ -902,6 +902,87 @@ def loss_module_vectors(out_dir):
     print("wrote loss_modules.npz; BPRLoss(reduce=) ->", msg)
 
 
+def run_meta_optimizer_case(out_dir, name="metamodel_optimizers", seed=27):
+    """MetaModel._get_meta_optimizers (metamodel.py:59-81) + MetaOptimizer.step's tail (utils/utils.py:242-250: p.grad = g,
+    clip_grad_norm_(10), meta_optimizer.step()) by RUNNING the reference with `meta_optimizer` = adam / adagrad / rmsprop / an unknown
+    name (its else branch: Adam WITH meta_weight_decay) / sgd: the reference builds its own torch optimizer over meta_module + tau, its
+    own MetaOptimizer.step runs with Hypergrad.grad replaced by three fixed gradient sets (the second one large enough to be clipped);
+    stored: the initial meta parameters, the gradients, the parameters after each step; 'sparse_adam': the error text of its first step."""
+    import torch
+    rng = np.random.default_rng(seed)
+    work = tempfile.mkdtemp(prefix="dr4sr_golden_")
+    cwd = os.getcwd()
+    out = {}
+    try:
+        os.symlink(os.path.join(REF, "configs"), os.path.join(work, "configs"))
+        build_dataset(work, 61, [3, 5, 8, 2], rng)
+        os.chdir(work)
+        import utils as rutils
+        import model.metamodel as mm
+        orig_load = rutils.load_config
+
+        def patched_load(cfg):                       # metamodel.py:41-50 hard-codes device 0 for the sub-model
+            c = orig_load(cfg)
+            c["train"]["device"] = "cpu"
+            c["data"]["train_file"] = "_ori"
+            return c
+        mm.load_config = patched_load
+
+        def register_sub_model(self):                 # metamodel.py:41-50 with the device line dropped
+            sc = patched_load({"dataset": self.config["data"]["dataset"], "model": self.config["model"]["sub_model"]})
+            return rutils.get_model_class(sc["model"])(sc, self.dataset_list)
+        mm.MetaModel._register_sub_model = register_sub_model
+        gen = torch.Generator().manual_seed(seed)
+        grads, phi0 = None, None
+        for opt_name in ("adam", "adagrad", "rmsprop", "lamb", "sgd", "sparse_adam"):
+            config = patched_load({"model": "MetaModel", "dataset": "amazon-toys"})
+            config["model"]["sub_model"] = "SASRec"
+            config["train"]["meta_optimizer"] = opt_name
+            rutils.setup_environment(config["train"])
+            torch.manual_seed(seed)
+            ds = rutils.prepare_datasets(config)
+            model = rutils.prepare_model(config, ds)
+            model._init_model(ds[0])
+            aux = list(model.meta_module.parameters())
+            names = [n for n, _ in model.meta_module.named_parameters()]
+            if grads is None:
+                phi0 = [p.detach().clone() for p in aux]
+                scales = (0.05, 3.0, 0.2)            # |g| of step 2 is far above max_grad_norm = 10: clipped
+                grads = [[sc * torch.randn(p.shape, generator=gen) for p in aux] for sc in scales]
+                for n, p in zip(names, phi0):
+                    out["phi0." + n] = p.numpy().copy()
+                for k, gs in enumerate(grads):
+                    for n, gg in zip(names, gs):
+                        out[f"grad{k + 1}." + n] = gg.numpy().copy()
+                    out[f"grad{k + 1}.norm"] = np.float64(torch.sqrt(sum((gg.double() ** 2).sum() for gg in gs)))
+                tc = config["train"]
+                for k in ("meta_learning_rate", "hpo_learning_rate", "meta_weight_decay"):
+                    out["meta." + k] = np.float64(tc[k])
+            with torch.no_grad():
+                for p, p0 in zip(aux, phi0):
+                    p.copy_(p0)
+            mo = model.meta_optimizer
+            out[f"{opt_name}.torch_class"] = np.array(type(mo.meta_optimizer).__name__)
+            for k, gs in enumerate(grads):
+                mo.hypergrad.grad = lambda gs=gs, **kw: [gg.clone() for gg in gs]
+                try:
+                    mo.step(train_loss=None, val_loss=None, parameters=None, aux_params=aux)
+                except Exception as e:          # noqa: BLE001 — sparse_adam: torch refuses dense gradients
+                    out[f"{opt_name}.error"] = np.array(f"{type(e).__name__}: {e}")
+                    break
+                for n, p in zip(names, aux):
+                    out[f"{opt_name}.step{k + 1}." + n] = p.detach().numpy().copy()
+            assert float(model.tau.detach()) == 10.0                 # tau is in the optimizer's list but never has a gradient
+        os.chdir(cwd)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); " + ", ".join(
+            f"{k.split('.')[0]}={out[k]}" for k in out if k.endswith("torch_class")) + "; sparse_adam: " + str(out.get("sparse_adam.error")))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -924,6 +1005,9 @@ def main():
         return
     if only == "curve":
         run_curve_case(out_dir)
+        return
+    if only == "meta_opt":
+        run_meta_optimizer_case(out_dir)
         return
     if only == "meta_cl":
         run_meta_case(out_dir, "metamodel_cl4srec", "CL4SRec", n_items=137, seqlens=seqlens, seed=23)
@@ -951,6 +1035,7 @@ def main():
     run_meta_case(out_dir, "metamodel_trained_toys", "SASRec", n_items=None, seqlens=None, seed=22, real=True)
     run_meta_case(out_dir, "metamodel_cl4srec", "CL4SRec", n_items=137, seqlens=seqlens, seed=23)
     run_curve_case(out_dir)
+    run_meta_optimizer_case(out_dir)
 
 
 if __name__ == "__main__":
