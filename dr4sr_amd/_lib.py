@@ -34,6 +34,18 @@ def check_ids(idx, n_items: int, what: str = "index"):
         raise IndexError(f"index out of range in self ({what}: {int(bad)} ids outside [0, {int(n_items)}))")
 
 
+def set_env(name: str, value=None):
+    """set (value=None: unset) a DR4SR_* switch in os.environ AND make the loaded library read it: libdr4sr_hip.so caches every switch
+    per call site until dr4sr_reload_env() bumps its generation (csrc/common.h), so a plain os.environ change after the first call of an
+    entry point would be silently ignored"""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    if _lib is not None:
+        _lib.dr4sr_reload_env()
+
+
 def optimizer_settings(name: str, weight_decay: float):
     """/root/reference model/basemodel.py:79-98 -> (DR4SR_OPT_* kind, (beta1, beta2), eps, weight_decay): each optimizer with torch's
     defaults as the reference constructs it — Adam(lr, weight_decay), SGD(lr, weight_decay) (no momentum), Adagrad(lr, weight_decay)

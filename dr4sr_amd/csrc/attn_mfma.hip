@@ -653,7 +653,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     Tn.list = ws.seq_class + 4 + 6 * B; Tn.list_count = ws.seq_class + 2; Tn.desc = ws.seq_class + 4;
     const size_t lds_s = lds_of(16), lds_l = lds_of(64);
     // default: the 1..8-token and 9..16-token classes as ONE launch (k_attn_small_*), then the 64-row list.  DR4SR_ATTN_NOMERGE: one
-    // launch per class (cross-check, read per call like DR4SR_ATTN_NOTINY)
+    // launch per class (cross-check; cached until dr4sr_reload_env() like every switch)
     // The length classes are disjoint sets of sequences: their launches are independent and go to side streams (parallel branches of a
     // captured step graph): the class kernels are latency-bound at 1-7 % MFMA utilisation, side by side they take the longest one's time
     const StepFork& fk = step_fork();

@@ -8,14 +8,23 @@
 #include <string.h>
 
 // Environment switches: every site caches its variable's value and re-reads it when dr4sr_reload_env() (hooks header) has bumped the
-// generation — process-lifetime constants in production, switchable in-process by the tests.  The value is COPIED (a later setenv may
-// free the string getenv returned).  DR4SR_ENV("X") -> const char* or nullptr.
+// generation — process-lifetime constants in production, switchable in-process by the tests.  NOTE for callers: changing os.environ /
+// setenv AFTER the first call of an entry point has no effect until dr4sr_reload_env() is called (dr4sr_amd/_lib.py: set_env(name,
+// value) does both).  The value is COPIED (a later setenv may free the string getenv returned; values longer than 255 bytes are cut —
+// DR4SR_LIB_PATH-like paths are read by the binding, not here).  The refresh is serialised by one mutex (two host threads entering the
+// same site after a reload), the fast path is one relaxed atomic load.  DR4SR_ENV("X") -> const char* or nullptr.
+#include <atomic>
+#include <mutex>
 int dr4sr_env_generation();                                   // step.hip
+std::mutex& dr4sr_env_mutex();                                // step.hip
 #define DR4SR_ENV(NAME) ([]() -> const char* {                                                   \
-    static int gen_ = -1; static bool set_ = false; static char buf_[64];                        \
+    static std::atomic<int> gen_{-1}; static bool set_ = false; static char buf_[256];           \
     const int cur_ = dr4sr_env_generation();                                                     \
-    if (gen_ != cur_) { const char* e_ = getenv(NAME); set_ = e_ != nullptr;                     \
-        if (e_) { strncpy(buf_, e_, sizeof(buf_) - 1); buf_[sizeof(buf_) - 1] = 0; } gen_ = cur_; } \
+    if (gen_.load(std::memory_order_acquire) != cur_) {                                          \
+        std::lock_guard<std::mutex> lk_(dr4sr_env_mutex());                                      \
+        if (gen_.load(std::memory_order_relaxed) != cur_) { const char* e_ = getenv(NAME); set_ = e_ != nullptr; \
+            if (e_) { strncpy(buf_, e_, sizeof(buf_) - 1); buf_[sizeof(buf_) - 1] = 0; }         \
+            gen_.store(cur_, std::memory_order_release); } }                                     \
     return set_ ? buf_ : nullptr; }())
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

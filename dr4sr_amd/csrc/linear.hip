@@ -79,7 +79,7 @@ static bool scatter_in_wgrad(const Workspace& ws) {
 }
 // large batches: the item-table gradient is NOT accumulated with fp32 atomics (scorer: 2 rows per token, embedding stage: 1) but
 // summed row by row by owner workgroups inside k_wgrad (owner_job): deterministic, and ~55 us of a toys-shaped B = 8192 step
-// cheaper.  DR4SR_DE_ATOMIC (read per call) restores the atomics as a cross-check.
+// cheaper.  DR4SR_DE_ATOMIC (cached until dr4sr_reload_env()) restores the atomics as a cross-check.
 static bool de_owner_mode(const Workspace& ws) { return scatter_in_wgrad(ws) && !DR4SR_ENV("DR4SR_DE_ATOMIC"); }
 // Owner geometry of the table gradient: G = 2^logG owners, the smallest power of two (>= 256) whose rows fit k_wgrad's LDS four
 // times (one private copy per wave) plus the queues.  Shared by the scorer launch (tile_sort needs G) and the k_wgrad launch.
@@ -100,7 +100,7 @@ static int owner_logG(const dr4sr_sasrec_plan* p) {
     return logG;
 }
 // tiles hand their entries over sorted by owner (tile_sort / owner_job_sorted) when the offset tables are byte-sized and small:
-// 32- or 64-row tiles, at most 1024 owners.  DR4SR_OWNER_SCAN (read per call) keeps the scanning owners as a cross-check.
+// 32- or 64-row tiles, at most 1024 owners.  DR4SR_OWNER_SCAN (cached until dr4sr_reload_env()) keeps the scanning owners as a cross-check.
 // the fused last-layer launch takes the wave-tile form (csrc/linear_wave.hip: 16-token tiles) — not for the MetaModel weighting
 static bool wt_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta) { return wave_tiles(p, ws) && wt_bwd_on() && !meta; }
 static int mid_tile_rows(const dr4sr_sasrec_plan* p, const Workspace& ws, bool meta) { return wt_mid(p, ws, meta) ? 16 : tile_rows(ws); }

@@ -6,6 +6,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -22,17 +23,28 @@ void big_lds_impl(const void* kernel, size_t bytes) {
 
 extern "C" int dr4sr_abi_version(void) { return DR4SR_ABI_VERSION; }
 
-// ---- side streams (common.h StepFork).  Created on the first call from OUTSIDE a stream capture (every caller warms a step up before it
-// captures one: engine.py, basemodel.py, bench.py); a first call from inside a capture leaves them off for that call only.
+// ---- side streams (common.h StepFork).  Created on the first call that asks for them (DR4SR_STREAMS).
 static StepFork g_fork = {};
 const StepFork& step_fork() {
     if (g_fork.state == 0 && DR4SR_ENV("DR4SR_STREAMS")) {
+        // A first call may come from INSIDE a stream capture (the callers warm a step up first, but nothing forces them to): stream /
+        // event creation is made legal there by switching this thread to the relaxed capture mode for the duration.  Whatever still
+        // fails leaves the state at 0 — side streams off for THIS call only, retried by the next — and nothing half-created behind.
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
         bool ok = true;
-        for (int i = 0; i < StepFork::NSIDE && ok; ++i) ok = hipStreamCreateWithFlags(&g_fork.side_[i], hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < StepFork::NSIDE && ok; ++i) ok = hipEventCreateWithFlags(&g_fork.fork_ev[i], hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < StepFork::NSIDE && ok; ++i) ok = hipEventCreateWithFlags(&g_fork.join_ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) (void)hipGetLastError();
-        g_fork.state = ok ? 1 : -1;
+        int ns = 0, nf = 0, nj = 0;
+        for (; ns < StepFork::NSIDE && ok; ++ns) ok = hipStreamCreateWithFlags(&g_fork.side_[ns], hipStreamNonBlocking) == hipSuccess;
+        for (; nf < StepFork::NSIDE && ok; ++nf) ok = hipEventCreateWithFlags(&g_fork.fork_ev[nf], hipEventDisableTiming) == hipSuccess;
+        for (; nj < StepFork::NSIDE && ok; ++nj) ok = hipEventCreateWithFlags(&g_fork.join_ev[nj], hipEventDisableTiming) == hipSuccess;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);                        // back to the caller's mode
+        if (!ok) {                                                              // partial creation: destroy what exists, stay retryable
+            (void)hipGetLastError();
+            for (int i = 0; i < ns; ++i) if (g_fork.side_[i]) { (void)hipStreamDestroy(g_fork.side_[i]); g_fork.side_[i] = nullptr; }
+            for (int i = 0; i < nf; ++i) if (g_fork.fork_ev[i]) { (void)hipEventDestroy(g_fork.fork_ev[i]); g_fork.fork_ev[i] = nullptr; }
+            for (int i = 0; i < nj; ++i) if (g_fork.join_ev[i]) { (void)hipEventDestroy(g_fork.join_ev[i]); g_fork.join_ev[i] = nullptr; }
+            (void)hipGetLastError();
+        } else g_fork.state = 1;
     }
     return g_fork;
 }
@@ -61,9 +73,10 @@ int StepFork::join(hipStream_t main, int first, int n) const {
     return hip_ret(e);
 }
 
-static int g_env_generation = 0;
-int dr4sr_env_generation() { return g_env_generation; }
-extern "C" int dr4sr_reload_env(void) { return ++g_env_generation; }
+static std::atomic<int> g_env_generation{0};
+int dr4sr_env_generation() { return g_env_generation.load(std::memory_order_acquire); }
+std::mutex& dr4sr_env_mutex() { static std::mutex mu; return mu; }
+extern "C" int dr4sr_reload_env(void) { return g_env_generation.fetch_add(1, std::memory_order_acq_rel) + 1; }
 extern "C" int dr4sr_sasrec_plan_sizeof(void) { return (int)sizeof(dr4sr_sasrec_plan); }
 
 extern "C" int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
@@ -127,7 +140,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // runs faster as one 8-wave workgroup per sequence at every size (round 3, all-50 batches: B = 2 048 0.929 vs 0.990 ms,
         // B = 8 192 3.36 vs 3.62 ms), so the lists also need an expected mean length of at most 16 tokens
         ws->attn_split = known ? (hint * D > (int64_t)DR4SR_ATTN_SPLIT_TOKENS * 64 && hint <= 16 * (int64_t)p->B) : at_scale((int)Tmax);
-        // tests (read per call): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
+        // tests (cached per process until dr4sr_reload_env(), common.h): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
         // round 4, opt-in (DR4SR_ATTN_WINDOW=1): where the lists would run on a short-sequence plan at d = 64, the window attention of

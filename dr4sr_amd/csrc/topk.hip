@@ -594,7 +594,7 @@ static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, con
     // Measured (2048 x 11 925, k = 100, tools/topk_probe.py): the fused form moves ~50 MB instead of 332 MB but takes 167 us against the
     // two-kernel form's 104 us (subset pass 38, emit 85, candidate select 40: per-row LDS counters in the GEMM epilogue and 2048 small
     // selection waves cost more than the 97 MB matrix round trip at 3.2 TB/s); at N = 200 000 1.3-1.8 ms against 1.55 ms.  It is
-    // therefore OPT-IN (DR4SR_TOPK_FUSED=1, read per call) until the emit epilogue is cheaper; the tests run both forms.
+    // therefore OPT-IN (DR4SR_TOPK_FUSED=1; cached until dr4sr_reload_env()) until the emit epilogue is cheaper; the tests run both forms.
     const bool unfused = DR4SR_ENV("DR4SR_TOPK_FUSED") == nullptr;
     constexpr int CAPC = 2048;
     const int stride = 8, n_sub = (n_items - 1 + stride - 1) / stride, sub_s = (n_sub + 63) / 64 * 64;

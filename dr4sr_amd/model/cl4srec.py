@@ -140,6 +140,8 @@ class CL4SRec(SASRec):
                 aug.end_step()
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         sc = torch.empty(1, dtype=torch.float32, device=dev)               # InfoNCE backward scale
+        if B == 0 and dp_counts is None:                                   # an empty batch outside data parallelism: no rows, no term
+            return stats.zero_()
         if dp_counts is None:
             valid = torch.empty(B, dtype=torch.uint8, device=dev)
             lse, loss_row = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
@@ -218,14 +220,17 @@ class CL4SRec(SASRec):
         eng.adam_step(plan)
 
     def _fused_cl_graph(self, fields, bl, k):
-        key = ("cl_rows", fields["in_" + self.fiid].data_ptr(), bl, k, self._loss_log.data_ptr(), self._perm_buf.data_ptr())
+        aug = self.augmentation_model.augmentation
+        if getattr(aug, "step_dev", None) is None:
+            self._api_graph_begin()
+        # every address the captured graph bakes in is part of the key (_rows_buf / _neg_buf are re-allocated when the batch
+        # size grows, and a cached graph would replay against freed buffers)
+        key = ("cl_rows", fields["in_" + self.fiid].data_ptr(), bl, k, self._loss_log.data_ptr(), self._perm_buf.data_ptr(),
+               self._perm_counter.data_ptr(), self._rows_buf.data_ptr(), self._neg_buf.data_ptr(), aug.step_dev.data_ptr())
         if key in self._graphs:
             return self._graphs[key]
         from ..utils.graphs import capture
         eng = self.engine
-        aug = self.augmentation_model.augmentation
-        if getattr(aug, "step_dev", None) is None:
-            self._api_graph_begin()
         rows = self._rows_buf[:bl]
         plan = eng.make_plan(fields["in_" + self.fiid], fields[self.fiid], fields["seqlen"], rows=rows, neg_item=self._neg_buf, sample_neg=True,
                              perm_sel=(self._perm_buf, int(self.config["train"]["batch_size"]), 0, self._perm_counter), loss_log=self._loss_log)

@@ -586,13 +586,13 @@ class MetaModel(BaseModel):
             rng_views = [s[_lib.STATE_RNGSTEP:_lib.STATE_RNGSTEP + 1].clone() for s in eng.states[1:]]
 
         fused = self._fused_ok()
-        # One-sided Neumann probes (round 4): H v ~ [G(W + e v) - G(W)] / e with the base gradient G(W) evaluated ONCE — 3 evaluations
-        # of L_train instead of 6.  The three terms enter the hyper-gradient scaled by hpo_lr, so their O(e) truncation error is
-        # invisible where the loss curvature is moderate (tests/test_meta_oracle.py, against the reference's double backward: SASRec
-        # 1.2e-5 one-sided / 1.4e-5 central, at the shipped trained checkpoint 1.3e-5 / 1.1e-5) — and is not where it is large: a
-        # CL4SRec sub-model's InfoNCE term gives 3.9e-4 / 2.2e-5, so that sub-model keeps the central form.
-        # train.hypergrad_forward_hvp overrides.
-        fwd_hvp = bool(self.config["train"].get("hypergrad_forward_hvp", not self._cl_sub()))
+        # Neumann probes.  DEFAULT (round 5): central differences, H v ~ [G(W + e v) - G(W - e v)] / 2e — O(e^2) truncation,
+        # 6 evaluations of L_train; the reference's double backward is exact, and the central form stayed within 2.2e-5 of it in every
+        # regime measured.  OPT-IN speed switch `train.hypergrad_forward_hvp: true` (round 4's default for BCE sub-models): one-sided
+        # probes against a base gradient G(W) evaluated once — 3 evaluations instead of 6 (outer step 1.5 -> 1.32 ms) with O(e)
+        # truncation: 1.2e-5 (SASRec, init), 1.3e-5 (shipped trained checkpoint), but 3.9e-4 where the curvature is large (CL4SRec's
+        # InfoNCE term) — measured at two operating points per model only, hence not the default (INTEGRATION.md "Limitations").
+        fwd_hvp = bool(self.config["train"].get("hypergrad_forward_hvp", False))
         g0 = self._buf("g0", n + _lib.GRAD_TAIL) if fwd_hvp else None
         gate_packed = None
 

@@ -22,6 +22,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -43,7 +45,11 @@ def embed_gather_posadd(E: torch.Tensor, P: torch.Tensor, idx: torch.Tensor) -> 
     B, L = idx.shape
     N, D = E.shape
     E, P, idx = E.contiguous(), P.contiguous(), idx.contiguous()
-    _lib.check_ids(idx, N, "embed_gather_posadd")          # nn.Embedding's IndexError (the kernel itself clamps)
+    # nn.Embedding's IndexError (the kernel itself clamps).  The check is an extra launch + a blocking device-to-host read: skipped
+    # inside a stream capture (a synchronisation there raises) and under DR4SR_NO_ID_CHECK — check the id tensor once up front then
+    # (BaseModel._check_dataset_ids does so for every split's resident tensors)
+    if not torch.cuda.is_current_stream_capturing() and not os.environ.get("DR4SR_NO_ID_CHECK"):
+        _lib.check_ids(idx, N, "embed_gather_posadd")
     out = torch.empty(B, L, D, dtype=torch.float32, device=E.device)
     _lib.check(lib.dr4sr_embed_gather_posadd(_lib.ptr(E), _lib.ptr(P), _lib.ptr(idx), _lib.ptr(out), B, L, D, N, _lib.cur_stream()),
                "dr4sr_embed_gather_posadd")

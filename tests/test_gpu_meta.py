@@ -194,9 +194,13 @@ def test_fused_weighted_step_matches_reference_and_dense_path(golden_dir, monkey
     assert rel(g_fused[:n].cpu().numpy(), g_dense[:n].cpu().numpy()) < 1e-4
 
 
-def test_hypergradient_and_meta_sgd_match_reference(golden_dir, monkeypatch):
+@pytest.mark.parametrize("forward_hvp", [False, True])
+def test_hypergradient_and_meta_sgd_match_reference(golden_dir, monkeypatch, forward_hvp):
+    """forward_hvp: the opt-in one-sided Neumann probes (train.hypergrad_forward_hvp; round 5: the default is the central form)"""
     z = np.load(os.path.join(golden_dir, "metamodel_sasrec.npz"))
-    ds, model = build(make_config(int(z["meta.num_items"])), monkeypatch)
+    cfg = make_config(int(z["meta.num_items"]))
+    cfg["train"]["hypergrad_forward_hvp"] = forward_hvp
+    ds, model = build(cfg, monkeypatch)
     z, bt, bv = load_golden(golden_dir, model)
     model.train()
     theta = model.engine.params.clone()
