@@ -377,6 +377,80 @@ __device__ __forceinline__ void tile_mma_xw(const float* __restrict__ As, int ld
     }
 }
 
+// ---- the same tile GEMM on the bf16 matrix cores as a 3-term split (round 5; d = 128 at scale).  The 256-thread tile kernels of a
+// d = 128 layer are bound by the fp32 matrix pipe — v_mfma_f32_16x16x4_f32 issues every 32 cycles per SIMD and shares the datapath with
+// the VALU: issuing HALF of them (timing probe) took the B = 8 192 step from 1.382 to 1.236 ms.  a = ah + al, w = wh + wl with bf16 parts,
+// a w ~ al wh + ah wl + ah wh accumulated in fp32 (the split k_wgrad_bf has used since round 3: max-norm error 5e-6 of the fp32 product):
+// three v_mfma_f32_16x16x32_bf16 (17 cycles each) replace EIGHT fp32 MFMAs (256 cycles).  The A operand is split in registers from the
+// fp32 LDS tile (the row passes keep reading that tile as fp32); the weights come pre-split from an image k_wsplit writes once per step:
+// bf16 high parts of the [N][K] matrix in fragment-major order (bf3_frag_off), the low parts `lo` elements behind, same k-permuted map as
+// tile_mma_xwT (lane group g owns k in [g K/4, (g+1) K/4): A and B use the same map, so the contraction is unchanged).  Data-gradient GEMMs (tile_mma_xw: C += A W) run as
+// this form on the TRANSPOSED image.
+typedef __bf16 t_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 t_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf3_split8(const float4 p, const float4 q, t_bf16x8& hi, t_bf16x8& lo) {
+    const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(v[e] - (float)h);
+    }
+}
+// FRAGMENT-MAJOR image: the 8 elements lane (g, r16) feeds to one MFMA — column n = 16 ct + r16, k = g K/4 + 8 q .. + 7 — are contiguous, the 64
+// lanes of a (column tile ct, chunk q) pair follow each other: a wave's operand load is ONE contiguous 1 KB block (16 full 64-byte
+// sectors).  With the plain [N][K] image the same instruction touched 64 sectors for 1 KB of payload, and the weight stream — every
+// 32-token tile re-reads the layer's 393 KB — was what bounded these kernels (loads removed, timing probe: 1.282 -> 1.068 ms).
+__host__ __device__ __forceinline__ size_t bf3_frag_off(const int n, const int k, const int K) {
+    const int KQ = K / 4, g = k / KQ, rem = k % KQ;
+    return ((size_t)((n >> 4) * (KQ / 8) + (rem >> 3)) * 64 + (g * 16 + (n & 15))) * 8 + (rem & 7);
+}
+template <int BM, int K, int N>
+__device__ __forceinline__ void tile_mma_xwT_bf3(const float* __restrict__ As, int lda, const unsigned short* __restrict__ Wh, const int lo,
+                                                 TileAcc<BM, N>& t) {
+    static_assert((BM == 16 || BM == 32) && K % 32 == 0, "16x16x32 bf16 path");
+    constexpr int KQ = K / 4, RT = BM / 16, CW = N / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < KQ; c += 8) {
+        t_bf16x8 ah[RT], al[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float* ap = As + (r * 16 + r16) * lda + g * KQ + c;
+            bf3_split8(ld4(ap), ld4(ap + 4), ah[r], al[r]);
+        }
+#pragma unroll
+        for (int i = 0; i < CW; ++i) {
+            const unsigned short* wp = Wh + bf3_frag_off((w + 4 * i) * 16 + r16, g * KQ + c, K);     // one contiguous 1 KB block per load instruction
+            const t_bf16x8 bh = *reinterpret_cast<const t_bf16x8*>(wp), bl = *reinterpret_cast<const t_bf16x8*>(wp + lo);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                t.a[r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[r], bh, t.a[r][i], 0, 0, 0);
+                t.a[r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bl, t.a[r][i], 0, 0, 0);
+                t.a[r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bh, t.a[r][i], 0, 0, 0);
+            }
+        }
+    }
+}
+// the split-weight image of ONE layer (Workspace::wsplit): E = 4 D^2 + 2 D F elements per part; orientation o (0: [out][in] as stored,
+// 1: transposed [in][out]) starts at o * 2 E, high parts first, low parts E behind; matrices at IN 0 | OUT 3 D^2 | W1 4 D^2 | W2 4 D^2 + F D
+struct WSplit {
+    const unsigned short* base;                // NULL: fp32 MFMA path
+    int E;
+    int mode;                                  // bit 0: forward-orientation GEMMs on the split, bit 1: transposed (data-gradient) GEMMs (DR4SR_TILE_BF3_MODE, default 3)
+    __host__ __device__ const unsigned short* img(int m_off, bool transposed) const { return base + (transposed ? 2 * (size_t)E : 0) + m_off; }
+};
+// C += A W^T (transposed = false: W [N][K] as stored) or C += A W (transposed = true: W [K][N] as stored -> its [N][K] transposed image)
+template <bool BF3, int BM, int K, int N>
+__device__ __forceinline__ void tile_gemm(const float* __restrict__ As, int lda, const float* __restrict__ W, int ldw, bool transposed,
+                                          const WSplit& sp, int m_off, TileAcc<BM, N>& t) {
+    if constexpr (BF3 && (BM == 16 || BM == 32) && K % 32 == 0) {
+        if (sp.base && (sp.mode & (transposed ? 2 : 1))) { tile_mma_xwT_bf3<BM, K, N>(As, lda, sp.img(m_off, transposed), sp.E, t); return; }
+    }
+    if (transposed) tile_mma_xw<BM, K, N>(As, lda, W, ldw, t);
+    else tile_mma_xwT<BM, K, N>(As, lda, W, ldw, t);
+}
+
 // Register-resident B-operand fragments of the BM = 16 / 32 tile GEMMs.  Loading them is decoupled from the MFMA loop so that
 // a latency-bound kernel can issue ALL its weight loads up front (they depend on nothing) and overlap their L2 round trips
 // with the phases before the GEMM that consumes them.

@@ -47,6 +47,8 @@ struct Workspace {
     int2* tok;                                 // [Tmax] {first token of the token's sequence, sequence slot | sequence length << 20 | PAD << 30}, written by k_embqkv_fwd (attn_tile.h)
     int4* de_ent;                              // [3 Tmax] table-gradient entries of each token tile sorted by owner (linear.hip tile_sort)
     unsigned char* de_off;                     // [Tmax / 32 + 1][1028] start offsets of the owners' buckets inside each tile's entries
+    unsigned short* wsplit;                    // d = 128 at scale: bf16 hi | lo images of every layer's weights, both orientations (common.h WSplit; k_wsplit)
+    int64_t wsplit_E;                          // elements per part and layer (4 D^2 + 2 D F); a layer's block is 4 of them; 0: off
     float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
     int64_t wT_stride;                         // floats per layer in wT
     float* score_part;                         // [B][2]  per-sequence (count, loss sum) of the scorer
@@ -121,6 +123,7 @@ struct PostArgs {
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
     float* nx_dqkv_zero;                       // ... and the launch that emits layer+1's qkv zeroes the K | V rows of its dqkv (atomics target)
     float* dn_dqkv_zero;                       // backward: the K | V rows of layer-1's dqkv, zeroed by the launch in front of their accumulation
+    WSplit sp, sp_nx;                          // bf16x3 tile GEMMs (d = 128 at scale): this layer's / layer + 1's split-weight images (base NULL: fp32)
 };
 
 // layer-0 fusions (linear.hip k_embqkv_fwd / k_qkv_embed_bwd and their wave-tile forms)
@@ -131,11 +134,13 @@ struct EmbQkvArgs {
     int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
     int2* tok; float* dqkv_zero;               // attention in the tile kernels (attn_tile.h): per-token words out, layer 0's dK | dV rows zeroed
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
+    WSplit sp;                                 // layer 0's split-weight image (bf16x3 tile GEMMs), base NULL: fp32
 };
 struct QkvEmbBwdArgs {
     const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
     float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
     float* gout;                 // large batches: masked dx0 rows are stored here and scattered by a job of k_wgrad (overlaps its MFMA work)
+    WSplit sp;                   // layer 0's split-weight image (bf16x3 tile GEMMs), base NULL: fp32
 };
 
 // scorer half of the fused last-layer launch (k_post_mid / k_wt_post_mid)
@@ -211,6 +216,8 @@ int launch_unpack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* 
 int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* dout, float* dX, int mode, hipStream_t s);
 
 int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
+bool tile_bf3(const dr4sr_sasrec_plan* p, const Workspace& ws);              // the 256-thread tile kernels' GEMMs run as a bf16x3 split (d = 128 at scale)
+int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);       // ... from the images this launch writes (once per forward pass)
 int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s, const dr4sr_meta_weighting* mw = nullptr);

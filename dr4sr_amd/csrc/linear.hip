@@ -44,6 +44,46 @@ int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hi
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 hi | lo images of every layer's four weight matrices, as stored and transposed (common.h WSplit): what the bf16x3 tile GEMMs of
+// the d = 128 at-scale step read as their B operand.  One launch per forward pass (the optimizer has just rewritten the weights);
+// 98 k elements per layer.  DR4SR_TILE_F32: the fp32 MFMA tile GEMMs (cross-check).
+int tile_rows(const Workspace& ws);
+bool tile_bf3(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    return ws.wsplit != nullptr && ws.scale && p->D == 128 && tile_rows(ws) == 32 && !DR4SR_ENV("DR4SR_TILE_F32") && !DR4SR_ENV("DR4SR_NO_FUSE");
+}
+__global__ __launch_bounds__(256) void k_wsplit(const float* __restrict__ params, unsigned short* __restrict__ img, int64_t o_in, int64_t o_out,
+                                                int64_t o_w1, int64_t o_w2, int64_t layer_stride, int E, int D, int F) {
+    const int layer = blockIdx.y;
+    unsigned short* base = img + (size_t)layer * 4 * E;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) {
+        const float* src; int R, C, m_off;                   // matrix [R][C] at element offset m_off of a part
+        if (e < 3 * D * D) { src = params + o_in; R = 3 * D; C = D; m_off = 0; }
+        else if (e < 4 * D * D) { src = params + o_out; R = D; C = D; m_off = 3 * D * D; }
+        else if (e < 4 * D * D + F * D) { src = params + o_w1; R = F; C = D; m_off = 4 * D * D; }
+        else { src = params + o_w2; R = D; C = F; m_off = 4 * D * D + F * D; }
+        const int i = e - m_off, r = i / C, c = i % C;
+        const float v = src[layer * layer_stride + i];
+        const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+        const unsigned short hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+        const size_t a = m_off + bf3_frag_off(r, c, C);                           // as stored: N = R rows, K = C (fragment-major, common.h)
+        base[a] = hb; base[(size_t)E + a] = lb;
+        const size_t t = (size_t)2 * E + m_off + bf3_frag_off(c, r, R);           // transposed: N = C rows, K = R
+        base[t] = hb; base[t + E] = lb;
+    }
+}
+int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
+    const int64_t layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
+    hipLaunchKernelGGL(k_wsplit, dim3(96, p->n_layer), dim3(256), 0, s, p->params, ws.wsplit, poff(ws, 0, P_IN_W), poff(ws, 0, P_OUT_W),
+                       poff(ws, 0, P_W1), poff(ws, 0, P_W2), layer_stride, (int)ws.wsplit_E, p->D, p->F);
+    return DR4SR_LAUNCH_CHECK();
+}
+static WSplit wsplit_of(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer) {
+    WSplit w; w.base = nullptr; w.E = (int)ws.wsplit_E; w.mode = DR4SR_ENV("DR4SR_TILE_BF3_MODE") ? atoi(DR4SR_ENV("DR4SR_TILE_BF3_MODE")) : 3;
+    if (tile_bf3(p, ws) && layer >= 0 && layer < p->n_layer) w.base = ws.wsplit + (size_t)layer * 4 * ws.wsplit_E;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int BM, int D>
 __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                  const float* __restrict__ bias, float* __restrict__ QKV,
@@ -194,7 +234,7 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     TileAcc<BM, N> acc;
     tile_zero(acc);
     if constexpr (PFE) tile_mma_frag<BM, D, N>(As, LDA, f_in, acc);
-    else tile_mma_xwT<BM, D, N>(As, LDA, A.W, D, acc);
+    else tile_gemm<D == 128, BM, D, N>(As, LDA, A.W, D, false, A.sp, 0, acc);
     tile_to_global<BM, N>(acc, A.QKV, N, A.bias, t0, T);
     if (A.dqkv_zero) zero_kv_rows<BM, D>(A.dqkv_zero, t0, T);
 }
@@ -208,6 +248,7 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.W = p->params + poff(ws, 0, P_IN_W); A.bias = p->params + poff(ws, 0, P_IN_B); A.QKV = ws.layer[0].qkv; A.state = p->state;
     A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.idx32 = de_owner_mode(ws) ? ws.idx32 : nullptr;
+    A.sp = wsplit_of(p, ws, 0);
     const bool in_tile = attn_in_tile(p, ws);
     A.tok = (in_tile || ws.attn_tile_sa) ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
     A.xcd = tile_xcd_order(p, ws) ? 1 : 0;
@@ -358,7 +399,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
             TileAcc<BM, D> acc;
             tile_zero(acc);
             if constexpr (PF) tile_mma_frag<BM, D, D>(R0, LD, f_out, acc);
-            else tile_mma_xwT<BM, D, D>(R0, LD, A.out_w, D, acc);
+            else tile_gemm<D == 128, BM, D, D>(R0, LD, A.out_w, D, false, A.sp, 3 * D * D, acc);
             tile_to_lds<BM, D>(acc, R2, LD, A.out_b);
         }
         lds_barrier(); STAMP(2);
@@ -371,7 +412,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, F> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, D, F>(R1, LD, f_w1, acc);
-        else tile_mma_xwT<BM, D, F>(R1, LD, A.w1, D, acc);
+        else tile_gemm<D == 128, BM, D, F>(R1, LD, A.w1, D, false, A.sp, 4 * D * D, acc);
         tile_to_lds<BM, F>(acc, R2, LF, A.b1);
     }
     lds_barrier(); STAMP(4);
@@ -402,7 +443,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, F, D>(R2, LF, f_w2, acc);
-        else tile_mma_xwT<BM, F, D>(R2, LF, A.w2, F, acc);
+        else tile_gemm<D == 128, BM, F, D>(R2, LF, A.w2, F, false, A.sp, 4 * D * D + F * D, acc);
         tile_to_lds<BM, D>(acc, R0, LD, A.b2);
     }
     lds_barrier(); STAMP(6);
@@ -412,7 +453,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, 3 * D> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, D, 3 * D>(R1, LD, f_nx, acc);
-        else tile_mma_xwT<BM, D, 3 * D>(R1, LD, A.nx_in_w, D, acc);
+        else tile_gemm<D == 128, BM, D, 3 * D>(R1, LD, A.nx_in_w, D, false, A.sp_nx, 0, acc);
         tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
         if (A.nx_dqkv_zero) zero_kv_rows<BM, D>(A.nx_dqkv_zero, t0, T);
     } else {
@@ -597,7 +638,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_w2, A.w2, F); tile_mma_frag<BM, 3 * D, D>(Aq, LQ, fr_up, acc); }
-        else { tile_mma_xw<BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, acc); if constexpr (PF128) wfrag_load(fr_w2, A.w2, F); }
+        else { tile_gemm<D == 128, BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, true, A.sp_nx, 0, acc); if constexpr (PF128) wfrag_load(fr_w2, A.w2, F); }
         tile_to_lds<BM, D>(acc, R1, LD, nullptr);
         lds_barrier();
         ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
@@ -615,7 +656,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_w1, A.w1, D); tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); }
         else if constexpr (PF128) { tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); wfrag_load(fr_w1, A.w1, D); }
-        else tile_mma_xw<BM, D, F>(R0, LD, A.w2, F, acc);
+        else tile_gemm<D == 128, BM, D, F>(R0, LD, A.w2, F, true, A.sp, 4 * D * D + F * D, acc);
         tile_to_lds<BM, F>(acc, R2, LF, nullptr);
     }
     lds_barrier();
@@ -644,7 +685,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_out, A.out_w, D); tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); }
         else if constexpr (PF128) { tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); wfrag_load(fr_out, A.out_w, D); }
-        else tile_mma_xw<BM, F, D>(R2, LF, A.w1, D, acc);
+        else tile_gemm<D == 128, BM, F, D>(R2, LF, A.w1, D, true, A.sp, 4 * D * D, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
@@ -666,7 +707,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PFB) tile_mma_frag<BM, D, D>(R1, LD, fr_out, acc);
-        else tile_mma_xw<BM, D, D>(R1, LD, A.out_w, D, acc);
+        else tile_gemm<D == 128, BM, D, D>(R1, LD, A.out_w, D, true, A.sp, 3 * D * D, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
@@ -1221,6 +1262,7 @@ PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int lay
     if (A.at.on && !DR4SR_ENV("DR4SR_ATTN_TILE_FULL") && ((near_ok && p->D == 128) || DR4SR_ENV("DR4SR_ATTN_TILE_NEAR"))) A.at.on |= 4;
     if (A.at.on && DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;       // cross-check: every dK | dV row through atomics (no plain stores)
     A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L;
+    A.sp = wsplit_of(p, ws, layer); A.sp_nx = wsplit_of(p, ws, A.nx_in_w ? layer + 1 : -1);
     A.nx_dqkv_zero = (A.at.on && A.nx_qkv) ? ws.layer[layer + 1].dqkv : nullptr;
     A.dn_dqkv_zero = (A.at.on && layer > 0) ? ws.layer[layer - 1].dqkv : nullptr;
     return A;
@@ -1389,7 +1431,7 @@ __device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const
     TileAcc<BM, D> acc;
     tile_zero(acc);
     if constexpr (PFQ) tile_mma_frag<BM, K, D>(As, LDA, f_in, acc);
-    else tile_mma_xw<BM, K, D>(As, LDA, A.W, D, acc);
+    else tile_gemm<D == 128, BM, K, D>(As, LDA, A.W, D, true, A.sp, 0, acc);
     tile_to_lds<BM, D>(acc, Cs, LDC, nullptr);
     lds_barrier();
     const int c = (threadIdx.x % LPT) * 4;
@@ -1462,6 +1504,7 @@ static QkvEmbBwdArgs make_qeb_args(const dr4sr_sasrec_plan* p, const Workspace& 
     A.dE = p->grads + ws.off[0]; A.dP = p->grads + ws.off[1]; A.state = p->state; A.B = p->B; A.L = p->L; A.n_items = p->n_items;
     A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.gout = scatter_in_wgrad(ws) ? ws.dX[0] : nullptr;
+    A.sp = wsplit_of(p, ws, 0);
     return A;
 }
 // latency regime: k_qkv_embed_bwd and k_wgrad are independent (the weight gradients read dqkv / X, not dx0), so the embedding tiles

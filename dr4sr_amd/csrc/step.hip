@@ -168,6 +168,10 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->de_ent = (int4*)take(Tmax * 12); ws->de_off = (unsigned char*)take((Tmax / 16 + 1) * 257);     // [tiles of >= 16 tokens][G + 4 <= 1028 bytes]
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
+    // d = 128: split-weight images of the bf16x3 tile GEMMs (common.h WSplit): 2 orientations x (hi | lo) x E bf16 per layer = 2 E floats
+    ws->wsplit_E = D == 128 ? ws->wT_stride : 0;
+    ws->wsplit = ws->wsplit_E ? reinterpret_cast<unsigned short*>(take(2 * ws->wsplit_E * p->n_layer)) : nullptr;
+    if (!base && ws->wsplit_E) ws->wsplit = reinterpret_cast<unsigned short*>(1);      // (size probe: non-NULL so that the launch forms report alike)
     ws->score_part = take(2LL * (p->B > (Tmax + 15) / 16 ? p->B : (Tmax + 15) / 16));   // per sequence, or per token tile (fused last layer)
     ws->ln_part = take((int64_t)p->n_layer * ((Tmax + 15) / 16) * 4 * D);
     for (int l = 0; l < p->n_layer; ++l) {
@@ -411,6 +415,7 @@ static int attn_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int l, int 
 // mid_fused: the last layer's post_fwd / scorer / post_bwd run as ONE launch (launch_post_mid) between the two halves
 static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s, bool mid_fused = false) {
     const bool fuse = DR4SR_ENV("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1),
+    if (tile_bf3(p, ws)) RC(launch_wsplit(p, ws, s));                // d = 128 at scale: this pass's weights as bf16 hi | lo images
     if (fuse) RC(launch_embqkv_fwd(p, ws, training, s));             // qkv of layer 0 by the embedding gather
     else RC(launch_embed_fwd(p, ws, training, s));
     const bool in_tile = attn_in_tile(p, ws);                    // the attention runs at the head of post_fwd / post_mid (attn_tile.h)

@@ -179,3 +179,41 @@ def test_bench_self_launches_eight_ranks_on_a_shared_gpu():
     assert "gloo" in j["config"]["collective"] and j["value"] > 0 and j["final_loss"] == j["final_loss"]
     st = j["strong"][0]
     assert st["global_batch"] == 16384 and st["per_gpu_batch"] == 2048 and st["n_gpus"] == 8 and st["speedup"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ d = 128 at scale
+def test_d128_at_scale_bf16x3_tile_gemms_vs_oracle_and_fp32(monkeypatch):
+    """BASELINE configs[3]'s width in the at-scale launch forms: the 256-thread tile kernels' GEMMs run as a 3-term bf16 split from
+    fragment-major weight images (k_wsplit, csrc/common.h tile_mma_xwT_bf3).  B = 1 024 toys-shaped rows of the yelp-sized table
+    against the ORACLE's autograd (loss, every gradient) and against the fp32 MFMA kernels of the same step (DR4SR_TILE_F32=1);
+    reference arithmetic: /root/reference/model/sasrec.py:39-75 + model/basemodel.py:204-214 + model/loss_func.py:9-38"""
+    from oracle import sasrec_oracle as O
+    from test_gpu_parity import _random_params, _toys_batch, relerr
+    from dr4sr_amd import _lib
+    from dr4sr_amd.engine import SasrecEngine
+    dev = torch.device("cuda", 0)
+    B, D, N = 1024, 128, 20034
+    b, N = _toys_batch(B, False, seed=11, n_items=N)
+    params = _random_params(N, D, 128, 2, seed=4)
+    out = {}
+    for f32 in (False, True):
+        if f32:
+            monkeypatch.setenv("DR4SR_TILE_F32", "1")
+        eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, 0.0, B, dev)
+        eng.load_named(params)
+        plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                             neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+        assert int(eng.lib.dr4sr_sasrec_at_scale(_lib.C.byref(plan))) & 1          # 5.6 k tokens x 128 columns: the at-scale forms
+        eng.fwd_bwd(plan)
+        out[f32] = (eng.loss_and_count(), {k: v.clone() for k, v in eng.normalized_grads().items()})
+    (loss, n), grads = out[False]
+    loss_o, _, grads_o = O.grads_of(params, b, 2, 2, 1e-12)
+    assert n == int((b["item_id"] != 0).sum()) and abs(loss - float(loss_o)) < 2e-5
+    worst = 0.0
+    for k, gv in grads.items():
+        e = relerr(gv, grads_o[k])
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e)
+        assert relerr(gv, out[True][1][k].cpu()) < 5e-5, k                          # split vs fp32 MFMA: 5e-6 per product, two layers deep
+    assert abs(loss - out[True][0][0]) < 1e-5
+    print("d = 128 at scale, bf16x3 tile GEMMs: worst gradient error vs oracle %.2e" % worst)
