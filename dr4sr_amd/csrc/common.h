@@ -432,20 +432,17 @@ __device__ __forceinline__ void tile_mma_xwT_bf3(const float* __restrict__ As, i
         }
     }
 }
-// the split-weight image of ONE layer (Workspace::wsplit): E = 4 D^2 + 2 D F elements per part; orientation o (0: [out][in] as stored,
-// 1: transposed [in][out]) starts at o * 2 E, high parts first, low parts E behind; matrices at IN 0 | OUT 3 D^2 | W1 4 D^2 | W2 4 D^2 + F D
-struct WSplit {
-    const unsigned short* base;                // NULL: fp32 MFMA path
-    int E;
-    int mode;                                  // bit 0: forward-orientation GEMMs on the split, bit 1: transposed (data-gradient) GEMMs (DR4SR_TILE_BF3_MODE, default 3)
-    __host__ __device__ const unsigned short* img(int m_off, bool transposed) const { return base + (transposed ? 2 * (size_t)E : 0) + m_off; }
-};
-// C += A W^T (transposed = false: W [N][K] as stored) or C += A W (transposed = true: W [K][N] as stored -> its [N][K] transposed image)
+// the split-weight images (Workspace::wsplit): per layer 4 E bf16 with E = 4 D^2 + 2 D F — orientation o (0: [out][in] as stored, 1:
+// transposed [in][out]) starts at o * 2 E, high parts first, low parts E behind; matrices at IN 0 | OUT 3 D^2 | W1 4 D^2 | W2 4 D^2 + F D.
+// One pointer in the argument blocks (NULL: fp32 MFMA path); layer + 1's block follows at + 4 E.
+template <int D, int F> struct WSplitGeo { static constexpr int E = 4 * D * D + 2 * D * F, OUT = 3 * D * D, W1 = 4 * D * D, W2 = 4 * D * D + F * D; };
+// C += A W^T (transposed = false: W [N][K] as stored) or C += A W (transposed = true: W [K][N] as stored -> its [N][K] transposed image);
+// sp = the layer's split-weight block or NULL, E = elements per part, m_off = the matrix's offset in a part
 template <bool BF3, int BM, int K, int N>
 __device__ __forceinline__ void tile_gemm(const float* __restrict__ As, int lda, const float* __restrict__ W, int ldw, bool transposed,
-                                          const WSplit& sp, int m_off, TileAcc<BM, N>& t) {
+                                          const unsigned short* __restrict__ sp, int E, int m_off, TileAcc<BM, N>& t) {
     if constexpr (BF3 && (BM == 16 || BM == 32) && K % 32 == 0) {
-        if (sp.base && (sp.mode & (transposed ? 2 : 1))) { tile_mma_xwT_bf3<BM, K, N>(As, lda, sp.img(m_off, transposed), sp.E, t); return; }
+        if (sp) { tile_mma_xwT_bf3<BM, K, N>(As, lda, sp + (transposed ? 2 * (size_t)E : 0) + m_off, E, t); return; }
     }
     if (transposed) tile_mma_xw<BM, K, N>(As, lda, W, ldw, t);
     else tile_mma_xwT<BM, K, N>(As, lda, W, ldw, t);

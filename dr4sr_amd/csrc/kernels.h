@@ -102,7 +102,7 @@ struct TileAttnArgs {
     const float* qkv; float* dqkv; float* ctx; float* stat; const int2* tok; int L;
     int on;                                    // bit 0: on; bit 1 (DR4SR_ATTN_TILE_ATOMICS): no plain stores for tile-private dK | dV rows; bit 2: near rows first (short-sequence plans)
 };
-struct PostArgs {
+struct alignas(16) PostArgs {                   // (16: the argument block behind it in a kernel's kernarg segment keeps its alignment — s_load grouping)
     // forward inputs / saved activations
     const float* ctx; const float* x;
     const float* out_w; const float* out_b; const float* ln1_w; const float* ln1_b;
@@ -123,7 +123,7 @@ struct PostArgs {
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
     float* nx_dqkv_zero;                       // ... and the launch that emits layer+1's qkv zeroes the K | V rows of its dqkv (atomics target)
     float* dn_dqkv_zero;                       // backward: the K | V rows of layer-1's dqkv, zeroed by the launch in front of their accumulation
-    WSplit sp, sp_nx;                          // bf16x3 tile GEMMs (d = 128 at scale): this layer's / layer + 1's split-weight images (base NULL: fp32)
+    const unsigned short* sp;                  // bf16x3 tile GEMMs (d = 128 at scale): this layer's split-weight block, layer + 1's right behind (common.h); NULL: fp32
 };
 
 // layer-0 fusions (linear.hip k_embqkv_fwd / k_qkv_embed_bwd and their wave-tile forms)
@@ -134,13 +134,13 @@ struct EmbQkvArgs {
     int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
     int2* tok; float* dqkv_zero;               // attention in the tile kernels (attn_tile.h): per-token words out, layer 0's dK | dV rows zeroed
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
-    WSplit sp;                                 // layer 0's split-weight image (bf16x3 tile GEMMs), base NULL: fp32
+    const unsigned short* sp;                  // layer 0's split-weight block (bf16x3 tile GEMMs), NULL: fp32
 };
 struct QkvEmbBwdArgs {
     const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
     float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
     float* gout;                 // large batches: masked dx0 rows are stored here and scattered by a job of k_wgrad (overlaps its MFMA work)
-    WSplit sp;                   // layer 0's split-weight image (bf16x3 tile GEMMs), base NULL: fp32
+    const unsigned short* sp;    // layer 0's split-weight block (bf16x3 tile GEMMs), NULL: fp32
 };
 
 // scorer half of the fused last-layer launch (k_post_mid / k_wt_post_mid)

@@ -238,7 +238,7 @@ static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
 //   DR4SR_OPT_ADAGRAD  torch.optim.Adagrad(lr, weight_decay)    g += wd p ; V += g^2 ; p -= lr g / (sqrt(V) + eps)     (eps 1e-10, lr_decay 0)
 //   DR4SR_OPT_RMSPROP  torch.optim.RMSprop(lr, weight_decay)    g += wd p ; V = b2 V + (1 - b2) g^2 ; p -= lr g / (sqrt(V) + eps)   (b2 = alpha 0.99)
 // The un-normalised gradient, the poison word, the step counter and the fused next-step prep are the same for all four.
-struct AdamNext { int enable; int phase2_launch; PrepArgs prep; int probe; };      // probe (DR4SR_ADAM_PROBE, timing only; tools/adam_probe.sh): 1 = skip the prep chain, 2 = skip the sweep
+struct AdamNext { int enable; int phase2_launch; PrepArgs prep; };
 template <int OPT>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __restrict__ G, float* __restrict__ M,
                                               float* __restrict__ V, int64_t n, int* __restrict__ state, float lr, float b1,
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ P, float* __re
         const float lossv = G[n + 1] * gs;                 //  whose index the prep is about to advance)
         if (loss_log && threadIdx.x == 0) loss_log[log_index ? max(*log_index - 1, 0) : 0] = lossv;
         __syncthreads();
-        if (next.probe != 1) prep_body<256>(next.prep, part);
-    } else if (next.probe != 2) {
+        prep_body<256>(next.prep, part);
+    } else {
         if (threadIdx.x == 0) {               // double-precision bias corrections, once per block
             const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
             sh[0] = (float)((double)lr / bc1);
@@ -352,7 +352,6 @@ int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* sta
     AdamNext nx;
     nx.enable = next ? (next->B > 1024 && next->len_buf && blocks <= PREP_MAX_BLK && (next->B + blocks - 1) / blocks < 65536 ? 2 : 1) : 0;
     nx.phase2_launch = 0;
-    nx.probe = DR4SR_ENV("DR4SR_ADAM_PROBE") ? atoi(DR4SR_ENV("DR4SR_ADAM_PROBE")) : 0;
     if (next) nx.prep = *next; else nx.prep = PrepArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, PermSel{nullptr, 0, 0, 0, nullptr}, nullptr, nullptr, nullptr};
     const bool p2_inline = DR4SR_ENV("DR4SR_PREP2_INLINE") != nullptr;      // cross-check: phase 2 as the tail of the optimizer launch
     nx.phase2_launch = nx.enable == 2 && !p2_inline;
