@@ -2115,7 +2115,10 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     // round 4 (64 x 64 block jobs, four workgroups per CU): dense B = 8 192 128 / 192 / 256 / 320 splits -> 713 / 681 / 680 / 720 us, toys B = 8 192
     // 96 / 128 / 160 / 192 / 256 -> 92 / 83 / 83 / 89 / 105 us: the upper cap comes down from 320 to 224
     const int gw_hi = sub64 ? 224 : 320;
-    const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > gw_hi ? gw_hi : hint_tiles / 16) : 160);
+    // round 5 (64 x 64 block jobs, B = 3 072 / 4 096 / 6 144 toys-shaped rows = 262 / 350 / 525 expected tiles): 96 splits 0.3208 / 0.3467 ms
+    // against 0.3350 / 0.3593 at 160 (each workgroup sums >= 3 tiles before its 4 096 atomics); 112 at 525 tiles; 128..160 equal at 700
+    const int gw_small = (sub64 && hint_tiles > 0 && hint_tiles < 450) ? 96 : (sub64 && hint_tiles > 0 && hint_tiles < 620) ? 112 : 160;
+    const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > gw_hi ? gw_hi : hint_tiles / 16) : gw_small);
     // floor: 48 splits (36 real tiles at the toys B = 256 batch: one each), 64 once the batch is expected to hold >= 100 tiles
     // (dense B = 256, 200 tiles: k_wgrad 49.4 -> 44.2 us; 80 splits: 44.8)
     const bool gw_env = DR4SR_ENV("DR4SR_WGRAD_GW") != nullptr;
