@@ -28,7 +28,7 @@ import ctypes as C  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PROFILE_ROUND = 4              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
+PROFILE_ROUND = 5              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 

@@ -2,7 +2,7 @@
 # Regenerates the round's measurement artefacts on the GPU box into gpurun_out/r<ROUND>/ (copy what you keep into profiles/).
 set -u
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-3}; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-5}; mkdir -p $O
 trace() {  # tag, bench args...
   tag=$1; shift
   rm -rf /tmp/kt_$tag

@@ -2,7 +2,7 @@
 # one kernel-trace + timeline of bench.py with the given args:  tools/trace_one.sh <tag> <bench args...>   -> gpurun_out/r<ROUND>/{kernels,timeline}_<tag>.txt
 set -u
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-3}; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-5}; mkdir -p $O
 tag=$1; shift
 rm -rf /tmp/kt_$tag
 timeout 400 rocprofv3 --kernel-trace -d /tmp/kt_$tag -o t -- python $R/bench.py --no-cpu-baseline --no-throughput-mode --no-strong "$@" > /tmp/kt_$tag.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the training-step kernels: two PMC passes (FETCH_SIZE / WRITE_SIZE) per workload -> gpurun_out/r<ROUND>/pmc_traffic_<tag>.json
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-3}; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-5}; mkdir -p $O
 run() {  # tag, bench args
   tag=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
