@@ -404,7 +404,7 @@ def bench_metamodel(args):
             extra["cpu_baseline"] = cpu_baseline_leg(rows_np, eng.n_items, "metamodel", args.dropout, interval=args.interval)
     if rank == 0:
         B = args.batch
-        print(json.dumps({
+        emit({
             **extra,
             "metric": "training sequences/sec, MetaModel(SASRec) d=64 L=50", "value": world * B * args.steps / wall,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps,
@@ -413,7 +413,7 @@ def bench_metamodel(args):
                                    "inner step every step + hyper-gradient outer step every %d steps, B=%d rows/GPU/step, dropout %.2f"
                                    % (args.interval, B, args.dropout),
                        "global_batch": B * world, "seq_len": 50, "parallelism": "dp%d" % world, "hip_graph": True},
-            "outer_step_ms": outer_ms, "final_loss": float(loss)}))
+            "outer_step_ms": outer_ms, "final_loss": float(loss)})
     if world > 1:
         dist.destroy_process_group()
 
@@ -489,14 +489,14 @@ def bench_cl4srec(args):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         form = "API path replayed as one HIP graph per step" if graph else "API path, eager" 
-    print(json.dumps({
+    emit({
         "metric": "training sequences/sec, CL4SRec d=64 L=50", "value": args.batch * args.steps / wall, "unit": "sequences/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CL4SRec (item_random augmentation, cl_weight 0.1) on amazon-toys-shaped synthetic rows, B=%d, dropout %.2f: "
                                "three encoder passes + InfoNCE per step, %s" % (args.batch, args.dropout, form),
                    "global_batch": args.batch, "seq_len": 50, "parallelism": "dp1", "hip_graph": bool(graph)},
-        "final_loss": float(loss.detach())}))
+        "final_loss": float(loss.detach())})
 
 
 def relaunch_under_torchrun(n_gpus):
@@ -519,10 +519,31 @@ def relaunch_under_torchrun(n_gpus):
         env.setdefault("DR4SR_DP_BACKEND", "gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd, env=env))
+    sys.exit(subprocess.call(cmd, env=env, stdout=_REAL_STDOUT))       # (this process's fd 1 already points at stderr: guard_stdout)
+
+
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio when a communicator is created, and that buffer
+    is flushed at process exit — i.e. BEHIND the JSON line (seen: `tail -1` of the default run returned "Librccl path : ...").  So file
+    descriptor 1 is pointed at stderr for the rest of the process and the JSON line is written to a duplicate of the original stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
 
 
 def main():
+    guard_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -650,7 +671,9 @@ def main():
         # gradient buckets of the data-parallel step (parallel.dp_backward): at scale the item-table gradient is final one launch before
         # the rest, its all-reduce runs beside that launch and only the 280 KB encoder bucket is exposed; one flat all-reduce in the
         # latency forms (and for GRU4Rec / FMLP).  Every rank has B rows here, so every rank decides alike.
-        buckets = parallel.grad_buckets(eng, B, data["seqlen"]) if (dp and args.model == "sasrec" and not dp_flat) else None
+        # (two buckets only inside the captured graph: launched from the host the two-bucket step is four submissions per step, +91 us at
+        #  16 384 rows per rank with one RCCL rank against +30 us in the graph — the host form stays flat, as in BaseModel._step_graph)
+        buckets = parallel.grad_buckets(eng, B, data["seqlen"]) if (dp and args.model == "sasrec" and not dp_flat and dp_form == "in_graph") else None
         two = buckets is not None and len(buckets) == 2
 
         def step_eager():
@@ -738,45 +761,30 @@ def main():
                 else:
                     return None                              # the caller reports in_graph: null (capture failed on some rank)
             if run_steps is None and use_graph and dp and args.model == "sasrec":
-                # Host-launched collectives between graphs.  The graph that holds the optimizer of step j (which also prepares the
-                # next batch) holds the backward of step j + 1 up to its first collective as well: ONE graph launch per collective.
-                #   one bucket :  [fwd_bwd] AR ([adam+prep | fwd_bwd_prepared] AR)* ...
-                #   two buckets:  [phase 1] AR0 [phase 2] AR1 ([adam+prep | phase 1] AR0 [phase 2] AR1)* ...
+                # Host-launched collective between graphs, one flat bucket.  The graph that holds the optimizer of step j (which also prepares
+                # the next batch) holds the backward of step j + 1 as well: ONE graph launch + one collective per step.
+                #   [fwd_bwd] AR ([adam+prep | fwd_bwd_prepared] AR)* ... [adam]
                 def graph_of(fn):
                     g = torch.cuda.CUDAGraph()
                     with graph_capture(g, stream=stream):
                         fn()
                     return g
-                if two:
-                    g_first = graph_of(lambda: eng.fwd_bwd_phase(plan, False, 1))
-                    g_p2 = graph_of(lambda: eng.fwd_bwd_phase(plan, True, 2))
-                    g_mid = graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_phase(plan, True, 1)))
-                    (b0lo, b0hi), (b1lo, b1hi) = buckets
-                else:
-                    g_first = graph_of(lambda: eng.fwd_bwd(plan))
-                    g_mid = graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_prepared(plan)))
+                g_first = graph_of(lambda: eng.fwd_bwd(plan))
+                g_mid = graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_prepared(plan)))
                 g_fin = graph_of(lambda: eng.adam_step(plan))
                 pending = [False]                            # a step whose optimizer has not run yet (it rides in the next call's first graph)
 
                 def run_steps(n):
                     for _ in range(n):
                         (g_mid if pending[0] else g_first).replay()
-                        if two:
-                            h0 = parallel.allreduce_begin(eng.grads[b0lo:b0hi])
-                            g_p2.replay()
-                            h1 = parallel.allreduce_begin(eng.grads[b1lo:b1hi])
-                            parallel.allreduce_end(h0)
-                            parallel.allreduce_end(h1)
-                        else:
-                            reduce_grads()
+                        reduce_grads()
                         pending[0] = True
 
                 def finish_steps():                          # the last step's optimizer: inside the timed region (main loop below)
                     if pending[0]:
                         g_fin.replay()
                         pending[0] = False
-                collective = "%s all-reduce launched by the host between graphs (%s)" % (
-                    parallel.backend_name(), "2 buckets: table beside the last weight-gradient launch, then encoder + tail" if two else "1 flat bucket")
+                collective = "%s all-reduce launched by the host between graphs (1 flat bucket)" % parallel.backend_name()
             elif run_steps is None and use_graph and dp:
                 g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with graph_capture(g_a, stream=stream):
@@ -1033,12 +1041,12 @@ def main():
                 igf = measure(per, st, wu, None, dp=True, dp_form="in_graph", repeats=sec_rep, dp_flat=True) \
                     if (ig is not None and "2 buckets" in (ig["config"].get("collective") or "")) else None
                 igf = igf[0] if igf is not None else None
-                best = min(host["ms_per_step"], ig["ms_per_step"]) if ig is not None else host["ms_per_step"]
+                best = min([host["ms_per_step"]] + [x["ms_per_step"] for x in (ig, igf) if x is not None])
                 ent["dp_1rank_rccl"] = {
                     "assumed_gpus": Wd, "per_gpu_batch": per, "single_gpu_form_ms": plain["ms_per_step"],
                     "dp_host_ms": host["ms_per_step"], "dp_in_graph_ms": None if ig is None else ig["ms_per_step"],
                     "dp_in_graph_flat_ms": None if igf is None else igf["ms_per_step"],
-                    "collective_exposed_us": 1e3 * (best - plain["ms_per_step"]),
+                    "collective_exposed_us": 1e3 * (best - plain["ms_per_step"]),         # fastest form (one rank: the flat in-graph form, whose collective is a no-op)
                     "collective_exposed_us_host": 1e3 * (host["ms_per_step"] - plain["ms_per_step"]),
                     "collective_exposed_us_in_graph": None if ig is None else 1e3 * (ig["ms_per_step"] - plain["ms_per_step"]),
                     "collective": (ig or host)["config"]["collective"], "allreduce_us_standalone_flat_1rank": host.get("allreduce_us_standalone"),
@@ -1051,7 +1059,7 @@ def main():
         finally:
             os.environ.pop("DR4SR_BENCH_FORCE_DP", None)
             if dist.is_initialized():
-                print(json.dumps(out), flush=True)
+                emit(out)
                 dist.destroy_process_group()
                 return
 
@@ -1069,7 +1077,7 @@ def main():
             def give_up():
                 forms["in_graph_error"] = "watchdog: the in-graph form did not finish within %d s" % args.in_graph_timeout
                 if rank == 0:
-                    print(json.dumps(out), flush=True)
+                    emit(out)
                 os._exit(0)
             dog = threading.Timer(args.in_graph_timeout, give_up)
             dog.daemon = True
@@ -1113,11 +1121,11 @@ def main():
                 forms["in_graph_error"] = "%s: %s" % (type(e).__name__, e)
                 dog.cancel()
                 if rank == 0:
-                    print(json.dumps(out), flush=True)
+                    emit(out)
                 os._exit(0)                                  # the communicator may be wedged: do not enter another collective
             dog.cancel()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dp:
         dist.destroy_process_group()
 

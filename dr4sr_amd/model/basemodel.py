@@ -352,8 +352,11 @@ class BaseModel(nn.Module):
             # Gradient buckets (parallel.dp_backward): at scale the table gradient is final one launch before the rest and its all-reduce
             # runs beside that launch; the latency forms have one bucket = the flat all-reduce.
             has_prep = perm_sel is not None and hasattr(eng, "fwd_bwd_prepared")      # the optimizer launch of step j prepares step j + 1 (any batch size)
-            buckets = parallel.grad_buckets(eng, dp_rows, fields.get("seqlen"))
-            two = len(buckets) == 2
+            # Two buckets only INSIDE a captured graph (where the asynchronous table collective is a parallel branch for free): launched from
+            # the host, the two-bucket step is four submissions per step instead of two and measured +91 us at 16 384 rows per rank with one
+            # RCCL rank, against +30 us in the graph (profiles/round5_bench_default.json strong[].dp_1rank_rccl) — the host form stays flat.
+            buckets = parallel.grad_buckets(eng, dp_rows if in_graph else None, fields.get("seqlen"))
+            flat = parallel.grad_buckets(eng, None)
 
             def body(reduce):
                 for j in range(group):
@@ -385,44 +388,31 @@ class BaseModel(nn.Module):
                     elif ok:
                         self.logger.warning("in-graph all-reduce capture failed on another rank; using host-launched collectives")
                 if run is None:
-                    # Host-launched collectives between graphs.  The graph that holds the optimizer of step j also holds the backward of
-                    # step j + 1 up to its first collective, so a step costs ONE graph launch per collective (round 4: two graphs + one
-                    # collective per step; the extra launch was ~8 us of idle GPU per step at B = 256).
-                    #   one bucket :  [fwd_bwd] AR ([adam+prep | fwd_bwd_prepared] AR)* [adam]
-                    #   two buckets:  [phase 1] AR0 [phase 2] AR1 ([adam+prep | phase 1] AR0 [phase 2] AR1)* [adam]
+                    # Host-launched collective between graphs, one flat bucket.  The graph that holds the optimizer of step j also holds the
+                    # backward of step j + 1, so a step costs ONE graph launch + one collective (round 4: two graphs + one collective per
+                    # step; the extra launch was ~8 us of idle GPU per step at B = 256):  [fwd_bwd] AR ([adam+prep | fwd_bwd_prepared] AR)* [adam]
+                    buckets = flat
+
                     def graph_of(fn):
                         g = torch.cuda.CUDAGraph()
                         with capture(g):
                             fn()
                         return g
                     prep = has_prep and group > 1
-                    if two:
-                        g_first = graph_of(lambda: eng.fwd_bwd_phase(plan, False, 1))
-                        g_p2 = graph_of(lambda: eng.fwd_bwd_phase(plan, prep, 2))         # (phase 2 is the same launch either way)
-                        g_mid = None if group == 1 else \
-                            graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_phase(plan, True, 1))) if prep else \
-                            graph_of(lambda: (eng.adam_step(plan), eng.fwd_bwd_phase(plan, False, 1)))
-                    else:
-                        g_first = graph_of(lambda: eng.fwd_bwd(plan))
-                        g_mid = None if group == 1 else \
-                            graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_prepared(plan))) if prep else \
-                            graph_of(lambda: (eng.adam_step(plan), eng.fwd_bwd(plan)))
+                    g_first = graph_of(lambda: eng.fwd_bwd(plan))
+                    g_mid = None if group == 1 else \
+                        graph_of(lambda: (eng.adam_step_prepare_next(plan), eng.fwd_bwd_prepared(plan))) if prep else \
+                        graph_of(lambda: (eng.adam_step(plan), eng.fwd_bwd(plan)))
                     g_last = graph_of(lambda: eng.adam_step(plan))
-                    (b0lo, b0hi), (b1lo, b1hi) = buckets[0], buckets[-1]
 
                     def run():
                         for j in range(group):
                             (g_mid if j > 0 else g_first).replay()
-                            if two:
-                                h0 = parallel.allreduce_begin(eng.grads[b0lo:b0hi])
-                                g_p2.replay()
-                                h1 = parallel.allreduce_begin(eng.grads[b1lo:b1hi])
-                                parallel.allreduce_end(h0)
-                                parallel.allreduce_end(h1)
-                            else:
-                                allreduce_flat(eng.grads)             # RCCL sum: gradients + {n_valid, loss_sum, poison} tail
+                            allreduce_flat(eng.grads)             # RCCL sum: gradients + {n_valid, loss_sum, poison} tail
                         g_last.replay()
             else:
+                buckets = flat
+
                 def run():
                     body(True)
         self._graphs[key] = (run, plan)
@@ -460,8 +450,11 @@ class BaseModel(nn.Module):
                 # host all-reduce below — always uses the host-launched collective
                 k = group if (i + group) * B <= n else 1
                 full = (i + 1) * B <= n
+                # (the in-graph form also needs every rank to HAVE rows — a rank with an empty slice of a full batch builds no graph and would
+                #  miss the capture-success collective; then every rank takes the host form, as on partial tail batches)
+                every_rank_has_rows = (B + W - 1) // W * (W - 1) < B
                 run, _ = self._step_graph(loader.fields, bl, sel, group=k, loss_log=losses,      # k_adam logs the (all-reduced) mean loss
-                                          in_graph=W > 1 and full and self._dp_in_graph(),
+                                          in_graph=W > 1 and full and every_rank_has_rows and self._dp_in_graph(),
                                           dp_rows=(B + W - 1) // W if (W > 1 and full) else None)
                 run()
                 i += k
@@ -471,8 +464,7 @@ class BaseModel(nn.Module):
                 run, _ = self._step_graph(loader.fields, bl)
                 run()
             else:                                          # fewer rows than ranks: contribute zeros to the same collectives as the others
-                full = (i + 1) * B <= n
-                parallel.dp_reduce_empty(eng, parallel.grad_buckets(eng, (B + W - 1) // W if full else None, loader.fields.get("seqlen")))
+                parallel.dp_reduce_empty(eng, None)      # the ranks with rows take the host-launched flat form here (see every_rank_has_rows above)
                 eng.adam_step(self._api_plan())
             losses[i] = tail[1] / tail[0]
             i += 1
