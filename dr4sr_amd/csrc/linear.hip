@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     TileAcc<BM, N> acc;
     tile_zero(acc);
     if constexpr (PFE) tile_mma_frag<BM, D, N>(As, LDA, f_in, acc);
-    else tile_gemm<D == 128, BM, D, N>(As, LDA, A.W, D, false, A.sp, WSplitGeo<D, 128>::E, 0, acc);
+    else tile_gemm<D == 128 && BM == 32, BM, D, N>(As, LDA, A.W, D, false, A.sp, WSplitGeo<D, 128>::E, 0, acc);
     tile_to_global<BM, N>(acc, A.QKV, N, A.bias, t0, T);
     if (A.dqkv_zero) zero_kv_rows<BM, D>(A.dqkv_zero, t0, T);
 }
@@ -399,7 +399,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
             TileAcc<BM, D> acc;
             tile_zero(acc);
             if constexpr (PF) tile_mma_frag<BM, D, D>(R0, LD, f_out, acc);
-            else tile_gemm<D == 128, BM, D, D>(R0, LD, A.out_w, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
+            else tile_gemm<D == 128 && BM == 32, BM, D, D>(R0, LD, A.out_w, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
             tile_to_lds<BM, D>(acc, R2, LD, A.out_b);
         }
         lds_barrier(); STAMP(2);
@@ -412,7 +412,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, F> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, D, F>(R1, LD, f_w1, acc);
-        else tile_gemm<D == 128, BM, D, F>(R1, LD, A.w1, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
+        else tile_gemm<D == 128 && BM == 32, BM, D, F>(R1, LD, A.w1, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
         tile_to_lds<BM, F>(acc, R2, LF, A.b1);
     }
     lds_barrier(); STAMP(4);
@@ -443,7 +443,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, F, D>(R2, LF, f_w2, acc);
-        else tile_gemm<D == 128, BM, F, D>(R2, LF, A.w2, F, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
+        else tile_gemm<D == 128 && BM == 32, BM, F, D>(R2, LF, A.w2, F, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
         tile_to_lds<BM, D>(acc, R0, LD, A.b2);
     }
     lds_barrier(); STAMP(6);
@@ -453,7 +453,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, 3 * D> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, D, 3 * D>(R1, LD, f_nx, acc);
-        else tile_gemm<D == 128, BM, D, 3 * D>(R1, LD, A.nx_in_w, D, false, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc);
+        else tile_gemm<D == 128 && BM == 32, BM, D, 3 * D>(R1, LD, A.nx_in_w, D, false, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc);
         tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
         if (A.nx_dqkv_zero) zero_kv_rows<BM, D>(A.nx_dqkv_zero, t0, T);
     } else {
@@ -638,7 +638,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_w2, A.w2, F); tile_mma_frag<BM, 3 * D, D>(Aq, LQ, fr_up, acc); }
-        else { tile_gemm<D == 128, BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, true, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc); if constexpr (PF128) wfrag_load(fr_w2, A.w2, F); }
+        else { tile_gemm<D == 128 && BM == 32, BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, true, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc); if constexpr (PF128) wfrag_load(fr_w2, A.w2, F); }
         tile_to_lds<BM, D>(acc, R1, LD, nullptr);
         lds_barrier();
         ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
@@ -656,7 +656,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_w1, A.w1, D); tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); }
         else if constexpr (PF128) { tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); wfrag_load(fr_w1, A.w1, D); }
-        else tile_gemm<D == 128, BM, D, F>(R0, LD, A.w2, F, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
+        else tile_gemm<D == 128 && BM == 32, BM, D, F>(R0, LD, A.w2, F, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
         tile_to_lds<BM, F>(acc, R2, LF, nullptr);
     }
     lds_barrier();
@@ -685,7 +685,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_out, A.out_w, D); tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); }
         else if constexpr (PF128) { tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); wfrag_load(fr_out, A.out_w, D); }
-        else tile_gemm<D == 128, BM, F, D>(R2, LF, A.w1, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
+        else tile_gemm<D == 128 && BM == 32, BM, F, D>(R2, LF, A.w1, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
@@ -707,7 +707,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PFB) tile_mma_frag<BM, D, D>(R1, LD, fr_out, acc);
-        else tile_gemm<D == 128, BM, D, D>(R1, LD, A.out_w, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
+        else tile_gemm<D == 128 && BM == 32, BM, D, D>(R1, LD, A.out_w, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
@@ -1431,7 +1431,7 @@ __device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const
     TileAcc<BM, D> acc;
     tile_zero(acc);
     if constexpr (PFQ) tile_mma_frag<BM, K, D>(As, LDA, f_in, acc);
-    else tile_gemm<D == 128, BM, K, D>(As, LDA, A.W, D, true, A.sp, WSplitGeo<D, 128>::E, 0, acc);
+    else tile_gemm<D == 128 && BM == 32, BM, K, D>(As, LDA, A.W, D, true, A.sp, WSplitGeo<D, 128>::E, 0, acc);
     tile_to_lds<BM, D>(acc, Cs, LDC, nullptr);
     lds_barrier();
     const int c = (threadIdx.x % LPT) * 4;
