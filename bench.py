@@ -555,7 +555,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--steps-per-graph", type=int, default=30, help="whole training steps captured per HIP graph (single GPU)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
-    ap.add_argument("--strong-global-batch", type=int, nargs="*", default=[8192, 32768, 131072],
+    ap.add_argument("--strong-global-batch", type=int, nargs="*", default=[8192, 32768, 131072, 262144],
                     help="fixed GLOBAL batch sizes of the strong-scaling runs reported as `strong` (per-rank batch = global / N)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling runs")
     ap.add_argument("--gather-tokens", type=int, default=16 * 1024 * 1024, help="tokens of the K1 gather microbench")
@@ -605,6 +605,9 @@ def main():
     lib = _lib.load()
 
     def measure(B_arg, steps, warmup, extras, dp=dp, dp_form="host", repeats=None, dp_flat=False):
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()                  # the workspace is sized for B * L tokens (72 GiB at 131 072 rows, 145 GiB at 262 144): hand the previous size's blocks back first
         """one timed run of the training step at B_arg rows per GPU; extras = per-kernel launch times + the K1 gather microbench.
         dp=False under a multi-rank launch: every rank runs the single-GPU step on its own (no collective) — the 1-GPU reference
         of the strong-scaling runs.  dp_form (data parallel): "host" = two graphs around a host-launched all-reduce (the model's
@@ -999,7 +1002,14 @@ def main():
         for G in args.strong_global_batch:
             if G % world or G // world < 1:
                 continue
-            one = tm if (G == 8192 and tm is not None) else measure(G, 20, 5, None, dp=False, repeats=sec_rep)[0]
+            try:
+                one = tm if (G == 8192 and tm is not None) else measure(G, 20, 5, None, dp=False, repeats=sec_rep)[0]
+            except Exception as e:      # noqa: BLE001 — e.g. no room for the 145 GiB workspace of 262 144 rows: the size is skipped on EVERY rank alike
+                one = None              #  (every rank measures the same single-GPU size on an identical device)
+                if rank == 0:
+                    out.setdefault("strong_skipped", []).append({"global_batch": G, "error": "%s: %s" % (type(e).__name__, str(e)[:200])})
+            if one is None:
+                continue
             st_n = one if world == 1 else measure(G // world, max(20, min(100, args.steps)), 10, None, dp=True, repeats=sec_rep)[0]
             strong.append({"global_batch": G, "per_gpu_batch": G // world, "n_gpus": world, "value": st_n["value"], "unit": "sequences/s",
                            "ms_per_step": st_n["ms_per_step"], "ms_per_step_spread": st_n.get("ms_per_step_spread"), "dtype": st_n["dtype"],
