@@ -569,6 +569,7 @@ def main():
                     help="repetitions of the timed region (each exactly --steps steps): ms_per_step = median, ms_per_step_spread = min / max")
     ap.add_argument("--in-graph-timeout", type=int, default=150,
                     help="data parallel: seconds the in-graph-collective attempt (second form) may take before the line is printed without it")
+    ap.add_argument("--no-deterministic-leg", action="store_true", help="skip the extra run of the step in deterministic mode (deterministic_mode)")
     ap.add_argument("--no-dp-leg", action="store_true",
                     help="single GPU: skip the 1-rank RCCL runs of the data-parallel step forms (strong[].dp_1rank_rccl)")
     ap.add_argument("--dp-leg-gpus", type=int, default=8, help="the GPU count whose per-GPU share of each strong-scaling size the 1-rank RCCL leg runs")
@@ -604,7 +605,13 @@ def main():
     from dr4sr_amd.engine import SasrecEngine
     lib = _lib.load()
 
-    def measure(B_arg, steps, warmup, extras, dp=dp, dp_form="host", repeats=None, dp_flat=False):
+    def measure(B_arg, steps, warmup, extras, dp=dp, dp_form="host", repeats=None, dp_flat=False, deterministic=False):
+        if deterministic:                          # fixed summation order (train.deterministic): the library reads the switch when a plan is carved
+            _lib.set_env("DR4SR_DETERMINISTIC", "1")
+            try:
+                return measure(B_arg, steps, warmup, extras, dp=dp, dp_form=dp_form, repeats=repeats, dp_flat=dp_flat)
+            finally:
+                _lib.set_env("DR4SR_DETERMINISTIC", None)
         import gc
         gc.collect()
         torch.cuda.empty_cache()                  # the workspace is sized for B * L tokens (72 GiB at 131 072 rows, 145 GiB at 262 144): hand the previous size's blocks back first
@@ -994,6 +1001,16 @@ def main():
             out["throughput_mode"] = {k: tm[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_spread", "steps", "warmup", "dtype", "config",
                                                           "roofline", "roofline_gather_step", "kernel_us_per_step", "valid_tokens_last_step",
                                                           "roofline_step", "roofline_tile_kernels") if k in tm}
+    if args.model == "sasrec" and not dp and rank == 0 and not args.no_deterministic_leg:
+        # what run-to-run determinism costs at this workload (train.deterministic; the reference sets cudnn.deterministic, utils/utils.py:19):
+        # the same step with every reduction in a fixed order — at-scale launch forms + ordered partial sums in the weight-gradient launch
+        try:
+            dm = measure(args.batch, args.steps, args.warmup, None, dp=False, repeats=sec_rep, deterministic=True)[0]
+            out["deterministic_mode"] = {"value": dm["value"], "unit": dm["unit"], "ms_per_step": dm["ms_per_step"],
+                                         "cost_frac": dm["ms_per_step"] / out["ms_per_step"] - 1.0,
+                                         "note": "train.deterministic / DR4SR_DETERMINISTIC=1: bit-identical parameters run to run (tests/test_gpu_dp.py); opt-in"}
+        except Exception as e:      # noqa: BLE001
+            out["deterministic_mode"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     strong = []
     if args.model == "sasrec" and not args.no_strong and args.embed_dim == 64 and not args.dense and args.batch < 8192:
         # STRONG scaling (north_star: ">= 6x at 8 GPUs"): a FIXED global batch G split over the N ranks (G / N rows per rank per

@@ -47,6 +47,8 @@ struct Workspace {
     int2* tok;                                 // [Tmax] {first token of the token's sequence, sequence slot | sequence length << 20 | PAD << 30}, written by k_embqkv_fwd (attn_tile.h)
     int4* de_ent;                              // [3 Tmax] table-gradient entries of each token tile sorted by owner (linear.hip tile_sort)
     unsigned char* de_off;                     // [Tmax / 32 + 1][1028] start offsets of the owners' buckets inside each tile's entries
+    bool det;                                  // deterministic summation order (DR4SR_DETERMINISTIC): the at-scale forms whatever the size + ordered partial sums in k_wgrad
+    float* det_part; float* det_ln; float* det_dp; int64_t det_stride;     // ... their partial buffers (NULL: mode off)
     unsigned short* wsplit;                    // d = 128 at scale: bf16 hi | lo images of every layer's weights, both orientations (common.h WSplit; k_wsplit)
     int64_t wsplit_E;                          // elements per part and layer (4 D^2 + 2 D F); a layer's block is 4 of them; 0: off
     float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
@@ -164,6 +166,7 @@ struct WgradJob {
     float* dW; float* db;                     // db == NULL: no bias sum from this job (a column block of X: the row block's other job adds it)
     int ldw;                                  // row pitch of dW (0: the job's own KX)
 };
+#define DR4SR_DET_MAX_SPLITS 320              // deterministic mode: token splits the partial buffers are carved for (the launch's cap)
 #define DR4SR_WGRAD_MAX_JOBS 12               // per layer: 6 GEMMs, or their 64 x 64 blocks (d = 64: 4 + 2 F / 64)
 struct WgradArgs {
     WgradJob job[DR4SR_WGRAD_MAX_JOBS * DR4SR_MAX_LAYERS];
@@ -187,6 +190,10 @@ struct WgradArgs {
     // ow_planes are the owner workgroups, owner o = y * gridDim.x + x accumulates the rows {id : id mod 2^ow_logG == o}
     const int4* ow_ent; const unsigned char* ow_off;     // per-tile entries sorted by owner + byte offset tables (k_post_mid's tile_sort); NULL: scan
     int ow_on; const int4* ow_rec; const int* ow_idx32; const float* ow_z; int ow_logG, ow_planes, ow_rpo;     // ow_rec == NULL: no scorer stream (autograd path)
+    // deterministic mode (DR4SR_DETERMINISTIC / train.deterministic; det == NULL: off): every job STORES its partial result — GEMM jobs
+    // [job][token split][det_stride], the LayerNorm reduce blocks [layer][block][4 D], the position-table scatter [block][L D] — and
+    // k_wgrad_det_reduce sums them in a fixed order; the item table is owner-computed as always at scale
+    float* det; int det_stride; float* det_ln; float* det_dp;
 };
 
 // linear_wave.hip: wave-autonomous 16-token tiles with LDS-resident weights (at scale, d = 64 / FFN 128)

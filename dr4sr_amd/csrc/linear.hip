@@ -1535,7 +1535,7 @@ int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int tr
 // flat gradient with 128-B-coalesced fp32 atomics at the end.
 
 template <int NG, int KX>
-__device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A) {
+__device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A, float* __restrict__ part = nullptr) {      // part: wgrad_bf.h
     constexpr int NT = NG / 32, KT = KX / 32, TPW = (NT * KT) / 4;
     static_assert((NT * KT) % 4 == 0, "tile count must split over 4 waves");
     const int T = A.state[DR4SR_STATE_T];
@@ -1626,13 +1626,14 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& J, const WgradArgs& A
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-            unsafeAtomicAdd(J.dW + (size_t)row * (J.ldw ? J.ldw : KX) + kt * 32 + r, acc[i][e]);
+            if (part) part[(size_t)row * KX + kt * 32 + r] = acc[i][e];
+            else unsafeAtomicAdd(J.dW + (size_t)row * (J.ldw ? J.ldw : KX) + kt * 32 + r, acc[i][e]);
         }
     }
 #pragma unroll
     for (int i = 0; i < (NG + 255) / 256; ++i) {
         const int n = threadIdx.x + 256 * i;
-        if (n < NG && J.db) unsafeAtomicAdd(J.db + n, bsum[i]);
+        if (n < NG && J.db) { if (part) part[(size_t)NG * KX + n] = bsum[i]; else unsafeAtomicAdd(J.db + n, bsum[i]); }
     }
 }
 
@@ -1649,7 +1650,8 @@ __device__ __forceinline__ void reduce_jobs(const WgradArgs& A, const int layer)
         float s = 0.f;
         for (int t = blockIdx.x; t < ntiles; t += gridDim.x) s += part[(size_t)t * 4 * D + c];
         const int dstc = c < 2 * D ? c + 2 * D : c - 2 * D;          // partial rows are (ln2, ln1); gradient is (ln1, ln2)
-        if (gridDim.x == 1) g[dstc] += s; else unsafeAtomicAdd(g + dstc, s);
+        if (A.det_ln) A.det_ln[((size_t)layer * gridDim.x + blockIdx.x) * 4 * D + dstc] = s;      // deterministic mode: summed over the blocks in order by k_wgrad_det_reduce
+        else if (gridDim.x == 1) g[dstc] += s; else unsafeAtomicAdd(g + dstc, s);
     }
     if (blockIdx.x == 0 && layer == 0 && A.score_part) {
         __shared__ float red[512];
@@ -1668,9 +1670,36 @@ __device__ __forceinline__ void reduce_jobs(const WgradArgs& A, const int layer)
 
 // a3 backward for large batches: dE[idx[t]] += g[t] (not PAD), dP[pos[t]] += g[t] with g = masked dx0 rows left by
 // k_qkv_embed_bwd.  16 lanes per token; dP accumulates in LDS and is flushed once per workgroup.
+// deterministic position-table gradient: block k owns the sequences [k C, (k + 1) C); thread (position group pg, column c) adds, sequence by
+// sequence in slot order, the masked dx0 rows of the positions pos = pg (mod 256 / D) into register accumulators, and stores them as this
+// block's [L][D] partial (k_wgrad_det_reduce sums the blocks in order).  No search, no atomics; loads coalesced over c.
+template <int D>
+__device__ __forceinline__ void scatter_job_det(const WgradArgs& A) {
+    constexpr int PG = 256 / D, NK = (64 + PG - 1) / PG;
+    const int c = threadIdx.x % D, pg = threadIdx.x / D, C = (A.B + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = min(A.B, (int)blockIdx.x * C), b1 = min(A.B, b0 + C);
+    float acc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int t0 = A.cu[b], n = A.cu[b + 1] - t0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int pos = pg + PG * k;
+            if (pos < n) acc[k] += A.sc_g[(size_t)(t0 + pos) * D + c];
+        }
+    }
+    float* out = A.det_dp + (size_t)blockIdx.x * A.sc_L * D;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int pos = pg + PG * k;
+        if (pos < A.sc_L) out[pos * D + c] = acc[k];
+    }
+}
 template <int D>
 __device__ __forceinline__ void scatter_job(const WgradArgs& A) {
     constexpr int LPT = D / 4, TPB = 256 / LPT;
+    if (A.det_dp) { scatter_job_det<D>(A); return; }
     const int T = A.state[DR4SR_STATE_T], ntiles = (T + 63) / 64;
     if ((int)blockIdx.x >= ntiles) return;
     float* accP = smem;                                   // [L][D]
@@ -1923,16 +1952,18 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvE
     }
     if (j == A.jobs_per_layer) { reduce_jobs(A, layer); return; }
     const WgradJob& J = A.job[layer * A.jobs_per_layer + j];
+    // deterministic mode: this (job, token split)'s partial block instead of atomics into the gradient
+    float* part = A.det ? A.det + ((size_t)(layer * A.jobs_per_layer + j) * gridDim.x + blockIdx.x) * A.det_stride : nullptr;
     if constexpr (SUB) {
-        wgrad_body_bf<64, 64>(J, A.state);       // (DEEP measured: 176 VGPRs -> 2 waves per SIMD again, 88.6 -> 102 us toys, 770 -> 780 us dense)
+        wgrad_body_bf<64, 64>(J, A.state, part);       // (DEEP measured: 176 VGPRs -> 2 waves per SIMD again, 88.6 -> 102 us toys, 770 -> 780 us dense)
     } else if constexpr (BF) {
-        if (j < 4) wgrad_body_bf<D, D>(J, A.state);
-        else if (j == 4) wgrad_body_bf<F, D>(J, A.state);
-        else wgrad_body_bf<D, F>(J, A.state);
+        if (j < 4) wgrad_body_bf<D, D>(J, A.state, part);
+        else if (j == 4) wgrad_body_bf<F, D>(J, A.state, part);
+        else wgrad_body_bf<D, F>(J, A.state, part);
     } else {
-        if (j < 4) wgrad_body<D, D>(J, A);
-        else if (j == 4) wgrad_body<F, D>(J, A);
-        else wgrad_body<D, F>(J, A);
+        if (j < 4) wgrad_body<D, D>(J, A, part);
+        else if (j == 4) wgrad_body<F, D>(J, A, part);
+        else wgrad_body<D, F>(J, A, part);
     }
 }
 template <int D, int F>
@@ -1945,6 +1976,49 @@ __global__ __launch_bounds__(256) void k_wgrad_bf64(const WgradArgs A, const Qkv
 template <int D, int F>
 __global__ __launch_bounds__(256) void k_wgrad_blk(const WgradArgs A, const QkvEmbBwdArgs Q) { wgrad_kernel_body<D, F, false, false, true>(A, Q); }
 
+
+// ---- deterministic mode: the partial results k_wgrad's jobs stored (WgradArgs::det*) summed in a FIXED order into the flat gradient.
+// blockIdx.z = layer of the launch, blockIdx.y = GEMM job | jobs_per_layer: the LayerNorm partials | jobs_per_layer + 1 (plane of the launch's
+// first layer only): the position-table partials.  One thread per gradient element, the token splits / blocks walked in index order:
+// the result is a pure function of the batch.  gw = the k_wgrad launch's grid width, gemm / table: which job kinds that launch carried.
+struct DetDims { short ng[DR4SR_WGRAD_MAX_JOBS], kx[DR4SR_WGRAD_MAX_JOBS]; };
+// sum of n values `stride` floats apart, added in index order (the order IS the contract); eight loads in flight per thread
+__device__ __forceinline__ float det_sum(const float* __restrict__ p, const int n, const size_t stride) {
+    float s = 0.f;
+    int x = 0;
+    for (; x + 8 <= n; x += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(x + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; x < n; ++x) s += p[(size_t)x * stride];
+    return s;
+}
+__global__ __launch_bounds__(256) void k_wgrad_det_reduce(const WgradArgs A, const DetDims dm, const int gw, const int gemm, const int table) {
+    const int layer = A.layer0 + (int)blockIdx.z, j = blockIdx.y, T = A.state[DR4SR_STATE_T];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (j < A.jobs_per_layer) {
+        if (!gemm) return;
+        const WgradJob& J = A.job[layer * A.jobs_per_layer + j];
+        const int NG = dm.ng[j], KX = dm.kx[j], nsplit = min(gw, (T + 63) / 64);
+        if (e >= NG * KX + NG) return;
+        const float* p = A.det + (size_t)(layer * A.jobs_per_layer + j) * gw * A.det_stride + e;
+        if (e >= NG * KX && !J.db) return;
+        const float s = det_sum(p, nsplit, (size_t)A.det_stride);
+        if (e < NG * KX) J.dW[(size_t)(e / KX) * (J.ldw ? J.ldw : KX) + e % KX] += s;
+        else J.db[e - NG * KX] += s;
+    } else if (j == A.jobs_per_layer) {
+        if (!gemm || e >= 4 * A.D) return;
+        const float* p = A.det_ln + (size_t)layer * gw * 4 * A.D + e;
+        const float s = det_sum(p, gw, (size_t)4 * A.D);
+        A.grads[A.o_ln1_w + (size_t)layer * A.layer_stride + e] += s;
+    } else {
+        if (!table || blockIdx.z != 0 || !A.det_dp || e >= A.sc_L * A.D) return;
+        A.sc_dP[e] += det_sum(A.det_dp + e, gw, (size_t)A.sc_L * A.D);
+    }
+}
 
 // ---- FMLP: weight gradients of the Intermediate blocks (dense_1, dense_2) + LayerNorm / scorer partial reductions
 __device__ __forceinline__ void reduce_jobs_fmlp(const WgradArgs& A) {
@@ -2041,6 +2115,7 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
     return DR4SR_LAUNCH_CHECK();
 }
 
+static bool blk_env_on() { const char* e = DR4SR_ENV("DR4SR_WGRAD_BLK"); return e && atoi(e) != 0; }      // (the fp32 64 x 64 block form has no partial outputs)
 bool wgrad_table_jobs(const dr4sr_sasrec_plan* p, const Workspace& ws) { (void)p; return scatter_in_wgrad(ws); }
 
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb, bool meta,
@@ -2135,6 +2210,11 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     const QkvEmbBwdArgs Q = make_qeb_args(p, ws, training);
     size_t lds = sub64 ? wgrad_lds_base(p) : sizeof(float) * 64 * (D + F > 2 * D ? D + F : 2 * D);
     if (scatter && sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;
+    // deterministic mode (Workspace::det): partial buffers instead of atomics + the ordered reduce launch below
+    A.det = nullptr; A.det_ln = nullptr; A.det_dp = nullptr; A.det_stride = 0;
+    if (ws.det && ws.det_part && ws.scale && !blk_env_on()) {
+        A.det = ws.det_part; A.det_stride = (int)ws.det_stride; A.det_ln = ws.det_ln; A.det_dp = scatter ? ws.det_dp : nullptr;
+    }
     A.ow_ent = nullptr; A.ow_off = nullptr;
     A.ow_on = 0; A.ow_rec = nullptr; A.ow_idx32 = nullptr; A.ow_z = nullptr; A.ow_logG = 0; A.ow_planes = 0; A.ow_rpo = 0;
     if (scatter && de_owner_mode(ws)) {
@@ -2150,6 +2230,13 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     const bool blk64 = !A.bf16x3 && (blk_env ? atoi(blk_env) != 0 : !ws.scale);
     const int NY = blk64 ? 4 * (D / 64) * (D / 64) + 2 * (D / 64) * (F / 64) : NJ;
     if (blk64 && !scatter) lds = sizeof(float) * 64 * 128;
+    if (A.det) {                                            // partial blocks must hold this launch's widest job (checked BEFORE anything is written)
+        if (blk64 || gw > DR4SR_DET_MAX_SPLITS) return DR4SR_E_SHAPE;
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int ng = sub64 ? 64 : (jj == 4 ? F : D), kx = sub64 ? 64 : (jj == 5 ? F : D);
+            if (ng * kx + ng > A.det_stride) return DR4SR_E_SHAPE;       // (e.g. DR4SR_WGRAD_WIDE at d = 64: whole jobs do not fit the 64 x 64 partial blocks)
+        }
+    }
     // (a table-only launch has no GEMM / reduce rows: y counts the owner planes and the scatter plane, one z plane)
     dim3 grid(gw, (gemm ? NY + 1 : 0) + (scatter ? 1 : 0) + A.ow_planes, (gemm ? l_hi - l_lo : 1) + A.qeb_plane), blk(256);
     const size_t lds_q = sizeof(float) * (16 * ((3 * D + 4) + (D + 4)) + (size_t)p->L * D + 16);
@@ -2163,5 +2250,18 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     else if (D == 64 && F == 256) WG(64, 256);
     else return DR4SR_E_SHAPE;
 #undef WG
+    if (A.det) {
+        DetDims dm;
+        for (int jj = 0; jj < NJ; ++jj) {
+            if (sub64) { dm.ng[jj] = 64; dm.kx[jj] = 64; }
+            else { dm.ng[jj] = (short)(jj == 4 ? F : D); dm.kx[jj] = (short)(jj == 5 ? F : D); }
+        }
+        int maxe = 4 * D > p->L * D ? 4 * D : p->L * D;
+        for (int jj = 0; jj < NJ; ++jj) {
+            if (dm.ng[jj] * dm.kx[jj] + dm.ng[jj] > maxe) maxe = dm.ng[jj] * dm.kx[jj] + dm.ng[jj];
+        }
+        hipLaunchKernelGGL(k_wgrad_det_reduce, dim3((maxe + 255) / 256, NJ + 2, gemm ? l_hi - l_lo : 1), dim3(256), 0, s, A, dm, gw, gemm ? 1 : 0,
+                           scatter ? 1 : 0);
+    }
     return DR4SR_LAUNCH_CHECK();
 }

@@ -140,6 +140,11 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // runs faster as one 8-wave workgroup per sequence at every size (round 3, all-50 batches: B = 2 048 0.929 vs 0.990 ms,
         // B = 8 192 3.36 vs 3.62 ms), so the lists also need an expected mean length of at most 16 tokens
         ws->attn_split = known ? (hint * D > (int64_t)DR4SR_ATTN_SPLIT_TOKENS * 64 && hint <= 16 * (int64_t)p->B) : at_scale((int)Tmax);
+        // deterministic summation order (DR4SR_DETERMINISTIC=1; Python: train.deterministic): the at-scale forms at every size — their item-table
+        // gradient is owner-computed, their attention has no atomics — with the weight-gradient launch's remaining atomics replaced by
+        // partial buffers summed in a fixed order (linear.hip k_wgrad_det_reduce)
+        ws->det = DR4SR_ENV("DR4SR_DETERMINISTIC") != nullptr && atoi(DR4SR_ENV("DR4SR_DETERMINISTIC")) != 0;
+        if (ws->det) ws->scale = true;
         // tests (cached per process until dr4sr_reload_env(), common.h): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
@@ -168,6 +173,14 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->de_ent = (int4*)take(Tmax * 12); ws->de_off = (unsigned char*)take((Tmax / 16 + 1) * 257);     // [tiles of >= 16 tokens][G + 4 <= 1028 bytes]
     ws->wT_stride = 4 * D * D + 2 * D * F;
     ws->wT = take(ws->wT_stride * p->n_layer);
+    // deterministic mode: partial blocks of the weight-gradient jobs [layer][job][split][stride], LayerNorm [layer][split][4 D], dP [split][L D]
+    ws->det_stride = D == 64 ? 64 * 64 + 64 : (int64_t)(D > F ? D : F) * (D > F ? D : F) + (D > F ? D : F);      // d = 64: 64 x 64 block jobs (k_wgrad_bf64); launch_wgrad refuses wider jobs
+    ws->det_part = nullptr; ws->det_ln = nullptr; ws->det_dp = nullptr;
+    if (ws->det) {
+        ws->det_part = take((int64_t)p->n_layer * DR4SR_WGRAD_MAX_JOBS * DR4SR_DET_MAX_SPLITS * ws->det_stride);
+        ws->det_ln = take((int64_t)p->n_layer * DR4SR_DET_MAX_SPLITS * 4 * D);
+        ws->det_dp = take((int64_t)DR4SR_DET_MAX_SPLITS * p->L * D);
+    }
     // d = 128: split-weight images of the bf16x3 tile GEMMs (common.h WSplit): 2 orientations x (hi | lo) x E bf16 per layer = 2 E floats
     ws->wsplit_E = D == 128 ? ws->wT_stride : 0;
     ws->wsplit = ws->wsplit_E ? reinterpret_cast<unsigned short*>(take(2 * ws->wsplit_E * p->n_layer)) : nullptr;

@@ -23,8 +23,11 @@ __device__ __forceinline__ void wg_pack(const float a, const float b, unsigned& 
 }
 // DEEP: the operand rows of TWO token tiles are in flight (two register sets, the loop unrolled by two): with one set the loads of tile
 // i + 1 fly only during the MFMA phase of tile i (a few hundred cycles) and are waited for right behind it
+// part (deterministic mode, round 5): instead of adding its [NG x KX] partial product and its NG bias sums into the gradient with fp32 atomics
+// — whose arrival order differs from run to run — the workgroup STORES them, row-major + the bias row behind, at `part`; k_wgrad_det_reduce
+// (linear.hip) sums the token splits' blocks in split order.
 template <int NG, int KX, bool DEEP = false>
-__device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const int* __restrict__ state) {
+__device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const int* __restrict__ state, float* __restrict__ part = nullptr) {
     constexpr int NT = NG / 32, KT = KX / 32, TPW = (NT * KT) / 4;
     static_assert((NT * KT) % 4 == 0, "tile count must split over 4 waves");
     const int T = state[DR4SR_STATE_T];
@@ -138,7 +141,8 @@ __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const int* __re
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-            unsafeAtomicAdd(J.dW + (size_t)row * (J.ldw ? J.ldw : KX) + kt * 32 + r, acc[i][e]);
+            if (part) part[(size_t)row * KX + kt * 32 + r] = acc[i][e];
+            else unsafeAtomicAdd(J.dW + (size_t)row * (J.ldw ? J.ldw : KX) + kt * 32 + r, acc[i][e]);
         }
     }
     if (!J.db) return;                                     // (uniform per workgroup)
@@ -154,7 +158,8 @@ __device__ __forceinline__ void wgrad_body_bf(const WgradJob& J, const int* __re
     for (int n = threadIdx.x; n < NG; n += 256) {
         float sum = 0.f;
         for (int pr = 0; pr < 32; ++pr) sum += bl[pr * NG + n];
-        unsafeAtomicAdd(J.db + n, sum);
+        if (part) part[(size_t)NG * KX + n] = sum;
+        else unsafeAtomicAdd(J.db + n, sum);
     }
 }
 

@@ -127,6 +127,12 @@ class BaseModel(nn.Module):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.engine = None                       # set by the subclass (owns item_embedding's storage)
+        # train.deterministic (the reference asks for run-to-run determinism, utils/utils.py:13-20 — seeds + cudnn.deterministic): fixed
+        # summation order in every reduction of the step (csrc/step.hip: DR4SR_DETERMINISTIC — the at-scale launch forms at every batch
+        # size + ordered partial sums in the weight-gradient launch).  Process-wide, like the reference's flag; costs speed (bench.py:
+        # deterministic_mode), not accuracy.
+        if bool(config["train"].get("deterministic", False)) or os.environ.get("DR4SR_DETERMINISTIC", "0") not in ("", "0"):
+            _lib.set_env("DR4SR_DETERMINISTIC", "1")
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ setup
