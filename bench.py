@@ -1008,7 +1008,7 @@ def main():
             dm = measure(args.batch, args.steps, args.warmup, None, dp=False, repeats=sec_rep, deterministic=True)[0]
             out["deterministic_mode"] = {"value": dm["value"], "unit": dm["unit"], "ms_per_step": dm["ms_per_step"],
                                          "cost_frac": dm["ms_per_step"] / out["ms_per_step"] - 1.0,
-                                         "note": "train.deterministic / DR4SR_DETERMINISTIC=1: bit-identical parameters run to run (tests/test_gpu_dp.py); opt-in"}
+                                         "note": "train.deterministic / DR4SR_DETERMINISTIC=1: bit-identical parameters run to run (tests/test_gpu_deterministic.py); opt-in"}
         except Exception as e:      # noqa: BLE001
             out["deterministic_mode"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     strong = []
