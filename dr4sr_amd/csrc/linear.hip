@@ -1929,13 +1929,17 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgradArgs& A, const QkvE
     // the first resident wave would only start when those finish — no overlap
     // (owner planes first, then the dP / atomic scatter plane)
     // (table jobs: plane z = 0 of the launch that carries them — layer 0's unless the data-parallel step moved them, launch_wgrad `table`)
-    const bool tz = (int)blockIdx.z == A.qeb_plane;
-    if (A.ow_on && (int)blockIdx.y < A.ow_planes) {
-        if (tz) { if (A.ow_ent) owner_job_sorted<D>(A, blockIdx.y * gridDim.x + blockIdx.x); else owner_job<D>(A, blockIdx.y * gridDim.x + blockIdx.x); }
-        return;
+    // (the 64 x 64 fp32 block form runs in the latency regime only, where the table gradient is NOT a set of jobs: no owner / scatter code there)
+    int j = (int)blockIdx.y;
+    if constexpr (!BLK) {
+        const bool tz = (int)blockIdx.z == A.qeb_plane;
+        if (A.ow_on && (int)blockIdx.y < A.ow_planes) {
+            if (tz) { if (A.ow_ent) owner_job_sorted<D>(A, blockIdx.y * gridDim.x + blockIdx.x); else owner_job<D>(A, blockIdx.y * gridDim.x + blockIdx.x); }
+            return;
+        }
+        j = (int)blockIdx.y - (A.ow_on ? A.ow_planes : 0) - (A.sc_g ? 1 : 0);
+        if (j < 0) { if (tz) scatter_job<D>(A); return; }
     }
-    const int j = (int)blockIdx.y - (A.ow_on ? A.ow_planes : 0) - (A.sc_g ? 1 : 0);
-    if (j < 0) { if (tz) scatter_job<D>(A); return; }
     if constexpr (BLK) {
         constexpr int RD = D / 64, RF = F / 64, NDD = RD * RD, NB = 4 * NDD + 2 * RD * RF;
         if (j == NB) { reduce_jobs(A, layer); return; }
@@ -2227,7 +2231,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     // fp32 jobs as 64 x 64 blocks cut on the device (k_wgrad_blk) below the at-scale forms: toys B = 256 step 0.1234 -> 0.1221 ms at d = 64
     // (three alternating pairs), 0.2284 -> 0.2152 ms at d = 128 (the [128 x 128] jobs were 42 us of it).  DR4SR_WGRAD_BLK=0: whole jobs
     const char* blk_env = DR4SR_ENV("DR4SR_WGRAD_BLK");
-    const bool blk64 = !A.bf16x3 && (blk_env ? atoi(blk_env) != 0 : !ws.scale);
+    const bool blk64 = !A.bf16x3 && !scatter && (blk_env ? atoi(blk_env) != 0 : !ws.scale);      // (never with table jobs in the launch: k_wgrad_blk has none)
     const int NY = blk64 ? 4 * (D / 64) * (D / 64) + 2 * (D / 64) * (F / 64) : NJ;
     if (blk64 && !scatter) lds = sizeof(float) * 64 * 128;
     if (A.det) {                                            // partial blocks must hold this launch's widest job (checked BEFORE anything is written)
