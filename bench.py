@@ -881,7 +881,7 @@ def main():
             if dtype != "f32" and D == 128 and not os.environ.get("DR4SR_TILE_F32"):
                 dtype = "f32 io (tile GEMMs and weight-gradient GEMMs as bf16x3 split with fp32 accumulation, err 5e-6 per product)"   # round 5
             if args.model == "fmlp":
-                dtype = "f32 (weight-gradient GEMMs as bf16x3 split with fp32 accumulation, err 5e-6)"      # k_fmlp_wgrad_bf64, round 4
+                dtype = "f32 io (Intermediate-block GEMMs and weight-gradient GEMMs as bf16x3 split with fp32 accumulation, err 5e-6 per product)"      # k_fmlp_wgrad_bf64 (round 4), tile GEMMs (round 5)
             if args.model == "gru4rec" and bool(lib.dr4sr_gru4rec_uses_cooperative(min(B, 256), 256)) and B <= 1536:
                 dtype = "f32 io, bf16x3 recurrent and weight-gradient GEMMs with fp32 accumulation (err 2e-6 / 5e-6)"
             out = {

@@ -405,6 +405,26 @@ __host__ __device__ __forceinline__ size_t bf3_frag_off(const int n, const int k
     const int KQ = K / 4, g = k / KQ, rem = k % KQ;
     return ((size_t)((n >> 4) * (KQ / 8) + (rem >> 3)) * 64 + (g * 16 + (n & 15))) * 8 + (rem & 7);
 }
+// one element of a layer's split-weight images (k_wsplit, and the extra blocks of FMLP's prep launch): element e of a part -> its matrix
+// [R][C] (IN 3D x D | OUT D x D | W1 F x D | W2 D x F; o_in < 0: no IN / OUT), bf16 high / low parts into both orientations
+__device__ __forceinline__ void wsplit_elem(const float* __restrict__ params, unsigned short* __restrict__ base, const int e, const int64_t o_in,
+                                            const int64_t o_out, const int64_t o_w1, const int64_t o_w2, const int64_t layer_off, const int E,
+                                            const int D, const int F) {
+    if (e < 4 * D * D && o_in < 0) return;
+    const float* src; int R, C, m_off;
+    if (e < 3 * D * D) { src = params + o_in; R = 3 * D; C = D; m_off = 0; }
+    else if (e < 4 * D * D) { src = params + o_out; R = D; C = D; m_off = 3 * D * D; }
+    else if (e < 4 * D * D + F * D) { src = params + o_w1; R = F; C = D; m_off = 4 * D * D; }
+    else { src = params + o_w2; R = D; C = F; m_off = 4 * D * D + F * D; }
+    const int i = e - m_off, r = i / C, c = i % C;
+    const float v = src[layer_off + i];
+    const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+    const unsigned short hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+    const size_t a = m_off + bf3_frag_off(r, c, C);                           // as stored: N = R rows, K = C
+    base[a] = hb; base[(size_t)E + a] = lb;
+    const size_t t = (size_t)2 * E + m_off + bf3_frag_off(c, r, R);           // transposed: N = C rows, K = R
+    base[t] = hb; base[t + E] = lb;
+}
 template <int BM, int K, int N>
 __device__ __forceinline__ void tile_mma_xwT_bf3(const float* __restrict__ As, int lda, const unsigned short* __restrict__ Wh, const int lo,
                                                  TileAcc<BM, N>& t) {

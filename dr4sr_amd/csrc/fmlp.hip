@@ -35,6 +35,7 @@ struct FmlpWs {
     float* dm_part;                           // [n_layer + 1][FM_DMBLK][L][D] per-block partials of dm, last slab: of dP (summed by k_fmlp_dm_reduce)
     float* ln_wg;                             // [n_layer + 1][FM_DMBLK][2][D] per-block partials of the filter LayerNorms' (last slab: the embedding LayerNorm's) d weight | d bias
     float* score_part; float* ln_part;        // [B][2]; [n_layer][ntiles][4][D]
+    unsigned short* wsplit;                   // bf16 hi | lo images of linear1 / linear2, both orientations, fragment-major (common.h WSplitGeo): 4 E per layer
     FmlpLayerWs layer[DR4SR_MAX_LAYERS];
     int64_t bytes;
 };
@@ -82,6 +83,7 @@ static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
     ws->ln_wg = take((int64_t)(p->n_layer + 1) * FM_DMBLK * 2 * D);
     ws->score_part = take(2LL * p->B);
     ws->ln_part = take((int64_t)p->n_layer * ((Tn + 31) / 32) * 4 * D);        // sized for the smallest FFN tile
+    ws->wsplit = reinterpret_cast<unsigned short*>(take((int64_t)p->n_layer * 2 * (4 * D * D + 2 * D * F)));
     for (int l = 0; l < p->n_layer; ++l) {
         FmlpLayerWs& w = ws->layer[l];
         w.uf = take(Tn * D); w.stf = take(Tn * 2); w.xf = take(Tn * D);
@@ -117,7 +119,11 @@ struct FPrepArgs {
     int* state; int Tn, bump; float* zero; int64_t n4; int zb;
     const float* params; int64_t o_cw0, layer_stride; float* m; float* dm; int L;
     PermSel sel; int64_t* rows; int B;                      // round 4: the batch selection of the fused step (sel.perm == NULL: none)
+    // round 5: FM_SPLIT_BLK more blocks per layer, behind the n_coef_blocks coefficient blocks, write the bf16 hi | lo fragment-major images of
+    // linear1 / linear2 (common.h wsplit_elem; wsplit == NULL: none)
+    unsigned short* wsplit; int64_t o_w1, o_w2; int n_coef_blocks;
 };
+constexpr int FM_SPLIT_BLK = 8;
 __global__ __launch_bounds__(1024) void k_fmlp_prep(const FPrepArgs A) {
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) { A.state[DR4SR_STATE_T] = A.Tn; if (A.bump) A.state[DR4SR_STATE_RNGSTEP] += 1; }
@@ -135,7 +141,16 @@ __global__ __launch_bounds__(1024) void k_fmlp_prep(const FPrepArgs A) {
         return;
     }
     __shared__ float ct[64], sn[64];
-    const int c = blockIdx.x - 1 - A.zb, layer = c / FM_COEF_BLK, L = A.L, K = L / 2 + 1;
+    const int c = blockIdx.x - 1 - A.zb, L = A.L, K = L / 2 + 1;
+    if (c >= A.n_coef_blocks) {                              // split-weight blocks
+        constexpr int E = 4 * FM_D * FM_D + 2 * FM_D * FM_F;
+        const int q = c - A.n_coef_blocks, layer_s = q / FM_SPLIT_BLK;
+        unsigned short* base = A.wsplit + (size_t)layer_s * 4 * E;
+        for (int e = 4 * FM_D * FM_D + (q % FM_SPLIT_BLK) * 1024 + threadIdx.x; e < E; e += FM_SPLIT_BLK * 1024)
+            wsplit_elem(A.params, base, e, -1, -1, A.o_w1, A.o_w2, layer_s * A.layer_stride, E, FM_D, FM_F);
+        return;
+    }
+    const int layer = c / FM_COEF_BLK;
     if ((int)threadIdx.x < L) sincospif(2.0f * threadIdx.x / (float)L, &sn[threadIdx.x], &ct[threadIdx.x]);
     __syncthreads();
     const float* cw = A.params + A.o_cw0 + layer * A.layer_stride;
@@ -530,6 +545,7 @@ __global__ void k_fmlp_last_bwd(const float* __restrict__ dout, float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ orchestration
+static bool fmlp_bf3(const FmlpWs& ws) { return ws.wsplit != nullptr && ffn_tile_rows(ws.Tn) == 32 && !DR4SR_ENV("DR4SR_TILE_F32"); }
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
 static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int zero_grads, hipStream_t s) {
@@ -542,9 +558,15 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
         if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
         sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
     }
+    // 32-row Intermediate kernels (below the at-scale tile size): GEMMs as a bf16x3 split from fragment-major bf16 hi | lo weight images
+    // (round 5: the d = 128 SASRec tile kernels' form, csrc/common.h tile_mma_xwT_bf3; DR4SR_TILE_F32: fp32 MFMA from the parameters); the
+    // images are written by extra blocks of the prep launch (as a launch of its own, k_wsplit: +5 us per step)
+    const bool bf3 = fmlp_bf3(ws);
+    constexpr int FE = 4 * FM_D * FM_D + 2 * FM_D * FM_F;
     const FPrepArgs PA{p->state, ws.Tn, training ? 1 : 0, zero_grads ? p->grads : nullptr, n4, zb,
-                       p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L, sel, const_cast<int64_t*>(p->rows), p->B};
-    hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb + nl * FM_COEF_BLK), dim3(1024), 0, s, PA);
+                       p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L, sel, const_cast<int64_t*>(p->rows), p->B,
+                       bf3 ? ws.wsplit : nullptr, foff(ws, 0, FP_W1), foff(ws, 0, FP_W2), nl * FM_COEF_BLK};
+    hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb + nl * FM_COEF_BLK + (bf3 ? nl * FM_SPLIT_BLK : 0)), dim3(1024), 0, s, PA);
     FEmbArgs E{};
     E.E = p->params + ws.off[0]; E.P = p->params + ws.off[1]; E.lnw = p->params + ws.off[2]; E.lnb = p->params + ws.off[3];
     E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0; E.x0 = ws.X[0];
@@ -567,6 +589,7 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
         A.a = w.a; A.h = w.h; A.u2 = w.u2; A.st2 = w.st2; A.z = ws.X[l + 1];
         A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
         A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr; A.rd = nullptr; A.n_head = 1;
+        A.sp = bf3 ? ws.wsplit + (size_t)l * 4 * FE : nullptr;
         RC(launch_ffn_fwd(A, ws.Tn, s));
     }
     return DR4SR_LAUNCH_CHECK();
@@ -584,6 +607,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         A.ln_part = ws.ln_part + (size_t)l * ntiles * 4 * FM_D;
         A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
         A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr; A.rd = nullptr; A.n_head = 1;
+        A.sp = fmlp_bf3(ws) ? ws.wsplit + (size_t)l * 4 * (4 * FM_D * FM_D + 2 * FM_D * FM_F) : nullptr;      // (written by this step's forward)
         RC(launch_ffn_bwd(A, ws.Tn, s));
         FFiltArgs Fa{};
         Fa.m = ws.m + (size_t)l * L * FM_D; Fa.dm = ws.dm_part + (size_t)l * FM_DMBLK * L * FM_D; Fa.x = ws.X[l];

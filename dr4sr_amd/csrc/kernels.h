@@ -224,7 +224,10 @@ int launch_pack(const dr4sr_sasrec_plan* p, const Workspace& ws, const float* do
 
 int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
 bool tile_bf3(const dr4sr_sasrec_plan* p, const Workspace& ws);              // the 256-thread tile kernels' GEMMs run as a bf16x3 split (d = 128 at scale)
-int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);       // ... from the images this launch writes (once per forward pass)
+int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
+// the same images for any parameter buffer (FMLP's Intermediate blocks: o_in < 0 = no in_proj / out_proj); E = 4 D^2 + 2 D F elements per part
+int launch_wsplit_raw(const float* params, unsigned short* img, int64_t o_in, int64_t o_out, int64_t o_w1, int64_t o_w2, int64_t layer_stride,
+                      int E, int D, int F, int n_layer, hipStream_t s);       // ... from the images this launch writes (once per forward pass)
 int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);
 int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s, const dr4sr_meta_weighting* mw = nullptr);

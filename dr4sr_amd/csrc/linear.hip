@@ -55,21 +55,8 @@ __global__ __launch_bounds__(256) void k_wsplit(const float* __restrict__ params
                                                 int64_t o_w1, int64_t o_w2, int64_t layer_stride, int E, int D, int F) {
     const int layer = blockIdx.y;
     unsigned short* base = img + (size_t)layer * 4 * E;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) {
-        const float* src; int R, C, m_off;                   // matrix [R][C] at element offset m_off of a part
-        if (e < 3 * D * D) { src = params + o_in; R = 3 * D; C = D; m_off = 0; }
-        else if (e < 4 * D * D) { src = params + o_out; R = D; C = D; m_off = 3 * D * D; }
-        else if (e < 4 * D * D + F * D) { src = params + o_w1; R = F; C = D; m_off = 4 * D * D; }
-        else { src = params + o_w2; R = D; C = F; m_off = 4 * D * D + F * D; }
-        const int i = e - m_off, r = i / C, c = i % C;
-        const float v = src[layer * layer_stride + i];
-        const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
-        const unsigned short hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
-        const size_t a = m_off + bf3_frag_off(r, c, C);                           // as stored: N = R rows, K = C (fragment-major, common.h)
-        base[a] = hb; base[(size_t)E + a] = lb;
-        const size_t t = (size_t)2 * E + m_off + bf3_frag_off(c, r, R);           // transposed: N = C rows, K = R
-        base[t] = hb; base[t + E] = lb;
-    }
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256)
+        wsplit_elem(params, base, e, o_in, o_out, o_w1, o_w2, layer * layer_stride, E, D, F);      // common.h
 }
 int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
     const int64_t layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
@@ -79,6 +66,11 @@ int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s
 }
 // the layer's split-weight block, or NULL (fp32 MFMA tile GEMMs).  (The embedding-stage kernels take F = 128 for the block geometry: the
 // only d = 128 shape, step.hip check_shape.)
+int launch_wsplit_raw(const float* params, unsigned short* img, int64_t o_in, int64_t o_out, int64_t o_w1, int64_t o_w2, int64_t layer_stride,
+                      int E, int D, int F, int n_layer, hipStream_t s) {
+    hipLaunchKernelGGL(k_wsplit, dim3(96, n_layer), dim3(256), 0, s, params, img, o_in, o_out, o_w1, o_w2, layer_stride, E, D, F);
+    return DR4SR_LAUNCH_CHECK();
+}
 static const unsigned short* wsplit_of(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer) {
     return (tile_bf3(p, ws) && layer >= 0 && layer < p->n_layer) ? ws.wsplit + (size_t)layer * 4 * ws.wsplit_E : nullptr;
 }
@@ -399,7 +391,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
             TileAcc<BM, D> acc;
             tile_zero(acc);
             if constexpr (PF) tile_mma_frag<BM, D, D>(R0, LD, f_out, acc);
-            else tile_gemm<D == 128 && BM == 32, BM, D, D>(R0, LD, A.out_w, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
+            else tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, D, D>(R0, LD, A.out_w, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
             tile_to_lds<BM, D>(acc, R2, LD, A.out_b);
         }
         lds_barrier(); STAMP(2);
@@ -412,7 +404,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, F> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, D, F>(R1, LD, f_w1, acc);
-        else tile_gemm<D == 128 && BM == 32, BM, D, F>(R1, LD, A.w1, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
+        else tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, D, F>(R1, LD, A.w1, D, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
         tile_to_lds<BM, F>(acc, R2, LF, A.b1);
     }
     lds_barrier(); STAMP(4);
@@ -443,7 +435,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, F, D>(R2, LF, f_w2, acc);
-        else tile_gemm<D == 128 && BM == 32, BM, F, D>(R2, LF, A.w2, F, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
+        else tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, F, D>(R2, LF, A.w2, F, false, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
         tile_to_lds<BM, D>(acc, R0, LD, A.b2);
     }
     lds_barrier(); STAMP(6);
@@ -453,7 +445,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, 3 * D> acc;
         tile_zero(acc);
         if constexpr (PF) tile_mma_frag<BM, D, 3 * D>(R1, LD, f_nx, acc);
-        else tile_gemm<D == 128 && BM == 32, BM, D, 3 * D>(R1, LD, A.nx_in_w, D, false, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc);
+        else tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, D, 3 * D>(R1, LD, A.nx_in_w, D, false, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc);
         tile_to_global<BM, 3 * D>(acc, A.nx_qkv, 3 * D, A.nx_in_b, t0, T);
         if (A.nx_dqkv_zero) zero_kv_rows<BM, D>(A.nx_dqkv_zero, t0, T);
     } else {
@@ -638,7 +630,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_w2, A.w2, F); tile_mma_frag<BM, 3 * D, D>(Aq, LQ, fr_up, acc); }
-        else { tile_gemm<D == 128 && BM == 32, BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, true, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc); if constexpr (PF128) wfrag_load(fr_w2, A.w2, F); }
+        else { tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, 3 * D, D>(Aq, LQ, A.up_in_w, D, true, A.sp ? A.sp + 4 * WSplitGeo<D, F>::E : nullptr, WSplitGeo<D, F>::E, 0, acc); if constexpr (PF128) wfrag_load(fr_w2, A.w2, F); }
         tile_to_lds<BM, D>(acc, R1, LD, nullptr);
         lds_barrier();
         ln_bwd_rowpass<BM, D, 2>(A.up_du1, R1, nullptr, LD, A.u2, A.st2, A.ln2_w, nullptr, R1, A.df, R0, dgam, dbet, t0, T, dodrop, rk, sF);
@@ -656,7 +648,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_w1, A.w1, D); tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); }
         else if constexpr (PF128) { tile_mma_frag<BM, D, F>(R0, LD, fr_w2, acc); wfrag_load(fr_w1, A.w1, D); }
-        else tile_gemm<D == 128 && BM == 32, BM, D, F>(R0, LD, A.w2, F, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
+        else tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, D, F>(R0, LD, A.w2, F, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W2, acc);
         tile_to_lds<BM, F>(acc, R2, LF, nullptr);
     }
     lds_barrier();
@@ -685,7 +677,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_out, A.out_w, D); tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); }
         else if constexpr (PF128) { tile_mma_frag<BM, F, D>(R2, LF, fr_w1, acc); wfrag_load(fr_out, A.out_w, D); }
-        else tile_gemm<D == 128 && BM == 32, BM, F, D>(R2, LF, A.w1, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
+        else tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, F, D>(R2, LF, A.w1, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::W1, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();
@@ -707,7 +699,7 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PFB) tile_mma_frag<BM, D, D>(R1, LD, fr_out, acc);
-        else tile_gemm<D == 128 && BM == 32, BM, D, D>(R1, LD, A.out_w, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
+        else tile_gemm<BM == 32 && (D == 128 || FFN_ONLY), BM, D, D>(R1, LD, A.out_w, D, true, A.sp, WSplitGeo<D, F>::E, WSplitGeo<D, F>::OUT, acc);
         tile_to_lds<BM, D>(acc, R0, LD, nullptr);
     }
     lds_barrier();

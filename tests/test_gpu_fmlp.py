@@ -174,3 +174,36 @@ def test_fmlp_weight_gradient_switches_vs_oracle(env, golden_dir, monkeypatch):
     test_fmlp_encode_fwd_bwd_adam_vs_golden(golden_dir)
     for B in (1, 37):
         test_fmlp_odd_batch_sizes_vs_oracle(B)
+
+
+def test_fmlp_bf16x3_intermediate_kernels_match_fp32_mfma(monkeypatch):
+    """round 5: the Intermediate-block GEMMs as a 3-term bf16 split from fragment-major weight images (csrc/common.h tile_mma_xwT_bf3; images
+    written by extra blocks of k_fmlp_prep) against the fp32-MFMA kernels of the same step (DR4SR_TILE_F32=1): loss and every gradient"""
+    from dr4sr_amd.data.synthetic import make_rows
+    from dr4sr_amd.fmlp_engine import FmlpEngine
+    dev = torch.device("cuda", 0)
+    B, L, N = 256, 50, 997
+    rows = make_rows(n_rows=B, n_items=N, seed=23)
+    hist, sl = torch.from_numpy(rows["in_item_id"]).to(dev), torch.from_numpy(rows["seqlen"]).to(dev)
+    ar = torch.arange(L, device=dev).view(1, -1)
+    shift = (L - sl).view(-1, 1)
+    ids = torch.where(ar >= shift, hist.gather(1, (ar - shift) % L), torch.zeros_like(hist)).contiguous()      # left-padded prefixes
+    tgt = torch.from_numpy(rows["item_id"]).to(dev).gather(1, (sl - 1).clamp(min=0).view(-1, 1)).squeeze(1).contiguous()
+    neg = torch.randint(1, N, (B,), generator=torch.Generator().manual_seed(2)).to(dev)
+    out = {}
+    for f32 in (False, True):
+        if f32:
+            monkeypatch.setenv("DR4SR_TILE_F32", "1")
+        eng = FmlpEngine(N, L, 64, 256, 2, 1e-12, 0.0, B, dev, seed=3, lr=1e-3)
+        g = torch.Generator().manual_seed(5)
+        for k, v in eng.views.items():
+            v.copy_(torch.ones(v.shape) if k.endswith("LayerNorm.weight") else (torch.zeros(v.shape) if k.endswith("bias") else 0.05 * torch.randn(v.shape, generator=g)))
+        eng.views["item_embedding.weight"][0] = 0
+        plan = eng.make_plan(ids, tgt, neg_item=neg, sample_neg=False)
+        eng.fwd_bwd(plan)
+        torch.cuda.synchronize()
+        out[f32] = (eng.loss_and_count(), eng.grads.clone())
+    (l0, n0), g0 = out[False]
+    (l1, n1), g1 = out[True]
+    assert n0 == n1 and abs(l0 - l1) < 1e-5
+    assert float((g0 - g1).abs().max()) <= 5e-5 * float(g1.abs().max())
