@@ -473,6 +473,19 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ As, int lda,
 // with the phases before the GEMM that consumes them.
 template <int K, int N> struct WFragT { float4 b[K / 16][N / 64]; };     // for C += A W^T, W [N][ldw]  (tile_mma_xwT addressing)
 template <int K, int N> struct WFragC { float4 b[K / 16][N / 64]; };     // for C += A W,   W [K][ldw]  (tile_mma_xw addressing)
+// The same fragments from a FRAGMENT-MAJOR fp32 image of the matrix (round 5; latency forms at d = 128): the float4 that lane `lane` of wave w
+// feeds to chunk ci of column tile ct sits at ((ct K/16 + ci) 64 + lane) 4 floats, so a load instruction reads one contiguous 1 KB block
+// (16 full 64-byte sectors) where the row-major addressing below touches 64 sectors (16 rows x 4 lane groups) — the kernels of the latency
+// regime spend microseconds ISSUING their fragment requests (round 4 stamps).  Written by the first launch of the forward pass
+// (linear.hip wfrag_image_write).  Matrix offsets inside a layer's image: WSplitGeo (IN 0 | OUT 3 D^2 | W1 4 D^2 | W2 4 D^2 + F D).
+template <int K, int N>
+__device__ __forceinline__ void wfrag_load_img(WFragT<K, N>& f, const float* __restrict__ img) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int ci = 0; ci < K / 16; ++ci)
+#pragma unroll
+        for (int i = 0; i < N / 64; ++i) f.b[ci][i] = ld4(img + ((size_t)((w + 4 * i) * (K / 16) + ci) * 64 + lane) * 4);
+}
 template <int K, int N>
 __device__ __forceinline__ void wfrag_load(WFragT<K, N>& f, const float* __restrict__ W, int ldw) {
     constexpr int KQ = K / 4;

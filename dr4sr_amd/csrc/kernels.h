@@ -49,6 +49,7 @@ struct Workspace {
     unsigned char* de_off;                     // [Tmax / 32 + 1][1028] start offsets of the owners' buckets inside each tile's entries
     bool det;                                  // deterministic summation order (DR4SR_DETERMINISTIC): the at-scale forms whatever the size + ordered partial sums in k_wgrad
     float* det_part; float* det_ln; float* det_dp; int64_t det_stride;     // ... their partial buffers (NULL: mode off)
+    float* wfrag;                              // d = 128, latency forms: fragment-major fp32 image of every layer's weights, E floats per layer (common.h wfrag_load_img)
     unsigned short* wsplit;                    // d = 128 at scale: bf16 hi | lo images of every layer's weights, both orientations (common.h WSplit; k_wsplit)
     int64_t wsplit_E;                          // elements per part and layer (4 D^2 + 2 D F); a layer's block is 4 of them; 0: off
     float* wT;                                 // transposed weights, per layer: in_wT[D,3D] out_wT[D,D] w1T[D,F] w2T[F,D]
@@ -125,7 +126,8 @@ struct alignas(16) PostArgs {                   // (16: the argument block behin
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
     float* nx_dqkv_zero;                       // ... and the launch that emits layer+1's qkv zeroes the K | V rows of its dqkv (atomics target)
     float* dn_dqkv_zero;                       // backward: the K | V rows of layer-1's dqkv, zeroed by the launch in front of their accumulation
-    const unsigned short* sp;                  // bf16x3 tile GEMMs (d = 128 at scale): this layer's split-weight block, layer + 1's right behind (common.h); NULL: fp32
+    const unsigned short* sp;                  // bf16x3 tile GEMMs (d = 128 at scale): this layer's split-weight block, layer + 1's right behind (common.h); NULL: fp32.
+                                               // Latency forms at d = 128 (16-row tiles): this layer's fragment-major fp32 image instead (as float*; layer + 1's E floats behind)
 };
 
 // layer-0 fusions (linear.hip k_embqkv_fwd / k_qkv_embed_bwd and their wave-tile forms)
@@ -136,7 +138,8 @@ struct EmbQkvArgs {
     int* idx32;                                // optional: the item id whose table row receives this token's gradient (0 = none)
     int2* tok; float* dqkv_zero;               // attention in the tile kernels (attn_tile.h): per-token words out, layer 0's dK | dV rows zeroed
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
-    const unsigned short* sp;                  // layer 0's split-weight block (bf16x3 tile GEMMs), NULL: fp32
+    int wf_layers;                             // latency forms at d = 128: > 0 = this launch also writes the fragment-major fp32 weight images of that many layers to `sp` (wfrag_image_write)
+    const unsigned short* sp;                  // at scale: layer 0's split-weight block (bf16x3 tile GEMMs), NULL: fp32 | latency forms, wf_layers > 0: the fp32 image buffer (as float*)
 };
 struct QkvEmbBwdArgs {
     const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
@@ -226,6 +229,8 @@ int launch_transpose_weights(const dr4sr_sasrec_plan* p, const Workspace& ws, hi
 bool tile_bf3(const dr4sr_sasrec_plan* p, const Workspace& ws);              // the 256-thread tile kernels' GEMMs run as a bf16x3 split (d = 128 at scale)
 int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);
 // the same images for any parameter buffer (FMLP's Intermediate blocks: o_in < 0 = no in_proj / out_proj); E = 4 D^2 + 2 D F elements per part
+int launch_wfrag_write(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s);      // d = 128 latency forms without k_embqkv_fwd (DR4SR_NO_FUSE): the fp32 fragment images
+bool wfrag_img_on(const dr4sr_sasrec_plan* p, const Workspace& ws);
 int launch_wsplit_raw(const float* params, unsigned short* img, int64_t o_in, int64_t o_out, int64_t o_w1, int64_t o_w2, int64_t layer_stride,
                       int E, int D, int F, int n_layer, hipStream_t s);       // ... from the images this launch writes (once per forward pass)
 int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s);

@@ -64,6 +64,14 @@ int launch_wsplit(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s
                        poff(ws, 0, P_W1), poff(ws, 0, P_W2), layer_stride, (int)ws.wsplit_E, p->D, p->F);
     return DR4SR_LAUNCH_CHECK();
 }
+// latency forms at d = 128: the forward GEMMs of k_post_fwd / k_post_mid read their prefetched weight fragments from the fragment-major fp32
+// image (common.h wfrag_load_img) that the first launch of the forward pass writes — k_embqkv_fwd<16, 128>, or k_wfrag_write where that kernel
+// does not run (DR4SR_NO_FUSE).  Measured on one box, B = 256: k_post_fwd 47.1 -> 36.5 us, k_post_mid 63.7 -> 58.8, the writer + 0.5 us:
+// step 0.2369 -> 0.2234 ms (before round 5's other d = 128 work).  At d = 64 the same images gained 1.0 us in k_post_fwd and cost 0.75 us in
+// k_embqkv_fwd: not used there.  No run-time switch between the two load forms inside the kernels: at d = 64 such a switch cost the step 11 %.
+bool wfrag_img_on(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    return p->D == 128 && p->F == 128 && ws.wfrag != nullptr && tile_rows(ws) == 16;
+}
 // the layer's split-weight block, or NULL (fp32 MFMA tile GEMMs).  (The embedding-stage kernels take F = 128 for the block geometry: the
 // only d = 128 shape, step.hip check_shape.)
 int launch_wsplit_raw(const float* params, unsigned short* img, int64_t o_in, int64_t o_out, int64_t o_w1, int64_t o_w2, int64_t layer_stride,
@@ -184,9 +192,44 @@ __device__ __forceinline__ void zero_kv_rows(float* dqkv, const int t0, const in
         if (t0 + r < T) st4(dqkv + (size_t)(t0 + r) * 3 * D + D + c, make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
+// Fragment-major fp32 images (common.h wfrag_load_img) of every layer's four weight matrices, written by the FIRST launch of a forward pass for
+// the launches behind it (latency forms at d = 128; F = 128): item j = one float4 of an image = the four k-consecutive values one lane feeds
+// to one MFMA chunk; 24 576 items per layer, about one per thread of the launch.  The source offsets follow the flat parameter layout
+// (dr4sr_sasrec_param_layout: E is the first tensor, so A.E is the buffer's base and A.W - A.E layer 0's in_proj offset).
+// Only the AS-STORED orientation (the forward GEMMs' WFragT): images of the transposed matrices for the backward's WFragC measured slower.
+template <int D>
+__device__ __forceinline__ void wfrag_image_write(const EmbQkvArgs& A) {
+    constexpr int F = 128, E = 4 * D * D + 2 * D * F, E4 = E / 4;
+    constexpr int64_t LSTR = (int64_t)E + 3 * D + D + F + D + 4 * D;           // weights + in_b, out_b, b1, b2 + the two LayerNorms
+    const int64_t o_in = A.W - A.E, o_out = o_in + 3 * D * D + 3 * D, o_w1 = o_out + D * D + D, o_w2 = o_w1 + F * D + F;
+    float* out = reinterpret_cast<float*>(const_cast<unsigned short*>(A.sp));
+    const int total = A.wf_layers * E4;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+        const int layer = j / E4, q = j % E4, e = 4 * q;
+        int64_t so; int C, m_off;                            // matrix stored [R][C] at element offset m_off of the image
+        if (e < 3 * D * D) { so = o_in; C = D; m_off = 0; }
+        else if (e < 4 * D * D) { so = o_out; C = D; m_off = 3 * D * D; }
+        else if (e < 4 * D * D + F * D) { so = o_w1; C = D; m_off = 4 * D * D; }
+        else { so = o_w2; C = F; m_off = 4 * D * D + F * D; }
+        const int K = C, idx = q - m_off / 4, lane = idx & 63, tq = idx >> 6, ci = tq % (K / 16), ct = tq / (K / 16);
+        const int n = ct * 16 + (lane & 15), k0 = (lane >> 4) * (K / 4) + 4 * ci;
+        st4(out + (size_t)layer * E + e, ld4(A.E + so + layer * LSTR + (size_t)n * C + k0));
+    }
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_wfrag_write(const EmbQkvArgs A) { wfrag_image_write<D>(A); }
+int launch_wfrag_write(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {
+    EmbQkvArgs A{};
+    A.E = p->params + ws.off[0]; A.W = p->params + poff(ws, 0, P_IN_W); A.wf_layers = p->n_layer;
+    A.sp = reinterpret_cast<const unsigned short*>(ws.wfrag);
+    hipLaunchKernelGGL(k_wfrag_write<128>, dim3(64), dim3(256), 0, s, A);
+    return DR4SR_LAUNCH_CHECK();
+}
+
 template <int BM, int D>
 __global__ __launch_bounds__(256) void k_embqkv_fwd(const EmbQkvArgs A) {
     constexpr int N = 3 * D, LDA = D + 4, LPT = D / 4, TPB = 256 / LPT;
+    if constexpr (BM == 16 && D == 128) { if (A.wf_layers > 0) wfrag_image_write<D>(A); }      // every block, before the early exit of tile-less blocks
     const int T = A.state[DR4SR_STATE_T], t0 = xcd_tile(T, BM, A.xcd) * BM;
     if (t0 >= T) return;
     float* As = smem;
@@ -240,7 +283,8 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.W = p->params + poff(ws, 0, P_IN_W); A.bias = p->params + poff(ws, 0, P_IN_B); A.QKV = ws.layer[0].qkv; A.state = p->state;
     A.B = p->B; A.L = p->L; A.n_items = p->n_items; A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.idx32 = de_owner_mode(ws) ? ws.idx32 : nullptr;
-    A.sp = wsplit_of(p, ws, 0);
+    A.sp = wsplit_of(p, ws, 0); A.wf_layers = 0;
+    if (wfrag_img_on(p, ws)) { A.sp = reinterpret_cast<const unsigned short*>(ws.wfrag); A.wf_layers = p->n_layer; }
     const bool in_tile = attn_in_tile(p, ws);
     A.tok = (in_tile || ws.attn_tile_sa) ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
     A.xcd = tile_xcd_order(p, ws) ? 1 : 0;
@@ -351,31 +395,31 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& A, const int t0, c
             if (at_on) {
                 tattn::fwd_issue<D, KEEPQ>(A, t0, T, att_pre);
                 __builtin_amdgcn_sched_barrier(0);
-                wfrag_load(f_out, A.out_w, D);
+                { if constexpr (D == 128) wfrag_load_img(f_out, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::OUT); else wfrag_load(f_out, A.out_w, D); }
                 __builtin_amdgcn_sched_barrier(0);
                 tattn::fwd_stage<D, KEEPQ>(A, t0, T, smem + att_lds_off(D, F), att_pre);
                 __builtin_amdgcn_sched_barrier(0);
-                wfrag_load(f_w1, A.w1, D);
-                wfrag_load(f_w2, A.w2, F);
+                { if constexpr (D == 128) wfrag_load_img(f_w1, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::W1); else wfrag_load(f_w1, A.w1, D); }
+                { if constexpr (D == 128) wfrag_load_img(f_w2, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::W2); else wfrag_load(f_w2, A.w2, F); }
                 __builtin_amdgcn_sched_barrier(0);
                 const tattn::Keep k = tattn::fwd_compute<D, KEEPQ>(A, t0, T, R0, LD, smem + att_lds_off(D, F), att_pre);
                 if (keep_out) *keep_out = k;
                 __builtin_amdgcn_sched_barrier(0);
-                if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+                if (A.nx_qkv) { if constexpr (D == 128) wfrag_load_img(f_nx, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::E); else wfrag_load(f_nx, A.nx_in_w, D); }
             } else {
-                wfrag_load(f_out, A.out_w, D);
-                wfrag_load(f_w1, A.w1, D);
-                wfrag_load(f_w2, A.w2, F);
-                if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+                { if constexpr (D == 128) wfrag_load_img(f_out, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::OUT); else wfrag_load(f_out, A.out_w, D); }
+                { if constexpr (D == 128) wfrag_load_img(f_w1, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::W1); else wfrag_load(f_w1, A.w1, D); }
+                { if constexpr (D == 128) wfrag_load_img(f_w2, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::W2); else wfrag_load(f_w2, A.w2, F); }
+                if (A.nx_qkv) { if constexpr (D == 128) wfrag_load_img(f_nx, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::E); else wfrag_load(f_nx, A.nx_in_w, D); }
             }
         } else {
             constexpr bool EARLY = D == 128;               // (window before the fragments: no register spill at d = 128)
             if constexpr (AT && EARLY) { if (at_on) { tattn::fwd_issue<D, KEEPQ>(A, t0, T, att_pre); __builtin_amdgcn_sched_barrier(0); } }
             if constexpr (PF) {
-                wfrag_load(f_out, A.out_w, D);
-                wfrag_load(f_w1, A.w1, D);
-                wfrag_load(f_w2, A.w2, F);
-                if (A.nx_qkv) wfrag_load(f_nx, A.nx_in_w, D);
+                { if constexpr (D == 128) wfrag_load_img(f_out, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::OUT); else wfrag_load(f_out, A.out_w, D); }
+                { if constexpr (D == 128) wfrag_load_img(f_w1, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::W1); else wfrag_load(f_w1, A.w1, D); }
+                { if constexpr (D == 128) wfrag_load_img(f_w2, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::W2); else wfrag_load(f_w2, A.w2, F); }
+                if (A.nx_qkv) { if constexpr (D == 128) wfrag_load_img(f_nx, reinterpret_cast<const float*>(A.sp) + WSplitGeo<D, F>::E); else wfrag_load(f_nx, A.nx_in_w, D); }
             }
             if constexpr (AT) {
                 if (at_on) {
@@ -1255,6 +1299,7 @@ PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int lay
     if (A.at.on && DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;       // cross-check: every dK | dV row through atomics (no plain stores)
     A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L;
     A.sp = wsplit_of(p, ws, layer);
+    if (wfrag_img_on(p, ws)) A.sp = reinterpret_cast<const unsigned short*>(ws.wfrag + (size_t)layer * ws.wT_stride);
     A.nx_dqkv_zero = (A.at.on && A.nx_qkv) ? ws.layer[layer + 1].dqkv : nullptr;
     A.dn_dqkv_zero = (A.at.on && layer > 0) ? ws.layer[layer - 1].dqkv : nullptr;
     return A;

@@ -181,6 +181,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         ws->det_ln = take((int64_t)p->n_layer * DR4SR_DET_MAX_SPLITS * 4 * D);
         ws->det_dp = take((int64_t)DR4SR_DET_MAX_SPLITS * p->L * D);
     }
+    ws->wfrag = D == 128 ? take(ws->wT_stride * p->n_layer) : nullptr;      // d = 128 latency forms: fp32 fragment-major images (linear.hip wfrag_image_write)
     // d = 128: split-weight images of the bf16x3 tile GEMMs (common.h WSplit): 2 orientations x (hi | lo) x E bf16 per layer = 2 E floats
     ws->wsplit_E = D == 128 ? ws->wT_stride : 0;
     ws->wsplit = ws->wsplit_E ? reinterpret_cast<unsigned short*>(take(2 * ws->wsplit_E * p->n_layer)) : nullptr;
@@ -429,7 +430,7 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
     const bool fuse = DR4SR_ENV("DR4SR_NO_FUSE") == nullptr;     // qkv of layer l>0 is emitted by post_fwd(l-1),
     if (tile_bf3(p, ws)) RC(launch_wsplit(p, ws, s));                // d = 128 at scale: this pass's weights as bf16 hi | lo images
     if (fuse) RC(launch_embqkv_fwd(p, ws, training, s));             // qkv of layer 0 by the embedding gather
-    else RC(launch_embed_fwd(p, ws, training, s));
+    else { RC(launch_embed_fwd(p, ws, training, s)); if (wfrag_img_on(p, ws)) RC(launch_wfrag_write(p, ws, s)); }
     const bool in_tile = attn_in_tile(p, ws);                    // the attention runs at the head of post_fwd / post_mid (attn_tile.h)
     for (int l = 0; l < p->n_layer; ++l) {
         if (!fuse) RC(launch_qkv_fwd(p, ws, l, s));
