@@ -217,3 +217,34 @@ def test_d128_at_scale_bf16x3_tile_gemms_vs_oracle_and_fp32(monkeypatch):
         assert relerr(gv, out[True][1][k].cpu()) < 5e-5, k                          # split vs fp32 MFMA: 5e-6 per product, two layers deep
     assert abs(loss - out[True][0][0]) < 1e-5
     print("d = 128 at scale, bf16x3 tile GEMMs: worst gradient error vs oracle %.2e" % worst)
+
+
+def test_d128_latency_forms_fragment_images_fused_and_unfused(monkeypatch):
+    """d = 128, B = 256 (BASELINE configs[3]'s per-GPU batch): the forward GEMMs of k_post_fwd / k_post_mid read their weight fragments from the
+    fragment-major fp32 image written by the step's first launch — k_embqkv_fwd<16, 128> in the fused step, k_wfrag_write under DR4SR_NO_FUSE
+    (csrc/linear.hip wfrag_image_write).  Both against the ORACLE, and after the parameters CHANGED between two steps (a stale image would
+    reproduce the first step's activations)."""
+    from oracle import sasrec_oracle as O
+    from test_gpu_parity import _random_params, _toys_batch, relerr
+    from dr4sr_amd.engine import SasrecEngine
+    dev = torch.device("cuda", 0)
+    B, D, N = 256, 128, 20034
+    b, N = _toys_batch(B, False, seed=13, n_items=N)
+    for nofuse in (False, True):
+        if nofuse:
+            monkeypatch.setenv("DR4SR_NO_FUSE", "1")
+        params = _random_params(N, D, 128, 2, seed=9)
+        eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, 0.0, B, dev, lr=1e-2)
+        eng.load_named(params)
+        plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev),
+                             neg_item=b["neg_item"].squeeze(-1).contiguous().to(dev), sample_neg=False)
+        eng.train_step(plan)                               # step 1 moves every weight by ~lr
+        eng.fwd_bwd(plan)                                  # step 2's gradients on the UPDATED weights
+        torch.cuda.synchronize()
+        p2 = {k: v.detach().cpu().clone() for k, v in eng.views.items()}
+        p2["query_encoder.item_encoder.weight"] = p2["item_embedding.weight"]
+        loss_o, _, grads_o = O.grads_of(p2, b, 2, 2, 1e-12)
+        loss, n = eng.loss_and_count()
+        assert abs(loss - float(loss_o)) < 5e-5, (nofuse, loss, float(loss_o))
+        for k, gv in eng.normalized_grads().items():
+            assert relerr(gv, grads_o[k]) < 2e-4, (nofuse, k)
