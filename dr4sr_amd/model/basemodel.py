@@ -133,6 +133,10 @@ class BaseModel(nn.Module):
         # deterministic_mode), not accuracy.
         if bool(config["train"].get("deterministic", False)) or os.environ.get("DR4SR_DETERMINISTIC", "0") not in ("", "0"):
             _lib.set_env("DR4SR_DETERMINISTIC", "1")
+            if type(self).__name__ != "SASRec":
+                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order is implemented and tested for the SASRec step "
+                                                 f"(tests/test_gpu_deterministic.py); {type(self).__name__}'s step keeps kernels whose fp32 atomics "
+                                                 "make runs differ in the last bits")
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ setup
