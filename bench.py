@@ -241,6 +241,63 @@ def gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, Hh, NLg, step_s):
                                              "(gemm_in then only runs for layer 1: half the figure above)")
 
 
+def fmlp_kernel_rooflines(lib, _lib, plan, out, T, D, Fh, NL, L, step_s):
+    """FMLP (model/fmlp.py:18-39, module/layers.py:740-807): launch durations of the step's heavy kernels (HIP events on the launch stream,
+    dr4sr_fmlp_launch_kernel on the state the last step left) -> out["roofline"] for the kernel with the largest share of the step, against
+    both roofs; out["roofline_step"]; out["kernel_us_per_step"].  T = B * L: FMLP computes every position of its left-padded rows.
+    Algorithmic work per launch (fp32 words, weights and the filter kernel cache-resident):
+      ffn_fwd   (k_post_fwd<.., FFN_ONLY>)  2 GEMMs 4 T D F flops; in xf [D]; out a, h [F], u2, z [D], LayerNorm statistics [2]
+      ffn_bwd   (k_post_bwd<.., FFN_ONLY>)  2 GEMMs 4 T D F flops; in dz, u2 [D], a [F], statistics; out df, dxf [D], da [F]
+      wgrad     (k_fmlp_wgrad_bf64)         2 GEMMs per layer 4 T D F flops; operands da, h [F], df, xf [D] per layer
+      filter_fwd / _bwd                     circular convolution along the sequence on the VALU: 2 T L D flops (x 2 backward: dx and dm);
+                                            in x [D]; out uf, xf [D] (backward: in dxf, x, uf; out dx)"""
+    def launch(kid, layer):
+        _lib.check(lib.dr4sr_fmlp_launch_kernel(C.byref(plan), kid, layer, _lib.cur_stream()), "fmlp_launch_kernel")
+    work = {"ffn_fwd": (4.0 * T * D * Fh, 4.0 * T * (3 * D + 2 * Fh + 2), NL, True),
+            "ffn_bwd": (4.0 * T * D * Fh, 4.0 * T * (4 * D + 2 * Fh + 2), NL, True),
+            "wgrad": (4.0 * T * D * Fh * NL, 4.0 * T * (2 * D + 2 * Fh) * NL, 1, True),
+            "filter_fwd": (2.0 * T * L * D, 4.0 * T * 3 * D, NL, False),
+            "filter_bwd": (4.0 * T * L * D, 4.0 * T * 4 * D, NL, False)}
+    ktime, reps = {}, 30
+    for name in work:
+        kid, tot = _lib.FMLP_KERNEL_IDS[name], 0.0
+        layers = range(NL) if work[name][2] > 1 else (0,)
+        for layer in layers:
+            for _ in range(3):
+                launch(kid, layer)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                launch(kid, layer)
+            b.record()
+            b.synchronize()
+            tot += a.elapsed_time(b) * 1e3 / reps
+        ktime[name] = tot / len(layers)                      # us per launch, mean over the layers
+    step_us = {k: v * work[k][2] for k, v in ktime.items()}
+    dom = max(step_us, key=step_us.get)
+    fl, by, nl_, mfma = work[dom]
+    tf, gbs = fl / (ktime[dom] * 1e-6) / 1e12, by / (ktime[dom] * 1e-6) / 1e9
+    kname = {"ffn_fwd": "k_post_fwd<32, 64, 256, true>", "ffn_bwd": "k_post_bwd<32, 64, 256, true>", "wgrad": "k_fmlp_wgrad_bf64",
+             "filter_fwd": "k_fmlp_filter_fwd", "filter_bwd": "k_fmlp_filter_bwd"}[dom]
+    hbm_bound = gbs / HBM_PEAK_GBS >= tf / MFMA_F32_PEAK_TF or not mfma
+    out["roofline"] = {"kernel": kname, "bound": "hbm" if hbm_bound else "mfma",
+                       "achieved": gbs if hbm_bound else tf, "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F32_PEAK_TF,
+                       "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": gbs / HBM_PEAK_GBS if hbm_bound else tf / MFMA_F32_PEAK_TF,
+                       "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_f32_frac": tf / MFMA_F32_PEAK_TF if mfma else None,
+                       "traffic": None, "traffic_source": None, "us_per_launch": ktime[dom], "launches_per_step": nl_,
+                       "flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+                       "note": "the flops are the fp32 problem's; the GEMMs run as a bf16x3 split (3 matrix instructions per product) and are "
+                               "priced against the fp32 MFMA peak, like the SASRec kernels"}
+    tot_fl = 3.0 * NL * 4.0 * T * D * Fh + 3.0 * NL * 2.0 * T * L * D
+    out["roofline_step"] = {"bound": "mfma", "achieved": tot_fl / step_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": tot_fl / step_s / 1e12 / MFMA_F32_PEAK_TF, "flops_per_step": tot_fl,
+                            "note": "3 x (Intermediate GEMMs + the filter's circular convolution) on all B * L positions"}
+    out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
+    out["roofline_kernels"] = {k: {"us_per_launch": round(ktime[k], 2), "hbm_frac": round(work[k][1] / (ktime[k] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "mfma_f32_frac": round(work[k][0] / (ktime[k] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4) if work[k][3] else None,
+                                   "algorithmic_bytes": work[k][1]} for k in work}
+
+
 def cpu_baseline_leg(rows_np, N, model_kind, p, interval=30):
     """the reference-equivalent CPU step (oracle/ref_trainer.py) on this box's host cores.  torch's default (all
     cores) is the slowest choice for these microsecond-sized ops on a 128-core host, so 8 / 16 / 32 intra-op threads are probed and
@@ -263,6 +320,10 @@ def cpu_baseline_leg(rows_np, N, model_kind, p, interval=30):
     what = {"sasrec": "nn.TransformerEncoder, multinomial sampler, per-sample DataLoader, Adam",
             "gru4rec": "torch.nn.GRU(bias=False, 2 x 256) behind Dropout(0.2), multinomial sampler, per-sample DataLoader, Adam(weight_decay 1e-4) "
                        "(model/gru4rec.py:12-34, module/layers.py:117-136)",
+            "fmlp": "Embedding + position -> LayerNorm -> Dropout(0.5) -> 2 x (torch.fft.rfft / irfft filter, Intermediate 64 -> 256 -> 64), last "
+                    "position as the query, one target + one multinomial negative per left-padded row, Adam (model/fmlp.py:8-39, module/layers.py:740-807)",
+            "cl4srec": "SASRec step + two item_random views per step (crop / mask / reorder applied row by row on the host, as "
+                       "module/data_augmentation.py:20-95) -> encoder -> mean pooling -> InfoNCE batch_both, cl_weight 0.1 (model/cl4srec.py:49-73)",
             "metamodel": "SASRec sub-model + gumbel-softmax selection MLP weighting every step, Hypergrad.grad (double backward, 3 Neumann terms) "
                          "+ clip + SGD every %d steps (model/metamodel.py:95-194, utils/utils.py:134-252); %d outer steps fell into the window"
                          % (interval, r.get("outer_steps", 0))}[model_kind]
@@ -489,7 +550,42 @@ def bench_cl4srec(args):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         form = "API path replayed as one HIP graph per step" if graph else "API path, eager" 
+    extra = {}
+    if not args.no_kernel_roofline:
+        # roofline of the dominant launch, measured live: the launches of the MAIN pass (the batch's SASRec step, one of the step's three
+        # encoder passes; the views run the same kernels on 2B shorter rows) re-enqueued one by one on the state a fwd_bwd of one
+        # materialised batch leaves in the workspace, HIP events on the launch stream
+        from dr4sr_amd import _lib
+        eng = model.engine
+        b0 = dict(batches[0])
+        b0["neg_item"] = model._neg_sampling(b0)
+        plan = model._batch_plan(b0)
+        eng.fwd_bwd(plan)
+        torch.cuda.synchronize()
+        sl = b0["seqlen"].clamp(0, eng.L).cpu().numpy()
+        sasrec_kernel_rooflines(eng.lib, _lib, plan, None, extra, args, int(sl.shape[0]), eng.L, eng.D, eng.F, eng.n_layer, int(sl.sum()), sl,
+                                max(1, min(args.steps_per_graph, args.steps)), wall / args.steps, dev)
+        # the whole step's flops: + the two views' encoder passes (forward + backward) on the lengths one draw gives them
+        aug = model.augmentation_model.augmentation
+        if hasattr(aug, "begin_step"):
+            aug.begin_step()
+        (_, li), (_, lj) = aug.two_views(b0["in_" + model.fiid], b0["seqlen"]) if hasattr(aug, "two_views") else (aug(b0["in_" + model.fiid], b0["seqlen"]), aug(b0["in_" + model.fiid], b0["seqlen"]))
+        vl = torch.cat([li, lj]).clamp(0, eng.L).cpu().numpy().astype(np.float64)
+        D_, F_, NL_ = eng.D, eng.F, eng.n_layer
+        view_fl = 3.0 * NL_ * (2 * D_ * 3 * D_ + 2 * D_ * D_ + 4 * D_ * F_) * float(vl.sum()) + 3.5 * NL_ * 2 * 2 * D_ * float((vl * (vl + 1) / 2).sum())
+        rs = extra["roofline_step"]
+        tot = rs["flops_per_step"] + view_fl
+        rs.update({"flops_per_step": tot, "achieved": tot / (wall / args.steps) / 1e12, "frac": tot / (wall / args.steps) / 1e12 / MFMA_F32_PEAK_TF,
+                   "note": "main pass + the two views' encoder passes (one draw's lengths: %d + %d tokens); InfoNCE's 2 B x 2 B similarity not counted"
+                           % (int(sl.sum()), int(vl.sum()))})
+        extra["kernel_us_per_step"]["note"] = "launches of the MAIN pass only (one of three encoder passes per step)"
+        extra["roofline"].update({"traffic": None, "traffic_source": None})      # (the committed PMC passes are of the plain SASRec step)
+    if not args.no_cpu_baseline:
+        from dr4sr_amd.data.synthetic import make_rows
+        extra["cpu_baseline"] = cpu_baseline_leg(make_rows(n_items=model.engine.n_items - 1, seed=2024, dense=args.dense), model.engine.n_items - 1,
+                                                 "cl4srec", args.dropout)
     emit({
+        **extra,
         "metric": "training sequences/sec, CL4SRec d=64 L=50", "value": args.batch * args.steps / wall, "unit": "sequences/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -553,6 +649,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true", help="cl4srec: skip the per-launch timing of the main pass")
     ap.add_argument("--steps-per-graph", type=int, default=30, help="whole training steps captured per HIP graph (single GPU)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra B=8192 run reported as `throughput_mode`")
     ap.add_argument("--strong-global-batch", type=int, nargs="*", default=[8192, 32768, 131072, 262144],
@@ -903,6 +1000,8 @@ def main():
 
             if rank == 0 and args.model == "gru4rec" and extras:
                 gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, 256, 2, wall / steps)
+            if rank == 0 and args.model == "fmlp" and extras:
+                fmlp_kernel_rooflines(lib, _lib, plan, out, B * L, 64, 256, 2, L, wall / steps)
             if rank == 0 and args.model == "sasrec" and extras:
                 # ---- per-kernel launch durations, HIP events on the launch stream, on the state of the last step
                 seqlen_last = data["seqlen"][rows_buf].clamp(0, L).cpu().numpy()
@@ -1037,7 +1136,7 @@ def main():
                            "allreduce_us_standalone": st_n.get("allreduce_us_standalone")})
         if rank == 0:
             out["strong"] = strong
-    if rank == 0 and not dp and not args.no_cpu_baseline and args.model in ("sasrec", "gru4rec"):
+    if rank == 0 and not dp and not args.no_cpu_baseline and args.model in ("sasrec", "gru4rec", "fmlp"):
         out["cpu_baseline"] = cpu_baseline_leg(rows_np, N, args.model, 0.2 if args.model == "gru4rec" else args.dropout)
 
     # ---- single GPU: what the DATA-PARALLEL form of the step costs beyond the single-GPU step, measured with the one RCCL rank a 1-GPU

@@ -70,6 +70,8 @@ KERNEL_IDS = {"prep": 0, "embed_fwd": 1, "qkv_fwd": 2, "attn_fwd": 3, "post_fwd"
               "post_bwd": 7, "attn_bwd": 8, "qkv_bwd": 9, "embed_bwd": 10, "wgrad": 11, "adam": 12, "zero_grads": 13,
               "embqkv_fwd": 14, "post_mid": 15, "qkv_embed_bwd": 16, "wgrad_fused": 17}
 
+FMLP_KERNEL_IDS = {"filter_fwd": 0, "ffn_fwd": 1, "ffn_bwd": 2, "filter_bwd": 3, "wgrad": 4}      # DR4SR_FK_* (include/dr4sr_hip_hooks.h)
+
 _f32p = C.c_void_p
 _i64p = C.c_void_p
 
@@ -203,6 +205,7 @@ SYMBOLS = {
     "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_launch_kernel_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_gru4rec_launch_kernel": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, C.c_void_p]),
+    "dr4sr_fmlp_launch_kernel": (C.c_int, [_FPLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_meta_param_count": (C.c_int64, [C.c_int32]),
     "dr4sr_meta_select_workspace_floats": (C.c_int64, [C.c_int64]),
     "dr4sr_meta_select_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, _i64p, _i64p, C.c_int64, C.c_int32,

@@ -548,8 +548,10 @@ __global__ void k_fmlp_last_bwd(const float* __restrict__ dout, float* __restric
 static bool fmlp_bf3(const FmlpWs& ws) { return ws.wsplit != nullptr && ffn_tile_rows(ws.Tn) == 32 && !DR4SR_ENV("DR4SR_TILE_F32"); }
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
-static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int zero_grads, hipStream_t s) {
+// `only` >= 0 (measurement hook dr4sr_fmlp_launch_kernel): just that launch (DR4SR_FK_*) of layer `only_layer`, on the state the last step left
+static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int zero_grads, hipStream_t s, int only = -1, int only_layer = 0) {
     const int L = p->L, nl = p->n_layer;
+    const bool all = only < 0;
     const int64_t n4 = zero_grads ? (ws.n_params + DR4SR_GRAD_TAIL) / 4 : 0;
     int zb = (int)((n4 + 1023) / 1024); if (zb > 255) zb = 255;
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
@@ -566,13 +568,13 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
     const FPrepArgs PA{p->state, ws.Tn, training ? 1 : 0, zero_grads ? p->grads : nullptr, n4, zb,
                        p->params, foff(ws, 0, FP_CW), lstride, ws.m, ws.dm, L, sel, const_cast<int64_t*>(p->rows), p->B,
                        bf3 ? ws.wsplit : nullptr, foff(ws, 0, FP_W1), foff(ws, 0, FP_W2), nl * FM_COEF_BLK};
-    hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb + nl * FM_COEF_BLK + (bf3 ? nl * FM_SPLIT_BLK : 0)), dim3(1024), 0, s, PA);
+    if (all) hipLaunchKernelGGL(k_fmlp_prep, dim3(1 + zb + nl * FM_COEF_BLK + (bf3 ? nl * FM_SPLIT_BLK : 0)), dim3(1024), 0, s, PA);
     FEmbArgs E{};
     E.E = p->params + ws.off[0]; E.P = p->params + ws.off[1]; E.lnw = p->params + ws.off[2]; E.lnb = p->params + ws.off[3];
     E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0; E.x0 = ws.X[0];
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
     int eb = (ws.Tn + 15) / 16; if (eb > 2048) eb = 2048;
-    hipLaunchKernelGGL(k_fmlp_embed_fwd, dim3(eb), dim3(256), 0, s, E);
+    if (all) hipLaunchKernelGGL(k_fmlp_embed_fwd, dim3(eb), dim3(256), 0, s, E);
     for (int l = 0; l < nl; ++l) {
         const FmlpLayerWs& w = ws.layer[l];
         FFiltArgs Fa{};
@@ -581,7 +583,7 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
         Fa.uf = w.uf; Fa.stf = w.stf; Fa.xf = w.xf; Fa.B = p->B; Fa.L = L; Fa.eps = p->ln_eps; Fa.state = p->state; Fa.seed = p->seed;
         Fa.p = p->p_drop; Fa.training = training; Fa.site = FS_FILT(l);
         const size_t lds = sizeof(float) * 3 * L * FM_D;
-        hipLaunchKernelGGL(k_fmlp_filter_fwd, dim3(p->B), dim3(256), lds, s, Fa);
+        if (all || (only == DR4SR_FK_FILTER_FWD && l == only_layer)) hipLaunchKernelGGL(k_fmlp_filter_fwd, dim3(p->B), dim3(256), lds, s, Fa);
         PostArgs A{};
         A.x = w.xf; A.w1 = p->params + foff(ws, l, FP_W1); A.b1 = p->params + foff(ws, l, FP_B1);
         A.w2 = p->params + foff(ws, l, FP_W2); A.b2 = p->params + foff(ws, l, FP_B2);
@@ -590,13 +592,14 @@ static int fmlp_forward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training
         A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
         A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr; A.rd = nullptr; A.n_head = 1;
         A.sp = bf3 ? ws.wsplit + (size_t)l * 4 * FE : nullptr;
-        RC(launch_ffn_fwd(A, ws.Tn, s));
+        if (all || (only == DR4SR_FK_FFN_FWD && l == only_layer)) RC(launch_ffn_fwd(A, ws.Tn, s));
     }
     return DR4SR_LAUNCH_CHECK();
 }
 
-static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int with_score, hipStream_t s) {
+static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int training, int with_score, hipStream_t s, int only = -1, int only_layer = 0) {
     const int L = p->L, nl = p->n_layer;
+    const bool all = only < 0;
     const int bm = ffn_tile_rows(ws.Tn), ntiles = (ws.Tn + bm - 1) / bm;
     for (int l = nl - 1; l >= 0; --l) {
         const FmlpLayerWs& w = ws.layer[l];
@@ -608,7 +611,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.eps = p->ln_eps; A.layer = l; A.training = training;
         A.sP = 0xffffffffu; A.sA = 0xffffffffu; A.sF = FS_FFN(l); A.stamps = nullptr; A.rd = nullptr; A.n_head = 1;
         A.sp = fmlp_bf3(ws) ? ws.wsplit + (size_t)l * 4 * (4 * FM_D * FM_D + 2 * FM_D * FM_F) : nullptr;      // (written by this step's forward)
-        RC(launch_ffn_bwd(A, ws.Tn, s));
+        if (all || (only == DR4SR_FK_FFN_BWD && l == only_layer)) RC(launch_ffn_bwd(A, ws.Tn, s));
         FFiltArgs Fa{};
         Fa.m = ws.m + (size_t)l * L * FM_D; Fa.dm = ws.dm_part + (size_t)l * FM_DMBLK * L * FM_D; Fa.x = ws.X[l];
         Fa.lnw = p->params + foff(ws, l, FP_FLN_W); Fa.uf = w.uf; Fa.stf = w.stf;
@@ -618,19 +621,19 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
         const size_t lds = sizeof(float) * (5 * L * FM_D + 32 * FM_D);
         big_lds(k_fmlp_filter_bwd, lds);
         const int gb = p->B < FM_DMBLK ? p->B : FM_DMBLK;
-        hipLaunchKernelGGL(k_fmlp_filter_bwd, dim3(gb), dim3(256), lds, s, Fa);
+        if (all || (only == DR4SR_FK_FILTER_BWD && l == only_layer)) hipLaunchKernelGGL(k_fmlp_filter_bwd, dim3(gb), dim3(256), lds, s, Fa);
     }
     FEmbArgs E{};
     E.lnw = p->params + ws.off[2]; E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0;
     E.dx0 = ws.dX[0]; E.dE = p->grads + ws.off[0]; E.dP = ws.dm_part + (size_t)nl * FM_DMBLK * L * FM_D; E.ln_wg = ws.ln_wg + (size_t)nl * FM_DMBLK * 2 * FM_D;
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
-    hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < FM_DMBLK ? p->B : FM_DMBLK), dim3(256), 0, s, E);    // one dP partial per workgroup
+    if (all) hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < FM_DMBLK ? p->B : FM_DMBLK), dim3(256), 0, s, E);    // one dP partial per workgroup
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
     FDmRedArgs R{};
     R.part = ws.dm_part; R.dm = ws.dm; R.dP = p->grads + ws.off[1]; R.ln_wg = ws.ln_wg; R.grads = p->grads;
     R.o_fln_w = foff(ws, 0, FP_FLN_W); R.o_fln_b = foff(ws, 0, FP_FLN_B); R.layer_stride = lstride; R.o_eln_w = ws.off[2]; R.o_eln_b = ws.off[3];
     R.nblk = p->B < FM_DMBLK ? p->B : FM_DMBLK; R.n = L * FM_D; R.n_layer = nl; R.nx = (L * FM_D + 63) / 64;
-    hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3(R.nx + 2, nl + 1), dim3(256), 0, s, R);
+    if (all) hipLaunchKernelGGL(k_fmlp_dm_reduce, dim3(R.nx + 2, nl + 1), dim3(256), 0, s, R);
     WgradArgs W{};
     for (int l = 0; l < nl; ++l) {
         const FmlpLayerWs& w = ws.layer[l];
@@ -646,7 +649,7 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     W.o_ln1_w = foff(ws, 0, FP_ILN_W); W.layer_stride = lstride;
     W.score_part = with_score ? ws.score_part : nullptr; W.tail = p->grads + ws.n_params; W.B = p->B; W.D = FM_D;
     W.fc_dm = ws.dm; W.fc_o_cw = foff(ws, 0, FP_CW); W.fc_L = L;      // d(complex_weight) = fold(dm) rides in the reduce blocks
-    RC(launch_fmlp_wgrad(W, ws.Tn, nl, s));
+    if (all || only == DR4SR_FK_WGRAD) RC(launch_fmlp_wgrad(W, ws.Tn, nl, s));
     return DR4SR_LAUNCH_CHECK();
 }
 
@@ -660,6 +663,19 @@ extern "C" int dr4sr_fmlp_fwd_bwd(const dr4sr_fmlp_plan* plan, void* stream) {
                        plan->grads + ws.off[0], ws.dX[plan->n_layer], plan->item_id, plan->rows, plan->neg_item, plan->sample_neg,
                        ws.score_part, plan->state, plan->seed, plan->n_items, plan->B, plan->L);
     return fmlp_backward(plan, ws, 1, 1, s);
+}
+
+// measurement hook (include/dr4sr_hip_hooks.h): ONE launch of the step on the workspace the last dr4sr_fmlp_fwd_bwd left
+extern "C" int dr4sr_fmlp_launch_kernel(const dr4sr_fmlp_plan* plan, int32_t kernel, int32_t layer, void* stream) {
+    FmlpWs ws;
+    RC(fmlp_ws(plan, &ws));
+    if (!plan->grads || layer < 0 || layer >= plan->n_layer) return DR4SR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (kernel) {
+        case DR4SR_FK_FILTER_FWD: case DR4SR_FK_FFN_FWD: return fmlp_forward(plan, ws, 1, 0, s, kernel, layer);
+        case DR4SR_FK_FFN_BWD: case DR4SR_FK_FILTER_BWD: case DR4SR_FK_WGRAD: return fmlp_backward(plan, ws, 1, 1, s, kernel, layer);
+        default: return DR4SR_E_ARG;
+    }
 }
 
 extern "C" int dr4sr_adam_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, int32_t* state,

@@ -59,6 +59,16 @@ int dr4sr_sasrec_launch_kernel_weighted(const dr4sr_sasrec_plan* plan, const dr4
 #define DR4SR_GK_WAVE_BWD 4
 int dr4sr_gru4rec_launch_kernel(const dr4sr_gru4rec_plan* plan, int32_t kernel, int32_t layer, void* stream);
 
+/* FMLP step (model/fmlp.py:18-39, module/layers.py:740-807): the filter layer (FFT-free circular convolution with the learned
+ * complex weight, LayerNorm, dropout) and the Intermediate block (linear 64 -> 256, GELU, linear 256 -> 64, dropout, LayerNorm) of one
+ * layer, forward and backward, and the weight-gradient launch of the step (`layer` ignored) */
+#define DR4SR_FK_FILTER_FWD 0
+#define DR4SR_FK_FFN_FWD    1
+#define DR4SR_FK_FFN_BWD    2
+#define DR4SR_FK_FILTER_BWD 3
+#define DR4SR_FK_WGRAD      4
+int dr4sr_fmlp_launch_kernel(const dr4sr_fmlp_plan* plan, int32_t kernel, int32_t layer, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,11 +19,23 @@ Round 3 — the other two BASELINE workloads that bench.py times get the same ki
                                                      64->64->2 MLP on the query rows, pattern rows -> 1, PAD -> 0) and, every
                                                      `interval` steps, the outer loop: Hypergrad.grad (Neumann series by double backward,
                                                      truncate_iter 3, hpo_lr 1e-3) -> clip_grad_norm_(10) -> SGD(momentum 0.9)
+
+Round 5 — the two remaining workloads bench.py times:
+  model/fmlp.py:8-39, module/layers.py:740-807       RefLikeFMLP: Embedding + position -> LayerNorm -> Dropout(0.5) -> 2 x (FilterLayer by
+                                                     torch.fft.rfft / irfft 'ortho' with a complex weight, Intermediate 64 -> 256 -> 64) ->
+                                                     the LAST position as the query; one target and one negative per row (basemodel.py:50-61)
+  model/cl4srec.py:28-73, module/data_augmentation.py:20-95, :305-350, :577-619
+                                                     RefLikeCL4SRec: SASRec with one more table row (the mask item) + two 'item_random' views
+                                                     per step (ONE of crop / mask / reorder drawn per view for the whole batch, applied row by
+                                                     row in Python, as the reference does) -> encoder -> mean pooling -> InfoNCE 'batch_both',
+                                                     rows of length 1 dropped; loss = BCE + cl_weight x InfoNCE
 """
 from __future__ import annotations
 
+import random
 import time
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -54,13 +66,17 @@ class QueryEncoder(nn.Module):
         self.transformer_layer = nn.TransformerEncoder(encoder_layer=layer, num_layers=n_layer)
         self.dropout = nn.Dropout(p=p)
 
-    def forward(self, batch, training_pool=True):
+    def encode(self, batch):                                # need_pooling=False (model/sasrec.py:69-70): every position's output
         hist = batch["in_item_id"]
         L = hist.size(1)
         pos = torch.arange(L, dtype=torch.long).unsqueeze(0).expand_as(hist)
         x = self.item_encoder(hist) + self.position_emb(pos)
         causal = torch.triu(torch.ones((L, L), dtype=torch.bool), 1)
-        out = self.transformer_layer(src=self.dropout(x), mask=causal, src_key_padding_mask=hist == 0)
+        return self.transformer_layer(src=self.dropout(x), mask=causal, src_key_padding_mask=hist == 0)
+
+    def forward(self, batch, training_pool=True):
+        out = self.encode(batch)
+        L = out.size(1)
         if training_pool:                                   # SeqPoolingLayer('origin')
             m = torch.arange(L).unsqueeze(0).unsqueeze(2).expand(out.size(0), -1, out.size(2))
             return out.masked_fill(m >= batch["seqlen"].view(-1, 1, 1), 0.0)
@@ -142,6 +158,160 @@ class RefLikeGRU4Rec(nn.Module):
         return (loss, q) if return_query else loss
 
 
+class _FmlpFilter(nn.Module):
+    """module/layers.py:745-763: learnable complex weight [1, L // 2 + 1, D] applied in the frequency domain along the sequence"""
+
+    def __init__(self, L, D, p, eps):
+        super().__init__()
+        self.complex_weight = nn.Parameter(torch.randn(1, L // 2 + 1, D, 2) * 0.02)
+        self.out_dropout = nn.Dropout(p)
+        self.LayerNorm = nn.LayerNorm(D, eps=eps)
+
+    def forward(self, x):
+        spec = torch.fft.rfft(x, dim=1, norm="ortho") * torch.view_as_complex(self.complex_weight)
+        y = torch.fft.irfft(spec, n=x.size(1), dim=1, norm="ortho")
+        return self.LayerNorm(self.out_dropout(y) + x)
+
+
+class _FmlpIntermediate(nn.Module):
+    """module/layers.py:765-783: dense 64 -> 256, GELU, dense 256 -> 64, dropout, LayerNorm(+ residual)"""
+
+    def __init__(self, D, p, eps):
+        super().__init__()
+        self.dense_1 = nn.Linear(D, 4 * D)
+        self.dense_2 = nn.Linear(4 * D, D)
+        self.LayerNorm = nn.LayerNorm(D, eps=eps)
+        self.dropout = nn.Dropout(p)
+
+    def forward(self, x):
+        return self.LayerNorm(self.dropout(self.dense_2(F.gelu(self.dense_1(x)))) + x)
+
+
+class _FmlpLayer(nn.Module):
+    def __init__(self, L, D, p, eps):
+        super().__init__()
+        self.filterlayer = _FmlpFilter(L, D, p, eps)
+        self.intermediate = _FmlpIntermediate(D, p, eps)
+
+    def forward(self, x):
+        return self.intermediate(self.filterlayer(x))
+
+
+class _FmlpEncoder(nn.Module):
+    def __init__(self, n_layer, L, D, p, eps):
+        super().__init__()
+        self.layer = nn.ModuleList([_FmlpLayer(L, D, p, eps) for _ in range(n_layer)])
+
+
+class RefLikeFMLP(nn.Module):
+    """model/fmlp.py:8-39 (L = 50, D = 64, dropout 0.5 hard-coded there).  State-dict names equal the reference's."""
+
+    def __init__(self, n_items, D=64, L=50, n_layer=2, p=0.5, eps=1e-12):
+        super().__init__()
+        self.n_items, self.L = n_items, L
+        self.item_embedding = nn.Embedding(n_items, D, padding_idx=0)
+        self.position_embeddings = nn.Embedding(L, D)
+        self.LayerNorm = nn.LayerNorm(D, eps=eps)
+        self.dropout = nn.Dropout(p)
+        self.item_encoder = _FmlpEncoder(n_layer, L, D, p, eps)
+        self.apply(RefLikeSASRec._init)
+
+    def neg_sampling(self, batch):                          # basemodel.py:50-61, the branch of a one-dimensional target
+        w = torch.ones(batch["in_item_id"].shape[0], self.n_items)
+        w[:, 0] = 0
+        return torch.multinomial(w, 1, replacement=True).reshape_as(batch["item_id"]).unsqueeze(-1)
+
+    def training_step(self, batch, reduce=True, return_query=False):
+        hist = batch["in_item_id"]
+        pos = torch.arange(hist.size(1), dtype=torch.long).unsqueeze(0).expand_as(hist)
+        x = self.dropout(self.LayerNorm(self.item_embedding(hist) + self.position_embeddings(pos)))
+        for layer in self.item_encoder.layer:
+            x = layer(x)
+        q = x[:, -1]
+        loss = bce_scorer(q, self.item_embedding.weight, batch, reduce)
+        return (loss, q) if return_query else loss
+
+
+def fmlp_rows(rows: dict) -> dict:
+    """right-padded SASRec rows -> FMLP's rows: the history left-padded (its last item at position L - 1, where fmlp.py:38 reads the
+    query) and ONE target per row, the item after the last one"""
+    hist, tgt, sl = np.asarray(rows["in_item_id"]), np.asarray(rows["item_id"]), np.asarray(rows["seqlen"])
+    n, L = hist.shape
+    ar = np.arange(L)[None, :]
+    shift = (L - sl)[:, None]
+    left = np.where(ar >= shift, np.take_along_axis(hist, (ar - shift) % L, 1), 0)
+    out = dict(rows)
+    out["in_item_id"] = np.ascontiguousarray(left)
+    out["item_id"] = np.ascontiguousarray(np.take_along_axis(tgt, np.clip(sl - 1, 0, None)[:, None], 1)[:, 0])
+    return out
+
+
+class RefLikeCL4SRec(RefLikeSASRec):
+    """model/cl4srec.py:28-73 around RefLikeSASRec; the augmentations are module/data_augmentation.py:20-95 restated: ONE method per
+    view for the whole batch, applied row by row on the host"""
+
+    def __init__(self, n_items, cl_weight=0.1, temperature=1.0, tau=0.2, gamma=0.7, beta=0.2, **kw):
+        super().__init__(n_items + 1, **kw)                 # one more row: the mask item (cl4srec.py:30-32)
+        self.mask_id, self.real_items = n_items, n_items
+        self.cl_weight, self.temperature, self.tau, self.gamma, self.beta = cl_weight, temperature, tau, gamma, beta
+
+    def neg_sampling(self, batch):                          # the sampler's range is the table's row count (basemodel.py:52: num_items of the dataset)
+        w = torch.ones(batch["in_item_id"].shape[0], self.real_items)
+        w[:, 0] = 0
+        return torch.multinomial(w, self.L, replacement=True).reshape_as(batch["item_id"]).unsqueeze(-1)
+
+    def _crop(self, seqs, lens):
+        out, new = [], torch.zeros_like(lens)
+        for i in range(seqs.size(0)):
+            n = int(lens[i])
+            m = max(1, int(self.tau * n))
+            s = int(torch.randint(0, n - m + 1, (1,)))
+            out.append(seqs[i, s:s + m])
+            new[i] = m
+        return nn.utils.rnn.pad_sequence(out, batch_first=True), new
+
+    def _mask(self, seqs, lens):
+        out = seqs.clone()
+        for i in range(seqs.size(0)):
+            n = int(lens[i])
+            idx = np.random.choice(n, size=int(self.gamma * n), replace=False).astype(np.int64)
+            out[i][idx] = self.mask_id
+        return out, lens
+
+    def _reorder(self, seqs, lens):
+        out = []
+        for i in range(seqs.size(0)):
+            n = int(lens[i])
+            m = int(self.beta * n)
+            s = random.randint(0, n - m)
+            order = list(range(m))
+            random.shuffle(order)
+            out.append(torch.cat([seqs[i, :s], seqs[i, s:s + m][order], seqs[i, s + m:]]))
+        return torch.stack(out, 0), lens
+
+    fixed_views = None                                  # tests: ((seq_i, len_i), (seq_j, len_j)) recorded from the reference instead of a draw
+
+    def _view(self, batch, which):
+        if self.fixed_views is not None:
+            v, n = self.fixed_views[which]
+        else:
+            aug = (self._crop, self._mask, self._reorder)[random.randint(0, 2)]
+            v, n = aug(batch["in_item_id"], batch["seqlen"])
+        x = self.query_encoder.encode({"in_item_id": v})
+        keep = (torch.arange(x.size(1)).view(1, -1) < n.view(-1, 1)).unsqueeze(-1)            # mean pooling (module/functional.py:28-55)
+        return x.masked_fill(~keep, 0.0).sum(1) / n.view(-1, 1).to(x.dtype)
+
+    def training_step(self, batch, reduce=True, return_query=False):
+        loss = super().training_step(batch, reduce)
+        vi, vj = self._view(batch, 0), self._view(batch, 1)
+        keep = batch["seqlen"] != 1
+        vi, vj = vi[keep], vj[keep]
+        n = vi.size(0)
+        sim_ii = (vi @ vi.T / self.temperature).masked_fill(torch.eye(n, dtype=torch.bool), float("-inf"))
+        logits = torch.cat([vi @ vj.T / self.temperature, sim_ii], dim=-1)                    # InfoNCELoss 'batch_both' (:322-350)
+        return loss + self.cl_weight * F.cross_entropy(logits, torch.arange(n))
+
+
 class RefLikeMetaModel(nn.Module):
     """model/metamodel.py: a trainer around a sub-model.  training_step = :174-194, the outer loop = :123-166 with utils/utils.py's
     Hypergrad (:134-205) and MetaOptimizer (:207-252) restated inline (same autograd.grad calls, same order)."""
@@ -217,6 +387,12 @@ def time_training(rows: dict, n_items: int, batch_size=256, warmup=3, max_steps=
         if model_kind == "gru4rec":                        # configs/gru4rec.yaml: dropout 0.2, Adam weight_decay 1e-4
             model = RefLikeGRU4Rec(n_items, p=p)
             opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        elif model_kind == "fmlp":                         # dropout 0.5 whatever the config says (fmlp.py:13, layers.py:744,:762)
+            model, rows = RefLikeFMLP(n_items), fmlp_rows(rows)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)
+        elif model_kind == "cl4srec":                      # configs/cl4srec.yaml: item_random, tau 0.2, gamma 0.7, beta 0.2, cl_weight 0.1
+            model = RefLikeCL4SRec(n_items, p=p)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)
         else:
             model = RefLikeSASRec(n_items, p=p)
             opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)

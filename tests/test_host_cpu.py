@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     product, hook_syms = set(re.findall(r"\b(dr4sr_[a-z0-9_]+)\s*\(", hdr)), set(re.findall(r"\b(dr4sr_[a-z0-9_]+)\s*\(", hooks))
     assert product and hook_syms and not (product & hook_syms), "no declarations parsed / a hook declared in the product header"
     assert hook_syms == {"dr4sr_dropout_mask", "dr4sr_sasrec_launch_kernel", "dr4sr_sasrec_launch_kernel_weighted", "dr4sr_gru4rec_launch_kernel",
-                         "dr4sr_reload_env"}
+                         "dr4sr_fmlp_launch_kernel", "dr4sr_reload_env"}
     declared = product | hook_syms
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:

@@ -148,6 +148,62 @@ def test_ref_like_gru4rec_trainer_matches_golden(golden_dir):
         assert float(np.abs(prm.grad.numpy() - ref).max()) <= 2e-5 * max(1e-8, float(np.abs(ref).max())) + 1e-9, n
 
 
+def test_ref_like_fmlp_trainer_matches_golden(golden_dir):
+    """bench.py --model fmlp's cpu_baseline leg (oracle/ref_trainer.RefLikeFMLP: torch.fft filter + Intermediate, model/fmlp.py:8-39,
+    module/layers.py:740-807) reproduces the reference's FMLP loss and gradients under the reference's own state-dict names"""
+    from oracle.ref_trainer import RefLikeFMLP
+    z = np.load(os.path.join(golden_dir, "fmlp_d64.npz"))
+    g = {k: z[k] for k in z.files}
+    m = RefLikeFMLP(int(g["meta.num_items"]), n_layer=int(g["meta.layer_num"]), p=0.0)
+    m.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}, strict=True)
+    m.train()
+    b = {k[len("batch."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("batch.")}
+    loss, q = m.training_step(b, return_query=True)
+    loss.backward()
+    np.testing.assert_allclose(q.detach().numpy(), g["out.query"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(loss.detach()), float(g["out.loss"]), rtol=2e-6)
+    for n, prm in m.named_parameters():
+        ref = g["grad." + n]
+        assert float(np.abs(prm.grad.numpy() - ref).max()) <= 3e-4 * max(1e-8, float(np.abs(ref).max())) + 1e-9, n
+
+
+def test_ref_like_cl4srec_trainer_matches_golden(golden_dir):
+    """bench.py --model cl4srec's cpu_baseline leg (oracle/ref_trainer.RefLikeCL4SRec) on the views the reference drew
+    (tests/golden/cl4srec_d64.npz): BCE + cl_weight x InfoNCE and its gradients; its own draws are legal augmentations"""
+    from oracle.ref_trainer import RefLikeCL4SRec
+    z = np.load(os.path.join(golden_dir, "cl4srec_d64.npz"))
+    g = {k: z[k] for k in z.files}
+    N = int(g["meta.num_items"])
+    m = RefLikeCL4SRec(N, cl_weight=float(g["meta.cl_weight"]), temperature=float(g["meta.temperature"]), tau=float(g["meta.tau"]),
+                       gamma=float(g["meta.gamma"]), beta=float(g["meta.beta"]), D=int(g["param.item_embedding.weight"].shape[1]), H=int(g["meta.head_num"]),
+                       Fh=int(g["meta.hidden_size"]), p=0.0, eps=float(g["meta.layer_norm_eps"]), n_layer=int(g["meta.layer_num"]))
+    m.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}, strict=True)
+    m.train()
+    b = {k[len("batch."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("batch.")}
+    m.fixed_views = ((torch.from_numpy(g["view.i"]), torch.from_numpy(g["view.i_len"])), (torch.from_numpy(g["view.j"]), torch.from_numpy(g["view.j_len"])))
+    loss = m.training_step(b)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["out.loss"]), rtol=1e-5)
+    for n, prm in m.named_parameters():
+        ref = g["grad." + n]
+        assert float(np.abs(prm.grad.numpy() - ref).max()) <= 2e-4 * max(1e-8, float(np.abs(ref).max())) + 1e-9, n
+    # the trainer's own draws: crop keeps a window of max(1, int(tau n)) items, mask replaces int(gamma n) items by the mask item,
+    # reorder permutes a window (module/data_augmentation.py:20-85)
+    m.fixed_views = None
+    hist, sl = b["in_item_id"], b["seqlen"]
+    v, n = m._crop(hist, sl)
+    for r in range(hist.shape[0]):
+        n0, n1 = int(sl[r]), int(n[r])
+        assert n1 == max(1, int(m.tau * n0)) and any(hist[r, s:s + n1].tolist() == v[r, :n1].tolist() for s in range(n0 - n1 + 1))
+    v, n = m._mask(hist, sl)
+    for r in range(hist.shape[0]):
+        n0 = int(sl[r])
+        assert int((v[r, :n0] == N).sum()) == int(m.gamma * n0) and bool(((v[r] == hist[r]) | (v[r] == N)).all())
+    v, n = m._reorder(hist, sl)
+    for r in range(hist.shape[0]):
+        assert sorted(v[r].tolist()) == sorted(hist[r].tolist()) and int(n[r]) == int(sl[r])
+
+
 def test_ref_like_metamodel_trainer_matches_golden(golden_dir):
     """bench.py --model metamodel's cpu_baseline leg (oracle/ref_trainer.RefLikeMetaModel) reproduces the reference's weighted inner
     loss and, after one outer loop (Hypergrad.grad -> clip -> SGD momentum), its meta-module parameters (metamodel_sasrec.npz)"""
