@@ -207,3 +207,33 @@ def test_fmlp_bf16x3_intermediate_kernels_match_fp32_mfma(monkeypatch):
     (l1, n1), g1 = out[True]
     assert n0 == n1 and abs(l0 - l1) < 1e-5
     assert float((g0 - g1).abs().max()) <= 5e-5 * float(g1.abs().max())
+
+
+def test_fmlp_launch_kernel_hook_replays_the_steps_launches(golden_dir):
+    """the measurement hook of bench.py's FMLP roofline (include/dr4sr_hip_hooks.h: dr4sr_fmlp_launch_kernel): every launch it re-enqueues
+    on the state a fwd_bwd left reproduces what that step wrote (dropout off: the launches are pure functions of the workspace); the
+    weight-gradient launch ACCUMULATES (the step zeroes the gradients in its first launch), so one replay doubles the GEMM gradients"""
+    import ctypes as C
+    from dr4sr_amd import _lib
+    g, params, b = load(golden_dir)
+    B = b["in_item_id"].shape[0]
+    eng = engine(g, params, B)
+    dev = eng.device
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), neg_item=b["neg_item"].view(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    torch.cuda.synchronize()
+    ws0 = eng.workspace.clone()
+    n0 = eng.loss_and_count()[1]
+    g0 = {k: v.clone() for k, v in eng.normalized_grads().items()}
+    lib = eng.lib
+    for name in ("filter_fwd", "ffn_fwd", "ffn_bwd", "filter_bwd"):
+        for layer in range(eng.n_layer):
+            _lib.check(lib.dr4sr_fmlp_launch_kernel(C.byref(plan), _lib.FMLP_KERNEL_IDS[name], layer, _lib.cur_stream()), name)
+            torch.cuda.synchronize()
+            assert torch.equal(eng.workspace, ws0), (name, layer)
+    _lib.check(lib.dr4sr_fmlp_launch_kernel(C.byref(plan), _lib.FMLP_KERNEL_IDS["wgrad"], 0, _lib.cur_stream()), "wgrad")
+    g1, n1 = eng.normalized_grads(), eng.loss_and_count()[1]        # (the launch's reduce blocks add the scorer's counts to the tail again)
+    k = "item_encoder.layer.0.intermediate.dense_1.weight"
+    assert relerr(g1[k] * n1, (2 * n0 * g0[k]).cpu()) < 1e-5
+    assert lib.dr4sr_fmlp_launch_kernel(C.byref(plan), 99, 0, _lib.cur_stream()) != 0
+    assert lib.dr4sr_fmlp_launch_kernel(C.byref(plan), 0, eng.n_layer, _lib.cur_stream()) != 0
