@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _engine(B, D=64, seed=3):
+def _engine(B, D=64, seed=3, NL=2):
     from test_gpu_parity import _random_params
     from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
     from dr4sr_amd.engine import SasrecEngine
@@ -34,8 +34,8 @@ def _engine(B, D=64, seed=3):
     rows = make_rows(n_rows=B, n_items=N, seed=17)
     data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
     negs = torch.randint(1, N, (B, L), generator=torch.Generator().manual_seed(8)).to(dev)
-    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, 0.3, B, dev, seed=seed, lr=1e-3)
-    eng.load_named(_random_params(N, D, 128, 2, seed=6))
+    eng = SasrecEngine(N, L, D, 2, 128, NL, 1e-12, 0.3, B, dev, seed=seed, lr=1e-3)
+    eng.load_named(_random_params(N, D, 128, NL, seed=6))
     plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], neg_item=negs, sample_neg=False)
     return eng, plan, data
 
@@ -77,6 +77,30 @@ def test_two_phase_step_equals_one_launch_step_at_scale(monkeypatch, split):
     scale = float(g_one.abs().max())
     assert float((g_one - g_two).abs().max()) <= 1e-6 * scale, float((g_one - g_two).abs().max()) / scale
     assert float(g_one[n]) == float(g_two[n]) and abs(float(g_one[n + 1]) - float(g_two[n + 1])) <= 1e-6 * abs(float(g_one[n + 1]))
+
+
+@pytest.mark.parametrize("NL", [1, 3])
+def test_two_phase_step_other_layer_counts(NL):
+    """the launch cut follows the layer count (default split layer max(1, n_layer / 2)): one layer — the table jobs alone in phase 1;
+    three layers — the table jobs + the two upper layers' weight gradients; both == the one-launch step"""
+    from dr4sr_amd import _lib
+    eng, plan, _ = _engine(4096, NL=NL)
+    assert int(eng.lib.dr4sr_sasrec_at_scale(_lib.C.byref(plan))) & 1
+    b, n = eng.grad_buckets(plan), eng.n_params
+    assert b == [(0, eng.offsets[2]), (eng.offsets[2], n + _lib.GRAD_TAIL)], b
+    g_one = _grads_of(eng, lambda: eng.fwd_bwd(plan))
+    mid = {}
+
+    def two():
+        eng.fwd_bwd_phase(plan, False, 1)
+        torch.cuda.synchronize()
+        mid["table"] = eng.grads[:b[0][1]].clone()
+        eng.fwd_bwd_phase(plan, False, 2)
+    g_two = _grads_of(eng, two)
+    assert torch.equal(mid["table"], g_two[:b[0][1]]) and torch.equal(g_one[:eng.offsets[1]], g_two[:eng.offsets[1]])
+    scale = float(g_one.abs().max())
+    assert float((g_one - g_two).abs().max()) <= 1e-6 * scale, float((g_one - g_two).abs().max()) / scale
+    assert float(g_one[n]) == float(g_two[n]) > 0
 
 
 def test_two_phase_step_is_the_whole_step_in_the_latency_forms():
