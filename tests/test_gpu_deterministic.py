@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(B, D, steps, seed=2023, dropout=0.5):
+def _run(B, D, steps, seed=2023, dropout=0.5, NL=2):
     from test_gpu_parity import _random_params
     from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
     from dr4sr_amd.engine import SasrecEngine
@@ -20,8 +20,8 @@ def _run(B, D, steps, seed=2023, dropout=0.5):
     rows = make_rows(n_rows=4096, n_items=N, seed=17)
     data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
     perm = torch.from_numpy(np.random.default_rng(3).permutation(4096)).to(dev)
-    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, dropout, B, dev, seed=seed, lr=1e-3)
-    eng.load_named(_random_params(N, D, 128, 2, seed=6))
+    eng = SasrecEngine(N, L, D, 2, 128, NL, 1e-12, dropout, B, dev, seed=seed, lr=1e-3)
+    eng.load_named(_random_params(N, D, 128, NL, seed=6))
     counter = torch.zeros(1, dtype=torch.int32, device=dev)
     log = torch.zeros(steps, dtype=torch.float32, device=dev)
     plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], rows=torch.zeros(B, dtype=torch.int64, device=dev),
@@ -46,6 +46,18 @@ def test_deterministic_mode_two_runs_bit_identical(monkeypatch, B, D):
     p0, l0, _ = _run(B, D, steps)
     # same training, other summation order: Adam turns ulps of a near-zero gradient into +- lr steps, so the parameters may drift by a few lr
     assert float((p0 - p1).abs().max()) < 3e-2 and float(((l0 - l1).abs() / l0.abs()).max()) < 1e-2
+
+
+@pytest.mark.parametrize("B,NL", [(1, 2), (3, 2), (33, 1), (100, 3), (8192, 2)])
+def test_deterministic_mode_odd_batches_and_layer_counts(monkeypatch, B, NL):
+    """the same bit-identity at the edges: one row, batches that fill no token tile, one and three encoder layers, and a batch whose
+    weight-gradient launch uses every token split (8 192 rows)"""
+    steps = 10 if B == 8192 else 40
+    monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
+    p1, l1, v1 = _run(B, 64, steps, NL=NL)
+    p2, l2, v2 = _run(B, 64, steps, NL=NL)
+    assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(l1, l2)
+    assert bool(torch.isfinite(p1).all()) and bool(torch.isfinite(l1).all())
 
 
 @pytest.mark.parametrize("D", [64, 128])
