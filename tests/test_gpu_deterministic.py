@@ -11,13 +11,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(B, D, steps, seed=2023, dropout=0.5, NL=2):
+def _run(B, D, steps, seed=2023, dropout=0.5, NL=2, dense=False):
     from test_gpu_parity import _random_params
     from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
     from dr4sr_amd.engine import SasrecEngine
     dev = torch.device("cuda", 0)
     L, N = 50, (20034 if D == 128 else TOYS_N_ITEMS)
-    rows = make_rows(n_rows=4096, n_items=N, seed=17)
+    rows = make_rows(n_rows=4096, n_items=N, seed=17, dense=dense)
     data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
     perm = torch.from_numpy(np.random.default_rng(3).permutation(4096)).to(dev)
     eng = SasrecEngine(N, L, D, 2, 128, NL, 1e-12, dropout, B, dev, seed=seed, lr=1e-3)
@@ -58,6 +58,15 @@ def test_deterministic_mode_odd_batches_and_layer_counts(monkeypatch, B, NL):
     p2, l2, v2 = _run(B, 64, steps, NL=NL)
     assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(l1, l2)
     assert bool(torch.isfinite(p1).all()) and bool(torch.isfinite(l1).all())
+
+
+@pytest.mark.parametrize("B,D", [(512, 64), (2048, 128)])
+def test_deterministic_mode_long_sequences(monkeypatch, B, D):
+    """all-50 rows (one workgroup per sequence attention, every token tile full) and the d = 128 tiles at scale"""
+    monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
+    p1, l1, v1 = _run(B, D, 12, dense=True)
+    p2, l2, v2 = _run(B, D, 12, dense=True)
+    assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(l1, l2) and bool(torch.isfinite(l1).all())
 
 
 @pytest.mark.parametrize("D", [64, 128])
