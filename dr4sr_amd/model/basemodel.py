@@ -133,10 +133,14 @@ class BaseModel(nn.Module):
         # deterministic_mode), not accuracy.
         if bool(config["train"].get("deterministic", False)) or os.environ.get("DR4SR_DETERMINISTIC", "0") not in ("", "0"):
             _lib.set_env("DR4SR_DETERMINISTIC", "1")
-            if type(self).__name__ != "SASRec":
-                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order is implemented and tested for the SASRec step "
-                                                 f"(tests/test_gpu_deterministic.py); {type(self).__name__}'s step keeps kernels whose fp32 atomics "
-                                                 "make runs differ in the last bits")
+            # bit-identical fits are tested for SASRec, CL4SRec and MetaModel around SASRec (tools/det_fit_check.py); GRU4Rec's and FMLP's steps
+            # keep fp32 atomics (table scatter, weight-gradient splits): measured 1e-7 / 2e-5 between two fits
+            name = type(self).__name__
+            inner = str(config["model"].get("sub_model", "")) if name == "MetaModel" else name
+            if inner not in ("SASRec", "CL4SRec") or (name == "MetaModel" and inner != "SASRec"):
+                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order covers the SASRec step (SASRec, CL4SRec, MetaModel around "
+                                                 f"SASRec: tests/test_gpu_deterministic.py); {name}{'(' + inner + ')' if name == 'MetaModel' else ''}'s "
+                                                 "step keeps kernels whose fp32 atomics make runs differ in the last bits")
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ setup

@@ -134,3 +134,17 @@ def test_deterministic_two_phase_step_is_bitwise_the_one_launch_step(monkeypatch
     g_one = _grads_of(eng, lambda: eng.fwd_bwd(plan))
     g_two = _grads_of(eng, lambda: (eng.fwd_bwd_phase(plan, False, 1), eng.fwd_bwd_phase(plan, False, 2)))
     assert torch.equal(g_one, g_two)
+
+
+@pytest.mark.parametrize("name", ["SASRec", "MetaModel", "CL4SRec"])
+def test_whole_fit_is_bit_identical_under_train_deterministic(name):
+    """two complete fit() calls (3 epochs of B = 256 on 1 024 toys-sized rows, dropout 0.5, validation every epoch; MetaModel: warm-up epoch +
+    an outer hyper-gradient step every 2 steps; CL4SRec: two drawn views + InfoNCE per step) end with bit-identical parameters (and meta
+    module) — tools/det_fit_check.py, a fresh process per pair so that the mode is set before the library caches its switches"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DET_N_ITEMS="11925", DET_ROWS="1024", DET_BATCH="256")
+    env.pop("DR4SR_DETERMINISTIC", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "det_fit_check.py"), name], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "identical: True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
