@@ -226,9 +226,10 @@ def gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, Hh, NLg, step_s):
         if coop and dom == "rec_bwd" and Hh == 256 and int(plan.B) <= 1536 and not os.environ.get("DR4SR_GRU_BWD_F32") \
                 and bool(lib.dr4sr_gru4rec_uses_cooperative(min(int(plan.B), 256), Hh)) and min(int(plan.B), 256) <= 256:
             kname = "k_gru_bwd_coop_bf"                   # 16 slices per group: the bf16x3 BPTT with W_hh in registers (csrc/gru_coop.hip)
+    traffic, traffic_src = pmc_traffic("gru4rec_B256", kname) if int(plan.B) == 256 else (None, None)
     out["roofline"] = {"kernel": kname, "bound": "mfma",
-                       "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                       "traffic_source": None, "us_per_launch": ktime_dom, "flops_per_launch": fl, "launches_per_step": nlaunch,
+                       "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic,
+                       "traffic_source": traffic_src, "us_per_launch": ktime_dom, "flops_per_launch": fl, "launches_per_step": nlaunch,
                        "note": "recurrent GEMM of one layer on the valid tokens; the launch is a chain of max(seqlen) dependent "
                                "time steps (latency-bound, SURVEY §8d), not an MFMA-throughput kernel"}
     per_tok = 3.0 * (2 * 3 * Hh * D + (NLg - 1) * 2 * 3 * Hh * Hh + NLg * 2 * 3 * Hh * Hh + 2 * Hh * D)
@@ -239,6 +240,19 @@ def gru_kernel_rooflines(lib, _lib, plan, out, T_last, D, Hh, NLg, step_s):
     if wave:
         out["kernel_us_per_step"]["note"] = ("rec_fwd = k_gru_fwd_wave: both layers' forward recurrences + gi_2 in one launch "
                                              "(gemm_in then only runs for layer 1: half the figure above)")
+
+
+def pmc_traffic(tag, kernel_prefix):
+    """(HBM bytes per launch, source file) of the kernel whose name starts with kernel_prefix, from the committed PMC passes of this workload
+    (tools/traffic_pmc*.sh: FETCH_SIZE x the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs) — NOT measured by this run"""
+    for rnd in range(PROFILE_ROUND, 0, -1):
+        pj = os.path.join(ROOT, "profiles", "round%d_pmc_traffic_%s.json" % (rnd, tag))
+        if os.path.exists(pj):
+            hits = [v["hbm_bytes_per_launch"] for k, v in json.load(open(pj)).items() if isinstance(v, dict) and k.startswith(kernel_prefix)
+                    and "hbm_bytes_per_launch" in v]
+            if hits:
+                return float(hits[0]), os.path.relpath(pj, ROOT)
+    return None, None
 
 
 def fmlp_kernel_rooflines(lib, _lib, plan, out, T, D, Fh, NL, L, step_s):
@@ -280,11 +294,12 @@ def fmlp_kernel_rooflines(lib, _lib, plan, out, T, D, Fh, NL, L, step_s):
     kname = {"ffn_fwd": "k_post_fwd<32, 64, 256, true>", "ffn_bwd": "k_post_bwd<32, 64, 256, true>", "wgrad": "k_fmlp_wgrad_bf64",
              "filter_fwd": "k_fmlp_filter_fwd", "filter_bwd": "k_fmlp_filter_bwd"}[dom]
     hbm_bound = gbs / HBM_PEAK_GBS >= tf / MFMA_F32_PEAK_TF or not mfma
+    traffic, traffic_src = pmc_traffic("fmlp_B256", kname.split("(")[0]) if T == 256 * L else (None, None)
     out["roofline"] = {"kernel": kname, "bound": "hbm" if hbm_bound else "mfma",
                        "achieved": gbs if hbm_bound else tf, "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F32_PEAK_TF,
                        "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": gbs / HBM_PEAK_GBS if hbm_bound else tf / MFMA_F32_PEAK_TF,
                        "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_f32_frac": tf / MFMA_F32_PEAK_TF if mfma else None,
-                       "traffic": None, "traffic_source": None, "us_per_launch": ktime[dom], "launches_per_step": nl_,
+                       "traffic": traffic, "traffic_source": traffic_src, "us_per_launch": ktime[dom], "launches_per_step": nl_,
                        "flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                        "note": "the flops are the fp32 problem's; the GEMMs run as a bf16x3 split (3 matrix instructions per product) and are "
                                "priced against the fp32 MFMA peak, like the SASRec kernels"}
