@@ -28,7 +28,7 @@ import ctypes as C  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PROFILE_ROUND = 5              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
+PROFILE_ROUND = 6              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
@@ -376,14 +376,9 @@ def bench_metamodel(args):
     # DR4SR_BENCH_SHARE_GPU=1 + DR4SR_BENCH_BACKEND=gloo: debug knobs that run the N-rank code path on ONE GPU (functional check only)
     dev = torch.device("cuda", 0 if os.environ.get("DR4SR_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(dev)
-    import torch.distributed as dist
+    from dr4sr_amd import parallel
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("DR4SR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        parallel.init_distributed(dev)                      # gloo control group + the library's RCCL communicator
     os.environ.setdefault("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
     import logging
     logging.getLogger("CDR").setLevel(logging.WARNING)
@@ -431,14 +426,12 @@ def bench_metamodel(args):
             return loss
 
     run(args.warmup)
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
+    parallel.barrier()
     t0 = time.perf_counter()
     loss = run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    parallel.barrier()
     wall = time.perf_counter() - t0
     # one outer step alone
     bv = model._local_batch(loader, perm, 0)
@@ -452,9 +445,7 @@ def bench_metamodel(args):
     torch.cuda.synchronize()
     outer_ms = (time.perf_counter() - t1) / 5 * 1e3
     if world > 1:
-        tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax)
+        wall = parallel.host_allreduce([wall], "max")[0]
     extra = {}
     if rank == 0 and fused:
         # roofline of the weighted inner step's dominant kernel, measured live: the launches of dr4sr_sasrec_fwd_bwd_weighted re-enqueued
@@ -490,8 +481,7 @@ def bench_metamodel(args):
                                    % (args.interval, B, args.dropout),
                        "global_batch": B * world, "seq_len": 50, "parallelism": "dp%d" % world, "hip_graph": True},
             "outer_step_ms": outer_ms, "final_loss": float(loss)})
-    if world > 1:
-        dist.destroy_process_group()
+    parallel.shutdown()
 
 
 def bench_cl4srec(args):
@@ -648,9 +638,42 @@ def guard_stdout():
 
 
 def emit(obj):
+    disarm_crash_line()
     out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
     out.write(json.dumps(obj) + "\n")
     out.flush()
+
+
+_CRASH_ARMED = [False]
+
+
+def arm_crash_line(out, leg):
+    """Abort safety of the ONE line.  Every leg after the headline measurement is extra evidence; none of them may
+    cost the line.  Python cannot catch a SIGABRT raised by a foreign thread's uncaught C++ exception, a SIGSEGV inside a driver library or
+    the SIGTERM a launcher sends to the surviving ranks once another rank died — so rank 0 keeps a COMPLETE copy of the line as it stands,
+    marked with the leg that is about to run, inside libdr4sr_hip.so (dr4sr_crash_line_set, include/dr4sr_hip_hooks.h): its signal handler
+    write(2)s that copy to the real stdout and _exit(0)s.  Re-armed before every later leg with the line as completed so far; emit() disarms."""
+    if _REAL_STDOUT is None or int(os.environ.get("RANK", "0")) != 0:
+        return
+    snap = dict(out)
+    snap["aborted_during"] = leg
+    if "collective_forms" in snap:
+        cf = dict(snap["collective_forms"])
+        cf.setdefault("in_graph_error", "process killed by a signal during: " + leg)
+        snap["collective_forms"] = cf
+    from dr4sr_amd import _lib
+    _lib.load().dr4sr_crash_line_set(json.dumps(snap).encode(), _REAL_STDOUT.fileno(), 0)
+    _CRASH_ARMED[0] = True
+    if os.environ.get("DR4SR_BENCH_INJECT_ABORT") == leg:          # test hook (tests/test_gpu_zz_transport.py): die the way a c10d thread did
+        _REAL_STDOUT.flush()
+        os.abort()
+
+
+def disarm_crash_line():
+    if _CRASH_ARMED[0]:
+        from dr4sr_amd import _lib
+        _lib.load().dr4sr_crash_line_set(None, 0, 0)
+        _CRASH_ARMED[0] = False
 
 
 def main():
@@ -686,7 +709,16 @@ def main():
                     help="single GPU: skip the 1-rank RCCL runs of the data-parallel step forms (strong[].dp_1rank_rccl)")
     ap.add_argument("--dp-leg-gpus", type=int, default=8, help="the GPU count whose per-GPU share of each strong-scaling size the 1-rank RCCL leg runs")
     ap.add_argument("--interval", type=int, default=30, help="metamodel: outer-loop period (configs/metamodel.yaml interval)")
+    ap.add_argument("--max-seconds", type=int, default=1500,
+                    help="whole-run watchdog: after this many seconds the process sends itself SIGTERM — rank 0 then prints the line as "
+                         "completed so far (arm_crash_line) instead of hanging the launcher in a wedged collective")
     args = ap.parse_args()
+    if args.max_seconds > 0:
+        import signal
+        import threading
+        wd = threading.Timer(args.max_seconds, lambda: os.kill(os.getpid(), signal.SIGTERM))
+        wd.daemon = True
+        wd.start()
     if args.model == "metamodel":
         return bench_metamodel(args)
     if args.model == "cl4srec":
@@ -708,7 +740,7 @@ def main():
     import torch.distributed as dist
     from dr4sr_amd import parallel
     if dp:
-        parallel.init_distributed(dev)
+        parallel.init_distributed(dev)                     # gloo control group + the library's own RCCL communicator (no ProcessGroupNCCL)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from dr4sr_amd import _lib
@@ -795,7 +827,7 @@ def main():
         # latency forms (and for GRU4Rec / FMLP).  Every rank has B rows here, so every rank decides alike.
         # (two buckets only inside the captured graph: launched from the host the two-bucket step is four submissions per step, +91 us at
         #  16 384 rows per rank with one RCCL rank against +30 us in the graph — the host form stays flat, as in BaseModel._step_graph)
-        buckets = parallel.grad_buckets(eng, B, data["seqlen"]) if (dp and args.model == "sasrec" and not dp_flat and dp_form == "in_graph") else None
+        buckets = parallel.grad_buckets(eng, B, data["seqlen"], want=2) if (dp and args.model == "sasrec" and not dp_flat and dp_form == "in_graph") else None
         two = buckets is not None and len(buckets) == 2
 
         def step_eager():
@@ -869,10 +901,8 @@ def main():
                     ok = 0
                 # every rank takes the same form: a capture that failed on ANY rank sends all of them to the host-launched collective
                 # (ranks mixing in-graph and host-launched collectives would deadlock the communicator)
-                flag = torch.tensor([float(ok)], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 stream.synchronize()
-                if float(flag) >= 1.0:
+                if parallel.all_ok(bool(ok)):
                     def run_steps(n):
                         for _ in range(n // group):
                             g_all.replay()
@@ -932,9 +962,9 @@ def main():
             stream.synchronize()
             walls, gpus = [], []
             for _ in range(repeats):
-                if dp:
-                    dist.barrier()
                 torch.cuda.synchronize()
+                if dp:
+                    parallel.barrier()                       # (control plane: a host barrier; the device is drained just above)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0 = time.perf_counter()
                 e0.record()
@@ -943,13 +973,11 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 if dp:
-                    dist.barrier()
+                    parallel.barrier()
                 walls.append(time.perf_counter() - t0)
                 gpus.append(e0.elapsed_time(e1))
-            if dp:                                           # every repetition: the MAX over ranks (one collective for all of them)
-                tmax = torch.tensor(walls, device=dev if parallel.can_capture() else "cpu", dtype=torch.float64)
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                walls = [float(x) for x in tmax]
+            if dp:                                           # every repetition: the MAX over ranks (one control-plane reduction for all of them)
+                walls = parallel.host_allreduce(walls, "max")
             order = sorted(range(repeats), key=lambda i: walls[i])
             mid = order[(repeats - 1) // 2]                  # the median repetition (the lower one of an even count)
             wall, gpu_ms = walls[mid], gpus[mid]
@@ -957,11 +985,8 @@ def main():
             per_rank_ms, coll_us = None, None
             loss, nvalid = eng.loss_and_count()             # (before the stand-alone collective timing below overwrites the gradient tail)
             if dp:
-                # this rank's own GPU time per step (events); gloo (shared-GPU functional runs) gathers host tensors only
-                mine = torch.tensor([gpu_ms / steps], device=dev if parallel.can_capture() else "cpu", dtype=torch.float64)
-                allr = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(allr, mine)
-                per_rank_ms = [round(float(x), 5) for x in allr]
+                # this rank's own GPU time per step (events), gathered over the control plane
+                per_rank_ms = [round(x, 5) for x in parallel.host_allgather(gpu_ms / steps)]
                 # the collective alone: the same flat buffer all-reduced back to back, HIP events around the host-launched form
                 # (every rank enters the same count; the gradient buffer is garbage afterwards — nothing reads it before the next step)
                 ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1105,6 +1130,9 @@ def main():
         return out, rows_np, N
 
     out, rows_np, N = measure(args.batch, args.steps, args.warmup, "full")
+    if dp:
+        out["collective_forms"] = {"host": out["ms_per_step"], "in_graph": None}
+    arm_crash_line(out, "throughput_mode")                   # from here on the line cannot be lost (see arm_crash_line)
     tm = None
     sec_rep = max(1, min(args.repeats, 5))                   # the secondary sizes: fewer repetitions of a longer timed region
     if args.model == "sasrec" and args.batch < 8192 and not args.no_throughput_mode:
@@ -1115,6 +1143,7 @@ def main():
             out["throughput_mode"] = {k: tm[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_spread", "steps", "warmup", "dtype", "config",
                                                           "roofline", "roofline_gather_step", "kernel_us_per_step", "valid_tokens_last_step",
                                                           "roofline_step", "roofline_tile_kernels") if k in tm}
+    arm_crash_line(out, "deterministic_mode")
     if args.model == "sasrec" and not dp and rank == 0 and not args.no_deterministic_leg:
         # what run-to-run determinism costs at this workload (train.deterministic; the reference sets cudnn.deterministic, utils/utils.py:19):
         # the same step with every reduction in a fixed order — at-scale launch forms + ordered partial sums in the weight-gradient launch
@@ -1125,6 +1154,7 @@ def main():
                                          "note": "train.deterministic / DR4SR_DETERMINISTIC=1: bit-identical parameters run to run (tests/test_gpu_deterministic.py); opt-in"}
         except Exception as e:      # noqa: BLE001
             out["deterministic_mode"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    arm_crash_line(out, "strong")
     strong = []
     if args.model == "sasrec" and not args.no_strong and args.embed_dim == 64 and not args.dense and args.batch < 8192:
         # STRONG scaling (north_star: ">= 6x at 8 GPUs"): a FIXED global batch G split over the N ranks (G / N rows per rank per
@@ -1151,6 +1181,7 @@ def main():
                            "allreduce_us_standalone": st_n.get("allreduce_us_standalone")})
         if rank == 0:
             out["strong"] = strong
+    arm_crash_line(out, "cpu_baseline")
     if rank == 0 and not dp and not args.no_cpu_baseline and args.model in ("sasrec", "gru4rec", "fmlp"):
         out["cpu_baseline"] = cpu_baseline_leg(rows_np, N, args.model, 0.2 if args.model == "gru4rec" else args.dropout)
 
@@ -1161,6 +1192,7 @@ def main():
     # that does not shrink with the rank count, EXCEPT the wire time of a real 8-rank all-reduce (nothing on this box can measure that;
     # the table bucket's share of it runs beside the last weight-gradient launch, whose duration is printed next to it).
     if world == 1 and not dp and rank == 0 and args.model == "sasrec" and strong and not args.no_dp_leg:
+        arm_crash_line(out, "dp_1rank_rccl")
         try:
             import socket
             with socket.socket() as sk:
@@ -1201,7 +1233,7 @@ def main():
             os.environ.pop("DR4SR_BENCH_FORCE_DP", None)
             if dist.is_initialized():
                 emit(out)
-                dist.destroy_process_group()
+                parallel.shutdown()
                 return
 
     # ---- data parallel, second form: the RCCL all-reduce captured INSIDE the k-step graph (the model's opt-in, train.dp_graph_allreduce).
@@ -1210,8 +1242,8 @@ def main():
     # multi-GPU run), rank 0 prints the line it already has with in_graph: null and every rank leaves through os._exit.
     if dp:
         host_ms = out["ms_per_step"]
-        forms = {"host": host_ms, "in_graph": None}
-        out["collective_forms"] = forms
+        forms = out["collective_forms"]
+        arm_crash_line(out, "in_graph")
         if parallel.can_capture() and args.model == "sasrec" and not args.no_graph and not os.environ.get("DR4SR_DP_HOST_ALLREDUCE"):
             import threading
 
@@ -1237,6 +1269,7 @@ def main():
                             out[k] = ig[k]
                         out["config"]["collective"] = ig["config"]["collective"]
                         out["config"]["steps_per_graph"] = ig["config"]["steps_per_graph"]
+                    arm_crash_line(out, "in_graph_strong")
                     for ent in strong:                       # every rank walks the same list in the same order
                         sg = measure(ent["global_batch"] // world, max(20, min(100, args.steps)), 10, None, dp=True, dp_form="in_graph",
                                      repeats=sec_rep)
@@ -1268,7 +1301,7 @@ def main():
     if rank == 0:
         emit(out)
     if dp:
-        dist.destroy_process_group()
+        parallel.shutdown()
 
 
 if __name__ == "__main__":

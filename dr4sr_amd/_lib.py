@@ -12,7 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR4SR_LIB_PATH") or os.path.join(_HERE, "csrc", "libdr4sr_hip.so")     # override: A/B runs of two builds on one box
 
-ABI_VERSION = 7
+ABI_VERSION = 8
+COMM_ID_BYTES = 128           # DR4SR_COMM_ID_BYTES (the RCCL unique id, a host buffer)
 GRAD_TAIL = 4
 STATE_WORDS = 16
 STATE_STEP, STATE_T, STATE_NVALID, STATE_RNGSTEP = 0, 1, 2, 3
@@ -253,6 +254,21 @@ SYMBOLS = {
                                                   C.c_int32, _f32p, C.c_int64, C.c_void_p]),
     "dr4sr_full_score_topk_ws": (C.c_int, [_f32p, _f32p, _i64p, _f32p, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            _f32p, C.c_int64, C.c_void_p]),
+    # ABI 8: the data-parallel transport (csrc/comm.hip, RCCL on the caller's stream); comm handles are opaque pointers
+    "dr4sr_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dr4sr_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "dr4sr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dr4sr_comm_rank": (C.c_int, [C.c_void_p]),
+    "dr4sr_comm_world": (C.c_int, [C.c_void_p]),
+    "dr4sr_comm_async_error": (C.c_int, [C.c_void_p]),
+    "dr4sr_comm_error_string": (C.c_char_p, [C.c_int]),
+    "dr4sr_allreduce_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_void_p]),
+    "dr4sr_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dr4sr_allreduce_f32_async": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_void_p]),
+    "dr4sr_comm_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dr4sr_allgather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dr4sr_broadcast_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dr4sr_crash_line_set": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32]),           # measurement hook (include/dr4sr_hip_hooks.h)
 }
 
 _lib = None

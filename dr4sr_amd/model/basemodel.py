@@ -350,7 +350,7 @@ class BaseModel(nn.Module):
             if use_graph:
                 warm_up(eager)
                 g = torch.cuda.CUDAGraph()
-                with capture(g):       # other threads (RCCL watchdog) may touch the device
+                with capture(g):
                     eager()
                 run = g.replay
             else:
@@ -369,7 +369,7 @@ class BaseModel(nn.Module):
             # Two buckets only INSIDE a captured graph (where the asynchronous table collective is a parallel branch for free): launched from
             # the host, the two-bucket step is four submissions per step instead of two and measured +91 us at 16 384 rows per rank with one
             # RCCL rank, against +30 us in the graph (profiles/round5_bench_default.json strong[].dp_1rank_rccl) — the host form stays flat.
-            buckets = parallel.grad_buckets(eng, dp_rows if in_graph else None, fields.get("seqlen"))
+            buckets = parallel.grad_buckets(eng, dp_rows if in_graph else None, fields.get("seqlen"), want=self.config["train"].get("dp_buckets"))
             flat = parallel.grad_buckets(eng, None)
 
             def body(reduce):
@@ -394,10 +394,7 @@ class BaseModel(nn.Module):
                     except Exception as e:                # noqa: BLE001 — any capture failure: keep training with the split form
                         self.logger.warning(f"in-graph all-reduce capture failed ({type(e).__name__}: {e}); using host-launched collectives")
                         ok, g = 0, None
-                    flag = torch.tensor([float(ok)], device=self.device)
-                    import torch.distributed as dist
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # every rank reaches this point for the same global batch
-                    if float(flag) >= 1.0:
+                    if parallel.all_ok(bool(ok)):                   # control plane; every rank reaches this point for the same global batch
                         run = g.replay
                     elif ok:
                         self.logger.warning("in-graph all-reduce capture failed on another rank; using host-launched collectives")

@@ -15,7 +15,7 @@
  *   - fp32 activations/parameters, int64 ids (as the reference stores them), row-major, contiguous
  *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no host sync,
  *     no allocation) so calls may be captured into a hipGraph
- *   - return value: 0 = ok, negative = argument error (DR4SR_E_*), positive = hipError_t
+ *   - return value: 0 = ok, negative = argument error (DR4SR_E_*; transport: DR4SR_E_RCCL_BASE - ncclResult_t), positive = hipError_t
  *   - nothing is retained across calls except what the caller passes in (plan + workspace)
  */
 #ifndef DR4SR_HIP_H
@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define DR4SR_ABI_VERSION 7
+#define DR4SR_ABI_VERSION 8
 
 #define DR4SR_E_ARG      (-1)   /* null pointer / bad size                                   */
 #define DR4SR_E_SHAPE    (-2)   /* unsupported D / H / F / L combination     */
 #define DR4SR_E_WS       (-3)   /* workspace too small                                       */
+#define DR4SR_E_RCCL_BASE (-100) /* transport (ABI 8): an RCCL error r is returned as DR4SR_E_RCCL_BASE - r (ncclResult_t, r >= 1) */
 
 /* dropout sites (RNG stream ids); per-layer sites are  kind + 4*layer */
 #define DR4SR_SITE_EMB   0      /* sasrec.py:66   dropout(seq_embs + position_embs)          */
@@ -178,6 +179,40 @@ int dr4sr_adam_step_prepare_next(const dr4sr_sasrec_plan* plan, void* stream);
  * Phase 1 + phase 2 leave exactly what dr4sr_sasrec_fwd_bwd[_prepared] leaves (same kernels, same jobs, cut into two launches). */
 int dr4sr_sasrec_grad_buckets(const dr4sr_sasrec_plan* plan, int64_t* bounds /* [3] or NULL */);
 int dr4sr_sasrec_fwd_bwd_phase(const dr4sr_sasrec_plan* plan, int32_t prepared, int32_t phase, void* stream);
+
+/* ABI 8 — the data-parallel TRANSPORT: RCCL collectives enqueued on the caller's HIP stream (csrc/comm.hip; library links librccl).
+ * SURVEY.md section 8(b) names `allreduce_flat(buf)` (RCCL) among the native entry points and 8(e) `ncclAllReduce(sum, fp32)` over the
+ * flat gradient buffer {E | P | encoder layers | n_valid, loss_sum, poison, -}; the reference has no distributed path
+ * (/root/reference/utils/callbacks.py:130 is its TODO), so these replace no reference line — they are what a maintainer adding DP to
+ * model/basemodel.py:193-199 (between `loss.backward()` and `optimizer.step()`) would call.  One communicator per process and GPU:
+ *   rank 0:      dr4sr_comm_unique_id(id)        (HOST buffer of DR4SR_COMM_ID_BYTES) ; carry `id` to every rank by any host means
+ *   every rank:  dr4sr_comm_init_rank(id, rank, world, device, &comm)                   (collective; hipSetDevice(device) inside)
+ *   per step:    dr4sr_sasrec_fwd_bwd(plan, s) ; dr4sr_allreduce_f32(comm, plan->grads, plan->n_params + 4, s) ; dr4sr_adam_step(plan, s)
+ * A collective is an enqueue on `stream`, ordered like a kernel launch: no host thread, no host sync, capturable into a hipGraph with the
+ * kernels around it.  Two-bucket step (dr4sr_sasrec_fwd_bwd_phase): dr4sr_allreduce_f32_async puts the collective on the communicator's
+ * own side stream BEHIND everything already enqueued on `stream`, which does not wait for it — phase 2's launch runs beside the table
+ * bucket's all-reduce (inside a capture: a parallel branch of the graph); dr4sr_comm_join(comm, stream) makes `stream` wait for every
+ * collective started that way.  Every rank must enter the same collectives in the same order with the same sizes.
+ * Errors: DR4SR_E_ARG, a hipError_t (> 0), or DR4SR_E_RCCL_BASE - ncclResult_t; dr4sr_comm_error_string(rc) names any of them.
+ * dr4sr_comm_destroy synchronises the side stream and frees the communicator (collective with RCCL: call on every rank). */
+#define DR4SR_COMM_ID_BYTES 128
+#define DR4SR_RED_SUM 0
+#define DR4SR_RED_MAX 1
+#define DR4SR_RED_MIN 2
+typedef struct dr4sr_comm dr4sr_comm;
+int dr4sr_comm_unique_id(void* id_out /* host, DR4SR_COMM_ID_BYTES */);
+int dr4sr_comm_init_rank(const void* id /* host */, int32_t rank, int32_t world, int32_t device, dr4sr_comm** out);
+int dr4sr_comm_destroy(dr4sr_comm* comm);
+int dr4sr_comm_rank(const dr4sr_comm* comm);
+int dr4sr_comm_world(const dr4sr_comm* comm);
+int dr4sr_comm_async_error(dr4sr_comm* comm);                 /* 0, or the communicator's asynchronous RCCL error as a return code */
+const char* dr4sr_comm_error_string(int rc);
+int dr4sr_allreduce_f32(dr4sr_comm* comm, float* buf, int64_t n, void* stream);            /* in place, sum */
+int dr4sr_allreduce_f64(dr4sr_comm* comm, double* buf, int64_t n, int32_t op /* DR4SR_RED_* */, void* stream);
+int dr4sr_allreduce_f32_async(dr4sr_comm* comm, float* buf, int64_t n, void* stream);      /* on the side stream, after `stream`'s work so far */
+int dr4sr_comm_join(dr4sr_comm* comm, void* stream);                                       /* `stream` waits for the async collectives */
+int dr4sr_allgather_bytes(dr4sr_comm* comm, const void* send, void* recv /* world * bytes */, int64_t bytes, void* stream);
+int dr4sr_broadcast_bytes(dr4sr_comm* comm, void* buf, int64_t bytes, int32_t root, void* stream);
 
 /* SASRecQueryEncoder.forward + SeqPoolingLayer (sasrec.py:39-75, layers.py:41-50/:69-73).
  * training != 0 applies dropout (RNG step = state[RNGSTEP]) and keeps activations in the

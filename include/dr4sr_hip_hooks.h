@@ -69,6 +69,12 @@ int dr4sr_gru4rec_launch_kernel(const dr4sr_gru4rec_plan* plan, int32_t kernel, 
 #define DR4SR_FK_WGRAD      4
 int dr4sr_fmlp_launch_kernel(const dr4sr_fmlp_plan* plan, int32_t kernel, int32_t layer, void* stream);
 
+/* Measurement hook of bench.py (the driver's contract is ONE JSON line on stdout): keep a COMPLETE line ready, and if the process is
+ * then killed by a fatal signal (SIGABRT from a foreign thread's uncaught exception, SIGSEGV / SIGBUS / SIGFPE / SIGILL, or the SIGTERM
+ * a launcher sends to the surviving ranks when another rank died) write it to `fd` and _exit(exit_code) from the signal handler —
+ * write(2) and _exit(2) only.  line = NULL disarms and restores the previous handlers.  The line is copied.  Returns 0, or DR4SR_E_ARG. */
+int dr4sr_crash_line_set(const char* line, int32_t fd, int32_t exit_code);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,23 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: GPU tests with minutes of CPU oracle time; not part of -m gpu (run -m 'gpu or slow')")
+    config.addinivalue_line("markers", "transport: launches child processes (torch.distributed.run / bench.py); collected last")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Transport / subprocess tests run LAST: they launch `torch.distributed.run` children or whole bench.py
+    processes, and under the driver's `pytest -x` one failure there used to hide every parity module that sorts behind it alphabetically
+    (round 5: all of test_gpu_trained.py and test_gpu_xcd_order.py).  A test is a transport test when it is marked `transport` or its code
+    names one of the launch helpers (tests/_launch.py torchrun, subprocess)."""
+    def is_transport(item):
+        if item.get_closest_marker("transport") is not None:
+            return True
+        fn = getattr(item, "function", None)
+        names = set(getattr(getattr(fn, "__code__", None), "co_names", ()))
+        return bool(names & {"torchrun", "subprocess"})
+    first = [it for it in items if not is_transport(it)]
+    last = [it for it in items if is_transport(it)]
+    items[:] = first + last
 
 
 @pytest.fixture(scope="session")

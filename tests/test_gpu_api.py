@@ -266,15 +266,10 @@ def test_train_steps_equals_repeated_train_step(B, U):
 def test_data_parallel_ranks_equal_single_rank():
     """2 ranks (gloo, sharing cuda:0) sharding every global batch + one sum-all-reduce of the flat gradient and its {n_valid, loss}
     tail == a single rank on the full batches (tools/dp_check.py); replicas stay bit-identical."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29541", os.path.join(root, "tools", "dp_check.py")], capture_output=True, text=True,
-                         timeout=300, env=env, cwd=root)
+    from _launch import report, torchrun
+    out = torchrun(2, "tools/dp_check.py", {"DR4SR_DP_BACKEND": "gloo"}, timeout=300)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CHECK")]
-    assert out.returncode == 0 and len(lines) == 2, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and len(lines) == 2, report(out)
     assert "replica checksums equal: True" in lines[1]
 
 
@@ -290,15 +285,10 @@ def test_data_parallel_fit_other_models(tmp_path, model_name):
         model_name, extra = "SASRec", {"DR4SR_EMBED_DIM": "128"}
     if model_name == "MetaModel-CL4SRec":                 # round 4: the tuple-loss sub-model, its contrastive term over the gathered global batch
         model_name, extra = "MetaModel", {"SUB_MODEL": "CL4SRec"}
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29581", os.path.join(root, "tools", "dp_fit_check.py")], capture_output=True, text=True,
-                         timeout=500, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path),
-                                               MODEL=model_name, **extra), cwd=root)
+    from _launch import report, torchrun
+    out = torchrun(2, "tools/dp_fit_check.py", dict(DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path), MODEL=model_name, **extra), timeout=500)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT ")]
-    err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]
+    err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else report(out)
     assert out.returncode == 0 and len(lines) == 1, err
     assert "replicas identical: True; finite: True" in lines[0] and "one ckpt stem: True" in lines[0], lines[0]
 
@@ -307,14 +297,10 @@ def test_data_parallel_fit_other_models(tmp_path, model_name):
 def test_data_parallel_fit_end_to_end(tmp_path):
     """fit() under 2 ranks (gloo, sharing cuda:0) on a dataset whose tail batch splits unevenly (13 rows: rank 0 gets a new slice size,
     rank 1 an empty one): every rank must enter the same collectives (graph warm-ups stay local) and the replicas stay bit-identical"""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29571", os.path.join(root, "tools", "dp_fit_check.py")], capture_output=True, text=True,
-                         timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path)), cwd=root)
+    from _launch import report, torchrun
+    out = torchrun(2, "tools/dp_fit_check.py", dict(DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path)), timeout=400)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT")]
-    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and len(lines) == 1, report(out)
     assert "replicas identical: True; finite: True" in lines[0] and "steps=27" in lines[0]
     # quickstart.run under W ranks: ONE log / checkpoint stem (rank 0's), every rank loaded rank 0's best checkpoint in evaluate()
     assert "one ckpt stem: True" in lines[0]
@@ -334,7 +320,7 @@ def test_bench_self_launches_n_ranks_on_a_shared_gpu():
                           "--no-throughput-mode", "--strong-global-batch", "512"], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, DR4SR_BENCH_SHARE_GPU="1"), cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and len(lines) == 1, "rc=%s\n" % out.returncode + out.stdout[-3000:] + out.stderr[-6000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 512 and j["config"]["parallelism"] == "dp2"
     assert "gloo" in j["config"]["collective"] and j["value"] > 0 and j["scaling"] == "weak"
@@ -347,15 +333,11 @@ def test_bench_single_rank_rccl_in_graph_allreduce():
     """the default N-rank form — RCCL all-reduce captured inside the k-step graph — exercised with the one rank a 1-GPU box has
     (DR4SR_BENCH_FORCE_DP); asserts that RCCL, not a fallback, carried the reduce"""
     import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                          "--no-throughput-mode", "--no-strong", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, DR4SR_BENCH_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=root)
+    from _launch import report, torchrun
+    out = torchrun(1, "bench.py", {"DR4SR_BENCH_FORCE_DP": "1"}, args=["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-throughput-mode",
+                                                                     "--no-strong", "--no-cpu-baseline"], timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and len(lines) == 1, report(out)
     j = json.loads(lines[0])
     assert "rccl all-reduce captured in the step graph" in j["config"]["collective"], j["config"]
     assert j["final_loss"] == j["final_loss"] and 0.5 < j["final_loss"] < 2.0

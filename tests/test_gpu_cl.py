@@ -262,13 +262,10 @@ def test_cl4srec_data_parallel_equals_single_process(tail):
     (CL4SRec._cl_term); 2 ranks sharing the GPU over the gloo transport == one process on the concatenated batches, same negatives,
     same views (tools/dp_cl_check.py).  tail = rows of the ragged last batch: 20 -> slices of 20 and 0 (an empty rank still takes
     part in the gather), 37 -> 32 and 5."""
-    import subprocess
-    import sys
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(29651 + tail), os.path.join(ROOT, "tools", "dp_cl_check.py")], capture_output=True, text=True,
-                         timeout=400, env=dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo", DP_CL_TAIL=str(tail)), cwd=ROOT)
+    from _launch import report, torchrun
+    out = torchrun(2, "tools/dp_cl_check.py", dict(DR4SR_DP_BACKEND="gloo", DP_CL_TAIL=str(tail)), timeout=400)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CL_CHECK")]
-    err = out.stdout[out.stdout.find("DP_CL_ERROR"):][:3000] if "DP_CL_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]
+    err = out.stdout[out.stdout.find("DP_CL_ERROR"):][:3000] if "DP_CL_ERROR" in out.stdout else report(out)
     assert out.returncode == 0 and len(lines) == 2, err
     print(lines[0])
     assert "replica checksums equal: True" in lines[1]

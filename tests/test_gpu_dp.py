@@ -120,13 +120,12 @@ def test_two_phase_step_is_the_whole_step_in_the_latency_forms():
     assert float((g_one - g_p1).abs().max()) <= 2e-5 * scale                 # fp32 atomics order (table gradient of the latency forms)
     # the probe the model decides with: a full slice of 4 096 rows of this dataset -> two buckets, whatever this plan's own size
     from dr4sr_amd import parallel
-    assert len(parallel.grad_buckets(eng, 4096, data["seqlen"])) == 2 and len(parallel.grad_buckets(eng, 256, data["seqlen"])) == 1
+    assert len(parallel.grad_buckets(eng, 4096, data["seqlen"], want=2)) == 2 and len(parallel.grad_buckets(eng, 256, data["seqlen"], want=2)) == 1
+    assert len(parallel.grad_buckets(eng, 4096, data["seqlen"])) == 1                # flat unless asked (train.dp_buckets / DR4SR_DP_BUCKETS)
     assert len(parallel.grad_buckets(eng, None, data["seqlen"])) == 1
 
 
-def _run(cmd, env, timeout=900):
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, MASTER_ADDR="127.0.0.1", **env), cwd=ROOT)
-    return out
+from _launch import report, torchrun
 
 
 @pytest.mark.parametrize("W,D,B,U,expect", [
@@ -136,11 +135,9 @@ def _run(cmd, env, timeout=900):
     (8, 64, 24576, 27576, "[1, 2]"),     # 8 ranks x 3 072 rows, two buckets; tail 3 000 rows -> rank 0 only, seven EMPTY slices
 ])
 def test_data_parallel_ranks_equal_single_rank_wide(W, D, B, U, expect):
-    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(W), "--master-addr", "127.0.0.1",
-                "--master-port", str(29600 + W + D // 64 + B % 97), os.path.join(ROOT, "tools", "dp_check.py")],
-               {"DP_D": str(D), "DP_B": str(B), "DP_U": str(U), "DR4SR_DP_BACKEND": "gloo"})
+    out = torchrun(W, "tools/dp_check.py", {"DP_D": D, "DP_B": B, "DP_U": U, "DR4SR_DP_BACKEND": "gloo", "DR4SR_DP_BUCKETS": 2})
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_CHECK")]
-    assert out.returncode == 0 and len(lines) == 2, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and len(lines) == 2, report(out)
     assert "buckets=" + expect in lines[0], lines[0]
     assert "replica checksums equal: True" in lines[1]
     if W == 8:
@@ -154,21 +151,17 @@ def test_rccl_buckets_inside_k_step_graph(B, buckets):
     asynchronously after phase 1 and joined before the optimizer (a parallel branch of the graph), the optimizer launches prepare the
     next batch in two phases — against the un-captured single-GPU loop; B = 1 536 (8.4 k tokens: latency forms above the old 1 024-row limit of the
     prepared form): one flat bucket"""
-    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                "--master-port", str(29660 + buckets), os.path.join(ROOT, "tools", "dp_graph_check.py")],
-               {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "DP_GRAPH_B": str(B), "DP_GRAPH_REPLAYS": "6", "DP_GRAPH_K": "3",
-                "DP_GRAPH_EXPECT_BUCKETS": str(buckets)})
-    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    out = torchrun(1, "tools/dp_graph_check.py", {"DP_GRAPH_B": B, "DP_GRAPH_REPLAYS": 6, "DP_GRAPH_K": 3, "DP_GRAPH_EXPECT_BUCKETS": buckets,
+                                                   "DR4SR_DP_BUCKETS": 2})
+    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, report(out)
     print([l for l in out.stdout.splitlines() if l.startswith("DP_GRAPH ")][0])
 
 
 @pytest.mark.parametrize("B", [96, 90])
 def test_metamodel_outer_step_eight_ranks_equal_single_rank(B):
     """BASELINE configs[4] is an 8-GPU configuration: the outer step's all-reduces on 8 ranks (12 rows per rank; B = 90: 12 x 7 + 6)"""
-    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-                "--master-port", str(29680 + B % 7), os.path.join(ROOT, "tools", "dp_meta_check.py")],
-               {"DR4SR_DP_BACKEND": "gloo", "DP_META_B": str(B)})
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    out = torchrun(8, "tools/dp_meta_check.py", {"DR4SR_DP_BACKEND": "gloo", "DP_META_B": B})
+    assert out.returncode == 0, report(out)
     line = [l for l in out.stdout.splitlines() if l.startswith("DP_META")]
     assert line and "world=8" in line[0] and "replicas identical: True" in line[0], out.stdout[-2000:]
     print(line[0])
@@ -181,11 +174,9 @@ def test_data_parallel_fit_eight_ranks(tmp_path, model_name):
     extra = {}
     if model_name == "SASRec-d128":
         model_name, extra = "SASRec", {"DR4SR_EMBED_DIM": "128"}
-    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-                "--master-port", "29691", os.path.join(ROOT, "tools", "dp_fit_check.py")],
-               dict(DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path), MODEL=model_name, **extra))
+    out = torchrun(8, "tools/dp_fit_check.py", dict(DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path), MODEL=model_name, **extra))
     lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT ")]
-    err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else out.stdout[-1500:] + out.stderr[-1500:]
+    err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else report(out)
     assert out.returncode == 0 and len(lines) == 1, err
     assert "world=8" in lines[0] and "replicas identical: True; finite: True" in lines[0] and "one ckpt stem: True" in lines[0], lines[0]
 

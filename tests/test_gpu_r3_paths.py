@@ -178,11 +178,9 @@ def test_metamodel_outer_step_two_ranks_equal_single_rank():
     """SURVEY §8(e) last row: the outer loop's all-reduces (d L_val / dW, six Hessian-vector probes, two mixed-derivative probes of both
     flat buffers) leave every rank with the single-rank hyper-gradient and meta-module step (tools/dp_meta_check.py: 2 ranks sharing
     cuda:0 over the gloo transport of dr4sr_amd/parallel.py, explicit Gumbel noise, dropout 0)"""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DR4SR_DP_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29547", os.path.join(ROOT, "tools", "dp_meta_check.py")], capture_output=True, text=True,
-                         env=env, timeout=600)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    from _launch import report, torchrun
+    out = torchrun(2, "tools/dp_meta_check.py", {"DR4SR_DP_BACKEND": "gloo"}, timeout=600)
+    assert out.returncode == 0, report(out)
     line = [l for l in out.stdout.splitlines() if l.startswith("DP_META")]
     assert line and "replicas identical: True" in line[0], out.stdout[-2000:]
     print(line[0])
@@ -192,9 +190,7 @@ def test_rccl_allreduce_inside_k_step_graph_replayed_120_times():
     """the opt-in data-parallel form (RCCL all-reduce captured inside the k-step graph, dr4sr_amd/model/basemodel.py:_step_graph and
     bench.py) with the one RCCL rank a 1-GPU box has: 30 replays of a 4-step graph = 120 steps, loss log and parameters against the
     un-captured single-GPU loop (tools/dp_graph_check.py)"""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", "29549", os.path.join(ROOT, "tools", "dp_graph_check.py")], capture_output=True, text=True,
-                         env=env, timeout=600)
-    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    from _launch import report, torchrun
+    out = torchrun(1, "tools/dp_graph_check.py", timeout=600)
+    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, report(out)
     print([l for l in out.stdout.splitlines() if l.startswith("DP_GRAPH ")][0])

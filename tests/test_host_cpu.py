@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     product, hook_syms = set(re.findall(r"\b(dr4sr_[a-z0-9_]+)\s*\(", hdr)), set(re.findall(r"\b(dr4sr_[a-z0-9_]+)\s*\(", hooks))
     assert product and hook_syms and not (product & hook_syms), "no declarations parsed / a hook declared in the product header"
     assert hook_syms == {"dr4sr_dropout_mask", "dr4sr_sasrec_launch_kernel", "dr4sr_sasrec_launch_kernel_weighted", "dr4sr_gru4rec_launch_kernel",
-                         "dr4sr_fmlp_launch_kernel", "dr4sr_reload_env"}
+                         "dr4sr_fmlp_launch_kernel", "dr4sr_reload_env", "dr4sr_crash_line_set"}
     declared = product | hook_syms
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
@@ -29,6 +29,55 @@ def test_library_exports_every_declared_symbol():
     assert lib.dr4sr_abi_version() == _lib.ABI_VERSION
     # the ctypes mirror of the plan struct must match the C layout the library was compiled with
     assert C.sizeof(_lib.SasrecPlan) == lib.dr4sr_sasrec_plan_sizeof()
+
+
+def test_transport_entry_points_bind_rccl_directly():
+    """ABI 8 (SURVEY 8(b) `allreduce_flat(buf)` (RCCL), 8(e) ncclAllReduce over the flat gradient): the library itself imports RCCL's
+    collectives — no torch.distributed ProcessGroupNCCL (and none of its threads) between a training step and its all-reduce"""
+    import subprocess
+    so = os.path.join(ROOT, "dr4sr_amd", "csrc", "libdr4sr_hip.so")
+    nm = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    undefined = {l.split()[-1] for l in nm.splitlines() if " U " in l}
+    assert {"ncclAllReduce", "ncclAllGather", "ncclBroadcast", "ncclCommInitRank", "ncclGetUniqueId", "ncclCommDestroy"} <= undefined
+    defined = {l.split()[-1] for l in nm.splitlines() if " T " in l}
+    assert {"dr4sr_comm_unique_id", "dr4sr_comm_init_rank", "dr4sr_comm_destroy", "dr4sr_allreduce_f32", "dr4sr_allreduce_f32_async",
+            "dr4sr_comm_join", "dr4sr_allgather_bytes", "dr4sr_broadcast_bytes"} <= defined
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    assert lib.dr4sr_comm_error_string(0) == b"ok" and lib.dr4sr_comm_error_string(-1) == b"argument error"
+    assert b"invalid usage" in lib.dr4sr_comm_error_string(-100 - 5)          # DR4SR_E_RCCL_BASE - ncclInvalidUsage
+    # argument checks need no GPU
+    assert lib.dr4sr_comm_unique_id(None) == -1 and lib.dr4sr_allreduce_f32(None, None, 4, None) == -1 and lib.dr4sr_comm_join(None, None) == -1
+    # the Python transport never names c10d's NCCL backend
+    src = open(os.path.join(ROOT, "dr4sr_amd", "parallel.py")).read()
+    assert 'init_process_group("nccl"' not in src and 'init_process_group("gloo")' in src
+
+
+def test_crash_line_survives_an_abort(tmp_path):
+    """bench.py's abort safety (include/dr4sr_hip_hooks.h dr4sr_crash_line_set): a process that armed a line and is then killed by SIGABRT
+    — what an uncaught exception in a foreign thread does, uncatchable from Python — still leaves exactly that line on the given fd and
+    exits 0; disarmed, the abort is an abort."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, os, sys\n"
+            "lib = C.CDLL(%r)\n"
+            "lib.dr4sr_crash_line_set.argtypes = [C.c_char_p, C.c_int32, C.c_int32]\n"
+            "fd = os.dup(1)\n"
+            "assert lib.dr4sr_crash_line_set(b'{\"value\": 1, \"aborted_during\": \"x\"}', fd, 0) == 0\n"
+            "assert lib.dr4sr_crash_line_set(b'{\"value\": 2, \"aborted_during\": \"y\"}', fd, 0) == 0\n"
+            "if sys.argv[1] == 'disarm': lib.dr4sr_crash_line_set(None, 0, 0)\n"
+            "if sys.argv[1] == 'thread':\n"
+            "    import threading\n"
+            "    t = threading.Thread(target=os.abort); t.start(); t.join()\n"
+            "if sys.argv[1] == 'term':\n"
+            "    import signal; os.kill(os.getpid(), signal.SIGTERM)\n"
+            "    import time; time.sleep(5)\n"
+            "os.abort()\n") % os.path.join(ROOT, "dr4sr_amd", "csrc", "libdr4sr_hip.so")
+    for mode in ("main", "thread", "term"):
+        out = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout == '{"value": 2, "aborted_during": "y"}\n', (mode, out.returncode, out.stdout, out.stderr[-500:])
+    out = subprocess.run([sys.executable, "-c", code, "disarm"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and out.stdout == ""
 
 
 def test_param_layout_matches_reference_state_dict(golden_dir):

@@ -64,9 +64,9 @@ def run(B, form, split=None):
                 parallel.dp_backward(eng, plan, prepared, two)
             elif form == "H":
                 eng.fwd_bwd_phase(plan, prepared, 1)
-                dist.all_reduce(eng.grads[two[0][0]:two[0][1]])
+                parallel.allreduce_flat(eng.grads[two[0][0]:two[0][1]])
                 eng.fwd_bwd_phase(plan, prepared, 2)
-                dist.all_reduce(eng.grads[two[1][0]:two[1][1]])
+                parallel.allreduce_flat(eng.grads[two[1][0]:two[1][1]])
             (eng.adam_step_prepare_next if j < n - 1 else eng.adam_step)(plan)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -97,4 +97,4 @@ for B in [int(x) for x in os.environ.get("PROBE_B", "4096,16384").split(",")]:
                               ("H", "1", "two-phase split 1 + all-reduces on the current stream")):
         ms = run(B, form, split)
         print("DP_COST B=%d  %s %-62s %.4f ms  (+%.1f us)" % (B, form, what, ms, 1e3 * (ms - base)), flush=True)
-dist.destroy_process_group()
+parallel.shutdown()

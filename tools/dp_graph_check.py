@@ -1,5 +1,5 @@
 """RCCL all-reduce captured INSIDE a k-step HIP graph, replayed many times — the only RCCL-in-graph evidence a
-1-GPU box can give: one rank (world_size 1, backend nccl = RCCL), k whole data-parallel steps per graph in the form
+1-GPU box can give: one rank (world_size 1, the library's own RCCL communicator — dr4sr_comm_*, include/dr4sr_hip.h ABI 8), k whole data-parallel steps per graph in the form
 BaseModel._step_graph / bench.py capture (fwd_bwd[_prepared] -> all-reduce of the flat gradient + tail -> adam_step[_prepare_next]),
 REPLAYS x k steps, per-step loss log and final parameters against the un-captured single-GPU form (dr4sr_sasrec_train_step in a
 loop, no collective, no graph).  Same seeds, dropout and in-kernel negatives on both sides.
@@ -19,7 +19,7 @@ from dr4sr_amd.utils.graphs import capture
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 parallel.init_distributed(dev)
-assert dist.get_backend() == "nccl" and parallel.can_capture()
+assert parallel.can_capture() and parallel.backend_name() == "rccl"
 # DP_GRAPH_B=8192: the at-scale launch forms -> TWO gradient buckets (parallel.dp_backward: the table bucket's all-reduce is a parallel
 # branch of the captured graph beside the last weight-gradient launch), optimizer launches with the two-phase prep
 U, B, L, N, K, REPLAYS = 19412, int(os.environ.get("DP_GRAPH_B", "256")), 50, TOYS_N_ITEMS, int(os.environ.get("DP_GRAPH_K", "4")), int(os.environ.get("DP_GRAPH_REPLAYS", "30"))
@@ -50,7 +50,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 # ---- captured: k DP steps + their k RCCL all-reduces in ONE graph
 eng1, plan1, c1, log1 = make()
-buckets = parallel.grad_buckets(eng1, B, data["seqlen"])
+buckets = parallel.grad_buckets(eng1, B, data["seqlen"])          # (two buckets are opt-in: DR4SR_DP_BUCKETS=2)
 if os.environ.get("DP_GRAPH_EXPECT_BUCKETS"):
     assert len(buckets) == int(os.environ["DP_GRAPH_EXPECT_BUCKETS"]), buckets
 stream = torch.cuda.Stream(device=dev)
@@ -79,5 +79,5 @@ print("DP_GRAPH rccl in-graph all-reduce (B = %d, %d bucket(s)): %d steps = %d r
       "final params max abs diff %.2e (|param| max %.3f), loss %.4f -> %.4f" % (B, len(buckets), steps, REPLAYS, K, d_first, d_all, dp, float(eng0.params.abs().max()),
                                                                                  float(log1[0]), float(log1[-1])))
 assert d_first < 2e-5 and d_all < 5e-3 and dp < 5e-3 and float(log1[-1]) < float(log1[0])
-print("DP_GRAPH_OK")
-dist.destroy_process_group()
+print("DP_GRAPH_OK", flush=True)
+parallel.shutdown()

@@ -14,4 +14,4 @@ for B in [int(x) for x in os.environ.get("SWEEP_B", "4096,16384").split(",")]:
         for f in forms:
             res.append("%s %.4f" % (f, run(B, f, {"C": "1", "D": "2"}.get(f))))
         print("DP_SWEEP B=%d %s=%s  %s ms" % (B, name, v, "  ".join(res)), flush=True)
-dist.destroy_process_group()
+parallel.shutdown()

@@ -22,7 +22,7 @@ assert torch.cuda.device_count() >= world, "one device per rank: %d devices for 
 dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
 parallel.init_distributed(dev)
-assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+assert parallel.can_capture() and dist.get_world_size() == world      # the library's own RCCL communicator; the gloo group is the control plane
 U, B, L, N, K, REPLAYS = 4096, 256 * world, 50, TOYS_N_ITEMS, 4, 3
 steps = K * REPLAYS
 rows = make_rows(n_rows=U, n_items=N, seed=21)
@@ -76,7 +76,7 @@ def train(eng, w, r, form):
 
 for form in ("host", "in_graph"):
     p_dp = train(make(B // world), world, rank, form)
-    chk = torch.tensor([float(p_dp.double().sum())], dtype=torch.float64, device=dev)
+    chk = torch.tensor([float(p_dp.double().sum())], dtype=torch.float64)      # (control plane: host tensors)
     lst = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(lst, chk)
     if rank == 0:
@@ -89,4 +89,4 @@ for form in ("host", "in_graph"):
     dist.barrier()
 if rank == 0:
     print("DP_RCCL_OK", flush=True)
-dist.destroy_process_group()
+parallel.shutdown()
