@@ -28,6 +28,9 @@ import ctypes as C  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pmc_match  # noqa: E402  (tools/pmc_match.py: launch kind -> the one rocprofv3 kernel name of the regime)
+
 PROFILE_ROUND = 6              # profiles/round<N>_* files this bench refers to (tools/refresh_profiles.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -133,18 +136,13 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
         pj = os.path.join(ROOT, "profiles", "round%d_pmc_traffic_%s.json" % (rnd, tag)) if tag and D == 64 else None
         if pj and os.path.exists(pj):
             pm = json.load(open(pj))
-            prefix = {"attn_fwd": "k_attn", "attn_bwd": "k_attn", "post_fwd": "k_post_fwd", "post_bwd": "k_post_bwd",
-                      "post_mid": "k_post_mid", "wgrad_fused": "k_wgrad", "embqkv_fwd": "k_embqkv_fwd",
-                      "qkv_embed_bwd": "k_qkv_embed_bwd"}[dom]
-            want_bwd = dom == "attn_bwd"
-
-            def is_bwd(k):                     # k_attn2_bwd<...> / k_attn_tiny<DH, true>
-                return "_bwd" in k or (k.startswith("k_attn_tiny") and k.rstrip(">").endswith("true"))
-            # (the at-scale forms of the token-tile kernels are the wave-tile ones of csrc/linear_wave.hip: k_wt_<name>)
-            hits = [v["hbm_bytes_per_launch"] for k, v in pm.items()
-                    if (k.startswith(prefix) or k.startswith("k_wt_" + prefix[2:])) and (not dom.startswith("attn") or is_bwd(k) == want_bwd)]
-            if hits:
-                traffic, traffic_src = float(sum(hits)), os.path.relpath(pj, ROOT)
+            # exactly ONE kernel name per (launch kind, regime) — tools/pmc_match.py; round 5 summed k_post_mid + k_wt_post_mid here
+            if dom.startswith("attn"):
+                got = pmc_match.match_attention(pm, dom == "attn_bwd")
+            else:
+                got = pmc_match.match(pm, dom, big, D)[0]
+            if got is not None:
+                traffic, traffic_src = got, os.path.relpath(pj, ROOT)
                 break
     # `traffic` is NOT measured by this run: rocprofv3 --pmc passes cannot run inside the bench; it is the per-launch HBM
     # byte count of the same kernel on the same workload from the committed PMC profile named in `traffic_source`

@@ -526,3 +526,27 @@ def test_bucketed_allreduce_equals_flat_gloo(world):
         one.fwd_bwd(list(range(i * 20, min(43, (i + 1) * 20))))         # the single-rank gradient of the whole global batch
         np.testing.assert_allclose(bucketed, one.grads.numpy(), rtol=1e-5, atol=1e-4)
         assert calls == ((["p1", "p2"] if i < 2 else ["flat"]) if nrows else [])
+
+
+def test_pmc_traffic_matcher_names_exactly_one_kernel_per_regime():
+    """bench.py's roofline.traffic summed k_post_mid + k_wt_post_mid (16.64 + 10.03 MB) because the committed round-5
+    PMC digest holds both regimes' kernels; tools/pmc_match.py picks the regime's ONE kernel.  Fed with the committed digests."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_match
+    pm = json.load(open(os.path.join(ROOT, "profiles", "round5_pmc_traffic_B256_toys.json")))
+    b, name = pmc_match.match(pm, "post_mid", False)
+    assert name.startswith("k_post_mid<") and abs(b - 16640816) < 1
+    b, name = pmc_match.match(pm, "post_mid", True)
+    assert name.startswith("k_wt_post_mid<") and abs(b - 10029921) < 1
+    b, name = pmc_match.match(pm, "wgrad_fused", False)
+    assert name.startswith("k_wgrad_blk<")                                     # not k_wgrad_det_reduce, not k_wgrad_bf64
+    assert pmc_match.match(pm, "wgrad_fused", True)[1].startswith("k_wgrad_bf64<")
+    assert pmc_match.match(pm, "qkv_embed_bwd", False) == (None, None)         # the latency regime has no such launch
+    big = json.load(open(os.path.join(ROOT, "profiles", "round5_pmc_traffic_B8192_toys.json")))
+    assert abs(pmc_match.match(big, "wgrad_fused", True)[0] - 420645591) < 1 and pmc_match.match(big, "post_mid", False) == (None, None)
+    assert pmc_match.match_attention(big, True) == 16896775 + 20876035 + 46685611
+    assert pmc_match.stem("void tiny::k_attn_tiny_bwd<32>(Args)") == "k_attn_tiny_bwd"
+    with pytest.raises(ValueError):
+        pmc_match.match({"k_post_mid<16, 64, 128, false>": {"hbm_bytes_per_launch": 1}, "k_post_mid<16, 64, 128, true>": {"hbm_bytes_per_launch": 2}},
+                        "post_mid", False)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r${ROUND:-5}; mkdir -p $O
 trace() {  # tag, bench args...
   tag=$1; shift
   rm -rf /tmp/kt_$tag
-  timeout 400 rocprofv3 --kernel-trace -d /tmp/kt_$tag -o t -- python $R/bench.py --no-cpu-baseline --no-throughput-mode --no-strong "$@" > /tmp/kt_$tag.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace -d /tmp/kt_$tag -o t -- python $R/bench.py --no-cpu-baseline --no-throughput-mode --no-strong --no-deterministic-leg "$@" > /tmp/kt_$tag.log 2>&1
   db=$(find /tmp/kt_$tag -name "*.db" | head -1)
   python $R/tools/kstat.py $db 24 > $O/kernels_$tag.txt
   python $R/tools/ktimeline.py $db 100 > $O/timeline_$tag.txt
@@ -16,7 +16,7 @@ trace sasrec_dense_B256 --steps 200 --warmup 20 --dense
 trace sasrec_B8192 --steps 60 --warmup 10 --batch 8192
 trace sasrec_dense_B8192 --steps 40 --warmup 10 --batch 8192 --dense
 # the literal rocprofv3 --stats summary of the default bench command
-rm -rf /tmp/st_default; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_default -o d -- python $R/bench.py --no-cpu-baseline --no-throughput-mode --no-strong > /tmp/st_default.log 2>&1
+rm -rf /tmp/st_default; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_default -o d -- python $R/bench.py --no-cpu-baseline --no-throughput-mode --no-strong --no-deterministic-leg > /tmp/st_default.log 2>&1
 cp $(find /tmp/st_default -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_default.csv
 cd $R
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json

@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTI
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/sq_$i
   timeout 300 rocprofv3 --pmc $set --kernel-trace -d /tmp/sq_$i -o t -- \
-    python $R/bench.py --steps 6 --warmup 2 --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --batch 8192 $SQ_EXTRA > /tmp/sq_$i.log 2>&1
+    python $R/bench.py --steps 6 --warmup 2 --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --no-deterministic-leg --batch 8192 $SQ_EXTRA > /tmp/sq_$i.log 2>&1
   db=$(find /tmp/sq_$i -name "*.db" | head -1)
   [ -n "$db" ] && python - "$db" >> $O/sq_pmc_B8192_toys.txt <<'PY'
 import sqlite3, sys, collections

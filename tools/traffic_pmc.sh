@@ -6,7 +6,7 @@ run() {  # tag, bench args
   tag=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pm_${tag}_$c
-    timeout 400 rocprofv3 --pmc $c --kernel-trace -d /tmp/pm_${tag}_$c -o t -- python $R/bench.py --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --steps 6 --warmup 2 "$@" > /tmp/pm_${tag}_$c.log 2>&1
+    timeout 400 rocprofv3 --pmc $c --kernel-trace -d /tmp/pm_${tag}_$c -o t -- python $R/bench.py --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --no-deterministic-leg --steps 6 --warmup 2 "$@" > /tmp/pm_${tag}_$c.log 2>&1
   done
   python $R/tools/traffic_pmc.py $(find /tmp/pm_${tag}_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pm_${tag}_WRITE_SIZE -name "*.db" | head -1) > $O/pmc_traffic_$tag.json
 }

@@ -9,7 +9,7 @@ for order in xcd plain; do
     tag=$(echo ${order}_$c | tr ' ' '_')
     rm -rf /tmp/xp_$tag
     if [ $order = plain ]; then export DR4SR_TILE_ORDER_PLAIN=1; else unset DR4SR_TILE_ORDER_PLAIN; fi
-    timeout 400 rocprofv3 --pmc $c --kernel-trace -d /tmp/xp_$tag -o t -- python $R/bench.py --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --steps 40 --warmup 5 ${ARGS:-} > /tmp/xp_$tag.log 2>&1
+    timeout 400 rocprofv3 --pmc $c --kernel-trace -d /tmp/xp_$tag -o t -- python $R/bench.py --no-graph --no-cpu-baseline --no-throughput-mode --no-strong --no-deterministic-leg --steps 40 --warmup 5 ${ARGS:-} > /tmp/xp_$tag.log 2>&1
     echo "== order=$order counters=$c ${ARGS:-}" >> $O/xcd_pmc.txt
     python $R/tools/pmcstat.py $(find /tmp/xp_$tag -name "*.db" | head -1) k_embqkv_fwd k_post_fwd k_post_mid k_post_bwd k_wgrad_blk >> $O/xcd_pmc.txt 2>&1
   done
