@@ -119,7 +119,8 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
     # three different kernels backward (1..8-token VALU class, 16-row, 64-row) and two forward: their summed time is no kernel's share
     # (round 4: the sum, 2 x 47 us at toys B = 8 192, tied with k_wt_post_mid's 95 us and made a three-kernel "kernel" the roofline's subject)
     # (round 4, plan bit 3: short-sequence plans at d = 64 run ONE window-attention launch per layer and direction instead — csrc/attn_tile_sa.hip)
-    lists = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 2) and not bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 8)
+    # (round 6, plan bit 4: where the lists would run, ONE wave-per-tile launch per layer and direction — csrc/attn_wave.hip)
+    lists = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 2) and not bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & (8 | 16))
     names_per_kind = {"attn_bwd": 3 if lists else 1, "attn_fwd": 2 if lists else 1}
     dom = max((k for k in step_us if kernel_flops(k, 1, B, L, D, F, NL, seqlen_last, big) > 0),
               key=lambda k: step_us[k] / names_per_kind.get(k, 1))

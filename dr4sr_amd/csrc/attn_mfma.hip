@@ -598,6 +598,7 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
     A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.layer = layer; A.training = training; A.L = p->L;
     A.list = nullptr; A.list_count = nullptr; A.desc = nullptr; A.stat = lw.attn_st; A.rd = ws.attn_rd;
+    A.tok = attn_wave_on(p, ws) ? ws.tok : nullptr;
     return A;
 }
 
@@ -632,6 +633,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
         else { big_lds(k_attn2_fwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
         return DR4SR_LAUNCH_CHECK();
     }
+    if (A.tok) return launch_attn_wave(A, DH, ws.Tmax, bwd, s);     // round 6: one wave per (token tile, head[, phase]), no lists (attn_wave.hip)
     // persistent grids = what is really co-resident (registers, LDS and wave slots, as the runtime computes it): a larger grid
     // runs in two rounds with an unbalanced tail, a smaller one leaves latency-hiding slots empty
     static int per_cu[2][2];                                                 // [bwd][long], per head width

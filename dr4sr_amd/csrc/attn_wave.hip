@@ -1,0 +1,349 @@
+// attn_wave.hip — causal 2-head self-attention over the PACKED TOKEN STREAM, one wave per (16-token tile, head[, phase]): the at-scale
+// attention of short-sequence plans as ONE launch per layer and direction (round 6).
+//
+// What it replaces.  At scale the attention of a layer was five launches over k_prep's length-class lists (attn_mfma.hip: 1..8-token VALU
+// class + 9..16-token MFMA list forward in one launch, the 64-row list in a second; three launches backward): 26 + 51 us per layer of a
+// 511 us step at toys B = 8 192 (profiles/round5_kernels_sasrec_B8192.txt), each launch a latency chain (list entry -> cu / rows ->
+// K | V rows -> LDS -> barrier -> compute) on a grid that holds one class.  Round 4's window form (attn_tile_sa.hip) put every tile through
+// a 256-thread workgroup with an 80-row LDS window and was slower than the lists.  This form has no lists, no LDS and no barrier:
+//   * the wave that owns query tile `it` (tokens [16 it, 16 it + 16) of the packed stream, whatever sequences they belong to) reads the
+//     per-token words the embedding stage wrote (Workspace::tok: {first token of the sequence, slot | length << 20 | PAD << 30}),
+//     finds the earliest key tile any of its queries needs (a wave-uniform minimum: 1 or 2 tiles for the short sequences that make up
+//     95 % of a toys batch, up to 5 for a 50-token sequence) and walks exactly those tiles;
+//   * "same sequence, causal, not PAD" is one comparison chain per score: key token tk belongs to query tq's sequence iff
+//     s0 <= tk, and causality is tk <= tq — the token order of the packed stream IS the position order inside a sequence;
+//   * operands go from global memory straight into MFMA fragments (attn_mfma.hip's transposed orientation: S^T = K Q^T, so the softmax
+//     output is the next product's B operand as it stands); rows of other sequences are multiplied by probabilities that are exactly 0;
+//   * backward: phase A (a wave per query tile and head) recomputes P^T and writes dQ; phase B (a wave per KEY tile and head) recomputes
+//     P for the query tiles [it, last tile any of its keys' sequences reaches] and writes dK | dV — every dqkv row has one writer, no
+//     atomics, bit-reproducible (the deterministic mode uses the same launch).
+// Arithmetic, saved statistics {row max, 1 / row sum} and dropout elements ((slot H + h) 64 + i) 64 + j are attn_mfma.hip's: the two forms
+// are interchangeable per launch and the tests hold them against each other and the oracle.
+//
+// Reference arithmetic: torch.nn.MultiheadAttention inside nn.TransformerEncoderLayer as configured at /root/reference model/sasrec.py:21-34
+// and called at :65-68: attn_mask = triu(ones, 1) (:58), key_padding_mask = (idx == 0) (:48), scale 1 / sqrt(head_dim), dropout on the
+// probabilities.
+#include "common.h"
+#include "kernels.h"
+#include "attn_args.h"
+
+namespace {
+
+constexpr int MT = 5;                         // key tiles a query tile can need: a sequence of <= 64 tokens touches at most 5 tiles
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float xg_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
+__device__ __forceinline__ float xg_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ int min16(int v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int max16(int v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// row fragment of an MFMA operand: lane (r16, g) takes DH / 4 consecutive floats of row (row0 + r16) at column col0 + g DH / 4; rows >= T
+// read as zero (rows behind the batch's last token hold whatever an earlier, larger batch left there)
+template <int DH>
+__device__ __forceinline__ void frag_rows(float (&f)[DH / 4], const float* __restrict__ base, const int ld, const int row0, const int col0, const int T) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    if (row0 + r16 < T) {
+        const float* p = base + (size_t)(row0 + r16) * ld + col0 + g * (DH / 4);
+#pragma unroll
+        for (int c = 0; c < DH / 4; c += 4) {
+            const float4 v = ld4(p + c);
+            f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) f[c] = 0.f;
+    }
+}
+template <int DH>
+__device__ __forceinline__ f32x4 mma_rows(const float (&a)[DH / 4], const float (&b)[DH / 4]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < DH / 4; ++s) acc = mfma16(a[s], b[s], acc);
+    return acc;
+}
+// acc[fb] += sum over the tile's 16 rows of M[row][col0 + 16 fb + i16] * w[row]: the A operand (rows 4 g + s, one column per lane) straight
+// from global memory — 16 lanes read 64 consecutive bytes of each of 4 rows
+template <int DH>
+__device__ __forceinline__ void mma_cols(f32x4 (&acc)[DH / 16], const float* __restrict__ base, const int ld, const int row0, const int col0, const f32x4 w,
+                                         const int T) {
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    float v[DH / 16][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int row = row0 + 4 * g + s;
+#pragma unroll
+        for (int fb = 0; fb < DH / 16; ++fb) v[fb][s] = row < T ? base[(size_t)row * ld + col0 + 16 * fb + i16] : 0.f;
+    }
+#pragma unroll
+    for (int fb = 0; fb < DH / 16; ++fb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[fb] = mfma16(v[fb][s], w[s], acc[fb]);
+}
+
+// keep decisions of one (query row, head): bit j of lo / hi = key position j / 32 + j is kept.  The four lanes of a query column each
+// compute one Philox call (8 decisions) and exchange them; `hi` only when some query of the tile has more than 32 keys (wave-uniform).
+struct Keep64 { unsigned lo, hi; };
+__device__ __forceinline__ Keep64 keep_row(const RngKey& rk, const uint32_t site, const uint64_t ebase, const bool need_hi, const bool dodrop) {
+    Keep64 k{0xffffffffu, 0xffffffffu};
+    if (!dodrop) return k;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    const unsigned m8 = drop_bits8(rk, site, ebase + 8 * g);
+    k.lo = __shfl(m8, i16, 64) | (__shfl(m8, i16 | 16, 64) << 8) | (__shfl(m8, i16 | 32, 64) << 16) | (__shfl(m8, i16 | 48, 64) << 24);
+    if (need_hi) {
+        const unsigned n8 = drop_bits8(rk, site, ebase + 32 + 8 * g);
+        k.hi = __shfl(n8, i16, 64) | (__shfl(n8, i16 | 16, 64) << 8) | (__shfl(n8, i16 | 32, 64) << 16) | (__shfl(n8, i16 | 48, 64) << 24);
+    }
+    return k;
+}
+__device__ __forceinline__ float keep_at(const Keep64& k, const int pos, const float scale) {
+    const unsigned w = pos < 32 ? k.lo : k.hi;
+    return ((w >> (pos & 31)) & 1u) ? scale : 0.f;
+}
+
+// PAD flags (bit 30 of the token words) of key tile jt as 16 bits, wave-uniform
+__device__ __forceinline__ unsigned pad_bits(const int2* __restrict__ tok, const int jt, const int T) {
+    const int lane = threadIdx.x & 63, t = 16 * jt + (lane & 15);
+    const int w = (lane < 16 && t < T) ? tok[t].y : 0;
+    return (unsigned)(__ballot((w >> 30) & 1) & 0xffffull);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// 256 threads = 2 query tiles x 2 heads
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_wave_fwd(const AttnArgs2 A) {
+    constexpr int D = 2 * DH, H = 2;
+    const int T = A.state[DR4SR_STATE_T];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, i16 = lane & 15, g = lane >> 4;
+    const int it = 2 * (int)blockIdx.x + (w >> 1), t0 = 16 * it;
+    if (t0 >= T) return;
+    const int tq = t0 + i16;
+    const bool qv = tq < T;
+    const int2 wq = qv ? A.tok[tq] : make_int2(tq, 0);
+    const int s0 = wq.x, nq = (wq.y >> 20) & 0x3ff, bq = wq.y & 0xfffff;
+    const int lo = __builtin_amdgcn_readfirstlane(max(min16(qv ? (s0 >> 4) : it), it - (MT - 1)));
+    const int nk = it - lo + 1;
+    const bool need_hi = __ballot(nq > 32) != 0ull;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const float* __restrict__ qkv = A.qkv;
+
+    float qf[DH / 4];
+    frag_rows<DH>(qf, qkv, 3 * D, t0, h * DH, T);
+    const Keep64 keep = keep_row(rk, site, ((uint64_t)(bq * H + h) * 64 + (uint64_t)(tq - s0)) * 64, need_hi, dodrop);
+    f32x4 s[MT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        if (k < nk) {
+            const int jt = it - k;
+            float kf[DH / 4];
+            frag_rows<DH>(kf, qkv, 3 * D, 16 * jt, D + h * DH, T);
+            const unsigned pad = pad_bits(A.tok, jt, T);
+            s[k] = mma_rows<DH>(kf, qf);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tk = 16 * jt + 4 * g + r;
+                const bool ok = qv && tk >= s0 && tk <= tq && !((pad >> (4 * g + r)) & 1u);
+                const float v = ok ? s[k][r] * scale : -INFINITY;
+                s[k][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+    }
+    m = xg_max(m);
+    const float mref = m == -INFINITY ? 0.f : m;            // a query whose every key is PAD: probabilities 0 (torch: NaN)
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MT; ++k)
+        if (k < nk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __expf(s[k][r] - mref); s[k][r] = e; sum += e; }
+    sum = xg_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    if (g == 0 && qv) { float* st = A.stat + ((size_t)tq * H + h) * 2; st[0] = mref; st[1] = inv; }
+    f32x4 o[DH / 16];
+#pragma unroll
+    for (int db = 0; db < DH / 16; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        if (k < nk) {
+            const int jt = it - k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[k][r] *= inv * keep_at(keep, 16 * jt + 4 * g + r - s0, rk.scale);
+            mma_cols<DH>(o, qkv, 3 * D, 16 * jt, 2 * D + h * DH, s[k], T);          // out^T[d][i] += sum_j V[j][d] P~[i][j]
+        }
+    }
+    if (qv) {
+#pragma unroll
+        for (int db = 0; db < DH / 16; ++db)
+            st4(A.ctx + (size_t)tq * D + h * DH + 16 * db + 4 * g, make_float4(o[db][0], o[db][1], o[db][2], o[db][3]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// 256 threads = 1 tile x 2 heads x {phase A: the tile as QUERY tile -> dQ | phase B: the tile as KEY tile -> dK, dV}.
+// No softmax pass: P = exp(s - m) / sum from the saved statistics, the row term sum_j P dP = <dctx, ctx> from the epilogue of the tile
+// kernel in front (A.rd), as in attn_mfma.hip.
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_wave_bwd(const AttnArgs2 A) {
+    constexpr int D = 2 * DH, H = 2;
+    const int T = A.state[DR4SR_STATE_T];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, i16 = lane & 15, g = lane >> 4;
+    const bool phaseB = w >= 2;
+    const int it = (int)blockIdx.x, t0 = 16 * it;
+    if (t0 >= T) return;
+    const bool dodrop = A.training && A.p > 0.f;
+    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
+    const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const float* __restrict__ qkv = A.qkv;
+    const float* __restrict__ dctx = A.dctx;
+    const int tl = t0 + i16;                               // this lane's own token: query row (phase A) / key row (phase B)
+    const bool lv = tl < T;
+    const int2 wl = lv ? A.tok[tl] : make_int2(tl, 0);
+    const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff, bl = wl.y & 0xfffff;
+
+    if (!phaseB) {
+        // ---- phase A: transposed orientation (lane: query i = i16, keys j = 4 g + r)  -> dQ rows of this tile
+        const int lo = __builtin_amdgcn_readfirstlane(max(min16(lv ? (s0 >> 4) : it), it - (MT - 1)));
+        const int nk = it - lo + 1;
+        const bool need_hi = __ballot(nl > 32) != 0ull;
+        float qf[DH / 4], cf[DH / 4];
+        frag_rows<DH>(qf, qkv, 3 * D, t0, h * DH, T);
+        frag_rows<DH>(cf, dctx, D, t0, h * DH, T);
+        float mi = 0.f, inv = 0.f, rdot = 0.f;
+        if (lv) {
+            const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)tl * H + h) * 2);
+            mi = st.x; inv = st.y; rdot = A.rd[(size_t)tl * H + h];
+        }
+        const Keep64 keep = keep_row(rk, site, ((uint64_t)(bl * H + h) * 64 + (uint64_t)(tl - s0)) * 64, need_hi, dodrop);
+        f32x4 o[DH / 16];
+#pragma unroll
+        for (int fb = 0; fb < DH / 16; ++fb) o[fb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            if (k < nk) {
+                const int jt = it - k;
+                float kf[DH / 4], vf[DH / 4];
+                frag_rows<DH>(kf, qkv, 3 * D, 16 * jt, D + h * DH, T);
+                frag_rows<DH>(vf, qkv, 3 * D, 16 * jt, 2 * D + h * DH, T);
+                const unsigned pad = pad_bits(A.tok, jt, T);
+                const f32x4 s = mma_rows<DH>(kf, qf);
+                const f32x4 dp = mma_rows<DH>(vf, cf);             // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
+                f32x4 ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tk = 16 * jt + 4 * g + r;
+                    const bool ok = lv && tk >= s0 && tk <= tl && !((pad >> (4 * g + r)) & 1u);
+                    const float p = ok ? __expf(s[r] * scale - mi) * inv : 0.f;
+                    ds[r] = p * (dp[r] * keep_at(keep, tk - s0, rk.scale) - rdot) * scale;      // dS^T[j][i]
+                }
+                mma_cols<DH>(o, qkv, 3 * D, 16 * jt, D + h * DH, ds, T);                       // dQ^T[f][i] += sum_j K[j][f] dS^T[j][i]
+            }
+        }
+        if (lv) {
+#pragma unroll
+            for (int fb = 0; fb < DH / 16; ++fb)
+                st4(A.dqkv + (size_t)tl * 3 * D + h * DH + 16 * fb + 4 * g, make_float4(o[fb][0], o[fb][1], o[fb][2], o[fb][3]));
+        }
+        return;
+    }
+    // ---- phase B: natural orientation (lane: key j = i16, queries i = 4 g + r)  -> dK, dV rows of this tile
+    const int last = (T - 1) >> 4;
+    const int hi = __builtin_amdgcn_readfirstlane(min(min(max16(lv ? ((s0 + max(nl, 1) - 1) >> 4) : it), it + (MT - 1)), last));
+    const int nqt = hi - it + 1;
+    const bool jok = lv && !((wl.y >> 30) & 1);
+    float kf[DH / 4], vf[DH / 4];
+    frag_rows<DH>(kf, qkv, 3 * D, t0, D + h * DH, T);
+    frag_rows<DH>(vf, qkv, 3 * D, t0, 2 * D + h * DH, T);
+    f32x4 dk[DH / 16], dv[DH / 16];
+#pragma unroll
+    for (int fb = 0; fb < DH / 16; ++fb) { dk[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+        if (q < nqt) {
+            const int qt = it + q;
+            float qf[DH / 4], cf[DH / 4];
+            frag_rows<DH>(qf, qkv, 3 * D, 16 * qt, h * DH, T);
+            frag_rows<DH>(cf, dctx, D, 16 * qt, h * DH, T);
+            const f32x4 s = mma_rows<DH>(qf, kf);                  // S[i][j]: rows i = 4 g + r (C layout), column j = i16
+            const f32x4 dp = mma_rows<DH>(cf, vf);                 // dP~[i][j] = sum_d dctx[i][d] V[j][d]
+            // the four query rows of this lane group: words, statistics
+            int qs0[4], qb[4]; float qm[4], qinv[4], qrd[4]; bool qok[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ti = 16 * qt + 4 * g + r;
+                qok[r] = ti < T;
+                const int2 wi = qok[r] ? A.tok[ti] : make_int2(-1, 0);
+                qs0[r] = wi.x; qb[r] = wi.y & 0xfffff;
+                qm[r] = 0.f; qinv[r] = 0.f; qrd[r] = 0.f;
+                if (qok[r]) {
+                    const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)ti * H + h) * 2);
+                    qm[r] = st.x; qinv[r] = st.y; qrd[r] = A.rd[(size_t)ti * H + h];
+                }
+            }
+            // dropout decisions of (query i, key position): query row i sees this key tile at positions p0 .. p0 + 15 with p0 = 16 it - s0_i
+            // (>= 0 for a query of a sequence that reaches back into this tile; clamped otherwise — such pairs are masked), i.e. at most
+            // three Philox calls (octets) per query: lane i16 of group g computes the call of query row 4 g + (i16 & 3), octet
+            // (p0 >> 3) + (i16 >> 2), and the lanes fetch their bits by ds_bpermute — one call per lane and query tile, as attn_mfma.hip
+            unsigned m8 = 0xffu;
+            if (dodrop) {
+                const int rs = i16 & 3;
+                const int ss = rs == 0 ? qs0[0] : rs == 1 ? qs0[1] : rs == 2 ? qs0[2] : qs0[3];
+                const int bb = rs == 0 ? qb[0] : rs == 1 ? qb[1] : rs == 2 ? qb[2] : qb[3];
+                const int ti = 16 * qt + 4 * g + rs;
+                const int p0 = max(t0 - ss, 0);
+                m8 = drop_bits8(rk, site, ((uint64_t)(bb * H + h) * 64 + (uint64_t)max(ti - ss, 0)) * 64 + 8 * ((p0 >> 3) + (i16 >> 2)));
+            }
+            f32x4 pt, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ti = 16 * qt + 4 * g + r;
+                const int pk = tl - qs0[r], p0 = max(t0 - qs0[r], 0);
+                const int rel = ((pk >> 3) - (p0 >> 3)) & 3;
+                const unsigned mm = __shfl(m8, (lane & 48) | (r + 4 * rel), 64);
+                const float mkv = dodrop ? (((mm >> (pk & 7)) & 1u) ? rk.scale : 0.f) : 1.f;
+                const bool ok = qok[r] && jok && qs0[r] == s0 && tl <= ti;
+                const float p = ok ? __expf(s[r] * scale - qm[r]) * qinv[r] : 0.f;
+                pt[r] = p * mkv;                                   // P~[i][j]
+                ds[r] = p * (dp[r] * mkv - qrd[r]) * scale;        // dS[i][j]
+            }
+            mma_cols<DH>(dk, qkv, 3 * D, 16 * qt, h * DH, ds, T);   // dK^T[f][j] += sum_i Q[i][f] dS[i][j]
+            mma_cols<DH>(dv, dctx, D, 16 * qt, h * DH, pt, T);      // dV^T[d][j] += sum_i dctx[i][d] P~[i][j]
+        }
+    }
+    if (lv) {
+#pragma unroll
+        for (int fb = 0; fb < DH / 16; ++fb) {
+            float* base = A.dqkv + (size_t)tl * 3 * D + h * DH + 16 * fb + 4 * g;
+            st4(base + D, make_float4(dk[fb][0], dk[fb][1], dk[fb][2], dk[fb][3]));
+            st4(base + 2 * D, make_float4(dv[fb][0], dv[fb][1], dv[fb][2], dv[fb][3]));
+        }
+    }
+}
+
+}  // namespace
+
+// grid by the capacity Tmax (the device-side token count is not known on the host); tiles behind the batch's last token exit at once
+int launch_attn_wave(const AttnArgs2& A, int DH, int Tmax, bool bwd, hipStream_t s) {
+    if (!A.tok || !A.stat || (bwd && (!A.rd || !A.dctx || !A.dqkv))) return DR4SR_E_ARG;
+    const int tiles = (Tmax + 15) / 16;
+    if (DH == 32) {
+        if (bwd) hipLaunchKernelGGL(k_attn_wave_bwd<32>, dim3(tiles), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL(k_attn_wave_fwd<32>, dim3((tiles + 1) / 2), dim3(256), 0, s, A);
+    } else if (DH == 64) {
+        if (bwd) hipLaunchKernelGGL(k_attn_wave_bwd<64>, dim3(tiles), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL(k_attn_wave_fwd<64>, dim3((tiles + 1) / 2), dim3(256), 0, s, A);
+    } else return DR4SR_E_SHAPE;
+    return DR4SR_LAUNCH_CHECK();
+}

@@ -109,8 +109,9 @@ int make_prep_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng
         if (!p->rows || !p->perm_counter || p->n_perm <= 0) return DR4SR_E_ARG;
         sel = PermSel{p->perm, p->n_perm, p->perm_stride, p->perm_offset, p->perm_counter};
     }
-    // the length-class lists are only read by the at-scale attention launches (attn_mfma.hip: split_by_length)
-    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, sel, ws.tile_seq, ws.attn_split ? ws.seq_class : nullptr, ws.len_buf};
+    // the length-class lists are only read by the at-scale attention LIST launches (attn_mfma.hip: split_by_length); the wave-per-tile form
+    // (attn_wave.hip) needs none of them
+    *out = PrepArgs{p->seqlen, p->rows, ws.cu, p->state, p->B, p->L, bump_rng, sel, ws.tile_seq, (ws.attn_split && !attn_wave_on(p, ws)) ? ws.seq_class : nullptr, ws.len_buf};
     return 0;
 }
 int launch_prep(const dr4sr_sasrec_plan* p, const Workspace& ws, int bump_rng, int zero_grads, hipStream_t s) {

@@ -249,6 +249,10 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
 // them whatever its layer range (which may be EMPTY: l_lo == l_hi), 0 = it does not — the two-bucket data-parallel step (step.hip)
 bool wgrad_table_jobs(const dr4sr_sasrec_plan* p, const Workspace& ws);      // the table gradient is a set of k_wgrad jobs (at scale, fused step)
 bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws);    // latency regime: attention inside k_post_fwd / k_post_mid / k_post_bwd (attn_tile.h)
+// at scale, where the length-class lists would run (Workspace::attn_split), two heads, fused step: ONE launch per layer and direction, a wave
+// per (16-token tile of the packed stream, head[, phase]) from the embedding stage's per-token words (attn_wave.hip, round 6); the lists
+// stay as the cross-check (DR4SR_ATTN_LISTS) and for the un-fused step, which writes no token words
+bool attn_wave_on(const dr4sr_sasrec_plan* p, const Workspace& ws);
 // at scale, short sequences, d = 64 (Workspace::attn_tile_sa): one window-attention launch per layer and direction instead of the
 // two / three length-class list launches (attn_tile_sa.hip; the same tattn::fwd / tattn::bwd bodies as the in-tile form)
 PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training);

@@ -178,6 +178,10 @@ bool attn_tile_capable(const dr4sr_sasrec_plan* p) {
 bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws) {
     return attn_tile_capable(p) && tile_rows(ws) == 16 && !ws.attn_split && !wave_tiles(p, ws);
 }
+bool attn_wave_on(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    return ws.attn_split && !ws.attn_tile_sa && p->H == 2 && p->L <= 64 && (p->D == 64 || p->D == 128) && !DR4SR_ENV("DR4SR_NO_FUSE")
+           && !DR4SR_ENV("DR4SR_ATTN_LISTS") && !DR4SR_ENV("DR4SR_ATTN_NOSPLIT") && !DR4SR_ENV("DR4SR_ATTN_VALU");
+}
 bool tile_xcd_order(const dr4sr_sasrec_plan* p, const Workspace& ws) { return attn_in_tile(p, ws) && !DR4SR_ENV("DR4SR_TILE_ORDER_PLAIN"); }
 
 // Layer-0 fusion: the token tile is gathered straight from the item/position tables (a3: sasrec.py:42-48,:61-66 —
@@ -286,7 +290,7 @@ int launch_embqkv_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int train
     A.sp = wsplit_of(p, ws, 0); A.wf_layers = 0;
     if (wfrag_img_on(p, ws)) { A.sp = reinterpret_cast<const unsigned short*>(ws.wfrag); A.wf_layers = p->n_layer; }
     const bool in_tile = attn_in_tile(p, ws);
-    A.tok = (in_tile || ws.attn_tile_sa) ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
+    A.tok = (in_tile || ws.attn_tile_sa || attn_wave_on(p, ws)) ? ws.tok : nullptr; A.dqkv_zero = in_tile ? ws.layer[0].dqkv : nullptr;
     A.xcd = tile_xcd_order(p, ws) ? 1 : 0;
     if (A.xcd) grid.x = xcd_grid((int)grid.x, bm);
     if (wave_tiles(p, ws)) return launch_wt_embqkv_fwd(A, ws.Tmax, s);

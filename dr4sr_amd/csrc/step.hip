@@ -219,7 +219,8 @@ extern "C" int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan) {
     Workspace ws;
     carve_workspace(&q, &ws);
     // bit 2: attention inside the tile kernels (attn_tile.h); bit 3: the same window attention as launches of its own instead of the lists
-    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0) | (ws.attn_tile_sa ? 8 : 0);
+    // bit 4 (round 6): where the lists would run, the wave-per-tile attention instead (attn_wave.hip) — one launch per layer and direction
+    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0) | (ws.attn_tile_sa ? 8 : 0) | (attn_wave_on(&q, ws) ? 16 : 0);
 }
 
 static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
