@@ -18,7 +18,7 @@ struct AttnArgs2 {
 };
 
 // at scale, short-sequence plans (round 6): one wave per (16-token tile, head[, phase]) of the packed stream, no lists, no LDS — attn_wave.hip
-int launch_attn_wave(const AttnArgs2& A, int DH, int Tmax, bool bwd, hipStream_t s);
+int launch_attn_wave(const AttnArgs2& A, int DH, int Tmax, int Thint, bool bwd, hipStream_t s);
 
 // tiny-sequence class (1..DR4SR_TINY_MAX tokens), attn_tiny_body.h: one wave per 4 list entries
 int launch_attn_tiny(const AttnArgs2& A, int DH, int B, bool bwd, hipStream_t s);

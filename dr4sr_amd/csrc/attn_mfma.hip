@@ -633,7 +633,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
         else { big_lds(k_attn2_fwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
         return DR4SR_LAUNCH_CHECK();
     }
-    if (A.tok) return launch_attn_wave(A, DH, ws.Tmax, bwd, s);     // round 6: one wave per (token tile, head[, phase]), no lists (attn_wave.hip)
+    if (A.tok) return launch_attn_wave(A, DH, ws.Tmax, p->expected_tokens, bwd, s);     // round 6: one wave per (token tile, head[, phase]), no lists (attn_wave.hip)
     // persistent grids = what is really co-resident (registers, LDS and wave slots, as the runtime computes it): a larger grid
     // runs in two rounds with an unbalanced tail, a smaller one leaves latency-hiding slots empty
     static int per_cu[2][2];                                                 // [bwd][long], per head width

@@ -48,8 +48,8 @@ __device__ __forceinline__ int max16(int v) {
 // row fragment of an MFMA operand: lane (r16, g) takes DH / 4 consecutive floats of row (row0 + r16) at column col0 + g DH / 4; rows >= T
 // read as zero (rows behind the batch's last token hold whatever an earlier, larger batch left there)
 template <int DH>
-__device__ __forceinline__ void frag_rows(float (&f)[DH / 4], const float* __restrict__ base, const int ld, const int row0, const int col0, const int T) {
-    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void frag_rows(const int lane, float (&f)[DH / 4], const float* __restrict__ base, const int ld, const int row0, const int col0, const int T) {
+    const int r16 = lane & 15, g = lane >> 4;
     if (row0 + r16 < T) {
         const float* p = base + (size_t)(row0 + r16) * ld + col0 + g * (DH / 4);
 #pragma unroll
@@ -72,9 +72,9 @@ __device__ __forceinline__ f32x4 mma_rows(const float (&a)[DH / 4], const float 
 // acc[fb] += sum over the tile's 16 rows of M[row][col0 + 16 fb + i16] * w[row]: the A operand (rows 4 g + s, one column per lane) straight
 // from global memory — 16 lanes read 64 consecutive bytes of each of 4 rows
 template <int DH>
-__device__ __forceinline__ void mma_cols(f32x4 (&acc)[DH / 16], const float* __restrict__ base, const int ld, const int row0, const int col0, const f32x4 w,
+__device__ __forceinline__ void mma_cols(const int lane, f32x4 (&acc)[DH / 16], const float* __restrict__ base, const int ld, const int row0, const int col0, const f32x4 w,
                                          const int T) {
-    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    const int i16 = lane & 15, g = lane >> 4;
     float v[DH / 16][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -91,10 +91,10 @@ __device__ __forceinline__ void mma_cols(f32x4 (&acc)[DH / 16], const float* __r
 // keep decisions of one (query row, head): bit j of lo / hi = key position j / 32 + j is kept.  The four lanes of a query column each
 // compute one Philox call (8 decisions) and exchange them; `hi` only when some query of the tile has more than 32 keys (wave-uniform).
 struct Keep64 { unsigned lo, hi; };
-__device__ __forceinline__ Keep64 keep_row(const RngKey& rk, const uint32_t site, const uint64_t ebase, const bool need_hi, const bool dodrop) {
+__device__ __forceinline__ Keep64 keep_row(const int lane, const RngKey& rk, const uint32_t site, const uint64_t ebase, const bool need_hi, const bool dodrop) {
     Keep64 k{0xffffffffu, 0xffffffffu};
     if (!dodrop) return k;
-    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    const int i16 = lane & 15, g = lane >> 4;
     const unsigned m8 = drop_bits8(rk, site, ebase + 8 * g);
     k.lo = __shfl(m8, i16, 64) | (__shfl(m8, i16 | 16, 64) << 8) | (__shfl(m8, i16 | 32, 64) << 16) | (__shfl(m8, i16 | 48, 64) << 24);
     if (need_hi) {
@@ -109,55 +109,108 @@ __device__ __forceinline__ float keep_at(const Keep64& k, const int pos, const f
 }
 
 // PAD flags (bit 30 of the token words) of key tile jt as 16 bits, wave-uniform
-__device__ __forceinline__ unsigned pad_bits(const int2* __restrict__ tok, const int jt, const int T) {
-    const int lane = threadIdx.x & 63, t = 16 * jt + (lane & 15);
+__device__ __forceinline__ unsigned pad_bits(const int lane, const int2* __restrict__ tok, const int jt, const int T) {
+    const int t = 16 * jt + (lane & 15);
     const int w = (lane < 16 && t < T) ? tok[t].y : 0;
     return (unsigned)(__ballot((w >> 30) & 1) & 0xffffull);
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-// 256 threads = 2 query tiles x 2 heads
+// ------------------------------------------------------------------------------------------------ staging helpers
+// A wave keeps the 16 x DH tiles it needs BOTH as row fragments (products contracted over the features) and column-wise (products contracted
+// over the tile's 16 rows) in a private LDS tile [16][DH + 4]: the row fragment is loaded once from global memory, stored, and every other
+// view is an LDS read — the first cut read the column view from global memory again, a second dependent round trip per tile.  Private to the
+// wave: LDS operations of one wave execute in order, so no barrier is needed, only the lgkmcnt wait the compiler places.
+template <int DH> struct WTile { static constexpr int LD = DH + 4, FLOATS = 16 * LD; };
+
 template <int DH>
-__global__ __launch_bounds__(256) void k_attn_wave_fwd(const AttnArgs2 A) {
+__device__ __forceinline__ void tile_store(const int lane, float* __restrict__ t, const float (&f)[DH / 4]) {
+    constexpr int LD = WTile<DH>::LD;
+    const int r16 = lane & 15, g = lane >> 4;
+    float* p = t + r16 * LD + g * (DH / 4);
+#pragma unroll
+    for (int c = 0; c < DH / 4; c += 4) st4(p + c, make_float4(f[c], f[c + 1], f[c + 2], f[c + 3]));
+}
+template <int DH>
+__device__ __forceinline__ void tile_frag(const int lane, float (&f)[DH / 4], const float* __restrict__ t) {
+    constexpr int LD = WTile<DH>::LD;
+    const int r16 = lane & 15, g = lane >> 4;
+    const float* p = t + r16 * LD + g * (DH / 4);
+#pragma unroll
+    for (int c = 0; c < DH / 4; c += 4) {
+        const float4 v = ld4(p + c);
+        f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
+    }
+}
+// acc[fb] += sum over the tile's 16 rows of tile[row][16 fb + i16] * w[row]  (w in C layout: register s = row 4 g + s)
+template <int DH>
+__device__ __forceinline__ void tile_cols(const int lane, f32x4 (&acc)[DH / 16], const float* __restrict__ t, const f32x4 w) {
+    constexpr int LD = WTile<DH>::LD;
+    const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int fb = 0; fb < DH / 16; ++fb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[fb] = mfma16(t[(4 * g + s) * LD + 16 * fb + i16], w[s], acc[fb]);
+}
+__device__ __forceinline__ unsigned pad16(const int word) { return (unsigned)(__ballot((word >> 30) & 1) & 0xffffull); }
+
+// ------------------------------------------------------------------------------------------------ forward
+// 256 threads = 2 query tiles x 2 heads.  Every load whose address does not depend on loaded data — the token words, the Q rows, the K | V
+// rows of the tile itself and of the tile in front of it (all a short sequence can need) — is requested before anything is consumed: one
+// round trip for 95 % of the tiles; only the tiles of long sequences take the dependent path (key tiles 2 .. 4 back).
+template <int DH>
+__device__ __forceinline__ void fwd_tile(const int tid, const AttnArgs2& A, const int T, const int it, float* __restrict__ vt0, float* __restrict__ vt1) {
     constexpr int D = 2 * DH, H = 2;
-    const int T = A.state[DR4SR_STATE_T];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, i16 = lane & 15, g = lane >> 4;
-    const int it = 2 * (int)blockIdx.x + (w >> 1), t0 = 16 * it;
-    if (t0 >= T) return;
+    const int lane = tid & 63, w = tid >> 6, h = w & 1, i16 = lane & 15, g = lane >> 4;
+    const int t0 = 16 * it;
     const int tq = t0 + i16;
-    const bool qv = tq < T;
+    const bool qv = tq < T, has1 = it > 0;
+    const float* __restrict__ qkv = A.qkv;
     const int2 wq = qv ? A.tok[tq] : make_int2(tq, 0);
+    const int w1 = has1 ? A.tok[tq - 16].y : 0;
+    float qf[DH / 4], kf0[DH / 4], vf0[DH / 4], kf1[DH / 4], vf1[DH / 4];
+    frag_rows<DH>(lane, qf, qkv, 3 * D, t0, h * DH, T);
+    frag_rows<DH>(lane, kf0, qkv, 3 * D, t0, D + h * DH, T);
+    frag_rows<DH>(lane, vf0, qkv, 3 * D, t0, 2 * D + h * DH, T);
+    frag_rows<DH>(lane, kf1, qkv, 3 * D, has1 ? t0 - 16 : t0, D + h * DH, has1 ? T : 0);
+    frag_rows<DH>(lane, vf1, qkv, 3 * D, has1 ? t0 - 16 : t0, 2 * D + h * DH, has1 ? T : 0);
     const int s0 = wq.x, nq = (wq.y >> 20) & 0x3ff, bq = wq.y & 0xfffff;
-    const int lo = __builtin_amdgcn_readfirstlane(max(min16(qv ? (s0 >> 4) : it), it - (MT - 1)));
+    const int lo = __builtin_amdgcn_readfirstlane(max(min16(qv ? (s0 >> 4) : it), max(it - (MT - 1), 0)));
     const int nk = it - lo + 1;
     const bool need_hi = __ballot(nq > 32) != 0ull;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
     const float scale = 1.0f / sqrtf((float)DH);
-    const float* __restrict__ qkv = A.qkv;
-
-    float qf[DH / 4];
-    frag_rows<DH>(qf, qkv, 3 * D, t0, h * DH, T);
-    const Keep64 keep = keep_row(rk, site, ((uint64_t)(bq * H + h) * 64 + (uint64_t)(tq - s0)) * 64, need_hi, dodrop);
+    const Keep64 keep = keep_row(lane, rk, site, ((uint64_t)(bq * H + h) * 64 + (uint64_t)(tq - s0)) * 64, need_hi, dodrop);
     f32x4 s[MT];
     float m = -INFINITY;
+    auto mask_tile = [&](const int k, const unsigned pad) {
+        const int jt = it - k;
 #pragma unroll
-    for (int k = 0; k < MT; ++k) {
+        for (int r = 0; r < 4; ++r) {
+            const int tk = 16 * jt + 4 * g + r;
+            const bool ok = qv && tk >= s0 && tk <= tq && !((pad >> (4 * g + r)) & 1u);
+            const float v = ok ? s[k][r] * scale : -INFINITY;
+            s[k][r] = v;
+            m = fmaxf(m, v);
+        }
+    };
+    s[0] = mma_rows<DH>(kf0, qf);
+    mask_tile(0, pad16(wq.y));
+    tile_store<DH>(lane, vt0, vf0);
+    if (nk > 1) {
+        s[1] = mma_rows<DH>(kf1, qf);
+        mask_tile(1, pad16(w1));
+        tile_store<DH>(lane, vt1, vf1);
+    }
+#pragma unroll
+    for (int k = 2; k < MT; ++k) {
         if (k < nk) {
-            const int jt = it - k;
             float kf[DH / 4];
-            frag_rows<DH>(kf, qkv, 3 * D, 16 * jt, D + h * DH, T);
-            const unsigned pad = pad_bits(A.tok, jt, T);
+            frag_rows<DH>(lane, kf, qkv, 3 * D, 16 * (it - k), D + h * DH, T);
+            const unsigned pad = pad_bits(lane, A.tok, it - k, T);
             s[k] = mma_rows<DH>(kf, qf);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tk = 16 * jt + 4 * g + r;
-                const bool ok = qv && tk >= s0 && tk <= tq && !((pad >> (4 * g + r)) & 1u);
-                const float v = ok ? s[k][r] * scale : -INFINITY;
-                s[k][r] = v;
-                m = fmaxf(m, v);
-            }
+            mask_tile(k, pad);
         }
     }
     m = xg_max(m);
@@ -170,7 +223,7 @@ __global__ __launch_bounds__(256) void k_attn_wave_fwd(const AttnArgs2 A) {
             for (int r = 0; r < 4; ++r) { const float e = __expf(s[k][r] - mref); s[k][r] = e; sum += e; }
     sum = xg_sum(sum);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    if (g == 0 && qv) { float* st = A.stat + ((size_t)tq * H + h) * 2; st[0] = mref; st[1] = inv; }
+    if (g == 0 && qv) *reinterpret_cast<float2*>(A.stat + ((size_t)tq * H + h) * 2) = make_float2(mref, inv);
     f32x4 o[DH / 16];
 #pragma unroll
     for (int db = 0; db < DH / 16; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -180,7 +233,9 @@ __global__ __launch_bounds__(256) void k_attn_wave_fwd(const AttnArgs2 A) {
             const int jt = it - k;
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[k][r] *= inv * keep_at(keep, 16 * jt + 4 * g + r - s0, rk.scale);
-            mma_cols<DH>(o, qkv, 3 * D, 16 * jt, 2 * D + h * DH, s[k], T);          // out^T[d][i] += sum_j V[j][d] P~[i][j]
+            if (k == 0) tile_cols<DH>(lane, o, vt0, s[k]);                                      // out^T[d][i] += sum_j V[j][d] P~[i][j]
+            else if (k == 1) tile_cols<DH>(lane, o, vt1, s[k]);
+            else mma_cols<DH>(lane, o, qkv, 3 * D, 16 * jt, 2 * D + h * DH, s[k], T);
         }
     }
     if (qv) {
@@ -190,18 +245,42 @@ __global__ __launch_bounds__(256) void k_attn_wave_fwd(const AttnArgs2 A) {
     }
 }
 
+// Persistent grid in the XCD-aware order: workgroup b runs on XCD b % 8 (observed on MI355X, MI355X_MICROARCH.md "Workgroup dispatch" — for
+// speed only, never for correctness), and XCD x owns the CONTIGUOUS units [x per, (x + 1) per).  A tile's neighbour — whose K | V rows
+// (forward, phase A) or Q | dctx rows (phase B) it reads too — is then worked on by the same XCD at about the same time: the second read
+// is an L2 hit instead of a second trip through the fabric (first cut, tile = blockIdx.x: the forward moved 68 MB for 47 MB of operands).
+// unit u of iteration k of workgroup (x = b & 7, j = b >> 3): x per + j + k (gridDim.x / 8).
+__device__ __forceinline__ int wave_units(const int n_units) { return (n_units + 7) >> 3; }
+
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_wave_fwd(const AttnArgs2 A) {
+    constexpr int TF = WTile<DH>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[4][2][TF];
+    const int T = A.state[DR4SR_STATE_T];
+    const int w = threadIdx.x >> 6;
+    const int units = (((T + 15) >> 4) + 1) >> 1, per = wave_units(units), x = (int)blockIdx.x & 7, stride = (int)gridDim.x >> 3;
+#pragma unroll 1
+    for (int j = (int)blockIdx.x >> 3; j < per; j += stride) {
+        // (the thread index through an opaque move: everything lane-dependent is then recomputed per tile instead of being hoisted out of the
+        //  loop and held in registers across the whole body — 74 -> 93 VGPRs forward, 89 -> 130 backward without it)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int u = x * per + j, it = 2 * u + (w >> 1);
+        if (u < units && 16 * it < T) fwd_tile<DH>(tid, A, T, it, lds[w][0], lds[w][1]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // 256 threads = 1 tile x 2 heads x {phase A: the tile as QUERY tile -> dQ | phase B: the tile as KEY tile -> dK, dV}.
 // No softmax pass: P = exp(s - m) / sum from the saved statistics, the row term sum_j P dP = <dctx, ctx> from the epilogue of the tile
-// kernel in front (A.rd), as in attn_mfma.hip.
+// kernel in front (A.rd), as in attn_mfma.hip.  Loads as in the forward: the tile's own rows and those of its neighbour (in front for
+// phase A, behind for phase B) are requested up front; further tiles (long sequences) take the dependent path.
 template <int DH>
-__global__ __launch_bounds__(256) void k_attn_wave_bwd(const AttnArgs2 A) {
+__device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, const int T, const int it, float (*__restrict__ lds)[WTile<DH>::FLOATS]) {
     constexpr int D = 2 * DH, H = 2;
-    const int T = A.state[DR4SR_STATE_T];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w & 1, i16 = lane & 15, g = lane >> 4;
+    const int lane = tid & 63, w = tid >> 6, h = w & 1, i16 = lane & 15, g = lane >> 4;
     const bool phaseB = w >= 2;
-    const int it = (int)blockIdx.x, t0 = 16 * it;
-    if (t0 >= T) return;
+    const int t0 = 16 * it;
     const bool dodrop = A.training && A.p > 0.f;
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
@@ -211,44 +290,64 @@ __global__ __launch_bounds__(256) void k_attn_wave_bwd(const AttnArgs2 A) {
     const int tl = t0 + i16;                               // this lane's own token: query row (phase A) / key row (phase B)
     const bool lv = tl < T;
     const int2 wl = lv ? A.tok[tl] : make_int2(tl, 0);
-    const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff, bl = wl.y & 0xfffff;
 
     if (!phaseB) {
         // ---- phase A: transposed orientation (lane: query i = i16, keys j = 4 g + r)  -> dQ rows of this tile
-        const int lo = __builtin_amdgcn_readfirstlane(max(min16(lv ? (s0 >> 4) : it), it - (MT - 1)));
-        const int nk = it - lo + 1;
-        const bool need_hi = __ballot(nl > 32) != 0ull;
-        float qf[DH / 4], cf[DH / 4];
-        frag_rows<DH>(qf, qkv, 3 * D, t0, h * DH, T);
-        frag_rows<DH>(cf, dctx, D, t0, h * DH, T);
+        float* kt0 = lds[2 * h];
+        float* kt1 = lds[2 * h + 1];
+        const bool has1 = it > 0;
+        const int w1 = has1 ? A.tok[tl - 16].y : 0;
+        float qf[DH / 4], cf[DH / 4], kf0[DH / 4], vf0[DH / 4], kf1[DH / 4], vf1[DH / 4];
+        frag_rows<DH>(lane, qf, qkv, 3 * D, t0, h * DH, T);
+        frag_rows<DH>(lane, cf, dctx, D, t0, h * DH, T);
+        frag_rows<DH>(lane, kf0, qkv, 3 * D, t0, D + h * DH, T);
+        frag_rows<DH>(lane, vf0, qkv, 3 * D, t0, 2 * D + h * DH, T);
+        frag_rows<DH>(lane, kf1, qkv, 3 * D, has1 ? t0 - 16 : t0, D + h * DH, has1 ? T : 0);
+        frag_rows<DH>(lane, vf1, qkv, 3 * D, has1 ? t0 - 16 : t0, 2 * D + h * DH, has1 ? T : 0);
         float mi = 0.f, inv = 0.f, rdot = 0.f;
         if (lv) {
             const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)tl * H + h) * 2);
             mi = st.x; inv = st.y; rdot = A.rd[(size_t)tl * H + h];
         }
-        const Keep64 keep = keep_row(rk, site, ((uint64_t)(bl * H + h) * 64 + (uint64_t)(tl - s0)) * 64, need_hi, dodrop);
+        const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff, bl = wl.y & 0xfffff;
+        const int lo = __builtin_amdgcn_readfirstlane(max(min16(lv ? (s0 >> 4) : it), max(it - (MT - 1), 0)));
+        const int nk = it - lo + 1;
+        const bool need_hi = __ballot(nl > 32) != 0ull;
+        const Keep64 keep = keep_row(lane, rk, site, ((uint64_t)(bl * H + h) * 64 + (uint64_t)(tl - s0)) * 64, need_hi, dodrop);
         f32x4 o[DH / 16];
 #pragma unroll
         for (int fb = 0; fb < DH / 16; ++fb) o[fb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto ds_of = [&](const int jt, const unsigned pad, const f32x4 s, const f32x4 dp) {
+            f32x4 ds;
 #pragma unroll
-        for (int k = 0; k < MT; ++k) {
+            for (int r = 0; r < 4; ++r) {
+                const int tk = 16 * jt + 4 * g + r;
+                const bool ok = lv && tk >= s0 && tk <= tl && !((pad >> (4 * g + r)) & 1u);
+                const float p = ok ? __expf(s[r] * scale - mi) * inv : 0.f;
+                ds[r] = p * (dp[r] * keep_at(keep, tk - s0, rk.scale) - rdot) * scale;      // dS^T[j][i]
+            }
+            return ds;
+        };
+        {
+            const f32x4 s = mma_rows<DH>(kf0, qf), dp = mma_rows<DH>(vf0, cf);                // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
+            tile_store<DH>(lane, kt0, kf0);
+            tile_cols<DH>(lane, o, kt0, ds_of(it, pad16(wl.y), s, dp));                             // dQ^T[f][i] += sum_j K[j][f] dS^T[j][i]
+        }
+        if (nk > 1) {
+            const f32x4 s = mma_rows<DH>(kf1, qf), dp = mma_rows<DH>(vf1, cf);
+            tile_store<DH>(lane, kt1, kf1);
+            tile_cols<DH>(lane, o, kt1, ds_of(it - 1, pad16(w1), s, dp));
+        }
+#pragma unroll
+        for (int k = 2; k < MT; ++k) {
             if (k < nk) {
                 const int jt = it - k;
                 float kf[DH / 4], vf[DH / 4];
-                frag_rows<DH>(kf, qkv, 3 * D, 16 * jt, D + h * DH, T);
-                frag_rows<DH>(vf, qkv, 3 * D, 16 * jt, 2 * D + h * DH, T);
-                const unsigned pad = pad_bits(A.tok, jt, T);
-                const f32x4 s = mma_rows<DH>(kf, qf);
-                const f32x4 dp = mma_rows<DH>(vf, cf);             // dP~^T[j][i] = sum_d V[j][d] dctx[i][d]
-                f32x4 ds;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int tk = 16 * jt + 4 * g + r;
-                    const bool ok = lv && tk >= s0 && tk <= tl && !((pad >> (4 * g + r)) & 1u);
-                    const float p = ok ? __expf(s[r] * scale - mi) * inv : 0.f;
-                    ds[r] = p * (dp[r] * keep_at(keep, tk - s0, rk.scale) - rdot) * scale;      // dS^T[j][i]
-                }
-                mma_cols<DH>(o, qkv, 3 * D, 16 * jt, D + h * DH, ds, T);                       // dQ^T[f][i] += sum_j K[j][f] dS^T[j][i]
+                frag_rows<DH>(lane, kf, qkv, 3 * D, 16 * jt, D + h * DH, T);
+                frag_rows<DH>(lane, vf, qkv, 3 * D, 16 * jt, 2 * D + h * DH, T);
+                const unsigned pad = pad_bits(lane, A.tok, jt, T);
+                const f32x4 s = mma_rows<DH>(kf, qf), dp = mma_rows<DH>(vf, cf);
+                mma_cols<DH>(lane, o, qkv, 3 * D, 16 * jt, D + h * DH, ds_of(jt, pad, s, dp), T);
             }
         }
         if (lv) {
@@ -259,67 +358,108 @@ __global__ __launch_bounds__(256) void k_attn_wave_bwd(const AttnArgs2 A) {
         return;
     }
     // ---- phase B: natural orientation (lane: key j = i16, queries i = 4 g + r)  -> dK, dV rows of this tile
+    float* qt0 = lds[4 + 4 * h], *ct0 = lds[4 + 4 * h + 1], *qt1 = lds[4 + 4 * h + 2], *ct1 = lds[4 + 4 * h + 3];
     const int last = (T - 1) >> 4;
+    const bool has1 = it < last;
+    const int t1 = tl + 16;
+    const bool v1 = has1 && t1 < T;
+    float kf[DH / 4], vf[DH / 4];
+    frag_rows<DH>(lane, kf, qkv, 3 * D, t0, D + h * DH, T);
+    frag_rows<DH>(lane, vf, qkv, 3 * D, t0, 2 * D + h * DH, T);
+    // row data of the query rows of tile it (this lane's own token) and it + 1, one row per lane; the natural orientation needs rows 4 g + r
+    // of them per lane: fetched by ds_bpermute below
+    float rm0 = 0.f, ri0 = 0.f, rr0 = 0.f, rm1 = 0.f, ri1 = 0.f, rr1 = 0.f;
+    if (lv) {
+        const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)tl * H + h) * 2);
+        rm0 = st.x; ri0 = st.y; rr0 = A.rd[(size_t)tl * H + h];
+    }
+    const int2 wn = v1 ? A.tok[t1] : make_int2(-1, 0);
+    if (v1) {
+        const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)t1 * H + h) * 2);
+        rm1 = st.x; ri1 = st.y; rr1 = A.rd[(size_t)t1 * H + h];
+    }
+    {
+        float qf[DH / 4], cf[DH / 4], qg[DH / 4], cg[DH / 4];
+        frag_rows<DH>(lane, qf, qkv, 3 * D, t0, h * DH, T);
+        frag_rows<DH>(lane, cf, dctx, D, t0, h * DH, T);
+        frag_rows<DH>(lane, qg, qkv, 3 * D, t0 + 16, h * DH, has1 ? T : 0);
+        frag_rows<DH>(lane, cg, dctx, D, t0 + 16, h * DH, has1 ? T : 0);
+        tile_store<DH>(lane, qt0, qf); tile_store<DH>(lane, ct0, cf);
+        tile_store<DH>(lane, qt1, qg); tile_store<DH>(lane, ct1, cg);
+    }
+    const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff;
     const int hi = __builtin_amdgcn_readfirstlane(min(min(max16(lv ? ((s0 + max(nl, 1) - 1) >> 4) : it), it + (MT - 1)), last));
     const int nqt = hi - it + 1;
     const bool jok = lv && !((wl.y >> 30) & 1);
-    float kf[DH / 4], vf[DH / 4];
-    frag_rows<DH>(kf, qkv, 3 * D, t0, D + h * DH, T);
-    frag_rows<DH>(vf, qkv, 3 * D, t0, 2 * D + h * DH, T);
     f32x4 dk[DH / 16], dv[DH / 16];
 #pragma unroll
     for (int fb = 0; fb < DH / 16; ++fb) { dk[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // one query tile: S, dP~ in the natural orientation, then P~ and dS for the four query rows 4 g + r of this lane.
+    // rs0 / rb / rm / ri / rr: sequence start (-1: no such row), slot, row max, 1 / row sum, row term of query row (lane & 15) of the tile
+    auto query_tile = [&](const int qt, const float (&qf)[DH / 4], const float (&cf)[DH / 4], const int rs0, const int rb, const float rm,
+                          const float ri, const float rr, f32x4& pt, f32x4& ds) {
+        const f32x4 s = mma_rows<DH>(qf, kf);                  // S[i][j]: rows i = 4 g + r (C layout), column j = i16
+        const f32x4 dp = mma_rows<DH>(cf, vf);                 // dP~[i][j] = sum_d dctx[i][d] V[j][d]
+        // dropout decisions: query row i sees this key tile at positions p0 .. p0 + 15, p0 = max(16 it - s0_i, 0): at most three Philox
+        // calls (octets) per query.  Lane i16 of group g computes the call of query row 4 g + (i16 & 3), octet (p0 >> 3) + (i16 >> 2), and
+        // the lanes fetch their bits by ds_bpermute — one call per lane and query tile, as attn_mfma.hip
+        unsigned m8 = 0xffu;
+        if (dodrop) {
+            const int src = 4 * g + (i16 & 3);
+            const int ss = __shfl(rs0, src, 64), bb = __shfl(rb, src, 64);
+            const int ti = 16 * qt + src;
+            const int p0 = max(t0 - ss, 0);
+            m8 = drop_bits8(rk, site, ((uint64_t)(bb * H + h) * 64 + (uint64_t)max(ti - ss, 0)) * 64 + 8 * ((p0 >> 3) + (i16 >> 2)));
+        }
 #pragma unroll
-    for (int q = 0; q < MT; ++q) {
+        for (int r = 0; r < 4; ++r) {
+            const int src = 4 * g + r, ti = 16 * qt + src;
+            const int qs0 = __shfl(rs0, src, 64);
+            const float qm = __shfl(rm, src, 64), qi = __shfl(ri, src, 64), qr = __shfl(rr, src, 64);
+            const int pk = tl - qs0, p0 = max(t0 - qs0, 0);
+            const int rel = ((pk >> 3) - (p0 >> 3)) & 3;
+            const unsigned mm = __shfl(m8, (lane & 48) | (r + 4 * rel), 64);
+            const float mkv = dodrop ? (((mm >> (pk & 7)) & 1u) ? rk.scale : 0.f) : 1.f;
+            const bool ok = jok && qs0 == s0 && tl <= ti;      // (qs0 == -1: no such query row)
+            const float p = ok ? __expf(s[r] * scale - qm) * qi : 0.f;
+            pt[r] = p * mkv;                                   // P~[i][j]
+            ds[r] = p * (dp[r] * mkv - qr) * scale;            // dS[i][j]
+        }
+    };
+    {
+        float qf[DH / 4], cf[DH / 4];
+        tile_frag<DH>(lane, qf, qt0); tile_frag<DH>(lane, cf, ct0);
+        f32x4 pt, ds;
+        query_tile(it, qf, cf, lv ? s0 : -1, wl.y & 0xfffff, rm0, ri0, rr0, pt, ds);
+        tile_cols<DH>(lane, dk, qt0, ds);                            // dK^T[f][j] += sum_i Q[i][f] dS[i][j]
+        tile_cols<DH>(lane, dv, ct0, pt);                            // dV^T[d][j] += sum_i dctx[i][d] P~[i][j]
+    }
+    if (nqt > 1) {
+        float qf[DH / 4], cf[DH / 4];
+        tile_frag<DH>(lane, qf, qt1); tile_frag<DH>(lane, cf, ct1);
+        f32x4 pt, ds;
+        query_tile(it + 1, qf, cf, wn.x, wn.y & 0xfffff, rm1, ri1, rr1, pt, ds);
+        tile_cols<DH>(lane, dk, qt1, ds);
+        tile_cols<DH>(lane, dv, ct1, pt);
+    }
+#pragma unroll
+    for (int q = 2; q < MT; ++q) {
         if (q < nqt) {
-            const int qt = it + q;
+            const int qt = it + q, ti = 16 * qt + i16;
+            const bool vi = ti < T;
             float qf[DH / 4], cf[DH / 4];
-            frag_rows<DH>(qf, qkv, 3 * D, 16 * qt, h * DH, T);
-            frag_rows<DH>(cf, dctx, D, 16 * qt, h * DH, T);
-            const f32x4 s = mma_rows<DH>(qf, kf);                  // S[i][j]: rows i = 4 g + r (C layout), column j = i16
-            const f32x4 dp = mma_rows<DH>(cf, vf);                 // dP~[i][j] = sum_d dctx[i][d] V[j][d]
-            // the four query rows of this lane group: words, statistics
-            int qs0[4], qb[4]; float qm[4], qinv[4], qrd[4]; bool qok[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ti = 16 * qt + 4 * g + r;
-                qok[r] = ti < T;
-                const int2 wi = qok[r] ? A.tok[ti] : make_int2(-1, 0);
-                qs0[r] = wi.x; qb[r] = wi.y & 0xfffff;
-                qm[r] = 0.f; qinv[r] = 0.f; qrd[r] = 0.f;
-                if (qok[r]) {
-                    const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)ti * H + h) * 2);
-                    qm[r] = st.x; qinv[r] = st.y; qrd[r] = A.rd[(size_t)ti * H + h];
-                }
-            }
-            // dropout decisions of (query i, key position): query row i sees this key tile at positions p0 .. p0 + 15 with p0 = 16 it - s0_i
-            // (>= 0 for a query of a sequence that reaches back into this tile; clamped otherwise — such pairs are masked), i.e. at most
-            // three Philox calls (octets) per query: lane i16 of group g computes the call of query row 4 g + (i16 & 3), octet
-            // (p0 >> 3) + (i16 >> 2), and the lanes fetch their bits by ds_bpermute — one call per lane and query tile, as attn_mfma.hip
-            unsigned m8 = 0xffu;
-            if (dodrop) {
-                const int rs = i16 & 3;
-                const int ss = rs == 0 ? qs0[0] : rs == 1 ? qs0[1] : rs == 2 ? qs0[2] : qs0[3];
-                const int bb = rs == 0 ? qb[0] : rs == 1 ? qb[1] : rs == 2 ? qb[2] : qb[3];
-                const int ti = 16 * qt + 4 * g + rs;
-                const int p0 = max(t0 - ss, 0);
-                m8 = drop_bits8(rk, site, ((uint64_t)(bb * H + h) * 64 + (uint64_t)max(ti - ss, 0)) * 64 + 8 * ((p0 >> 3) + (i16 >> 2)));
+            frag_rows<DH>(lane, qf, qkv, 3 * D, 16 * qt, h * DH, T);
+            frag_rows<DH>(lane, cf, dctx, D, 16 * qt, h * DH, T);
+            const int2 wi = vi ? A.tok[ti] : make_int2(-1, 0);
+            float rm = 0.f, ri = 0.f, rr = 0.f;
+            if (vi) {
+                const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)ti * H + h) * 2);
+                rm = st.x; ri = st.y; rr = A.rd[(size_t)ti * H + h];
             }
             f32x4 pt, ds;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ti = 16 * qt + 4 * g + r;
-                const int pk = tl - qs0[r], p0 = max(t0 - qs0[r], 0);
-                const int rel = ((pk >> 3) - (p0 >> 3)) & 3;
-                const unsigned mm = __shfl(m8, (lane & 48) | (r + 4 * rel), 64);
-                const float mkv = dodrop ? (((mm >> (pk & 7)) & 1u) ? rk.scale : 0.f) : 1.f;
-                const bool ok = qok[r] && jok && qs0[r] == s0 && tl <= ti;
-                const float p = ok ? __expf(s[r] * scale - qm[r]) * qinv[r] : 0.f;
-                pt[r] = p * mkv;                                   // P~[i][j]
-                ds[r] = p * (dp[r] * mkv - qrd[r]) * scale;        // dS[i][j]
-            }
-            mma_cols<DH>(dk, qkv, 3 * D, 16 * qt, h * DH, ds, T);   // dK^T[f][j] += sum_i Q[i][f] dS[i][j]
-            mma_cols<DH>(dv, dctx, D, 16 * qt, h * DH, pt, T);      // dV^T[d][j] += sum_i dctx[i][d] P~[i][j]
+            query_tile(qt, qf, cf, wi.x, wi.y & 0xfffff, rm, ri, rr, pt, ds);
+            mma_cols<DH>(lane, dk, qkv, 3 * D, 16 * qt, h * DH, ds, T);
+            mma_cols<DH>(lane, dv, dctx, D, 16 * qt, h * DH, pt, T);
         }
     }
     if (lv) {
@@ -332,18 +472,39 @@ __global__ __launch_bounds__(256) void k_attn_wave_bwd(const AttnArgs2 A) {
     }
 }
 
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_wave_bwd(const AttnArgs2 A) {
+    constexpr int TF = WTile<DH>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 + 2 * 4][TF];      // phase A waves: K tiles k = 0, 1; phase B waves: Q | dctx tiles q = 0, 1
+    const int T = A.state[DR4SR_STATE_T];
+    const int units = (T + 15) >> 4, per = wave_units(units), x = (int)blockIdx.x & 7, stride = (int)gridDim.x >> 3;
+#pragma unroll 1
+    for (int j = (int)blockIdx.x >> 3; j < per; j += stride) {
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int it = x * per + j;
+        if (it < units) bwd_tile<DH>(tid, A, T, it, lds);
+    }
+}
+
 }  // namespace
 
-// grid by the capacity Tmax (the device-side token count is not known on the host); tiles behind the batch's last token exit at once
-int launch_attn_wave(const AttnArgs2& A, int DH, int Tmax, bool bwd, hipStream_t s) {
+// Persistent grids: 8 x ceil(units / 8) workgroups for the units the plan EXPECTS (expected_tokens; the capacity Tmax without a hint), at most
+// what the device holds at once times four; the loop inside covers whatever the batch really has.  The first cut launched one workgroup per
+// tile of the CAPACITY: 25 600 workgroups at B = 8 192 of which 2 800 had a tile.
+int launch_attn_wave(const AttnArgs2& A, int DH, int Tmax, int Thint, bool bwd, hipStream_t s) {
     if (!A.tok || !A.stat || (bwd && (!A.rd || !A.dctx || !A.dqkv))) return DR4SR_E_ARG;
-    const int tiles = (Tmax + 15) / 16;
+    const int Te = Thint > 0 && Thint < Tmax ? Thint + Thint / 8 + 64 : Tmax;
+    const int tiles = ((Te < Tmax ? Te : Tmax) + 15) / 16, units = bwd ? tiles : (tiles + 1) / 2;
+    int grid = 8 * ((units + 7) / 8);
+    const int cap = DR4SR_ENV("DR4SR_ATTN_WAVE_GRID") ? atoi(DR4SR_ENV("DR4SR_ATTN_WAVE_GRID")) : 8192;
+    if (grid > cap) grid = cap > 8 ? cap / 8 * 8 : 8;
     if (DH == 32) {
-        if (bwd) hipLaunchKernelGGL(k_attn_wave_bwd<32>, dim3(tiles), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL(k_attn_wave_fwd<32>, dim3((tiles + 1) / 2), dim3(256), 0, s, A);
+        if (bwd) hipLaunchKernelGGL(k_attn_wave_bwd<32>, dim3(grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL(k_attn_wave_fwd<32>, dim3(grid), dim3(256), 0, s, A);
     } else if (DH == 64) {
-        if (bwd) hipLaunchKernelGGL(k_attn_wave_bwd<64>, dim3(tiles), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL(k_attn_wave_fwd<64>, dim3((tiles + 1) / 2), dim3(256), 0, s, A);
+        if (bwd) hipLaunchKernelGGL(k_attn_wave_bwd<64>, dim3(grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL(k_attn_wave_fwd<64>, dim3(grid), dim3(256), 0, s, A);
     } else return DR4SR_E_SHAPE;
     return DR4SR_LAUNCH_CHECK();
 }
