@@ -47,20 +47,38 @@ __device__ __forceinline__ int max16(int v) {
 
 // row fragment of an MFMA operand: lane (r16, g) takes DH / 4 consecutive floats of row (row0 + r16) at column col0 + g DH / 4; rows >= T
 // read as zero (rows behind the batch's last token hold whatever an earlier, larger batch left there)
+// BRANCH-FREE: the address is clamped into the batch and the value selected afterwards — a conditional load is a branch, and the compiler
+// drains every load in flight (s_waitcnt vmcnt(0)) at the join of the first one, which serialised the token-word round trip in front of
+// the operand round trip in the first cuts.  T <= 0 (no such tile): all zero.
 template <int DH>
 __device__ __forceinline__ void frag_rows(const int lane, float (&f)[DH / 4], const float* __restrict__ base, const int ld, const int row0, const int col0, const int T) {
     const int r16 = lane & 15, g = lane >> 4;
-    if (row0 + r16 < T) {
-        const float* p = base + (size_t)(row0 + r16) * ld + col0 + g * (DH / 4);
+    const int row = row0 + r16;
+    const bool ok = row < T;
+    const float* p = base + (size_t)max(min(row, T - 1), 0) * ld + col0 + g * (DH / 4);
 #pragma unroll
-        for (int c = 0; c < DH / 4; c += 4) {
-            const float4 v = ld4(p + c);
-            f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < DH / 4; ++c) f[c] = 0.f;
+    for (int c = 0; c < DH / 4; c += 4) {
+        const float4 v = ld4(p + c);
+        f[c] = ok ? v.x : 0.f; f[c + 1] = ok ? v.y : 0.f; f[c + 2] = ok ? v.z : 0.f; f[c + 3] = ok ? v.w : 0.f;
     }
+}
+// token word of token t, branch-free: {t, 0} (a sequence of its own, length 0) behind the batch's last token
+// tok_raw issues the load (clamped address, always executed); tok_fix, called AFTER the other loads of the flight have been issued, pins
+// the value with an opaque move — without it the compiler sinks the load back under the `t < T` branch (the select's only consumer) and
+// waits for it before it issues anything else.
+__device__ __forceinline__ int2 tok_raw(const int2* __restrict__ tok, const int t, const int T) { return tok[max(min(t, T - 1), 0)]; }
+__device__ __forceinline__ int2 tok_fix(int2 w, const int t, const int T) {
+    asm volatile("" : "+v"(w.x), "+v"(w.y));
+    return t < T ? w : make_int2(t, 0);
+}
+__device__ __forceinline__ int2 tok_word(const int2* __restrict__ tok, const int t, const int T) { return tok_fix(tok_raw(tok, t, T), t, T); }
+// saved softmax statistics {row max, 1 / row sum} and the row term of (token t, head h), branch-free (zeros behind the batch)
+__device__ __forceinline__ void row_stats(const AttnArgs2& A, const int t, const int h, const int T, float& m, float& inv, float& rd) {
+    const int tc = max(min(t, T - 1), 0);
+    const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)tc * 2 + h) * 2);
+    const float r = A.rd[(size_t)tc * 2 + h];
+    const bool ok = t < T;
+    m = ok ? st.x : 0.f; inv = ok ? st.y : 0.f; rd = ok ? r : 0.f;
 }
 template <int DH>
 __device__ __forceinline__ f32x4 mma_rows(const float (&a)[DH / 4], const float (&b)[DH / 4]) {
@@ -111,7 +129,7 @@ __device__ __forceinline__ float keep_at(const Keep64& k, const int pos, const f
 // PAD flags (bit 30 of the token words) of key tile jt as 16 bits, wave-uniform
 __device__ __forceinline__ unsigned pad_bits(const int lane, const int2* __restrict__ tok, const int jt, const int T) {
     const int t = 16 * jt + (lane & 15);
-    const int w = (lane < 16 && t < T) ? tok[t].y : 0;
+    const int w = tok_word(tok, t, T).y;
     return (unsigned)(__ballot((w >> 30) & 1) & 0xffffull);
 }
 
@@ -165,14 +183,15 @@ __device__ __forceinline__ void fwd_tile(const int tid, const AttnArgs2& A, cons
     const int tq = t0 + i16;
     const bool qv = tq < T, has1 = it > 0;
     const float* __restrict__ qkv = A.qkv;
-    const int2 wq = qv ? A.tok[tq] : make_int2(tq, 0);
-    const int w1 = has1 ? A.tok[tq - 16].y : 0;
+    const int2 wq_raw = tok_raw(A.tok, tq, T), w1_raw = tok_raw(A.tok, tq - 16, T);
     float qf[DH / 4], kf0[DH / 4], vf0[DH / 4], kf1[DH / 4], vf1[DH / 4];
     frag_rows<DH>(lane, qf, qkv, 3 * D, t0, h * DH, T);
     frag_rows<DH>(lane, kf0, qkv, 3 * D, t0, D + h * DH, T);
     frag_rows<DH>(lane, vf0, qkv, 3 * D, t0, 2 * D + h * DH, T);
     frag_rows<DH>(lane, kf1, qkv, 3 * D, has1 ? t0 - 16 : t0, D + h * DH, has1 ? T : 0);
     frag_rows<DH>(lane, vf1, qkv, 3 * D, has1 ? t0 - 16 : t0, 2 * D + h * DH, has1 ? T : 0);
+    const int2 wq = tok_fix(wq_raw, tq, T);
+    const int w1 = has1 ? tok_fix(w1_raw, tq - 16, T).y : 0;          // (has1 is wave-uniform)
     const int s0 = wq.x, nq = (wq.y >> 20) & 0x3ff, bq = wq.y & 0xfffff;
     const int lo = __builtin_amdgcn_readfirstlane(max(min16(qv ? (s0 >> 4) : it), max(it - (MT - 1), 0)));
     const int nk = it - lo + 1;
@@ -289,14 +308,14 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
     const float* __restrict__ dctx = A.dctx;
     const int tl = t0 + i16;                               // this lane's own token: query row (phase A) / key row (phase B)
     const bool lv = tl < T;
-    const int2 wl = lv ? A.tok[tl] : make_int2(tl, 0);
+    const int2 wl_raw = tok_raw(A.tok, tl, T);
 
     if (!phaseB) {
         // ---- phase A: transposed orientation (lane: query i = i16, keys j = 4 g + r)  -> dQ rows of this tile
         float* kt0 = lds[2 * h];
         float* kt1 = lds[2 * h + 1];
         const bool has1 = it > 0;
-        const int w1 = has1 ? A.tok[tl - 16].y : 0;
+        const int2 w1_raw = tok_raw(A.tok, tl - 16, T);
         float qf[DH / 4], cf[DH / 4], kf0[DH / 4], vf0[DH / 4], kf1[DH / 4], vf1[DH / 4];
         frag_rows<DH>(lane, qf, qkv, 3 * D, t0, h * DH, T);
         frag_rows<DH>(lane, cf, dctx, D, t0, h * DH, T);
@@ -304,11 +323,10 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
         frag_rows<DH>(lane, vf0, qkv, 3 * D, t0, 2 * D + h * DH, T);
         frag_rows<DH>(lane, kf1, qkv, 3 * D, has1 ? t0 - 16 : t0, D + h * DH, has1 ? T : 0);
         frag_rows<DH>(lane, vf1, qkv, 3 * D, has1 ? t0 - 16 : t0, 2 * D + h * DH, has1 ? T : 0);
-        float mi = 0.f, inv = 0.f, rdot = 0.f;
-        if (lv) {
-            const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)tl * H + h) * 2);
-            mi = st.x; inv = st.y; rdot = A.rd[(size_t)tl * H + h];
-        }
+        float mi, inv, rdot;
+        row_stats(A, tl, h, T, mi, inv, rdot);
+        const int2 wl = tok_fix(wl_raw, tl, T);
+        const int w1 = has1 ? tok_fix(w1_raw, tl - 16, T).y : 0;
         const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff, bl = wl.y & 0xfffff;
         const int lo = __builtin_amdgcn_readfirstlane(max(min16(lv ? (s0 >> 4) : it), max(it - (MT - 1), 0)));
         const int nk = it - lo + 1;
@@ -368,16 +386,10 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
     frag_rows<DH>(lane, vf, qkv, 3 * D, t0, 2 * D + h * DH, T);
     // row data of the query rows of tile it (this lane's own token) and it + 1, one row per lane; the natural orientation needs rows 4 g + r
     // of them per lane: fetched by ds_bpermute below
-    float rm0 = 0.f, ri0 = 0.f, rr0 = 0.f, rm1 = 0.f, ri1 = 0.f, rr1 = 0.f;
-    if (lv) {
-        const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)tl * H + h) * 2);
-        rm0 = st.x; ri0 = st.y; rr0 = A.rd[(size_t)tl * H + h];
-    }
-    const int2 wn = v1 ? A.tok[t1] : make_int2(-1, 0);
-    if (v1) {
-        const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)t1 * H + h) * 2);
-        rm1 = st.x; ri1 = st.y; rr1 = A.rd[(size_t)t1 * H + h];
-    }
+    float rm0, ri0, rr0, rm1, ri1, rr1;
+    row_stats(A, tl, h, T, rm0, ri0, rr0);
+    const int2 wn_raw = tok_raw(A.tok, t1, T);
+    row_stats(A, v1 ? t1 : T, h, T, rm1, ri1, rr1);
     {
         float qf[DH / 4], cf[DH / 4], qg[DH / 4], cg[DH / 4];
         frag_rows<DH>(lane, qf, qkv, 3 * D, t0, h * DH, T);
@@ -387,6 +399,9 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
         tile_store<DH>(lane, qt0, qf); tile_store<DH>(lane, ct0, cf);
         tile_store<DH>(lane, qt1, qg); tile_store<DH>(lane, ct1, cg);
     }
+    const int2 wl = tok_fix(wl_raw, tl, T);
+    int2 wn = tok_fix(wn_raw, t1, T);
+    if (!v1) wn = make_int2(-1, 0);
     const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff;
     const int hi = __builtin_amdgcn_readfirstlane(min(min(max16(lv ? ((s0 + max(nl, 1) - 1) >> 4) : it), it + (MT - 1)), last));
     const int nqt = hi - it + 1;
@@ -450,12 +465,10 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
             float qf[DH / 4], cf[DH / 4];
             frag_rows<DH>(lane, qf, qkv, 3 * D, 16 * qt, h * DH, T);
             frag_rows<DH>(lane, cf, dctx, D, 16 * qt, h * DH, T);
-            const int2 wi = vi ? A.tok[ti] : make_int2(-1, 0);
-            float rm = 0.f, ri = 0.f, rr = 0.f;
-            if (vi) {
-                const float2 st = *reinterpret_cast<const float2*>(A.stat + ((size_t)ti * H + h) * 2);
-                rm = st.x; ri = st.y; rr = A.rd[(size_t)ti * H + h];
-            }
+            int2 wi = tok_word(A.tok, ti, T);
+            if (!vi) wi = make_int2(-1, 0);
+            float rm, ri, rr;
+            row_stats(A, ti, h, T, rm, ri, rr);
             f32x4 pt, ds;
             query_tile(qt, qf, cf, wi.x, wi.y & 0xfffff, rm, ri, rr, pt, ds);
             mma_cols<DH>(lane, dk, qkv, 3 * D, 16 * qt, h * DH, ds, T);

@@ -252,8 +252,10 @@ def test_full_size_batch_vs_oracle(dev, dense, D, n_items):
 
 def test_large_batch_length_split_attention(dev, monkeypatch, at_scale):
     """B = 1024 (T_max > 16384): BM = 32 token tiles and the attention split into a short-sequence (n <= 16) and a long-sequence
-    persistent launch over k_prep's length-class lists.  Checked against the oracle and against the unsplit launch."""
+    persistent launch over k_prep's length-class lists.  Checked against the oracle and against the unsplit launch.
+    (Round 6: the lists are the cross-check form, DR4SR_ATTN_LISTS — the default at scale is csrc/attn_wave.hip, tests/test_gpu_attn_wave.py.)"""
     from dr4sr_amd.engine import SasrecEngine
+    monkeypatch.setenv("DR4SR_ATTN_LISTS", "1")
     B = 1024
     b, N = _toys_batch(B, False, seed=9)
     b["seqlen"][5] = 16
@@ -748,8 +750,9 @@ def test_persistent_attention_lists_longer_than_the_grid(dev, monkeypatch, at_sc
     """thousands of sequences per length class: every workgroup of the persistent attention launches walks SEVERAL list entries, i.e.
     the software-pipelined loop (rows of i+1 / cu words of i+2 / list entry of i+3 in flight) runs its steady state and its drain.
     Checked against the one-workgroup-per-sequence launch of the same step (itself checked against the oracle above); with dropout the
-    two draw identical masks (element-indexed Philox)."""
+    two draw identical masks (element-indexed Philox).  (Round 6: DR4SR_ATTN_LISTS selects the lists; default = csrc/attn_wave.hip.)"""
     from dr4sr_amd.engine import SasrecEngine
+    monkeypatch.setenv("DR4SR_ATTN_LISTS", "1")
     b, N = _toys_batch(B, False, seed=21)
     params = _random_params(N, D, 128, 2, seed=4)
     eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, p, B, "cuda", seed=11)

@@ -146,8 +146,10 @@ def test_tiny_attention_class_equals_mfma_kernels(monkeypatch, at_scale, D, B, p
     """sequences of 1..8 tokens run on the VALU kernels of csrc/attn_tiny_body.h in the split launches; DR4SR_ATTN_NOTINY sends the same
     list through the 16-row MFMA kernels: identical statistics / dropout element indexing, so losses and gradients agree to fp32
     summation order — also with dropout ON (the two classes regenerate the same Philox masks).  Batch with every length 1..8
-    present, PAD items inside sequences (key-padding mask) and both head widths."""
+    present, PAD items inside sequences (key-padding mask) and both head widths.  (Round 6: under DR4SR_ATTN_LISTS — the lists are the
+    cross-check form of the wave-per-tile launches.)"""
     from test_gpu_parity import _random_params, _toys_batch
+    monkeypatch.setenv("DR4SR_ATTN_LISTS", "1")
     from dr4sr_amd.engine import SasrecEngine
     b, N = _toys_batch(B, False, seed=33, n_items=3000)
     for r, n in enumerate([1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17]):       # both sides of every class boundary
@@ -300,6 +302,7 @@ _SWITCH_CASES = [
     ({"DR4SR_QEB_SEPARATE": "1"}, "full_size fuzz"),
     ({"DR4SR_SCATTER_INLINE": "1"}, "length_split"),
     ({"DR4SR_ATTN_GRID_FIXED": "1"}, "length_split"),
+    ({"DR4SR_ATTN_LISTS": "1", "DR4SR_FORCE_SCALE": "1"}, "full_size fuzz dropout"),      # round 6: the length-class lists instead of the wave-per-tile launches
     ({"DR4SR_BM": "32"}, "full_size fuzz"),                # the at-scale tile on small batches
     ({"DR4SR_BM": "64"}, "full_size_d64"),                 # tuning-only tile (d = 128 fits it up to L = 57 only: refused by the launch)
     # the middle regime (~5.5 k .. 14 k expected tokens): at-scale token-tile kernels with one attention workgroup per sequence
