@@ -203,6 +203,7 @@ SYMBOLS = {
     "dr4sr_gru4rec_encode_bwd": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dr4sr_adam_flat": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dr4sr_reload_env": (C.c_int, []),
+    "dr4sr_build_flags": (C.c_int, []),
     "dr4sr_sasrec_launch_kernel": (C.c_int, [_PLANP, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_sasrec_launch_kernel_weighted": (C.c_int, [_PLANP, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dr4sr_gru4rec_launch_kernel": (C.c_int, [_GPLANP, C.c_int32, C.c_int32, C.c_void_p]),

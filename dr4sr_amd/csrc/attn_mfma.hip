@@ -612,7 +612,7 @@ constexpr int SHORT_BWD_NT = 256;
 
 // workgroups of `kernel` that fit one CU (fallback: the hand-computed figure)
 static int resident_per_cu(const void* kernel, int threads, size_t lds, int fallback) {
-    if (DR4SR_ENV("DR4SR_ATTN_GRID_FIXED")) return fallback;
+    if (DR4SR_XENV("DR4SR_ATTN_GRID_FIXED")) return fallback;
     if (lds > 48 * 1024) big_lds_impl(kernel, lds);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fallback; }
@@ -627,7 +627,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
         const size_t lds = lds_of(64);
         // backward: 8 waves per sequence for both head widths (head_dim 64 needed 187 VGPRs and ran with 4 waves until the dropout decisions
         // came from one Philox call per lane and tile: 118 now; d = 128, B = 256: 2 x 19.4 -> 2 x 14.7 us).  DR4SR_ATTN_BWD_4WAVE: cross-check
-        const bool four = DR4SR_ENV("DR4SR_ATTN_BWD_4WAVE") != nullptr;
+        const bool four = DR4SR_XENV("DR4SR_ATTN_BWD_4WAVE") != nullptr;
         if (bwd && !four) { big_lds(k_attn2_bwd<DH, 64, 512, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 512, false>), dim3(B), dim3(512), lds, s, A); }
         else if (bwd) { big_lds(k_attn2_bwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_bwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
         else { big_lds(k_attn2_fwd<DH, 64, 256, false>, lds); hipLaunchKernelGGL((k_attn2_fwd<DH, 64, 256, false>), dim3(B), dim3(256), lds, s, A); }
@@ -644,7 +644,7 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
                              : resident_per_cu((const void*)k_attn2_fwd<DH, 64, 256, true>, 256, lds_of(64), 3);
         per_cu[bwd][0] = bwd ? resident_per_cu((const void*)k_attn2_bwd<DH, 16, SHORT_BWD_NT, true>, SHORT_BWD_NT, lds_of(16), 4)
                              : resident_per_cu((const void*)k_attn2_fwd<DH, 16, 128, true>, 128, lds_of(16), 8);
-        if (DR4SR_ENV("DR4SR_ATTN_GRID_PRINT")) fprintf(stderr, "attention grids (DH %d, %s): %d short / %d long workgroups per CU\n", DH, bwd ? "bwd" : "fwd", per_cu[bwd][0], per_cu[bwd][1]);
+        if (DR4SR_XENV("DR4SR_ATTN_GRID_PRINT")) fprintf(stderr, "attention grids (DH %d, %s): %d short / %d long workgroups per CU\n", DH, bwd ? "bwd" : "fwd", per_cu[bwd][0], per_cu[bwd][1]);
     }
     const int per_cu_s = per_cu[bwd][0], per_cu_l = per_cu[bwd][1];
     const int gs = B < 256 * per_cu_s ? B : 256 * per_cu_s;
@@ -659,12 +659,12 @@ static int attn2_launch(const dr4sr_sasrec_plan* p, const Workspace& ws, AttnArg
     // The length classes are disjoint sets of sequences: their launches are independent and go to side streams (parallel branches of a
     // captured step graph): the class kernels are latency-bound at 1-7 % MFMA utilisation, side by side they take the longest one's time
     const StepFork& fk = step_fork();
-    if (!DR4SR_ENV("DR4SR_ATTN_NOTINY") && !DR4SR_ENV("DR4SR_ATTN_NOMERGE")) {
-        const int dv = DR4SR_ENV("DR4SR_ATTN_SMALL_DIV") ? atoi(DR4SR_ENV("DR4SR_ATTN_SMALL_DIV")) : 2;      // share of the residency left to the tiny blocks (tuning)
+    if (!DR4SR_ENV("DR4SR_ATTN_NOTINY") && !DR4SR_XENV("DR4SR_ATTN_NOMERGE")) {
+        const int dv = DR4SR_XENV("DR4SR_ATTN_SMALL_DIV") ? atoi(DR4SR_XENV("DR4SR_ATTN_SMALL_DIV")) : 2;      // share of the residency left to the tiny blocks (tuning)
         const int gsm = gs / (dv > 0 ? dv : 1) > 0 ? gs / (dv > 0 ? dv : 1) : 1;
         const size_t lds_t = tiny::TinyLds<DH>::bytes(bwd), lds_m = lds_s > lds_t ? lds_s : lds_t;
         dim3 grid(gsm + (B + tiny::SPB - 1) / tiny::SPB);
-        const bool merge_bwd = DR4SR_ENV("DR4SR_ATTN_MERGE_BWD") != nullptr;
+        const bool merge_bwd = DR4SR_XENV("DR4SR_ATTN_MERGE_BWD") != nullptr;
         if (bwd && !merge_bwd) {
             // backward: NOT merged by default — the tiny class needs 192 VGPRs, the 16-row list 120; at the merged kernel's 208 the list's
             // workgroups fill the register file two per CU and the tiny blocks queue behind them (32.7 us against 19.2 + 9.8)

@@ -28,6 +28,7 @@
 // triu(1) :58, key_padding_mask idx == 0 :48.
 #include "common.h"
 #include "kernels.h"
+#ifdef DR4SR_EXPERIMENTS      // a rejected experiment (measured slower than the lists, and round 6's attn_wave.hip replaced both): not in the shipped build
 #include "attn_tile.h"
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -110,7 +111,7 @@ int sa_grid(const Workspace& ws, int D) {
     }
     const int per_cu = (int)((160 * 1024) / sa_lds_bytes(D));
     int wpc = per_cu > 0 ? per_cu : 1;
-    if (const char* e = DR4SR_ENV("DR4SR_ATTN_SA_WPC")) wpc = atoi(e) > 0 ? atoi(e) : wpc;       // sweeps: workgroups per CU of the persistent grid
+    if (const char* e = DR4SR_XENV("DR4SR_ATTN_SA_WPC")) wpc = atoi(e) > 0 ? atoi(e) : wpc;       // sweeps: workgroups per CU of the persistent grid
     const int tiles = (ws.Tmax + 15) / 16, g = cached * wpc;
     return tiles < g ? tiles : g;
 }
@@ -118,7 +119,7 @@ int sa_grid(const Workspace& ws, int D) {
 PostArgs sa_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training) {
     PostArgs A = make_post_args(p, ws, layer, training);
     A.at.on = 1;
-    if (!DR4SR_ENV("DR4SR_ATTN_TILE_FULL")) A.at.on |= 4;        // short-sequence plans by construction: the near half of the window first
+    if (!DR4SR_XENV("DR4SR_ATTN_TILE_FULL")) A.at.on |= 4;        // short-sequence plans by construction: the near half of the window first
     if (DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;      // cross-check: every dK | dV row through atomics
     A.stamps = nullptr;
     return A;
@@ -145,3 +146,8 @@ int launch_attn_tile_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int la
     hipLaunchKernelGGL(k_attn_tile_bwd<64>, dim3(sa_grid(ws, 64)), dim3(256), lds, s, A, ws.dctx, ws.attn_rd, zero);
     return DR4SR_LAUNCH_CHECK();
 }
+#else
+// shipped build: Workspace::attn_tile_sa is never set (DR4SR_ATTN_WINDOW is a compile-time nullptr, common.h DR4SR_XENV)
+int launch_attn_tile_fwd(const dr4sr_sasrec_plan*, const Workspace&, int, int, hipStream_t) { return DR4SR_E_SHAPE; }
+int launch_attn_tile_bwd(const dr4sr_sasrec_plan*, const Workspace&, int, int, hipStream_t) { return DR4SR_E_SHAPE; }
+#endif

@@ -510,7 +510,7 @@ int launch_attn_wave(const AttnArgs2& A, int DH, int Tmax, int Thint, bool bwd, 
     const int Te = Thint > 0 && Thint < Tmax ? Thint + Thint / 8 + 64 : Tmax;
     const int tiles = ((Te < Tmax ? Te : Tmax) + 15) / 16, units = bwd ? tiles : (tiles + 1) / 2;
     int grid = 8 * ((units + 7) / 8);
-    const int cap = DR4SR_ENV("DR4SR_ATTN_WAVE_GRID") ? atoi(DR4SR_ENV("DR4SR_ATTN_WAVE_GRID")) : 8192;
+    const int cap = DR4SR_XENV("DR4SR_ATTN_WAVE_GRID") ? atoi(DR4SR_XENV("DR4SR_ATTN_WAVE_GRID")) : 8192;
     if (grid > cap) grid = cap > 8 ? cap / 8 * 8 : 8;
     if (DH == 32) {
         if (bwd) hipLaunchKernelGGL(k_attn_wave_bwd<32>, dim3(grid), dim3(256), 0, s, A);

@@ -27,6 +27,16 @@ std::mutex& dr4sr_env_mutex();                                // step.hip
             gen_.store(cur_, std::memory_order_release); } }                                     \
     return set_ ? buf_ : nullptr; }())
 
+// Experiment / tuning switches (round 6): read only by a library built with -DDR4SR_EXPERIMENTS (`make EXPERIMENTS=1` -> libdr4sr_hip_exp.so).
+// In the shipped build they are a compile-time nullptr: the rejected experiments and the tuning knobs (the defaults are the measured
+// optima) carry neither their branches nor their kernels' ISA into the product, and cost no run-time lookups on the launch path.  The
+// cross-check switches the tests use stay run-time (DR4SR_ENV).  SWITCHES.md lists both kinds; dr4sr_build_flags() bit 0 says which build.
+#ifdef DR4SR_EXPERIMENTS
+#define DR4SR_XENV(NAME) DR4SR_ENV(NAME)
+#else
+#define DR4SR_XENV(NAME) (static_cast<const char*>(nullptr))
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

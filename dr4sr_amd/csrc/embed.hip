@@ -39,7 +39,7 @@ extern "C" int dr4sr_embed_gather_posadd(const float* E, const float* P, const i
     if (ntok == 0) return 0;
     const int tpb = 256 / (D / 4);
     int64_t blocks = (ntok + tpb - 1) / tpb;
-    const int64_t cap = DR4SR_ENV("DR4SR_GATHER_BLOCKS") ? atoll(DR4SR_ENV("DR4SR_GATHER_BLOCKS")) : 65536;     // measured: 16 tokens x 16 iterations per block beats 4096 long-running blocks by 12 %
+    const int64_t cap = DR4SR_XENV("DR4SR_GATHER_BLOCKS") ? atoll(DR4SR_XENV("DR4SR_GATHER_BLOCKS")) : 65536;     // measured: 16 tokens x 16 iterations per block beats 4096 long-running blocks by 12 %
     if (blocks > cap) blocks = cap;
     hipStream_t s = (hipStream_t)stream;
     if (D == 64) hipLaunchKernelGGL(k_embed_dense<64>, dim3((unsigned)blocks), dim3(256), 0, s, E, P, idx, out, ntok, L, n_items);

@@ -410,14 +410,14 @@ __global__ __launch_bounds__(256) void k_gru_dx_embed(const GruGlueArgs A) {
 
 // the fused glue applies to what the 16-row latency GEMMs apply to (small batches), D = 64
 static bool gru_glue_fused(const dr4sr_gru4rec_plan* p, int Tmax) {
-    return !DR4SR_ENV("DR4SR_GRU_NOFUSE_GLUE") && !DR4SR_ENV("DR4SR_GRU_GEMM64") && !at_scale(Tmax) && p->D == 64 && (p->H == 128 || p->H == 256);
+    return !DR4SR_ENV("DR4SR_GRU_NOFUSE_GLUE") && !DR4SR_XENV("DR4SR_GRU_GEMM64") && !at_scale(Tmax) && p->D == 64 && (p->H == 128 || p->H == 256);
 }
 
 static int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K, int N,
                        bool colmode, int Tmax, const int* state, hipStream_t s) {
     const size_t lds = sizeof(float) * 64 * 68;
     dim3 blk(256);
-    const bool no16 = DR4SR_ENV("DR4SR_GRU_GEMM64") != nullptr;          // cross-check switch: 64-row tiles everywhere
+    const bool no16 = DR4SR_XENV("DR4SR_GRU_GEMM64") != nullptr;          // cross-check switch: 64-row tiles everywhere
     if (!no16 && !at_scale(Tmax) && N % 64 == 0 && ((colmode && !bias && K == 64) || (!colmode && (K == 64 || K == 128 || K == 256)))) {
         const size_t l16 = sizeof(float) * 16 * (K + 4);
         dim3 grid((Tmax + 15) / 16, N / 64);
@@ -431,7 +431,7 @@ static int launch_gemm(const float* A, int lda, const float* W, int ldw, const f
         const size_t l16 = sizeof(float) * 16 * (K + 4);
         dim3 grid((Tmax + 15) / 16, N / 64);
         const size_t lsk = l16 + sizeof(float) * 4 * 16 * 68;
-        if (DR4SR_ENV("DR4SR_GRU_NO_SPLITK")) {             // cross-check: one K chain per wave (round 2's kernel)
+        if (DR4SR_XENV("DR4SR_GRU_NO_SPLITK")) {             // cross-check: one K chain per wave (round 2's kernel)
             if (K == 768) { big_lds(k_gemm16_col<768>, l16); hipLaunchKernelGGL(k_gemm16_col<768>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
             else { big_lds(k_gemm16_col<384>, l16); hipLaunchKernelGGL(k_gemm16_col<384>, grid, blk, l16, s, A, lda, W, ldw, C, ldc, state); }
         } else if (K == 768) { big_lds(k_gemm16_col_sk<768>, lsk); hipLaunchKernelGGL(k_gemm16_col_sk<768>, grid, blk, lsk, s, A, lda, W, ldw, C, ldc, state); }
@@ -917,7 +917,7 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     add(ws.dY, D, D, ws.layer[nl - 1].hout, H, H, Gd + ws.off_ow, Gd + ws.off_ob);
     WA.state = p->state;
     const int ntiles = (ws.Tmax + 63) / 64;
-    const int gwf = DR4SR_ENV("DR4SR_GRU_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_GRU_WGRAD_GW")) : 0;     // tuning knob
+    const int gwf = DR4SR_XENV("DR4SR_GRU_WGRAD_GW") ? atoi(DR4SR_XENV("DR4SR_GRU_WGRAD_GW")) : 0;     // tuning knob
     // token-tile splits per 64x64 output tile: every split ends in 4 096 atomics, so fewer, longer splits at small batches (B = 256: 6
     // instead of 12 is worth 0.8 % of the step; 2 is too few workgroups)
     // (bf16x3 jobs: the MFMA phase is 2.7x shorter, the 4 096-atomic tail is not — half as many splits: B = 256 6 -> 3 is worth 0.7 % of the step)

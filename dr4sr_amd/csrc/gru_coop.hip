@@ -1196,7 +1196,7 @@ static int device_cus() {
 static int coop_slices(int B, int H) {
     if (DR4SR_ENV("DR4SR_GRU_NOCOOP") || (H != 128 && H != 256)) return 0;
     const int groups = (B + 15) / 16, g8 = ((groups + 7) / 8) * 8, cus = device_cus();
-    const bool no16 = DR4SR_ENV("DR4SR_GRU_NS8") != nullptr;             // cross-check switch: always 8 slices
+    const bool no16 = DR4SR_XENV("DR4SR_GRU_NS8") != nullptr;             // cross-check switch: always 8 slices
     if (H == 256 && !no16 && g8 * 16 <= cus) return 16;
     int b8 = cus * 3 / 4;
     if (b8 > 192) b8 = 192;
@@ -1303,16 +1303,16 @@ int64_t gru_xch_words(int B, int H, int L, int n_layer) {
 // returns -100 when the plan does not qualify (caller: one cooperative launch per layer)
 int launch_gru_wave(const GruWaveArgs& G, unsigned long long* xch, int* ctl, int B, int H, int L, bool bwd, hipStream_t s) {
     if (!xch || !ctl || !wave_ok(B, H, 2, L)) return -100;
-    const bool wave_bwd = DR4SR_ENV("DR4SR_GRU_WAVE_BWD") != nullptr;
+    const bool wave_bwd = DR4SR_XENV("DR4SR_GRU_WAVE_BWD") != nullptr;
     if (bwd && !wave_bwd) return -100;
     const int cb = coop_chunk(B, H);
     WaveArgs A;
     A.gi1 = G.gi1; A.wih2 = G.wih2; A.dhout = G.dhout; A.xch = xch; A.ctl = ctl; A.L = L;
-    const int presleep = DR4SR_ENV("DR4SR_GRU_WAVE_PRESLEEP") ? atoi(DR4SR_ENV("DR4SR_GRU_WAVE_PRESLEEP")) : 0;
-    const int solo = DR4SR_ENV("DR4SR_GRU_WAVE_SOLO") ? atoi(DR4SR_ENV("DR4SR_GRU_WAVE_SOLO")) : 0;            // diagnosis only: the follower layer does not run (wrong results)
-    const int stamp = DR4SR_ENV("DR4SR_GRU_WAVE_STAMP") ? 1 : 0;
+    const int presleep = DR4SR_XENV("DR4SR_GRU_WAVE_PRESLEEP") ? atoi(DR4SR_XENV("DR4SR_GRU_WAVE_PRESLEEP")) : 0;
+    const int solo = DR4SR_XENV("DR4SR_GRU_WAVE_SOLO") ? atoi(DR4SR_XENV("DR4SR_GRU_WAVE_SOLO")) : 0;            // diagnosis only: the follower layer does not run (wrong results)
+    const int stamp = DR4SR_XENV("DR4SR_GRU_WAVE_STAMP") ? 1 : 0;
     A.presleep = presleep; A.solo = solo; A.stamp = stamp;
-    A.order = DR4SR_ENV("DR4SR_GRU_WAVE_ORDER") ? atoi(DR4SR_ENV("DR4SR_GRU_WAVE_ORDER")) : 1;
+    A.order = DR4SR_XENV("DR4SR_GRU_WAVE_ORDER") ? atoi(DR4SR_XENV("DR4SR_GRU_WAVE_ORDER")) : 1;
     for (int l = 0; l < 2; ++l) {
         A.whh[l] = G.whh[l]; A.r[l] = G.r[l]; A.z[l] = G.z[l]; A.n[l] = G.n[l]; A.ghn[l] = G.ghn[l]; A.hprev[l] = G.hprev[l]; A.hout[l] = G.hout[l];
         A.dgi[l] = G.dgi[l]; A.dgh[l] = G.dgh[l];

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ X, co
 // tile rows per workgroup for the token-tile kernels: 16 while the whole batch is small (latency regime: 4x shorter MFMA
 // chains, every CU gets work), 32 at scale (occupancy regime: 4 workgroups per CU interleave their latency chains).
 int latency_tmax() {
-    const int v = DR4SR_ENV("DR4SR_LATENCY_TMAX") ? atoi(DR4SR_ENV("DR4SR_LATENCY_TMAX")) : 16384;
+    const int v = DR4SR_XENV("DR4SR_LATENCY_TMAX") ? atoi(DR4SR_XENV("DR4SR_LATENCY_TMAX")) : 16384;
     return v;
 }
 int tile_rows(const Workspace& ws) {
@@ -125,16 +125,16 @@ static bool de_owner_mode(const Workspace& ws) { return scatter_in_wgrad(ws) && 
 // times (one private copy per wave) plus the queues.  Shared by the scorer launch (tile_sort needs G) and the k_wgrad launch.
 // at scale with d = 64 the weight-gradient GEMMs run as 64 x 64 blocks (k_wgrad_bf64): 32 KB of operand tiles per workgroup
 static bool wgrad_sub64(const dr4sr_sasrec_plan* p) {
-    return p->D == 64 && 4 + 2 * (p->F / 64) <= DR4SR_WGRAD_MAX_JOBS && !DR4SR_ENV("DR4SR_WGRAD_F32") && !DR4SR_ENV("DR4SR_WGRAD_WIDE");
+    return p->D == 64 && 4 + 2 * (p->F / 64) <= DR4SR_WGRAD_MAX_JOBS && !DR4SR_ENV("DR4SR_WGRAD_F32") && !DR4SR_XENV("DR4SR_WGRAD_WIDE");
 }
 static size_t wgrad_lds_base(const dr4sr_sasrec_plan* p) {          // (only the at-scale forms size their owners by it)
     const size_t D = p->D, F = p->F;
-    size_t lds = sizeof(float) * 64 * (wgrad_sub64(p) && !DR4SR_ENV("DR4SR_WGRAD_LDS48") ? 2 * D : (D + F > 2 * D ? D + F : 2 * D));
+    size_t lds = sizeof(float) * 64 * (wgrad_sub64(p) && !DR4SR_XENV("DR4SR_WGRAD_LDS48") ? 2 * D : (D + F > 2 * D ? D + F : 2 * D));
     if (sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;       // the scatter job's position-table accumulator
     return lds;
 }
 static int owner_logG(const dr4sr_sasrec_plan* p) {
-    int logG = DR4SR_ENV("DR4SR_OWNER_LOGG") ? atoi(DR4SR_ENV("DR4SR_OWNER_LOGG")) : 8;      // tuning knob
+    int logG = DR4SR_XENV("DR4SR_OWNER_LOGG") ? atoi(DR4SR_XENV("DR4SR_OWNER_LOGG")) : 8;      // tuning knob
     const size_t lds = wgrad_lds_base(p);
     while (sizeof(float) * 4 * (size_t)((p->n_items + (1 << logG) - 1) >> logG) * p->D + 4 * 16 * 4 * sizeof(int) > lds && logG < 20) ++logG;
     return logG;
@@ -1293,13 +1293,13 @@ PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int lay
         A.nx_in_w = P + poff(ws, layer + 1, P_IN_W); A.nx_in_b = P + poff(ws, layer + 1, P_IN_B); A.nx_qkv = ws.layer[layer + 1].qkv;
         A.up_dqkv = ws.layer[layer + 1].dqkv; A.up_in_w = P + poff(ws, layer + 1, P_IN_W); A.up_du1 = ws.layer[layer + 1].du1;
     }
-    A.stamps = DR4SR_ENV("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
+    A.stamps = DR4SR_XENV("DR4SR_STAMPS") ? reinterpret_cast<unsigned long long*>(ws.dctx) : nullptr;   // debug only: dctx is free during fwd
     A.at.on = attn_in_tile(p, ws) ? 1 : 0;
     A.xcd = tile_xcd_order(p, ws) ? 1 : 0;
     // short-sequence plans at d = 128 stage the near half of the window first (attn_tile.h far_rows_if_needed): toys B = 256 0.2115 -> 0.2074 ms;
     // at d = 64 the half window is not worth the second round trip of one tile in ten (0.1049 -> 0.1053).  DR4SR_ATTN_TILE_FULL / _NEAR force
     const bool near_ok = p->expected_tokens > 0 && p->expected_tokens <= 16 * (int64_t)p->B;
-    if (A.at.on && !DR4SR_ENV("DR4SR_ATTN_TILE_FULL") && ((near_ok && p->D == 128) || DR4SR_ENV("DR4SR_ATTN_TILE_NEAR"))) A.at.on |= 4;
+    if (A.at.on && !DR4SR_XENV("DR4SR_ATTN_TILE_FULL") && ((near_ok && p->D == 128) || DR4SR_XENV("DR4SR_ATTN_TILE_NEAR"))) A.at.on |= 4;
     if (A.at.on && DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;       // cross-check: every dK | dV row through atomics (no plain stores)
     A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L;
     A.sp = wsplit_of(p, ws, layer);
@@ -1363,7 +1363,7 @@ int launch_post_mid(const dr4sr_sasrec_plan* p, const Workspace& ws, int trainin
     }
     if (wt_mid(p, ws, mw != nullptr)) {                 // DR4SR_WT_RECOMPUTE_A: the backward half recomputes the linear1 pre-activations
         PostArgs Aw = A;
-        if (DR4SR_ENV("DR4SR_WT_RECOMPUTE_A")) Aw.a = nullptr;
+        if (DR4SR_XENV("DR4SR_WT_RECOMPUTE_A")) Aw.a = nullptr;
         return launch_wt_post_mid(Aw, S, ws.Tmax, s);
     }
     const int bm = tile_rows(ws);
@@ -1374,7 +1374,7 @@ int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, 
     if (wave_tiles(p, ws) && !A.stamps) {
         // DR4SR_WT_RECOMPUTE_A (round 4, measured slower, opt-in: linear_wave.hip wt_bwd_tile): the forward does not store the linear1
         // pre-activations for a wave-tile backward, which recomputes them from y
-        if (wt_bwd_on() && layer + 1 < p->n_layer && DR4SR_ENV("DR4SR_WT_RECOMPUTE_A")) A.a = nullptr;
+        if (wt_bwd_on() && layer + 1 < p->n_layer && DR4SR_XENV("DR4SR_WT_RECOMPUTE_A")) A.a = nullptr;
         return launch_wt_post_fwd(A, ws.Tmax, s);
     }
     const int bm = tile_rows(ws);
@@ -1383,7 +1383,7 @@ int launch_post_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, 
 int launch_post_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s) {
     PostArgs A = make_post_args(p, ws, layer, training);
     if (wave_tiles(p, ws) && wt_bwd_on() && layer + 1 < p->n_layer) {
-        if (DR4SR_ENV("DR4SR_WT_RECOMPUTE_A")) A.a = nullptr;          // recompute a = y W1^T + b1 (the forward did not store it)
+        if (DR4SR_XENV("DR4SR_WT_RECOMPUTE_A")) A.a = nullptr;          // recompute a = y W1^T + b1 (the forward did not store it)
         return launch_wt_post_bwd(A, ws.Tmax, s);
     }
     const int bm = tile_rows(ws);
@@ -2140,18 +2140,18 @@ __global__ __launch_bounds__(256) void k_fmlp_wgrad_bf64(const WgradArgs A) {
 }
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) {
     const int ntiles = (Tmax + 63) / 64;
-    const int gwf = DR4SR_ENV("DR4SR_FMLP_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_FMLP_WGRAD_GW")) : 0;     // tuning knob
+    const int gwf = DR4SR_XENV("DR4SR_FMLP_WGRAD_GW") ? atoi(DR4SR_XENV("DR4SR_FMLP_WGRAD_GW")) : 0;     // tuning knob
     int gw_t = gwf > 0 ? gwf : (ntiles / 16 > 64 ? (ntiles / 16 > 160 ? 160 : ntiles / 16) : 64);   // 64: every CU holds one heavy workgroup at B = 256 (48: 37.6 us, 64: 35.4)
     // (64 x 64 bf16x3 blocks, the default: 16 block jobs per layer pair instead of 4 whole ones -> fewer token splits: B = 256 measured
     //  16 / 24 / 32 / 48 / 64 splits = 0.1985 / 0.1926 / 0.1950 / 0.1985 / 0.2015 ms per step)
-    const bool blocks64 = !DR4SR_ENV("DR4SR_WGRAD_F32") && !DR4SR_ENV("DR4SR_FMLP_WGRAD_WIDE");
+    const bool blocks64 = !DR4SR_ENV("DR4SR_WGRAD_F32") && !DR4SR_XENV("DR4SR_FMLP_WGRAD_WIDE");
     if (blocks64 && gwf <= 0) gw_t = ntiles / 8 > 24 ? (ntiles / 8 > 160 ? 160 : ntiles / 8) : 24;
     int gw = ntiles < gw_t ? ntiles : gw_t;
     const size_t lds = sizeof(float) * 64 * (64 + 256);
     if (DR4SR_ENV("DR4SR_WGRAD_F32")) {
         big_lds(k_fmlp_wgrad, lds);
         hipLaunchKernelGGL(k_fmlp_wgrad, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
-    } else if (DR4SR_ENV("DR4SR_FMLP_WGRAD_WIDE")) {          // the two whole jobs per layer (cross-check of the 64 x 64 blocks)
+    } else if (DR4SR_XENV("DR4SR_FMLP_WGRAD_WIDE")) {          // the two whole jobs per layer (cross-check of the 64 x 64 blocks)
         big_lds(k_fmlp_wgrad_bf, lds);
         hipLaunchKernelGGL(k_fmlp_wgrad_bf, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
     } else {
@@ -2160,7 +2160,7 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
     return DR4SR_LAUNCH_CHECK();
 }
 
-static bool blk_env_on() { const char* e = DR4SR_ENV("DR4SR_WGRAD_BLK"); return e && atoi(e) != 0; }      // (the fp32 64 x 64 block form has no partial outputs)
+static bool blk_env_on() { const char* e = DR4SR_XENV("DR4SR_WGRAD_BLK"); return e && atoi(e) != 0; }      // (the fp32 64 x 64 block form has no partial outputs)
 bool wgrad_table_jobs(const dr4sr_sasrec_plan* p, const Workspace& ws) { (void)p; return scatter_in_wgrad(ws); }
 
 int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, int with_score, hipStream_t s, bool qeb, bool meta,
@@ -2226,11 +2226,11 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     A.o_ln1_w = poff(ws, 0, P_LN1_W); A.layer_stride = p->n_layer > 1 ? ws.off[2 + 12] - ws.off[2] : 0;
     A.score_part = with_score ? ws.score_part : nullptr; A.tail = G + ws.n_params; A.B = p->B; A.D = D;
     A.score_tiles = with_score == 2;
-    const int gw_max = DR4SR_ENV("DR4SR_WGRAD_GW") ? atoi(DR4SR_ENV("DR4SR_WGRAD_GW")) : 48;   // tuning knob
+    const int gw_max = DR4SR_XENV("DR4SR_WGRAD_GW") ? atoi(DR4SR_XENV("DR4SR_WGRAD_GW")) : 48;   // tuning knob
     // token splits per job at scale: 160 up to ~2 500 expected 64-token tiles, then tiles / 16 up to 320 (measured: toys B = 8 192,
     // 1 170 tiles: 128 / 160 / 224 splits -> 120.9 / 117.3 / 121.4 us; dense B = 8 192, 6 400 tiles: 160 / 224 / 320 / 448 -> 905 / 868 /
     // 840 / 854 us; toys B = 32 768: 160 -> 256 splits +1.4 % step).  Without a hint the capacity counts as before (cap 160).
-    const int gw_cap_env = DR4SR_ENV("DR4SR_WGRAD_GW_CAP") ? atoi(DR4SR_ENV("DR4SR_WGRAD_GW_CAP")) : 0;
+    const int gw_cap_env = DR4SR_XENV("DR4SR_WGRAD_GW_CAP") ? atoi(DR4SR_XENV("DR4SR_WGRAD_GW_CAP")) : 0;
     const int hint_tiles = p->expected_tokens > 0 ? (int)((p->expected_tokens < ws.Tmax ? p->expected_tokens : ws.Tmax) / 64) : 0;
     // round 4 (64 x 64 block jobs, four workgroups per CU): dense B = 8 192 128 / 192 / 256 / 320 splits -> 713 / 681 / 680 / 720 us, toys B = 8 192
     // 96 / 128 / 160 / 192 / 256 -> 92 / 83 / 83 / 89 / 105 us: the upper cap comes down from 320 to 224
@@ -2241,7 +2241,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     const int gw_cap = gw_cap_env > 0 ? gw_cap_env : (hint_tiles / 16 > 160 ? (hint_tiles / 16 > gw_hi ? gw_hi : hint_tiles / 16) : gw_small);
     // floor: 48 splits (36 real tiles at the toys B = 256 batch: one each), 64 once the batch is expected to hold >= 100 tiles
     // (dense B = 256, 200 tiles: k_wgrad 49.4 -> 44.2 us; 80 splits: 44.8)
-    const bool gw_env = DR4SR_ENV("DR4SR_WGRAD_GW") != nullptr;
+    const bool gw_env = DR4SR_XENV("DR4SR_WGRAD_GW") != nullptr;
     const int gw_floor = !gw_env && hint_tiles >= 100 && gw_max < 64 ? 64 : gw_max;
     int gw_t = ntiles / 16 > gw_floor ? (ntiles / 16 > gw_cap ? gw_cap : ntiles / 16) : gw_floor;   // >= 16 token tiles per workgroup at scale
     int gw = ntiles < gw_t ? ntiles : gw_t;
@@ -2271,7 +2271,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     }
     // fp32 jobs as 64 x 64 blocks cut on the device (k_wgrad_blk) below the at-scale forms: toys B = 256 step 0.1234 -> 0.1221 ms at d = 64
     // (three alternating pairs), 0.2284 -> 0.2152 ms at d = 128 (the [128 x 128] jobs were 42 us of it).  DR4SR_WGRAD_BLK=0: whole jobs
-    const char* blk_env = DR4SR_ENV("DR4SR_WGRAD_BLK");
+    const char* blk_env = DR4SR_XENV("DR4SR_WGRAD_BLK");
     const bool blk64 = !A.bf16x3 && !scatter && (blk_env ? atoi(blk_env) != 0 : !ws.scale);      // (never with table jobs in the launch: k_wgrad_blk has none)
     const int NY = blk64 ? 4 * (D / 64) * (D / 64) + 2 * (D / 64) * (F / 64) : NJ;
     if (blk64 && !scatter) lds = sizeof(float) * 64 * 128;

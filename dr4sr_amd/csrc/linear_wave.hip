@@ -845,7 +845,7 @@ int wt_waves(const char* e, int dflt) {
     return v == 16 ? 16 : v == 12 ? 12 : 8;
 }
 bool wt_exact() {                                           // DR4SR_WT_BF16X3: the bf16x3 split instead of fp32 MFMA (forward kernel only)
-    const bool v = DR4SR_ENV("DR4SR_WT_BF16X3") == nullptr;
+    const bool v = DR4SR_XENV("DR4SR_WT_BF16X3") == nullptr;
     return v;
 }
 
@@ -876,7 +876,7 @@ int wt_post_mid_launch(const PostArgs& A, const ScoreTileArgs& S, int grid, hipS
 template <int W>
 int wt_embqkv_launch(const EmbQkvArgs& A, int grid, hipStream_t s) {
     const size_t lds = WtImg<true, 192, 64>::bytes + 4 * 192;
-    if (DR4SR_ENV("DR4SR_WT_EMB_BF16X3")) {                 // the in_proj GEMM as a bf16x3 split (same image bytes)
+    if (DR4SR_XENV("DR4SR_WT_EMB_BF16X3")) {                 // the in_proj GEMM as a bf16x3 split (same image bytes)
         big_lds(k_wt_embqkv_fwd<64, W, false>, lds);
         hipLaunchKernelGGL((k_wt_embqkv_fwd<64, W, false>), dim3(grid), dim3(W * 64), lds, s, A);
         return DR4SR_LAUNCH_CHECK();
@@ -910,7 +910,7 @@ int launch_wt_post_fwd(const PostArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_FWD_WAVES"), 12);
+    const int W = wt_waves(DR4SR_XENV("DR4SR_WT_FWD_WAVES"), 12);
     if (wt_exact()) return W == 16 ? wt_post_fwd_launch<16, true>(A, grid, s) : W == 12 ? wt_post_fwd_launch<12, true>(A, grid, s) : wt_post_fwd_launch<8, true>(A, grid, s);
     return W == 16 ? wt_post_fwd_launch<16, false>(A, grid, s) : W == 12 ? wt_post_fwd_launch<12, false>(A, grid, s) : wt_post_fwd_launch<8, false>(A, grid, s);
 }
@@ -919,7 +919,7 @@ int launch_wt_post_bwd(const PostArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_BWD_WAVES"), 12);
+    const int W = wt_waves(DR4SR_XENV("DR4SR_WT_BWD_WAVES"), 12);
     return W == 16 ? wt_post_bwd_launch<16>(A, grid, s) : W == 12 ? wt_post_bwd_launch<12>(A, grid, s) : wt_post_bwd_launch<8>(A, grid, s);
 }
 
@@ -927,7 +927,7 @@ int launch_wt_post_mid(const PostArgs& A, const ScoreTileArgs& S, int Tmax, hipS
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    const int wm = wt_waves(DR4SR_ENV("DR4SR_WT_MID_WAVES"), 8);
+    const int wm = wt_waves(DR4SR_XENV("DR4SR_WT_MID_WAVES"), 8);
     return wm == 16 ? wt_post_mid_launch<16>(A, S, grid, s) : wm == 12 ? wt_post_mid_launch<12>(A, S, grid, s) : wt_post_mid_launch<8>(A, S, grid, s);
 }
 
@@ -935,13 +935,13 @@ int launch_wt_embqkv_fwd(const EmbQkvArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_EMB_WAVES"), 16);
+    const int W = wt_waves(DR4SR_XENV("DR4SR_WT_EMB_WAVES"), 16);
     return W == 16 ? wt_embqkv_launch<16>(A, grid, s) : W == 12 ? wt_embqkv_launch<12>(A, grid, s) : wt_embqkv_launch<8>(A, grid, s);
 }
 int launch_wt_qkv_embed_bwd(const QkvEmbBwdArgs& A, int Tmax, hipStream_t s) {
     int grid = wt_grid();
     const int tiles = (Tmax + 15) / 16;
     if (grid > tiles) grid = tiles;
-    const int W = wt_waves(DR4SR_ENV("DR4SR_WT_EMB_WAVES"), 16);
+    const int W = wt_waves(DR4SR_XENV("DR4SR_WT_EMB_WAVES"), 16);
     return W == 16 ? wt_qeb_launch<16>(A, grid, s) : W == 12 ? wt_qeb_launch<12>(A, grid, s) : wt_qeb_launch<8>(A, grid, s);
 }

@@ -26,7 +26,7 @@ extern "C" int dr4sr_abi_version(void) { return DR4SR_ABI_VERSION; }
 // ---- side streams (common.h StepFork).  Created on the first call that asks for them (DR4SR_STREAMS).
 static StepFork g_fork = {};
 const StepFork& step_fork() {
-    if (g_fork.state == 0 && DR4SR_ENV("DR4SR_STREAMS")) {
+    if (g_fork.state == 0 && DR4SR_XENV("DR4SR_STREAMS")) {
         // A first call may come from INSIDE a stream capture (the callers warm a step up first, but nothing forces them to): stream /
         // event creation is made legal there by switching this thread to the relaxed capture mode for the duration.  Whatever still
         // fails leaves the state at 0 — side streams off for THIS call only, retried by the next — and nothing half-created behind.
@@ -53,7 +53,7 @@ const StepFork& step_fork() {
 // 10-25 us launches it overlaps; B = 256: 0.1245 -> 0.1443 ms, B = 8 192: 0.523 -> 0.576 ms, B = 131 072: 5.77 -> 6.22 ms (the early
 // weight-gradient launch also takes CUs from the persistent tile kernels).  hipExtAnyOrderLaunch (no barrier bit inside ONE queue) is
 // documented as unsupported on gfx9.  Kept as a switch + test: the dependency analysis is right, the platform's price for it is not.
-bool StepFork::on() const { return state == 1 && DR4SR_ENV("DR4SR_STREAMS") != nullptr; }
+bool StepFork::on() const { return state == 1 && DR4SR_XENV("DR4SR_STREAMS") != nullptr; }
 int StepFork::fork(hipStream_t main, int first, int n) const {
     if (!on()) return 0;
     hipError_t e = hipSuccess;
@@ -78,6 +78,13 @@ int dr4sr_env_generation() { return g_env_generation.load(std::memory_order_acqu
 std::mutex& dr4sr_env_mutex() { static std::mutex mu; return mu; }
 extern "C" int dr4sr_reload_env(void) { return g_env_generation.fetch_add(1, std::memory_order_acq_rel) + 1; }
 extern "C" int dr4sr_sasrec_plan_sizeof(void) { return (int)sizeof(dr4sr_sasrec_plan); }
+extern "C" int dr4sr_build_flags(void) {
+#ifdef DR4SR_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int64_t dr4sr_sasrec_param_layout(int32_t n_items, int32_t L, int32_t D, int32_t F, int32_t n_layer,
                                              int64_t* off) {
@@ -127,7 +134,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->n_params = dr4sr_sasrec_param_layout(p->n_items, p->L, p->D, p->F, p->n_layer, ws->off);
     ws->Tmax = (int)Tmax;
     {
-        const bool forced = DR4SR_ENV("DR4SR_LATENCY_TMAX") != nullptr;           // sweeps: the capacity rule with a moved boundary
+        const bool forced = DR4SR_XENV("DR4SR_LATENCY_TMAX") != nullptr;           // sweeps: the capacity rule with a moved boundary
         const int64_t hint = p->expected_tokens < Tmax ? p->expected_tokens : Tmax;
         const bool known = hint > 0 && !forced;
         // boundaries measured at d = 64; at d = 128 both crossovers sit at half the token count (4 k / 7 k): the work per token doubles
@@ -152,7 +159,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // attn_tile.h as ONE launch per layer and direction (attn_tile_sa.hip).  Measured slower than the lists (toys B = 8 192: forward
         // 25 against 24 us per layer, backward 68 against 49; B = 32 768: 92 / 239 against 63 / 159): a 16 x 32 window computes ~9x the
         // (query, key) pairs the sequences hold and the launch is bound by instruction issue, not by its latency chain — NOTEBOOK round 4
-        ws->attn_tile_sa = DR4SR_ENV("DR4SR_ATTN_WINDOW") && ws->attn_split && p->D == 64 && hint > 0 && hint <= 16 * (int64_t)p->B
+        ws->attn_tile_sa = DR4SR_XENV("DR4SR_ATTN_WINDOW") && ws->attn_split && p->D == 64 && hint > 0 && hint <= 16 * (int64_t)p->B
                            && attn_tile_capable(p) && !DR4SR_ENV("DR4SR_ATTN_NOSPLIT");
     }
     char* base = (char*)p->workspace;
@@ -469,7 +476,7 @@ static int backward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int 
     // holds layer 0 (table-gradient jobs, embedding-stage plane, scorer partials) stays last, behind the join.  DR4SR_WGRAD_ONE_LAUNCH:
     // every layer in the last launch, as before round 4 (cross-check).
     const StepFork& fk = step_fork();
-    const bool early = fused && fk.on() && p->n_layer > 1 && !DR4SR_ENV("DR4SR_WGRAD_ONE_LAUNCH");
+    const bool early = fused && fk.on() && p->n_layer > 1 && !DR4SR_XENV("DR4SR_WGRAD_ONE_LAUNCH");
     bool forked = false;
     for (int l = p->n_layer - 1; l >= 0; --l) {
         if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_bwd(p, ws, l, training, s));

@@ -583,7 +583,7 @@ static int topk_ws_impl(const float* q, const float* E, const int64_t* hist, con
     if (workspace_bytes < B * (int64_t)lds_s * 4) return DR4SR_E_WS;
     const size_t lds_fix = sizeof(int) * (256 + 8) + sizeof(unsigned long long) * 512;
     const size_t lds_row = sizeof(unsigned) * ((n_items + 3) & ~3) + lds_fix;
-    const int lds_max_kb = DR4SR_ENV("DR4SR_TOPK_LDS_KB") ? atoi(DR4SR_ENV("DR4SR_TOPK_LDS_KB")) : 24;      // measured: above ~4 k items the LDS copy costs more occupancy than the second row read (0.120 vs 0.104 ms at N = 11 925)
+    const int lds_max_kb = DR4SR_XENV("DR4SR_TOPK_LDS_KB") ? atoi(DR4SR_XENV("DR4SR_TOPK_LDS_KB")) : 24;      // measured: above ~4 k items the LDS copy costs more occupancy than the second row read (0.120 vs 0.104 ms at N = 11 925)
     const bool ldsrow = lds_row <= (size_t)lds_max_kb * 1024;               // (above that the LDS copy costs more occupancy than the second row read)
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;

@@ -46,6 +46,11 @@ int dr4sr_sasrec_launch_kernel(const dr4sr_sasrec_plan* plan, int32_t kernel, in
  * a workspace sized under one setting must not be used under another (DR4SR_BM) — build the engine after the reload. */
 int dr4sr_reload_env(void);
 
+/* bit 0: the library was built with -DDR4SR_EXPERIMENTS (`make -C dr4sr_amd/csrc EXPERIMENTS=1` -> libdr4sr_hip_exp.so; load it through
+ * DR4SR_LIB_PATH): the experiment / tuning switches of SWITCHES.md's second table are read.  0: the shipped build — they are compile-time
+ * constants and only the cross-check switches of the first table exist (tests of experiment switches skip themselves). */
+int dr4sr_build_flags(void);
+
 /* the same with the MetaModel weighting (model/metamodel.py:174-194) on the launches that carry it (DR4SR_K_POST_MID); mw may be NULL */
 int dr4sr_sasrec_launch_kernel_weighted(const dr4sr_sasrec_plan* plan, const dr4sr_meta_weighting* mw, int32_t kernel, int32_t layer,
                                         void* stream);

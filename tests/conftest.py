@@ -48,6 +48,24 @@ def at_scale(monkeypatch):
     monkeypatch.setenv("DR4SR_FORCE_SCALE", "1")
 
 
+def _experiment_switches():
+    """the DR4SR_* names the library reads through DR4SR_XENV (csrc/common.h): experiment / tuning switches, compiled out of the shipped build"""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "dr4sr_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r'DR4SR_XENV\("(DR4SR_[A-Z0-9_]+)"\)', open(f).read()))
+    return names
+
+
+EXPERIMENT_SWITCHES = _experiment_switches()
+
+
+def _experiments_build() -> bool:
+    from dr4sr_amd import _lib
+    return bool(_lib.load().dr4sr_build_flags() & 1)
+
+
 def _reload_lib_env():
     """libdr4sr_hip.so caches every DR4SR_* switch per process; dr4sr_reload_env() (include/dr4sr_hip_hooks.h) makes it read them again"""
     from dr4sr_amd import _lib
@@ -64,6 +82,9 @@ def _dr4sr_env_switches_follow_monkeypatch(monkeypatch):
     real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
 
     def setenv(name, value, prepend=None):
+        if name in EXPERIMENT_SWITCHES and not _experiments_build():
+            pytest.skip("%s is an experiment / tuning switch: compiled out of the shipped library (csrc/common.h DR4SR_XENV); build "
+                        "`make -C dr4sr_amd/csrc EXPERIMENTS=1` and run with DR4SR_LIB_PATH=.../libdr4sr_hip_exp.so" % name)
         real_set(name, value, prepend)
         if name.startswith("DR4SR_"):
             _reload_lib_env()

@@ -576,15 +576,18 @@ def test_regime_follows_the_expected_token_hint(monkeypatch):
     # bit 2 (round 4): the attention runs inside the 16-token tile kernels — the latency regime (neither of the other two)
     assert scale(256, short) == 4 and scale(1400, short) == 4 and scale(2000, short) == 4      # 1 280 / 7 000 / 10 000 expected tokens
     assert scale(2100, short) == 1 and scale(2800, short) == 1                                 # 10 500 / 14 000: tiles at scale, attention per sequence
-    assert scale(2900, short) == 3 and scale(4096, short) == 3
+    assert scale(2900, short) == 3 | 16 and scale(4096, short) == 3 | 16      # bit 4 (round 6): the lists' regime runs the wave-per-tile launches
     # batches of LONG sequences (expected mean length > 16) never take the attention lists: one 8-wave workgroup per sequence is faster
     # at every size (round 3, tools/regime_sweep3.sh --dense)
     assert scale(120, full) == 4 and scale(128, full) == 1 and scale(160, full) == 1 and scale(300, full) == 1 and scale(4096, full) == 1      # 6 000 / 6 400 / 8 000 / 15 000 / 204 800 tokens (long sequences: boundary 6 144)
     mid = torch.full((4096,), 16, dtype=torch.int64, device=dev)
-    assert scale(1000, mid) == 3                                                                # 16 000 tokens, mean length 16: lists
-    assert scale(256, short, hint=0) == 4 and scale(400, short, hint=0) == 3                   # unknown: capacity 12 800 / 20 000 decides both
+    assert scale(1000, mid) == 3 | 16                                                            # 16 000 tokens, mean length 16: lists
+    assert scale(256, short, hint=0) == 4 and scale(400, short, hint=0) == 3 | 16                   # unknown: capacity 12 800 / 20 000 decides both
     monkeypatch.setenv("DR4SR_FORCE_SCALE", "1")
+    assert scale(64, short) == 3 | 16
+    monkeypatch.setenv("DR4SR_ATTN_LISTS", "1")                                                # cross-check: the length-class lists
     assert scale(64, short) == 3
+    monkeypatch.delenv("DR4SR_ATTN_LISTS")
     monkeypatch.setenv("DR4SR_FORCE_ATTN_SPLIT", "0")
     assert scale(64, short) == 1
     monkeypatch.delenv("DR4SR_FORCE_ATTN_SPLIT")
