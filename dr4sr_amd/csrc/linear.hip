@@ -2258,7 +2258,10 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     // deterministic mode (Workspace::det): partial buffers instead of atomics + the ordered reduce launch below
     A.det = nullptr; A.det_ln = nullptr; A.det_dp = nullptr; A.det_stride = 0;
     if (ws.det && ws.det_part && ws.scale && !blk_env_on()) {
-        A.det = ws.det_part; A.det_stride = (int)ws.det_stride; A.det_ln = ws.det_ln; A.det_dp = scatter ? ws.det_dp : nullptr;
+        //  the ordered position-table partials belong to the OWNER form of the table gradient: with DR4SR_DE_ATOMIC the scatter
+        // job keeps its atomics for dE and dP alike (complete, not ordered) instead of building dP partials only and dropping dE
+        A.det = ws.det_part; A.det_stride = (int)ws.det_stride; A.det_ln = ws.det_ln; A.det_dp = (scatter && de_owner_mode(ws)) ? ws.det_dp : nullptr;
+        A.xcd = 0;          //  k_wgrad_det_reduce sums partial blocks x in [0, min(gw, tiles)): block x must own tile x first — the plain order
     }
     A.ow_ent = nullptr; A.ow_off = nullptr;
     A.ow_on = 0; A.ow_rec = nullptr; A.ow_idx32 = nullptr; A.ow_z = nullptr; A.ow_logG = 0; A.ow_planes = 0; A.ow_rpo = 0;

@@ -151,7 +151,13 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // gradient is owner-computed, their attention has no atomics — with the weight-gradient launch's remaining atomics replaced by
         // partial buffers summed in a fixed order (linear.hip k_wgrad_det_reduce)
         ws->det = DR4SR_ENV("DR4SR_DETERMINISTIC") != nullptr && atoi(DR4SR_ENV("DR4SR_DETERMINISTIC")) != 0;
-        if (ws->det) ws->scale = true;
+        if (ws->det) {
+            ws->scale = true;
+            // round 6: the wave-per-tile attention (attn_wave.hip) writes every dqkv row from exactly one wave — bit-reproducible by
+            // construction and two launches per layer at any batch size, where the mode used to fall back to one workgroup per sequence
+            // below the lists' threshold (16 + 20 us of the mode's +70 us at B = 256, NOTEBOOK round 5)
+            if (p->H == 2 && p->L <= 64 && !DR4SR_ENV("DR4SR_NO_FUSE")) ws->attn_split = true;
+        }
         // tests (cached per process until dr4sr_reload_env(), common.h): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
         if (const char* f = DR4SR_ENV("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
@@ -184,7 +190,10 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->det_stride = D == 64 ? 64 * 64 + 64 : (int64_t)(D > F ? D : F) * (D > F ? D : F) + (D > F ? D : F);      // d = 64: 64 x 64 block jobs (k_wgrad_bf64); launch_wgrad refuses wider jobs
     ws->det_part = nullptr; ws->det_ln = nullptr; ws->det_dp = nullptr;
     if (ws->det) {
-        ws->det_part = take((int64_t)p->n_layer * DR4SR_WGRAD_MAX_JOBS * DR4SR_DET_MAX_SPLITS * ws->det_stride);
+        //  jobs per layer as launch_wgrad indexes them: the 64 x 64 blocks of d = 64 (4 + 2 F / 64), the six whole GEMMs of d = 128
+        // (253 MB per layer were carved for 12 jobs at d = 128, F = 128)
+        const int64_t det_jobs = D == 64 ? 4 + 2 * F / 64 : 6;
+        ws->det_part = take((int64_t)p->n_layer * det_jobs * DR4SR_DET_MAX_SPLITS * ws->det_stride);
         ws->det_ln = take((int64_t)p->n_layer * DR4SR_DET_MAX_SPLITS * 4 * D);
         ws->det_dp = take((int64_t)DR4SR_DET_MAX_SPLITS * p->L * D);
     }

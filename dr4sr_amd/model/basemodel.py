@@ -107,6 +107,8 @@ class _ScoreBCE(torch.autograd.Function):
 
 
 class BaseModel(nn.Module):
+    _det_set_by_model = False          # train.deterministic turned DR4SR_DETERMINISTIC on (as opposed to the user's environment)
+
     def __init__(self, config: Dict, dataset_list: List[BaseDataset]) -> None:
         super().__init__()
         self.config = config
@@ -131,7 +133,19 @@ class BaseModel(nn.Module):
         # summation order in every reduction of the step (csrc/step.hip: DR4SR_DETERMINISTIC — the at-scale launch forms at every batch
         # size + ordered partial sums in the weight-gradient launch).  Process-wide, like the reference's flag; costs speed (bench.py:
         # deterministic_mode), not accuracy.
-        if bool(config["train"].get("deterministic", False)) or os.environ.get("DR4SR_DETERMINISTIC", "0") not in ("", "0"):
+        #  The switch is read when an engine's workspace is carved, so it must be settled BEFORE this model's engine exists: a model
+        # built with deterministic = false after one that turned the mode on gets the default mode back (only if a MODEL turned it on — a
+        # DR4SR_DETERMINISTIC the user exported stays), and every change is logged.  Engines built earlier keep the mode they were sized for.
+        want = bool(config["train"].get("deterministic", False))
+        user_env = os.environ.get("DR4SR_DETERMINISTIC", "0") not in ("", "0") and not BaseModel._det_set_by_model
+        if not want and not user_env and BaseModel._det_set_by_model:
+            _lib.set_env("DR4SR_DETERMINISTIC", None)
+            BaseModel._det_set_by_model = False
+            logging.getLogger("CDR").info("train.deterministic: off for this model (an earlier model of this process had turned it on)")
+        if want or user_env:
+            if want and not user_env and not BaseModel._det_set_by_model:
+                BaseModel._det_set_by_model = True
+                logging.getLogger("CDR").info("train.deterministic: on (process-wide switch DR4SR_DETERMINISTIC, read when an engine is built)")
             _lib.set_env("DR4SR_DETERMINISTIC", "1")
             # bit-identical fits are tested for SASRec, CL4SRec and MetaModel around SASRec (tools/det_fit_check.py); GRU4Rec's and FMLP's steps
             # keep fp32 atomics (table scatter, weight-gradient splits): measured 1e-7 / 2e-5 between two fits
