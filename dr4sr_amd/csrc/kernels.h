@@ -76,6 +76,7 @@ int latency_tmax();
 static inline bool at_scale(int Tmax) { return Tmax > latency_tmax(); }
 constexpr int DR4SR_SCALE_TOKENS = 7168, DR4SR_ATTN_SPLIT_TOKENS = 14336;      // at d = 64; scaled by 64 / d
 constexpr int DR4SR_SCALE_TOKENS_SHORT = 10240, DR4SR_SCALE_TOKENS_LONG = 6144;    // ... with the attention inside the tile kernels: expected mean length <= 16 / above
+constexpr int DR4SR_SCALE_TOKENS_SHORT_WAVE = 7680;     // round 6: short-sequence plans whose at-scale attention is the wave-per-tile form (attn_wave.hip): tiles AND attention switch here
 bool attn_tile_capable(const dr4sr_sasrec_plan* p);
 // XCD-aware block -> tile order of the 256-thread token-tile kernels when the attention runs inside them (round 4).  A tile's window
 // holds the rows of the tiles in FRONT of it, written by the previous launch: with tile = blockIdx.x those ran on another XCD (block b

@@ -141,12 +141,21 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // round 4: with the attention inside the 16-token tile kernels (attn_tile.h) the latency forms carry toys-shaped batches further
         // (B = 1 536, 8.5 k tokens: 0.227 against 0.240 ms; tie at 11 k) and long-sequence batches less far (all-50 rows, 6 400 tokens:
         // 0.199 against 0.193 ms — every query sees all five key tiles of its window): the boundary follows the expected mean length
-        const int64_t scale_tokens = !attn_tile_capable(p) ? DR4SR_SCALE_TOKENS : (hint <= 16 * (int64_t)p->B ? DR4SR_SCALE_TOKENS_SHORT : DR4SR_SCALE_TOKENS_LONG);
+        // round 6: with the wave-per-tile attention (attn_wave.hip) the at-scale forms of SHORT-sequence plans overtake the latency forms between
+        // 7.0 k and 8.1 k expected tokens (toys rows, same box, latency / at scale: B = 1 280 0.1705 / 0.2043 ms, B = 1 536 0.2218 / 0.2090,
+        // B = 2 048 0.2536 / 0.2227, B = 2 560 0.2889 / 0.2343 — profiles/round6_regime_sweep.txt) and the middle regime (at-scale tiles with one
+        // attention workgroup per sequence: 0.2419 / 0.2652 / 0.2893 at the last three sizes) is never the fastest: one boundary for both
+        const bool wave_capable = p->H == 2 && p->L <= 64 && !DR4SR_ENV("DR4SR_NO_FUSE") && !DR4SR_ENV("DR4SR_ATTN_LISTS") && !DR4SR_ENV("DR4SR_ATTN_NOSPLIT")
+                                  && !DR4SR_ENV("DR4SR_ATTN_VALU");
+        const bool short_plan = hint <= 16 * (int64_t)p->B;
+        const int64_t scale_tokens = !attn_tile_capable(p) ? DR4SR_SCALE_TOKENS
+                                     : (short_plan ? (wave_capable ? DR4SR_SCALE_TOKENS_SHORT_WAVE : DR4SR_SCALE_TOKENS_SHORT) : DR4SR_SCALE_TOKENS_LONG);
         ws->scale = known ? hint * D > scale_tokens * 64 : at_scale((int)Tmax);
         // the length-class lists pay off through their short classes (1..8-token VALU class, 16-row tiles); a batch of LONG sequences
         // runs faster as one 8-wave workgroup per sequence at every size (round 3, all-50 batches: B = 2 048 0.929 vs 0.990 ms,
         // B = 8 192 3.36 vs 3.62 ms), so the lists also need an expected mean length of at most 16 tokens
-        ws->attn_split = known ? (hint * D > (int64_t)DR4SR_ATTN_SPLIT_TOKENS * 64 && hint <= 16 * (int64_t)p->B) : at_scale((int)Tmax);
+        ws->attn_split = known ? (hint * D > (int64_t)(wave_capable ? (scale_tokens < DR4SR_ATTN_SPLIT_TOKENS ? scale_tokens : DR4SR_ATTN_SPLIT_TOKENS) : DR4SR_ATTN_SPLIT_TOKENS) * 64 && short_plan)
+                               : at_scale((int)Tmax);
         // deterministic summation order (DR4SR_DETERMINISTIC=1; Python: train.deterministic): the at-scale forms at every size — their item-table
         // gradient is owner-computed, their attention has no atomics — with the weight-gradient launch's remaining atomics replaced by
         // partial buffers summed in a fixed order (linear.hip k_wgrad_det_reduce)

@@ -574,9 +574,13 @@ def test_regime_follows_the_expected_token_hint(monkeypatch):
     short, full = torch.full((4096,), 5, dtype=torch.int64, device=dev), torch.full((4096,), 50, dtype=torch.int64, device=dev)
     # bit 0: at-scale token-tile kernels (> ~7 k expected tokens), bit 1: length-class attention lists (> ~14 k),
     # bit 2 (round 4): the attention runs inside the 16-token tile kernels — the latency regime (neither of the other two)
-    assert scale(256, short) == 4 and scale(1400, short) == 4 and scale(2000, short) == 4      # 1 280 / 7 000 / 10 000 expected tokens
-    assert scale(2100, short) == 1 and scale(2800, short) == 1                                 # 10 500 / 14 000: tiles at scale, attention per sequence
-    assert scale(2900, short) == 3 | 16 and scale(4096, short) == 3 | 16      # bit 4 (round 6): the lists' regime runs the wave-per-tile launches
+    # round 6: short-sequence plans switch tiles AND attention at ~7.7 k expected tokens (wave-per-tile attention, bit 4); the middle regime
+    # (at-scale tiles, one attention workgroup per sequence) only exists for the cross-check forms
+    assert scale(256, short) == 4 and scale(1400, short) == 4 and scale(1500, short) == 4     # 1 280 / 7 000 / 7 500 expected tokens
+    assert scale(1600, short) == 3 | 16 and scale(2000, short) == 3 | 16 and scale(4096, short) == 3 | 16      # 8 000 / 10 000 / 20 480
+    monkeypatch.setenv("DR4SR_ATTN_LISTS", "1")                                                # the lists keep the round-4 boundaries
+    assert scale(2000, short) == 4 and scale(2100, short) == 1 and scale(2800, short) == 1 and scale(2900, short) == 3
+    monkeypatch.delenv("DR4SR_ATTN_LISTS")
     # batches of LONG sequences (expected mean length > 16) never take the attention lists: one 8-wave workgroup per sequence is faster
     # at every size (round 3, tools/regime_sweep3.sh --dense)
     assert scale(120, full) == 4 and scale(128, full) == 1 and scale(160, full) == 1 and scale(300, full) == 1 and scale(4096, full) == 1      # 6 000 / 6 400 / 8 000 / 15 000 / 204 800 tokens (long sequences: boundary 6 144)
