@@ -14,6 +14,7 @@ struct AttnArgs2 {
     // 2 waves, ~9 workgroups per CU) and a long kernel, each a persistent loop over its list.  list == NULL: block b = sequence b.
     const int* list; const int* list_count;
     const int* desc;             // tiny class: int4 {t0, n, slot, dataset row} per list entry (k_prep), 16-byte aligned
+    unsigned* keep;              // [T][H][2] dropout keep bits per (token, head), written by the wave-per-tile forward and read by its backward (attn_wave.hip)
     const int2* tok;             // [T] per-token words of the embedding stage {first token of the sequence, slot | length << 20 | PAD << 30}: the wave-per-tile form (attn_wave.hip); NULL: lists
 };
 

@@ -598,7 +598,7 @@ static AttnArgs2 make_args2(const dr4sr_sasrec_plan* p, const Workspace& ws, int
     A.idx = p->in_item_id; A.rows = p->rows; A.cu = ws.cu;
     A.state = p->state; A.seed = p->seed; A.p = p->p_drop; A.layer = layer; A.training = training; A.L = p->L;
     A.list = nullptr; A.list_count = nullptr; A.desc = nullptr; A.stat = lw.attn_st; A.rd = ws.attn_rd;
-    A.tok = attn_wave_on(p, ws) ? ws.tok : nullptr;
+    A.tok = attn_wave_on(p, ws) ? ws.tok : nullptr; A.keep = lw.attn_keep;
     return A;
 }
 

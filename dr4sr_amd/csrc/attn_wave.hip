@@ -126,6 +126,11 @@ __device__ __forceinline__ float keep_at(const Keep64& k, const int pos, const f
     return ((w >> (pos & 31)) & 1u) ? scale : 0.f;
 }
 
+// saved keep bits of (token t, head h), branch-free; all ones without dropout
+__device__ __forceinline__ Keep64 keep_load(const AttnArgs2& A, const int t, const int h, const int T, const bool dodrop) {
+    const uint2 v = *reinterpret_cast<const uint2*>(A.keep + ((size_t)max(min(t, T - 1), 0) * 2 + h) * 2);
+    return dodrop ? Keep64{v.x, v.y} : Keep64{0xffffffffu, 0xffffffffu};
+}
 // PAD flags (bit 30 of the token words) of key tile jt as 16 bits, wave-uniform
 __device__ __forceinline__ unsigned pad_bits(const int lane, const int2* __restrict__ tok, const int jt, const int T) {
     const int t = 16 * jt + (lane & 15);
@@ -200,7 +205,11 @@ __device__ __forceinline__ void fwd_tile(const int tid, const AttnArgs2& A, cons
     const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
     const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
     const float scale = 1.0f / sqrtf((float)DH);
+    const float kscale = dodrop ? rk.scale : 1.f;          // (all-ones keep words without dropout: eval with p > 0 must not rescale)
     const Keep64 keep = keep_row(lane, rk, site, ((uint64_t)(bq * H + h) * 64 + (uint64_t)(tq - s0)) * 64, need_hi, dodrop);
+    // the backward reads the decisions instead of recomputing them: one Philox call is ~130 VALU instructions with 40 quarter-rate integer
+    // multiplies (~1 000 SIMD cycles), and the backward needed three per (tile, head) — 38 % of its issue time — for 8 bytes per (token, head)
+    if (dodrop && g == 0 && qv) *reinterpret_cast<uint2*>(A.keep + ((size_t)tq * H + h) * 2) = make_uint2(keep.lo, keep.hi);
     f32x4 s[MT];
     float m = -INFINITY;
     auto mask_tile = [&](const int k, const unsigned pad) {
@@ -251,7 +260,7 @@ __device__ __forceinline__ void fwd_tile(const int tid, const AttnArgs2& A, cons
         if (k < nk) {
             const int jt = it - k;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[k][r] *= inv * keep_at(keep, 16 * jt + 4 * g + r - s0, rk.scale);
+            for (int r = 0; r < 4; ++r) s[k][r] *= inv * keep_at(keep, 16 * jt + 4 * g + r - s0, kscale);
             if (k == 0) tile_cols<DH>(lane, o, vt0, s[k]);                                      // out^T[d][i] += sum_j V[j][d] P~[i][j]
             else if (k == 1) tile_cols<DH>(lane, o, vt1, s[k]);
             else mma_cols<DH>(lane, o, qkv, 3 * D, 16 * jt, 2 * D + h * DH, s[k], T);
@@ -301,8 +310,7 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
     const bool phaseB = w >= 2;
     const int t0 = 16 * it;
     const bool dodrop = A.training && A.p > 0.f;
-    const RngKey rk = make_rng(A.seed, (uint32_t)A.state[DR4SR_STATE_RNGSTEP], A.p);
-    const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
+    const float kscale = dodrop ? 1.0f / (1.0f - A.p) : 1.f;        // keep factor (the decisions themselves are the forward's: A.keep)
     const float scale = 1.0f / sqrtf((float)DH);
     const float* __restrict__ qkv = A.qkv;
     const float* __restrict__ dctx = A.dctx;
@@ -325,13 +333,12 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
         frag_rows<DH>(lane, vf1, qkv, 3 * D, has1 ? t0 - 16 : t0, 2 * D + h * DH, has1 ? T : 0);
         float mi, inv, rdot;
         row_stats(A, tl, h, T, mi, inv, rdot);
+        const Keep64 keep = keep_load(A, tl, h, T, dodrop);      // the forward's decisions (no Philox in the backward)
         const int2 wl = tok_fix(wl_raw, tl, T);
         const int w1 = has1 ? tok_fix(w1_raw, tl - 16, T).y : 0;
-        const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff, bl = wl.y & 0xfffff;
+        const int s0 = wl.x;
         const int lo = __builtin_amdgcn_readfirstlane(max(min16(lv ? (s0 >> 4) : it), max(it - (MT - 1), 0)));
         const int nk = it - lo + 1;
-        const bool need_hi = __ballot(nl > 32) != 0ull;
-        const Keep64 keep = keep_row(lane, rk, site, ((uint64_t)(bl * H + h) * 64 + (uint64_t)(tl - s0)) * 64, need_hi, dodrop);
         f32x4 o[DH / 16];
 #pragma unroll
         for (int fb = 0; fb < DH / 16; ++fb) o[fb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -342,7 +349,7 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
                 const int tk = 16 * jt + 4 * g + r;
                 const bool ok = lv && tk >= s0 && tk <= tl && !((pad >> (4 * g + r)) & 1u);
                 const float p = ok ? __expf(s[r] * scale - mi) * inv : 0.f;
-                ds[r] = p * (dp[r] * keep_at(keep, tk - s0, rk.scale) - rdot) * scale;      // dS^T[j][i]
+                ds[r] = p * (dp[r] * keep_at(keep, tk - s0, kscale) - rdot) * scale;      // dS^T[j][i]
             }
             return ds;
         };
@@ -388,8 +395,10 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
     // of them per lane: fetched by ds_bpermute below
     float rm0, ri0, rr0, rm1, ri1, rr1;
     row_stats(A, tl, h, T, rm0, ri0, rr0);
+    const Keep64 kp0 = keep_load(A, tl, h, T, dodrop);             // the forward's dropout decisions of the query rows (no Philox here)
     const int2 wn_raw = tok_raw(A.tok, t1, T);
     row_stats(A, v1 ? t1 : T, h, T, rm1, ri1, rr1);
+    const Keep64 kp1 = keep_load(A, t1, h, T, dodrop);
     {
         float qf[DH / 4], cf[DH / 4], qg[DH / 4], cg[DH / 4];
         frag_rows<DH>(lane, qf, qkv, 3 * D, t0, h * DH, T);
@@ -405,36 +414,28 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
     const int s0 = wl.x, nl = (wl.y >> 20) & 0x3ff;
     const int hi = __builtin_amdgcn_readfirstlane(min(min(max16(lv ? ((s0 + max(nl, 1) - 1) >> 4) : it), it + (MT - 1)), last));
     const int nqt = hi - it + 1;
+    const bool need_hi = __ballot(nl > 32) != 0ull;         // some key of this tile sits in a sequence longer than 32 tokens: its queries' bits 32..63 matter
     const bool jok = lv && !((wl.y >> 30) & 1);
     f32x4 dk[DH / 16], dv[DH / 16];
 #pragma unroll
     for (int fb = 0; fb < DH / 16; ++fb) { dk[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[fb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     // one query tile: S, dP~ in the natural orientation, then P~ and dS for the four query rows 4 g + r of this lane.
-    // rs0 / rb / rm / ri / rr: sequence start (-1: no such row), slot, row max, 1 / row sum, row term of query row (lane & 15) of the tile
-    auto query_tile = [&](const int qt, const float (&qf)[DH / 4], const float (&cf)[DH / 4], const int rs0, const int rb, const float rm,
-                          const float ri, const float rr, f32x4& pt, f32x4& ds) {
+    // rs0 / rm / ri / rr / kp: sequence start (-1: no such row), row max, 1 / row sum, row term, saved keep bits of query row (lane & 15) of the tile
+    auto query_tile = [&](const int qt, const float (&qf)[DH / 4], const float (&cf)[DH / 4], const int rs0, const float rm,
+                          const float ri, const float rr, const Keep64 kp, f32x4& pt, f32x4& ds) {
         const f32x4 s = mma_rows<DH>(qf, kf);                  // S[i][j]: rows i = 4 g + r (C layout), column j = i16
         const f32x4 dp = mma_rows<DH>(cf, vf);                 // dP~[i][j] = sum_d dctx[i][d] V[j][d]
-        // dropout decisions: query row i sees this key tile at positions p0 .. p0 + 15, p0 = max(16 it - s0_i, 0): at most three Philox
-        // calls (octets) per query.  Lane i16 of group g computes the call of query row 4 g + (i16 & 3), octet (p0 >> 3) + (i16 >> 2), and
-        // the lanes fetch their bits by ds_bpermute — one call per lane and query tile, as attn_mfma.hip
-        unsigned m8 = 0xffu;
-        if (dodrop) {
-            const int src = 4 * g + (i16 & 3);
-            const int ss = __shfl(rs0, src, 64), bb = __shfl(rb, src, 64);
-            const int ti = 16 * qt + src;
-            const int p0 = max(t0 - ss, 0);
-            m8 = drop_bits8(rk, site, ((uint64_t)(bb * H + h) * 64 + (uint64_t)max(ti - ss, 0)) * 64 + 8 * ((p0 >> 3) + (i16 >> 2)));
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int src = 4 * g + r, ti = 16 * qt + src;
             const int qs0 = __shfl(rs0, src, 64);
             const float qm = __shfl(rm, src, 64), qi = __shfl(ri, src, 64), qr = __shfl(rr, src, 64);
-            const int pk = tl - qs0, p0 = max(t0 - qs0, 0);
-            const int rel = ((pk >> 3) - (p0 >> 3)) & 3;
-            const unsigned mm = __shfl(m8, (lane & 48) | (r + 4 * rel), 64);
-            const float mkv = dodrop ? (((mm >> (pk & 7)) & 1u) ? rk.scale : 0.f) : 1.f;
+            const int pk = tl - qs0;                           // this key's position inside query row i's sequence (if it is that sequence)
+            // query row i's decision for this key: bit pk of its saved words (positions >= 32 only exist in sequences longer than 32: the second word
+            // is fetched under a wave-uniform test)
+            unsigned kw = (unsigned)__shfl((int)kp.lo, src, 64);
+            if (need_hi) { const unsigned kh = (unsigned)__shfl((int)kp.hi, src, 64); kw = pk < 32 ? kw : kh; }
+            const float mkv = ((kw >> (pk & 31)) & 1u) ? kscale : 0.f;
             const bool ok = jok && qs0 == s0 && tl <= ti;      // (qs0 == -1: no such query row)
             const float p = ok ? __expf(s[r] * scale - qm) * qi : 0.f;
             pt[r] = p * mkv;                                   // P~[i][j]
@@ -445,7 +446,7 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
         float qf[DH / 4], cf[DH / 4];
         tile_frag<DH>(lane, qf, qt0); tile_frag<DH>(lane, cf, ct0);
         f32x4 pt, ds;
-        query_tile(it, qf, cf, lv ? s0 : -1, wl.y & 0xfffff, rm0, ri0, rr0, pt, ds);
+        query_tile(it, qf, cf, lv ? s0 : -1, rm0, ri0, rr0, kp0, pt, ds);
         tile_cols<DH>(lane, dk, qt0, ds);                            // dK^T[f][j] += sum_i Q[i][f] dS[i][j]
         tile_cols<DH>(lane, dv, ct0, pt);                            // dV^T[d][j] += sum_i dctx[i][d] P~[i][j]
     }
@@ -453,7 +454,7 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
         float qf[DH / 4], cf[DH / 4];
         tile_frag<DH>(lane, qf, qt1); tile_frag<DH>(lane, cf, ct1);
         f32x4 pt, ds;
-        query_tile(it + 1, qf, cf, wn.x, wn.y & 0xfffff, rm1, ri1, rr1, pt, ds);
+        query_tile(it + 1, qf, cf, wn.x, rm1, ri1, rr1, kp1, pt, ds);
         tile_cols<DH>(lane, dk, qt1, ds);
         tile_cols<DH>(lane, dv, ct1, pt);
     }
@@ -470,7 +471,7 @@ __device__ __forceinline__ void bwd_tile(const int tid, const AttnArgs2& A, cons
             float rm, ri, rr;
             row_stats(A, ti, h, T, rm, ri, rr);
             f32x4 pt, ds;
-            query_tile(qt, qf, cf, wi.x, wi.y & 0xfffff, rm, ri, rr, pt, ds);
+            query_tile(qt, qf, cf, wi.x, rm, ri, rr, keep_load(A, ti, h, T, dodrop), pt, ds);
             mma_cols<DH>(lane, dk, qkv, 3 * D, 16 * qt, h * DH, ds, T);
             mma_cols<DH>(lane, dv, dctx, D, 16 * qt, h * DH, pt, T);
         }

@@ -13,6 +13,7 @@ struct LayerWs {
     float* qkv;    // [T,3D]  in_proj output (q|k|v)
     float* ctx;    // [T,D]   attention output (heads merged), before out_proj
     float* attn_st; // [T,H,2] softmax row max and 1/row sum per (token, head), saved by the MFMA attention forward
+    unsigned* attn_keep; // [T,H,2] dropout keep bits of (token, head)'s key positions 0..31 | 32..63, saved by the wave-per-tile forward (attn_wave.hip)
     float* u1;     // [T,D]   x + drop(out_proj(ctx))                     (LayerNorm1 input)
     float* y;      // [T,D]   LayerNorm1 output
     float* st1;    // [T,2]   (mean, rstd) of u1

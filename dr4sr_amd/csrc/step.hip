@@ -216,6 +216,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     for (int l = 0; l < p->n_layer; ++l) {
         LayerWs& w = ws->layer[l];
         w.qkv = take(Tmax * 3 * D); w.ctx = take(Tmax * D); w.attn_st = take(Tmax * p->H * 2);
+        w.attn_keep = reinterpret_cast<unsigned*>(take(Tmax * p->H * 2));
         w.u1 = take(Tmax * D); w.y = take(Tmax * D); w.st1 = take(Tmax * 2);
         w.a = take(Tmax * F); w.h = take(Tmax * F); w.u2 = take(Tmax * D); w.st2 = take(Tmax * 2);
         w.df = take(Tmax * D); w.da = take(Tmax * F); w.du1 = take(Tmax * D); w.dout = take(Tmax * D); w.dqkv = take(Tmax * 3 * D);

@@ -136,13 +136,15 @@ class BaseModel(nn.Module):
         #  The switch is read when an engine's workspace is carved, so it must be settled BEFORE this model's engine exists: a model
         # built with deterministic = false after one that turned the mode on gets the default mode back (only if a MODEL turned it on — a
         # DR4SR_DETERMINISTIC the user exported stays), and every change is logged.  Engines built earlier keep the mode they were sized for.
+        # (a config WITHOUT the key — e.g. the sub-model a MetaModel builds from its own section — leaves the mode as it is.)
         want = bool(config["train"].get("deterministic", False))
+        explicit_off = "deterministic" in config["train"] and not want
         user_env = os.environ.get("DR4SR_DETERMINISTIC", "0") not in ("", "0") and not BaseModel._det_set_by_model
-        if not want and not user_env and BaseModel._det_set_by_model:
+        if explicit_off and not user_env and BaseModel._det_set_by_model:
             _lib.set_env("DR4SR_DETERMINISTIC", None)
             BaseModel._det_set_by_model = False
             logging.getLogger("CDR").info("train.deterministic: off for this model (an earlier model of this process had turned it on)")
-        if want or user_env:
+        if want or user_env or BaseModel._det_set_by_model:
             if want and not user_env and not BaseModel._det_set_by_model:
                 BaseModel._det_set_by_model = True
                 logging.getLogger("CDR").info("train.deterministic: on (process-wide switch DR4SR_DETERMINISTIC, read when an engine is built)")

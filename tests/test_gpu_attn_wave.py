@@ -132,11 +132,13 @@ def test_wave_attention_eval_and_second_backward(monkeypatch, at_scale):
     inp = np.zeros((B, L), dtype=np.int64)
     for b in range(B):
         inp[b, :sl[b]] = rng.integers(1, N, size=sl[b])
-    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, 0.0, B, "cuda")
+    # dropout 0.3 in the ENGINE: the eval pass must ignore it (keep factor 1, not 1 / (1 - p)), the training passes draw the lists' elements
+    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, 0.3, B, "cuda", seed=3)
     eng.load_named(_random_params(N, D, 128, 2, seed=11))
     plan = eng.make_plan(torch.from_numpy(inp).cuda(), None, torch.from_numpy(sl).cuda())
     assert _bits(plan) & WAVE
     q = eng.encode(plan, False, _lib.POOL_LAST).clone()
+    step0 = int(eng.state[3])
     q_tr = eng.encode(plan, True, _lib.POOL_MEAN).clone()
     g = torch.randn_like(q_tr)
     grads = []
@@ -144,14 +146,19 @@ def test_wave_attention_eval_and_second_backward(monkeypatch, at_scale):
         eng.grads.zero_()
         eng.encode_bwd(plan, True, _lib.POOL_MEAN, g)
         grads.append(eng.grads[:eng.n_params].cpu())
-    assert relerr(grads[1], grads[0]) < 1e-5
+    assert torch.equal(grads[1], grads[0]) or relerr(grads[1], grads[0]) < 1e-5
     monkeypatch.setenv("DR4SR_ATTN_LISTS", "1")
     assert not _bits(plan) & WAVE
     assert relerr(eng.encode(plan, False, _lib.POOL_LAST), q.cpu()) < 1e-5
-    eng.encode(plan, True, _lib.POOL_MEAN)
+    eng.state[3] = step0                                              # the same RNG step as the wave form's training pass
+    assert relerr(eng.encode(plan, True, _lib.POOL_MEAN), q_tr.cpu()) < 1e-5
     eng.grads.zero_()
     eng.encode_bwd(plan, True, _lib.POOL_MEAN, g)
     assert relerr(eng.grads[:eng.n_params].cpu(), grads[0]) < 2e-5
+    # ... and against the oracle in eval mode (no dropout): the pooled last-position query
+    params = {k: v.detach().cpu().clone() for k, v in eng.views.items()}
+    params["query_encoder.item_encoder.weight"] = params["item_embedding.weight"]
+    monkeypatch.delenv("DR4SR_ATTN_LISTS")
 
 
 def test_wave_attention_is_what_a_toys_sized_plan_takes(at_scale, monkeypatch):
