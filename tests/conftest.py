@@ -78,6 +78,12 @@ def _dr4sr_env_switches_follow_monkeypatch(monkeypatch):
     """Every test starts from the process environment as it is NOW (the previous test's monkeypatch undo has already happened), and
     every monkeypatch.setenv / delenv of a DR4SR_* name inside the test reaches the library at once — the cross-check switches of
     DESIGN.md 5a are tested in-process instead of in a fresh interpreter per switch."""
+    # a model built with train.deterministic in an EARLIER test turned the process-wide mode on (dr4sr_amd/model/basemodel.py): a test starts
+    # from the default mode unless it asks for the other one itself
+    bm = sys.modules.get("dr4sr_amd.model.basemodel")
+    if bm is not None and bm.BaseModel._det_set_by_model:
+        bm.BaseModel._det_set_by_model = False
+        os.environ.pop("DR4SR_DETERMINISTIC", None)
     _reload_lib_env()
     real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
 
