@@ -145,12 +145,12 @@ def test_data_parallel_ranks_equal_single_rank_wide(W, D, B, U, expect):
     print(lines[0])
 
 
-@pytest.mark.parametrize("B,buckets", [(8192, 2), (1536, 1)])
+@pytest.mark.parametrize("B,buckets", [(8192, 2), (1280, 1)])
 def test_rccl_buckets_inside_k_step_graph(B, buckets):
     """one RCCL rank: k DP steps per graph, each with its collective(s) captured — at B = 8 192 the table bucket's all-reduce is issued
     asynchronously after phase 1 and joined before the optimizer (a parallel branch of the graph), the optimizer launches prepare the
-    next batch in two phases — against the un-captured single-GPU loop; B = 1 536 (8.4 k tokens: latency forms above the old 1 024-row limit of the
-    prepared form): one flat bucket"""
+    next batch in two phases — against the un-captured single-GPU loop; B = 1 280 (7.0 k tokens: latency forms — below round 6's 7.7 k boundary — above the
+    old 1 024-row limit of the prepared form): one flat bucket"""
     out = torchrun(1, "tools/dp_graph_check.py", {"DP_GRAPH_B": B, "DP_GRAPH_REPLAYS": 6, "DP_GRAPH_K": 3, "DP_GRAPH_EXPECT_BUCKETS": buckets,
                                                    "DR4SR_DP_BUCKETS": 2})
     assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, report(out)

@@ -562,3 +562,50 @@ def test_switch_inventory_is_generated_from_the_source_and_small():
     assert n_run <= 35, out.stdout
     from dr4sr_amd import _lib
     assert _lib.load().dr4sr_build_flags() in (0, 1)
+
+
+def _control_plane_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from dr4sr_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), DR4SR_DP_BACKEND="gloo")
+    assert parallel.init_distributed() and dist.get_backend() == "gloo" and not parallel.can_capture()
+    ok_all = parallel.all_ok(True)
+    ok_one_bad = parallel.all_ok(rank != 1)
+    mx = parallel.host_allreduce([float(rank), 10.0 - rank], "max")
+    sm = parallel.host_allreduce([1.0], "sum")
+    ga = parallel.host_allgather(100.0 + rank)
+    t = torch.full((5,), float(rank + 1))
+    parallel.allreduce_flat(t)
+    h = parallel.allreduce_begin(t)
+    parallel.allreduce_end(h)
+    g = parallel.all_gather_flat(torch.tensor([rank, rank * 2], dtype=torch.int64))
+    b = parallel.broadcast(torch.tensor([float(rank)]), src=1)
+    parallel.barrier()
+    if rank == 0:
+        q.put((ok_all, ok_one_bad, mx, sm, ga, t.tolist(), g.tolist(), b.tolist()))
+    parallel.shutdown()
+    parallel.shutdown()                                    # idempotent
+
+
+def test_control_plane_helpers_gloo_world3():
+    """round 6: torch.distributed carries only the CONTROL plane (a CPU gloo group): decisions every rank must take alike, timings, barriers,
+    and — with DR4SR_DP_BACKEND=gloo — the staged data plane of the functional tests.  World size 3 on CPU."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    W = 3
+    procs = [ctx.Process(target=_control_plane_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    ok_all, ok_one_bad, mx, sm, ga, t, g, b = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok_all is True and ok_one_bad is False
+    assert mx == [2.0, 10.0] and sm == [3.0] and ga == [100.0, 101.0, 102.0]
+    assert t == [18.0] * 5                                  # 1 + 2 + 3 = 6 on every rank, then the begin / end form reduces that again: 18
+    assert g == [[0, 0], [1, 2], [2, 4]] and b == [1.0]
