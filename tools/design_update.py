@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "5"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "6"
 tables = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), rnd], capture_output=True, text=True, check=True).stdout
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
