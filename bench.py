@@ -93,7 +93,8 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
     # it is a launch of its own.
     big = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 1)
     in_tile = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 4)       # latency regime: no attention launches (csrc/attn_tile.h)
-    launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1)] + ([] if in_tile else [("attn_fwd", NL - 1, NL)]) + [("post_fwd", 0, NL - 1),
+    fold_fwd = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 32)     # round 6: the attention forward runs inside the wave-tile forward launches
+    launches = [("prep", 0, 1.0 / max(1, group)), ("embqkv_fwd", 0, 1)] + ([] if (in_tile or fold_fwd) else [("attn_fwd", NL - 1, NL)]) + [("post_fwd", 0, NL - 1),
                 ("post_mid", 0, 1)] + ([] if in_tile else [("attn_bwd", NL - 1, NL)]) + [("post_bwd", 0, NL - 1)]
     launches += ([("qkv_embed_bwd", 0, 1)] if big else []) + [("wgrad_fused", 0, 1), ("adam", 0, 1)]
     per_step_launches = {k: n for k, _, n in launches}

@@ -105,6 +105,7 @@ __device__ __forceinline__ int xcd_tile(const int T, const int BM, const int on)
 // per-token words {first token of the sequence, sequence slot | sequence length << 20 | PAD << 30} the embedding stage wrote
 struct TileAttnArgs {
     const float* qkv; float* dqkv; float* ctx; float* stat; const int2* tok; int L;
+    unsigned* keep;                            // [T][H][2] dropout keep bits saved by the wave-per-tile forward (attn_wave.hip / wt_attn_ctx) for its backward
     int on;                                    // bit 0: on; bit 1 (DR4SR_ATTN_TILE_ATOMICS): no plain stores for tile-private dK | dV rows; bit 2: near rows first (short-sequence plans)
 };
 struct alignas(16) PostArgs {                   // (16: the argument block behind it in a kernel's kernarg segment keeps its alignment — s_load grouping)
@@ -128,6 +129,8 @@ struct alignas(16) PostArgs {                   // (16: the argument block behin
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
     float* nx_dqkv_zero;                       // ... and the launch that emits layer+1's qkv zeroes the K | V rows of its dqkv (atomics target)
     float* dn_dqkv_zero;                       // backward: the K | V rows of layer-1's dqkv, zeroed by the launch in front of their accumulation
+    int wt_attn;                               // wave-tile forward kernels (linear_wave.hip), round 6: 1 = the layer's attention forward runs at the head of every tile
+                                               // (wt_attn_ctx: from at.qkv / at.tok; ctx, statistics and keep bits are still stored for the backward) — no attention launch
     const unsigned short* sp;                  // bf16x3 tile GEMMs (d = 128 at scale): this layer's split-weight block, layer + 1's right behind (common.h); NULL: fp32.
                                                // Latency forms at d = 128 (16-row tiles): this layer's fragment-major fp32 image instead (as float*; layer + 1's E floats behind)
 };
@@ -255,6 +258,9 @@ bool attn_in_tile(const dr4sr_sasrec_plan* p, const Workspace& ws);    // latenc
 // per (16-token tile of the packed stream, head[, phase]) from the embedding stage's per-token words (attn_wave.hip, round 6); the lists
 // stay as the cross-check (DR4SR_ATTN_LISTS) and for the un-fused step, which writes no token words
 bool attn_wave_on(const dr4sr_sasrec_plan* p, const Workspace& ws);
+// ... and its FORWARD folded into the wave-tile forward kernels (d = 64 at scale: k_wt_post_fwd / k_wt_post_mid compute the tile's ctx rows
+// themselves: one attention launch per layer — the backward — instead of two).  Experiments build only, DR4SR_ATTN_FOLD=1: measured slower
+bool attn_fold_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws);
 // at scale, short sequences, d = 64 (Workspace::attn_tile_sa): one window-attention launch per layer and direction instead of the
 // two / three length-class list launches (attn_tile_sa.hip; the same tattn::fwd / tattn::bwd bodies as the in-tile form)
 PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training);

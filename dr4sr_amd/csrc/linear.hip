@@ -182,6 +182,16 @@ bool attn_wave_on(const dr4sr_sasrec_plan* p, const Workspace& ws) {
     return ws.attn_split && !ws.attn_tile_sa && p->H == 2 && p->L <= 64 && (p->D == 64 || p->D == 128) && !DR4SR_ENV("DR4SR_NO_FUSE")
            && !DR4SR_ENV("DR4SR_ATTN_LISTS") && !DR4SR_ENV("DR4SR_ATTN_NOSPLIT") && !DR4SR_ENV("DR4SR_ATTN_VALU");
 }
+// OPT-IN, experiments build only (DR4SR_ATTN_FOLD=1): built for the review's "attention + FFN as one block at scale", oracle-tested, measured
+// SLOWER than the launch of its own it replaces — toys rows, same box, folded / launch of its own: B = 8 192 0.4665 / 0.4589 ms (k_wt_post_fwd
+// 49.1 -> 69.6 us, k_wt_post_mid 102 -> 126 for a 17.6 us launch removed twice), B = 4 096 0.3067 / 0.3035, B = 2 048 0.2357 / 0.2234,
+// B = 32 768 1.4745 / 1.4304 (profiles/round6_attn_fold_ab.txt).  The wave-tile kernels run ONE workgroup of 8 - 12 waves per CU (their LDS
+// weight image) with about one tile per wave at B = 8 192: the attention's dependent chain (token words -> K | Q rows -> S -> V columns from
+// global memory, no LDS left to stage them) is added to every wave's single tile at 3 waves per SIMD, where the launch of its own hides it
+// behind 5 - 8 waves per SIMD.  NOTEBOOK round 6.
+bool attn_fold_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws) {
+    return DR4SR_XENV("DR4SR_ATTN_FOLD") && attn_wave_on(p, ws) && wave_tiles(p, ws) && p->D == 64;
+}
 bool tile_xcd_order(const dr4sr_sasrec_plan* p, const Workspace& ws) { return attn_in_tile(p, ws) && !DR4SR_ENV("DR4SR_TILE_ORDER_PLAIN"); }
 
 // Layer-0 fusion: the token tile is gathered straight from the item/position tables (a3: sasrec.py:42-48,:61-66 —
@@ -1301,7 +1311,8 @@ PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int lay
     const bool near_ok = p->expected_tokens > 0 && p->expected_tokens <= 16 * (int64_t)p->B;
     if (A.at.on && !DR4SR_XENV("DR4SR_ATTN_TILE_FULL") && ((near_ok && p->D == 128) || DR4SR_XENV("DR4SR_ATTN_TILE_NEAR"))) A.at.on |= 4;
     if (A.at.on && DR4SR_ENV("DR4SR_ATTN_TILE_ATOMICS")) A.at.on |= 2;       // cross-check: every dK | dV row through atomics (no plain stores)
-    A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L;
+    A.at.qkv = lw.qkv; A.at.dqkv = lw.dqkv; A.at.ctx = lw.ctx; A.at.stat = lw.attn_st; A.at.tok = ws.tok; A.at.L = p->L; A.at.keep = lw.attn_keep;
+    A.wt_attn = attn_fold_fwd(p, ws) ? 1 : 0;
     A.sp = wsplit_of(p, ws, layer);
     if (wfrag_img_on(p, ws)) A.sp = reinterpret_cast<const unsigned short*>(ws.wfrag + (size_t)layer * ws.wT_stride);
     A.nx_dqkv_zero = (A.at.on && A.nx_qkv) ? ws.layer[layer + 1].dqkv : nullptr;

@@ -30,6 +30,7 @@
 // GELU, batch_first), called at model/sasrec.py:65-68.
 #include "common.h"
 #include "kernels.h"
+#include "attn_wave_body.h"
 #include <cstdlib>
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -302,6 +303,95 @@ template <bool EXACT, int D, int F> struct WtFwdLds {
     static constexpr int total = o_vec + 4 * n_vec;
 };
 
+// Round 6 — the layer's attention FORWARD at the head of the tile (PostArgs::wt_attn): the ctx rows of this wave's 16 tokens computed from
+// qkv in global memory (written by the launch in front) instead of being read back from an attention launch of its own.  The arithmetic,
+// the saved statistics / keep bits and the dropout elements are attn_wave.hip's (shared bodies: attn_wave_body.h); the output lands directly
+// in this kernel's register layout — lane (token, g) holds columns 32 J + 8 g .. + 7 of head J as bc[2 J], bc[2 J + 1] — because which V
+// column feeds which C-tile row of P V is a free permutation (awv::mma_cols_wt).  ctx is still STORED (the backward's <dctx, ctx> row term and
+// the out_proj weight gradient read it); what disappears is one launch per layer and ctx's way back in.  LDS is full of weight images
+// (148 of 160 KB), so the V operand comes straight from global memory.  Reference: torch MHA as configured at model/sasrec.py:21-34, called
+// :65-68, masks :48, :58.
+template <int D>
+__device__ __forceinline__ void wt_attn_ctx(const PostArgs& A, f32x4 (&bc)[D / 16], const int tile, const int T, const bool dodrop, const RngKey& rk) {
+    static_assert(D == 64, "two heads of 32 columns");
+    constexpr int DH = 32, H = 2, MT = awv::MT;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    const int it = tile, t0 = 16 * it, tq = t0 + i16;
+    const bool qv = tq < T, has1 = it > 0;
+    const float* __restrict__ qkv = A.at.qkv;
+    const int2 wq_raw = awv::tok_raw(A.at.tok, tq, T), w1_raw = awv::tok_raw(A.at.tok, tq - 16, T);
+    float qf[H][DH / 4], kf0[H][DH / 4], kf1[H][DH / 4];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        awv::frag_rows<DH>(lane, qf[h], qkv, 3 * D, t0, h * DH, T);
+        awv::frag_rows<DH>(lane, kf0[h], qkv, 3 * D, t0, D + h * DH, T);
+        awv::frag_rows<DH>(lane, kf1[h], qkv, 3 * D, has1 ? t0 - 16 : t0, D + h * DH, has1 ? T : 0);
+    }
+    const int2 wq = awv::tok_fix(wq_raw, tq, T);
+    const int w1 = has1 ? awv::tok_fix(w1_raw, tq - 16, T).y : 0;
+    const int s0 = wq.x, nq = (wq.y >> 20) & 0x3ff, bq = wq.y & 0xfffff;
+    const int lo = __builtin_amdgcn_readfirstlane(max(awv::min16(qv ? (s0 >> 4) : it), max(it - (MT - 1), 0)));
+    const int nk = it - lo + 1;
+    const bool need_hi = __ballot(nq > 32) != 0ull;
+    const uint32_t site = DR4SR_SITE_ATTN + 4 * A.layer;
+    const float scale = 0.17677669529663687f;               // 1 / sqrt(32)
+    const float kscale = dodrop ? rk.scale : 1.f;
+    const unsigned pad0 = awv::pad16(wq.y), pad1 = awv::pad16(w1);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const awv::Keep64 keep = awv::keep_row(lane, rk, site, ((uint64_t)(bq * H + h) * 64 + (uint64_t)(tq - s0)) * 64, need_hi, dodrop);
+        if (dodrop && g == 0 && qv) *reinterpret_cast<uint2*>(A.at.keep + ((size_t)tq * H + h) * 2) = make_uint2(keep.lo, keep.hi);
+        f32x4 s[MT];
+        float m = -INFINITY;
+        auto mask_tile = [&](const int k, const unsigned pad) {
+            const int jt = it - k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tk = 16 * jt + 4 * g + r;
+                const bool ok = qv && tk >= s0 && tk <= tq && !((pad >> (4 * g + r)) & 1u);
+                const float v = ok ? s[k][r] * scale : -INFINITY;
+                s[k][r] = v;
+                m = fmaxf(m, v);
+            }
+        };
+        s[0] = awv::mma_rows<DH>(kf0[h], qf[h]);
+        mask_tile(0, pad0);
+        if (nk > 1) { s[1] = awv::mma_rows<DH>(kf1[h], qf[h]); mask_tile(1, pad1); }
+#pragma unroll
+        for (int k = 2; k < MT; ++k) {
+            if (k < nk) {
+                float kf[DH / 4];
+                awv::frag_rows<DH>(lane, kf, qkv, 3 * D, 16 * (it - k), D + h * DH, T);
+                const unsigned pad = awv::pad_bits(lane, A.at.tok, it - k, T);
+                s[k] = awv::mma_rows<DH>(kf, qf[h]);
+                mask_tile(k, pad);
+            }
+        }
+        m = awv::xg_max(m);
+        const float mref = m == -INFINITY ? 0.f : m;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < MT; ++k)
+            if (k < nk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __expf(s[k][r] - mref); s[k][r] = e; sum += e; }
+        sum = awv::xg_sum(sum);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        if (g == 0 && qv) *reinterpret_cast<float2*>(A.at.stat + ((size_t)tq * H + h) * 2) = make_float2(mref, inv);
+        f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            if (k < nk) {
+                const int jt = it - k;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[k][r] *= inv * awv::keep_at(keep, 16 * jt + 4 * g + r - s0, kscale);
+                awv::mma_cols_wt<DH>(lane, o, qkv, 3 * D, 16 * jt, 2 * D + h * DH, s[k], T);       // out^T += V^T P~^T, rows in this kernel's layout
+            }
+        }
+        bc[2 * h] = o[0]; bc[2 * h + 1] = o[1];
+    }
+}
+
 // the forward chain for ONE 16-token tile of a wave; z (out): the LayerNorm2 output rows (this lane's columns), also stored to A.z if set
 template <int D, int F, bool EXACT, typename Lds>
 __device__ __forceinline__ void wt_fwd_tile(const PostArgs& A, const char* lds, const float* vec, f32x4 (&yout)[D / 16], const int tile, const int T,
@@ -316,6 +406,15 @@ __device__ __forceinline__ void wt_fwd_tile(const PostArgs& A, const char* lds, 
         const bool ok = t < T;
         const size_t tl = ok ? t : T - 1;                   // rows past T: a valid row again (a token is one MFMA column: no mixing)
         f32x4 bc[DT];
+#ifdef DR4SR_EXPERIMENTS                                    // (measured slower than the attention launch of its own: linear.hip attn_fold_fwd — not in the shipped kernels)
+        if constexpr (D == 64) {
+            if (A.wt_attn) {                                 // this layer's attention for the tile's 16 queries (no attention launch forward)
+                wt_attn_ctx<D>(A, bc, tile, T, dodrop, rk);
+                if (ok) wt_row_store<D>(A.at.ctx + (size_t)t * D, bc, g);
+                __builtin_amdgcn_sched_barrier(0);
+            } else wt_row_load<D>(bc, A.ctx + tl * D, g);
+        } else
+#endif
         wt_row_load<D>(bc, A.ctx + tl * D, g);
         wt_row_load<D>(y, A.x + tl * D, g);                 // the residual; becomes u1, then y
         // ---- out_proj + dropout1 + residual + LayerNorm1

@@ -246,7 +246,9 @@ extern "C" int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan) {
     carve_workspace(&q, &ws);
     // bit 2: attention inside the tile kernels (attn_tile.h); bit 3: the same window attention as launches of its own instead of the lists
     // bit 4 (round 6): where the lists would run, the wave-per-tile attention instead (attn_wave.hip) — one launch per layer and direction
-    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0) | (ws.attn_tile_sa ? 8 : 0) | (attn_wave_on(&q, ws) ? 16 : 0);
+    // bit 5: ... with its forward folded into the wave-tile forward kernels (no attention launch forward)
+    return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0) | (ws.attn_tile_sa ? 8 : 0) | (attn_wave_on(&q, ws) ? 16 : 0)
+           | (attn_fold_fwd(&q, ws) ? 32 : 0);
 }
 
 static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {
@@ -461,7 +463,7 @@ static int forward_layers(const dr4sr_sasrec_plan* p, const Workspace& ws, int t
     const bool in_tile = attn_in_tile(p, ws);                    // the attention runs at the head of post_fwd / post_mid (attn_tile.h)
     for (int l = 0; l < p->n_layer; ++l) {
         if (!fuse) RC(launch_qkv_fwd(p, ws, l, s));
-        if (!in_tile) RC(attn_fwd(p, ws, l, training, s));
+        if (!in_tile && !attn_fold_fwd(p, ws)) RC(attn_fwd(p, ws, l, training, s));     // (folded: at the head of the wave-tile forward launch, linear_wave.hip wt_attn_ctx)
         if (!(mid_fused && l == p->n_layer - 1)) RC(launch_post_fwd(p, ws, l, training, s));
     }
     return 0;

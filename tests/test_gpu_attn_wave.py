@@ -16,6 +16,7 @@ from oracle import sasrec_oracle as O  # noqa: E402
 from test_gpu_parity import _random_params, _toys_batch, relerr  # noqa: E402
 
 WAVE = 16          # dr4sr_sasrec_at_scale bit 4
+FOLD = 32          # bit 5: the wave attention's forward folded into the wave-tile forward launches (d = 64)
 
 
 def _bits(plan):
@@ -76,6 +77,7 @@ def test_wave_attention_edge_cases_vs_oracle_and_lists(D, L, case, monkeypatch, 
     assert abs(loss - float(loss_o)) < 3e-5
     for k, v in g_w.items():
         assert relerr(v, grads_o[k]) < 5e-4, k
+    assert not _bits(plan) & FOLD
     for switch in ("DR4SR_ATTN_LISTS", "DR4SR_ATTN_NOSPLIT"):
         monkeypatch.setenv(switch, "1")
         assert not _bits(plan) & WAVE
@@ -170,7 +172,8 @@ def test_wave_attention_is_what_a_toys_sized_plan_takes(at_scale, monkeypatch):
     full = torch.full((512,), 50, dtype=torch.int64, device="cuda")
     for D in (64, 128):
         eng = SasrecEngine(500, 50, D, 2, 128, 2, 1e-12, 0.0, 512, "cuda")
-        assert _bits(eng.make_plan(ids, ids, short)) & WAVE
+        bits = _bits(eng.make_plan(ids, ids, short))
+        assert bits & WAVE and not bits & FOLD
     monkeypatch.delenv("DR4SR_FORCE_SCALE")
     eng = SasrecEngine(500, 50, 64, 2, 128, 2, 1e-12, 0.0, 8192, "cuda")
     ids8, short8, full8 = ids.repeat(16, 1), short.repeat(16), full.repeat(16)
@@ -178,3 +181,36 @@ def test_wave_attention_is_what_a_toys_sized_plan_takes(at_scale, monkeypatch):
     assert not _bits(eng.make_plan(ids8, ids8, full8)) & (WAVE | 2)
     monkeypatch.setenv("DR4SR_NO_FUSE", "1")
     assert not _bits(eng.make_plan(ids8, ids8, short8)) & WAVE and _bits(eng.make_plan(ids8, ids8, short8)) & 2
+
+
+@pytest.mark.parametrize("case,p", [("edge", 0.0), ("straddlers", 0.0), ("long_mix", 0.0), ("toys", 0.5)])
+def test_attention_forward_folded_into_the_wave_tile_kernels(case, p, monkeypatch, at_scale):
+    """experiments build only (DR4SR_ATTN_FOLD: measured slower, NOTEBOOK round 6): the wave attention's forward at the head of k_wt_post_fwd /
+    k_wt_post_mid (linear_wave.hip wt_attn_ctx, output directly in the tile kernels' register layout) equals the launch of its own — loss and
+    every gradient, dropout on for the toys batch (same saved keep bits and Philox elements)"""
+    from dr4sr_amd.engine import SasrecEngine
+    monkeypatch.setenv("DR4SR_ATTN_FOLD", "1")            # (skips the test on the shipped build)
+    rng = np.random.default_rng(77)
+    L, D, N = 50, 64, 157
+    if case == "toys":
+        batch, N = _toys_batch(2048, False, seed=31)
+    else:
+        sl, pads = _cases(L)[case]
+        batch = _batch_of(sl, L, rng, N, pads)
+    B = batch["seqlen"].shape[0]
+    eng = SasrecEngine(N, L, D, 2, 128, 2, 1e-12, p, B, "cuda", seed=13)
+    eng.load_named(_random_params(N, D, 128, 2, L=L, seed=9))
+    plan = eng.make_plan(batch["in_item_id"].cuda(), batch["item_id"].cuda(), batch["seqlen"].cuda(),
+                         neg_item=batch["neg_item"].squeeze(-1).contiguous().cuda(), sample_neg=False, expected_tokens=8 * B)
+    assert _bits(plan) & FOLD and _bits(plan) & WAVE
+    eng.fwd_bwd(plan)
+    loss_f, _ = eng.loss_and_count()
+    g_f = {k: v.clone() for k, v in eng.normalized_grads().items()}
+    monkeypatch.delenv("DR4SR_ATTN_FOLD")
+    assert not _bits(plan) & FOLD
+    eng.state[3] -= 1
+    eng.fwd_bwd(plan)
+    loss_l, _ = eng.loss_and_count()
+    assert abs(loss_l - loss_f) < 1e-5
+    for k, v in eng.normalized_grads().items():
+        assert relerr(v, g_f[k].cpu()) < 2e-5, k
