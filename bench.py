@@ -164,8 +164,13 @@ def sasrec_kernel_rooflines(lib, _lib, plan, mw, out, args, B, L, D, F, NL, T_la
     out["kernel_us_per_step"] = {k: round(v, 2) for k, v in step_us.items()}
     # the token-tile kernels against BOTH roofs: at scale they are bound by the saved-activation stream (HBM), not by the matrix pipe
     both = {}
+    wave_attn = bool(lib.dr4sr_sasrec_at_scale(C.byref(plan)) & 16)
     for k, us in ktime.items():
         kb = kernel_bytes(k, T_last, D, F, NL, in_tile)
+        if kb is None and wave_attn and k in ("attn_fwd", "attn_bwd"):
+            # the wave-per-tile launches (csrc/attn_wave.hip), fp32 words per token: forward q | k | v in, ctx + {row max, 1 / row sum} x 2 heads out;
+            # backward q | k | v, dctx, statistics, row terms, keep bits in, dq | dk | dv out
+            kb = 4.0 * T_last * ((3 * D + D + 4) if k == "attn_fwd" else (3 * D + D + 4 + 2 + 4 + 3 * D))
         if kb is None:
             continue
         fk = kernel_flops(k, T_last, B, L, D, F, NL, seqlen_last, big, in_tile)
@@ -740,7 +745,7 @@ def main():
     import torch.distributed as dist
     from dr4sr_amd import parallel
     if dp:
-        parallel.init_distributed(dev)                     # gloo control group + the library's own RCCL communicator (no ProcessGroupNCCL)
+        parallel.init_distributed(dev, allow_fallback=True)      # gloo control group + the library's own RCCL communicator (no ProcessGroupNCCL)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from dr4sr_amd import _lib
@@ -1132,6 +1137,8 @@ def main():
     out, rows_np, N = measure(args.batch, args.steps, args.warmup, "full")
     if dp:
         out["collective_forms"] = {"host": out["ms_per_step"], "in_graph": None}
+        if parallel.FALLBACK_REASON:
+            out["transport_fallback"] = parallel.FALLBACK_REASON
     arm_crash_line(out, "throughput_mode")                   # from here on the line cannot be lost (see arm_crash_line)
     tm = None
     sec_rep = max(1, min(args.repeats, 5))                   # the secondary sizes: fewer repetitions of a longer timed region

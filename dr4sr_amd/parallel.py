@@ -51,6 +51,7 @@ def backend_name() -> str:
 
 _COMM = None            # ctypes handle of the native communicator (dr4sr_comm*), None = staged gloo data plane
 _COMM_DEVICE = None
+FALLBACK_REASON = None  # set when init_distributed(allow_fallback=True) could not create the RCCL communicator on every rank
 
 
 def _native():
@@ -65,11 +66,13 @@ def _check(rc: int, what: str):
         raise _lib.Dr4srError("%s failed: rc %d (%s)" % (what, rc, msg.decode() if msg else "?"))
 
 
-def init_distributed(device=None):
+def init_distributed(device=None, allow_fallback=False):
     """Create the control group (gloo) and, for the rccl data plane, the native communicator — once (no-op for a single process unless
     DR4SR_BENCH_FORCE_DP asks for the 1-rank form).  RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from torch.distributed.run.
-    Collective: every rank of the job must call it."""
-    global _COMM, _COMM_DEVICE
+    Collective: every rank of the job must call it.  A communicator that cannot be created on EVERY rank raises (training must not silently
+    run over a slow transport); allow_fallback=True (bench.py: a flagged line beats no line) drops all ranks to the host-staged gloo data
+    plane instead and records why in FALLBACK_REASON."""
+    global _COMM, _COMM_DEVICE, FALLBACK_REASON
     import torch
     import torch.distributed as dist
     if world_size() <= 1 and not os.environ.get("DR4SR_BENCH_FORCE_DP"):
@@ -96,11 +99,22 @@ def init_distributed(device=None):
         dist.broadcast_object_list(box, src=0)                       # the id travels over the control plane
         ident = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
         torch.cuda.synchronize(device)
-        handle = C.c_void_p()
-        _check(lib.dr4sr_comm_init_rank(ident, dist.get_rank(), dist.get_world_size(), int(idx), C.byref(handle)), "dr4sr_comm_init_rank")
-        _COMM, _COMM_DEVICE = handle, device
-        import atexit
-        atexit.register(shutdown)
+        handle, err = C.c_void_p(), None
+        try:
+            _check(lib.dr4sr_comm_init_rank(ident, dist.get_rank(), dist.get_world_size(), int(idx), C.byref(handle)), "dr4sr_comm_init_rank")
+        except Exception as e:      # noqa: BLE001 — decided below, on every rank alike
+            err = e
+        if all_ok(err is None):
+            _COMM, _COMM_DEVICE = handle, device
+            import atexit
+            atexit.register(shutdown)
+        else:
+            if err is None:
+                lib.dr4sr_comm_destroy(handle)
+            why = "the RCCL communicator could not be created on every rank (this rank: %s)" % (err if err is not None else "ok")
+            if not allow_fallback:
+                raise _lib.Dr4srError(why)
+            FALLBACK_REASON = why + "; host-staged gloo data plane instead (functional, not a performance path)"
     return True
 
 

@@ -68,3 +68,16 @@ def test_bench_line_survives_an_abort_in_the_in_graph_leg():
     cf = j["collective_forms"]
     assert cf["in_graph"] is None and "signal" in cf["in_graph_error"] and cf["host"] == j["ms_per_step"]
     assert "rccl all-reduce launched by the host" in j["config"]["collective"]
+
+
+def test_bench_falls_back_to_the_staged_data_plane_when_rccl_refuses():
+    """two ranks on ONE GPU with the RCCL data plane asked for explicitly: RCCL refuses a second rank on a device, every rank sees the failure
+    over the control plane (parallel.init_distributed(allow_fallback=True): all_ok), all of them drop to the host-staged gloo data plane and
+    rank 0 still prints ONE line — flagged with `transport_fallback`, never silently.  (fit() / run.py do NOT fall back: they raise.)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "2",
+                          "--no-throughput-mode", "--no-strong"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, DR4SR_BENCH_SHARE_GPU="1", DR4SR_DP_BACKEND="rccl"), cwd=ROOT)
+    j = _one_line(out)
+    assert out.returncode == 0, report(out)
+    assert j["n_gpus"] == 2 and "could not be created" in j["transport_fallback"] and "gloo" in j["transport_fallback"]
+    assert j["value"] > 0 and j["collective_forms"]["in_graph"] is None

@@ -17,6 +17,8 @@ STEP_KERNELS = {
     "wgrad_fused":   ("k_wgrad_blk", "k_wgrad_bf64", "k_wgrad_bf"),
     "wgrad":         ("k_wgrad_blk", "k_wgrad_bf64", "k_wgrad_bf"),
     "adam":          ("k_adam", "k_adam", "k_adam"),
+    "attn_fwd":      (None, "k_attn_wave_fwd", "k_attn_wave_fwd"),      # round 6: ONE kernel per direction where the lists (several) would run
+    "attn_bwd":      (None, "k_attn_wave_bwd", "k_attn_wave_bwd"),
     "prep":          ("k_prep", "k_prep", "k_prep"),
 }
 
