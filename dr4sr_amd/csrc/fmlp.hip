@@ -16,6 +16,8 @@ extern __shared__ __attribute__((aligned(16))) float smem[];
 #define FM_D 64
 #define FM_F 256
 #define FM_DMBLK 256                           // workgroups of k_fmlp_filter_bwd (= rows of dm_part per layer)
+#define FM_DET_SPLITS 160                      // deterministic mode: token splits of the weight-gradient launch (launch_fmlp_wgrad's cap)
+#define FM_DET_STRIDE (64 * 64 + 64)           // ... floats per stored 64 x 64 block + its bias row
 #define FS_EMB 0u
 #define FS_FILT(l) (1u + 2u * (l))
 #define FS_FFN(l) (2u + 2u * (l))
@@ -36,6 +38,12 @@ struct FmlpWs {
     float* ln_wg;                             // [n_layer + 1][FM_DMBLK][2][D] per-block partials of the filter LayerNorms' (last slab: the embedding LayerNorm's) d weight | d bias
     float* score_part; float* ln_part;        // [B][2]; [n_layer][ntiles][4][D]
     unsigned short* wsplit;                   // bf16 hi | lo images of linear1 / linear2, both orientations, fragment-major (common.h WSplitGeo): 4 E per layer
+    // deterministic mode (DR4SR_DETERMINISTIC / train.deterministic; round 6): no fp32 atomics anywhere in the step.  The item-table gradient is
+    // owner-computed (linear.hip owner_job) from the scorer's records de_rec [Tn] {target, negative, dpos, dneg} (zero off the last position) and
+    // the ids idx32 [Tn] of the masked LayerNorm-backward rows k_fmlp_embed_bwd leaves in det_g [Tn][D]; the dense_1 / dense_2 weight-gradient blocks and
+    // the Intermediate LayerNorm sums are stored per token split (det_part [layer][8][split][64 x 64 + 64], det_ln [layer][split][4 D]) and
+    // summed in split order by k_wgrad_det_reduce
+    bool det; float* det_part; float* det_ln; int* idx32; int4* de_rec; float* det_g;
     FmlpLayerWs layer[DR4SR_MAX_LAYERS];
     int64_t bytes;
 };
@@ -89,6 +97,15 @@ static void fmlp_carve(const dr4sr_fmlp_plan* p, FmlpWs* ws) {
         w.uf = take(Tn * D); w.stf = take(Tn * 2); w.xf = take(Tn * D);
         w.a = take(Tn * F); w.h = take(Tn * F); w.u2 = take(Tn * D); w.st2 = take(Tn * 2);
         w.df = take(Tn * D); w.da = take(Tn * F); w.dxf = take(Tn * D);
+    }
+    ws->det = DR4SR_ENV("DR4SR_DETERMINISTIC") != nullptr && atoi(DR4SR_ENV("DR4SR_DETERMINISTIC")) != 0;
+    ws->det_part = nullptr; ws->det_ln = nullptr; ws->idx32 = nullptr; ws->de_rec = nullptr; ws->det_g = nullptr;
+    if (ws->det) {
+        ws->det_part = take((int64_t)p->n_layer * 8 * FM_DET_SPLITS * FM_DET_STRIDE);
+        ws->det_ln = take((int64_t)p->n_layer * FM_DET_SPLITS * 4 * D);
+        ws->idx32 = reinterpret_cast<int*>(take(Tn));
+        ws->de_rec = reinterpret_cast<int4*>(take(4 * Tn));
+        ws->det_g = take(Tn * D);
     }
     ws->bytes = o;
 }
@@ -222,6 +239,7 @@ struct FEmbArgs {
     float* e0; float* st0; float* x0;
     const float* dx0; float* dE; float* dP; float* ln_wg;
     int B, L, n_items; float eps; const int* state; uint64_t seed; float p; int training;
+    float* g_out; int* idx32;                  // deterministic mode (idx32 != NULL): the rows go to g_out + their ids, no atomics
 };
 
 __global__ __launch_bounds__(256) void k_fmlp_embed_fwd(const FEmbArgs A) {
@@ -273,7 +291,10 @@ __global__ __launch_bounds__(256) void k_fmlp_embed_bwd(const FEmbArgs A) {
                 ln_bwd_row<1>(g, u, A.st0[2 * t], A.st0[2 * t + 1], gam, dgam, dbet);
                 accP[ps].x += g[0].x; accP[ps].y += g[0].y; accP[ps].z += g[0].z; accP[ps].w += g[0].w;
                 const int64_t id = A.idx[row * A.L + l];
-                if (id > 0 && id < A.n_items) {
+                if (A.idx32) {                           // the owners of linear.hip launch_table_owner64 add the rows in token order
+                    st4(A.g_out + t * FM_D + c, g[0]);
+                    if (l16 == 0) A.idx32[t] = (id > 0 && id < A.n_items) ? (int)id : 0;
+                } else if (id > 0 && id < A.n_items) {
                     float* d = A.dE + id * FM_D + c;
                     unsafeAtomicAdd(d, g[0].x); unsafeAtomicAdd(d + 1, g[0].y); unsafeAtomicAdd(d + 2, g[0].z); unsafeAtomicAdd(d + 3, g[0].w);
                 }
@@ -496,7 +517,7 @@ __global__ __launch_bounds__(256) void k_fmlp_score(const float* __restrict__ Z,
                                                     float* __restrict__ dZ, const int64_t* __restrict__ target,
                                                     const int64_t* __restrict__ rows, int64_t* __restrict__ neg_item, int sample_neg,
                                                     float* __restrict__ part, const int* __restrict__ state, uint64_t seed,
-                                                    int n_items, int B, int L) {
+                                                    int n_items, int B, int L, int4* __restrict__ rec) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const int64_t row = rows ? rows[b] : b;
@@ -514,6 +535,7 @@ __global__ __launch_bounds__(256) void k_fmlp_score(const float* __restrict__ Z,
     ng = ng < 0 ? 0 : (ng >= n_items ? n_items - 1 : ng);
     float* dzb = dZ + (size_t)b * L * FM_D;
     for (int i = lane; i < (L - 1) * FM_D / 4; i += 64) st4(dzb + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (rec && lane < L - 1) rec[(size_t)b * L + lane] = make_int4(0, 0, 0, 0);      // deterministic mode: records instead of atomics (L <= 50)
     const size_t tl = ((size_t)b * L + L - 1) * FM_D;
     float cnt = 0.f, ls = 0.f;
     if (tgt > 0 && tgt < n_items) {
@@ -523,10 +545,15 @@ __global__ __launch_bounds__(256) void k_fmlp_score(const float* __restrict__ Z,
         cnt = 1.f;
         const float dpos = -sigmoid_f(-sp), dneg = sigmoid_f(sn);
         dZ[tl + lane] = dpos * ep + dneg * en;
-        unsafeAtomicAdd(dE + tgt * FM_D + lane, dpos * q);
-        unsafeAtomicAdd(dE + ng * FM_D + lane, dneg * q);
+        if (rec) {
+            if (lane == 0) rec[(size_t)b * L + L - 1] = make_int4((int)tgt, (int)ng, __float_as_int(dpos), __float_as_int(dneg));
+        } else {
+            unsafeAtomicAdd(dE + tgt * FM_D + lane, dpos * q);
+            unsafeAtomicAdd(dE + ng * FM_D + lane, dneg * q);
+        }
     } else {
         dZ[tl + lane] = 0.f;
+        if (rec && lane == 0) rec[(size_t)b * L + L - 1] = make_int4(0, 0, 0, 0);
     }
     if (lane == 0) { part[2 * b] = cnt; part[2 * b + 1] = ls; }
 }
@@ -627,7 +654,10 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     E.lnw = p->params + ws.off[2]; E.idx = p->in_item_id; E.rows = p->rows; E.e0 = ws.e0; E.st0 = ws.st0;
     E.dx0 = ws.dX[0]; E.dE = p->grads + ws.off[0]; E.dP = ws.dm_part + (size_t)nl * FM_DMBLK * L * FM_D; E.ln_wg = ws.ln_wg + (size_t)nl * FM_DMBLK * 2 * FM_D;
     E.B = p->B; E.L = L; E.n_items = p->n_items; E.eps = p->ln_eps; E.state = p->state; E.seed = p->seed; E.p = p->p_drop; E.training = training;
+    if (ws.det) { E.g_out = ws.det_g; E.idx32 = ws.idx32; }
     if (all) hipLaunchKernelGGL(k_fmlp_embed_bwd, dim3(p->B < FM_DMBLK ? p->B : FM_DMBLK), dim3(256), 0, s, E);    // one dP partial per workgroup
+    if (all && ws.det)                                      // dE: scorer records (fused step only) + embedding rows, owner-computed in token order
+        RC(launch_table_owner64(p->state, with_score ? ws.de_rec : nullptr, ws.idx32, ws.X[nl], ws.det_g, p->grads + ws.off[0], p->n_items, s));
     const int64_t lstride = nl > 1 ? ws.off[4 + 9] - ws.off[4] : 0;
     FDmRedArgs R{};
     R.part = ws.dm_part; R.dm = ws.dm; R.dP = p->grads + ws.off[1]; R.ln_wg = ws.ln_wg; R.grads = p->grads;
@@ -637,13 +667,21 @@ static int fmlp_backward(const dr4sr_fmlp_plan* p, const FmlpWs& ws, int trainin
     WgradArgs W{};
     for (int l = 0; l < nl; ++l) {
         const FmlpLayerWs& w = ws.layer[l];
-        WgradJob& J1 = W.job[l * 6 + 4];
-        J1.G = w.da; J1.ldg = FM_F; J1.gcol = 0; J1.X = w.xf; J1.ldx = FM_D;
+        WgradJob J1, J2;
+        J1.G = w.da; J1.ldg = FM_F; J1.gcol = 0; J1.X = w.xf; J1.ldx = FM_D; J1.ldw = 0;
         J1.dW = p->grads + foff(ws, l, FP_W1); J1.db = p->grads + foff(ws, l, FP_B1);
-        WgradJob& J2 = W.job[l * 6 + 5];
-        J2.G = w.df; J2.ldg = FM_D; J2.gcol = 0; J2.X = w.h; J2.ldx = FM_F;
+        J2.G = w.df; J2.ldg = FM_D; J2.gcol = 0; J2.X = w.h; J2.ldx = FM_F; J2.ldw = 0;
         J2.dW = p->grads + foff(ws, l, FP_W2); J2.db = p->grads + foff(ws, l, FP_B2);
+        if (!ws.det) { W.job[l * 6 + 4] = J1; W.job[l * 6 + 5] = J2; continue; }
+        for (int j = 0; j < 8; ++j) {                       // deterministic mode: the eight 64 x 64 blocks as explicit jobs (k_wgrad_det_reduce reads them)
+            WgradJob J = j < 4 ? J1 : J2;
+            if (j < 4) { J.gcol += 64 * j; J.dW += (size_t)64 * j * 64; J.ldw = 64; J.db += 64 * j; }
+            else { const int kb = j - 4; J.X += 64 * kb; J.dW += 64 * kb; J.ldw = 256; if (kb) J.db = nullptr; }
+            W.job[l * 8 + j] = J;
+        }
     }
+    W.jobs_per_layer = ws.det ? 8 : 6;
+    if (ws.det) { W.det = ws.det_part; W.det_stride = FM_DET_STRIDE; W.det_ln = ws.det_ln; }
     W.state = p->state; W.seed = p->seed; W.p = p->p_drop; W.training = training;
     W.ln_part = ws.ln_part; W.ln_layer_stride = (int64_t)ntiles * 4 * FM_D; W.grads = p->grads; W.ln_tile_rows = bm;
     W.o_ln1_w = foff(ws, 0, FP_ILN_W); W.layer_stride = lstride;
@@ -661,7 +699,7 @@ extern "C" int dr4sr_fmlp_fwd_bwd(const dr4sr_fmlp_plan* plan, void* stream) {
     RC(fmlp_forward(plan, ws, 1, 1, s));
     hipLaunchKernelGGL(k_fmlp_score, dim3((plan->B + 3) / 4), dim3(256), 0, s, ws.X[plan->n_layer], plan->params + ws.off[0],
                        plan->grads + ws.off[0], ws.dX[plan->n_layer], plan->item_id, plan->rows, plan->neg_item, plan->sample_neg,
-                       ws.score_part, plan->state, plan->seed, plan->n_items, plan->B, plan->L);
+                       ws.score_part, plan->state, plan->seed, plan->n_items, plan->B, plan->L, ws.det ? ws.de_rec : nullptr);
     return fmlp_backward(plan, ws, 1, 1, s);
 }
 

@@ -218,6 +218,9 @@ int ffn_tile_rows(int Tmax);
 int launch_ffn_fwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_ffn_bwd(const PostArgs& A, int Tmax, hipStream_t s);
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s);
+// deterministic item-table gradient as a launch of its own (FMLP): dE[r] += sum over the tokens, in token order, of rec's scorer terms (coefficient x z
+// row; rec == NULL: none) and of the rows g whose id idx32[t] == r — linear.hip owner_job<64>, no atomics
+int launch_table_owner64(const int* state, const int4* rec, const int* idx32, const float* z, const float* g, float* dE, int n_items, hipStream_t s);
 int launch_adam_flat(float* P, float* G, float* M, float* V, int64_t n, int* state, float lr, float b1, float b2, float eps, float wd, hipStream_t s,
                      float* loss_log = nullptr, const int* log_index = nullptr, const PrepArgs* next = nullptr, int opt = DR4SR_OPT_ADAM);
 

@@ -2052,7 +2052,9 @@ __device__ __forceinline__ float det_sum(const float* __restrict__ p, const int 
     for (; x < n; ++x) s += p[(size_t)x * stride];
     return s;
 }
-__global__ __launch_bounds__(256) void k_wgrad_det_reduce(const WgradArgs A, const DetDims dm, const int gw, const int gemm, const int table) {
+// ln_cols: LayerNorm affine sums per layer in det_ln's [4 D] rows (SASRec: 4 D = ln1 w | b | ln2 w | b; FMLP: 2 D = Intermediate LayerNorm w | b)
+__global__ __launch_bounds__(256) void k_wgrad_det_reduce(const WgradArgs A, const DetDims dm, const int gw, const int gemm, const int table,
+                                                          const int ln_cols) {
     const int layer = A.layer0 + (int)blockIdx.z, j = blockIdx.y, T = A.state[DR4SR_STATE_T];
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (j < A.jobs_per_layer) {
@@ -2066,7 +2068,7 @@ __global__ __launch_bounds__(256) void k_wgrad_det_reduce(const WgradArgs A, con
         if (e < NG * KX) J.dW[(size_t)(e / KX) * (J.ldw ? J.ldw : KX) + e % KX] += s;
         else J.db[e - NG * KX] += s;
     } else if (j == A.jobs_per_layer) {
-        if (!gemm || e >= 4 * A.D) return;
+        if (!gemm || e >= ln_cols) return;
         const float* p = A.det_ln + (size_t)layer * gw * 4 * A.D + e;
         const float s = det_sum(p, gw, (size_t)4 * A.D);
         A.grads[A.o_ln1_w + (size_t)layer * A.layer_stride + e] += s;
@@ -2084,7 +2086,8 @@ __device__ __forceinline__ void reduce_jobs_fmlp(const WgradArgs& A) {
     for (int c = threadIdx.x; c < 2 * D; c += 256) {
         float s = 0.f;
         for (int t = blockIdx.x; t < ntiles; t += gridDim.x) s += part[(size_t)t * 4 * D + c];
-        unsafeAtomicAdd(g + c, s);
+        if (A.det_ln) A.det_ln[((size_t)layer * gridDim.x + blockIdx.x) * 4 * D + c] = s;       // deterministic mode: summed over the blocks in order by k_wgrad_det_reduce
+        else unsafeAtomicAdd(g + c, s);
     }
     if (blockIdx.x == 0 && layer == 0 && A.score_part) {
         __shared__ float red[512];
@@ -2144,10 +2147,28 @@ __global__ __launch_bounds__(256) void k_fmlp_wgrad_bf(const WgradArgs A) {
 __global__ __launch_bounds__(256) void k_fmlp_wgrad_bf64(const WgradArgs A) {
     const int j = blockIdx.y;
     if (j == 8) { reduce_jobs_fmlp(A); if (A.fc_dm) fmlp_coef_bwd_job(A); return; }
+    if (A.det) {                                            // deterministic mode (fmlp.hip fmlp_backward): the eight blocks are explicit jobs, results stored per split
+        wgrad_body_bf<64, 64>(A.job[blockIdx.z * 8 + j], A.state, A.det + ((size_t)(blockIdx.z * 8 + j) * gridDim.x + blockIdx.x) * A.det_stride);
+        return;
+    }
     WgradJob J = A.job[blockIdx.z * 6 + 4 + (j >= 4 ? 1 : 0)];
     if (j < 4) { J.gcol += 64 * j; J.dW += (size_t)64 * j * 64; J.ldw = 64; if (J.db) J.db += 64 * j; }
     else { const int kb = j - 4; J.X += 64 * kb; J.dW += 64 * kb; J.ldw = 256; if (kb) J.db = nullptr; }
     wgrad_body_bf<64, 64>(J, A.state);
+}
+// the owner-computed item-table gradient (owner_job above) as a launch of its own: FMLP's deterministic mode.  rec == NULL: no scorer stream
+__global__ __launch_bounds__(256) void k_table_owner64(const WgradArgs A) { owner_job<64>(A, blockIdx.x); }
+int launch_table_owner64(const int* state, const int4* rec, const int* idx32, const float* z, const float* g, float* dE, int n_items, hipStream_t s) {
+    WgradArgs A{};
+    int logG = 8;
+    auto lds_of = [&](int lg) { return sizeof(float) * 4 * (size_t)((n_items + (1 << lg) - 1) >> lg) * 64 + 4 * 16 * 4 * sizeof(int); };
+    while (lds_of(logG) > 96 * 1024 && logG < 20) ++logG;
+    A.state = state; A.ow_on = 1; A.ow_rec = rec; A.ow_idx32 = idx32; A.ow_z = z; A.sc_g = g; A.sc_dE = dE; A.sc_n_items = n_items;
+    A.ow_logG = logG; A.ow_rpo = (n_items + (1 << logG) - 1) >> logG;
+    const size_t lds = lds_of(logG);
+    big_lds(k_table_owner64, lds);
+    hipLaunchKernelGGL(k_table_owner64, dim3(1 << logG), dim3(256), lds, s, A);
+    return DR4SR_LAUNCH_CHECK();
 }
 int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) {
     const int ntiles = (Tmax + 63) / 64;
@@ -2159,6 +2180,7 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
     if (blocks64 && gwf <= 0) gw_t = ntiles / 8 > 24 ? (ntiles / 8 > 160 ? 160 : ntiles / 8) : 24;
     int gw = ntiles < gw_t ? ntiles : gw_t;
     const size_t lds = sizeof(float) * 64 * (64 + 256);
+    if (A.det && (!blocks64 || gw > 160 || A.jobs_per_layer != 8)) return DR4SR_E_SHAPE;      // partial blocks exist for the 64 x 64 block form only
     if (DR4SR_ENV("DR4SR_WGRAD_F32")) {
         big_lds(k_fmlp_wgrad, lds);
         hipLaunchKernelGGL(k_fmlp_wgrad, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
@@ -2167,6 +2189,11 @@ int launch_fmlp_wgrad(const WgradArgs& A, int Tmax, int n_layer, hipStream_t s) 
         hipLaunchKernelGGL(k_fmlp_wgrad_bf, dim3(gw, 3, n_layer), dim3(256), lds, s, A);
     } else {
         hipLaunchKernelGGL(k_fmlp_wgrad_bf64, dim3(gw, 9, n_layer), dim3(256), sizeof(float) * 2 * 64 * 64, s, A);
+    }
+    if (A.det) {                                            // the stored blocks and LayerNorm sums, added in split order
+        DetDims dm;
+        for (int jj = 0; jj < 8; ++jj) { dm.ng[jj] = 64; dm.kx[jj] = 64; }
+        hipLaunchKernelGGL(k_wgrad_det_reduce, dim3((64 * 64 + 64 + 255) / 256, 8 + 1, n_layer), dim3(256), 0, s, A, dm, gw, 1, 0, 2 * A.D);
     }
     return DR4SR_LAUNCH_CHECK();
 }
@@ -2320,7 +2347,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
             if (dm.ng[jj] * dm.kx[jj] + dm.ng[jj] > maxe) maxe = dm.ng[jj] * dm.kx[jj] + dm.ng[jj];
         }
         hipLaunchKernelGGL(k_wgrad_det_reduce, dim3((maxe + 255) / 256, NJ + 2, gemm ? l_hi - l_lo : 1), dim3(256), 0, s, A, dm, gw, gemm ? 1 : 0,
-                           scatter ? 1 : 0);
+                           scatter ? 1 : 0, 4 * D);
     }
     return DR4SR_LAUNCH_CHECK();
 }

@@ -149,13 +149,13 @@ class BaseModel(nn.Module):
                 BaseModel._det_set_by_model = True
                 logging.getLogger("CDR").info("train.deterministic: on (process-wide switch DR4SR_DETERMINISTIC, read when an engine is built)")
             _lib.set_env("DR4SR_DETERMINISTIC", "1")
-            # bit-identical fits are tested for SASRec, CL4SRec and MetaModel around SASRec (tools/det_fit_check.py); GRU4Rec's and FMLP's steps
-            # keep fp32 atomics (table scatter, weight-gradient splits): measured 1e-7 / 2e-5 between two fits
+            # bit-identical fits are tested for SASRec, CL4SRec, MetaModel around SASRec and (round 6) FMLP (tools/det_fit_check.py); GRU4Rec's
+            # step keeps fp32 atomics (table scatter, weight-gradient splits): measured 1e-7 between two fits
             name = type(self).__name__
             inner = str(config["model"].get("sub_model", "")) if name == "MetaModel" else name
-            if inner not in ("SASRec", "CL4SRec") or (name == "MetaModel" and inner != "SASRec"):
-                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order covers the SASRec step (SASRec, CL4SRec, MetaModel around "
-                                                 f"SASRec: tests/test_gpu_deterministic.py); {name}{'(' + inner + ')' if name == 'MetaModel' else ''}'s "
+            if inner not in ("SASRec", "CL4SRec", "FMLP") or (name == "MetaModel" and inner != "SASRec"):
+                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order covers the SASRec and FMLP steps (SASRec, CL4SRec, FMLP, "
+                                                 f"MetaModel around SASRec: tests/test_gpu_deterministic.py); {name}{'(' + inner + ')' if name == 'MetaModel' else ''}'s "
                                                  "step keeps kernels whose fp32 atomics make runs differ in the last bits")
         self._graphs = {}
 

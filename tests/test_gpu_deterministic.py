@@ -136,7 +136,82 @@ def test_deterministic_two_phase_step_is_bitwise_the_one_launch_step(monkeypatch
     assert torch.equal(g_one, g_two)
 
 
-@pytest.mark.parametrize("name", ["SASRec", "MetaModel", "CL4SRec"])
+def _fmlp_run(B, NL, L, N, steps, dropout=0.5, sample_neg=True):
+    from dr4sr_amd.fmlp_engine import FmlpEngine, fmlp_param_names, fmlp_param_shapes
+    gen = torch.Generator().manual_seed(77 + B)
+    idx = torch.zeros(B, L, dtype=torch.long)
+    for i in range(B):
+        n = int(torch.randint(1, L + 1, (1,), generator=gen))
+        idx[i, L - n:] = torch.randint(1, min(N, 400), (n,), generator=gen)          # few distinct ids: many rows meet in every table row
+    tgt = torch.randint(1, N, (B,), generator=gen)
+    neg = torch.randint(1, N, (B, 1), generator=gen)
+    params = {}
+    for nme, shp in zip(fmlp_param_names(NL), fmlp_param_shapes(N, L, 64, 256, NL)):
+        params[nme] = (1.0 if nme.endswith("LayerNorm.weight") else 0.0) + 0.05 * torch.randn(shp, generator=gen)
+    params["item_embedding.weight"][0] = 0
+    eng = FmlpEngine(N, L, 64, 256, NL, 1e-12, dropout, B, "cuda", seed=11, lr=1e-3)
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(idx.to(dev), tgt.to(dev), neg_item=neg.view(-1).contiguous().to(dev), sample_neg=sample_neg)
+    eng.fwd_bwd(plan)
+    torch.cuda.synchronize()
+    g0 = eng.grads.clone()
+    for _ in range(steps):
+        eng.train_step(plan)
+    torch.cuda.synchronize()
+    return g0, eng.params.clone(), params, {"in_item_id": idx, "item_id": tgt, "neg_item": neg}
+
+
+@pytest.mark.parametrize("B,NL,L,N", [(256, 2, 50, 11925), (33, 3, 20, 150), (1024, 2, 50, 40000), (1, 1, 2, 150)])
+def test_fmlp_deterministic_mode_two_runs_bit_identical(monkeypatch, B, NL, L, N):
+    """round 6: FMLP under DR4SR_DETERMINISTIC — the item-table gradient owner-computed in token order (linear.hip
+    launch_table_owner64 over the scorer's records + the embedding stage's rows), the dense_1 / dense_2 blocks and the Intermediate LayerNorm
+    sums stored per token split and added in split order: the first step's whole flat gradient and the parameters after 40 steps (dropout
+    0.5, in-kernel negatives) are bit-identical between two runs — and differ between two runs of the default mode's atomics only in the
+    last bits (the mode changes the ORDER of the sums, nothing else)"""
+    monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
+    g_a, p_a, _, _ = _fmlp_run(B, NL, L, N, 40)
+    g_b, p_b, _, _ = _fmlp_run(B, NL, L, N, 40)
+    assert torch.equal(g_a, g_b) and torch.equal(p_a, p_b) and bool(torch.isfinite(p_a).all())
+    monkeypatch.delenv("DR4SR_DETERMINISTIC")
+    g_c, p_c, _, _ = _fmlp_run(B, NL, L, N, 40)
+    scale = float(g_c.abs().max())
+    assert float((g_a - g_c).abs().max()) < 2e-5 * scale, (float((g_a - g_c).abs().max()), scale)
+
+
+@pytest.mark.parametrize("B,NL,L", [(29, 2, 50), (100, 1, 8), (256, 2, 50)])
+def test_fmlp_deterministic_mode_gradients_match_oracle(monkeypatch, B, NL, L):
+    """the same gradients as the default mode's: loss and every parameter's gradient against the fp32 oracle (tests/test_gpu_fmlp.py's bar)"""
+    from oracle import fmlp_oracle as FO
+    from test_gpu_fmlp import relerr, REL
+    from dr4sr_amd.fmlp_engine import FmlpEngine
+    monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
+    N = 150
+    _, _, params, batch = _fmlp_run(B, NL, L, N, 0, dropout=0.0, sample_neg=False)
+    eng = FmlpEngine(N, L, 64, 256, NL, 1e-12, 0.0, B, "cuda")
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(batch["in_item_id"].to(dev), batch["item_id"].to(dev), neg_item=batch["neg_item"].view(-1).contiguous().to(dev), sample_neg=False)
+    eng.fwd_bwd(plan)
+    loss_o, _, grads_o = FO.grads_of(params, batch, NL)
+    loss, n = eng.loss_and_count()
+    assert n == B and abs(loss - float(loss_o)) < 3e-5
+    for k, gv in eng.normalized_grads().items():
+        assert relerr(gv, grads_o[k]) < REL, k
+    # the autograd path's backward (encode_bwd: no scorer records, embedding rows only) in the same mode
+    out = eng.encode(plan, False)
+    d_out = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    eng.grads.zero_()
+    eng.encode_bwd(plan, False, d_out)
+    torch.cuda.synchronize()
+    g1 = eng.grads.clone()
+    eng.grads.zero_()
+    eng.encode_bwd(plan, False, d_out)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, eng.grads)
+
+
+@pytest.mark.parametrize("name", ["SASRec", "MetaModel", "CL4SRec", "FMLP"])
 def test_whole_fit_is_bit_identical_under_train_deterministic(name):
     """two complete fit() calls (3 epochs of B = 256 on 1 024 toys-sized rows, dropout 0.5, validation every epoch; MetaModel: warm-up epoch +
     an outer hyper-gradient step every 2 steps; CL4SRec: two drawn views + InfoNCE per step) end with bit-identical parameters (and meta
