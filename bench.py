@@ -1151,7 +1151,7 @@ def main():
                                                           "roofline", "roofline_gather_step", "kernel_us_per_step", "valid_tokens_last_step",
                                                           "roofline_step", "roofline_tile_kernels") if k in tm}
     arm_crash_line(out, "deterministic_mode")
-    if args.model in ("sasrec", "fmlp") and not dp and rank == 0 and not args.no_deterministic_leg:
+    if args.model in ("sasrec", "fmlp", "gru4rec") and not dp and rank == 0 and not args.no_deterministic_leg:
         # what run-to-run determinism costs at this workload (train.deterministic; the reference sets cudnn.deterministic, utils/utils.py:19):
         # the same step with every reduction in a fixed order — at-scale launch forms + ordered partial sums in the weight-gradient launch
         try:

@@ -677,3 +677,17 @@ struct StepFork {
 };
 const StepFork& step_fork();
 #define DR4SR_LAUNCH_CHECK() hip_ret(hipGetLastError())
+// sum of n values `stride` floats apart, added in index order (the order IS the contract); eight loads in flight per thread
+__device__ __forceinline__ float det_sum(const float* __restrict__ p, const int n, const size_t stride) {
+    float s = 0.f;
+    int x = 0;
+    for (; x + 8 <= n; x += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(x + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; x < n; ++x) s += p[(size_t)x * stride];
+    return s;
+}

@@ -42,6 +42,12 @@ struct GruWs {
     float* X0; float* dX0; float* Y; float* dY; float* dH;     // dH: grad w.r.t. a layer's output rows [T,H]
     float* score_part;
     unsigned long long* xch; int* ctl;                        // cooperative recurrence (gru_coop.hip): granule area, control words
+    // deterministic mode (DR4SR_DETERMINISTIC / train.deterministic; round 6): no fp32 atomics in the step.  The separate glue launches run at every
+    // size (their y and d x rows live in global memory); the scorer leaves records de_rec [T] {target, negative, dpos, dneg} instead of its
+    // atomics, k_gru_det_rows masks d x in place and writes the rows' ids idx32 [T], the item-table gradient is owner-computed in token order
+    // (linear.hip launch_table_owner64); the 64 x 64 weight-gradient jobs store one block per token split (det_part [job][split][64 x 64 + 64])
+    // and k_wgrad64_det_reduce adds them in split order
+    bool det; float* det_part; int* idx32; int4* de_rec;
     GruLayerWs layer[GRU_MAX_LAYERS];
     int64_t bytes;
 };
@@ -61,6 +67,10 @@ extern "C" int64_t dr4sr_gru4rec_param_layout(int32_t n_items, int32_t D, int32_
     put(2 + 2 * n_layer, D);
     return o;
 }
+
+#define GRU_DET_SPLITS 32                      // deterministic mode: token splits of the weight-gradient launch (gru_backward's cap)
+#define GRU_DET_STRIDE (64 * 64 + 64)          // ... floats per stored 64 x 64 block + its bias row
+static bool gru_det() { const char* e = DR4SR_ENV("DR4SR_DETERMINISTIC"); return e && atoi(e) != 0; }
 
 static int gru_check(const dr4sr_gru4rec_plan* p) {
     if (!p || p->abi_version != DR4SR_ABI_VERSION) return DR4SR_E_ARG;
@@ -99,6 +109,15 @@ static void gru_carve(const dr4sr_gru4rec_plan* p, GruWs* ws) {
         GruLayerWs& w = ws->layer[l];
         w.gi = take(Tmax * 3 * H); w.r = take(Tmax * H); w.z = take(Tmax * H); w.n = take(Tmax * H); w.ghn = take(Tmax * H);
         w.hprev = take(Tmax * H); w.hout = take(Tmax * H); w.dgi = take(Tmax * 3 * H); w.dgh = take(Tmax * 3 * H);
+    }
+    ws->det = gru_det();
+    ws->det_part = nullptr; ws->idx32 = nullptr; ws->de_rec = nullptr;
+    if (ws->det) {
+        int64_t jobs = (D / 64) * (H / 64);                   // as gru_backward builds them
+        for (int l = 0; l < p->n_layer; ++l) jobs += (3 * H / 64) * ((l == 0 ? D : H) / 64) + (3 * H / 64) * (H / 64);
+        ws->det_part = take(jobs * GRU_DET_SPLITS * GRU_DET_STRIDE);
+        ws->idx32 = reinterpret_cast<int*>(take(Tmax));
+        ws->de_rec = reinterpret_cast<int4*>(take(4 * Tmax));
     }
     ws->bytes = o;
 }
@@ -410,7 +429,8 @@ __global__ __launch_bounds__(256) void k_gru_dx_embed(const GruGlueArgs A) {
 
 // the fused glue applies to what the 16-row latency GEMMs apply to (small batches), D = 64
 static bool gru_glue_fused(const dr4sr_gru4rec_plan* p, int Tmax) {
-    return !DR4SR_ENV("DR4SR_GRU_NOFUSE_GLUE") && !DR4SR_XENV("DR4SR_GRU_GEMM64") && !at_scale(Tmax) && p->D == 64 && (p->H == 128 || p->H == 256);
+    return !DR4SR_ENV("DR4SR_GRU_NOFUSE_GLUE") && !DR4SR_XENV("DR4SR_GRU_GEMM64") && !at_scale(Tmax) && p->D == 64 && (p->H == 128 || p->H == 256)
+        && !gru_det();                                      // deterministic mode: the separate launches (the owners read y and d x from global memory)
 }
 
 static int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K, int N,
@@ -461,6 +481,7 @@ struct Wg64Args {
     // cooperative recurrence's error word — was a launch of its own (k_sum_score_part, 4.7 us of a 0.49 ms step)
     int njobs; const float* score_part; float* tail; int nscore; const int* err_word;
     int score_tiles;                                          // 1: one (count, loss) pair per 16-token tile (k_gru_mid) instead of per sequence
+    float* det;                                               // deterministic mode: [job][split][GRU_DET_STRIDE] stored blocks instead of atomics (NULL: off)
 };
 
 // tail[0..1] += sum of the scorer's per-sequence (count, loss) partials
@@ -493,7 +514,40 @@ __global__ __launch_bounds__(256) void k_wgrad64_bf(const Wg64Args A) {
     WgradJob J;
     J.G = M.G; J.ldg = M.ldg; J.gcol = n0; J.X = M.X + k0; J.ldx = M.ldx;
     J.dW = M.dW + (size_t)n0 * M.KX + k0; J.ldw = M.KX; J.db = (M.db && k0 == 0) ? M.db + n0 : nullptr;
-    wgrad_body_bf<64, 64>(J, A.state);
+    wgrad_body_bf<64, 64>(J, A.state, A.det ? A.det + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GRU_DET_STRIDE : nullptr);
+}
+// deterministic mode: dW / db += the stored blocks of the gw token splits, in split order (thread = one element of one job's block)
+__global__ __launch_bounds__(256) void k_wgrad64_det_reduce(const Wg64Args A, const int gw) {
+    const int job = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= GRU_DET_STRIDE) return;
+    int mi = 0;
+    for (int m = 1; m < A.nmat; ++m) if (job >= A.mat[m].start) mi = m;
+    const Wg64Mat M = A.mat[mi];
+    const int local = job - M.start, nkb = M.KX / 64, n0 = (local / nkb) * 64, k0 = (local % nkb) * 64;
+    if (e >= 64 * 64 && !(M.db && k0 == 0)) return;
+    const int T = A.state[DR4SR_STATE_T], nsplit = min(gw, (T + 63) / 64);
+    const float sum = det_sum(A.det + (size_t)job * gw * GRU_DET_STRIDE + e, nsplit, (size_t)GRU_DET_STRIDE);
+    if (e < 64 * 64) M.dW[(size_t)(n0 + e / 64) * M.KX + k0 + e % 64] += sum;
+    else M.db[n0 + e - 64 * 64] += sum;
+}
+// deterministic mode: g = d x[t] * the embedding dropout mask, in place, + the row's id (0: no gradient row) for the owners
+__global__ __launch_bounds__(256) void k_gru_det_rows(float* __restrict__ dX, int* __restrict__ idx32, const int64_t* __restrict__ idx,
+                                                      const int64_t* __restrict__ rows, const int* __restrict__ cu, int B, int L, int n_items,
+                                                      const int* __restrict__ state, uint64_t seed, float p, int training) {
+    constexpr int D = 64;
+    const int T = state[DR4SR_STATE_T], t = blockIdx.x * 16 + (threadIdx.x >> 4), c = (threadIdx.x & 15) * 4;
+    if (t >= T) return;
+    const int b = find_seq(cu, B, t), pos = t - cu[b];
+    const int64_t row = rows ? rows[b] : b;
+    const int64_t id = idx[row * L + pos];
+    if (training && p > 0.f) {
+        const RngKey rk = make_rng(seed, (uint32_t)state[DR4SR_STATE_RNGSTEP], p);
+        const float4 m = drop4(rk, DR4SR_SITE_EMB, ((uint64_t)b * L + pos) * D + c);
+        float4 g = ld4(dX + (size_t)t * D + c);
+        g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+        st4(dX + (size_t)t * D + c, g);
+    }
+    if ((threadIdx.x & 15) == 0) idx32[t] = (id > 0 && id < n_items) ? (int)id : 0;
 }
 
 __global__ __launch_bounds__(256) void k_wgrad64(const Wg64Args A) {
@@ -856,7 +910,7 @@ static int gru_mid(const dr4sr_gru4rec_plan* p, const GruWs& ws, hipStream_t s) 
 }
 
 // d x = d gi_1 W_ih1 and the embedding-table scatter: one launch in the latency regime (k_gru_dx_embed), else GEMM + scatter
-static int gru_dx_embed(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, hipStream_t s) {
+static int gru_dx_embed(const dr4sr_gru4rec_plan* p, const GruWs& ws, int training, hipStream_t s, int with_score = 0) {
     const int D = p->D, H = p->H;
     if (gru_glue_fused(p, ws.Tmax)) {
         GruGlueArgs A = glue_args(p, ws, training);
@@ -873,6 +927,11 @@ static int gru_dx_embed(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
         return DR4SR_LAUNCH_CHECK();
     }
     RC(launch_gemm(ws.layer[0].dgi, 3 * H, p->params + ws.off_wih[0], D, nullptr, ws.dX0, D, 3 * H, D, true, ws.Tmax, p->state, s));
+    if (ws.det) {                                           // d E: the scorer's records (fused step only) + the masked d x rows, owner-computed in token order
+        hipLaunchKernelGGL(k_gru_det_rows, dim3((ws.Tmax + 15) / 16), dim3(256), 0, s, ws.dX0, ws.idx32, p->in_item_id, p->rows, ws.cu, p->B, p->L,
+                           p->n_items, p->state, p->seed, p->p_drop, training);
+        return launch_table_owner64(p->state, with_score ? ws.de_rec : nullptr, ws.idx32, ws.Y, ws.dX0, p->grads + ws.off_E, p->n_items, s);
+    }
     return launch_embed_bwd_raw(ws.dX0, p->in_item_id, p->rows, ws.cu, p->grads + ws.off_E, nullptr, p->B, p->L, D, p->n_items, p->state,
                                 p->seed, p->p_drop, training, s);
 }
@@ -899,7 +958,7 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
         // d(input of this layer) = dgi W_ih
         if (l > 0) RC(launch_gemm(w.dgi, 3 * H, p->params + ws.off_wih[l], H, nullptr, ws.dH, H, 3 * H, H, true, ws.Tmax, p->state, s));
     }
-    RC(gru_dx_embed(p, ws, training, s));
+    RC(gru_dx_embed(p, ws, training, s, with_score));
     // weight gradients: one 64x64 output tile per job (jobs decoded in-kernel from per-matrix descriptors)
     Wg64Args WA{};
     int nj = 0;
@@ -928,8 +987,13 @@ static int gru_backward(const dr4sr_gru4rec_plan* p, const GruWs& ws, int traini
     // with_score == 0 (autograd path): no scorer partials to add, the extra job only forwards the recurrence's error word
     WA.njobs = nj; WA.score_part = ws.score_part; WA.tail = p->grads + ws.n_params; WA.nscore = with_score ? p->B : 0; WA.err_word = ws.ctl + 2;
     WA.score_tiles = mid_done ? 1 : 0;
+    if (ws.det) {                                           // stored blocks exist for the bf16x3 launch only
+        if (wg_f32 || gw > GRU_DET_SPLITS) return DR4SR_E_SHAPE;
+        WA.det = ws.det_part;
+    }
     if (wg_f32) hipLaunchKernelGGL(k_wgrad64, dim3(gw, nj + 1), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
     else hipLaunchKernelGGL(k_wgrad64_bf, dim3(gw, nj + 1), dim3(256), sizeof(float) * 2 * 64 * 64, s, WA);
+    if (ws.det) hipLaunchKernelGGL(k_wgrad64_det_reduce, dim3((GRU_DET_STRIDE + 255) / 256, nj), dim3(256), 0, s, WA, gw);
     return DR4SR_LAUNCH_CHECK();
 }
 
@@ -950,7 +1014,7 @@ static int gru_fwd_bwd_core(const dr4sr_gru4rec_plan* plan, const GruWs& ws, hip
     }
     RC(launch_score_packed_raw(ws.Y, plan->params + ws.off_E, plan->grads + ws.off_E, ws.dY, plan->item_id, plan->rows, ws.cu,
                                plan->neg_item, plan->sample_neg, ws.score_part, plan->state, plan->seed, plan->n_items, plan->B,
-                               plan->L, plan->D, s));
+                               plan->L, plan->D, s, ws.det ? ws.de_rec : nullptr));
     return gru_backward(plan, ws, 1, 1, s);
 }
 

@@ -293,7 +293,7 @@ int launch_unpack_raw(const float* X, const int* cu, float* out, int B, int L, i
 int launch_pack_raw(const float* dout, const int* cu, float* dX, int B, int L, int D, int last, hipStream_t s);
 int launch_score_packed_raw(const float* Z, const float* E, float* dE, float* dZ, const int64_t* target, const int64_t* rows,
                             const int* cu, int64_t* neg_item, int sample_neg, float* part, const int* state, uint64_t seed,
-                            int n_items, int B, int L, int D, hipStream_t s);
+                            int n_items, int B, int L, int D, hipStream_t s, int4* rec = nullptr);      // rec: records instead of dE atomics (gru.hip, deterministic mode)
 
 int launch_attn2_fwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);   // MFMA, H == 2
 int launch_attn2_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, int training, hipStream_t s);

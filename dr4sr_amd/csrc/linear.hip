@@ -2038,20 +2038,6 @@ __global__ __launch_bounds__(256) void k_wgrad_blk(const WgradArgs A, const QkvE
 // first layer only): the position-table partials.  One thread per gradient element, the token splits / blocks walked in index order:
 // the result is a pure function of the batch.  gw = the k_wgrad launch's grid width, gemm / table: which job kinds that launch carried.
 struct DetDims { short ng[DR4SR_WGRAD_MAX_JOBS], kx[DR4SR_WGRAD_MAX_JOBS]; };
-// sum of n values `stride` floats apart, added in index order (the order IS the contract); eight loads in flight per thread
-__device__ __forceinline__ float det_sum(const float* __restrict__ p, const int n, const size_t stride) {
-    float s = 0.f;
-    int x = 0;
-    for (; x + 8 <= n; x += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(x + u) * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; x < n; ++x) s += p[(size_t)x * stride];
-    return s;
-}
 // ln_cols: LayerNorm affine sums per layer in det_ln's [4 D] rows (SASRec: 4 D = ln1 w | b | ln2 w | b; FMLP: 2 D = Intermediate LayerNorm w | b)
 __global__ __launch_bounds__(256) void k_wgrad_det_reduce(const WgradArgs A, const DetDims dm, const int gw, const int gemm, const int table,
                                                           const int ln_cols) {

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
                                                       const int64_t* __restrict__ target, const int64_t* __restrict__ rows,
                                                       const int* __restrict__ cu, int64_t* __restrict__ neg_item,
                                                       int sample_neg, float* __restrict__ part, const int* __restrict__ state,
-                                                      uint64_t seed, int n_items, int B, int L) {
+                                                      uint64_t seed, int n_items, int B, int L, int4* __restrict__ rec) {
+    // rec != NULL (deterministic mode of the GRU4Rec step): per token a record {target, negative, dpos, dneg} (zero: no loss term) for the owners
+    // of linear.hip launch_table_owner64 instead of the atomics into dE
     constexpr int NV = D / 32;                            // floats per lane (half-wave covers D)
     __shared__ int s_tgt[64], s_neg[64], s_list[64];
     __shared__ unsigned long long s_valid;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
         const int l = i / (D / 4), c = (i % (D / 4)) * 4;
         if (!((valid >> l) & 1ull)) st4(dZ + (size_t)(t0 + l) * D + c, make_float4(0.f, 0.f, 0.f, 0.f));
     }
+    if (rec && (int)threadIdx.x < n && !((valid >> threadIdx.x) & 1ull)) rec[t0 + threadIdx.x] = make_int4(0, 0, 0, 0);
     const int hw = threadIdx.x >> 5, l32 = threadIdx.x & 31;          // 8 half-waves
     float lsum = 0.f, cnt = 0.f;
     const int nvalid = __popcll(valid);
@@ -107,9 +110,12 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 dZ[(size_t)(t0 + l) * D + l32 + 32 * j] = dpos * ep[j] + dneg * en[j];
-                unsafeAtomicAdd(dE + (size_t)tgt * D + l32 + 32 * j, dpos * q[j]);
-                unsafeAtomicAdd(dE + (size_t)ng * D + l32 + 32 * j, dneg * q[j]);
+                if (!rec) {
+                    unsafeAtomicAdd(dE + (size_t)tgt * D + l32 + 32 * j, dpos * q[j]);
+                    unsafeAtomicAdd(dE + (size_t)ng * D + l32 + 32 * j, dneg * q[j]);
+                }
             }
+            if (rec && l32 == 0) rec[t0 + l] = make_int4(tgt, ng, __float_as_int(dpos), __float_as_int(dneg));
         }
     }
     if (l32 == 0) { red[2 * hw] = cnt; red[2 * hw + 1] = lsum; }
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(256) void k_score_packed(const float* __restrict__ 
 
 int launch_score_packed_raw(const float* Z, const float* E, float* dE, float* dZ, const int64_t* target, const int64_t* rows,
                             const int* cu, int64_t* neg_item, int sample_neg, float* part, const int* state, uint64_t seed,
-                            int n_items, int B, int L, int D, hipStream_t s) {
+                            int n_items, int B, int L, int D, hipStream_t s, int4* rec) {
     dim3 grid(B), blk(256);
-    if (D == 64) hipLaunchKernelGGL(k_score_packed<64>, grid, blk, 0, s, Z, E, dE, dZ, target, rows, cu, neg_item, sample_neg, part, state, seed, n_items, B, L);
-    else hipLaunchKernelGGL(k_score_packed<128>, grid, blk, 0, s, Z, E, dE, dZ, target, rows, cu, neg_item, sample_neg, part, state, seed, n_items, B, L);
+    if (D == 64) hipLaunchKernelGGL(k_score_packed<64>, grid, blk, 0, s, Z, E, dE, dZ, target, rows, cu, neg_item, sample_neg, part, state, seed, n_items, B, L, rec);
+    else hipLaunchKernelGGL(k_score_packed<128>, grid, blk, 0, s, Z, E, dE, dZ, target, rows, cu, neg_item, sample_neg, part, state, seed, n_items, B, L, rec);
     return DR4SR_LAUNCH_CHECK();
 }
 int launch_score_packed(const dr4sr_sasrec_plan* p, const Workspace& ws, hipStream_t s) {

@@ -149,14 +149,15 @@ class BaseModel(nn.Module):
                 BaseModel._det_set_by_model = True
                 logging.getLogger("CDR").info("train.deterministic: on (process-wide switch DR4SR_DETERMINISTIC, read when an engine is built)")
             _lib.set_env("DR4SR_DETERMINISTIC", "1")
-            # bit-identical fits are tested for SASRec, CL4SRec, MetaModel around SASRec and (round 6) FMLP (tools/det_fit_check.py); GRU4Rec's
-            # step keeps fp32 atomics (table scatter, weight-gradient splits): measured 1e-7 between two fits
+            # bit-identical fits are tested for SASRec, CL4SRec, MetaModel around SASRec and (round 6) FMLP and GRU4Rec (tools/det_fit_check.py).  A
+            # MetaModel around GRU4Rec / FMLP trains through the dense C-ABI composition (encode -> dense scorer -> encode_bwd), whose scorer backward
+            # keeps fp32 atomics into the item table
             name = type(self).__name__
             inner = str(config["model"].get("sub_model", "")) if name == "MetaModel" else name
-            if inner not in ("SASRec", "CL4SRec", "FMLP") or (name == "MetaModel" and inner != "SASRec"):
-                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order covers the SASRec and FMLP steps (SASRec, CL4SRec, FMLP, "
-                                                 f"MetaModel around SASRec: tests/test_gpu_deterministic.py); {name}{'(' + inner + ')' if name == 'MetaModel' else ''}'s "
-                                                 "step keeps kernels whose fp32 atomics make runs differ in the last bits")
+            if inner not in ("SASRec", "CL4SRec", "FMLP", "GRU4Rec") or (name == "MetaModel" and inner != "SASRec"):
+                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order covers the fused training steps (SASRec, CL4SRec, FMLP, GRU4Rec, "
+                                                 f"MetaModel around SASRec: tests/test_gpu_deterministic.py); {name}{'(' + inner + ')' if name == 'MetaModel' else ''} "
+                                                 "trains through kernels whose fp32 atomics make runs differ in the last bits")
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ setup

@@ -211,7 +211,58 @@ def test_fmlp_deterministic_mode_gradients_match_oracle(monkeypatch, B, NL, L):
     assert torch.equal(g1, eng.grads)
 
 
-@pytest.mark.parametrize("name", ["SASRec", "MetaModel", "CL4SRec", "FMLP"])
+def _gru_run(B, H, NL, N, steps, L=50):
+    from dr4sr_amd.data.synthetic import make_rows
+    from dr4sr_amd.gru_engine import GruEngine, gru_param_names, gru_param_shapes
+    rows = make_rows(n_rows=B, n_items=N, seed=3)
+    b = {k: torch.from_numpy(rows[k]) for k in ("in_item_id", "item_id", "seqlen")}
+    gen = torch.Generator().manual_seed(1)
+    params = {}
+    for nme, shp in zip(gru_param_names(NL), gru_param_shapes(N, 64, H, NL)):
+        params[nme] = 0.08 * torch.randn(shp, generator=gen)
+    params["item_embedding.weight"][0] = 0
+    eng = GruEngine(N, L, 64, H, NL, 0.2, B, "cuda", seed=5)
+    eng.load_named(params)
+    dev = eng.device
+    plan = eng.make_plan(b["in_item_id"].to(dev), b["item_id"].to(dev), b["seqlen"].to(dev))          # in-kernel negatives
+    eng.fwd_bwd(plan)
+    torch.cuda.synchronize()
+    g0 = eng.grads.clone()
+    for _ in range(steps):
+        eng.train_step(plan)
+    torch.cuda.synchronize()
+    return g0, eng.params.clone()
+
+
+@pytest.mark.parametrize("B,H,NL,N", [(256, 256, 2, 12102), (40, 128, 1, 300), (1024, 128, 2, 12102), (17, 256, 3, 300)])
+def test_gru4rec_deterministic_mode_two_runs_bit_identical(monkeypatch, B, H, NL, N):
+    """round 6: GRU4Rec under DR4SR_DETERMINISTIC — the separate glue launches at every size, the scorer's records + the masked
+    d x rows owner-computed into the item table in token order (launch_table_owner64), every 64 x 64 weight-gradient job's block stored per
+    token split and added in split order (k_wgrad64_det_reduce): the first step's flat gradient and the parameters after 30 steps (dropout
+    0.2, in-kernel negatives; one- and two-layer recurrences, the layer wavefront and the per-layer launches) bit-identical between two
+    runs, and equal to the default mode's up to the order of the sums"""
+    monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
+    g_a, p_a = _gru_run(B, H, NL, N, 30)
+    g_b, p_b = _gru_run(B, H, NL, N, 30)
+    assert torch.equal(g_a, g_b) and torch.equal(p_a, p_b) and bool(torch.isfinite(p_a).all())
+    monkeypatch.delenv("DR4SR_DETERMINISTIC")
+    g_c, _ = _gru_run(B, H, NL, N, 0)
+    scale = float(g_c.abs().max())
+    assert float((g_a - g_c).abs().max()) < 2e-5 * scale, (float((g_a - g_c).abs().max()), scale)
+
+
+@pytest.mark.parametrize("case", ["odd-40", "h128-3-layers", "h256-1-layer", "full-size-dropout"])
+def test_gru4rec_deterministic_mode_gradients_match_oracle(monkeypatch, case):
+    """the oracle parity cases of tests/test_gpu_gru.py with the mode on: loss and every gradient within the same bar"""
+    import test_gpu_gru as G
+    monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
+    if case == "full-size-dropout":
+        G.test_gru4rec_full_size_vs_oracle(False)
+    else:
+        G._gru_case(*{"odd-40": (40, 256, 2, 50), "h128-3-layers": (29, 128, 3, 7), "h256-1-layer": (29, 256, 1, 50)}[case])
+
+
+@pytest.mark.parametrize("name", ["SASRec", "MetaModel", "CL4SRec", "FMLP", "GRU4Rec"])
 def test_whole_fit_is_bit_identical_under_train_deterministic(name):
     """two complete fit() calls (3 epochs of B = 256 on 1 024 toys-sized rows, dropout 0.5, validation every epoch; MetaModel: warm-up epoch +
     an outer hyper-gradient step every 2 steps; CL4SRec: two drawn views + InfoNCE per step) end with bit-identical parameters (and meta
