@@ -338,7 +338,9 @@ __device__ __forceinline__ Keep fwd(const PostArgs& P, const int t0, const int T
 // the two waves of a head, so that the atomics are in flight during the dQ phase: 0.1090 against 0.1066; the dK | dV rows through a
 // per-wave LDS exchange tile so that an atomic instruction covers ONE row's 64 columns instead of 4-byte pieces of 16 rows: 0.1091 /
 // 0.1080 — the isolated launch liked both (19.2 against 20.1 us), the step did not.
-template <int D>
+// DET (deterministic latency form, kernels.h Workspace::det_lat): the rows another tile adds to as well go to this query tile's partial blocks
+// instead (linear.hip det_kv_rows sums them in query-tile order) — a separate instantiation, the default kernels are unchanged.
+template <int D, bool DET = false>
 __device__ __forceinline__ void bwd(const PostArgs& P, const int t0, const int T, const float* Cs, const int ldc, float* base, const Keep keep) {
     constexpr int DH = D / 2, LD = D + 4;
     const TileAttnArgs& A = P.at;
@@ -426,7 +428,7 @@ __device__ __forceinline__ void bwd(const PostArgs& P, const int t0, const int T
             ds[r] = p * (dp[r] * mk - rdr[r]) * scale;
         }
         const bool live = tk >= wmin && tk < hi;               // a row of one of the tile's sequences
-        const bool own = !(A.on & 2) && tk >= t0 && kw.x + ((kw.y >> 20) & 0x7f) <= t0 + 16;     // ... that no other tile adds to
+        const bool own = (DET || !(A.on & 2)) && tk >= t0 && kw.x + ((kw.y >> 20) & 0x7f) <= t0 + 16;     // ... that no other tile adds to
         // dK^T[f][j] = sum_i Q[i][f] dS[i][j] ;  dV^T[d][j] = sum_i dctx[i][d] P~[i][j]
 #pragma unroll
         for (int fb = 0; fb < DH / 16; ++fb) {
@@ -441,6 +443,10 @@ __device__ __forceinline__ void bwd(const PostArgs& P, const int t0, const int T
                 if (own) {
                     st4(dst, make_float4(dk[0], dk[1], dk[2], dk[3]));
                     st4(dst + D, make_float4(dv[0], dv[1], dv[2], dv[3]));
+                } else if constexpr (DET) {                    // this query tile's block for key tile jt
+                    float* pb = A.kv_part + (((size_t)(t0 >> 4) * MT + jt) * 16 + i16) * 2 * D + h * DH + fb * 16 + 4 * g;
+                    st4(pb, make_float4(dk[0], dk[1], dk[2], dk[3]));
+                    st4(pb + D, make_float4(dv[0], dv[1], dv[2], dv[3]));
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(dst + e, dk[e]); unsafeAtomicAdd(dst + D + e, dv[e]); }

@@ -49,6 +49,12 @@ struct Workspace {
     int4* de_ent;                              // [3 Tmax] table-gradient entries of each token tile sorted by owner (linear.hip tile_sort)
     unsigned char* de_off;                     // [Tmax / 32 + 1][1028] start offsets of the owners' buckets inside each tile's entries
     bool det;                                  // deterministic summation order (DR4SR_DETERMINISTIC): the at-scale forms whatever the size + ordered partial sums in k_wgrad
+    // round 6: `scale` picks the token-tile / attention forms, `scale_wg` the table-gradient and weight-gradient forms (owner / scatter jobs and bf16x3
+    // blocks inside k_wgrad).  They differ in ONE case — det_lat, the deterministic mode of a plan in the latency regime: the six latency launches
+    // keep their 16-token tiles with the attention inside (scale = false), the attention's shared dK | dV rows go through partial blocks (det_kv
+    // [layer][tile][5][16][2 D], TileAttnArgs::kv_part), the embedding stage runs as a launch of its own in front of k_wgrad, and k_wgrad takes its
+    // at-scale, ordered forms (scale_wg = true)
+    bool scale_wg, det_lat; float* det_kv; int64_t det_kv_layer;
     float* det_part; float* det_ln; float* det_dp; int64_t det_stride;     // ... their partial buffers (NULL: mode off)
     float* wfrag;                              // d = 128, latency forms: fragment-major fp32 image of every layer's weights, E floats per layer (common.h wfrag_load_img)
     unsigned short* wsplit;                    // d = 128 at scale: bf16 hi | lo images of every layer's weights, both orientations (common.h WSplit; k_wsplit)
@@ -107,6 +113,10 @@ struct TileAttnArgs {
     const float* qkv; float* dqkv; float* ctx; float* stat; const int2* tok; int L;
     unsigned* keep;                            // [T][H][2] dropout keep bits saved by the wave-per-tile forward (attn_wave.hip / wt_attn_ctx) for its backward
     int on;                                    // bit 0: on; bit 1 (DR4SR_ATTN_TILE_ATOMICS): no plain stores for tile-private dK | dV rows; bit 2: near rows first (short-sequence plans)
+    // deterministic latency form (Workspace::det_lat): the dK | dV rows a query tile adds to OTHER tiles' tokens (and to shared rows of its own) are
+    // stored as this layer's partial blocks [query tile][key tile of the window: 5][16 rows][2 D] instead of added with atomics; the launch that
+    // consumes the layer's dqkv sums them in query-tile order (linear.hip det_kv_rows).  NULL: atomics
+    float* kv_part;
 };
 struct alignas(16) PostArgs {                   // (16: the argument block behind it in a kernel's kernarg segment keeps its alignment — s_load grouping)
     // forward inputs / saved activations
@@ -125,6 +135,7 @@ struct alignas(16) PostArgs {                   // (16: the argument block behin
     // layer-boundary fusions (NULL = not fused)
     const float* nx_in_w; const float* nx_in_b; float* nx_qkv;     // fwd: also emit qkv of layer+1 = z W_in^T + b
     const float* up_dqkv; const float* up_in_w; const float* up_du1;   // bwd: dz = up_dqkv W_in(layer+1) + up_du1 instead of reading A.dz
+    const float* up_kv_part;                   // deterministic latency form: layer + 1's dK | dV partial blocks (TileAttnArgs::kv_part), summed into up_dqkv's tile first
     TileAttnArgs at;                           // at.on: the attention of this layer runs inside the tile kernels (no attention launches)
     int xcd;                                   // 1: XCD-aware block -> tile order (xcd_tile below); the grid is a multiple of 8
     float* nx_dqkv_zero;                       // ... and the launch that emits layer+1's qkv zeroes the K | V rows of its dqkv (atomics target)
@@ -150,6 +161,7 @@ struct QkvEmbBwdArgs {
     const float* dQKV; const float* W; const float* dU1; const int64_t* idx; const int64_t* rows; const int* cu; const int* tile_seq;
     float* dE; float* dP; const int* state; int B, L, n_items, training; uint64_t seed; float p;
     float* gout;                 // large batches: masked dx0 rows are stored here and scattered by a job of k_wgrad (overlaps its MFMA work)
+    const float* kv_part; const int2* tok;     // deterministic latency form: layer 0's dK | dV partial blocks + the tokens' words (NULL: dQKV is complete)
     const unsigned short* sp;    // layer 0's split-weight block (bf16x3 tile GEMMs), NULL: fp32
 };
 

@@ -115,7 +115,7 @@ int tile_rows(const Workspace& ws) {
 // when it sits at the end of k_qkv_embed_bwd) runs as an extra job of k_wgrad, where it overlaps the MFMA-bound weight-gradient jobs
 static bool scatter_in_wgrad(const Workspace& ws) {
     const bool off = DR4SR_ENV("DR4SR_SCATTER_INLINE") != nullptr || DR4SR_ENV("DR4SR_NO_FUSE") != nullptr;
-    return !off && ws.scale;
+    return !off && ws.scale_wg;
 }
 // large batches: the item-table gradient is NOT accumulated with fp32 atomics (scorer: 2 rows per token, embedding stage: 1) but
 // summed row by row by owner workgroups inside k_wgrad (owner_job): deterministic, and ~55 us of a toys-shaped B = 8192 step
@@ -204,6 +204,39 @@ __device__ __forceinline__ void zero_kv_rows(float* dqkv, const int t0, const in
     for (int i = threadIdx.x; i < BM * C4; i += 256) {
         const int r = i / C4, c = (i % C4) * 4;
         if (t0 + r < T) st4(dqkv + (size_t)(t0 + r) * 3 * D + D + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+// Deterministic latency form (kernels.h Workspace::det_lat): the dK | dV rows of token tile t0 / 16 of a layer, completed by the launch that
+// consumes the layer's dqkv.  attn_tile.h's backward stored, per query tile q, the rows it contributes to the five key tiles of its window as
+// partial blocks part[q][jt][16][2 D] (key tile q - 4 + jt), except the rows no other tile adds to, which it stored in dqkv itself.  Row tk of
+// tile c = (that stored row, if tile-private) + the blocks of q = c .. c + 4 at jt = 4 - (q - c) whose window reaches back to tk (tk >= first
+// token of the sequence of token 16 q), added in q order.  The sums replace the K | V columns of the staged tile Aq [16][ldq] and of dqkv (the
+// weight-gradient launch reads them).  Every thread of the workgroup; the tile's rows are in LDS and a barrier has passed; ends with no barrier.
+template <int D>
+__device__ __forceinline__ void det_kv_rows(float* Aq, const int ldq, float* dqkv, const float* __restrict__ part, const int2* __restrict__ tok,
+                                            const int t0, const int T) {
+    constexpr int C4 = 2 * D / 4, PER = (16 * C4) / 256;
+    const int tile = t0 >> 4;
+    int first[5];                                         // first token of the sequence of token 16 (tile + q): the reach of query tile tile + q
+#pragma unroll
+    for (int q = 0; q < 5; ++q) first[q] = t0 + 16 * q < T ? tok[t0 + 16 * q].x : 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = threadIdx.x + 256 * u, r = i / C4, c = (i % C4) * 4, tk = t0 + r;
+        if (tk >= T) continue;
+        const int2 kw = tok[tk];
+        const bool own = kw.x + ((kw.y >> 20) & 0x7f) <= t0 + 16;      // the sequence ends inside this tile (tk >= t0): attn_tile.h's plain store
+        float4 v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tk >= first[q] && !(q == 0 && own)) v[q] = ld4(part + (((size_t)(tile + q) * 5 + (4 - q)) * 16 + r) * 2 * D + c);
+        }
+        float4 a = own ? ld4(Aq + r * ldq + D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+        st4(Aq + r * ldq + D + c, a);
+        st4(dqkv + (size_t)tk * 3 * D + D + c, a);
     }
 }
 // Fragment-major fp32 images (common.h wfrag_load_img) of every layer's four weight matrices, written by the FIRST launch of a forward pass for
@@ -603,7 +636,9 @@ __device__ __forceinline__ void ln_bwd_rowpass(const float* __restrict__ Gg, con
     }
 }
 
-template <int BM, int D, int F, bool FFN_ONLY>
+// DET: the deterministic latency form (kernels.h Workspace::det_lat) — a separate instantiation: as a run-time branch it cost the default step
+// 0.8 % (d = 64) / 2 % (d = 128) at B = 256
+template <int BM, int D, int F, bool FFN_ONLY, bool DET = false>
 __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, const int T, const int tile,
                                               const float4 (*dzreg)[D / 64] = nullptr, const tattn::Keep* att_staged = nullptr) {
     constexpr int LD = D + 4, LF = F + 4, NV = D / 64, NVF = F / 64, PASSES = BM / 16;
@@ -685,6 +720,10 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
         } else load_tile_bm<BM, 3 * D>(Aq, LQ, A.up_dqkv, 3 * D, t0, T);
         att_commit();                              // behind this phase's own loads: one round trip for both
         lds_barrier();
+        if constexpr (AT && DET) {                 // layer + 1's shared dK | dV rows arrive as partial blocks
+            det_kv_rows<D>(Aq, LQ, const_cast<float*>(A.up_dqkv), A.up_kv_part, A.at.tok, t0, T);
+            lds_barrier();
+        }
         TileAcc<BM, D> acc;
         tile_zero(acc);
         if constexpr (PF64) { wfrag_load(fr_w2, A.w2, F); tile_mma_frag<BM, 3 * D, D>(Aq, LQ, fr_up, acc); }
@@ -783,17 +822,17 @@ __device__ __forceinline__ void post_bwd_body(const PostArgs& A, const int t0, c
             lds_barrier();
             if (at_stage) tattn::far_rows_if_needed<D>(A.at, tattn::Lds<D>(smem + att_lds_off(D, F)), t0, T);
             STAMP(18);
-            tattn::bwd<D>(A, t0, T, R0, LD, smem + att_lds_off(D, F), keep);
+            tattn::bwd<D, DET>(A, t0, T, R0, LD, smem + att_lds_off(D, F), keep);
         }
     }
     STAMP(26);
 }
 
-template <int BM, int D, int F, bool FFN_ONLY>
+template <int BM, int D, int F, bool FFN_ONLY, bool DET = false>
 __global__ __launch_bounds__(256) void k_post_bwd(const PostArgs A) {
     const int T = A.state[DR4SR_STATE_T], bx = xcd_tile(T, BM, A.xcd), t0 = bx * BM;
     if (t0 >= T) return;
-    post_bwd_body<BM, D, F, FFN_ONLY>(A, t0, T, bx);
+    post_bwd_body<BM, D, F, FFN_ONLY, DET>(A, t0, T, bx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1239,7 +1278,7 @@ __device__ __forceinline__ void score_tile_regs(const PostArgs& A, const ScoreTi
     }
 }
 
-template <int BM, int D, int F, bool META>
+template <int BM, int D, int F, bool META, bool DET = false>
 __device__ __forceinline__ void post_mid_body(const PostArgs& A, const ScoreTileArgs& S) {
     const int T = A.state[DR4SR_STATE_T], bx = xcd_tile(T, BM, A.xcd), t0 = bx * BM;
     if (t0 >= T) return;
@@ -1256,7 +1295,7 @@ __device__ __forceinline__ void post_mid_body(const PostArgs& A, const ScoreTile
         if constexpr (META) lds_barrier();                   // every wave is past the forward half's last LDS reads: the tiles are free
         score_tile_regs<BM, META>(A, S, t0, T, bx, P, zreg, dzreg, smem + post_lds_floats(D, F, BM), smem);
         if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, bx, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
-        post_bwd_body<BM, D, F, false>(A, t0, T, bx, dzreg, &keep);
+        post_bwd_body<BM, D, F, false, DET>(A, t0, T, bx, dzreg, &keep);
     } else {
         tattn::Keep keep{0xffffffffu, 0xffffffffu};
         post_fwd_body<BM, D, F, false, true>(A, t0, T, nullptr, &keep);
@@ -1264,11 +1303,11 @@ __device__ __forceinline__ void post_mid_body(const PostArgs& A, const ScoreTile
         score_tile<BM, D, META>(A, S, t0, T, bx, smem + post_lds_floats(D, F, BM) + 8);
         if constexpr (BM != 16) { if (S.ent) tile_sort<BM>(S, bx, t0, T, smem + post_lds_floats(D, F, BM) + 8); }
         __syncthreads();                               // dz rows written, LDS scratch free again
-        post_bwd_body<BM, D, F, false>(A, t0, T, bx, nullptr, &keep);
+        post_bwd_body<BM, D, F, false, DET>(A, t0, T, bx, nullptr, &keep);
     }
 }
-template <int BM, int D, int F, bool META>
-__global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) { post_mid_body<BM, D, F, META>(A, S); }
+template <int BM, int D, int F, bool META, bool DET = false>
+__global__ __launch_bounds__(256) void k_post_mid(const PostArgs A, const ScoreTileArgs S) { post_mid_body<BM, D, F, META, DET>(A, S); }
 // The 32-row (at-scale) form with its registers capped at 128: the fused kernel carries the query / dz rows and the scorer's prefetch
 // across its two halves (160 VGPRs: 3 waves per SIMD, where k_post_fwd / k_post_bwd run 4); capped it allocates 119 without a
 // vector spill and the fourth workgroup per CU (LDS: 4 x 36 KB) is worth 3 % (toys) to 6 % (dense) of the launch at B = 8192.
@@ -1315,6 +1354,8 @@ PostArgs make_post_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int lay
     A.wt_attn = attn_fold_fwd(p, ws) ? 1 : 0;
     A.sp = wsplit_of(p, ws, layer);
     if (wfrag_img_on(p, ws)) A.sp = reinterpret_cast<const unsigned short*>(ws.wfrag + (size_t)layer * ws.wT_stride);
+    A.at.kv_part = (A.at.on && ws.det_lat && ws.det_kv) ? ws.det_kv + (size_t)layer * ws.det_kv_layer : nullptr;
+    A.up_kv_part = (A.at.kv_part && A.up_dqkv) ? ws.det_kv + (size_t)(layer + 1) * ws.det_kv_layer : nullptr;
     A.nx_dqkv_zero = (A.at.on && A.nx_qkv) ? ws.layer[layer + 1].dqkv : nullptr;
     A.dn_dqkv_zero = (A.at.on && layer > 0) ? ws.layer[layer - 1].dqkv : nullptr;
     return A;
@@ -1327,7 +1368,9 @@ static int post_launch_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const
     dim3 grid((ws.Tmax + BM - 1) / BM), blk(256);
     if (A.xcd) grid.x = xcd_grid((int)grid.x, BM);
     const size_t lds = (BM == 16 && A.at.on) ? sizeof(float) * att_lds_off(p->D, p->F) + att_lds_bytes(p->D) : post_lds(p->D, p->F, BM);
-#define PL(D_, F_) do { if (bwd) { big_lds(k_post_bwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_bwd<BM, D_, F_, false>), grid, blk, lds, s, A); } \
+#define PL(D_, F_) do { if (bwd && BM == 16 && A.at.kv_part) { big_lds((k_post_bwd<BM == 16 ? 16 : 64, D_, F_, false, BM == 16>), lds); \
+                                                              hipLaunchKernelGGL((k_post_bwd<BM == 16 ? 16 : 64, D_, F_, false, BM == 16>), grid, blk, lds, s, A); } \
+                        else if (bwd) { big_lds(k_post_bwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_bwd<BM, D_, F_, false>), grid, blk, lds, s, A); } \
                         else { big_lds(k_post_fwd<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_fwd<BM, D_, F_, false>), grid, blk, lds, s, A); } } while (0)
     if (p->D == 64 && p->F == 128) PL(64, 128);
     else if (p->D == 128 && p->F == 128) PL(128, 128);
@@ -1342,11 +1385,15 @@ static int post_mid_bm(const dr4sr_sasrec_plan* p, const Workspace& ws, const Po
     if (A.xcd) grid.x = xcd_grid((int)grid.x, BM);
     const size_t lds = (BM == 16 && A.at.on) ? sizeof(float) * att_lds_off(p->D, p->F) + att_lds_bytes(p->D)
                        : post_lds(p->D, p->F, BM) + 8 * sizeof(float) + (S.ent ? tile_sort_lds_bytes(BM, 1 << S.logG) : 0);   // + the scorer's (count, loss) reduction scratch + tile_sort's records
-#define PM(D_, F_) do { if constexpr (BM == 32 && D_ == 64) { big_lds(k_post_mid32<D_, F_>, lds); hipLaunchKernelGGL((k_post_mid32<D_, F_>), grid, blk, lds, s, A, S); } \
+#define PM(D_, F_) do { if (BM == 16 && A.at.kv_part) { big_lds((k_post_mid<BM == 16 ? 16 : 64, D_, F_, false, BM == 16>), lds); \
+                                                       hipLaunchKernelGGL((k_post_mid<BM == 16 ? 16 : 64, D_, F_, false, BM == 16>), grid, blk, lds, s, A, S); } \
+                        else if constexpr (BM == 32 && D_ == 64) { big_lds(k_post_mid32<D_, F_>, lds); hipLaunchKernelGGL((k_post_mid32<D_, F_>), grid, blk, lds, s, A, S); } \
                         else { big_lds(k_post_mid<BM, D_, F_, false>, lds); hipLaunchKernelGGL((k_post_mid<BM, D_, F_, false>), grid, blk, lds, s, A, S); } } while (0)
     if (S.phi) {                                       // MetaModel weighting: D = 64 only (checked by the entry point)
         if (p->D != 64 || p->F != 128) return DR4SR_E_SHAPE;
-        big_lds(k_post_mid<BM, 64, 128, true>, lds); hipLaunchKernelGGL((k_post_mid<BM, 64, 128, true>), grid, blk, lds, s, A, S);
+        if (BM == 16 && A.at.kv_part) { big_lds((k_post_mid<BM == 16 ? 16 : 64, 64, 128, true, BM == 16>), lds);
+                                        hipLaunchKernelGGL((k_post_mid<BM == 16 ? 16 : 64, 64, 128, true, BM == 16>), grid, blk, lds, s, A, S); }
+        else { big_lds(k_post_mid<BM, 64, 128, true>, lds); hipLaunchKernelGGL((k_post_mid<BM, 64, 128, true>), grid, blk, lds, s, A, S); }
         return DR4SR_LAUNCH_CHECK();
     }
     if (p->D == 64 && p->F == 128) PM(64, 128);
@@ -1466,7 +1513,7 @@ int launch_qkv_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int layer, h
 // Layer-0 fusion of the backward tail: dx0 = dqkv W_in + du1 stays in LDS and is scattered straight into the tables
 // (a3 backward: g = dx0 * mask_emb; dE[idx] += g except padding_idx 0; dP[pos] += g), 16 lanes per token; dP is first
 // accumulated in LDS and flushed with one atomic per touched element per workgroup.
-template <int BM, int D>
+template <int BM, int D, bool DET = false>
 __device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const int t0, const int T) {
     constexpr int K = 3 * D, LDA = K + 4, LDC = D + 4, LPT = D / 4, TPB = 256 / LPT;
     float* As = smem;
@@ -1480,6 +1527,10 @@ __device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const
     for (int i = threadIdx.x; i < A.L * D; i += 256) accP[i] = 0.f;
     load_tile_bm<BM, K>(As, LDA, A.dQKV, K, t0, T);
     lds_barrier();
+    if constexpr (BM == 16 && DET) {                        // deterministic latency form: layer 0's shared dK | dV rows arrive as partial blocks
+        det_kv_rows<D>(As, LDA, const_cast<float*>(A.dQKV), A.kv_part, A.tok, t0, T);
+        lds_barrier();
+    }
     TileAcc<BM, D> acc;
     tile_zero(acc);
     if constexpr (PFQ) tile_mma_frag<BM, K, D>(As, LDA, f_in, acc);
@@ -1542,11 +1593,11 @@ __device__ __forceinline__ void qkv_embed_bwd_body(const QkvEmbBwdArgs& A, const
         if (v != 0.f) unsafeAtomicAdd(A.dP + i, v);
     }
 }
-template <int BM, int D>
+template <int BM, int D, bool DET = false>
 __global__ __launch_bounds__(256) void k_qkv_embed_bwd(const QkvEmbBwdArgs A) {
     const int T = A.state[DR4SR_STATE_T], t0 = blockIdx.x * BM;
     if (t0 >= T) return;
-    qkv_embed_bwd_body<BM, D>(A, t0, T);
+    qkv_embed_bwd_body<BM, D, DET>(A, t0, T);
 }
 
 static QkvEmbBwdArgs make_qeb_args(const dr4sr_sasrec_plan* p, const Workspace& ws, int training) {
@@ -1556,6 +1607,7 @@ static QkvEmbBwdArgs make_qeb_args(const dr4sr_sasrec_plan* p, const Workspace& 
     A.dE = p->grads + ws.off[0]; A.dP = p->grads + ws.off[1]; A.state = p->state; A.B = p->B; A.L = p->L; A.n_items = p->n_items;
     A.training = training; A.seed = p->seed; A.p = p->p_drop;
     A.gout = scatter_in_wgrad(ws) ? ws.dX[0] : nullptr;
+    A.kv_part = (ws.det_lat && ws.det_kv && attn_in_tile(p, ws)) ? ws.det_kv : nullptr; A.tok = ws.tok;
     A.sp = wsplit_of(p, ws, 0);
     return A;
 }
@@ -1563,7 +1615,7 @@ static QkvEmbBwdArgs make_qeb_args(const dr4sr_sasrec_plan* p, const Workspace& 
 // run as the first plane of the k_wgrad launch: one launch boundary less per step and the two overlap
 bool qeb_in_wgrad(const Workspace& ws) {
     const bool off = DR4SR_ENV("DR4SR_QEB_SEPARATE") != nullptr || DR4SR_ENV("DR4SR_NO_FUSE") != nullptr;
-    return !off && tile_rows(ws) == 16;
+    return !off && tile_rows(ws) == 16 && !ws.det_lat;       // (deterministic latency form: the embedding tiles complete layer 0's dqkv rows BEFORE k_wgrad reads them)
 }
 
 int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, hipStream_t s) {
@@ -1572,7 +1624,9 @@ int launch_qkv_embed_bwd(const dr4sr_sasrec_plan* p, const Workspace& ws, int tr
     dim3 grid((ws.Tmax + bm - 1) / bm), blk(256);
     const QkvEmbBwdArgs A = make_qeb_args(p, ws, training);
     if (wave_tiles(p, ws) && wt_bwd_on() && A.gout) return launch_wt_qkv_embed_bwd(A, ws.Tmax, s);
-#define QE(B_) do { if (D == 64) { big_lds(k_qkv_embed_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 64>), grid, blk, lds, s, A); } \
+#define QE(B_) do { if (B_ == 16 && A.kv_part) { if (D == 64) { big_lds((k_qkv_embed_bwd<16, 64, true>), lds); hipLaunchKernelGGL((k_qkv_embed_bwd<16, 64, true>), grid, blk, lds, s, A); } \
+                                                 else { big_lds((k_qkv_embed_bwd<16, 128, true>), lds); hipLaunchKernelGGL((k_qkv_embed_bwd<16, 128, true>), grid, blk, lds, s, A); } } \
+                    else if (D == 64) { big_lds(k_qkv_embed_bwd<B_, 64>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 64>), grid, blk, lds, s, A); } \
                     else { big_lds(k_qkv_embed_bwd<B_, 128>, lds); hipLaunchKernelGGL((k_qkv_embed_bwd<B_, 128>), grid, blk, lds, s, A); } } while (0)
     BM_DISPATCH(bm, QE);
 #undef QE
@@ -2200,7 +2254,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     const int D = p->D, F = p->F;
     float* G = p->grads;
     const bool wg_f32 = DR4SR_ENV("DR4SR_WGRAD_F32") != nullptr;
-    A.bf16x3 = (ws.scale && !wg_f32) ? 1 : 0;              // at scale: weight gradients on the bf16 matrix cores (3-term split)
+    A.bf16x3 = (ws.scale_wg && !wg_f32) ? 1 : 0;              // at scale: weight gradients on the bf16 matrix cores (3-term split)
     A.xcd = (tile_xcd_order(p, ws) && !DR4SR_ENV("DR4SR_WGRAD_ORDER_PLAIN")) ? tile_rows(ws) : 0;       // follow the token-tile kernels' XCD-aware order
     // at scale with d = 64: 64 x 64 blocks (k_wgrad_bf64, see wgrad_kernel_body); DR4SR_WGRAD_WIDE: the six whole jobs (cross-check)
     const bool sub64 = A.bf16x3 && wgrad_sub64(p);
@@ -2281,7 +2335,7 @@ int launch_wgrad(const dr4sr_sasrec_plan* p, const Workspace& ws, int training, 
     if (scatter && sizeof(float) * p->L * D > lds) lds = sizeof(float) * p->L * D;
     // deterministic mode (Workspace::det): partial buffers instead of atomics + the ordered reduce launch below
     A.det = nullptr; A.det_ln = nullptr; A.det_dp = nullptr; A.det_stride = 0;
-    if (ws.det && ws.det_part && ws.scale && !blk_env_on()) {
+    if (ws.det && ws.det_part && ws.scale_wg && !blk_env_on()) {
         //  the ordered position-table partials belong to the OWNER form of the table gradient: with DR4SR_DE_ATOMIC the scatter
         // job keeps its atomics for dE and dP alike (complete, not ordered) instead of building dP partials only and dropping dE
         A.det = ws.det_part; A.det_stride = (int)ws.det_stride; A.det_ln = ws.det_ln; A.det_dp = (scatter && de_owner_mode(ws)) ? ws.det_dp : nullptr;

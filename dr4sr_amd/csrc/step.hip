@@ -129,6 +129,10 @@ static int check_plan(const dr4sr_sasrec_plan* p) {
     return 0;
 }
 
+// the deterministic latency form needs the partial blocks of the in-tile attention's shared dK | dV rows: 5 x 2 D floats per token slot and layer
+// (a toys plan of the latency regime, 1 280 x 50 slots: 328 MB) — carved for every deterministic-mode workspace of up to 131 072 slots
+static bool det_lat_capable(const dr4sr_sasrec_plan* p) { return attn_tile_capable(p) && (int64_t)p->B * p->L <= 131072; }
+
 int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     const int64_t D = p->D, F = p->F, Tmax = (int64_t)p->B * p->L;
     ws->n_params = dr4sr_sasrec_param_layout(p->n_items, p->L, p->D, p->F, p->n_layer, ws->off);
@@ -160,7 +164,12 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
         // gradient is owner-computed, their attention has no atomics — with the weight-gradient launch's remaining atomics replaced by
         // partial buffers summed in a fixed order (linear.hip k_wgrad_det_reduce)
         ws->det = DR4SR_ENV("DR4SR_DETERMINISTIC") != nullptr && atoi(DR4SR_ENV("DR4SR_DETERMINISTIC")) != 0;
+        ws->det_lat = false;
         if (ws->det) {
+            // round 6: a plan the rule above leaves in the latency regime keeps its latency launches (16-token tiles, attention
+            // inside) — kernels.h Workspace::det_lat; every other plan takes the at-scale forms as before.  DR4SR_DET_SCALE_FORMS (experiments
+            // build): the at-scale forms at every size, round 5's mode (A/B)
+            ws->det_lat = !ws->scale && !ws->attn_split && det_lat_capable(p) && !DR4SR_XENV("DR4SR_DET_SCALE_FORMS");
             ws->scale = true;
             // round 6: the wave-per-tile attention (attn_wave.hip) writes every dqkv row from exactly one wave — bit-reproducible by
             // construction and two launches per layer at any batch size, where the mode used to fall back to one workgroup per sequence
@@ -168,8 +177,14 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
             if (p->H == 2 && p->L <= 64 && !DR4SR_ENV("DR4SR_NO_FUSE")) ws->attn_split = true;
         }
         // tests (cached per process until dr4sr_reload_env(), common.h): DR4SR_FORCE_SCALE = 1 / 0 forces every at-scale / latency form, DR4SR_FORCE_ATTN_SPLIT the attention alone
-        if (const char* f = DR4SR_ENV("DR4SR_FORCE_SCALE")) ws->scale = ws->attn_split = atoi(f) != 0;
-        if (const char* f = DR4SR_ENV("DR4SR_FORCE_ATTN_SPLIT")) ws->attn_split = atoi(f) != 0;
+        if (const char* f = DR4SR_ENV("DR4SR_FORCE_SCALE")) {
+            ws->scale = ws->attn_split = atoi(f) != 0;
+            if (ws->det) ws->det_lat = !ws->scale && det_lat_capable(p) && !DR4SR_XENV("DR4SR_DET_SCALE_FORMS");
+        }
+        if (const char* f = DR4SR_ENV("DR4SR_FORCE_ATTN_SPLIT")) { ws->attn_split = atoi(f) != 0; if (ws->attn_split) ws->det_lat = false; }
+        ws->scale_wg = ws->scale || ws->det;
+        if (ws->det_lat) { ws->scale = false; ws->attn_split = false; }
+        else if (ws->det) ws->scale = true;
         // round 4, opt-in (DR4SR_ATTN_WINDOW=1): where the lists would run on a short-sequence plan at d = 64, the window attention of
         // attn_tile.h as ONE launch per layer and direction (attn_tile_sa.hip).  Measured slower than the lists (toys B = 8 192: forward
         // 25 against 24 us per layer, backward 68 against 49; B = 32 768: 92 / 239 against 63 / 159): a 16 x 32 window computes ~9x the
@@ -197,7 +212,9 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->wT = take(ws->wT_stride * p->n_layer);
     // deterministic mode: partial blocks of the weight-gradient jobs [layer][job][split][stride], LayerNorm [layer][split][4 D], dP [split][L D]
     ws->det_stride = D == 64 ? 64 * 64 + 64 : (int64_t)(D > F ? D : F) * (D > F ? D : F) + (D > F ? D : F);      // d = 64: 64 x 64 block jobs (k_wgrad_bf64); launch_wgrad refuses wider jobs
-    ws->det_part = nullptr; ws->det_ln = nullptr; ws->det_dp = nullptr;
+    ws->det_part = nullptr; ws->det_ln = nullptr; ws->det_dp = nullptr; ws->det_kv = nullptr;
+    ws->det_kv_layer = ((Tmax + 15) / 16) * 5 * 16 * 2 * D;
+    if (ws->det && det_lat_capable(p)) ws->det_kv = take(ws->det_kv_layer * p->n_layer);      // (whatever THIS plan's regime: the plans of one workspace differ in their hints)
     if (ws->det) {
         //  jobs per layer as launch_wgrad indexes them: the 64 x 64 blocks of d = 64 (4 + 2 F / 64), the six whole GEMMs of d = 128
         // (253 MB per layer were carved for 12 jobs at d = 128, F = 128)
@@ -247,8 +264,9 @@ extern "C" int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan) {
     // bit 2: attention inside the tile kernels (attn_tile.h); bit 3: the same window attention as launches of its own instead of the lists
     // bit 4 (round 6): where the lists would run, the wave-per-tile attention instead (attn_wave.hip) — one launch per layer and direction
     // bit 5: ... with its forward folded into the wave-tile forward kernels (no attention launch forward)
+    // bit 6: the deterministic latency form (Workspace::det_lat): latency tile launches, ordered table / weight-gradient forms in k_wgrad
     return (ws.scale ? 1 : 0) | (ws.attn_split ? 2 : 0) | (attn_in_tile(&q, ws) ? 4 : 0) | (ws.attn_tile_sa ? 8 : 0) | (attn_wave_on(&q, ws) ? 16 : 0)
-           | (attn_fold_fwd(&q, ws) ? 32 : 0);
+           | (attn_fold_fwd(&q, ws) ? 32 : 0) | (ws.det_lat ? 64 : 0);
 }
 
 static int get_ws(const dr4sr_sasrec_plan* p, Workspace* ws) {

@@ -135,7 +135,9 @@ int64_t dr4sr_sasrec_workspace_bytes(const dr4sr_sasrec_plan* plan);
  * bit 1 = the at-scale attention regime of short-sequence plans (length-class lists, or — bit 4 — the wave-per-tile launches that
  * replace them: csrc/attn_wave.hip), bit 2 = the attention runs inside the 16-token tile launches (the latency forms: no attention
  * launches; csrc/attn_tile.h), bit 3 = the opt-in window launches (csrc/attn_tile_sa.hip), bit 5 = bit 4 with the forward folded into the
- * wave-tile forward launches (bits 3 and 5: experiments build only, both measured slower); < 0: DR4SR_E_* */
+ * wave-tile forward launches (bits 3 and 5: experiments build only, both measured slower), bit 6 = the deterministic latency form
+ * (DR4SR_DETERMINISTIC on a plan of the latency regime: the latency launches of bit 2 with the attention's shared dK | dV rows, the table
+ * gradient and the weight-gradient splits summed in a fixed order); < 0: DR4SR_E_* */
 int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan);
 
 /* One reference training step minus the optimizer:  basemodel.py:193-198

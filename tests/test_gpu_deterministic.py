@@ -2,6 +2,7 @@
 cudnn.deterministic = True).  DR4SR_DETERMINISTIC=1 / train.deterministic: every reduction of the step in a fixed order — the at-scale launch
 forms at every batch size (owner-computed item-table gradient, per-sequence / list attention: no atomics) + the weight-gradient launch's partial
 sums stored per token split and added in split order by k_wgrad_det_reduce (csrc/linear.hip).  Done = two 100-step runs bit-identical."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -96,6 +97,55 @@ def test_deterministic_mode_gradients_match_oracle(monkeypatch, D):
     eng.fwd_bwd(plan)
     torch.cuda.synchronize()
     assert torch.equal(g1, eng.grads)
+
+
+@pytest.mark.parametrize("B,D,dense", [(256, 64, False), (64, 64, True), (32, 128, True), (1, 64, True), (1280, 64, False)])
+def test_deterministic_latency_form(monkeypatch, B, D, dense):
+    """round 6: a plan of the latency regime keeps its latency launches in deterministic mode (dr4sr_sasrec_at_scale bit 6: 16-token
+    tiles with the attention inside, bit 2) — the in-tile attention's shared dK | dV rows go through per-query-tile partial blocks that the next
+    launch sums in tile order (csrc/linear.hip det_kv_rows), table gradient and weight-gradient splits through k_wgrad's ordered forms.
+    Toys rows and all-50 rows (every key row collects from up to five query tiles), one row, the largest toys batch of the regime: two runs
+    bit-identical, the first step's gradient equal to the default mode's up to the order of the sums, and the autograd-path backward
+    (dr4sr_sasrec_encode_bwd) repeatable bit for bit"""
+    from test_gpu_parity import _random_params
+    from dr4sr_amd import _lib
+    from dr4sr_amd.data.synthetic import make_rows, TOYS_N_ITEMS
+    from dr4sr_amd.engine import SasrecEngine
+    dev = torch.device("cuda", 0)
+    N = 20034 if D == 128 else TOYS_N_ITEMS
+    rows = make_rows(n_rows=B, n_items=N, seed=23, dense=dense)
+    data = {k: torch.from_numpy(rows[k]).to(dev) for k in ("in_item_id", "item_id", "seqlen")}
+
+    def grads(det):
+        (monkeypatch.setenv("DR4SR_DETERMINISTIC", "1") if det else monkeypatch.delenv("DR4SR_DETERMINISTIC", raising=False))
+        eng = SasrecEngine(N, 50, D, 2, 128, 2, 1e-12, 0.5, B, dev, seed=9)
+        eng.load_named(_random_params(N, D, 128, 2, seed=6))
+        plan = eng.make_plan(data["in_item_id"], data["item_id"], data["seqlen"], neg_item=torch.zeros(B, 50, dtype=torch.int64, device=dev), sample_neg=True)
+        bits = eng.lib.dr4sr_sasrec_at_scale(C.byref(plan))
+        eng.fwd_bwd(plan)
+        torch.cuda.synchronize()
+        g = eng.grads.clone()
+        q = eng.encode(plan, True, _lib.POOL_LAST)
+        d_out = torch.randn(q.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+        api = []
+        for _ in range(2):
+            eng.grads.zero_()
+            eng.encode_bwd(plan, True, _lib.POOL_LAST, d_out)
+            torch.cuda.synchronize()
+            api.append(eng.grads.clone())
+        for _ in range(20):
+            eng.train_step(plan)
+        torch.cuda.synchronize()
+        return bits, g, api, eng.params.clone()
+
+    bits, g1, api1, p1 = grads(True)
+    assert bits & 64 and bits & 4 and not bits & 1, bits
+    _, g2, api2, p2 = grads(True)
+    assert torch.equal(g1, g2) and torch.equal(p1, p2) and torch.equal(api1[0], api1[1]) and torch.equal(api1[0], api2[0])
+    bits0, g0, api0, _ = grads(False)
+    assert not bits0 & 64 and bits0 & 4
+    scale = float(g0[:-4].abs().max())
+    assert float((g1 - g0)[:-4].abs().max()) < 2e-5 * scale and float((api1[0] - api0[0])[:-4].abs().max()) < 2e-5 * float(api0[0][:-4].abs().max())
 
 
 def test_deterministic_config_key_sets_the_mode(monkeypatch, tmp_path):
