@@ -174,12 +174,14 @@ def test_deterministic_config_key_sets_the_mode(monkeypatch, tmp_path):
     assert torch.equal(outs[0], outs[1])
 
 
-def test_deterministic_two_phase_step_is_bitwise_the_one_launch_step(monkeypatch):
+@pytest.mark.parametrize("B", [4096, 256])
+def test_deterministic_two_phase_step_is_bitwise_the_one_launch_step(monkeypatch, B):
     """the two-bucket data-parallel step (dr4sr_sasrec_fwd_bwd_phase 1 + 2: the last backward launch cut in two, each half followed by its
-    ordered reduce) leaves bit for bit the gradient of dr4sr_sasrec_fwd_bwd in deterministic mode — every float of the flat buffer"""
+    ordered reduce) leaves bit for bit the gradient of dr4sr_sasrec_fwd_bwd in deterministic mode — every float of the flat buffer.
+    B = 256: the deterministic latency form, whose table gradient is a set of k_wgrad jobs too (two buckets where the default mode has one)"""
     from test_gpu_dp import _engine, _grads_of
     monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
-    eng, plan, _ = _engine(4096)
+    eng, plan, _ = _engine(B)
     assert len(eng.grad_buckets(plan)) == 2
     g_one = _grads_of(eng, lambda: eng.fwd_bwd(plan))
     g_two = _grads_of(eng, lambda: (eng.fwd_bwd_phase(plan, False, 1), eng.fwd_bwd_phase(plan, False, 2)))
