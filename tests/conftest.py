@@ -59,6 +59,7 @@ def _experiment_switches():
 
 
 EXPERIMENT_SWITCHES = _experiment_switches()
+SESSION_DETERMINISTIC = os.environ.get("DR4SR_DETERMINISTIC")          # set by whoever started pytest, not by a test
 
 
 def _experiments_build() -> bool:
@@ -80,10 +81,13 @@ def _dr4sr_env_switches_follow_monkeypatch(monkeypatch):
     DESIGN.md 5a are tested in-process instead of in a fresh interpreter per switch."""
     # a model built with train.deterministic in an EARLIER test turned the process-wide mode on (dr4sr_amd/model/basemodel.py): a test starts
     # from the default mode unless it asks for the other one itself
+    # (a DR4SR_DETERMINISTIC exported for the whole session — the forced-mode run of the suite, DESIGN §4f — stays what the session was given)
     bm = sys.modules.get("dr4sr_amd.model.basemodel")
     if bm is not None and bm.BaseModel._det_set_by_model:
         bm.BaseModel._det_set_by_model = False
         os.environ.pop("DR4SR_DETERMINISTIC", None)
+    if SESSION_DETERMINISTIC is not None:                  # (also after a test that cleared the switch by hand: _lib.set_env(..., None))
+        os.environ["DR4SR_DETERMINISTIC"] = SESSION_DETERMINISTIC
     _reload_lib_env()
     real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
 
