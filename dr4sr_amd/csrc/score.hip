@@ -253,6 +253,52 @@ extern "C" int dr4sr_score_bpr_fwd(const float* query, const float* E, const int
     return score_dense_fwd<true>(query, E, target, neg, pos_score, neg_score, loss_pos, stats, B, L, D, stream);
 }
 
+// Deterministic mode (DR4SR_DETERMINISTIC; round 6): dE of the dense scorer without atomics and without a workspace (the entry point has none).
+// Owner wave o of G = 1024 adds, in position order (target term before negative term), the rows whose id is o modulo G: it scans the
+// target / negative ids 64 positions at a time, recomputes the two coefficients of the positions it owns a row of (three row loads, two
+// wave sums) and read-modify-writes the table-gradient row itself — a row has one writer, its sum one order.
+constexpr int SCORE_OWNERS = 1024;
+template <int D, bool BPR>
+__global__ __launch_bounds__(256) void k_score_dense_owner(const float* __restrict__ Q, const float* __restrict__ E,
+                                                           const int64_t* __restrict__ target, const int64_t* __restrict__ neg,
+                                                           const float* __restrict__ wgt, const float* __restrict__ scale,
+                                                           float* dE, int64_t npos) {
+    constexpr int NV = D / 64;
+    const int lane = threadIdx.x & 63, owner = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float sc = scale ? *scale : 1.f;
+    for (int64_t base = 0; base < npos; base += 64) {
+        const int64_t i = base + lane;
+        const int64_t tgt = i < npos ? target[i] : 0, ng = i < npos ? neg[i] : 0;
+        const bool live = tgt != 0;
+        unsigned long long m = __ballot(live && ((int)(tgt & (SCORE_OWNERS - 1)) == owner || (int)(ng & (SCORE_OWNERS - 1)) == owner));
+        while (m) {
+            const int l = __ffsll((long long)m) - 1; m &= m - 1;
+            const int64_t p = base + l;
+            const int64_t t = __shfl(tgt, l, 64), n = __shfl(ng, l, 64);          // (64-bit shuffles: two dwords each)
+            float q[NV], sp = 0.f, sn = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                q[j] = Q[p * D + lane + 64 * j];
+                sp += q[j] * E[t * D + lane + 64 * j];
+                sn += q[j] * E[n * D + lane + 64 * j];
+            }
+            sp = wave_sum(sp);
+            sn = wave_sum(sn);
+            const float up = sc * (wgt ? wgt[p] : 1.f);
+            const float dneg = (BPR ? sigmoid_f(sn - sp) : sigmoid_f(sn)) * up;
+            const float dpos = BPR ? -dneg : -sigmoid_f(-sp) * up;
+            if ((int)(t & (SCORE_OWNERS - 1)) == owner) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) dE[t * D + lane + 64 * j] += dpos * q[j];
+            }
+            if ((int)(n & (SCORE_OWNERS - 1)) == owner) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) dE[n * D + lane + 64 * j] += dneg * q[j];
+            }
+        }
+    }
+}
+
 template <bool BPR>
 static int score_dense_bwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,
                            const float* w, const float* scale, float* d_query, float* dE, int64_t B, int32_t L,
@@ -264,8 +310,15 @@ static int score_dense_bwd(const float* query, const float* E, const int64_t* ta
     int64_t blocks = (npos + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
-    if (D == 64) hipLaunchKernelGGL((k_score_dense_bwd<64, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
-    else hipLaunchKernelGGL((k_score_dense_bwd<128, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE, npos);
+    const char* de = DR4SR_ENV("DR4SR_DETERMINISTIC");
+    const bool det = dE && de && atoi(de) != 0;
+    float* dE_at = det ? nullptr : dE;                      // deterministic mode: the first launch writes d_query only
+    if (D == 64) hipLaunchKernelGGL((k_score_dense_bwd<64, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE_at, npos);
+    else hipLaunchKernelGGL((k_score_dense_bwd<128, BPR>), dim3((unsigned)blocks), dim3(256), 0, s, query, E, target, neg, w, scale, d_query, dE_at, npos);
+    if (det) {
+        if (D == 64) hipLaunchKernelGGL((k_score_dense_owner<64, BPR>), dim3(SCORE_OWNERS / 4), dim3(256), 0, s, query, E, target, neg, w, scale, dE, npos);
+        else hipLaunchKernelGGL((k_score_dense_owner<128, BPR>), dim3(SCORE_OWNERS / 4), dim3(256), 0, s, query, E, target, neg, w, scale, dE, npos);
+    }
     return DR4SR_LAUNCH_CHECK();
 }
 extern "C" int dr4sr_score_bce_bwd(const float* query, const float* E, const int64_t* target, const int64_t* neg,

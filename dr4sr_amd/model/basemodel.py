@@ -149,15 +149,14 @@ class BaseModel(nn.Module):
                 BaseModel._det_set_by_model = True
                 logging.getLogger("CDR").info("train.deterministic: on (process-wide switch DR4SR_DETERMINISTIC, read when an engine is built)")
             _lib.set_env("DR4SR_DETERMINISTIC", "1")
-            # bit-identical fits are tested for SASRec, CL4SRec, MetaModel around SASRec and (round 6) FMLP and GRU4Rec (tools/det_fit_check.py).  A
-            # MetaModel around GRU4Rec / FMLP trains through the dense C-ABI composition (encode -> dense scorer -> encode_bwd), whose scorer backward
-            # keeps fp32 atomics into the item table
+            # bit-identical fits are tested for every shipped model: SASRec, CL4SRec, FMLP, GRU4Rec and MetaModel around each of them (round 6;
+            # tools/det_fit_check.py, tests/test_gpu_deterministic.py) — the fused steps, the autograd-path backwards and the dense scorer all
+            # sum in a fixed order in the mode.  A model class outside that list gets a warning, not a promise
             name = type(self).__name__
             inner = str(config["model"].get("sub_model", "")) if name == "MetaModel" else name
-            if inner not in ("SASRec", "CL4SRec", "FMLP", "GRU4Rec") or (name == "MetaModel" and inner != "SASRec"):
-                logging.getLogger("CDR").warning("train.deterministic: the fixed summation order covers the fused training steps (SASRec, CL4SRec, FMLP, GRU4Rec, "
-                                                 f"MetaModel around SASRec: tests/test_gpu_deterministic.py); {name}{'(' + inner + ')' if name == 'MetaModel' else ''} "
-                                                 "trains through kernels whose fp32 atomics make runs differ in the last bits")
+            if inner not in ("SASRec", "CL4SRec", "FMLP", "GRU4Rec"):
+                logging.getLogger("CDR").warning("train.deterministic: bit-identical fits are tested for SASRec, CL4SRec, FMLP, GRU4Rec and MetaModel around them "
+                                                 f"(tests/test_gpu_deterministic.py); {name}{'(' + inner + ')' if name == 'MetaModel' else ''} is not in that list")
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ setup

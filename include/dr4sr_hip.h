@@ -143,10 +143,10 @@ int dr4sr_sasrec_at_scale(const dr4sr_sasrec_plan* plan);
 /* Deterministic mode (the reference's run-to-run determinism request, utils/utils.py:13-20).  Environment switch DR4SR_DETERMINISTIC=1, read
  * when a plan's workspace is carved (like every switch: cached per call site until the hooks header's reload entry point is called): every reduction of the training
  * steps dr4sr_sasrec_fwd_bwd[_weighted / _phase] / _train_step[s], dr4sr_fmlp_fwd_bwd / _train_step, dr4sr_gru4rec_fwd_bwd / _train_step[s] and
- * of the autograd-path backwards (dr4sr_*_encode_bwd) runs in a fixed order — no fp32 atomics — so two runs from one state are bit-identical.
+ * of the autograd-path backwards (dr4sr_*_encode_bwd) and of the dense scorer backward (dr4sr_score_bce_bwd / _bpr_bwd) runs in a fixed order — no fp32 atomics — so two runs from one state are bit-identical.
  * The mode needs partial-sum buffers: the *_workspace_bytes entry points answer for the mode that is set when it is called, and a workspace sized without
  * the mode is refused with DR4SR_E_WS once the mode is on.  It is combined with neither DR4SR_WGRAD_F32 (DR4SR_E_SHAPE) nor, for ordered
- * results, DR4SR_DE_ATOMIC.  The dense scorer backward (dr4sr_score_*_bwd) keeps its atomics. */
+ * results, DR4SR_DE_ATOMIC. */
 
 /* One reference training step minus the optimizer:  basemodel.py:193-198
  *   (_neg_sampling) -> training_step (sasrec.py:39-75 encoder, basemodel.py:204-214 scorer,

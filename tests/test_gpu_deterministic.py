@@ -314,7 +314,37 @@ def test_gru4rec_deterministic_mode_gradients_match_oracle(monkeypatch, case):
         G._gru_case(*{"odd-40": (40, 256, 2, 50), "h128-3-layers": (29, 128, 3, 7), "h256-1-layer": (29, 256, 1, 50)}[case])
 
 
-@pytest.mark.parametrize("name", ["SASRec", "MetaModel", "CL4SRec", "FMLP", "GRU4Rec"])
+@pytest.mark.parametrize("D,bpr", [(64, False), (128, False), (64, True)])
+def test_dense_scorer_backward_is_ordered_in_deterministic_mode(monkeypatch, D, bpr):
+    """dr4sr_score_bce_bwd / dr4sr_score_bpr_bwd (the scorer of the dense C-ABI composition: MetaModel around GRU4Rec / FMLP, the autograd path) in
+    deterministic mode: d_query as always, the table gradient by owner waves in position order (csrc/score.hip k_score_dense_owner) — two calls
+    bit-identical, equal to the default mode's atomics up to summation order; few distinct ids so that many positions meet in every row"""
+    from dr4sr_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(4)
+    B, L, N = 200, 50, 300
+    q = torch.randn(B, L, D, generator=g).to(dev)
+    E = (0.3 * torch.randn(N, D, generator=g)).to(dev)
+    tgt = torch.randint(0, N, (B, L), generator=g).to(dev)             # zeros = padded positions
+    neg = torch.randint(1, N, (B, L), generator=g).to(dev)
+    w = torch.rand(B * L, generator=g).to(dev)
+    fn = lib.dr4sr_score_bpr_bwd if bpr else lib.dr4sr_score_bce_bwd
+
+    def run():
+        dq, dE = torch.empty_like(q), torch.zeros_like(E)
+        _lib.check(fn(_lib.ptr(q), _lib.ptr(E), _lib.ptr(tgt), _lib.ptr(neg), _lib.ptr(w), None, _lib.ptr(dq), _lib.ptr(dE), B, L, D, _lib.cur_stream()), "score_bwd")
+        torch.cuda.synchronize()
+        return dq, dE
+    dq0, dE0 = run()
+    monkeypatch.setenv("DR4SR_DETERMINISTIC", "1")
+    dq1, dE1 = run()
+    dq2, dE2 = run()
+    assert torch.equal(dE1, dE2) and torch.equal(dq1, dq2) and torch.equal(dq1, dq0)
+    assert float((dE1 - dE0).abs().max()) < 1e-5 * float(dE0.abs().max()) and float(dE0.abs().max()) > 0
+
+
+@pytest.mark.parametrize("name", ["SASRec", "MetaModel", "CL4SRec", "FMLP", "GRU4Rec", "MetaModel:GRU4Rec", "MetaModel:FMLP", "MetaModel:CL4SRec"])
 def test_whole_fit_is_bit_identical_under_train_deterministic(name):
     """two complete fit() calls (3 epochs of B = 256 on 1 024 toys-sized rows, dropout 0.5, validation every epoch; MetaModel: warm-up epoch +
     an outer hyper-gradient step every 2 steps; CL4SRec: two drawn views + InfoNCE per step) end with bit-identical parameters (and meta

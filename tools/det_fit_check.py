@@ -1,5 +1,6 @@
 """Run-to-run determinism of whole fit() calls under train.deterministic (GPU tool; tests/test_gpu_deterministic.py calls it).
-Usage: python tools/det_fit_check.py [SASRec|MetaModel]  -> prints "identical: True/False" for the flat parameter buffer (+ the meta module)."""
+Usage: python tools/det_fit_check.py [SASRec|CL4SRec|FMLP|GRU4Rec|MetaModel|MetaModel:GRU4Rec|MetaModel:FMLP]  -> prints "identical: True/False" for the
+flat parameter buffer (+ the meta module).  MetaModel:<sub>: the DR4SR+ weighting around that sub-model (GRU4Rec / FMLP train through the dense C-ABI composition)."""
 import os
 import sys
 
@@ -13,10 +14,16 @@ os.environ.setdefault("DR4SR_CONFIG_DIR", os.path.join(ROOT, "configs"))
 
 
 def one_fit(name, workdir):
+    name, _, meta_sub = name.partition(":")
     from test_gpu_meta import make_config
     from dr4sr_amd.utils import prepare_datasets, prepare_model, seed_everything
     n_items, n_rows, batch = (int(os.environ.get(k, d)) for k, d in (("DET_N_ITEMS", 150), ("DET_ROWS", 600), ("DET_BATCH", 64)))
-    cfg = make_config(n_items, sub="SASRec" if name in ("SASRec", "MetaModel") else name, dropout=0.5, n_rows=n_rows, batch=batch, epochs=3, warmup=0, interval=2)
+    sub = (meta_sub or "SASRec") if name in ("SASRec", "MetaModel") else name
+    cfg = make_config(n_items, sub=sub, dropout=0.5 if sub != "GRU4Rec" else 0.2, n_rows=n_rows, batch=batch, epochs=3, warmup=0, interval=2)
+    if name == "MetaModel" and sub == "FMLP":
+        cfg["data"]["prefix_rows"] = True
+    if name == "MetaModel" and sub == "GRU4Rec":
+        cfg["model"]["sub_overrides"]["model"]["hidden_size"] = 128
     if name != "MetaModel":
         cfg["model"]["model"] = name
         cfg["model"].pop("sub_model"), cfg["model"].pop("sub_overrides")
