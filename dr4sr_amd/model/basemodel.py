@@ -503,8 +503,7 @@ class BaseModel(nn.Module):
             return [self._fused_epoch(loader)]
         outputs = []
         if self.world_size > 1:
-            raise NotImplementedError("the API path (DR4SR_NO_FAST_PATH / non-BCE loss) has no gradient all-reduce: data parallelism "
-                                      "needs the fused path")
+            return [self._api_epoch_dp(loader)]
         if self._api_graph_ok():
             fields = getattr(loader, "fields", None)
             if fields is not None and hasattr(loader, "permutation"):
@@ -521,6 +520,48 @@ class BaseModel(nn.Module):
             self.optimizer.step()
             outputs.append({"loss_0": loss.detach()})
         return [outputs]
+
+    def _api_epoch_dp(self, loader):
+        """The reference loop (basemodel.py:192-200) through the model API — DR4SR_NO_FAST_PATH, loss_fn 'bpr' — under data parallelism
+        (round 6; it used to raise).  Every rank walks the global batches of ONE permutation (rank 0's, broadcast) and takes its
+        shard_bounds slice; the global objective is the mean over ALL ranks' valid positions, so a rank scales its own mean loss by
+        n_valid_local / n_valid_global before backward (the counts travel with the loss sums in one float64 all-reduce) and the flat gradient
+        is SUM-reduced; the dense optimizer step then runs identically on every replica.  A rank whose slice of a short tail batch is empty
+        contributes zeros to the same two collectives.  Eager (no graph): the path is host-bound by design."""
+        eng, W, r = self.engine, self.world_size, self.rank
+        fields = getattr(loader, "fields", None)
+        if fields is None or not hasattr(loader, "permutation"):
+            raise NotImplementedError("data parallelism needs the device-resident loader (fields + permutation)")
+        B, n, nb = loader.batch_size, loader.n, len(loader)
+        perm = loader.permutation()
+        parallel.broadcast(perm, src=0)
+        perm = perm.to(self.device)
+        outputs = []
+        cnt = torch.zeros(2, dtype=torch.float64, device=self.device)
+        base = getattr(self, "_neg_calls", 0)
+        for i in range(nb):
+            lo, hi = parallel.shard_bounds(i, B, n, W, r)
+            self.optimizer.zero_grad()
+            cnt.zero_()
+            loss = None
+            if hi > lo:
+                rows = perm[lo:hi]
+                batch = {k: v.index_select(0, rows) for k, v in fields.items()}
+                self._neg_calls = base + i * W + r             # one sampler stream per (global batch, rank)
+                batch["neg_item"] = self._neg_sampling(batch)
+                n_loc = (batch[self.fiid] != 0).sum().to(torch.float64)
+                if int(n_loc) > 0:                               # (a slice without a valid target has no mean to take)
+                    loss = self.training_step(batch=batch)       # mean over THIS rank's valid positions
+                    cnt[0] = n_loc
+                    cnt[1] = loss.detach().to(torch.float64) * n_loc
+            parallel.allreduce_flat(cnt)
+            if loss is not None:
+                (loss * (n_loc / cnt[0]).to(torch.float32)).backward()
+            parallel.allreduce_flat(eng.grads)
+            self.optimizer.step()
+            outputs.append({"loss_0": (cnt[1] / cnt[0]).to(torch.float32)})
+        self._neg_calls = base + nb * W
+        return outputs
 
     # ---- API path under a HIP graph: models whose step is a composition of C-ABI calls behind autograd (CL4SRec) are host-bound when
     # run eagerly (≈100 launches + autograd bookkeeping per step); the loop body of basemodel.py:192-200 is captured once per batch

@@ -181,6 +181,27 @@ def test_data_parallel_fit_eight_ranks(tmp_path, model_name):
     assert "world=8" in lines[0] and "replicas identical: True; finite: True" in lines[0] and "one ckpt stem: True" in lines[0], lines[0]
 
 
+@pytest.mark.parametrize("model_name,loss,W", [("SASRec", "bpr", 2), ("SASRec", "bce", 3), ("GRU4Rec", "bpr", 2), ("FMLP", "bpr", 2)])
+def test_model_api_loop_under_data_parallelism_equals_one_rank(model_name, loss, W):
+    """round 6: the model-API training loop (loss_fn 'bpr', or DR4SR_NO_FAST_PATH with 'bce' — it raised under W > 1 before) sliced over W ranks
+    (BaseModel._api_epoch_dp: local mean loss scaled by n_valid_local / n_valid_global, SUM all-reduce of the flat gradient, a rank with an EMPTY
+    slice of the tail batch still in both collectives) moves the parameters exactly as the same loop on one rank does (tools/dp_api_check.py:
+    dropout 0, negatives a function of the targets): replicas bit-identical, parameters and per-step losses within fp32 summation order"""
+    out = torchrun(W, "tools/dp_api_check.py", dict(DR4SR_DP_BACKEND="gloo", MODEL=model_name, LOSS_FN=loss))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_API")]
+    assert out.returncode == 0 and len(lines) == 2 and lines[1] == "DP_API_OK", report(out)
+    assert "world=%d" % W in lines[0] and "replicas identical: True" in lines[0], lines[0]
+
+
+def test_data_parallel_fit_with_the_model_api_loop(tmp_path):
+    """quickstart.run (fit + evaluate) of SASRec with loss_fn 'bpr' under two ranks: the model-API loop end to end (tools/dp_fit_check.py)"""
+    out = torchrun(2, "tools/dp_fit_check.py", dict(DR4SR_DP_BACKEND="gloo", DP_FIT_DIR=str(tmp_path), MODEL="SASRec", LOSS_FN="bpr"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_FIT ")]
+    err = out.stdout[out.stdout.find("DP_FIT_ERROR"):][:3000] if "DP_FIT_ERROR" in out.stdout else report(out)
+    assert out.returncode == 0 and len(lines) == 1, err
+    assert "world=2" in lines[0] and "replicas identical: True; finite: True" in lines[0] and "one ckpt stem: True" in lines[0], lines[0]
+
+
 def test_bench_self_launches_eight_ranks_on_a_shared_gpu():
     """`python bench.py --gpus 8` (the driver's widest command) on ONE GPU over gloo: every rank takes the data-parallel step, the
     strong-scaling entry splits 16 384 rows into 2 048 per rank; one JSON line from rank 0"""

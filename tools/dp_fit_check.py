@@ -26,6 +26,8 @@ if MODEL == "MetaModel":
 if MODEL == "FMLP":
     cfg["data"]["prefix_rows"] = True                     # one query per row: left-padded prefixes with scalar targets (model/fmlp.py:38)
 cfg["model"]["dropout_rate"] = 0.2
+if os.environ.get("LOSS_FN"):                             # 'bpr': the model-API loop (BaseModel._api_epoch_dp) instead of the fused step
+    cfg["model"]["loss_fn"] = os.environ["LOSS_FN"]
 cfg["train"].update({"batch_size": 128, "epochs": 3, "device": "cuda:0", "hip_graph": True, "steps_per_graph": 3})   # 8 full batches: groups of 3, 3, then singles
 if "interval" in cfg["train"]:
     cfg["train"]["interval"] = 4                          # MetaModel: several outer steps per epoch
