@@ -131,7 +131,10 @@ static int check_plan(const dr4sr_sasrec_plan* p) {
 
 // the deterministic latency form needs the partial blocks of the in-tile attention's shared dK | dV rows: 5 x 2 D floats per token slot and layer
 // (a toys plan of the latency regime, 1 280 x 50 slots: 328 MB) — carved for every deterministic-mode workspace of up to 131 072 slots
-static bool det_lat_capable(const dr4sr_sasrec_plan* p) { return attn_tile_capable(p) && (int64_t)p->B * p->L <= 131072; }
+// (the carving depends on the plan's SHAPE only, not on the cross-check switches attn_tile_capable reads: a workspace sized under one switch
+//  setting stays valid under another)
+static bool det_kv_shape(const dr4sr_sasrec_plan* p) { return p->H == 2 && p->L <= 64 && (p->D == 64 || p->D == 128) && (int64_t)p->B * p->L <= 131072; }
+static bool det_lat_capable(const dr4sr_sasrec_plan* p) { return attn_tile_capable(p) && det_kv_shape(p); }
 
 int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     const int64_t D = p->D, F = p->F, Tmax = (int64_t)p->B * p->L;
@@ -214,7 +217,7 @@ int carve_workspace(const dr4sr_sasrec_plan* p, Workspace* ws) {
     ws->det_stride = D == 64 ? 64 * 64 + 64 : (int64_t)(D > F ? D : F) * (D > F ? D : F) + (D > F ? D : F);      // d = 64: 64 x 64 block jobs (k_wgrad_bf64); launch_wgrad refuses wider jobs
     ws->det_part = nullptr; ws->det_ln = nullptr; ws->det_dp = nullptr; ws->det_kv = nullptr;
     ws->det_kv_layer = ((Tmax + 15) / 16) * 5 * 16 * 2 * D;
-    if (ws->det && det_lat_capable(p)) ws->det_kv = take(ws->det_kv_layer * p->n_layer);      // (whatever THIS plan's regime: the plans of one workspace differ in their hints)
+    if (ws->det && det_kv_shape(p)) ws->det_kv = take(ws->det_kv_layer * p->n_layer);      // (whatever THIS plan's regime: the plans of one workspace differ in their hints)
     if (ws->det) {
         //  jobs per layer as launch_wgrad indexes them: the 64 x 64 blocks of d = 64 (4 + 2 F / 64), the six whole GEMMs of d = 128
         // (253 MB per layer were carved for 12 jobs at d = 128, F = 128)
