@@ -709,6 +709,8 @@ def main():
                     help="repetitions of the timed region (each exactly --steps steps): ms_per_step = median, ms_per_step_spread = min / max")
     ap.add_argument("--in-graph-timeout", type=int, default=150,
                     help="data parallel: seconds the in-graph-collective attempt (second form) may take before the line is printed without it")
+    ap.add_argument("--comm-init-timeout", type=float, default=240.0,
+                    help="seconds the RCCL communicator's bootstrap may take before every rank drops to the staged gloo data plane (flagged in the line)")
     ap.add_argument("--no-deterministic-leg", action="store_true", help="skip the extra run of the step in deterministic mode (deterministic_mode)")
     ap.add_argument("--no-dp-leg", action="store_true",
                     help="single GPU: skip the 1-rank RCCL runs of the data-parallel step forms (strong[].dp_1rank_rccl)")
@@ -745,7 +747,8 @@ def main():
     import torch.distributed as dist
     from dr4sr_amd import parallel
     if dp:
-        parallel.init_distributed(dev, allow_fallback=True)      # gloo control group + the library's own RCCL communicator (no ProcessGroupNCCL)
+        # gloo control group + the library's own RCCL communicator (no ProcessGroupNCCL); a bootstrap that does not return in time counts as failed
+        parallel.init_distributed(dev, allow_fallback=True, init_timeout=args.comm_init_timeout)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from dr4sr_amd import _lib

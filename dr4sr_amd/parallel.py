@@ -66,12 +66,14 @@ def _check(rc: int, what: str):
         raise _lib.Dr4srError("%s failed: rc %d (%s)" % (what, rc, msg.decode() if msg else "?"))
 
 
-def init_distributed(device=None, allow_fallback=False):
+def init_distributed(device=None, allow_fallback=False, init_timeout=None):
     """Create the control group (gloo) and, for the rccl data plane, the native communicator — once (no-op for a single process unless
     DR4SR_BENCH_FORCE_DP asks for the 1-rank form).  RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from torch.distributed.run.
     Collective: every rank of the job must call it.  A communicator that cannot be created on EVERY rank raises (training must not silently
     run over a slow transport); allow_fallback=True (bench.py: a flagged line beats no line) drops all ranks to the host-staged gloo data
-    plane instead and records why in FALLBACK_REASON."""
+    plane instead and records why in FALLBACK_REASON.  init_timeout (seconds, bench.py only): the communicator's bootstrap runs in a helper
+    thread and a rank on which it has not returned in time counts as failed — a wedged bootstrap then costs the timeout and a flagged line
+    instead of the whole run (the ranks agree over the control plane; None = wait for it, as training does)."""
     global _COMM, _COMM_DEVICE, FALLBACK_REASON
     import torch
     import torch.distributed as dist
@@ -100,8 +102,29 @@ def init_distributed(device=None, allow_fallback=False):
         ident = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
         torch.cuda.synchronize(device)
         handle, err = C.c_void_p(), None
+        rank_, world_ = dist.get_rank(), dist.get_world_size()
+
+        def boot():
+            _check(lib.dr4sr_comm_init_rank(ident, rank_, world_, int(idx), C.byref(handle)), "dr4sr_comm_init_rank")
         try:
-            _check(lib.dr4sr_comm_init_rank(ident, dist.get_rank(), dist.get_world_size(), int(idx), C.byref(handle)), "dr4sr_comm_init_rank")
+            if init_timeout is None:
+                boot()
+            else:                                            # (ctypes releases the GIL for the call: the wait below really runs)
+                import threading
+                box_err = []
+
+                def guarded():
+                    try:
+                        boot()
+                    except Exception as e:      # noqa: BLE001
+                        box_err.append(e)
+                th = threading.Thread(target=guarded, name="dr4sr-comm-bootstrap", daemon=True)
+                th.start()
+                th.join(float(init_timeout))
+                if th.is_alive():
+                    raise TimeoutError("dr4sr_comm_init_rank did not return within %.0f s" % float(init_timeout))
+                if box_err:
+                    raise box_err[0]
         except Exception as e:      # noqa: BLE001 — decided below, on every rank alike
             err = e
         if all_ok(err is None):
@@ -111,6 +134,8 @@ def init_distributed(device=None, allow_fallback=False):
         else:
             if err is None:
                 lib.dr4sr_comm_destroy(handle)
+            elif isinstance(err, TimeoutError):
+                handle = C.c_void_p()                        # (the helper thread may still write the old one: never touched again)
             why = "the RCCL communicator could not be created on every rank (this rank: %s)" % (err if err is not None else "ok")
             if not allow_fallback:
                 raise _lib.Dr4srError(why)

@@ -81,3 +81,39 @@ def test_bench_falls_back_to_the_staged_data_plane_when_rccl_refuses():
     assert out.returncode == 0, report(out)
     assert j["n_gpus"] == 2 and "could not be created" in j["transport_fallback"] and "gloo" in j["transport_fallback"]
     assert j["value"] > 0 and j["collective_forms"]["in_graph"] is None
+
+
+def test_a_wedged_communicator_bootstrap_costs_the_timeout_not_the_run(monkeypatch):
+    """parallel.init_distributed(allow_fallback=True, init_timeout=...) — what bench.py calls: the RCCL bootstrap runs in a helper thread; when it
+    does not return in time (here: the entry point replaced by one that sleeps) the rank counts as failed, the ranks agree over the control plane
+    and take the staged gloo data plane with the reason recorded, instead of hanging the launcher"""
+    import time
+    import torch
+    from _launch import free_port
+    from dr4sr_amd import _lib, parallel
+    lib = _lib.load()
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(free_port())), ("DR4SR_BENCH_FORCE_DP", "1")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("DR4SR_DP_BACKEND", raising=False)
+    real = lib.dr4sr_comm_init_rank
+    calls = []
+
+    def stalls(*a):
+        calls.append(1)
+        time.sleep(3.0)
+        return -1
+    lib.dr4sr_comm_init_rank = stalls
+    try:
+        t0 = time.time()
+        assert parallel.init_distributed(torch.device("cuda", 0), allow_fallback=True, init_timeout=0.5)
+        took = time.time() - t0
+        assert calls and took < 2.5 and not parallel.can_capture()
+        assert "did not return within" in parallel.FALLBACK_REASON and "gloo" in parallel.FALLBACK_REASON
+        g = torch.ones(1000, device="cuda")
+        parallel.allreduce_flat(g)                               # the staged plane carries the collective (one rank: identity)
+        assert bool((g == 1).all())
+    finally:
+        lib.dr4sr_comm_init_rank = real
+        parallel.shutdown()
+        parallel.FALLBACK_REASON = None
+        time.sleep(3.0)                                        # let the helper thread's sleep end before the next test
