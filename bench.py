@@ -756,6 +756,17 @@ def main():
     from dr4sr_amd.data.synthetic import TOYS_N_ITEMS, make_rows
     from dr4sr_amd.engine import SasrecEngine
     lib = _lib.load()
+    if dp and rank == 0 and _REAL_STDOUT is not None:
+        # a multi-rank run whose FIRST collective wedges is killed by the watchdog (--max-seconds) or by the launcher before any measurement
+        # exists: leave a diagnosable line (value null, exit code 3) instead of silence; the first arm_crash_line() replaces it
+        lib.dr4sr_crash_line_set(json.dumps({"metric": "training sequences/sec", "value": None, "unit": "sequences/s", "n_gpus": args.gpus,
+                                             "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                                             "aborted_during": "headline measurement (no measurement completed)",
+                                             "transport_fallback": parallel.FALLBACK_REASON}).encode(), _REAL_STDOUT.fileno(), 3)
+        _CRASH_ARMED[0] = True
+        if os.environ.get("DR4SR_BENCH_INJECT_ABORT") == "headline":       # test hook, as in arm_crash_line
+            _REAL_STDOUT.flush()
+            os.abort()
 
     def measure(B_arg, steps, warmup, extras, dp=dp, dp_form="host", repeats=None, dp_flat=False, deterministic=False):
         if deterministic:                          # fixed summation order (train.deterministic): the library reads the switch when a plan is carved

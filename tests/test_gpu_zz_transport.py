@@ -70,6 +70,17 @@ def test_bench_line_survives_an_abort_in_the_in_graph_leg():
     assert "rccl all-reduce launched by the host" in j["config"]["collective"]
 
 
+def test_bench_says_so_when_a_multi_rank_run_dies_before_its_first_measurement():
+    """a data-parallel run killed before ANY measurement exists (a wedged first collective + the watchdog, a launcher's SIGTERM): rank 0 leaves one
+    parseable line with value null and the reason, and the process exits non-zero — not silence"""
+    out = torchrun(1, "bench.py", {"DR4SR_BENCH_FORCE_DP": "1", "DR4SR_BENCH_INJECT_ABORT": "headline"},
+                   args=["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-throughput-mode", "--no-strong", "--no-cpu-baseline"], timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode != 0 and len(lines) == 1, report(out)
+    j = json.loads(lines[0])
+    assert j["value"] is None and "no measurement completed" in j["aborted_during"] and j["n_gpus"] == 1
+
+
 def test_bench_falls_back_to_the_staged_data_plane_when_rccl_refuses():
     """two ranks on ONE GPU with the RCCL data plane asked for explicitly: RCCL refuses a second rank on a device, every rank sees the failure
     over the control plane (parallel.init_distributed(allow_fallback=True): all_ok), all of them drop to the host-staged gloo data plane and
